@@ -1,0 +1,306 @@
+"""CPU: pins oracle/nerfacto_oracle.py against (i) the fixtures generated from the reference itself
+(tests/golden/make_golden.py), (ii) the seed-free KATs of SURVEY.md §8(c), (iii) the numeric anchors the reference's
+own tests hold (tests/utils/test_spherical_harmonics.py:8-16, tests/cameras/test_rays.py:11-30,
+tests/model_components/test_renderers.py:12-83)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerfacto_oracle as orc
+
+T = torch.from_numpy
+
+
+def close(a, b, atol=1e-6, rtol=1e-5):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, np.asarray(b), atol=atol, rtol=rtol)
+
+
+def small_cfg(main_log2, prop_log2, num_images):
+    return orc.NerfactoCfg(
+        main_grid=orc.HashGridCfg(16, 16, 2048, int(main_log2)),
+        prop_grids=(orc.HashGridCfg(5, 16, 128, int(prop_log2)), orc.HashGridCfg(5, 16, 256, int(prop_log2))),
+        num_images=int(num_images),
+    )
+
+
+# ---------------------------------------------------------------- KATs --------------------------------------------
+def test_kat_hash(golden):
+    g = golden("kat")
+    xyz = g["hash_in"]
+    got = [int(orc.hash_corner_index(xyz[i : i + 1, 0], xyz[i : i + 1, 1], xyz[i : i + 1, 2], i, 32)[0]) for i in range(2)]
+    assert got == list(g["hash_out"]) == [19, 60]
+
+
+def test_kat_scalings(golden):
+    g = golden("kat")
+    for name, (L, lo, hi) in {"main": (16, 16, 2048), "prop0": (5, 16, 128), "prop1": (5, 16, 256)}.items():
+        np.testing.assert_array_equal(orc.hash_level_scalings(L, lo, hi).numpy(), g[f"scalings_{name}"])
+    assert orc.hash_level_scalings(16, 16, 2048).tolist() == [16, 22, 30, 42, 58, 80, 111, 153, 212, 294, 406, 561, 776, 1072, 1482, 2047]
+
+
+def test_kat_sh_contraction(golden):
+    g = golden("kat")
+    close(orc.sh_levels4(T(g["sh_in"])), g["sh_out"], atol=1e-7)
+    close(orc.contract_linf(T(g["contract_in"])), g["contract_out"], atol=0)
+    close(orc.contract_linf(torch.tensor([[2.0, 0, 0], [-4.0, 2, 1]])), [[1.5, 0, 0], [-1.75, 0.875, 0.4375]], atol=0)
+
+
+def test_kat_sampler_and_render(golden):
+    g = golden("kat")
+    nears, fars = torch.full((1, 1), 0.05), torch.full((1, 1), 1000.0)
+    s, t = orc.piecewise_bins(nears, fars, 4, None)
+    close(t[0, :-1], g["pw_starts"], atol=0, rtol=1e-7)
+    close(t[0, 1:], g["pw_ends"], atol=0, rtol=1e-7)
+    close(t[0, :-1], [0.05, 0.53724998, 1.02511537, 2.04813099], rtol=1e-6)
+    w = orc.weights_from_density(t, torch.ones(1, 4))
+    close(w[0], g["pw_weights"], atol=1e-7)
+    s2, t2, _ = orc.pdf_resample(s, w, 3, None, nears, fars)
+    close(t2[0, :-1], g["pdf_starts"], rtol=2e-6)
+    close(t2[0, 1:], g["pdf_ends"], rtol=2e-6)
+    rgbs = torch.tensor([[[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0], [1.0, 1, 1]]])
+    close(orc.composite_rgb(rgbs, w), g["rgb_last_sample"][None], atol=1e-7)
+    close(orc.depth_median(w, t)[0][0], g["depth_median"], rtol=1e-7)
+    close(orc.depth_expected(w, t)[0], g["depth_expected"], rtol=1e-6)
+
+
+def test_reference_test_anchors(golden):
+    # tests/cameras/test_rays.py:11-30 — Frustums.get_positions KAT [0, 3.5, 2] ... here origins=1, dir=(0,1,0), 2..3
+    g = golden("kat")
+    o = torch.ones(5, 3)
+    d = torch.ones(5, 3) * torch.tensor([0.0, 1.0, 0.0])
+    t_bins = torch.tensor([[2.0, 3.0]]).expand(5, 2)
+    pos = orc.sample_positions(o, d, t_bins)[:, 0]
+    close(pos, g["frustum_positions"], atol=0)
+    close(pos[0], [1.0, 3.5, 1.0], atol=0)
+    # tests/utils/test_spherical_harmonics.py:8-16 — orthonormality of the basis on the sphere, atol 1.5e-2
+    torch.manual_seed(0)
+    n = 1_000_000
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)
+    sh = orc.sh_levels4(dirs)
+    gram = (sh.T @ sh) / n * 4 * np.pi
+    close(gram, np.eye(16), atol=1.5e-2, rtol=0)
+    # tests/model_components/test_renderers.py — rgb of an opaque white ray > 0.9; zero weights -> background only
+    w = torch.zeros(3, 8)
+    w[:, 0] = 1.0
+    assert float(orc.composite_rgb(torch.ones(3, 8, 3), w, "black").max()) > 0.9
+    assert float(orc.composite_rgb(torch.ones(3, 8, 3), torch.zeros(3, 8), "black").abs().max()) == pytest.approx(0)
+
+
+# ---------------------------------------------------------------- hash grid ---------------------------------------
+def test_hashgrid_fixture(golden):
+    g = golden("hashgrid")
+    L, lo, hi, log2T, F = [int(v) for v in g["cfg"]]
+    scal = orc.hash_level_scalings(L, lo, hi)
+    np.testing.assert_array_equal(scal.numpy(), g["scalings"])
+    x = T(g["x"]).requires_grad_(True)
+    table = T(g["table"]).requires_grad_(True)
+    out = orc.hashgrid_encode(x, table, scal, 2**log2T)
+    close(out, g["out"], atol=1e-6)
+    (out * T(g["gout"])).sum().backward()
+    close(x.grad, g["dx"], atol=1e-4, rtol=1e-4)
+    close(table.grad, g["dtable"], atol=1e-5, rtol=1e-5)
+
+
+# ---------------------------------------------------------------- fields ------------------------------------------
+def _field_setup(g):
+    cfg = small_cfg(g["cfg_main_log2"], g["cfg_prop_log2"], g["num_images"])
+    params = orc.init_params(cfg, seed=int(g["seed"]), table_std=float(g["table_std"]))
+    for v in params.values():
+        v.requires_grad_(True)
+    return cfg, params
+
+
+def test_proposal_density_fixture(golden):
+    g = golden("fields")
+    cfg, params = _field_setup(g)
+    for i in range(2):
+        pos = T(g["positions"]).requires_grad_(True)
+        dens = orc.proposal_density(pos, params, i, cfg)
+        close(dens, g[f"prop{i}_density"], atol=1e-6, rtol=2e-5)
+        (dens * T(g[f"prop{i}_g"])).sum().backward()
+        close(pos.grad, g[f"prop{i}_dpos"], atol=1e-4, rtol=1e-3)
+        close(params[f"proposal_networks.{i}.encoding.hash_table"].grad, g[f"prop{i}_dtable"], atol=1e-5, rtol=1e-4)
+        for j in range(2):
+            close(params[f"proposal_networks.{i}.mlp_base.1.layers.{j}.weight"].grad, g[f"prop{i}_dW{j}"], atol=1e-4, rtol=1e-4)
+            close(params[f"proposal_networks.{i}.mlp_base.1.layers.{j}.bias"].grad, g[f"prop{i}_db{j}"], atol=1e-4, rtol=1e-4)
+
+
+def test_nerfacto_field_fixture(golden):
+    g = golden("fields")
+    cfg, params = _field_setup(g)
+    pos, dirs, cam = T(g["positions"]).requires_grad_(True), T(g["directions"]), T(g["cams"])
+    dens, rgb, _ = orc.nerfacto_field(pos, dirs, cam, params, cfg, training=True)
+    close(dens, g["main_train_density"], atol=1e-6, rtol=2e-5)
+    close(rgb, g["main_train_rgb"], atol=2e-6)
+    ((dens * T(g["main_g_density"])).sum() + (rgb * T(g["main_g_rgb"])).sum()).backward()
+    close(pos.grad, g["main_dpos"], atol=2e-3, rtol=2e-3)
+    close(params["field.mlp_base.model.0.hash_table"].grad, g["main_dtable"], atol=1e-5, rtol=1e-4)
+    close(params["field.embedding_appearance.embedding.weight"].grad, g["main_demb"], atol=1e-5, rtol=1e-4)
+    for j in range(2):
+        close(params[f"field.mlp_base.model.1.layers.{j}.weight"].grad, g[f"main_base_dW{j}"], atol=1e-4, rtol=1e-4)
+        close(params[f"field.mlp_base.model.1.layers.{j}.bias"].grad, g[f"main_base_db{j}"], atol=1e-4, rtol=1e-4)
+    for j in range(3):
+        close(params[f"field.mlp_head.layers.{j}.weight"].grad, g[f"main_head_dW{j}"], atol=1e-4, rtol=1e-4)
+        close(params[f"field.mlp_head.layers.{j}.bias"].grad, g[f"main_head_db{j}"], atol=1e-4, rtol=1e-4)
+    with torch.no_grad():
+        dens_e, rgb_e, _ = orc.nerfacto_field(pos.detach(), dirs, cam, params, cfg, training=False)
+    close(dens_e, g["main_eval_density"], atol=1e-6, rtol=2e-5)
+    close(rgb_e, g["main_eval_rgb"], atol=2e-6)
+
+
+# ---------------------------------------------------------------- samplers ----------------------------------------
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_sampler_fixture(golden, mode):
+    g = golden("samplers")
+    nears, fars = T(g["nears"]), T(g["fars"])
+    tr = mode == "train"
+    s0, t0 = orc.piecewise_bins(nears, fars, 256, T(g["j0"]) if tr else None)
+    np.testing.assert_array_equal(s0.numpy(), g[f"{mode}_l0_s_bins"])  # elementwise IEEE ops only -> bit exact
+    np.testing.assert_array_equal(t0.numpy(), g[f"{mode}_l0_t_bins"])
+    w0 = orc.weights_from_density(t0, T(g[f"{mode}_l0_density"]))
+    close(w0, g[f"{mode}_l0_weights"], atol=1e-7, rtol=1e-6)
+    # feed the REFERENCE's weights so the index comparison isolates the resampler
+    dbg = {}
+    s1, t1, i1 = orc.pdf_resample(s0, T(g[f"{mode}_l0_weights"]), 96, T(g["j1"]) if tr else None, nears, fars, debug=dbg)
+    _check_inds(i1, g[f"{mode}_l1_inds"], dbg)
+    close(s1, g[f"{mode}_l1_s_bins"], atol=2e-6, rtol=0)
+    _check_t_bins(t1, s1, g[f"{mode}_l1_s_bins"], g[f"{mode}_l1_t_bins"], nears, fars)
+    w1 = T(g[f"{mode}_l1_weights"])
+    close(orc.weights_from_density(T(g[f"{mode}_l1_t_bins"]), T(g[f"{mode}_l1_density"])), w1, atol=1e-7, rtol=1e-6)
+    s2, t2, i2 = orc.pdf_resample(
+        T(g[f"{mode}_l1_s_bins"]), torch.pow(w1, float(g["anneal"])), 48, T(g["j2"]) if tr else None, nears, fars, debug=dbg
+    )
+    _check_inds(i2, g[f"{mode}_l2_inds"], dbg)
+    close(s2, g[f"{mode}_l2_s_bins"], atol=2e-6, rtol=0)
+    _check_t_bins(t2, s2, g[f"{mode}_l2_s_bins"], g[f"{mode}_l2_t_bins"], nears, fars)
+
+
+def _check_t_bins(t_mine, s_mine, s_ref, t_ref, nears, fars):
+    """t = 1/(2-2s') is ill-conditioned as s'->1 (far field): an ulp of s moves t by t*ulp/(1-s'). So (i) mapping the
+    REFERENCE's s_bins through the oracle's s->t map must be bit-exact, (ii) the oracle's own t may deviate only by
+    what its s deviation explains."""
+    np.testing.assert_array_equal(orc.spacing_to_euclidean(T(s_ref), nears, fars).numpy(), t_ref)
+    ds = np.abs(s_mine.numpy() - s_ref)
+    s_far = orc.spacing_fn(fars).numpy()
+    cond = 2.0 * np.maximum(t_ref, 1.0) ** 2 * s_far  # |dt/ds| for the far branch t = 1/(2-2x), x = s*s_far+(1-s)*s_near
+    assert np.all(np.abs(t_mine.numpy() - t_ref) <= cond * ds * 1.5 + 1e-6 * np.abs(t_ref))
+
+
+def _check_inds(mine, ref, dbg):
+    """Index equality with the reference. The oracle sums the weights left-to-right where the reference uses
+    torch.sum (ATen's blocked order), so cdf values can differ by an ulp; an index may differ ONLY where u ties with
+    every cdf entry between the two answers to within 2 ulp (on the fixtures: the eval-mode u = 0.5 of the two
+    degenerate rays, whose cdf hits 0.5 exactly). Anything else fails."""
+    mine = mine.numpy()
+    bad = np.argwhere(mine != ref)
+    assert len(bad) <= 4, f"{len(bad)} searchsorted indices differ from the reference"
+    cdf, u = dbg["cdf"].numpy(), dbg["u"].numpy()
+    for r, c in bad:
+        lo, hi = sorted((int(mine[r, c]), int(ref[r, c])))
+        gap = np.abs(cdf[r, lo:hi] - u[r, c])
+        assert np.all(gap <= 2 * np.spacing(np.float32(u[r, c]))), (r, c, mine[r, c], ref[r, c], gap)
+
+
+def test_weights_backward_fixture(golden):
+    g = golden("samplers")
+    dens = T(g["train_l0_density"]).requires_grad_(True)
+    w = orc.weights_from_density(T(g["train_l0_t_bins"]), dens)
+    (w * T(g["weights_g"])).sum().backward()
+    close(dens.grad, g["weights_ddensity"], atol=1e-5, rtol=1e-4)
+
+
+# ---------------------------------------------------------------- render / losses ---------------------------------
+def test_render_fixture(golden):
+    g = golden("render")
+    t_bins = T(g["t_bins"])
+    dens = T(g["density"]).requires_grad_(True)
+    rgb = T(g["rgb"]).requires_grad_(True)
+    w = orc.weights_from_density(t_bins, dens)
+    close(w, g["weights"], atol=1e-7, rtol=1e-6)
+    for bg in ("last_sample", "white", "black", "random"):
+        close(orc.composite_rgb(rgb, w, bg, True), g[f"rgb_train_{bg}"], atol=1e-6)
+    close(orc.composite_rgb(T(g["rgb_eval_in"]), w.detach(), "last_sample", False), g["rgb_eval_last_sample"], atol=1e-6)
+    close(orc.accumulation(w), g["accumulation"], atol=1e-6)
+    dm, idx = orc.depth_median(w.detach(), t_bins)
+    np.testing.assert_array_equal(idx.numpy(), g["depth_median_idx"])
+    close(dm, g["depth_median"], atol=0, rtol=1e-7)
+    de = orc.depth_expected(w, t_bins)
+    close(de, g["depth_expected"], rtol=1e-5)
+    comp = orc.composite_rgb(rgb, w, "last_sample", True)
+    ((comp * T(g["g_rgb"])).sum() + (orc.accumulation(w) * T(g["g_acc"])).sum() + (de * T(g["g_dep"])).sum()).backward()
+    close(dens.grad, g["d_density"], atol=1e-4, rtol=1e-4)
+    close(rgb.grad, g["d_rgb"], atol=1e-6, rtol=1e-5)
+
+
+def test_losses_fixture(golden):
+    g = golden("losses")
+    ws = [T(g[f"w{i}"]).requires_grad_(True) for i in range(3)]
+    bins = [T(g[f"s_bins{i}"]) for i in range(3)]
+    li = orc.interlevel_loss(ws, bins)
+    ld = orc.distortion_loss(ws[-1], bins[-1])
+    close(li, g["interlevel"], rtol=1e-5)
+    close(ld, g["distortion"], rtol=1e-5)
+    (li + 0.5 * ld).backward()
+    for i in range(3):
+        close(ws[i].grad, g[f"dw{i}"], atol=1e-7, rtol=1e-4)
+
+
+# ---------------------------------------------------------------- whole pipeline ----------------------------------
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_pipeline_fixture(golden, mode):
+    g = golden("pipeline")
+    cfg = small_cfg(g["main_log2"], g["prop_log2"], g["num_images"])
+    params = orc.init_params(cfg, seed=int(g["seed"]), table_std=float(g["table_std"]))
+    for v in params.values():
+        v.requires_grad_(True)
+    jit = [T(g[f"j{i}"]) for i in range(3)]
+    out = orc.nerfacto_forward(params, cfg, T(g["origins"]), T(g["directions"]), T(g["cams"]), jit, training=(mode == "train"))
+    for i in range(3):
+        close(out["s_bins_list"][i], g[f"{mode}_s_bins{i}"], atol=5e-6, rtol=0)
+        close(out["t_bins_list"][i], g[f"{mode}_t_bins{i}"], atol=0, rtol=2e-3)  # far-field conditioning, see _check_t_bins
+        close(out["weights_list"][i], g[f"{mode}_w{i}"], atol=2e-5, rtol=1e-3)
+    for k, (mine, ref) in enumerate(zip(out["inds_list"], (g[f"{mode}_inds1"], g[f"{mode}_inds2"]))):
+        frac = float((mine.numpy() != ref).mean())
+        assert frac <= 2e-3, f"level {k + 1}: {frac:.2%} of indices differ (end-to-end, ulp-level weight noise)"
+    close(out["rgb"], g[f"{mode}_rgb"], atol=1e-5, rtol=0)
+    close(out["accumulation"], g[f"{mode}_acc"], atol=1e-5, rtol=0)
+    close(out["expected_depth"], g[f"{mode}_expected_depth"], rtol=1e-4)
+    close(out["depth"], g[f"{mode}_depth"], rtol=1e-4)
+    for i in range(2):
+        close(out[f"prop_depth_{i}"], g[f"{mode}_prop_depth_{i}"], rtol=1e-4)
+    if mode == "train":
+        losses = orc.nerfacto_losses(out, T(g["target"]), cfg)
+        close(losses["rgb_loss"], g["loss_rgb"], rtol=1e-5)
+        close(losses["interlevel_loss"], g["loss_interlevel"], rtol=1e-4)
+        close(losses["distortion_loss"], g["loss_distortion"], rtol=1e-4)
+        sum(losses.values()).backward()
+
+        def gclose(name, ref, scale=1.0):
+            a, b = params[name].grad.numpy(), g[ref]
+            tol = 1e-4 * max(1e-12, float(np.abs(b).max()))
+            np.testing.assert_allclose(a, b, atol=tol, rtol=1e-3)
+
+        gclose("field.mlp_base.model.0.hash_table", "g_main_table")
+        gclose("field.embedding_appearance.embedding.weight", "g_emb")
+        for j in range(2):
+            gclose(f"field.mlp_base.model.1.layers.{j}.weight", f"g_base_W{j}")
+            gclose(f"field.mlp_base.model.1.layers.{j}.bias", f"g_base_b{j}")
+        for j in range(3):
+            gclose(f"field.mlp_head.layers.{j}.weight", f"g_head_W{j}")
+            gclose(f"field.mlp_head.layers.{j}.bias", f"g_head_b{j}")
+        for i in range(2):
+            gclose(f"proposal_networks.{i}.encoding.hash_table", f"g_prop{i}_table")
+            for j in range(2):
+                gclose(f"proposal_networks.{i}.mlp_base.1.layers.{j}.weight", f"g_prop{i}_W{j}")
+                gclose(f"proposal_networks.{i}.mlp_base.1.layers.{j}.bias", f"g_prop{i}_b{j}")
+
+
+# ---------------------------------------------------------------- raygen ------------------------------------------
+def test_raygen_fixture(golden):
+    g = golden("raygen")
+    out = orc.raygen_pinhole(T(g["ray_indices"]), T(g["c2w"]), T(g["fx"]), T(g["fy"]), T(g["cx"]), T(g["cy"]))
+    close(out["origins"], g["origins"], atol=0)
+    close(out["directions"], g["directions"], atol=1e-7)
+    close(out["pixel_area"], g["pixel_area"], rtol=1e-4)
+    close(out["directions_norm"], g["directions_norm"], rtol=1e-6)
