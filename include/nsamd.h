@@ -1,0 +1,248 @@
+/*
+ * nsamd.h — C ABI of libnsamd.so: the MI355X (gfx950) volumetric-rendering core behind nerfstudio's
+ * Field / Encoding / Sampler / Renderer plugin API (nerfacto hot path).
+ *
+ * The boundary: plain pointers, sizes, small POD structs passed by value and a hipStream_t. No torch types.
+ * Every pointer is a DEVICE pointer unless the name ends in `_host`. All tensors are fp32 unless noted, dense,
+ * row-major. Every entry point returns 0 (NSAMD_OK) or a negative nsamd_status; nothing is launched on error.
+ * Kernels are enqueued on `stream` and never synchronise the device.
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference/nerfstudio/):
+ *   the reference's only FFI seam for this path is `implementation="tcnn"` —
+ *     tcnn.Encoding(HashGrid)            field_components/encodings.py:353-365, :460-463
+ *     tcnn.Encoding(SphericalHarmonics)  field_components/encodings.py:772-786, :796-799
+ *     tcnn.Network / NetworkWithInputEncoding   field_components/mlp.py:103-114, :252-269, :181-184, :294-295
+ *   and nerfacc for packed compositing (model_components/renderers.py:97-102). Everything else on the path is
+ *   eager torch; those stages are listed per function below with the torch-path lines they restate.
+ *
+ * Numerics contract (BASELINE.json north_star): results follow the reference's TORCH path —
+ * bit-exact integer sample indices and bins for identical inputs (left-to-right fp32 sums, IEEE div, no FMA
+ * contraction in the sampler kernels), fp32 everywhere, RGB within 1e-4 L-inf of the torch field.
+ */
+#ifndef NSAMD_H
+#define NSAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* hipStream_t without pulling hip headers into C callers (ctypes passes the raw pointer value). */
+typedef void* nsamd_stream_t;
+
+typedef enum nsamd_status {
+  NSAMD_OK = 0,
+  NSAMD_ERR_INVALID_ARG = -1,   /* null pointer, negative size, inconsistent shapes      */
+  NSAMD_ERR_UNSUPPORTED = -2,   /* configuration outside what the kernels are built for  */
+  NSAMD_ERR_LAUNCH = -3,        /* hipGetLastError() != hipSuccess after the launch      */
+  NSAMD_ERR_NO_DEVICE = -4      /* no gfx950 device / HIP runtime error at query time    */
+} nsamd_status;
+
+#define NSAMD_MAX_LEVELS 32
+
+/* Multiresolution hash grid (HashEncoding ctor, field_components/encodings.py:321-370).
+ * features_per_level is fixed at 2 (the only value any nerfacto config uses); table is [L * 2^log2_T, 2].
+ * scalings[l] = floor(min_res * growth^l) evaluated in fp32 by the host exactly as the reference does. */
+typedef struct nsamd_grid {
+  int32_t num_levels;
+  int32_t log2_table_size;
+  float scalings[NSAMD_MAX_LEVELS];
+} nsamd_grid;
+
+/* Where the M sample points come from. Either
+ *   positions != NULL : explicit [M,3] positions (Field.density_fn, fields/base_field.py:48-68), or
+ *   positions == NULL : M = num_rays * S points o + d * (t[s] + t[s+1]) / 2   (Frustums.get_positions,
+ *                       cameras/rays.py:50-59) — positions are never materialised in HBM.               */
+typedef struct nsamd_points {
+  const float* positions;  /* [M,3] or NULL                    */
+  const float* origins;    /* [num_rays,3]      (ray mode)     */
+  const float* directions; /* [num_rays,3]      (ray mode)     */
+  const float* t_bins;     /* [num_rays,S+1]    (ray mode)     */
+  int32_t samples_per_ray; /* S                 (ray mode)     */
+} nsamd_points;
+
+/* Position normalisation ahead of the hash grid (fields/density_fields.py:95-103, nerfacto_field.py:205-214). */
+typedef enum nsamd_transform {
+  NSAMD_XFORM_NONE = 0,       /* x already in [0,1]^3; selector = 1                                            */
+  NSAMD_XFORM_CONTRACT = 1,   /* L-inf SceneContraction (spatial_distortions.py:66-69), (x+2)/4, selector mask */
+  NSAMD_XFORM_AABB = 2        /* (x - aabb_min) / (aabb_max - aabb_min)  (data/scene_box.py:62-71), selector   */
+} nsamd_transform;
+
+typedef struct nsamd_aabb { float lo[3]; float hi[3]; } nsamd_aabb;
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Hash encoding.  Replaces tcnn.Encoding(HashGrid) with TORCH-path semantics (HashEncoding.pytorch_fwd,
+ * encodings.py:417-458; hash_fn :398-415): ceil/floor corners, every level hashed, blend order x,y,z.
+ * enc element (point p, feature k = 2*level + f) is written at enc[p*stride_p + k*stride_k]; the fused fields use
+ * the feature-major layout (stride_p = 1, stride_k = M) so that both producer and consumer are coalesced.
+ * selector (nullable) receives 1.0f / 0.0f per point (all coords strictly inside (0,1) after the transform).
+ * ------------------------------------------------------------------------------------------------------------ */
+int nsamd_hashgrid_encode_fwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
+                              nsamd_grid grid, float* enc, int64_t stride_p, int64_t stride_k, float* selector,
+                              nsamd_stream_t stream);
+
+/* Backward: dtable[L*T,2] += scatter of denc (fp32 atomics; caller zero-fills); dpositions (nullable) [M,3]
+ * receives dL/d(raw position) through offset = scaled - floor(scaled), the selector, the affine map and the
+ * contraction Jacobian exactly as autograd differentiates the reference (SURVEY.md §8a gradient-flow facts). */
+int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
+                              nsamd_grid grid, const float* denc, int64_t stride_p, int64_t stride_k,
+                              float* dtable, float* dpositions, nsamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * SH encoding, 4 levels = 16 components (SHEncoding.pytorch_fwd, encodings.py:791-794 ->
+ * utils/spherical_harmonics.py:24-93), evaluated on the input as given. dirs [M,3] -> out [M,16]. No gradient.
+ * ------------------------------------------------------------------------------------------------------------ */
+int nsamd_sh4_encode(const float* dirs, int64_t M, float* out, nsamd_stream_t stream);
+
+/* SceneContraction(order=inf) forward on [M,3] (spatial_distortions.py:66-69). */
+int nsamd_contract_linf(const float* x, int64_t M, float* out, nsamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Proposal density head: MLP in(=2L) -> H (ReLU) -> 1, density = avg_init * trunc_exp(.) * selector
+ * (HashMLPDensityField.get_density, fields/density_fields.py:104-117; MLP.pytorch_fwd mlp.py:160-179;
+ * trunc_exp activations.py:28-54). enc is feature-major [in_dim, M]. Weights as nn.Linear: W0 [H,in], b0 [H],
+ * W1 [1,H], b1 [1]. Supported: in_dim <= 32, H <= 64.
+ * pre (nullable) receives the pre-activation (needed by the backward).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct nsamd_density_mlp {
+  const float* W0; const float* b0; const float* W1; const float* b1;
+  int32_t in_dim; int32_t hidden;
+  float average_init_density;
+} nsamd_density_mlp;
+
+int nsamd_density_mlp_fwd(const float* enc, const float* selector, int64_t M, nsamd_density_mlp mlp,
+                          float* density, float* pre, nsamd_stream_t stream);
+
+/* Backward: ddensity [M] -> denc feature-major [in_dim,M] (overwritten), and dW0,db0,dW1,db1 accumulated
+ * (caller zero-fills). trunc_exp backward clamps the exponent to [-15,15] (activations.py:39-42). */
+int nsamd_density_mlp_bwd(const float* enc, const float* selector, const float* pre, const float* ddensity,
+                          int64_t M, nsamd_density_mlp mlp, float* denc, float* dW0, float* db0, float* dW1,
+                          float* db1, nsamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * nerfacto main field head (NerfactoField.get_density + get_outputs, fields/nerfacto_field.py:203-310):
+ *   base MLP 32 -> 64 (ReLU) -> 16 ; density = avg_init * trunc_exp(out[0]) * selector ; geo = out[1:16]
+ *   head MLP [SH16(dir') | geo15 | appearance32] = 63 -> 64 -> 64 -> 3, sigmoid ; dir' = (dir+1)/2
+ * fp32 MFMA (v_mfma_f32_16x16x4_f32), one wavefront per 16 samples, weights staged once per workgroup in LDS.
+ * enc: feature-major [32, M]. directions: [num_dirs,3] with point p using row p / dir_group (dir_group = S for
+ * per-ray directions, 1 for per-point). camera_indices likewise ([num_dirs] int64) — NULL selects
+ * `appearance_const` ([32], the eval-time mean/zero embedding, nerfacto_field.py:253-261) for every point.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct nsamd_field_mlp {
+  const float* base_W0; const float* base_b0;   /* [64,32],[64] */
+  const float* base_W1; const float* base_b1;   /* [16,64],[16] */
+  const float* head_W0; const float* head_b0;   /* [64,63],[64] */
+  const float* head_W1; const float* head_b1;   /* [64,64],[64] */
+  const float* head_W2; const float* head_b2;   /* [3,64],[3]   */
+  const float* appearance;                      /* [num_images,32] embedding table (may be NULL if unused) */
+  int32_t num_images;
+  float average_init_density;
+} nsamd_field_mlp;
+
+int nsamd_field_mlp_fwd(const float* enc, const float* selector, const float* directions,
+                        const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
+                        nsamd_field_mlp mlp, float* density, float* rgb, nsamd_stream_t stream);
+
+typedef struct nsamd_field_mlp_grads {          /* all accumulated; caller zero-fills */
+  float* base_W0; float* base_b0; float* base_W1; float* base_b1;
+  float* head_W0; float* head_b0; float* head_W1; float* head_b1; float* head_W2; float* head_b2;
+  float* appearance;                            /* [num_images,32] or NULL */
+} nsamd_field_mlp_grads;
+
+/* Backward recomputes the activations from enc (nothing but enc is kept from the forward).
+ * ddensity [M], drgb [M,3] -> denc feature-major [32,M] (overwritten) + parameter gradients. */
+int nsamd_field_mlp_bwd(const float* enc, const float* selector, const float* directions,
+                        const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
+                        nsamd_field_mlp mlp, const float* ddensity, const float* drgb, float* denc,
+                        nsamd_field_mlp_grads grads, nsamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Samplers (model_components/ray_samplers.py). Bins are [num_rays, S+1]; `s` = normalised spacing domain,
+ * `t` = euclidean distance. lin_host-free: `edges` is the device copy of torch.linspace(0,1,S+1) and `u_base` of
+ * torch.linspace(0, 1-1/(S+1), S+1) (the host evaluates them with torch so the fp32 values are the reference's).
+ * jitter (nullable = eval) is the raw U[0,1) draw per ray ([num_rays], single_jitter).
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* UniformLinDispPiecewiseSampler / SpacedSampler.generate_ray_samples (ray_samplers.py:78-128, 225-248). */
+int nsamd_piecewise_bins(const float* nears, const float* fars, const float* edges, const float* jitter,
+                         int64_t num_rays, int32_t S, float* s_bins, float* t_bins, nsamd_stream_t stream);
+
+/* RaySamples.get_weights (cameras/rays.py:129-152): left-to-right cumsum per ray. */
+int nsamd_weights_fwd(const float* t_bins, const float* density, int64_t num_rays, int32_t S, float* weights,
+                      nsamd_stream_t stream);
+int nsamd_weights_bwd(const float* t_bins, const float* density, const float* dweights, int64_t num_rays,
+                      int32_t S, float* ddensity, nsamd_stream_t stream);
+
+/* PDFSampler.generate_ray_samples, include_original=False (ray_samplers.py:276-372) preceded by the anneal
+ * pow(weights, anneal) (ray_samplers.py:601; skipped when anneal == 1). inds (nullable) receives the
+ * searchsorted(side="right") result as int32 [num_rays, S+1]. u_offset = (float)(1.0 / (2 * (S+1))) is the eval-mode
+ * offset (ray_samplers.py:327), rounded double->float by the host like torch rounds the Python scalar. */
+int nsamd_pdf_resample(const float* s_bins_prev, const float* weights, int32_t S_prev, const float* u_base,
+                       const float* jitter, const float* nears, const float* fars, float anneal,
+                       float histogram_padding, float eps, float u_offset, int64_t num_rays, int32_t S,
+                       float* s_bins, float* t_bins, int32_t* inds, nsamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Compositing (model_components/renderers.py): RGBRenderer.combine_rgb :72-119 (+ eval nan_to_num/clamp
+ * :225-231), AccumulationRenderer :293-317, DepthRenderer median :354-364 and expected :365-383.
+ * background: 0 = "random"/none, 1 = "last_sample", 2 = constant colour bg_rgb[3] (host values).
+ * Outputs (any may be NULL): rgb_out [N,3], acc [N], depth_expected [N] (clipped to the batch-global min/max of
+ * the sample midpoints, as the reference does), depth_median [N], median_idx [N] int32.
+ * `workspace` = 2 floats of device scratch (global min / max), only needed when depth_expected != NULL.
+ * ------------------------------------------------------------------------------------------------------------ */
+int nsamd_composite_fwd(const float* rgb, const float* weights, const float* t_bins, int64_t num_rays, int32_t S,
+                        int background, const float* bg_rgb_host, int eval_mode, float* rgb_out, float* acc,
+                        float* depth_expected, float* depth_median, int32_t* median_idx, float* workspace,
+                        nsamd_stream_t stream);
+
+/* Backward of rgb_out / acc / depth_expected w.r.t. rgb samples and weights (training mode).
+ * d_rgb_out [N,3], d_acc [N] (nullable), d_depth [N] (nullable; needs `workspace` from the forward and t_bins). */
+int nsamd_composite_bwd(const float* rgb, const float* weights, const float* t_bins, int64_t num_rays, int32_t S,
+                        int background, const float* bg_rgb_host, const float* d_rgb_out, const float* d_acc,
+                        const float* d_depth, const float* workspace, float* d_rgb, float* d_weights,
+                        nsamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Proposal losses (model_components/losses.py). Per-ray fused forward + gradient:
+ * interlevel (:53-131): per_ray_loss[n] = sum_i clip(w_i - outer_i, 0)^2 / (w_i + 1e-7); dwp = d(sum)/d(wp).
+ * distortion (:135-154): per_ray_loss[n] and dw. The host applies mean() and the loss multipliers to the value;
+ * the gradients are pre-multiplied by grad_scale (= multiplier / number of terms in the mean). dw may be NULL.
+ * ------------------------------------------------------------------------------------------------------------ */
+int nsamd_interlevel_loss(const float* s_bins_fine, const float* w_fine, int32_t S_fine, const float* s_bins_prop,
+                          const float* w_prop, int32_t S_prop, int64_t num_rays, float grad_scale,
+                          float* per_ray_loss, float* dw_prop, nsamd_stream_t stream);
+int nsamd_distortion_loss(const float* s_bins, const float* weights, int32_t S, int64_t num_rays, float grad_scale,
+                          float* per_ray_loss, float* dweights, nsamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Pinhole ray generation (RayGenerator.forward, model_components/ray_generators.py:41-56 ->
+ * Cameras._generate_rays_from_coords perspective branch, cameras/cameras.py:598-634, 655-656, 781-787, 887-909).
+ * ray_indices [N,3] int64 (camera,row,col); c2w [C,3,4]; fx,fy,cx,cy [C]. Pixel centres at +0.5.
+ * ------------------------------------------------------------------------------------------------------------ */
+int nsamd_raygen_pinhole(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy,
+                         const float* cx, const float* cy, int64_t num_rays, int32_t num_cameras, float* origins,
+                         float* directions, float* pixel_area, float* directions_norm, nsamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused Adam over a flat fp32 arena (engine/optimizers.py:74-193 with AdamOptimizerConfig(lr, eps=1e-15),
+ * torch.optim.Adam semantics: bias-corrected, no weight decay, no amsgrad). grad_scale multiplies the gradient
+ * first (1/world_size for the data-parallel mean, or the inverse loss scale). step is 1-based.
+ * ------------------------------------------------------------------------------------------------------------ */
+int nsamd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                    float beta1, float beta2, float eps, int32_t step, float grad_scale, nsamd_stream_t stream);
+
+/* Library / device introspection. */
+const char* nsamd_version(void);
+const char* nsamd_status_string(int status);
+int nsamd_device_info(int32_t* num_cus, int32_t* wavefront_size, int32_t* lds_bytes_per_cu, char* arch_name,
+                      int32_t arch_name_len);
+
+/* MFMA lane-layout probe used by the tests: out[16,16] = A[16,4] * B[4,16] through one v_mfma_f32_16x16x4_f32
+ * with the operand/result lane mapping the field kernels assume. */
+int nsamd_probe_mfma16(const float* A, const float* B, float* out, nsamd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSAMD_H */

@@ -1,0 +1,220 @@
+"""ctypes binding of libnsamd.so — the C-ABI boundary declared in include/nsamd.h.
+
+This is the ONLY place the product touches native code. It never falls back: if the shared library is missing or a
+kernel reports an error a RuntimeError is raised (the reference's tcnn seam silently falls back to torch,
+field_components/encodings.py:350-352 — a `implementation="hip"` request must not).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnsamd.so")
+
+MAX_LEVELS = 32
+XFORM_NONE, XFORM_CONTRACT, XFORM_AABB = 0, 1, 2
+BG_NONE, BG_LAST_SAMPLE, BG_CONSTANT = 0, 1, 2
+
+vp = C.c_void_p
+i64 = C.c_int64
+i32 = C.c_int32
+f32 = C.c_float
+
+
+class Grid(C.Structure):
+    _fields_ = [("num_levels", i32), ("log2_table_size", i32), ("scalings", f32 * MAX_LEVELS)]
+
+
+class Points(C.Structure):
+    _fields_ = [("positions", vp), ("origins", vp), ("directions", vp), ("t_bins", vp), ("samples_per_ray", i32)]
+
+
+class Aabb(C.Structure):
+    _fields_ = [("lo", f32 * 3), ("hi", f32 * 3)]
+
+
+class DensityMlp(C.Structure):
+    _fields_ = [("W0", vp), ("b0", vp), ("W1", vp), ("b1", vp), ("in_dim", i32), ("hidden", i32),
+                ("average_init_density", f32)]
+
+
+class FieldMlp(C.Structure):
+    _fields_ = [("base_W0", vp), ("base_b0", vp), ("base_W1", vp), ("base_b1", vp), ("head_W0", vp), ("head_b0", vp),
+                ("head_W1", vp), ("head_b1", vp), ("head_W2", vp), ("head_b2", vp), ("appearance", vp),
+                ("num_images", i32), ("average_init_density", f32)]
+
+
+class FieldMlpGrads(C.Structure):
+    _fields_ = [("base_W0", vp), ("base_b0", vp), ("base_W1", vp), ("base_b1", vp), ("head_W0", vp), ("head_b0", vp),
+                ("head_W1", vp), ("head_b1", vp), ("head_W2", vp), ("head_b2", vp), ("appearance", vp)]
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPES). Mirrors include/nsamd.h one to one; the CPU test
+# tests/test_abi.py checks that every symbol declared in the header is exported by the library and listed here.
+_SIGNATURES = {
+    "nsamd_hashgrid_encode_fwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp],
+    "nsamd_hashgrid_encode_bwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, vp],
+    "nsamd_sh4_encode": [vp, i64, vp, vp],
+    "nsamd_contract_linf": [vp, i64, vp, vp],
+    "nsamd_density_mlp_fwd": [vp, vp, i64, DensityMlp, vp, vp, vp],
+    "nsamd_density_mlp_bwd": [vp, vp, vp, vp, i64, DensityMlp, vp, vp, vp, vp, vp, vp],
+    "nsamd_field_mlp_fwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp],
+    "nsamd_field_mlp_bwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp],
+    "nsamd_piecewise_bins": [vp, vp, vp, vp, i64, i32, vp, vp, vp],
+    "nsamd_weights_fwd": [vp, vp, i64, i32, vp, vp],
+    "nsamd_weights_bwd": [vp, vp, vp, i64, i32, vp, vp],
+    "nsamd_pdf_resample": [vp, vp, i32, vp, vp, vp, vp, f32, f32, f32, f32, i64, i32, vp, vp, vp, vp],
+    "nsamd_composite_fwd": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), C.c_int, vp, vp, vp, vp, vp, vp, vp],
+    "nsamd_composite_bwd": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, vp, vp, vp, vp, vp, vp],
+    "nsamd_interlevel_loss": [vp, vp, i32, vp, vp, i32, i64, f32, vp, vp, vp],
+    "nsamd_distortion_loss": [vp, vp, i32, i64, f32, vp, vp, vp],
+    "nsamd_raygen_pinhole": [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp],
+    "nsamd_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp],
+    "nsamd_version": [],
+    "nsamd_status_string": [C.c_int],
+    "nsamd_device_info": [C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32],
+    "nsamd_probe_mfma16": [vp, vp, vp, vp],
+}
+_RESTYPES = {"nsamd_version": C.c_char_p, "nsamd_status_string": C.c_char_p}
+
+_lib = None
+
+# Optional live kernel timing (bench.py's `roofline` leg): when PROFILE is a dict, every launch through the binding is
+# bracketed by a pair of HIP events recorded on torch's current stream — the stream the kernels are enqueued on.
+PROFILE: Optional[dict] = None
+
+
+class _Entry:
+    """One C-ABI entry point; transparently records (start, end) events per call when profiling is enabled."""
+
+    __slots__ = ("fn", "name")
+
+    def __init__(self, fn, name):
+        self.fn, self.name = fn, name
+
+    def __call__(self, *args):
+        prof = PROFILE
+        if prof is None:
+            return self.fn(*args)
+        key = self.name
+        if self.name.startswith("nsamd_hashgrid_encode"):
+            key = f"{self.name}[L={args[5].num_levels},M={args[1]}]"
+        elif self.name.startswith("nsamd_density_mlp"):
+            key = f"{self.name}[M={args[2] if self.name.endswith('fwd') else args[4]}]"
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = self.fn(*args)
+        e1.record()
+        prof.setdefault(key, []).append((e0, e1))
+        return r
+
+
+class _Lib:
+    pass
+
+
+def load():
+    """Load libnsamd.so (once). Raises RuntimeError when it has not been built — there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"nerfstudio_amd: native library not found at {LIB_PATH}. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C nerfstudio_amd/csrc`). "
+            "There is no CPU/torch fallback for implementation='hip'."
+        )
+    cdll = C.CDLL(LIB_PATH)
+    lib = _Lib()
+    lib.cdll = cdll
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(cdll, name)  # AttributeError here = header / library mismatch
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+        setattr(lib, name, _Entry(fn, name) if fn.restype is C.c_int and name not in ("nsamd_device_info",) else fn)
+    _lib = lib
+    return lib
+
+
+def profile_summary(prof: dict) -> dict:
+    """{key: (calls, total_ms, mean_ms)} from recorded event pairs (call after a device synchronise)."""
+    out = {}
+    for key, pairs in prof.items():
+        ms = [a.elapsed_time(b) for a, b in pairs]
+        out[key] = (len(ms), float(sum(ms)), float(sum(ms) / max(1, len(ms))))
+    return out
+
+
+def status_string(status: int) -> str:
+    return load().nsamd_status_string(status).decode()
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise RuntimeError(f"nsamd: {what} failed with status {status}: {status_string(status)}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device pointer of a tensor (None -> NULL). The tensor must be contiguous; callers keep it alive."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "nsamd kernels take dense row-major tensors"
+    return t.data_ptr()
+
+
+def stream() -> int:
+    """The raw hipStream_t of torch's current stream (kernels must run on it, SURVEY.md §8b threading)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors: Optional[torch.Tensor]) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "nerfstudio_amd: implementation='hip' runs on an MI355X only; got a CPU tensor "
+                "(there is no CPU fallback — use the reference's implementation='torch' for CPU runs)."
+            )
+
+
+def make_grid(num_levels: int, log2_table_size: int, scalings) -> Grid:
+    if num_levels > MAX_LEVELS:
+        raise ValueError(f"at most {MAX_LEVELS} hash levels are supported, got {num_levels}")
+    g = Grid()
+    g.num_levels = int(num_levels)
+    g.log2_table_size = int(log2_table_size)
+    for i, s in enumerate(scalings):
+        g.scalings[i] = float(s)
+    return g
+
+
+def make_points(positions=None, origins=None, directions=None, t_bins=None, samples_per_ray: int = 0) -> Points:
+    p = Points()
+    p.positions = ptr(positions)
+    p.origins = ptr(origins)
+    p.directions = ptr(directions)
+    p.t_bins = ptr(t_bins)
+    p.samples_per_ray = int(samples_per_ray)
+    return p
+
+
+def make_aabb(aabb: Optional[torch.Tensor]) -> Aabb:
+    a = Aabb()
+    if aabb is not None:
+        vals = aabb.detach().cpu().reshape(2, 3).tolist()
+        for i in range(3):
+            a.lo[i] = vals[0][i]
+            a.hi[i] = vals[1][i]
+    return a
+
+
+def device_info() -> dict:
+    lib = load()
+    cus, wf, lds = i32(), i32(), i32()
+    name = C.create_string_buffer(64)
+    check(lib.nsamd_device_info(C.byref(cus), C.byref(wf), C.byref(lds), name, 64), "nsamd_device_info")
+    return {"num_cus": cus.value, "wavefront_size": wf.value, "lds_bytes_per_cu": lds.value, "arch": name.value.decode()}

@@ -1,0 +1,184 @@
+// Shared helpers for the nsamd HIP kernels (gfx950 only).
+// Per-point / per-ray arithmetic lives in NSAMD_HD inline functions so that tests/hostsim can run the very same
+// code on the host (unit tests of kernel logic without a GPU). The product never runs them on the CPU.
+#pragma once
+
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/nsamd.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define NSAMD_HD __host__ __device__ __forceinline__
+#define NSAMD_D __device__ __forceinline__
+#else
+#define NSAMD_HD inline
+#define NSAMD_D inline
+#endif
+
+#if defined(__HIPCC__)
+#define NSAMD_CHECK_LAUNCH()                                   \
+  do {                                                         \
+    hipError_t e__ = hipGetLastError();                        \
+    if (e__ != hipSuccess) return NSAMD_ERR_LAUNCH;            \
+  } while (0)
+#endif
+
+#define NSAMD_REQUIRE(cond) \
+  do {                      \
+    if (!(cond)) return NSAMD_ERR_INVALID_ARG; \
+  } while (0)
+
+namespace nsamd {
+
+constexpr uint32_t kPrimeY = 2654435761u;  // encodings.py:410
+constexpr uint32_t kPrimeZ = 805459861u;   // encodings.py:410
+
+// ---- position of sample p (Frustums.get_positions, cameras/rays.py:50-59) -------------------------------------
+NSAMD_HD void load_position(const nsamd_points& P, int64_t p, float& x, float& y, float& z) {
+  if (P.positions != nullptr) {
+    x = P.positions[3 * p + 0];
+    y = P.positions[3 * p + 1];
+    z = P.positions[3 * p + 2];
+  } else {
+    const int64_t S = P.samples_per_ray;
+    const int64_t ray = p / S;
+    const int64_t s = p - ray * S;
+    const float* tb = P.t_bins + ray * (S + 1) + s;
+    const float span = tb[0] + tb[1];  // starts + ends
+    const float* o = P.origins + 3 * ray;
+    const float* d = P.directions + 3 * ray;
+    x = o[0] + d[0] * span / 2.0f;
+    y = o[1] + d[1] * span / 2.0f;
+    z = o[2] + d[2] * span / 2.0f;
+  }
+}
+
+// ---- L-inf scene contraction (spatial_distortions.py:66-69) ---------------------------------------------------
+NSAMD_HD void contract_linf(float& x, float& y, float& z) {
+  const float mag = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+  if (!(mag < 1.0f)) {  // torch.where(mag < 1, x, ...): NaN takes the second branch
+    const float a = 2.0f - (1.0f / mag);
+    x = a * (x / mag);
+    y = a * (y / mag);
+    z = a * (z / mag);
+  }
+}
+
+// Backward of contract_linf as autograd differentiates `(2 - 1/mag) * (x / mag)` with mag = ||x||_inf
+// (linalg_vector_norm backward shares the gradient equally between tied maxima).
+NSAMD_HD void contract_linf_bwd(float x, float y, float z, float& gx, float& gy, float& gz) {
+  const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+  const float mag = fmaxf(ax, fmaxf(ay, az));
+  if (mag < 1.0f) return;
+  const float a = 2.0f - (1.0f / mag);
+  const float inv = 1.0f / mag;
+  // y_i = a * b_i, b_i = x_i / mag
+  const float g_a = gx * (x * inv) + gy * (y * inv) + gz * (z * inv);
+  float g_mag = g_a * (inv * inv);  // d a / d mag = 1/mag^2
+  // d b_i / d mag = -x_i / mag^2
+  g_mag -= a * (gx * x + gy * y + gz * z) * (inv * inv);
+  const float tx = (ax == mag) ? 1.0f : 0.0f, ty = (ay == mag) ? 1.0f : 0.0f, tz = (az == mag) ? 1.0f : 0.0f;
+  const float cnt = tx + ty + tz;
+  const float sx = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+  const float sy = (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f);
+  const float sz = (z > 0.0f) ? 1.0f : ((z < 0.0f) ? -1.0f : 0.0f);
+  gx = gx * a * inv + g_mag * sx * tx / cnt;
+  gy = gy * a * inv + g_mag * sy * ty / cnt;
+  gz = gz * a * inv + g_mag * sz * tz / cnt;
+}
+
+// ---- raw position -> hash-grid input in [0,1] + selector (density_fields.py:95-103) ---------------------------
+NSAMD_HD float normalise_position(int transform, const nsamd_aabb& box, float& x, float& y, float& z) {
+  if (transform == NSAMD_XFORM_NONE) return 1.0f;
+  if (transform == NSAMD_XFORM_CONTRACT) {
+    contract_linf(x, y, z);
+    x = (x + 2.0f) / 4.0f;
+    y = (y + 2.0f) / 4.0f;
+    z = (z + 2.0f) / 4.0f;
+  } else {
+    x = (x - box.lo[0]) / (box.hi[0] - box.lo[0]);
+    y = (y - box.lo[1]) / (box.hi[1] - box.lo[1]);
+    z = (z - box.lo[2]) / (box.hi[2] - box.lo[2]);
+  }
+  const bool inside = (x > 0.0f) && (x < 1.0f) && (y > 0.0f) && (y < 1.0f) && (z > 0.0f) && (z < 1.0f);
+  const float sel = inside ? 1.0f : 0.0f;
+  x *= sel;  // positions * selector[..., None]
+  y *= sel;
+  z *= sel;
+  return sel;
+}
+
+// ---- spatial hash (HashEncoding.hash_fn, encodings.py:398-415) in wrap-around uint32 --------------------------
+NSAMD_HD uint32_t hash_corner(int32_t ix, int32_t iy, int32_t iz, uint32_t mask) {
+  return ((uint32_t)ix ^ ((uint32_t)iy * kPrimeY) ^ ((uint32_t)iz * kPrimeZ)) & mask;
+}
+
+// Per-level cell data of one point: integer floor/ceil corners and the ceil-corner blend weights.
+struct Cell {
+  int32_t lo[3];
+  int32_t hi[3];
+  float w[3];
+};
+
+NSAMD_HD Cell locate_cell(float x, float y, float z, float scale) {
+  Cell c;
+  const float sx = x * scale, sy = y * scale, sz = z * scale;
+  const float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
+  c.lo[0] = (int32_t)fx;
+  c.lo[1] = (int32_t)fy;
+  c.lo[2] = (int32_t)fz;
+  c.hi[0] = (int32_t)ceilf(sx);
+  c.hi[1] = (int32_t)ceilf(sy);
+  c.hi[2] = (int32_t)ceilf(sz);
+  c.w[0] = sx - fx;
+  c.w[1] = sy - fy;
+  c.w[2] = sz - fz;
+  return c;
+}
+
+// Corner order used throughout: bit0 = x is ceil, bit1 = y is ceil, bit2 = z is ceil.
+NSAMD_HD uint32_t corner_index(const Cell& c, int corner, uint32_t mask) {
+  return hash_corner((corner & 1) ? c.hi[0] : c.lo[0], (corner & 2) ? c.hi[1] : c.lo[1],
+                     (corner & 4) ? c.hi[2] : c.lo[2], mask);
+}
+
+// ---- piecewise spacing function (ray_samplers.py:244-245) -----------------------------------------------------
+NSAMD_HD float spacing_fn(float x) { return (x < 1.0f) ? (x / 2.0f) : (1.0f - 1.0f / (2.0f * x)); }
+NSAMD_HD float spacing_fn_inv(float x) { return (x < 0.5f) ? (2.0f * x) : (1.0f / (2.0f - 2.0f * x)); }
+// closure of ray_samplers.py:115-116
+NSAMD_HD float spacing_to_euclidean(float s, float s_near, float s_far) {
+  return spacing_fn_inv(s * s_far + (1.0f - s) * s_near);
+}
+
+// ---- real spherical harmonics, 4 levels (utils/spherical_harmonics.py:24-93), same association order -----------
+NSAMD_HD void sh4_components(float x, float y, float z, float* c) {
+  const float xx = x * x, yy = y * y, zz = z * z;
+  c[0] = 0.28209479177387814f;
+  c[1] = 0.4886025119029199f * y;
+  c[2] = 0.4886025119029199f * z;
+  c[3] = 0.4886025119029199f * x;
+  c[4] = 1.0925484305920792f * x * y;
+  c[5] = 1.0925484305920792f * y * z;
+  c[6] = 0.9461746957575601f * zz - 0.31539156525251999f;
+  c[7] = 1.0925484305920792f * x * z;
+  c[8] = 0.5462742152960396f * (xx - yy);
+  c[9] = 0.5900435899266435f * y * (3.0f * xx - yy);
+  c[10] = 2.890611442640554f * x * y * z;
+  c[11] = 0.4570457994644658f * y * (5.0f * zz - 1.0f);
+  c[12] = 0.3731763325901154f * z * (5.0f * zz - 3.0f);
+  c[13] = 0.4570457994644658f * x * (5.0f * zz - 1.0f);
+  c[14] = 1.445305721320277f * z * (xx - yy);
+  c[15] = 0.5900435899266435f * x * (xx - 3.0f * yy);
+}
+
+// torch.nan_to_num defaults: nan -> 0 (or `nan`), +inf -> FLT_MAX, -inf -> -FLT_MAX
+NSAMD_HD float nan_to_num(float v, float nan_value = 0.0f) {
+  if (v != v) return nan_value;
+  if (v > 3.4028234663852886e38f) return 3.4028234663852886e38f;
+  if (v < -3.4028234663852886e38f) return -3.4028234663852886e38f;
+  return v;
+}
+
+}  // namespace nsamd

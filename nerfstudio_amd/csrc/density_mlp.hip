@@ -1,0 +1,196 @@
+// Proposal-network density head for gfx950: MLP IN -> H (ReLU) -> 1, density = avg * trunc_exp(.) * selector.
+// Reference: HashMLPDensityField.get_density, /root/reference/nerfstudio/fields/density_fields.py:104-117;
+// MLP.pytorch_fwd field_components/mlp.py:160-179; trunc_exp field_components/activations.py:28-54.
+//
+// 176 MACs per point (IN=10, H=16) is far too little for MFMA tiles to pay (the 16x16x4 tile would be 90 % padding
+// on the output layer); the f32 vector rate equals the f32 MFMA rate on gfx950 anyway. So: one point per lane,
+// feature-major enc[k][p] makes every load a coalesced 256-B row, the weights are wave-uniform and arrive through
+// the scalar cache (s_load -> v_fmac with an SGPR operand), no LDS in the forward.
+// Backward: the per-point input gradient is the same shape of work; the weight gradients need a sum over points,
+// done per 256-point chunk through LDS ([feature][point] rows, stride 257 -> conflict-free) with each thread owning
+// a few weight elements in registers across the chunks of a persistent workgroup, flushed once with atomics
+// (<= kMaxBlocks atomics per weight element).
+#include "common.h"
+
+namespace nsamd {
+
+constexpr int kMlpBlock = 256;
+constexpr int kMaxBlocks = 1024;
+
+template <int IN, int H>
+__global__ __launch_bounds__(kMlpBlock) void density_mlp_fwd_kernel(const float* __restrict__ enc,
+                                                                    const float* __restrict__ selector, int64_t M,
+                                                                    nsamd_density_mlp mlp,
+                                                                    float* __restrict__ density,
+                                                                    float* __restrict__ pre_out) {
+  const float* __restrict__ W0 = mlp.W0;
+  const float* __restrict__ b0 = mlp.b0;
+  const float* __restrict__ W1 = mlp.W1;
+  for (int64_t p = (int64_t)blockIdx.x * kMlpBlock + threadIdx.x; p < M; p += (int64_t)gridDim.x * kMlpBlock) {
+    float x[IN];
+#pragma unroll
+    for (int k = 0; k < IN; ++k) x[k] = enc[(int64_t)k * M + p];
+    float out = mlp.b1[0];
+    constexpr int JU = (H <= 16) ? H : 4;
+#pragma unroll JU
+    for (int j = 0; j < H; ++j) {
+      float a = b0[j];
+#pragma unroll
+      for (int k = 0; k < IN; ++k) a = fmaf(W0[j * IN + k], x[k], a);
+      out = fmaf(W1[j], fmaxf(a, 0.0f), out);
+    }
+    const float sel = selector ? selector[p] : 1.0f;
+    if (pre_out) pre_out[p] = out;
+    density[p] = mlp.average_init_density * expf(out) * sel;
+  }
+}
+
+template <int IN, int H>
+__global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
+    const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ pre,
+    const float* __restrict__ ddensity, int64_t M, nsamd_density_mlp mlp, float* __restrict__ denc,
+    float* __restrict__ dW0, float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1) {
+  constexpr int LD = kMlpBlock + 1;
+  extern __shared__ float lds[];
+  float* gh_T = lds;            // [H][LD]   dL/d(hidden pre-activation) per point
+  float* x_T = lds + H * LD;    // [IN][LD]  encoded features per point
+  float* hg_T = x_T + IN * LD;  // [H][LD]   relu(hidden) * dL/dpre  (for dW1)
+  float* gp = hg_T + H * LD;    // [LD]      dL/dpre per point
+  const float* __restrict__ W0 = mlp.W0;
+  const float* __restrict__ b0 = mlp.b0;
+  const float* __restrict__ W1 = mlp.W1;
+
+  constexpr int NW0 = (H * IN + kMlpBlock - 1) / kMlpBlock;
+  float accW0[NW0];
+#pragma unroll
+  for (int i = 0; i < NW0; ++i) accW0[i] = 0.0f;
+  float accV = 0.0f;  // thread t < H: db0[t]; H <= t < 2H: dW1[t-H]; t == 2H: db1
+
+  const int64_t chunks = (M + kMlpBlock - 1) / kMlpBlock;
+  for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    const int64_t p = c * kMlpBlock + threadIdx.x;
+    const bool live = p < M;
+    float x[IN];
+#pragma unroll
+    for (int k = 0; k < IN; ++k) x[k] = live ? enc[(int64_t)k * M + p] : 0.0f;
+    float g_pre = 0.0f;
+    if (live) {
+      const float sel = selector ? selector[p] : 1.0f;
+      // d density / d pre = avg * sel * exp(clamp(pre, -15, 15))            (activations.py:39-42)
+      g_pre = ddensity[p] * sel * mlp.average_init_density * expf(fminf(fmaxf(pre[p], -15.0f), 15.0f));
+    }
+    float dx[IN];
+#pragma unroll
+    for (int k = 0; k < IN; ++k) dx[k] = 0.0f;
+    constexpr int JU = (H <= 16) ? H : 2;  // wide hidden layers: keep the weight working set in SGPRs
+#pragma unroll JU
+    for (int j = 0; j < H; ++j) {
+      float a = b0[j];
+#pragma unroll
+      for (int k = 0; k < IN; ++k) a = fmaf(W0[j * IN + k], x[k], a);
+      const float gh = (a > 0.0f) ? g_pre * W1[j] : 0.0f;
+      gh_T[j * LD + threadIdx.x] = gh;
+      hg_T[j * LD + threadIdx.x] = fmaxf(a, 0.0f) * g_pre;
+#pragma unroll
+      for (int k = 0; k < IN; ++k) dx[k] = fmaf(gh, W0[j * IN + k], dx[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < IN; ++k) {
+      x_T[k * LD + threadIdx.x] = x[k];
+      if (live) denc[(int64_t)k * M + p] = dx[k];
+    }
+    gp[threadIdx.x] = g_pre;
+    __syncthreads();
+    // weight-gradient partial sums over the 256 points of this chunk
+#pragma unroll
+    for (int i = 0; i < NW0; ++i) {
+      const int e = threadIdx.x + i * kMlpBlock;
+      if (e < H * IN) {
+        const float* a = gh_T + (e / IN) * LD;
+        const float* b = x_T + (e % IN) * LD;
+        float s = 0.0f;
+#pragma unroll 8
+        for (int q = 0; q < kMlpBlock; ++q) s = fmaf(a[q], b[q], s);
+        accW0[i] += s;
+      }
+    }
+    if (threadIdx.x < 2 * H + 1) {
+      const float* a = (threadIdx.x < H)       ? gh_T + threadIdx.x * LD
+                       : (threadIdx.x < 2 * H) ? hg_T + (threadIdx.x - H) * LD
+                                               : gp;
+      float s = 0.0f;
+#pragma unroll 8
+      for (int q = 0; q < kMlpBlock; ++q) s += a[q];
+      accV += s;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < NW0; ++i) {
+    const int e = threadIdx.x + i * kMlpBlock;
+    if (e < H * IN) unsafeAtomicAdd(dW0 + e, accW0[i]);
+  }
+  if (threadIdx.x < H) unsafeAtomicAdd(db0 + threadIdx.x, accV);
+  else if (threadIdx.x < 2 * H) unsafeAtomicAdd(dW1 + (threadIdx.x - H), accV);
+  else if (threadIdx.x == 2 * H) unsafeAtomicAdd(db1, accV);
+}
+
+template <int IN, int H>
+static int launch_fwd(const float* enc, const float* selector, int64_t M, nsamd_density_mlp mlp, float* density,
+                      float* pre, hipStream_t stream) {
+  const unsigned blocks = (unsigned)min((int64_t)8192, (M + kMlpBlock - 1) / kMlpBlock);
+  density_mlp_fwd_kernel<IN, H><<<blocks, kMlpBlock, 0, stream>>>(enc, selector, M, mlp, density, pre);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+template <int IN, int H>
+static int launch_bwd(const float* enc, const float* selector, const float* pre, const float* ddensity, int64_t M,
+                      nsamd_density_mlp mlp, float* denc, float* dW0, float* db0, float* dW1, float* db1,
+                      hipStream_t stream) {
+  const unsigned blocks = (unsigned)min((int64_t)kMaxBlocks, (M + kMlpBlock - 1) / kMlpBlock);
+  const size_t lds = sizeof(float) * (size_t)(2 * H + IN + 1) * (kMlpBlock + 1);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&density_mlp_bwd_kernel<IN, H>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  density_mlp_bwd_kernel<IN, H><<<blocks, kMlpBlock, lds, stream>>>(enc, selector, pre, ddensity, M, mlp, denc, dW0,
+                                                                   db0, dW1, db1);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+}  // namespace nsamd
+
+using namespace nsamd;
+
+#define NSAMD_DENSITY_DISPATCH(CALL)                                  \
+  if (mlp.in_dim == 10 && mlp.hidden == 16) return CALL(10, 16);      \
+  if (mlp.in_dim == 16 && mlp.hidden == 16) return CALL(16, 16);      \
+  if (mlp.in_dim == 10 && mlp.hidden == 64) return CALL(10, 64);      \
+  if (mlp.in_dim == 16 && mlp.hidden == 64) return CALL(16, 64);      \
+  return NSAMD_ERR_UNSUPPORTED;
+
+extern "C" int nsamd_density_mlp_fwd(const float* enc, const float* selector, int64_t M, nsamd_density_mlp mlp,
+                                     float* density, float* pre, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(M >= 0);
+  if (M == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(enc && density && mlp.W0 && mlp.b0 && mlp.W1 && mlp.b1);
+#define CALL(IN, H) launch_fwd<IN, H>(enc, selector, M, mlp, density, pre, (hipStream_t)stream)
+  NSAMD_DENSITY_DISPATCH(CALL)
+#undef CALL
+}
+
+extern "C" int nsamd_density_mlp_bwd(const float* enc, const float* selector, const float* pre,
+                                     const float* ddensity, int64_t M, nsamd_density_mlp mlp, float* denc,
+                                     float* dW0, float* db0, float* dW1, float* db1, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(M >= 0);
+  if (M == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(enc && pre && ddensity && denc && dW0 && db0 && dW1 && db1 && mlp.W0 && mlp.b0 && mlp.W1 && mlp.b1);
+#define CALL(IN, H) \
+  launch_bwd<IN, H>(enc, selector, pre, ddensity, M, mlp, denc, dW0, db0, dW1, db1, (hipStream_t)stream)
+  NSAMD_DENSITY_DISPATCH(CALL)
+#undef CALL
+}

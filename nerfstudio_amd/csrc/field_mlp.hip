@@ -1,0 +1,574 @@
+// nerfacto main-field MLPs on the gfx950 matrix cores, fp32 in / fp32 accumulate (v_mfma_f32_16x16x4_f32).
+// Reference: NerfactoField.get_density + get_outputs, /root/reference/nerfstudio/fields/nerfacto_field.py:203-310
+// (base MLP 32->64->16, trunc_exp density, SH16 | geo15 | appearance32 -> 64 -> 64 -> 3 sigmoid), torch path.
+//
+// fp32 because the contract is 1e-4 RGB L-inf against the fp32 torch field; gfx950 has no TF32, and the f32 MFMA
+// is an exact k-ordered fmaf chain at the f32 vector rate — what it buys over VALU is operand bandwidth: 2048 MACs
+// per instruction from two VGPRs, so the weights can stream from LDS at 16 B per lane per 4 MFMAs.
+//
+// Chain layout. One wavefront owns a tile of 16 sample points. A vector of F features of those points lives in
+// registers as X[t][r] (t < F/16, r < 4): lane (j = lane & 15, g = lane >> 4) holds feature 16t + 4g + r of point
+// j. With Y^T = W X^T, MFMA step (t, r) takes  A = W[16n + j][16t + 4g + r]  and  B = X[t][r]; the C/D fragment of
+// output tile n is then neuron 16n + 4g + r' of point j — the SAME layout, so a layer's accumulators are the
+// next layer's B operands with no shuffle or LDS round trip. The K-order permutation this implies is folded into
+// the weight fragments when a workgroup stages them in LDS (once; workgroups are persistent over tiles):
+//   Wf[n][t][lane][r] = W[16n + j][16t + 4g + r]   -> one conflict-free ds_read_b128 per lane feeds 4 MFMAs.
+// Backward data products use W^T fragments  Wb[m][t][lane][r] = W[16t + 4g + r][16m + j]. The weight-gradient
+// GEMMs reduce over POINTS, so their operands need points on the k axis: each wave transposes the two 16 x F tiles
+// through a private LDS scratch (row stride 80 floats = 16 mod 32 banks: conflict-free b32 column reads) and
+// accumulates dW tiles in registers across all the tiles it processes; one LDS reduction over the 4 waves and one
+// atomic flush per workgroup at the end.
+//
+// Head input slots (internal K order of head layer 0): [0,16) SH, 16 = density pre-activation (zero weight),
+// [17,32) geo features = base outputs 1..15 in place, [32,64) appearance embedding. Logical column = slot for
+// slot < 16, slot - 1 for slot >= 17.
+#include "common.h"
+
+namespace nsamd {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kWaves = 4;
+constexpr int kFieldThreads = 64 * kWaves;
+constexpr int kScratchLd = 80;                      // floats per scratch row (16 mod 32 banks)
+constexpr int kScratchTile = 16 * kScratchLd;       // one 16 x 64 tile
+// fragment sizes in floats: (N_out padded to 16) x (K padded to 16)
+constexpr int kFragBase0 = 64 * 32, kFragBase1 = 16 * 64, kFragHead0 = 64 * 64, kFragHead1 = 64 * 64,
+              kFragHead2 = 16 * 64;
+constexpr int kOffBase0 = 0, kOffBase1 = kOffBase0 + kFragBase0, kOffHead0 = kOffBase1 + kFragBase1,
+              kOffHead1 = kOffHead0 + kFragHead0, kOffHead2 = kOffHead1 + kFragHead1,
+              kFragTotal = kOffHead2 + kFragHead2;  // 12288 floats = 48 KiB
+constexpr int kBiasTotal = 64 + 16 + 64 + 64 + 16;  // padded biases
+constexpr int kBiasBase0 = 0, kBiasBase1 = 64, kBiasHead0 = 80, kBiasHead1 = 144, kBiasHead2 = 208;
+
+__device__ __forceinline__ v4f mfma16(float a, float b, v4f c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// logical column of head layer 0 for internal slot s (-1: no column)
+__device__ __forceinline__ int head0_col(int s, int app_dim) {
+  if (s < 16) return s;
+  if (s == 16) return -1;
+  if (s < 32) return s - 1;
+  return (s - 32 < app_dim) ? s - 1 : -1;
+}
+
+// Wf[n][t][lane][r] = Wint[16n + j][16t + 4g + r]
+__device__ void stage_fwd_frag(float* dst, const float* __restrict__ W, int n_real, int k_real, int NT, int KT,
+                               bool head0, int app_dim) {
+  const int total = NT * KT * 256;
+  for (int e = threadIdx.x; e < total; e += kFieldThreads) {
+    const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8;
+    const int t = tile % KT, n = tile / KT;
+    const int j = lane & 15, g = lane >> 4;
+    const int row = 16 * n + j, slot = 16 * t + 4 * g + r;
+    const int col = head0 ? head0_col(slot, app_dim) : slot;
+    dst[e] = (row < n_real && col >= 0 && col < k_real) ? W[row * k_real + col] : 0.0f;
+  }
+}
+
+// Wb[m][t][lane][r] = Wint[16t + 4g + r][16m + j]     (m over input tiles, t over output tiles)
+__device__ void stage_bwd_frag(float* dst, const float* __restrict__ W, int n_real, int k_real, int NT, int KT,
+                               bool head0, int app_dim) {
+  const int total = NT * KT * 256;
+  for (int e = threadIdx.x; e < total; e += kFieldThreads) {
+    const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8;
+    const int t = tile % NT, m = tile / NT;
+    const int j = lane & 15, g = lane >> 4;
+    const int row = 16 * t + 4 * g + r, slot = 16 * m + j;
+    const int col = head0 ? head0_col(slot, app_dim) : slot;
+    dst[e] = (row < n_real && col >= 0 && col < k_real) ? W[row * k_real + col] : 0.0f;
+  }
+}
+
+__device__ void stage_bias(float* dst, const float* __restrict__ b, int n_real, int n_pad) {
+  for (int e = threadIdx.x; e < n_pad; e += kFieldThreads) dst[e] = (e < n_real) ? b[e] : 0.0f;
+}
+
+// out[n] (+)= sum over input tiles; frag = Wf-style block for this layer: [NT][KT][64][4]
+template <int NT, int KT>
+__device__ __forceinline__ void chain_gemm(const float* frag, const v4f* in, v4f* out, int lane) {
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    v4f a[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) a[n] = *reinterpret_cast<const v4f*>(frag + ((n * KT + t) * 64 + lane) * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) out[n] = mfma16(a[n][r], in[t][r], out[n]);
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void load_bias(const float* bias, v4f* out, int g) {
+#pragma unroll
+  for (int n = 0; n < NT; ++n) out[n] = *reinterpret_cast<const v4f*>(bias + 16 * n + 4 * g);
+}
+
+template <int NT>
+__device__ __forceinline__ void relu_tiles(v4f* x) {
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[n][r] = fmaxf(x[n][r], 0.0f);
+}
+
+struct TileInputs {
+  int64_t p;       // clamped point index of this lane
+  bool live;       // point index < M
+  float sel;       // selector
+  int64_t cam;     // camera index (or 0)
+};
+
+// Forward of one 16-point tile; keeps every activation the backward needs.
+struct FieldActs {
+  v4f enc[2];
+  v4f h1[4];      // relu
+  v4f o16[1];     // base output (pre-activation)
+  v4f hin[4];     // head input slots
+  v4f ha[4];      // relu
+  v4f hb[4];      // relu
+  v4f rgbp[1];    // rgb pre-sigmoid (rows 0..2 of tile 0)
+};
+
+__device__ __forceinline__ void field_forward_tile(const float* wf, const float* bias, const float* __restrict__ enc,
+                                                   const float* __restrict__ directions,
+                                                   const float* __restrict__ app_table,
+                                                   const float* __restrict__ app_const, int64_t dir_group, int64_t M,
+                                                   int app_dim, const TileInputs& ti, int lane, FieldActs& A) {
+  const int g = lane >> 4;
+  // encoded features: feature-major [32][M]; lane needs features 16t + 4g + r of its point
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) A.enc[t][r] = enc[(int64_t)(16 * t + 4 * g + r) * M + ti.p];
+
+  load_bias<4>(bias + kBiasBase0, A.h1, g);
+  chain_gemm<4, 2>(wf + kOffBase0, A.enc, A.h1, lane);
+  relu_tiles<4>(A.h1);
+  load_bias<1>(bias + kBiasBase1, A.o16, g);
+  chain_gemm<1, 4>(wf + kOffBase1, A.h1, A.o16, lane);
+
+  // head input: SH of (dir + 1) / 2  (base_field.py:136-142), geo in place, appearance embedding
+  const float* d = directions + 3 * (ti.p / dir_group);
+  float sh[16];
+  sh4_components((d[0] + 1.0f) / 2.0f, (d[1] + 1.0f) / 2.0f, (d[2] + 1.0f) / 2.0f, sh);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    // select comps 4g + r without dynamic register indexing
+    float v = sh[r];
+    v = (g == 1) ? sh[4 + r] : v;
+    v = (g == 2) ? sh[8 + r] : v;
+    v = (g == 3) ? sh[12 + r] : v;
+    A.hin[0][r] = v;
+  }
+  A.hin[1] = A.o16[0];
+  if (app_dim > 0) {
+    const float* src = (app_table != nullptr) ? app_table + ti.cam * 32 : app_const;
+    A.hin[2] = *reinterpret_cast<const v4f*>(src + 4 * g);
+    A.hin[3] = *reinterpret_cast<const v4f*>(src + 16 + 4 * g);
+  } else {
+    A.hin[2] = v4f{0.f, 0.f, 0.f, 0.f};
+    A.hin[3] = v4f{0.f, 0.f, 0.f, 0.f};
+  }
+  load_bias<4>(bias + kBiasHead0, A.ha, g);
+  chain_gemm<4, 4>(wf + kOffHead0, A.hin, A.ha, lane);
+  relu_tiles<4>(A.ha);
+  load_bias<4>(bias + kBiasHead1, A.hb, g);
+  chain_gemm<4, 4>(wf + kOffHead1, A.ha, A.hb, lane);
+  relu_tiles<4>(A.hb);
+  load_bias<1>(bias + kBiasHead2, A.rgbp, g);
+  chain_gemm<1, 4>(wf + kOffHead2, A.hb, A.rgbp, lane);
+}
+
+__device__ __forceinline__ TileInputs tile_inputs(int64_t tile, int lane, int64_t M, const float* selector,
+                                                  const int64_t* cams, int64_t dir_group) {
+  TileInputs ti;
+  const int64_t p = tile * 16 + (lane & 15);
+  ti.live = p < M;
+  ti.p = ti.live ? p : M - 1;
+  ti.sel = selector ? selector[ti.p] : 1.0f;
+  ti.cam = cams ? cams[ti.p / dir_group] : 0;
+  return ti;
+}
+
+__device__ void stage_all_fwd(float* wf, float* bias, const nsamd_field_mlp& mlp, int app_dim) {
+  stage_fwd_frag(wf + kOffBase0, mlp.base_W0, 64, 32, 4, 2, false, 0);
+  stage_fwd_frag(wf + kOffBase1, mlp.base_W1, 16, 64, 1, 4, false, 0);
+  stage_fwd_frag(wf + kOffHead0, mlp.head_W0, 64, 31 + app_dim, 4, 4, true, app_dim);
+  stage_fwd_frag(wf + kOffHead1, mlp.head_W1, 64, 64, 4, 4, false, 0);
+  stage_fwd_frag(wf + kOffHead2, mlp.head_W2, 3, 64, 1, 4, false, 0);
+  stage_bias(bias + kBiasBase0, mlp.base_b0, 64, 64);
+  stage_bias(bias + kBiasBase1, mlp.base_b1, 16, 16);
+  stage_bias(bias + kBiasHead0, mlp.head_b0, 64, 64);
+  stage_bias(bias + kBiasHead1, mlp.head_b1, 64, 64);
+  stage_bias(bias + kBiasHead2, mlp.head_b2, 3, 16);
+}
+
+__global__ __launch_bounds__(kFieldThreads, 2) void field_mlp_fwd_kernel(
+    const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
+    const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
+    nsamd_field_mlp mlp, int app_dim, float* __restrict__ density, float* __restrict__ rgb) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* wf = lds;
+  float* bias = lds + kFragTotal;
+  stage_all_fwd(wf, bias, mlp, app_dim);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tiles = (M + 15) / 16;
+  const float* app_table = cams ? mlp.appearance : nullptr;
+  for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += (int64_t)gridDim.x * kWaves) {
+    // The fragments are loop-invariant LDS data: without this the compiler hoists all 192 VGPRs of them out of the
+    // tile loop and the kernel drops to one wave per SIMD with nothing to hide the enc loads behind.
+    asm volatile("" ::: "memory");
+    const TileInputs ti = tile_inputs(tile, lane, M, selector, cams, dir_group);
+    FieldActs A;
+    field_forward_tile(wf, bias, enc, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A);
+    if (lane < 16 && ti.live) {  // g == 0 holds neurons 0..3 of tile 0
+      density[ti.p] = mlp.average_init_density * expf(A.o16[0][0]) * ti.sel;
+      float* o = rgb + 3 * ti.p;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] = 1.0f / (1.0f + expf(-A.rgbp[0][c]));
+    }
+  }
+}
+
+// ---- backward -------------------------------------------------------------------------------------------------
+// store a chain-layout vector (T tiles) as rows S[point][feature]
+template <int T>
+__device__ __forceinline__ void store_rows(float* S, const v4f* x, int j, int g) {
+#pragma unroll
+  for (int t = 0; t < T; ++t) *reinterpret_cast<v4f*>(S + j * kScratchLd + 16 * t + 4 * g) = x[t];
+}
+
+// dW[n][m] += Dout^T X over the 16 points of the tile; db[n] partial sums (per lane: points = g mod 4)
+template <int NT, int MT>
+__device__ __forceinline__ void dw_accumulate(v4f* acc /*[NT*MT]*/, float* dbacc /*[NT]*/, const float* Sd,
+                                              const float* Sx, int j, int g) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float a[NT], b[MT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) a[n] = Sd[(4 * q + g) * kScratchLd + 16 * n + j];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) b[m] = Sx[(4 * q + g) * kScratchLd + 16 * m + j];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) dbacc[n] += a[n];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[n * MT + m] = mfma16(a[n], b[m], acc[n * MT + m]);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void zero_tiles(v4f* x) {
+#pragma unroll
+  for (int n = 0; n < N; ++n) x[n] = v4f{0.f, 0.f, 0.f, 0.f};
+}
+
+template <int NT>
+__device__ __forceinline__ void relu_mask(v4f* grad, const v4f* act) {
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) grad[n][r] = (act[n][r] > 0.0f) ? grad[n][r] : 0.0f;
+}
+
+// Reduce the per-wave dW tiles over the waves of the workgroup (LDS, reusing the weight area) and flush with atomics.
+// acc lane (j,g) reg r' of tile (n,m) = dW[16n + 4g + r'][slot 16m + j]
+template <int NT, int MT>
+__device__ __forceinline__ void flush_dw(float* red, const v4f* acc, int j, int g) {
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        atomicAdd(red + (16 * n + 4 * g + r) * (16 * MT) + 16 * m + j, acc[n * MT + m][r]);  // ds_add_f32
+}
+
+__device__ void export_dw(const float* red, float* __restrict__ dst, int n_real, int k_real, int n_pad, int k_pad,
+                          bool head0, int app_dim) {
+  if (dst == nullptr) return;
+  for (int e = threadIdx.x; e < n_pad * k_pad; e += kFieldThreads) {
+    const int row = e / k_pad, slot = e - row * k_pad;
+    const int col = head0 ? head0_col(slot, app_dim) : slot;
+    if (row < n_real && col >= 0 && col < k_real) unsafeAtomicAdd(dst + row * k_real + col, red[e]);
+  }
+}
+
+__global__ __launch_bounds__(kFieldThreads, 1) void field_mlp_bwd_kernel(
+    const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
+    const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
+    nsamd_field_mlp mlp, int app_dim, const float* __restrict__ ddensity, const float* __restrict__ drgb,
+    float* __restrict__ denc, nsamd_field_mlp_grads grads) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* wf = lds;                           // forward fragments          48 KiB
+  float* wb = lds + kFragTotal;              // transposed fragments       48 KiB
+  float* bias = wb + kFragTotal;             // 224 floats (+ pad to 256)
+  float* scratch = bias + 256;               // kWaves x 2 tiles
+  stage_all_fwd(wf, bias, mlp, app_dim);
+  stage_bwd_frag(wb + kOffBase0, mlp.base_W0, 64, 32, 4, 2, false, 0);
+  stage_bwd_frag(wb + kOffBase1, mlp.base_W1, 16, 64, 1, 4, false, 0);
+  stage_bwd_frag(wb + kOffHead0, mlp.head_W0, 64, 31 + app_dim, 4, 4, true, app_dim);
+  stage_bwd_frag(wb + kOffHead1, mlp.head_W1, 64, 64, 4, 4, false, 0);
+  stage_bwd_frag(wb + kOffHead2, mlp.head_W2, 3, 64, 1, 4, false, 0);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  float* Sd = scratch + wave * 2 * kScratchTile;
+  float* Sx = Sd + kScratchTile;
+  const float* app_table = cams ? mlp.appearance : nullptr;
+
+  // weight-gradient accumulators (registers, whole kernel lifetime)
+  v4f dW_b0[4 * 2], dW_b1[1 * 4], dW_h0[4 * 4], dW_h1[4 * 4], dW_h2[1 * 4];
+  float db_b0[4] = {0, 0, 0, 0}, db_b1[1] = {0}, db_h0[4] = {0, 0, 0, 0}, db_h1[4] = {0, 0, 0, 0}, db_h2[1] = {0};
+  zero_tiles<8>(dW_b0);
+  zero_tiles<4>(dW_b1);
+  zero_tiles<16>(dW_h0);
+  zero_tiles<16>(dW_h1);
+  zero_tiles<4>(dW_h2);
+
+  const int64_t tiles = (M + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += (int64_t)gridDim.x * kWaves) {
+    const TileInputs ti = tile_inputs(tile, lane, M, selector, cams, dir_group);
+    FieldActs A;
+    field_forward_tile(wf, bias, enc, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A);
+
+    // ---- head layer 2 (64 -> 3, sigmoid) ----
+    v4f g_rgbp[1];
+    zero_tiles<1>(g_rgbp);
+    if (g == 0 && ti.live) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float s = 1.0f / (1.0f + expf(-A.rgbp[0][c]));
+        g_rgbp[0][c] = drgb[3 * ti.p + c] * (s * (1.0f - s));
+      }
+    }
+    store_rows<1>(Sd, g_rgbp, j, g);
+    store_rows<4>(Sx, A.hb, j, g);
+    __builtin_amdgcn_wave_barrier();
+    dw_accumulate<1, 4>(dW_h2, db_h2, Sd, Sx, j, g);
+    v4f g_hb[4];
+    zero_tiles<4>(g_hb);
+    chain_gemm<4, 1>(wb + kOffHead2, g_rgbp, g_hb, lane);
+    relu_mask<4>(g_hb, A.hb);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- head layer 1 (64 -> 64) ----
+    store_rows<4>(Sd, g_hb, j, g);
+    store_rows<4>(Sx, A.ha, j, g);
+    __builtin_amdgcn_wave_barrier();
+    dw_accumulate<4, 4>(dW_h1, db_h1, Sd, Sx, j, g);
+    v4f g_ha[4];
+    zero_tiles<4>(g_ha);
+    chain_gemm<4, 4>(wb + kOffHead1, g_hb, g_ha, lane);
+    relu_mask<4>(g_ha, A.ha);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- head layer 0 (slots 64 -> 64) ----
+    store_rows<4>(Sd, g_ha, j, g);
+    store_rows<4>(Sx, A.hin, j, g);
+    __builtin_amdgcn_wave_barrier();
+    dw_accumulate<4, 4>(dW_h0, db_h0, Sd, Sx, j, g);
+    v4f g_hin[4];
+    zero_tiles<4>(g_hin);
+    chain_gemm<4, 4>(wb + kOffHead0, g_ha, g_hin, lane);  // tile 0 (SH) is unused: SH carries no gradient
+    __builtin_amdgcn_wave_barrier();
+
+    // appearance-embedding gradient (slots 32..63): rows of one camera are pre-reduced over the tile's points
+    if (app_table != nullptr && grads.appearance != nullptr) {
+      const int cam32 = (int)ti.cam;
+      const int cam0 = __shfl(cam32, 0);
+      const bool uniform = __all(cam32 == cam0);
+      if (uniform) {
+#pragma unroll
+        for (int t = 2; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = g_hin[t][r];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            if (j == 0) unsafeAtomicAdd(grads.appearance + (int64_t)cam0 * 32 + 16 * (t - 2) + 4 * g + r, v);
+          }
+      } else if (ti.live) {
+#pragma unroll
+        for (int t = 2; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            unsafeAtomicAdd(grads.appearance + ti.cam * 32 + 16 * (t - 2) + 4 * g + r, g_hin[t][r]);
+      }
+    }
+
+    // ---- base layer 1 (64 -> 16): slot 16 + n  <-  base output n; n = 0 is the density pre-activation ----
+    v4f g_o16[1];
+    g_o16[0] = g_hin[1];
+    if (g == 0) {
+      // d density / d pre = avg * sel * exp(clamp(pre,-15,15))   (activations.py:39-42); slot 16 has zero weight
+      const float pre = A.o16[0][0];
+      g_o16[0][0] = ti.live ? ddensity[ti.p] * ti.sel * mlp.average_init_density *
+                                  expf(fminf(fmaxf(pre, -15.0f), 15.0f))
+                            : 0.0f;
+    }
+    store_rows<1>(Sd, g_o16, j, g);
+    store_rows<4>(Sx, A.h1, j, g);
+    __builtin_amdgcn_wave_barrier();
+    dw_accumulate<1, 4>(dW_b1, db_b1, Sd, Sx, j, g);
+    v4f g_h1[4];
+    zero_tiles<4>(g_h1);
+    chain_gemm<4, 1>(wb + kOffBase1, g_o16, g_h1, lane);
+    relu_mask<4>(g_h1, A.h1);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- base layer 0 (32 -> 64) ----
+    store_rows<4>(Sd, g_h1, j, g);
+    store_rows<2>(Sx, A.enc, j, g);
+    __builtin_amdgcn_wave_barrier();
+    dw_accumulate<4, 2>(dW_b0, db_b0, Sd, Sx, j, g);
+    v4f g_enc[2];
+    zero_tiles<2>(g_enc);
+    chain_gemm<2, 4>(wb + kOffBase0, g_h1, g_enc, lane);
+    __builtin_amdgcn_wave_barrier();
+    if (ti.live) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) denc[(int64_t)(16 * t + 4 * g + r) * M + ti.p] = g_enc[t][r];
+    }
+  }
+
+  // ---- reduce over the workgroup's waves in LDS (the fragment area is dead now) and flush --------------------
+  __syncthreads();
+  float* red = lds;  // 12288 + 256 floats needed; lds holds 2 * 12288 + ...
+  for (int e = threadIdx.x; e < kFragTotal + 256; e += kFieldThreads) red[e] = 0.0f;
+  __syncthreads();
+  flush_dw<4, 2>(red + kOffBase0, dW_b0, j, g);
+  flush_dw<1, 4>(red + kOffBase1, dW_b1, j, g);
+  flush_dw<4, 4>(red + kOffHead0, dW_h0, j, g);
+  flush_dw<4, 4>(red + kOffHead1, dW_h1, j, g);
+  flush_dw<1, 4>(red + kOffHead2, dW_h2, j, g);
+  float* redb = red + kFragTotal;  // bias sums: lane (j,g) holds neuron 16n + j partial
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    atomicAdd(redb + kBiasBase0 + 16 * n + j, db_b0[n]);
+    atomicAdd(redb + kBiasHead0 + 16 * n + j, db_h0[n]);
+    atomicAdd(redb + kBiasHead1 + 16 * n + j, db_h1[n]);
+  }
+  atomicAdd(redb + kBiasBase1 + j, db_b1[0]);
+  atomicAdd(redb + kBiasHead2 + j, db_h2[0]);
+  __syncthreads();
+  export_dw(red + kOffBase0, grads.base_W0, 64, 32, 64, 32, false, 0);
+  export_dw(red + kOffBase1, grads.base_W1, 16, 64, 16, 64, false, 0);
+  export_dw(red + kOffHead0, grads.head_W0, 64, 31 + app_dim, 64, 64, true, app_dim);
+  export_dw(red + kOffHead1, grads.head_W1, 64, 64, 64, 64, false, 0);
+  export_dw(red + kOffHead2, grads.head_W2, 3, 64, 16, 64, false, 0);
+  for (int e = threadIdx.x; e < kBiasTotal; e += kFieldThreads) {
+    float* dst = nullptr;
+    int idx = 0, n_real = 0;
+    if (e < kBiasBase1) { dst = grads.base_b0; idx = e; n_real = 64; }
+    else if (e < kBiasHead0) { dst = grads.base_b1; idx = e - kBiasBase1; n_real = 16; }
+    else if (e < kBiasHead1) { dst = grads.head_b0; idx = e - kBiasHead0; n_real = 64; }
+    else if (e < kBiasHead2) { dst = grads.head_b1; idx = e - kBiasHead1; n_real = 64; }
+    else { dst = grads.head_b2; idx = e - kBiasHead2; n_real = 3; }
+    if (dst != nullptr && idx < n_real) unsafeAtomicAdd(dst + idx, redb[e]);
+  }
+}
+
+// one MFMA with the assumed operand / result lane mapping (layout probe for the tests)
+__global__ void probe_mfma16_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                    float* __restrict__ out) {
+  const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+  v4f c = {0.f, 0.f, 0.f, 0.f};
+  c = mfma16(A[j * 4 + g], B[g * 16 + j], c);  // A[16][4] row-major, B[4][16] row-major
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[(4 * g + r) * 16 + j] = c[r];
+}
+
+}  // namespace nsamd
+
+using namespace nsamd;
+
+static int field_common_checks(const float* enc, const float* directions, int64_t dir_group, int64_t M,
+                               const nsamd_field_mlp& mlp, const int64_t* cams, const float* app_const, int* app_dim) {
+  NSAMD_REQUIRE(M >= 0 && dir_group >= 1);
+  NSAMD_REQUIRE(enc && directions);
+  NSAMD_REQUIRE(mlp.base_W0 && mlp.base_b0 && mlp.base_W1 && mlp.base_b1 && mlp.head_W0 && mlp.head_b0 &&
+                mlp.head_W1 && mlp.head_b1 && mlp.head_W2 && mlp.head_b2);
+  if (cams != nullptr) {
+    NSAMD_REQUIRE(mlp.appearance != nullptr && mlp.num_images > 0);
+    *app_dim = 32;
+  } else if (app_const != nullptr) {
+    *app_dim = 32;
+  } else {
+    *app_dim = 0;  // field built without an appearance embedding: head input is SH16 | geo15
+  }
+  return NSAMD_OK;
+}
+
+static int num_cus() {
+  static int cached = 0;
+  if (cached == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    cached = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return cached;
+}
+
+extern "C" int nsamd_field_mlp_fwd(const float* enc, const float* selector, const float* directions,
+                                   const int64_t* camera_indices, const float* appearance_const, int64_t dir_group,
+                                   int64_t M, nsamd_field_mlp mlp, float* density, float* rgb,
+                                   nsamd_stream_t stream) {
+  if (M == 0) return NSAMD_OK;
+  int app_dim = 0;
+  int st = field_common_checks(enc, directions, dir_group, M, mlp, camera_indices, appearance_const, &app_dim);
+  if (st) return st;
+  NSAMD_REQUIRE(density && rgb);
+  const size_t lds = sizeof(float) * (kFragTotal + 256);
+  const int64_t tiles = (M + 15) / 16;
+  const unsigned blocks = (unsigned)min((int64_t)num_cus() * 3, (tiles + kWaves - 1) / kWaves);
+  field_mlp_fwd_kernel<<<blocks, kFieldThreads, lds, (hipStream_t)stream>>>(
+      enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_field_mlp_bwd(const float* enc, const float* selector, const float* directions,
+                                   const int64_t* camera_indices, const float* appearance_const, int64_t dir_group,
+                                   int64_t M, nsamd_field_mlp mlp, const float* ddensity, const float* drgb,
+                                   float* denc, nsamd_field_mlp_grads grads, nsamd_stream_t stream) {
+  if (M == 0) return NSAMD_OK;
+  int app_dim = 0;
+  int st = field_common_checks(enc, directions, dir_group, M, mlp, camera_indices, appearance_const, &app_dim);
+  if (st) return st;
+  NSAMD_REQUIRE(ddensity && drgb && denc);
+  const size_t lds = sizeof(float) * (2 * kFragTotal + 256 + kWaves * 2 * kScratchTile);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return NSAMD_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int64_t tiles = (M + 15) / 16;
+  const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + kWaves - 1) / kWaves);
+  field_mlp_bwd_kernel<<<blocks, kFieldThreads, lds, (hipStream_t)stream>>>(
+      enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
+      grads);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_probe_mfma16(const float* A, const float* B, float* out, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(A && B && out);
+  probe_mfma16_kernel<<<1, 64, 0, (hipStream_t)stream>>>(A, B, out);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}

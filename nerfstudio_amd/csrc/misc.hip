@@ -1,0 +1,163 @@
+// Pinhole ray generation, fused Adam and library introspection for gfx950.
+#include <string.h>
+
+#include "common.h"
+
+namespace nsamd {
+
+// RayGenerator.forward (/root/reference/nerfstudio/model_components/ray_generators.py:41-56) ->
+// Cameras._generate_rays_from_coords, perspective branch (cameras/cameras.py:598-634 coords, :655-656 y flip,
+// :781-787 directions, :887-909 rotate, normalise, pixel area). One ray per lane; the per-camera pose and
+// intrinsics are gathered through L2 (a few hundred cameras at most).
+__global__ void raygen_pinhole_kernel(const int64_t* __restrict__ ray_indices, const float* __restrict__ c2w,
+                                      const float* __restrict__ fx, const float* __restrict__ fy,
+                                      const float* __restrict__ cx, const float* __restrict__ cy, int64_t num_rays,
+                                      float* __restrict__ origins, float* __restrict__ directions,
+                                      float* __restrict__ pixel_area, float* __restrict__ directions_norm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num_rays) return;
+  const int64_t cam = ray_indices[3 * i + 0];
+  const float y = (float)ray_indices[3 * i + 1] + 0.5f;  // image_coords = meshgrid + 0.5 (cameras.py:312-313)
+  const float x = (float)ray_indices[3 * i + 2] + 0.5f;
+  const float fxr = fx[cam], fyr = fy[cam], cxr = cx[cam], cyr = cy[cam];
+  const float* m = c2w + cam * 12;  // [3][4] row-major
+  const float eps = 8.881784197001252e-16f;  // camera_utils._EPS = 4 * float64 eps, cast to fp32
+  // three coords: centre, +1 in x, +1 in y  (cameras.py:622-634)
+  const float px[3] = {(x - cxr) / fxr, (x - cxr + 1.0f) / fxr, (x - cxr) / fxr};
+  const float py[3] = {(y - cyr) / fyr, (y - cyr) / fyr, (y - cyr + 1.0f) / fyr};
+  float d[3][3];
+  float n0 = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float lx = px[k], ly = -py[k], lz = -1.0f;  // OpenCV -> OpenGL (cameras.py:655-656), z = -1 (:787)
+    float v[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) v[r] = (lx * m[4 * r + 0] + ly * m[4 * r + 1]) + lz * m[4 * r + 2];
+    const float nrm = fmaxf(sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]), eps);
+    if (k == 0) n0 = nrm;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) d[k][r] = v[r] / nrm;
+  }
+  float dx = 0.0f, dy = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float a = d[0][r] - d[1][r], b = d[0][r] - d[2][r];
+    dx += a * a;
+    dy += b * b;
+  }
+  dx = sqrtf(dx);
+  dy = sqrtf(dy);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    origins[3 * i + r] = m[4 * r + 3];
+    directions[3 * i + r] = d[0][r];
+  }
+  pixel_area[i] = dx * dy;
+  if (directions_norm) directions_norm[i] = n0;
+}
+
+// torch.optim.Adam (no amsgrad / weight decay / maximize): one pass over the flat arena, 16 B per lane.
+// bias corrections are folded by the host into step_size = lr / (1 - b1^t) and inv_sqrt_bc2 = 1 / sqrt(1 - b2^t).
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float beta1, float beta2, float eps, float step_size,
+                            float inv_sqrt_bc2, float grad_scale) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* pa = reinterpret_cast<float*>(&pp);
+    const float* ga = reinterpret_cast<const float*>(&gg);
+    float* ma = reinterpret_cast<float*>(&mm);
+    float* va = reinterpret_cast<float*>(&vv);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = ga[k] * grad_scale;
+      ma[k] = ma[k] + (gr - ma[k]) * (1.0f - beta1);        // exp_avg.lerp_(grad, 1 - beta1)
+      va[k] = va[k] * beta2 + (1.0f - beta2) * gr * gr;     // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+      const float denom = sqrtf(va[k]) * inv_sqrt_bc2 + eps;
+      pa[k] = pa[k] - step_size * (ma[k] / denom);
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  // tail (n not a multiple of 4)
+  const int64_t tail0 = n4 << 2;
+  const int64_t t = tail0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) {
+    const float gr = g[t] * grad_scale;
+    const float m1 = m[t] + (gr - m[t]) * (1.0f - beta1);
+    const float v1 = v[t] * beta2 + (1.0f - beta2) * gr * gr;
+    m[t] = m1;
+    v[t] = v1;
+    p[t] = p[t] - step_size * (m1 / (sqrtf(v1) * inv_sqrt_bc2 + eps));
+  }
+}
+
+}  // namespace nsamd
+
+using namespace nsamd;
+
+extern "C" int nsamd_raygen_pinhole(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy,
+                                    const float* cx, const float* cy, int64_t num_rays, int32_t num_cameras,
+                                    float* origins, float* directions, float* pixel_area, float* directions_norm,
+                                    nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && num_cameras > 0);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(ray_indices && c2w && fx && fy && cx && cy && origins && directions && pixel_area);
+  raygen_pinhole_kernel<<<(unsigned)((num_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      ray_indices, c2w, fx, fy, cx, cy, num_rays, origins, directions, pixel_area, directions_norm);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                               float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,
+                               nsamd_stream_t stream) {
+  NSAMD_REQUIRE(n >= 0 && step >= 1);
+  if (n == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(params && grads && exp_avg && exp_avg_sq);
+  NSAMD_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const int64_t n4 = (n + 3) / 4;
+  const unsigned blocks = (unsigned)min((int64_t)256 * 8, (n4 + 255) / 256);
+  adam_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, beta1, beta2, eps,
+                                                       step_size, inv_sqrt_bc2, grad_scale);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" const char* nsamd_version(void) { return "nsamd 0.1.0 (gfx950)"; }
+
+extern "C" const char* nsamd_status_string(int status) {
+  switch (status) {
+    case NSAMD_OK: return "ok";
+    case NSAMD_ERR_INVALID_ARG: return "invalid argument (null pointer, negative size or inconsistent shapes)";
+    case NSAMD_ERR_UNSUPPORTED: return "configuration not supported by the gfx950 kernels";
+    case NSAMD_ERR_LAUNCH: return "HIP kernel launch failed";
+    case NSAMD_ERR_NO_DEVICE: return "no HIP device";
+    default: return "unknown nsamd status";
+  }
+}
+
+extern "C" int nsamd_device_info(int32_t* num_cus, int32_t* wavefront_size, int32_t* lds_bytes_per_cu,
+                                 char* arch_name, int32_t arch_name_len) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+    return NSAMD_ERR_NO_DEVICE;
+  if (num_cus) *num_cus = prop.multiProcessorCount;
+  if (wavefront_size) *wavefront_size = prop.warpSize;
+  if (lds_bytes_per_cu) *lds_bytes_per_cu = (int32_t)prop.maxSharedMemoryPerMultiProcessor;
+  if (arch_name && arch_name_len > 0) {
+    strncpy(arch_name, prop.gcnArchName, (size_t)arch_name_len - 1);
+    arch_name[arch_name_len - 1] = '\0';
+  }
+  return NSAMD_OK;
+}

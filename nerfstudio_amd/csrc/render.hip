@@ -1,0 +1,259 @@
+// Alpha compositing for gfx950 (reference: /root/reference/nerfstudio/model_components/renderers.py —
+// RGBRenderer.combine_rgb :72-119 + eval nan_to_num/clamp :225-231, AccumulationRenderer :293-317,
+// DepthRenderer median :354-364 / expected :365-383).
+//
+// One wavefront per ray: lane s owns sample s (stride 64 for S > 64), so the [S,3] rgb row and the weight row are
+// read as contiguous, fully coalesced segments; the five running sums collapse with a 6-step xor-shuffle wave
+// reduction. The median depth needs the reference's left-to-right running weight sum (the integer index must match
+// bit-for-bit), so lane 0 walks the row once in LDS. The expected depth is clipped to the batch-GLOBAL min/max of
+// the sample midpoints as the reference does, which needs a device-wide min/max: ordered-uint atomics into a 2-word
+// workspace + a finishing pass.
+#include "common.h"
+
+namespace nsamd {
+
+constexpr int kRenderThreads = 256;
+constexpr int kRaysPerBlock = kRenderThreads / 64;
+
+__device__ __forceinline__ uint32_t float_key(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__global__ void minmax_init_kernel(uint32_t* ws) {
+  ws[0] = float_key(__uint_as_float(0x7f800000u));  // +inf (running min)
+  ws[1] = float_key(__uint_as_float(0xff800000u));  // -inf (running max)
+}
+
+__global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
+    const float* __restrict__ rgb, const float* __restrict__ weights, const float* __restrict__ t_bins,
+    int64_t num_rays, int S, int background, float bg_r, float bg_g, float bg_b, int eval_mode,
+    float* __restrict__ rgb_out, float* __restrict__ acc_out, float* __restrict__ depth_exp,
+    float* __restrict__ depth_med, int32_t* __restrict__ med_idx, uint32_t* __restrict__ ws) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wave;
+  if (ray >= num_rays) return;
+  float* wrow = lds + wave * S;
+  const float* w_in = weights + ray * S;
+  const float* tb = t_bins ? t_bins + ray * (S + 1) : nullptr;
+  float sw = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f;
+  float tmin = __uint_as_float(0x7f800000u), tmax = __uint_as_float(0xff800000u);
+  for (int s = lane; s < S; s += 64) {
+    const float w = w_in[s];
+    wrow[s] = w;
+    sw += w;
+    if (rgb) {
+      const float* c = rgb + (ray * S + s) * 3;
+      float r = c[0], g = c[1], b = c[2];
+      if (eval_mode) { r = nan_to_num(r); g = nan_to_num(g); b = nan_to_num(b); }
+      sr += w * r;
+      sg += w * g;
+      sb += w * b;
+    }
+    if (tb) {
+      const float step = (tb[s] + tb[s + 1]) / 2.0f;
+      sd += w * step;
+      tmin = fminf(tmin, step);
+      tmax = fmaxf(tmax, step);
+    }
+  }
+  sw = wave_sum(sw);
+  if (rgb && rgb_out) {
+    sr = wave_sum(sr);
+    sg = wave_sum(sg);
+    sb = wave_sum(sb);
+    if (lane == 0) {
+      float br = 0.f, bgc = 0.f, bb = 0.f;
+      bool blend = false;
+      if (background == 1) {  // "last_sample"  (renderers.py:112-114)
+        const float* c = rgb + (ray * S + (S - 1)) * 3;
+        br = c[0]; bgc = c[1]; bb = c[2];
+        if (eval_mode) { br = nan_to_num(br); bgc = nan_to_num(bgc); bb = nan_to_num(bb); }
+        blend = true;
+      } else if (background == 2) {
+        br = bg_r; bgc = bg_g; bb = bg_b;
+        blend = true;
+      }
+      if (blend) {
+        const float rem = 1.0f - sw;
+        sr = sr + br * rem;
+        sg = sg + bgc * rem;
+        sb = sb + bb * rem;
+      }
+      if (eval_mode) {
+        sr = fminf(fmaxf(sr, 0.f), 1.f);
+        sg = fminf(fmaxf(sg, 0.f), 1.f);
+        sb = fminf(fmaxf(sb, 0.f), 1.f);
+      }
+      rgb_out[ray * 3 + 0] = sr;
+      rgb_out[ray * 3 + 1] = sg;
+      rgb_out[ray * 3 + 2] = sb;
+    }
+  }
+  if (acc_out && lane == 0) acc_out[ray] = sw;
+  if (tb && depth_exp) {
+    sd = wave_sum(sd);
+    tmin = wave_min(tmin);
+    tmax = wave_max(tmax);
+    if (lane == 0) {
+      depth_exp[ray] = sd / (sw + 1e-10f);  // clipped by the finishing pass
+      atomicMin(ws + 0, float_key(tmin));
+      atomicMax(ws + 1, float_key(tmax));
+    }
+  }
+  if (tb && (depth_med || med_idx)) {
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {  // searchsorted(cumsum(w), 0.5, side="left"), clamped  (renderers.py:359-362)
+      float run = 0.0f;
+      int idx = S;
+      for (int s = 0; s < S; ++s) {
+        run = run + wrow[s];
+        if (run >= 0.5f) { idx = s; break; }
+      }
+      idx = min(idx, S - 1);
+      if (med_idx) med_idx[ray] = idx;
+      if (depth_med) depth_med[ray] = (tb[idx] + tb[idx + 1]) / 2.0f;
+    }
+  }
+}
+
+__global__ void depth_clip_kernel(float* __restrict__ depth, int64_t n, const uint32_t* __restrict__ ws) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float lo = key_float(ws[0]), hi = key_float(ws[1]);
+  depth[i] = fminf(fmaxf(depth[i], lo), hi);  // torch.clip(depth, steps.min(), steps.max())
+}
+
+__global__ __launch_bounds__(kRenderThreads) void composite_bwd_kernel(
+    const float* __restrict__ rgb, const float* __restrict__ weights, const float* __restrict__ t_bins,
+    int64_t num_rays, int S, int background, float bg_r, float bg_g, float bg_b,
+    const float* __restrict__ d_rgb_out, const float* __restrict__ d_acc, const float* __restrict__ d_depth,
+    const uint32_t* __restrict__ ws, float* __restrict__ d_rgb, float* __restrict__ d_weights) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wave;
+  if (ray >= num_rays) return;
+  const float* w_in = weights + ray * S;
+  const float* tb = (d_depth && t_bins) ? t_bins + ray * (S + 1) : nullptr;
+  float sw = 0.f, sd = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float w = w_in[s];
+    sw += w;
+    if (tb) sd += w * ((tb[s] + tb[s + 1]) / 2.0f);
+  }
+  sw = wave_sum(sw);
+  sd = wave_sum(sd);
+  const float gr = d_rgb_out ? d_rgb_out[ray * 3 + 0] : 0.f;
+  const float gg = d_rgb_out ? d_rgb_out[ray * 3 + 1] : 0.f;
+  const float gb = d_rgb_out ? d_rgb_out[ray * 3 + 2] : 0.f;
+  const float ga = d_acc ? d_acc[ray] : 0.f;
+  float br = 0.f, bgc = 0.f, bb = 0.f;
+  if (background == 1) {
+    const float* c = rgb + (ray * S + (S - 1)) * 3;
+    br = c[0]; bgc = c[1]; bb = c[2];
+  } else if (background == 2) {
+    br = bg_r; bgc = bg_g; bb = bg_b;
+  }
+  // expected depth = clip(num / (den + eps)); clip passes gradient inside [lo, hi] (inclusive)
+  float g_num = 0.f, g_den = 0.f;
+  if (tb) {
+    const float den = sw + 1e-10f;
+    const float raw = sd / den;
+    const float lo = key_float(ws[0]), hi = key_float(ws[1]);
+    const float gd = (raw >= lo && raw <= hi) ? d_depth[ray] : 0.f;
+    g_num = gd / den;
+    g_den = -gd * sd / (den * den);
+  }
+  const float bg_dot = gr * br + gg * bgc + gb * bb;  // d comp / d acc = -bg
+  const float rem = 1.0f - sw;
+  for (int s = lane; s < S; s += 64) {
+    const float* c = rgb + (ray * S + s) * 3;
+    const float w = w_in[s];
+    float dw = gr * c[0] + gg * c[1] + gb * c[2] - bg_dot + ga + g_den;
+    if (tb) dw += g_num * ((tb[s] + tb[s + 1]) / 2.0f);
+    d_weights[ray * S + s] = dw;
+    float* o = d_rgb + (ray * S + s) * 3;
+    float e = w;
+    if (background == 1 && s == S - 1) e += rem;
+    o[0] = gr * e;
+    o[1] = gg * e;
+    o[2] = gb * e;
+  }
+}
+
+}  // namespace nsamd
+
+using namespace nsamd;
+
+extern "C" int nsamd_composite_fwd(const float* rgb, const float* weights, const float* t_bins, int64_t num_rays,
+                                   int32_t S, int background, const float* bg_rgb_host, int eval_mode,
+                                   float* rgb_out, float* acc, float* depth_expected, float* depth_median,
+                                   int32_t* median_idx, float* workspace, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && S > 0);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(weights != nullptr);
+  NSAMD_REQUIRE(background >= 0 && background <= 2);
+  NSAMD_REQUIRE(rgb_out == nullptr || rgb != nullptr);
+  NSAMD_REQUIRE(background != 2 || bg_rgb_host != nullptr);
+  const bool need_t = depth_expected || depth_median || median_idx;
+  NSAMD_REQUIRE(!need_t || t_bins != nullptr);
+  NSAMD_REQUIRE(depth_expected == nullptr || workspace != nullptr);
+  if (S > 4096) return NSAMD_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
+  if (depth_expected) {
+    minmax_init_kernel<<<1, 1, 0, st>>>(ws);
+    NSAMD_CHECK_LAUNCH();
+  }
+  const unsigned blocks = (unsigned)((num_rays + kRaysPerBlock - 1) / kRaysPerBlock);
+  const float br = bg_rgb_host ? bg_rgb_host[0] : 0.f, bg = bg_rgb_host ? bg_rgb_host[1] : 0.f,
+              bb = bg_rgb_host ? bg_rgb_host[2] : 0.f;
+  composite_fwd_kernel<<<blocks, kRenderThreads, sizeof(float) * kRaysPerBlock * S, st>>>(
+      rgb, weights, need_t ? t_bins : nullptr, num_rays, S, background, br, bg, bb, eval_mode, rgb_out, acc,
+      depth_expected, depth_median, median_idx, ws);
+  NSAMD_CHECK_LAUNCH();
+  if (depth_expected) {
+    depth_clip_kernel<<<(unsigned)((num_rays + 255) / 256), 256, 0, st>>>(depth_expected, num_rays, ws);
+    NSAMD_CHECK_LAUNCH();
+  }
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_composite_bwd(const float* rgb, const float* weights, const float* t_bins, int64_t num_rays,
+                                   int32_t S, int background, const float* bg_rgb_host, const float* d_rgb_out,
+                                   const float* d_acc, const float* d_depth, const float* workspace, float* d_rgb,
+                                   float* d_weights, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && S > 0);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(rgb && weights && d_rgb && d_weights);
+  NSAMD_REQUIRE(background >= 0 && background <= 2);
+  NSAMD_REQUIRE(background != 2 || bg_rgb_host != nullptr);
+  NSAMD_REQUIRE(d_depth == nullptr || (t_bins != nullptr && workspace != nullptr));
+  const unsigned blocks = (unsigned)((num_rays + kRaysPerBlock - 1) / kRaysPerBlock);
+  const float br = bg_rgb_host ? bg_rgb_host[0] : 0.f, bg = bg_rgb_host ? bg_rgb_host[1] : 0.f,
+              bb = bg_rgb_host ? bg_rgb_host[2] : 0.f;
+  composite_bwd_kernel<<<blocks, kRenderThreads, 0, (hipStream_t)stream>>>(
+      rgb, weights, t_bins, num_rays, S, background, br, bg, bb, d_rgb_out, d_acc, d_depth,
+      reinterpret_cast<const uint32_t*>(workspace), d_rgb, d_weights);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}

@@ -1,0 +1,112 @@
+"""MLP containers (reference: nerfstudio/field_components/mlp.py — MLP :61-184, MLPWithHashEncoding :187-295).
+
+The parameters are plain `nn.Linear` weights/biases under the reference's names (`layers.{i}.weight`), so
+`state_dict`s interchange with the torch path. The arithmetic of the nerfacto shapes runs in the fused field kernels
+(csrc/density_mlp.hip for the proposal heads, csrc/field_mlp.hip on MFMA for the main field), which read these
+tensors in place; the fields call them, not `MLP.forward`.
+"""
+from typing import Literal, Optional, Set, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from .base_field_component import FieldComponent, check_implementation
+from .encodings import HashEncoding
+
+
+class MLP(FieldComponent):
+    def __init__(
+        self,
+        in_dim: int,
+        num_layers: int,
+        layer_width: int,
+        out_dim: Optional[int] = None,
+        skip_connections: Optional[Tuple[int]] = None,
+        activation: Optional[nn.Module] = nn.ReLU(),
+        out_activation: Optional[nn.Module] = None,
+        implementation: Literal["hip"] = "hip",
+    ) -> None:
+        super().__init__()
+        check_implementation(implementation, "MLP")
+        self.in_dim = in_dim
+        assert self.in_dim > 0
+        self.out_dim = out_dim if out_dim is not None else layer_width
+        self.num_layers = num_layers
+        self.layer_width = layer_width
+        self.skip_connections = skip_connections
+        self._skip_connections: Set[int] = set(skip_connections) if skip_connections else set()
+        if self._skip_connections:
+            raise ValueError("nerfstudio_amd MLPs have no skip connections (none on the nerfacto path)")
+        if activation is not None and not isinstance(activation, nn.ReLU):
+            raise ValueError("nerfstudio_amd MLPs use ReLU hidden activations (the nerfacto configuration)")
+        if out_activation is not None and not isinstance(out_activation, nn.Sigmoid):
+            raise ValueError("nerfstudio_amd MLPs support out_activation None or Sigmoid")
+        self.activation = activation
+        self.out_activation = out_activation
+        self.build_nn_modules()
+
+    def build_nn_modules(self) -> None:
+        layers = []
+        if self.num_layers == 1:
+            layers.append(nn.Linear(self.in_dim, self.out_dim))
+        else:
+            for i in range(self.num_layers - 1):
+                layers.append(nn.Linear(self.in_dim if i == 0 else self.layer_width, self.layer_width))
+            layers.append(nn.Linear(self.layer_width, self.out_dim))
+        self.layers = nn.ModuleList(layers)
+
+    def param_tensors(self):
+        """[W0, b0, W1, b1, ...] in layer order — what the fused kernels bind."""
+        out = []
+        for layer in self.layers:
+            out += [layer.weight, layer.bias]
+        return out
+
+    def forward(self, in_tensor: Tensor) -> Tensor:
+        raise NotImplementedError(
+            "nerfstudio_amd.MLP is evaluated inside the fused HIP field kernels (HashMLPDensityField / NerfactoField); "
+            "a stand-alone generic-shape MLP kernel is not part of this build. There is no torch fallback."
+        )
+
+
+class MLPWithHashEncoding(FieldComponent):
+    """Hash encoding + MLP (mlp.py:187-295); `model = Sequential(HashEncoding, MLP)` keeps the reference's
+    state-dict names `model.0.hash_table`, `model.1.layers.{i}.*`."""
+
+    def __init__(
+        self,
+        num_levels: int = 16,
+        min_res: int = 16,
+        max_res: int = 1024,
+        log2_hashmap_size: int = 19,
+        features_per_level: int = 2,
+        hash_init_scale: float = 0.001,
+        interpolation: Optional[Literal["Nearest", "Linear", "Smoothstep"]] = None,
+        num_layers: int = 2,
+        layer_width: int = 64,
+        out_dim: Optional[int] = None,
+        skip_connections: Optional[Tuple[int]] = None,
+        activation: Optional[nn.Module] = nn.ReLU(),
+        out_activation: Optional[nn.Module] = None,
+        implementation: Literal["hip"] = "hip",
+    ) -> None:
+        super().__init__()
+        check_implementation(implementation, "MLPWithHashEncoding")
+        self.in_dim = 3
+        self.out_dim = out_dim if out_dim is not None else layer_width
+        encoder = HashEncoding(num_levels, min_res, max_res, log2_hashmap_size, features_per_level, hash_init_scale,
+                               implementation, interpolation)
+        mlp = MLP(encoder.get_out_dim(), num_layers, layer_width, self.out_dim, skip_connections, activation,
+                  out_activation, implementation)
+        self.model = torch.nn.Sequential(encoder, mlp)
+
+    @property
+    def encoding(self) -> HashEncoding:
+        return self.model[0]
+
+    @property
+    def mlp(self) -> MLP:
+        return self.model[1]
+
+    def forward(self, in_tensor: Tensor) -> Tensor:
+        return self.model[1](self.model[0](in_tensor))

@@ -1,0 +1,87 @@
+"""Proposal network field (reference: nerfstudio/fields/density_fields.py:33-120)."""
+from typing import Literal, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from .. import _native as N
+from .. import functional as F
+from ..cameras.rays import RaySamples
+from ..field_components.base_field_component import check_implementation
+from ..field_components.encodings import HashEncoding
+from ..field_components.mlp import MLP
+from ..field_components.spatial_distortions import SceneContraction, SpatialDistortion
+from .base_field import Field, point_spec
+
+
+def transform_of(spatial_distortion: Optional[SpatialDistortion]) -> int:
+    if spatial_distortion is None:
+        return N.XFORM_AABB
+    if isinstance(spatial_distortion, SceneContraction):
+        return N.XFORM_CONTRACT
+    raise ValueError("the hip fields support spatial_distortion None (aabb normalisation) or SceneContraction(inf)")
+
+
+class HashMLPDensityField(Field):
+    """A lightweight density field: scene contraction -> hash grid -> MLP -> trunc_exp, one fused gfx950 pipeline
+    (csrc/hashgrid.hip + csrc/density_mlp.hip). Arguments as the reference (density_fields.py:46-61)."""
+
+    aabb: Tensor
+
+    def __init__(
+        self,
+        aabb: Tensor,
+        num_layers: int = 2,
+        hidden_dim: int = 64,
+        spatial_distortion: Optional[SpatialDistortion] = None,
+        use_linear: bool = False,
+        num_levels: int = 8,
+        max_res: int = 1024,
+        base_res: int = 16,
+        log2_hashmap_size: int = 18,
+        features_per_level: int = 2,
+        average_init_density: float = 1.0,
+        implementation: Literal["hip"] = "hip",
+    ) -> None:
+        super().__init__()
+        check_implementation(implementation, "HashMLPDensityField")
+        if use_linear:
+            raise ValueError("HashMLPDensityField(use_linear=True) is not built for the hip backend")
+        if num_layers != 2:
+            raise ValueError("the hip density head is MLP(num_layers=2): in -> hidden -> 1")
+        self.register_buffer("aabb", aabb)
+        self.spatial_distortion = spatial_distortion
+        self.use_linear = use_linear
+        self.average_init_density = average_init_density
+        self.register_buffer("max_res", torch.tensor(max_res))
+        self.register_buffer("num_levels", torch.tensor(num_levels))
+        self.register_buffer("log2_hashmap_size", torch.tensor(log2_hashmap_size))
+        self.encoding = HashEncoding(
+            num_levels=num_levels,
+            min_res=base_res,
+            max_res=max_res,
+            log2_hashmap_size=log2_hashmap_size,
+            features_per_level=features_per_level,
+            implementation=implementation,
+        )
+        network = MLP(
+            in_dim=self.encoding.get_out_dim(),
+            num_layers=num_layers,
+            layer_width=hidden_dim,
+            out_dim=1,
+            activation=nn.ReLU(),
+            out_activation=None,
+            implementation=implementation,
+        )
+        self.mlp_base = torch.nn.Sequential(self.encoding, network)
+        self._transform = transform_of(spatial_distortion)
+
+    def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, None]:
+        spec, shape = point_spec(ray_samples)
+        mlp: MLP = self.mlp_base[1]
+        density = F.density_field(spec, self.encoding.hash_table, *mlp.param_tensors(), self.encoding.spec,
+                                  self._transform, self.aabb, self.average_init_density)
+        return density.view(*shape, 1), None
+
+    def get_outputs(self, ray_samples: RaySamples, density_embedding: Optional[Tensor] = None) -> dict:
+        return {}

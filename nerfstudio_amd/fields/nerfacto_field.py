@@ -1,0 +1,148 @@
+"""nerfacto main field (reference: nerfstudio/fields/nerfacto_field.py:42-310)."""
+from typing import Dict, Literal, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from .. import functional as F
+from ..cameras.rays import RaySamples
+from ..field_components.base_field_component import check_implementation
+from ..field_components.embedding import Embedding
+from ..field_components.encodings import SHEncoding
+from ..field_components.field_heads import FieldHeadNames
+from ..field_components.mlp import MLP, MLPWithHashEncoding
+from ..field_components.spatial_distortions import SpatialDistortion
+from .base_field import Field, point_spec
+from .density_fields import transform_of
+
+
+class NerfactoField(Field):
+    """Compound field: hash grid + base MLP (density, geo features) and SH + appearance embedding + colour MLP.
+
+    Arguments as the reference (nerfacto_field.py:72-98). The hip backend builds the nerfacto shape
+    (hidden_dim = hidden_dim_color = 64, geo_feat_dim = 15, num_levels*features = 32, num_layers 2 / 3,
+    appearance_embedding_dim 32 or 0); the transient / semantic / normal heads belong to other methods.
+
+    `get_density` + `get_outputs` are ONE pipeline on the GPU (hash encode -> MFMA MLP chain), so `get_density`
+    evaluates both and hands rgb to `get_outputs` through the density embedding slot.
+    """
+
+    aabb: Tensor
+
+    def __init__(
+        self,
+        aabb: Tensor,
+        num_images: int,
+        num_layers: int = 2,
+        hidden_dim: int = 64,
+        geo_feat_dim: int = 15,
+        num_levels: int = 16,
+        base_res: int = 16,
+        max_res: int = 2048,
+        log2_hashmap_size: int = 19,
+        num_layers_color: int = 3,
+        num_layers_transient: int = 2,
+        features_per_level: int = 2,
+        hidden_dim_color: int = 64,
+        hidden_dim_transient: int = 64,
+        appearance_embedding_dim: int = 32,
+        transient_embedding_dim: int = 16,
+        use_transient_embedding: bool = False,
+        use_semantics: bool = False,
+        num_semantic_classes: int = 100,
+        pass_semantic_gradients: bool = False,
+        use_pred_normals: bool = False,
+        use_average_appearance_embedding: bool = False,
+        spatial_distortion: Optional[SpatialDistortion] = None,
+        average_init_density: float = 1.0,
+        implementation: Literal["hip"] = "hip",
+    ) -> None:
+        super().__init__()
+        check_implementation(implementation, "NerfactoField")
+        if use_transient_embedding or use_semantics or use_pred_normals:
+            raise ValueError("transient / semantic / predicted-normal heads are not part of the hip nerfacto field")
+        if (hidden_dim, hidden_dim_color, geo_feat_dim, num_layers, num_layers_color) != (64, 64, 15, 2, 3) or \
+                num_levels * features_per_level != 32 or appearance_embedding_dim not in (0, 32):
+            raise ValueError(
+                "the hip NerfactoField is built for hidden_dim=64, hidden_dim_color=64, geo_feat_dim=15, num_layers=2, "
+                "num_layers_color=3, num_levels*features_per_level=32, appearance_embedding_dim in {0, 32}")
+        self.register_buffer("aabb", aabb)
+        self.geo_feat_dim = geo_feat_dim
+        self.register_buffer("max_res", torch.tensor(max_res))
+        self.register_buffer("num_levels", torch.tensor(num_levels))
+        self.register_buffer("log2_hashmap_size", torch.tensor(log2_hashmap_size))
+        self.spatial_distortion = spatial_distortion
+        self.num_images = num_images
+        self.appearance_embedding_dim = appearance_embedding_dim
+        self.embedding_appearance = Embedding(num_images, appearance_embedding_dim) if appearance_embedding_dim > 0 else None
+        self.use_average_appearance_embedding = use_average_appearance_embedding
+        self.use_transient_embedding = use_transient_embedding
+        self.use_semantics = use_semantics
+        self.use_pred_normals = use_pred_normals
+        self.base_res = base_res
+        self.average_init_density = average_init_density
+        self.step = 0
+        self.direction_encoding = SHEncoding(levels=4, implementation=implementation)
+        self.mlp_base = MLPWithHashEncoding(
+            num_levels=num_levels,
+            min_res=base_res,
+            max_res=max_res,
+            log2_hashmap_size=log2_hashmap_size,
+            features_per_level=features_per_level,
+            num_layers=num_layers,
+            layer_width=hidden_dim,
+            out_dim=1 + self.geo_feat_dim,
+            activation=nn.ReLU(),
+            out_activation=None,
+            implementation=implementation,
+        )
+        self.mlp_head = MLP(
+            in_dim=self.direction_encoding.get_out_dim() + self.geo_feat_dim + self.appearance_embedding_dim,
+            num_layers=num_layers_color,
+            layer_width=hidden_dim_color,
+            out_dim=3,
+            activation=nn.ReLU(),
+            out_activation=nn.Sigmoid(),
+            implementation=implementation,
+        )
+        self._transform = transform_of(spatial_distortion)
+
+    # -----------------------------------------------------------------------------------------------------------
+    def _evaluate(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
+        if ray_samples.camera_indices is None:
+            raise AttributeError("Camera indices are not provided.")
+        spec, shape = point_spec(ray_samples)
+        fr = ray_samples.frustums
+        if spec.ray_mode:
+            view_dirs = ray_samples.pack.directions
+            dir_group = spec.samples_per_ray
+            cams = ray_samples.camera_indices.reshape(view_dirs.shape[0], -1)[:, 0]
+        else:
+            view_dirs = fr.directions.expand(*shape, 3).reshape(-1, 3)
+            dir_group = 1
+            cams = ray_samples.camera_indices.expand(*shape, 1).reshape(-1)
+        emb = self.embedding_appearance.embedding.weight if self.embedding_appearance is not None else None
+        app_const = None
+        if emb is not None and not self.training:
+            # nerfacto_field.py:253-261: eval uses the mean embedding (or zeros) for every sample
+            cams = None
+            with torch.no_grad():
+                app_const = emb.mean(dim=0) if self.use_average_appearance_embedding else torch.zeros_like(emb[0])
+            app_const = app_const.contiguous()
+        if emb is None:
+            cams = None
+        enc = self.mlp_base.encoding
+        density, rgb = F.nerfacto_field(
+            spec, enc.hash_table, self.mlp_base.mlp.param_tensors(), self.mlp_head.param_tensors(), emb, view_dirs, cams,
+            app_const, dir_group, enc.spec, self._transform, self.aabb, self.average_init_density)
+        return density.view(*shape, 1), rgb.view(*shape, 3)
+
+    def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
+        """Densities `[*bs,1]`; the second value carries the rgb already evaluated by the fused pipeline."""
+        density, rgb = self._evaluate(ray_samples)
+        return density, rgb
+
+    def get_outputs(self, ray_samples: RaySamples, density_embedding: Optional[Tensor] = None
+                    ) -> Dict[FieldHeadNames, Tensor]:
+        assert density_embedding is not None
+        return {FieldHeadNames.RGB: density_embedding}

@@ -1,0 +1,614 @@
+"""torch.autograd glue over the nsamd C ABI (include/nsamd.h).
+
+Each public function here is one stage of the nerfacto hot path running as hand-written gfx950
+kernels. PyTorch only provides device memory, the stream and the autograd graph — no arithmetic of the path is done
+by torch ops. Reference citations are relative to /root/reference/nerfstudio/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _native as N
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configuration records
+# ---------------------------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class HashGridSpec:
+    """Hyper-parameters of one multiresolution hash grid (HashEncoding ctor, field_components/encodings.py:321-347)."""
+
+    num_levels: int
+    min_res: int
+    max_res: int
+    log2_hashmap_size: int
+    features_per_level: int = 2
+
+    def __post_init__(self):
+        if self.features_per_level != 2:
+            raise ValueError("nerfstudio_amd hash grids are built for features_per_level=2 (every nerfacto config)")
+        if not (0 < self.num_levels <= N.MAX_LEVELS):
+            raise ValueError(f"num_levels must be in [1, {N.MAX_LEVELS}]")
+
+    @property
+    def table_size(self) -> int:
+        return 2**self.log2_hashmap_size
+
+    @property
+    def out_dim(self) -> int:
+        return self.num_levels * self.features_per_level
+
+    @property
+    def growth_factor(self) -> float:
+        if self.num_levels > 1:
+            return math.exp((math.log(self.max_res) - math.log(self.min_res)) / (self.num_levels - 1))
+        return 1.0
+
+    def scalings(self) -> Tensor:
+        """floor(min_res * growth**level) evaluated in fp32 on the host, exactly like encodings.py:342-344 (where
+        `np.float64 ** LongTensor` dispatches to torch's __rpow__ and yields fp32)."""
+        levels = torch.arange(self.num_levels)
+        return torch.floor(self.min_res * self.growth_factor**levels).to(torch.float32)
+
+    def native(self) -> N.Grid:
+        return N.make_grid(self.num_levels, self.log2_hashmap_size, self.scalings().tolist())
+
+
+@dataclass
+class PointSpec:
+    """Sample points either as explicit `[M,3]` positions or as rays + bin edges (never materialised)."""
+
+    positions: Optional[Tensor] = None
+    origins: Optional[Tensor] = None
+    directions: Optional[Tensor] = None
+    t_bins: Optional[Tensor] = None
+
+    @property
+    def ray_mode(self) -> bool:
+        return self.positions is None
+
+    @property
+    def num_points(self) -> int:
+        if self.positions is not None:
+            return self.positions.shape[0]
+        return self.t_bins.shape[0] * (self.t_bins.shape[1] - 1)
+
+    @property
+    def samples_per_ray(self) -> int:
+        return 0 if self.positions is not None else self.t_bins.shape[1] - 1
+
+    def tensors(self) -> Tuple[Optional[Tensor], ...]:
+        return (self.positions, self.origins, self.directions, self.t_bins)
+
+    def native(self) -> N.Points:
+        N.require_cuda(*self.tensors())
+        return N.make_points(self.positions, self.origins, self.directions, self.t_bins, self.samples_per_ray)
+
+    def needs_position_grad(self) -> bool:
+        if self.positions is not None:
+            return self.positions.requires_grad
+        return bool(self.origins.requires_grad or self.directions.requires_grad)
+
+
+def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _spec_from_flat(positions, origins, directions, t_bins) -> PointSpec:
+    return PointSpec(_f32c(positions), _f32c(origins), _f32c(directions), _f32c(t_bins))
+
+
+def _position_grads(spec: PointSpec, dpos: Tensor):
+    """dL/dpositions [M,3] -> gradients of whatever the spec was built from."""
+    if not spec.ray_mode:
+        return dpos, None, None
+    n, s1 = spec.t_bins.shape
+    d = dpos.view(n, s1 - 1, 3)
+    mid = ((spec.t_bins[:, :-1] + spec.t_bins[:, 1:]) / 2)[..., None]
+    return None, d.sum(dim=1), (d * mid).sum(dim=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a8  stand-alone hash encoding (Encoding API: [M,3] in [0,1] -> [M, 2L])
+# ---------------------------------------------------------------------------------------------------------------
+class _HashEncodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, table: Tensor, grid: HashGridSpec):
+        N.require_cuda(x, table)
+        x = _f32c(x)
+        M = x.shape[0]
+        out = torch.empty((M, grid.out_dim), device=x.device, dtype=torch.float32)
+        pts = N.make_points(positions=x)
+        N.check(
+            N.load().nsamd_hashgrid_encode_fwd(pts, M, N.XFORM_NONE, N.Aabb(), N.ptr(table), grid.native(), N.ptr(out),
+                                              grid.out_dim, 1, None, N.stream()),
+            "hashgrid_encode_fwd",
+        )
+        ctx.save_for_backward(x, table)
+        ctx.grid = grid
+        return out
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        x, table = ctx.saved_tensors
+        grid: HashGridSpec = ctx.grid
+        gout = _f32c(gout)
+        M = x.shape[0]
+        dtable = torch.zeros_like(table) if ctx.needs_input_grad[1] else None
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        if dtable is not None or dx is not None:
+            pts = N.make_points(positions=x)
+            N.check(
+                N.load().nsamd_hashgrid_encode_bwd(pts, M, N.XFORM_NONE, N.Aabb(), N.ptr(table), grid.native(),
+                                                  N.ptr(gout), grid.out_dim, 1, N.ptr(dtable), N.ptr(dx), N.stream()),
+                "hashgrid_encode_bwd",
+            )
+        return dx, dtable, None
+
+
+def hashgrid_encode(x: Tensor, table: Tensor, grid: HashGridSpec) -> Tensor:
+    """HashEncoding.pytorch_fwd semantics (encodings.py:417-458) on `[*bs,3]` -> `[*bs, 2L]`."""
+    shape = x.shape[:-1]
+    return _HashEncodeFn.apply(x.reshape(-1, 3), table, grid).view(*shape, grid.out_dim)
+
+
+def sh4_encode(directions: Tensor) -> Tensor:
+    """SHEncoding(levels=4).pytorch_fwd (encodings.py:791-794); no gradient (it is @torch.no_grad there)."""
+    N.require_cuda(directions)
+    shape = directions.shape[:-1]
+    d = _f32c(directions.detach().reshape(-1, 3))
+    out = torch.empty((d.shape[0], 16), device=d.device, dtype=torch.float32)
+    N.check(N.load().nsamd_sh4_encode(N.ptr(d), d.shape[0], N.ptr(out), N.stream()), "sh4_encode")
+    return out.view(*shape, 16)
+
+
+def contract_linf(x: Tensor) -> Tensor:
+    """SceneContraction(order=inf).forward (spatial_distortions.py:66-69), forward only (the fused fields carry
+    the Jacobian inside their own backward)."""
+    N.require_cuda(x)
+    shape = x.shape
+    xf = _f32c(x.detach().reshape(-1, 3))
+    out = torch.empty_like(xf)
+    N.check(N.load().nsamd_contract_linf(N.ptr(xf), xf.shape[0], N.ptr(out), N.stream()), "contract_linf")
+    return out.view(shape)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a6  proposal density field: contraction -> hash grid -> MLP -> trunc_exp           (fields/density_fields.py:94-117)
+# ---------------------------------------------------------------------------------------------------------------
+class _DensityFieldFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, positions, origins, directions, t_bins, table, W0, b0, W1, b1, grid: HashGridSpec,
+                transform: int, aabb, avg_density: float):
+        spec = _spec_from_flat(positions, origins, directions, t_bins)
+        N.require_cuda(table, W0, b0, W1, b1)
+        lib = N.load()
+        M = spec.num_points
+        dev = table.device
+        enc = torch.empty((grid.out_dim, M), device=dev, dtype=torch.float32)  # feature-major
+        sel = torch.empty((M,), device=dev, dtype=torch.float32)
+        g = grid.native()
+        box = N.make_aabb(aabb)
+        N.check(lib.nsamd_hashgrid_encode_fwd(spec.native(), M, transform, box, N.ptr(table), g, N.ptr(enc), 1, M,
+                                              N.ptr(sel), N.stream()), "hashgrid_encode_fwd")
+        mlp = N.DensityMlp(N.ptr(W0), N.ptr(b0), N.ptr(W1), N.ptr(b1), W0.shape[1], W0.shape[0], avg_density)
+        density = torch.empty((M,), device=dev, dtype=torch.float32)
+        pre = torch.empty((M,), device=dev, dtype=torch.float32)
+        N.check(lib.nsamd_density_mlp_fwd(N.ptr(enc), N.ptr(sel), M, mlp, N.ptr(density), N.ptr(pre), N.stream()),
+                "density_mlp_fwd")
+        ctx.spec, ctx.grid, ctx.transform, ctx.box, ctx.avg = spec, grid, transform, box, avg_density
+        ctx.save_for_backward(table, W0, b0, W1, b1, enc, sel, pre)
+        return density
+
+    @staticmethod
+    def backward(ctx, gdens: Tensor):
+        table, W0, b0, W1, b1, enc, sel, pre = ctx.saved_tensors
+        spec: PointSpec = ctx.spec
+        lib = N.load()
+        M = spec.num_points
+        gdens = _f32c(gdens)
+        denc = torch.empty_like(enc)
+        dW0, db0, dW1, db1 = (torch.zeros_like(t) for t in (W0, b0, W1, b1))
+        mlp = N.DensityMlp(N.ptr(W0), N.ptr(b0), N.ptr(W1), N.ptr(b1), W0.shape[1], W0.shape[0], ctx.avg)
+        N.check(lib.nsamd_density_mlp_bwd(N.ptr(enc), N.ptr(sel), N.ptr(pre), N.ptr(gdens), M, mlp, N.ptr(denc),
+                                          N.ptr(dW0), N.ptr(db0), N.ptr(dW1), N.ptr(db1), N.stream()),
+                "density_mlp_bwd")
+        need_pos = any(ctx.needs_input_grad[:3])
+        dtable = torch.zeros_like(table) if ctx.needs_input_grad[4] else None
+        dpos = torch.empty((M, 3), device=table.device, dtype=torch.float32) if need_pos else None
+        if dtable is not None or dpos is not None:
+            N.check(lib.nsamd_hashgrid_encode_bwd(spec.native(), M, ctx.transform, ctx.box, N.ptr(table),
+                                                  ctx.grid.native(), N.ptr(denc), 1, M, N.ptr(dtable), N.ptr(dpos),
+                                                  N.stream()), "hashgrid_encode_bwd")
+        gp, go, gd = _position_grads(spec, dpos) if dpos is not None else (None, None, None)
+        return gp, go, gd, None, dtable, dW0, db0, dW1, db1, None, None, None, None
+
+
+def density_field(spec: PointSpec, table: Tensor, W0: Tensor, b0: Tensor, W1: Tensor, b1: Tensor, grid: HashGridSpec,
+                  transform: int, aabb: Optional[Tensor], average_init_density: float) -> Tensor:
+    """HashMLPDensityField.get_density on M points -> density `[M]`."""
+    return _DensityFieldFn.apply(spec.positions, spec.origins, spec.directions, spec.t_bins, table, W0, b0, W1, b1,
+                                 grid, transform, aabb, float(average_init_density))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a10 + a12  nerfacto main field                                                   (fields/nerfacto_field.py:203-310)
+# ---------------------------------------------------------------------------------------------------------------
+class _NerfactoFieldFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, positions, origins, directions, t_bins, table, bW0, bb0, bW1, bb1, hW0, hb0, hW1, hb1, hW2, hb2,
+                appearance, view_dirs, camera_indices, appearance_const, dir_group: int, grid: HashGridSpec,
+                transform: int, aabb, avg_density: float):
+        spec = _spec_from_flat(positions, origins, directions, t_bins)
+        params = (bW0, bb0, bW1, bb1, hW0, hb0, hW1, hb1, hW2, hb2)
+        N.require_cuda(table, *params, view_dirs, appearance, camera_indices, appearance_const)
+        if tuple(bW0.shape) != (64, 32) or tuple(bW1.shape) != (16, 64) or tuple(hW1.shape) != (64, 64) or \
+                tuple(hW2.shape) != (3, 64) or hW0.shape[0] != 64 or hW0.shape[1] not in (31, 63):
+            raise RuntimeError(
+                "nsamd main-field kernels are built for the nerfacto shape: L=16,F=2 -> 64 -> 16, head 31|63 -> 64 -> 64 "
+                f"-> 3; got base {tuple(bW0.shape)}/{tuple(bW1.shape)}, head {tuple(hW0.shape)}/{tuple(hW1.shape)}/"
+                f"{tuple(hW2.shape)}")
+        lib = N.load()
+        M = spec.num_points
+        dev = table.device
+        view_dirs = _f32c(view_dirs)
+        cams = camera_indices.contiguous().to(torch.int64) if camera_indices is not None else None
+        enc = torch.empty((grid.out_dim, M), device=dev, dtype=torch.float32)
+        sel = torch.empty((M,), device=dev, dtype=torch.float32)
+        box = N.make_aabb(aabb)
+        N.check(lib.nsamd_hashgrid_encode_fwd(spec.native(), M, transform, box, N.ptr(table), grid.native(),
+                                              N.ptr(enc), 1, M, N.ptr(sel), N.stream()), "hashgrid_encode_fwd")
+        mlp = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(appearance),
+                         appearance.shape[0] if appearance is not None else 0, avg_density)
+        density = torch.empty((M,), device=dev, dtype=torch.float32)
+        rgb = torch.empty((M, 3), device=dev, dtype=torch.float32)
+        N.check(lib.nsamd_field_mlp_fwd(N.ptr(enc), N.ptr(sel), N.ptr(view_dirs), N.ptr(cams),
+                                        N.ptr(appearance_const), dir_group, M, mlp, N.ptr(density), N.ptr(rgb),
+                                        N.stream()), "field_mlp_fwd")
+        ctx.spec, ctx.grid, ctx.transform, ctx.box, ctx.avg, ctx.dir_group = spec, grid, transform, box, avg_density, dir_group
+        ctx.cams, ctx.app_const, ctx.has_app = cams, appearance_const, appearance is not None
+        ctx.save_for_backward(table, *params, appearance if appearance is not None else table.new_empty(0), enc, sel,
+                              view_dirs)
+        return density, rgb
+
+    @staticmethod
+    def backward(ctx, gdens: Tensor, grgb: Tensor):
+        saved = ctx.saved_tensors
+        table, params, appearance, enc, sel, view_dirs = saved[0], saved[1:11], saved[11], saved[12], saved[13], saved[14]
+        if not ctx.has_app:
+            appearance = None
+        spec: PointSpec = ctx.spec
+        lib = N.load()
+        M = spec.num_points
+        gdens = _f32c(gdens) if gdens is not None else torch.zeros((M,), device=table.device)
+        grgb = _f32c(grgb) if grgb is not None else torch.zeros((M, 3), device=table.device)
+        denc = torch.empty_like(enc)
+        gparams = [torch.zeros_like(p) for p in params]
+        gapp = torch.zeros_like(appearance) if (appearance is not None and ctx.cams is not None) else None
+        mlp = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(appearance),
+                         appearance.shape[0] if appearance is not None else 0, ctx.avg)
+        grads = N.FieldMlpGrads(*(N.ptr(g) for g in gparams), N.ptr(gapp))
+        N.check(lib.nsamd_field_mlp_bwd(N.ptr(enc), N.ptr(sel), N.ptr(view_dirs), N.ptr(ctx.cams),
+                                        N.ptr(ctx.app_const), ctx.dir_group, M, mlp, N.ptr(gdens), N.ptr(grgb),
+                                        N.ptr(denc), grads, N.stream()), "field_mlp_bwd")
+        need_pos = any(ctx.needs_input_grad[:3])
+        dtable = torch.zeros_like(table) if ctx.needs_input_grad[4] else None
+        dpos = torch.empty((M, 3), device=table.device, dtype=torch.float32) if need_pos else None
+        if dtable is not None or dpos is not None:
+            N.check(lib.nsamd_hashgrid_encode_bwd(spec.native(), M, ctx.transform, ctx.box, N.ptr(table),
+                                                  ctx.grid.native(), N.ptr(denc), 1, M, N.ptr(dtable), N.ptr(dpos),
+                                                  N.stream()), "hashgrid_encode_bwd")
+        gp, go, gd = _position_grads(spec, dpos) if dpos is not None else (None, None, None)
+        return (gp, go, gd, None, dtable, *gparams, gapp, None, None, None, None, None, None, None, None)
+
+
+def nerfacto_field(spec: PointSpec, table: Tensor, base_params: Sequence[Tensor], head_params: Sequence[Tensor],
+                   appearance: Optional[Tensor], view_dirs: Tensor, camera_indices: Optional[Tensor],
+                   appearance_const: Optional[Tensor], dir_group: int, grid: HashGridSpec, transform: int,
+                   aabb: Optional[Tensor], average_init_density: float) -> Tuple[Tensor, Tensor]:
+    """NerfactoField.forward on M points -> (density `[M]`, rgb `[M,3]`).
+
+    view_dirs `[num_dirs,3]` / camera_indices `[num_dirs]`: point p uses row p // dir_group.
+    camera_indices None -> every point uses `appearance_const` `[32]` (eval: mean or zeros, nerfacto_field.py:253-261);
+    both None -> the field has no appearance embedding.
+    """
+    return _NerfactoFieldFn.apply(spec.positions, spec.origins, spec.directions, spec.t_bins, table, *base_params,
+                                  *head_params, appearance, view_dirs, camera_indices, appearance_const, int(dir_group),
+                                  grid, transform, aabb, float(average_init_density))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a4 / a13 / a14  samplers
+# ---------------------------------------------------------------------------------------------------------------
+_LINSPACE_CACHE: dict = {}
+
+
+def _linspace(kind: str, num_samples: int, device) -> Tensor:
+    """Host-evaluated torch.linspace tables (so the fp32 values are bit-identical to the reference's CPU path)."""
+    key = (kind, num_samples, str(device))
+    t = _LINSPACE_CACHE.get(key)
+    if t is None:
+        if kind == "edges":  # ray_samplers.py:100
+            t = torch.linspace(0.0, 1.0, num_samples + 1)
+        else:  # "u": ray_samplers.py:317 / :326
+            nb = num_samples + 1
+            t = torch.linspace(0.0, 1.0 - (1.0 / nb), steps=nb)
+        t = t.to(device)
+        _LINSPACE_CACHE[key] = t
+    return t
+
+
+@torch.no_grad()
+def piecewise_bins(nears: Tensor, fars: Tensor, num_samples: int, jitter: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    """UniformLinDispPiecewiseSampler (ray_samplers.py:78-128, 225-248). nears/fars `[N]` or `[N,1]`;
+    jitter = the single-jitter U[0,1) draw per ray or None (eval). Returns (s_bins, t_bins) `[N, S+1]`."""
+    N.require_cuda(nears, fars, jitter)
+    nears, fars = _f32c(nears.reshape(-1)), _f32c(fars.reshape(-1))
+    jitter = _f32c(jitter.reshape(-1)) if jitter is not None else None
+    n = nears.shape[0]
+    s_bins = torch.empty((n, num_samples + 1), device=nears.device, dtype=torch.float32)
+    t_bins = torch.empty_like(s_bins)
+    edges = _linspace("edges", num_samples, nears.device)
+    N.check(N.load().nsamd_piecewise_bins(N.ptr(nears), N.ptr(fars), N.ptr(edges), N.ptr(jitter), n, num_samples,
+                                          N.ptr(s_bins), N.ptr(t_bins), N.stream()), "piecewise_bins")
+    return s_bins, t_bins
+
+
+class _WeightsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t_bins: Tensor, density: Tensor):
+        N.require_cuda(t_bins, density)
+        t_bins, density = _f32c(t_bins), _f32c(density)
+        n, s = density.shape
+        w = torch.empty_like(density)
+        N.check(N.load().nsamd_weights_fwd(N.ptr(t_bins), N.ptr(density), n, s, N.ptr(w), N.stream()), "weights_fwd")
+        ctx.save_for_backward(t_bins, density)
+        return w
+
+    @staticmethod
+    def backward(ctx, gw: Tensor):
+        t_bins, density = ctx.saved_tensors
+        n, s = density.shape
+        gw = _f32c(gw)
+        gd = torch.empty_like(density)
+        N.check(N.load().nsamd_weights_bwd(N.ptr(t_bins), N.ptr(density), N.ptr(gw), n, s, N.ptr(gd), N.stream()),
+                "weights_bwd")
+        return None, gd
+
+
+def weights_from_density(t_bins: Tensor, density: Tensor) -> Tensor:
+    """RaySamples.get_weights (cameras/rays.py:129-152): `[N,S+1]`, `[N,S]` -> `[N,S]`."""
+    return _WeightsFn.apply(t_bins, density)
+
+
+@torch.no_grad()
+def pdf_resample(s_bins_prev: Tensor, weights: Tensor, num_samples: int, jitter: Optional[Tensor], nears: Tensor,
+                 fars: Tensor, anneal: float = 1.0, histogram_padding: float = 0.01, eps: float = 1e-5,
+                 return_indices: bool = False):
+    """PDFSampler.generate_ray_samples(include_original=False) (ray_samplers.py:276-372) incl. the weight anneal
+    (ray_samplers.py:601). Returns (s_bins, t_bins[, inds]) with `[N, S+1]` each; inds int32."""
+    N.require_cuda(s_bins_prev, weights, nears, fars, jitter)
+    s_bins_prev, weights = _f32c(s_bins_prev), _f32c(weights.detach())
+    nears, fars = _f32c(nears.reshape(-1)), _f32c(fars.reshape(-1))
+    jitter = _f32c(jitter.reshape(-1)) if jitter is not None else None
+    n, s_prev = weights.shape
+    nb = num_samples + 1
+    dev = weights.device
+    s_bins = torch.empty((n, nb), device=dev, dtype=torch.float32)
+    t_bins = torch.empty_like(s_bins)
+    inds = torch.empty((n, nb), device=dev, dtype=torch.int32) if return_indices else None
+    u_base = _linspace("u", num_samples, dev)
+    N.check(N.load().nsamd_pdf_resample(N.ptr(s_bins_prev), N.ptr(weights), s_prev, N.ptr(u_base), N.ptr(jitter),
+                                        N.ptr(nears), N.ptr(fars), float(anneal), float(histogram_padding), float(eps),
+                                        1.0 / (2 * nb), n, num_samples, N.ptr(s_bins), N.ptr(t_bins), N.ptr(inds),
+                                        N.stream()), "pdf_resample")
+    return (s_bins, t_bins, inds) if return_indices else (s_bins, t_bins)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a16-a18  compositing
+# ---------------------------------------------------------------------------------------------------------------
+def _bg_args(background, device):
+    """-> (mode, ctypes float[3] or None)."""
+    if background is None or (isinstance(background, str) and background in ("random", "none")):
+        return N.BG_NONE, None
+    if isinstance(background, str):
+        if background == "last_sample":
+            return N.BG_LAST_SAMPLE, None
+        named = {"white": (1.0, 1.0, 1.0), "black": (0.0, 0.0, 0.0)}
+        if background not in named:
+            raise ValueError(f"unsupported background colour {background!r}")
+        vals = named[background]
+    else:
+        vals = [float(v) for v in torch.as_tensor(background).reshape(3).tolist()]
+    return N.BG_CONSTANT, (C.c_float * 3)(*vals)
+
+
+class _CompositeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb: Tensor, weights: Tensor, t_bins: Optional[Tensor], bg_mode: int, bg_vals, want_depth: bool):
+        N.require_cuda(rgb, weights, t_bins)
+        rgb, weights = _f32c(rgb), _f32c(weights)
+        t_bins = _f32c(t_bins) if t_bins is not None else None
+        n, s = weights.shape
+        dev = weights.device
+        out = torch.empty((n, 3), device=dev, dtype=torch.float32)
+        acc = torch.empty((n,), device=dev, dtype=torch.float32)
+        depth = torch.empty((n,), device=dev, dtype=torch.float32) if want_depth else None
+        ws = torch.empty((2,), device=dev, dtype=torch.float32) if want_depth else None
+        N.check(N.load().nsamd_composite_fwd(N.ptr(rgb), N.ptr(weights), N.ptr(t_bins) if want_depth else None, n, s,
+                                             bg_mode, bg_vals, 0, N.ptr(out), N.ptr(acc), N.ptr(depth), None, None,
+                                             N.ptr(ws), N.stream()), "composite_fwd")
+        ctx.save_for_backward(rgb, weights, t_bins if want_depth else None, ws)
+        ctx.bg_mode, ctx.bg_vals, ctx.want_depth = bg_mode, bg_vals, want_depth
+        if want_depth:
+            return out, acc, depth
+        return out, acc, None
+
+    @staticmethod
+    def backward(ctx, g_out, g_acc, g_depth):
+        rgb, weights, t_bins, ws = ctx.saved_tensors
+        n, s = weights.shape
+        g_out = _f32c(g_out) if g_out is not None else None
+        g_acc = _f32c(g_acc) if g_acc is not None else None
+        g_depth = _f32c(g_depth) if (g_depth is not None and ctx.want_depth) else None
+        d_rgb = torch.empty_like(rgb)
+        d_w = torch.empty_like(weights)
+        N.check(N.load().nsamd_composite_bwd(N.ptr(rgb), N.ptr(weights), N.ptr(t_bins), n, s, ctx.bg_mode, ctx.bg_vals,
+                                             N.ptr(g_out), N.ptr(g_acc), N.ptr(g_depth), N.ptr(ws), N.ptr(d_rgb),
+                                             N.ptr(d_w), N.stream()), "composite_bwd")
+        return d_rgb, d_w, None, None, None, None
+
+
+def composite(rgb: Tensor, weights: Tensor, t_bins: Optional[Tensor] = None, background="last_sample",
+              expected_depth: bool = True):
+    """Training-mode RGB + accumulation (+ expected depth) in one launch, differentiable w.r.t. rgb and weights.
+    rgb `[N,S,3]`, weights `[N,S]`, t_bins `[N,S+1]` -> (rgb `[N,3]`, accumulation `[N]`, depth `[N]` or None)."""
+    mode, vals = _bg_args(background, weights.device)
+    return _CompositeFn.apply(rgb, weights, t_bins, mode, vals, bool(expected_depth and t_bins is not None))
+
+
+@torch.no_grad()
+def composite_eval(rgb: Tensor, weights: Tensor, t_bins: Tensor, background="last_sample"):
+    """Eval-mode compositing (nan_to_num on the samples, clamp to [0,1]; renderers.py:225-231):
+    -> rgb `[N,3]`, accumulation `[N]`, expected depth `[N]`, median depth `[N]`."""
+    N.require_cuda(rgb, weights, t_bins)
+    rgb, weights, t_bins = _f32c(rgb), _f32c(weights), _f32c(t_bins)
+    n, s = weights.shape
+    dev = weights.device
+    mode, vals = _bg_args(background, dev)
+    out = torch.empty((n, 3), device=dev, dtype=torch.float32)
+    acc = torch.empty((n,), device=dev, dtype=torch.float32)
+    dexp = torch.empty((n,), device=dev, dtype=torch.float32)
+    dmed = torch.empty((n,), device=dev, dtype=torch.float32)
+    ws = torch.empty((2,), device=dev, dtype=torch.float32)
+    N.check(N.load().nsamd_composite_fwd(N.ptr(rgb), N.ptr(weights), N.ptr(t_bins), n, s, mode, vals, 1, N.ptr(out),
+                                         N.ptr(acc), N.ptr(dexp), N.ptr(dmed), None, N.ptr(ws), N.stream()),
+            "composite_fwd")
+    return out, acc, dexp, dmed
+
+
+@torch.no_grad()
+def depth_median(weights: Tensor, t_bins: Tensor, return_index: bool = False):
+    """DepthRenderer(method="median") (renderers.py:354-364) -> `[N]` (and the int32 sample index)."""
+    N.require_cuda(weights, t_bins)
+    weights, t_bins = _f32c(weights.detach()), _f32c(t_bins)
+    n, s = weights.shape
+    d = torch.empty((n,), device=weights.device, dtype=torch.float32)
+    idx = torch.empty((n,), device=weights.device, dtype=torch.int32) if return_index else None
+    N.check(N.load().nsamd_composite_fwd(None, N.ptr(weights), N.ptr(t_bins), n, s, N.BG_NONE, None, 0, None, None,
+                                         None, N.ptr(d), N.ptr(idx), None, N.stream()), "composite_fwd(median)")
+    return (d, idx) if return_index else d
+
+
+@torch.no_grad()
+def accumulation(weights: Tensor) -> Tensor:
+    """AccumulationRenderer (renderers.py:293-317) without gradient -> `[N]` (use `composite` when training)."""
+    N.require_cuda(weights)
+    weights = _f32c(weights)
+    n, s = weights.shape
+    acc = torch.empty((n,), device=weights.device, dtype=torch.float32)
+    N.check(N.load().nsamd_composite_fwd(None, N.ptr(weights), None, n, s, N.BG_NONE, None, 0, None, N.ptr(acc), None,
+                                         None, None, None, N.stream()), "composite_fwd(acc)")
+    return acc
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a19  proposal losses
+# ---------------------------------------------------------------------------------------------------------------
+class _InterlevelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w_prop: Tensor, s_bins_prop: Tensor, w_fine: Tensor, s_bins_fine: Tensor):
+        N.require_cuda(w_prop, s_bins_prop, w_fine, s_bins_fine)
+        w_prop, s_bins_prop = _f32c(w_prop), _f32c(s_bins_prop)
+        w_fine, s_bins_fine = _f32c(w_fine.detach()), _f32c(s_bins_fine.detach())
+        n, sp = w_prop.shape
+        sf = w_fine.shape[1]
+        per_ray = torch.empty((n,), device=w_prop.device, dtype=torch.float32)
+        dw = torch.empty_like(w_prop)
+        N.check(N.load().nsamd_interlevel_loss(N.ptr(s_bins_fine), N.ptr(w_fine), sf, N.ptr(s_bins_prop), N.ptr(w_prop),
+                                               sp, n, 1.0 / (n * sf), N.ptr(per_ray), N.ptr(dw), N.stream()),
+                "interlevel_loss")
+        ctx.save_for_backward(dw)
+        return per_ray.sum() / (n * sf)  # torch.mean over [N, S_fine]  (losses.py:128)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dw,) = ctx.saved_tensors
+        return dw * g, None, None, None
+
+
+def interlevel_loss(weights_list: Sequence[Tensor], s_bins_list: Sequence[Tensor]) -> Tensor:
+    """losses.py:113-131 (weights `[N,S_i]`, spacing bins `[N,S_i+1]`, last entry = the nerf level, detached)."""
+    total = None
+    for w, b in zip(weights_list[:-1], s_bins_list[:-1]):
+        term = _InterlevelFn.apply(w, b, weights_list[-1], s_bins_list[-1])
+        total = term if total is None else total + term
+    return total
+
+
+class _DistortionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights: Tensor, s_bins: Tensor):
+        N.require_cuda(weights, s_bins)
+        weights, s_bins = _f32c(weights), _f32c(s_bins)
+        n, s = weights.shape
+        per_ray = torch.empty((n,), device=weights.device, dtype=torch.float32)
+        dw = torch.empty_like(weights)
+        N.check(N.load().nsamd_distortion_loss(N.ptr(s_bins), N.ptr(weights), s, n, 1.0 / n, N.ptr(per_ray), N.ptr(dw),
+                                               N.stream()), "distortion_loss")
+        ctx.save_for_backward(dw)
+        return per_ray.sum() / n  # torch.mean over rays (losses.py:153)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dw,) = ctx.saved_tensors
+        return dw * g, None
+
+
+def distortion_loss(weights: Tensor, s_bins: Tensor) -> Tensor:
+    """losses.py:149-154 on the final level."""
+    return _DistortionFn.apply(weights, s_bins)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a1  pinhole ray generation
+# ---------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def raygen_pinhole(ray_indices: Tensor, c2w: Tensor, fx: Tensor, fy: Tensor, cx: Tensor, cy: Tensor):
+    """RayGenerator.forward for perspective cameras (ray_generators.py:41-56; cameras.py:598-634, 781-787, 887-909).
+    -> origins `[N,3]`, directions `[N,3]`, pixel_area `[N,1]`, directions_norm `[N,1]`."""
+    N.require_cuda(ray_indices, c2w, fx, fy, cx, cy)
+    idx = ray_indices.contiguous().to(torch.int64)
+    c2w = _f32c(c2w.reshape(-1, 3, 4))
+    fx, fy, cx, cy = (_f32c(t.reshape(-1)) for t in (fx, fy, cx, cy))
+    n = idx.shape[0]
+    dev = idx.device
+    o = torch.empty((n, 3), device=dev, dtype=torch.float32)
+    d = torch.empty((n, 3), device=dev, dtype=torch.float32)
+    pa = torch.empty((n, 1), device=dev, dtype=torch.float32)
+    dn = torch.empty((n, 1), device=dev, dtype=torch.float32)
+    N.check(N.load().nsamd_raygen_pinhole(N.ptr(idx), N.ptr(c2w), N.ptr(fx), N.ptr(fy), N.ptr(cx), N.ptr(cy), n,
+                                          c2w.shape[0], N.ptr(o), N.ptr(d), N.ptr(pa), N.ptr(dn), N.stream()),
+            "raygen_pinhole")
+    return o, d, pa, dn
+
+
+@torch.no_grad()
+def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,
+              betas=(0.9, 0.999), eps: float = 1e-15, grad_scale: float = 1.0) -> None:
+    """torch.optim.Adam step over a flat fp32 arena (engine/optimizers.py:74-193; AdamOptimizerConfig eps=1e-15)."""
+    N.require_cuda(params, grads, exp_avg, exp_avg_sq)
+    N.check(N.load().nsamd_adam_step(N.ptr(params), N.ptr(grads), N.ptr(exp_avg), N.ptr(exp_avg_sq), params.numel(),
+                                     float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
+                                     float(grad_scale), N.stream()), "adam_step")

@@ -1,0 +1,114 @@
+"""Renderers (reference: nerfstudio/model_components/renderers.py — RGBRenderer :60-232, AccumulationRenderer
+:289-317, DepthRenderer :320-385). One HIP kernel, one wavefront per ray (csrc/render.hip)."""
+from typing import Literal, Optional, Union
+
+import torch
+from torch import Tensor, nn
+
+from .. import functional as F
+from ..cameras.rays import RaySamples
+
+BackgroundColor = Union[Literal["random", "last_sample", "black", "white"], Tensor]
+
+
+def _no_packed(ray_indices, num_rays) -> None:
+    if ray_indices is not None and num_rays is not None:
+        raise NotImplementedError(
+            "packed samples (ray_indices / num_rays; the instant-ngp path through nerfacc) are not built yet "
+            "(SURVEY.md §8 f4)")
+
+
+class RGBRenderer(nn.Module):
+    """Standard volumetric rendering of colour."""
+
+    def __init__(self, background_color: BackgroundColor = "random") -> None:
+        super().__init__()
+        self.background_color: BackgroundColor = background_color
+
+    def forward(self, rgb: Tensor, weights: Tensor, ray_indices: Optional[Tensor] = None,
+                num_rays: Optional[int] = None, background_color: Optional[BackgroundColor] = None) -> Tensor:
+        """rgb `[*bs,S,3]`, weights `[*bs,S,1]` -> `[*bs,3]` (renderers.py:201-232)."""
+        _no_packed(ray_indices, num_rays)
+        if background_color is None:
+            background_color = self.background_color
+        shape = rgb.shape[:-2]
+        s = rgb.shape[-2]
+        rgb2, w2 = rgb.reshape(-1, s, 3), weights.reshape(-1, s)
+        if self.training:
+            out, _, _ = F.composite(rgb2, w2, None, background_color, expected_depth=False)
+        else:
+            # eval: nan_to_num on the samples, clamp the result (renderers.py:225-231); no gradient needed
+            dummy_t = torch.zeros((w2.shape[0], s + 1), device=w2.device)
+            out = F.composite_eval(rgb2, w2, dummy_t, background_color)[0]
+        return out.view(*shape, 3)
+
+    @classmethod
+    def get_background_color(cls, background_color, shape, device):
+        named = {"white": (1.0, 1.0, 1.0), "black": (0.0, 0.0, 0.0)}
+        if isinstance(background_color, str):
+            background_color = torch.tensor(named[background_color])
+        return background_color.expand(shape).to(device)
+
+    def blend_background(self, image: Tensor, background_color: Optional[BackgroundColor] = None) -> Tensor:
+        """RGBA ground truth -> RGB over the background (renderers.py:150-173); RGB passes through."""
+        if image.size(-1) < 4:
+            return image
+        rgb, opacity = image[..., :3], image[..., 3:]
+        if background_color is None:
+            background_color = self.background_color
+            if background_color in {"last_sample", "random"}:
+                background_color = "black"
+        bg = self.get_background_color(background_color, rgb.shape, rgb.device)
+        return rgb * opacity + bg * (1 - opacity)
+
+    def blend_background_for_loss_computation(self, pred_image: Tensor, pred_accumulation: Tensor, gt_image: Tensor):
+        """renderers.py:175-199."""
+        background_color = self.background_color
+        if background_color == "last_sample":
+            background_color = "black"
+        elif background_color == "random":
+            background_color = torch.rand_like(pred_image)
+            pred_image = pred_image + background_color * (1.0 - pred_accumulation)
+        gt_image = self.blend_background(gt_image, background_color=background_color)
+        return pred_image, gt_image
+
+
+class AccumulationRenderer(nn.Module):
+    """Accumulated weight along a ray."""
+
+    @classmethod
+    def forward(cls, weights: Tensor, ray_indices: Optional[Tensor] = None, num_rays: Optional[int] = None) -> Tensor:
+        _no_packed(ray_indices, num_rays)
+        shape = weights.shape[:-2]
+        s = weights.shape[-2]
+        w2 = weights.reshape(-1, s)
+        if w2.requires_grad:
+            rgb0 = torch.zeros((w2.shape[0], s, 3), device=w2.device)
+            acc = F.composite(rgb0, w2, None, "random", expected_depth=False)[1]
+        else:
+            acc = F.accumulation(w2)
+        return acc.view(*shape, 1)
+
+
+class DepthRenderer(nn.Module):
+    """Depth along a ray: "median" = first sample where the running weight reaches 0.5; "expected" = weighted mean of
+    the sample midpoints, clipped to the batch-wide midpoint range (renderers.py:320-385)."""
+
+    def __init__(self, method: Literal["median", "expected"] = "median") -> None:
+        super().__init__()
+        if method not in ("median", "expected"):
+            raise NotImplementedError(f"Method {method} not implemented")
+        self.method = method
+
+    def forward(self, weights: Tensor, ray_samples: RaySamples, ray_indices: Optional[Tensor] = None,
+                num_rays: Optional[int] = None) -> Tensor:
+        _no_packed(ray_indices, num_rays)
+        shape = weights.shape[:-2]
+        s = weights.shape[-2]
+        w2 = weights.reshape(-1, s)
+        t_bins = ray_samples._t_bins().reshape(-1, s + 1)
+        if self.method == "median":
+            return F.depth_median(w2, t_bins).view(*shape, 1)
+        rgb0 = torch.zeros((w2.shape[0], s, 3), device=w2.device)
+        depth = F.composite(rgb0, w2, t_bins, "random", expected_depth=True)[2]
+        return depth.view(*shape, 1)

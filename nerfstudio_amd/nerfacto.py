@@ -1,0 +1,210 @@
+"""nerfacto wiring over the HIP components (reference: nerfstudio/models/nerfacto.py — config :46-133,
+populate_modules :144-253, get_param_groups :255-260, callbacks :262-296, get_outputs :298-348, get_metrics_dict
+:350-361, get_loss_dict :363-392; defaults overridden by configs/method_configs.py:87-121).
+
+This is the caller of the hot path, kept thin: it instantiates the fields / sampler / renderers of this package with
+the reference's hyper-parameters and reproduces the reference's control flow (proposal update schedule, weight
+anneal, eval-mode switches). The trainer, datamanager, viewer and camera optimiser stay nerfstudio's.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Literal, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+from torch.nn import Parameter
+
+from .cameras.rays import RayBundle, RaySamples
+from .field_components.field_heads import FieldHeadNames
+from .field_components.spatial_distortions import SceneContraction
+from .fields.density_fields import HashMLPDensityField
+from .fields.nerfacto_field import NerfactoField
+from .model_components.losses import MSELoss, distortion_loss, interlevel_loss
+from .model_components.ray_samplers import ProposalNetworkSampler
+from .model_components.renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
+from .model_components.scene_colliders import NearFarCollider
+
+
+@dataclass
+class NerfactoModelConfig:
+    """models/nerfacto.py:46-133 with the `nerfacto` method overrides (method_configs.py:99-103)."""
+
+    near_plane: float = 0.05
+    far_plane: float = 1000.0
+    background_color: Literal["random", "last_sample", "black", "white"] = "last_sample"
+    hidden_dim: int = 64
+    hidden_dim_color: int = 64
+    num_levels: int = 16
+    base_res: int = 16
+    max_res: int = 2048
+    log2_hashmap_size: int = 19
+    features_per_level: int = 2
+    num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96)
+    num_nerf_samples_per_ray: int = 48
+    proposal_update_every: int = 5
+    proposal_warmup: int = 5000
+    num_proposal_iterations: int = 2
+    use_same_proposal_network: bool = False
+    proposal_net_args_list: List[Dict] = field(
+        default_factory=lambda: [
+            {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 128, "use_linear": False},
+            {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 256, "use_linear": False},
+        ]
+    )
+    interlevel_loss_mult: float = 1.0
+    distortion_loss_mult: float = 0.002
+    use_proposal_weight_anneal: bool = True
+    use_appearance_embedding: bool = True
+    use_average_appearance_embedding: bool = True
+    proposal_weights_anneal_slope: float = 10.0
+    proposal_weights_anneal_max_num_iters: int = 1000
+    use_single_jitter: bool = True
+    disable_scene_contraction: bool = False
+    implementation: Literal["hip"] = "hip"
+    appearance_embed_dim: int = 32
+    average_init_density: float = 0.01
+    eval_num_rays_per_chunk: int = 32768
+
+
+class NerfactoModel(nn.Module):
+    """The nerfacto graph on the MI355X kernels. `forward(ray_bundle)` = collider -> get_outputs
+    (models/base_model.py:132-143)."""
+
+    def __init__(self, config: NerfactoModelConfig, aabb: Tensor, num_train_data: int) -> None:
+        super().__init__()
+        self.config = config
+        self.register_buffer("aabb", aabb.float())
+        self.num_train_data = num_train_data
+        self.populate_modules()
+
+    def populate_modules(self) -> None:
+        c = self.config
+        scene_contraction = None if c.disable_scene_contraction else SceneContraction(order=float("inf"))
+        self.field = NerfactoField(
+            self.aabb,
+            hidden_dim=c.hidden_dim,
+            num_levels=c.num_levels,
+            max_res=c.max_res,
+            base_res=c.base_res,
+            features_per_level=c.features_per_level,
+            log2_hashmap_size=c.log2_hashmap_size,
+            hidden_dim_color=c.hidden_dim_color,
+            spatial_distortion=scene_contraction,
+            num_images=self.num_train_data,
+            use_average_appearance_embedding=c.use_average_appearance_embedding,
+            appearance_embedding_dim=c.appearance_embed_dim if c.use_appearance_embedding else 0,
+            average_init_density=c.average_init_density,
+            implementation=c.implementation,
+        )
+        self.density_fns = []
+        self.proposal_networks = nn.ModuleList()
+        n_props = c.num_proposal_iterations
+        n_nets = 1 if c.use_same_proposal_network else n_props
+        for i in range(n_nets):
+            args = c.proposal_net_args_list[min(i, len(c.proposal_net_args_list) - 1)]
+            self.proposal_networks.append(
+                HashMLPDensityField(self.aabb, spatial_distortion=scene_contraction, **args,
+                                    average_init_density=c.average_init_density, implementation=c.implementation))
+        if c.use_same_proposal_network:
+            self.density_fns.extend([self.proposal_networks[0].density_fn for _ in range(n_props)])
+        else:
+            self.density_fns.extend([net.density_fn for net in self.proposal_networks])
+
+        def update_schedule(step):  # models/nerfacto.py:208-213
+            return np.clip(np.interp(step, [0, c.proposal_warmup], [0, c.proposal_update_every]), 1,
+                           c.proposal_update_every)
+
+        self.proposal_sampler = ProposalNetworkSampler(
+            num_nerf_samples_per_ray=c.num_nerf_samples_per_ray,
+            num_proposal_samples_per_ray=c.num_proposal_samples_per_ray,
+            num_proposal_network_iterations=c.num_proposal_iterations,
+            single_jitter=c.use_single_jitter,
+            update_sched=update_schedule,
+        )
+        self.collider = NearFarCollider(near_plane=c.near_plane, far_plane=c.far_plane)
+        self.renderer_rgb = RGBRenderer(background_color=c.background_color)
+        self.renderer_accumulation = AccumulationRenderer()
+        self.renderer_depth = DepthRenderer(method="median")
+        self.renderer_expected_depth = DepthRenderer(method="expected")
+        self.rgb_loss = MSELoss()
+        self.step = 0
+
+    # --- reference API -------------------------------------------------------------------------------------------
+    def get_param_groups(self) -> Dict[str, List[Parameter]]:
+        return {"proposal_networks": list(self.proposal_networks.parameters()), "fields": list(self.field.parameters())}
+
+    def set_step(self, step: int) -> None:
+        """BEFORE_TRAIN_ITERATION callback: proposal weight anneal (models/nerfacto.py:270-280)."""
+        self.step = step
+        if self.config.use_proposal_weight_anneal:
+            n = self.config.proposal_weights_anneal_max_num_iters
+            frac = np.clip(step / n, 0, 1)
+            b = self.config.proposal_weights_anneal_slope
+            self.proposal_sampler.set_anneal(float(b * frac / ((b - 1) * frac + 1)))
+
+    def after_step(self, step: int) -> None:
+        """AFTER_TRAIN_ITERATION callback (ray_samplers.py:571-574)."""
+        self.proposal_sampler.step_cb(step)
+
+    def forward(self, ray_bundle: RayBundle, jitters: Optional[List[Tensor]] = None) -> Dict[str, object]:
+        ray_bundle = self.collider(ray_bundle)
+        return self.get_outputs(ray_bundle, jitters)
+
+    def get_outputs(self, ray_bundle: RayBundle, jitters: Optional[List[Tensor]] = None) -> Dict[str, object]:
+        ray_samples: RaySamples
+        ray_samples, weights_list, ray_samples_list = self.proposal_sampler(ray_bundle, density_fns=self.density_fns,
+                                                                            jitters=jitters)
+        field_outputs = self.field.forward(ray_samples)
+        weights = ray_samples.get_weights(field_outputs[FieldHeadNames.DENSITY])
+        weights_list.append(weights)
+        ray_samples_list.append(ray_samples)
+        rgb = self.renderer_rgb(rgb=field_outputs[FieldHeadNames.RGB], weights=weights)
+        with torch.no_grad():
+            depth = self.renderer_depth(weights=weights, ray_samples=ray_samples)
+        expected_depth = self.renderer_expected_depth(weights=weights, ray_samples=ray_samples)
+        accumulation = self.renderer_accumulation(weights=weights)
+        outputs: Dict[str, object] = {"rgb": rgb, "accumulation": accumulation, "depth": depth,
+                                      "expected_depth": expected_depth}
+        if self.training:
+            outputs["weights_list"] = weights_list
+            outputs["ray_samples_list"] = ray_samples_list
+        for i in range(self.config.num_proposal_iterations):
+            outputs[f"prop_depth_{i}"] = self.renderer_depth(weights=weights_list[i], ray_samples=ray_samples_list[i])
+        return outputs
+
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, Tensor]:
+        metrics = {}
+        gt = self.renderer_rgb.blend_background(batch["image"].to(outputs["rgb"].device))
+        mse = torch.mean((outputs["rgb"].detach() - gt) ** 2)
+        metrics["psnr"] = -10.0 * torch.log10(mse)
+        if self.training:
+            metrics["distortion"] = distortion_loss(outputs["weights_list"], outputs["ray_samples_list"])
+        return metrics
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
+        image = batch["image"].to(outputs["rgb"].device)
+        pred_rgb, gt_rgb = self.renderer_rgb.blend_background_for_loss_computation(
+            pred_image=outputs["rgb"], pred_accumulation=outputs["accumulation"], gt_image=image)
+        loss_dict = {"rgb_loss": self.rgb_loss(gt_rgb, pred_rgb)}
+        if self.training:
+            loss_dict["interlevel_loss"] = self.config.interlevel_loss_mult * interlevel_loss(
+                outputs["weights_list"], outputs["ray_samples_list"])
+            assert metrics_dict is not None and "distortion" in metrics_dict
+            loss_dict["distortion_loss"] = self.config.distortion_loss_mult * metrics_dict["distortion"]
+        return loss_dict
+
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """Chunked full-image render (models/base_model.py:178-205)."""
+        image_shape = camera_ray_bundle.origins.shape[:-1]
+        num_rays = len(camera_ray_bundle)
+        chunk = self.config.eval_num_rays_per_chunk
+        outs: Dict[str, List[Tensor]] = {}
+        for i in range(0, num_rays, chunk):
+            rb = camera_ray_bundle.get_row_major_sliced_ray_bundle(i, i + chunk)
+            for k, v in self.forward(rb).items():
+                if torch.is_tensor(v):
+                    outs.setdefault(k, []).append(v)
+        return {k: torch.cat(v).view(*image_shape, -1) for k, v in outs.items()}

@@ -1,0 +1,138 @@
+"""CPU: host-side logic of the plugin mirror — hyper-parameter tables, state-dict names, error behaviour, schedules.
+No kernels are launched."""
+import numpy as np
+import pytest
+import torch
+
+from nerfstudio_amd import functional as F
+
+
+def test_scalings_match_reference(golden):
+    g = golden("kat")
+    for name, (L, lo, hi, t) in {"main": (16, 16, 2048, 19), "prop0": (5, 16, 128, 17), "prop1": (5, 16, 256, 17)}.items():
+        spec = F.HashGridSpec(L, lo, hi, t)
+        np.testing.assert_array_equal(spec.scalings().numpy(), g[f"scalings_{name}"])
+    assert F.HashGridSpec(16, 16, 2048, 19).scalings().tolist()[-1] == 2047.0  # fp32 pow quirk, SURVEY §8 a8
+    assert F.HashGridSpec(16, 16, 2048, 19).native().num_levels == 16
+
+
+def test_state_dict_names_match_reference_torch_path():
+    """SURVEY.md §5 checkpoint contract + Appendix A shapes."""
+    from nerfstudio_amd.nerfacto import NerfactoModel, NerfactoModelConfig
+
+    m = NerfactoModel(NerfactoModelConfig(log2_hashmap_size=8, proposal_net_args_list=[
+        {"hidden_dim": 16, "log2_hashmap_size": 6, "num_levels": 5, "max_res": 128, "use_linear": False},
+        {"hidden_dim": 16, "log2_hashmap_size": 6, "num_levels": 5, "max_res": 256, "use_linear": False}]),
+        torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_train_data=100)
+    sd = m.state_dict()
+    expect = {
+        "field.mlp_base.model.0.hash_table": (16 * 256, 2),
+        "field.mlp_base.model.1.layers.0.weight": (64, 32),
+        "field.mlp_base.model.1.layers.1.weight": (16, 64),
+        "field.mlp_head.layers.0.weight": (64, 63),
+        "field.mlp_head.layers.1.weight": (64, 64),
+        "field.mlp_head.layers.2.weight": (3, 64),
+        "field.embedding_appearance.embedding.weight": (100, 32),
+        "proposal_networks.0.encoding.hash_table": (5 * 64, 2),
+        "proposal_networks.0.mlp_base.0.hash_table": (5 * 64, 2),
+        "proposal_networks.0.mlp_base.1.layers.0.weight": (16, 10),
+        "proposal_networks.1.mlp_base.1.layers.1.weight": (1, 16),
+    }
+    for k, shape in expect.items():
+        assert k in sd, k
+        assert tuple(sd[k].shape) == shape, (k, sd[k].shape)
+    groups = m.get_param_groups()
+    assert set(groups) == {"proposal_networks", "fields"}
+    n_field = sum(p.numel() for p in groups["fields"])
+    assert n_field == 16 * 256 * 2 + 64 * 32 + 64 + 16 * 64 + 16 + 64 * 63 + 64 + 64 * 64 + 64 + 3 * 64 + 3 + 100 * 32
+
+
+def test_full_size_parameter_count():
+    """field 16 792 019 (100 images), each proposal net 1 310 913."""
+    from nerfstudio_amd.nerfacto import NerfactoModel, NerfactoModelConfig
+
+    m = NerfactoModel(NerfactoModelConfig(), torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_train_data=100)
+    g = m.get_param_groups()
+    assert sum(p.numel() for p in g["fields"]) == 16_792_019
+    assert sum(p.numel() for p in g["proposal_networks"]) == 2 * 1_310_913
+
+
+def test_no_silent_fallback():
+    from nerfstudio_amd.field_components.encodings import HashEncoding, SHEncoding
+    from nerfstudio_amd.field_components.mlp import MLP
+
+    for impl in ("torch", "tcnn"):
+        with pytest.raises(ValueError, match="implementation='hip' only"):
+            HashEncoding(implementation=impl)
+        with pytest.raises(ValueError, match="implementation='hip' only"):
+            MLP(in_dim=4, num_layers=2, layer_width=8, implementation=impl)
+    enc = HashEncoding(num_levels=2, log2_hashmap_size=4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        enc(torch.rand(4, 3))  # CPU tensor: the product never computes on the host
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SHEncoding()(torch.rand(4, 3))
+    with pytest.raises(ValueError):
+        SHEncoding(levels=7)  # reference error behaviour (encodings.py:762-765)
+    with pytest.raises(ValueError):
+        F.HashGridSpec(16, 16, 2048, 19, features_per_level=4)
+
+
+def test_encoding_api_contract():
+    """tests/field_components/test_encodings.py:143-169 / test_mlp.py:11-28 shape contracts (host side)."""
+    from nerfstudio_amd.field_components.encodings import HashEncoding
+    from nerfstudio_amd.field_components.mlp import MLP, MLPWithHashEncoding
+
+    enc = HashEncoding(num_levels=8, features_per_level=2, log2_hashmap_size=5, min_res=2, max_res=4)
+    assert enc.get_out_dim() == 16 and enc.hash_table.shape == (8 * 32, 2)
+    assert float(enc.hash_table.abs().max()) <= 1e-3
+    mlp = MLP(in_dim=6, num_layers=2, layer_width=8, out_dim=10)
+    assert mlp.get_out_dim() == 10 and [tuple(p.shape) for p in mlp.param_tensors()] == [(8, 6), (8,), (10, 8), (10,)]
+    m = MLPWithHashEncoding(num_levels=4, log2_hashmap_size=4, layer_width=64, out_dim=16)
+    assert list(dict(m.named_parameters())) == ["model.0.hash_table", "model.1.layers.0.weight", "model.1.layers.0.bias",
+                                                 "model.1.layers.1.weight", "model.1.layers.1.bias"]
+
+
+def test_ray_datastructures_shapes():
+    from nerfstudio_amd.cameras.rays import Frustums, RayBundle, samples_from_bins
+
+    n, s = 5, 7
+    rb = RayBundle(origins=torch.zeros(n, 3), directions=torch.ones(n, 3), pixel_area=torch.ones(n, 1),
+                   camera_indices=torch.arange(n)[:, None], nears=torch.zeros(n, 1), fars=torch.ones(n, 1))
+    assert len(rb) == n and len(rb[:3]) == 3 and len(rb.get_row_major_sliced_ray_bundle(1, 4)) == 3
+    t = torch.linspace(0, 1, s + 1)[None].expand(n, s + 1).contiguous()
+    rs = samples_from_bins(rb, t, t * 2, None)
+    assert rs.frustums.starts.shape == (n, s, 1) and rs.deltas.shape == (n, s, 1)
+    assert rs.frustums.origins.shape == (n, 1, 3) and rs.camera_indices.shape == (n, 1, 1)
+    assert tuple(rs.frustums.shape) == (n, s)
+    assert rs.frustums.get_positions().shape == (n, s, 3)
+    # Frustums.get_positions KAT of the reference's tests/cameras/test_rays.py:11-30
+    fr = Frustums(origins=torch.ones(5, 3), directions=torch.ones(5, 3) * torch.tensor([0.0, 1.0, 0.0]),
+                  starts=torch.ones(5, 1) * 2, ends=torch.ones(5, 1) * 3, pixel_area=torch.ones(5, 1))
+    assert torch.allclose(fr.get_positions()[0], torch.tensor([1.0, 3.5, 1.0]))
+
+
+def test_proposal_schedule_and_anneal():
+    """Control flow of ProposalNetworkSampler / NerfactoModel callbacks (ray_samplers.py:567-574,590;
+    models/nerfacto.py:208-213, 270-280)."""
+    from nerfstudio_amd.nerfacto import NerfactoModel, NerfactoModelConfig
+
+    m = NerfactoModel(NerfactoModelConfig(log2_hashmap_size=6, proposal_net_args_list=[
+        {"hidden_dim": 16, "log2_hashmap_size": 5, "num_levels": 5, "max_res": 128, "use_linear": False}] * 2),
+        torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_train_data=3)
+    ps = m.proposal_sampler
+    assert ps.update_sched(0) == 1 and ps.update_sched(5000) == 5 and ps.update_sched(2500) == 2.5
+    m.set_step(0)
+    assert ps._anneal == 0.0
+    m.set_step(1000)
+    assert ps._anneal == pytest.approx(1.0)
+    m.set_step(100)
+    assert ps._anneal == pytest.approx(10 * 0.1 / (9 * 0.1 + 1))
+    updated = []
+    ps._step, ps._steps_since_update = 0, 0
+    for step in range(1, 30):
+        upd = ps._steps_since_update > ps.update_sched(ps._step) or ps._step < 10
+        updated.append(upd)
+        if upd:
+            ps._steps_since_update = 0
+        ps.step_cb(step)
+    assert all(updated[:10]) and updated[10:16] == [False, True, False, True, False, True]
