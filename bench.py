@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py — training rays/sec of the nerfacto hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full nerfacto training iteration on a batch of 4096 synthetic rays PER GPU (BASELINE configs[1]:
+L=16 hash T=2^19 F=2, 64-wide MLPs, proposal sampler 256 -> 96 -> 48 samples/ray): proposal sampling, main field,
+compositing, MSE + interlevel + distortion losses, backward of all of it, gradient all-reduce (N > 1), Adam over all
+19.4 M parameters, and the reference's per-step callbacks (proposal update schedule, weight anneal). Rays are
+resident in HBM before the timed region. value = world_size * rays_per_batch / time_per_step, the reference's own
+rays/s definition (engine/trainer.py:276-284) with a device sync around the timed region.
+
+Extra objects on the JSON line:
+  roofline     — the kernel with the largest share of the step, timed live with HIP events on the launch stream
+                 (separate, untimed profiling steps after the timed region), against its algorithmic bytes / flops.
+  cpu_baseline — the CPU oracle (oracle/nerfacto_oracle.py, kind "port") running the same training step on a bounded
+                 ray sample on this box's host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+RAYS_PER_GPU = 4096
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-in MFMA = f32 vector peak
+
+
+def build_model(device, seed):
+    from nerfstudio_amd.nerfacto import NerfactoModel, NerfactoModelConfig
+
+    torch.manual_seed(seed)
+    model = NerfactoModel(NerfactoModelConfig(), torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_train_data=100)
+    return model.to(device).train()
+
+
+def synthetic_batch(device, seed):
+    """BASELINE.md §2 synthetic input: origins ~ N(0, 0.5^2), unit directions, camera ids U{0..99}, targets U(0,1)."""
+    from nerfstudio_amd.cameras.rays import RayBundle
+
+    rs = np.random.RandomState(seed)
+    n = RAYS_PER_GPU
+    o = (rs.standard_normal((n, 3)) * 0.5).astype(np.float32)
+    d = rs.standard_normal((n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    cam = rs.randint(0, 100, size=(n, 1)).astype(np.int64)
+    tgt = rs.uniform(0, 1, size=(n, 3)).astype(np.float32)
+    rb = RayBundle(origins=torch.from_numpy(o).to(device), directions=torch.from_numpy(d.astype(np.float32)).to(device),
+                   pixel_area=torch.full((n, 1), 1e-6, device=device), camera_indices=torch.from_numpy(cam).to(device))
+    return rb, {"image": torch.from_numpy(tgt).to(device)}
+
+
+class Trainer:
+    """The reference's Trainer.train_iteration (engine/trainer.py:487-531) for this path, minus logging."""
+
+    def __init__(self, model, arena, ray_bundle, batch):
+        self.model, self.arena, self.rb, self.batch = model, arena, ray_bundle, batch
+        self.step = 0
+
+    def train_iteration(self):
+        from nerfstudio_amd.cameras.rays import RayBundle
+
+        m = self.model
+        m.set_step(self.step)  # BEFORE_TRAIN_ITERATION callbacks
+        self.arena.zero_grad()
+        rb = RayBundle(origins=self.rb.origins, directions=self.rb.directions, pixel_area=self.rb.pixel_area,
+                       camera_indices=self.rb.camera_indices)
+        out = m(rb)
+        metrics = m.get_metrics_dict(out, self.batch)
+        loss_dict = m.get_loss_dict(out, self.batch, metrics)
+        loss = loss_dict["rgb_loss"] + loss_dict["interlevel_loss"] + loss_dict["distortion_loss"]
+        loss.backward()
+        scale = self.arena.all_reduce()
+        self.arena.step(grad_scale=scale)
+        m.after_step(self.step)  # AFTER_TRAIN_ITERATION callbacks
+        self.step += 1
+        return loss
+
+
+# algorithmic work per launch: bytes for the HBM-bound kernels, flops for the MFMA kernels
+def algorithmic_model(key):
+    import re
+
+    m = re.search(r"L=(\d+),M=(\d+)", key)
+    if key.startswith("nsamd_hashgrid_encode_fwd") and m:
+        L, M = int(m.group(1)), int(m.group(2))
+        return "hbm", M * L * 8 * 8  # 8 corner gathers x 8 B (F=2 fp32) per level and sample
+    if key.startswith("nsamd_hashgrid_encode_bwd") and m:
+        L, M = int(m.group(1)), int(m.group(2))
+        return "hbm", M * L * 8 * 16  # read-modify-write of 8 corners x 8 B
+    M_main = RAYS_PER_GPU * 48
+    if key == "nsamd_field_mlp_fwd":
+        return "mfma", M_main * 2 * 11392  # MACs/sample: 32*64 + 64*16 + 63*64 + 64*64 + 64*3  
+    if key == "nsamd_field_mlp_bwd":
+        return "mfma", M_main * 2 * 11392 * 3  # recompute + data gradient + weight gradient
+    m2 = re.search(r"\[M=(\d+)\]", key)
+    if key.startswith("nsamd_density_mlp_fwd") and m2:
+        return "hbm", int(m2.group(1)) * (10 * 4 + 4 + 8)  # enc row + selector in, density + pre out
+    if key.startswith("nsamd_density_mlp_bwd") and m2:
+        return "hbm", int(m2.group(1)) * (10 * 4 * 2 + 4 * 3)
+    if key == "nsamd_adam_step":
+        return "hbm", None  # filled in by the caller (arena size x 28 B)
+    return None, None
+
+
+def measure_roofline(trainer, arena, steps):
+    from nerfstudio_amd import _native as N
+
+    N.PROFILE = {}
+    for _ in range(steps):
+        trainer.train_iteration()
+    torch.cuda.synchronize()
+    prof = N.profile_summary(N.PROFILE)
+    N.PROFILE = None
+    table = []
+    for key, (calls, total_ms, mean_ms) in prof.items():
+        bound, work = algorithmic_model(key)
+        if key == "nsamd_adam_step":
+            work = arena.numel * 28
+        table.append({"kernel": key, "calls_per_step": calls / steps, "ms_per_step": total_ms / steps, "mean_ms": mean_ms,
+                      "bound": bound, "work": work})
+    table.sort(key=lambda r: -r["ms_per_step"])
+    top = next((r for r in table if r["bound"] is not None and r["work"]), None)
+    roof = None
+    if top is not None:
+        sec = top["mean_ms"] * 1e-3
+        if top["bound"] == "hbm":
+            ach, peak, unit = top["work"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = top["work"] / sec / 1e12, F32_MFMA_PEAK_TFLOPS, "TFLOP/s"
+        roof = {"bound": top["bound"], "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+                "traffic": None, "kernel": top["kernel"], "avg_launch_ms": round(top["mean_ms"], 4),
+                "algorithmic_per_launch": top["work"]}
+    return roof, table
+
+
+def cpu_baseline(n_rays=256, steps=3):
+    """The CPU oracle running the same training step (fwd + losses + bwd + Adam) on a bounded sample of rays."""
+    from oracle import nerfacto_oracle as orc
+
+    cfg = orc.NerfactoCfg()
+    params = orc.init_params(cfg, seed=0)
+    plist = list(params.values())
+    for p in plist:
+        p.requires_grad_(True)
+    opt = torch.optim.Adam(plist, lr=1e-2, eps=1e-15)
+    o, d, cam, tgt = orc.synthetic_rays(n_rays, cfg.num_images, seed=0)
+    rs = np.random.RandomState(1)
+    times = []
+    for it in range(steps + 1):
+        jit = [torch.from_numpy(rs.uniform(0, 1, (n_rays, 1)).astype(np.float32)) for _ in range(3)]
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        out = orc.nerfacto_forward(params, cfg, o, d, cam, jit, training=True)
+        sum(orc.nerfacto_losses(out, tgt, cfg).values()).backward()
+        opt.step()
+        if it > 0:  # first step pays allocator / thread-pool warm-up
+            times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": round(n_rays / med, 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_rays} rays x (256,96,48) samples, full nerfacto tables, fwd+losses+bwd+Adam, median of {steps} "
+                      f"steps ({med:.2f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
+
+    from nerfstudio_amd import _native
+    from nerfstudio_amd.arena import ParamArena
+
+    _native.load()  # fail loudly if the HIP extension is missing
+    model = build_model(device, seed=0)  # same init on every rank (replicated model)
+    arena = ParamArena(model.parameters(), lr=1e-2, eps=1e-15)  # AdamOptimizerConfig(lr=1e-2, eps=1e-15)
+    arena.broadcast_params()
+    rb, batch = synthetic_batch(device, seed=1000 + rank)  # each rank its own rays (scripts/train.py:98)
+    trainer = Trainer(model, arena, rb, batch)
+
+    for _ in range(args.warmup):
+        trainer.train_iteration()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.train_iteration()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(loss)), "training diverged"
+
+    roof, table = (None, [])
+    if rank == 0:
+        roof, table = measure_roofline(trainer, arena, max(1, args.profile_steps))
+    elif world > 1:  # keep the collective pattern identical on every rank during the profiling steps
+        for _ in range(max(1, args.profile_steps)):
+            trainer.train_iteration()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "training rays/sec (4096 rays x 48 samples per GPU)",
+            "value": round(world * RAYS_PER_GPU / (elapsed / args.steps), 1),
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "nerfacto 1xMI355X: L=16 hash (T=2^19, F=2), 64x2 MLP, 48 samples/ray, 4096 rays/batch "
+                                   "(BASELINE configs[1]); full training step incl. proposal nets 256->96, losses, Adam",
+                       "rays_per_gpu": RAYS_PER_GPU, "global_rays": world * RAYS_PER_GPU,
+                       "parallelism": f"dp{world}: rays sharded by batch, one RCCL all-reduce of the 77.7 MB gradient arena",
+                       "params": arena.numel, "final_loss": round(float(loss), 6)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        if args.kernel_table:
+            for r in table:
+                print(f"{r['kernel']:64s} {r['calls_per_step']:5.1f}/step {r['ms_per_step']:9.4f} ms/step "
+                      f"{r['mean_ms']:9.4f} ms/launch", file=sys.stderr)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

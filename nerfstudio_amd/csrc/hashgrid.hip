@@ -190,6 +190,7 @@ using namespace nsamd;
 extern "C" int nsamd_hashgrid_encode_fwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb,
                                          const float* table, nsamd_grid grid, float* enc, int64_t stride_p,
                                          int64_t stride_k, float* selector, nsamd_stream_t stream) {
+  if (M == 0) return NSAMD_OK;  // empty input: nothing to launch (empty tensors carry NULL data pointers)
   int st = check_points(pts, M);
   if (st) return st;
   st = check_grid(grid);
@@ -210,6 +211,7 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
                                          const float* table, nsamd_grid grid, const float* denc, int64_t stride_p,
                                          int64_t stride_k, float* dtable, float* dpositions,
                                          nsamd_stream_t stream) {
+  if (M == 0) return NSAMD_OK;
   int st = check_points(pts, M);
   if (st) return st;
   st = check_grid(grid);

@@ -52,11 +52,11 @@ __global__ __launch_bounds__(kLossThreads) void interlevel_kernel(
   for (int i = lane; i < Sf; i += 64) w[i] = w_in[ray * Sf + i];
   __builtin_amdgcn_wave_barrier();
   if (lane == 0) {  // cy = [0, cumsum(wp)] left-to-right   (losses.py:69)
-    float run = 0.0f;
+    double run = 0.0;
     cy[0] = 0.0f;
     for (int k = 0; k < Sp; ++k) {
-      run = run + cy[k + 1];
-      cy[k + 1] = run;
+      run = run + (double)cy[k + 1];
+      cy[k + 1] = (float)run;
     }
   }
   __builtin_amdgcn_wave_barrier();

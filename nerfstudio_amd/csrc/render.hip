@@ -124,11 +124,11 @@ __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
   if (tb && (depth_med || med_idx)) {
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {  // searchsorted(cumsum(w), 0.5, side="left"), clamped  (renderers.py:359-362)
-      float run = 0.0f;
+      double run = 0.0;  // torch.cumsum (CPU): double accumulator, each output rounded to fp32
       int idx = S;
       for (int s = 0; s < S; ++s) {
-        run = run + wrow[s];
-        if (run >= 0.5f) { idx = s; break; }
+        run = run + (double)wrow[s];
+        if ((float)run >= 0.5f) { idx = s; break; }
       }
       idx = min(idx, S - 1);
       if (med_idx) med_idx[ray] = idx;

@@ -2,9 +2,11 @@
 // cameras/rays.py:129-152).
 //
 // Shape of the work: N rays x S (<= a few hundred) samples, a few MB per launch, all of it L2 resident. Two things
-// matter: (1) every fp32 result that decides an integer sample index must equal the reference's torch-CPU value,
-// so the two scans per ray (weight sum, CDF cumsum) run strictly left-to-right on one lane, IEEE div, no FMA
-// contraction (this TU is built with -ffp-contract=off); (2) everything else is elementwise and uses all lanes.
+// matter: (1) every fp32 result that decides an integer sample index must equal the reference's torch-CPU value.
+// ATen's CPU cumsum accumulates fp32 inputs left-to-right in DOUBLE and rounds every output to fp32
+// (acc_type<float> = double), so the scans per ray (transmittance, weight sum, CDF) do exactly that on one lane,
+// with IEEE div and no FMA contraction (this TU is built with -ffp-contract=off); (2) everything else is
+// elementwise and uses all lanes.
 // Layout: kRays rays per 256-thread workgroup; each ray's row is staged once in LDS with coalesced loads
 // (row stride S+1 or S+2 floats = odd, so the one-lane-per-ray scan walks conflict-free banks), results leave
 // through coalesced stores. N = 4096 gives 256 workgroups = one per CU.
@@ -66,10 +68,10 @@ __global__ __launch_bounds__(kThreads) void weights_fwd_kernel(const float* __re
   if (threadIdx.x < nr) {  // exclusive left-to-right cumsum, one lane per ray
     const float* d = dd + threadIdx.x * ld;
     float* a = acc + threadIdx.x * ld;
-    float run = 0.0f;
+    double run = 0.0;  // torch.cumsum on CPU: double accumulator, fp32 outputs
     for (int i = 0; i < S; ++i) {
-      a[i] = run;
-      run = run + d[i];
+      a[i] = (float)run;
+      run = run + (double)d[i];
     }
   }
   __syncthreads();
@@ -103,10 +105,10 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
   if (threadIdx.x < nr) {
     const float* d = dd + threadIdx.x * ld;
     float* a = acc + threadIdx.x * ld;
-    float run = 0.0f;
+    double run = 0.0;  // torch.cumsum on CPU: double accumulator, fp32 outputs
     for (int i = 0; i < S; ++i) {
-      a[i] = run;
-      run = run + d[i];
+      a[i] = (float)run;
+      run = run + (double)d[i];
     }
   }
   __syncthreads();
@@ -122,11 +124,11 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
   __syncthreads();
   if (threadIdx.x < nr) {  // in-place exclusive suffix sums  suf_j = sum_{i>j} gw_i  (reverse cumsum, as autograd)
     float* q = gw + threadIdx.x * ld;
-    float run = 0.0f;
+    double run = 0.0;
     for (int i = S - 1; i >= 0; --i) {
       const float v = q[i];
-      q[i] = run;
-      run = run + v;
+      q[i] = (float)run;
+      run = run + (double)v;
     }
   }
   __syncthreads();
@@ -171,8 +173,9 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
   // (2) left-to-right sum; padding for all-zero rays                         ray_samplers.py:306-309
   if (threadIdx.x < nr) {
     const float* q = w + threadIdx.x * ldp;
-    float run = 0.0f;
-    for (int i = 0; i < S_prev; ++i) run = run + q[i];
+    double acc = 0.0;  // double-accumulated sum, rounded once (= cumsum(w)[-1] of the oracle; closest to torch.sum)
+    for (int i = 0; i < S_prev; ++i) acc = acc + (double)q[i];
+    const float run = (float)acc;
     const float pad = fmaxf(eps - run, 0.0f);
     wpad[threadIdx.x] = pad / (float)S_prev;
     wsum[threadIdx.x] = run + pad;
@@ -188,11 +191,11 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
   if (threadIdx.x < nr) {
     const float* q = w + threadIdx.x * ldp;
     float* c = cdf + threadIdx.x * ldp;
-    float run = 0.0f;
+    double run = 0.0;
     c[0] = 0.0f;
     for (int i = 0; i < S_prev; ++i) {
-      run = run + q[i];
-      c[i + 1] = fminf(1.0f, run);
+      run = run + (double)q[i];
+      c[i + 1] = fminf(1.0f, (float)run);
     }
   }
   __syncthreads();

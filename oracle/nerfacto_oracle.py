@@ -13,7 +13,9 @@ Conventions
 * bins: `s_bins [N, S+1]` (normalised "spacing" domain) and `t_bins [N, S+1]` (euclidean distance along the ray);
 * parameters live in a plain `dict` keyed with the reference's torch-path `state_dict` names
   (SURVEY.md §5 "Checkpoint / resume"): `hash_table`, `layers.{i}.weight`, ...
-* sums that decide integer indices are LEFT-TO-RIGHT fp32 (`torch.cumsum` on CPU is sequential).
+* scans that decide integer indices use `torch.cumsum` on CPU, whose fp32 kernel accumulates LEFT-TO-RIGHT IN DOUBLE
+  and rounds every output to fp32 (ATen acc_type<float> = double) — the HIP kernels and oracle/hash_oracle.c do the
+  same, so they agree bit-for-bit with the reference's own CPU cumsum.
 """
 from __future__ import annotations
 
@@ -410,13 +412,13 @@ def pdf_resample(
     `debug`, if given, receives the intermediate `cdf` and `u` (used by the tie analysis in the tests).
 
     `jitter` `[N,1]` is the raw `torch.rand` draw (divided by num_bins here, ray_samplers.py:320-322); None = eval.
-    The weight sum is taken LEFT-TO-RIGHT (see module docstring); everything downstream follows the reference's
-    operation order exactly.
+    The weight sum is `cumsum(w)[-1]` (double-accumulated, rounded once; see module docstring) where the reference
+    calls torch.sum; everything downstream follows the reference's operation order exactly.
     """
     S_prev = weights.shape[-1]
     nb = num_samples + 1
     w = weights + histogram_padding
-    w_sum = torch.cumsum(w, dim=-1)[:, -1:]  # sequential fp32 sum           (ray_samplers.py:306)
+    w_sum = torch.cumsum(w, dim=-1)[:, -1:]  # double-accumulated sum         (ray_samplers.py:306)
     pad = torch.relu(eps - w_sum)
     w = w + pad / S_prev
     w_sum = w_sum + pad

@@ -1,0 +1,89 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange of the path — replicated parameters in one flat arena,
+per-rank gradients, ONE all-reduce of the gradient arena, mean folded into the optimiser scale (the reference gets
+the same numbers from DistributedDataParallel, pipelines/base_pipeline.py:279-282)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerfstudio_amd.arena import ParamArena
+
+        torch.manual_seed(123 + rank)  # different init per rank on purpose: broadcast must fix it
+        net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+        shared = torch.nn.Parameter(torch.randn(11, 2))
+        params = list(net.parameters()) + [shared, shared]  # a parameter registered twice (proposal-net hash table)
+        arena = ParamArena(params)
+        assert len(arena.params) == 5
+        arena.broadcast_params(src=0)
+        ref0 = [p.detach().clone() for p in arena.params]
+        # per-rank batch ("each rank draws its own rays", scripts/train.py:98)
+        g = torch.Generator().manual_seed(1000 + rank)
+        x = torch.randn(16, 7, generator=g)
+        arena.zero_grad()
+        loss = net(x).pow(2).mean() + (shared * (rank + 1)).sum()
+        loss.backward()
+        for p, off in zip(arena.params, arena.offsets):  # gradients landed in the arena views
+            assert p.grad.data_ptr() == arena.grad.data_ptr() + 4 * off
+        local = arena.grad.clone()
+        scale = arena.all_reduce()
+        assert scale == 1.0 / world
+        q.put((rank, [r.numpy() for r in ref0], local.numpy(), arena.grad.clone().numpy(), arena.numel))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_arena_allreduce_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=90) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    (_, p0, l0, s0, n0), (_, p1, l1, s1, n1) = res
+    assert n0 == n1 and n0 % 64 == 0
+    for a, b in zip(p0, p1):  # replicated parameters after the broadcast
+        assert (a == b).all()
+    assert not (l0 == l1).all()  # different rays -> different local gradients
+    import numpy as np
+
+    np.testing.assert_allclose(s0, l0 + l1, rtol=1e-6, atol=1e-7)  # the arena holds the SUM on every rank
+    np.testing.assert_array_equal(s0, s1)
+
+
+def test_arena_single_process_layout():
+    from nerfstudio_amd.arena import ParamArena
+
+    a = torch.nn.Parameter(torch.arange(10.0))
+    b = torch.nn.Parameter(torch.ones(3, 70))
+    arena = ParamArena([a, b])
+    assert arena.offsets == [0, 64] and arena.numel == 64 + 256
+    assert a.data_ptr() == arena.flat.data_ptr() and b.data_ptr() == arena.flat.data_ptr() + 4 * 64
+    assert torch.equal(arena.flat[:10], torch.arange(10.0)) and float(arena.flat[10:64].abs().sum()) == 0
+    (a.sum() * 2 + b.sum()).backward()
+    assert float(arena.grad[:10].sum()) == 20 and float(arena.grad[64:64 + 210].sum()) == 210
+    arena.zero_grad()
+    assert float(arena.grad.abs().sum()) == 0 and a.grad.data_ptr() == arena.grad.data_ptr()
+    assert arena.all_reduce() == 1.0  # no process group: no-op

@@ -304,3 +304,60 @@ def test_raygen_fixture(golden):
     close(out["directions"], g["directions"], atol=1e-7)
     close(out["pixel_area"], g["pixel_area"], rtol=1e-4)
     close(out["directions_norm"], g["directions_norm"], rtol=1e-6)
+
+
+# ---------------------------------------------------------------- C restatement -----------------------------------
+def _c_oracle():
+    import ctypes
+    import os
+    import subprocess
+
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    so = os.path.join(here, "liboracle_c.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", here], check=True)
+    return ctypes.CDLL(so)
+
+
+def test_c_oracle_hash_and_cdf(golden):
+    """oracle/hash_oracle.c (plain C, integer / ordering-critical pieces) == numpy/torch oracle == reference."""
+    import ctypes as C
+
+    lib = _c_oracle()
+    g = golden("hashgrid")
+    L, lo, hi, log2T, _ = [int(v) for v in g["cfg"]]
+    x = np.ascontiguousarray(g["x"], dtype=np.float32)
+    M = x.shape[0]
+    scal = orc.hash_level_scalings(L, lo, hi).numpy()
+    for lvl in range(L):
+        out = np.zeros((M, 8), dtype=np.int64)
+        lib.oracle_hash_corner_indices(x.ctypes.data_as(C.c_void_p), C.c_int64(M), C.c_float(float(scal[lvl])), lvl, log2T,
+                                       out.ctypes.data_as(C.c_void_p))
+        s = x * scal[lvl]
+        f, c = np.floor(s).astype(np.int32), np.ceil(s).astype(np.int32)
+        for corner in range(8):
+            ix = (c if corner & 1 else f)[:, 0]
+            iy = (c if corner & 2 else f)[:, 1]
+            iz = (c if corner & 4 else f)[:, 2]
+            np.testing.assert_array_equal(out[:, corner], orc.hash_corner_index(ix, iy, iz, lvl, 2**log2T))
+    # KAT of SURVEY §8c through the C path: corners of (3,7,11) at level 0 and (1,2,3) at level 1, T = 32
+    pts = np.array([[3, 7, 11], [1, 2, 3]], dtype=np.float32)
+    out = np.zeros((2, 8), dtype=np.int64)
+    lib.oracle_hash_corner_indices(pts.ctypes.data_as(C.c_void_p), C.c_int64(2), C.c_float(1.0), 0, 5, out.ctypes.data_as(C.c_void_p))
+    assert out[0, 0] == 19 and out[1, 0] + 32 == 60
+
+    gs = golden("samplers")
+    w = np.ascontiguousarray(gs["train_l0_weights"], dtype=np.float32)
+    n, S = w.shape
+    cdf = np.zeros((n, S + 1), dtype=np.float32)
+    lib.oracle_pdf_cdf(w.ctypes.data_as(C.c_void_p), C.c_int64(n), S, C.c_float(0.01), C.c_float(1e-5), cdf.ctypes.data_as(C.c_void_p))
+    dbg = {}
+    nears, fars = T(gs["nears"]), T(gs["fars"])
+    _, _, inds = orc.pdf_resample(T(gs["train_l0_s_bins"]), T(w), 96, T(gs["j1"]), nears, fars, debug=dbg)
+    np.testing.assert_array_equal(cdf, dbg["cdf"].numpy())  # same left-to-right fp32 arithmetic, bit for bit
+    u = np.ascontiguousarray(dbg["u"].numpy(), dtype=np.float32)
+    idx = np.zeros((n, 97), dtype=np.int32)
+    lib.oracle_searchsorted_right(cdf.ctypes.data_as(C.c_void_p), C.c_int64(n), S + 1, u.ctypes.data_as(C.c_void_p), 97,
+                                  idx.ctypes.data_as(C.c_void_p))
+    np.testing.assert_array_equal(idx, inds.numpy())
+    np.testing.assert_array_equal(idx, gs["train_l1_inds"])  # and equal to the reference's own indices
