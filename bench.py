@@ -62,17 +62,43 @@ def synthetic_batch(device, seed):
 
 
 class Trainer:
-    """The reference's Trainer.train_iteration (engine/trainer.py:487-531) for this path, minus logging."""
+    """The reference's Trainer.train_iteration (engine/trainer.py:487-531) for this path, minus logging.
 
-    def __init__(self, model, arena, ray_bundle, batch):
-        self.model, self.arena, self.rb, self.batch = model, arena, ray_bundle, batch
+    Eager mode runs the Python body every step. Graph mode captures that same body ONCE per schedule variant
+    (proposal networks updated this step / not updated, ray_samplers.py:590) into a hipGraph and replays it: ~60
+    kernel launches become one graph launch, which is what a 1-2 ms step needs (MI355X_MICROARCH.md price list:
+    eager goes host-bound below ~3 us per kernel). Everything that changes from step to step lives in device memory:
+    the ray batch, the jitter draws (graph-safe Philox), the anneal exponent and Adam's bias-corrected step size
+    (`hyper`, refreshed by an 12-byte async copy before each replay). With N > 1 the RCCL all-reduce of the gradient
+    arena runs eagerly between two captured halves (forward+backward | optimiser)."""
+
+    def __init__(self, model, arena, ray_bundle, batch, world=1, use_graph=True):
+        self.model, self.arena, self.rb, self.batch, self.world = model, arena, ray_bundle, batch, world
         self.step = 0
+        self.opt_step = 0
+        dev = ray_bundle.origins.device
+        self.hyper = torch.zeros(3, device=dev)  # [lr/(1-b1^t), 1/sqrt(1-b2^t), anneal]
+        self.hyper_host = torch.zeros(3).pin_memory()
+        self.loss_buf = torch.zeros((), device=dev)
+        model.proposal_sampler.anneal_dev = self.hyper[2:3]
+        self.graphs = None
+        self.use_graph = use_graph
 
-    def train_iteration(self):
+    # -- pieces of one iteration ---------------------------------------------------------------------------------
+    def _prologue(self):
+        from nerfstudio_amd import functional as F
+
+        m = self.model
+        m.set_step(self.step)  # BEFORE_TRAIN_ITERATION callback: proposal weight anneal
+        s, b = F.adam_hyper(self.opt_step + 1, self.arena.lr, self.arena.betas)
+        self.hyper_host[0], self.hyper_host[1], self.hyper_host[2] = s, b, m.proposal_sampler._anneal
+        self.hyper.copy_(self.hyper_host, non_blocking=True)
+
+    def _fwd_bwd(self, updated):
         from nerfstudio_amd.cameras.rays import RayBundle
 
         m = self.model
-        m.set_step(self.step)  # BEFORE_TRAIN_ITERATION callbacks
+        m.proposal_sampler.force_updated = updated
         self.arena.zero_grad()
         rb = RayBundle(origins=self.rb.origins, directions=self.rb.directions, pixel_area=self.rb.pixel_area,
                        camera_indices=self.rb.camera_indices)
@@ -81,11 +107,77 @@ class Trainer:
         loss_dict = m.get_loss_dict(out, self.batch, metrics)
         loss = loss_dict["rgb_loss"] + loss_dict["interlevel_loss"] + loss_dict["distortion_loss"]
         loss.backward()
-        scale = self.arena.all_reduce()
-        self.arena.step(grad_scale=scale)
-        m.after_step(self.step)  # AFTER_TRAIN_ITERATION callbacks
+        self.loss_buf.copy_(loss.detach())
+
+    def _optimise(self):
+        self.arena.step(grad_scale=1.0 / self.world, hyper_dev=self.hyper)
+
+    # -- graph capture ---------------------------------------------------------------------------------------------
+    def capture(self):
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # allocator / autograd warm-up of both variants on a side stream
+            for upd in (True, False):
+                self._prologue()
+                self._fwd_bwd(upd)
+                if self.world > 1:
+                    self.arena.all_reduce()
+                self._optimise()
+                self.opt_step += 1
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graphs = {}
+        for upd in (True, False):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._fwd_bwd(upd)
+                if self.world == 1:
+                    self._optimise()
+            graphs[upd] = g
+        if self.world > 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._optimise()
+            graphs["opt"] = g
+        self.graphs = graphs
+
+    def try_capture(self):
+        if not self.use_graph:
+            return False
+        try:
+            self.capture()
+            return True
+        except Exception as e:  # noqa: BLE001 - any capture problem degrades to the eager path, never to no result
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            self.graphs = None
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
+            return False
+
+    # -- one training iteration ------------------------------------------------------------------------------------
+    def train_iteration(self):
+        ps = self.model.proposal_sampler
+        updated = ps.updated_this_step()
+        self._prologue()
+        if self.graphs is not None:
+            self.graphs[updated].replay()
+            if self.world > 1:
+                self.arena.all_reduce()
+                self.graphs["opt"].replay()
+        else:
+            self._fwd_bwd(updated)
+            if self.world > 1:
+                self.arena.all_reduce()
+            self._optimise()
+        self.opt_step += 1
+        if updated:
+            ps.mark_updated()
+        self.model.after_step(self.step)  # AFTER_TRAIN_ITERATION callback
         self.step += 1
-        return loss
+        return self.loss_buf
 
 
 # algorithmic work per launch: bytes for the HBM-bound kernels, flops for the MFMA kernels
@@ -117,12 +209,14 @@ def algorithmic_model(key):
 def measure_roofline(trainer, arena, steps):
     from nerfstudio_amd import _native as N
 
+    graphs, trainer.graphs = trainer.graphs, None  # per-kernel events need eager launches
     N.PROFILE = {}
     for _ in range(steps):
         trainer.train_iteration()
     torch.cuda.synchronize()
     prof = N.profile_summary(N.PROFILE)
     N.PROFILE = None
+    trainer.graphs = graphs
     table = []
     for key, (calls, total_ms, mean_ms) in prof.items():
         bound, work = algorithmic_model(key)
@@ -145,9 +239,15 @@ def measure_roofline(trainer, arena, steps):
     return roof, table
 
 
-def cpu_baseline(n_rays=256, steps=3):
-    """The CPU oracle running the same training step (fwd + losses + bwd + Adam) on a bounded sample of rays."""
+def cpu_baseline(n_rays=256, steps=3, threads=None):
+    """The CPU oracle running the same training step (fwd + losses + bwd + Adam) on a bounded sample of rays.
+    Thread count: torch's CPU ops on this workload peak at ~16 threads on the MI355X host (measured 8/16/32/64/128
+    threads: 135/141/111/63/30 rays/s, profiles/r01_probe_scatter.log), so 16 is used rather than all cores."""
     from oracle import nerfacto_oracle as orc
+
+    if threads is None:
+        threads = min(16, os.cpu_count() or 16)
+    torch.set_num_threads(threads)
 
     cfg = orc.NerfactoCfg()
     params = orc.init_params(cfg, seed=0)
@@ -179,6 +279,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
     args = ap.parse_args()
@@ -195,16 +296,21 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
 
     from nerfstudio_amd import _native
+    from nerfstudio_amd import functional as F
     from nerfstudio_amd.arena import ParamArena
 
     _native.load()  # fail loudly if the HIP extension is missing
+    F.DIRECT_GRAD = True  # backward kernels accumulate straight into the arena's gradient views
     model = build_model(device, seed=0)  # same init on every rank (replicated model)
     arena = ParamArena(model.parameters(), lr=1e-2, eps=1e-15)  # AdamOptimizerConfig(lr=1e-2, eps=1e-15)
     arena.broadcast_params()
     rb, batch = synthetic_batch(device, seed=1000 + rank)  # each rank its own rays (scripts/train.py:98)
-    trainer = Trainer(model, arena, rb, batch)
+    trainer = Trainer(model, arena, rb, batch, world=world, use_graph=not args.no_graph)
 
-    for _ in range(args.warmup):
+    for _ in range(max(1, args.warmup // 2)):  # eager warm-up: lazy kernel attributes, caches, allocator
+        trainer.train_iteration()
+    graphed = trainer.try_capture()
+    for _ in range(args.warmup - max(1, args.warmup // 2)):
         trainer.train_iteration()
 
     if world > 1:
@@ -249,7 +355,8 @@ def main():
                                    "(BASELINE configs[1]); full training step incl. proposal nets 256->96, losses, Adam",
                        "rays_per_gpu": RAYS_PER_GPU, "global_rays": world * RAYS_PER_GPU,
                        "parallelism": f"dp{world}: rays sharded by batch, one RCCL all-reduce of the 77.7 MB gradient arena",
-                       "params": arena.numel, "final_loss": round(float(loss), 6)},
+                       "params": arena.numel, "final_loss": round(float(loss), 6),
+                       "launch": "hipGraph replay (2 captured variants)" if graphed else "eager"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -82,12 +82,17 @@ int nsamd_hashgrid_encode_fwd(nsamd_points pts, int64_t M, int transform, nsamd_
                               nsamd_grid grid, float* enc, int64_t stride_p, int64_t stride_k, float* selector,
                               nsamd_stream_t stream);
 
-/* Backward: dtable[L*T,2] += scatter of denc (fp32 atomics; caller zero-fills); dpositions (nullable) [M,3]
+/* Backward: dtable[L*T,2] += scatter of denc (caller zero-fills or accumulates); dpositions (nullable) [M,3]
  * receives dL/d(raw position) through offset = scaled - floor(scaled), the selector, the affine map and the
- * contraction Jacobian exactly as autograd differentiates the reference (SURVEY.md §8a gradient-flow facts). */
+ * contraction Jacobian exactly as autograd differentiates the reference (SURVEY.md §8a gradient-flow facts).
+ * The scatter is partitioned into LDS-owned (level, slice) tiles (no global atomics, see csrc/hashgrid.hip);
+ * `workspace` (nullable, `workspace_floats` words of device scratch) enables the binned two-pass path: it must be
+ * ZERO-INITIALISED ONCE by its owner (the per-tile queue cursors at its start are left at zero by every call) and
+ * hold >= tiles * (1 + 3 * 1.25 * 8 * M / tiles_per_level) words; smaller or NULL selects the scratch-free scan. */
 int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
                               nsamd_grid grid, const float* denc, int64_t stride_p, int64_t stride_k,
-                              float* dtable, float* dpositions, nsamd_stream_t stream);
+                              float* dtable, float* dpositions, float* workspace, int64_t workspace_floats,
+                              nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * SH encoding, 4 levels = 16 components (SHEncoding.pytorch_fwd, encodings.py:791-794 ->
@@ -177,11 +182,13 @@ int nsamd_weights_bwd(const float* t_bins, const float* density, const float* dw
 /* PDFSampler.generate_ray_samples, include_original=False (ray_samplers.py:276-372) preceded by the anneal
  * pow(weights, anneal) (ray_samplers.py:601; skipped when anneal == 1). inds (nullable) receives the
  * searchsorted(side="right") result as int32 [num_rays, S+1]. u_offset = (float)(1.0 / (2 * (S+1))) is the eval-mode
- * offset (ray_samplers.py:327), rounded double->float by the host like torch rounds the Python scalar. */
+ * offset (ray_samplers.py:327), rounded double->float by the host like torch rounds the Python scalar.
+ * anneal_dev (nullable): device copy of the anneal exponent; overrides `anneal` so that a captured hipGraph of the
+ * training step can be replayed while the schedule advances. */
 int nsamd_pdf_resample(const float* s_bins_prev, const float* weights, int32_t S_prev, const float* u_base,
                        const float* jitter, const float* nears, const float* fars, float anneal,
-                       float histogram_padding, float eps, float u_offset, int64_t num_rays, int32_t S,
-                       float* s_bins, float* t_bins, int32_t* inds, nsamd_stream_t stream);
+                       const float* anneal_dev, float histogram_padding, float eps, float u_offset, int64_t num_rays,
+                       int32_t S, float* s_bins, float* t_bins, int32_t* inds, nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Compositing (model_components/renderers.py): RGBRenderer.combine_rgb :72-119 (+ eval nan_to_num/clamp
@@ -189,7 +196,8 @@ int nsamd_pdf_resample(const float* s_bins_prev, const float* weights, int32_t S
  * background: 0 = "random"/none, 1 = "last_sample", 2 = constant colour bg_rgb[3] (host values).
  * Outputs (any may be NULL): rgb_out [N,3], acc [N], depth_expected [N] (clipped to the batch-global min/max of
  * the sample midpoints, as the reference does), depth_median [N], median_idx [N] int32.
- * `workspace` = 2 floats of device scratch (global min / max), only needed when depth_expected != NULL.
+ * `workspace` = 2 + 2*ceil(num_rays/4) floats of device scratch (final and per-workgroup min / max of the sample
+ * midpoints), only needed when depth_expected != NULL; words 0..1 are read again by the backward.
  * ------------------------------------------------------------------------------------------------------------ */
 int nsamd_composite_fwd(const float* rgb, const float* weights, const float* t_bins, int64_t num_rays, int32_t S,
                         int background, const float* bg_rgb_host, int eval_mode, float* rgb_out, float* acc,
@@ -228,9 +236,12 @@ int nsamd_raygen_pinhole(const int64_t* ray_indices, const float* c2w, const flo
  * Fused Adam over a flat fp32 arena (engine/optimizers.py:74-193 with AdamOptimizerConfig(lr, eps=1e-15),
  * torch.optim.Adam semantics: bias-corrected, no weight decay, no amsgrad). grad_scale multiplies the gradient
  * first (1/world_size for the data-parallel mean, or the inverse loss scale). step is 1-based.
+ * hyper_dev (nullable): device floats {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)} overriding the values derived
+ * from (lr, step) — lets a captured hipGraph be replayed across steps.
  * ------------------------------------------------------------------------------------------------------------ */
 int nsamd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                    float beta1, float beta2, float eps, int32_t step, float grad_scale, nsamd_stream_t stream);
+                    float beta1, float beta2, float eps, int32_t step, float grad_scale, const float* hyper_dev,
+                    nsamd_stream_t stream);
 
 /* Library / device introspection. */
 const char* nsamd_version(void);

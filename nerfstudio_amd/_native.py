@@ -57,7 +57,7 @@ class FieldMlpGrads(C.Structure):
 # tests/test_abi.py checks that every symbol declared in the header is exported by the library and listed here.
 _SIGNATURES = {
     "nsamd_hashgrid_encode_fwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp],
-    "nsamd_hashgrid_encode_bwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, vp],
+    "nsamd_hashgrid_encode_bwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, vp, i64, vp],
     "nsamd_sh4_encode": [vp, i64, vp, vp],
     "nsamd_contract_linf": [vp, i64, vp, vp],
     "nsamd_density_mlp_fwd": [vp, vp, i64, DensityMlp, vp, vp, vp],
@@ -67,13 +67,13 @@ _SIGNATURES = {
     "nsamd_piecewise_bins": [vp, vp, vp, vp, i64, i32, vp, vp, vp],
     "nsamd_weights_fwd": [vp, vp, i64, i32, vp, vp],
     "nsamd_weights_bwd": [vp, vp, vp, i64, i32, vp, vp],
-    "nsamd_pdf_resample": [vp, vp, i32, vp, vp, vp, vp, f32, f32, f32, f32, i64, i32, vp, vp, vp, vp],
+    "nsamd_pdf_resample": [vp, vp, i32, vp, vp, vp, vp, f32, vp, f32, f32, f32, i64, i32, vp, vp, vp, vp],
     "nsamd_composite_fwd": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), C.c_int, vp, vp, vp, vp, vp, vp, vp],
     "nsamd_composite_bwd": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, vp, vp, vp, vp, vp, vp],
     "nsamd_interlevel_loss": [vp, vp, i32, vp, vp, i32, i64, f32, vp, vp, vp],
     "nsamd_distortion_loss": [vp, vp, i32, i64, f32, vp, vp, vp],
     "nsamd_raygen_pinhole": [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp],
-    "nsamd_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp],
+    "nsamd_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, vp],
     "nsamd_version": [],
     "nsamd_status_string": [C.c_int],
     "nsamd_device_info": [C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32],

@@ -75,7 +75,9 @@ class ParamArena:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.broadcast(self.flat, src=src, group=group)
 
-    def step(self, grad_scale: float = 1.0, lr: Optional[float] = None) -> None:
+    def step(self, grad_scale: float = 1.0, lr: Optional[float] = None, hyper_dev: Optional[torch.Tensor] = None) -> None:
+        """One Adam update of the whole arena. With `hyper_dev` (device floats from functional.adam_hyper) the launch
+        carries no step-dependent host value and can be replayed from a captured hipGraph."""
         self.step_count += 1
         F.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, lr if lr is not None else self.lr,
-                    self.betas, self.eps, grad_scale)
+                    self.betas, self.eps, grad_scale, hyper_dev)

@@ -8,8 +8,23 @@
 // The feature-major output (stride_p = 1) makes the 8-B-per-point result store one coalesced 256-B row per
 // wavefront and feature; the [M, 2L] row-major layout of the stand-alone Encoding API is the strided variant.
 //
-// HBM-bound integer/gather work: no LDS, no MFMA. Algorithmic bytes: 8 corners x 8 B per point and level (fwd),
-// 8 corners x 2 atomics x 4 B (bwd).
+// HBM-bound integer/gather work, no MFMA. Algorithmic bytes: 8 corners x 8 B per point and level (fwd),
+// 8 corners x 16 B read-modify-write (bwd).
+//
+// Backward = scatter-add into the table gradient. Measured on MI355X (scripts/probe_scatter.py, profiles/): fp32
+// global atomics retire at a flat ~20 G lane-ops/s chip-wide whatever the locality (they are serviced memory-side,
+// past the per-XCD L2s; contended coarse levels drop to 6 G/s) — 15x below the gather rate, 2.9 ms for the nerfacto
+// main table. So the big scatter uses NO global atomics: the table gradient is partitioned into (level, 16K-entry
+// slice) tiles of 128 KiB; one 1024-thread workgroup OWNS a tile in LDS, scans the sample points, adds the corner
+// contributions that hash into its slice with LDS atomics (ds_add_f32: thousands of lane-ops per clock chip-wide),
+// and writes the tile back with plain coalesced stores. Re-deriving the 8 hashes per (point, level) once per slice
+// costs ALU (measured 0.70 ms for the main table, 32 slices per level). With scratch memory from the caller the
+// redundancy goes away too ("binned" path, the default): pass 1 derives every corner update ONCE and appends
+// (local index, g0, g1) to the queue of the tile it falls into — a workgroup-local counting sort in LDS, one
+// returning global atomic per (workgroup, non-empty tile) to reserve queue space, 12-B records written in runs; pass
+// 2 runs one workgroup per tile that streams its queue into the LDS tile and stores it. Queues are sized 2x the
+// uniform-hash expectation; the rare overflow falls back to a direct atomic, so the result never depends on sizing.
+// Tiny problems keep the direct-atomic kernel.
 #include "common.h"
 
 namespace nsamd {
@@ -82,6 +97,161 @@ __global__ __launch_bounds__(kHashBlock) void hash_encode_bwd_table_kernel(
     const uint32_t idx = corner_index(c, k, mask);
     unsafeAtomicAdd(tl + 2 * (size_t)idx + 0, ((g0 * bz) * by) * bx);
     unsafeAtomicAdd(tl + 2 * (size_t)idx + 1, ((g1 * bz) * by) * bx);
+  }
+}
+
+// ---- partitioned scatter (see the header comment) ----------------------------------------------------------------
+constexpr int kSliceLog2Max = 14;  // 16384 entries x 2 floats = 128 KiB of the 160 KiB LDS
+constexpr int kSliceThreads = 1024;
+
+__global__ __launch_bounds__(kSliceThreads) void hash_encode_bwd_sliced_kernel(
+    nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
+    int64_t stride_p, int64_t stride_k, float* __restrict__ dst, int64_t dst_chunk_stride, int accumulate) {
+  extern __shared__ float acc[];  // [slice_entries][2]
+  const int slice = blockIdx.x, level = blockIdx.y, chunk = blockIdx.z, chunks = gridDim.z;
+  const int slice_log2 = min(grid.log2_table_size, kSliceLog2Max);
+  const int slice_entries = 1 << slice_log2;
+  for (int e = threadIdx.x; e < 2 * slice_entries; e += kSliceThreads) acc[e] = 0.0f;
+  __syncthreads();
+  const int64_t per = (M + chunks - 1) / chunks;
+  const int64_t p_end = min(M, (int64_t)(chunk + 1) * per);
+  const uint32_t mask = (1u << grid.log2_table_size) - 1u;
+  const float scale = grid.scalings[level];
+  for (int64_t p = (int64_t)chunk * per + threadIdx.x; p < p_end; p += kSliceThreads) {
+    const float* gptr = denc + p * stride_p + (int64_t)(2 * level) * stride_k;
+    const float g0 = gptr[0], g1 = gptr[stride_k];
+    if (g0 == 0.0f && g1 == 0.0f) continue;
+    float x, y, z;
+    load_position(P, p, x, y, z);
+    (void)normalise_position(transform, box, x, y, z);
+    const Cell c = locate_cell(x, y, z, scale);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t idx = corner_index(c, k, mask);
+      if ((int)(idx >> slice_log2) == slice) {
+        const float bz = (k & 4) ? c.w[2] : 1.0f - c.w[2];
+        const float by = (k & 2) ? c.w[1] : 1.0f - c.w[1];
+        const float bx = (k & 1) ? c.w[0] : 1.0f - c.w[0];
+        const uint32_t local = idx & (uint32_t)(slice_entries - 1);
+        atomicAdd(acc + 2 * local + 0, ((g0 * bz) * by) * bx);  // ds_add_f32
+        atomicAdd(acc + 2 * local + 1, ((g1 * bz) * by) * bx);
+      }
+    }
+  }
+  __syncthreads();
+  float* out = dst + (int64_t)chunk * dst_chunk_stride +
+               ((((size_t)level << grid.log2_table_size) + ((size_t)slice << slice_log2)) << 1);
+  if (accumulate) {
+    for (int e = threadIdx.x; e < 2 * slice_entries; e += kSliceThreads) out[e] += acc[e];  // sole owner of the tile
+  } else {
+    for (int e = threadIdx.x; e < 2 * slice_entries; e += kSliceThreads) out[e] = acc[e];
+  }
+}
+
+// ---- binned scatter: pass 1 (route) + pass 2 (apply) -------------------------------------------------------------
+constexpr int kBinThreads = 1024;
+constexpr int kMaxBins = 4096;
+
+__global__ __launch_bounds__(kBinThreads) void hash_bwd_bin_kernel(
+    nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
+    int64_t stride_p, int64_t stride_k, int slice_log2, uint32_t cap, uint32_t* __restrict__ cursors,
+    uint32_t* __restrict__ queues, float* __restrict__ dtable) {
+  extern __shared__ uint32_t lds_u[];
+  const int level = blockIdx.y;
+  const int B = 1 << (grid.log2_table_size - slice_log2);
+  uint32_t* cnt = lds_u;        // [B] updates of this workgroup per tile
+  uint32_t* base = lds_u + B;   // [B] reserved queue offset per tile
+  for (int t = threadIdx.x; t < B; t += kBinThreads) cnt[t] = 0;
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * kBinThreads + threadIdx.x;
+  bool active = p < M;
+  float g0 = 0.f, g1 = 0.f;
+  if (active) {
+    const float* gptr = denc + p * stride_p + (int64_t)(2 * level) * stride_k;
+    g0 = gptr[0];
+    g1 = gptr[stride_k];
+    active = !(g0 == 0.0f && g1 == 0.0f);
+  }
+  uint32_t idx[8], rank[8];
+  Cell c;
+  if (active) {
+    float x, y, z;
+    load_position(P, p, x, y, z);
+    (void)normalise_position(transform, box, x, y, z);
+    c = locate_cell(x, y, z, grid.scalings[level]);
+    const uint32_t mask = (1u << grid.log2_table_size) - 1u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      idx[k] = corner_index(c, k, mask);
+      rank[k] = atomicAdd(cnt + (idx[k] >> slice_log2), 1u);  // ds_add_rtn_u32
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < B; t += kBinThreads) {
+    const uint32_t n = cnt[t];
+    base[t] = n ? atomicAdd(cursors + (size_t)level * B + t, n) : 0u;
+  }
+  __syncthreads();
+  if (active) {
+    const uint32_t local_mask = (1u << slice_log2) - 1u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float bz = (k & 4) ? c.w[2] : 1.0f - c.w[2];
+      const float by = (k & 2) ? c.w[1] : 1.0f - c.w[1];
+      const float bx = (k & 1) ? c.w[0] : 1.0f - c.w[0];
+      const float v0 = ((g0 * bz) * by) * bx, v1 = ((g1 * bz) * by) * bx;
+      const uint32_t bin = idx[k] >> slice_log2;
+      const uint32_t pos = base[bin] + rank[k];
+      if (pos < cap) {
+        uint32_t* q = queues + (((size_t)level * B + bin) * cap + pos) * 3;
+        q[0] = idx[k] & local_mask;
+        q[1] = __float_as_uint(v0);
+        q[2] = __float_as_uint(v1);
+      } else {  // queue full (a very hot cell): direct atomics keep the result exact
+        float* t = dtable + ((((size_t)level << grid.log2_table_size) + idx[k]) << 1);
+        unsafeAtomicAdd(t + 0, v0);
+        unsafeAtomicAdd(t + 1, v1);
+      }
+    }
+  }
+}
+
+__global__ void hash_bwd_apply_kernel(nsamd_grid grid, int slice_log2, uint32_t cap,
+                                      const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ queues,
+                                      float* __restrict__ dtable) {
+  extern __shared__ float acc[];
+  const int bin = blockIdx.x, level = blockIdx.y;
+  const int B = gridDim.x;
+  const int entries = 1 << slice_log2;
+  for (int e = threadIdx.x; e < 2 * entries; e += blockDim.x) acc[e] = 0.0f;
+  __syncthreads();
+  const uint32_t n = min(cursors[(size_t)level * B + bin], cap);
+  __syncthreads();
+  // self-cleaning cursor: the next launch finds zeros again, so no memset node is needed per call (the workspace is
+  // zero-initialised once by its owner)
+  if (threadIdx.x == 0) const_cast<uint32_t*>(cursors)[(size_t)level * B + bin] = 0u;
+  const uint32_t* q = queues + ((size_t)level * B + bin) * cap * 3;
+  for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+    const uint32_t local = q[3 * e];
+    atomicAdd(acc + 2 * local + 0, __uint_as_float(q[3 * e + 1]));  // ds_add_f32
+    atomicAdd(acc + 2 * local + 1, __uint_as_float(q[3 * e + 2]));
+  }
+  __syncthreads();
+  float* out = dtable + ((((size_t)level << grid.log2_table_size) + ((size_t)bin << slice_log2)) << 1);
+  for (int e = threadIdx.x; e < 2 * entries; e += blockDim.x) out[e] += acc[e];  // sole owner of the tile
+}
+
+// dtable[i] += sum over chunks of partial[c][i]
+__global__ void hash_partial_reduce_kernel(const float* __restrict__ partial, int chunks, int64_t n,
+                                           float* __restrict__ dtable) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 s = reinterpret_cast<const float4*>(dtable)[i];
+    for (int c = 0; c < chunks; ++c) {
+      const float4 v = reinterpret_cast<const float4*>(partial + (int64_t)c * n)[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(dtable)[i] = s;
   }
 }
 
@@ -207,10 +377,21 @@ extern "C" int nsamd_hashgrid_encode_fwd(nsamd_points pts, int64_t M, int transf
   return NSAMD_OK;
 }
 
+static int device_cus() {
+  static int cached = 0;
+  if (cached == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    cached = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return cached;
+}
+
 extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb,
                                          const float* table, nsamd_grid grid, const float* denc, int64_t stride_p,
-                                         int64_t stride_k, float* dtable, float* dpositions,
-                                         nsamd_stream_t stream) {
+                                         int64_t stride_k, float* dtable, float* dpositions, float* workspace,
+                                         int64_t workspace_floats, nsamd_stream_t stream) {
   if (M == 0) return NSAMD_OK;
   int st = check_points(pts, M);
   if (st) return st;
@@ -222,11 +403,92 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
   if (M == 0) return NSAMD_OK;
   const int64_t nb = (M + kHashBlock - 1) / kHashBlock;
   if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
-  if (dtable != nullptr) {
+  if (dtable != nullptr && M < 8192) {
+    // small batches: direct fire-and-forget atomics (zeroing / writing whole tiles would dominate)
     dim3 g((unsigned)nb, (unsigned)grid.num_levels);
     hash_encode_bwd_table_kernel<<<g, kHashBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, grid, denc,
                                                                              stride_p, stride_k, dtable);
     NSAMD_CHECK_LAUNCH();
+  } else if (dtable != nullptr && [&]() -> bool {
+               // binned path: tile size chosen so that (tiles = bins x levels) >= 512 fills the chip
+               int bits = 0;
+               while ((grid.num_levels << bits) < 512) ++bits;
+               int sl = grid.log2_table_size - bits;
+               sl = sl > kSliceLog2Max ? kSliceLog2Max : (sl < 8 ? 8 : sl);
+               if (sl > grid.log2_table_size) sl = grid.log2_table_size;
+               const int64_t B = (int64_t)1 << (grid.log2_table_size - sl);
+               if (workspace == nullptr || B > kMaxBins) return false;
+               const int64_t tiles = B * grid.num_levels;
+               const int64_t cap = (workspace_floats - tiles) / (3 * tiles);
+               const int64_t expect = (8 * M + B - 1) / B;  // uniform hashing: updates per tile
+               return cap >= expect + expect / 4 && cap < 0x7fffffffLL;
+             }()) {
+    int bits = 0;
+    while ((grid.num_levels << bits) < 512) ++bits;
+    int sl = grid.log2_table_size - bits;
+    sl = sl > kSliceLog2Max ? kSliceLog2Max : (sl < 8 ? 8 : sl);
+    if (sl > grid.log2_table_size) sl = grid.log2_table_size;
+    const int B = 1 << (grid.log2_table_size - sl);
+    const int64_t tiles = (int64_t)B * grid.num_levels;
+    const uint32_t cap = (uint32_t)((workspace_floats - tiles) / (3 * tiles));
+    uint32_t* cursors = reinterpret_cast<uint32_t*>(workspace);
+    uint32_t* queues = cursors + tiles;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g1((unsigned)((M + kBinThreads - 1) / kBinThreads), (unsigned)grid.num_levels);
+    hash_bwd_bin_kernel<<<g1, kBinThreads, sizeof(uint32_t) * 2 * B, st>>>(pts, M, transform, aabb, grid, denc, stride_p,
+                                                                       stride_k, sl, cap, cursors, queues, dtable);
+    NSAMD_CHECK_LAUNCH();
+    static bool attr2 = false;
+    if (!attr2) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hash_bwd_apply_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sizeof(float) << kSliceLog2Max) !=
+          hipSuccess)
+        return NSAMD_ERR_LAUNCH;
+      attr2 = true;
+    }
+    dim3 g2((unsigned)B, (unsigned)grid.num_levels);
+    const unsigned threads = sl > 11 ? 1024u : 256u;
+    hash_bwd_apply_kernel<<<g2, threads, sizeof(float) * 2 * ((size_t)1 << sl), st>>>(grid, sl, cap, cursors, queues,
+                                                                                    dtable);
+    NSAMD_CHECK_LAUNCH();
+  } else if (dtable != nullptr) {
+    const int slice_log2 = grid.log2_table_size < kSliceLog2Max ? grid.log2_table_size : kSliceLog2Max;
+    const int slices = 1 << (grid.log2_table_size - slice_log2);
+    const size_t lds = sizeof(float) * 2 * ((size_t)1 << slice_log2);
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hash_encode_bwd_sliced_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sizeof(float) << kSliceLog2Max) !=
+          hipSuccess)
+        return NSAMD_ERR_LAUNCH;
+      attr_set = true;
+    }
+    const int64_t table_floats = ((int64_t)grid.num_levels << grid.log2_table_size) * 2;
+    // split the points into chunks until the grid covers ~2 workgroups per CU (needs workspace for the partials)
+    int chunks = 1;
+    const int tiles = slices * grid.num_levels;
+    if (workspace != nullptr && tiles < 2 * device_cus()) {
+      chunks = (2 * device_cus() + tiles - 1) / tiles;
+      const int64_t fit = workspace_floats / table_floats;
+      if (chunks > fit) chunks = (int)fit;
+      if (chunks > 32) chunks = 32;
+      const int64_t max_by_points = (M + 4095) / 4096;  // keep >= 4096 points per chunk
+      if (chunks > max_by_points) chunks = (int)max_by_points;
+      if (chunks < 1) chunks = 1;
+    }
+    dim3 g((unsigned)slices, (unsigned)grid.num_levels, (unsigned)chunks);
+    if (chunks == 1) {
+      hash_encode_bwd_sliced_kernel<<<g, kSliceThreads, lds, (hipStream_t)stream>>>(
+          pts, M, transform, aabb, grid, denc, stride_p, stride_k, dtable, 0, /*accumulate=*/1);
+      NSAMD_CHECK_LAUNCH();
+    } else {
+      hash_encode_bwd_sliced_kernel<<<g, kSliceThreads, lds, (hipStream_t)stream>>>(
+          pts, M, transform, aabb, grid, denc, stride_p, stride_k, workspace, table_floats, /*accumulate=*/0);
+      NSAMD_CHECK_LAUNCH();
+      const unsigned rb = (unsigned)((table_floats / 4 + 255) / 256 < 4096 ? (table_floats / 4 + 255) / 256 : 4096);
+      hash_partial_reduce_kernel<<<rb, 256, 0, (hipStream_t)stream>>>(workspace, chunks, table_floats, dtable);
+      NSAMD_CHECK_LAUNCH();
+    }
   }
   if (dpositions != nullptr) {
     NSAMD_REQUIRE(table != nullptr);

@@ -59,8 +59,10 @@ __global__ void raygen_pinhole_kernel(const int64_t* __restrict__ ray_indices, c
 // torch.optim.Adam (no amsgrad / weight decay / maximize): one pass over the flat arena, 16 B per lane.
 // bias corrections are folded by the host into step_size = lr / (1 - b1^t) and inv_sqrt_bc2 = 1 / sqrt(1 - b2^t).
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, int64_t n, float beta1, float beta2, float eps, float step_size,
-                            float inv_sqrt_bc2, float grad_scale) {
+                            float* __restrict__ v, int64_t n, float beta1, float beta2, float eps, float step_size_host,
+                            float inv_sqrt_bc2_host, const float* __restrict__ hyper_dev, float grad_scale) {
+  const float step_size = hyper_dev ? hyper_dev[0] : step_size_host;
+  const float inv_sqrt_bc2 = hyper_dev ? hyper_dev[1] : inv_sqrt_bc2_host;
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -116,7 +118,7 @@ extern "C" int nsamd_raygen_pinhole(const int64_t* ray_indices, const float* c2w
 
 extern "C" int nsamd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                                float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,
-                               nsamd_stream_t stream) {
+                               const float* hyper_dev, nsamd_stream_t stream) {
   NSAMD_REQUIRE(n >= 0 && step >= 1);
   if (n == 0) return NSAMD_OK;
   NSAMD_REQUIRE(params && grads && exp_avg && exp_avg_sq);
@@ -128,7 +130,7 @@ extern "C" int nsamd_adam_step(float* params, const float* grads, float* exp_avg
   const int64_t n4 = (n + 3) / 4;
   const unsigned blocks = (unsigned)min((int64_t)256 * 8, (n4 + 255) / 256);
   adam_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, beta1, beta2, eps,
-                                                       step_size, inv_sqrt_bc2, grad_scale);
+                                                       step_size, inv_sqrt_bc2, hyper_dev, grad_scale);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

@@ -6,8 +6,9 @@
 // read as contiguous, fully coalesced segments; the five running sums collapse with a 6-step xor-shuffle wave
 // reduction. The median depth needs the reference's left-to-right running weight sum (the integer index must match
 // bit-for-bit), so lane 0 walks the row once in LDS. The expected depth is clipped to the batch-GLOBAL min/max of
-// the sample midpoints as the reference does, which needs a device-wide min/max: ordered-uint atomics into a 2-word
-// workspace + a finishing pass.
+// the sample midpoints as the reference does, which needs a device-wide min/max: every workgroup stores its partial
+// min/max (no atomics: 8192 same-address device atomics cost ~100 us on this part, measured) and the finishing pass
+// re-reduces the <= few thousand partials from L2 before clipping.
 #include "common.h"
 
 namespace nsamd {
@@ -39,20 +40,24 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__global__ void minmax_init_kernel(uint32_t* ws) {
-  ws[0] = float_key(__uint_as_float(0x7f800000u));  // +inf (running min)
-  ws[1] = float_key(__uint_as_float(0xff800000u));  // -inf (running max)
-}
 
 __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
     const float* __restrict__ rgb, const float* __restrict__ weights, const float* __restrict__ t_bins,
     int64_t num_rays, int S, int background, float bg_r, float bg_g, float bg_b, int eval_mode,
     float* __restrict__ rgb_out, float* __restrict__ acc_out, float* __restrict__ depth_exp,
-    float* __restrict__ depth_med, int32_t* __restrict__ med_idx, uint32_t* __restrict__ ws) {
+    float* __restrict__ depth_med, int32_t* __restrict__ med_idx, float* __restrict__ ws) {
   extern __shared__ float lds[];
+  __shared__ float blk_min[kRaysPerBlock], blk_max[kRaysPerBlock];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wave;
-  if (ray >= num_rays) return;
+  const bool want_minmax = t_bins != nullptr && depth_exp != nullptr;
+  if (ray >= num_rays) {  // tail workgroup: idle waves still take part in the partial min/max
+    if (want_minmax) {
+      if (lane == 0) { blk_min[wave] = __uint_as_float(0x7f800000u); blk_max[wave] = __uint_as_float(0xff800000u); }
+      __syncthreads();
+    }
+    return;
+  }
   float* wrow = lds + wave * S;
   const float* w_in = weights + ray * S;
   const float* tb = t_bins ? t_bins + ray * (S + 1) : nullptr;
@@ -117,8 +122,16 @@ __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
     tmax = wave_max(tmax);
     if (lane == 0) {
       depth_exp[ray] = sd / (sw + 1e-10f);  // clipped by the finishing pass
-      atomicMin(ws + 0, float_key(tmin));
-      atomicMax(ws + 1, float_key(tmax));
+      blk_min[wave] = tmin;
+      blk_max[wave] = tmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float lo = blk_min[0], hi = blk_max[0];
+#pragma unroll
+      for (int i = 1; i < kRaysPerBlock; ++i) { lo = fminf(lo, blk_min[i]); hi = fmaxf(hi, blk_max[i]); }
+      ws[2 + 2 * blockIdx.x] = lo;  // partials live after the two final words
+      ws[3 + 2 * blockIdx.x] = hi;
     }
   }
   if (tb && (depth_med || med_idx)) {
@@ -126,9 +139,10 @@ __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
     if (lane == 0) {  // searchsorted(cumsum(w), 0.5, side="left"), clamped  (renderers.py:359-362)
       double run = 0.0;  // torch.cumsum (CPU): double accumulator, each output rounded to fp32
       int idx = S;
-      for (int s = 0; s < S; ++s) {
+#pragma unroll 8
+      for (int s = 0; s < S; ++s) {  // no early exit: lets the LDS reads run ahead of the dependent adds
         run = run + (double)wrow[s];
-        if ((float)run >= 0.5f) { idx = s; break; }
+        idx = (idx == S && (float)run >= 0.5f) ? s : idx;
       }
       idx = min(idx, S - 1);
       if (med_idx) med_idx[ray] = idx;
@@ -137,18 +151,35 @@ __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
   }
 }
 
-__global__ void depth_clip_kernel(float* __restrict__ depth, int64_t n, const uint32_t* __restrict__ ws) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float lo = key_float(ws[0]), hi = key_float(ws[1]);
-  depth[i] = fminf(fmaxf(depth[i], lo), hi);  // torch.clip(depth, steps.min(), steps.max())
+__global__ void depth_clip_kernel(float* __restrict__ depth, int64_t n, float* __restrict__ ws, int partials) {
+  __shared__ float s_lo[256], s_hi[256];
+  float lo = __uint_as_float(0x7f800000u), hi = __uint_as_float(0xff800000u);
+  for (int i = threadIdx.x; i < partials; i += 256) {
+    lo = fminf(lo, ws[2 + 2 * i]);
+    hi = fmaxf(hi, ws[3 + 2 * i]);
+  }
+  s_lo[threadIdx.x] = lo;
+  s_hi[threadIdx.x] = hi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      s_lo[threadIdx.x] = fminf(s_lo[threadIdx.x], s_lo[threadIdx.x + o]);
+      s_hi[threadIdx.x] = fmaxf(s_hi[threadIdx.x], s_hi[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  lo = s_lo[0];
+  hi = s_hi[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { ws[0] = lo; ws[1] = hi; }  // kept for the backward's clip mask
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) depth[i] = fminf(fmaxf(depth[i], lo), hi);  // torch.clip(depth, steps.min(), steps.max())
 }
 
 __global__ __launch_bounds__(kRenderThreads) void composite_bwd_kernel(
     const float* __restrict__ rgb, const float* __restrict__ weights, const float* __restrict__ t_bins,
     int64_t num_rays, int S, int background, float bg_r, float bg_g, float bg_b,
     const float* __restrict__ d_rgb_out, const float* __restrict__ d_acc, const float* __restrict__ d_depth,
-    const uint32_t* __restrict__ ws, float* __restrict__ d_rgb, float* __restrict__ d_weights) {
+    const float* __restrict__ ws, float* __restrict__ d_rgb, float* __restrict__ d_weights) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wave;
   if (ray >= num_rays) return;
@@ -178,7 +209,7 @@ __global__ __launch_bounds__(kRenderThreads) void composite_bwd_kernel(
   if (tb) {
     const float den = sw + 1e-10f;
     const float raw = sd / den;
-    const float lo = key_float(ws[0]), hi = key_float(ws[1]);
+    const float lo = ws[0], hi = ws[1];
     const float gd = (raw >= lo && raw <= hi) ? d_depth[ray] : 0.f;
     g_num = gd / den;
     g_den = -gd * sd / (den * den);
@@ -219,11 +250,7 @@ extern "C" int nsamd_composite_fwd(const float* rgb, const float* weights, const
   NSAMD_REQUIRE(depth_expected == nullptr || workspace != nullptr);
   if (S > 4096) return NSAMD_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
-  if (depth_expected) {
-    minmax_init_kernel<<<1, 1, 0, st>>>(ws);
-    NSAMD_CHECK_LAUNCH();
-  }
+  float* ws = workspace;
   const unsigned blocks = (unsigned)((num_rays + kRaysPerBlock - 1) / kRaysPerBlock);
   const float br = bg_rgb_host ? bg_rgb_host[0] : 0.f, bg = bg_rgb_host ? bg_rgb_host[1] : 0.f,
               bb = bg_rgb_host ? bg_rgb_host[2] : 0.f;
@@ -232,7 +259,7 @@ extern "C" int nsamd_composite_fwd(const float* rgb, const float* weights, const
       depth_expected, depth_median, median_idx, ws);
   NSAMD_CHECK_LAUNCH();
   if (depth_expected) {
-    depth_clip_kernel<<<(unsigned)((num_rays + 255) / 256), 256, 0, st>>>(depth_expected, num_rays, ws);
+    depth_clip_kernel<<<(unsigned)((num_rays + 255) / 256), 256, 0, st>>>(depth_expected, num_rays, ws, (int)blocks);
     NSAMD_CHECK_LAUNCH();
   }
   return NSAMD_OK;
@@ -252,8 +279,7 @@ extern "C" int nsamd_composite_bwd(const float* rgb, const float* weights, const
   const float br = bg_rgb_host ? bg_rgb_host[0] : 0.f, bg = bg_rgb_host ? bg_rgb_host[1] : 0.f,
               bb = bg_rgb_host ? bg_rgb_host[2] : 0.f;
   composite_bwd_kernel<<<blocks, kRenderThreads, 0, (hipStream_t)stream>>>(
-      rgb, weights, t_bins, num_rays, S, background, br, bg, bb, d_rgb_out, d_acc, d_depth,
-      reinterpret_cast<const uint32_t*>(workspace), d_rgb, d_weights);
+      rgb, weights, t_bins, num_rays, S, background, br, bg, bb, d_rgb_out, d_acc, d_depth, workspace, d_rgb, d_weights);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

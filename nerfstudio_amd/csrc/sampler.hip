@@ -69,6 +69,7 @@ __global__ __launch_bounds__(kThreads) void weights_fwd_kernel(const float* __re
     const float* d = dd + threadIdx.x * ld;
     float* a = acc + threadIdx.x * ld;
     double run = 0.0;  // torch.cumsum on CPU: double accumulator, fp32 outputs
+#pragma unroll 8
     for (int i = 0; i < S; ++i) {
       a[i] = (float)run;
       run = run + (double)d[i];
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
     const float* d = dd + threadIdx.x * ld;
     float* a = acc + threadIdx.x * ld;
     double run = 0.0;  // torch.cumsum on CPU: double accumulator, fp32 outputs
+#pragma unroll 8
     for (int i = 0; i < S; ++i) {
       a[i] = (float)run;
       run = run + (double)d[i];
@@ -151,7 +153,8 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
 __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     const float* __restrict__ s_bins_prev, const float* __restrict__ weights, int S_prev,
     const float* __restrict__ u_base, const float* __restrict__ jitter, const float* __restrict__ nears,
-    const float* __restrict__ fars, float anneal, float hist_pad, float eps, float u_offset, int64_t num_rays, int S,
+    const float* __restrict__ fars, float anneal_host, const float* __restrict__ anneal_dev, float hist_pad, float eps,
+    float u_offset, int64_t num_rays, int S,
     float* __restrict__ s_bins, float* __restrict__ t_bins, int32_t* __restrict__ inds) {
   extern __shared__ float lds[];
   const int ldp = (S_prev + 1) | 1;
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
   float* wpad = wsum + kRays;           // [kRays] padding / S_prev
   const int64_t ray0 = (int64_t)blockIdx.x * kRays;
   const int nr = (int)min((int64_t)kRays, num_rays - ray0);
+  const float anneal = anneal_dev ? anneal_dev[0] : anneal_host;  // device copy: graph-replayable schedules
 
   // (1) weights (annealed) + histogram padding                              ray_samplers.py:601, :303
   for (int e = threadIdx.x; e < nr * S_prev; e += kThreads) {
@@ -174,6 +178,7 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
   if (threadIdx.x < nr) {
     const float* q = w + threadIdx.x * ldp;
     double acc = 0.0;  // double-accumulated sum, rounded once (= cumsum(w)[-1] of the oracle; closest to torch.sum)
+#pragma unroll 8
     for (int i = 0; i < S_prev; ++i) acc = acc + (double)q[i];
     const float run = (float)acc;
     const float pad = fmaxf(eps - run, 0.0f);
@@ -193,6 +198,7 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     float* c = cdf + threadIdx.x * ldp;
     double run = 0.0;
     c[0] = 0.0f;
+#pragma unroll 8
     for (int i = 0; i < S_prev; ++i) {
       run = run + (double)q[i];
       c[i + 1] = fminf(1.0f, (float)run);
@@ -279,16 +285,17 @@ extern "C" int nsamd_weights_bwd(const float* t_bins, const float* density, cons
 
 extern "C" int nsamd_pdf_resample(const float* s_bins_prev, const float* weights, int32_t S_prev,
                                   const float* u_base, const float* jitter, const float* nears, const float* fars,
-                                  float anneal, float histogram_padding, float eps, float u_offset,
-                                  int64_t num_rays, int32_t S, float* s_bins, float* t_bins, int32_t* inds,
-                                  nsamd_stream_t stream) {
+                                  float anneal, const float* anneal_dev, float histogram_padding, float eps,
+                                  float u_offset, int64_t num_rays, int32_t S, float* s_bins, float* t_bins,
+                                  int32_t* inds, nsamd_stream_t stream) {
   NSAMD_REQUIRE(num_rays >= 0 && S > 0 && S_prev > 0);
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(s_bins_prev && weights && u_base && nears && fars && s_bins && t_bins);
   if (S_prev > 1024) return NSAMD_ERR_UNSUPPORTED;
   const size_t lds = sizeof(float) * (2 * kRays * ((S_prev + 1) | 1) + 2 * kRays);
   pdf_resample_kernel<<<ray_blocks(num_rays), kThreads, lds, (hipStream_t)stream>>>(
-      s_bins_prev, weights, S_prev, u_base, jitter, nears, fars, anneal, histogram_padding, eps, u_offset, num_rays, S,
+      s_bins_prev, weights, S_prev, u_base, jitter, nears, fars, anneal, anneal_dev, histogram_padding, eps, u_offset,
+      num_rays, S,
       s_bins, t_bins, inds);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;

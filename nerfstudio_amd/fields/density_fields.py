@@ -75,12 +75,13 @@ class HashMLPDensityField(Field):
         )
         self.mlp_base = torch.nn.Sequential(self.encoding, network)
         self._transform = transform_of(spatial_distortion)
+        self._box = N.make_aabb(aabb)  # host copy of the scene box: no device sync on the hot path
 
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, None]:
         spec, shape = point_spec(ray_samples)
         mlp: MLP = self.mlp_base[1]
         density = F.density_field(spec, self.encoding.hash_table, *mlp.param_tensors(), self.encoding.spec,
-                                  self._transform, self.aabb, self.average_init_density)
+                                  self._transform, self._box, self.average_init_density)
         return density.view(*shape, 1), None
 
     def get_outputs(self, ray_samples: RaySamples, density_embedding: Optional[Tensor] = None) -> dict:

@@ -4,6 +4,7 @@ from typing import Dict, Literal, Optional, Tuple
 import torch
 from torch import Tensor, nn
 
+from .. import _native as N
 from .. import functional as F
 from ..cameras.rays import RaySamples
 from ..field_components.base_field_component import check_implementation
@@ -106,6 +107,7 @@ class NerfactoField(Field):
             implementation=implementation,
         )
         self._transform = transform_of(spatial_distortion)
+        self._box = N.make_aabb(aabb)  # host copy of the scene box: no device sync on the hot path
 
     # -----------------------------------------------------------------------------------------------------------
     def _evaluate(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
@@ -134,7 +136,7 @@ class NerfactoField(Field):
         enc = self.mlp_base.encoding
         density, rgb = F.nerfacto_field(
             spec, enc.hash_table, self.mlp_base.mlp.param_tensors(), self.mlp_head.param_tensors(), emb, view_dirs, cams,
-            app_const, dir_group, enc.spec, self._transform, self.aabb, self.average_init_density)
+            app_const, dir_group, enc.spec, self._transform, self._box, self.average_init_density)
         return density.view(*shape, 1), rgb.view(*shape, 3)
 
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:

@@ -17,6 +17,25 @@ from torch import Tensor
 from . import _native as N
 
 
+_GRID_CACHE: dict = {}
+
+# When True, the backward kernels of the fused fields accumulate straight into `param.grad` whenever that buffer
+# already exists (e.g. the views of arena.ParamArena) and autograd receives None for those inputs. This removes a
+# zero-fill, a read-modify-write and an AccumulateGrad pass over every parameter (67 MB for the main hash table) per
+# step. Semantics are those of gradient accumulation into a pre-zeroed .grad; off by default.
+DIRECT_GRAD = False
+
+
+def _grad_target(param: Tensor, needed: bool):
+    """-> (buffer to accumulate into, value to return to autograd)."""
+    if not needed:
+        return None, None
+    if DIRECT_GRAD and getattr(param, "grad", None) is not None and param.grad.is_contiguous():
+        return param.grad, None
+    buf = torch.zeros_like(param)
+    return buf, buf
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # configuration records
 # ---------------------------------------------------------------------------------------------------------------
@@ -57,7 +76,11 @@ class HashGridSpec:
         return torch.floor(self.min_res * self.growth_factor**levels).to(torch.float32)
 
     def native(self) -> N.Grid:
-        return N.make_grid(self.num_levels, self.log2_hashmap_size, self.scalings().tolist())
+        g = _GRID_CACHE.get(self)
+        if g is None:
+            g = N.make_grid(self.num_levels, self.log2_hashmap_size, self.scalings().tolist())
+            _GRID_CACHE[self] = g
+        return g
 
 
 @dataclass
@@ -108,6 +131,33 @@ def _spec_from_flat(positions, origins, directions, t_bins) -> PointSpec:
     return PointSpec(_f32c(positions), _f32c(origins), _f32c(directions), _f32c(t_bins))
 
 
+_SCATTER_WS: dict = {}
+
+
+def _scatter_workspace(grid: HashGridSpec, device, num_points: int = 0) -> Tuple[Optional[Tensor], int]:
+    """Device scratch for the table-gradient scatter (csrc/hashgrid.hip, "binned" path): per (level, tile) a cursor and
+    a queue of 12-byte (local index, g0, g1) records sized 2x the uniform-hash expectation 8*M/tiles_per_level.
+    Cached per (grid, M); the kernels fall back to the scratch-free scan when it is too small."""
+    if num_points < 8192:
+        return None, 0
+    bits = 0
+    while (grid.num_levels << bits) < 512:
+        bits += 1
+    sl = min(14, max(8, grid.log2_hashmap_size - bits))
+    sl = min(sl, grid.log2_hashmap_size)
+    bins = 1 << (grid.log2_hashmap_size - sl)
+    tiles = bins * grid.num_levels
+    cap = 2 * ((8 * num_points + bins - 1) // bins) + 64
+    words = tiles + 3 * tiles * cap
+    key = (grid, num_points, str(device))
+    ws = _SCATTER_WS.get(key)
+    if ws is None:
+        ws = torch.empty(words, device=device, dtype=torch.float32)
+        ws[:tiles].zero_()  # queue cursors: zeroed once, kept at zero by the kernels themselves
+        _SCATTER_WS[key] = ws
+    return ws, ws.numel()
+
+
 def _position_grads(spec: PointSpec, dpos: Tensor):
     """dL/dpositions [M,3] -> gradients of whatever the spec was built from."""
     if not spec.ray_mode:
@@ -148,9 +198,11 @@ class _HashEncodeFn(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         if dtable is not None or dx is not None:
             pts = N.make_points(positions=x)
+            ws, ws_n = _scatter_workspace(grid, x.device, M)
             N.check(
                 N.load().nsamd_hashgrid_encode_bwd(pts, M, N.XFORM_NONE, N.Aabb(), N.ptr(table), grid.native(),
-                                                  N.ptr(gout), grid.out_dim, 1, N.ptr(dtable), N.ptr(dx), N.stream()),
+                                                  N.ptr(gout), grid.out_dim, 1, N.ptr(dtable), N.ptr(dx), N.ptr(ws),
+                                                  ws_n, N.stream()),
                 "hashgrid_encode_bwd",
             )
         return dx, dtable, None
@@ -198,7 +250,7 @@ class _DensityFieldFn(torch.autograd.Function):
         enc = torch.empty((grid.out_dim, M), device=dev, dtype=torch.float32)  # feature-major
         sel = torch.empty((M,), device=dev, dtype=torch.float32)
         g = grid.native()
-        box = N.make_aabb(aabb)
+        box = aabb if isinstance(aabb, N.Aabb) else N.make_aabb(aabb)
         N.check(lib.nsamd_hashgrid_encode_fwd(spec.native(), M, transform, box, N.ptr(table), g, N.ptr(enc), 1, M,
                                               N.ptr(sel), N.stream()), "hashgrid_encode_fwd")
         mlp = N.DensityMlp(N.ptr(W0), N.ptr(b0), N.ptr(W1), N.ptr(b1), W0.shape[1], W0.shape[0], avg_density)
@@ -207,6 +259,7 @@ class _DensityFieldFn(torch.autograd.Function):
         N.check(lib.nsamd_density_mlp_fwd(N.ptr(enc), N.ptr(sel), M, mlp, N.ptr(density), N.ptr(pre), N.stream()),
                 "density_mlp_fwd")
         ctx.spec, ctx.grid, ctx.transform, ctx.box, ctx.avg = spec, grid, transform, box, avg_density
+        ctx.param_refs = (table, W0, b0, W1, b1)
         ctx.save_for_backward(table, W0, b0, W1, b1, enc, sel, pre)
         return density
 
@@ -218,20 +271,22 @@ class _DensityFieldFn(torch.autograd.Function):
         M = spec.num_points
         gdens = _f32c(gdens)
         denc = torch.empty_like(enc)
-        dW0, db0, dW1, db1 = (torch.zeros_like(t) for t in (W0, b0, W1, b1))
+        refs = ctx.param_refs
+        (tW0, rW0), (tb0, rb0), (tW1, rW1), (tb1, rb1) = (_grad_target(r, True) for r in refs[1:])
         mlp = N.DensityMlp(N.ptr(W0), N.ptr(b0), N.ptr(W1), N.ptr(b1), W0.shape[1], W0.shape[0], ctx.avg)
         N.check(lib.nsamd_density_mlp_bwd(N.ptr(enc), N.ptr(sel), N.ptr(pre), N.ptr(gdens), M, mlp, N.ptr(denc),
-                                          N.ptr(dW0), N.ptr(db0), N.ptr(dW1), N.ptr(db1), N.stream()),
+                                          N.ptr(tW0), N.ptr(tb0), N.ptr(tW1), N.ptr(tb1), N.stream()),
                 "density_mlp_bwd")
         need_pos = any(ctx.needs_input_grad[:3])
-        dtable = torch.zeros_like(table) if ctx.needs_input_grad[4] else None
+        ttable, rtable = _grad_target(refs[0], ctx.needs_input_grad[4])
         dpos = torch.empty((M, 3), device=table.device, dtype=torch.float32) if need_pos else None
-        if dtable is not None or dpos is not None:
+        if ttable is not None or dpos is not None:
+            ws, ws_n = _scatter_workspace(ctx.grid, table.device, M)
             N.check(lib.nsamd_hashgrid_encode_bwd(spec.native(), M, ctx.transform, ctx.box, N.ptr(table),
-                                                  ctx.grid.native(), N.ptr(denc), 1, M, N.ptr(dtable), N.ptr(dpos),
-                                                  N.stream()), "hashgrid_encode_bwd")
+                                                  ctx.grid.native(), N.ptr(denc), 1, M, N.ptr(ttable), N.ptr(dpos),
+                                                  N.ptr(ws), ws_n, N.stream()), "hashgrid_encode_bwd")
         gp, go, gd = _position_grads(spec, dpos) if dpos is not None else (None, None, None)
-        return gp, go, gd, None, dtable, dW0, db0, dW1, db1, None, None, None, None
+        return gp, go, gd, None, rtable, rW0, rb0, rW1, rb1, None, None, None, None
 
 
 def density_field(spec: PointSpec, table: Tensor, W0: Tensor, b0: Tensor, W1: Tensor, b1: Tensor, grid: HashGridSpec,
@@ -265,7 +320,7 @@ class _NerfactoFieldFn(torch.autograd.Function):
         cams = camera_indices.contiguous().to(torch.int64) if camera_indices is not None else None
         enc = torch.empty((grid.out_dim, M), device=dev, dtype=torch.float32)
         sel = torch.empty((M,), device=dev, dtype=torch.float32)
-        box = N.make_aabb(aabb)
+        box = aabb if isinstance(aabb, N.Aabb) else N.make_aabb(aabb)
         N.check(lib.nsamd_hashgrid_encode_fwd(spec.native(), M, transform, box, N.ptr(table), grid.native(),
                                               N.ptr(enc), 1, M, N.ptr(sel), N.stream()), "hashgrid_encode_fwd")
         mlp = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(appearance),
@@ -277,6 +332,7 @@ class _NerfactoFieldFn(torch.autograd.Function):
                                         N.stream()), "field_mlp_fwd")
         ctx.spec, ctx.grid, ctx.transform, ctx.box, ctx.avg, ctx.dir_group = spec, grid, transform, box, avg_density, dir_group
         ctx.cams, ctx.app_const, ctx.has_app = cams, appearance_const, appearance is not None
+        ctx.param_refs = (table, *params, appearance)
         ctx.save_for_backward(table, *params, appearance if appearance is not None else table.new_empty(0), enc, sel,
                               view_dirs)
         return density, rgb
@@ -293,21 +349,24 @@ class _NerfactoFieldFn(torch.autograd.Function):
         gdens = _f32c(gdens) if gdens is not None else torch.zeros((M,), device=table.device)
         grgb = _f32c(grgb) if grgb is not None else torch.zeros((M, 3), device=table.device)
         denc = torch.empty_like(enc)
-        gparams = [torch.zeros_like(p) for p in params]
-        gapp = torch.zeros_like(appearance) if (appearance is not None and ctx.cams is not None) else None
+        refs = ctx.param_refs
+        targets = [_grad_target(r, True) for r in refs[1:11]]
+        tparams, gparams = [t for t, _ in targets], [r for _, r in targets]
+        tapp, gapp = _grad_target(refs[11], True) if (appearance is not None and ctx.cams is not None) else (None, None)
         mlp = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(appearance),
                          appearance.shape[0] if appearance is not None else 0, ctx.avg)
-        grads = N.FieldMlpGrads(*(N.ptr(g) for g in gparams), N.ptr(gapp))
+        grads = N.FieldMlpGrads(*(N.ptr(g) for g in tparams), N.ptr(tapp))
         N.check(lib.nsamd_field_mlp_bwd(N.ptr(enc), N.ptr(sel), N.ptr(view_dirs), N.ptr(ctx.cams),
                                         N.ptr(ctx.app_const), ctx.dir_group, M, mlp, N.ptr(gdens), N.ptr(grgb),
                                         N.ptr(denc), grads, N.stream()), "field_mlp_bwd")
         need_pos = any(ctx.needs_input_grad[:3])
-        dtable = torch.zeros_like(table) if ctx.needs_input_grad[4] else None
+        ttable, dtable = _grad_target(refs[0], ctx.needs_input_grad[4])
         dpos = torch.empty((M, 3), device=table.device, dtype=torch.float32) if need_pos else None
-        if dtable is not None or dpos is not None:
+        if ttable is not None or dpos is not None:
+            ws, ws_n = _scatter_workspace(ctx.grid, table.device, M)
             N.check(lib.nsamd_hashgrid_encode_bwd(spec.native(), M, ctx.transform, ctx.box, N.ptr(table),
-                                                  ctx.grid.native(), N.ptr(denc), 1, M, N.ptr(dtable), N.ptr(dpos),
-                                                  N.stream()), "hashgrid_encode_bwd")
+                                                  ctx.grid.native(), N.ptr(denc), 1, M, N.ptr(ttable), N.ptr(dpos),
+                                                  N.ptr(ws), ws_n, N.stream()), "hashgrid_encode_bwd")
         gp, go, gd = _position_grads(spec, dpos) if dpos is not None else (None, None, None)
         return (gp, go, gd, None, dtable, *gparams, gapp, None, None, None, None, None, None, None, None)
 
@@ -394,7 +453,7 @@ def weights_from_density(t_bins: Tensor, density: Tensor) -> Tensor:
 @torch.no_grad()
 def pdf_resample(s_bins_prev: Tensor, weights: Tensor, num_samples: int, jitter: Optional[Tensor], nears: Tensor,
                  fars: Tensor, anneal: float = 1.0, histogram_padding: float = 0.01, eps: float = 1e-5,
-                 return_indices: bool = False):
+                 return_indices: bool = False, anneal_dev: Optional[Tensor] = None):
     """PDFSampler.generate_ray_samples(include_original=False) (ray_samplers.py:276-372) incl. the weight anneal
     (ray_samplers.py:601). Returns (s_bins, t_bins[, inds]) with `[N, S+1]` each; inds int32."""
     N.require_cuda(s_bins_prev, weights, nears, fars, jitter)
@@ -409,7 +468,8 @@ def pdf_resample(s_bins_prev: Tensor, weights: Tensor, num_samples: int, jitter:
     inds = torch.empty((n, nb), device=dev, dtype=torch.int32) if return_indices else None
     u_base = _linspace("u", num_samples, dev)
     N.check(N.load().nsamd_pdf_resample(N.ptr(s_bins_prev), N.ptr(weights), s_prev, N.ptr(u_base), N.ptr(jitter),
-                                        N.ptr(nears), N.ptr(fars), float(anneal), float(histogram_padding), float(eps),
+                                        N.ptr(nears), N.ptr(fars), float(anneal), N.ptr(anneal_dev),
+                                        float(histogram_padding), float(eps),
                                         1.0 / (2 * nb), n, num_samples, N.ptr(s_bins), N.ptr(t_bins), N.ptr(inds),
                                         N.stream()), "pdf_resample")
     return (s_bins, t_bins, inds) if return_indices else (s_bins, t_bins)
@@ -445,7 +505,7 @@ class _CompositeFn(torch.autograd.Function):
         out = torch.empty((n, 3), device=dev, dtype=torch.float32)
         acc = torch.empty((n,), device=dev, dtype=torch.float32)
         depth = torch.empty((n,), device=dev, dtype=torch.float32) if want_depth else None
-        ws = torch.empty((2,), device=dev, dtype=torch.float32) if want_depth else None
+        ws = torch.empty((2 + 2 * ((n + 3) // 4),), device=dev, dtype=torch.float32) if want_depth else None
         N.check(N.load().nsamd_composite_fwd(N.ptr(rgb), N.ptr(weights), N.ptr(t_bins) if want_depth else None, n, s,
                                              bg_mode, bg_vals, 0, N.ptr(out), N.ptr(acc), N.ptr(depth), None, None,
                                              N.ptr(ws), N.stream()), "composite_fwd")
@@ -491,7 +551,7 @@ def composite_eval(rgb: Tensor, weights: Tensor, t_bins: Tensor, background="las
     acc = torch.empty((n,), device=dev, dtype=torch.float32)
     dexp = torch.empty((n,), device=dev, dtype=torch.float32)
     dmed = torch.empty((n,), device=dev, dtype=torch.float32)
-    ws = torch.empty((2,), device=dev, dtype=torch.float32)
+    ws = torch.empty((2 + 2 * ((n + 3) // 4),), device=dev, dtype=torch.float32)
     N.check(N.load().nsamd_composite_fwd(N.ptr(rgb), N.ptr(weights), N.ptr(t_bins), n, s, mode, vals, 1, N.ptr(out),
                                          N.ptr(acc), N.ptr(dexp), N.ptr(dmed), None, N.ptr(ws), N.stream()),
             "composite_fwd")
@@ -605,10 +665,15 @@ def raygen_pinhole(ray_indices: Tensor, c2w: Tensor, fx: Tensor, fy: Tensor, cx:
 
 
 @torch.no_grad()
+def adam_hyper(step: int, lr: float, betas=(0.9, 0.999)) -> Tuple[float, float]:
+    """(lr / (1 - b1^step), 1 / sqrt(1 - b2^step)) — the two step-dependent scalars of Adam."""
+    return lr / (1.0 - betas[0] ** step), 1.0 / math.sqrt(1.0 - betas[1] ** step)
+
+
 def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,
-              betas=(0.9, 0.999), eps: float = 1e-15, grad_scale: float = 1.0) -> None:
+              betas=(0.9, 0.999), eps: float = 1e-15, grad_scale: float = 1.0, hyper_dev: Optional[Tensor] = None) -> None:
     """torch.optim.Adam step over a flat fp32 arena (engine/optimizers.py:74-193; AdamOptimizerConfig eps=1e-15)."""
     N.require_cuda(params, grads, exp_avg, exp_avg_sq)
     N.check(N.load().nsamd_adam_step(N.ptr(params), N.ptr(grads), N.ptr(exp_avg), N.ptr(exp_avg_sq), params.numel(),
                                      float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
-                                     float(grad_scale), N.stream()), "adam_step")
+                                     float(grad_scale), N.ptr(hyper_dev), N.stream()), "adam_step")

@@ -78,7 +78,8 @@ class PDFSampler(Sampler):
 
     def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, ray_samples: Optional[RaySamples] = None,
                              weights: Optional[Tensor] = None, num_samples: Optional[int] = None, eps: float = 1e-5,
-                             jitter: Optional[Tensor] = None, anneal: float = 1.0) -> RaySamples:
+                             jitter: Optional[Tensor] = None, anneal: float = 1.0,
+                             anneal_dev: Optional[Tensor] = None) -> RaySamples:
         if ray_samples is None or ray_bundle is None:
             raise ValueError("ray_samples and ray_bundle must be provided")
         assert weights is not None, "weights must be provided"
@@ -98,7 +99,8 @@ class PDFSampler(Sampler):
         else:
             existing = torch.cat([ray_samples.spacing_starts[..., 0], ray_samples.spacing_ends[..., -1:, 0]], dim=-1)
         s_bins, t_bins = F.pdf_resample(existing, weights[..., 0], num_samples, jitter, ray_bundle.nears, ray_bundle.fars,
-                                        anneal=anneal, histogram_padding=self.histogram_padding, eps=eps)
+                                        anneal=anneal, histogram_padding=self.histogram_padding, eps=eps,
+                                        anneal_dev=anneal_dev)
         return samples_from_bins(ray_bundle, s_bins, t_bins, ray_samples.spacing_to_euclidean_fn)
 
 
@@ -128,6 +130,10 @@ class ProposalNetworkSampler(Sampler):
         self._anneal = 1.0
         self._steps_since_update = 0
         self._step = 0
+        # graph-replay hooks (set by a trainer that captures the step in a hipGraph): a device copy of the anneal
+        # exponent, and an override of the host-side "update the proposal nets this step?" decision
+        self.anneal_dev: Optional[Tensor] = None
+        self.force_updated: Optional[bool] = None
 
     def set_anneal(self, anneal: float) -> None:
         self._anneal = anneal
@@ -135,6 +141,13 @@ class ProposalNetworkSampler(Sampler):
     def step_cb(self, step) -> None:
         self._step = step
         self._steps_since_update += 1
+
+    def updated_this_step(self) -> bool:
+        """ray_samplers.py:590 — proposal networks get gradient on this step?"""
+        return bool(self._steps_since_update > self.update_sched(self._step) or self._step < 10)
+
+    def mark_updated(self) -> None:
+        self._steps_since_update = 0
 
     def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, density_fns: Optional[List[Callable]] = None,
                              jitters: Optional[List[Tensor]] = None) -> Tuple[RaySamples, List, List]:
@@ -145,7 +158,7 @@ class ProposalNetworkSampler(Sampler):
         n = self.num_proposal_network_iterations
         weights = None
         ray_samples = None
-        updated = self._steps_since_update > self.update_sched(self._step) or self._step < 10
+        updated = self.updated_this_step() if self.force_updated is None else self.force_updated
         for i_level in range(n + 1):
             is_prop = i_level < n
             num_samples = self.num_proposal_samples_per_ray[i_level] if is_prop else self.num_nerf_samples_per_ray
@@ -156,14 +169,14 @@ class ProposalNetworkSampler(Sampler):
                 assert weights is not None
                 # the anneal pow(weights, anneal) (ray_samplers.py:601) happens inside the resampling kernel
                 ray_samples = self.pdf_sampler(ray_bundle, ray_samples, weights, num_samples=num_samples, jitter=jit,
-                                               anneal=self._anneal)
+                                               anneal=self._anneal, anneal_dev=self.anneal_dev)
             if is_prop:
                 with torch.set_grad_enabled(updated and torch.is_grad_enabled()):
                     density = self._density(density_fns[i_level], ray_samples)
                 weights = ray_samples.get_weights(density)
                 weights_list.append(weights)
                 ray_samples_list.append(ray_samples)
-        if updated:
+        if updated and self.force_updated is None:
             self._steps_since_update = 0
         assert ray_samples is not None
         return ray_samples, weights_list, ray_samples_list

@@ -160,11 +160,20 @@ class NerfactoModel(nn.Module):
         weights = ray_samples.get_weights(field_outputs[FieldHeadNames.DENSITY])
         weights_list.append(weights)
         ray_samples_list.append(ray_samples)
-        rgb = self.renderer_rgb(rgb=field_outputs[FieldHeadNames.RGB], weights=weights)
+        if self.training:
+            # RGBRenderer + AccumulationRenderer + DepthRenderer("expected") share one pass over the samples:
+            # a single composite launch (csrc/render.hip) instead of the reference's three module calls.
+            from . import functional as F
+
+            rgb, acc1, dep1 = F.composite(field_outputs[FieldHeadNames.RGB], weights[..., 0], ray_samples.pack.t_bins,
+                                          self.renderer_rgb.background_color, expected_depth=True)
+            accumulation, expected_depth = acc1[:, None], dep1[:, None]
+        else:
+            rgb = self.renderer_rgb(rgb=field_outputs[FieldHeadNames.RGB], weights=weights)
+            expected_depth = self.renderer_expected_depth(weights=weights, ray_samples=ray_samples)
+            accumulation = self.renderer_accumulation(weights=weights)
         with torch.no_grad():
             depth = self.renderer_depth(weights=weights, ray_samples=ray_samples)
-        expected_depth = self.renderer_expected_depth(weights=weights, ray_samples=ray_samples)
-        accumulation = self.renderer_accumulation(weights=weights)
         outputs: Dict[str, object] = {"rgb": rgb, "accumulation": accumulation, "depth": depth,
                                       "expected_depth": expected_depth}
         if self.training:

@@ -44,7 +44,7 @@ for log2T in (19,):
             denc = torch.randn(2, M, device=dev)
             P = N.make_points(positions=pts)
             f = lambda: N.check(lib.nsamd_hashgrid_encode_fwd(P, M, 0, N.Aabb(), N.ptr(table), g, N.ptr(enc), 1, M, None, N.stream()), "f")
-            b = lambda: N.check(lib.nsamd_hashgrid_encode_bwd(P, M, 0, N.Aabb(), N.ptr(table), g, N.ptr(denc), 1, M, N.ptr(dtable), None, N.stream()), "b")
+            b = lambda: N.check(lib.nsamd_hashgrid_encode_bwd(P, M, 0, N.Aabb(), N.ptr(table), g, N.ptr(denc), 1, M, N.ptr(dtable), None, None, 0, N.stream()), "b")
             tf, tb = timeit(f), timeit(b)
             print(f"T=2^{log2T} {name:15s} res={res:5d}  fwd {tf*1e3:8.1f} us   bwd {tb*1e3:8.1f} us   "
                   f"({M*16/tb/1e6:7.2f} G atomics/s)", flush=True)
