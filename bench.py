@@ -72,7 +72,7 @@ class Trainer:
     (`hyper`, refreshed by an 12-byte async copy before each replay). With N > 1 the RCCL all-reduce of the gradient
     arena runs eagerly between two captured halves (forward+backward | optimiser)."""
 
-    def __init__(self, model, arena, ray_bundle, batch, world=1, use_graph=True):
+    def __init__(self, model, arena, ray_bundle, batch, world=1, use_graph=True, use_runner=True):
         self.model, self.arena, self.rb, self.batch, self.world = model, arena, ray_bundle, batch, world
         self.step = 0
         self.opt_step = 0
@@ -83,6 +83,13 @@ class Trainer:
         model.proposal_sampler.anneal_dev = self.hyper[2:3]
         self.graphs = None
         self.use_graph = use_graph
+        self.runner = None
+        if use_runner:  # explicit kernel schedule over static buffers (nerfstudio_amd/train_step.py); default
+            from nerfstudio_amd.train_step import NerfactoTrainStep
+
+            self.runner = NerfactoTrainStep(model, ray_bundle.origins.shape[0], dev)
+            self.runner.set_batch(ray_bundle.origins, ray_bundle.directions, ray_bundle.camera_indices, batch["image"])
+            self.runner.anneal_dev = self.hyper[2:3]
 
     # -- pieces of one iteration ---------------------------------------------------------------------------------
     def _prologue(self):
@@ -97,6 +104,10 @@ class Trainer:
     def _fwd_bwd(self, updated):
         from nerfstudio_amd.cameras.rays import RayBundle
 
+        if self.runner is not None:
+            self.arena.zero_grad()
+            self.runner.forward_backward(updated)
+            return
         m = self.model
         m.proposal_sampler.force_updated = updated
         self.arena.zero_grad()
@@ -177,6 +188,11 @@ class Trainer:
             ps.mark_updated()
         self.model.after_step(self.step)  # AFTER_TRAIN_ITERATION callback
         self.step += 1
+        return self.loss_buf
+
+    def last_loss(self):
+        if self.runner is not None:
+            return sum(self.runner.loss_dict().values())
         return self.loss_buf
 
 
@@ -280,6 +296,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
+    ap.add_argument("--autograd", action="store_true",
+                    help="drive the step through the nn.Module / autograd API instead of the explicit kernel schedule")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
     args = ap.parse_args()
@@ -305,7 +323,7 @@ def main():
     arena = ParamArena(model.parameters(), lr=1e-2, eps=1e-15)  # AdamOptimizerConfig(lr=1e-2, eps=1e-15)
     arena.broadcast_params()
     rb, batch = synthetic_batch(device, seed=1000 + rank)  # each rank its own rays (scripts/train.py:98)
-    trainer = Trainer(model, arena, rb, batch, world=world, use_graph=not args.no_graph)
+    trainer = Trainer(model, arena, rb, batch, world=world, use_graph=not args.no_graph, use_runner=not args.autograd)
 
     for _ in range(max(1, args.warmup // 2)):  # eager warm-up: lazy kernel attributes, caches, allocator
         trainer.train_iteration()
@@ -318,7 +336,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.train_iteration()
+        trainer.train_iteration()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -327,6 +345,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    loss = trainer.last_loss()
     assert bool(torch.isfinite(loss)), "training diverged"
 
     roof, table = (None, [])
@@ -356,7 +375,8 @@ def main():
                        "rays_per_gpu": RAYS_PER_GPU, "global_rays": world * RAYS_PER_GPU,
                        "parallelism": f"dp{world}: rays sharded by batch, one RCCL all-reduce of the 77.7 MB gradient arena",
                        "params": arena.numel, "final_loss": round(float(loss), 6),
-                       "launch": "hipGraph replay (2 captured variants)" if graphed else "eager"},
+                       "launch": "hipGraph replay (2 captured variants)" if graphed else "eager",
+                       "driver": "autograd modules" if args.autograd else "explicit kernel schedule (train_step.py)"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

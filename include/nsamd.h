@@ -88,7 +88,7 @@ int nsamd_hashgrid_encode_fwd(nsamd_points pts, int64_t M, int transform, nsamd_
  * The scatter is partitioned into LDS-owned (level, slice) tiles (no global atomics, see csrc/hashgrid.hip);
  * `workspace` (nullable, `workspace_floats` words of device scratch) enables the binned two-pass path: it must be
  * ZERO-INITIALISED ONCE by its owner (the per-tile queue cursors at its start are left at zero by every call) and
- * hold >= tiles * (1 + 3 * 1.25 * 8 * M / tiles_per_level) words; smaller or NULL selects the scratch-free scan. */
+ * hold >= tiles * (1 + 4 * 1.25 * 8 * M / tiles_per_level) + 8 words (base 16-B aligned); smaller or NULL selects the scratch-free scan. */
 int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
                               nsamd_grid grid, const float* denc, int64_t stride_p, int64_t stride_k,
                               float* dtable, float* dpositions, float* workspace, int64_t workspace_floats,
@@ -205,11 +205,17 @@ int nsamd_composite_fwd(const float* rgb, const float* weights, const float* t_b
                         nsamd_stream_t stream);
 
 /* Backward of rgb_out / acc / depth_expected w.r.t. rgb samples and weights (training mode).
- * d_rgb_out [N,3], d_acc [N] (nullable), d_depth [N] (nullable; needs `workspace` from the forward and t_bins). */
+ * d_rgb_out [N,3], d_acc [N] (nullable), d_depth [N] (nullable; needs `workspace` from the forward and t_bins).
+ * d_weights_add (nullable) [N,S] is added to d_weights (gradient of another loss on the same weights). */
 int nsamd_composite_bwd(const float* rgb, const float* weights, const float* t_bins, int64_t num_rays, int32_t S,
                         int background, const float* bg_rgb_host, const float* d_rgb_out, const float* d_acc,
-                        const float* d_depth, const float* workspace, float* d_rgb, float* d_weights,
-                        nsamd_stream_t stream);
+                        const float* d_depth, const float* workspace, const float* d_weights_add, float* d_rgb,
+                        float* d_weights, nsamd_stream_t stream);
+
+/* MSELoss (model_components/losses.py:31): loss_sum += sum((pred-target)^2) (caller zeroes; mean = /n),
+ * dpred (nullable) = 2 (pred-target) grad_scale  with grad_scale = upstream / n. */
+int nsamd_mse_loss(const float* pred, const float* target, int64_t n, float grad_scale, float* loss_sum, float* dpred,
+                   nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Proposal losses (model_components/losses.py). Per-ray fused forward + gradient:

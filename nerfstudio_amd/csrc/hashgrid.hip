@@ -20,8 +20,8 @@
 // and writes the tile back with plain coalesced stores. Re-deriving the 8 hashes per (point, level) once per slice
 // costs ALU (measured 0.70 ms for the main table, 32 slices per level). With scratch memory from the caller the
 // redundancy goes away too ("binned" path, the default): pass 1 derives every corner update ONCE and appends
-// (local index, g0, g1) to the queue of the tile it falls into — a workgroup-local counting sort in LDS, one
-// returning global atomic per (workgroup, non-empty tile) to reserve queue space, 12-B records written in runs; pass
+// a 16-B record (local index, g0, g1, pad) to the queue of the tile it falls into — a workgroup-local counting sort in LDS, one
+// returning global atomic per (workgroup, non-empty tile) to reserve queue space, one dwordx4 store per record; pass
 // 2 runs one workgroup per tile that streams its queue into the LDS tile and stores it. Queues are sized 2x the
 // uniform-hash expectation; the rare overflow falls back to a direct atomic, so the result never depends on sizing.
 // Tiny problems keep the direct-atomic kernel.
@@ -100,6 +100,24 @@ __global__ __launch_bounds__(kHashBlock) void hash_encode_bwd_table_kernel(
   }
 }
 
+// LDS accumulate of one (g0, g1) pair. Measured on MI355X (scripts/probe_lds_atomics.hip, profiles/): ds_add_f32 with
+// divergent addresses retires only 0.33 lane-ops/clk/CU — 12x below ds_add_u32 / a plain LDS read-modify-write — but
+// 2.4 when the lanes of a wave share an address; a compare-and-swap loop is the opposite (2.2 when divergent). So:
+// ONE 64-bit CAS attempt on the float pair (random hashed addresses: almost always succeeds, and covers both features
+// with a single LDS atomic), and only the lanes that lost a race — true same-entry conflicts, i.e. hot coarse cells —
+// fall back to ds_add_f32, which is the fast path for exactly that case.
+__device__ __forceinline__ void lds_add_pair(float* pair, float v0, float v1) {
+  unsigned long long* w = reinterpret_cast<unsigned long long*>(pair);
+  const unsigned long long old = *w;
+  const float n0 = __uint_as_float((uint32_t)old) + v0;
+  const float n1 = __uint_as_float((uint32_t)(old >> 32)) + v1;
+  const unsigned long long want = (unsigned long long)__float_as_uint(n0) | ((unsigned long long)__float_as_uint(n1) << 32);
+  if (atomicCAS(w, old, want) != old) {
+    atomicAdd(pair + 0, v0);  // ds_add_f32
+    atomicAdd(pair + 1, v1);
+  }
+}
+
 // ---- partitioned scatter (see the header comment) ----------------------------------------------------------------
 constexpr int kSliceLog2Max = 14;  // 16384 entries x 2 floats = 128 KiB of the 160 KiB LDS
 constexpr int kSliceThreads = 1024;
@@ -107,7 +125,7 @@ constexpr int kSliceThreads = 1024;
 __global__ __launch_bounds__(kSliceThreads) void hash_encode_bwd_sliced_kernel(
     nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
     int64_t stride_p, int64_t stride_k, float* __restrict__ dst, int64_t dst_chunk_stride, int accumulate) {
-  extern __shared__ float acc[];  // [slice_entries][2]
+  extern __shared__ __attribute__((aligned(16))) float acc[];  // [slice_entries][2]
   const int slice = blockIdx.x, level = blockIdx.y, chunk = blockIdx.z, chunks = gridDim.z;
   const int slice_log2 = min(grid.log2_table_size, kSliceLog2Max);
   const int slice_entries = 1 << slice_log2;
@@ -133,8 +151,7 @@ __global__ __launch_bounds__(kSliceThreads) void hash_encode_bwd_sliced_kernel(
         const float by = (k & 2) ? c.w[1] : 1.0f - c.w[1];
         const float bx = (k & 1) ? c.w[0] : 1.0f - c.w[0];
         const uint32_t local = idx & (uint32_t)(slice_entries - 1);
-        atomicAdd(acc + 2 * local + 0, ((g0 * bz) * by) * bx);  // ds_add_f32
-        atomicAdd(acc + 2 * local + 1, ((g1 * bz) * by) * bx);
+        lds_add_pair(acc + 2 * local, ((g0 * bz) * by) * bx, ((g1 * bz) * by) * bx);
       }
     }
   }
@@ -152,10 +169,14 @@ __global__ __launch_bounds__(kSliceThreads) void hash_encode_bwd_sliced_kernel(
 constexpr int kBinThreads = 1024;
 constexpr int kMaxBins = 4096;
 
+// Pass 1. `merge_mask` bit l set = on level l consecutive lanes (consecutive samples of a ray) are likely to share a
+// cell (cell size > sample spacing): their 8-corner contributions are summed with a wave-level segmented scan over
+// runs of identical cells and only the last lane of each run emits records. On the coarse levels this removes most of
+// the records (and with them the hot-entry conflicts in pass 2); measured in profiles/.
 __global__ __launch_bounds__(kBinThreads) void hash_bwd_bin_kernel(
     nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
-    int64_t stride_p, int64_t stride_k, int slice_log2, uint32_t cap, uint32_t* __restrict__ cursors,
-    uint32_t* __restrict__ queues, float* __restrict__ dtable) {
+    int64_t stride_p, int64_t stride_k, int slice_log2, uint32_t cap, uint32_t merge_mask,
+    uint32_t* __restrict__ cursors, uint32_t* __restrict__ queues, float* __restrict__ dtable) {
   extern __shared__ uint32_t lds_u[];
   const int level = blockIdx.y;
   const int B = 1 << (grid.log2_table_size - slice_log2);
@@ -173,12 +194,49 @@ __global__ __launch_bounds__(kBinThreads) void hash_bwd_bin_kernel(
     active = !(g0 == 0.0f && g1 == 0.0f);
   }
   uint32_t idx[8], rank[8];
+  float v0[8], v1[8];
   Cell c;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { c.lo[a] = 0; c.hi[a] = 0; c.w[a] = 0.f; }
   if (active) {
     float x, y, z;
     load_position(P, p, x, y, z);
     (void)normalise_position(transform, box, x, y, z);
     c = locate_cell(x, y, z, grid.scalings[level]);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float bz = (k & 4) ? c.w[2] : 1.0f - c.w[2];
+    const float by = (k & 2) ? c.w[1] : 1.0f - c.w[1];
+    const float bx = (k & 1) ? c.w[0] : 1.0f - c.w[0];
+    v0[k] = active ? ((g0 * bz) * by) * bx : 0.0f;
+    v1[k] = active ? ((g1 * bz) * by) * bx : 0.0f;
+  }
+  bool emit = active;
+  if ((merge_mask >> level) & 1u) {  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    bool same = active && lane > 0 && __shfl_up((int)active, 1) != 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      same = same && (__shfl_up(c.lo[a], 1) == c.lo[a]) && (__shfl_up(c.hi[a], 1) == c.hi[a]);
+    }
+    const bool head = !same;
+    bool f = head;  // segmented inclusive scan: (v, f) o (v', f') = (f' ? v' : v + v', f | f')
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const bool take = (lane >= d) && !f;
+      const int fp = __shfl_up((int)f, d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float a0 = __shfl_up(v0[k], d), a1 = __shfl_up(v1[k], d);
+        if (take) { v0[k] += a0; v1[k] += a1; }
+      }
+      if (take) f = fp != 0;
+    }
+    const bool next_head = (lane == 63) || (__shfl_down((int)head, 1) != 0);
+    emit = active && next_head;  // the last lane of a run carries the run's sums
+  }
+  if (emit) {
     const uint32_t mask = (1u << grid.log2_table_size) - 1u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -192,25 +250,19 @@ __global__ __launch_bounds__(kBinThreads) void hash_bwd_bin_kernel(
     base[t] = n ? atomicAdd(cursors + (size_t)level * B + t, n) : 0u;
   }
   __syncthreads();
-  if (active) {
+  if (emit) {
     const uint32_t local_mask = (1u << slice_log2) - 1u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float bz = (k & 4) ? c.w[2] : 1.0f - c.w[2];
-      const float by = (k & 2) ? c.w[1] : 1.0f - c.w[1];
-      const float bx = (k & 1) ? c.w[0] : 1.0f - c.w[0];
-      const float v0 = ((g0 * bz) * by) * bx, v1 = ((g1 * bz) * by) * bx;
       const uint32_t bin = idx[k] >> slice_log2;
       const uint32_t pos = base[bin] + rank[k];
-      if (pos < cap) {
-        uint32_t* q = queues + (((size_t)level * B + bin) * cap + pos) * 3;
-        q[0] = idx[k] & local_mask;
-        q[1] = __float_as_uint(v0);
-        q[2] = __float_as_uint(v1);
+      if (pos < cap) {  // one 16-B record = one global_store_dwordx4
+        uint4* q = reinterpret_cast<uint4*>(queues) + (((size_t)level * B + bin) * cap + pos);
+        *q = make_uint4(idx[k] & local_mask, __float_as_uint(v0[k]), __float_as_uint(v1[k]), 0u);
       } else {  // queue full (a very hot cell): direct atomics keep the result exact
         float* t = dtable + ((((size_t)level << grid.log2_table_size) + idx[k]) << 1);
-        unsafeAtomicAdd(t + 0, v0);
-        unsafeAtomicAdd(t + 1, v1);
+        unsafeAtomicAdd(t + 0, v0[k]);
+        unsafeAtomicAdd(t + 1, v1[k]);
       }
     }
   }
@@ -219,7 +271,7 @@ __global__ __launch_bounds__(kBinThreads) void hash_bwd_bin_kernel(
 __global__ void hash_bwd_apply_kernel(nsamd_grid grid, int slice_log2, uint32_t cap,
                                       const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ queues,
                                       float* __restrict__ dtable) {
-  extern __shared__ float acc[];
+  extern __shared__ __attribute__((aligned(16))) float acc[];
   const int bin = blockIdx.x, level = blockIdx.y;
   const int B = gridDim.x;
   const int entries = 1 << slice_log2;
@@ -230,15 +282,33 @@ __global__ void hash_bwd_apply_kernel(nsamd_grid grid, int slice_log2, uint32_t 
   // self-cleaning cursor: the next launch finds zeros again, so no memset node is needed per call (the workspace is
   // zero-initialised once by its owner)
   if (threadIdx.x == 0) const_cast<uint32_t*>(cursors)[(size_t)level * B + bin] = 0u;
-  const uint32_t* q = queues + ((size_t)level * B + bin) * cap * 3;
-  for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-    const uint32_t local = q[3 * e];
-    atomicAdd(acc + 2 * local + 0, __uint_as_float(q[3 * e + 1]));  // ds_add_f32
-    atomicAdd(acc + 2 * local + 1, __uint_as_float(q[3 * e + 2]));
+  const uint4* q = reinterpret_cast<const uint4*>(queues) + ((size_t)level * B + bin) * cap;
+  // One workgroup per CU (the tile fills the LDS), so memory-level parallelism has to come from each thread: keep 8
+  // independent 16-B queue loads in flight before touching the LDS (measured: 285 -> see profiles/ us per launch).
+  constexpr int kU = 8;
+  uint32_t e = threadIdx.x;
+  const uint32_t stride = blockDim.x;
+  for (; e + (kU - 1) * stride < n; e += kU * stride) {
+    uint4 r[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) r[u] = q[e + u * stride];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) lds_add_pair(acc + 2 * r[u].x, __uint_as_float(r[u].y), __uint_as_float(r[u].z));
+  }
+  for (; e < n; e += stride) {
+    const uint4 r = q[e];
+    lds_add_pair(acc + 2 * r.x, __uint_as_float(r.y), __uint_as_float(r.z));
   }
   __syncthreads();
-  float* out = dtable + ((((size_t)level << grid.log2_table_size) + ((size_t)bin << slice_log2)) << 1);
-  for (int e = threadIdx.x; e < 2 * entries; e += blockDim.x) out[e] += acc[e];  // sole owner of the tile
+  float4* out = reinterpret_cast<float4*>(
+      dtable + ((((size_t)level << grid.log2_table_size) + ((size_t)bin << slice_log2)) << 1));
+  const float4* a4 = reinterpret_cast<const float4*>(acc);
+  for (int i = threadIdx.x; i < entries / 2; i += blockDim.x) {  // sole owner of the tile: plain read-modify-write
+    float4 o = out[i];
+    const float4 a = a4[i];
+    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    out[i] = o;
+  }
 }
 
 // dtable[i] += sum over chunks of partial[c][i]
@@ -419,7 +489,7 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
                const int64_t B = (int64_t)1 << (grid.log2_table_size - sl);
                if (workspace == nullptr || B > kMaxBins) return false;
                const int64_t tiles = B * grid.num_levels;
-               const int64_t cap = (workspace_floats - tiles) / (3 * tiles);
+               const int64_t cap = (workspace_floats - tiles - 4) / (4 * tiles);
                const int64_t expect = (8 * M + B - 1) / B;  // uniform hashing: updates per tile
                return cap >= expect + expect / 4 && cap < 0x7fffffffLL;
              }()) {
@@ -430,13 +500,19 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
     if (sl > grid.log2_table_size) sl = grid.log2_table_size;
     const int B = 1 << (grid.log2_table_size - sl);
     const int64_t tiles = (int64_t)B * grid.num_levels;
-    const uint32_t cap = (uint32_t)((workspace_floats - tiles) / (3 * tiles));
+    const uint32_t cap = (uint32_t)((workspace_floats - tiles - 4) / (4 * tiles));
     uint32_t* cursors = reinterpret_cast<uint32_t*>(workspace);
-    uint32_t* queues = cursors + tiles;
+    uint32_t* queues = cursors + ((tiles + 3) & ~(int64_t)3);  // 16-B aligned records
     hipStream_t st = (hipStream_t)stream;
     dim3 g1((unsigned)((M + kBinThreads - 1) / kBinThreads), (unsigned)grid.num_levels);
-    hash_bwd_bin_kernel<<<g1, kBinThreads, sizeof(uint32_t) * 2 * B, st>>>(pts, M, transform, aabb, grid, denc, stride_p,
-                                                                       stride_k, sl, cap, cursors, queues, dtable);
+    // merge runs of samples that share a cell where the cell is wider than ~4 sample spacings (ray mode only: the
+    // lanes of a wave are then consecutive samples of one ray)
+    uint32_t merge_mask = 0;
+    if (pts.positions == nullptr)
+      for (int l = 0; l < grid.num_levels; ++l)
+        if (grid.scalings[l] < 4.0f * (float)pts.samples_per_ray) merge_mask |= 1u << l;
+    hash_bwd_bin_kernel<<<g1, kBinThreads, sizeof(uint32_t) * 2 * B, st>>>(
+        pts, M, transform, aabb, grid, denc, stride_p, stride_k, sl, cap, merge_mask, cursors, queues, dtable);
     NSAMD_CHECK_LAUNCH();
     static bool attr2 = false;
     if (!attr2) {

@@ -179,7 +179,8 @@ __global__ __launch_bounds__(kRenderThreads) void composite_bwd_kernel(
     const float* __restrict__ rgb, const float* __restrict__ weights, const float* __restrict__ t_bins,
     int64_t num_rays, int S, int background, float bg_r, float bg_g, float bg_b,
     const float* __restrict__ d_rgb_out, const float* __restrict__ d_acc, const float* __restrict__ d_depth,
-    const float* __restrict__ ws, float* __restrict__ d_rgb, float* __restrict__ d_weights) {
+    const float* __restrict__ ws, const float* __restrict__ d_weights_add, float* __restrict__ d_rgb,
+    float* __restrict__ d_weights) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wave;
   if (ray >= num_rays) return;
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(kRenderThreads) void composite_bwd_kernel(
     const float w = w_in[s];
     float dw = gr * c[0] + gg * c[1] + gb * c[2] - bg_dot + ga + g_den;
     if (tb) dw += g_num * ((tb[s] + tb[s + 1]) / 2.0f);
+    if (d_weights_add) dw += d_weights_add[ray * S + s];  // e.g. the distortion-loss gradient on the same weights
     d_weights[ray * S + s] = dw;
     float* o = d_rgb + (ray * S + s) * 3;
     float e = w;
@@ -231,9 +233,37 @@ __global__ __launch_bounds__(kRenderThreads) void composite_bwd_kernel(
   }
 }
 
+// MSELoss (model_components/losses.py:31 = nn.MSELoss, mean over all N*3 elements): value and gradient in one pass.
+// loss_sum receives the SUM of squared errors (one atomic per workgroup; the caller zeroes it and divides by n).
+__global__ void mse_loss_kernel(const float* __restrict__ pred, const float* __restrict__ target, int64_t n,
+                                float grad_scale, float* __restrict__ loss_sum, float* __restrict__ dpred) {
+  float acc = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = pred[i] - target[i];
+    acc += d * d;
+    if (dpred) dpred[i] = 2.0f * d * grad_scale;
+  }
+  acc = wave_sum(acc);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss_sum) unsafeAtomicAdd(loss_sum, part[0] + part[1] + part[2] + part[3]);
+}
+
 }  // namespace nsamd
 
 using namespace nsamd;
+
+extern "C" int nsamd_mse_loss(const float* pred, const float* target, int64_t n, float grad_scale, float* loss_sum,
+                              float* dpred, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(n >= 0);
+  if (n == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(pred && target);
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
+  mse_loss_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(pred, target, n, grad_scale, loss_sum, dpred);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
 
 extern "C" int nsamd_composite_fwd(const float* rgb, const float* weights, const float* t_bins, int64_t num_rays,
                                    int32_t S, int background, const float* bg_rgb_host, int eval_mode,
@@ -267,8 +297,9 @@ extern "C" int nsamd_composite_fwd(const float* rgb, const float* weights, const
 
 extern "C" int nsamd_composite_bwd(const float* rgb, const float* weights, const float* t_bins, int64_t num_rays,
                                    int32_t S, int background, const float* bg_rgb_host, const float* d_rgb_out,
-                                   const float* d_acc, const float* d_depth, const float* workspace, float* d_rgb,
-                                   float* d_weights, nsamd_stream_t stream) {
+                                   const float* d_acc, const float* d_depth, const float* workspace,
+                                   const float* d_weights_add, float* d_rgb, float* d_weights,
+                                   nsamd_stream_t stream) {
   NSAMD_REQUIRE(num_rays >= 0 && S > 0);
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(rgb && weights && d_rgb && d_weights);
@@ -279,7 +310,8 @@ extern "C" int nsamd_composite_bwd(const float* rgb, const float* weights, const
   const float br = bg_rgb_host ? bg_rgb_host[0] : 0.f, bg = bg_rgb_host ? bg_rgb_host[1] : 0.f,
               bb = bg_rgb_host ? bg_rgb_host[2] : 0.f;
   composite_bwd_kernel<<<blocks, kRenderThreads, 0, (hipStream_t)stream>>>(
-      rgb, weights, t_bins, num_rays, S, background, br, bg, bb, d_rgb_out, d_acc, d_depth, workspace, d_rgb, d_weights);
+      rgb, weights, t_bins, num_rays, S, background, br, bg, bb, d_rgb_out, d_acc, d_depth, workspace, d_weights_add, d_rgb,
+      d_weights);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

@@ -136,7 +136,7 @@ _SCATTER_WS: dict = {}
 
 def _scatter_workspace(grid: HashGridSpec, device, num_points: int = 0) -> Tuple[Optional[Tensor], int]:
     """Device scratch for the table-gradient scatter (csrc/hashgrid.hip, "binned" path): per (level, tile) a cursor and
-    a queue of 12-byte (local index, g0, g1) records sized 2x the uniform-hash expectation 8*M/tiles_per_level.
+    a queue of 16-byte (local index, g0, g1, pad) records sized 2x the uniform-hash expectation 8*M/tiles_per_level.
     Cached per (grid, M); the kernels fall back to the scratch-free scan when it is too small."""
     if num_points < 8192:
         return None, 0
@@ -148,7 +148,7 @@ def _scatter_workspace(grid: HashGridSpec, device, num_points: int = 0) -> Tuple
     bins = 1 << (grid.log2_hashmap_size - sl)
     tiles = bins * grid.num_levels
     cap = 2 * ((8 * num_points + bins - 1) // bins) + 64
-    words = tiles + 3 * tiles * cap
+    words = tiles + 8 + 4 * tiles * cap
     key = (grid, num_points, str(device))
     ws = _SCATTER_WS.get(key)
     if ws is None:
@@ -525,7 +525,7 @@ class _CompositeFn(torch.autograd.Function):
         d_rgb = torch.empty_like(rgb)
         d_w = torch.empty_like(weights)
         N.check(N.load().nsamd_composite_bwd(N.ptr(rgb), N.ptr(weights), N.ptr(t_bins), n, s, ctx.bg_mode, ctx.bg_vals,
-                                             N.ptr(g_out), N.ptr(g_acc), N.ptr(g_depth), N.ptr(ws), N.ptr(d_rgb),
+                                             N.ptr(g_out), N.ptr(g_acc), N.ptr(g_depth), N.ptr(ws), None, N.ptr(d_rgb),
                                              N.ptr(d_w), N.stream()), "composite_bwd")
         return d_rgb, d_w, None, None, None, None
 

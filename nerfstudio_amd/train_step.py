@@ -1,0 +1,226 @@
+"""One nerfacto training iteration as an explicit kernel schedule (no autograd graph, no torch arithmetic).
+
+What the reference does per step (engine/trainer.py:487-531 -> pipelines/base_pipeline.py:290-303 ->
+models/nerfacto.py:298-392): collider, ProposalNetworkSampler (3 levels), NerfactoField, weights, renderers, MSE +
+interlevel + distortion losses, `backward()`, optimiser. `NerfactoModel` (nerfacto.py) reproduces that through the
+module API with autograd; this runner issues THE SAME kernels in a fixed order over buffers allocated once:
+
+  forward : piecewise_bins -> [hash_fwd -> density_mlp_fwd -> weights_fwd -> pdf_resample] x 2 proposal levels
+            -> hash_fwd(main) -> field_mlp_fwd -> weights_fwd -> composite_fwd (+ median depths)
+  backward: mse_loss, distortion_loss, interlevel_loss x 2 (value + gradient in one pass each)
+            -> composite_bwd -> weights_bwd -> field_mlp_bwd -> hash_bwd(main)
+            -> (only on proposal-update steps, ray_samplers.py:590) weights_bwd -> density_mlp_bwd -> hash_bwd x 2
+
+~30 launches, every one a libnsamd kernel; parameter gradients accumulate directly into `param.grad` (the views of
+arena.ParamArena). Nothing here depends on host-side values that change from step to step (the jitter is drawn on the
+device, the anneal exponent lives in device memory), so the whole iteration can be captured in a hipGraph once per
+schedule variant and replayed. Numerically identical to the autograd path (tests/test_gpu_kernels.py compares them).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+from torch import Tensor
+
+from . import _native as N
+from . import functional as F
+from .nerfacto import NerfactoModel
+
+
+class NerfactoTrainStep:
+    def __init__(self, model: NerfactoModel, num_rays: int, device, compute_depths: bool = True) -> None:
+        self.model = model
+        cfg = model.config
+        self.cfg = cfg
+        self.n = n = int(num_rays)
+        self.counts = (*cfg.num_proposal_samples_per_ray, cfg.num_nerf_samples_per_ray)
+        self.n_prop = len(cfg.num_proposal_samples_per_ray)
+        self.compute_depths = compute_depths
+        if cfg.background_color not in ("last_sample", "random", "black", "white"):
+            raise ValueError(cfg.background_color)
+        self.bg_mode, self.bg_vals = F._bg_args(cfg.background_color, device)
+        f32 = dict(device=device, dtype=torch.float32)
+        e = lambda *shape: torch.empty(shape, **f32)  # noqa: E731
+        # ---- per-step inputs (static addresses; the caller fills them) ----
+        self.origins, self.directions = e(n, 3), e(n, 3)
+        self.camera_indices = torch.zeros((n,), device=device, dtype=torch.int64)
+        self.target = e(n, 3)
+        self.nears = torch.full((n,), float(cfg.near_plane), **f32)  # NearFarCollider, training mode
+        self.fars = torch.full((n,), float(cfg.far_plane), **f32)
+        self.jitter = e(self.n_prop + 1, n)
+        self.anneal_dev = torch.ones((1,), **f32)
+        # ---- sampler state ----
+        self.s_bins = [e(n, s + 1) for s in self.counts]
+        self.t_bins = [e(n, s + 1) for s in self.counts]
+        self.weights = [e(n, s) for s in self.counts]
+        # ---- fields ----
+        self.props = list(model.proposal_networks) if not cfg.use_same_proposal_network else \
+            [model.proposal_networks[0]] * self.n_prop
+        self.p_enc, self.p_sel, self.p_pre, self.p_dens = [], [], [], []
+        for lvl in range(self.n_prop):
+            m = n * self.counts[lvl]
+            self.p_enc.append(e(self.props[lvl].encoding.get_out_dim(), m))
+            self.p_sel.append(e(m))
+            self.p_pre.append(e(m))
+            self.p_dens.append(e(m))
+        self.m_main = mm = n * self.counts[-1]
+        fld = model.field
+        self.f_enc, self.f_sel, self.f_dens, self.f_rgb = e(fld.mlp_base.encoding.get_out_dim(), mm), e(mm), e(mm), e(mm, 3)
+        # ---- outputs ----
+        self.rgb, self.acc, self.depth_exp = e(n, 3), e(n), e(n)
+        self.minmax_ws = e(2 + 2 * ((n + 3) // 4))
+        self.depth_med = [e(n) for _ in self.counts]
+        # ---- losses / gradients ----
+        self.loss_sums = torch.zeros((1,), **f32)  # sum of squared rgb errors
+        self.dist_per_ray = e(n)
+        self.inter_per_ray = [e(n) for _ in range(self.n_prop)]
+        self.d_rgb_out = e(n, 3)
+        self.dw_dist = e(n, self.counts[-1])
+        self.dw_prop = [e(n, self.counts[lvl]) for lvl in range(self.n_prop)]
+        self.d_w_main, self.d_rgb_s, self.d_dens_main = e(n, self.counts[-1]), e(mm, 3), e(mm)
+        self.f_denc = torch.empty_like(self.f_enc)
+        self.p_ddens = [torch.empty_like(t) for t in self.p_dens]
+        self.p_denc = [torch.empty_like(t) for t in self.p_enc]
+        # host-evaluated tables (bit-identical to the reference's CPU linspace)
+        self.edges = F._linspace("edges", self.counts[0], device)
+        self.u_base = [None] + [F._linspace("u", s, device) for s in self.counts[1:]]
+
+    # -------------------------------------------------------------------------------------------------------------
+    def set_batch(self, origins: Tensor, directions: Tensor, camera_indices: Tensor, target_rgb: Tensor) -> None:
+        self.origins.copy_(origins)
+        self.directions.copy_(directions)
+        self.camera_indices.copy_(camera_indices.reshape(-1))
+        self.target.copy_(target_rgb)
+
+    def _grad(self, p: Tensor) -> Tensor:
+        assert p.grad is not None and p.grad.is_contiguous(), "parameters need preallocated .grad (use arena.ParamArena)"
+        return p.grad
+
+    def _points(self, lvl: int) -> N.Points:
+        return N.make_points(None, self.origins, self.directions, self.t_bins[lvl], self.counts[lvl])
+
+    # -------------------------------------------------------------------------------------------------------------
+    def forward_backward(self, updated: bool, draw_jitter: bool = True) -> None:
+        """One iteration up to (not including) the optimiser. `updated`: proposal networks receive gradient this step
+        (ProposalNetworkSampler.updated_this_step()). Gradients ACCUMULATE into param.grad (zero them first)."""
+        lib, st, n, cfg = N.load(), N.stream(), self.n, self.cfg
+        ck = N.check
+        if draw_jitter:
+            self.jitter.uniform_()  # torch.rand per level and ray (ray_samplers.py:105, :322), drawn on the device
+        S0 = self.counts[0]
+        ck(lib.nsamd_piecewise_bins(N.ptr(self.nears), N.ptr(self.fars), N.ptr(self.edges), N.ptr(self.jitter[0]), n, S0,
+                                    N.ptr(self.s_bins[0]), N.ptr(self.t_bins[0]), st), "piecewise_bins")
+        # ---- proposal levels ----
+        for lvl in range(self.n_prop):
+            net = self.props[lvl]
+            S, m = self.counts[lvl], n * self.counts[lvl]
+            mlp = net.mlp_base[1]
+            W0, b0, W1, b1 = mlp.param_tensors()
+            dm = N.DensityMlp(N.ptr(W0), N.ptr(b0), N.ptr(W1), N.ptr(b1), W0.shape[1], W0.shape[0],
+                              float(net.average_init_density))
+            ck(lib.nsamd_hashgrid_encode_fwd(self._points(lvl), m, net._transform, net._box, N.ptr(net.encoding.hash_table),
+                                             net.encoding.spec.native(), N.ptr(self.p_enc[lvl]), 1, m,
+                                             N.ptr(self.p_sel[lvl]), st), "hashgrid_encode_fwd")
+            ck(lib.nsamd_density_mlp_fwd(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), m, dm, N.ptr(self.p_dens[lvl]),
+                                         N.ptr(self.p_pre[lvl]), st), "density_mlp_fwd")
+            ck(lib.nsamd_weights_fwd(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), n, S, N.ptr(self.weights[lvl]), st),
+               "weights_fwd")
+            S2 = self.counts[lvl + 1]
+            ck(lib.nsamd_pdf_resample(N.ptr(self.s_bins[lvl]), N.ptr(self.weights[lvl]), S, N.ptr(self.u_base[lvl + 1]),
+                                      N.ptr(self.jitter[lvl + 1]), N.ptr(self.nears), N.ptr(self.fars), 1.0,
+                                      N.ptr(self.anneal_dev), 0.01, 1e-5, 1.0 / (2 * (S2 + 1)), n, S2,
+                                      N.ptr(self.s_bins[lvl + 1]), N.ptr(self.t_bins[lvl + 1]), None, st), "pdf_resample")
+        # ---- main field ----
+        fld = self.model.field
+        L = self.n_prop
+        S, mm = self.counts[L], self.m_main
+        enc = fld.mlp_base.encoding
+        params = [*fld.mlp_base.mlp.param_tensors(), *fld.mlp_head.param_tensors()]
+        emb = fld.embedding_appearance.embedding.weight if fld.embedding_appearance is not None else None
+        fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), emb.shape[0] if emb is not None else 0,
+                        float(fld.average_init_density))
+        cams = N.ptr(self.camera_indices) if emb is not None else None
+        ck(lib.nsamd_hashgrid_encode_fwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
+                                         enc.spec.native(), N.ptr(self.f_enc), 1, mm, N.ptr(self.f_sel), st),
+           "hashgrid_encode_fwd")
+        ck(lib.nsamd_field_mlp_fwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
+                                   N.ptr(self.f_dens), N.ptr(self.f_rgb), st), "field_mlp_fwd")
+        ck(lib.nsamd_weights_fwd(N.ptr(self.t_bins[L]), N.ptr(self.f_dens), n, S, N.ptr(self.weights[L]), st), "weights_fwd")
+        ck(lib.nsamd_composite_fwd(N.ptr(self.f_rgb), N.ptr(self.weights[L]), N.ptr(self.t_bins[L]), n, S, self.bg_mode,
+                                   self.bg_vals, 0, N.ptr(self.rgb), N.ptr(self.acc), N.ptr(self.depth_exp),
+                                   N.ptr(self.depth_med[L]) if self.compute_depths else None, None,
+                                   N.ptr(self.minmax_ws), st), "composite_fwd")
+        if self.compute_depths:  # prop_depth_i outputs of get_outputs (models/nerfacto.py:346-347)
+            for lvl in range(self.n_prop):
+                ck(lib.nsamd_composite_fwd(None, N.ptr(self.weights[lvl]), N.ptr(self.t_bins[lvl]), n, self.counts[lvl],
+                                           N.BG_NONE, None, 0, None, None, None, N.ptr(self.depth_med[lvl]), None, None, st),
+                   "composite_fwd(median)")
+        # ---- losses: value + gradient in one pass each (models/nerfacto.py:363-375) ----
+        self.loss_sums.zero_()
+        ck(lib.nsamd_mse_loss(N.ptr(self.rgb), N.ptr(self.target), 3 * n, 1.0 / (3 * n), N.ptr(self.loss_sums),
+                              N.ptr(self.d_rgb_out), st), "mse_loss")
+        ck(lib.nsamd_distortion_loss(N.ptr(self.s_bins[L]), N.ptr(self.weights[L]), S, n,
+                                     float(cfg.distortion_loss_mult) / n, N.ptr(self.dist_per_ray), N.ptr(self.dw_dist), st),
+           "distortion_loss")
+        for lvl in range(self.n_prop):
+            ck(lib.nsamd_interlevel_loss(N.ptr(self.s_bins[L]), N.ptr(self.weights[L]), S, N.ptr(self.s_bins[lvl]),
+                                         N.ptr(self.weights[lvl]), self.counts[lvl], n,
+                                         float(cfg.interlevel_loss_mult) / (n * S), N.ptr(self.inter_per_ray[lvl]),
+                                         N.ptr(self.dw_prop[lvl]) if updated else None, st), "interlevel_loss")
+        # ---- backward: main field ----
+        ck(lib.nsamd_composite_bwd(N.ptr(self.f_rgb), N.ptr(self.weights[L]), None, n, S, self.bg_mode, self.bg_vals,
+                                   N.ptr(self.d_rgb_out), None, None, None, N.ptr(self.dw_dist), N.ptr(self.d_rgb_s),
+                                   N.ptr(self.d_w_main), st), "composite_bwd")
+        ck(lib.nsamd_weights_bwd(N.ptr(self.t_bins[L]), N.ptr(self.f_dens), N.ptr(self.d_w_main), n, S,
+                                 N.ptr(self.d_dens_main), st), "weights_bwd")
+        grads = N.FieldMlpGrads(*(N.ptr(self._grad(p)) for p in params), N.ptr(self._grad(emb)) if emb is not None else None)
+        ck(lib.nsamd_field_mlp_bwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
+                                   N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s), N.ptr(self.f_denc), grads, st),
+           "field_mlp_bwd")
+        ws, ws_n = F._scatter_workspace(enc.spec, self.f_enc.device, mm)
+        ck(lib.nsamd_hashgrid_encode_bwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
+                                         enc.spec.native(), N.ptr(self.f_denc), 1, mm, N.ptr(self._grad(enc.hash_table)),
+                                         None, N.ptr(ws), ws_n, st), "hashgrid_encode_bwd")
+        # ---- backward: proposal networks (interlevel loss only; main-level weights are detached, losses.py:119-120) ----
+        if updated:
+            for lvl in range(self.n_prop):
+                net = self.props[lvl]
+                S, m = self.counts[lvl], n * self.counts[lvl]
+                mlp = net.mlp_base[1]
+                W0, b0, W1, b1 = mlp.param_tensors()
+                dm = N.DensityMlp(N.ptr(W0), N.ptr(b0), N.ptr(W1), N.ptr(b1), W0.shape[1], W0.shape[0],
+                                  float(net.average_init_density))
+                ck(lib.nsamd_weights_bwd(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]), n, S,
+                                         N.ptr(self.p_ddens[lvl]), st), "weights_bwd")
+                ck(lib.nsamd_density_mlp_bwd(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]),
+                                             N.ptr(self.p_ddens[lvl]), m, dm, N.ptr(self.p_denc[lvl]), N.ptr(self._grad(W0)),
+                                             N.ptr(self._grad(b0)), N.ptr(self._grad(W1)), N.ptr(self._grad(b1)), st),
+                   "density_mlp_bwd")
+                spec = net.encoding.spec
+                ws, ws_n = F._scatter_workspace(spec, self.f_enc.device, m)
+                ck(lib.nsamd_hashgrid_encode_bwd(self._points(lvl), m, net._transform, net._box,
+                                                 N.ptr(net.encoding.hash_table), spec.native(), N.ptr(self.p_denc[lvl]), 1, m,
+                                                 N.ptr(self._grad(net.encoding.hash_table)), None, N.ptr(ws), ws_n, st),
+                   "hashgrid_encode_bwd")
+
+    # -------------------------------------------------------------------------------------------------------------
+    def loss_dict(self) -> Dict[str, Tensor]:
+        """Loss values of the last iteration (models/nerfacto.py:363-375); a few tiny torch reductions, call on demand."""
+        n, S = self.n, self.counts[-1]
+        out = {"rgb_loss": self.loss_sums[0] / (3 * n),
+               "distortion_loss": self.cfg.distortion_loss_mult * self.dist_per_ray.sum() / n}
+        inter = sum(p.sum() for p in self.inter_per_ray) / (n * S)
+        out["interlevel_loss"] = self.cfg.interlevel_loss_mult * inter
+        return out
+
+    def outputs(self) -> Dict[str, Tensor]:
+        """The tensors NerfactoModel.get_outputs returns, as views of the static buffers."""
+        out = {"rgb": self.rgb, "accumulation": self.acc[:, None], "expected_depth": self.depth_exp[:, None],
+               "weights_list": [w[..., None] for w in self.weights]}
+        if self.compute_depths:
+            out["depth"] = self.depth_med[-1][:, None]
+            for i in range(self.n_prop):
+                out[f"prop_depth_{i}"] = self.depth_med[i][:, None]
+        return out

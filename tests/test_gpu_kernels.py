@@ -510,3 +510,58 @@ def test_full_size_properties(F):
     model.proposal_sampler._step = 0
     out2 = model(rb, jitters=None)
     assert out2["rgb"].shape == (n, 3)
+
+
+def test_train_step_runner_matches_autograd_path(F):
+    """nerfstudio_amd/train_step.py (explicit kernel schedule, gradients straight into the arena) against the
+    nn.Module / autograd path on the same rays, jitter and parameters: outputs, losses and every gradient."""
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.cameras.rays import RayBundle
+    from nerfstudio_amd.train_step import NerfactoTrainStep
+
+    cfg = small_cfg(12, 10, 6)
+    params = orc.init_params(cfg, seed=7, table_std=0.4)
+    n = 300  # not a multiple of 16 rays / 4 rays per workgroup
+    o, d, cam, tgt = orc.synthetic_rays(n, cfg.num_images, seed=8)
+    o[n // 2:] *= 4.0
+    rs = np.random.RandomState(2)
+    jit = torch.from_numpy(rs.uniform(0, 1, (3, n)).astype(np.float32)).cuda()
+
+    # autograd path
+    model_a = _hip_model(cfg, params)
+    model_a.set_step(137)
+    rb = RayBundle(origins=o.cuda(), directions=d.cuda(), pixel_area=torch.full((n, 1), 1e-6).cuda(),
+                   camera_indices=cam.cuda()[:, None])
+    out = model_a(rb, jitters=[jit[i][:, None] for i in range(3)])
+    batch = {"image": tgt.cuda()}
+    ld = model_a.get_loss_dict(out, batch, model_a.get_metrics_dict(out, batch))
+    sum(ld.values()).backward()
+
+    # runner
+    model_b = _hip_model(cfg, params)
+    model_b.set_step(137)
+    arena = ParamArena(model_b.parameters())
+    step = NerfactoTrainStep(model_b, n, torch.device("cuda"))
+    step.set_batch(o.cuda(), d.cuda(), cam.cuda(), tgt.cuda())
+    step.jitter.copy_(jit)
+    step.anneal_dev.fill_(model_b.proposal_sampler._anneal)
+    arena.zero_grad()
+    step.forward_backward(updated=True, draw_jitter=False)
+    ob = step.outputs()
+    exact(step.s_bins[2], out["ray_samples_list"][2].pack.s_bins, "final sample bins")
+    close(ob["rgb"], out["rgb"], atol=1e-6, rtol=0)
+    close(ob["accumulation"], out["accumulation"], atol=1e-6, rtol=0)
+    close(ob["expected_depth"], out["expected_depth"], rtol=1e-6)
+    exact(ob["depth"], out["depth"])
+    lb = step.loss_dict()
+    for k in ("rgb_loss", "interlevel_loss", "distortion_loss"):
+        close(lb[k], ld[k], rtol=1e-5, atol=1e-9, msg=k)
+    pa, pb = dict(model_a.named_parameters()), dict(model_b.named_parameters())
+    for k in pa:
+        gclose(pb[k].grad, pa[k].grad, 2e-5, k)
+    # a non-update step leaves the proposal networks without gradient
+    arena.zero_grad()
+    step.forward_backward(updated=False, draw_jitter=False)
+    for k, p in pb.items():
+        if k.startswith("proposal_networks"):
+            assert float(p.grad.abs().max()) == 0.0, k
