@@ -156,11 +156,14 @@ typedef struct nsamd_field_mlp_grads {          /* all accumulated; caller zero-
 } nsamd_field_mlp_grads;
 
 /* Backward recomputes the activations from enc (nothing but enc is kept from the forward).
- * ddensity [M], drgb [M,3] -> denc feature-major [32,M] (overwritten) + parameter gradients. */
+ * ddensity [M], drgb [M,3] -> denc feature-major [32,M] (overwritten) + parameter gradients.
+ * workspace (nullable): >= 256 CUs * 12544 floats of device scratch for per-workgroup weight-gradient partials
+ * (summed by a single-writer pass); without it the workgroups flush with global atomics. */
 int nsamd_field_mlp_bwd(const float* enc, const float* selector, const float* directions,
                         const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
                         nsamd_field_mlp mlp, const float* ddensity, const float* drgb, float* denc,
-                        nsamd_field_mlp_grads grads, nsamd_stream_t stream);
+                        nsamd_field_mlp_grads grads, float* workspace, int64_t workspace_floats,
+                        nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Samplers (model_components/ray_samplers.py). Bins are [num_rays, S+1]; `s` = normalised spacing domain,

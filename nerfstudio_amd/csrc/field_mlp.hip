@@ -40,6 +40,7 @@ constexpr int kOffBase0 = 0, kOffBase1 = kOffBase0 + kFragBase0, kOffHead0 = kOf
               kFragTotal = kOffHead2 + kFragHead2;  // 12288 floats = 48 KiB
 constexpr int kBiasTotal = 64 + 16 + 64 + 64 + 16;  // padded biases
 constexpr int kBiasBase0 = 0, kBiasBase1 = 64, kBiasHead0 = 80, kBiasHead1 = 144, kBiasHead2 = 208;
+constexpr int kPartialStride = kFragTotal + 256;    // floats per workgroup in the weight-gradient partial buffer
 
 __device__ __forceinline__ v4f mfma16(float a, float b, v4f c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -277,7 +278,10 @@ __device__ __forceinline__ void relu_mask(v4f* grad, const v4f* act) {
     for (int r = 0; r < 4; ++r) grad[n][r] = (act[n][r] > 0.0f) ? grad[n][r] : 0.0f;
 }
 
-// Reduce the per-wave dW tiles over the waves of the workgroup (LDS, reusing the weight area) and flush with atomics.
+// Reduce the per-wave dW tiles over the waves of the workgroup in LDS (reusing the weight area). Each lane owns a
+// distinct address per (n, m, r), so a wave can add its registers with a PLAIN read-modify-write; the caller runs the
+// waves one after the other between barriers. (ds_add_f32 with divergent addresses retires 0.33 lane-ops/clk/CU on
+// gfx950 — 12288 of them per wave made this reduction 27 % of the kernel, see profiles/r01k_pmc_summary.csv.)
 // acc lane (j,g) reg r' of tile (n,m) = dW[16n + 4g + r'][slot 16m + j]
 template <int NT, int MT>
 __device__ __forceinline__ void flush_dw(float* red, const v4f* acc, int j, int g) {
@@ -286,8 +290,7 @@ __device__ __forceinline__ void flush_dw(float* red, const v4f* acc, int j, int 
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        atomicAdd(red + (16 * n + 4 * g + r) * (16 * MT) + 16 * m + j, acc[n * MT + m][r]);  // ds_add_f32
+      for (int r = 0; r < 4; ++r) red[(16 * n + 4 * g + r) * (16 * MT) + 16 * m + j] += acc[n * MT + m][r];
 }
 
 __device__ void export_dw(const float* red, float* __restrict__ dst, int n_real, int k_real, int n_pad, int k_pad,
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(kFieldThreads, 1) void field_mlp_bwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
     nsamd_field_mlp mlp, int app_dim, const float* __restrict__ ddensity, const float* __restrict__ drgb,
-    float* __restrict__ denc, nsamd_field_mlp_grads grads) {
+    float* __restrict__ denc, nsamd_field_mlp_grads grads, float* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* wf = lds;                           // forward fragments          48 KiB
   float* wb = lds + kFragTotal;              // transposed fragments       48 KiB
@@ -448,21 +451,43 @@ __global__ __launch_bounds__(kFieldThreads, 1) void field_mlp_bwd_kernel(
   float* red = lds;  // 12288 + 256 floats needed; lds holds 2 * 12288 + ...
   for (int e = threadIdx.x; e < kFragTotal + 256; e += kFieldThreads) red[e] = 0.0f;
   __syncthreads();
-  flush_dw<4, 2>(red + kOffBase0, dW_b0, j, g);
-  flush_dw<1, 4>(red + kOffBase1, dW_b1, j, g);
-  flush_dw<4, 4>(red + kOffHead0, dW_h0, j, g);
-  flush_dw<4, 4>(red + kOffHead1, dW_h1, j, g);
-  flush_dw<1, 4>(red + kOffHead2, dW_h2, j, g);
-  float* redb = red + kFragTotal;  // bias sums: lane (j,g) holds neuron 16n + j partial
+  float* redb = red + kFragTotal;  // bias sums: lane (j,g) holds the partial of neuron 16n + j over points = g mod 4
+  for (int turn = 0; turn < kWaves; ++turn) {
+    if (wave == turn) {
+      flush_dw<4, 2>(red + kOffBase0, dW_b0, j, g);
+      flush_dw<1, 4>(red + kOffBase1, dW_b1, j, g);
+      flush_dw<4, 4>(red + kOffHead0, dW_h0, j, g);
+      flush_dw<4, 4>(red + kOffHead1, dW_h1, j, g);
+      flush_dw<1, 4>(red + kOffHead2, dW_h2, j, g);
+      // the 4 lanes (g = 0..3) sharing a bias address are folded with two xor-shuffles first
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    atomicAdd(redb + kBiasBase0 + 16 * n + j, db_b0[n]);
-    atomicAdd(redb + kBiasHead0 + 16 * n + j, db_h0[n]);
-    atomicAdd(redb + kBiasHead1 + 16 * n + j, db_h1[n]);
+      for (int n = 0; n < 4; ++n) {
+        float b0 = db_b0[n], h0 = db_h0[n], h1 = db_h1[n];
+        b0 += __shfl_xor(b0, 16); b0 += __shfl_xor(b0, 32);
+        h0 += __shfl_xor(h0, 16); h0 += __shfl_xor(h0, 32);
+        h1 += __shfl_xor(h1, 16); h1 += __shfl_xor(h1, 32);
+        if (g == 0) {
+          redb[kBiasBase0 + 16 * n + j] += b0;
+          redb[kBiasHead0 + 16 * n + j] += h0;
+          redb[kBiasHead1 + 16 * n + j] += h1;
+        }
+      }
+      float b1 = db_b1[0], h2 = db_h2[0];
+      b1 += __shfl_xor(b1, 16); b1 += __shfl_xor(b1, 32);
+      h2 += __shfl_xor(h2, 16); h2 += __shfl_xor(h2, 32);
+      if (g == 0) {
+        redb[kBiasBase1 + j] += b1;
+        redb[kBiasHead2 + j] += h2;
+      }
+    }
+    __syncthreads();
   }
-  atomicAdd(redb + kBiasBase1 + j, db_b1[0]);
-  atomicAdd(redb + kBiasHead2 + j, db_h2[0]);
-  __syncthreads();
+  if (partials != nullptr) {  // single-writer reduction in field_dw_reduce_kernel: no global atomics at all
+    float4* dst = reinterpret_cast<float4*>(partials + (size_t)blockIdx.x * kPartialStride);
+    const float4* src = reinterpret_cast<const float4*>(red);
+    for (int e = threadIdx.x; e < kPartialStride / 4; e += kFieldThreads) dst[e] = src[e];
+    return;
+  }
   export_dw(red + kOffBase0, grads.base_W0, 64, 32, 64, 32, false, 0);
   export_dw(red + kOffBase1, grads.base_W1, 16, 64, 16, 64, false, 0);
   export_dw(red + kOffHead0, grads.head_W0, 64, 31 + app_dim, 64, 64, true, app_dim);
@@ -478,6 +503,50 @@ __global__ __launch_bounds__(kFieldThreads, 1) void field_mlp_bwd_kernel(
     else { dst = grads.head_b2; idx = e - kBiasHead2; n_real = 3; }
     if (dst != nullptr && idx < n_real) unsafeAtomicAdd(dst + idx, redb[e]);
   }
+}
+
+// destination of element e of the [kPartialStride] reduction layout (weights: padded [rows][slots] per layer, then
+// the padded biases); nullptr for padding / absent tensors
+__device__ __forceinline__ float* dw_destination(int e, const nsamd_field_mlp_grads& g, int app_dim) {
+  auto weight = [&](float* base, int off, int n_real, int k_real, int k_pad, bool head0) -> float* {
+    const int row = (e - off) / k_pad, slot = (e - off) - row * k_pad;
+    const int col = head0 ? head0_col(slot, app_dim) : slot;
+    return (base != nullptr && row < n_real && col >= 0 && col < k_real) ? base + row * k_real + col : nullptr;
+  };
+  if (e < kOffBase1) return weight(g.base_W0, kOffBase0, 64, 32, 32, false);
+  if (e < kOffHead0) return weight(g.base_W1, kOffBase1, 16, 64, 64, false);
+  if (e < kOffHead1) return weight(g.head_W0, kOffHead0, 64, 31 + app_dim, 64, true);
+  if (e < kOffHead2) return weight(g.head_W1, kOffHead1, 64, 64, 64, false);
+  if (e < kFragTotal) return weight(g.head_W2, kOffHead2, 3, 64, 64, false);
+  const int b = e - kFragTotal;
+  auto bias = [&](float* base, int off, int n_real) -> float* {
+    return (base != nullptr && b - off < n_real) ? base + (b - off) : nullptr;
+  };
+  if (b < kBiasBase1) return bias(g.base_b0, kBiasBase0, 64);
+  if (b < kBiasHead0) return bias(g.base_b1, kBiasBase1, 16);
+  if (b < kBiasHead1) return bias(g.head_b0, kBiasHead0, 64);
+  if (b < kBiasHead2) return bias(g.head_b1, kBiasHead1, 64);
+  if (b < kBiasTotal) return bias(g.head_b2, kBiasHead2, 3);
+  return nullptr;
+}
+
+// grads[...] += sum over workgroups of their partial weight gradients (one thread per element: sole writer)
+__global__ void field_dw_reduce_kernel(const float* __restrict__ partials, int num_partials, nsamd_field_mlp_grads grads,
+                                       int app_dim) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= kPartialStride) return;
+  float* dst = dw_destination(e, grads, app_dim);
+  if (dst == nullptr) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < num_partials; b += 4) {
+    s0 += partials[(size_t)(b + 0) * kPartialStride + e];
+    s1 += partials[(size_t)(b + 1) * kPartialStride + e];
+    s2 += partials[(size_t)(b + 2) * kPartialStride + e];
+    s3 += partials[(size_t)(b + 3) * kPartialStride + e];
+  }
+  for (; b < num_partials; ++b) s0 += partials[(size_t)b * kPartialStride + e];
+  *dst += (s0 + s1) + (s2 + s3);
 }
 
 // one MFMA with the assumed operand / result lane mapping (layout probe for the tests)
@@ -543,7 +612,8 @@ extern "C" int nsamd_field_mlp_fwd(const float* enc, const float* selector, cons
 extern "C" int nsamd_field_mlp_bwd(const float* enc, const float* selector, const float* directions,
                                    const int64_t* camera_indices, const float* appearance_const, int64_t dir_group,
                                    int64_t M, nsamd_field_mlp mlp, const float* ddensity, const float* drgb,
-                                   float* denc, nsamd_field_mlp_grads grads, nsamd_stream_t stream) {
+                                   float* denc, nsamd_field_mlp_grads grads, float* workspace,
+                                   int64_t workspace_floats, nsamd_stream_t stream) {
   if (M == 0) return NSAMD_OK;
   int app_dim = 0;
   int st = field_common_checks(enc, directions, dir_group, M, mlp, camera_indices, appearance_const, &app_dim);
@@ -559,10 +629,16 @@ extern "C" int nsamd_field_mlp_bwd(const float* enc, const float* selector, cons
   }
   const int64_t tiles = (M + 15) / 16;
   const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + kWaves - 1) / kWaves);
+  float* partials = (workspace != nullptr && workspace_floats >= (int64_t)blocks * kPartialStride) ? workspace : nullptr;
   field_mlp_bwd_kernel<<<blocks, kFieldThreads, lds, (hipStream_t)stream>>>(
       enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-      grads);
+      grads, partials);
   NSAMD_CHECK_LAUNCH();
+  if (partials != nullptr) {
+    field_dw_reduce_kernel<<<(kPartialStride + 255) / 256, 256, 0, (hipStream_t)stream>>>(partials, (int)blocks, grads,
+                                                                                       app_dim);
+    NSAMD_CHECK_LAUNCH();
+  }
   return NSAMD_OK;
 }
 

@@ -132,6 +132,16 @@ def _spec_from_flat(positions, origins, directions, t_bins) -> PointSpec:
 
 
 _SCATTER_WS: dict = {}
+_FIELD_WS: dict = {}
+
+
+def field_bwd_workspace(device) -> Tuple[Tensor, int]:
+    """Scratch for the per-workgroup weight-gradient partials of nsamd_field_mlp_bwd (<= 1024 workgroups x 12544)."""
+    ws = _FIELD_WS.get(str(device))
+    if ws is None:
+        ws = torch.empty(1024 * 12544, device=device, dtype=torch.float32)
+        _FIELD_WS[str(device)] = ws
+    return ws, ws.numel()
 
 
 def _scatter_workspace(grid: HashGridSpec, device, num_points: int = 0) -> Tuple[Optional[Tensor], int]:
@@ -356,9 +366,10 @@ class _NerfactoFieldFn(torch.autograd.Function):
         mlp = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(appearance),
                          appearance.shape[0] if appearance is not None else 0, ctx.avg)
         grads = N.FieldMlpGrads(*(N.ptr(g) for g in tparams), N.ptr(tapp))
+        fws, fws_n = field_bwd_workspace(table.device)
         N.check(lib.nsamd_field_mlp_bwd(N.ptr(enc), N.ptr(sel), N.ptr(view_dirs), N.ptr(ctx.cams),
                                         N.ptr(ctx.app_const), ctx.dir_group, M, mlp, N.ptr(gdens), N.ptr(grgb),
-                                        N.ptr(denc), grads, N.stream()), "field_mlp_bwd")
+                                        N.ptr(denc), grads, N.ptr(fws), fws_n, N.stream()), "field_mlp_bwd")
         need_pos = any(ctx.needs_input_grad[:3])
         ttable, dtable = _grad_target(refs[0], ctx.needs_input_grad[4])
         dpos = torch.empty((M, 3), device=table.device, dtype=torch.float32) if need_pos else None

@@ -83,6 +83,7 @@ class NerfactoTrainStep:
         self.f_denc = torch.empty_like(self.f_enc)
         self.p_ddens = [torch.empty_like(t) for t in self.p_dens]
         self.p_denc = [torch.empty_like(t) for t in self.p_enc]
+        self.field_ws, _ = F.field_bwd_workspace(device)
         # host-evaluated tables (bit-identical to the reference's CPU linspace)
         self.edges = F._linspace("edges", self.counts[0], device)
         self.u_base = [None] + [F._linspace("u", s, device) for s in self.counts[1:]]
@@ -177,8 +178,8 @@ class NerfactoTrainStep:
                                  N.ptr(self.d_dens_main), st), "weights_bwd")
         grads = N.FieldMlpGrads(*(N.ptr(self._grad(p)) for p in params), N.ptr(self._grad(emb)) if emb is not None else None)
         ck(lib.nsamd_field_mlp_bwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
-                                   N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s), N.ptr(self.f_denc), grads, st),
-           "field_mlp_bwd")
+                                   N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s), N.ptr(self.f_denc), grads, N.ptr(self.field_ws),
+                                   self.field_ws.numel(), st), "field_mlp_bwd")
         ws, ws_n = F._scatter_workspace(enc.spec, self.f_enc.device, mm)
         ck(lib.nsamd_hashgrid_encode_bwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
                                          enc.spec.native(), N.ptr(self.f_denc), 1, mm, N.ptr(self._grad(enc.hash_table)),
