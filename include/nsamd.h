@@ -166,15 +166,27 @@ int nsamd_field_mlp_bwd(const float* enc, const float* selector, const float* di
                         nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Generic dense layer for the stand-alone MLP of the plugin API (MLP.pytorch_fwd, field_components/mlp.py:160-179):
+ * y[M,N] = act(x[M,K] W[N,K]^T + b[N]); activation 0 = none, 1 = ReLU, 2 = Sigmoid; K, N <= 128; fp32 MFMA.
+ * Backward: dx[M,K] (nullable, overwritten), dW[N,K] / db[N] accumulated (nullable); y = the forward's output.
+ * ------------------------------------------------------------------------------------------------------------ */
+int nsamd_linear_fwd(const float* x, const float* W, const float* b, int64_t M, int32_t K, int32_t N, int activation,
+                     float* y, nsamd_stream_t stream);
+int nsamd_linear_bwd(const float* x, const float* W, const float* y, const float* dy, int64_t M, int32_t K, int32_t N,
+                     int activation, float* dx, float* dW, float* db, nsamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Samplers (model_components/ray_samplers.py). Bins are [num_rays, S+1]; `s` = normalised spacing domain,
  * `t` = euclidean distance. lin_host-free: `edges` is the device copy of torch.linspace(0,1,S+1) and `u_base` of
  * torch.linspace(0, 1-1/(S+1), S+1) (the host evaluates them with torch so the fp32 values are the reference's).
  * jitter (nullable = eval) is the raw U[0,1) draw per ray ([num_rays], single_jitter).
  * ------------------------------------------------------------------------------------------------------------ */
 
-/* UniformLinDispPiecewiseSampler / SpacedSampler.generate_ray_samples (ray_samplers.py:78-128, 225-248). */
+/* SpacedSampler.generate_ray_samples (ray_samplers.py:78-128): spacing 0 = UniformLinDispPiecewiseSampler
+ * (:225-248, nerfacto default), 1 = UniformSampler (:131-155, the Blender benchmark recipe). */
 int nsamd_piecewise_bins(const float* nears, const float* fars, const float* edges, const float* jitter,
-                         int64_t num_rays, int32_t S, float* s_bins, float* t_bins, nsamd_stream_t stream);
+                         int64_t num_rays, int32_t S, int spacing, float* s_bins, float* t_bins,
+                         nsamd_stream_t stream);
 
 /* RaySamples.get_weights (cameras/rays.py:129-152): left-to-right cumsum per ray. */
 int nsamd_weights_fwd(const float* t_bins, const float* density, int64_t num_rays, int32_t S, float* weights,
@@ -187,11 +199,13 @@ int nsamd_weights_bwd(const float* t_bins, const float* density, const float* dw
  * searchsorted(side="right") result as int32 [num_rays, S+1]. u_offset = (float)(1.0 / (2 * (S+1))) is the eval-mode
  * offset (ray_samplers.py:327), rounded double->float by the host like torch rounds the Python scalar.
  * anneal_dev (nullable): device copy of the anneal exponent; overrides `anneal` so that a captured hipGraph of the
- * training step can be replayed while the schedule advances. */
+ * training step can be replayed while the schedule advances. spacing: as in nsamd_piecewise_bins (the s -> t map of
+ * the initial sampler, ray_samplers.py:112-116). */
 int nsamd_pdf_resample(const float* s_bins_prev, const float* weights, int32_t S_prev, const float* u_base,
                        const float* jitter, const float* nears, const float* fars, float anneal,
-                       const float* anneal_dev, float histogram_padding, float eps, float u_offset, int64_t num_rays,
-                       int32_t S, float* s_bins, float* t_bins, int32_t* inds, nsamd_stream_t stream);
+                       const float* anneal_dev, float histogram_padding, float eps, float u_offset, int spacing,
+                       int64_t num_rays, int32_t S, float* s_bins, float* t_bins, int32_t* inds,
+                       nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Compositing (model_components/renderers.py): RGBRenderer.combine_rgb :72-119 (+ eval nan_to_num/clamp

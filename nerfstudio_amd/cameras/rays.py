@@ -27,6 +27,7 @@ class RayPack:
     s_bins: Optional[Tensor] = None  # [N,S+1] normalised spacing bin edges
     nears: Optional[Tensor] = None  # [N]
     fars: Optional[Tensor] = None  # [N]
+    spacing: int = 0  # s -> t map of the initial sampler: 0 = uniform / linear-in-disparity piecewise, 1 = uniform
 
 
 @dataclass
@@ -177,8 +178,8 @@ class RayBundle:
         )
 
 
-def samples_from_bins(ray_bundle: RayBundle, s_bins: Tensor, t_bins: Tensor, spacing_to_euclidean_fn: Optional[Callable]
-                      ) -> RaySamples:
+def samples_from_bins(ray_bundle: RayBundle, s_bins: Tensor, t_bins: Tensor, spacing_to_euclidean_fn: Optional[Callable],
+                      spacing: int = 0) -> RaySamples:
     """RaySamples over dense `[N,S+1]` bin-edge arrays (what the HIP samplers emit), with the pack attached."""
     pack = RayPack(
         origins=ray_bundle.origins,
@@ -187,6 +188,7 @@ def samples_from_bins(ray_bundle: RayBundle, s_bins: Tensor, t_bins: Tensor, spa
         s_bins=s_bins,
         nears=None if ray_bundle.nears is None else ray_bundle.nears.reshape(-1),
         fars=None if ray_bundle.fars is None else ray_bundle.fars.reshape(-1),
+        spacing=spacing,
     )
     return ray_bundle.get_ray_samples(
         bin_starts=t_bins[..., :-1, None],

@@ -151,6 +151,12 @@ NSAMD_HD float spacing_fn_inv(float x) { return (x < 0.5f) ? (2.0f * x) : (1.0f 
 NSAMD_HD float spacing_to_euclidean(float s, float s_near, float s_far) {
   return spacing_fn_inv(s * s_far + (1.0f - s) * s_near);
 }
+// spacing 0 = UniformLinDispPiecewiseSampler (ray_samplers.py:244-245), 1 = UniformSampler (identity, :131-155)
+NSAMD_HD float spacing_fn_mode(int spacing, float x) { return spacing == 1 ? x : spacing_fn(x); }
+NSAMD_HD float spacing_to_euclidean_mode(int spacing, float s, float s_near, float s_far) {
+  const float v = s * s_far + (1.0f - s) * s_near;
+  return spacing == 1 ? v : spacing_fn_inv(v);
+}
 
 // ---- real spherical harmonics, 4 levels (utils/spherical_harmonics.py:24-93), same association order -----------
 NSAMD_HD void sh4_components(float x, float y, float z, float* c) {

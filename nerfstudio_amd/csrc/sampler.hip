@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kThreads) void piecewise_bins_kernel(const float* _
                                                                   const float* __restrict__ fars,
                                                                   const float* __restrict__ edges,
                                                                   const float* __restrict__ jitter,
-                                                                  int64_t num_rays, int S,
+                                                                  int64_t num_rays, int S, int spacing,
                                                                   float* __restrict__ s_bins,
                                                                   float* __restrict__ t_bins) {
   const int64_t total = num_rays * (int64_t)(S + 1);
@@ -38,10 +38,10 @@ __global__ __launch_bounds__(kThreads) void piecewise_bins_kernel(const float* _
       const float upper = (i == S) ? edges[S] : (edges[i + 1] + edges[i]) / 2.0f;
       b = lower + (upper - lower) * jitter[ray];
     }
-    const float s_near = spacing_fn(nears[ray]);
-    const float s_far = spacing_fn(fars[ray]);
+    const float s_near = spacing_fn_mode(spacing, nears[ray]);
+    const float s_far = spacing_fn_mode(spacing, fars[ray]);
     s_bins[e] = b;
-    t_bins[e] = spacing_to_euclidean(b, s_near, s_far);
+    t_bins[e] = spacing_to_euclidean_mode(spacing, b, s_near, s_far);
   }
 }
 
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     const float* __restrict__ s_bins_prev, const float* __restrict__ weights, int S_prev,
     const float* __restrict__ u_base, const float* __restrict__ jitter, const float* __restrict__ nears,
     const float* __restrict__ fars, float anneal_host, const float* __restrict__ anneal_dev, float hist_pad, float eps,
-    float u_offset, int64_t num_rays, int S,
+    float u_offset, int spacing, int64_t num_rays, int S,
     float* __restrict__ s_bins, float* __restrict__ t_bins, int32_t* __restrict__ inds) {
   extern __shared__ float lds[];
   const int ldp = (S_prev + 1) | 1;
@@ -229,10 +229,10 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     float t = nan_to_num((u - c0) / (c1 - c0), 0.0f);
     t = fminf(fmaxf(t, 0.0f), 1.0f);
     const float b = b0 + t * (b1 - b0);
-    const float s_near = spacing_fn(nears[ray]);
-    const float s_far = spacing_fn(fars[ray]);
+    const float s_near = spacing_fn_mode(spacing, nears[ray]);
+    const float s_far = spacing_fn_mode(spacing, fars[ray]);
     s_bins[ray * nb + j] = b;
-    t_bins[ray * nb + j] = spacing_to_euclidean(b, s_near, s_far);
+    t_bins[ray * nb + j] = spacing_to_euclidean_mode(spacing, b, s_near, s_far);
     if (inds != nullptr) inds[ray * nb + j] = lo;
   }
 }
@@ -244,14 +244,14 @@ using namespace nsamd;
 static inline unsigned ray_blocks(int64_t num_rays) { return (unsigned)((num_rays + kRays - 1) / kRays); }
 
 extern "C" int nsamd_piecewise_bins(const float* nears, const float* fars, const float* edges, const float* jitter,
-                                    int64_t num_rays, int32_t S, float* s_bins, float* t_bins,
+                                    int64_t num_rays, int32_t S, int spacing, float* s_bins, float* t_bins,
                                     nsamd_stream_t stream) {
-  NSAMD_REQUIRE(num_rays >= 0 && S > 0);
+  NSAMD_REQUIRE(num_rays >= 0 && S > 0 && (spacing == 0 || spacing == 1));
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(nears && fars && edges && s_bins && t_bins);
   const int64_t total = num_rays * (int64_t)(S + 1);
   const unsigned blocks = (unsigned)min((int64_t)8192, (total + kThreads - 1) / kThreads);
-  piecewise_bins_kernel<<<blocks, kThreads, 0, (hipStream_t)stream>>>(nears, fars, edges, jitter, num_rays, S,
+  piecewise_bins_kernel<<<blocks, kThreads, 0, (hipStream_t)stream>>>(nears, fars, edges, jitter, num_rays, S, spacing,
                                                                       s_bins, t_bins);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
@@ -286,16 +286,16 @@ extern "C" int nsamd_weights_bwd(const float* t_bins, const float* density, cons
 extern "C" int nsamd_pdf_resample(const float* s_bins_prev, const float* weights, int32_t S_prev,
                                   const float* u_base, const float* jitter, const float* nears, const float* fars,
                                   float anneal, const float* anneal_dev, float histogram_padding, float eps,
-                                  float u_offset, int64_t num_rays, int32_t S, float* s_bins, float* t_bins,
-                                  int32_t* inds, nsamd_stream_t stream) {
-  NSAMD_REQUIRE(num_rays >= 0 && S > 0 && S_prev > 0);
+                                  float u_offset, int spacing, int64_t num_rays, int32_t S, float* s_bins,
+                                  float* t_bins, int32_t* inds, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && S > 0 && S_prev > 0 && (spacing == 0 || spacing == 1));
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(s_bins_prev && weights && u_base && nears && fars && s_bins && t_bins);
   if (S_prev > 1024) return NSAMD_ERR_UNSUPPORTED;
   const size_t lds = sizeof(float) * (2 * kRays * ((S_prev + 1) | 1) + 2 * kRays);
   pdf_resample_kernel<<<ray_blocks(num_rays), kThreads, lds, (hipStream_t)stream>>>(
       s_bins_prev, weights, S_prev, u_base, jitter, nears, fars, anneal, anneal_dev, histogram_padding, eps, u_offset,
-      num_rays, S,
+      spacing, num_rays, S,
       s_bins, t_bins, inds);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;

@@ -3,7 +3,7 @@
 The parameters are plain `nn.Linear` weights/biases under the reference's names (`layers.{i}.weight`), so
 `state_dict`s interchange with the torch path. The arithmetic of the nerfacto shapes runs in the fused field kernels
 (csrc/density_mlp.hip for the proposal heads, csrc/field_mlp.hip on MFMA for the main field), which read these
-tensors in place; the fields call them, not `MLP.forward`.
+tensors in place; a stand-alone `MLP.forward` of any shape (widths <= 128) runs layer by layer on csrc/linear.hip.
 """
 from typing import Literal, Optional, Set, Tuple
 
@@ -63,10 +63,19 @@ class MLP(FieldComponent):
         return out
 
     def forward(self, in_tensor: Tensor) -> Tensor:
-        raise NotImplementedError(
-            "nerfstudio_amd.MLP is evaluated inside the fused HIP field kernels (HashMLPDensityField / NerfactoField); "
-            "a stand-alone generic-shape MLP kernel is not part of this build. There is no torch fallback."
-        )
+        """`[*bs, in_dim] -> [*bs, out_dim]` (mlp.py:160-179): one MFMA dense-layer kernel per layer
+        (csrc/linear.hip), ReLU between layers, optional Sigmoid at the end; widths up to 128."""
+        from .. import functional as F
+
+        x = in_tensor
+        last = len(self.layers) - 1
+        for i, layer in enumerate(self.layers):
+            if i < last:
+                act = "relu" if self.activation is not None else None
+            else:
+                act = "sigmoid" if self.out_activation is not None else None
+            x = F.linear(x, layer.weight, layer.bias, act)
+        return x
 
 
 class MLPWithHashEncoding(FieldComponent):

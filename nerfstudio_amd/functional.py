@@ -246,6 +246,50 @@ def contract_linf(x: Tensor) -> Tensor:
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# a9  stand-alone dense layer / MLP of arbitrary width (<= 128)                      (field_components/mlp.py:160-179)
+# ---------------------------------------------------------------------------------------------------------------
+_ACT = {None: 0, "relu": 1, "sigmoid": 2}
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, W: Tensor, b: Optional[Tensor], act: int):
+        N.require_cuda(x, W, b)
+        x = _f32c(x)
+        M, K = x.shape
+        Nout = W.shape[0]
+        y = torch.empty((M, Nout), device=x.device, dtype=torch.float32)
+        N.check(N.load().nsamd_linear_fwd(N.ptr(x), N.ptr(W), N.ptr(b), M, K, Nout, act, N.ptr(y), N.stream()), "linear_fwd")
+        ctx.save_for_backward(x, W, y)
+        ctx.act, ctx.has_bias = act, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        x, W, y = ctx.saved_tensors
+        gy = _f32c(gy)
+        M, K = x.shape
+        Nout = W.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.zeros_like(W) if ctx.needs_input_grad[1] else None
+        db = torch.zeros((Nout,), device=x.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if dW is None and db is not None:
+            dW = torch.zeros_like(W)
+        N.check(N.load().nsamd_linear_bwd(N.ptr(x), N.ptr(W), N.ptr(y), N.ptr(gy), M, K, Nout, ctx.act, N.ptr(dx), N.ptr(dW),
+                                          N.ptr(db), N.stream()), "linear_bwd")
+        return dx, (dW if ctx.needs_input_grad[1] else None), db, None
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], activation: Optional[str] = None) -> Tensor:
+    """act(x W^T + b) on `[*bs, K]` with `weight [N,K]` (nn.Linear layout); activation None | "relu" | "sigmoid"."""
+    if weight.shape[0] > 128 or weight.shape[1] > 128:
+        raise RuntimeError("nsamd linear layers support widths up to 128")
+    shape = x.shape[:-1]
+    y = _LinearFn.apply(x.reshape(-1, x.shape[-1]), weight, bias, _ACT[activation])
+    return y.view(*shape, weight.shape[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # a6  proposal density field: contraction -> hash grid -> MLP -> trunc_exp           (fields/density_fields.py:94-117)
 # ---------------------------------------------------------------------------------------------------------------
 class _DensityFieldFn(torch.autograd.Function):
@@ -419,7 +463,8 @@ def _linspace(kind: str, num_samples: int, device) -> Tensor:
 
 
 @torch.no_grad()
-def piecewise_bins(nears: Tensor, fars: Tensor, num_samples: int, jitter: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+def piecewise_bins(nears: Tensor, fars: Tensor, num_samples: int, jitter: Optional[Tensor], spacing: int = 0
+                   ) -> Tuple[Tensor, Tensor]:
     """UniformLinDispPiecewiseSampler (ray_samplers.py:78-128, 225-248). nears/fars `[N]` or `[N,1]`;
     jitter = the single-jitter U[0,1) draw per ray or None (eval). Returns (s_bins, t_bins) `[N, S+1]`."""
     N.require_cuda(nears, fars, jitter)
@@ -430,7 +475,7 @@ def piecewise_bins(nears: Tensor, fars: Tensor, num_samples: int, jitter: Option
     t_bins = torch.empty_like(s_bins)
     edges = _linspace("edges", num_samples, nears.device)
     N.check(N.load().nsamd_piecewise_bins(N.ptr(nears), N.ptr(fars), N.ptr(edges), N.ptr(jitter), n, num_samples,
-                                          N.ptr(s_bins), N.ptr(t_bins), N.stream()), "piecewise_bins")
+                                          int(spacing), N.ptr(s_bins), N.ptr(t_bins), N.stream()), "piecewise_bins")
     return s_bins, t_bins
 
 
@@ -464,7 +509,7 @@ def weights_from_density(t_bins: Tensor, density: Tensor) -> Tensor:
 @torch.no_grad()
 def pdf_resample(s_bins_prev: Tensor, weights: Tensor, num_samples: int, jitter: Optional[Tensor], nears: Tensor,
                  fars: Tensor, anneal: float = 1.0, histogram_padding: float = 0.01, eps: float = 1e-5,
-                 return_indices: bool = False, anneal_dev: Optional[Tensor] = None):
+                 return_indices: bool = False, anneal_dev: Optional[Tensor] = None, spacing: int = 0):
     """PDFSampler.generate_ray_samples(include_original=False) (ray_samplers.py:276-372) incl. the weight anneal
     (ray_samplers.py:601). Returns (s_bins, t_bins[, inds]) with `[N, S+1]` each; inds int32."""
     N.require_cuda(s_bins_prev, weights, nears, fars, jitter)
@@ -481,7 +526,7 @@ def pdf_resample(s_bins_prev: Tensor, weights: Tensor, num_samples: int, jitter:
     N.check(N.load().nsamd_pdf_resample(N.ptr(s_bins_prev), N.ptr(weights), s_prev, N.ptr(u_base), N.ptr(jitter),
                                         N.ptr(nears), N.ptr(fars), float(anneal), N.ptr(anneal_dev),
                                         float(histogram_padding), float(eps),
-                                        1.0 / (2 * nb), n, num_samples, N.ptr(s_bins), N.ptr(t_bins), N.ptr(inds),
+                                        1.0 / (2 * nb), int(spacing), n, num_samples, N.ptr(s_bins), N.ptr(t_bins), N.ptr(inds),
                                         N.stream()), "pdf_resample")
     return (s_bins, t_bins, inds) if return_indices else (s_bins, t_bins)
 

@@ -25,9 +25,11 @@ class Sampler(nn.Module):
         return self.generate_ray_samples(*args, **kwargs)
 
 
-def _spacing_closure(nears: Tensor, fars: Tensor) -> Callable:
+def _spacing_closure(nears: Tensor, fars: Tensor, spacing: int = 0) -> Callable:
     """The reference's `spacing_to_euclidean_fn` closure (ray_samplers.py:112-116) for downstream torch callers; the
     HIP samplers evaluate the same map in-kernel."""
+    if spacing == 1:
+        return lambda x: x * fars + (1 - x) * nears
     fn = lambda x: torch.where(x < 1, x / 2, 1 - 1 / (2 * x))  # noqa: E731
     inv = lambda x: torch.where(x < 0.5, 2 * x, 1 / (2 - 2 * x))  # noqa: E731
     s_near, s_far = fn(nears), fn(fars)
@@ -36,6 +38,8 @@ def _spacing_closure(nears: Tensor, fars: Tensor) -> Callable:
 
 class UniformLinDispPiecewiseSampler(Sampler):
     """First half of the samples uniform, second half linear in disparity (ray_samplers.py:225-248)."""
+
+    spacing = 0
 
     def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=False) -> None:
         super().__init__(num_samples=num_samples)
@@ -59,8 +63,16 @@ class UniformLinDispPiecewiseSampler(Sampler):
                 jitter = torch.rand((num_rays, 1), dtype=torch.float32, device=ray_bundle.origins.device)
         else:
             jitter = None
-        s_bins, t_bins = F.piecewise_bins(ray_bundle.nears, ray_bundle.fars, num_samples, jitter)
-        return samples_from_bins(ray_bundle, s_bins, t_bins, _spacing_closure(ray_bundle.nears, ray_bundle.fars))
+        s_bins, t_bins = F.piecewise_bins(ray_bundle.nears, ray_bundle.fars, num_samples, jitter, self.spacing)
+        return samples_from_bins(ray_bundle, s_bins, t_bins,
+                                 _spacing_closure(ray_bundle.nears, ray_bundle.fars, self.spacing), self.spacing)
+
+
+class UniformSampler(UniformLinDispPiecewiseSampler):
+    """Sample uniformly along a ray (ray_samplers.py:131-155) — the `proposal-initial-sampler uniform` of the Blender
+    benchmark recipe (scripts/benchmarking/launch_train_blender.sh:28-33). Same kernel, identity spacing function."""
+
+    spacing = 1
 
 
 class PDFSampler(Sampler):
@@ -94,14 +106,15 @@ class PDFSampler(Sampler):
                 jitter = torch.rand((weights.shape[0], 1), device=weights.device)
         else:
             jitter = None
+        spacing = ray_samples.pack.spacing if ray_samples.pack is not None else 0
         if ray_samples.pack is not None and ray_samples.pack.s_bins is not None:
             existing = ray_samples.pack.s_bins
         else:
             existing = torch.cat([ray_samples.spacing_starts[..., 0], ray_samples.spacing_ends[..., -1:, 0]], dim=-1)
         s_bins, t_bins = F.pdf_resample(existing, weights[..., 0], num_samples, jitter, ray_bundle.nears, ray_bundle.fars,
                                         anneal=anneal, histogram_padding=self.histogram_padding, eps=eps,
-                                        anneal_dev=anneal_dev)
-        return samples_from_bins(ray_bundle, s_bins, t_bins, ray_samples.spacing_to_euclidean_fn)
+                                        anneal_dev=anneal_dev, spacing=spacing)
+        return samples_from_bins(ray_bundle, s_bins, t_bins, ray_samples.spacing_to_euclidean_fn, spacing)
 
 
 class ProposalNetworkSampler(Sampler):

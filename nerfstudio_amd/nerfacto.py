@@ -43,6 +43,7 @@ class NerfactoModelConfig:
     features_per_level: int = 2
     num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96)
     num_nerf_samples_per_ray: int = 48
+    proposal_initial_sampler: Literal["piecewise", "uniform"] = "piecewise"
     proposal_update_every: int = 5
     proposal_warmup: int = 5000
     num_proposal_iterations: int = 2
@@ -116,7 +117,13 @@ class NerfactoModel(nn.Module):
             return np.clip(np.interp(step, [0, c.proposal_warmup], [0, c.proposal_update_every]), 1,
                            c.proposal_update_every)
 
+        initial_sampler = None  # piecewise by default (models/nerfacto.py:215-218)
+        if c.proposal_initial_sampler == "uniform":
+            from .model_components.ray_samplers import UniformSampler
+
+            initial_sampler = UniformSampler(single_jitter=c.use_single_jitter)
         self.proposal_sampler = ProposalNetworkSampler(
+            initial_sampler=initial_sampler,
             num_nerf_samples_per_ray=c.num_nerf_samples_per_ray,
             num_proposal_samples_per_ray=c.num_proposal_samples_per_ray,
             num_proposal_network_iterations=c.num_proposal_iterations,

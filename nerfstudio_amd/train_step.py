@@ -84,6 +84,7 @@ class NerfactoTrainStep:
         self.p_ddens = [torch.empty_like(t) for t in self.p_dens]
         self.p_denc = [torch.empty_like(t) for t in self.p_enc]
         self.field_ws, _ = F.field_bwd_workspace(device)
+        self.spacing = int(getattr(model.proposal_sampler.initial_sampler, "spacing", 0))
         # host-evaluated tables (bit-identical to the reference's CPU linspace)
         self.edges = F._linspace("edges", self.counts[0], device)
         self.u_base = [None] + [F._linspace("u", s, device) for s in self.counts[1:]]
@@ -112,7 +113,7 @@ class NerfactoTrainStep:
             self.jitter.uniform_()  # torch.rand per level and ray (ray_samplers.py:105, :322), drawn on the device
         S0 = self.counts[0]
         ck(lib.nsamd_piecewise_bins(N.ptr(self.nears), N.ptr(self.fars), N.ptr(self.edges), N.ptr(self.jitter[0]), n, S0,
-                                    N.ptr(self.s_bins[0]), N.ptr(self.t_bins[0]), st), "piecewise_bins")
+                                    self.spacing, N.ptr(self.s_bins[0]), N.ptr(self.t_bins[0]), st), "piecewise_bins")
         # ---- proposal levels ----
         for lvl in range(self.n_prop):
             net = self.props[lvl]
@@ -131,7 +132,7 @@ class NerfactoTrainStep:
             S2 = self.counts[lvl + 1]
             ck(lib.nsamd_pdf_resample(N.ptr(self.s_bins[lvl]), N.ptr(self.weights[lvl]), S, N.ptr(self.u_base[lvl + 1]),
                                       N.ptr(self.jitter[lvl + 1]), N.ptr(self.nears), N.ptr(self.fars), 1.0,
-                                      N.ptr(self.anneal_dev), 0.01, 1e-5, 1.0 / (2 * (S2 + 1)), n, S2,
+                                      N.ptr(self.anneal_dev), 0.01, 1e-5, 1.0 / (2 * (S2 + 1)), self.spacing, n, S2,
                                       N.ptr(self.s_bins[lvl + 1]), N.ptr(self.t_bins[lvl + 1]), None, st), "pdf_resample")
         # ---- main field ----
         fld = self.model.field

@@ -357,13 +357,17 @@ def spacing_fn_inv(x: Tensor) -> Tensor:  # ray_samplers.py:245
     return torch.where(x < 0.5, 2 * x, 1 / (2 - 2 * x))
 
 
-def spacing_to_euclidean(s: Tensor, nears: Tensor, fars: Tensor) -> Tensor:
-    """closure built at ray_samplers.py:115-116; nears/fars `[N,1]`."""
+def spacing_to_euclidean(s: Tensor, nears: Tensor, fars: Tensor, uniform: bool = False) -> Tensor:
+    """closure built at ray_samplers.py:115-116; nears/fars `[N,1]`. `uniform`: UniformSampler's identity spacing
+    function (ray_samplers.py:131-155) instead of the piecewise one."""
+    if uniform:
+        return s * fars + (1 - s) * nears
     s_near, s_far = spacing_fn(nears), spacing_fn(fars)
     return spacing_fn_inv(s * s_far + (1 - s) * s_near)
 
 
-def piecewise_bins(nears: Tensor, fars: Tensor, num_samples: int, jitter: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+def piecewise_bins(nears: Tensor, fars: Tensor, num_samples: int, jitter: Optional[Tensor], uniform: bool = False
+                   ) -> Tuple[Tensor, Tensor]:
     """Returns (s_bins, t_bins), both `[N, S+1]`. `jitter` `[N,1]` = the `torch.rand` draw of single-jitter
     stratified training (ray_samplers.py:103-111); None = eval (plain linspace)."""
     N = nears.shape[0]
@@ -374,7 +378,7 @@ def piecewise_bins(nears: Tensor, fars: Tensor, num_samples: int, jitter: Option
         lower = torch.cat([edges[:, :1], mid], -1)
         edges = lower + (upper - lower) * jitter
     s_bins = edges.expand(N, num_samples + 1).contiguous()
-    return s_bins, spacing_to_euclidean(s_bins, nears, fars)
+    return s_bins, spacing_to_euclidean(s_bins, nears, fars, uniform)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -407,6 +411,7 @@ def pdf_resample(
     histogram_padding: float = 0.01,
     eps: float = 1e-5,
     debug: Optional[dict] = None,
+    uniform: bool = False,
 ) -> Tuple[Tensor, Tensor, Tensor]:
     """Returns (s_bins `[N,S+1]`, t_bins `[N,S+1]`, inds `[N,S+1]` int64 = the searchsorted result).
     `debug`, if given, receives the intermediate `cdf` and `u` (used by the tie analysis in the tests).
@@ -440,7 +445,7 @@ def pdf_resample(
     b0, b1 = torch.gather(s_bins_prev, -1, below), torch.gather(s_bins_prev, -1, above)
     t = torch.clip(torch.nan_to_num((u - c0) / (c1 - c0), 0), 0, 1)
     s_bins = (b0 + t * (b1 - b0)).detach()  # gradients stop here            (ray_samplers.py:360)
-    return s_bins, spacing_to_euclidean(s_bins, nears, fars), inds
+    return s_bins, spacing_to_euclidean(s_bins, nears, fars, uniform), inds
 
 
 # ---------------------------------------------------------------------------------------------------------------
