@@ -76,11 +76,14 @@ class Trainer:
         self.model, self.arena, self.rb, self.batch, self.world = model, arena, ray_bundle, batch, world
         self.step = 0
         self.opt_step = 0
+        self._true_steps = dict(arena.step_counts)
         dev = ray_bundle.origins.device
-        self.hyper = torch.zeros(3, device=dev)  # [lr/(1-b1^t), 1/sqrt(1-b2^t), anneal]
-        self.hyper_host = torch.zeros(3).pin_memory()
+        # device-resident step-dependent scalars: Adam (step size, 1/sqrt(bc2)) per optimiser group + the anneal exponent
+        self.hyper = torch.zeros(5, device=dev)
+        self.hyper_host = torch.zeros(5).pin_memory()
+        self.hyper_views = {"fields": self.hyper[0:2], "proposal_networks": self.hyper[2:4]}
         self.loss_buf = torch.zeros((), device=dev)
-        model.proposal_sampler.anneal_dev = self.hyper[2:3]
+        model.proposal_sampler.anneal_dev = self.hyper[4:5]
         self.graphs = None
         self.use_graph = use_graph
         self.runner = None
@@ -89,24 +92,26 @@ class Trainer:
 
             self.runner = NerfactoTrainStep(model, ray_bundle.origins.shape[0], dev)
             self.runner.set_batch(ray_bundle.origins, ray_bundle.directions, ray_bundle.camera_indices, batch["image"])
-            self.runner.anneal_dev = self.hyper[2:3]
+            self.runner.anneal_dev = self.hyper[4:5]
 
     # -- pieces of one iteration ---------------------------------------------------------------------------------
-    def _prologue(self):
+    def _prologue(self, updated):
         from nerfstudio_amd import functional as F
 
-        m = self.model
+        m, a = self.model, self.arena
         m.set_step(self.step)  # BEFORE_TRAIN_ITERATION callback: proposal weight anneal
-        s, b = F.adam_hyper(self.opt_step + 1, self.arena.lr, self.arena.betas)
-        self.hyper_host[0], self.hyper_host[1], self.hyper_host[2] = s, b, m.proposal_sampler._anneal
-        self.hyper.copy_(self.hyper_host, non_blocking=True)
+        h = self.hyper_host
+        h[0], h[1] = F.adam_hyper(a.step_counts["fields"] + 1, a.lr, a.betas)
+        h[2], h[3] = F.adam_hyper(a.step_counts["proposal_networks"] + 1, a.lr, a.betas)
+        h[4] = m.proposal_sampler._anneal
+        self.hyper.copy_(h, non_blocking=True)
 
     def _fwd_bwd(self, updated):
         from nerfstudio_amd.cameras.rays import RayBundle
 
         if self.runner is not None:
             self.arena.zero_grad()
-            self.runner.forward_backward(updated)
+            self.runner.forward_backward_main(updated)
             return
         m = self.model
         m.proposal_sampler.force_updated = updated
@@ -120,8 +125,28 @@ class Trainer:
         loss.backward()
         self.loss_buf.copy_(loss.detach())
 
-    def _optimise(self):
-        self.arena.step(grad_scale=1.0 / self.world, hyper_dev=self.hyper)
+    def _bwd_proposals(self):
+        if self.runner is not None:  # (the autograd path has already done it inside loss.backward())
+            self.runner.backward_proposals()
+
+    def _optimise(self, updated):
+        # the reference steps an optimiser group only when it received gradients (engine/optimizers.py:160-172)
+        groups = ["fields", "proposal_networks"] if updated else ["fields"]
+        self.arena.step(grad_scale=1.0 / self.world, groups=groups, hyper_dev=self.hyper_views)
+
+    def _exchange(self, updated, between=None):
+        """Data-parallel gradient exchange (N > 1): the main-field slice (87 % of the bytes) is all-reduced
+        asynchronously on RCCL's stream while `between` (the proposal-network backward) still runs on the compute
+        stream; the proposal slice follows on update steps and is skipped otherwise (all ranks share the schedule, so
+        it is zero everywhere — DDP would average zeros)."""
+        a = self.arena
+        h1 = a.all_reduce_span(*a.groups["fields"], async_op=True)
+        if between is not None:
+            between()
+        h2 = a.all_reduce_span(*a.groups["proposal_networks"], async_op=True) if updated else None
+        for h in (h1, h2):
+            if h is not None:
+                h.wait()
 
     # -- graph capture ---------------------------------------------------------------------------------------------
     def capture(self):
@@ -130,28 +155,43 @@ class Trainer:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # allocator / autograd warm-up of both variants on a side stream
             for upd in (True, False):
-                self._prologue()
-                self._fwd_bwd(upd)
-                if self.world > 1:
-                    self.arena.all_reduce()
-                self._optimise()
-                self.opt_step += 1
+                self._eager_iteration(upd)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graphs = {}
+        single = self.world == 1
         for upd in (True, False):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g):  # single GPU: the whole iteration is one graph
                 self._fwd_bwd(upd)
-                if self.world == 1:
-                    self._optimise()
-            graphs[upd] = g
-        if self.world > 1:
+                if single:
+                    if upd:
+                        self._bwd_proposals()
+                    self._optimise(upd)
+            graphs[("main", upd)] = g
+            if not single:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._optimise(upd)
+                graphs[("opt", upd)] = g
+        if not single:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._optimise()
-            graphs["opt"] = g
+                self._bwd_proposals()
+            graphs["props"] = g
+        for name in self.arena.step_counts:  # captures executed nothing; undo the host-side counters they bumped
+            self.arena.step_counts[name] = self._true_steps[name]
         self.graphs = graphs
+
+    def _eager_iteration(self, updated):
+        self._prologue(updated)
+        self._fwd_bwd(updated)
+        if self.world > 1:
+            self._exchange(updated, between=self._bwd_proposals if updated else None)
+        elif updated:
+            self._bwd_proposals()
+        self._optimise(updated)
+        self._true_steps = dict(self.arena.step_counts)
 
     def try_capture(self):
         if not self.use_graph:
@@ -172,17 +212,17 @@ class Trainer:
     def train_iteration(self):
         ps = self.model.proposal_sampler
         updated = ps.updated_this_step()
-        self._prologue()
-        if self.graphs is not None:
-            self.graphs[updated].replay()
-            if self.world > 1:
-                self.arena.all_reduce()
-                self.graphs["opt"].replay()
+        if self.graphs is None:
+            self._eager_iteration(updated)
         else:
-            self._fwd_bwd(updated)
+            self._prologue(updated)
+            self.graphs[("main", updated)].replay()
             if self.world > 1:
-                self.arena.all_reduce()
-            self._optimise()
+                self._exchange(updated, between=self.graphs["props"].replay if updated else None)
+                self.graphs[("opt", updated)].replay()
+            for name in (("fields", "proposal_networks") if updated else ("fields",)):
+                self.arena.step_counts[name] += 1  # the replayed Adam launches did step these groups
+            self._true_steps = dict(self.arena.step_counts)
         self.opt_step += 1
         if updated:
             ps.mark_updated()
@@ -299,6 +339,8 @@ def main():
     ap.add_argument("--autograd", action="store_true",
                     help="drive the step through the nn.Module / autograd API instead of the explicit kernel schedule")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL on ROCm); gloo only for functional tests")
+    ap.add_argument("--share-gpu", action="store_true", help="functional test: every rank uses cuda:0 (needs gloo)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
     args = ap.parse_args()
 
@@ -307,11 +349,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     from nerfstudio_amd import _native
     from nerfstudio_amd import functional as F
@@ -320,7 +367,8 @@ def main():
     _native.load()  # fail loudly if the HIP extension is missing
     F.DIRECT_GRAD = True  # backward kernels accumulate straight into the arena's gradient views
     model = build_model(device, seed=0)  # same init on every rank (replicated model)
-    arena = ParamArena(model.parameters(), lr=1e-2, eps=1e-15)  # AdamOptimizerConfig(lr=1e-2, eps=1e-15)
+    # the reference's optimiser groups (models/nerfacto.py:255-260), AdamOptimizerConfig(lr=1e-2, eps=1e-15) each
+    arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
     arena.broadcast_params()
     rb, batch = synthetic_batch(device, seed=1000 + rank)  # each rank its own rays (scripts/train.py:98)
     trainer = Trainer(model, arena, rb, batch, world=world, use_graph=not args.no_graph, use_runner=not args.autograd)
@@ -370,10 +418,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "nerfacto 1xMI355X: L=16 hash (T=2^19, F=2), 64x2 MLP, 48 samples/ray, 4096 rays/batch "
-                                   "(BASELINE configs[1]); full training step incl. proposal nets 256->96, losses, Adam",
+            "config": {"workload": ("nerfacto 1xMI355X" if world == 1 else f"nerfacto {world}xMI355X data-parallel") +
+                                   ": L=16 hash (T=2^19, F=2), 64x2 MLP, 48 samples/ray, 4096 rays/batch per GPU "
+                                   "(BASELINE configs[1]/[2]); full training step incl. proposal nets 256->96, losses, Adam",
                        "rays_per_gpu": RAYS_PER_GPU, "global_rays": world * RAYS_PER_GPU,
-                       "parallelism": f"dp{world}: rays sharded by batch, one RCCL all-reduce of the 77.7 MB gradient arena",
+                       "parallelism": f"dp{world}: rays sharded by batch; RCCL all-reduce of the gradient arena slices "
+                                      "(main field 67 MB async under the proposal backward, proposals only on update steps)",
                        "params": arena.numel, "final_loss": round(float(loss), 6),
                        "launch": "hipGraph replay (2 captured variants)" if graphed else "eager",
                        "driver": "autograd modules" if args.autograd else "explicit kernel schedule (train_step.py)"},

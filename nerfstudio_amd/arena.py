@@ -14,7 +14,7 @@ Rays shard by batch: each rank draws its own rays (seed + rank, as scripts/train
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Optional
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
 import torch
 import torch.distributed as dist
@@ -26,13 +26,27 @@ _ALIGN = 64  # floats: every tensor starts on a 256-B boundary
 
 
 class ParamArena:
-    def __init__(self, params: Iterable[Parameter], lr: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-15) -> None:
+    """`params` is either an iterable of Parameters (one group "all") or an ordered dict {group name: parameters} — the
+    reference's optimiser groups (models/nerfacto.py:255-260: "fields", "proposal_networks"). Groups are laid out one
+    after the other, so each is one contiguous slice for the all-reduce and for Adam, and each has its own step counter:
+    the reference steps a group's Adam only on iterations where the group received gradients
+    (engine/optimizers.py:160-172 with zero_grad(set_to_none=True)), i.e. the proposal networks' parameters and moments
+    stay untouched on the steps where the sampler runs them under no_grad (ray_samplers.py:590,604-609)."""
+
+    def __init__(self, params: Union[Iterable[Parameter], Dict[str, Iterable[Parameter]]], lr: float = 1e-2,
+                 betas=(0.9, 0.999), eps: float = 1e-15) -> None:
+        groups = params if isinstance(params, dict) else {"all": params}
         self.params: List[Parameter] = []
+        self.group_params: Dict[str, List[Parameter]] = {}
         seen = set()
-        for p in params:
-            if id(p) not in seen and p.requires_grad:
-                seen.add(id(p))
-                self.params.append(p)
+        for name, plist in groups.items():
+            mine = []
+            for p in plist:
+                if id(p) not in seen and p.requires_grad:
+                    seen.add(id(p))
+                    mine.append(p)
+            self.group_params[name] = mine
+            self.params += mine
         assert self.params, "no trainable parameters"
         dev = self.params[0].device
         self.offsets, total = [], 0
@@ -50,14 +64,37 @@ class ParamArena:
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
+        self.groups: Dict[str, Tuple[int, int]] = {n: self.span(pl) for n, pl in self.group_params.items() if pl}
+        self.step_counts: Dict[str, int] = {n: 0 for n in self.groups}
         self.lr, self.betas, self.eps = lr, betas, eps
-        self.step_count = 0
+
+    @property
+    def step_count(self) -> int:
+        return max(self.step_counts.values())
 
     def zero_grad(self) -> None:
         self.grad.zero_()
         for p, off in zip(self.params, self.offsets):  # autograd may have replaced .grad; re-point the views
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + p.numel()].view(p.shape)
+
+    def span(self, params: Iterable[Parameter]):
+        """(start, end) float offsets of the contiguous arena range holding `params` (they must be adjacent, which is
+        how callers build the arena: one parameter group after the other)."""
+        ids = {id(p) for p in params}
+        idx = [i for i, p in enumerate(self.params) if id(p) in ids]
+        assert idx and idx == list(range(idx[0], idx[-1] + 1)), "parameters of a span must be adjacent in the arena"
+        start = self.offsets[idx[0]]
+        end = self.offsets[idx[-1] + 1] if idx[-1] + 1 < len(self.params) else self.numel
+        return start, end
+
+    def all_reduce_span(self, start: int, end: int, async_op: bool = False, group: Optional[dist.ProcessGroup] = None):
+        """Sum one contiguous slice of the gradient arena over the ranks. With async_op the collective runs on the
+        communication stream (RCCL) while the caller keeps launching compute; `.wait()` the returned handle before the
+        optimiser reads the slice. Returns None when there is nothing to do (single process)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return None
+        return dist.all_reduce(self.grad[start:end], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
     def all_reduce(self, group: Optional[dist.ProcessGroup] = None) -> float:
         """Sum the gradient arena over the ranks (RCCL when the tensors are on the GPU, gloo on CPU). Returns the scale
@@ -75,9 +112,14 @@ class ParamArena:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.broadcast(self.flat, src=src, group=group)
 
-    def step(self, grad_scale: float = 1.0, lr: Optional[float] = None, hyper_dev: Optional[torch.Tensor] = None) -> None:
-        """One Adam update of the whole arena. With `hyper_dev` (device floats from functional.adam_hyper) the launch
-        carries no step-dependent host value and can be replayed from a captured hipGraph."""
-        self.step_count += 1
-        F.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, lr if lr is not None else self.lr,
-                    self.betas, self.eps, grad_scale, hyper_dev)
+    def step(self, grad_scale: float = 1.0, lr: Optional[float] = None, groups: Optional[Sequence[str]] = None,
+             hyper_dev: Optional[Dict[str, torch.Tensor]] = None) -> None:
+        """One Adam update (csrc/misc.hip) per selected group (default: all), each with its own bias-correction step.
+        `hyper_dev[name]` (device floats from functional.adam_hyper) removes every step-dependent host value from the
+        launch so it can be replayed from a captured hipGraph."""
+        for name in (groups if groups is not None else self.groups):
+            a, b = self.groups[name]
+            self.step_counts[name] += 1
+            hd = hyper_dev.get(name) if isinstance(hyper_dev, dict) else hyper_dev
+            F.adam_step(self.flat[a:b], self.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.step_counts[name],
+                        lr if lr is not None else self.lr, self.betas, self.eps, grad_scale, hd)

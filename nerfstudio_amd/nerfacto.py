@@ -142,6 +142,12 @@ class NerfactoModel(nn.Module):
     def get_param_groups(self) -> Dict[str, List[Parameter]]:
         return {"proposal_networks": list(self.proposal_networks.parameters()), "fields": list(self.field.parameters())}
 
+    def get_param_groups_ordered(self) -> Dict[str, List[Parameter]]:
+        """Same groups, main field first: the order arena.ParamArena lays them out in (the main-field gradients are
+        complete first in the backward, so their all-reduce can overlap the proposal-network backward)."""
+        g = self.get_param_groups()
+        return {"fields": g["fields"], "proposal_networks": g["proposal_networks"]}
+
     def set_step(self, step: int) -> None:
         """BEFORE_TRAIN_ITERATION callback: proposal weight anneal (models/nerfacto.py:270-280)."""
         self.step = step

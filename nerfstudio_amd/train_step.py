@@ -107,6 +107,14 @@ class NerfactoTrainStep:
     def forward_backward(self, updated: bool, draw_jitter: bool = True) -> None:
         """One iteration up to (not including) the optimiser. `updated`: proposal networks receive gradient this step
         (ProposalNetworkSampler.updated_this_step()). Gradients ACCUMULATE into param.grad (zero them first)."""
+        self.forward_backward_main(updated, draw_jitter)
+        if updated:
+            self.backward_proposals()
+
+    def forward_backward_main(self, updated: bool, draw_jitter: bool = True) -> None:
+        """Forward of everything, the losses, and the backward of the MAIN field (87 % of the gradient bytes). With data
+        parallelism the all-reduce of the main-field gradients can start right after this while `backward_proposals`
+        (interlevel-loss gradients of the proposal networks) still runs."""
         lib, st, n, cfg = N.load(), N.stream(), self.n, self.cfg
         ck = N.check
         if draw_jitter:
@@ -185,8 +193,13 @@ class NerfactoTrainStep:
         ck(lib.nsamd_hashgrid_encode_bwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
                                          enc.spec.native(), N.ptr(self.f_denc), 1, mm, N.ptr(self._grad(enc.hash_table)),
                                          None, N.ptr(ws), ws_n, st), "hashgrid_encode_bwd")
-        # ---- backward: proposal networks (interlevel loss only; main-level weights are detached, losses.py:119-120) ----
-        if updated:
+
+    def backward_proposals(self) -> None:
+        """Backward of the proposal networks (interlevel loss only; main-level weights are detached, losses.py:119-120).
+        Needs the dw_prop written by forward_backward_main(updated=True)."""
+        lib, st, n = N.load(), N.stream(), self.n
+        ck = N.check
+        for _ in (0,):
             for lvl in range(self.n_prop):
                 net = self.props[lvl]
                 S, m = self.counts[lvl], n * self.counts[lvl]

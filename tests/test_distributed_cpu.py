@@ -44,7 +44,17 @@ def _worker(rank, world, port, q):
         local = arena.grad.clone()
         scale = arena.all_reduce()
         assert scale == 1.0 / world
-        q.put((rank, [r.numpy() for r in ref0], local.numpy(), arena.grad.clone().numpy(), arena.numel))
+        summed = arena.grad.clone()
+        # grouped arena: asynchronous all-reduce of ONE group's slice leaves the other group's gradients local
+        g = ParamArena({"fields": [torch.nn.Parameter(torch.full((70,), float(rank + 1)))],
+                        "proposal_networks": [torch.nn.Parameter(torch.full((5, 3), 10.0 * (rank + 1)))]})
+        assert list(g.groups) == ["fields", "proposal_networks"] and g.groups["fields"] == (0, 128) and g.groups["proposal_networks"] == (128, 192)
+        for p_ in g.params:
+            p_.grad.copy_(p_.data)
+        h = g.all_reduce_span(*g.groups["fields"], async_op=True)
+        h.wait()
+        assert float(g.grad[:70].sum()) == 70 * 3.0 and float(g.grad[128:143].sum()) == 15 * 10.0 * (rank + 1)
+        q.put((rank, [r.numpy() for r in ref0], local.numpy(), summed.numpy(), arena.numel))
     finally:
         dist.destroy_process_group()
 

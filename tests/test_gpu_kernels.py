@@ -624,7 +624,8 @@ def test_training_trajectory_matches_oracle(F):
 
     params = orc.init_params(cfg, seed=33, table_std=0.3)
     model = _hip_model(cfg, params)
-    arena = ParamArena(model.parameters(), lr=1e-2, eps=1e-15)
+    arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)  # the reference's two optimiser groups
+    assert list(arena.groups) == ["fields", "proposal_networks"] and arena.groups["fields"][0] == 0
     runner = NerfactoTrainStep(model, n, torch.device("cuda"))
     runner.set_batch(o.cuda(), d.cuda(), cam.cuda(), tgt.cuda())
     hip_losses, schedule, anneals = [], [], []
@@ -638,7 +639,8 @@ def test_training_trajectory_matches_oracle(F):
         runner.jitter.copy_(torch.from_numpy(jit[step]))
         arena.zero_grad()
         runner.forward_backward(updated, draw_jitter=False)
-        arena.step()
+        # a group is stepped only when it received gradients (engine/optimizers.py:160-172)
+        arena.step(groups=["fields", "proposal_networks"] if updated else ["fields"])
         hip_losses.append(float(sum(runner.loss_dict().values())))
         if updated:
             ps.mark_updated()
@@ -660,6 +662,7 @@ def test_training_trajectory_matches_oracle(F):
         opt.step()
         ref_losses.append(float(loss))
     hip_losses, ref_losses = np.array(hip_losses), np.array(ref_losses)
+    assert arena.step_counts["fields"] == steps and arena.step_counts["proposal_networks"] == sum(schedule) < steps
     assert ref_losses[-1] < 0.7 * ref_losses[0], "the oracle itself should be learning"
     np.testing.assert_allclose(hip_losses[:5], ref_losses[:5], rtol=2e-4)
     np.testing.assert_allclose(hip_losses, ref_losses, rtol=3e-2)
