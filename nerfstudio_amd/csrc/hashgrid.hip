@@ -292,6 +292,9 @@ __global__ void hash_bwd_apply_kernel(nsamd_grid grid, int slice_log2, uint32_t 
     uint4 r[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u) r[u] = q[e + u * stride];
+    // (Measured: issuing the 8 reads, then the 8 CAS attempts, widens the read->CAS window enough that races between the
+    // waves on small hot tiles make it 2.4x SLOWER for the proposal tables — every lost race pays the divergent
+    // ds_add_f32 path. Keep read and CAS of a record adjacent.)
 #pragma unroll
     for (int u = 0; u < kU; ++u) lds_add_pair(acc + 2 * r[u].x, __uint_as_float(r[u].y), __uint_as_float(r[u].z));
   }
