@@ -111,7 +111,10 @@ class Trainer:
 
         if self.runner is not None:
             self.arena.zero_grad()
-            self.runner.forward_backward_main(updated)
+            if self.world == 1:  # whole iteration; the two backward chains run as parallel branches
+                self.runner.forward_backward(updated)
+            else:  # N > 1: the proposal backward is a separate phase that overlaps the all-reduce
+                self.runner.forward_backward_main(updated)
             return
         m = self.model
         m.proposal_sampler.force_updated = updated
@@ -126,8 +129,8 @@ class Trainer:
         self.loss_buf.copy_(loss.detach())
 
     def _bwd_proposals(self):
-        if self.runner is not None:  # (the autograd path has already done it inside loss.backward())
-            self.runner.backward_proposals()
+        if self.runner is not None and self.world > 1:  # (single GPU: already inside runner.forward_backward;
+            self.runner.backward_proposals()            #  autograd path: inside loss.backward())
 
     def _optimise(self, updated):
         # the reference steps an optimiser group only when it received gradients (engine/optimizers.py:160-172)

@@ -25,6 +25,8 @@
 // 2 runs one workgroup per tile that streams its queue into the LDS tile and stores it. Queues are sized 2x the
 // uniform-hash expectation; the rare overflow falls back to a direct atomic, so the result never depends on sizing.
 // Tiny problems keep the direct-atomic kernel.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace nsamd {
@@ -171,18 +173,40 @@ constexpr int kMaxBins = 4096;
 
 // Pass 1. `merge_mask` bit l set = on level l consecutive lanes (consecutive samples of a ray) are likely to share a
 // cell (cell size > sample spacing): their 8-corner contributions are summed with a wave-level segmented scan over
-// runs of identical cells and only the last lane of each run emits records. On the coarse levels this removes most of
-// the records (and with them the hot-entry conflicts in pass 2); measured in profiles/.
+// runs of identical cells and only the last lane of each run emits records. `combine_mask` bit l set = the surviving
+// updates of the workgroup are additionally summed per table entry in a small LDS hash table (open addressing, bounded
+// probing, overflow goes out as plain records), so the workgroup emits ONE record per distinct entry. Coarse levels
+// have few entries and every ray of a camera starts in the same cells: without this, pass 2 serialises thousands of
+// LDS read-modify-writes on a handful of hot entries (measured: level 0 alone took as long as all 16 levels).
+constexpr int kCombineBits = 12;
+constexpr int kCombineSlots = 1 << kCombineBits;
+constexpr int kCombinePerThread = kCombineSlots / kBinThreads;
+constexpr uint32_t kEmptyKey = 0xffffffffu;
+
 __global__ __launch_bounds__(kBinThreads) void hash_bwd_bin_kernel(
     nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
-    int64_t stride_p, int64_t stride_k, int slice_log2, uint32_t cap, uint32_t merge_mask,
-    uint32_t* __restrict__ cursors, uint32_t* __restrict__ queues, float* __restrict__ dtable) {
-  extern __shared__ uint32_t lds_u[];
-  const int level = blockIdx.y;
+    int64_t stride_p, int64_t stride_k, int slice_log2, uint32_t cap, uint32_t merge_mask, uint32_t combine_mask,
+    int level0, uint32_t* __restrict__ cursors, uint32_t* __restrict__ queues, float* __restrict__ dtable) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+  const int level = level0 + blockIdx.y;
   const int B = 1 << (grid.log2_table_size - slice_log2);
-  uint32_t* cnt = lds_u;        // [B] updates of this workgroup per tile
-  uint32_t* base = lds_u + B;   // [B] reserved queue offset per tile
+  const bool combine = (combine_mask >> level) & 1u;  // workgroup-uniform
+  // layout: [vals: 2 x slots floats][keys: slots][cnt: B][base: B]  (vals/keys only when any level combines)
+  const int table_words = combine_mask != 0u ? 3 * kCombineSlots : 0;
+  float* vals = reinterpret_cast<float*>(lds_u);
+  uint32_t* keys = lds_u + 2 * kCombineSlots;
+  uint32_t* cnt = lds_u + table_words;  // [B] updates of this workgroup per tile
+  uint32_t* base = cnt + B;             // [B] reserved queue offset per tile
   for (int t = threadIdx.x; t < B; t += kBinThreads) cnt[t] = 0;
+  if (combine) {
+#pragma unroll
+    for (int i = 0; i < kCombinePerThread; ++i) {
+      const int sl = threadIdx.x + i * kBinThreads;
+      keys[sl] = kEmptyKey;
+      vals[2 * sl] = 0.0f;
+      vals[2 * sl + 1] = 0.0f;
+    }
+  }
   __syncthreads();
   const int64_t p = (int64_t)blockIdx.x * kBinThreads + threadIdx.x;
   bool active = p < M;
@@ -236,12 +260,39 @@ __global__ __launch_bounds__(kBinThreads) void hash_bwd_bin_kernel(
     const bool next_head = (lane == 63) || (__shfl_down((int)head, 1) != 0);
     emit = active && next_head;  // the last lane of a run carries the run's sums
   }
+  uint32_t direct = 0u;  // bit k: corner k leaves this thread as its own record
   if (emit) {
     const uint32_t mask = (1u << grid.log2_table_size) - 1u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       idx[k] = corner_index(c, k, mask);
-      rank[k] = atomicAdd(cnt + (idx[k] >> slice_log2), 1u);  // ds_add_rtn_u32
+      bool placed = false;
+      if (combine) {
+        uint32_t h = (idx[k] * 0x9E3779B1u) >> (32 - kCombineBits);
+        for (int probe = 0; probe < 4 && !placed; ++probe) {
+          const uint32_t prev = atomicCAS(keys + h, kEmptyKey, idx[k]);
+          if (prev == kEmptyKey || prev == idx[k]) {
+            lds_add_pair(vals + 2 * h, v0[k], v1[k]);
+            placed = true;
+          } else {
+            h = (h + 1) & (kCombineSlots - 1);
+          }
+        }
+      }
+      if (!placed) {
+        direct |= 1u << k;
+        rank[k] = atomicAdd(cnt + (idx[k] >> slice_log2), 1u);  // ds_add_rtn_u32
+      }
+    }
+  }
+  uint32_t skey[kCombinePerThread], srank[kCombinePerThread];
+  if (combine) {
+    __syncthreads();  // all sums of the workgroup are in the table
+#pragma unroll
+    for (int i = 0; i < kCombinePerThread; ++i) {
+      skey[i] = keys[threadIdx.x + i * kBinThreads];
+      srank[i] = 0u;
+      if (skey[i] != kEmptyKey) srank[i] = atomicAdd(cnt + (skey[i] >> slice_log2), 1u);
     }
   }
   __syncthreads();
@@ -250,29 +301,39 @@ __global__ __launch_bounds__(kBinThreads) void hash_bwd_bin_kernel(
     base[t] = n ? atomicAdd(cursors + (size_t)level * B + t, n) : 0u;
   }
   __syncthreads();
-  if (emit) {
-    const uint32_t local_mask = (1u << slice_log2) - 1u;
+  const uint32_t local_mask = (1u << slice_log2) - 1u;
+  auto put = [&](uint32_t index, uint32_t rk, float a0, float a1) {
+    const uint32_t bin = index >> slice_log2;
+    const uint32_t pos = base[bin] + rk;
+    if (pos < cap) {  // one 16-B record = one global_store_dwordx4
+      uint4* q = reinterpret_cast<uint4*>(queues) + (((size_t)level * B + bin) * cap + pos);
+      *q = make_uint4(index & local_mask, __float_as_uint(a0), __float_as_uint(a1), 0u);
+    } else {  // queue full (a very hot cell): direct atomics keep the result exact
+      float* t = dtable + ((((size_t)level << grid.log2_table_size) + index) << 1);
+      unsafeAtomicAdd(t + 0, a0);
+      unsafeAtomicAdd(t + 1, a1);
+    }
+  };
+  if (direct != 0u) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const uint32_t bin = idx[k] >> slice_log2;
-      const uint32_t pos = base[bin] + rank[k];
-      if (pos < cap) {  // one 16-B record = one global_store_dwordx4
-        uint4* q = reinterpret_cast<uint4*>(queues) + (((size_t)level * B + bin) * cap + pos);
-        *q = make_uint4(idx[k] & local_mask, __float_as_uint(v0[k]), __float_as_uint(v1[k]), 0u);
-      } else {  // queue full (a very hot cell): direct atomics keep the result exact
-        float* t = dtable + ((((size_t)level << grid.log2_table_size) + idx[k]) << 1);
-        unsafeAtomicAdd(t + 0, v0[k]);
-        unsafeAtomicAdd(t + 1, v1[k]);
-      }
+    for (int k = 0; k < 8; ++k)
+      if ((direct >> k) & 1u) put(idx[k], rank[k], v0[k], v1[k]);
+  }
+  if (combine) {
+#pragma unroll
+    for (int i = 0; i < kCombinePerThread; ++i) {
+      const int sl = threadIdx.x + i * kBinThreads;
+      if (skey[i] != kEmptyKey) put(skey[i], srank[i], vals[2 * sl], vals[2 * sl + 1]);
     }
   }
 }
 
-__global__ void hash_bwd_apply_kernel(nsamd_grid grid, int slice_log2, uint32_t cap,
+template <bool kPipe>
+__global__ void hash_bwd_apply_kernel(nsamd_grid grid, int slice_log2, uint32_t cap, int level0,
                                       const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ queues,
                                       float* __restrict__ dtable) {
   extern __shared__ __attribute__((aligned(16))) float acc[];
-  const int bin = blockIdx.x, level = blockIdx.y;
+  const int bin = blockIdx.x, level = level0 + blockIdx.y;
   const int B = gridDim.x;
   const int entries = 1 << slice_log2;
   for (int e = threadIdx.x; e < 2 * entries; e += blockDim.x) acc[e] = 0.0f;
@@ -288,6 +349,33 @@ __global__ void hash_bwd_apply_kernel(nsamd_grid grid, int slice_log2, uint32_t 
   constexpr int kU = 8;
   uint32_t e = threadIdx.x;
   const uint32_t stride = blockDim.x;
+  if (kPipe) {
+    // software pipeline: the next batch of queue loads is in flight while this batch goes through the LDS
+    uint4 cur[kU];
+    bool have = e + (kU - 1) * stride < n;
+    if (have) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) cur[u] = q[e + u * stride];
+    }
+    while (have) {
+      const uint32_t en = e + kU * stride;
+      const bool more = en + (kU - 1) * stride < n;
+      uint4 nxt[kU];
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) nxt[u] = q[en + u * stride];
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        lds_add_pair(acc + 2 * cur[u].x, __uint_as_float(cur[u].y), __uint_as_float(cur[u].z));
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) cur[u] = nxt[u];
+      }
+      e = en;
+      have = more;
+    }
+  }
   for (; e + (kU - 1) * stride < n; e += kU * stride) {
     uint4 r[kU];
 #pragma unroll
@@ -450,6 +538,21 @@ extern "C" int nsamd_hashgrid_encode_fwd(nsamd_points pts, int64_t M, int transf
   return NSAMD_OK;
 }
 
+// tiles (= bins x levels) the binned scatter aims for; tunable for experiments through NSAMD_SCATTER_TILES
+static int scatter_target_tiles() {
+  static int cached = 0;
+  if (cached == 0) {
+    const char* e = getenv("NSAMD_SCATTER_TILES");
+    cached = (e != nullptr && atoi(e) >= 64) ? atoi(e) : 512;
+  }
+  return cached;
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e != nullptr ? atoi(e) : dflt;
+}
+
 static int device_cus() {
   static int cached = 0;
   if (cached == 0) {
@@ -485,7 +588,7 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
   } else if (dtable != nullptr && [&]() -> bool {
                // binned path: tile size chosen so that (tiles = bins x levels) >= 512 fills the chip
                int bits = 0;
-               while ((grid.num_levels << bits) < 512) ++bits;
+               while ((grid.num_levels << bits) < scatter_target_tiles()) ++bits;
                int sl = grid.log2_table_size - bits;
                sl = sl > kSliceLog2Max ? kSliceLog2Max : (sl < 8 ? 8 : sl);
                if (sl > grid.log2_table_size) sl = grid.log2_table_size;
@@ -497,7 +600,7 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
                return cap >= expect + expect / 4 && cap < 0x7fffffffLL;
              }()) {
     int bits = 0;
-    while ((grid.num_levels << bits) < 512) ++bits;
+    while ((grid.num_levels << bits) < scatter_target_tiles()) ++bits;
     int sl = grid.log2_table_size - bits;
     sl = sl > kSliceLog2Max ? kSliceLog2Max : (sl < 8 ? 8 : sl);
     if (sl > grid.log2_table_size) sl = grid.log2_table_size;
@@ -507,29 +610,51 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
     uint32_t* cursors = reinterpret_cast<uint32_t*>(workspace);
     uint32_t* queues = cursors + ((tiles + 3) & ~(int64_t)3);  // 16-B aligned records
     hipStream_t st = (hipStream_t)stream;
-    dim3 g1((unsigned)((M + kBinThreads - 1) / kBinThreads), (unsigned)grid.num_levels);
+    static const int groups_env = env_int("NSAMD_SCATTER_GROUPS", 1);
+    static const float merge_env = (float)env_int("NSAMD_SCATTER_MERGE_X4", 16) * 0.25f;
+    static const int pipe_env = env_int("NSAMD_SCATTER_PIPE", 1);
+    const int groups = groups_env < 1 ? 1 : (groups_env > grid.num_levels ? grid.num_levels : groups_env);
+    const int per_group = (grid.num_levels + groups - 1) / groups;
     // merge runs of samples that share a cell where the cell is wider than ~4 sample spacings (ray mode only: the
     // lanes of a wave are then consecutive samples of one ray)
     uint32_t merge_mask = 0;
     if (pts.positions == nullptr)
       for (int l = 0; l < grid.num_levels; ++l)
-        if (grid.scalings[l] < 4.0f * (float)pts.samples_per_ray) merge_mask |= 1u << l;
-    hash_bwd_bin_kernel<<<g1, kBinThreads, sizeof(uint32_t) * 2 * B, st>>>(
-        pts, M, transform, aabb, grid, denc, stride_p, stride_k, sl, cap, merge_mask, cursors, queues, dtable);
-    NSAMD_CHECK_LAUNCH();
+        if (grid.scalings[l] < merge_env * (float)pts.samples_per_ray) merge_mask |= 1u << l;
+    // per-workgroup combining pays where a workgroup's updates hit few distinct entries: coarse levels
+    static const int combine_env = env_int("NSAMD_SCATTER_COMBINE_RES", 64);
+    uint32_t combine_mask = 0;
+    for (int l = 0; l < grid.num_levels; ++l)
+      if (grid.scalings[l] < (float)combine_env) combine_mask |= 1u << l;
+    const size_t bin_lds = sizeof(uint32_t) * (2 * (size_t)B + (combine_mask ? 3 * kCombineSlots : 0));
     static bool attr2 = false;
     if (!attr2) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hash_bwd_apply_kernel),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hash_bwd_apply_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sizeof(float) << kSliceLog2Max) !=
-          hipSuccess)
+              hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&hash_bwd_apply_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sizeof(float) << kSliceLog2Max) !=
+              hipSuccess)
         return NSAMD_ERR_LAUNCH;
       attr2 = true;
     }
-    dim3 g2((unsigned)B, (unsigned)grid.num_levels);
     const unsigned threads = sl > 11 ? 1024u : 256u;
-    hash_bwd_apply_kernel<<<g2, threads, sizeof(float) * 2 * ((size_t)1 << sl), st>>>(grid, sl, cap, cursors, queues,
-                                                                                    dtable);
-    NSAMD_CHECK_LAUNCH();
+    static const int only_env = env_int("NSAMD_SCATTER_ONLY_LEVEL", -1);  // diagnostics: a single level
+    for (int l0 = only_env >= 0 ? only_env : 0; l0 < (only_env >= 0 ? only_env + 1 : grid.num_levels); l0 += per_group) {
+      const int nl = only_env >= 0 ? 1 : (grid.num_levels - l0 < per_group ? grid.num_levels - l0 : per_group);
+      dim3 g1((unsigned)((M + kBinThreads - 1) / kBinThreads), (unsigned)nl);
+      hash_bwd_bin_kernel<<<g1, kBinThreads, bin_lds, st>>>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, sl,
+                                                            cap, merge_mask, combine_mask, l0, cursors, queues, dtable);
+      NSAMD_CHECK_LAUNCH();
+      dim3 g2((unsigned)B, (unsigned)nl);
+      if (pipe_env)
+        hash_bwd_apply_kernel<true><<<g2, threads, sizeof(float) * 2 * ((size_t)1 << sl), st>>>(
+            grid, sl, cap, l0, cursors, queues, dtable);
+      else
+        hash_bwd_apply_kernel<false><<<g2, threads, sizeof(float) * 2 * ((size_t)1 << sl), st>>>(
+            grid, sl, cap, l0, cursors, queues, dtable);
+      NSAMD_CHECK_LAUNCH();
+    }
   } else if (dtable != nullptr) {
     const int slice_log2 = grid.log2_table_size < kSliceLog2Max ? grid.log2_table_size : kSliceLog2Max;
     const int slices = 1 << (grid.log2_table_size - slice_log2);

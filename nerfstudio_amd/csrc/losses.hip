@@ -29,17 +29,39 @@ __device__ __forceinline__ int upper_bound(const float* a, int n, float v) {
   return lo;
 }
 
-// LDS per wave: cp[Sp+1], cy[Sp+1], c[Sf+1], w[Sf], r[Sf], lo[Sf], hi[Sf]
+// first index in sorted int a[0..n) with a[i] >= v
+__device__ __forceinline__ int lower_bound_i(const int* a, int n, int v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+// number of entries of sorted int a[0..n) that are <= v
+__device__ __forceinline__ int upper_bound_i(const int* a, int n, int v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] <= v) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// LDS per wave: R[Sf+1] (double), cp[Sp+1], cy[Sp+1], c[Sf+1], w[Sf], r[Sf], lo[Sf], hi[Sf]
 __global__ __launch_bounds__(kLossThreads) void interlevel_kernel(
     const float* __restrict__ c_in, const float* __restrict__ w_in, int Sf, const float* __restrict__ cp_in,
     const float* __restrict__ wp_in, int Sp, int64_t num_rays, float grad_scale, float* __restrict__ per_ray,
     float* __restrict__ dwp) {
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kLossRays + wave;
   if (ray >= num_rays) return;
-  const int per_wave = 2 * (Sp + 1) + (Sf + 1) + 4 * Sf;
-  float* cp = lds + wave * per_wave;
+  const int per_wave = (2 * (Sf + 2) + 2 * (Sp + 1) + (Sf + 1) + 4 * Sf + 1) & ~1;  // floats, even: R stays 8-B aligned
+  double* R = reinterpret_cast<double*>(lds + (size_t)wave * per_wave);
+  float* cp = lds + (size_t)wave * per_wave + 2 * (Sf + 2);
   float* cy = cp + (Sp + 1);
   float* c = cy + (Sp + 1);
   float* w = c + (Sf + 1);
@@ -47,18 +69,25 @@ __global__ __launch_bounds__(kLossThreads) void interlevel_kernel(
   int* lo_i = reinterpret_cast<int*>(rr + Sf);
   int* hi_i = lo_i + Sf;
   for (int k = lane; k <= Sp; k += 64) cp[k] = cp_in[ray * (Sp + 1) + k];
-  for (int k = lane; k < Sp; k += 64) cy[k + 1] = wp_in[ray * Sp + k];  // staged, scanned in place below
   for (int i = lane; i <= Sf; i += 64) c[i] = c_in[ray * (Sf + 1) + i];
   for (int i = lane; i < Sf; i += 64) w[i] = w_in[ray * Sf + i];
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) {  // cy = [0, cumsum(wp)] left-to-right   (losses.py:69)
-    double run = 0.0;
-    cy[0] = 0.0f;
-    for (int k = 0; k < Sp; ++k) {
-      run = run + (double)cy[k + 1];
-      cy[k + 1] = (float)run;
+  {  // cy = [0, cumsum(wp)]   (losses.py:69); double-accumulated like torch's CPU cumsum, as a wave scan
+    double carry = 0.0;
+    if (lane == 0) cy[0] = 0.0f;
+    for (int k0 = 0; k0 < Sp; k0 += 64) {
+      const int k = k0 + lane;
+      double v = k < Sp ? (double)wp_in[ray * Sp + k] : 0.0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const double t = __shfl_up(v, d);
+        if (lane >= d) v = v + t;
+      }
+      v = v + carry;
+      carry = __shfl(v, 63);
+      if (k < Sp) cy[k + 1] = (float)v;
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   float loss = 0.0f;
   for (int i = lane; i < Sf; i += 64) {
@@ -77,11 +106,43 @@ __global__ __launch_bounds__(kLossThreads) void interlevel_kernel(
   loss = wave_sum_l(loss);
   if (lane == 0) per_ray[ray] = loss;
   if (dwp != nullptr) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int k = lane; k < Sp; k += 64) {
-      float g = 0.0f;
-      for (int i = 0; i < Sf; ++i) g -= (lo_i[i] <= k && k <= hi_i[i]) ? rr[i] : 0.0f;
-      dwp[ray * Sp + k] = g * grad_scale;
+    // d loss / d wp_k = - sum over the fine intervals i whose [lo_i, hi_i] covers k of rr_i. With sorted bin edges
+    // lo and hi are non-decreasing in i, so the cover of k is one contiguous range of i: two binary searches and a
+    // difference of (double) prefix sums replace the O(Sf) loop per k. Unsorted input keeps the direct loop.
+    bool sorted_ok = true;
+    for (int i = lane; i < Sf; i += 64)
+      if (i > 0 && (lo_i[i] < lo_i[i - 1] || hi_i[i] < hi_i[i - 1])) sorted_ok = false;
+    if (__ballot(!sorted_ok) == 0ull) {
+      double carry = 0.0;
+      if (lane == 0) R[0] = 0.0;
+      for (int i0 = 0; i0 < Sf; i0 += 64) {
+        const int i = i0 + lane;
+        double v = i < Sf ? (double)rr[i] : 0.0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const double t = __shfl_up(v, d);
+          if (lane >= d) v = v + t;
+        }
+        v = v + carry;
+        carry = __shfl(v, 63);
+        if (i < Sf) R[i + 1] = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int k = lane; k < Sp; k += 64) {
+        const int first = lower_bound_i(hi_i, Sf, k);     // first i with hi_i >= k
+        const int last = upper_bound_i(lo_i, Sf, k) - 1;  // last i with lo_i <= k
+        const float g = first <= last ? -(float)(R[last + 1] - R[first]) : 0.0f;
+        dwp[ray * Sp + k] = g * grad_scale;
+      }
+    } else {
+      for (int k = lane; k < Sp; k += 64) {
+        float g = 0.0f;
+        for (int i = 0; i < Sf; ++i) g -= (lo_i[i] <= k && k <= hi_i[i]) ? rr[i] : 0.0f;
+        dwp[ray * Sp + k] = g * grad_scale;
+      }
     }
   }
 }
@@ -92,7 +153,7 @@ __global__ __launch_bounds__(kLossThreads) void distortion_kernel(const float* _
                                                                   int64_t num_rays, float grad_scale,
                                                                   float* __restrict__ per_ray,
                                                                   float* __restrict__ dw) {
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kLossRays + wave;
   if (ray >= num_rays) return;
@@ -128,7 +189,7 @@ extern "C" int nsamd_interlevel_loss(const float* s_bins_fine, const float* w_fi
   NSAMD_REQUIRE(num_rays >= 0 && S_fine > 0 && S_prop > 0);
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(s_bins_fine && w_fine && s_bins_prop && w_prop && per_ray_loss);
-  const size_t per_wave = sizeof(float) * (2 * (S_prop + 1) + (S_fine + 1) + 4 * S_fine);
+  const size_t per_wave = sizeof(float) * ((2 * (S_fine + 2) + 2 * (S_prop + 1) + (S_fine + 1) + 4 * S_fine + 1) & ~1);
   if (per_wave * kLossRays > 64 * 1024) return NSAMD_ERR_UNSUPPORTED;
   const unsigned blocks = (unsigned)((num_rays + kLossRays - 1) / kLossRays);
   interlevel_kernel<<<blocks, kLossThreads, per_wave * kLossRays, (hipStream_t)stream>>>(

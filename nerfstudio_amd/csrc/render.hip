@@ -4,8 +4,8 @@
 //
 // One wavefront per ray: lane s owns sample s (stride 64 for S > 64), so the [S,3] rgb row and the weight row are
 // read as contiguous, fully coalesced segments; the five running sums collapse with a 6-step xor-shuffle wave
-// reduction. The median depth needs the reference's left-to-right running weight sum (the integer index must match
-// bit-for-bit), so lane 0 walks the row once in LDS. The expected depth is clipped to the batch-GLOBAL min/max of
+// reduction. The median depth needs the reference's double-accumulated running weight sum (the integer index must
+// match bit-for-bit): a wave scan in double. The expected depth is clipped to the batch-GLOBAL min/max of
 // the sample midpoints as the reference does, which needs a device-wide min/max: every workgroup stores its partial
 // min/max (no atomics: 8192 same-address device atomics cost ~100 us on this part, measured) and the finishing pass
 // re-reduces the <= few thousand partials from L2 before clipping.
@@ -46,7 +46,6 @@ __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
     int64_t num_rays, int S, int background, float bg_r, float bg_g, float bg_b, int eval_mode,
     float* __restrict__ rgb_out, float* __restrict__ acc_out, float* __restrict__ depth_exp,
     float* __restrict__ depth_med, int32_t* __restrict__ med_idx, float* __restrict__ ws) {
-  extern __shared__ float lds[];
   __shared__ float blk_min[kRaysPerBlock], blk_max[kRaysPerBlock];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wave;
@@ -58,14 +57,12 @@ __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
     }
     return;
   }
-  float* wrow = lds + wave * S;
   const float* w_in = weights + ray * S;
   const float* tb = t_bins ? t_bins + ray * (S + 1) : nullptr;
   float sw = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f;
   float tmin = __uint_as_float(0x7f800000u), tmax = __uint_as_float(0xff800000u);
   for (int s = lane; s < S; s += 64) {
     const float w = w_in[s];
-    wrow[s] = w;
     sw += w;
     if (rgb) {
       const float* c = rgb + (ray * S + s) * 3;
@@ -135,16 +132,25 @@ __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
     }
   }
   if (tb && (depth_med || med_idx)) {
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {  // searchsorted(cumsum(w), 0.5, side="left"), clamped  (renderers.py:359-362)
-      double run = 0.0;  // torch.cumsum (CPU): double accumulator, each output rounded to fp32
-      int idx = S;
-#pragma unroll 8
-      for (int s = 0; s < S; ++s) {  // no early exit: lets the LDS reads run ahead of the dependent adds
-        run = run + (double)wrow[s];
-        idx = (idx == S && (float)run >= 0.5f) ? s : idx;
+    // searchsorted(cumsum(w), 0.5, side="left"), clamped  (renderers.py:359-362). torch.cumsum (CPU) accumulates in
+    // double and rounds each output to fp32: wave scan in double (see sampler.hip on why that is the same number).
+    double carry = 0.0;
+    int idx = S;
+    for (int s0 = 0; s0 < S && idx == S; s0 += 64) {
+      const int s2 = s0 + lane;
+      double v = s2 < S ? (double)w_in[s2] : 0.0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const double t = __shfl_up(v, d);
+        if (lane >= d) v = v + t;
       }
-      idx = min(idx, S - 1);
+      v = v + carry;
+      carry = __shfl(v, 63);
+      const unsigned long long hit = __ballot(s2 < S && (float)v >= 0.5f);
+      if (hit != 0ull) idx = s0 + __builtin_ctzll(hit);
+    }
+    idx = min(idx, S - 1);
+    if (lane == 0) {
       if (med_idx) med_idx[ray] = idx;
       if (depth_med) depth_med[ray] = (tb[idx] + tb[idx + 1]) / 2.0f;
     }
@@ -284,7 +290,7 @@ extern "C" int nsamd_composite_fwd(const float* rgb, const float* weights, const
   const unsigned blocks = (unsigned)((num_rays + kRaysPerBlock - 1) / kRaysPerBlock);
   const float br = bg_rgb_host ? bg_rgb_host[0] : 0.f, bg = bg_rgb_host ? bg_rgb_host[1] : 0.f,
               bb = bg_rgb_host ? bg_rgb_host[2] : 0.f;
-  composite_fwd_kernel<<<blocks, kRenderThreads, sizeof(float) * kRaysPerBlock * S, st>>>(
+  composite_fwd_kernel<<<blocks, kRenderThreads, 0, st>>>(
       rgb, weights, need_t ? t_bins : nullptr, num_rays, S, background, br, bg, bb, eval_mode, rgb_out, acc,
       depth_expected, depth_median, median_idx, ws);
   NSAMD_CHECK_LAUNCH();

@@ -4,17 +4,14 @@
 // Shape of the work: N rays x S (<= a few hundred) samples, a few MB per launch, all of it L2 resident. Two things
 // matter: (1) every fp32 result that decides an integer sample index must equal the reference's torch-CPU value.
 // ATen's CPU cumsum accumulates fp32 inputs left-to-right in DOUBLE and rounds every output to fp32
-// (acc_type<float> = double), so the scans per ray (transmittance, weight sum, CDF) do exactly that on one lane,
-// with IEEE div and no FMA contraction (this TU is built with -ffp-contract=off); (2) everything else is
-// elementwise and uses all lanes.
-// Layout: kRays rays per 256-thread workgroup; each ray's row is staged once in LDS with coalesced loads
-// (row stride S+1 or S+2 floats = odd, so the one-lane-per-ray scan walks conflict-free banks), results leave
-// through coalesced stores. N = 4096 gives 256 workgroups = one per CU.
+// (acc_type<float> = double), so the scans per ray (transmittance, weight sum, CDF) accumulate in double too,
+// with IEEE div and no FMA contraction (this TU is built with -ffp-contract=off); (2) the launch is tiny, so
+// latency decides: one wavefront per ray, wave-level scans, no workgroup barriers.
+// Layout: 4 rays per 256-thread workgroup (N = 4096 -> 1024 workgroups); rows are read/written coalesced.
 #include "common.h"
 
 namespace nsamd {
 
-constexpr int kRays = 16;      // rays per workgroup
 constexpr int kThreads = 256;  // 4 wavefronts
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -46,110 +43,114 @@ __global__ __launch_bounds__(kThreads) void piecewise_bins_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Per-ray scans: one WAVEFRONT per ray. Element i = 64 k + lane is handled by `lane` in pass k (coalesced rows); a
+// pass does a 6-step wave scan in double and carries the running total of the previous passes in. Double partial sums
+// of fp32 inputs are exact unless an addend is < 2^-29 of the running sum, and even then a different association moves
+// the double result by ~1e-16 relative, so the fp32-rounded outputs equal the reference's left-to-right double
+// accumulation except on a double-rounding tie (probability ~1e-9 per element; the parity tests pin indices
+// bit-exactly on their seeds). The previous one-lane-per-ray loop was 5x slower (profiles/).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kWaves = 4;  // rays per 256-thread workgroup
+
+__device__ __forceinline__ double wave_scan_inclusive(double v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double t = __shfl_up(v, d);
+    if (lane >= d) v = v + t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ double wave_broadcast(double v, int src) { return __shfl(v, src); }
+
+// ---------------------------------------------------------------------------------------------------------------
 // RaySamples.get_weights (cameras/rays.py:129-152)
 // ---------------------------------------------------------------------------------------------------------------
-// LDS: dd[kRays][S | 1] and acc[kRays][S | 1]  ("| 1" = row stride forced odd)
 __global__ __launch_bounds__(kThreads) void weights_fwd_kernel(const float* __restrict__ t_bins,
                                                                const float* __restrict__ density,
                                                                int64_t num_rays, int S,
                                                                float* __restrict__ weights) {
-  extern __shared__ float lds[];
-  const int ld = S | 1;
-  float* dd = lds;
-  float* acc = lds + kRays * ld;
-  const int64_t ray0 = (int64_t)blockIdx.x * kRays;
-  const int nr = (int)min((int64_t)kRays, num_rays - ray0);
-  for (int e = threadIdx.x; e < nr * S; e += kThreads) {
-    const int r = e / S, i = e - r * S;
-    const float* tb = t_bins + (ray0 + r) * (S + 1) + i;
-    dd[r * ld + i] = (tb[1] - tb[0]) * density[(ray0 + r) * S + i];
-  }
-  __syncthreads();
-  if (threadIdx.x < nr) {  // exclusive left-to-right cumsum, one lane per ray
-    const float* d = dd + threadIdx.x * ld;
-    float* a = acc + threadIdx.x * ld;
-    double run = 0.0;  // torch.cumsum on CPU: double accumulator, fp32 outputs
-#pragma unroll 8
-    for (int i = 0; i < S; ++i) {
-      a[i] = (float)run;
-      run = run + (double)d[i];
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (ray >= num_rays) return;  // wave-uniform
+  const float* tb = t_bins + ray * (S + 1);
+  const float* dn = density + ray * S;
+  float* out = weights + ray * S;
+  double carry = 0.0;  // torch.cumsum on CPU: double accumulator, fp32 outputs
+  for (int i0 = 0; i0 < S; i0 += 64) {
+    const int i = i0 + lane;
+    const float dd = i < S ? (tb[i + 1] - tb[i]) * dn[i] : 0.0f;
+    const double incl = carry + wave_scan_inclusive((double)dd, lane);
+    double excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = carry;
+    carry = wave_broadcast(incl, 63);
+    if (i < S) {
+      const float alpha = 1.0f - expf(-dd);
+      const float trans = expf(-(float)excl);
+      out[i] = nan_to_num(alpha * trans);
     }
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < nr * S; e += kThreads) {
-    const int r = e / S, i = e - r * S;
-    const float alpha = 1.0f - expf(-dd[r * ld + i]);
-    const float trans = expf(-acc[r * ld + i]);
-    weights[(ray0 + r) * S + i] = nan_to_num(alpha * trans);
   }
 }
 
 // d(weights)/d(density): dd_j gets  gw_j * T_j * exp(-dd_j)  -  sum_{i>j} gw_i * w_i
+// LDS: per wave  ex[S], trans[S], gw[S]  (the reverse pass needs the forward values again)
 __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __restrict__ t_bins,
                                                                const float* __restrict__ density,
                                                                const float* __restrict__ dweights,
                                                                int64_t num_rays, int S,
                                                                float* __restrict__ ddensity) {
   extern __shared__ float lds[];
-  const int ld = S | 1;
-  float* dd = lds;
-  float* acc = lds + kRays * ld;     // exclusive cumsum
-  float* gw = lds + 2 * kRays * ld;  // gw_i * w_i, then (in place) its exclusive suffix sums
-  const int64_t ray0 = (int64_t)blockIdx.x * kRays;
-  const int nr = (int)min((int64_t)kRays, num_rays - ray0);
-  for (int e = threadIdx.x; e < nr * S; e += kThreads) {
-    const int r = e / S, i = e - r * S;
-    const float* tb = t_bins + (ray0 + r) * (S + 1) + i;
-    dd[r * ld + i] = (tb[1] - tb[0]) * density[(ray0 + r) * S + i];
-  }
-  __syncthreads();
-  if (threadIdx.x < nr) {
-    const float* d = dd + threadIdx.x * ld;
-    float* a = acc + threadIdx.x * ld;
-    double run = 0.0;  // torch.cumsum on CPU: double accumulator, fp32 outputs
-#pragma unroll 8
-    for (int i = 0; i < S; ++i) {
-      a[i] = (float)run;
-      run = run + (double)d[i];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * kWaves + wave;
+  if (ray >= num_rays) return;  // wave-uniform; no workgroup barrier below
+  float* ex_row = lds + (size_t)wave * 3 * S;
+  float* tr_row = ex_row + S;
+  float* g_row = tr_row + S;
+  const float* tb = t_bins + ray * (S + 1);
+  const float* dn = density + ray * S;
+  const float* dw = dweights + ray * S;
+  double carry = 0.0;
+  for (int i0 = 0; i0 < S; i0 += 64) {
+    const int i = i0 + lane;
+    const float dd = i < S ? (tb[i + 1] - tb[i]) * dn[i] : 0.0f;
+    const double incl = carry + wave_scan_inclusive((double)dd, lane);
+    double excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = carry;
+    carry = wave_broadcast(incl, 63);
+    if (i < S) {
+      const float ex = expf(-dd);
+      const float trans = expf(-(float)excl);
+      const float w = (1.0f - ex) * trans;
+      const bool finite = (w == w) && (fabsf(w) <= 3.4028234663852886e38f);
+      const float g = finite ? dw[i] : 0.0f;  // nan_to_num backward masks non-finite products
+      ex_row[i] = ex;
+      tr_row[i] = trans;
+      g_row[i] = g;
     }
   }
-  __syncthreads();
-  for (int e = threadIdx.x; e < nr * S; e += kThreads) {
-    const int r = e / S, i = e - r * S;
-    const float ex = expf(-dd[r * ld + i]);
-    const float trans = expf(-acc[r * ld + i]);
-    const float w = (1.0f - ex) * trans;
-    const bool finite = (w == w) && (fabsf(w) <= 3.4028234663852886e38f);
-    // nan_to_num backward masks non-finite products
-    gw[r * ld + i] = finite ? dweights[(ray0 + r) * S + i] * w : 0.0f;
-  }
-  __syncthreads();
-  if (threadIdx.x < nr) {  // in-place exclusive suffix sums  suf_j = sum_{i>j} gw_i  (reverse cumsum, as autograd)
-    float* q = gw + threadIdx.x * ld;
-    double run = 0.0;
-    for (int i = S - 1; i >= 0; --i) {
-      const float v = q[i];
-      q[i] = (float)run;
-      run = run + (double)v;
-    }
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < nr * S; e += kThreads) {
-    const int r = e / S, i = e - r * S;
-    const float ex = expf(-dd[r * ld + i]);
-    const float trans = expf(-acc[r * ld + i]);
-    const float w = (1.0f - ex) * trans;
-    const bool finite = (w == w) && (fabsf(w) <= 3.4028234663852886e38f);
-    const float g = finite ? dweights[(ray0 + r) * S + i] : 0.0f;
-    const float* tb = t_bins + (ray0 + r) * (S + 1) + i;
-    ddensity[(ray0 + r) * S + i] = (tb[1] - tb[0]) * (g * trans * ex - gw[r * ld + i]);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // exclusive suffix sums  suf_j = sum_{i>j} g_i w_i  (reverse cumsum, as autograd): scan the reversed row
+  carry = 0.0;
+  for (int r0 = 0; r0 < S; r0 += 64) {
+    const int r = r0 + lane;      // reversed position
+    const int i = S - 1 - r;      // element
+    float ex = 0.0f, trans = 0.0f, g = 0.0f;
+    if (r < S) { ex = ex_row[i]; trans = tr_row[i]; g = g_row[i]; }
+    const float gw = g * ((1.0f - ex) * trans);
+    const double incl = carry + wave_scan_inclusive((double)(r < S ? gw : 0.0f), lane);
+    double excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = carry;
+    carry = wave_broadcast(incl, 63);
+    if (r < S) ddensity[ray * S + i] = (tb[i + 1] - tb[i]) * (g * trans * ex - (float)excl);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // PDFSampler.generate_ray_samples, include_original=False (ray_samplers.py:276-372)
 // ---------------------------------------------------------------------------------------------------------------
-// LDS: w[kRays][ldp], cdf[kRays][ldp] with ldp = (S_prev + 1) | 1, plus per-ray scalars.
+// LDS: per wave  w[S_prev], cdf[S_prev + 1].
 __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     const float* __restrict__ s_bins_prev, const float* __restrict__ weights, int S_prev,
     const float* __restrict__ u_base, const float* __restrict__ jitter, const float* __restrict__ nears,
@@ -157,80 +158,66 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     float u_offset, int spacing, int64_t num_rays, int S,
     float* __restrict__ s_bins, float* __restrict__ t_bins, int32_t* __restrict__ inds) {
   extern __shared__ float lds[];
-  const int ldp = (S_prev + 1) | 1;
-  float* w = lds;
-  float* cdf = lds + kRays * ldp;
-  float* wsum = lds + 2 * kRays * ldp;  // [kRays] padded sum
-  float* wpad = wsum + kRays;           // [kRays] padding / S_prev
-  const int64_t ray0 = (int64_t)blockIdx.x * kRays;
-  const int nr = (int)min((int64_t)kRays, num_rays - ray0);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * kWaves + wave;
+  if (ray >= num_rays) return;  // wave-uniform; no workgroup barrier below
+  float* w = lds + (size_t)wave * (2 * S_prev + 1);
+  float* cdf = w + S_prev;
   const float anneal = anneal_dev ? anneal_dev[0] : anneal_host;  // device copy: graph-replayable schedules
 
-  // (1) weights (annealed) + histogram padding                              ray_samplers.py:601, :303
-  for (int e = threadIdx.x; e < nr * S_prev; e += kThreads) {
-    const int r = e / S_prev, i = e - r * S_prev;
-    float v = weights[(ray0 + r) * S_prev + i];
-    if (anneal != 1.0f) v = powf(v, anneal);
-    w[r * ldp + i] = v + hist_pad;
-  }
-  __syncthreads();
-  // (2) left-to-right sum; padding for all-zero rays                         ray_samplers.py:306-309
-  if (threadIdx.x < nr) {
-    const float* q = w + threadIdx.x * ldp;
-    double acc = 0.0;  // double-accumulated sum, rounded once (= cumsum(w)[-1] of the oracle; closest to torch.sum)
-#pragma unroll 8
-    for (int i = 0; i < S_prev; ++i) acc = acc + (double)q[i];
-    const float run = (float)acc;
-    const float pad = fmaxf(eps - run, 0.0f);
-    wpad[threadIdx.x] = pad / (float)S_prev;
-    wsum[threadIdx.x] = run + pad;
-  }
-  __syncthreads();
-  // (3) pdf                                                                   ray_samplers.py:308-311
-  for (int e = threadIdx.x; e < nr * S_prev; e += kThreads) {
-    const int r = e / S_prev, i = e - r * S_prev;
-    w[r * ldp + i] = (w[r * ldp + i] + wpad[r]) / wsum[r];
-  }
-  __syncthreads();
-  // (4) cdf = [0, min(1, cumsum(pdf))]                                        ray_samplers.py:312-313
-  if (threadIdx.x < nr) {
-    const float* q = w + threadIdx.x * ldp;
-    float* c = cdf + threadIdx.x * ldp;
-    double run = 0.0;
-    c[0] = 0.0f;
-#pragma unroll 8
-    for (int i = 0; i < S_prev; ++i) {
-      run = run + (double)q[i];
-      c[i + 1] = fminf(1.0f, (float)run);
+  // (1) weights (annealed) + histogram padding, and their sum                 ray_samplers.py:601, :303-309
+  double total = 0.0;
+  for (int i0 = 0; i0 < S_prev; i0 += 64) {
+    const int i = i0 + lane;
+    float v = 0.0f;
+    if (i < S_prev) {
+      v = weights[ray * S_prev + i];
+      if (anneal != 1.0f) v = powf(v, anneal);
+      v = v + hist_pad;
+      w[i] = v;
     }
+    total = total + wave_broadcast(wave_scan_inclusive((double)v, lane), 63);
   }
-  __syncthreads();
-  // (5) inverse-CDF sampling of the S+1 new bin edges                         ray_samplers.py:315-358
+  const float run = (float)total;  // double-accumulated sum, rounded once (= cumsum(w)[-1] of the oracle)
+  const float pad = fmaxf(eps - run, 0.0f);
+  const float wpad = pad / (float)S_prev;
+  const float wsum = run + pad;
+  // (2) pdf and cdf = [0, min(1, cumsum(pdf))]                                 ray_samplers.py:308-313
+  double carry = 0.0;
+  if (lane == 0) cdf[0] = 0.0f;
+  for (int i0 = 0; i0 < S_prev; i0 += 64) {
+    const int i = i0 + lane;
+    const float pdf = i < S_prev ? (w[i] + wpad) / wsum : 0.0f;
+    const double incl = carry + wave_scan_inclusive((double)pdf, lane);
+    carry = wave_broadcast(incl, 63);
+    if (i < S_prev) cdf[i + 1] = fminf(1.0f, (float)incl);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // (3) inverse-CDF sampling of the S+1 new bin edges                         ray_samplers.py:315-358
   const int nb = S + 1;
-  for (int e = threadIdx.x; e < nr * nb; e += kThreads) {
-    const int r = e / nb, j = e - r * nb;
-    const int64_t ray = ray0 + r;
+  const float s_near = spacing_fn_mode(spacing, nears[ray]);
+  const float s_far = spacing_fn_mode(spacing, fars[ray]);
+  const float* bp = s_bins_prev + ray * (S_prev + 1);
+  for (int j = lane; j < nb; j += 64) {
     float u = u_base[j];
     if (jitter != nullptr) u = u + jitter[ray] / (float)nb;  // rand / num_bins   (ray_samplers.py:320)
     else u = u + u_offset;                                    // 1 / (2 num_bins)  (ray_samplers.py:327), host-rounded
-    const float* c = cdf + r * ldp;
     // searchsorted(side="right"): number of cdf entries <= u
     int lo = 0, hi = S_prev + 1;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if (c[mid] <= u) lo = mid + 1;
+      if (cdf[mid] <= u) lo = mid + 1;
       else hi = mid;
     }
     const int below = min(max(lo - 1, 0), S_prev);
     const int above = min(max(lo, 0), S_prev);
-    const float c0 = c[below], c1 = c[above];
-    const float* bp = s_bins_prev + ray * (S_prev + 1);
+    const float c0 = cdf[below], c1 = cdf[above];
     const float b0 = bp[below], b1 = bp[above];
     float t = nan_to_num((u - c0) / (c1 - c0), 0.0f);
     t = fminf(fmaxf(t, 0.0f), 1.0f);
     const float b = b0 + t * (b1 - b0);
-    const float s_near = spacing_fn_mode(spacing, nears[ray]);
-    const float s_far = spacing_fn_mode(spacing, fars[ray]);
     s_bins[ray * nb + j] = b;
     t_bins[ray * nb + j] = spacing_to_euclidean_mode(spacing, b, s_near, s_far);
     if (inds != nullptr) inds[ray * nb + j] = lo;
@@ -241,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
 
 using namespace nsamd;
 
-static inline unsigned ray_blocks(int64_t num_rays) { return (unsigned)((num_rays + kRays - 1) / kRays); }
+static inline unsigned ray_blocks(int64_t num_rays) { return (unsigned)((num_rays + kWaves - 1) / kWaves); }
 
 extern "C" int nsamd_piecewise_bins(const float* nears, const float* fars, const float* edges, const float* jitter,
                                     int64_t num_rays, int32_t S, int spacing, float* s_bins, float* t_bins,
@@ -262,9 +249,7 @@ extern "C" int nsamd_weights_fwd(const float* t_bins, const float* density, int6
   NSAMD_REQUIRE(num_rays >= 0 && S > 0);
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(t_bins && density && weights);
-  if (S > 1024) return NSAMD_ERR_UNSUPPORTED;
-  const size_t lds = sizeof(float) * 2 * kRays * (S | 1);
-  weights_fwd_kernel<<<ray_blocks(num_rays), kThreads, lds, (hipStream_t)stream>>>(t_bins, density, num_rays, S,
+  weights_fwd_kernel<<<ray_blocks(num_rays), kThreads, 0, (hipStream_t)stream>>>(t_bins, density, num_rays, S,
                                                                                    weights);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
@@ -275,8 +260,8 @@ extern "C" int nsamd_weights_bwd(const float* t_bins, const float* density, cons
   NSAMD_REQUIRE(num_rays >= 0 && S > 0);
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(t_bins && density && dweights && ddensity);
-  if (S > 512) return NSAMD_ERR_UNSUPPORTED;
-  const size_t lds = sizeof(float) * 3 * kRays * (S | 1);
+  if (S > 1024) return NSAMD_ERR_UNSUPPORTED;
+  const size_t lds = sizeof(float) * 3 * kWaves * (size_t)S;
   weights_bwd_kernel<<<ray_blocks(num_rays), kThreads, lds, (hipStream_t)stream>>>(t_bins, density, dweights,
                                                                                    num_rays, S, ddensity);
   NSAMD_CHECK_LAUNCH();
@@ -292,7 +277,7 @@ extern "C" int nsamd_pdf_resample(const float* s_bins_prev, const float* weights
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(s_bins_prev && weights && u_base && nears && fars && s_bins && t_bins);
   if (S_prev > 1024) return NSAMD_ERR_UNSUPPORTED;
-  const size_t lds = sizeof(float) * (2 * kRays * ((S_prev + 1) | 1) + 2 * kRays);
+  const size_t lds = sizeof(float) * kWaves * (2 * (size_t)S_prev + 1);
   pdf_resample_kernel<<<ray_blocks(num_rays), kThreads, lds, (hipStream_t)stream>>>(
       s_bins_prev, weights, S_prev, u_base, jitter, nears, fars, anneal, anneal_dev, histogram_padding, eps, u_offset,
       spacing, num_rays, S,

@@ -150,8 +150,11 @@ def _scatter_workspace(grid: HashGridSpec, device, num_points: int = 0) -> Tuple
     Cached per (grid, M); the kernels fall back to the scratch-free scan when it is too small."""
     if num_points < 8192:
         return None, 0
+    import os
+
+    target = max(64, int(os.environ.get("NSAMD_SCATTER_TILES", "512")))  # must mirror csrc/hashgrid.hip
     bits = 0
-    while (grid.num_levels << bits) < 512:
+    while (grid.num_levels << bits) < target:
         bits += 1
     sl = min(14, max(8, grid.log2_hashmap_size - bits))
     sl = min(sl, grid.log2_hashmap_size)

@@ -84,6 +84,11 @@ class NerfactoTrainStep:
         self.p_ddens = [torch.empty_like(t) for t in self.p_dens]
         self.p_denc = [torch.empty_like(t) for t in self.p_enc]
         self.field_ws, _ = F.field_bwd_workspace(device)
+        # Optional second stream for the proposal-network backward (set `side_stream = torch.cuda.Stream()` to fork/join
+        # the two backward chains). Measured on MI355X: 1.505 vs 1.52 ms/step — each of these kernels already occupies
+        # the chip (128 KiB LDS tiles, 1024-thread workgroups), so it is off by default.
+        self.side_stream = None
+        self._fork, self._join = torch.cuda.Event(), torch.cuda.Event()
         self.spacing = int(getattr(model.proposal_sampler.initial_sampler, "spacing", 0))
         # host-evaluated tables (bit-identical to the reference's CPU linspace)
         self.edges = F._linspace("edges", self.counts[0], device)
@@ -107,14 +112,32 @@ class NerfactoTrainStep:
     def forward_backward(self, updated: bool, draw_jitter: bool = True) -> None:
         """One iteration up to (not including) the optimiser. `updated`: proposal networks receive gradient this step
         (ProposalNetworkSampler.updated_this_step()). Gradients ACCUMULATE into param.grad (zero them first)."""
-        self.forward_backward_main(updated, draw_jitter)
-        if updated:
-            self.backward_proposals()
+        self.forward_and_losses(updated, draw_jitter)
+        if updated and self.side_stream is not None:
+            # The two backward chains are independent (disjoint gradients, separate scratch): fork the proposal chain
+            # onto a second stream so that these latency-bound kernels overlap; inside a captured hipGraph this becomes
+            # two parallel branches.
+            main = torch.cuda.current_stream()
+            self._fork.record(main)
+            self.side_stream.wait_event(self._fork)
+            with torch.cuda.stream(self.side_stream):
+                self.backward_proposals()
+                self._join.record(self.side_stream)
+            self.backward_main()
+            main.wait_event(self._join)
+        else:
+            self.backward_main()
+            if updated:
+                self.backward_proposals()
 
     def forward_backward_main(self, updated: bool, draw_jitter: bool = True) -> None:
         """Forward of everything, the losses, and the backward of the MAIN field (87 % of the gradient bytes). With data
         parallelism the all-reduce of the main-field gradients can start right after this while `backward_proposals`
         (interlevel-loss gradients of the proposal networks) still runs."""
+        self.forward_and_losses(updated, draw_jitter)
+        self.backward_main()
+
+    def forward_and_losses(self, updated: bool, draw_jitter: bool = True) -> None:
         lib, st, n, cfg = N.load(), N.stream(), self.n, self.cfg
         ck = N.check
         if draw_jitter:
@@ -179,7 +202,20 @@ class NerfactoTrainStep:
                                          N.ptr(self.weights[lvl]), self.counts[lvl], n,
                                          float(cfg.interlevel_loss_mult) / (n * S), N.ptr(self.inter_per_ray[lvl]),
                                          N.ptr(self.dw_prop[lvl]) if updated else None, st), "interlevel_loss")
-        # ---- backward: main field ----
+
+    def backward_main(self) -> None:
+        """composite -> weights -> field MLPs -> main hash table (MSE + distortion gradients)."""
+        lib, st, n = N.load(), N.stream(), self.n
+        ck = N.check
+        fld = self.model.field
+        L = self.n_prop
+        S, mm = self.counts[L], self.m_main
+        enc = fld.mlp_base.encoding
+        params = [*fld.mlp_base.mlp.param_tensors(), *fld.mlp_head.param_tensors()]
+        emb = fld.embedding_appearance.embedding.weight if fld.embedding_appearance is not None else None
+        fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), emb.shape[0] if emb is not None else 0,
+                        float(fld.average_init_density))
+        cams = N.ptr(self.camera_indices) if emb is not None else None
         ck(lib.nsamd_composite_bwd(N.ptr(self.f_rgb), N.ptr(self.weights[L]), None, n, S, self.bg_mode, self.bg_vals,
                                    N.ptr(self.d_rgb_out), None, None, None, N.ptr(self.dw_dist), N.ptr(self.d_rgb_s),
                                    N.ptr(self.d_w_main), st), "composite_bwd")

@@ -10,14 +10,17 @@ __device__ __forceinline__ void lds_add_pair(float* pair, float v0, float v1) {
   const unsigned long long want = (unsigned long long)__float_as_uint(n0) | ((unsigned long long)__float_as_uint(n1) << 32);
   if (atomicCAS(w, old, want) != old) { atomicAdd(pair, v0); atomicAdd(pair + 1, v1); }
 }
-// MODE 0: full; 1: no LDS accumulate (register sum); 2: no queue read (synthetic records)
+// MODE 0: full; 1: no LDS accumulate (register sum); 2: no queue read (synthetic records);
+// MODE 3: one private copy of the tile per wavefront (no cross-wave contention), summed at the end
 template <int MODE, int THREADS>
 __global__ __launch_bounds__(THREADS) void apply(const uint4* __restrict__ queues, uint32_t n, uint32_t cap, int slice_log2,
                                                 float* __restrict__ dtable, long long* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) float acc[];
   const int entries = 1 << slice_log2;
+  const int copies = (MODE == 3) ? THREADS / 64 : 1;
+  float* mine = acc + (MODE == 3 ? (threadIdx.x >> 6) * 2 * entries : 0);
   long long t0 = clock64();
-  for (int e = threadIdx.x; e < 2 * entries; e += THREADS) acc[e] = 0.0f;
+  for (int e = threadIdx.x; e < 2 * entries * copies; e += THREADS) acc[e] = 0.0f;
   __syncthreads();
   long long t1 = clock64();
   const uint4* q = queues + (size_t)blockIdx.x * cap;
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(THREADS) void apply(const uint4* __restrict__ queue
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       if (MODE == 1) dummy += __uint_as_float(r[u].y) + (float)r[u].x;
-      else lds_add_pair(acc + 2 * r[u].x, __uint_as_float(r[u].y), __uint_as_float(r[u].z));
+      else lds_add_pair(mine + 2 * r[u].x, __uint_as_float(r[u].y), __uint_as_float(r[u].z));
     }
   }
   __syncthreads();
@@ -42,7 +45,8 @@ __global__ __launch_bounds__(THREADS) void apply(const uint4* __restrict__ queue
   float4* out = reinterpret_cast<float4*>(dtable + ((size_t)blockIdx.x << slice_log2) * 2);
   const float4* a4 = reinterpret_cast<const float4*>(acc);
   for (int i = threadIdx.x; i < entries / 2; i += THREADS) {
-    float4 o = out[i]; const float4 a = a4[i];
+    float4 o = out[i]; float4 a = a4[i];
+    for (int c = 1; c < copies; ++c) { const float4 b = a4[i + c * (entries / 2)]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
     o.x += a.x + dummy; o.y += a.y; o.z += a.z; o.w += a.w;
     out[i] = o;
   }
@@ -50,6 +54,7 @@ __global__ __launch_bounds__(THREADS) void apply(const uint4* __restrict__ queue
   long long t3 = clock64();
   if (threadIdx.x == 0 && blockIdx.x < 64) { stamps[blockIdx.x * 4 + 0] = t1 - t0; stamps[blockIdx.x * 4 + 1] = t2 - t1; stamps[blockIdx.x * 4 + 2] = t3 - t2; }
 }
+static float g_hot_frac = 0.f; static int g_hot_n = 1;
 template <int MODE, int THREADS> void run(const char* name, int tiles, int slice_log2, uint32_t n) {
   const uint32_t cap = n + 64;
   uint4* q; float* dt; long long* st;
@@ -57,9 +62,15 @@ template <int MODE, int THREADS> void run(const char* name, int tiles, int slice
   hipMemset(dt, 0, ((size_t)tiles << slice_log2) * 8);
   std::vector<uint4> h((size_t)cap);
   uint32_t s = 12345;
-  for (uint32_t i = 0; i < cap; ++i) { s = s * 1664525u + 1013904223u; h[i] = make_uint4((s >> 8) & ((1u << slice_log2) - 1), 0x3f800000u, 0x3f000000u, 0); }
+  for (uint32_t i = 0; i < cap; ++i) {
+    s = s * 1664525u + 1013904223u;
+    uint32_t idx = (s >> 8) & ((1u << slice_log2) - 1);
+    s = s * 1664525u + 1013904223u;
+    if ((s >> 8) / 16777216.0f < g_hot_frac) idx = (idx % g_hot_n) * 37 % (1u << slice_log2);
+    h[i] = make_uint4(idx, 0x3f800000u, 0x3f000000u, 0);
+  }
   for (int t = 0; t < tiles; ++t) hipMemcpy(q + (size_t)t * cap, h.data(), (size_t)cap * 16, hipMemcpyHostToDevice);
-  const size_t lds = (size_t)8 << slice_log2;
+  const size_t lds = ((size_t)8 << slice_log2) * (MODE == 3 ? THREADS / 64 : 1);
   hipFuncSetAttribute((const void*)apply<MODE, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   apply<MODE, THREADS><<<tiles, THREADS, lds>>>(q, n, cap, slice_log2, dt, st);
@@ -74,10 +85,14 @@ template <int MODE, int THREADS> void run(const char* name, int tiles, int slice
 }
 int main() {
   run<0, 1024>("full", 512, 14, 49152);
-  run<1, 1024>("no LDS accumulate", 512, 14, 49152);
-  run<2, 1024>("no queue read", 512, 14, 49152);
-  run<0, 1024>("full, 8K tiles (2 blocks/CU)", 1024, 13, 24576);
-  run<0, 512>("full, 4K tiles, 512 thr", 2048, 12, 12288);
-  run<0, 256>("full, 1K tiles, 256 thr", 8192, 10, 3072);
+  run<0, 256>("1K tiles uniform", 640, 10, 65536);
+  run<3, 256>("1K tiles uniform, per-wave copies", 640, 10, 65536);
+  for (float hf : {0.1f, 0.5f}) for (int hn : {1, 16}) {
+    g_hot_frac = hf; g_hot_n = hn;
+    printf("-- %.0f%% of the records on %d hot entries\n", hf * 100, hn);
+    run<0, 256>("1K tiles", 640, 10, 65536);
+    run<3, 256>("1K tiles, per-wave copies", 640, 10, 65536);
+    run<0, 1024>("16K tiles", 512, 14, 49152);
+  }
   return 0;
 }
