@@ -86,13 +86,18 @@ int nsamd_hashgrid_encode_fwd(nsamd_points pts, int64_t M, int transform, nsamd_
  * receives dL/d(raw position) through offset = scaled - floor(scaled), the selector, the affine map and the
  * contraction Jacobian exactly as autograd differentiates the reference (SURVEY.md §8a gradient-flow facts).
  * The scatter is partitioned into LDS-owned (level, slice) tiles (no global atomics, see csrc/hashgrid.hip);
- * `workspace` (nullable, `workspace_floats` words of device scratch) enables the binned two-pass path: it must be
- * ZERO-INITIALISED ONCE by its owner (the per-tile queue cursors at its start are left at zero by every call) and
- * hold >= tiles * (1 + 4 * 1.25 * 8 * M / tiles_per_level) + 8 words (base 16-B aligned); smaller or NULL selects the scratch-free scan. */
+ * `workspace` (nullable, `workspace_floats` words of device scratch, base 16-B aligned) enables the binned two-pass
+ * path: it must be ZERO-INITIALISED ONCE by its owner (the per-tile queue cursors at its start are left at zero by
+ * every call) and hold at least nsamd_hashgrid_encode_bwd_workspace(grid, M) words; smaller or NULL selects the
+ * scratch-free scan. */
 int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
                               nsamd_grid grid, const float* denc, int64_t stride_p, int64_t stride_k,
                               float* dtable, float* dpositions, float* workspace, int64_t workspace_floats,
                               nsamd_stream_t stream);
+
+/* Words of scratch the binned scatter of nsamd_hashgrid_encode_bwd wants for (grid, M); 0 when that path does not
+ * apply (M < 8192 or an unsupported grid). Host-only, no device work. */
+int64_t nsamd_hashgrid_encode_bwd_workspace(nsamd_grid grid, int64_t M);
 
 /* ------------------------------------------------------------------------------------------------------------
  * SH encoding, 4 levels = 16 components (SHEncoding.pytorch_fwd, encodings.py:791-794 ->

@@ -58,6 +58,7 @@ class FieldMlpGrads(C.Structure):
 _SIGNATURES = {
     "nsamd_hashgrid_encode_fwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp],
     "nsamd_hashgrid_encode_bwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, vp, i64, vp],
+    "nsamd_hashgrid_encode_bwd_workspace": [Grid, i64],
     "nsamd_sh4_encode": [vp, i64, vp, vp],
     "nsamd_contract_linf": [vp, i64, vp, vp],
     "nsamd_density_mlp_fwd": [vp, vp, i64, DensityMlp, vp, vp, vp],
@@ -82,7 +83,8 @@ _SIGNATURES = {
     "nsamd_device_info": [C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32],
     "nsamd_probe_mfma16": [vp, vp, vp, vp],
 }
-_RESTYPES = {"nsamd_version": C.c_char_p, "nsamd_status_string": C.c_char_p}
+_RESTYPES = {"nsamd_version": C.c_char_p, "nsamd_status_string": C.c_char_p,
+             "nsamd_hashgrid_encode_bwd_workspace": C.c_int64}
 
 _lib = None
 

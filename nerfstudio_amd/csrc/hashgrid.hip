@@ -170,167 +170,287 @@ __global__ __launch_bounds__(kSliceThreads) void hash_encode_bwd_sliced_kernel(
 // ---- binned scatter: pass 1 (route) + pass 2 (apply) -------------------------------------------------------------
 constexpr int kBinThreads = 1024;
 constexpr int kMaxBins = 4096;
+struct LevelList {
+  int8_t level[32];
+  int count;
+};
 
-// Pass 1. `merge_mask` bit l set = on level l consecutive lanes (consecutive samples of a ray) are likely to share a
-// cell (cell size > sample spacing): their 8-corner contributions are summed with a wave-level segmented scan over
-// runs of identical cells and only the last lane of each run emits records. `combine_mask` bit l set = the surviving
-// updates of the workgroup are additionally summed per table entry in a small LDS hash table (open addressing, bounded
-// probing, overflow goes out as plain records), so the workgroup emits ONE record per distinct entry. Coarse levels
-// have few entries and every ray of a camera starts in the same cells: without this, pass 2 serialises thousands of
-// LDS read-modify-writes on a handful of hot entries (measured: level 0 alone took as long as all 16 levels).
+// Pass 1 for the COARSE levels (cell wider than the sample spacing, few distinct entries per workgroup).
+// Consecutive samples of a ray share a cell there, all rays of a camera start in the same cells, and a level has few
+// entries in total: emitted naively, pass 2 serialises thousands of LDS read-modify-writes on a handful of hot
+// entries (measured: level 0 alone took as long as all 16 levels together). So:
+//  * every thread walks kRunLen CONSECUTIVE samples and sums the 8 corner contributions in registers while the cell
+//    stays the same (a run) — sequential, no cross-lane traffic (the earlier wave-level segmented scan of 16 values
+//    cost ~1500 instructions per sample and made this kernel ALU-bound);
+//  * a finished run is summed per table entry into a workgroup-wide LDS hash table (open addressing, bounded probing;
+//    a full table sends the update out as a direct atomic), so the workgroup emits ONE single record per distinct
+//    entry.
+constexpr int kRunThreads = 256;
 constexpr int kCombineBits = 12;
 constexpr int kCombineSlots = 1 << kCombineBits;
-constexpr int kCombinePerThread = kCombineSlots / kBinThreads;
+constexpr int kCombinePerThread = kCombineSlots / kRunThreads;
 constexpr uint32_t kEmptyKey = 0xffffffffu;
 
-__global__ __launch_bounds__(kBinThreads) void hash_bwd_bin_kernel(
+template <int kRunLen>
+__global__ __launch_bounds__(kRunThreads) void hash_bwd_bin_runs_kernel(
     nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
-    int64_t stride_p, int64_t stride_k, int slice_log2, uint32_t cap, uint32_t merge_mask, uint32_t combine_mask,
-    int level0, uint32_t* __restrict__ cursors, uint32_t* __restrict__ queues, float* __restrict__ dtable) {
+    int64_t stride_p, int64_t stride_k, int slice_log2, uint32_t cap, LevelList levels,
+    uint32_t* __restrict__ cursors, uint4* __restrict__ queues, float* __restrict__ dtable) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
-  const int level = level0 + blockIdx.y;
+  const int level = levels.level[blockIdx.y];
   const int B = 1 << (grid.log2_table_size - slice_log2);
-  const bool combine = (combine_mask >> level) & 1u;  // workgroup-uniform
-  // layout: [vals: 2 x slots floats][keys: slots][cnt: B][base: B]  (vals/keys only when any level combines)
-  const int table_words = combine_mask != 0u ? 3 * kCombineSlots : 0;
+  // layout: [vals: 2 x slots floats][keys: slots][cnt: B][base: B]
   float* vals = reinterpret_cast<float*>(lds_u);
   uint32_t* keys = lds_u + 2 * kCombineSlots;
-  uint32_t* cnt = lds_u + table_words;  // [B] updates of this workgroup per tile
-  uint32_t* base = cnt + B;             // [B] reserved queue offset per tile
-  for (int t = threadIdx.x; t < B; t += kBinThreads) cnt[t] = 0;
-  if (combine) {
+  uint32_t* cnt = lds_u + 3 * kCombineSlots;  // [B] records of this workgroup per tile
+  uint32_t* base = cnt + B;                   // [B] reserved queue offset per tile
+  for (int t = threadIdx.x; t < B; t += kRunThreads) cnt[t] = 0;
 #pragma unroll
-    for (int i = 0; i < kCombinePerThread; ++i) {
-      const int sl = threadIdx.x + i * kBinThreads;
-      keys[sl] = kEmptyKey;
-      vals[2 * sl] = 0.0f;
-      vals[2 * sl + 1] = 0.0f;
+  for (int i = 0; i < kCombinePerThread; ++i) {
+    const int sl = threadIdx.x + i * kRunThreads;
+    keys[sl] = kEmptyKey;
+    vals[2 * sl] = 0.0f;
+    vals[2 * sl + 1] = 0.0f;
+  }
+  const int64_t p0 = ((int64_t)blockIdx.x * kRunThreads + threadIdx.x) * kRunLen;
+  float g0[kRunLen], g1[kRunLen];
+#pragma unroll
+  for (int i = 0; i < kRunLen; ++i) {  // gradient loads in flight before anything depends on them
+    g0[i] = 0.0f;
+    g1[i] = 0.0f;
+    if (p0 + i < M) {
+      const float* gptr = denc + (p0 + i) * stride_p + (int64_t)(2 * level) * stride_k;
+      g0[i] = gptr[0];
+      g1[i] = gptr[stride_k];
+    }
+  }
+  float px[kRunLen], py[kRunLen], pz[kRunLen];
+#pragma unroll
+  for (int i = 0; i < kRunLen; ++i) {  // ... and the positions: the run loop below must not wait on global memory
+    px[i] = py[i] = pz[i] = 0.0f;
+    if (p0 + i < M) {
+      load_position(P, p0 + i, px[i], py[i], pz[i]);
+      (void)normalise_position(transform, box, px[i], py[i], pz[i]);
     }
   }
   __syncthreads();
-  const int64_t p = (int64_t)blockIdx.x * kBinThreads + threadIdx.x;
-  bool active = p < M;
-  float g0 = 0.f, g1 = 0.f;
-  if (active) {
-    const float* gptr = denc + p * stride_p + (int64_t)(2 * level) * stride_k;
-    g0 = gptr[0];
-    g1 = gptr[stride_k];
-    active = !(g0 == 0.0f && g1 == 0.0f);
-  }
-  uint32_t idx[8], rank[8];
-  float v0[8], v1[8];
-  Cell c;
+  const uint32_t mask = (1u << grid.log2_table_size) - 1u;
+  float* const level_table = dtable + (((size_t)level << grid.log2_table_size) << 1);
+  const float scale = grid.scalings[level];
+  Cell cur{};
+  float a0[8], a1[8];
+  bool have = false;
 #pragma unroll
-  for (int a = 0; a < 3; ++a) { c.lo[a] = 0; c.hi[a] = 0; c.w[a] = 0.f; }
-  if (active) {
-    float x, y, z;
-    load_position(P, p, x, y, z);
-    (void)normalise_position(transform, box, x, y, z);
-    c = locate_cell(x, y, z, grid.scalings[level]);
-  }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float bz = (k & 4) ? c.w[2] : 1.0f - c.w[2];
-    const float by = (k & 2) ? c.w[1] : 1.0f - c.w[1];
-    const float bx = (k & 1) ? c.w[0] : 1.0f - c.w[0];
-    v0[k] = active ? ((g0 * bz) * by) * bx : 0.0f;
-    v1[k] = active ? ((g1 * bz) * by) * bx : 0.0f;
-  }
-  bool emit = active;
-  if ((merge_mask >> level) & 1u) {  // wave-uniform
-    const int lane = threadIdx.x & 63;
-    bool same = active && lane > 0 && __shfl_up((int)active, 1) != 0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      same = same && (__shfl_up(c.lo[a], 1) == c.lo[a]) && (__shfl_up(c.hi[a], 1) == c.hi[a]);
+  for (int i = 0; i <= kRunLen; ++i) {
+    bool live = false;
+    Cell c = cur;
+    if (i < kRunLen) {
+      live = (p0 + i < M) && !(g0[i] == 0.0f && g1[i] == 0.0f);
+      if (live) c = locate_cell(px[i], py[i], pz[i], scale);
     }
-    const bool head = !same;
-    bool f = head;  // segmented inclusive scan: (v, f) o (v', f') = (f' ? v' : v + v', f | f')
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const bool take = (lane >= d) && !f;
-      const int fp = __shfl_up((int)f, d);
+    const bool same = have && live && c.lo[0] == cur.lo[0] && c.lo[1] == cur.lo[1] && c.lo[2] == cur.lo[2] &&
+                      c.hi[0] == cur.hi[0] && c.hi[1] == cur.hi[1] && c.hi[2] == cur.hi[2];
+    if (have && (i == kRunLen || (live && !same))) {  // the run ends: sum it into the workgroup's table
+      // Each step below is one LDS round trip; the 8 corners go through every step together (8 operations in flight)
+      // instead of one corner after the other — the workgroup's life is this latency chain.
+      uint32_t index[8], h[8], prev[8];
+      unsigned long long old[8];
+      uint32_t placed = 0u;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float a0 = __shfl_up(v0[k], d), a1 = __shfl_up(v1[k], d);
-        if (take) { v0[k] += a0; v1[k] += a1; }
+        index[k] = corner_index(cur, k, mask);
+        h[k] = (index[k] * 0x9E3779B1u) >> (32 - kCombineBits);
       }
-      if (take) f = fp != 0;
-    }
-    const bool next_head = (lane == 63) || (__shfl_down((int)head, 1) != 0);
-    emit = active && next_head;  // the last lane of a run carries the run's sums
-  }
-  uint32_t direct = 0u;  // bit k: corner k leaves this thread as its own record
-  if (emit) {
-    const uint32_t mask = (1u << grid.log2_table_size) - 1u;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      idx[k] = corner_index(c, k, mask);
-      bool placed = false;
-      if (combine) {
-        uint32_t h = (idx[k] * 0x9E3779B1u) >> (32 - kCombineBits);
-        for (int probe = 0; probe < 4 && !placed; ++probe) {
-          const uint32_t prev = atomicCAS(keys + h, kEmptyKey, idx[k]);
-          if (prev == kEmptyKey || prev == idx[k]) {
-            lds_add_pair(vals + 2 * h, v0[k], v1[k]);
-            placed = true;
-          } else {
-            h = (h + 1) & (kCombineSlots - 1);
+      for (int k = 0; k < 8; ++k) prev[k] = atomicCAS(keys + h[k], kEmptyKey, index[k]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (prev[k] == kEmptyKey || prev[k] == index[k]) {
+          placed |= 1u << k;
+        } else {  // slot taken by another entry: linear probing (rare while the table is sparse)
+          for (int probe = 1; probe < 8 && !((placed >> k) & 1u); ++probe) {
+            h[k] = (h[k] + 1) & (kCombineSlots - 1);
+            const uint32_t pv = atomicCAS(keys + h[k], kEmptyKey, index[k]);
+            if (pv == kEmptyKey || pv == index[k]) placed |= 1u << k;
           }
         }
       }
-      if (!placed) {
-        direct |= 1u << k;
-        rank[k] = atomicAdd(cnt + (idx[k] >> slice_log2), 1u);  // ds_add_rtn_u32
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if ((placed >> k) & 1u) old[k] = *reinterpret_cast<volatile unsigned long long*>(vals + 2 * h[k]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if ((placed >> k) & 1u) {
+          const float n0 = __uint_as_float((uint32_t)old[k]) + a0[k];
+          const float n1 = __uint_as_float((uint32_t)(old[k] >> 32)) + a1[k];
+          const unsigned long long want =
+              (unsigned long long)__float_as_uint(n0) | ((unsigned long long)__float_as_uint(n1) << 32);
+          old[k] = atomicCAS(reinterpret_cast<unsigned long long*>(vals + 2 * h[k]), old[k], want) ^ old[k];
+        }
       }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if ((placed >> k) & 1u) {
+          if (old[k] != 0ull) {  // lost the race on this slot (another run of the same cell): ds_add_f32
+            atomicAdd(vals + 2 * h[k], a0[k]);
+            atomicAdd(vals + 2 * h[k] + 1, a1[k]);
+          }
+        } else {  // table full around this slot: direct atomics keep the result exact
+          unsafeAtomicAdd(level_table + 2 * (size_t)index[k], a0[k]);
+          unsafeAtomicAdd(level_table + 2 * (size_t)index[k] + 1, a1[k]);
+        }
+      }
+      have = false;
+    }
+    if (i < kRunLen && live) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float bz = (k & 4) ? c.w[2] : 1.0f - c.w[2];
+        const float by = (k & 2) ? c.w[1] : 1.0f - c.w[1];
+        const float bx = (k & 1) ? c.w[0] : 1.0f - c.w[0];
+        const float t0 = ((g0[i] * bz) * by) * bx, t1 = ((g1[i] * bz) * by) * bx;
+        a0[k] = same ? a0[k] + t0 : t0;
+        a1[k] = same ? a1[k] + t1 : t1;
+      }
+      cur = c;
+      have = true;
     }
   }
+  __syncthreads();  // all sums of the workgroup are in the table
   uint32_t skey[kCombinePerThread], srank[kCombinePerThread];
-  if (combine) {
-    __syncthreads();  // all sums of the workgroup are in the table
 #pragma unroll
-    for (int i = 0; i < kCombinePerThread; ++i) {
-      skey[i] = keys[threadIdx.x + i * kBinThreads];
-      srank[i] = 0u;
-      if (skey[i] != kEmptyKey) srank[i] = atomicAdd(cnt + (skey[i] >> slice_log2), 1u);
-    }
+  for (int i = 0; i < kCombinePerThread; ++i) {
+    skey[i] = keys[threadIdx.x + i * kRunThreads];
+    srank[i] = 0u;
+    if (skey[i] != kEmptyKey) srank[i] = atomicAdd(cnt + (skey[i] >> slice_log2), 1u);  // ds_add_rtn_u32
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < B; t += kBinThreads) {
+  for (int t = threadIdx.x; t < B; t += kRunThreads) {
     const uint32_t n = cnt[t];
     base[t] = n ? atomicAdd(cursors + (size_t)level * B + t, n) : 0u;
   }
   __syncthreads();
   const uint32_t local_mask = (1u << slice_log2) - 1u;
-  auto put = [&](uint32_t index, uint32_t rk, float a0, float a1) {
-    const uint32_t bin = index >> slice_log2;
-    const uint32_t pos = base[bin] + rk;
-    if (pos < cap) {  // one 16-B record = one global_store_dwordx4
-      uint4* q = reinterpret_cast<uint4*>(queues) + (((size_t)level * B + bin) * cap + pos);
-      *q = make_uint4(index & local_mask, __float_as_uint(a0), __float_as_uint(a1), 0u);
-    } else {  // queue full (a very hot cell): direct atomics keep the result exact
-      float* t = dtable + ((((size_t)level << grid.log2_table_size) + index) << 1);
-      unsafeAtomicAdd(t + 0, a0);
-      unsafeAtomicAdd(t + 1, a1);
-    }
-  };
-  if (direct != 0u) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if ((direct >> k) & 1u) put(idx[k], rank[k], v0[k], v1[k]);
-  }
-  if (combine) {
-#pragma unroll
-    for (int i = 0; i < kCombinePerThread; ++i) {
-      const int sl = threadIdx.x + i * kBinThreads;
-      if (skey[i] != kEmptyKey) put(skey[i], srank[i], vals[2 * sl], vals[2 * sl + 1]);
+  for (int i = 0; i < kCombinePerThread; ++i) {
+    if (skey[i] == kEmptyKey) continue;
+    const int sl = threadIdx.x + i * kRunThreads;
+    const uint32_t bin = skey[i] >> slice_log2;
+    const uint32_t pos = base[bin] + srank[i];
+    const float v0 = vals[2 * sl], v1 = vals[2 * sl + 1];
+    if (pos < cap) {  // single record (f0, f1, -, local index): one global_store_dwordx4
+      queues[((size_t)level * B + bin) * cap + pos] =
+          make_uint4(__float_as_uint(v0), __float_as_uint(v1), 0u, skey[i] & local_mask);
+    } else {  // queue full (a very hot tile): direct atomics keep the result exact
+      unsafeAtomicAdd(level_table + 2 * (size_t)skey[i], v0);
+      unsafeAtomicAdd(level_table + 2 * (size_t)skey[i] + 1, v1);
     }
   }
 }
 
-template <bool kPipe>
+// Pass 1 for the FINE levels (no run-merging, no combining): every thread takes its point through kFineLevels (2 or 4)
+// levels at once. A workgroup's life is a chain of latencies (gradient loads -> LDS ranks -> barrier -> one returning global
+// atomic per tile -> barrier -> stores), and with 2048 threads per CU there is no occupancy left to hide it: levels
+// per thread are the only source of independent work. The position (ray fetch + contraction) is also computed once
+// instead of once per level. Emits x-pair records only.
+template <int kFineLevels>
+__global__ __launch_bounds__(kBinThreads) void hash_bwd_bin_fine_kernel(
+    nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
+    int64_t stride_p, int64_t stride_k, int slice_log2, uint32_t cap, LevelList levels,
+    uint32_t* __restrict__ cursors, uint4* __restrict__ queues, float* __restrict__ dtable) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+  const int B = 1 << (grid.log2_table_size - slice_log2);
+  uint32_t* cnt = lds_u;                     // [kFineLevels][B]
+  uint32_t* base = lds_u + kFineLevels * B;  // [kFineLevels][B]
+  for (int t = threadIdx.x; t < kFineLevels * B; t += kBinThreads) cnt[t] = 0;
+  const int first = blockIdx.y * kFineLevels;
+  const int64_t p = (int64_t)blockIdx.x * kBinThreads + threadIdx.x;
+  const bool inside = p < M;
+  float g0[kFineLevels], g1[kFineLevels];
+  int lvl[kFineLevels];
+#pragma unroll
+  for (int i = 0; i < kFineLevels; ++i) {  // all gradient loads in flight before anything depends on them
+    lvl[i] = first + i < levels.count ? (int)levels.level[first + i] : -1;
+    g0[i] = 0.0f;
+    g1[i] = 0.0f;
+    if (inside && lvl[i] >= 0) {
+      const float* gptr = denc + p * stride_p + (int64_t)(2 * lvl[i]) * stride_k;
+      g0[i] = gptr[0];
+      g1[i] = gptr[stride_k];
+    }
+  }
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (inside) {
+    load_position(P, p, x, y, z);
+    (void)normalise_position(transform, box, x, y, z);
+  }
+  __syncthreads();
+  const uint32_t mask = (1u << grid.log2_table_size) - 1u;
+  const uint32_t local_mask = (1u << slice_log2) - 1u;
+  float w[kFineLevels][3];
+  uint32_t word[kFineLevels][4], bin[kFineLevels][4], rank[kFineLevels][4];
+  uint32_t recmask = 0u;  // bit 4 i + q
+#pragma unroll
+  for (int i = 0; i < kFineLevels; ++i) {
+    if (lvl[i] < 0 || !inside || (g0[i] == 0.0f && g1[i] == 0.0f)) continue;
+    const Cell c = locate_cell(x, y, z, grid.scalings[lvl[i]]);
+    w[i][0] = c.w[0]; w[i][1] = c.w[1]; w[i][2] = c.w[2];
+    float* const level_table = dtable + (((size_t)lvl[i] << grid.log2_table_size) << 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t ia = corner_index(c, 2 * q, mask), ib = corner_index(c, 2 * q + 1, mask);
+      bin[i][q] = ia >> slice_log2;
+      word[i][q] = (ia & local_mask) | ((ib & local_mask) << 14) | 0x80000000u;
+      if ((ib >> slice_log2) == bin[i][q]) {
+        recmask |= 1u << (4 * i + q);
+        rank[i][q] = atomicAdd(cnt + i * B + bin[i][q], 1u);  // ds_add_rtn_u32
+      } else {  // the pair straddles two tiles (needs a carry past bit slice_log2): rare, direct atomics
+        const float bz = (q & 2) ? c.w[2] : 1.0f - c.w[2];
+        const float by = (q & 1) ? c.w[1] : 1.0f - c.w[1];
+        const float a0 = (g0[i] * bz) * by, a1 = (g1[i] * bz) * by;
+        unsafeAtomicAdd(level_table + 2 * (size_t)ia, a0 * (1.0f - c.w[0]));
+        unsafeAtomicAdd(level_table + 2 * (size_t)ia + 1, a1 * (1.0f - c.w[0]));
+        unsafeAtomicAdd(level_table + 2 * (size_t)ib, a0 * c.w[0]);
+        unsafeAtomicAdd(level_table + 2 * (size_t)ib + 1, a1 * c.w[0]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < kFineLevels * B; t += kBinThreads) {
+    const int i = t / B;
+    const int level = first + i < levels.count ? (int)levels.level[first + i] : -1;
+    const uint32_t n = cnt[t];
+    base[t] = (n && level >= 0) ? atomicAdd(cursors + (size_t)level * B + (t - i * B), n) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kFineLevels; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!((recmask >> (4 * i + q)) & 1u)) continue;
+      const float bz = (q & 2) ? w[i][2] : 1.0f - w[i][2];
+      const float by = (q & 1) ? w[i][1] : 1.0f - w[i][1];
+      const float a0 = (g0[i] * bz) * by, a1 = (g1[i] * bz) * by;
+      const uint32_t pos = base[i * B + bin[i][q]] + rank[i][q];
+      if (pos < cap) {  // one 16-B record = one global_store_dwordx4
+        queues[((size_t)lvl[i] * B + bin[i][q]) * cap + pos] =
+            make_uint4(__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(w[i][0]), word[i][q]);
+      } else {  // queue full (a very hot cell): direct atomics keep the result exact
+        float* const level_table = dtable + (((size_t)lvl[i] << grid.log2_table_size) << 1);
+        const size_t ia = ((size_t)bin[i][q] << slice_log2) + (word[i][q] & 0x3fffu);
+        const size_t ib = ((size_t)bin[i][q] << slice_log2) + ((word[i][q] >> 14) & 0x3fffu);
+        unsafeAtomicAdd(level_table + 2 * ia, a0 * (1.0f - w[i][0]));
+        unsafeAtomicAdd(level_table + 2 * ia + 1, a1 * (1.0f - w[i][0]));
+        unsafeAtomicAdd(level_table + 2 * ib, a0 * w[i][0]);
+        unsafeAtomicAdd(level_table + 2 * ib + 1, a1 * w[i][0]);
+      }
+    }
+  }
+}
+
+// Pass 2: one workgroup per (level, tile) streams the tile's queue into LDS and adds the finished tile to the table.
 __global__ void hash_bwd_apply_kernel(nsamd_grid grid, int slice_log2, uint32_t cap, int level0,
-                                      const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ queues,
+                                      const uint32_t* __restrict__ cursors, const uint4* __restrict__ queues,
                                       float* __restrict__ dtable) {
   extern __shared__ __attribute__((aligned(16))) float acc[];
   const int bin = blockIdx.x, level = level0 + blockIdx.y;
@@ -343,52 +463,55 @@ __global__ void hash_bwd_apply_kernel(nsamd_grid grid, int slice_log2, uint32_t 
   // self-cleaning cursor: the next launch finds zeros again, so no memset node is needed per call (the workspace is
   // zero-initialised once by its owner)
   if (threadIdx.x == 0) const_cast<uint32_t*>(cursors)[(size_t)level * B + bin] = 0u;
-  const uint4* q = reinterpret_cast<const uint4*>(queues) + ((size_t)level * B + bin) * cap;
-  // One workgroup per CU (the tile fills the LDS), so memory-level parallelism has to come from each thread: keep 8
-  // independent 16-B queue loads in flight before touching the LDS (measured: 285 -> see profiles/ us per launch).
-  constexpr int kU = 8;
-  uint32_t e = threadIdx.x;
-  const uint32_t stride = blockDim.x;
-  if (kPipe) {
-    // software pipeline: the next batch of queue loads is in flight while this batch goes through the LDS
-    uint4 cur[kU];
-    bool have = e + (kU - 1) * stride < n;
-    if (have) {
-#pragma unroll
-      for (int u = 0; u < kU; ++u) cur[u] = q[e + u * stride];
+  const uint4* q = queues + ((size_t)level * B + bin) * cap;
+  // The tile fills the LDS (one or two workgroups per CU), so memory-level parallelism has to come from each thread:
+  // 8 records in flight before touching the LDS. A thread takes 2 groups of 4 CONSECUTIVE records (one 64-B line
+  // each): consecutive samples of a ray sit next to each other in the queue and — where the sampler has concentrated
+  // them — hit the same entries, so equal neighbours are summed in registers first (fewer LDS operations, and the
+  // lanes of a wave no longer race each other on them; a lost race costs the slow divergent ds_add_f32 path).
+  auto add_entry = [&](uint32_t word, float c0, float c1, float c2, float c3) {
+    if (word & 0x80000000u) {  // x-pair
+      lds_add_pair(acc + 2 * (word & 0x3fffu), c0, c1);
+      lds_add_pair(acc + 2 * ((word >> 14) & 0x3fffu), c2, c3);
+    } else {
+      lds_add_pair(acc + 2 * word, c0, c1);
     }
-    while (have) {
-      const uint32_t en = e + kU * stride;
-      const bool more = en + (kU - 1) * stride < n;
-      uint4 nxt[kU];
-      if (more) {
+  };
+  const uint32_t per_pass = blockDim.x * 8u;
+  for (uint32_t e0 = 0; e0 < n; e0 += per_pass) {
+    uint4 r[8];
+    bool ok[8];
 #pragma unroll
-        for (int u = 0; u < kU; ++u) nxt[u] = q[en + u * stride];
-      }
-#pragma unroll
-      for (int u = 0; u < kU; ++u)
-        lds_add_pair(acc + 2 * cur[u].x, __uint_as_float(cur[u].y), __uint_as_float(cur[u].z));
-      if (more) {
-#pragma unroll
-        for (int u = 0; u < kU; ++u) cur[u] = nxt[u];
-      }
-      e = en;
-      have = more;
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t e = e0 + (uint32_t)(u >> 2) * (blockDim.x * 4u) + threadIdx.x * 4u + (uint32_t)(u & 3);
+      ok[u] = e < n;
+      r[u] = ok[u] ? q[e] : make_uint4(0u, 0u, 0u, 0u);
     }
-  }
-  for (; e + (kU - 1) * stride < n; e += kU * stride) {
-    uint4 r[kU];
 #pragma unroll
-    for (int u = 0; u < kU; ++u) r[u] = q[e + u * stride];
-    // (Measured: issuing the 8 reads, then the 8 CAS attempts, widens the read->CAS window enough that races between the
-    // waves on small hot tiles make it 2.4x SLOWER for the proposal tables — every lost race pays the divergent
-    // ds_add_f32 path. Keep read and CAS of a record adjacent.)
+    for (int grp = 0; grp < 2; ++grp) {
+      uint32_t word = 0u;
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+      bool have = false;
 #pragma unroll
-    for (int u = 0; u < kU; ++u) lds_add_pair(acc + 2 * r[u].x, __uint_as_float(r[u].y), __uint_as_float(r[u].z));
-  }
-  for (; e < n; e += stride) {
-    const uint4 r = q[e];
-    lds_add_pair(acc + 2 * r.x, __uint_as_float(r.y), __uint_as_float(r.z));
+      for (int v = 0; v < 4; ++v) {
+        const int u = 4 * grp + v;
+        if (!ok[u]) continue;
+        const float f0 = __uint_as_float(r[u].x), f1 = __uint_as_float(r[u].y);
+        float p0 = f0, p1 = f1, p2 = 0.f, p3 = 0.f;
+        if (r[u].w & 0x80000000u) {  // x-pair: see pass 1
+          const float wx = __uint_as_float(r[u].z), omx = 1.0f - wx;
+          p0 = f0 * omx; p1 = f1 * omx; p2 = f0 * wx; p3 = f1 * wx;
+        }
+        if (have && r[u].w == word) {
+          c0 += p0; c1 += p1; c2 += p2; c3 += p3;
+        } else {
+          if (have) add_entry(word, c0, c1, c2, c3);
+          word = r[u].w; c0 = p0; c1 = p1; c2 = p2; c3 = p3;
+          have = true;
+        }
+      }
+      if (have) add_entry(word, c0, c1, c2, c3);
+    }
   }
   __syncthreads();
   float4* out = reinterpret_cast<float4*>(
@@ -553,6 +676,44 @@ static int env_int(const char* name, int dflt) {
   return e != nullptr ? atoi(e) : dflt;
 }
 
+// Geometry of the binned scatter for (grid, M): tile size chosen so that (tiles = bins x levels) >= ~512 fills the
+// chip; queues sized for 2x the uniform-hash expectation of 8 M single records per level (the fine levels need half:
+// x-pair records), 4 words per record.
+struct ScatterPlan {
+  bool ok;
+  int slice_log2, bins;
+  int64_t tiles, cursor_words;
+  uint32_t cap;
+};
+
+static bool sl_too_wide(int sl) { return sl > 14; }  // local indices are 14-bit
+
+static ScatterPlan scatter_geometry(const nsamd_grid& grid) {
+  ScatterPlan p{};
+  int bits = 0;
+  while ((grid.num_levels << bits) < scatter_target_tiles()) ++bits;
+  int sl = grid.log2_table_size - bits;
+  sl = sl > kSliceLog2Max ? kSliceLog2Max : (sl < 8 ? 8 : sl);
+  if (sl > grid.log2_table_size) sl = grid.log2_table_size;
+  p.slice_log2 = sl;
+  p.bins = 1 << (grid.log2_table_size - sl);
+  p.tiles = (int64_t)p.bins * grid.num_levels;
+  p.cursor_words = (p.tiles + 3) & ~(int64_t)3;
+  return p;
+}
+
+static int64_t scatter_expected_records(const ScatterPlan& p, int64_t M) { return (8 * M + p.bins - 1) / p.bins; }
+
+static ScatterPlan scatter_plan(const nsamd_grid& grid, int64_t M, const float* workspace, int64_t workspace_floats) {
+  ScatterPlan p = scatter_geometry(grid);
+  if (workspace == nullptr || p.bins > kMaxBins || sl_too_wide(p.slice_log2)) return p;
+  const int64_t cap = (workspace_floats - p.cursor_words) / (4 * p.tiles);
+  const int64_t expect = scatter_expected_records(p, M);
+  p.ok = cap >= expect + expect / 4 && cap < 0x7fffffffLL;
+  p.cap = p.ok ? (uint32_t)cap : 0u;
+  return p;
+}
+
 static int device_cus() {
   static int cached = 0;
   if (cached == 0) {
@@ -585,76 +746,77 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
     hash_encode_bwd_table_kernel<<<g, kHashBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, grid, denc,
                                                                              stride_p, stride_k, dtable);
     NSAMD_CHECK_LAUNCH();
-  } else if (dtable != nullptr && [&]() -> bool {
-               // binned path: tile size chosen so that (tiles = bins x levels) >= 512 fills the chip
-               int bits = 0;
-               while ((grid.num_levels << bits) < scatter_target_tiles()) ++bits;
-               int sl = grid.log2_table_size - bits;
-               sl = sl > kSliceLog2Max ? kSliceLog2Max : (sl < 8 ? 8 : sl);
-               if (sl > grid.log2_table_size) sl = grid.log2_table_size;
-               const int64_t B = (int64_t)1 << (grid.log2_table_size - sl);
-               if (workspace == nullptr || B > kMaxBins) return false;
-               const int64_t tiles = B * grid.num_levels;
-               const int64_t cap = (workspace_floats - tiles - 4) / (4 * tiles);
-               const int64_t expect = (8 * M + B - 1) / B;  // uniform hashing: updates per tile
-               return cap >= expect + expect / 4 && cap < 0x7fffffffLL;
-             }()) {
-    int bits = 0;
-    while ((grid.num_levels << bits) < scatter_target_tiles()) ++bits;
-    int sl = grid.log2_table_size - bits;
-    sl = sl > kSliceLog2Max ? kSliceLog2Max : (sl < 8 ? 8 : sl);
-    if (sl > grid.log2_table_size) sl = grid.log2_table_size;
-    const int B = 1 << (grid.log2_table_size - sl);
-    const int64_t tiles = (int64_t)B * grid.num_levels;
-    const uint32_t cap = (uint32_t)((workspace_floats - tiles - 4) / (4 * tiles));
+  } else if (dtable != nullptr && scatter_plan(grid, M, workspace, workspace_floats).ok) {
+    const ScatterPlan plan = scatter_plan(grid, M, workspace, workspace_floats);
+    const int sl = plan.slice_log2, B = plan.bins;
+    const uint32_t cap = plan.cap;
     uint32_t* cursors = reinterpret_cast<uint32_t*>(workspace);
-    uint32_t* queues = cursors + ((tiles + 3) & ~(int64_t)3);  // 16-B aligned records
+    uint4* queues = reinterpret_cast<uint4*>(cursors + plan.cursor_words);  // 16-B aligned
     hipStream_t st = (hipStream_t)stream;
-    static const int groups_env = env_int("NSAMD_SCATTER_GROUPS", 1);
-    static const float merge_env = (float)env_int("NSAMD_SCATTER_MERGE_X4", 16) * 0.25f;
-    static const int pipe_env = env_int("NSAMD_SCATTER_PIPE", 1);
-    const int groups = groups_env < 1 ? 1 : (groups_env > grid.num_levels ? grid.num_levels : groups_env);
-    const int per_group = (grid.num_levels + groups - 1) / groups;
-    // merge runs of samples that share a cell where the cell is wider than ~4 sample spacings (ray mode only: the
-    // lanes of a wave are then consecutive samples of one ray)
-    uint32_t merge_mask = 0;
-    if (pts.positions == nullptr)
-      for (int l = 0; l < grid.num_levels; ++l)
-        if (grid.scalings[l] < merge_env * (float)pts.samples_per_ray) merge_mask |= 1u << l;
-    // per-workgroup combining pays where a workgroup's updates hit few distinct entries: coarse levels
-    static const int combine_env = env_int("NSAMD_SCATTER_COMBINE_RES", 64);
-    uint32_t combine_mask = 0;
+    // Coarse levels go through the run-merging / combining kernel: those whose cells are wide against the sample
+    // spacing (resolution below the samples per ray) or that have few entries anyway (resolution < 64). Measured
+    // optimum on MI355X for S = 48 / 96 / 256 (profiles/r01_scatter_*): finer levels overflow the workgroup's table.
+    static const int combine_env = env_int("NSAMD_SCATTER_COMBINE_RES", 0);  // > 0 overrides the rule (experiments)
+    float coarse_below = 64.0f;
+    if (pts.positions == nullptr && (float)pts.samples_per_ray > coarse_below) coarse_below = (float)pts.samples_per_ray;
+    if (combine_env > 0) coarse_below = (float)combine_env;
+    uint32_t coarse_mask = 0;
     for (int l = 0; l < grid.num_levels; ++l)
-      if (grid.scalings[l] < (float)combine_env) combine_mask |= 1u << l;
-    const size_t bin_lds = sizeof(uint32_t) * (2 * (size_t)B + (combine_mask ? 3 * kCombineSlots : 0));
+      if (grid.scalings[l] < coarse_below) coarse_mask |= 1u << l;
+    static const int only_env = env_int("NSAMD_SCATTER_ONLY_LEVEL", -1);  // diagnostics: a single level
+    const int l0 = only_env >= 0 && only_env < grid.num_levels ? only_env : 0;
+    const int nl = only_env >= 0 && only_env < grid.num_levels ? 1 : grid.num_levels;
+    LevelList coarse{}, fine{};
+    for (int l = l0; l < l0 + nl; ++l) {
+      LevelList& dst = ((coarse_mask >> l) & 1u) ? coarse : fine;
+      dst.level[dst.count++] = (int8_t)l;
+    }
     static bool attr2 = false;
     if (!attr2) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hash_bwd_apply_kernel<true>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hash_bwd_apply_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sizeof(float) << kSliceLog2Max) !=
-              hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(&hash_bwd_apply_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sizeof(float) << kSliceLog2Max) !=
-              hipSuccess)
+          hipSuccess)
         return NSAMD_ERR_LAUNCH;
       attr2 = true;
     }
     const unsigned threads = sl > 11 ? 1024u : 256u;
-    static const int only_env = env_int("NSAMD_SCATTER_ONLY_LEVEL", -1);  // diagnostics: a single level
-    for (int l0 = only_env >= 0 ? only_env : 0; l0 < (only_env >= 0 ? only_env + 1 : grid.num_levels); l0 += per_group) {
-      const int nl = only_env >= 0 ? 1 : (grid.num_levels - l0 < per_group ? grid.num_levels - l0 : per_group);
-      dim3 g1((unsigned)((M + kBinThreads - 1) / kBinThreads), (unsigned)nl);
-      hash_bwd_bin_kernel<<<g1, kBinThreads, bin_lds, st>>>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, sl,
-                                                            cap, merge_mask, combine_mask, l0, cursors, queues, dtable);
+    const unsigned point_blocks = (unsigned)((M + kBinThreads - 1) / kBinThreads);
+    static const int fine_env = env_int("NSAMD_SCATTER_FINE_LEVELS", 4);
+    if (fine.count > 0 && fine_env >= 4) {
+      dim3 g1(point_blocks, (unsigned)((fine.count + 3) / 4));
+      hash_bwd_bin_fine_kernel<4><<<g1, kBinThreads, sizeof(uint32_t) * 2 * 4 * (size_t)B, st>>>(
+          pts, M, transform, aabb, grid, denc, stride_p, stride_k, sl, cap, fine, cursors, queues, dtable);
       NSAMD_CHECK_LAUNCH();
-      dim3 g2((unsigned)B, (unsigned)nl);
-      if (pipe_env)
-        hash_bwd_apply_kernel<true><<<g2, threads, sizeof(float) * 2 * ((size_t)1 << sl), st>>>(
-            grid, sl, cap, l0, cursors, queues, dtable);
-      else
-        hash_bwd_apply_kernel<false><<<g2, threads, sizeof(float) * 2 * ((size_t)1 << sl), st>>>(
-            grid, sl, cap, l0, cursors, queues, dtable);
+    } else if (fine.count > 0 && fine_env >= 2) {
+      dim3 g1(point_blocks, (unsigned)((fine.count + 1) / 2));
+      hash_bwd_bin_fine_kernel<2><<<g1, kBinThreads, sizeof(uint32_t) * 2 * 2 * (size_t)B, st>>>(
+          pts, M, transform, aabb, grid, denc, stride_p, stride_k, sl, cap, fine, cursors, queues, dtable);
+      NSAMD_CHECK_LAUNCH();
+    } else if (fine.count > 0) {
+      dim3 g1(point_blocks, (unsigned)fine.count);
+      hash_bwd_bin_fine_kernel<1><<<g1, kBinThreads, sizeof(uint32_t) * 2 * (size_t)B, st>>>(
+          pts, M, transform, aabb, grid, denc, stride_p, stride_k, sl, cap, fine, cursors, queues, dtable);
       NSAMD_CHECK_LAUNCH();
     }
+    if (coarse.count > 0) {
+      const size_t bin_lds = sizeof(uint32_t) * (2 * (size_t)B + 3 * kCombineSlots);
+      static const int run_env = env_int("NSAMD_SCATTER_RUN_LEN", 4);
+      const int run_len = run_env >= 8 ? 8 : (run_env >= 4 ? 4 : 2);
+      const int64_t per_block = (int64_t)kRunThreads * run_len;
+      dim3 g1((unsigned)((M + per_block - 1) / per_block), (unsigned)coarse.count);
+#define NSAMD_RUNS(L)                                                                                              \
+  hash_bwd_bin_runs_kernel<L><<<g1, kRunThreads, bin_lds, st>>>(pts, M, transform, aabb, grid, denc, stride_p,     \
+                                                                stride_k, sl, cap, coarse, cursors, queues, dtable)
+      if (run_len == 8) NSAMD_RUNS(8);
+      else if (run_len == 4) NSAMD_RUNS(4);
+      else NSAMD_RUNS(2);
+#undef NSAMD_RUNS
+      NSAMD_CHECK_LAUNCH();
+    }
+    dim3 g2((unsigned)B, (unsigned)nl);
+    hash_bwd_apply_kernel<<<g2, threads, sizeof(float) * 2 * ((size_t)1 << sl), st>>>(grid, sl, cap, l0, cursors,
+                                                                                    queues, dtable);
+    NSAMD_CHECK_LAUNCH();
   } else if (dtable != nullptr) {
     const int slice_log2 = grid.log2_table_size < kSliceLog2Max ? grid.log2_table_size : kSliceLog2Max;
     const int slices = 1 << (grid.log2_table_size - slice_log2);
@@ -702,6 +864,14 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
     NSAMD_CHECK_LAUNCH();
   }
   return NSAMD_OK;
+}
+
+extern "C" int64_t nsamd_hashgrid_encode_bwd_workspace(nsamd_grid grid, int64_t M) {
+  if (M < 8192 || check_grid(grid) != NSAMD_OK) return 0;
+  const ScatterPlan p = scatter_geometry(grid);
+  if (p.bins > kMaxBins) return 0;
+  const int64_t cap = 2 * scatter_expected_records(p, M) + 64;
+  return p.cursor_words + 4 * p.tiles * cap;
 }
 
 extern "C" int nsamd_sh4_encode(const float* dirs, int64_t M, float* out, nsamd_stream_t stream) {

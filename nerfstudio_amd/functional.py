@@ -146,27 +146,15 @@ def field_bwd_workspace(device) -> Tuple[Tensor, int]:
 
 def _scatter_workspace(grid: HashGridSpec, device, num_points: int = 0) -> Tuple[Optional[Tensor], int]:
     """Device scratch for the table-gradient scatter (csrc/hashgrid.hip, "binned" path): per (level, tile) a cursor and
-    a queue of 16-byte (local index, g0, g1, pad) records sized 2x the uniform-hash expectation 8*M/tiles_per_level.
-    Cached per (grid, M); the kernels fall back to the scratch-free scan when it is too small."""
-    if num_points < 8192:
+    a queue of pair records; the library says how many words it wants (nsamd_hashgrid_encode_bwd_workspace). Zeroed
+    once here (the kernels leave the cursors at zero), cached per (grid, M)."""
+    words = int(N.load().nsamd_hashgrid_encode_bwd_workspace(grid.native(), num_points))
+    if words <= 0:
         return None, 0
-    import os
-
-    target = max(64, int(os.environ.get("NSAMD_SCATTER_TILES", "512")))  # must mirror csrc/hashgrid.hip
-    bits = 0
-    while (grid.num_levels << bits) < target:
-        bits += 1
-    sl = min(14, max(8, grid.log2_hashmap_size - bits))
-    sl = min(sl, grid.log2_hashmap_size)
-    bins = 1 << (grid.log2_hashmap_size - sl)
-    tiles = bins * grid.num_levels
-    cap = 2 * ((8 * num_points + bins - 1) // bins) + 64
-    words = tiles + 8 + 4 * tiles * cap
     key = (grid, num_points, str(device))
     ws = _SCATTER_WS.get(key)
     if ws is None:
-        ws = torch.empty(words, device=device, dtype=torch.float32)
-        ws[:tiles].zero_()  # queue cursors: zeroed once, kept at zero by the kernels themselves
+        ws = torch.zeros(words, device=device, dtype=torch.float32)
         _SCATTER_WS[key] = ws
     return ws, ws.numel()
 

@@ -17,8 +17,11 @@ def timeit(fn, reps=5):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for name, S, spec in (("prop0", 256, F.HashGridSpec(5, 16, 128, 17)), ("prop1", 96, F.HashGridSpec(5, 16, 256, 17)),
-                      ("main", 48, F.HashGridSpec(16, 16, 2048, 19))):
+CONFIGS = (("prop0", 256, F.HashGridSpec(5, 16, 128, 17)), ("prop1", 96, F.HashGridSpec(5, 16, 256, 17)),
+           ("main", 48, F.HashGridSpec(16, 16, 2048, 19)))
+if "--main" in sys.argv:
+    CONFIGS = CONFIGS[2:]
+for name, S, spec in CONFIGS:
     s_bins, t_bins = F.piecewise_bins(nears, fars, S, torch.rand(n, device=dev))
     M = n * S
     table = torch.randn(spec.num_levels * spec.table_size, 2, device=dev); dtable = torch.zeros_like(table)
