@@ -93,6 +93,8 @@ class Trainer:
             self.runner = NerfactoTrainStep(model, ray_bundle.origins.shape[0], dev)
             self.runner.set_batch(ray_bundle.origins, ray_bundle.directions, ray_bundle.camera_indices, batch["image"])
             self.runner.anneal_dev = self.hyper[4:5]
+            if os.environ.get("NSAMD_SIDE_STREAM", "1") == "0":  # A/B switch: proposal backward on the main stream
+                self.runner.side_stream = None
 
     # -- pieces of one iteration ---------------------------------------------------------------------------------
     def _prologue(self, updated):
@@ -269,6 +271,10 @@ def measure_roofline(trainer, arena, steps):
     from nerfstudio_amd import _native as N
 
     graphs, trainer.graphs = trainer.graphs, None  # per-kernel events need eager launches
+    runner = getattr(trainer, "runner", None)
+    side = getattr(runner, "side_stream", None)
+    if runner is not None:
+        runner.side_stream = None  # one stream: a kernel's events must not include a concurrent branch's work
     N.PROFILE = {}
     for _ in range(steps):
         trainer.train_iteration()
@@ -276,6 +282,8 @@ def measure_roofline(trainer, arena, steps):
     prof = N.profile_summary(N.PROFILE)
     N.PROFILE = None
     trainer.graphs = graphs
+    if runner is not None:
+        runner.side_stream = side
     table = []
     for key, (calls, total_ms, mean_ms) in prof.items():
         bound, work = algorithmic_model(key)

@@ -13,15 +13,18 @@
 // next layer's B operands with no shuffle or LDS round trip. The K-order permutation this implies is folded into
 // the weight fragments when a workgroup stages them in LDS (once; workgroups are persistent over tiles):
 //   Wf[n][t][lane][r] = W[16n + j][16t + 4g + r]   -> one conflict-free ds_read_b128 per lane feeds 4 MFMAs.
-// Backward data products use W^T fragments  Wb[m][t][lane][r] = W[16t + 4g + r][16m + j]. The weight-gradient
-// GEMMs reduce over POINTS, so their operands need points on the k axis: each wave transposes the two 16 x F tiles
-// through a private LDS scratch (row stride 80 floats = 16 mod 32 banks: conflict-free b32 column reads) and
-// accumulates dW tiles in registers across all the tiles it processes; one LDS reduction over the 4 waves and one
-// atomic flush per workgroup at the end.
+// That is the forward kernel (4 waves per workgroup, fragments staged once, workgroups persistent over tiles). The
+// backward kernel (further down) recomputes the forward per tile, runs the data-gradient GEMMs in the same chain
+// layout with W^T operands, and needs points on the k axis for the weight-gradient GEMMs: each wave transposes its
+// (Dout, X) tiles through an LDS scratch (row stride 80 floats = 16 mod 32 banks: conflict-free b32 column reads).
+// Its first version gave every wave all 48 dW accumulator tiles (424 registers, one wave per SIMD, MFMA busy 33 %);
+// the current one shares dW out over 8 waves by output tile — see "backward: cooperative over the workgroup".
 //
 // Head input slots (internal K order of head layer 0): [0,16) SH, 16 = density pre-activation (zero weight),
 // [17,32) geo features = base outputs 1..15 in place, [32,64) appearance embedding. Logical column = slot for
 // slot < 16, slot - 1 for slot >= 17.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace nsamd {
@@ -63,20 +66,6 @@ __device__ void stage_fwd_frag(float* dst, const float* __restrict__ W, int n_re
     const int t = tile % KT, n = tile / KT;
     const int j = lane & 15, g = lane >> 4;
     const int row = 16 * n + j, slot = 16 * t + 4 * g + r;
-    const int col = head0 ? head0_col(slot, app_dim) : slot;
-    dst[e] = (row < n_real && col >= 0 && col < k_real) ? W[row * k_real + col] : 0.0f;
-  }
-}
-
-// Wb[m][t][lane][r] = Wint[16t + 4g + r][16m + j]     (m over input tiles, t over output tiles)
-__device__ void stage_bwd_frag(float* dst, const float* __restrict__ W, int n_real, int k_real, int NT, int KT,
-                               bool head0, int app_dim) {
-  const int total = NT * KT * 256;
-  for (int e = threadIdx.x; e < total; e += kFieldThreads) {
-    const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8;
-    const int t = tile % NT, m = tile / NT;
-    const int j = lane & 15, g = lane >> 4;
-    const int row = 16 * t + 4 * g + r, slot = 16 * m + j;
     const int col = head0 ? head0_col(slot, app_dim) : slot;
     dst[e] = (row < n_real && col >= 0 && col < k_real) ? W[row * k_real + col] : 0.0f;
   }
@@ -134,18 +123,22 @@ struct FieldActs {
   v4f rgbp[1];    // rgb pre-sigmoid (rows 0..2 of tile 0)
 };
 
-__device__ __forceinline__ void field_forward_tile(const float* wf, const float* bias, const float* __restrict__ enc,
+// encoded features: feature-major [32][M]; lane needs features 16t + 4g + r of its point
+__device__ __forceinline__ void load_enc_tile(const float* __restrict__ enc, int64_t M, int64_t p, int lane, v4f* out) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[t][r] = enc[(int64_t)(16 * t + 4 * g + r) * M + p];
+}
+
+// A.enc must hold the tile's encoded features (load_enc_tile) on entry.
+__device__ __forceinline__ void field_forward_tile(const float* wf, const float* bias,
                                                    const float* __restrict__ directions,
                                                    const float* __restrict__ app_table,
                                                    const float* __restrict__ app_const, int64_t dir_group, int64_t M,
                                                    int app_dim, const TileInputs& ti, int lane, FieldActs& A) {
   const int g = lane >> 4;
-  // encoded features: feature-major [32][M]; lane needs features 16t + 4g + r of its point
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) A.enc[t][r] = enc[(int64_t)(16 * t + 4 * g + r) * M + ti.p];
-
   load_bias<4>(bias + kBiasBase0, A.h1, g);
   chain_gemm<4, 2>(wf + kOffBase0, A.enc, A.h1, lane);
   relu_tiles<4>(A.h1);
@@ -226,7 +219,8 @@ __global__ __launch_bounds__(kFieldThreads, 2) void field_mlp_fwd_kernel(
     asm volatile("" ::: "memory");
     const TileInputs ti = tile_inputs(tile, lane, M, selector, cams, dir_group);
     FieldActs A;
-    field_forward_tile(wf, bias, enc, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A);
+    load_enc_tile(enc, M, ti.p, lane, A.enc);
+    field_forward_tile(wf, bias, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A);
     if (lane < 16 && ti.live) {  // g == 0 holds neurons 0..3 of tile 0
       density[ti.p] = mlp.average_init_density * expf(A.o16[0][0]) * ti.sel;
       float* o = rgb + 3 * ti.p;
@@ -244,26 +238,6 @@ __device__ __forceinline__ void store_rows(float* S, const v4f* x, int j, int g)
   for (int t = 0; t < T; ++t) *reinterpret_cast<v4f*>(S + j * kScratchLd + 16 * t + 4 * g) = x[t];
 }
 
-// dW[n][m] += Dout^T X over the 16 points of the tile; db[n] partial sums (per lane: points = g mod 4)
-template <int NT, int MT>
-__device__ __forceinline__ void dw_accumulate(v4f* acc /*[NT*MT]*/, float* dbacc /*[NT]*/, const float* Sd,
-                                              const float* Sx, int j, int g) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float a[NT], b[MT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) a[n] = Sd[(4 * q + g) * kScratchLd + 16 * n + j];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) b[m] = Sx[(4 * q + g) * kScratchLd + 16 * m + j];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) dbacc[n] += a[n];
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[n * MT + m] = mfma16(a[n], b[m], acc[n * MT + m]);
-  }
-}
-
 template <int N>
 __device__ __forceinline__ void zero_tiles(v4f* x) {
 #pragma unroll
@@ -278,47 +252,178 @@ __device__ __forceinline__ void relu_mask(v4f* grad, const v4f* act) {
     for (int r = 0; r < 4; ++r) grad[n][r] = (act[n][r] > 0.0f) ? grad[n][r] : 0.0f;
 }
 
-// Reduce the per-wave dW tiles over the waves of the workgroup in LDS (reusing the weight area). Each lane owns a
-// distinct address per (n, m, r), so a wave can add its registers with a PLAIN read-modify-write; the caller runs the
-// waves one after the other between barriers. (ds_add_f32 with divergent addresses retires 0.33 lane-ops/clk/CU on
-// gfx950 — 12288 of them per wave made this reduction 27 % of the kernel, see profiles/r01k_pmc_summary.csv.)
-// acc lane (j,g) reg r' of tile (n,m) = dW[16n + 4g + r'][slot 16m + j]
-template <int NT, int MT>
-__device__ __forceinline__ void flush_dw(float* red, const v4f* acc, int j, int g) {
-#pragma unroll
-  for (int n = 0; n < NT; ++n)
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[(16 * n + 4 * g + r) * (16 * MT) + 16 * m + j] += acc[n * MT + m][r];
-}
+// ---- backward: cooperative over the workgroup --------------------------------------------------------------------
+// 8 waves per workgroup = two per SIMD, so a wave's LDS/MFMA latencies are covered by its SIMD mate. What makes that
+// fit (256 registers per wave, 160 KiB LDS):
+//  * ONE copy of the weights in LDS, row-major with a row stride = 4 mod 32 floats. The forward A operand
+//    W[16n+j][16t+4g .. +3] is one conflict-free ds_read_b128; the transposed operand of the data-gradient GEMMs,
+//    W[16t+4g+r][16m+j], is four ds_read_b32 of the same array (2-way bank conflict) instead of a second 48 KiB copy.
+//  * The weight-gradient GEMMs are shared out over the waves BY OUTPUT TILE instead of by point tile: every wave
+//    stores the transposed (Dout, X) tiles of its 16 points in its scratch, the workgroup synchronises, and wave w
+//    accumulates its own 1-2 tiles of dW over all 128 points of the 8 scratch areas. 7 accumulator tiles per wave
+//    instead of 48, no cross-wave reduction at the end, and every wave writes its tiles of the partial straight out.
+constexpr int kCoopWaves = 8;
+constexpr int kCoopThreads = 64 * kCoopWaves;
+constexpr int kLd64 = 68, kLd32 = 36;  // row strides (floats) of the K = 64 / K = 32 weight matrices in LDS
+constexpr int kRowBase0 = 0, kRowBase1 = kRowBase0 + 64 * kLd32, kRowHead0 = kRowBase1 + 16 * kLd64,
+              kRowHead1 = kRowHead0 + 64 * kLd64, kRowHead2 = kRowHead1 + 64 * kLd64,
+              kRowTotal = kRowHead2 + 16 * kLd64;  // 13184 floats = 51.5 KiB
 
-__device__ void export_dw(const float* red, float* __restrict__ dst, int n_real, int k_real, int n_pad, int k_pad,
-                          bool head0, int app_dim) {
-  if (dst == nullptr) return;
-  for (int e = threadIdx.x; e < n_pad * k_pad; e += kFieldThreads) {
+// W (n_real x k_real, row-major in global memory) -> LDS rows [n_pad][ld], internal slot order, zero padded
+__device__ void stage_rows(float* dst, const float* __restrict__ W, int n_real, int k_real, int n_pad, int k_pad, int ld,
+                           bool head0, int app_dim) {
+  for (int e = threadIdx.x; e < n_pad * k_pad; e += kCoopThreads) {
     const int row = e / k_pad, slot = e - row * k_pad;
     const int col = head0 ? head0_col(slot, app_dim) : slot;
-    if (row < n_real && col >= 0 && col < k_real) unsafeAtomicAdd(dst + row * k_real + col, red[e]);
+    dst[row * ld + slot] = (row < n_real && col >= 0 && col < k_real) ? W[row * k_real + col] : 0.0f;
   }
 }
 
-__global__ __launch_bounds__(kFieldThreads, 1) void field_mlp_bwd_kernel(
+// out[n] += W[16n + j][:] . in   (forward direction; Wrows = LDS rows with stride LD)
+template <int NT, int KT, int LD>
+__device__ __forceinline__ void rows_gemm_fwd(const float* Wrows, const v4f* in, v4f* out, int j, int g) {
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    v4f a[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) a[n] = *reinterpret_cast<const v4f*>(Wrows + (16 * n + j) * LD + 16 * t + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) out[n] = mfma16(a[n][r], in[t][r], out[n]);
+    }
+  }
+}
+
+// out[m] += W[:][16m + j]^T . in   (data-gradient direction: MT input-feature tiles, NT neuron tiles)
+template <int MT, int NT, int LD>
+__device__ __forceinline__ void rows_gemm_bwd(const float* Wrows, const v4f* in, v4f* out, int j, int g) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = Wrows[(16 * t + 4 * g + r) * LD + 16 * m + j];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) out[m] = mfma16(a[m], in[t][r], out[m]);
+    }
+  }
+}
+
+__device__ __forceinline__ void coop_forward_tile(const float* W, const float* bias,
+                                                  const float* __restrict__ directions,
+                                                  const float* __restrict__ app_table,
+                                                  const float* __restrict__ app_const, int64_t dir_group, int app_dim,
+                                                  const TileInputs& ti, int lane, FieldActs& A) {
+  const int j = lane & 15, g = lane >> 4;
+  load_bias<4>(bias + kBiasBase0, A.h1, g);
+  rows_gemm_fwd<4, 2, kLd32>(W + kRowBase0, A.enc, A.h1, j, g);
+  relu_tiles<4>(A.h1);
+  load_bias<1>(bias + kBiasBase1, A.o16, g);
+  rows_gemm_fwd<1, 4, kLd64>(W + kRowBase1, A.h1, A.o16, j, g);
+  const float* d = directions + 3 * (ti.p / dir_group);
+  float sh[16];
+  sh4_components((d[0] + 1.0f) / 2.0f, (d[1] + 1.0f) / 2.0f, (d[2] + 1.0f) / 2.0f, sh);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v = sh[r];
+    v = (g == 1) ? sh[4 + r] : v;
+    v = (g == 2) ? sh[8 + r] : v;
+    v = (g == 3) ? sh[12 + r] : v;
+    A.hin[0][r] = v;
+  }
+  A.hin[1] = A.o16[0];
+  if (app_dim > 0) {
+    const float* src = (app_table != nullptr) ? app_table + ti.cam * 32 : app_const;
+    A.hin[2] = *reinterpret_cast<const v4f*>(src + 4 * g);
+    A.hin[3] = *reinterpret_cast<const v4f*>(src + 16 + 4 * g);
+  } else {
+    A.hin[2] = v4f{0.f, 0.f, 0.f, 0.f};
+    A.hin[3] = v4f{0.f, 0.f, 0.f, 0.f};
+  }
+  load_bias<4>(bias + kBiasHead0, A.ha, g);
+  rows_gemm_fwd<4, 4, kLd64>(W + kRowHead0, A.hin, A.ha, j, g);
+  relu_tiles<4>(A.ha);
+  load_bias<4>(bias + kBiasHead1, A.hb, g);
+  rows_gemm_fwd<4, 4, kLd64>(W + kRowHead1, A.ha, A.hb, j, g);
+  relu_tiles<4>(A.hb);
+  load_bias<1>(bias + kBiasHead2, A.rgbp, g);
+  rows_gemm_fwd<1, 4, kLd64>(W + kRowHead2, A.hb, A.rgbp, j, g);
+}
+
+// dW tile (n, m) += sum over the points of scratch areas [first, first + count): Dout^T X
+template <int TILES>
+__device__ __forceinline__ void coop_dw(v4f* acc, float* dbacc, bool want_db, const float* scratch, int first,
+                                        int count, int n, int m0, int j, int g) {
+#pragma unroll 2  // full unrolling hoists all 96 scratch reads and spills
+  for (int area = first; area < first + count; ++area) {
+    const float* Sd = scratch + area * 2 * kScratchTile;
+    const float* Sx = Sd + kScratchTile;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float a = Sd[(4 * q + g) * kScratchLd + 16 * n + j];
+      float b[TILES];
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) b[i] = Sx[(4 * q + g) * kScratchLd + 16 * (m0 + i) + j];
+      if (want_db) *dbacc += a;
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) acc[i] = mfma16(a, b[i], acc[i]);
+    }
+  }
+}
+
+// acc lane (j, g) reg r of tile (n, m) = dW[16n + 4g + r][slot 16m + j]: to the workgroup's partial row (plain stores,
+// this wave is the only writer) or, without a partial buffer, straight into the gradient with atomics
+__device__ __forceinline__ void coop_emit(const v4f& acc, int n, int m, int k_pad, float* partial_layer,
+                                          float* __restrict__ dst, int n_real, int k_real, bool head0, int app_dim,
+                                          int j, int g) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * n + 4 * g + r, slot = 16 * m + j;
+    if (partial_layer != nullptr) {
+      partial_layer[row * k_pad + slot] = acc[r];
+    } else if (dst != nullptr) {
+      const int col = head0 ? head0_col(slot, app_dim) : slot;
+      if (row < n_real && col >= 0 && col < k_real) unsafeAtomicAdd(dst + row * k_real + col, acc[r]);
+    }
+  }
+}
+
+__device__ __forceinline__ void coop_emit_bias(float v, int n, int j, int g, float* partial_bias, float* __restrict__ dst,
+                                               int n_real) {
+  // lane (j, g) holds the partial of neuron 16n + j over the points = g mod 4: fold the four g first
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  if (g == 0) {
+    if (partial_bias != nullptr) partial_bias[16 * n + j] = v;
+    else if (dst != nullptr && 16 * n + j < n_real) unsafeAtomicAdd(dst + 16 * n + j, v);
+  }
+}
+
+__global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
     nsamd_field_mlp mlp, int app_dim, const float* __restrict__ ddensity, const float* __restrict__ drgb,
     float* __restrict__ denc, nsamd_field_mlp_grads grads, float* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* wf = lds;                           // forward fragments          48 KiB
-  float* wb = lds + kFragTotal;              // transposed fragments       48 KiB
-  float* bias = wb + kFragTotal;             // 224 floats (+ pad to 256)
-  float* scratch = bias + 256;               // kWaves x 2 tiles
-  stage_all_fwd(wf, bias, mlp, app_dim);
-  stage_bwd_frag(wb + kOffBase0, mlp.base_W0, 64, 32, 4, 2, false, 0);
-  stage_bwd_frag(wb + kOffBase1, mlp.base_W1, 16, 64, 1, 4, false, 0);
-  stage_bwd_frag(wb + kOffHead0, mlp.head_W0, 64, 31 + app_dim, 4, 4, true, app_dim);
-  stage_bwd_frag(wb + kOffHead1, mlp.head_W1, 64, 64, 4, 4, false, 0);
-  stage_bwd_frag(wb + kOffHead2, mlp.head_W2, 3, 64, 1, 4, false, 0);
+  float* W = lds;                     // kRowTotal
+  float* bias = lds + kRowTotal;      // 256
+  float* scratch = bias + 256;        // kCoopWaves x 2 tiles
+  stage_rows(W + kRowBase0, mlp.base_W0, 64, 32, 64, 32, kLd32, false, 0);
+  stage_rows(W + kRowBase1, mlp.base_W1, 16, 64, 16, 64, kLd64, false, 0);
+  stage_rows(W + kRowHead0, mlp.head_W0, 64, 31 + app_dim, 64, 64, kLd64, true, app_dim);
+  stage_rows(W + kRowHead1, mlp.head_W1, 64, 64, 64, 64, kLd64, false, 0);
+  stage_rows(W + kRowHead2, mlp.head_W2, 3, 64, 16, 64, kLd64, false, 0);
+  for (int e = threadIdx.x; e < 256; e += kCoopThreads) {
+    float v = 0.0f;
+    if (e < kBiasBase1) v = mlp.base_b0[e];
+    else if (e < kBiasHead0) v = mlp.base_b1[e - kBiasBase1];
+    else if (e < kBiasHead1) v = mlp.head_b0[e - kBiasHead0];
+    else if (e < kBiasHead2) v = mlp.head_b1[e - kBiasHead1];
+    else if (e < kBiasHead2 + 3) v = mlp.head_b2[e - kBiasHead2];
+    bias[e] = v;
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -326,21 +431,31 @@ __global__ __launch_bounds__(kFieldThreads, 1) void field_mlp_bwd_kernel(
   float* Sd = scratch + wave * 2 * kScratchTile;
   float* Sx = Sd + kScratchTile;
   const float* app_table = cams ? mlp.appearance : nullptr;
-
-  // weight-gradient accumulators (registers, whole kernel lifetime)
-  v4f dW_b0[4 * 2], dW_b1[1 * 4], dW_h0[4 * 4], dW_h1[4 * 4], dW_h2[1 * 4];
-  float db_b0[4] = {0, 0, 0, 0}, db_b1[1] = {0}, db_h0[4] = {0, 0, 0, 0}, db_h1[4] = {0, 0, 0, 0}, db_h2[1] = {0};
-  zero_tiles<8>(dW_b0);
-  zero_tiles<4>(dW_b1);
-  zero_tiles<16>(dW_h0);
-  zero_tiles<16>(dW_h1);
-  zero_tiles<4>(dW_h2);
+  // this wave's share of the weight gradients
+  const int own_n = wave >> 1;           // 4 x 4 and 4 x 2 layers: row tile
+  const int own_m2 = 2 * (wave & 1);     // 4 x 4 layers: column tiles own_m2, own_m2 + 1
+  const int own_m1 = wave & 1;           // 4 x 2 layer: column tile
+  const int own_q = wave & 3;            // 1 x 4 layers: column tile; the points are split in two halves
+  const int own_half = wave >> 2;
+  v4f dW_h1[2], dW_h0[2], dW_b0[1], dW_h2[1], dW_b1[1];
+  float db_h1 = 0.f, db_h0 = 0.f, db_b0 = 0.f, db_h2 = 0.f, db_b1 = 0.f;
+  zero_tiles<2>(dW_h1);
+  zero_tiles<2>(dW_h0);
+  zero_tiles<1>(dW_b0);
+  zero_tiles<1>(dW_h2);
+  zero_tiles<1>(dW_b1);
+  const bool bias_owner44 = (wave & 1) == 0, bias_owner14 = own_q == 0;
 
   const int64_t tiles = (M + 15) / 16;
-  for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += (int64_t)gridDim.x * kWaves) {
-    const TileInputs ti = tile_inputs(tile, lane, M, selector, cams, dir_group);
+  const int64_t per_iter = (int64_t)gridDim.x * kCoopWaves;
+  const int64_t iters = (tiles + per_iter - 1) / per_iter;
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t tile = (it * gridDim.x + blockIdx.x) * kCoopWaves + wave;
+    TileInputs ti = tile_inputs(tile < tiles ? tile : tiles - 1, lane, M, selector, cams, dir_group);
+    if (tile >= tiles) ti.live = false;  // idle wave of the last round: computes, contributes zeros
     FieldActs A;
-    field_forward_tile(wf, bias, enc, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A);
+    load_enc_tile(enc, M, ti.p, lane, A.enc);
+    coop_forward_tile(W, bias, directions, app_table, app_const, dir_group, app_dim, ti, lane, A);
 
     // ---- head layer 2 (64 -> 3, sigmoid) ----
     v4f g_rgbp[1];
@@ -348,40 +463,40 @@ __global__ __launch_bounds__(kFieldThreads, 1) void field_mlp_bwd_kernel(
     if (g == 0 && ti.live) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float s = 1.0f / (1.0f + expf(-A.rgbp[0][c]));
-        g_rgbp[0][c] = drgb[3 * ti.p + c] * (s * (1.0f - s));
+        const float sg = 1.0f / (1.0f + expf(-A.rgbp[0][c]));
+        g_rgbp[0][c] = drgb[3 * ti.p + c] * (sg * (1.0f - sg));
       }
     }
     store_rows<1>(Sd, g_rgbp, j, g);
     store_rows<4>(Sx, A.hb, j, g);
-    __builtin_amdgcn_wave_barrier();
-    dw_accumulate<1, 4>(dW_h2, db_h2, Sd, Sx, j, g);
+    __syncthreads();
+    coop_dw<1>(dW_h2, &db_h2, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
     v4f g_hb[4];
     zero_tiles<4>(g_hb);
-    chain_gemm<4, 1>(wb + kOffHead2, g_rgbp, g_hb, lane);
+    rows_gemm_bwd<4, 1, kLd64>(W + kRowHead2, g_rgbp, g_hb, j, g);
     relu_mask<4>(g_hb, A.hb);
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
 
     // ---- head layer 1 (64 -> 64) ----
     store_rows<4>(Sd, g_hb, j, g);
     store_rows<4>(Sx, A.ha, j, g);
-    __builtin_amdgcn_wave_barrier();
-    dw_accumulate<4, 4>(dW_h1, db_h1, Sd, Sx, j, g);
+    __syncthreads();
+    coop_dw<2>(dW_h1, &db_h1, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
     v4f g_ha[4];
     zero_tiles<4>(g_ha);
-    chain_gemm<4, 4>(wb + kOffHead1, g_hb, g_ha, lane);
+    rows_gemm_bwd<4, 4, kLd64>(W + kRowHead1, g_hb, g_ha, j, g);
     relu_mask<4>(g_ha, A.ha);
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
 
     // ---- head layer 0 (slots 64 -> 64) ----
     store_rows<4>(Sd, g_ha, j, g);
     store_rows<4>(Sx, A.hin, j, g);
-    __builtin_amdgcn_wave_barrier();
-    dw_accumulate<4, 4>(dW_h0, db_h0, Sd, Sx, j, g);
+    __syncthreads();
+    coop_dw<2>(dW_h0, &db_h0, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
     v4f g_hin[4];
     zero_tiles<4>(g_hin);
-    chain_gemm<4, 4>(wb + kOffHead0, g_ha, g_hin, lane);  // tile 0 (SH) is unused: SH carries no gradient
-    __builtin_amdgcn_wave_barrier();
+    rows_gemm_bwd<4, 4, kLd64>(W + kRowHead0, g_ha, g_hin, j, g);  // tile 0 (SH) is unused: SH carries no gradient
+    __syncthreads();
 
     // appearance-embedding gradient (slots 32..63): rows of one camera are pre-reduced over the tile's points
     if (app_table != nullptr && grads.appearance != nullptr) {
@@ -398,7 +513,7 @@ __global__ __launch_bounds__(kFieldThreads, 1) void field_mlp_bwd_kernel(
             v += __shfl_xor(v, 2);
             v += __shfl_xor(v, 4);
             v += __shfl_xor(v, 8);
-            if (j == 0) unsafeAtomicAdd(grads.appearance + (int64_t)cam0 * 32 + 16 * (t - 2) + 4 * g + r, v);
+            if (j == 0 && v != 0.0f) unsafeAtomicAdd(grads.appearance + (int64_t)cam0 * 32 + 16 * (t - 2) + 4 * g + r, v);
           }
       } else if (ti.live) {
 #pragma unroll
@@ -421,88 +536,71 @@ __global__ __launch_bounds__(kFieldThreads, 1) void field_mlp_bwd_kernel(
     }
     store_rows<1>(Sd, g_o16, j, g);
     store_rows<4>(Sx, A.h1, j, g);
-    __builtin_amdgcn_wave_barrier();
-    dw_accumulate<1, 4>(dW_b1, db_b1, Sd, Sx, j, g);
+    __syncthreads();
+    coop_dw<1>(dW_b1, &db_b1, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
     v4f g_h1[4];
     zero_tiles<4>(g_h1);
-    chain_gemm<4, 1>(wb + kOffBase1, g_o16, g_h1, lane);
+    rows_gemm_bwd<4, 1, kLd64>(W + kRowBase1, g_o16, g_h1, j, g);
     relu_mask<4>(g_h1, A.h1);
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
 
     // ---- base layer 0 (32 -> 64) ----
     store_rows<4>(Sd, g_h1, j, g);
     store_rows<2>(Sx, A.enc, j, g);
-    __builtin_amdgcn_wave_barrier();
-    dw_accumulate<4, 2>(dW_b0, db_b0, Sd, Sx, j, g);
+    __syncthreads();
+    coop_dw<1>(dW_b0, &db_b0, own_m1 == 0, scratch, 0, kCoopWaves, own_n, own_m1, j, g);
     v4f g_enc[2];
     zero_tiles<2>(g_enc);
-    chain_gemm<2, 4>(wb + kOffBase0, g_h1, g_enc, lane);
-    __builtin_amdgcn_wave_barrier();
+    rows_gemm_bwd<2, 4, kLd32>(W + kRowBase0, g_h1, g_enc, j, g);
     if (ti.live) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) denc[(int64_t)(16 * t + 4 * g + r) * M + ti.p] = g_enc[t][r];
     }
-  }
-
-  // ---- reduce over the workgroup's waves in LDS (the fragment area is dead now) and flush --------------------
-  __syncthreads();
-  float* red = lds;  // 12288 + 256 floats needed; lds holds 2 * 12288 + ...
-  for (int e = threadIdx.x; e < kFragTotal + 256; e += kFieldThreads) red[e] = 0.0f;
-  __syncthreads();
-  float* redb = red + kFragTotal;  // bias sums: lane (j,g) holds the partial of neuron 16n + j over points = g mod 4
-  for (int turn = 0; turn < kWaves; ++turn) {
-    if (wave == turn) {
-      flush_dw<4, 2>(red + kOffBase0, dW_b0, j, g);
-      flush_dw<1, 4>(red + kOffBase1, dW_b1, j, g);
-      flush_dw<4, 4>(red + kOffHead0, dW_h0, j, g);
-      flush_dw<4, 4>(red + kOffHead1, dW_h1, j, g);
-      flush_dw<1, 4>(red + kOffHead2, dW_h2, j, g);
-      // the 4 lanes (g = 0..3) sharing a bias address are folded with two xor-shuffles first
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        float b0 = db_b0[n], h0 = db_h0[n], h1 = db_h1[n];
-        b0 += __shfl_xor(b0, 16); b0 += __shfl_xor(b0, 32);
-        h0 += __shfl_xor(h0, 16); h0 += __shfl_xor(h0, 32);
-        h1 += __shfl_xor(h1, 16); h1 += __shfl_xor(h1, 32);
-        if (g == 0) {
-          redb[kBiasBase0 + 16 * n + j] += b0;
-          redb[kBiasHead0 + 16 * n + j] += h0;
-          redb[kBiasHead1 + 16 * n + j] += h1;
-        }
-      }
-      float b1 = db_b1[0], h2 = db_h2[0];
-      b1 += __shfl_xor(b1, 16); b1 += __shfl_xor(b1, 32);
-      h2 += __shfl_xor(h2, 16); h2 += __shfl_xor(h2, 32);
-      if (g == 0) {
-        redb[kBiasBase1 + j] += b1;
-        redb[kBiasHead2 + j] += h2;
-      }
-    }
     __syncthreads();
   }
-  if (partials != nullptr) {  // single-writer reduction in field_dw_reduce_kernel: no global atomics at all
-    float4* dst = reinterpret_cast<float4*>(partials + (size_t)blockIdx.x * kPartialStride);
-    const float4* src = reinterpret_cast<const float4*>(red);
-    for (int e = threadIdx.x; e < kPartialStride / 4; e += kFieldThreads) dst[e] = src[e];
-    return;
+
+  // ---- the two point-halves of the 1 x 4 layers meet in LDS (scratch is free now) ---------------------------------
+  float* stash = scratch;  // [2 layers][4 tiles][64 lanes][4] + [2][4][64] bias partials
+  if (own_half == 1) {
+    *reinterpret_cast<v4f*>(stash + ((0 * 4 + own_q) * 64 + lane) * 4) = dW_h2[0];
+    *reinterpret_cast<v4f*>(stash + ((1 * 4 + own_q) * 64 + lane) * 4) = dW_b1[0];
+    if (bias_owner14) {
+      stash[2048 + lane] = db_h2;
+      stash[2048 + 64 + lane] = db_b1;
+    }
   }
-  export_dw(red + kOffBase0, grads.base_W0, 64, 32, 64, 32, false, 0);
-  export_dw(red + kOffBase1, grads.base_W1, 16, 64, 16, 64, false, 0);
-  export_dw(red + kOffHead0, grads.head_W0, 64, 31 + app_dim, 64, 64, true, app_dim);
-  export_dw(red + kOffHead1, grads.head_W1, 64, 64, 64, 64, false, 0);
-  export_dw(red + kOffHead2, grads.head_W2, 3, 64, 16, 64, false, 0);
-  for (int e = threadIdx.x; e < kBiasTotal; e += kFieldThreads) {
-    float* dst = nullptr;
-    int idx = 0, n_real = 0;
-    if (e < kBiasBase1) { dst = grads.base_b0; idx = e; n_real = 64; }
-    else if (e < kBiasHead0) { dst = grads.base_b1; idx = e - kBiasBase1; n_real = 16; }
-    else if (e < kBiasHead1) { dst = grads.head_b0; idx = e - kBiasHead0; n_real = 64; }
-    else if (e < kBiasHead2) { dst = grads.head_b1; idx = e - kBiasHead1; n_real = 64; }
-    else { dst = grads.head_b2; idx = e - kBiasHead2; n_real = 3; }
-    if (dst != nullptr && idx < n_real) unsafeAtomicAdd(dst + idx, redb[e]);
+  __syncthreads();
+  float* prow = partials != nullptr ? partials + (size_t)blockIdx.x * kPartialStride : nullptr;
+  float* pbias = prow != nullptr ? prow + kFragTotal : nullptr;
+  if (prow != nullptr) {  // padding of the row that no wave owns: the bias tail
+    for (int e = kBiasTotal + threadIdx.x; e < 256; e += kCoopThreads) pbias[e] = 0.0f;
   }
+  if (own_half == 0) {
+    const v4f o_h2 = *reinterpret_cast<const v4f*>(stash + ((0 * 4 + own_q) * 64 + lane) * 4);
+    const v4f o_b1 = *reinterpret_cast<const v4f*>(stash + ((1 * 4 + own_q) * 64 + lane) * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dW_h2[0][r] += o_h2[r]; dW_b1[0][r] += o_b1[r]; }
+    coop_emit(dW_h2[0], 0, own_q, 64, prow ? prow + kOffHead2 : nullptr, grads.head_W2, 3, 64, false, 0, j, g);
+    coop_emit(dW_b1[0], 0, own_q, 64, prow ? prow + kOffBase1 : nullptr, grads.base_W1, 16, 64, false, 0, j, g);
+    if (bias_owner14) {
+      coop_emit_bias(db_h2 + stash[2048 + lane], 0, j, g, pbias ? pbias + kBiasHead2 : nullptr, grads.head_b2, 3);
+      coop_emit_bias(db_b1 + stash[2048 + 64 + lane], 0, j, g, pbias ? pbias + kBiasBase1 : nullptr, grads.base_b1, 16);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    coop_emit(dW_h1[i], own_n, own_m2 + i, 64, prow ? prow + kOffHead1 : nullptr, grads.head_W1, 64, 64, false, 0, j, g);
+    coop_emit(dW_h0[i], own_n, own_m2 + i, 64, prow ? prow + kOffHead0 : nullptr, grads.head_W0, 64, 31 + app_dim, true,
+              app_dim, j, g);
+  }
+  coop_emit(dW_b0[0], own_n, own_m1, 32, prow ? prow + kOffBase0 : nullptr, grads.base_W0, 64, 32, false, 0, j, g);
+  if (bias_owner44) {
+    coop_emit_bias(db_h1, own_n, j, g, pbias ? pbias + kBiasHead1 : nullptr, grads.head_b1, 64);
+    coop_emit_bias(db_h0, own_n, j, g, pbias ? pbias + kBiasHead0 : nullptr, grads.head_b0, 64);
+  }
+  if (own_m1 == 0) coop_emit_bias(db_b0, own_n, j, g, pbias ? pbias + kBiasBase0 : nullptr, grads.base_b0, 64);
 }
 
 // destination of element e of the [kPartialStride] reduction layout (weights: padded [rows][slots] per layer, then
@@ -625,7 +723,8 @@ extern "C" int nsamd_field_mlp_bwd(const float* enc, const float* selector, cons
   int st = field_common_checks(enc, directions, dir_group, M, mlp, camera_indices, appearance_const, &app_dim);
   if (st) return st;
   NSAMD_REQUIRE(ddensity && drgb && denc);
-  const size_t lds = sizeof(float) * (2 * kFragTotal + 256 + kWaves * 2 * kScratchTile);
+  const int64_t tiles = (M + 15) / 16;
+  const size_t lds = sizeof(float) * (kRowTotal + 256 + kCoopWaves * 2 * kScratchTile);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel),
@@ -633,10 +732,9 @@ extern "C" int nsamd_field_mlp_bwd(const float* enc, const float* selector, cons
       return NSAMD_ERR_LAUNCH;
     attr_set = true;
   }
-  const int64_t tiles = (M + 15) / 16;
-  const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + kWaves - 1) / kWaves);
+  const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + kCoopWaves - 1) / kCoopWaves);
   float* partials = (workspace != nullptr && workspace_floats >= (int64_t)blocks * kPartialStride) ? workspace : nullptr;
-  field_mlp_bwd_kernel<<<blocks, kFieldThreads, lds, (hipStream_t)stream>>>(
+  field_mlp_bwd_kernel<<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
       enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
       grads, partials);
   NSAMD_CHECK_LAUNCH();
