@@ -212,6 +212,16 @@ int nsamd_pdf_resample(const float* s_bins_prev, const float* weights, int32_t S
                        int64_t num_rays, int32_t S, float* s_bins, float* t_bins, int32_t* inds,
                        nsamd_stream_t stream);
 
+/* One proposal level of ProposalNetworkSampler.generate_ray_samples (ray_samplers.py:576-617) in a single launch:
+ * weights = RaySamples.get_weights(density) of the level's samples (t_bins_prev), its median depth (nullable;
+ * models/nerfacto.py:346-347 renders prop_depth_i for every level), then nsamd_pdf_resample on those weights.
+ * Same numbers as nsamd_weights_fwd + nsamd_composite_fwd(median) + nsamd_pdf_resample. */
+int nsamd_proposal_resample(const float* t_bins_prev, const float* s_bins_prev, const float* density, int32_t S_prev,
+                            const float* u_base, const float* jitter, const float* nears, const float* fars,
+                            float anneal, const float* anneal_dev, float histogram_padding, float eps, float u_offset,
+                            int spacing, int64_t num_rays, int32_t S, float* weights, float* depth_median,
+                            float* s_bins, float* t_bins, nsamd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Compositing (model_components/renderers.py): RGBRenderer.combine_rgb :72-119 (+ eval nan_to_num/clamp
  * :225-231), AccumulationRenderer :293-317, DepthRenderer median :354-364 and expected :365-383.
@@ -234,6 +244,21 @@ int nsamd_composite_bwd(const float* rgb, const float* weights, const float* t_b
                         const float* d_depth, const float* workspace, const float* d_weights_add, float* d_rgb,
                         float* d_weights, nsamd_stream_t stream);
 
+/* Training-step fusions of the above (same numbers, fewer launches):
+ * nsamd_render_train = nsamd_weights_fwd (weights [N,S] out) + nsamd_composite_fwd (training mode) + the MSE loss of the
+ * composited colour against target [N,3]: sq_err [N] (nullable) = per-ray sum of squared errors, d_rgb_out [N,3]
+ * (nullable) = 2 (rgb_out - target) grad_scale. target may be NULL (no loss).
+ * nsamd_render_train_bwd = nsamd_composite_bwd (d_rgb_out, d_weights_add) + nsamd_weights_bwd: d_rgb [N,S,3] and
+ * d_density [N,S]; `weights` are the forward's. */
+int nsamd_render_train(const float* rgb, const float* density, const float* t_bins, int64_t num_rays, int32_t S,
+                       int background, const float* bg_rgb_host, const float* target, float grad_scale, float* weights,
+                       float* rgb_out, float* acc, float* depth_expected, float* depth_median, float* workspace,
+                       float* sq_err, float* d_rgb_out, nsamd_stream_t stream);
+int nsamd_render_train_bwd(const float* rgb, const float* weights, const float* density, const float* t_bins,
+                           int64_t num_rays, int32_t S, int background, const float* bg_rgb_host,
+                           const float* d_rgb_out, const float* d_weights_add, float* d_rgb, float* d_density,
+                           nsamd_stream_t stream);
+
 /* MSELoss (model_components/losses.py:31): loss_sum += sum((pred-target)^2) (caller zeroes; mean = /n),
  * dpred (nullable) = 2 (pred-target) grad_scale  with grad_scale = upstream / n. */
 int nsamd_mse_loss(const float* pred, const float* target, int64_t n, float grad_scale, float* loss_sum, float* dpred,
@@ -250,6 +275,15 @@ int nsamd_interlevel_loss(const float* s_bins_fine, const float* w_fine, int32_t
                           float* per_ray_loss, float* dw_prop, nsamd_stream_t stream);
 int nsamd_distortion_loss(const float* s_bins, const float* weights, int32_t S, int64_t num_rays, float grad_scale,
                           float* per_ray_loss, float* dweights, nsamd_stream_t stream);
+
+/* All proposal losses of a training step in one launch (models/nerfacto.py:367-375): the interlevel loss of each of
+ * `levels` (<= 4) proposal levels against the fine samples, and the distortion loss of the fine samples. The pointer
+ * arrays are HOST arrays of `levels` device pointers; dw_prop (or any entry) and dw_distortion may be NULL. */
+int nsamd_proposal_losses(const float* s_bins_fine, const float* w_fine, int32_t S_fine, int32_t levels,
+                          const float* const* s_bins_prop, const float* const* w_prop, const int32_t* S_prop,
+                          int64_t num_rays, float interlevel_grad_scale, float distortion_grad_scale,
+                          float* const* interlevel_per_ray, float* const* dw_prop, float* distortion_per_ray,
+                          float* dw_distortion, nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Pinhole ray generation (RayGenerator.forward, model_components/ray_generators.py:41-56 ->

@@ -71,11 +71,15 @@ _SIGNATURES = {
     "nsamd_weights_fwd": [vp, vp, i64, i32, vp, vp],
     "nsamd_weights_bwd": [vp, vp, vp, i64, i32, vp, vp],
     "nsamd_pdf_resample": [vp, vp, i32, vp, vp, vp, vp, f32, vp, f32, f32, f32, C.c_int, i64, i32, vp, vp, vp, vp],
+    "nsamd_proposal_resample": [vp, vp, vp, i32, vp, vp, vp, vp, f32, vp, f32, f32, f32, C.c_int, i64, i32, vp, vp, vp, vp, vp],
     "nsamd_composite_fwd": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), C.c_int, vp, vp, vp, vp, vp, vp, vp],
+    "nsamd_render_train": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "nsamd_render_train_bwd": [vp, vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, vp, vp, vp, vp],
     "nsamd_composite_bwd": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, vp, vp, vp, vp, vp, vp, vp],
     "nsamd_mse_loss": [vp, vp, i64, f32, vp, vp, vp],
     "nsamd_interlevel_loss": [vp, vp, i32, vp, vp, i32, i64, f32, vp, vp, vp],
     "nsamd_distortion_loss": [vp, vp, i32, i64, f32, vp, vp, vp],
+    "nsamd_proposal_losses": [vp, vp, i32, i32, vp, vp, vp, i64, f32, f32, vp, vp, vp, vp, vp],
     "nsamd_raygen_pinhole": [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp],
     "nsamd_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, vp],
     "nsamd_version": [],

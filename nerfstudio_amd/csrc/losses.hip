@@ -51,11 +51,10 @@ __device__ __forceinline__ int upper_bound_i(const int* a, int n, int v) {
 }
 
 // LDS per wave: R[Sf+1] (double), cp[Sp+1], cy[Sp+1], c[Sf+1], w[Sf], r[Sf], lo[Sf], hi[Sf]
-__global__ __launch_bounds__(kLossThreads) void interlevel_kernel(
-    const float* __restrict__ c_in, const float* __restrict__ w_in, int Sf, const float* __restrict__ cp_in,
+__device__ __forceinline__ void interlevel_body(
+    float* lds, const float* __restrict__ c_in, const float* __restrict__ w_in, int Sf, const float* __restrict__ cp_in,
     const float* __restrict__ wp_in, int Sp, int64_t num_rays, float grad_scale, float* __restrict__ per_ray,
     float* __restrict__ dwp) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kLossRays + wave;
   if (ray >= num_rays) return;
@@ -148,12 +147,10 @@ __global__ __launch_bounds__(kLossThreads) void interlevel_kernel(
 }
 
 // LDS per wave: mid[S], w[S]
-__global__ __launch_bounds__(kLossThreads) void distortion_kernel(const float* __restrict__ s_bins,
-                                                                  const float* __restrict__ weights, int S,
-                                                                  int64_t num_rays, float grad_scale,
-                                                                  float* __restrict__ per_ray,
-                                                                  float* __restrict__ dw) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void distortion_body(float* lds, const float* __restrict__ s_bins,
+                                                const float* __restrict__ weights, int S, int64_t num_rays,
+                                                float grad_scale, float* __restrict__ per_ray,
+                                                float* __restrict__ dw) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kLossRays + wave;
   if (ray >= num_rays) return;
@@ -178,9 +175,85 @@ __global__ __launch_bounds__(kLossThreads) void distortion_kernel(const float* _
   if (lane == 0) per_ray[ray] = loss;
 }
 
+__global__ __launch_bounds__(kLossThreads) void interlevel_kernel(
+    const float* __restrict__ c_in, const float* __restrict__ w_in, int Sf, const float* __restrict__ cp_in,
+    const float* __restrict__ wp_in, int Sp, int64_t num_rays, float grad_scale, float* __restrict__ per_ray,
+    float* __restrict__ dwp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  interlevel_body(lds, c_in, w_in, Sf, cp_in, wp_in, Sp, num_rays, grad_scale, per_ray, dwp);
+}
+
+__global__ __launch_bounds__(kLossThreads) void distortion_kernel(const float* __restrict__ s_bins,
+                                                                  const float* __restrict__ weights, int S,
+                                                                  int64_t num_rays, float grad_scale,
+                                                                  float* __restrict__ per_ray,
+                                                                  float* __restrict__ dw) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  distortion_body(lds, s_bins, weights, S, num_rays, grad_scale, per_ray, dw);
+}
+
+// All proposal losses of one training step in one launch: blockIdx.y < levels = interlevel loss of that proposal level,
+// blockIdx.y == levels = distortion loss of the fine samples (models/nerfacto.py:367-375).
+constexpr int kMaxPropLevels = 4;
+struct PropLossArgs {
+  const float* s_bins[kMaxPropLevels];
+  const float* weights[kMaxPropLevels];
+  float* per_ray[kMaxPropLevels];
+  float* dw[kMaxPropLevels];
+  int S[kMaxPropLevels];
+  int levels;
+};
+
+__global__ __launch_bounds__(kLossThreads) void proposal_losses_kernel(
+    const float* __restrict__ s_fine, const float* __restrict__ w_fine, int Sf, PropLossArgs a, int64_t num_rays,
+    float inter_scale, float dist_scale, float* __restrict__ dist_per_ray, float* __restrict__ dw_dist) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int job = blockIdx.y;
+  if (job < a.levels) {
+    interlevel_body(lds, s_fine, w_fine, Sf, a.s_bins[job], a.weights[job], a.S[job], num_rays, inter_scale,
+                    a.per_ray[job], a.dw[job]);
+  } else {
+    distortion_body(lds, s_fine, w_fine, Sf, num_rays, dist_scale, dist_per_ray, dw_dist);
+  }
+}
+
 }  // namespace nsamd
 
 using namespace nsamd;
+
+extern "C" int nsamd_proposal_losses(const float* s_bins_fine, const float* w_fine, int32_t S_fine, int32_t levels,
+                                     const float* const* s_bins_prop, const float* const* w_prop,
+                                     const int32_t* S_prop, int64_t num_rays, float interlevel_grad_scale,
+                                     float distortion_grad_scale, float* const* interlevel_per_ray,
+                                     float* const* dw_prop, float* distortion_per_ray, float* dw_distortion,
+                                     nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && S_fine > 0 && levels >= 0 && levels <= kMaxPropLevels);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(s_bins_fine && w_fine && distortion_per_ray);
+  NSAMD_REQUIRE(levels == 0 || (s_bins_prop && w_prop && S_prop && interlevel_per_ray));
+  if (S_fine > 2048) return NSAMD_ERR_UNSUPPORTED;
+  PropLossArgs a{};
+  a.levels = levels;
+  size_t lds = sizeof(float) * 2 * S_fine * kLossRays;
+  for (int i = 0; i < levels; ++i) {
+    NSAMD_REQUIRE(s_bins_prop[i] && w_prop[i] && interlevel_per_ray[i] && S_prop[i] > 0);
+    a.s_bins[i] = s_bins_prop[i];
+    a.weights[i] = w_prop[i];
+    a.per_ray[i] = interlevel_per_ray[i];
+    a.dw[i] = dw_prop ? dw_prop[i] : nullptr;
+    a.S[i] = S_prop[i];
+    const size_t per_wave =
+        sizeof(float) * ((2 * (S_fine + 2) + 2 * (S_prop[i] + 1) + (S_fine + 1) + 4 * S_fine + 1) & ~1);
+    if (per_wave * kLossRays > lds) lds = per_wave * kLossRays;
+  }
+  if (lds > 64 * 1024) return NSAMD_ERR_UNSUPPORTED;
+  dim3 g((unsigned)((num_rays + kLossRays - 1) / kLossRays), (unsigned)(levels + 1));
+  proposal_losses_kernel<<<g, kLossThreads, lds, (hipStream_t)stream>>>(
+      s_bins_fine, w_fine, S_fine, a, num_rays, interlevel_grad_scale, distortion_grad_scale, distortion_per_ray,
+      dw_distortion);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
 
 extern "C" int nsamd_interlevel_loss(const float* s_bins_fine, const float* w_fine, int32_t S_fine,
                                      const float* s_bins_prop, const float* w_prop, int32_t S_prop,

@@ -45,7 +45,12 @@ __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
     const float* __restrict__ rgb, const float* __restrict__ weights, const float* __restrict__ t_bins,
     int64_t num_rays, int S, int background, float bg_r, float bg_g, float bg_b, int eval_mode,
     float* __restrict__ rgb_out, float* __restrict__ acc_out, float* __restrict__ depth_exp,
-    float* __restrict__ depth_med, int32_t* __restrict__ med_idx, float* __restrict__ ws) {
+    float* __restrict__ depth_med, int32_t* __restrict__ med_idx, float* __restrict__ ws,
+    const float* __restrict__ density, float* __restrict__ weights_out, const float* __restrict__ target,
+    float grad_scale, float* __restrict__ sq_err, float* __restrict__ d_rgb_out) {
+  // density != nullptr (training step, nsamd_render_train): the weights are computed here from the densities
+  // (RaySamples.get_weights, as sampler.hip) and written to weights_out; target != nullptr adds the per-ray squared
+  // error and the MSE gradient of the composited colour.
   __shared__ float blk_min[kRaysPerBlock], blk_max[kRaysPerBlock];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wave;
@@ -57,12 +62,34 @@ __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
     }
     return;
   }
-  const float* w_in = weights + ray * S;
+  const float* w_in = density ? weights_out + ray * S : weights + ray * S;
   const float* tb = t_bins ? t_bins + ray * (S + 1) : nullptr;
   float sw = 0.f, sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f;
   float tmin = __uint_as_float(0x7f800000u), tmax = __uint_as_float(0xff800000u);
-  for (int s = lane; s < S; s += 64) {
-    const float w = w_in[s];
+  double w_carry = 0.0;  // running sum of density * delta (double, as torch's CPU cumsum)
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    float w = 0.0f;
+    if (density) {
+      const float dd = s < S ? (tb[s + 1] - tb[s]) * density[ray * S + s] : 0.0f;
+      double incl = (double)dd;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const double t = __shfl_up(incl, d);
+        if (lane >= d) incl = incl + t;
+      }
+      incl = incl + w_carry;
+      double excl = __shfl_up(incl, 1);
+      if (lane == 0) excl = w_carry;
+      w_carry = __shfl(incl, 63);
+      if (s < S) {
+        w = nan_to_num((1.0f - expf(-dd)) * expf(-(float)excl));
+        weights_out[ray * S + s] = w;
+      }
+    } else if (s < S) {
+      w = w_in[s];
+    }
+    if (s >= S) continue;
     sw += w;
     if (rgb) {
       const float* c = rgb + (ray * S + s) * 3;
@@ -110,6 +137,15 @@ __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
       rgb_out[ray * 3 + 0] = sr;
       rgb_out[ray * 3 + 1] = sg;
       rgb_out[ray * 3 + 2] = sb;
+      if (target) {  // MSELoss value (per ray) and gradient, losses.py:31
+        const float dr = sr - target[ray * 3 + 0], dg = sg - target[ray * 3 + 1], db = sb - target[ray * 3 + 2];
+        if (sq_err) sq_err[ray] = (dr * dr + dg * dg) + db * db;
+        if (d_rgb_out) {
+          d_rgb_out[ray * 3 + 0] = 2.0f * dr * grad_scale;
+          d_rgb_out[ray * 3 + 1] = 2.0f * dg * grad_scale;
+          d_rgb_out[ray * 3 + 2] = 2.0f * db * grad_scale;
+        }
+      }
     }
   }
   if (acc_out && lane == 0) acc_out[ray] = sw;
@@ -131,6 +167,7 @@ __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
       ws[3 + 2 * blockIdx.x] = hi;
     }
   }
+  if (density) __threadfence_block();  // the median pass re-reads the weights this wave has just written
   if (tb && (depth_med || med_idx)) {
     // searchsorted(cumsum(w), 0.5, side="left"), clamped  (renderers.py:359-362). torch.cumsum (CPU) accumulates in
     // double and rounds each output to fp32: wave scan in double (see sampler.hip on why that is the same number).
@@ -186,7 +223,10 @@ __global__ __launch_bounds__(kRenderThreads) void composite_bwd_kernel(
     int64_t num_rays, int S, int background, float bg_r, float bg_g, float bg_b,
     const float* __restrict__ d_rgb_out, const float* __restrict__ d_acc, const float* __restrict__ d_depth,
     const float* __restrict__ ws, const float* __restrict__ d_weights_add, float* __restrict__ d_rgb,
-    float* __restrict__ d_weights) {
+    float* __restrict__ d_weights, const float* __restrict__ density, float* __restrict__ d_density) {
+  // density != nullptr (nsamd_render_train_bwd): d_weights is not stored; the gradient goes on through
+  // RaySamples.get_weights to d_density (same formulas as weights_bwd_kernel in sampler.hip).
+  extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wave;
   if (ray >= num_rays) return;
@@ -229,13 +269,66 @@ __global__ __launch_bounds__(kRenderThreads) void composite_bwd_kernel(
     float dw = gr * c[0] + gg * c[1] + gb * c[2] - bg_dot + ga + g_den;
     if (tb) dw += g_num * ((tb[s] + tb[s + 1]) / 2.0f);
     if (d_weights_add) dw += d_weights_add[ray * S + s];  // e.g. the distortion-loss gradient on the same weights
-    d_weights[ray * S + s] = dw;
+    if (density) lds[(size_t)wave * 3 * S + s] = dw;
+    else d_weights[ray * S + s] = dw;
     float* o = d_rgb + (ray * S + s) * 3;
     float e = w;
     if (background == 1 && s == S - 1) e += rem;
     o[0] = gr * e;
     o[1] = gg * e;
     o[2] = gb * e;
+  }
+  if (density) {
+    // d weights / d density: dd_j gets  gw_j T_j exp(-dd_j) - sum_{i>j} gw_i w_i, through delta_j
+    const float* tbw = t_bins + ray * (S + 1);
+    float* dwr = lds + (size_t)wave * 3 * S;
+    float* ex_row = dwr + S;
+    float* tr_row = ex_row + S;
+    double carry = 0.0;
+    for (int i0 = 0; i0 < S; i0 += 64) {
+      const int i = i0 + lane;
+      const float dd = i < S ? (tbw[i + 1] - tbw[i]) * density[ray * S + i] : 0.0f;
+      double incl = (double)dd;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const double t = __shfl_up(incl, d);
+        if (lane >= d) incl = incl + t;
+      }
+      incl = incl + carry;
+      double excl = __shfl_up(incl, 1);
+      if (lane == 0) excl = carry;
+      carry = __shfl(incl, 63);
+      if (i < S) {
+        ex_row[i] = expf(-dd);
+        tr_row[i] = expf(-(float)excl);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    carry = 0.0;
+    for (int r0 = 0; r0 < S; r0 += 64) {  // reversed order: exclusive suffix sums of gw * w
+      const int r = r0 + lane;
+      const int i = S - 1 - r;
+      float ex = 0.f, trans = 0.f, g = 0.f;
+      if (r < S) {
+        ex = ex_row[i];
+        trans = tr_row[i];
+        const float w = (1.0f - ex) * trans;
+        const bool finite = (w == w) && (fabsf(w) <= 3.4028234663852886e38f);
+        g = finite ? dwr[i] : 0.0f;  // nan_to_num backward masks non-finite products
+      }
+      double incl = (double)(r < S ? g * ((1.0f - ex) * trans) : 0.0f);
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const double t = __shfl_up(incl, d);
+        if (lane >= d) incl = incl + t;
+      }
+      incl = incl + carry;
+      double excl = __shfl_up(incl, 1);
+      if (lane == 0) excl = carry;
+      carry = __shfl(incl, 63);
+      if (r < S) d_density[ray * S + i] = (tbw[i + 1] - tbw[i]) * (g * trans * ex - (float)excl);
+    }
   }
 }
 
@@ -292,7 +385,7 @@ extern "C" int nsamd_composite_fwd(const float* rgb, const float* weights, const
               bb = bg_rgb_host ? bg_rgb_host[2] : 0.f;
   composite_fwd_kernel<<<blocks, kRenderThreads, 0, st>>>(
       rgb, weights, need_t ? t_bins : nullptr, num_rays, S, background, br, bg, bb, eval_mode, rgb_out, acc,
-      depth_expected, depth_median, median_idx, ws);
+      depth_expected, depth_median, median_idx, ws, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr);
   NSAMD_CHECK_LAUNCH();
   if (depth_expected) {
     depth_clip_kernel<<<(unsigned)((num_rays + 255) / 256), 256, 0, st>>>(depth_expected, num_rays, ws, (int)blocks);
@@ -317,7 +410,55 @@ extern "C" int nsamd_composite_bwd(const float* rgb, const float* weights, const
               bb = bg_rgb_host ? bg_rgb_host[2] : 0.f;
   composite_bwd_kernel<<<blocks, kRenderThreads, 0, (hipStream_t)stream>>>(
       rgb, weights, t_bins, num_rays, S, background, br, bg, bb, d_rgb_out, d_acc, d_depth, workspace, d_weights_add, d_rgb,
-      d_weights);
+      d_weights, nullptr, nullptr);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_render_train(const float* rgb, const float* density, const float* t_bins, int64_t num_rays,
+                                  int32_t S, int background, const float* bg_rgb_host, const float* target,
+                                  float grad_scale, float* weights, float* rgb_out, float* acc, float* depth_expected,
+                                  float* depth_median, float* workspace, float* sq_err, float* d_rgb_out,
+                                  nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && S > 0);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(rgb && density && t_bins && weights && rgb_out);
+  NSAMD_REQUIRE(background >= 0 && background <= 2);
+  NSAMD_REQUIRE(background != 2 || bg_rgb_host != nullptr);
+  NSAMD_REQUIRE(depth_expected == nullptr || workspace != nullptr);
+  if (S > 4096) return NSAMD_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)((num_rays + kRaysPerBlock - 1) / kRaysPerBlock);
+  const float br = bg_rgb_host ? bg_rgb_host[0] : 0.f, bg = bg_rgb_host ? bg_rgb_host[1] : 0.f,
+              bb = bg_rgb_host ? bg_rgb_host[2] : 0.f;
+  composite_fwd_kernel<<<blocks, kRenderThreads, 0, st>>>(rgb, nullptr, t_bins, num_rays, S, background, br, bg, bb, 0,
+                                                          rgb_out, acc, depth_expected, depth_median, nullptr, workspace,
+                                                          density, weights, target, grad_scale, sq_err, d_rgb_out);
+  NSAMD_CHECK_LAUNCH();
+  if (depth_expected) {
+    depth_clip_kernel<<<(unsigned)((num_rays + 255) / 256), 256, 0, st>>>(depth_expected, num_rays, workspace,
+                                                                          (int)blocks);
+    NSAMD_CHECK_LAUNCH();
+  }
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_render_train_bwd(const float* rgb, const float* weights, const float* density,
+                                      const float* t_bins, int64_t num_rays, int32_t S, int background,
+                                      const float* bg_rgb_host, const float* d_rgb_out, const float* d_weights_add,
+                                      float* d_rgb, float* d_density, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && S > 0);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(rgb && weights && density && t_bins && d_rgb_out && d_rgb && d_density);
+  NSAMD_REQUIRE(background >= 0 && background <= 2);
+  NSAMD_REQUIRE(background != 2 || bg_rgb_host != nullptr);
+  if (S > 1024) return NSAMD_ERR_UNSUPPORTED;
+  const unsigned blocks = (unsigned)((num_rays + kRaysPerBlock - 1) / kRaysPerBlock);
+  const float br = bg_rgb_host ? bg_rgb_host[0] : 0.f, bg = bg_rgb_host ? bg_rgb_host[1] : 0.f,
+              bb = bg_rgb_host ? bg_rgb_host[2] : 0.f;
+  composite_bwd_kernel<<<blocks, kRenderThreads, sizeof(float) * 3 * kRaysPerBlock * (size_t)S, (hipStream_t)stream>>>(
+      rgb, weights, t_bins, num_rays, S, background, br, bg, bb, d_rgb_out, nullptr, nullptr, nullptr, d_weights_add,
+      d_rgb, nullptr, density, d_density);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

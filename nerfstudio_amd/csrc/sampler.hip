@@ -151,12 +151,18 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
 // PDFSampler.generate_ray_samples, include_original=False (ray_samplers.py:276-372)
 // ---------------------------------------------------------------------------------------------------------------
 // LDS: per wave  w[S_prev], cdf[S_prev + 1].
+// kFused: the launch also does the level's RaySamples.get_weights (weights_out) and, optionally, its median depth
+// (DepthRenderer "median", renderers.py:354-364; models/nerfacto.py:346-347 renders one per proposal level) — the three
+// launches per proposal level of the training step in one, the weight row never leaves the wave.
+template <bool kFused>
 __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     const float* __restrict__ s_bins_prev, const float* __restrict__ weights, int S_prev,
     const float* __restrict__ u_base, const float* __restrict__ jitter, const float* __restrict__ nears,
     const float* __restrict__ fars, float anneal_host, const float* __restrict__ anneal_dev, float hist_pad, float eps,
     float u_offset, int spacing, int64_t num_rays, int S,
-    float* __restrict__ s_bins, float* __restrict__ t_bins, int32_t* __restrict__ inds) {
+    float* __restrict__ s_bins, float* __restrict__ t_bins, int32_t* __restrict__ inds,
+    const float* __restrict__ t_bins_prev, const float* __restrict__ density, float* __restrict__ weights_out,
+    float* __restrict__ depth_median) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -166,13 +172,47 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
   float* cdf = w + S_prev;
   const float anneal = anneal_dev ? anneal_dev[0] : anneal_host;  // device copy: graph-replayable schedules
 
+  if (kFused) {
+    // (0) weights of the previous level  (cameras/rays.py:129-152), kept in the LDS row
+    const float* tb = t_bins_prev + ray * (S_prev + 1);
+    const float* dn = density + ray * S_prev;
+    double carry0 = 0.0;
+    for (int i0 = 0; i0 < S_prev; i0 += 64) {
+      const int i = i0 + lane;
+      const float dd = i < S_prev ? (tb[i + 1] - tb[i]) * dn[i] : 0.0f;
+      const double incl = carry0 + wave_scan_inclusive((double)dd, lane);
+      double excl = __shfl_up(incl, 1);
+      if (lane == 0) excl = carry0;
+      carry0 = wave_broadcast(incl, 63);
+      if (i < S_prev) {
+        const float alpha = 1.0f - expf(-dd);
+        const float trans = expf(-(float)excl);
+        const float wv = nan_to_num(alpha * trans);
+        weights_out[ray * S_prev + i] = wv;
+        w[i] = wv;
+      }
+    }
+    if (depth_median != nullptr) {  // searchsorted(cumsum(w), 0.5, side="left"), clamped
+      double carry1 = 0.0;
+      int idx = S_prev;
+      for (int i0 = 0; i0 < S_prev && idx == S_prev; i0 += 64) {
+        const int i = i0 + lane;
+        const double incl = carry1 + wave_scan_inclusive(i < S_prev ? (double)w[i] : 0.0, lane);
+        carry1 = wave_broadcast(incl, 63);
+        const unsigned long long hit = __ballot(i < S_prev && (float)incl >= 0.5f);
+        if (hit != 0ull) idx = i0 + __builtin_ctzll(hit);
+      }
+      idx = min(idx, S_prev - 1);
+      if (lane == 0) depth_median[ray] = (tb[idx] + tb[idx + 1]) / 2.0f;
+    }
+  }
   // (1) weights (annealed) + histogram padding, and their sum                 ray_samplers.py:601, :303-309
   double total = 0.0;
   for (int i0 = 0; i0 < S_prev; i0 += 64) {
     const int i = i0 + lane;
     float v = 0.0f;
     if (i < S_prev) {
-      v = weights[ray * S_prev + i];
+      v = kFused ? w[i] : weights[ray * S_prev + i];
       if (anneal != 1.0f) v = powf(v, anneal);
       v = v + hist_pad;
       w[i] = v;
@@ -278,10 +318,27 @@ extern "C" int nsamd_pdf_resample(const float* s_bins_prev, const float* weights
   NSAMD_REQUIRE(s_bins_prev && weights && u_base && nears && fars && s_bins && t_bins);
   if (S_prev > 1024) return NSAMD_ERR_UNSUPPORTED;
   const size_t lds = sizeof(float) * kWaves * (2 * (size_t)S_prev + 1);
-  pdf_resample_kernel<<<ray_blocks(num_rays), kThreads, lds, (hipStream_t)stream>>>(
+  pdf_resample_kernel<false><<<ray_blocks(num_rays), kThreads, lds, (hipStream_t)stream>>>(
       s_bins_prev, weights, S_prev, u_base, jitter, nears, fars, anneal, anneal_dev, histogram_padding, eps, u_offset,
-      spacing, num_rays, S,
-      s_bins, t_bins, inds);
+      spacing, num_rays, S, s_bins, t_bins, inds, nullptr, nullptr, nullptr, nullptr);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_proposal_resample(const float* t_bins_prev, const float* s_bins_prev, const float* density,
+                                       int32_t S_prev, const float* u_base, const float* jitter, const float* nears,
+                                       const float* fars, float anneal, const float* anneal_dev,
+                                       float histogram_padding, float eps, float u_offset, int spacing,
+                                       int64_t num_rays, int32_t S, float* weights, float* depth_median, float* s_bins,
+                                       float* t_bins, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && S > 0 && S_prev > 0 && (spacing == 0 || spacing == 1));
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(t_bins_prev && s_bins_prev && density && u_base && nears && fars && weights && s_bins && t_bins);
+  if (S_prev > 1024) return NSAMD_ERR_UNSUPPORTED;
+  const size_t lds = sizeof(float) * kWaves * (2 * (size_t)S_prev + 1);
+  pdf_resample_kernel<true><<<ray_blocks(num_rays), kThreads, lds, (hipStream_t)stream>>>(
+      s_bins_prev, nullptr, S_prev, u_base, jitter, nears, fars, anneal, anneal_dev, histogram_padding, eps, u_offset,
+      spacing, num_rays, S, s_bins, t_bins, nullptr, t_bins_prev, density, weights, depth_median);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

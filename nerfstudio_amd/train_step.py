@@ -73,13 +73,24 @@ class NerfactoTrainStep:
         self.minmax_ws = e(2 + 2 * ((n + 3) // 4))
         self.depth_med = [e(n) for _ in self.counts]
         # ---- losses / gradients ----
-        self.loss_sums = torch.zeros((1,), **f32)  # sum of squared rgb errors
+        self.sq_err = e(n)  # per-ray sum of squared rgb errors
         self.dist_per_ray = e(n)
         self.inter_per_ray = [e(n) for _ in range(self.n_prop)]
         self.d_rgb_out = e(n, 3)
         self.dw_dist = e(n, self.counts[-1])
         self.dw_prop = [e(n, self.counts[lvl]) for lvl in range(self.n_prop)]
-        self.d_w_main, self.d_rgb_s, self.d_dens_main = e(n, self.counts[-1]), e(mm, 3), e(mm)
+        self.d_rgb_s, self.d_dens_main = e(mm, 3), e(mm)
+        # host arrays of device pointers for nsamd_proposal_losses (the buffers are static, so built once)
+        import ctypes as C
+
+        def parr(ts):
+            return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+        self._pl_s_bins = parr(self.s_bins[: self.n_prop])
+        self._pl_weights = parr(self.weights[: self.n_prop])
+        self._pl_per_ray = parr(self.inter_per_ray)
+        self._pl_dw = parr(self.dw_prop)
+        self._pl_S = (C.c_int32 * self.n_prop)(*self.counts[: self.n_prop])
         self.f_denc = torch.empty_like(self.f_enc)
         self.p_ddens = [torch.empty_like(t) for t in self.p_dens]
         self.p_denc = [torch.empty_like(t) for t in self.p_enc]
@@ -159,13 +170,15 @@ class NerfactoTrainStep:
                                              N.ptr(self.p_sel[lvl]), st), "hashgrid_encode_fwd")
             ck(lib.nsamd_density_mlp_fwd(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), m, dm, N.ptr(self.p_dens[lvl]),
                                          N.ptr(self.p_pre[lvl]), st), "density_mlp_fwd")
-            ck(lib.nsamd_weights_fwd(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), n, S, N.ptr(self.weights[lvl]), st),
-               "weights_fwd")
             S2 = self.counts[lvl + 1]
-            ck(lib.nsamd_pdf_resample(N.ptr(self.s_bins[lvl]), N.ptr(self.weights[lvl]), S, N.ptr(self.u_base[lvl + 1]),
-                                      N.ptr(self.jitter[lvl + 1]), N.ptr(self.nears), N.ptr(self.fars), 1.0,
-                                      N.ptr(self.anneal_dev), 0.01, 1e-5, 1.0 / (2 * (S2 + 1)), self.spacing, n, S2,
-                                      N.ptr(self.s_bins[lvl + 1]), N.ptr(self.t_bins[lvl + 1]), None, st), "pdf_resample")
+            # weights of this level, its median depth (prop_depth_i, models/nerfacto.py:346-347) and the PDF resampling
+            ck(lib.nsamd_proposal_resample(N.ptr(self.t_bins[lvl]), N.ptr(self.s_bins[lvl]), N.ptr(self.p_dens[lvl]), S,
+                                           N.ptr(self.u_base[lvl + 1]), N.ptr(self.jitter[lvl + 1]), N.ptr(self.nears),
+                                           N.ptr(self.fars), 1.0, N.ptr(self.anneal_dev), 0.01, 1e-5,
+                                           1.0 / (2 * (S2 + 1)), self.spacing, n, S2, N.ptr(self.weights[lvl]),
+                                           N.ptr(self.depth_med[lvl]) if self.compute_depths else None,
+                                           N.ptr(self.s_bins[lvl + 1]), N.ptr(self.t_bins[lvl + 1]), st),
+               "proposal_resample")
         # ---- main field ----
         fld = self.model.field
         L = self.n_prop
@@ -181,28 +194,18 @@ class NerfactoTrainStep:
            "hashgrid_encode_fwd")
         ck(lib.nsamd_field_mlp_fwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
                                    N.ptr(self.f_dens), N.ptr(self.f_rgb), st), "field_mlp_fwd")
-        ck(lib.nsamd_weights_fwd(N.ptr(self.t_bins[L]), N.ptr(self.f_dens), n, S, N.ptr(self.weights[L]), st), "weights_fwd")
-        ck(lib.nsamd_composite_fwd(N.ptr(self.f_rgb), N.ptr(self.weights[L]), N.ptr(self.t_bins[L]), n, S, self.bg_mode,
-                                   self.bg_vals, 0, N.ptr(self.rgb), N.ptr(self.acc), N.ptr(self.depth_exp),
-                                   N.ptr(self.depth_med[L]) if self.compute_depths else None, None,
-                                   N.ptr(self.minmax_ws), st), "composite_fwd")
-        if self.compute_depths:  # prop_depth_i outputs of get_outputs (models/nerfacto.py:346-347)
-            for lvl in range(self.n_prop):
-                ck(lib.nsamd_composite_fwd(None, N.ptr(self.weights[lvl]), N.ptr(self.t_bins[lvl]), n, self.counts[lvl],
-                                           N.BG_NONE, None, 0, None, None, None, N.ptr(self.depth_med[lvl]), None, None, st),
-                   "composite_fwd(median)")
-        # ---- losses: value + gradient in one pass each (models/nerfacto.py:363-375) ----
-        self.loss_sums.zero_()
-        ck(lib.nsamd_mse_loss(N.ptr(self.rgb), N.ptr(self.target), 3 * n, 1.0 / (3 * n), N.ptr(self.loss_sums),
-                              N.ptr(self.d_rgb_out), st), "mse_loss")
-        ck(lib.nsamd_distortion_loss(N.ptr(self.s_bins[L]), N.ptr(self.weights[L]), S, n,
-                                     float(cfg.distortion_loss_mult) / n, N.ptr(self.dist_per_ray), N.ptr(self.dw_dist), st),
-           "distortion_loss")
-        for lvl in range(self.n_prop):
-            ck(lib.nsamd_interlevel_loss(N.ptr(self.s_bins[L]), N.ptr(self.weights[L]), S, N.ptr(self.s_bins[lvl]),
-                                         N.ptr(self.weights[lvl]), self.counts[lvl], n,
-                                         float(cfg.interlevel_loss_mult) / (n * S), N.ptr(self.inter_per_ray[lvl]),
-                                         N.ptr(self.dw_prop[lvl]) if updated else None, st), "interlevel_loss")
+        # weights + compositing + MSE value/gradient in one launch (+ the global depth clip)
+        ck(lib.nsamd_render_train(N.ptr(self.f_rgb), N.ptr(self.f_dens), N.ptr(self.t_bins[L]), n, S, self.bg_mode,
+                                  self.bg_vals, N.ptr(self.target), 1.0 / (3 * n), N.ptr(self.weights[L]), N.ptr(self.rgb),
+                                  N.ptr(self.acc), N.ptr(self.depth_exp),
+                                  N.ptr(self.depth_med[L]) if self.compute_depths else None, N.ptr(self.minmax_ws),
+                                  N.ptr(self.sq_err), N.ptr(self.d_rgb_out), st), "render_train")
+        # ---- proposal losses: value + gradient, all levels in one launch (models/nerfacto.py:363-375) ----
+        ck(lib.nsamd_proposal_losses(N.ptr(self.s_bins[L]), N.ptr(self.weights[L]), S, self.n_prop, self._pl_s_bins,
+                                     self._pl_weights, self._pl_S, n, float(cfg.interlevel_loss_mult) / (n * S),
+                                     float(cfg.distortion_loss_mult) / n, self._pl_per_ray,
+                                     self._pl_dw if updated else None, N.ptr(self.dist_per_ray), N.ptr(self.dw_dist), st),
+           "proposal_losses")
 
     def backward_main(self) -> None:
         """composite -> weights -> field MLPs -> main hash table (MSE + distortion gradients)."""
@@ -217,11 +220,9 @@ class NerfactoTrainStep:
         fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), emb.shape[0] if emb is not None else 0,
                         float(fld.average_init_density))
         cams = N.ptr(self.camera_indices) if emb is not None else None
-        ck(lib.nsamd_composite_bwd(N.ptr(self.f_rgb), N.ptr(self.weights[L]), None, n, S, self.bg_mode, self.bg_vals,
-                                   N.ptr(self.d_rgb_out), None, None, None, N.ptr(self.dw_dist), N.ptr(self.d_rgb_s),
-                                   N.ptr(self.d_w_main), st), "composite_bwd")
-        ck(lib.nsamd_weights_bwd(N.ptr(self.t_bins[L]), N.ptr(self.f_dens), N.ptr(self.d_w_main), n, S,
-                                 N.ptr(self.d_dens_main), st), "weights_bwd")
+        ck(lib.nsamd_render_train_bwd(N.ptr(self.f_rgb), N.ptr(self.weights[L]), N.ptr(self.f_dens), N.ptr(self.t_bins[L]),
+                                      n, S, self.bg_mode, self.bg_vals, N.ptr(self.d_rgb_out), N.ptr(self.dw_dist),
+                                      N.ptr(self.d_rgb_s), N.ptr(self.d_dens_main), st), "render_train_bwd")
         grads = N.FieldMlpGrads(*(N.ptr(self._grad(p)) for p in params), N.ptr(self._grad(emb)) if emb is not None else None)
         ck(lib.nsamd_field_mlp_bwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
                                    N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s), N.ptr(self.f_denc), grads, N.ptr(self.field_ws),
@@ -261,7 +262,7 @@ class NerfactoTrainStep:
     def loss_dict(self) -> Dict[str, Tensor]:
         """Loss values of the last iteration (models/nerfacto.py:363-375); a few tiny torch reductions, call on demand."""
         n, S = self.n, self.counts[-1]
-        out = {"rgb_loss": self.loss_sums[0] / (3 * n),
+        out = {"rgb_loss": self.sq_err.sum() / (3 * n),
                "distortion_loss": self.cfg.distortion_loss_mult * self.dist_per_ray.sum() / n}
         inter = sum(p.sum() for p in self.inter_per_ray) / (n * S)
         out["interlevel_loss"] = self.cfg.interlevel_loss_mult * inter

@@ -720,3 +720,85 @@ def test_uniform_initial_sampler(F):
     s1o, t1o, _ = orc.pdf_resample(so, w[..., 0], 32, jit[1], nears, fars, uniform=True)
     exact(rs1.pack.s_bins, s1o)
     exact(rs1.pack.t_bins, t1o)
+
+
+def test_fused_training_entry_points_equal_the_separate_ones(F):
+    """nsamd_proposal_resample / nsamd_render_train(_bwd) / nsamd_proposal_losses are launch fusions: same kernels'
+    arithmetic, so the outputs must be bit-identical to the separate entry points on the same inputs."""
+    import ctypes as C
+
+    from nerfstudio_amd import _native as N
+
+    lib = N.load()
+    torch.manual_seed(3)
+    n, S0, S1 = 1027, 96, 48  # ragged ray count: tail workgroup
+    st = N.stream()
+    e = lambda *s: torch.empty(*s, device="cuda")
+    nears, fars = torch.full((n,), 0.05, device="cuda"), torch.full((n,), 1000.0, device="cuda")
+    s0, t0 = F.piecewise_bins(nears, fars, S0, torch.rand(n, device="cuda"))
+    dens0 = torch.rand(n, S0, device="cuda") * 3
+    dens0[5] = 0.0  # an all-zero ray
+    jit = torch.rand(n, device="cuda")
+    u = F._linspace("u", S1, torch.device("cuda"))
+    anneal = torch.tensor([0.7], device="cuda")
+    # separate
+    w_a = e(n, S0); s_a, t_a, med_a = e(n, S1 + 1), e(n, S1 + 1), e(n)
+    N.check(lib.nsamd_weights_fwd(N.ptr(t0), N.ptr(dens0), n, S0, N.ptr(w_a), st), "w")
+    N.check(lib.nsamd_composite_fwd(None, N.ptr(w_a), N.ptr(t0), n, S0, N.BG_NONE, None, 0, None, None, None, N.ptr(med_a),
+                                    None, None, st), "med")
+    N.check(lib.nsamd_pdf_resample(N.ptr(s0), N.ptr(w_a), S0, N.ptr(u), N.ptr(jit), N.ptr(nears), N.ptr(fars), 1.0,
+                                   N.ptr(anneal), 0.01, 1e-5, 1.0 / (2 * (S1 + 1)), 0, n, S1, N.ptr(s_a), N.ptr(t_a), None, st),
+            "pdf")
+    # fused
+    w_b = e(n, S0); s_b, t_b, med_b = e(n, S1 + 1), e(n, S1 + 1), e(n)
+    N.check(lib.nsamd_proposal_resample(N.ptr(t0), N.ptr(s0), N.ptr(dens0), S0, N.ptr(u), N.ptr(jit), N.ptr(nears),
+                                        N.ptr(fars), 1.0, N.ptr(anneal), 0.01, 1e-5, 1.0 / (2 * (S1 + 1)), 0, n, S1,
+                                        N.ptr(w_b), N.ptr(med_b), N.ptr(s_b), N.ptr(t_b), st), "fused")
+    for a, b, name in ((w_a, w_b, "weights"), (med_a, med_b, "median"), (s_a, s_b, "s_bins"), (t_a, t_b, "t_bins")):
+        assert torch.equal(a, b), name
+
+    # ---- main render: weights + composite + mse, and its backward ----
+    rgb = torch.rand(n, S1, 3, device="cuda"); dens1 = torch.rand(n, S1, device="cuda") * 5
+    target = torch.rand(n, 3, device="cuda")
+    bgv = (C.c_float * 3)(0.1, 0.2, 0.3)
+    for bg in (N.BG_NONE, 1, 2):
+        w_a = e(n, S1); rgb_a, acc_a, dexp_a, dmed_a = e(n, 3), e(n), e(n), e(n)
+        ws_a = e(2 + 2 * ((n + 3) // 4)); loss_a = torch.zeros(1, device="cuda"); dro_a = e(n, 3)
+        N.check(lib.nsamd_weights_fwd(N.ptr(t_a), N.ptr(dens1), n, S1, N.ptr(w_a), st), "w")
+        N.check(lib.nsamd_composite_fwd(N.ptr(rgb), N.ptr(w_a), N.ptr(t_a), n, S1, bg, bgv, 0, N.ptr(rgb_a), N.ptr(acc_a),
+                                        N.ptr(dexp_a), N.ptr(dmed_a), None, N.ptr(ws_a), st), "c")
+        N.check(lib.nsamd_mse_loss(N.ptr(rgb_a), N.ptr(target), 3 * n, 1.0 / (3 * n), N.ptr(loss_a), N.ptr(dro_a), st), "m")
+        w_b = e(n, S1); rgb_b, acc_b, dexp_b, dmed_b = e(n, 3), e(n), e(n), e(n)
+        ws_b = e(2 + 2 * ((n + 3) // 4)); sq_b = e(n); dro_b = e(n, 3)
+        N.check(lib.nsamd_render_train(N.ptr(rgb), N.ptr(dens1), N.ptr(t_a), n, S1, bg, bgv, N.ptr(target), 1.0 / (3 * n),
+                                       N.ptr(w_b), N.ptr(rgb_b), N.ptr(acc_b), N.ptr(dexp_b), N.ptr(dmed_b), N.ptr(ws_b),
+                                       N.ptr(sq_b), N.ptr(dro_b), st), "rt")
+        for a, b, name in ((w_a, w_b, "w"), (rgb_a, rgb_b, "rgb"), (acc_a, acc_b, "acc"), (dexp_a, dexp_b, "dexp"),
+                           (dmed_a, dmed_b, "dmed"), (dro_a, dro_b, "d_rgb_out")):
+            assert torch.equal(a, b), (bg, name)
+        close(sq_b.sum(), loss_a[0], rtol=1e-5)
+        dw_add = torch.randn(n, S1, device="cuda") * 1e-3
+        drgb_a, dw_a, dd_a = e(n, S1, 3), e(n, S1), e(n, S1)
+        N.check(lib.nsamd_composite_bwd(N.ptr(rgb), N.ptr(w_a), None, n, S1, bg, bgv, N.ptr(dro_a), None, None, None,
+                                        N.ptr(dw_add), N.ptr(drgb_a), N.ptr(dw_a), st), "cb")
+        N.check(lib.nsamd_weights_bwd(N.ptr(t_a), N.ptr(dens1), N.ptr(dw_a), n, S1, N.ptr(dd_a), st), "wb")
+        drgb_b, dd_b = e(n, S1, 3), e(n, S1)
+        N.check(lib.nsamd_render_train_bwd(N.ptr(rgb), N.ptr(w_a), N.ptr(dens1), N.ptr(t_a), n, S1, bg, bgv, N.ptr(dro_a),
+                                           N.ptr(dw_add), N.ptr(drgb_b), N.ptr(dd_b), st), "rtb")
+        assert torch.equal(drgb_a, drgb_b) and torch.equal(dd_a, dd_b), bg
+
+    # ---- proposal losses ----
+    wp = [torch.rand(n, S0, device="cuda") / S0, torch.rand(n, 64, device="cuda") / 64]
+    sp = [s0, torch.sort(torch.rand(n, 65, device="cuda"), dim=-1).values]
+    wf = torch.rand(n, S1, device="cuda") / S1
+    per_a = [e(n), e(n)]; dwp_a = [e(n, S0), e(n, 64)]; dist_a, dwd_a = e(n), e(n, S1)
+    for i in range(2):
+        N.check(lib.nsamd_interlevel_loss(N.ptr(s_a), N.ptr(wf), S1, N.ptr(sp[i]), N.ptr(wp[i]), wp[i].shape[1], n, 0.37,
+                                          N.ptr(per_a[i]), N.ptr(dwp_a[i]), st), "il")
+    N.check(lib.nsamd_distortion_loss(N.ptr(s_a), N.ptr(wf), S1, n, 0.011, N.ptr(dist_a), N.ptr(dwd_a), st), "dl")
+    per_b = [e(n), e(n)]; dwp_b = [e(n, S0), e(n, 64)]; dist_b, dwd_b = e(n), e(n, S1)
+    parr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    N.check(lib.nsamd_proposal_losses(N.ptr(s_a), N.ptr(wf), S1, 2, parr(sp), parr(wp), (C.c_int32 * 2)(S0, 64), n, 0.37,
+                                      0.011, parr(per_b), parr(dwp_b), N.ptr(dist_b), N.ptr(dwd_b), st), "pl")
+    for a, b in zip(per_a + dwp_a + [dist_a, dwd_a], per_b + dwp_b + [dist_b, dwd_b]):
+        assert torch.equal(a, b)
