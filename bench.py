@@ -69,8 +69,14 @@ class Trainer:
     kernel launches become one graph launch, which is what a 1-2 ms step needs (MI355X_MICROARCH.md price list:
     eager goes host-bound below ~3 us per kernel). Everything that changes from step to step lives in device memory:
     the ray batch, the jitter draws (graph-safe Philox), the anneal exponent and Adam's bias-corrected step size
-    (`hyper`, refreshed by an 12-byte async copy before each replay). With N > 1 the RCCL all-reduce of the gradient
-    arena runs eagerly between two captured halves (forward+backward | optimiser)."""
+    (`hyper`, refreshed by a 20-byte async copy from a ring of pinned host slots before each replay).
+
+    N > 1 (data parallel): the iteration is captured in segments and the 67 MB main-field all-reduce (RCCL, its own
+    stream) is PIPELINED across steps. The proposal forward of step k+1 reads only proposal-network parameters, so
+        step k:   [proposal fwd k] -> (wait AR_main k-1) [Adam main k-1] -> [main fwd + losses + main bwd k]
+                  -> AR_main k (async) -> [proposal bwd k] -> AR_props k -> [Adam props k]      (last two: update steps)
+    hides the all-reduce behind the proposal backward of step k AND the proposal forward of step k+1, with exactly the
+    sequential semantics (every parameter is updated before its next use). `finish()` drains the pending update."""
 
     def __init__(self, model, arena, ray_bundle, batch, world=1, use_graph=True, use_runner=True):
         self.model, self.arena, self.rb, self.batch, self.world = model, arena, ray_bundle, batch, world
@@ -80,7 +86,13 @@ class Trainer:
         dev = ray_bundle.origins.device
         # device-resident step-dependent scalars: Adam (step size, 1/sqrt(bc2)) per optimiser group + the anneal exponent
         self.hyper = torch.zeros(5, device=dev)
-        self.hyper_host = torch.zeros(5).pin_memory()
+        # The host runs ahead of the GPU, so the pinned source of an async copy must not be rewritten before the copy
+        # has executed: a ring of slots, each guarded by the event recorded after its last copy.
+        self.hyper_ring = [torch.zeros(5).pin_memory() for _ in range(64)]
+        self.hyper_events = [None] * 64
+        self.hyper_slot = 0
+        self._pending_main = None  # (handle,) of the in-flight main-field all-reduce (N > 1)
+        self._have_pending = False
         self.hyper_views = {"fields": self.hyper[0:2], "proposal_networks": self.hyper[2:4]}
         self.loss_buf = torch.zeros((), device=dev)
         model.proposal_sampler.anneal_dev = self.hyper[4:5]
@@ -102,25 +114,36 @@ class Trainer:
 
         m, a = self.model, self.arena
         m.set_step(self.step)  # BEFORE_TRAIN_ITERATION callback: proposal weight anneal
-        h = self.hyper_host
+        self._push_hyper()
+
+    def _push_hyper(self):
+        """Adam step sizes of the NEXT update of each group + the anneal exponent -> device (async, race-free)."""
+        from nerfstudio_amd import functional as F
+
+        m, a = self.model, self.arena
+        slot = self.hyper_slot
+        self.hyper_slot = (slot + 1) % len(self.hyper_ring)
+        if self.hyper_events[slot] is not None:
+            self.hyper_events[slot].synchronize()  # the copy that last read this slot (64 pushes ago) is done
+        h = self.hyper_ring[slot]
         h[0], h[1] = F.adam_hyper(a.step_counts["fields"] + 1, a.lr, a.betas)
         h[2], h[3] = F.adam_hyper(a.step_counts["proposal_networks"] + 1, a.lr, a.betas)
         h[4] = m.proposal_sampler._anneal
         self.hyper.copy_(h, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.hyper_events[slot] = ev
 
     def _fwd_bwd(self, updated):
+        """Single-process path: forward, losses and the main backward (runner: also the proposal backward)."""
         from nerfstudio_amd.cameras.rays import RayBundle
 
+        self.arena.zero_grad()
         if self.runner is not None:
-            self.arena.zero_grad()
-            if self.world == 1:  # whole iteration; the two backward chains run as parallel branches
-                self.runner.forward_backward(updated)
-            else:  # N > 1: the proposal backward is a separate phase that overlaps the all-reduce
-                self.runner.forward_backward_main(updated)
+            self.runner.forward_backward(updated)  # the two backward chains run as parallel branches
             return
         m = self.model
         m.proposal_sampler.force_updated = updated
-        self.arena.zero_grad()
         rb = RayBundle(origins=self.rb.origins, directions=self.rb.directions, pixel_area=self.rb.pixel_area,
                        camera_indices=self.rb.camera_indices)
         out = m(rb)
@@ -130,76 +153,126 @@ class Trainer:
         loss.backward()
         self.loss_buf.copy_(loss.detach())
 
-    def _bwd_proposals(self):
-        if self.runner is not None and self.world > 1:  # (single GPU: already inside runner.forward_backward;
-            self.runner.backward_proposals()            #  autograd path: inside loss.backward())
-
     def _optimise(self, updated):
         # the reference steps an optimiser group only when it received gradients (engine/optimizers.py:160-172)
         groups = ["fields", "proposal_networks"] if updated else ["fields"]
         self.arena.step(grad_scale=1.0 / self.world, groups=groups, hyper_dev=self.hyper_views)
 
-    def _exchange(self, updated, between=None):
-        """Data-parallel gradient exchange (N > 1): the main-field slice (87 % of the bytes) is all-reduced
-        asynchronously on RCCL's stream while `between` (the proposal-network backward) still runs on the compute
-        stream; the proposal slice follows on update steps and is skipped otherwise (all ranks share the schedule, so
-        it is zero everywhere — DDP would average zeros)."""
+    # -- data-parallel segments (N > 1, runner) --------------------------------------------------------------------------
+    @property
+    def pipelined(self):
+        return self.world > 1 and self.runner is not None
+
+    def _seg(self, name):
+        """The body of one captured segment (also what the eager path runs)."""
+        r, a = self.runner, self.arena
+        if name == "pfwd":
+            r.forward_proposals()
+        elif name in (("main", True), ("main", False)):
+            a.zero_grad(["fields"])
+            r.forward_main_and_losses(name[1])
+            r.backward_main()
+        elif name == "pbwd":
+            a.zero_grad(["proposal_networks"])
+            r.backward_proposals()
+        elif name == "mopt":
+            a.step(grad_scale=1.0 / self.world, groups=["fields"], hyper_dev=self.hyper_views)
+        elif name == "popt":
+            a.step(grad_scale=1.0 / self.world, groups=["proposal_networks"], hyper_dev=self.hyper_views)
+        else:
+            raise KeyError(name)
+
+    _SEGMENTS = ("pfwd", ("main", True), ("main", False), "pbwd", "mopt", "popt")
+
+    def _run(self, name):
+        if self.graphs is not None:
+            self.graphs[name].replay()
+            if name == "mopt":
+                self.arena.step_counts["fields"] += 1  # the replayed Adam launch did step the group
+            elif name == "popt":
+                self.arena.step_counts["proposal_networks"] += 1
+        else:
+            self._seg(name)
+
+    def _finish_main(self):
+        """Wait for the in-flight main-field all-reduce and apply its Adam update."""
+        if self._have_pending:
+            if self._pending_main is not None:
+                self._pending_main.wait()
+            self._run("mopt")
+            self._pending_main, self._have_pending = None, False
+
+    def finish(self):
+        """Drain the pipeline: after this every parameter reflects every step taken (no-op for N = 1)."""
+        if self._have_pending:
+            self._push_hyper()  # step size of the update that is still pending
+            self._finish_main()
+
+    def _pipelined_iteration(self, updated):
         a = self.arena
-        h1 = a.all_reduce_span(*a.groups["fields"], async_op=True)
-        if between is not None:
-            between()
-        h2 = a.all_reduce_span(*a.groups["proposal_networks"], async_op=True) if updated else None
-        for h in (h1, h2):
+        self._prologue(updated)
+        self._run("pfwd")          # overlaps the all-reduce of the previous step's main-field gradients
+        self._finish_main()
+        self._run(("main", updated))
+        self._pending_main = a.all_reduce_span(*a.groups["fields"], async_op=True)
+        self._have_pending = True
+        if updated:
+            self._run("pbwd")      # ... and so does this
+            h = a.all_reduce_span(*a.groups["proposal_networks"], async_op=True)
             if h is not None:
                 h.wait()
+            self._run("popt")
+
+    def _plain_dp_iteration(self, updated):
+        """N > 1 through the autograd modules: one blocking all-reduce of the whole arena (not pipelined)."""
+        self._prologue(updated)
+        self._fwd_bwd(updated)
+        self.arena.all_reduce()
+        self._optimise(updated)
 
     # -- graph capture ---------------------------------------------------------------------------------------------
     def capture(self):
         torch.cuda.synchronize()
+        assert not self._have_pending
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # allocator / autograd warm-up of both variants on a side stream
             for upd in (True, False):
                 self._eager_iteration(upd)
+            self.finish()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graphs = {}
-        single = self.world == 1
-        for upd in (True, False):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):  # single GPU: the whole iteration is one graph
-                self._fwd_bwd(upd)
-                if single:
-                    if upd:
-                        self._bwd_proposals()
-                    self._optimise(upd)
-            graphs[("main", upd)] = g
-            if not single:
+        if self.pipelined:
+            for name in self._SEGMENTS:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
+                    self._seg(name)
+                graphs[name] = g
+        else:
+            for upd in (True, False):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):  # the whole iteration is one graph
+                    self._fwd_bwd(upd)
                     self._optimise(upd)
-                graphs[("opt", upd)] = g
-        if not single:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._bwd_proposals()
-            graphs["props"] = g
+                graphs[("all", upd)] = g
         for name in self.arena.step_counts:  # captures executed nothing; undo the host-side counters they bumped
             self.arena.step_counts[name] = self._true_steps[name]
         self.graphs = graphs
 
     def _eager_iteration(self, updated):
-        self._prologue(updated)
-        self._fwd_bwd(updated)
-        if self.world > 1:
-            self._exchange(updated, between=self._bwd_proposals if updated else None)
-        elif updated:
-            self._bwd_proposals()
-        self._optimise(updated)
+        if self.pipelined:
+            self._pipelined_iteration(updated)
+        elif self.world > 1:
+            self._plain_dp_iteration(updated)
+        else:
+            self._prologue(updated)
+            self._fwd_bwd(updated)
+            self._optimise(updated)
         self._true_steps = dict(self.arena.step_counts)
 
     def try_capture(self):
-        if not self.use_graph:
+        if not self.use_graph or (self.world > 1 and not self.pipelined):
             return False
         try:
             self.capture()
@@ -217,14 +290,11 @@ class Trainer:
     def train_iteration(self):
         ps = self.model.proposal_sampler
         updated = ps.updated_this_step()
-        if self.graphs is None:
-            self._eager_iteration(updated)
+        if self.graphs is None or self.pipelined:
+            self._eager_iteration(updated)  # (pipelined: the segments replay their graphs)
         else:
             self._prologue(updated)
-            self.graphs[("main", updated)].replay()
-            if self.world > 1:
-                self._exchange(updated, between=self.graphs["props"].replay if updated else None)
-                self.graphs[("opt", updated)].replay()
+            self.graphs[("all", updated)].replay()
             for name in (("fields", "proposal_networks") if updated else ("fields",)):
                 self.arena.step_counts[name] += 1  # the replayed Adam launches did step these groups
             self._true_steps = dict(self.arena.step_counts)
@@ -278,6 +348,7 @@ def measure_roofline(trainer, arena, steps):
     N.PROFILE = {}
     for _ in range(steps):
         trainer.train_iteration()
+    trainer.finish()
     torch.cuda.synchronize()
     prof = N.profile_summary(N.PROFILE)
     N.PROFILE = None
@@ -381,14 +452,17 @@ def main():
     # the reference's optimiser groups (models/nerfacto.py:255-260), AdamOptimizerConfig(lr=1e-2, eps=1e-15) each
     arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
     arena.broadcast_params()
-    rb, batch = synthetic_batch(device, seed=1000 + rank)  # each rank its own rays (scripts/train.py:98)
+    same = os.environ.get("NSAMD_BENCH_SAME_RAYS") == "1"  # functional check: N ranks, identical rays == the N=1 run
+    rb, batch = synthetic_batch(device, seed=1000 + (0 if same else rank))  # each rank its own rays (scripts/train.py:98)
     trainer = Trainer(model, arena, rb, batch, world=world, use_graph=not args.no_graph, use_runner=not args.autograd)
 
     for _ in range(max(1, args.warmup // 2)):  # eager warm-up: lazy kernel attributes, caches, allocator
         trainer.train_iteration()
+    trainer.finish()
     graphed = trainer.try_capture()
     for _ in range(args.warmup - max(1, args.warmup // 2)):
         trainer.train_iteration()
+    trainer.finish()
 
     if world > 1:
         dist.barrier()
@@ -396,6 +470,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.train_iteration()
+    trainer.finish()  # N > 1: the last step's pending main-field update is part of the timed work
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -413,6 +488,7 @@ def main():
     elif world > 1:  # keep the collective pattern identical on every rank during the profiling steps
         for _ in range(max(1, args.profile_steps)):
             trainer.train_iteration()
+        trainer.finish()
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -434,9 +510,11 @@ def main():
                                    "(BASELINE configs[1]/[2]); full training step incl. proposal nets 256->96, losses, Adam",
                        "rays_per_gpu": RAYS_PER_GPU, "global_rays": world * RAYS_PER_GPU,
                        "parallelism": f"dp{world}: rays sharded by batch; RCCL all-reduce of the gradient arena slices "
-                                      "(main field 67 MB async under the proposal backward, proposals only on update steps)",
+                                      "(main field 67 MB async, pipelined under the proposal backward and the next proposal forward; "
+                                      "proposal slice only on update steps)",
                        "params": arena.numel, "final_loss": round(float(loss), 6),
-                       "launch": "hipGraph replay (2 captured variants)" if graphed else "eager",
+                       "launch": ("hipGraph replay (2 captured variants)" if world == 1 else
+                                  "hipGraph replay (6 captured segments)") if graphed else "eager",
                        "driver": "autograd modules" if args.autograd else "explicit kernel schedule (train_step.py)"},
             "roofline": roof,
         }

@@ -72,8 +72,14 @@ class ParamArena:
     def step_count(self) -> int:
         return max(self.step_counts.values())
 
-    def zero_grad(self) -> None:
-        self.grad.zero_()
+    def zero_grad(self, groups: Optional[Sequence[str]] = None) -> None:
+        """Zero the gradient arena, or only the contiguous slices of the named optimiser groups."""
+        if groups is None:
+            self.grad.zero_()
+        else:
+            for name in groups:
+                a, b = self.groups[name]
+                self.grad[a:b].zero_()
         for p, off in zip(self.params, self.offsets):  # autograd may have replaced .grad; re-point the views
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + p.numel()].view(p.shape)

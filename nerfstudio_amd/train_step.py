@@ -150,7 +150,14 @@ class NerfactoTrainStep:
         self.backward_main()
 
     def forward_and_losses(self, updated: bool, draw_jitter: bool = True) -> None:
-        lib, st, n, cfg = N.load(), N.stream(), self.n, self.cfg
+        self.forward_proposals(draw_jitter)
+        self.forward_main_and_losses(updated)
+
+    def forward_proposals(self, draw_jitter: bool = True) -> None:
+        """Initial bins and the proposal levels (density fields + resampling): reads only the proposal networks'
+        parameters, so with data parallelism it can run while the main-field gradients of the previous step are still
+        being all-reduced (bench.py)."""
+        lib, st, n = N.load(), N.stream(), self.n
         ck = N.check
         if draw_jitter:
             self.jitter.uniform_()  # torch.rand per level and ray (ray_samplers.py:105, :322), drawn on the device
@@ -179,7 +186,11 @@ class NerfactoTrainStep:
                                            N.ptr(self.depth_med[lvl]) if self.compute_depths else None,
                                            N.ptr(self.s_bins[lvl + 1]), N.ptr(self.t_bins[lvl + 1]), st),
                "proposal_resample")
-        # ---- main field ----
+
+    def forward_main_and_losses(self, updated: bool) -> None:
+        """Main field on the final samples, compositing, and the three losses with their gradients."""
+        lib, st, n, cfg = N.load(), N.stream(), self.n, self.cfg
+        ck = N.check
         fld = self.model.field
         L = self.n_prop
         S, mm = self.counts[L], self.m_main
