@@ -542,7 +542,33 @@ def gen_raygen():
          directions_norm=rb.metadata["directions_norm"])
 
 
+def gen_schedulers():
+    """Learning rates torch's LambdaLR sets with the reference's ExponentialDecayScheduler (engine/schedulers.py:109-142),
+    read off the optimiser after `step` x (optimizer.step(); scheduler.step())."""
+    from nerfstudio.engine.schedulers import ExponentialDecayScheduler, ExponentialDecaySchedulerConfig
+
+    steps = [0, 1, 10, 999, 1000, 30000, 199999, 200000, 250000]
+    out = {}
+    for name, cfg in (("nerfacto", ExponentialDecaySchedulerConfig(lr_final=1e-4, max_steps=200000)),
+                      ("warm_cos", ExponentialDecaySchedulerConfig(lr_final=1e-4, max_steps=5000, warmup_steps=100,
+                                                                   lr_pre_warmup=1e-8)),
+                      ("warm_lin", ExponentialDecaySchedulerConfig(lr_final=None, max_steps=5000, warmup_steps=100,
+                                                                   ramp="linear"))):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=1e-2)
+        sch = ExponentialDecayScheduler(cfg).get_scheduler(opt, 1e-2)
+        lrs = []
+        for s_ in range(max(steps) + 1):
+            if s_ in steps:
+                lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        out[name] = np.array(lrs, dtype=np.float64)
+    save("schedulers", steps=np.array(steps), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "hashgrid", "fields", "samplers", "render", "losses", "pipeline", "raygen"]
+    which = sys.argv[1:] or ["kat", "hashgrid", "fields", "samplers", "render", "losses", "pipeline", "raygen",
+                             "schedulers"]
     for w in which:
         globals()["gen_" + w]()

@@ -136,3 +136,19 @@ def test_proposal_schedule_and_anneal():
             ps._steps_since_update = 0
         ps.step_cb(step)
     assert all(updated[:10]) and updated[10:16] == [False, True, False, True, False, True]
+
+
+def test_lr_schedule_matches_reference_lambda_lr(golden):
+    """ExponentialDecayScheduler vs the lr torch's LambdaLR sets with the reference's scheduler (fixture generated from
+    /root/reference/nerfstudio/engine/schedulers.py by running optimizer.step(); scheduler.step() up to 250 000 times)."""
+    import numpy as np
+
+    from nerfstudio_amd.schedulers import ExponentialDecayScheduler as S, ExponentialDecaySchedulerConfig as C
+
+    g = golden("schedulers")
+    cfgs = {"nerfacto": C(lr_final=1e-4, max_steps=200000),
+            "warm_cos": C(lr_final=1e-4, max_steps=5000, warmup_steps=100, lr_pre_warmup=1e-8),
+            "warm_lin": C(lr_final=None, max_steps=5000, warmup_steps=100, ramp="linear")}
+    for name, cfg in cfgs.items():
+        got = np.array([S(cfg).get_lr(int(s), 1e-2) for s in g["steps"]])
+        np.testing.assert_allclose(got, g[name], rtol=1e-12, err_msg=name)
