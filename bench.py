@@ -345,6 +345,19 @@ def algorithmic_model(key):
     return None, None
 
 
+def pmc_traffic(kernel_key):
+    """HBM-side bytes per launch of `kernel_key` from the committed rocprofv3 PMC passes (scripts/collect_pmc.sh ->
+    profiles/pmc_traffic.json: FETCH_SIZE, doubled for 16-B-per-lane streaming reads as MI355X_MICROARCH.md prescribes for
+    gfx950, + WRITE_SIZE; separate --pmc passes). Counters cannot be read from inside this process, so the value is the
+    one measured for this kernel at the commit that wrote the file; None when the file has no entry for the kernel."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        entry = json.load(open(path)).get(kernel_key)
+        return int(entry["hbm_bytes"]) if entry else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def measure_roofline(trainer, arena, steps):
     from nerfstudio_amd import _native as N
 
@@ -380,7 +393,7 @@ def measure_roofline(trainer, arena, steps):
         else:
             ach, peak, unit = top["work"] / sec / 1e12, F32_MFMA_PEAK_TFLOPS, "TFLOP/s"
         roof = {"bound": top["bound"], "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
-                "traffic": None, "kernel": top["kernel"], "avg_launch_ms": round(top["mean_ms"], 4),
+                "traffic": pmc_traffic(top["kernel"]), "kernel": top["kernel"], "avg_launch_ms": round(top["mean_ms"], 4),
                 "algorithmic_per_launch": top["work"]}
     return roof, table
 

@@ -1,38 +1,85 @@
 #!/bin/bash
-# GPU box: hardware counters for the hot kernels (run via gpurun). Three passes: SQ (MFMA/LDS/wait), TCC fetch, TCC write.
-# PMC passes use --kernel-trace only (no sys/hip/hsa tracing), as required on this pool.
+# GPU box: rocprofv3 evidence for the bench command (run via gpurun). Writes under gpurun_out/final/:
+#   kernel_stats.csv     per-kernel time (rocprofv3 --kernel-trace --stats of `bench.py --steps 20`, graph replay)
+#   pmc_summary.csv      SQ counters (MFMA busy, LDS waits, ...), FETCH_SIZE, WRITE_SIZE per kernel — three separate
+#                        passes with --kernel-trace only (no sys/hip/hsa tracing), as required on this pool
+#   pmc_traffic.json     HBM-side bytes per launch for the bench's kernel keys (MI355X_MICROARCH.md "HBM": FETCH_SIZE and
+#                        WRITE_SIZE are reported in KiB; FETCH_SIZE counts 128-B requests at 64 B for wide coalesced
+#                        streaming reads -> doubled for the kernels that stream 16 B per lane, raw value kept too)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/pmc
+OUT=$R/gpurun_out/final
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kstats -o k -- python $R/bench.py --steps 20 --warmup 10 --no-cpu-baseline --profile-steps 1 > $OUT/rocprof_bench.log 2>&1
 CMD="python $R/bench.py --steps 3 --warmup 3 --no-graph --no-cpu-baseline --profile-steps 1"
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq -o sq -- $CMD > $OUT/sq.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- $CMD > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- $CMD > $OUT/write.log 2>&1
+export NSAMD_SIDE_STREAM=0
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_INST_LDS --output-format csv -d /tmp/pmc_sq -o sq -- $CMD > $OUT/pmc_sq.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -o f -- $CMD > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -o w -- $CMD > $OUT/pmc_write.log 2>&1
 cd $R
 python - <<'PY'
-import csv, glob, collections, os
-out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out", "pmc")
-def load(sub):
+import csv, glob, collections, json, os, sqlite3
+out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out", "final")
+# ---- kernel stats from the graph-replay run
+dbs = glob.glob("/tmp/kstats/**/*results.db", recursive=True)
+if dbs:
+    db = sqlite3.connect(dbs[0])
+    rows = db.execute("select name, grid_x*grid_y*grid_z, workgroup_x, count(*), avg(end-start)/1000.0, sum(end-start)/1000.0 "
+                      "from kernels group by name, grid_x, grid_y, workgroup_x order by 6 desc").fetchall()
+    tot = sum(r[5] for r in rows)
+    with open(os.path.join(out, "kernel_stats.csv"), "w") as f:
+        f.write("kernel,grid_threads,workgroup,calls,avg_us,total_us,percent\n")
+        for r in rows:
+            f.write(f"\"{r[0][:90]}\",{r[1]},{r[2]},{r[3]},{r[4]:.2f},{r[5]:.1f},{100*r[5]/tot:.2f}\n")
+    print(open(os.path.join(out, "kernel_stats.csv")).read()[:3500])
+# ---- PMC
+def load(d):
     rows = []
-    for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         rows += list(csv.DictReader(open(f)))
     return rows
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for sub in ("sq", "fetch", "write"):
-    for r in load(sub):
-        name = r.get("Kernel_Name", "")
-        if "nsamd" not in name:
+for d in ("/tmp/pmc_sq", "/tmp/pmc_fetch", "/tmp/pmc_write"):
+    for r in load(d):
+        n = r.get("Kernel_Name", "")
+        if "nsamd" not in n:
             continue
-        key = name.split("(")[0].replace("void ", "") + f" grid={r.get('Grid_Size','?')}"
+        key = n.split("(")[0].replace("void ", "").replace("nsamd::", "") + " grid=" + r.get("Grid_Size", "?")
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
-with open(os.path.join(out, "summary.csv"), "w") as f:
-    names = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
-             "SQ_INSTS_VALU", "SQ_WAIT_INST_LDS", "FETCH_SIZE", "WRITE_SIZE"]
+names = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+         "SQ_INSTS_VALU", "SQ_WAIT_INST_LDS", "FETCH_SIZE", "WRITE_SIZE"]
+mean = lambda v: sum(v) / len(v) if v else None
+with open(os.path.join(out, "pmc_summary.csv"), "w") as f:
     f.write("kernel,dispatches," + ",".join(names) + "\n")
     for k in sorted(agg):
         n = max(len(v) for v in agg[k].values())
-        f.write(k + f",{n}," + ",".join(f"{sum(agg[k][c])/len(agg[k][c]):.1f}" if agg[k][c] else "" for c in names) + "\n")
-print(open(os.path.join(out, "summary.csv")).read())
+        f.write(k + f",{n}," + ",".join(f"{mean(agg[k][c]):.1f}" if agg[k][c] else "" for c in names) + "\n")
+print(open(os.path.join(out, "pmc_summary.csv")).read())
+# ---- HBM-side bytes per launch of the bench's kernel keys (config 2: N = 4096, S = (256, 96, 48))
+def kib(k, c):
+    return (mean(agg[k][c]) or 0.0) * 1024.0
+groups = {  # bench key -> (kernel substring, grid) parts; streaming = 16 B/lane coalesced reads dominate the fetches
+    "nsamd_hashgrid_encode_bwd[L=16,M=196608]": [("hash_bwd_bin_fine_kernel<4>", None, False), ("hash_bwd_bin_runs_kernel<4>", "245760", False),
+                                                  ("hash_bwd_apply_kernel", "524288", True)],
+    "nsamd_adam_step": [("adam_kernel", "524288", True)],
+    "nsamd_hashgrid_encode_fwd[L=16,M=196608]": [("hash_encode_fwd_kernel", "3145728", False)],
+}
+traffic = {}
+for key, parts in groups.items():
+    fetch_raw = fetch_cal = write = 0.0
+    found = []
+    for sub, grid, streaming in parts:
+        for k in agg:
+            if sub in k and (grid is None or k.endswith("grid=" + grid)):
+                if grid is None and not any(g in k for g in ("589824", "786432")) and "fine" in sub:
+                    continue  # main-table launches of the fine pass only (3 or 4 level groups x 192 blocks x 1024)
+                fr = kib(k, "FETCH_SIZE")
+                fetch_raw += fr
+                fetch_cal += fr * (2.0 if streaming else 1.0)
+                write += kib(k, "WRITE_SIZE")
+                found.append(k)
+    traffic[key] = {"fetch_bytes_raw": fetch_raw, "fetch_bytes_calibrated": fetch_cal, "write_bytes": write,
+                    "hbm_bytes": fetch_cal + write, "kernels": found}
+json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1))
 PY
-find $OUT -name "*.csv" ! -name summary.csv -size +2M -delete
