@@ -186,17 +186,45 @@ struct LevelList {
 //    a full table sends the update out as a direct atomic), so the workgroup emits ONE single record per distinct
 //    entry.
 constexpr int kRunThreads = 256;
-constexpr int kCombineBits = 12;
-constexpr int kCombineSlots = 1 << kCombineBits;
-constexpr int kCombinePerThread = kCombineSlots / kRunThreads;
 constexpr uint32_t kEmptyKey = 0xffffffffu;
 
-template <int kRunLen>
+// DPP moves inside a row of 16 lanes: value of lane - D (row_shr) / lane + 1 (row_shl); lanes without a source get `old`
+template <int D>
+__device__ __forceinline__ int dpp_row_shr(int v, int old) {
+  return __builtin_amdgcn_update_dpp(old, v, 0x110 | D, 0xf, 0xf, false);
+}
+template <int D>
+__device__ __forceinline__ float dpp_row_shr(float v, float old) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x110 | D, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int dpp_row_shl1(int v, int old) {
+  return __builtin_amdgcn_update_dpp(old, v, 0x101, 0xf, 0xf, false);
+}
+
+// One step of the segmented inclusive scan over the lanes of a 16-lane row (f = "my prefix already reaches a segment
+// head").
+template <int D>
+__device__ __forceinline__ void lane_merge_step(float (&a0)[8], float (&a1)[8], int& f) {
+  const int fp = dpp_row_shr<D>(f, 1);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float t0 = dpp_row_shr<D>(a0[k], 0.0f), t1 = dpp_row_shr<D>(a1[k], 0.0f);
+    if (!f) { a0[k] += t0; a1[k] += t1; }
+  }
+  if (!f) f = fp;
+}
+
+// kCombineBits: log2 of the table size. 12 (48 KiB, 3 workgroups per CU) holds the distinct entries of ~20 rays of a
+// level with resolution < 64; 11 (24 KiB, 6 workgroups per CU) is enough when a workgroup's 1024 samples are only a
+// few long rays (samples per ray >= 192) and doubles the occupancy of this latency-bound kernel.
+template <int kRunLen, int kCombineBits>
 __global__ __launch_bounds__(kRunThreads) void hash_bwd_bin_runs_kernel(
     nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
     int64_t stride_p, int64_t stride_k, int slice_log2, uint32_t cap, LevelList levels,
     uint32_t* __restrict__ cursors, uint4* __restrict__ queues, float* __restrict__ dtable) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+  constexpr int kCombineSlots = 1 << kCombineBits;
+  constexpr int kCombinePerThread = kCombineSlots / kRunThreads;
   const int level = levels.level[blockIdx.y];
   const int B = 1 << (grid.log2_table_size - slice_log2);
   // layout: [vals: 2 x slots floats][keys: slots][cnt: B][base: B]
@@ -239,9 +267,30 @@ __global__ __launch_bounds__(kRunThreads) void hash_bwd_bin_runs_kernel(
   const float scale = grid.scalings[level];
   Cell cur{};
   float a0[8], a1[8];
-  bool have = false;
+  bool have = false, single = true;  // single: no run of this thread has been flushed yet
 #pragma unroll
   for (int i = 0; i <= kRunLen; ++i) {
+    if (i == kRunLen) {
+      // Lane-level run merging before the last flush: consecutive lanes are consecutive pieces of a ray, and on a
+      // coarse level several of them sit in ONE cell. A lane whose only run continues the previous lane's open run
+      // hands nothing to the table itself: the sums travel down the chain (segmented scan inside 16-lane rows, DPP
+      // only) and the last lane of the chain inserts once. The table inserts are what bounds this kernel (LDS
+      // address conflicts between exactly these lanes, profiles/r01_scatter_pmc_counters.log).
+      int same = (have && single && (threadIdx.x & 15) != 0) ? 1 : 0;
+      same &= dpp_row_shr<1>(have ? 1 : 0, 0);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        same &= (dpp_row_shr<1>(cur.lo[a], -1) == cur.lo[a]) ? 1 : 0;
+        same &= (dpp_row_shr<1>(cur.hi[a], -1) == cur.hi[a]) ? 1 : 0;
+      }
+      const int head = same ^ 1;
+      int f = head;
+      lane_merge_step<1>(a0, a1, f);
+      lane_merge_step<2>(a0, a1, f);
+      lane_merge_step<4>(a0, a1, f);
+      lane_merge_step<8>(a0, a1, f);
+      have = have && (dpp_row_shl1(head, 1) != 0);  // only the last lane of a chain still owns a run
+    }
     bool live = false;
     Cell c = cur;
     if (i < kRunLen) {
@@ -301,6 +350,7 @@ __global__ __launch_bounds__(kRunThreads) void hash_bwd_bin_runs_kernel(
         }
       }
       have = false;
+      single = false;
     }
     if (i < kRunLen && live) {
 #pragma unroll
@@ -799,18 +849,18 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
       NSAMD_CHECK_LAUNCH();
     }
     if (coarse.count > 0) {
-      const size_t bin_lds = sizeof(uint32_t) * (2 * (size_t)B + 3 * kCombineSlots);
-      static const int run_env = env_int("NSAMD_SCATTER_RUN_LEN", 4);
-      const int run_len = run_env >= 8 ? 8 : (run_env >= 4 ? 4 : 2);
-      const int64_t per_block = (int64_t)kRunThreads * run_len;
+      static const int bits_env = env_int("NSAMD_SCATTER_TABLE_BITS", 0);  // experiments: force 11 / 12
+      const bool long_rays = pts.positions == nullptr && pts.samples_per_ray >= 192;
+      const int bits = bits_env ? bits_env : (long_rays ? 11 : 12);
+      const size_t bin_lds = sizeof(uint32_t) * (2 * (size_t)B + 3 * ((size_t)1 << bits));
+      const int64_t per_block = (int64_t)kRunThreads * 4;
       dim3 g1((unsigned)((M + per_block - 1) / per_block), (unsigned)coarse.count);
-#define NSAMD_RUNS(L)                                                                                              \
-  hash_bwd_bin_runs_kernel<L><<<g1, kRunThreads, bin_lds, st>>>(pts, M, transform, aabb, grid, denc, stride_p,     \
-                                                                stride_k, sl, cap, coarse, cursors, queues, dtable)
-      if (run_len == 8) NSAMD_RUNS(8);
-      else if (run_len == 4) NSAMD_RUNS(4);
-      else NSAMD_RUNS(2);
-#undef NSAMD_RUNS
+      if (bits == 11)
+        hash_bwd_bin_runs_kernel<4, 11><<<g1, kRunThreads, bin_lds, st>>>(pts, M, transform, aabb, grid, denc, stride_p,
+                                                                          stride_k, sl, cap, coarse, cursors, queues, dtable);
+      else
+        hash_bwd_bin_runs_kernel<4, 12><<<g1, kRunThreads, bin_lds, st>>>(pts, M, transform, aabb, grid, denc, stride_p,
+                                                                          stride_k, sl, cap, coarse, cursors, queues, dtable);
       NSAMD_CHECK_LAUNCH();
     }
     dim3 g2((unsigned)B, (unsigned)nl);

@@ -100,7 +100,10 @@ class NerfactoTrainStep:
         # MI355X (profiles/). `side_stream = None` runs them back to back (the data-parallel path does: its proposal
         # chain is the cover for the main-field all-reduce).
         self.side_stream = torch.cuda.Stream(device=device)
+        # ... and the proposal levels are independent of each other too: level i > 0 gets its own stream
+        self.level_streams = [torch.cuda.Stream(device=device) for _ in range(max(self.n_prop - 1, 0))]
         self._fork, self._join = torch.cuda.Event(), torch.cuda.Event()
+        self._level_join = [torch.cuda.Event() for _ in self.level_streams]
         self.spacing = int(getattr(model.proposal_sampler.initial_sampler, "spacing", 0))
         # host-evaluated tables (bit-identical to the reference's CPU linspace)
         self.edges = F._linspace("edges", self.counts[0], device)
@@ -133,10 +136,17 @@ class NerfactoTrainStep:
             self._fork.record(main)
             self.side_stream.wait_event(self._fork)
             with torch.cuda.stream(self.side_stream):
-                self.backward_proposals()
+                self.backward_proposals(levels=[0])
                 self._join.record(self.side_stream)
+            for i, ls in enumerate(self.level_streams):
+                ls.wait_event(self._fork)
+                with torch.cuda.stream(ls):
+                    self.backward_proposals(levels=[i + 1])
+                    self._level_join[i].record(ls)
             self.backward_main()
             main.wait_event(self._join)
+            for ev in self._level_join:
+                main.wait_event(ev)
         else:
             self.backward_main()
             if updated:
@@ -243,13 +253,14 @@ class NerfactoTrainStep:
                                          enc.spec.native(), N.ptr(self.f_denc), 1, mm, N.ptr(self._grad(enc.hash_table)),
                                          None, N.ptr(ws), ws_n, st), "hashgrid_encode_bwd")
 
-    def backward_proposals(self) -> None:
+    def backward_proposals(self, levels=None) -> None:
         """Backward of the proposal networks (interlevel loss only; main-level weights are detached, losses.py:119-120).
-        Needs the dw_prop written by forward_backward_main(updated=True)."""
+        Needs the dw_prop written by forward_backward_main(updated=True). `levels`: subset of proposal levels (their
+        chains share nothing, so they may run on different streams)."""
         lib, st, n = N.load(), N.stream(), self.n
         ck = N.check
         for _ in (0,):
-            for lvl in range(self.n_prop):
+            for lvl in (range(self.n_prop) if levels is None else levels):
                 net = self.props[lvl]
                 S, m = self.counts[lvl], n * self.counts[lvl]
                 mlp = net.mlp_base[1]
