@@ -7,9 +7,11 @@
 // feature-major enc[k][p] makes every load a coalesced 256-B row, the weights are wave-uniform and arrive through
 // the scalar cache (s_load -> v_fmac with an SGPR operand), no LDS in the forward.
 // Backward: the per-point input gradient is the same shape of work; the weight gradients need a sum over points,
-// done per 256-point chunk through LDS ([feature][point] rows, stride 257 -> conflict-free) with each thread owning
-// a few weight elements in registers across the chunks of a persistent workgroup, flushed once with atomics
-// (<= kMaxBlocks atomics per weight element).
+// done per 256-point chunk through LDS ([feature][point] rows, stride 257). dW0 = Gh X^T (H x IN, k = points) IS a
+// GEMM with a long k axis: each wave takes 64 of the chunk's points through 16 v_mfma_f32_16x16x4_f32 per row tile
+// (operands are the LDS rows as they stand) and keeps its partial in registers across the chunks of a persistent
+// workgroup — the first version gave each of 160 threads a 256-long dot product (1536 LDS read instructions per chunk
+// against 128 now). One LDS reduction over the 4 waves and <= kMaxBlocks atomics per weight element at the end.
 #include "common.h"
 
 namespace nsamd {
@@ -51,48 +53,79 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
     const float* __restrict__ ddensity, int64_t M, nsamd_density_mlp mlp, float* __restrict__ denc,
     float* __restrict__ dW0, float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1) {
   constexpr int LD = kMlpBlock + 1;
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   float* gh_T = lds;            // [H][LD]   dL/d(hidden pre-activation) per point
   float* x_T = lds + H * LD;    // [IN][LD]  encoded features per point
   float* hg_T = x_T + IN * LD;  // [H][LD]   relu(hidden) * dL/dpre  (for dW1)
   float* gp = hg_T + H * LD;    // [LD]      dL/dpre per point
-  const float* __restrict__ W0 = mlp.W0;
-  const float* __restrict__ b0 = mlp.b0;
-  const float* __restrict__ W1 = mlp.W1;
+  // Weights: 193 wave-uniform scalars do not fit the SGPR file (the compiler spilled 147 of them to VGPR lanes);
+  // staged once in LDS as rows of INP = IN rounded up to 4 floats and read back as broadcast ds_read_b128.
+  constexpr int INP = (IN + 3) & ~3;
+  float* w0s = lds + (((2 * H + IN + 1) * LD + 3) & ~3);  // [H][INP], 16-B aligned
+  float* b0s = w0s + H * INP;   // [H]
+  float* w1s = b0s + H;         // [H]
+  for (int e = threadIdx.x; e < H * INP; e += kMlpBlock) {
+    const int j = e / INP, k = e - j * INP;
+    w0s[e] = k < IN ? mlp.W0[j * IN + k] : 0.0f;
+  }
+  for (int e = threadIdx.x; e < H; e += kMlpBlock) {
+    b0s[e] = mlp.b0[e];
+    w1s[e] = mlp.W1[e];
+  }
+  __syncthreads();
 
-  constexpr int NW0 = (H * IN + kMlpBlock - 1) / kMlpBlock;
-  float accW0[NW0];
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  constexpr int NT = H / 16;  // row tiles of dW0
+  static_assert(H % 16 == 0 && IN <= 16, "dW0 tiling");
+  v4f accM[NT];
 #pragma unroll
-  for (int i = 0; i < NW0; ++i) accW0[i] = 0.0f;
+  for (int n = 0; n < NT; ++n) accM[n] = v4f{0.f, 0.f, 0.f, 0.f};
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, jj = lane & 15, gg = lane >> 4;
   float accV = 0.0f;  // thread t < H: db0[t]; H <= t < 2H: dW1[t-H]; t == 2H: db1
 
   const int64_t chunks = (M + kMlpBlock - 1) / kMlpBlock;
+  // The chunk loop alternates a per-point phase (global loads) and a weight-gradient phase (LDS only): the next chunk's
+  // inputs are fetched during the latter, otherwise every chunk starts with an exposed HBM round trip.
+  float x_next[IN];
+  float gd_next = 0.0f, sel_next = 1.0f, pre_next = 0.0f;
+  auto fetch = [&](int64_t c) {
+    const int64_t p = c * kMlpBlock + threadIdx.x;
+    const bool live = c < chunks && p < M;
+#pragma unroll
+    for (int k = 0; k < IN; ++k) x_next[k] = live ? enc[(int64_t)k * M + p] : 0.0f;
+    gd_next = live ? ddensity[p] : 0.0f;
+    sel_next = (live && selector) ? selector[p] : 1.0f;
+    pre_next = live ? pre[p] : 0.0f;
+  };
+  fetch(blockIdx.x);
   for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
     const int64_t p = c * kMlpBlock + threadIdx.x;
     const bool live = p < M;
     float x[IN];
 #pragma unroll
-    for (int k = 0; k < IN; ++k) x[k] = live ? enc[(int64_t)k * M + p] : 0.0f;
-    float g_pre = 0.0f;
-    if (live) {
-      const float sel = selector ? selector[p] : 1.0f;
-      // d density / d pre = avg * sel * exp(clamp(pre, -15, 15))            (activations.py:39-42)
-      g_pre = ddensity[p] * sel * mlp.average_init_density * expf(fminf(fmaxf(pre[p], -15.0f), 15.0f));
-    }
+    for (int k = 0; k < IN; ++k) x[k] = x_next[k];
+    // d density / d pre = avg * sel * exp(clamp(pre, -15, 15))            (activations.py:39-42)
+    const float g_pre =
+        live ? gd_next * sel_next * mlp.average_init_density * expf(fminf(fmaxf(pre_next, -15.0f), 15.0f)) : 0.0f;
     float dx[IN];
 #pragma unroll
     for (int k = 0; k < IN; ++k) dx[k] = 0.0f;
-    constexpr int JU = (H <= 16) ? H : 2;  // wide hidden layers: keep the weight working set in SGPRs
-#pragma unroll JU
+#pragma unroll 4
     for (int j = 0; j < H; ++j) {
-      float a = b0[j];
+      float wj[INP];
 #pragma unroll
-      for (int k = 0; k < IN; ++k) a = fmaf(W0[j * IN + k], x[k], a);
-      const float gh = (a > 0.0f) ? g_pre * W1[j] : 0.0f;
+      for (int k4 = 0; k4 < INP; k4 += 4) {
+        const float4 w4 = *reinterpret_cast<const float4*>(w0s + j * INP + k4);
+        wj[k4] = w4.x; wj[k4 + 1] = w4.y; wj[k4 + 2] = w4.z; wj[k4 + 3] = w4.w;
+      }
+      float a = b0s[j];
+#pragma unroll
+      for (int k = 0; k < IN; ++k) a = fmaf(wj[k], x[k], a);
+      const float gh = (a > 0.0f) ? g_pre * w1s[j] : 0.0f;
       gh_T[j * LD + threadIdx.x] = gh;
       hg_T[j * LD + threadIdx.x] = fmaxf(a, 0.0f) * g_pre;
 #pragma unroll
-      for (int k = 0; k < IN; ++k) dx[k] = fmaf(gh, W0[j * IN + k], dx[k]);
+      for (int k = 0; k < IN; ++k) dx[k] = fmaf(gh, wj[k], dx[k]);
     }
 #pragma unroll
     for (int k = 0; k < IN; ++k) {
@@ -101,18 +134,16 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
     }
     gp[threadIdx.x] = g_pre;
     __syncthreads();
-    // weight-gradient partial sums over the 256 points of this chunk
+    fetch(c + gridDim.x);
+    // weight-gradient partial sums over the 256 points of this chunk: dW0[i][j] += sum_p gh[i][p] x[j][p]
+    // (A lane (i = lane & 15, k = lane >> 4) = gh_T[i][p], B lane (j, k) = x_T[j][p], 4 points per MFMA)
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+      const int pt = 64 * wv + 4 * q + gg;
+      const float b = jj < IN ? x_T[jj * LD + pt] : 0.0f;
 #pragma unroll
-    for (int i = 0; i < NW0; ++i) {
-      const int e = threadIdx.x + i * kMlpBlock;
-      if (e < H * IN) {
-        const float* a = gh_T + (e / IN) * LD;
-        const float* b = x_T + (e % IN) * LD;
-        float s = 0.0f;
-#pragma unroll 8
-        for (int q = 0; q < kMlpBlock; ++q) s = fmaf(a[q], b[q], s);
-        accW0[i] += s;
-      }
+      for (int n = 0; n < NT; ++n)
+        accM[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(gh_T[(16 * n + jj) * LD + pt], b, accM[n], 0, 0, 0);
     }
     if (threadIdx.x < 2 * H + 1) {
       const float* a = (threadIdx.x < H)       ? gh_T + threadIdx.x * LD
@@ -125,11 +156,20 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
     }
     __syncthreads();
   }
+  // accM lane (j, g) reg r = dW0[16n + 4g + r][j] of this wave's points: add the 4 waves up in LDS (free by now)
+  float* red = lds;  // [H][16]
+  for (int e = threadIdx.x; e < H * 16; e += kMlpBlock) red[e] = 0.0f;
+  __syncthreads();
+  for (int turn = 0; turn < kMlpBlock / 64; ++turn) {
+    if (wv == turn) {
 #pragma unroll
-  for (int i = 0; i < NW0; ++i) {
-    const int e = threadIdx.x + i * kMlpBlock;
-    if (e < H * IN) unsafeAtomicAdd(dW0 + e, accW0[i]);
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(16 * n + 4 * gg + r) * 16 + jj] += accM[n][r];  // distinct address per lane
+    }
+    __syncthreads();
   }
+  for (int e = threadIdx.x; e < H * IN; e += kMlpBlock) unsafeAtomicAdd(dW0 + e, red[(e / IN) * 16 + (e % IN)]);
   if (threadIdx.x < H) unsafeAtomicAdd(db0 + threadIdx.x, accV);
   else if (threadIdx.x < 2 * H) unsafeAtomicAdd(dW1 + (threadIdx.x - H), accV);
   else if (threadIdx.x == 2 * H) unsafeAtomicAdd(db1, accV);
@@ -149,7 +189,7 @@ static int launch_bwd(const float* enc, const float* selector, const float* pre,
                       nsamd_density_mlp mlp, float* denc, float* dW0, float* db0, float* dW1, float* db1,
                       hipStream_t stream) {
   const unsigned blocks = (unsigned)min((int64_t)kMaxBlocks, (M + kMlpBlock - 1) / kMlpBlock);
-  const size_t lds = sizeof(float) * (size_t)(2 * H + IN + 1) * (kMlpBlock + 1);
+  const size_t lds = sizeof(float) * ((size_t)(2 * H + IN + 1) * (kMlpBlock + 1) + 8 + (size_t)H * (((IN + 3) & ~3) + 2));
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&density_mlp_bwd_kernel<IN, H>),
