@@ -33,45 +33,58 @@ namespace nsamd {
 
 constexpr int kHashBlock = 256;
 
+// kLevels levels per thread: the position (ray fetch + contraction) is computed once and 8 * kLevels gathers are in
+// flight per lane.
+template <int kLevels>
 __global__ __launch_bounds__(kHashBlock) void hash_encode_fwd_kernel(nsamd_points P, int64_t M, int transform,
                                                                      nsamd_aabb box,
                                                                      const float2* __restrict__ table,
                                                                      nsamd_grid grid, float* __restrict__ enc,
                                                                      int64_t stride_p, int64_t stride_k,
                                                                      float* __restrict__ selector) {
-  const int level = blockIdx.y;
+  const int level0 = blockIdx.y * kLevels;
   const int64_t p = (int64_t)blockIdx.x * kHashBlock + threadIdx.x;
   if (p >= M) return;
   float x, y, z;
   load_position(P, p, x, y, z);
   const float sel = normalise_position(transform, box, x, y, z);
-  if (level == 0 && selector != nullptr) selector[p] = sel;
-
-  const Cell c = locate_cell(x, y, z, grid.scalings[level]);
+  if (level0 == 0 && selector != nullptr) selector[p] = sel;
   const uint32_t mask = (1u << grid.log2_table_size) - 1u;
-  const float2* __restrict__ tl = table + ((size_t)level << grid.log2_table_size);
-  float2 v[8];
+  float2 v[kLevels][8];
+  float w[kLevels][3];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) v[k] = tl[corner_index(c, k, mask)];
-
-  const float wx = c.w[0], wy = c.w[1], wz = c.w[2];
-  const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
-  float r[2];
+  for (int i = 0; i < kLevels; ++i) {
+    const int level = level0 + i;
+    if (level >= grid.num_levels) break;
+    const Cell c = locate_cell(x, y, z, grid.scalings[level]);
+    w[i][0] = c.w[0]; w[i][1] = c.w[1]; w[i][2] = c.w[2];
+    const float2* __restrict__ tl = table + ((size_t)level << grid.log2_table_size);
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    auto g = [&](int k) { return f == 0 ? v[k].x : v[k].y; };
-    // blend order x, y, z exactly as encodings.py:446-456
-    const float yc_zc = g(7) * wx + g(6) * ux;
-    const float yf_zc = g(5) * wx + g(4) * ux;
-    const float yf_zf = g(1) * wx + g(0) * ux;
-    const float yc_zf = g(3) * wx + g(2) * ux;
-    const float zc = yc_zc * wy + yf_zc * uy;
-    const float zf = yc_zf * wy + yf_zf * uy;
-    r[f] = zc * wz + zf * uz;
+    for (int k = 0; k < 8; ++k) v[i][k] = tl[corner_index(c, k, mask)];
   }
-  float* o = enc + p * stride_p + (int64_t)(2 * level) * stride_k;
-  o[0] = r[0];
-  o[stride_k] = r[1];
+#pragma unroll
+  for (int i = 0; i < kLevels; ++i) {
+    const int level = level0 + i;
+    if (level >= grid.num_levels) break;
+    const float wx = w[i][0], wy = w[i][1], wz = w[i][2];
+    const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+    float r[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      auto g = [&](int k) { return f == 0 ? v[i][k].x : v[i][k].y; };
+      // blend order x, y, z exactly as encodings.py:446-456
+      const float yc_zc = g(7) * wx + g(6) * ux;
+      const float yf_zc = g(5) * wx + g(4) * ux;
+      const float yf_zf = g(1) * wx + g(0) * ux;
+      const float yc_zf = g(3) * wx + g(2) * ux;
+      const float zc = yc_zc * wy + yf_zc * uy;
+      const float zf = yc_zf * wy + yf_zf * uy;
+      r[f] = zc * wz + zf * uz;
+    }
+    float* o = enc + p * stride_p + (int64_t)(2 * level) * stride_k;
+    o[0] = r[0];
+    o[stride_k] = r[1];
+  }
 }
 
 // dL/dtable: one thread per (point, level); 16 fire-and-forget fp32 atomics (global_atomic_add_f32).
@@ -691,6 +704,11 @@ static int check_grid(const nsamd_grid& g) {
 
 using namespace nsamd;
 
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e != nullptr ? atoi(e) : dflt;
+}
+
 extern "C" int nsamd_hashgrid_encode_fwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb,
                                          const float* table, nsamd_grid grid, float* enc, int64_t stride_p,
                                          int64_t stride_k, float* selector, nsamd_stream_t stream) {
@@ -704,9 +722,24 @@ extern "C" int nsamd_hashgrid_encode_fwd(nsamd_points pts, int64_t M, int transf
   if (M == 0) return NSAMD_OK;
   const int64_t nb = (M + kHashBlock - 1) / kHashBlock;
   if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
-  dim3 g((unsigned)nb, (unsigned)grid.num_levels);
-  hash_encode_fwd_kernel<<<g, kHashBlock, 0, (hipStream_t)stream>>>(
-      pts, M, transform, aabb, reinterpret_cast<const float2*>(table), grid, enc, stride_p, stride_k, selector);
+  // Levels per thread: small tables (all levels of a proposal grid sit in one XCD's L2 together) gain from sharing the
+  // position and having 32 gathers in flight (44.5 -> 38.8 us, 27.9 -> 24.6 us); for the main grid one level already
+  // fills an L2 and sweeping several at once thrashes it (80 -> 97 us). Measured, profiles/r01_negative_results.txt.
+  static const int lv_force = env_int("NSAMD_HASH_FWD_LEVELS", 0);
+  const int lv_env = lv_force ? lv_force : (((int64_t)8 << grid.log2_table_size) >= (2 << 20) ? 1 : 4);
+  if (lv_env >= 4) {
+    dim3 g((unsigned)nb, (unsigned)((grid.num_levels + 3) / 4));
+    hash_encode_fwd_kernel<4><<<g, kHashBlock, 0, (hipStream_t)stream>>>(
+        pts, M, transform, aabb, reinterpret_cast<const float2*>(table), grid, enc, stride_p, stride_k, selector);
+  } else if (lv_env >= 2) {
+    dim3 g((unsigned)nb, (unsigned)((grid.num_levels + 1) / 2));
+    hash_encode_fwd_kernel<2><<<g, kHashBlock, 0, (hipStream_t)stream>>>(
+        pts, M, transform, aabb, reinterpret_cast<const float2*>(table), grid, enc, stride_p, stride_k, selector);
+  } else {
+    dim3 g((unsigned)nb, (unsigned)grid.num_levels);
+    hash_encode_fwd_kernel<1><<<g, kHashBlock, 0, (hipStream_t)stream>>>(
+        pts, M, transform, aabb, reinterpret_cast<const float2*>(table), grid, enc, stride_p, stride_k, selector);
+  }
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }
@@ -721,10 +754,6 @@ static int scatter_target_tiles() {
   return cached;
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e != nullptr ? atoi(e) : dflt;
-}
 
 // Geometry of the binned scatter for (grid, M): tile size chosen so that (tiles = bins x levels) >= ~512 fills the
 // chip; queues sized for 2x the uniform-hash expectation of 8 M single records per level (the fine levels need half:
