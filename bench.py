@@ -146,10 +146,11 @@ class Trainer:
         """Single-process path: forward, losses and the main backward (runner: also the proposal backward)."""
         from nerfstudio_amd.cameras.rays import RayBundle
 
-        self.arena.zero_grad()
         if self.runner is not None:
+            self.arena.zero_grad(skip=self.runner.written_params())  # the table gradients are written, not accumulated
             self.runner.forward_backward(updated)  # the two backward chains run as parallel branches
             return
+        self.arena.zero_grad()
         m = self.model
         m.proposal_sampler.force_updated = updated
         rb = RayBundle(origins=self.rb.origins, directions=self.rb.directions, pixel_area=self.rb.pixel_area,
@@ -177,11 +178,11 @@ class Trainer:
         if name == "pfwd":
             r.forward_proposals()
         elif name in (("main", True), ("main", False)):
-            a.zero_grad(["fields"])
+            a.zero_grad(["fields"], skip=r.written_params())
             r.forward_main_and_losses(name[1])
             r.backward_main()
         elif name == "pbwd":
-            a.zero_grad(["proposal_networks"])
+            a.zero_grad(["proposal_networks"], skip=r.written_params())
             r.backward_proposals()
         elif name == "mopt":
             a.step(grad_scale=1.0 / self.world, groups=["fields"], hyper_dev=self.hyper_views)

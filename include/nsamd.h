@@ -95,9 +95,19 @@ int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transform, nsamd_
                               float* dtable, float* dpositions, float* workspace, int64_t workspace_floats,
                               nsamd_stream_t stream);
 
-/* Words of scratch the binned scatter of nsamd_hashgrid_encode_bwd wants for (grid, M); 0 when that path does not
- * apply (M < 8192 or an unsupported grid). Host-only, no device work. */
-int64_t nsamd_hashgrid_encode_bwd_workspace(nsamd_grid grid, int64_t M);
+/* Same scatter, but dtable is WRITE-ONLY: every entry is set (zero where nothing lands), so the caller neither
+ * zero-fills the gradient before the call nor pays the read of the accumulate — with Adam consuming the gradient right
+ * after, that removes 2 x 67 MB of HBM traffic per step for the nerfacto main table. Needs the workspace of
+ * nsamd_hashgrid_encode_bwd_workspace(grid, M, 1) to stay on the binned path (updates pass 1 cannot queue go to a
+ * deferred list sized for the worst case and are applied after pass 2); otherwise it zero-fills and accumulates. */
+int nsamd_hashgrid_encode_bwd_set(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
+                                  nsamd_grid grid, const float* denc, int64_t stride_p, int64_t stride_k, float* dtable,
+                                  float* dpositions, float* workspace, int64_t workspace_floats, nsamd_stream_t stream);
+
+/* Words of scratch the binned scatter of nsamd_hashgrid_encode_bwd (write_only = 0) / nsamd_hashgrid_encode_bwd_set
+ * (write_only = 1) wants for (grid, M); 0 when that path does not apply (M < 8192 or an unsupported grid). Host-only,
+ * no device work. */
+int64_t nsamd_hashgrid_encode_bwd_workspace(nsamd_grid grid, int64_t M, int write_only);
 
 /* ------------------------------------------------------------------------------------------------------------
  * SH encoding, 4 levels = 16 components (SHEncoding.pytorch_fwd, encodings.py:791-794 ->

@@ -58,7 +58,8 @@ class FieldMlpGrads(C.Structure):
 _SIGNATURES = {
     "nsamd_hashgrid_encode_fwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp],
     "nsamd_hashgrid_encode_bwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, vp, i64, vp],
-    "nsamd_hashgrid_encode_bwd_workspace": [Grid, i64],
+    "nsamd_hashgrid_encode_bwd_set": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, vp, i64, vp],
+    "nsamd_hashgrid_encode_bwd_workspace": [Grid, i64, C.c_int],
     "nsamd_sh4_encode": [vp, i64, vp, vp],
     "nsamd_contract_linf": [vp, i64, vp, vp],
     "nsamd_density_mlp_fwd": [vp, vp, i64, DensityMlp, vp, vp, vp],

@@ -72,14 +72,27 @@ class ParamArena:
     def step_count(self) -> int:
         return max(self.step_counts.values())
 
-    def zero_grad(self, groups: Optional[Sequence[str]] = None) -> None:
-        """Zero the gradient arena, or only the contiguous slices of the named optimiser groups."""
-        if groups is None:
-            self.grad.zero_()
-        else:
-            for name in groups:
-                a, b = self.groups[name]
-                self.grad[a:b].zero_()
+    def zero_grad(self, groups: Optional[Sequence[str]] = None, skip: Optional[Iterable[Parameter]] = None) -> None:
+        """Zero the gradient arena, or only the contiguous slices of the named optimiser groups. `skip`: parameters
+        whose gradient the next backward WRITES rather than accumulates (nsamd_hashgrid_encode_bwd_set) — their 67 MB
+        need no zero-fill."""
+        spans = [(0, self.numel)] if groups is None else [self.groups[name] for name in groups]
+        if skip:
+            ids = {id(p) for p in skip}
+            holes = sorted((off, off + p.numel()) for p, off in zip(self.params, self.offsets) if id(p) in ids)
+            cut = []
+            for a, b in spans:
+                for ha, hb in holes:
+                    if hb <= a or ha >= b:
+                        continue
+                    if ha > a:
+                        cut.append((a, ha))
+                    a = max(a, hb)
+                if a < b:
+                    cut.append((a, b))
+            spans = cut
+        for a, b in spans:
+            self.grad[a:b].zero_()
         for p, off in zip(self.params, self.offsets):  # autograd may have replaced .grad; re-point the views
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + p.numel()].view(p.shape)

@@ -201,6 +201,36 @@ struct LevelList {
 constexpr int kRunThreads = 256;
 constexpr uint32_t kEmptyKey = 0xffffffffu;
 
+// Where pass 1 cannot queue an update (queue or combining table full, pair straddling two tiles) the update must still
+// arrive exactly. Accumulating call: a direct global atomic on the table gradient. Write-only call (`..._set`: pass 2
+// OVERWRITES every tile, so nothing may be added before it): the update is appended to a deferred list sized for the
+// worst case and applied by hash_bwd_deferred_kernel after pass 2.
+struct Deferred {
+  uint32_t* count;  // nullptr: accumulate directly
+  uint4* list;
+  uint32_t cap;
+};
+
+__device__ __forceinline__ void fallback_add(float* level_table, int level, uint32_t index, float v0, float v1,
+                                             const Deferred& d) {
+  if (d.count != nullptr) {
+    // one returning atomic per wavefront, not per lane: the counter is a single address (~12 ns per atomic)
+    const unsigned long long active = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    const int leader = __builtin_ctzll(active);
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(d.count, (uint32_t)__builtin_popcountll(active));
+    base = __shfl(base, leader);
+    const uint32_t pos = base + (uint32_t)__builtin_popcountll(active & ((1ull << lane) - 1ull));
+    if (pos < d.cap) {
+      d.list[pos] = make_uint4(index, (uint32_t)level, __float_as_uint(v0), __float_as_uint(v1));
+      return;
+    }
+  }
+  unsafeAtomicAdd(level_table + 2 * (size_t)index, v0);
+  unsafeAtomicAdd(level_table + 2 * (size_t)index + 1, v1);
+}
+
 // DPP moves inside a row of 16 lanes: value of lane - D (row_shr) / lane + 1 (row_shl); lanes without a source get `old`
 template <int D>
 __device__ __forceinline__ int dpp_row_shr(int v, int old) {
@@ -234,7 +264,7 @@ template <int kRunLen, int kCombineBits>
 __global__ __launch_bounds__(kRunThreads) void hash_bwd_bin_runs_kernel(
     nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
     int64_t stride_p, int64_t stride_k, int slice_log2, uint32_t cap, LevelList levels,
-    uint32_t* __restrict__ cursors, uint4* __restrict__ queues, float* __restrict__ dtable) {
+    uint32_t* __restrict__ cursors, uint4* __restrict__ queues, float* __restrict__ dtable, Deferred deferred) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   constexpr int kCombineSlots = 1 << kCombineBits;
   constexpr int kCombinePerThread = kCombineSlots / kRunThreads;
@@ -358,8 +388,7 @@ __global__ __launch_bounds__(kRunThreads) void hash_bwd_bin_runs_kernel(
             atomicAdd(vals + 2 * h[k] + 1, a1[k]);
           }
         } else {  // table full around this slot: direct atomics keep the result exact
-          unsafeAtomicAdd(level_table + 2 * (size_t)index[k], a0[k]);
-          unsafeAtomicAdd(level_table + 2 * (size_t)index[k] + 1, a1[k]);
+          fallback_add(level_table, level, index[k], a0[k], a1[k], deferred);
         }
       }
       have = false;
@@ -405,8 +434,7 @@ __global__ __launch_bounds__(kRunThreads) void hash_bwd_bin_runs_kernel(
       queues[((size_t)level * B + bin) * cap + pos] =
           make_uint4(__float_as_uint(v0), __float_as_uint(v1), 0u, skey[i] & local_mask);
     } else {  // queue full (a very hot tile): direct atomics keep the result exact
-      unsafeAtomicAdd(level_table + 2 * (size_t)skey[i], v0);
-      unsafeAtomicAdd(level_table + 2 * (size_t)skey[i] + 1, v1);
+      fallback_add(level_table, level, skey[i], v0, v1, deferred);
     }
   }
 }
@@ -420,7 +448,7 @@ template <int kFineLevels>
 __global__ __launch_bounds__(kBinThreads) void hash_bwd_bin_fine_kernel(
     nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
     int64_t stride_p, int64_t stride_k, int slice_log2, uint32_t cap, LevelList levels,
-    uint32_t* __restrict__ cursors, uint4* __restrict__ queues, float* __restrict__ dtable) {
+    uint32_t* __restrict__ cursors, uint4* __restrict__ queues, float* __restrict__ dtable, Deferred deferred) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   const int B = 1 << (grid.log2_table_size - slice_log2);
   uint32_t* cnt = lds_u;                     // [kFineLevels][B]
@@ -471,10 +499,8 @@ __global__ __launch_bounds__(kBinThreads) void hash_bwd_bin_fine_kernel(
         const float bz = (q & 2) ? c.w[2] : 1.0f - c.w[2];
         const float by = (q & 1) ? c.w[1] : 1.0f - c.w[1];
         const float a0 = (g0[i] * bz) * by, a1 = (g1[i] * bz) * by;
-        unsafeAtomicAdd(level_table + 2 * (size_t)ia, a0 * (1.0f - c.w[0]));
-        unsafeAtomicAdd(level_table + 2 * (size_t)ia + 1, a1 * (1.0f - c.w[0]));
-        unsafeAtomicAdd(level_table + 2 * (size_t)ib, a0 * c.w[0]);
-        unsafeAtomicAdd(level_table + 2 * (size_t)ib + 1, a1 * c.w[0]);
+        fallback_add(level_table, lvl[i], ia, a0 * (1.0f - c.w[0]), a1 * (1.0f - c.w[0]), deferred);
+        fallback_add(level_table, lvl[i], ib, a0 * c.w[0], a1 * c.w[0], deferred);
       }
     }
   }
@@ -502,10 +528,8 @@ __global__ __launch_bounds__(kBinThreads) void hash_bwd_bin_fine_kernel(
         float* const level_table = dtable + (((size_t)lvl[i] << grid.log2_table_size) << 1);
         const size_t ia = ((size_t)bin[i][q] << slice_log2) + (word[i][q] & 0x3fffu);
         const size_t ib = ((size_t)bin[i][q] << slice_log2) + ((word[i][q] >> 14) & 0x3fffu);
-        unsafeAtomicAdd(level_table + 2 * ia, a0 * (1.0f - w[i][0]));
-        unsafeAtomicAdd(level_table + 2 * ia + 1, a1 * (1.0f - w[i][0]));
-        unsafeAtomicAdd(level_table + 2 * ib, a0 * w[i][0]);
-        unsafeAtomicAdd(level_table + 2 * ib + 1, a1 * w[i][0]);
+        fallback_add(level_table, lvl[i], (uint32_t)ia, a0 * (1.0f - w[i][0]), a1 * (1.0f - w[i][0]), deferred);
+        fallback_add(level_table, lvl[i], (uint32_t)ib, a0 * w[i][0], a1 * w[i][0], deferred);
       }
     }
   }
@@ -514,7 +538,7 @@ __global__ __launch_bounds__(kBinThreads) void hash_bwd_bin_fine_kernel(
 // Pass 2: one workgroup per (level, tile) streams the tile's queue into LDS and adds the finished tile to the table.
 __global__ void hash_bwd_apply_kernel(nsamd_grid grid, int slice_log2, uint32_t cap, int level0,
                                       const uint32_t* __restrict__ cursors, const uint4* __restrict__ queues,
-                                      float* __restrict__ dtable) {
+                                      float* __restrict__ dtable, int overwrite) {
   extern __shared__ __attribute__((aligned(16))) float acc[];
   const int bin = blockIdx.x, level = level0 + blockIdx.y;
   const int B = gridDim.x;
@@ -580,11 +604,34 @@ __global__ void hash_bwd_apply_kernel(nsamd_grid grid, int slice_log2, uint32_t 
   float4* out = reinterpret_cast<float4*>(
       dtable + ((((size_t)level << grid.log2_table_size) + ((size_t)bin << slice_log2)) << 1));
   const float4* a4 = reinterpret_cast<const float4*>(acc);
+  if (overwrite) {  // write-only gradient: no zero-fill before the call, no read here
+    for (int i = threadIdx.x; i < entries / 2; i += blockDim.x) out[i] = a4[i];
+    return;
+  }
   for (int i = threadIdx.x; i < entries / 2; i += blockDim.x) {  // sole owner of the tile: plain read-modify-write
     float4 o = out[i];
     const float4 a = a4[i];
     o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
     out[i] = o;
+  }
+}
+
+// Applies the deferred updates of a write-only call after pass 2 (normally none: one workgroup, returns at once) and
+// leaves the counter at zero for the next call.
+__global__ void hash_bwd_deferred_kernel(nsamd_grid grid, uint32_t* __restrict__ count, const uint4* __restrict__ list,
+                                         uint32_t cap, float* __restrict__ dtable) {
+  const uint32_t n = min(count[0], cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint4 r = list[i];
+    float* t = dtable + ((((size_t)r.y << grid.log2_table_size) + r.x) << 1);
+    unsafeAtomicAdd(t, __uint_as_float(r.z));
+    unsafeAtomicAdd(t + 1, __uint_as_float(r.w));
+  }
+  __syncthreads();
+  // count[1] = ticket: the last workgroup to finish (every workgroup has read count[0] by then) resets both
+  if (threadIdx.x == 0 && atomicAdd(count + 1, 1u) == gridDim.x - 1) {
+    count[0] = 0u;
+    count[1] = 0u;
   }
 }
 
@@ -763,6 +810,7 @@ struct ScatterPlan {
   int slice_log2, bins;
   int64_t tiles, cursor_words;
   uint32_t cap;
+  int64_t deferred_cap;  // records of the deferred list (write-only calls), 0 = none
 };
 
 static bool sl_too_wide(int sl) { return sl > 14; }  // local indices are 14-bit
@@ -783,10 +831,17 @@ static ScatterPlan scatter_geometry(const nsamd_grid& grid) {
 
 static int64_t scatter_expected_records(const ScatterPlan& p, int64_t M) { return (8 * M + p.bins - 1) / p.bins; }
 
-static ScatterPlan scatter_plan(const nsamd_grid& grid, int64_t M, const float* workspace, int64_t workspace_floats) {
+// worst case of deferred updates: every corner update of the call
+static int64_t scatter_deferred_cap(const nsamd_grid& grid, int64_t M) { return 8 * M * grid.num_levels; }
+
+// workspace = [cursors: cursor_words][deferred count: 4 words][queues: tiles x cap x 4][deferred list: deferred_cap x 4]
+static ScatterPlan scatter_plan(const nsamd_grid& grid, int64_t M, const float* workspace, int64_t workspace_floats,
+                                bool overwrite) {
   ScatterPlan p = scatter_geometry(grid);
   if (workspace == nullptr || p.bins > kMaxBins || sl_too_wide(p.slice_log2)) return p;
-  const int64_t cap = (workspace_floats - p.cursor_words) / (4 * p.tiles);
+  p.deferred_cap = overwrite ? scatter_deferred_cap(grid, M) : 0;
+  if (p.deferred_cap > 0xffffffffLL) return p;
+  const int64_t cap = (workspace_floats - p.cursor_words - 4 - 4 * p.deferred_cap) / (4 * p.tiles);
   const int64_t expect = scatter_expected_records(p, M);
   p.ok = cap >= expect + expect / 4 && cap < 0x7fffffffLL;
   p.cap = p.ok ? (uint32_t)cap : 0u;
@@ -804,11 +859,11 @@ static int device_cus() {
   return cached;
 }
 
-extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb,
-                                         const float* table, nsamd_grid grid, const float* denc, int64_t stride_p,
-                                         int64_t stride_k, float* dtable, float* dpositions, float* workspace,
-                                         int64_t workspace_floats, nsamd_stream_t stream) {
-  if (M == 0) return NSAMD_OK;
+static int hashgrid_encode_bwd_impl(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
+                                    nsamd_grid grid, const float* denc, int64_t stride_p, int64_t stride_k,
+                                    float* dtable, float* dpositions, float* workspace, int64_t workspace_floats,
+                                    bool overwrite, nsamd_stream_t stream) {
+  if (M == 0 && !overwrite) return NSAMD_OK;
   int st = check_points(pts, M);
   if (st) return st;
   st = check_grid(grid);
@@ -816,6 +871,16 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
   NSAMD_REQUIRE(denc != nullptr);
   NSAMD_REQUIRE(transform >= 0 && transform <= 2);
   NSAMD_REQUIRE(dtable != nullptr || dpositions != nullptr);
+  if (overwrite) {
+    // write-only table gradient: the binned path overwrites every tile; anything else zero-fills first
+    NSAMD_REQUIRE(dtable != nullptr);
+    if (M < 8192 || !scatter_plan(grid, M, workspace, workspace_floats, true).ok) {
+      if (hipMemsetAsync(dtable, 0, sizeof(float) * 2 * ((size_t)grid.num_levels << grid.log2_table_size),
+                         (hipStream_t)stream) != hipSuccess)
+        return NSAMD_ERR_LAUNCH;
+      overwrite = false;
+    }
+  }
   if (M == 0) return NSAMD_OK;
   const int64_t nb = (M + kHashBlock - 1) / kHashBlock;
   if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
@@ -825,19 +890,31 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
     hash_encode_bwd_table_kernel<<<g, kHashBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, grid, denc,
                                                                              stride_p, stride_k, dtable);
     NSAMD_CHECK_LAUNCH();
-  } else if (dtable != nullptr && scatter_plan(grid, M, workspace, workspace_floats).ok) {
-    const ScatterPlan plan = scatter_plan(grid, M, workspace, workspace_floats);
+  } else if (dtable != nullptr && scatter_plan(grid, M, workspace, workspace_floats, overwrite).ok) {
+    const ScatterPlan plan = scatter_plan(grid, M, workspace, workspace_floats, overwrite);
     const int sl = plan.slice_log2, B = plan.bins;
     const uint32_t cap = plan.cap;
     uint32_t* cursors = reinterpret_cast<uint32_t*>(workspace);
-    uint4* queues = reinterpret_cast<uint4*>(cursors + plan.cursor_words);  // 16-B aligned
+    uint4* queues = reinterpret_cast<uint4*>(cursors + plan.cursor_words + 4);  // 16-B aligned
+    Deferred deferred{nullptr, nullptr, 0u};
+    if (overwrite) {
+      deferred.count = cursors + plan.cursor_words;
+      deferred.list = queues + (size_t)plan.tiles * cap;
+      deferred.cap = (uint32_t)plan.deferred_cap;
+    }
     hipStream_t st = (hipStream_t)stream;
     // Coarse levels go through the run-merging / combining kernel: those whose cells are wide against the sample
-    // spacing (resolution below the samples per ray) or that have few entries anyway (resolution < 64). Measured
-    // optimum on MI355X for S = 48 / 96 / 256 (profiles/r01_scatter_*): finer levels overflow the workgroup's table.
+    // spacing. Measured on MI355X (bench workload, profiles/r01_scatter_*): resolution < samples per ray / 2 (at least
+    // 24) — 16, 22 of the main grid (S = 48), 16, 32 of the second proposal grid (S = 96); finer levels overflow the
+    // workgroup's 4096-slot table and every overflow is a deferred / direct atomic. With >= 192 samples per ray a
+    // workgroup holds only 4 rays and every level of the (small) proposal grid pays off.
     static const int combine_env = env_int("NSAMD_SCATTER_COMBINE_RES", 0);  // > 0 overrides the rule (experiments)
-    float coarse_below = 64.0f;
-    if (pts.positions == nullptr && (float)pts.samples_per_ray > coarse_below) coarse_below = (float)pts.samples_per_ray;
+    float coarse_below = 24.0f;
+    if (pts.positions == nullptr) {
+      const float S = (float)pts.samples_per_ray;
+      coarse_below = fmaxf(24.0f, 0.5f * S);
+      if (pts.samples_per_ray >= 192) coarse_below = S;
+    }
     if (combine_env > 0) coarse_below = (float)combine_env;
     uint32_t coarse_mask = 0;
     for (int l = 0; l < grid.num_levels; ++l)
@@ -864,17 +941,17 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
     if (fine.count > 0 && fine_env >= 4) {
       dim3 g1(point_blocks, (unsigned)((fine.count + 3) / 4));
       hash_bwd_bin_fine_kernel<4><<<g1, kBinThreads, sizeof(uint32_t) * 2 * 4 * (size_t)B, st>>>(
-          pts, M, transform, aabb, grid, denc, stride_p, stride_k, sl, cap, fine, cursors, queues, dtable);
+          pts, M, transform, aabb, grid, denc, stride_p, stride_k, sl, cap, fine, cursors, queues, dtable, deferred);
       NSAMD_CHECK_LAUNCH();
     } else if (fine.count > 0 && fine_env >= 2) {
       dim3 g1(point_blocks, (unsigned)((fine.count + 1) / 2));
       hash_bwd_bin_fine_kernel<2><<<g1, kBinThreads, sizeof(uint32_t) * 2 * 2 * (size_t)B, st>>>(
-          pts, M, transform, aabb, grid, denc, stride_p, stride_k, sl, cap, fine, cursors, queues, dtable);
+          pts, M, transform, aabb, grid, denc, stride_p, stride_k, sl, cap, fine, cursors, queues, dtable, deferred);
       NSAMD_CHECK_LAUNCH();
     } else if (fine.count > 0) {
       dim3 g1(point_blocks, (unsigned)fine.count);
       hash_bwd_bin_fine_kernel<1><<<g1, kBinThreads, sizeof(uint32_t) * 2 * (size_t)B, st>>>(
-          pts, M, transform, aabb, grid, denc, stride_p, stride_k, sl, cap, fine, cursors, queues, dtable);
+          pts, M, transform, aabb, grid, denc, stride_p, stride_k, sl, cap, fine, cursors, queues, dtable, deferred);
       NSAMD_CHECK_LAUNCH();
     }
     if (coarse.count > 0) {
@@ -886,16 +963,20 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
       dim3 g1((unsigned)((M + per_block - 1) / per_block), (unsigned)coarse.count);
       if (bits == 11)
         hash_bwd_bin_runs_kernel<4, 11><<<g1, kRunThreads, bin_lds, st>>>(pts, M, transform, aabb, grid, denc, stride_p,
-                                                                          stride_k, sl, cap, coarse, cursors, queues, dtable);
+                                                                          stride_k, sl, cap, coarse, cursors, queues, dtable, deferred);
       else
         hash_bwd_bin_runs_kernel<4, 12><<<g1, kRunThreads, bin_lds, st>>>(pts, M, transform, aabb, grid, denc, stride_p,
-                                                                          stride_k, sl, cap, coarse, cursors, queues, dtable);
+                                                                          stride_k, sl, cap, coarse, cursors, queues, dtable, deferred);
       NSAMD_CHECK_LAUNCH();
     }
     dim3 g2((unsigned)B, (unsigned)nl);
     hash_bwd_apply_kernel<<<g2, threads, sizeof(float) * 2 * ((size_t)1 << sl), st>>>(grid, sl, cap, l0, cursors,
-                                                                                    queues, dtable);
+                                                                                    queues, dtable, overwrite ? 1 : 0);
     NSAMD_CHECK_LAUNCH();
+    if (overwrite) {
+      hash_bwd_deferred_kernel<<<64, 256, 0, st>>>(grid, deferred.count, deferred.list, deferred.cap, dtable);
+      NSAMD_CHECK_LAUNCH();
+    }
   } else if (dtable != nullptr) {
     const int slice_log2 = grid.log2_table_size < kSliceLog2Max ? grid.log2_table_size : kSliceLog2Max;
     const int slices = 1 << (grid.log2_table_size - slice_log2);
@@ -945,12 +1026,28 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
   return NSAMD_OK;
 }
 
-extern "C" int64_t nsamd_hashgrid_encode_bwd_workspace(nsamd_grid grid, int64_t M) {
+extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb,
+                                         const float* table, nsamd_grid grid, const float* denc, int64_t stride_p,
+                                         int64_t stride_k, float* dtable, float* dpositions, float* workspace,
+                                         int64_t workspace_floats, nsamd_stream_t stream) {
+  return hashgrid_encode_bwd_impl(pts, M, transform, aabb, table, grid, denc, stride_p, stride_k, dtable, dpositions,
+                                  workspace, workspace_floats, false, stream);
+}
+
+extern "C" int nsamd_hashgrid_encode_bwd_set(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb,
+                                             const float* table, nsamd_grid grid, const float* denc, int64_t stride_p,
+                                             int64_t stride_k, float* dtable, float* dpositions, float* workspace,
+                                             int64_t workspace_floats, nsamd_stream_t stream) {
+  return hashgrid_encode_bwd_impl(pts, M, transform, aabb, table, grid, denc, stride_p, stride_k, dtable, dpositions,
+                                  workspace, workspace_floats, true, stream);
+}
+
+extern "C" int64_t nsamd_hashgrid_encode_bwd_workspace(nsamd_grid grid, int64_t M, int write_only) {
   if (M < 8192 || check_grid(grid) != NSAMD_OK) return 0;
   const ScatterPlan p = scatter_geometry(grid);
   if (p.bins > kMaxBins) return 0;
   const int64_t cap = 2 * scatter_expected_records(p, M) + 64;
-  return p.cursor_words + 4 * p.tiles * cap;
+  return p.cursor_words + 4 + 4 * p.tiles * cap + (write_only ? 4 * scatter_deferred_cap(grid, M) : 0);
 }
 
 extern "C" int nsamd_sh4_encode(const float* dirs, int64_t M, float* out, nsamd_stream_t stream) {

@@ -144,14 +144,14 @@ def field_bwd_workspace(device) -> Tuple[Tensor, int]:
     return ws, ws.numel()
 
 
-def _scatter_workspace(grid: HashGridSpec, device, num_points: int = 0) -> Tuple[Optional[Tensor], int]:
+def _scatter_workspace(grid: HashGridSpec, device, num_points: int = 0, write_only: bool = False) -> Tuple[Optional[Tensor], int]:
     """Device scratch for the table-gradient scatter (csrc/hashgrid.hip, "binned" path): per (level, tile) a cursor and
     a queue of pair records; the library says how many words it wants (nsamd_hashgrid_encode_bwd_workspace). Zeroed
     once here (the kernels leave the cursors at zero), cached per (grid, M)."""
-    words = int(N.load().nsamd_hashgrid_encode_bwd_workspace(grid.native(), num_points))
+    words = int(N.load().nsamd_hashgrid_encode_bwd_workspace(grid.native(), num_points, 1 if write_only else 0))
     if words <= 0:
         return None, 0
-    key = (grid, num_points, str(device))
+    key = (grid, num_points, str(device), write_only)
     ws = _SCATTER_WS.get(key)
     if ws is None:
         ws = torch.zeros(words, device=device, dtype=torch.float32)

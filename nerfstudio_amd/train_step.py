@@ -159,6 +159,14 @@ class NerfactoTrainStep:
         self.forward_and_losses(updated, draw_jitter)
         self.backward_main()
 
+    def written_params(self):
+        """Parameters whose gradient this runner WRITES (hash tables, nsamd_hashgrid_encode_bwd_set): callers need not
+        zero them (ParamArena.zero_grad(skip=...)). All other gradients accumulate and must be zeroed first."""
+        tables = [self.model.field.mlp_base.encoding.hash_table]
+        if not self.cfg.use_same_proposal_network:  # a shared network gets one gradient contribution per level: accumulate
+            tables += [net.encoding.hash_table for net in self.props]
+        return tables
+
     def forward_and_losses(self, updated: bool, draw_jitter: bool = True) -> None:
         self.forward_proposals(draw_jitter)
         self.forward_main_and_losses(updated)
@@ -248,8 +256,8 @@ class NerfactoTrainStep:
         ck(lib.nsamd_field_mlp_bwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
                                    N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s), N.ptr(self.f_denc), grads, N.ptr(self.field_ws),
                                    self.field_ws.numel(), st), "field_mlp_bwd")
-        ws, ws_n = F._scatter_workspace(enc.spec, self.f_enc.device, mm)
-        ck(lib.nsamd_hashgrid_encode_bwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
+        ws, ws_n = F._scatter_workspace(enc.spec, self.f_enc.device, mm, write_only=True)
+        ck(lib.nsamd_hashgrid_encode_bwd_set(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
                                          enc.spec.native(), N.ptr(self.f_denc), 1, mm, N.ptr(self._grad(enc.hash_table)),
                                          None, N.ptr(ws), ws_n, st), "hashgrid_encode_bwd")
 
@@ -274,8 +282,10 @@ class NerfactoTrainStep:
                                              N.ptr(self._grad(b0)), N.ptr(self._grad(W1)), N.ptr(self._grad(b1)), st),
                    "density_mlp_bwd")
                 spec = net.encoding.spec
-                ws, ws_n = F._scatter_workspace(spec, self.f_enc.device, m)
-                ck(lib.nsamd_hashgrid_encode_bwd(self._points(lvl), m, net._transform, net._box,
+                shared = self.cfg.use_same_proposal_network
+                ws, ws_n = F._scatter_workspace(spec, self.f_enc.device, m, write_only=not shared)
+                scatter = lib.nsamd_hashgrid_encode_bwd if shared else lib.nsamd_hashgrid_encode_bwd_set
+                ck(scatter(self._points(lvl), m, net._transform, net._box,
                                                  N.ptr(net.encoding.hash_table), spec.native(), N.ptr(self.p_denc[lvl]), 1, m,
                                                  N.ptr(self._grad(net.encoding.hash_table)), None, N.ptr(ws), ws_n, st),
                    "hashgrid_encode_bwd")

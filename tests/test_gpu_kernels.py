@@ -838,3 +838,25 @@ def test_table_scatter_binned_equals_scan_path(F, S, levels, log2_T, max_res):
             scale = float(ref.abs().max())
             assert float((got - ref).abs().max()) <= 2e-5 * scale, (S, zero_frac, float((got - ref).abs().max()), scale)
             assert int((ref != 0).sum()) > 0
+            # write-only variant: the gradient buffer starts as garbage and must come back complete
+            ws2, ws2_n = F._scatter_workspace(spec, torch.device("cuda"), M, write_only=True)
+            got2 = torch.full_like(table, float("nan"))
+            N.check(lib.nsamd_hashgrid_encode_bwd_set(P, M, N.XFORM_CONTRACT, N.Aabb(), N.ptr(table), spec.native(),
+                                                      N.ptr(denc), 1, M, N.ptr(got2), None, N.ptr(ws2), ws2_n, N.stream()),
+                    "binned, write-only")
+            assert float((got2 - ref).abs().max()) <= 2e-5 * scale
+    # degenerate batch: every ray identical -> a handful of tiles receive everything, their queues overflow and the
+    # updates go through the direct-atomic (accumulate) / deferred-list (write-only) paths
+    o1, d1 = o[:1].expand(n, 3).contiguous(), d[:1].expand(n, 3).contiguous()
+    t1 = t_uniform[:1].expand(n, S + 1).contiguous()
+    P = N.make_points(None, o1, d1, t1, S)
+    denc = torch.randn(spec.out_dim, M, device="cuda")
+    ws, ws_n = F._scatter_workspace(spec, torch.device("cuda"), M)
+    ws2, ws2_n = F._scatter_workspace(spec, torch.device("cuda"), M, write_only=True)
+    got, got2, ref = torch.zeros_like(table), torch.full_like(table, float("nan")), torch.zeros_like(table)
+    for fn, out, w, wn in ((lib.nsamd_hashgrid_encode_bwd, got, ws, ws_n), (lib.nsamd_hashgrid_encode_bwd_set, got2, ws2, ws2_n),
+                           (lib.nsamd_hashgrid_encode_bwd, ref, None, 0)):
+        N.check(fn(P, M, N.XFORM_CONTRACT, N.Aabb(), N.ptr(table), spec.native(), N.ptr(denc), 1, M, N.ptr(out), None,
+                   N.ptr(w) if w is not None else None, wn, N.stream()), "degenerate")
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 1e-4 * scale and float((got2 - ref).abs().max()) <= 1e-4 * scale
