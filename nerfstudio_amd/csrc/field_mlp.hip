@@ -628,28 +628,40 @@ __device__ __forceinline__ float* dw_destination(int e, const nsamd_field_mlp_gr
   return nullptr;
 }
 
-// grads[...] += sum over workgroups of their partial weight gradients. 64 elements x 4 partial-groups per workgroup
-// (196 workgroups instead of 49: the 12.8 MB of partials is read with 4x the memory-level parallelism); the 4 group
-// sums meet in LDS and one thread per element does the single-writer update.
-__global__ __launch_bounds__(256) void field_dw_reduce_kernel(const float* __restrict__ partials, int num_partials,
-                                                              nsamd_field_mlp_grads grads, int app_dim) {
-  __shared__ float part[4][64];
+// grads[...] += sum over workgroups of their partial weight gradients. 64 elements x 16 partial-groups per workgroup:
+// every thread has its <= 16 loads in flight at once (the 12.8 MB of partials are a pure latency problem: the first
+// version walked 64 partials per thread two at a time and took 15 us); the 16 group sums meet in LDS and one thread per
+// element does the single-writer update.
+constexpr int kReduceGroups = 16;
+__global__ __launch_bounds__(64 * kReduceGroups) void field_dw_reduce_kernel(const float* __restrict__ partials,
+                                                                             int num_partials,
+                                                                             nsamd_field_mlp_grads grads, int app_dim) {
+  __shared__ float part[kReduceGroups][64];
   const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + el;
-  float s0 = 0.f, s1 = 0.f;
+  float s = 0.f;
   if (e < kPartialStride) {
-    int b = grp;
-    for (; b + 4 < num_partials; b += 8) {
-      s0 += partials[(size_t)b * kPartialStride + e];
-      s1 += partials[(size_t)(b + 4) * kPartialStride + e];
+    for (int b0 = grp; b0 < num_partials; b0 += kReduceGroups * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int b = b0 + u * kReduceGroups;
+        v[u] = b < num_partials ? partials[(size_t)b * kPartialStride + e] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
     }
-    for (; b < num_partials; b += 4) s0 += partials[(size_t)b * kPartialStride + e];
   }
-  part[grp][el] = s0 + s1;
+  part[grp][el] = s;
   __syncthreads();
   if (grp == 0 && e < kPartialStride) {
     float* dst = dw_destination(e, grads, app_dim);
-    if (dst != nullptr) *dst += (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+    if (dst != nullptr) {
+      float t = 0.f;
+#pragma unroll
+      for (int g2 = 0; g2 < kReduceGroups; ++g2) t += part[g2][el];
+      *dst += t;
+    }
   }
 }
 
@@ -739,7 +751,7 @@ extern "C" int nsamd_field_mlp_bwd(const float* enc, const float* selector, cons
       grads, partials);
   NSAMD_CHECK_LAUNCH();
   if (partials != nullptr) {
-    field_dw_reduce_kernel<<<(kPartialStride + 63) / 64, 256, 0, (hipStream_t)stream>>>(partials, (int)blocks, grads,
+    field_dw_reduce_kernel<<<(kPartialStride + 63) / 64, 64 * kReduceGroups, 0, (hipStream_t)stream>>>(partials, (int)blocks, grads,
                                                                                       app_dim);
     NSAMD_CHECK_LAUNCH();
   }
