@@ -332,10 +332,12 @@ def algorithmic_model(key):
         L, M = int(m.group(1)), int(m.group(2))
         return "hbm", M * L * 8 * 16  # read-modify-write of 8 corners x 8 B
     M_main = RAYS_PER_GPU * 48
-    if key == "nsamd_field_mlp_fwd":
+    if key in ("nsamd_field_mlp_fwd", "nsamd_field_mlp_fwd_save"):
         return "mfma", M_main * 2 * 11392  # MACs/sample: 32*64 + 64*16 + 63*64 + 64*64 + 64*3  
     if key == "nsamd_field_mlp_bwd":
         return "mfma", M_main * 2 * 11392 * 3  # recompute + data gradient + weight gradient
+    if key == "nsamd_field_mlp_bwd_saved":
+        return "mfma", M_main * 2 * 11392 * 2  # data gradient + weight gradient (activations loaded, not recomputed)
     m2 = re.search(r"\[M=(\d+)\]", key)
     if key.startswith("nsamd_density_mlp_fwd") and m2:
         return "hbm", int(m2.group(1)) * (10 * 4 + 4 + 8)  # enc row + selector in, density + pre out

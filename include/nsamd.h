@@ -180,6 +180,19 @@ int nsamd_field_mlp_bwd(const float* enc, const float* selector, const float* di
                         nsamd_field_mlp_grads grads, float* workspace, int64_t workspace_floats,
                         nsamd_stream_t stream);
 
+/* Training-step pair that trades HBM for MFMA time: the forward also writes the activations the backward needs
+ * (`saved`: nsamd_field_mlp_saved_floats(M) floats = 896 B per point, chain-layout fragments), and the backward loads
+ * them instead of recomputing the forward — a third of its matrix work. Same outputs as the plain pair. */
+int64_t nsamd_field_mlp_saved_floats(int64_t M);
+int nsamd_field_mlp_fwd_save(const float* enc, const float* selector, const float* directions,
+                             const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
+                             nsamd_field_mlp mlp, float* density, float* rgb, float* saved, nsamd_stream_t stream);
+int nsamd_field_mlp_bwd_saved(const float* enc, const float* selector, const float* directions,
+                              const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
+                              nsamd_field_mlp mlp, const float* saved, const float* ddensity, const float* drgb,
+                              float* denc, nsamd_field_mlp_grads grads, float* workspace, int64_t workspace_floats,
+                              nsamd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Generic dense layer for the stand-alone MLP of the plugin API (MLP.pytorch_fwd, field_components/mlp.py:160-179):
  * y[M,N] = act(x[M,K] W[N,K]^T + b[N]); activation 0 = none, 1 = ReLU, 2 = Sigmoid; K, N <= 128; fp32 MFMA.

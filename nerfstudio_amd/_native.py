@@ -66,6 +66,9 @@ _SIGNATURES = {
     "nsamd_density_mlp_bwd": [vp, vp, vp, vp, i64, DensityMlp, vp, vp, vp, vp, vp, vp],
     "nsamd_field_mlp_fwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp],
     "nsamd_field_mlp_bwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp, i64, vp],
+    "nsamd_field_mlp_saved_floats": [i64],
+    "nsamd_field_mlp_fwd_save": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, vp],
+    "nsamd_field_mlp_bwd_saved": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, vp, FieldMlpGrads, vp, i64, vp],
     "nsamd_linear_fwd": [vp, vp, vp, i64, i32, i32, C.c_int, vp, vp],
     "nsamd_linear_bwd": [vp, vp, vp, vp, i64, i32, i32, C.c_int, vp, vp, vp, vp],
     "nsamd_piecewise_bins": [vp, vp, vp, vp, i64, i32, C.c_int, vp, vp, vp],
@@ -89,7 +92,7 @@ _SIGNATURES = {
     "nsamd_probe_mfma16": [vp, vp, vp, vp],
 }
 _RESTYPES = {"nsamd_version": C.c_char_p, "nsamd_status_string": C.c_char_p,
-             "nsamd_hashgrid_encode_bwd_workspace": C.c_int64}
+             "nsamd_hashgrid_encode_bwd_workspace": C.c_int64, "nsamd_field_mlp_saved_floats": C.c_int64}
 
 _lib = None
 

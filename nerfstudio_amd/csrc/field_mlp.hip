@@ -123,6 +123,63 @@ struct FieldActs {
   v4f rgbp[1];    // rgb pre-sigmoid (rows 0..2 of tile 0)
 };
 
+// Activations the backward needs, saved by the forward of a training step (nsamd_field_mlp_fwd_save) so that the backward
+// does not recompute the forward (a third of its MFMAs): per 16-point tile 14 fragments in the chain layout,
+// acts[tile][slot][lane] (v4f): h1[0..3], o16, ha[0..3], hb[0..3], rgbp. 896 B per point, fully coalesced.
+constexpr int kActSlots = 14;
+
+__device__ __forceinline__ void store_acts(float* __restrict__ acts, int64_t tile, int lane, const FieldActs& A) {
+  v4f* dst = reinterpret_cast<v4f*>(acts) + (tile * kActSlots) * 64 + lane;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) dst[t * 64] = A.h1[t];
+  dst[4 * 64] = A.o16[0];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) dst[(5 + t) * 64] = A.ha[t];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) dst[(9 + t) * 64] = A.hb[t];
+  dst[13 * 64] = A.rgbp[0];
+}
+
+__device__ __forceinline__ void load_acts(const float* __restrict__ acts, int64_t tile, int lane, FieldActs& A) {
+  const v4f* src = reinterpret_cast<const v4f*>(acts) + (tile * kActSlots) * 64 + lane;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) A.h1[t] = src[t * 64];
+  A.o16[0] = src[4 * 64];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) A.ha[t] = src[(5 + t) * 64];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) A.hb[t] = src[(9 + t) * 64];
+  A.rgbp[0] = src[13 * 64];
+}
+
+// head input slots of a tile from saved / recomputed pieces: SH of the view direction, base outputs, appearance row
+__device__ __forceinline__ void build_head_input(const float* __restrict__ directions,
+                                                 const float* __restrict__ app_table,
+                                                 const float* __restrict__ app_const, int64_t dir_group, int app_dim,
+                                                 const TileInputs& ti, int lane, FieldActs& A) {
+  const int g = lane >> 4;
+  const float* d = directions + 3 * (ti.p / dir_group);
+  float sh[16];
+  sh4_components((d[0] + 1.0f) / 2.0f, (d[1] + 1.0f) / 2.0f, (d[2] + 1.0f) / 2.0f, sh);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v = sh[r];
+    v = (g == 1) ? sh[4 + r] : v;
+    v = (g == 2) ? sh[8 + r] : v;
+    v = (g == 3) ? sh[12 + r] : v;
+    A.hin[0][r] = v;
+  }
+  A.hin[1] = A.o16[0];
+  if (app_dim > 0) {
+    const float* src = (app_table != nullptr) ? app_table + ti.cam * 32 : app_const;
+    A.hin[2] = *reinterpret_cast<const v4f*>(src + 4 * g);
+    A.hin[3] = *reinterpret_cast<const v4f*>(src + 16 + 4 * g);
+  } else {
+    A.hin[2] = v4f{0.f, 0.f, 0.f, 0.f};
+    A.hin[3] = v4f{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 // encoded features: feature-major [32][M]; lane needs features 16t + 4g + r of its point
 __device__ __forceinline__ void load_enc_tile(const float* __restrict__ enc, int64_t M, int64_t p, int lane, v4f* out) {
   const int g = lane >> 4;
@@ -204,7 +261,8 @@ __device__ void stage_all_fwd(float* wf, float* bias, const nsamd_field_mlp& mlp
 __global__ __launch_bounds__(kFieldThreads, 2) void field_mlp_fwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
-    nsamd_field_mlp mlp, int app_dim, float* __restrict__ density, float* __restrict__ rgb) {
+    nsamd_field_mlp mlp, int app_dim, float* __restrict__ density, float* __restrict__ rgb,
+    float* __restrict__ acts) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* wf = lds;
   float* bias = lds + kFragTotal;
@@ -221,6 +279,7 @@ __global__ __launch_bounds__(kFieldThreads, 2) void field_mlp_fwd_kernel(
     FieldActs A;
     load_enc_tile(enc, M, ti.p, lane, A.enc);
     field_forward_tile(wf, bias, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A);
+    if (acts != nullptr) store_acts(acts, tile, lane, A);
     if (lane < 16 && ti.live) {  // g == 0 holds neurons 0..3 of tile 0
       density[ti.p] = mlp.average_init_density * expf(A.o16[0][0]) * ti.sel;
       float* o = rgb + 3 * ti.p;
@@ -405,7 +464,8 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
     nsamd_field_mlp mlp, int app_dim, const float* __restrict__ ddensity, const float* __restrict__ drgb,
-    float* __restrict__ denc, nsamd_field_mlp_grads grads, float* __restrict__ partials) {
+    float* __restrict__ denc, nsamd_field_mlp_grads grads, float* __restrict__ partials,
+    const float* __restrict__ acts) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* W = lds;                     // kRowTotal
   float* bias = lds + kRowTotal;      // 256
@@ -455,7 +515,12 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     if (tile >= tiles) ti.live = false;  // idle wave of the last round: computes, contributes zeros
     FieldActs A;
     load_enc_tile(enc, M, ti.p, lane, A.enc);
-    coop_forward_tile(W, bias, directions, app_table, app_const, dir_group, app_dim, ti, lane, A);
+    if (acts != nullptr) {  // saved by the forward of this step: no recomputation
+      load_acts(acts, tile < tiles ? tile : tiles - 1, lane, A);
+      build_head_input(directions, app_table, app_const, dir_group, app_dim, ti, lane, A);
+    } else {
+      coop_forward_tile(W, bias, directions, app_table, app_const, dir_group, app_dim, ti, lane, A);
+    }
 
     // ---- head layer 2 (64 -> 3, sigmoid) ----
     v4f g_rgbp[1];
@@ -707,10 +772,9 @@ static int num_cus() {
   return cached;
 }
 
-extern "C" int nsamd_field_mlp_fwd(const float* enc, const float* selector, const float* directions,
-                                   const int64_t* camera_indices, const float* appearance_const, int64_t dir_group,
-                                   int64_t M, nsamd_field_mlp mlp, float* density, float* rgb,
-                                   nsamd_stream_t stream) {
+static int field_mlp_fwd_impl(const float* enc, const float* selector, const float* directions,
+                              const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
+                              nsamd_field_mlp mlp, float* density, float* rgb, float* acts, nsamd_stream_t stream) {
   if (M == 0) return NSAMD_OK;
   int app_dim = 0;
   int st = field_common_checks(enc, directions, dir_group, M, mlp, camera_indices, appearance_const, &app_dim);
@@ -720,16 +784,35 @@ extern "C" int nsamd_field_mlp_fwd(const float* enc, const float* selector, cons
   const int64_t tiles = (M + 15) / 16;
   const unsigned blocks = (unsigned)min((int64_t)num_cus() * 3, (tiles + kWaves - 1) / kWaves);
   field_mlp_fwd_kernel<<<blocks, kFieldThreads, lds, (hipStream_t)stream>>>(
-      enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb);
+      enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb, acts);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }
 
-extern "C" int nsamd_field_mlp_bwd(const float* enc, const float* selector, const float* directions,
+extern "C" int nsamd_field_mlp_fwd(const float* enc, const float* selector, const float* directions,
                                    const int64_t* camera_indices, const float* appearance_const, int64_t dir_group,
-                                   int64_t M, nsamd_field_mlp mlp, const float* ddensity, const float* drgb,
-                                   float* denc, nsamd_field_mlp_grads grads, float* workspace,
-                                   int64_t workspace_floats, nsamd_stream_t stream) {
+                                   int64_t M, nsamd_field_mlp mlp, float* density, float* rgb,
+                                   nsamd_stream_t stream) {
+  return field_mlp_fwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, density,
+                            rgb, nullptr, stream);
+}
+
+extern "C" int64_t nsamd_field_mlp_saved_floats(int64_t M) { return M <= 0 ? 0 : ((M + 15) / 16) * kActSlots * 256; }
+
+extern "C" int nsamd_field_mlp_fwd_save(const float* enc, const float* selector, const float* directions,
+                                        const int64_t* camera_indices, const float* appearance_const,
+                                        int64_t dir_group, int64_t M, nsamd_field_mlp mlp, float* density, float* rgb,
+                                        float* saved, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(M == 0 || saved != nullptr);
+  return field_mlp_fwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, density,
+                            rgb, saved, stream);
+}
+
+static int field_mlp_bwd_impl(const float* enc, const float* selector, const float* directions,
+                              const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
+                              nsamd_field_mlp mlp, const float* ddensity, const float* drgb, float* denc,
+                              nsamd_field_mlp_grads grads, float* workspace, int64_t workspace_floats,
+                              const float* acts, nsamd_stream_t stream) {
   if (M == 0) return NSAMD_OK;
   int app_dim = 0;
   int st = field_common_checks(enc, directions, dir_group, M, mlp, camera_indices, appearance_const, &app_dim);
@@ -748,7 +831,7 @@ extern "C" int nsamd_field_mlp_bwd(const float* enc, const float* selector, cons
   float* partials = (workspace != nullptr && workspace_floats >= (int64_t)blocks * kPartialStride) ? workspace : nullptr;
   field_mlp_bwd_kernel<<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
       enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-      grads, partials);
+      grads, partials, acts);
   NSAMD_CHECK_LAUNCH();
   if (partials != nullptr) {
     field_dw_reduce_kernel<<<(kPartialStride + 63) / 64, 64 * kReduceGroups, 0, (hipStream_t)stream>>>(partials, (int)blocks, grads,
@@ -756,6 +839,26 @@ extern "C" int nsamd_field_mlp_bwd(const float* enc, const float* selector, cons
     NSAMD_CHECK_LAUNCH();
   }
   return NSAMD_OK;
+}
+
+extern "C" int nsamd_field_mlp_bwd(const float* enc, const float* selector, const float* directions,
+                                   const int64_t* camera_indices, const float* appearance_const, int64_t dir_group,
+                                   int64_t M, nsamd_field_mlp mlp, const float* ddensity, const float* drgb,
+                                   float* denc, nsamd_field_mlp_grads grads, float* workspace,
+                                   int64_t workspace_floats, nsamd_stream_t stream) {
+  return field_mlp_bwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, ddensity,
+                            drgb, denc, grads, workspace, workspace_floats, nullptr, stream);
+}
+
+extern "C" int nsamd_field_mlp_bwd_saved(const float* enc, const float* selector, const float* directions,
+                                         const int64_t* camera_indices, const float* appearance_const,
+                                         int64_t dir_group, int64_t M, nsamd_field_mlp mlp, const float* saved,
+                                         const float* ddensity, const float* drgb, float* denc,
+                                         nsamd_field_mlp_grads grads, float* workspace, int64_t workspace_floats,
+                                         nsamd_stream_t stream) {
+  NSAMD_REQUIRE(M == 0 || saved != nullptr);
+  return field_mlp_bwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, ddensity,
+                            drgb, denc, grads, workspace, workspace_floats, saved, stream);
 }
 
 extern "C" int nsamd_probe_mfma16(const float* A, const float* B, float* out, nsamd_stream_t stream) {

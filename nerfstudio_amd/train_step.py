@@ -95,6 +95,13 @@ class NerfactoTrainStep:
         self.p_ddens = [torch.empty_like(t) for t in self.p_dens]
         self.p_denc = [torch.empty_like(t) for t in self.p_enc]
         self.field_ws, _ = F.field_bwd_workspace(device)
+        # Optional (NSAMD_FIELD_SAVE_ACTS=1): the forward saves the main field's activations (896 B per sample) and the
+        # backward loads them instead of recomputing the forward. Measured on MI355X: backward 186 -> 176 us but forward
+        # 60 -> 76 us — the backward is bound by its workgroup barriers, not by the recomputed MFMAs — so off by default.
+        import os
+
+        self.save_acts = os.environ.get("NSAMD_FIELD_SAVE_ACTS", "0") == "1"
+        self.f_saved = e(int(N.load().nsamd_field_mlp_saved_floats(mm))) if self.save_acts else None
         # Second stream for the proposal-network backward: the two backward chains are independent, and since the
         # scatter kernels were reworked (latency-bound phases, small workgroups) they overlap: 3.87 -> 4.02 M rays/s on
         # MI355X (profiles/). `side_stream = None` runs them back to back (the data-parallel path does: its proposal
@@ -221,8 +228,13 @@ class NerfactoTrainStep:
         ck(lib.nsamd_hashgrid_encode_fwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
                                          enc.spec.native(), N.ptr(self.f_enc), 1, mm, N.ptr(self.f_sel), st),
            "hashgrid_encode_fwd")
-        ck(lib.nsamd_field_mlp_fwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
-                                   N.ptr(self.f_dens), N.ptr(self.f_rgb), st), "field_mlp_fwd")
+        if self.save_acts:
+            ck(lib.nsamd_field_mlp_fwd_save(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm,
+                                            fm, N.ptr(self.f_dens), N.ptr(self.f_rgb), N.ptr(self.f_saved), st),
+               "field_mlp_fwd_save")
+        else:
+            ck(lib.nsamd_field_mlp_fwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
+                                       N.ptr(self.f_dens), N.ptr(self.f_rgb), st), "field_mlp_fwd")
         # weights + compositing + MSE value/gradient in one launch (+ the global depth clip)
         ck(lib.nsamd_render_train(N.ptr(self.f_rgb), N.ptr(self.f_dens), N.ptr(self.t_bins[L]), n, S, self.bg_mode,
                                   self.bg_vals, N.ptr(self.target), 1.0 / (3 * n), N.ptr(self.weights[L]), N.ptr(self.rgb),
@@ -253,9 +265,15 @@ class NerfactoTrainStep:
                                       n, S, self.bg_mode, self.bg_vals, N.ptr(self.d_rgb_out), N.ptr(self.dw_dist),
                                       N.ptr(self.d_rgb_s), N.ptr(self.d_dens_main), st), "render_train_bwd")
         grads = N.FieldMlpGrads(*(N.ptr(self._grad(p)) for p in params), N.ptr(self._grad(emb)) if emb is not None else None)
-        ck(lib.nsamd_field_mlp_bwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
-                                   N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s), N.ptr(self.f_denc), grads, N.ptr(self.field_ws),
-                                   self.field_ws.numel(), st), "field_mlp_bwd")
+        if self.save_acts:
+            ck(lib.nsamd_field_mlp_bwd_saved(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S,
+                                             mm, fm, N.ptr(self.f_saved), N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s),
+                                             N.ptr(self.f_denc), grads, N.ptr(self.field_ws), self.field_ws.numel(), st),
+               "field_mlp_bwd_saved")
+        else:
+            ck(lib.nsamd_field_mlp_bwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
+                                       N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s), N.ptr(self.f_denc), grads,
+                                       N.ptr(self.field_ws), self.field_ws.numel(), st), "field_mlp_bwd")
         ws, ws_n = F._scatter_workspace(enc.spec, self.f_enc.device, mm, write_only=True)
         ck(lib.nsamd_hashgrid_encode_bwd_set(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
                                          enc.spec.native(), N.ptr(self.f_denc), 1, mm, N.ptr(self._grad(enc.hash_table)),

@@ -860,3 +860,50 @@ def test_table_scatter_binned_equals_scan_path(F, S, levels, log2_T, max_res):
                    N.ptr(w) if w is not None else None, wn, N.stream()), "degenerate")
     scale = float(ref.abs().max())
     assert float((got - ref).abs().max()) <= 1e-4 * scale and float((got2 - ref).abs().max()) <= 1e-4 * scale
+
+
+def test_field_mlp_saved_activation_pair_equals_recompute(F):
+    """nsamd_field_mlp_fwd_save / _bwd_saved (activations through HBM) against the recomputing pair: same outputs, and
+    gradients equal up to the order of the weight-gradient sums (identical MFMA sequence, so bit-identical here)."""
+    from nerfstudio_amd import _native as N
+
+    lib = N.load()
+    torch.manual_seed(5)
+    M, S = 48 * 211 + 7 * 0, 48  # whole rays
+    M = 48 * 211
+    e = lambda *s: torch.empty(*s, device="cuda")
+    enc = torch.randn(32, M, device="cuda")
+    sel = (torch.rand(M, device="cuda") > 0.1).float()
+    dirs = torch.nn.functional.normalize(torch.randn(M // S, 3, device="cuda"), dim=-1)
+    cams = torch.randint(0, 7, (M // S,), device="cuda")
+    params = [torch.randn(64, 32), torch.randn(64), torch.randn(16, 64), torch.randn(16), torch.randn(64, 63), torch.randn(64),
+              torch.randn(64, 64), torch.randn(64), torch.randn(3, 64), torch.randn(3)]
+    params = [(p * 0.2).cuda().contiguous() for p in params]
+    emb = (torch.randn(7, 32) * 0.3).cuda()
+    fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), 7, 0.01)
+    st = N.stream()
+    dens_a, rgb_a, dens_b, rgb_b = e(M), e(M, 3), e(M), e(M, 3)
+    saved = e(int(lib.nsamd_field_mlp_saved_floats(M)))
+    N.check(lib.nsamd_field_mlp_fwd(N.ptr(enc), N.ptr(sel), N.ptr(dirs), N.ptr(cams), None, S, M, fm, N.ptr(dens_a),
+                                    N.ptr(rgb_a), st), "fwd")
+    N.check(lib.nsamd_field_mlp_fwd_save(N.ptr(enc), N.ptr(sel), N.ptr(dirs), N.ptr(cams), None, S, M, fm, N.ptr(dens_b),
+                                         N.ptr(rgb_b), N.ptr(saved), st), "fwd_save")
+    assert torch.equal(dens_a, dens_b) and torch.equal(rgb_a, rgb_b)
+    dd, dr = torch.randn(M, device="cuda"), torch.randn(M, 3, device="cuda")
+    ws, _ = F.field_bwd_workspace(torch.device("cuda"))
+    outs = []
+    for saved_mode in (False, True):
+        g = [torch.zeros_like(p) for p in params] + [torch.zeros_like(emb)]
+        grads = N.FieldMlpGrads(*(N.ptr(t) for t in g))
+        denc = e(32, M)
+        if saved_mode:
+            N.check(lib.nsamd_field_mlp_bwd_saved(N.ptr(enc), N.ptr(sel), N.ptr(dirs), N.ptr(cams), None, S, M, fm,
+                                                  N.ptr(saved), N.ptr(dd), N.ptr(dr), N.ptr(denc), grads, N.ptr(ws), ws.numel(),
+                                                  st), "bwd_saved")
+        else:
+            N.check(lib.nsamd_field_mlp_bwd(N.ptr(enc), N.ptr(sel), N.ptr(dirs), N.ptr(cams), None, S, M, fm, N.ptr(dd),
+                                            N.ptr(dr), N.ptr(denc), grads, N.ptr(ws), ws.numel(), st), "bwd")
+        outs.append([denc] + g)
+    for a, b in zip(*outs):
+        scale = float(a.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 1e-5 * scale
