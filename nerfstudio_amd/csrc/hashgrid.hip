@@ -205,26 +205,33 @@ constexpr uint32_t kEmptyKey = 0xffffffffu;
 // arrive exactly. Accumulating call: a direct global atomic on the table gradient. Write-only call (`..._set`: pass 2
 // OVERWRITES every tile, so nothing may be added before it): the update is appended to a deferred list sized for the
 // worst case and applied by hash_bwd_deferred_kernel after pass 2.
+constexpr int kDeferredLists = 64;  // sub-lists, each with its own counter: a single counter serialises at ~12 ns/atomic
 struct Deferred {
-  uint32_t* count;  // nullptr: accumulate directly
-  uint4* list;
-  uint32_t cap;
+  uint32_t* count;  // [kDeferredLists] (+ ticket word); nullptr: accumulate directly
+  uint4* list;      // kDeferredLists x sub_cap records
+  uint32_t sub_cap;
 };
 
 __device__ __forceinline__ void fallback_add(float* level_table, int level, uint32_t index, float v0, float v1,
                                              const Deferred& d) {
   if (d.count != nullptr) {
-    // one returning atomic per wavefront, not per lane: the counter is a single address (~12 ns per atomic)
+    // one returning atomic per wavefront and sub-list; a group that does not fit moves on to the next sub-list (the
+    // lists together hold the worst case plus 64 records of slack each, so it always lands)
     const unsigned long long active = __ballot(1);
     const int lane = threadIdx.x & 63;
     const int leader = __builtin_ctzll(active);
-    uint32_t base = 0u;
-    if (lane == leader) base = atomicAdd(d.count, (uint32_t)__builtin_popcountll(active));
-    base = __shfl(base, leader);
-    const uint32_t pos = base + (uint32_t)__builtin_popcountll(active & ((1ull << lane) - 1ull));
-    if (pos < d.cap) {
-      d.list[pos] = make_uint4(index, (uint32_t)level, __float_as_uint(v0), __float_as_uint(v1));
-      return;
+    const uint32_t n = (uint32_t)__builtin_popcountll(active);
+    const uint32_t mine = (uint32_t)__builtin_popcountll(active & ((1ull << lane) - 1ull));
+    for (int t = 0; t < kDeferredLists; ++t) {
+      const uint32_t sub = (blockIdx.x + blockIdx.y * 7u + (uint32_t)t) & (kDeferredLists - 1);
+      uint32_t base = 0u;
+      if (lane == leader) base = atomicAdd(d.count + sub, n);
+      base = __shfl(base, leader);
+      if (base + n <= d.sub_cap) {
+        d.list[(size_t)sub * d.sub_cap + base + mine] =
+            make_uint4(index, (uint32_t)level, __float_as_uint(v0), __float_as_uint(v1));
+        return;
+      }
     }
   }
   unsafeAtomicAdd(level_table + 2 * (size_t)index, v0);
@@ -619,19 +626,27 @@ __global__ void hash_bwd_apply_kernel(nsamd_grid grid, int slice_log2, uint32_t 
 // Applies the deferred updates of a write-only call after pass 2 (normally none: one workgroup, returns at once) and
 // leaves the counter at zero for the next call.
 __global__ void hash_bwd_deferred_kernel(nsamd_grid grid, uint32_t* __restrict__ count, const uint4* __restrict__ list,
-                                         uint32_t cap, float* __restrict__ dtable) {
-  const uint32_t n = min(count[0], cap);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint4 r = list[i];
-    float* t = dtable + ((((size_t)r.y << grid.log2_table_size) + r.x) << 1);
-    unsafeAtomicAdd(t, __uint_as_float(r.z));
-    unsafeAtomicAdd(t + 1, __uint_as_float(r.w));
+                                         uint32_t sub_cap, float* __restrict__ dtable) {
+  for (int sub = 0; sub < kDeferredLists; ++sub) {
+    // a counter can overshoot by groups that moved on to the next list: entries [0, first overshooting base) are valid,
+    // and every group checked base + n <= sub_cap before writing, so clamping is exact for the written prefix only if
+    // groups are written in counter order — they are not; instead every slot a group skipped stays "empty" (level
+    // word = 0xffffffff, set by the previous pass of this kernel)
+    const uint32_t n = min(count[sub], sub_cap);
+    const uint4* l = list + (size_t)sub * sub_cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const uint4 r = l[i];
+      if (r.y == 0xffffffffu) continue;
+      float* t = dtable + ((((size_t)r.y << grid.log2_table_size) + r.x) << 1);
+      unsafeAtomicAdd(t, __uint_as_float(r.z));
+      unsafeAtomicAdd(t + 1, __uint_as_float(r.w));
+      const_cast<uint4*>(l)[i].y = 0xffffffffu;
+    }
   }
   __syncthreads();
-  // count[1] = ticket: the last workgroup to finish (every workgroup has read count[0] by then) resets both
-  if (threadIdx.x == 0 && atomicAdd(count + 1, 1u) == gridDim.x - 1) {
-    count[0] = 0u;
-    count[1] = 0u;
+  // count[kDeferredLists] = ticket: the last workgroup to finish (every workgroup has read the counters by then) resets
+  if (threadIdx.x == 0 && atomicAdd(count + kDeferredLists, 1u) == gridDim.x - 1) {
+    for (int sub = 0; sub <= kDeferredLists; ++sub) count[sub] = 0u;
   }
 }
 
@@ -831,17 +846,22 @@ static ScatterPlan scatter_geometry(const nsamd_grid& grid) {
 
 static int64_t scatter_expected_records(const ScatterPlan& p, int64_t M) { return (8 * M + p.bins - 1) / p.bins; }
 
-// worst case of deferred updates: every corner update of the call
+// worst case of deferred updates: every corner update of the call; split over kDeferredLists sub-lists (+ 64 records of
+// slack each: a wavefront's group needs contiguous room)
 static int64_t scatter_deferred_cap(const nsamd_grid& grid, int64_t M) { return 8 * M * grid.num_levels; }
+static int64_t scatter_deferred_sub_cap(int64_t total) { return (total + kDeferredLists - 1) / kDeferredLists + 64; }
+constexpr int kDeferredCountWords = kDeferredLists + 4;  // counters + ticket, padded to 16 B
 
-// workspace = [cursors: cursor_words][deferred count: 4 words][queues: tiles x cap x 4][deferred list: deferred_cap x 4]
+// workspace = [cursors: cursor_words][deferred counters: 68 words][queues: tiles x cap x 4]
+//             [deferred lists: kDeferredLists x sub_cap x 4]
 static ScatterPlan scatter_plan(const nsamd_grid& grid, int64_t M, const float* workspace, int64_t workspace_floats,
                                 bool overwrite) {
   ScatterPlan p = scatter_geometry(grid);
   if (workspace == nullptr || p.bins > kMaxBins || sl_too_wide(p.slice_log2)) return p;
   p.deferred_cap = overwrite ? scatter_deferred_cap(grid, M) : 0;
-  if (p.deferred_cap > 0xffffffffLL) return p;
-  const int64_t cap = (workspace_floats - p.cursor_words - 4 - 4 * p.deferred_cap) / (4 * p.tiles);
+  if (scatter_deferred_sub_cap(p.deferred_cap) > 0x7fffffffLL) return p;
+  const int64_t deferred_words = overwrite ? 4 * kDeferredLists * scatter_deferred_sub_cap(p.deferred_cap) : 0;
+  const int64_t cap = (workspace_floats - p.cursor_words - kDeferredCountWords - deferred_words) / (4 * p.tiles);
   const int64_t expect = scatter_expected_records(p, M);
   p.ok = cap >= expect + expect / 4 && cap < 0x7fffffffLL;
   p.cap = p.ok ? (uint32_t)cap : 0u;
@@ -895,12 +915,12 @@ static int hashgrid_encode_bwd_impl(nsamd_points pts, int64_t M, int transform, 
     const int sl = plan.slice_log2, B = plan.bins;
     const uint32_t cap = plan.cap;
     uint32_t* cursors = reinterpret_cast<uint32_t*>(workspace);
-    uint4* queues = reinterpret_cast<uint4*>(cursors + plan.cursor_words + 4);  // 16-B aligned
+    uint4* queues = reinterpret_cast<uint4*>(cursors + plan.cursor_words + kDeferredCountWords);  // 16-B aligned
     Deferred deferred{nullptr, nullptr, 0u};
     if (overwrite) {
       deferred.count = cursors + plan.cursor_words;
       deferred.list = queues + (size_t)plan.tiles * cap;
-      deferred.cap = (uint32_t)plan.deferred_cap;
+      deferred.sub_cap = (uint32_t)scatter_deferred_sub_cap(plan.deferred_cap);
     }
     hipStream_t st = (hipStream_t)stream;
     // Coarse levels go through the run-merging / combining kernel: those whose cells are wide against the sample
@@ -956,8 +976,9 @@ static int hashgrid_encode_bwd_impl(nsamd_points pts, int64_t M, int transform, 
     }
     if (coarse.count > 0) {
       static const int bits_env = env_int("NSAMD_SCATTER_TABLE_BITS", 0);  // experiments: force 11 / 12
-      const bool long_rays = pts.positions == nullptr && pts.samples_per_ray >= 192;
-      const int bits = bits_env ? bits_env : (long_rays ? 11 : 12);
+      // (an 11-bit table doubles the occupancy but overflows on dense gradients: 264 vs 275 us when it fits, 1153 us
+      // when it does not, profiles/r01_scatter_runs_kernel_sweeps.log)
+      const int bits = bits_env ? bits_env : 12;
       const size_t bin_lds = sizeof(uint32_t) * (2 * (size_t)B + 3 * ((size_t)1 << bits));
       const int64_t per_block = (int64_t)kRunThreads * 4;
       dim3 g1((unsigned)((M + per_block - 1) / per_block), (unsigned)coarse.count);
@@ -974,7 +995,7 @@ static int hashgrid_encode_bwd_impl(nsamd_points pts, int64_t M, int transform, 
                                                                                     queues, dtable, overwrite ? 1 : 0);
     NSAMD_CHECK_LAUNCH();
     if (overwrite) {
-      hash_bwd_deferred_kernel<<<64, 256, 0, st>>>(grid, deferred.count, deferred.list, deferred.cap, dtable);
+      hash_bwd_deferred_kernel<<<256, 256, 0, st>>>(grid, deferred.count, deferred.list, deferred.sub_cap, dtable);
       NSAMD_CHECK_LAUNCH();
     }
   } else if (dtable != nullptr) {
@@ -1047,7 +1068,8 @@ extern "C" int64_t nsamd_hashgrid_encode_bwd_workspace(nsamd_grid grid, int64_t 
   const ScatterPlan p = scatter_geometry(grid);
   if (p.bins > kMaxBins) return 0;
   const int64_t cap = 2 * scatter_expected_records(p, M) + 64;
-  return p.cursor_words + 4 + 4 * p.tiles * cap + (write_only ? 4 * scatter_deferred_cap(grid, M) : 0);
+  return p.cursor_words + kDeferredCountWords + 4 * p.tiles * cap +
+         (write_only ? 4 * kDeferredLists * scatter_deferred_sub_cap(scatter_deferred_cap(grid, M)) : 0);
 }
 
 extern "C" int nsamd_sh4_encode(const float* dirs, int64_t M, float* out, nsamd_stream_t stream) {

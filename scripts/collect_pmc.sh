@@ -58,11 +58,15 @@ print(open(os.path.join(out, "pmc_summary.csv")).read())
 # ---- HBM-side bytes per launch of the bench's kernel keys (config 2: N = 4096, S = (256, 96, 48))
 def kib(k, c):
     return (mean(agg[k][c]) or 0.0) * 1024.0
-groups = {  # bench key -> (kernel substring, grid) parts; streaming = 16 B/lane coalesced reads dominate the fetches
-    "nsamd_hashgrid_encode_bwd[L=16,M=196608]": [("hash_bwd_bin_fine_kernel<4>", None, False), ("hash_bwd_bin_runs_kernel<4>", "245760", False),
-                                                  ("hash_bwd_apply_kernel", "524288", True)],
+groups = {  # bench key -> (kernel substring, grid, streaming) parts; streaming = 16 B/lane coalesced reads dominate
+    "nsamd_hashgrid_encode_bwd_set[L=16,M=196608]": [("hash_bwd_bin_fine_kernel<4>", "786432", False),
+                                                      ("hash_bwd_bin_runs_kernel<4, 12>", "98304", False),
+                                                      ("hash_bwd_apply_kernel", "524288", True),
+                                                      ("hash_bwd_deferred_kernel", "16384", False)],
+    "nsamd_field_mlp_bwd": [("field_mlp_bwd_kernel", "131072", False), ("field_dw_reduce_kernel", None, False)],
+    "nsamd_field_mlp_fwd": [("field_mlp_fwd_kernel", "196608", False)],
     "nsamd_adam_step": [("adam_kernel", "524288", True)],
-    "nsamd_hashgrid_encode_fwd[L=16,M=196608]": [("hash_encode_fwd_kernel", "3145728", False)],
+    "nsamd_hashgrid_encode_fwd[L=16,M=196608]": [("hash_encode_fwd_kernel<1>", "3145728", False)],
 }
 traffic = {}
 for key, parts in groups.items():
@@ -71,8 +75,6 @@ for key, parts in groups.items():
     for sub, grid, streaming in parts:
         for k in agg:
             if sub in k and (grid is None or k.endswith("grid=" + grid)):
-                if grid is None and not any(g in k for g in ("589824", "786432")) and "fine" in sub:
-                    continue  # main-table launches of the fine pass only (3 or 4 level groups x 192 blocks x 1024)
                 fr = kib(k, "FETCH_SIZE")
                 fetch_raw += fr
                 fetch_cal += fr * (2.0 if streaming else 1.0)

