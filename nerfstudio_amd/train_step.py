@@ -169,10 +169,10 @@ class NerfactoTrainStep:
     def written_params(self):
         """Parameters whose gradient this runner WRITES (hash tables, nsamd_hashgrid_encode_bwd_set): callers need not
         zero them (ParamArena.zero_grad(skip=...)). All other gradients accumulate and must be zeroed first."""
-        tables = [self.model.field.mlp_base.encoding.hash_table]
-        if not self.cfg.use_same_proposal_network:  # a shared network gets one gradient contribution per level: accumulate
-            tables += [net.encoding.hash_table for net in self.props]
-        return tables
+        # Only the 67 MB main table: for the 5 MB proposal tables the zero-fill is nothing, while the write-only path's
+        # deferred list costs more than direct atomics whenever a combining table overflows (dense early-training
+        # gradients: 300 vs 231 us, profiles/r01_scatter_write_only_sweeps.log).
+        return [self.model.field.mlp_base.encoding.hash_table]
 
     def forward_and_losses(self, updated: bool, draw_jitter: bool = True) -> None:
         self.forward_proposals(draw_jitter)
@@ -300,10 +300,8 @@ class NerfactoTrainStep:
                                              N.ptr(self._grad(b0)), N.ptr(self._grad(W1)), N.ptr(self._grad(b1)), st),
                    "density_mlp_bwd")
                 spec = net.encoding.spec
-                shared = self.cfg.use_same_proposal_network
-                ws, ws_n = F._scatter_workspace(spec, self.f_enc.device, m, write_only=not shared)
-                scatter = lib.nsamd_hashgrid_encode_bwd if shared else lib.nsamd_hashgrid_encode_bwd_set
-                ck(scatter(self._points(lvl), m, net._transform, net._box,
+                ws, ws_n = F._scatter_workspace(spec, self.f_enc.device, m)
+                ck(lib.nsamd_hashgrid_encode_bwd(self._points(lvl), m, net._transform, net._box,
                                                  N.ptr(net.encoding.hash_table), spec.native(), N.ptr(self.p_denc[lvl]), 1, m,
                                                  N.ptr(self._grad(net.encoding.hash_table)), None, N.ptr(ws), ws_n, st),
                    "hashgrid_encode_bwd")
