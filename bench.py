@@ -94,8 +94,7 @@ class Trainer:
         from nerfstudio_amd.schedulers import nerfacto_schedulers
 
         self.schedulers = nerfacto_schedulers()
-        self._pending_main = None  # (handle,) of the in-flight main-field all-reduce (N > 1)
-        self._have_pending = False
+        self.exchange = None  # nerfstudio_amd.dp_schedule.PipelinedExchange (N > 1 with the runner)
         self.hyper_views = {"fields": self.hyper[0:2], "proposal_networks": self.hyper[2:4]}
         self.loss_buf = torch.zeros((), device=dev)
         model.proposal_sampler.anneal_dev = self.hyper[4:5]
@@ -110,6 +109,10 @@ class Trainer:
             self.runner.anneal_dev = self.hyper[4:5]
             if os.environ.get("NSAMD_SIDE_STREAM", "1") == "0":  # A/B switch: proposal backward on the main stream
                 self.runner.side_stream = None
+            if world > 1:
+                from nerfstudio_amd.dp_schedule import PipelinedExchange
+
+                self.exchange = PipelinedExchange(arena, self._run, before_main_update=self._push_hyper)
 
     # -- pieces of one iteration ---------------------------------------------------------------------------------
     def _prologue(self, updated):
@@ -191,7 +194,6 @@ class Trainer:
         else:
             raise KeyError(name)
 
-    _SEGMENTS = ("pfwd", ("main", True), ("main", False), "pbwd", "mopt", "popt")
 
     def _run(self, name):
         if self.graphs is not None:
@@ -203,34 +205,18 @@ class Trainer:
         else:
             self._seg(name)
 
-    def _finish_main(self):
-        """Wait for the in-flight main-field all-reduce and apply its Adam update."""
-        if self._have_pending:
-            if self._pending_main is not None:
-                self._pending_main.wait()
-            self._run("mopt")
-            self._pending_main, self._have_pending = None, False
-
     def finish(self):
-        """Drain the pipeline: after this every parameter reflects every step taken (no-op for N = 1)."""
-        if self._have_pending:
-            self._push_hyper()  # step size of the update that is still pending
-            self._finish_main()
+        """Drain the data-parallel pipeline (no-op for N = 1)."""
+        if self.exchange is not None:
+            self.exchange.finish()
+
+    @property
+    def _have_pending(self):
+        return self.exchange is not None and self.exchange.pending
 
     def _pipelined_iteration(self, updated):
-        a = self.arena
         self._prologue(updated)
-        self._run("pfwd")          # overlaps the all-reduce of the previous step's main-field gradients
-        self._finish_main()
-        self._run(("main", updated))
-        self._pending_main = a.all_reduce_span(*a.groups["fields"], async_op=True)
-        self._have_pending = True
-        if updated:
-            self._run("pbwd")      # ... and so does this
-            h = a.all_reduce_span(*a.groups["proposal_networks"], async_op=True)
-            if h is not None:
-                h.wait()
-            self._run("popt")
+        self.exchange.iteration(updated)
 
     def _plain_dp_iteration(self, updated):
         """N > 1 through the autograd modules: one blocking all-reduce of the whole arena (not pipelined)."""
@@ -253,7 +239,9 @@ class Trainer:
         torch.cuda.synchronize()
         graphs = {}
         if self.pipelined:
-            for name in self._SEGMENTS:
+            from nerfstudio_amd.dp_schedule import SEGMENTS
+
+            for name in SEGMENTS:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._seg(name)

@@ -5,7 +5,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 export NSAMD_BENCH_SAME_RAYS=1
-for mode in "" "" "--no-graph"; do
+for mode in ""; do
   one=$(python bench.py --steps 40 --warmup 10 --no-cpu-baseline --profile-steps 1 $mode 2>/dev/null | tail -1)
   echo "N=1 $mode : $(echo $one | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["config"]["final_loss"], d["ms_per_step"], d["config"]["launch"])')"
 done

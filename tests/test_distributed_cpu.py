@@ -97,3 +97,102 @@ def test_arena_single_process_layout():
     arena.zero_grad()
     assert float(arena.grad.abs().sum()) == 0 and a.grad.data_ptr() == arena.grad.data_ptr()
     assert arena.all_reduce() == 1.0  # no process group: no-op
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dp_schedule.PipelinedExchange: the main-group all-reduce stays in flight across the step boundary
+# ---------------------------------------------------------------------------------------------------------------------
+def _toy_batches(rank, steps):
+    g = torch.Generator().manual_seed(77 + rank)
+    return [(torch.randn(8, 6, generator=g), torch.randn(8, generator=g)) for _ in range(steps)]
+
+
+def _toy_reference(world, steps, lr):
+    """Sequential semantics: mean gradient over the ranks' batches, main group every step, proposal group on update
+    steps (even steps), every parameter updated before its next use."""
+    wf, wp = torch.full((6,), 0.3), torch.full((6,), -0.2)
+    data = [_toy_batches(r, steps) for r in range(world)]
+    for k in range(steps):
+        updated = k % 2 == 0
+        gf, gp = torch.zeros(6), torch.zeros(6)
+        for r in range(world):
+            x, y = data[r][k]
+            s = torch.tanh(x @ wp)                       # "proposal forward"
+            err = (x * s[:, None]) @ wf - y              # "main forward" on the proposal output
+            gf += 2 * ((x * s[:, None]) * err[:, None]).mean(0)
+            if updated:
+                ds = 2 * err * (x @ wf) / len(y)         # dL/ds
+                gp += ((1 - s * s) * ds) @ x
+        wf = wf - lr * gf / world
+        if updated:
+            wp = wp - lr * gp / world
+    return wf, wp
+
+
+def _schedule_worker(rank, world, port, q, steps, lr):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerfstudio_amd.arena import ParamArena
+        from nerfstudio_amd.dp_schedule import PipelinedExchange
+
+        wf, wp = torch.nn.Parameter(torch.full((6,), 0.3)), torch.nn.Parameter(torch.full((6,), -0.2))
+        arena = ParamArena({"fields": [wf], "proposal_networks": [wp]})
+        data = _toy_batches(rank, steps)
+        state = {"k": 0}
+        order = []
+
+        def run(name):
+            order.append(name)
+            x, y = data[state["k"]]
+            with torch.no_grad():
+                if name == "pfwd":
+                    state["s"] = torch.tanh(x @ wp)
+                elif name in (("main", True), ("main", False)):
+                    arena.zero_grad(["fields"])
+                    s = state["s"]
+                    err = (x * s[:, None]) @ wf - y
+                    wf.grad += 2 * ((x * s[:, None]) * err[:, None]).mean(0)
+                    state["ds"] = 2 * err * (x @ wf) / len(y)
+                elif name == "pbwd":
+                    arena.zero_grad(["proposal_networks"])
+                    s = state["s"]
+                    wp.grad += ((1 - s * s) * state["ds"]) @ x
+                elif name == "mopt":
+                    a, b = arena.groups["fields"]
+                    arena.flat[a:b] -= lr * arena.grad[a:b] / world
+                elif name == "popt":
+                    a, b = arena.groups["proposal_networks"]
+                    arena.flat[a:b] -= lr * arena.grad[a:b] / world
+
+        ex = PipelinedExchange(arena, run)
+        for k in range(steps):
+            state["k"] = k
+            ex.iteration(updated=(k % 2 == 0))
+        assert ex.pending  # the last main update is still in flight ...
+        ex.finish()        # ... until the pipeline is drained
+        assert not ex.pending
+        q.put((rank, wf.detach().clone().numpy(), wp.detach().clone().numpy(), order[:9]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_exchange_equals_sequential_data_parallel():
+    world, steps, lr = 2, 7, 0.05
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_schedule_worker, args=(r, world, port, q, steps, lr)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    wf_ref, wp_ref = _toy_reference(world, steps, lr)
+    for rank, wf, wp, order in out:
+        assert torch.allclose(torch.from_numpy(wf), wf_ref, atol=1e-6), (rank, wf, wf_ref)
+        assert torch.allclose(torch.from_numpy(wp), wp_ref, atol=1e-6), (rank, wp, wp_ref)
+    # step 0: pfwd, main, pbwd, popt (main update pending); step 1 starts with pfwd BEFORE the pending main update
+    assert out[0][3] == ["pfwd", ("main", True), "pbwd", "popt", "pfwd", "mopt", ("main", False), "pfwd", "mopt"]
