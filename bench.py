@@ -71,8 +71,8 @@ class Trainer:
     the ray batch, the jitter draws (graph-safe Philox), the anneal exponent and Adam's bias-corrected step size
     (`hyper`, refreshed by a 20-byte async copy from a ring of pinned host slots before each replay).
 
-    N > 1 (data parallel): the iteration is captured in segments and the 67 MB main-field all-reduce (RCCL, its own
-    stream) is PIPELINED across steps. The proposal forward of step k+1 reads only proposal-network parameters, so
+    N > 1 (data parallel): the iteration runs as segments (eager launches by default, captured hipGraphs with --dp-graph)
+    and the 67 MB main-field all-reduce (RCCL, its own stream) is PIPELINED across steps (nerfstudio_amd/dp_schedule.py). The proposal forward of step k+1 reads only proposal-network parameters, so
         step k:   [proposal fwd k] -> (wait AR_main k-1) [Adam main k-1] -> [main fwd + losses + main bwd k]
                   -> AR_main k (async) -> [proposal bwd k] -> AR_props k -> [Adam props k]      (last two: update steps)
     hides the all-reduce behind the proposal backward of step k AND the proposal forward of step k+1, with exactly the
@@ -196,6 +196,17 @@ class Trainer:
 
 
     def _run(self, name):
+        if os.environ.get("NSAMD_DP_TIMING") == "1":  # diagnostics: host-synchronous per-segment timing
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            self._run_inner(name)
+            torch.cuda.synchronize()
+            self._seg_times = getattr(self, "_seg_times", {})
+            self._seg_times.setdefault(str(name), []).append((time.perf_counter() - t0) * 1e3)
+            return
+        self._run_inner(name)
+
+    def _run_inner(self, name):
         if self.graphs is not None:
             self.graphs[name].replay()
             if name == "mopt":
@@ -436,6 +447,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL on ROCm); gloo only for functional tests")
     ap.add_argument("--share-gpu", action="store_true", help="functional test: every rank uses cuda:0 (needs gloo)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--dp-graph", action="store_true", help="N > 1: replay captured hipGraph segments instead of eager launches")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -471,7 +483,11 @@ def main():
     for _ in range(max(1, args.warmup // 2)):  # eager warm-up: lazy kernel attributes, caches, allocator
         trainer.train_iteration()
     trainer.finish()
-    graphed = trainer.try_capture()
+    # N > 1 launches the segments eagerly by default: at this kernel granularity the host keeps ahead of the GPU either
+    # way (N = 1: 1.00 ms/step eager vs 1.03 ms replayed), and replaying captured segments between eager collectives could
+    # only be exercised over gloo with two ranks sharing one GPU, where it is pathologically slow (profiles/
+    # r01_dp_schedule_check.log). --dp-graph opts in.
+    graphed = trainer.try_capture() if (world == 1 or args.dp_graph) else False
     for _ in range(args.warmup - max(1, args.warmup // 2)):
         trainer.train_iteration()
     trainer.finish()
@@ -493,6 +509,9 @@ def main():
         elapsed = float(t.item())
     loss = trainer.last_loss()
     assert bool(torch.isfinite(loss)), "training diverged"
+    if getattr(trainer, "_seg_times", None) and rank == 0:
+        for k, v in trainer._seg_times.items():
+            print(f"[dp-timing] {k:16s} n={len(v):4d} median {sorted(v)[len(v) // 2]:9.3f} ms  max {max(v):9.3f} ms", file=sys.stderr)
 
     roof, table = (None, [])
     if rank == 0:
