@@ -152,3 +152,52 @@ def test_lr_schedule_matches_reference_lambda_lr(golden):
     for name, cfg in cfgs.items():
         got = np.array([S(cfg).get_lr(int(s), 1e-2) for s in g["steps"]])
         np.testing.assert_allclose(got, g[name], rtol=1e-12, err_msg=name)
+
+
+def test_checkpoint_interchange_with_reference_layout():
+    """Model tensors under `_model.` (with and without DDP's `module.`), Adam state in torch.optim.Adam's own layout —
+    torch's optimiser must accept it — and a round trip through the arena."""
+    import torch
+
+    from nerfstudio_amd import checkpoint as C
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.nerfacto import NerfactoModel, NerfactoModelConfig
+
+    def small():
+        cfg = NerfactoModelConfig(log2_hashmap_size=8, num_levels=16, max_res=64,
+                                  proposal_net_args_list=[{"hidden_dim": 16, "log2_hashmap_size": 7, "num_levels": 3, "max_res": 32,
+                                                           "use_linear": False}] * 2)
+        return NerfactoModel(cfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_train_data=5)
+
+    torch.manual_seed(0)
+    a = small()
+    arena = ParamArena(a.get_param_groups_ordered())
+    arena.exp_avg.uniform_(-1, 1)
+    arena.exp_avg_sq.uniform_(0, 1)
+    arena.step_counts.update({"fields": 12, "proposal_networks": 7})
+    ckpt = C.make_checkpoint(a, arena, step=12)
+    assert all(k.startswith("_model.") for k in ckpt["pipeline"])
+    assert "_model.field.mlp_base.model.0.hash_table" in ckpt["pipeline"]
+    # torch's own optimiser accepts the state (what Optimizers.load_optimizers does, engine/optimizers.py:195-203)
+    for name, params in a.get_param_groups().items():
+        opt = torch.optim.Adam(params, lr=1e-2, eps=1e-15)
+        opt.load_state_dict(ckpt["optimizers"][name])
+        st = opt.state[params[0]]
+        assert float(st["step"]) == arena.step_counts[name] and st["exp_avg"].shape == params[0].shape
+    # into a second model + arena, through DDP-style keys and some foreign entries
+    torch.manual_seed(1)
+    b = small()
+    arena_b = ParamArena(b.get_param_groups_ordered())
+    foreign = {"module." + k: v for k, v in ckpt["pipeline"].items()}
+    foreign["module.datamanager.train_camera_optimizer.pose_adjustment"] = torch.zeros(5, 6)
+    assert C.load_model_state(b, foreign) == []
+    C.load_optimizer_states(b, arena_b, ckpt["optimizers"])
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    for p_, off in zip(arena.params, arena.offsets):  # (the alignment padding between tensors is not part of a checkpoint)
+        sl = slice(off, off + p_.numel())
+        assert torch.equal(arena.exp_avg[sl], arena_b.exp_avg[sl]) and torch.equal(arena.exp_avg_sq[sl], arena_b.exp_avg_sq[sl])
+    assert arena_b.step_counts == {"fields": 12, "proposal_networks": 7}
+    assert b.field.mlp_base.encoding.hash_table.data_ptr() >= arena_b.flat.data_ptr()  # still views of the arena
+    with pytest.raises(KeyError):
+        C.load_model_state(small(), {"_model.field.mlp_head.layers.0.weight": torch.zeros(64, 63)})
