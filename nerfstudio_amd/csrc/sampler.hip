@@ -24,21 +24,26 @@ __global__ __launch_bounds__(kThreads) void piecewise_bins_kernel(const float* _
                                                                   int64_t num_rays, int S, int spacing,
                                                                   float* __restrict__ s_bins,
                                                                   float* __restrict__ t_bins) {
-  const int64_t total = num_rays * (int64_t)(S + 1);
-  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
-    const int64_t ray = e / (S + 1);
-    const int i = (int)(e - ray * (S + 1));
+  // one wavefront per ray (4 rays per workgroup): per-ray scalars are computed once, the edge index is a 32-bit loop
+  // counter (the flat-index version spent its time in 64-bit divisions)
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (ray >= num_rays) return;
+  const float s_near = spacing_fn_mode(spacing, nears[ray]);
+  const float s_far = spacing_fn_mode(spacing, fars[ray]);
+  const float jit = jitter != nullptr ? jitter[ray] : 0.0f;
+  float* sb = s_bins + ray * (S + 1);
+  float* tb = t_bins + ray * (S + 1);
+  for (int i = lane; i <= S; i += 64) {
     float b = edges[i];
     if (jitter != nullptr) {
       // lower = [edges[0], centres], upper = [centres, edges[S]]   (ray_samplers.py:108-110)
       const float lower = (i == 0) ? edges[0] : (edges[i] + edges[i - 1]) / 2.0f;
       const float upper = (i == S) ? edges[S] : (edges[i + 1] + edges[i]) / 2.0f;
-      b = lower + (upper - lower) * jitter[ray];
+      b = lower + (upper - lower) * jit;
     }
-    const float s_near = spacing_fn_mode(spacing, nears[ray]);
-    const float s_far = spacing_fn_mode(spacing, fars[ray]);
-    s_bins[e] = b;
-    t_bins[e] = spacing_to_euclidean_mode(spacing, b, s_near, s_far);
+    sb[i] = b;
+    tb[i] = spacing_to_euclidean_mode(spacing, b, s_near, s_far);
   }
 }
 
@@ -276,10 +281,10 @@ extern "C" int nsamd_piecewise_bins(const float* nears, const float* fars, const
   NSAMD_REQUIRE(num_rays >= 0 && S > 0 && (spacing == 0 || spacing == 1));
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(nears && fars && edges && s_bins && t_bins);
-  const int64_t total = num_rays * (int64_t)(S + 1);
-  const unsigned blocks = (unsigned)min((int64_t)8192, (total + kThreads - 1) / kThreads);
-  piecewise_bins_kernel<<<blocks, kThreads, 0, (hipStream_t)stream>>>(nears, fars, edges, jitter, num_rays, S, spacing,
-                                                                      s_bins, t_bins);
+  const int64_t blocks64 = (num_rays + (kThreads / 64) - 1) / (kThreads / 64);
+  if (blocks64 > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
+  piecewise_bins_kernel<<<(unsigned)blocks64, kThreads, 0, (hipStream_t)stream>>>(nears, fars, edges, jitter, num_rays, S,
+                                                                                  spacing, s_bins, t_bins);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }
