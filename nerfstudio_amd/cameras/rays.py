@@ -8,7 +8,7 @@ are never materialised in HBM on that path. Everything the reference fields expo
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field, fields, replace
+from dataclasses import dataclass, field, fields
 from typing import Callable, Dict, Optional
 
 import torch

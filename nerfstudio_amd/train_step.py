@@ -19,7 +19,7 @@ schedule variant and replayed. Numerically identical to the autograd path (tests
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional
+from typing import Dict
 
 import torch
 from torch import Tensor
