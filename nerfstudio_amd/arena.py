@@ -25,6 +25,27 @@ from . import functional as F
 _ALIGN = 64  # floats: every tensor starts on a 256-B boundary
 
 
+class _GroupHandle:
+    """wait() for every collective of a group exchange, then put the compact rows back into the gradient."""
+
+    def __init__(self, handles, post) -> None:
+        self.handles, self.post = handles, post
+        if not handles:  # synchronous exchange: the collectives are done
+            self._finish()
+
+    def _finish(self) -> None:
+        for view, idx, buf in self.post:
+            view.index_copy_(0, idx, buf)
+        self.post = []
+
+    def wait(self) -> None:
+        for h in self.handles:
+            if h is not None:
+                h.wait()
+        self.handles = []
+        self._finish()
+
+
 class ParamArena:
     """`params` is either an iterable of Parameters (one group "all") or an ordered dict {group name: parameters} — the
     reference's optimiser groups (models/nerfacto.py:255-260: "fields", "proposal_networks"). Groups are laid out one
@@ -114,6 +135,41 @@ class ParamArena:
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return None
         return dist.all_reduce(self.grad[start:end], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+    # ---- compact exchange of hash-table prefixes ---------------------------------------------------------------------
+    def register_compact(self, param: Parameter, prefix_rows: int, index: Tensor) -> None:
+        """Declare that of the first `prefix_rows` rows of `param` ([rows, F]) only the rows in `index` can ever carry a
+        gradient (functional.HashGridSpec.reachable_prefix). all_reduce_group then exchanges those rows as one compact
+        buffer instead of the whole prefix (nerfacto main table: 2.7 MB instead of 21 MB of the 67 MB)."""
+        off = next(o for p, o in zip(self.params, self.offsets) if p is param)
+        feat = param.shape[-1]
+        assert param.dim() == 2 and 0 < prefix_rows <= param.shape[0] and index.numel() > 0
+        assert int(index.max()) < prefix_rows
+        idx = index.to(self.grad.device)
+        self._compact = getattr(self, "_compact", {})
+        self._compact[id(param)] = (off, prefix_rows, feat, idx, torch.zeros((idx.numel(), feat), device=self.grad.device))
+
+    def all_reduce_group(self, name: str, async_op: bool = False, group: Optional[dist.ProcessGroup] = None):
+        """Sum one optimiser group's gradients over the ranks: dense spans as they lie, registered table prefixes
+        through their compact buffers. Returns a handle whose wait() also scatters the reduced rows back (None when
+        there is nothing to do)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return None
+        a, b = self.groups[name]
+        compact = sorted((c for c in getattr(self, "_compact", {}).values() if a <= c[0] < b), key=lambda c: c[0])
+        handles, post = [], []
+        cursor = a
+        for off, rows, feat, idx, buf in compact:
+            if off > cursor:
+                handles.append(dist.all_reduce(self.grad[cursor:off], op=dist.ReduceOp.SUM, group=group, async_op=async_op))
+            view = self.grad[off:off + rows * feat].view(rows, feat)
+            torch.index_select(view, 0, idx, out=buf)
+            handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op))
+            post.append((view, idx, buf))
+            cursor = off + rows * feat
+        if cursor < b:
+            handles.append(dist.all_reduce(self.grad[cursor:b], op=dist.ReduceOp.SUM, group=group, async_op=async_op))
+        return _GroupHandle(handles if async_op else [], post)
 
     def all_reduce(self, group: Optional[dist.ProcessGroup] = None) -> float:
         """Sum the gradient arena over the ranks (RCCL when the tensors are on the GPU, gloo on CPU). Returns the scale

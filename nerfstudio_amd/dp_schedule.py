@@ -48,11 +48,11 @@ class PipelinedExchange:
         self.run("pfwd")          # overlaps the all-reduce of the previous step's main-field gradients
         self._finish_main()
         self.run(("main", updated))
-        self._handle = a.all_reduce_span(*a.groups[self.main_group], async_op=True)
+        self._handle = a.all_reduce_group(self.main_group, async_op=True)
         self.pending = True
         if updated:
             self.run("pbwd")      # ... and so does this
-            h = a.all_reduce_span(*a.groups[self.proposal_group], async_op=True)
+            h = a.all_reduce_group(self.proposal_group, async_op=True)
             if h is not None:
                 h.wait()
             self.run("popt")

@@ -75,6 +75,29 @@ class HashGridSpec:
         levels = torch.arange(self.num_levels)
         return torch.floor(self.min_res * self.growth_factor**levels).to(torch.float32)
 
+    def reachable_prefix(self):
+        """(rows, index): the leading `rows` rows of the `[L*T, F]` table belong to the coarse levels whose lattice
+        (res + 1)^3 is smaller than the table, and `index` (int64, sorted) lists the rows of that prefix a position in
+        [0, 1]^3 can ever touch. The torch path hashes every level (encodings.py:398-415), so on those levels all other
+        rows keep a zero gradient for ever — SURVEY.md 8a: 332 k of the first 2.6 M rows of the nerfacto main table —
+        and a data-parallel exchange only needs the listed ones. Host arithmetic in wrap-around uint32, as the kernels."""
+        import numpy as np
+
+        T = self.table_size
+        scal = self.scalings().tolist()
+        parts, levels = [], 0
+        for lvl, s_ in enumerate(scal):
+            res = int(s_)
+            if (res + 1) ** 3 >= T:
+                break
+            c = np.arange(res + 1, dtype=np.uint32)
+            with np.errstate(over="ignore"):
+                h = c[:, None, None] ^ (c[None, :, None] * np.uint32(2654435761)) ^ (c[None, None, :] * np.uint32(805459861))
+            parts.append(np.unique((h & np.uint32(T - 1)).astype(np.int64)) + lvl * T)
+            levels += 1
+        index = torch.from_numpy(np.concatenate(parts)) if parts else torch.zeros(0, dtype=torch.int64)
+        return levels * T, index
+
     def native(self) -> N.Grid:
         g = _GRID_CACHE.get(self)
         if g is None:

@@ -196,3 +196,59 @@ def test_pipelined_exchange_equals_sequential_data_parallel():
         assert torch.allclose(torch.from_numpy(wp), wp_ref, atol=1e-6), (rank, wp, wp_ref)
     # step 0: pfwd, main, pbwd, popt (main update pending); step 1 starts with pfwd BEFORE the pending main update
     assert out[0][3] == ["pfwd", ("main", True), "pbwd", "popt", "pfwd", "mopt", ("main", False), "pfwd", "mopt"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ParamArena.all_reduce_group with a registered compact table prefix == plain all-reduce of the whole slice
+# ---------------------------------------------------------------------------------------------------------------------
+def _compact_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerfstudio_amd import functional as F
+        from nerfstudio_amd.arena import ParamArena
+
+        spec = F.HashGridSpec(num_levels=6, min_res=2, max_res=40, log2_hashmap_size=8)
+        rows, idx = spec.reachable_prefix()
+        assert 0 < idx.numel() < rows < spec.num_levels * spec.table_size
+        table = torch.nn.Parameter(torch.zeros(spec.num_levels * spec.table_size, 2))
+        other = torch.nn.Parameter(torch.zeros(37))
+        prop = torch.nn.Parameter(torch.zeros(5, 3))
+        arena = ParamArena({"fields": [other, table], "proposal_networks": [prop]})  # table NOT first: two dense spans
+        g = torch.Generator().manual_seed(5 + rank)
+        with torch.no_grad():
+            table.grad[idx] = torch.randn(idx.numel(), 2, generator=g)          # only reachable rows of the prefix
+            table.grad[rows:] = torch.randn(table.shape[0] - rows, 2, generator=g)  # fine levels: dense
+            other.grad.copy_(torch.randn(37, generator=g))
+            prop.grad.fill_(float(rank + 1))
+        expect = arena.grad.clone()
+        dist.all_reduce(expect)  # what a plain all-reduce of everything gives
+        arena.register_compact(table, rows, idx)
+        for async_op in (True, False):
+            saved = arena.grad.clone()
+            h = arena.all_reduce_group("fields", async_op=async_op)
+            h.wait()
+            a, b = arena.groups["fields"]
+            assert torch.equal(arena.grad[a:b], expect[a:b]), async_op
+            pa, pb = arena.groups["proposal_networks"]
+            assert torch.equal(arena.grad[pa:pb], saved[pa:pb])  # the other group is untouched
+            arena.grad.copy_(saved)
+        q.put((rank, int(idx.numel()), rows))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_compact_table_prefix_exchange_equals_full_all_reduce():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_compact_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out[0][1:] == out[1][1:]

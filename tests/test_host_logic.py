@@ -201,3 +201,38 @@ def test_checkpoint_interchange_with_reference_layout():
     assert b.field.mlp_base.encoding.hash_table.data_ptr() >= arena_b.flat.data_ptr()  # still views of the arena
     with pytest.raises(KeyError):
         C.load_model_state(small(), {"_model.field.mlp_head.layers.0.weight": torch.zeros(64, 63)})
+
+
+def test_reachable_prefix_covers_every_corner_the_oracle_can_produce():
+    """HashGridSpec.reachable_prefix (the rows a data-parallel exchange needs on the coarse levels) against the oracle's
+    hash: every corner index of random and extreme positions lies in the list, and the list is exactly the lattice hash."""
+    import numpy as np
+    import torch
+
+    from nerfstudio_amd import functional as F
+    from oracle import nerfacto_oracle as orc
+
+    spec = F.HashGridSpec(16, 16, 2048, 19)
+    rows, idx = spec.reachable_prefix()
+    T = spec.table_size
+    assert rows == 5 * T and idx.numel() == 288066  # levels 16, 22, 30, 42, 58: (res+1)^3 < 2^19; 59^3 = 205 379 -> fewer after collisions
+    scal = spec.scalings()
+    assert torch.equal(scal, orc.hash_level_scalings(16, 16, 2048))
+    allowed = set(idx.tolist())
+    rs = np.random.RandomState(3)
+    x = np.concatenate([rs.uniform(0, 1, (5000, 3)), np.array([[0, 0, 0], [1 - 2**-24] * 3, [0.5, 0, 1 - 2**-24]])]).astype(np.float32)
+    for lvl in range(5):
+        s_ = np.float32(scal[lvl])
+        sc = x * s_
+        lo, hi = np.floor(sc).astype(np.int64), np.ceil(sc).astype(np.int64)
+        for cx in (lo[:, 0], hi[:, 0]):
+            for cy in (lo[:, 1], hi[:, 1]):
+                for cz in (lo[:, 2], hi[:, 2]):
+                    got = orc.hash_corner_index(cx, cy, cz, lvl, T)
+                    assert set(got.tolist()) <= allowed
+        res = int(s_)
+        c = np.arange(res + 1)
+        gx, gy, gz = np.meshgrid(c, c, c, indexing="ij")
+        lattice = np.unique(orc.hash_corner_index(gx.ravel(), gy.ravel(), gz.ravel(), lvl, T))
+        mine = idx[(idx >= lvl * T) & (idx < (lvl + 1) * T)].numpy()
+        assert np.array_equal(lattice, mine)
