@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""CPU oracle training run on the procedural scene of tests/psnr_scene.py -> tests/golden/psnr_scene.npz: per-step losses,
+the update schedule / anneal values, the rendered held-out view and its PSNR. The oracle is pinned to the reference by
+the other fixtures (make_golden.py); this one pins the GPU path's TRAINING OUTCOME to the oracle's (PSNR stand-in).
+Run from the repository root:  python tests/golden/make_psnr_fixture.py   (about 2 minutes on 8 cores)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import psnr_scene as S  # noqa: E402
+from oracle import nerfacto_oracle as orc  # noqa: E402
+
+torch.set_num_threads(8)
+MAIN_LOG2, PROP_LOG2, SEED = 14, 12, 41
+
+
+def schedule(cb_step, steps_since_update):
+    """ProposalNetworkSampler update rule (ray_samplers.py:590) with nerfacto's schedule (nerfacto.py:208-213).
+    `cb_step` is the sampler's own `_step`: set by step_cb AFTER a training iteration (ray_samplers.py:571-574), so during
+    iteration k it still holds k - 1 (0 for the first two iterations)."""
+    every = float(np.clip(np.interp(cb_step, [0, 5000], [0, 5]), 1, 5))
+    return steps_since_update > every or cb_step < 10
+
+
+def anneal_at(step, slope=10.0, n=1000):
+    frac = float(np.clip(step / n, 0, 1))
+    return slope * frac / ((slope - 1) * frac + 1)
+
+
+def main():
+    cfg = orc.NerfactoCfg(main_grid=orc.HashGridCfg(16, 16, 2048, MAIN_LOG2),
+                          prop_grids=(orc.HashGridCfg(5, 16, 128, PROP_LOG2), orc.HashGridCfg(5, 16, 256, PROP_LOG2)),
+                          num_images=S.N_TRAIN, appearance_embed_dim=0)  # eval and training see the same network
+    params = orc.init_params(cfg, seed=SEED)
+    names = list(params)
+    for p in params.values():
+        p.requires_grad_(True)
+    groups = {"proposal_networks": [params[k] for k in names if k.startswith("proposal_networks")],
+              "fields": [params[k] for k in names if k.startswith("field")]}
+    opts = {g: torch.optim.Adam(ps, lr=1e-2, eps=1e-15) for g, ps in groups.items()}
+    losses, sched, anneals = [], [], []
+    since, cb_step = 0, 0
+    for step, (o, d, cam, tgt, jit) in enumerate(S.batches()):
+        upd = schedule(cb_step, since)
+        an = anneal_at(step)
+        for opt in opts.values():
+            opt.zero_grad(set_to_none=True)
+        j = [S.to_t(jit[i])[:, None] for i in range(3)]
+        out = orc.nerfacto_forward(params, cfg, S.to_t(o), S.to_t(d), S.to_t(cam), j, training=True, anneal=an,
+                                   proposal_requires_grad=upd)
+        loss = sum(orc.nerfacto_losses(out, S.to_t(tgt), cfg).values())
+        loss.backward()
+        opts["fields"].step()
+        if upd:  # a group is stepped only when it received gradients (engine/optimizers.py:160-172)
+            opts["proposal_networks"].step()
+            since = 0
+        cb_step = step  # step_cb(step): AFTER_TRAIN_ITERATION
+        since += 1
+        losses.append(float(loss))
+        sched.append(upd)
+        anneals.append(an)
+        if step % 25 == 0:
+            print(f"step {step:4d} loss {float(loss):.5f} updated {upd}", flush=True)
+    images, psnrs = [], []
+    for cam_id in S.EVAL_CAMERAS:  # eval-mode renders (no jitter, near plane 0, clamp) of whole views
+        o, d, gt = S.full_view(cam_id)
+        with torch.no_grad():
+            ev = orc.nerfacto_forward(params, cfg, S.to_t(o), S.to_t(d), torch.zeros(len(o), dtype=torch.int64), None,
+                                      training=False)
+        images.append(ev["rgb"].numpy().astype(np.float32))
+        psnrs.append(S.psnr(images[-1], gt))
+        print(f"oracle PSNR of camera {cam_id} after {S.STEPS} steps: {psnrs[-1]:.3f} dB")
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "psnr_scene.npz"), losses=np.array(losses, np.float64),
+                        schedule=np.array(sched), anneals=np.array(anneals, np.float64), images=np.stack(images),
+                        psnr=np.array(psnrs), cfg=np.array([MAIN_LOG2, PROP_LOG2, SEED]))
+
+
+if __name__ == "__main__":
+    main()

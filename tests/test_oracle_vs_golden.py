@@ -361,3 +361,21 @@ def test_c_oracle_hash_and_cdf(golden):
                                   idx.ctypes.data_as(C.c_void_p))
     np.testing.assert_array_equal(idx, inds.numpy())
     np.testing.assert_array_equal(idx, gs["train_l1_inds"])  # and equal to the reference's own indices
+
+
+def test_psnr_fixture_is_reproducible_from_the_scene_definition(golden):
+    """tests/golden/psnr_scene.npz (oracle training run on the procedural scene): the stored PSNRs are those of the
+    stored images against the ground truth recomputed from tests/psnr_scene.py, and the batch stream is deterministic."""
+    import numpy as np
+    import psnr_scene as S
+
+    g = golden("psnr_scene")
+    assert g["losses"].shape == (S.STEPS,) and g["losses"][-1] < 0.02 * g["losses"][0]
+    for k, cam_id in enumerate(S.EVAL_CAMERAS):
+        _, _, gt = S.full_view(cam_id)
+        assert abs(S.psnr(g["images"][k], gt) - float(g["psnr"][k])) < 1e-6
+    b1, b2 = S.batches()[:2], S.batches()[:2]
+    for x, y in zip(b1, b2):
+        for u, v in zip(x, y):
+            assert np.array_equal(u, v)
+    assert float(g["psnr"][0]) > 30 and float(g["psnr"][1]) > 30
