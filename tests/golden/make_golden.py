@@ -542,6 +542,96 @@ def gen_raygen():
          directions_norm=rb.metadata["directions_norm"])
 
 
+def gen_vanilla():
+    """BASELINE configs[0] (vanilla NeRF, the reference's CPU-runnable case): NeRFEncoding, the 8x256 skip MLP field,
+    UniformSampler(64) + PDFSampler(128, include_original=True) and the NeRFModel.get_outputs wiring
+    (models/vanilla_nerf.py:139-196), composed from the reference's own modules with the oracle's seeded parameters."""
+    from nerfstudio.field_components.encodings import NeRFEncoding
+    from nerfstudio.fields.vanilla_nerf_field import NeRFField
+    from nerfstudio.model_components.ray_samplers import PDFSampler, UniformSampler
+
+    from oracle import vanilla_oracle as van
+
+    cfg = van.VanillaCfg()
+    rs = np.random.RandomState(91)
+    out = {}
+    # encoding known-answer block
+    x = torch.from_numpy(rs.uniform(-1.5, 1.5, (7, 3)).astype(np.float32))
+    out["enc_x"] = x
+    out["enc_pos"] = NeRFEncoding(3, 10, 0.0, 8.0, include_input=True)(x)
+    out["enc_dir"] = NeRFEncoding(3, 4, 0.0, 4.0, include_input=True)(x)
+    out["enc_plain"] = NeRFEncoding(3, 6, 0.0, 5.0, include_input=False)(x)
+    # the two fields with oracle-initialised parameters
+    params = {}
+    params.update(van.init_field_params(cfg, 92, "field_coarse."))
+    params.update(van.init_field_params(cfg, 93, "field_fine."))
+    pe = NeRFEncoding(3, cfg.pos_frequencies, 0.0, cfg.pos_max_exp, include_input=True)
+    de = NeRFEncoding(3, cfg.dir_frequencies, 0.0, cfg.dir_max_exp, include_input=True)
+    fields = {}
+    for name in ("field_coarse", "field_fine"):
+        f = NeRFField(position_encoding=pe, direction_encoding=de)
+        sd = {k[len(name) + 1:]: v for k, v in params.items() if k.startswith(name + ".")}
+        missing, unexpected = f.load_state_dict(sd, strict=False)
+        assert not unexpected and not missing, (missing, unexpected)
+        fields[name] = f
+    # the parameters are NOT stored (4.4 MB): the oracle regenerates them from the seeds; a checksum pins that
+    out["param_checksum"] = torch.stack([v.double().sum() for v in params.values()])
+    N = 12
+    o = torch.from_numpy((rs.standard_normal((N, 3)) * 0.3 + np.array([0, 0, -4.0])).astype(np.float32))
+    d = torch.from_numpy(rs.standard_normal((N, 3)).astype(np.float32) * 0.15 + torch.tensor([0.0, 0, 1.0]).numpy())
+    d = d / d.norm(dim=-1, keepdim=True)
+    tgt = torch.from_numpy(rs.uniform(0, 1, (N, 3)).astype(np.float32))
+    out.update(origins=o, directions=d, target=tgt)
+    # vanilla NeRF keeps the samplers' default single_jitter=False: one draw per bin edge (ray_samplers.py:107, :323)
+    j0 = torch.from_numpy(rs.uniform(0, 1, (N, cfg.num_coarse_samples + 1)).astype(np.float32))
+    j1 = torch.from_numpy(rs.uniform(0, 1, (N, cfg.num_importance_samples + 1)).astype(np.float32))
+    out.update(j0=j0, j1=j1)
+    rgb_r, acc_r, dep_r = RGBRenderer(background_color="white"), AccumulationRenderer(), DepthRenderer()
+    for mode in ("train", "eval"):
+        training = mode == "train"
+        rb = RayBundle(origins=o, directions=d, pixel_area=torch.ones(N, 1))
+        rb = NearFarCollider(cfg.near_plane, cfg.far_plane, reset_near_plane=False)(rb)
+        su, sp = UniformSampler(num_samples=cfg.num_coarse_samples), PDFSampler(num_samples=cfg.num_importance_samples)
+        for m in (su, sp, rgb_r, *fields.values()):
+            m.train(training)
+        for p_ in params.values():
+            p_.requires_grad_(True)
+        for f in fields.values():
+            f.zero_grad()
+        with replay_rand([j0] if training else []):
+            rs_u = su(rb)
+        fo_c = fields["field_coarse"].forward(rs_u)
+        w_c = rs_u.get_weights(fo_c[FieldHeadNames.DENSITY])
+        with replay_rand([j1] if training else []), record_searchsorted() as rec:
+            rs_p = sp(rb, rs_u, w_c)
+        fo_f = fields["field_fine"].forward(rs_p)
+        w_f = rs_p.get_weights(fo_f[FieldHeadNames.DENSITY])
+        res = {"rgb_coarse": rgb_r(rgb=fo_c[FieldHeadNames.RGB], weights=w_c), "rgb_fine": rgb_r(rgb=fo_f[FieldHeadNames.RGB], weights=w_f),
+               "accumulation_coarse": acc_r(w_c), "accumulation_fine": acc_r(w_f), "depth_coarse": dep_r(w_c, rs_u),
+               "depth_fine": dep_r(w_f, rs_p), "weights_coarse": w_c[..., 0], "weights_fine": w_f[..., 0],
+               "density_coarse": fo_c[FieldHeadNames.DENSITY][..., 0], "rgb_samples_coarse": fo_c[FieldHeadNames.RGB],
+               "pdf_inds": rec.calls[0],
+               "s_bins_fine": torch.cat([rs_p.spacing_starts[..., 0], rs_p.spacing_ends[:, -1:, 0]], -1),
+               "t_bins_fine": torch.cat([rs_p.frustums.starts[..., 0], rs_p.frustums.ends[:, -1:, 0]], -1),
+               "t_bins_coarse": torch.cat([rs_u.frustums.starts[..., 0], rs_u.frustums.ends[:, -1:, 0]], -1)}
+        if training:
+            loss = torch.mean((tgt - res["rgb_coarse"]) ** 2) + torch.mean((tgt - res["rgb_fine"]) ** 2)
+            loss.backward()
+            res["loss"] = loss
+            # gradients: 4.4 MB in full -> per tensor the L2 norm, the sum and 48 elements at seeded positions
+            pick = np.random.RandomState(94)
+            for name, f in fields.items():
+                for k, p_ in f.named_parameters():
+                    g_ = p_.grad.reshape(-1)
+                    idx = torch.from_numpy(pick.randint(0, g_.numel(), 48))
+                    res[f"gidx_{name}.{k}"] = idx
+                    res[f"gval_{name}.{k}"] = g_[idx]
+                    res[f"gstat_{name}.{k}"] = torch.stack([g_.double().norm(), g_.double().sum()])
+        for k, v in res.items():
+            out[f"{mode}_{k}"] = v
+    save("vanilla", **out)
+
+
 def gen_schedulers():
     """Learning rates torch's LambdaLR sets with the reference's ExponentialDecayScheduler (engine/schedulers.py:109-142),
     read off the optimiser after `step` x (optimizer.step(); scheduler.step())."""
@@ -569,6 +659,6 @@ def gen_schedulers():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["kat", "hashgrid", "fields", "samplers", "render", "losses", "pipeline", "raygen",
-                             "schedulers"]
+                             "schedulers", "vanilla"]
     for w in which:
         globals()["gen_" + w]()

@@ -379,3 +379,62 @@ def test_psnr_fixture_is_reproducible_from_the_scene_definition(golden):
         for u, v in zip(x, y):
             assert np.array_equal(u, v)
     assert float(g["psnr"][0]) > 30 and float(g["psnr"][1]) > 30
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[0]: vanilla NeRF (oracle/vanilla_oracle.py) against the reference's own modules
+# ---------------------------------------------------------------------------------------------------------------------
+def test_vanilla_nerf_encoding_matches_reference(golden):
+    from oracle import vanilla_oracle as van
+
+    g = golden("vanilla")
+    x = torch.from_numpy(g["enc_x"])
+    for name, args in (("enc_pos", (10, 0.0, 8.0, True)), ("enc_dir", (4, 0.0, 4.0, True)), ("enc_plain", (6, 0.0, 5.0, False))):
+        got = van.nerf_encoding(x, *args)
+        assert got.shape == g[name].shape
+        np.testing.assert_array_equal(got.numpy(), g[name])  # same torch ops in the same order: bit-equal
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_vanilla_nerf_pipeline_matches_reference(golden, mode):
+    """NeRFModel.get_outputs wiring (uniform 64 -> coarse field -> PDF 128 + original edges -> fine field, white
+    background, median depth), per-edge jitter (single_jitter=False, the samplers' default), losses and gradients."""
+    from oracle import vanilla_oracle as van
+
+    g = golden("vanilla")
+    cfg = van.VanillaCfg()
+    params = {}
+    params.update(van.init_field_params(cfg, 92, "field_coarse."))
+    params.update(van.init_field_params(cfg, 93, "field_fine."))
+    np.testing.assert_allclose(np.array([float(v.double().sum()) for v in params.values()]), g["param_checksum"], rtol=1e-12)
+    training = mode == "train"
+    for p in params.values():
+        p.requires_grad_(training)
+    o, d = torch.from_numpy(g["origins"]), torch.from_numpy(g["directions"])
+    jit = [torch.from_numpy(g["j0"]), torch.from_numpy(g["j1"])] if training else None
+    out = van.vanilla_forward(params, cfg, o, d, jit, training=training)
+    pre = mode + "_"
+    np.testing.assert_array_equal(out["t_bins_coarse"].numpy(), g[pre + "t_bins_coarse"])
+    np.testing.assert_allclose(out["weights_coarse"].detach().numpy(), g[pre + "weights_coarse"], rtol=2e-4, atol=1e-7)
+    assert out["s_bins_fine"].shape == (o.shape[0], 64 + 128 + 2)
+    np.testing.assert_allclose(out["s_bins_fine"].numpy(), g[pre + "s_bins_fine"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["t_bins_fine"].numpy(), g[pre + "t_bins_fine"], rtol=0, atol=1e-5)
+    for k in ("rgb_coarse", "rgb_fine", "accumulation_coarse", "accumulation_fine"):
+        np.testing.assert_allclose(out[k].detach().numpy(), g[pre + k], rtol=0, atol=2e-6, err_msg=k)
+    for k in ("depth_coarse", "depth_fine"):
+        np.testing.assert_allclose(out[k].detach().numpy(), g[pre + k], rtol=2e-5, err_msg=k)
+    if training:
+        tgt = torch.from_numpy(g["target"])
+        loss = sum(van.vanilla_losses(out, tgt, cfg).values())
+        np.testing.assert_allclose(float(loss), float(g["train_loss"]), rtol=1e-5)
+        loss.backward()
+        for name, p in params.items():
+            gr = p.grad.reshape(-1)
+            idx = torch.from_numpy(g[f"train_gidx_{name}"])
+            stat = g[f"train_gstat_{name}"]
+            scale = max(float(stat[0]), 1e-30)
+            ref_vals = g[f"train_gval_{name}"]
+            atol = 3e-2 * max(float(np.abs(ref_vals).max()), scale / np.sqrt(gr.numel())) + 1e-12  # cancellation-heavy sums
+            np.testing.assert_allclose(gr[idx].numpy(), ref_vals, rtol=0, atol=atol, err_msg=name)
+            # (256-wide matmuls: MKL's blocking order differs between the two compositions of the same graph)
+            np.testing.assert_allclose(float(gr.double().norm()), float(stat[0]), rtol=2e-3, err_msg=name)
