@@ -392,7 +392,7 @@ def weights_from_density(t_bins: Tensor, density: Tensor) -> Tensor:
     ds = deltas * density
     alphas = 1 - torch.exp(-ds)
     acc = torch.cumsum(ds[:, :-1], dim=-1)
-    acc = torch.cat([torch.zeros_like(acc[:, :1]), acc], dim=-1)
+    acc = torch.cat([torch.zeros((ds.shape[0], 1), dtype=ds.dtype), acc], dim=-1)  # rays.py:141-144 (also right for S = 1)
     return torch.nan_to_num(alphas * torch.exp(-acc))
 
 
