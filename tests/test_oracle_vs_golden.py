@@ -438,3 +438,60 @@ def test_vanilla_nerf_pipeline_matches_reference(golden, mode):
             np.testing.assert_allclose(gr[idx].numpy(), ref_vals, rtol=0, atol=atol, err_msg=name)
             # (256-wide matmuls: MKL's blocking order differs between the two compositions of the same graph)
             np.testing.assert_allclose(float(gr.double().norm()), float(stat[0]), rtol=2e-3, err_msg=name)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# instant-ngp packed arithmetic (oracle/packed_oracle.py): anchored on the pinned DENSE path
+# ---------------------------------------------------------------------------------------------------------------------
+def test_packed_weights_and_compositing_equal_the_dense_reference_path(golden):
+    """With the same number of samples on every ray, packing is a reshape: render_weight_from_density / the packed
+    renderer branches must reproduce the reference's dense get_weights / renderers (fixtures samplers.npz, render.npz)."""
+    from oracle import packed_oracle as pk
+
+    g = golden("render")
+    w_ref = torch.from_numpy(g["weights"])                     # reference RaySamples.get_weights on ...
+    t_bins, dens = torch.from_numpy(g["t_bins"]), torch.from_numpy(g["density"])
+    n, s = dens.shape
+    ray_idx = torch.arange(n).repeat_interleave(s)
+    t0, t1 = t_bins[:, :-1].reshape(-1), t_bins[:, 1:].reshape(-1)
+    w, trans, alphas = pk.render_weight_from_density(t0, t1, dens.reshape(-1), ray_idx, n)
+    np.testing.assert_allclose(w.view(n, s).numpy(), w_ref.numpy(), rtol=2e-5, atol=1e-7)
+    info = pk.pack_info(ray_idx, n)
+    assert torch.equal(info[:, 1], torch.full((n,), s)) and torch.equal(info[:, 0], torch.arange(n) * s)
+    rgb = torch.from_numpy(g["rgb"])
+    for bg in ("white", "black"):
+        comp, acc, depth = pk.composite_packed(rgb.reshape(-1, 3), w_ref.reshape(-1), t0, t1, ray_idx, n, background=bg)
+        dense = orc.composite_rgb(rgb, w_ref, bg, training=True)
+        np.testing.assert_allclose(comp.numpy(), dense.numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(acc.numpy(), orc.accumulation(w_ref).numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(depth.numpy(), orc.depth_expected(w_ref, t_bins).numpy(), rtol=2e-5)
+    np.testing.assert_allclose(acc.numpy(), g["accumulation"], rtol=0, atol=2e-6)  # and the reference's own renderer output
+
+
+def test_packed_ragged_rays_and_visibility():
+    """Ragged packing (rays with 0 .. many samples): per-ray results equal the dense formulas applied ray by ray; the
+    visibility mask follows its definition (transmittance before the sample >= eps, alpha >= threshold)."""
+    from oracle import packed_oracle as pk
+
+    rs = np.random.RandomState(17)
+    counts = [0, 5, 1, 0, 12, 3]
+    ray_idx = torch.tensor([r for r, c in enumerate(counts) for _ in range(c)])
+    m = int(ray_idx.numel())
+    t0 = torch.from_numpy(np.concatenate([np.sort(rs.uniform(0.1, 4, c)) for c in counts if c]).astype(np.float32))
+    t1 = t0 + torch.from_numpy(rs.uniform(0.01, 0.2, m).astype(np.float32))
+    sig = torch.from_numpy((np.exp(rs.standard_normal(m) * 2)).astype(np.float32))
+    w, trans, alphas = pk.render_weight_from_density(t0, t1, sig, ray_idx, len(counts))
+    off = 0
+    for r, c in enumerate(counts):
+        if c == 0:
+            continue
+        sd = sig[off:off + c] * (t1[off:off + c] - t0[off:off + c])
+        excl = torch.cumsum(sd, 0) - sd
+        np.testing.assert_allclose(trans[off:off + c].numpy(), torch.exp(-excl).numpy(), rtol=1e-5)
+        np.testing.assert_allclose(w[off:off + c].numpy(), (torch.exp(-excl) * (1 - torch.exp(-sd))).numpy(), rtol=1e-5, atol=1e-8)
+        off += c
+    acc = pk.accumulate_along_rays(w, None, ray_idx, len(counts))
+    assert float(acc[0]) == 0.0 and float(acc[3]) == 0.0 and float(acc.max()) <= 1.0 + 1e-6
+    vis = pk.render_visibility_from_density(t0, t1, sig, ray_idx, len(counts), early_stop_eps=1e-2, alpha_thre=0.05)
+    assert torch.equal(vis, (trans >= 1e-2) & (alphas >= 0.05))
+    assert torch.equal(pk.pack_info(ray_idx, len(counts))[:, 1], torch.tensor(counts))
