@@ -65,3 +65,36 @@ def test_argument_validation_without_gpu():
     assert 0 < w1 < w2 and w1 * 4 < 2**31
     assert lib.nsamd_hashgrid_encode_bwd_workspace(g19, 196608, 1) > w1 + 4 * 8 * 196608 * 16  # + the deferred lists
     assert lib.nsamd_linear_fwd(None, None, None, 4, 0, 3, 0, None, None) == -1
+
+
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """The boundary is a C ABI: include/nsamd.h must compile as C99 (no C++ / torch types), and a C translation unit that
+    references every declared entry point must link against libnsamd.so (host-only calls: version, status strings,
+    argument validation — no GPU needed)."""
+    import subprocess
+
+    from nerfstudio_amd import _native
+
+    if not os.path.exists(_native.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", HEADER], check=True)
+    src = tmp_path / "use.c"
+    refs = "\n".join(f"    (void*)&{s}," for s in declared_symbols())
+    src.write_text(
+        '#include <stdio.h>\n#include <string.h>\n#include "nsamd.h"\n'
+        "static void* const table[] = {\n" + refs + "\n};\n"
+        "int main(void) {\n"
+        '  if (strncmp(nsamd_version(), "nsamd", 5) != 0) return 1;\n'
+        '  if (strcmp(nsamd_status_string(0), "ok") != 0) return 2;\n'
+        "  if (nsamd_sh4_encode(NULL, 5, NULL, NULL) != -1) return 3;   /* invalid argument, nothing launched */\n"
+        "  if (nsamd_sh4_encode(NULL, 0, NULL, NULL) != 0) return 4;    /* empty input is a no-op */\n"
+        '  printf("%d symbols\\n", (int)(sizeof(table) / sizeof(table[0])));\n'
+        "  return 0;\n}\n")
+    exe = tmp_path / "use"
+    libdir = os.path.dirname(_native.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.dirname(HEADER), str(src), "-o", str(exe), "-L", libdir, "-lnsamd",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert out.strip() == f"{len(declared_symbols())} symbols"
