@@ -236,3 +236,25 @@ def test_reachable_prefix_covers_every_corner_the_oracle_can_produce():
         lattice = np.unique(orc.hash_corner_index(gx.ravel(), gy.ravel(), gz.ravel(), lvl, T))
         mine = idx[(idx >= lvl * T) & (idx < (lvl + 1) * T)].numpy()
         assert np.array_equal(lattice, mine)
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01_final_bench_default.json is what `python bench.py` printed on the MI355X box: every field of the
+    driver's contract is there with the right type, the roofline fraction is achieved / peak, value = rays / step time."""
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_final_bench_default.json")
+    d = json.load(open(path))
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], typ), key
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["data"] == "synthetic" and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["n_gpus"] * 4096 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
