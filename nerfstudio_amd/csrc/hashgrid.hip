@@ -1,30 +1,33 @@
 // Multiresolution hash encoding for gfx950, torch-path semantics of the reference
 // (HashEncoding.pytorch_fwd, /root/reference/nerfstudio/field_components/encodings.py:417-458).
 //
-// Mapping: grid = (ceil(M/256), L). blockIdx.y is the LEVEL, so the blocks resident at any moment sweep one or two
-// levels of the table (2^log2_T * 8 B each; 4 MiB for the nerfacto main grid = one XCD's L2) instead of all L —
-// the gathers are L2 hits instead of Infinity-Cache/HBM trips. Consecutive lanes are consecutive samples of one
-// ray, i.e. spatial neighbours: on the coarse levels most of a wavefront reads the same few 128-B lines.
-// The feature-major output (stride_p = 1) makes the 8-B-per-point result store one coalesced 256-B row per
-// wavefront and feature; the [M, 2L] row-major layout of the stand-alone Encoding API is the strided variant.
+// Forward mapping: grid = (ceil(M/256), L / levels-per-thread). For the nerfacto main grid one thread = one (point,
+// level) and blockIdx.y is the LEVEL, so the blocks resident at any moment sweep one or two levels of the table
+// (2^log2_T * 8 B each; 4 MiB = one XCD's L2) instead of all L — the gathers are L2 hits instead of Infinity-Cache/HBM
+// trips; for small tables (all levels of a proposal grid fit one L2 together) a thread takes 4 levels: the position is
+// computed once and 32 gathers are in flight. Consecutive lanes are consecutive samples of one ray, i.e. spatial
+// neighbours: on the coarse levels most of a wavefront reads the same few 128-B lines. The feature-major output
+// (stride_p = 1) makes the 8-B-per-point result store one coalesced 256-B row per wavefront and feature; the [M, 2L]
+// row-major layout of the stand-alone Encoding API is the strided variant.
 //
 // HBM-bound integer/gather work, no MFMA. Algorithmic bytes: 8 corners x 8 B per point and level (fwd),
 // 8 corners x 16 B read-modify-write (bwd).
 //
-// Backward = scatter-add into the table gradient. Measured on MI355X (scripts/probe_scatter.py, profiles/): fp32
+// Backward = scatter-add into the table gradient. Measured on MI355X (scripts/probe_scatter*.py, profiles/): fp32
 // global atomics retire at a flat ~20 G lane-ops/s chip-wide whatever the locality (they are serviced memory-side,
 // past the per-XCD L2s; contended coarse levels drop to 6 G/s) — 15x below the gather rate, 2.9 ms for the nerfacto
-// main table. So the big scatter uses NO global atomics: the table gradient is partitioned into (level, 16K-entry
-// slice) tiles of 128 KiB; one 1024-thread workgroup OWNS a tile in LDS, scans the sample points, adds the corner
-// contributions that hash into its slice with LDS atomics (ds_add_f32: thousands of lane-ops per clock chip-wide),
-// and writes the tile back with plain coalesced stores. Re-deriving the 8 hashes per (point, level) once per slice
-// costs ALU (measured 0.70 ms for the main table, 32 slices per level). With scratch memory from the caller the
-// redundancy goes away too ("binned" path, the default): pass 1 derives every corner update ONCE and appends
-// a 16-B record (local index, g0, g1, pad) to the queue of the tile it falls into — a workgroup-local counting sort in LDS, one
-// returning global atomic per (workgroup, non-empty tile) to reserve queue space, one dwordx4 store per record; pass
-// 2 runs one workgroup per tile that streams its queue into the LDS tile and stores it. Queues are sized 2x the
-// uniform-hash expectation; the rare overflow falls back to a direct atomic, so the result never depends on sizing.
-// Tiny problems keep the direct-atomic kernel.
+// main table. So the big scatter uses NO global atomics on its normal path ("binned" scatter, needs scratch from the
+// caller): the table gradient is partitioned into (level, up-to-16K-entry) tiles; PASS 1 derives every corner update
+// once and appends a 16-B record to the queue of the tile it falls into — a workgroup-local counting sort in LDS, one
+// returning global atomic per (workgroup, non-empty tile) to reserve queue space, one dwordx4 store per record — with
+// two kernels chosen per level (fine levels: x-pair records, 4 levels per thread; coarse levels: run merging + a
+// workgroup-wide combining table); PASS 2 runs one workgroup per tile that accumulates its queue in an LDS tile
+// (CAS on the float pair; ds_add_f32 with divergent addresses retires only 0.33 lane-ops/clk/CU) and adds — or, for
+// the write-only entry point, stores — the tile with plain coalesced float4 accesses. Queues are sized 2x the
+// uniform-hash expectation; what does not fit goes out as direct atomics (accumulating call) or through a deferred
+// list applied after pass 2 (write-only call), so the result never depends on sizing. Fallbacks: without scratch one
+// workgroup OWNS a tile and scans all sample points (hash_encode_bwd_sliced_kernel, 32x redundant hashing, 0.70 ms for
+// the main table); tiny problems keep the direct-atomic kernel. DESIGN.md 4.1 has the measurements behind each choice.
 #include <stdlib.h>
 
 #include "common.h"
