@@ -45,20 +45,45 @@ def build_model(device, seed):
     return model.to(device).train()
 
 
-def synthetic_batch(device, seed):
-    """BASELINE.md §2 synthetic input: origins ~ N(0, 0.5^2), unit directions, camera ids U{0..99}, targets U(0,1)."""
-    from nerfstudio_amd.cameras.rays import RayBundle
+BATCH_SLOTS = 8  # pre-generated ray batches resident in HBM; the timed loop takes a different one every step
 
+
+def synthetic_rays(seed, workload="bounded"):
+    """One batch of RAYS_PER_GPU synthetic rays (numpy): origins, unit directions, camera ids U{0..99}, targets U(0,1).
+    "bounded"   — BASELINE.md §2: origins ~ N(0, 0.5^2) inside the [-1,1]^3 box, isotropic directions (configs[1]/[2]).
+    "unbounded" — configs[4] (mipnerf-360-style capture): cameras on a shell of radius ~3 around the box
+                  looking inward with a wide field of view, so most samples fall in the contracted region ||x||_inf > 1
+                  (far plane 1000, L-inf scene contraction); same model and sampler (256 -> 96 -> 48)."""
     rs = np.random.RandomState(seed)
     n = RAYS_PER_GPU
-    o = (rs.standard_normal((n, 3)) * 0.5).astype(np.float32)
-    d = rs.standard_normal((n, 3)).astype(np.float32)
+    if workload == "unbounded":
+        u = rs.standard_normal((n, 3))
+        u /= np.linalg.norm(u, axis=-1, keepdims=True)
+        o = (3.0 * u + 0.1 * rs.standard_normal((n, 3))).astype(np.float32)
+        d = (-u + 0.45 * rs.standard_normal((n, 3))).astype(np.float32)
+    else:
+        o = (rs.standard_normal((n, 3)) * 0.5).astype(np.float32)
+        d = rs.standard_normal((n, 3)).astype(np.float32)
     d /= np.linalg.norm(d, axis=-1, keepdims=True)
     cam = rs.randint(0, 100, size=(n, 1)).astype(np.int64)
     tgt = rs.uniform(0, 1, size=(n, 3)).astype(np.float32)
-    rb = RayBundle(origins=torch.from_numpy(o).to(device), directions=torch.from_numpy(d.astype(np.float32)).to(device),
-                   pixel_area=torch.full((n, 1), 1e-6, device=device), camera_indices=torch.from_numpy(cam).to(device))
-    return rb, {"image": torch.from_numpy(tgt).to(device)}
+    return o, d.astype(np.float32), cam, tgt
+
+
+def synthetic_batch(device, seed, workload="bounded"):
+    """-> (RayBundle of slot 0, {"image": targets of slot 0}, pool): the pool holds BATCH_SLOTS batches in HBM as
+    [slots, N, 3] / [slots, N] tensors (seeds seed, seed + 1, ...)."""
+    from nerfstudio_amd.cameras.rays import RayBundle
+
+    n = RAYS_PER_GPU
+    parts = [synthetic_rays(seed + k, workload) for k in range(BATCH_SLOTS)]
+    pool = {"origins": torch.from_numpy(np.stack([p[0] for p in parts])).to(device),
+            "directions": torch.from_numpy(np.stack([p[1] for p in parts])).to(device),
+            "cameras": torch.from_numpy(np.stack([p[2][:, 0] for p in parts])).to(device),
+            "target": torch.from_numpy(np.stack([p[3] for p in parts])).to(device)}
+    rb = RayBundle(origins=pool["origins"][0].clone(), directions=pool["directions"][0].clone(),
+                   pixel_area=torch.full((n, 1), 1e-6, device=device), camera_indices=pool["cameras"][0].clone()[:, None])
+    return rb, {"image": pool["target"][0].clone()}, pool
 
 
 class Trainer:
@@ -78,17 +103,18 @@ class Trainer:
     hides the all-reduce behind the proposal backward of step k AND the proposal forward of step k+1, with exactly the
     sequential semantics (every parameter is updated before its next use). `finish()` drains the pending update."""
 
-    def __init__(self, model, arena, ray_bundle, batch, world=1, use_graph=True, use_runner=True):
+    def __init__(self, model, arena, ray_bundle, batch, world=1, use_graph=True, use_runner=True, pool=None):
         self.model, self.arena, self.rb, self.batch, self.world = model, arena, ray_bundle, batch, world
+        self.pool = pool  # BATCH_SLOTS pre-generated batches in HBM (None: one fixed batch)
         self.step = 0
         self.opt_step = 0
         self._true_steps = dict(arena.step_counts)
         dev = ray_bundle.origins.device
         # device-resident step-dependent scalars: Adam (step size, 1/sqrt(bc2)) per optimiser group + the anneal exponent
-        self.hyper = torch.zeros(5, device=dev)
+        self.hyper = torch.zeros(6, device=dev)  # [5] = batch slot of this step
         # The host runs ahead of the GPU, so the pinned source of an async copy must not be rewritten before the copy
         # has executed: a ring of slots, each guarded by the event recorded after its last copy.
-        self.hyper_ring = [torch.zeros(5).pin_memory() for _ in range(64)]
+        self.hyper_ring = [torch.zeros(6).pin_memory() for _ in range(64)]
         self.hyper_events = [None] * 64
         self.hyper_slot = 0
         from nerfstudio_amd.schedulers import nerfacto_schedulers
@@ -146,6 +172,7 @@ class Trainer:
         h[0], h[1] = F.adam_hyper(a.step_counts["fields"] + 1, lr_f, a.betas)
         h[2], h[3] = F.adam_hyper(a.step_counts["proposal_networks"] + 1, lr_p, a.betas)
         h[4] = m.proposal_sampler._anneal
+        h[5] = float(self.step % BATCH_SLOTS)
         self.hyper.copy_(h, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -156,9 +183,11 @@ class Trainer:
         from nerfstudio_amd.cameras.rays import RayBundle
 
         if self.runner is not None:
+            self._select_batch()
             self.arena.zero_grad(skip=self.runner.written_params())  # the table gradients are written, not accumulated
             self.runner.forward_backward(updated)  # the two backward chains run as parallel branches
             return
+        self._select_batch()
         self.arena.zero_grad()
         m = self.model
         m.proposal_sampler.force_updated = updated
@@ -170,6 +199,23 @@ class Trainer:
         loss = loss_dict["rgb_loss"] + loss_dict["interlevel_loss"] + loss_dict["distortion_loss"]
         loss.backward()
         self.loss_buf.copy_(loss.detach())
+
+    def _select_batch(self):
+        """This step's rays out of the HBM-resident pool (slot index in device memory: replayable) — the hand-over the
+        reference's datamanager does each iteration (base_datamanager.py:506-515)."""
+        if self.pool is None:
+            return
+        from nerfstudio_amd import _native as N
+
+        p = self.pool
+        if self.runner is not None:
+            r = self.runner
+            o, d, c, t = r.origins, r.directions, r.camera_indices, r.target
+        else:
+            o, d, c, t = self.rb.origins, self.rb.directions, self.rb.camera_indices, self.batch["image"]
+        N.check(N.load().nsamd_select_batch(N.ptr(self.hyper[5:6]), BATCH_SLOTS, o.shape[0], N.ptr(p["origins"]),
+                                            N.ptr(p["directions"]), N.ptr(p["cameras"]), N.ptr(p["target"]), N.ptr(o),
+                                            N.ptr(d), N.ptr(c), N.ptr(t), N.stream()), "select_batch")
 
     def _optimise(self, updated):
         # the reference steps an optimiser group only when it received gradients (engine/optimizers.py:160-172)
@@ -185,6 +231,7 @@ class Trainer:
         """The body of one captured segment (also what the eager path runs)."""
         r, a = self.runner, self.arena
         if name == "pfwd":
+            self._select_batch()
             r.forward_proposals()
         elif name in (("main", True), ("main", False)):
             a.zero_grad(["fields"], skip=r.written_params())
@@ -353,16 +400,34 @@ def algorithmic_model(key):
     return None, None
 
 
+def kernel_sources_hash():
+    """sha256 over the kernel sources: stamps profiles/pmc_traffic.json (scripts/collect_pmc.sh) so that a traffic
+    figure measured on other kernels is never reported."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "nerfstudio_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_key):
     """HBM-side bytes per launch of `kernel_key` from the committed rocprofv3 PMC passes (scripts/collect_pmc.sh ->
     profiles/pmc_traffic.json: FETCH_SIZE, doubled for 16-B-per-lane streaming reads as MI355X_MICROARCH.md prescribes for
     gfx950, + WRITE_SIZE; separate --pmc passes). Counters cannot be read from inside this process, so the value is the
-    one measured for this kernel at the commit that wrote the file; None when the file has no entry for the kernel."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    one measured for this kernel by the PMC passes — and only if they ran on THESE kernel sources (the file carries
+    their hash): None (JSON null) when the sources changed since, or the file has no entry for the kernel."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        entry = json.load(open(path)).get(kernel_key)
+        data = json.load(open(path))
+        if data.get("_kernel_sources_sha256_16") != kernel_sources_hash():
+            return None
+        entry = data.get(kernel_key)
         return int(entry["hbm_bytes"]) if entry else None
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, TypeError):
         return None
 
 
@@ -406,10 +471,14 @@ def measure_roofline(trainer, arena, steps):
     return roof, table
 
 
-def cpu_baseline(n_rays=256, steps=3, threads=None):
-    """The CPU oracle running the same training step (fwd + losses + bwd + Adam) on a bounded sample of rays.
+def cpu_baseline(n_rays=RAYS_PER_GPU, steps=3, threads=None, workload="bounded"):
+    """The CPU oracle (oracle/nerfacto_oracle.py, a restatement of the reference's torch path pinned to it by
+    tests/golden) running the same training step — forward, losses, backward, Adam over all 19.4 M parameters — on the
+    METRIC'S configuration: one batch of 4096 rays (BASELINE configs[1]); 1 warm-up step + `steps` timed ones, median
+    (about 2-4 s per step). profiles/r02_cpu_reference_vs_port.txt holds the authoring-container comparison of this port
+    with the reference's own modules on the same 4096 rays (within +-20 %).
     Thread count: torch's CPU ops on this workload peak at ~16 threads on the MI355X host (measured 8/16/32/64/128
-    threads: 135/141/111/63/30 rays/s, profiles/r01_probe_scatter.log), so 16 is used rather than all cores."""
+    threads: 135/141/111/63/30 rays/s on the 256-ray sample of round 1), so 16 is used rather than all cores."""
     from oracle import nerfacto_oracle as orc
 
     if threads is None:
@@ -422,7 +491,8 @@ def cpu_baseline(n_rays=256, steps=3, threads=None):
     for p in plist:
         p.requires_grad_(True)
     opt = torch.optim.Adam(plist, lr=1e-2, eps=1e-15)
-    o, d, cam, tgt = orc.synthetic_rays(n_rays, cfg.num_images, seed=0)
+    o, d, cam, tgt = (torch.from_numpy(a) for a in synthetic_rays(1000, workload))
+    o, d, cam, tgt = o[:n_rays], d[:n_rays], cam[:n_rays, 0], tgt[:n_rays]
     rs = np.random.RandomState(1)
     times = []
     for it in range(steps + 1):
@@ -436,8 +506,8 @@ def cpu_baseline(n_rays=256, steps=3, threads=None):
             times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     return {"value": round(n_rays / med, 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_rays} rays x (256,96,48) samples, full nerfacto tables, fwd+losses+bwd+Adam, median of {steps} "
-                      f"steps ({med:.2f} s/step)"}
+            "sample": f"{n_rays} rays x (256,96,48) samples = one full batch of the metric's configuration, full nerfacto "
+                      f"tables, fwd+losses+bwd+Adam, median of {steps} steps after 1 warm-up ({med:.2f} s/step)"}
 
 
 def main():
@@ -454,6 +524,10 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="functional test: every rank uses cuda:0 (needs gloo)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--dp-graph", action="store_true", help="N > 1: replay captured hipGraph segments instead of eager launches")
+    ap.add_argument("--workload", choices=["bounded", "unbounded"], default="bounded",
+                    help="bounded = BASELINE configs[1]/[2] (the metric's configuration); unbounded = configs[4] "
+                         "(cameras outside the box, most samples in the contracted region)")
+    ap.add_argument("--fixed-batch", action="store_true", help="train on one fixed ray batch instead of rotating the pool")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -483,8 +557,10 @@ def main():
     arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
     arena.broadcast_params()
     same = os.environ.get("NSAMD_BENCH_SAME_RAYS") == "1"  # functional check: N ranks, identical rays == the N=1 run
-    rb, batch = synthetic_batch(device, seed=1000 + (0 if same else rank))  # each rank its own rays (scripts/train.py:98)
-    trainer = Trainer(model, arena, rb, batch, world=world, use_graph=not args.no_graph, use_runner=not args.autograd)
+    # each rank its own rays (scripts/train.py:98): BATCH_SLOTS batches per rank, disjoint seeds
+    rb, batch, pool = synthetic_batch(device, seed=1000 + (0 if same else 100 * rank), workload=args.workload)
+    trainer = Trainer(model, arena, rb, batch, world=world, use_graph=not args.no_graph, use_runner=not args.autograd,
+                      pool=None if args.fixed_batch else pool)
 
     for _ in range(max(1, args.warmup // 2)):  # eager warm-up: lazy kernel attributes, caches, allocator
         trainer.train_iteration()
@@ -543,8 +619,12 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": ("nerfacto 1xMI355X" if world == 1 else f"nerfacto {world}xMI355X data-parallel") +
-                                   ": L=16 hash (T=2^19, F=2), 64x2 MLP, 48 samples/ray, 4096 rays/batch per GPU "
-                                   "(BASELINE configs[1]/[2]); full training step incl. proposal nets 256->96, losses, Adam",
+                                   ": L=16 hash (T=2^19, F=2), 64x2 MLP, 48 samples/ray, 4096 rays/batch per GPU " +
+                                   ("(BASELINE configs[1]/[2])" if args.workload == "bounded" else
+                                    "(BASELINE configs[4]: unbounded scene, cameras at radius ~3, L-inf contraction)") +
+                                   "; full training step incl. proposal nets 256->96, losses, Adam; "
+                                   f"{1 if args.fixed_batch else BATCH_SLOTS} ray batches resident in HBM, rotated per step",
+                       "rays": args.workload,
                        "rays_per_gpu": RAYS_PER_GPU, "global_rays": world * RAYS_PER_GPU,
                        "parallelism": f"dp{world}: rays sharded by batch; RCCL all-reduce of the gradient arena slices "
                                       "(main field 48 MB async — the coarse table levels go as their 288 k reachable rows — "
@@ -557,7 +637,7 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(workload=args.workload)
         if args.kernel_table:
             for r in table:
                 print(f"{r['kernel']:64s} {r['calls_per_step']:5.1f}/step {r['ms_per_step']:9.4f} ms/step "

@@ -85,11 +85,13 @@ int nsamd_hashgrid_encode_fwd(nsamd_points pts, int64_t M, int transform, nsamd_
 /* Backward: dtable[L*T,2] += scatter of denc (caller zero-fills or accumulates); dpositions (nullable) [M,3]
  * receives dL/d(raw position) through offset = scaled - floor(scaled), the selector, the affine map and the
  * contraction Jacobian exactly as autograd differentiates the reference (SURVEY.md §8a gradient-flow facts).
- * The scatter is partitioned into LDS-owned (level, slice) tiles (no global atomics, see csrc/hashgrid.hip);
- * `workspace` (nullable, `workspace_floats` words of device scratch, base 16-B aligned) enables the binned two-pass
- * path: it must be ZERO-INITIALISED ONCE by its owner (the per-tile queue cursors at its start are left at zero by
- * every call) and hold at least nsamd_hashgrid_encode_bwd_workspace(grid, M) words; smaller or NULL selects the
- * scratch-free scan. */
+ * `workspace` (nullable, `workspace_floats` 4-byte words of device scratch, base 16-B aligned) enables the binned
+ * two-pass scatter (csrc/scatter.hip): no float atomics, sums accumulated in 64-bit fixed point, so the result is
+ * BIT-REPRODUCIBLE from run to run (the reference's CPU index_put is sequential; its CUDA one is not reproducible).
+ * The workspace must hold nsamd_hashgrid_encode_bwd_workspace(grid, M, write_only) words and its first
+ * nsamd_hashgrid_encode_bwd_workspace_state(grid, M) words must be ZERO before the first call (every call leaves them
+ * zero again; the rest needs no initialisation). One workspace serves one call at a time (no concurrent streams).
+ * Smaller or NULL selects a scratch-free path (float atomics / racing LDS sums: same values up to summation order). */
 int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
                               nsamd_grid grid, const float* denc, int64_t stride_p, int64_t stride_k,
                               float* dtable, float* dpositions, float* workspace, int64_t workspace_floats,
@@ -98,16 +100,25 @@ int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transform, nsamd_
 /* Same scatter, but dtable is WRITE-ONLY: every entry is set (zero where nothing lands), so the caller neither
  * zero-fills the gradient before the call nor pays the read of the accumulate — with Adam consuming the gradient right
  * after, that removes 2 x 67 MB of HBM traffic per step for the nerfacto main table. Needs the workspace of
- * nsamd_hashgrid_encode_bwd_workspace(grid, M, 1) to stay on the binned path (updates pass 1 cannot queue go to a
- * deferred list sized for the worst case and are applied after pass 2); otherwise it zero-fills and accumulates. */
+ * nsamd_hashgrid_encode_bwd_workspace(grid, M, 1) (its spill list is sized for the worst case, so the result never
+ * depends on how the updates spread over the table); otherwise it zero-fills and accumulates. */
 int nsamd_hashgrid_encode_bwd_set(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
                                   nsamd_grid grid, const float* denc, int64_t stride_p, int64_t stride_k, float* dtable,
                                   float* dpositions, float* workspace, int64_t workspace_floats, nsamd_stream_t stream);
 
 /* Words of scratch the binned scatter of nsamd_hashgrid_encode_bwd (write_only = 0) / nsamd_hashgrid_encode_bwd_set
- * (write_only = 1) wants for (grid, M); 0 when that path does not apply (M < 8192 or an unsupported grid). Host-only,
+ * (write_only = 1) wants for (grid, M); 0 when that path does not apply (M <= 0 or an unsupported grid). Host-only,
  * no device work. */
 int64_t nsamd_hashgrid_encode_bwd_workspace(nsamd_grid grid, int64_t M, int write_only);
+
+/* Leading words of that workspace which must be zero before its first use (header + per-tile cursors). Host-only. */
+int64_t nsamd_hashgrid_encode_bwd_workspace_state(nsamd_grid grid, int64_t M);
+
+/* Diagnostics of a scatter workspace since it was zeroed: events_host[0] = records that did not fit their tile's
+ * queue and went through the spill list, [1] = of those, records applied with float atomics in no fixed order (more
+ * than 8192 spills in one call: the result of that call was exact but not bit-reproducible), [2] = records lost
+ * (must be 0). Synchronises `stream`. */
+int nsamd_hashgrid_scatter_events(const float* workspace, uint32_t* events_host, nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * SH encoding, 4 levels = 16 components (SHEncoding.pytorch_fwd, encodings.py:791-794 ->
@@ -135,10 +146,13 @@ int nsamd_density_mlp_fwd(const float* enc, const float* selector, int64_t M, ns
                           float* density, float* pre, nsamd_stream_t stream);
 
 /* Backward: ddensity [M] -> denc feature-major [in_dim,M] (overwritten), and dW0,db0,dW1,db1 accumulated
- * (caller zero-fills). trunc_exp backward clamps the exponent to [-15,15] (activations.py:39-42). */
+ * (caller zero-fills). trunc_exp backward clamps the exponent to [-15,15] (activations.py:39-42).
+ * workspace (nullable): >= 1024 * 1092 floats of scratch (one row of partial weight-gradient sums per workgroup,
+ * summed in a fixed order: bit-reproducible). Without it the partial sums meet through float atomics (same values up to
+ * summation order). One workspace serves one call at a time. */
 int nsamd_density_mlp_bwd(const float* enc, const float* selector, const float* pre, const float* ddensity,
                           int64_t M, nsamd_density_mlp mlp, float* denc, float* dW0, float* db0, float* dW1,
-                          float* db1, nsamd_stream_t stream);
+                          float* db1, float* workspace, int64_t workspace_floats, nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * nerfacto main field head (NerfactoField.get_density + get_outputs, fields/nerfacto_field.py:203-310):
@@ -316,6 +330,15 @@ int nsamd_proposal_losses(const float* s_bins_fine, const float* w_fine, int32_t
 int nsamd_raygen_pinhole(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy,
                          const float* cx, const float* cy, int64_t num_rays, int32_t num_cameras, float* origins,
                          float* directions, float* pixel_area, float* directions_norm, nsamd_stream_t stream);
+
+/* The step's ray batch out of `slots` pre-generated batches resident in HBM (what VanillaDataManager.next_train hands
+ * the model each iteration, data/datamanagers/base_datamanager.py:506-515): pools [slots, N, 3] fp32 (origins,
+ * directions, target rgb) and [slots, N] int64 (camera indices) -> the [N,3] / [N] buffers of the step. The slot index
+ * is read from DEVICE memory (slot_dev[0], a float like the other per-step scalars; clamped to [0, slots)), so a captured
+ * hipGraph replays with a new batch every step. */
+int nsamd_select_batch(const float* slot_dev, int32_t slots, int64_t num_rays, const float* origins_pool,
+                       const float* directions_pool, const int64_t* cameras_pool, const float* target_pool,
+                       float* origins, float* directions, int64_t* cameras, float* target, nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fused Adam over a flat fp32 arena (engine/optimizers.py:74-193 with AdamOptimizerConfig(lr, eps=1e-15),

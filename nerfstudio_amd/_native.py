@@ -60,10 +60,12 @@ _SIGNATURES = {
     "nsamd_hashgrid_encode_bwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, vp, i64, vp],
     "nsamd_hashgrid_encode_bwd_set": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, vp, i64, vp],
     "nsamd_hashgrid_encode_bwd_workspace": [Grid, i64, C.c_int],
+    "nsamd_hashgrid_encode_bwd_workspace_state": [Grid, i64],
+    "nsamd_hashgrid_scatter_events": [vp, vp, vp],
     "nsamd_sh4_encode": [vp, i64, vp, vp],
     "nsamd_contract_linf": [vp, i64, vp, vp],
     "nsamd_density_mlp_fwd": [vp, vp, i64, DensityMlp, vp, vp, vp],
-    "nsamd_density_mlp_bwd": [vp, vp, vp, vp, i64, DensityMlp, vp, vp, vp, vp, vp, vp],
+    "nsamd_density_mlp_bwd": [vp, vp, vp, vp, i64, DensityMlp, vp, vp, vp, vp, vp, vp, i64, vp],
     "nsamd_field_mlp_fwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp],
     "nsamd_field_mlp_bwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp, i64, vp],
     "nsamd_field_mlp_saved_floats": [i64],
@@ -85,6 +87,7 @@ _SIGNATURES = {
     "nsamd_distortion_loss": [vp, vp, i32, i64, f32, vp, vp, vp],
     "nsamd_proposal_losses": [vp, vp, i32, i32, vp, vp, vp, i64, f32, f32, vp, vp, vp, vp, vp],
     "nsamd_raygen_pinhole": [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp],
+    "nsamd_select_batch": [vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "nsamd_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, vp],
     "nsamd_version": [],
     "nsamd_status_string": [C.c_int],
@@ -92,7 +95,7 @@ _SIGNATURES = {
     "nsamd_probe_mfma16": [vp, vp, vp, vp],
 }
 _RESTYPES = {"nsamd_version": C.c_char_p, "nsamd_status_string": C.c_char_p,
-             "nsamd_hashgrid_encode_bwd_workspace": C.c_int64, "nsamd_field_mlp_saved_floats": C.c_int64}
+             "nsamd_hashgrid_encode_bwd_workspace": C.c_int64, "nsamd_hashgrid_encode_bwd_workspace_state": C.c_int64, "nsamd_field_mlp_saved_floats": C.c_int64}
 
 _lib = None
 

@@ -86,7 +86,19 @@ def load_optimizer_states(model, arena, optimizers: Mapping[str, Mapping[str, An
         arena.step_counts[name] = steps
 
 
-def make_checkpoint(model, arena, step: int, lr: Optional[Mapping[str, float]] = None) -> Dict[str, Any]:
-    """A dict in the reference trainer's layout (trainer.py:467-478) for the parts this package owns."""
+def grad_scaler_state(scalers: Optional[Mapping[str, Any]] = None) -> Dict[str, Any]:
+    """State of the reference trainer's GradScaler (trainer.py:137, :475). nerfacto trains with mixed_precision=True, so
+    that scaler is ENABLED and `load_state_dict` of an empty dict raises (trainer.py:439,450) — a checkpoint must carry
+    a valid state. This package computes in fp32 without loss scaling, so it passes a loaded state through unchanged
+    or emits a fresh scaler's defaults (scale 2^16, growth 2, backoff 0.5, interval 2000, tracker 0)."""
+    if scalers:
+        return dict(scalers)
+    return {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 0}
+
+
+def make_checkpoint(model, arena, step: int, lr: Optional[Mapping[str, float]] = None,
+                    scalers: Optional[Mapping[str, Any]] = None) -> Dict[str, Any]:
+    """A dict in the reference trainer's layout (trainer.py:467-478) for the parts this package owns. `scalers`: the
+    GradScaler state of a checkpoint this run was resumed from (kept as is); default = a fresh enabled scaler's state."""
     return {"step": step, "pipeline": model_state_dict(model), "optimizers": optimizer_state_dicts(model, arena, lr),
-            "schedulers": {}, "scalers": {}}
+            "schedulers": {}, "scalers": grad_scaler_state(scalers)}

@@ -11,13 +11,20 @@
 // GEMM with a long k axis: each wave takes 64 of the chunk's points through 16 v_mfma_f32_16x16x4_f32 per row tile
 // (operands are the LDS rows as they stand) and keeps its partial in registers across the chunks of a persistent
 // workgroup — the first version gave each of 160 threads a 256-long dot product (1536 LDS read instructions per chunk
-// against 128 now). One LDS reduction over the 4 waves and <= kMaxBlocks atomics per weight element at the end.
+// against 128 now). One LDS reduction over the 4 waves at the end; the workgroup's partial goes to a scratch row that
+// density_dw_reduce_kernel sums in a fixed order (bit-reproducible; without scratch: <= kMaxBlocks float atomics per
+// weight element).
 #include "common.h"
 
 namespace nsamd {
 
 constexpr int kMlpBlock = 256;
 constexpr int kMaxBlocks = 1024;
+
+// floats per workgroup row of the weight-gradient partial buffer: [dW0 | db0 | dW1 | db1], padded to 16 B
+__host__ __device__ constexpr int density_partial_stride(int in_dim, int hidden) {
+  return (hidden * in_dim + 2 * hidden + 1 + 3) & ~3;
+}
 
 template <int IN, int H>
 __global__ __launch_bounds__(kMlpBlock) void density_mlp_fwd_kernel(const float* __restrict__ enc,
@@ -51,7 +58,8 @@ template <int IN, int H>
 __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ pre,
     const float* __restrict__ ddensity, int64_t M, nsamd_density_mlp mlp, float* __restrict__ denc,
-    float* __restrict__ dW0, float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1) {
+    float* __restrict__ dW0, float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1,
+    float* __restrict__ partials) {
   constexpr int LD = kMlpBlock + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* gh_T = lds;            // [H][LD]   dL/d(hidden pre-activation) per point
@@ -169,10 +177,55 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
     }
     __syncthreads();
   }
+  if (partials != nullptr) {
+    // one row of partial sums per workgroup, [dW0 (H x IN) | db0 (H) | dW1 (H) | db1]: density_dw_reduce_kernel adds the
+    // rows up in a fixed order, so the weight gradients are bit-reproducible (float atomics are not)
+    float* row = partials + (size_t)blockIdx.x * density_partial_stride(IN, H);
+    for (int e = threadIdx.x; e < H * IN; e += kMlpBlock) row[e] = red[(e / IN) * 16 + (e % IN)];
+    if (threadIdx.x < 2 * H + 1) row[H * IN + threadIdx.x] = accV;
+    return;
+  }
   for (int e = threadIdx.x; e < H * IN; e += kMlpBlock) unsafeAtomicAdd(dW0 + e, red[(e / IN) * 16 + (e % IN)]);
   if (threadIdx.x < H) unsafeAtomicAdd(db0 + threadIdx.x, accV);
   else if (threadIdx.x < 2 * H) unsafeAtomicAdd(dW1 + (threadIdx.x - H), accV);
   else if (threadIdx.x == 2 * H) unsafeAtomicAdd(db1, accV);
+}
+
+// grads += sum over the workgroups' partial rows, in a fixed order: 64 elements x 16 row-groups per workgroup, every
+// thread has 16 loads in flight (the partials are a pure latency problem), the 16 group sums meet in LDS.
+constexpr int kDwGroups = 16;
+__global__ __launch_bounds__(64 * kDwGroups) void density_dw_reduce_kernel(const float* __restrict__ partials, int rows,
+                                                                            int stride, int n_w0, int hidden,
+                                                                            float* __restrict__ dW0,
+                                                                            float* __restrict__ db0,
+                                                                            float* __restrict__ dW1,
+                                                                            float* __restrict__ db1) {
+  __shared__ float part[kDwGroups][64];
+  const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  const int total = n_w0 + 2 * hidden + 1;
+  float s = 0.f;
+  if (e < total) {
+    for (int b0i = grp; b0i < rows; b0i += kDwGroups * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int b = b0i + u * kDwGroups;
+        v[u] = b < rows ? partials[(size_t)b * stride + e] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+  }
+  part[grp][el] = s;
+  __syncthreads();
+  if (grp == 0 && e < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < kDwGroups; ++g2) t += part[g2][el];
+    float* dst = e < n_w0 ? dW0 + e : (e < n_w0 + hidden ? db0 + (e - n_w0) : (e < n_w0 + 2 * hidden ? dW1 + (e - n_w0 - hidden) : db1));
+    *dst += t;
+  }
 }
 
 template <int IN, int H>
@@ -187,18 +240,25 @@ static int launch_fwd(const float* enc, const float* selector, int64_t M, nsamd_
 template <int IN, int H>
 static int launch_bwd(const float* enc, const float* selector, const float* pre, const float* ddensity, int64_t M,
                       nsamd_density_mlp mlp, float* denc, float* dW0, float* db0, float* dW1, float* db1,
-                      hipStream_t stream) {
+                      float* workspace, int64_t workspace_floats, hipStream_t stream) {
   const unsigned blocks = (unsigned)min((int64_t)kMaxBlocks, (M + kMlpBlock - 1) / kMlpBlock);
   const size_t lds = sizeof(float) * ((size_t)(2 * H + IN + 1) * (kMlpBlock + 1) + 8 + (size_t)H * (((IN + 3) & ~3) + 2));
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&density_mlp_bwd_kernel<IN, H>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  if (lds > 64 * 1024) {  // per-device opt-in; cheap enough to repeat
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&density_mlp_bwd_kernel<IN, H>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return NSAMD_ERR_LAUNCH;
   }
+  constexpr int stride = density_partial_stride(IN, H);
+  float* partials = (workspace != nullptr && workspace_floats >= (int64_t)blocks * stride) ? workspace : nullptr;
   density_mlp_bwd_kernel<IN, H><<<blocks, kMlpBlock, lds, stream>>>(enc, selector, pre, ddensity, M, mlp, denc, dW0,
-                                                                   db0, dW1, db1);
+                                                                   db0, dW1, db1, partials);
   NSAMD_CHECK_LAUNCH();
+  if (partials != nullptr) {
+    const int total = H * IN + 2 * H + 1;
+    density_dw_reduce_kernel<<<(total + 63) / 64, 64 * kDwGroups, 0, stream>>>(partials, (int)blocks, stride, H * IN, H,
+                                                                             dW0, db0, dW1, db1);
+    NSAMD_CHECK_LAUNCH();
+  }
   return NSAMD_OK;
 }
 
@@ -225,12 +285,14 @@ extern "C" int nsamd_density_mlp_fwd(const float* enc, const float* selector, in
 
 extern "C" int nsamd_density_mlp_bwd(const float* enc, const float* selector, const float* pre,
                                      const float* ddensity, int64_t M, nsamd_density_mlp mlp, float* denc,
-                                     float* dW0, float* db0, float* dW1, float* db1, nsamd_stream_t stream) {
+                                     float* dW0, float* db0, float* dW1, float* db1, float* workspace,
+                                     int64_t workspace_floats, nsamd_stream_t stream) {
   NSAMD_REQUIRE(M >= 0);
   if (M == 0) return NSAMD_OK;
   NSAMD_REQUIRE(enc && pre && ddensity && denc && dW0 && db0 && dW1 && db1 && mlp.W0 && mlp.b0 && mlp.W1 && mlp.b1);
-#define CALL(IN, H) \
-  launch_bwd<IN, H>(enc, selector, pre, ddensity, M, mlp, denc, dW0, db0, dW1, db1, (hipStream_t)stream)
+#define CALL(IN, H)                                                                                          \
+  launch_bwd<IN, H>(enc, selector, pre, ddensity, M, mlp, denc, dW0, db0, dW1, db1, workspace, workspace_floats, \
+                    (hipStream_t)stream)
   NSAMD_DENSITY_DISPATCH(CALL)
 #undef CALL
 }

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
     nsamd_field_mlp mlp, int app_dim, const float* __restrict__ ddensity, const float* __restrict__ drgb,
     float* __restrict__ denc, nsamd_field_mlp_grads grads, float* __restrict__ partials,
-    const float* __restrict__ acts) {
+    float* __restrict__ app_partials, const float* __restrict__ acts) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* W = lds;                     // kRowTotal
   float* bias = lds + kRowTotal;      // 256
@@ -565,27 +565,44 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
 
     // appearance-embedding gradient (slots 32..63): rows of one camera are pre-reduced over the tile's points
     if (app_table != nullptr && grads.appearance != nullptr) {
-      const int cam32 = (int)ti.cam;
-      const int cam0 = __shfl(cam32, 0);
-      const bool uniform = __all(cam32 == cam0);
-      if (uniform) {
+      if (app_partials != nullptr) {
+        // every tile lies inside one ray (the host checked samples-per-ray % 16 == 0): its 32 sums go to a scratch row
+        // and field_app_reduce_kernel adds the rows of each camera in a fixed order — bit-reproducible, no atomics
 #pragma unroll
-        for (int t = 2; t < 4; ++t)
+        for (int t = 2; t < 4; ++t) {
+          v4f v = g_hin[t];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float v = g_hin[t][r];
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 8);
-            if (j == 0 && v != 0.0f) unsafeAtomicAdd(grads.appearance + (int64_t)cam0 * 32 + 16 * (t - 2) + 4 * g + r, v);
+            v[r] += __shfl_xor(v[r], 1);
+            v[r] += __shfl_xor(v[r], 2);
+            v[r] += __shfl_xor(v[r], 4);
+            v[r] += __shfl_xor(v[r], 8);
           }
-      } else if (ti.live) {
+          if (j == 0 && tile < tiles) *reinterpret_cast<v4f*>(app_partials + tile * 32 + 16 * (t - 2) + 4 * g) = v;
+        }
+      } else {
+        const int cam32 = (int)ti.cam;
+        const int cam0 = __shfl(cam32, 0);
+        const bool uniform = __all(cam32 == cam0);
+        if (uniform) {
 #pragma unroll
-        for (int t = 2; t < 4; ++t)
+          for (int t = 2; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            unsafeAtomicAdd(grads.appearance + ti.cam * 32 + 16 * (t - 2) + 4 * g + r, g_hin[t][r]);
+            for (int r = 0; r < 4; ++r) {
+              float v = g_hin[t][r];
+              v += __shfl_xor(v, 1);
+              v += __shfl_xor(v, 2);
+              v += __shfl_xor(v, 4);
+              v += __shfl_xor(v, 8);
+              if (j == 0 && v != 0.0f) unsafeAtomicAdd(grads.appearance + (int64_t)cam0 * 32 + 16 * (t - 2) + 4 * g + r, v);
+            }
+        } else if (ti.live) {
+#pragma unroll
+          for (int t = 2; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              unsafeAtomicAdd(grads.appearance + ti.cam * 32 + 16 * (t - 2) + 4 * g + r, g_hin[t][r]);
+        }
       }
     }
 
@@ -730,6 +747,39 @@ __global__ __launch_bounds__(64 * kReduceGroups) void field_dw_reduce_kernel(con
   }
 }
 
+// Appearance-embedding gradient from the per-tile rows of the backward: one workgroup per camera adds the rows of its
+// rays — thread t takes rays t, t + 256, ... in order, the 256 partial sums meet in LDS and are added up in index
+// order. Fixed assignment, fixed order: bit-reproducible (the float atomics this replaces were not).
+__global__ __launch_bounds__(256) void field_app_reduce_kernel(const float* __restrict__ rows,
+                                                               const int64_t* __restrict__ cams, int64_t num_rays,
+                                                               int tiles_per_ray, float* __restrict__ grad) {
+  __shared__ float part[256][33];
+  const int64_t cam = blockIdx.x;
+  float acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) acc[k] = 0.0f;
+  for (int64_t r = threadIdx.x; r < num_rays; r += 256) {
+    if (cams[r] != cam) continue;
+    for (int t = 0; t < tiles_per_ray; ++t) {
+      const v4f* row = reinterpret_cast<const v4f*>(rows + (r * tiles_per_ray + t) * 32);
+#pragma unroll
+      for (int k4 = 0; k4 < 8; ++k4) {
+        const v4f v = row[k4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[4 * k4 + c] += v[c];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 32; ++k) part[threadIdx.x][k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float s = 0.0f;
+    for (int t = 0; t < 256; ++t) s += part[t][threadIdx.x];
+    if (s != 0.0f) grad[cam * 32 + threadIdx.x] += s;
+  }
+}
+
 // one MFMA with the assumed operand / result lane mapping (layout probe for the tests)
 __global__ void probe_mfma16_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                     float* __restrict__ out) {
@@ -820,22 +870,36 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
   NSAMD_REQUIRE(ddensity && drgb && denc);
   const int64_t tiles = (M + 15) / 16;
   const size_t lds = sizeof(float) * (kRowTotal + 256 + kCoopWaves * 2 * kScratchTile);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return NSAMD_ERR_NO_DEVICE;
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {  // the dynamic-LDS opt-in is per device
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return NSAMD_ERR_LAUNCH;
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + kCoopWaves - 1) / kCoopWaves);
   float* partials = (workspace != nullptr && workspace_floats >= (int64_t)blocks * kPartialStride) ? workspace : nullptr;
+  // per-tile rows of the appearance-embedding gradient (fixed-order reduction per camera): needs every 16-point tile
+  // inside one ray and room behind the weight-gradient partials; otherwise float atomics (sums in no fixed order)
+  float* app_partials = nullptr;
+  if (partials != nullptr && camera_indices != nullptr && grads.appearance != nullptr && dir_group % 16 == 0 &&
+      M % dir_group == 0 && mlp.num_images <= 8192 &&
+      workspace_floats >= (int64_t)blocks * kPartialStride + tiles * 32)
+    app_partials = workspace + (int64_t)blocks * kPartialStride;
   field_mlp_bwd_kernel<<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
       enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-      grads, partials, acts);
+      grads, partials, app_partials, acts);
   NSAMD_CHECK_LAUNCH();
   if (partials != nullptr) {
     field_dw_reduce_kernel<<<(kPartialStride + 63) / 64, 64 * kReduceGroups, 0, (hipStream_t)stream>>>(partials, (int)blocks, grads,
                                                                                       app_dim);
+    NSAMD_CHECK_LAUNCH();
+  }
+  if (app_partials != nullptr) {
+    field_app_reduce_kernel<<<(unsigned)mlp.num_images, 256, 0, (hipStream_t)stream>>>(
+        app_partials, camera_indices, M / dir_group, (int)(dir_group / 16), grads.appearance);
     NSAMD_CHECK_LAUNCH();
   }
   return NSAMD_OK;

@@ -56,6 +56,27 @@ __global__ void raygen_pinhole_kernel(const int64_t* __restrict__ ray_indices, c
   if (directions_norm) directions_norm[i] = n0;
 }
 
+// The step's ray batch out of a pool of pre-generated batches resident in HBM: what VanillaDataManager.next_train
+// (/root/reference/nerfstudio/data/datamanagers/base_datamanager.py:506-515) hands the model each iteration. The slot
+// comes from DEVICE memory (a float, as the other per-step scalars) so that a captured hipGraph replays with a new
+// batch every step. One launch copies origins, directions, camera indices and target colours.
+__global__ void select_batch_kernel(const float* __restrict__ slot_dev, int32_t slots, int64_t n,
+                                    const float* __restrict__ origins_pool, const float* __restrict__ directions_pool,
+                                    const int64_t* __restrict__ cameras_pool, const float* __restrict__ target_pool,
+                                    float* __restrict__ origins, float* __restrict__ directions,
+                                    int64_t* __restrict__ cameras, float* __restrict__ target) {
+  int32_t slot = (int32_t)slot_dev[0];
+  slot = slot < 0 ? 0 : (slot >= slots ? slots - 1 : slot);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3 * n) {
+    const int64_t src = (int64_t)slot * 3 * n + i;
+    origins[i] = origins_pool[src];
+    directions[i] = directions_pool[src];
+    target[i] = target_pool[src];
+  }
+  if (i < n) cameras[i] = cameras_pool[(int64_t)slot * n + i];
+}
+
 // torch.optim.Adam (no amsgrad / weight decay / maximize): one pass over the flat arena, 16 B per lane.
 // bias corrections are folded by the host into step_size = lr / (1 - b1^t) and inv_sqrt_bc2 = 1 / sqrt(1 - b2^t).
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -119,6 +140,23 @@ extern "C" int nsamd_raygen_pinhole(const int64_t* ray_indices, const float* c2w
   NSAMD_REQUIRE(ray_indices && c2w && fx && fy && cx && cy && origins && directions && pixel_area);
   raygen_pinhole_kernel<<<(unsigned)((num_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(
       ray_indices, c2w, fx, fy, cx, cy, num_rays, origins, directions, pixel_area, directions_norm);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_select_batch(const float* slot_dev, int32_t slots, int64_t num_rays, const float* origins_pool,
+                                  const float* directions_pool, const int64_t* cameras_pool, const float* target_pool,
+                                  float* origins, float* directions, int64_t* cameras, float* target,
+                                  nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && slots >= 1);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(slot_dev && origins_pool && directions_pool && cameras_pool && target_pool && origins && directions &&
+                cameras && target);
+  const int64_t nb = (3 * num_rays + 255) / 256;
+  if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
+  select_batch_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(slot_dev, slots, num_rays, origins_pool,
+                                                                     directions_pool, cameras_pool, target_pool,
+                                                                     origins, directions, cameras, target);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

@@ -1,0 +1,105 @@
+// Internal interface of the table-gradient scatter (scatter.hip), used by hashgrid.hip's backward entry points.
+// Not part of the C ABI.
+#pragma once
+
+#include "common.h"
+
+namespace nsamd {
+
+// ---- order-independent accumulation -------------------------------------------------------------------------------
+// Float sums depend on their order, and every parallel scatter order is a race; Adam (eps = 1e-15) then turns the
+// rounding residue of a cancelling sum into a full-size step, so two identical training runs drift apart within tens
+// of steps. The scatter therefore accumulates in 64-bit FIXED POINT: integer addition is
+// associative, so the result is bit-identical whatever the order of the atomics, the queue layout or which path
+// (static segment / dynamic area / spill list) a record took. Scale per hash level: with `max` the largest |value| a
+// record of the level can carry (exponent field e_max) and `headroom` bits for the number of summands,
+//   fixed(v) = trunc(v * 2^k),  k = 188 - headroom - e_max   =>   |v * 2^k| < 2^(62 - headroom), |sum| < 2^62.
+// A value keeps its full 24-bit mantissa while it is larger than max * 2^-(38 - headroom); smaller ones lose low bits
+// gradually (absolute error <= 2^-k per summand, i.e. < 1e-12 of the level's largest gradient for headroom 20).
+struct FixedScale {
+  int k;       // value = fixed * 2^-k
+  bool empty;  // nothing recorded on this level
+  bool bad;    // non-finite gradient on this level: the output is NaN
+};
+
+__device__ __forceinline__ FixedScale fixed_scale(uint32_t max_bits, int headroom) {
+  FixedScale s;
+  const int e_max = (int)((max_bits >> 23) & 0xffu);
+  s.empty = e_max == 0;  // zero (or denormal: < 1.2e-38, flushed) everywhere
+  s.bad = e_max == 255;
+  s.k = 188 - headroom - e_max;
+  return s;
+}
+
+// trunc(v * 2^k) as a 64-bit two's-complement integer, |v * 2^k| < 2^44 (headroom >= 18). 8 VALU operations: the scaled
+// value is split into a high part (multiple of 2^24) and the rest, both exactly representable, each converted with the
+// hardware float -> int32 conversion (round toward zero: symmetric, -0 -> 0) and rejoined by one 64-bit multiply-add.
+__device__ __forceinline__ unsigned long long to_fixed(float v, int k) {
+  const float t = ldexpf(v, k);                          // exact (or flushed to zero when denormal)
+  const float hi_f = truncf(t * 5.9604644775390625e-8f); // t * 2^-24
+  const float lo_f = fmaf(hi_f, -16777216.0f, t);        // exact: t minus its high part
+  const long long r = (long long)(int)hi_f * 16777216ll + (long long)(int)lo_f;
+  return (unsigned long long)r;  // the atomics add modulo 2^64
+}
+
+__device__ __forceinline__ float from_fixed(unsigned long long a, int k) {
+  return (float)ldexp((double)(long long)a, -k);
+}
+
+// ---- geometry -----------------------------------------------------------------------------------------------------
+struct LevelList {
+  int8_t level[32];
+  int count;
+};
+
+// The table gradient is partitioned into (level, tile) pieces of 2^slice_log2 entries; a tile's queue holds `tile_cap`
+// 16-B records: first `segs * seg_cap` slots in STATIC segments (one per pass-1 workgroup: no reservation atomics),
+// then a dynamic area handed out by a per-tile cursor (levels routed in run mode use the whole queue dynamically).
+struct ScatterGeom {
+  int32_t slice_log2, log2_bins, num_levels, headroom;
+  uint32_t segs;         // pass-1 workgroups along the points = ceil(M / block_points)
+  uint32_t block_points; // points per pass-1 workgroup of the fine kernel
+  uint32_t seg_cap;      // records per static segment
+  uint32_t tile_cap;     // records per tile queue
+  uint32_t spill_cap;    // records of the spill list
+  uint32_t coarse_mask;  // bit l: level l is routed by the run kernel (no static segments)
+};
+
+struct ScatterBufs {
+  uint32_t* hdr;         // [kHdrWords]
+  uint32_t* dyn_cursor;  // [tiles]
+  uint32_t* counts;      // [tiles][segs]
+  uint4* queues;         // [tiles][tile_cap]
+  uint4* spill_rec;      // [spill_cap]
+  uint32_t* spill_tile;  // [spill_cap]
+  // last resort of an ACCUMULATING call whose (bounded) spill list is full: float atomics straight into the gradient
+  // (nullptr for write-only calls, whose list holds the worst case)
+  float* direct_table;
+  int32_t log2_table_size, log2_bins, slice_log2;
+};
+
+constexpr int kHdrWords = 64;
+constexpr int kHdrSpillCount = 32;   // records appended to the spill list by this call
+constexpr int kHdrTicket = 33;       // finish kernel: last workgroup resets the header
+constexpr int kHdrEvtSpill = 40;     // sticky: spill records seen since the workspace was created
+constexpr int kHdrEvtUnordered = 41; // sticky: spill records applied with float atomics (beyond the fold limit)
+constexpr int kHdrEvtLost = 42;      // sticky: records that found no room at all (cannot happen with a worst-case list)
+constexpr uint32_t kSpillFold = 8192;  // spill records pass 2 folds into its tiles (exact, order-independent)
+
+struct ScatterPlan {
+  bool ok;
+  ScatterGeom geom;
+  int64_t tiles;
+  int64_t state_words;  // leading words that must be zero before the first call (header + cursors)
+  int64_t total_words;
+};
+
+// Host: geometry for (grid, M); `max_spill` = true sizes the spill list for the worst case (write-only calls).
+ScatterPlan scatter_plan(const nsamd_grid& grid, int64_t M, bool max_spill);
+
+// Host: enqueue route (pass 1) + apply (pass 2) + finish on `stream`. Returns an nsamd_status.
+int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsamd_aabb& aabb, const nsamd_grid& grid,
+                   const float* denc, int64_t stride_p, int64_t stride_k, float* dtable, float* workspace,
+                   const ScatterPlan& plan, bool overwrite, hipStream_t stream);
+
+}  // namespace nsamd

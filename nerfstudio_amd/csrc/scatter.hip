@@ -1,0 +1,740 @@
+// Table-gradient scatter of the hash encoding for gfx950 (backward of HashEncoding.pytorch_fwd,
+// /root/reference/nerfstudio/field_components/encodings.py:417-458 — autograd's index_put accumulate into the dense
+// [L*T, 2] gradient). HBM-bound byte work: 8 corners x 16 B read-modify-write per (point, level) algorithmically.
+//
+// fp32 global atomics retire at ~20 G lane-ops/s on this part (profiles/r01_probe_scatter*.log) — 2.9 ms for the
+// nerfacto main table — so the scatter is two passes over 16-B records with NO float atomics anywhere:
+//
+//  PASS 1 (route)  derives every corner update once and appends a record to the queue of the (level, tile) it hashes
+//    into. Records are x-PAIRS: idx = x ^ y*P1 ^ z*P2 differs only in low bits between x and x+1, so both
+//    x-neighbours of a cell edge share a tile and everything but the x weight: (g0*bz*by, g1*bz*by, wx, ia|ib<<14|flag).
+//    Fine levels (scatter_route_fine_kernel): a tile's queue starts with one STATIC segment per pass-1 workgroup, so a
+//    record's slot is  segment base + ds_add_rtn rank  — no reservation round trip to global memory, one barrier, the
+//    store leaves as soon as the rank is back. Only what overflows a segment (non-uniform levels) takes the classic
+//    route: one returning global atomic per (workgroup, tile) into the tile's dynamic area, records recomputed in a
+//    second sweep. Coarse levels (scatter_route_runs_kernel, cell wider than the sample spacing): a thread walks 4
+//    consecutive samples and sums the corner contributions in registers while the cell stays the same (fixed order),
+//    then count -> reserve -> emit in two sweeps.
+//  PASS 2 (apply)  one workgroup per tile accumulates its queue in LDS and stores (write-only call) or adds the tile
+//    with coalesced accesses.
+//
+// Determinism: pass 2 accumulates in 64-bit fixed point (scatter.h) with ds_add_u64 — native, fire-and-forget, 3.0
+// lane-ops/clk/CU with divergent addresses and no slower on one hot address (the float CAS loop of round 1: 2.2, and
+// it collapsed on hot coarse cells). Integer addition is associative, so queue order, the static/dynamic/spill
+// routing and the atomics' order do not reach the result: two runs on the same inputs give the same bits. Records that
+// find no room in their tile go to a spill list; pass 2 folds the first kSpillFold of them into their tiles (still
+// exact and order-free), the finish kernel applies any rest with float atomics and counts them (hdr[kHdrEvtUnordered]).
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "scatter.h"
+
+namespace nsamd {
+
+constexpr int kRunLen = 4;        // consecutive samples per thread in the run kernel
+constexpr int kRunThreads = 256;  // -> 1024 points per workgroup
+constexpr int kMaxLog2Bins = 10;  // pass-1 LDS counters: 3 x 4 levels x bins x 4 B <= 48 KiB
+
+// Append a record that found no room in its tile (or an x-pair straddling two tiles). One returning atomic per
+// wavefront; out of line: this is the cold path of ~50 call sites. False when the list is full.
+__device__ __noinline__ bool spill_list_append(uint32_t* hdr, uint4* spill_rec, uint32_t* spill_tile, uint32_t cap,
+                                               uint32_t tile, uint4 rec) {
+  const unsigned long long active = __ballot(1);
+  const int lane = threadIdx.x & 63;
+  const int leader = __builtin_ctzll(active);
+  const uint32_t n = (uint32_t)__builtin_popcountll(active);
+  const uint32_t mine = (uint32_t)__builtin_popcountll(active & ((1ull << lane) - 1ull));
+  uint32_t base = 0u;
+  if (lane == leader) base = atomicAdd(hdr + kHdrSpillCount, n);
+  base = __shfl(base, leader);
+  const uint32_t pos = base + mine;
+  if (pos >= cap) return false;
+  spill_rec[pos] = rec;
+  spill_tile[pos] = tile;
+  return true;
+}
+
+// Last resort of an ACCUMULATING call whose (bounded) spill list is full: float atomics straight into the gradient —
+// exact, but in no fixed order (counted). `table_level_tile` = start of the tile in the gradient.
+__device__ __noinline__ void spill_direct(float* t, uint32_t* hdr, uint4 rec) {
+  const float f0 = __uint_as_float(rec.x), f1 = __uint_as_float(rec.y);
+  if (rec.w & 0x80000000u) {
+    const float wx = __uint_as_float(rec.z), omx = 1.0f - wx;
+    float* a = t + 2 * (size_t)(rec.w & 0x3fffu);
+    float* b = t + 2 * (size_t)((rec.w >> 14) & 0x3fffu);
+    unsafeAtomicAdd(a, f0 * omx);
+    unsafeAtomicAdd(a + 1, f1 * omx);
+    unsafeAtomicAdd(b, f0 * wx);
+    unsafeAtomicAdd(b + 1, f1 * wx);
+  } else {
+    float* a = t + 2 * (size_t)(rec.w & 0x3fffu);
+    unsafeAtomicAdd(a, f0);
+    unsafeAtomicAdd(a + 1, f1);
+  }
+  atomicAdd(hdr + kHdrEvtUnordered, 1u);
+}
+
+__device__ __forceinline__ void spill_append(const ScatterBufs& buf, uint32_t cap, uint32_t tile, const uint4& rec) {
+  if (spill_list_append(buf.hdr, buf.spill_rec, buf.spill_tile, cap, tile, rec)) return;
+  if (buf.direct_table != nullptr) {
+    const uint32_t level = tile >> buf.log2_bins, bin = tile & ((1u << buf.log2_bins) - 1u);
+    spill_direct(buf.direct_table + ((((size_t)level << buf.log2_table_size) + ((size_t)bin << buf.slice_log2)) << 1),
+                 buf.hdr, rec);
+  } else {
+    atomicAdd(buf.hdr + kHdrEvtLost, 1u);  // cannot happen: write-only calls size the list for the worst case
+  }
+}
+
+struct PairHash {
+  uint32_t ia, ib;
+};
+
+// hashes of the x-pair q (bit0: y is ceil, bit1: z is ceil) of a cell
+__device__ __forceinline__ PairHash pair_hash(const Cell& c, int q, uint32_t mask) {
+  const uint32_t yz = ((uint32_t)((q & 1) ? c.hi[1] : c.lo[1]) * kPrimeY) ^ ((uint32_t)((q & 2) ? c.hi[2] : c.lo[2]) * kPrimeZ);
+  return PairHash{((uint32_t)c.lo[0] ^ yz) & mask, ((uint32_t)c.hi[0] ^ yz) & mask};
+}
+
+// ---- pass 1, fine levels -------------------------------------------------------------------------------------------
+// kThreads x kPts points per workgroup, kLevels levels per thread (position computed once, 4 * kLevels * kPts
+// independent record chains per thread to cover the load -> LDS rank -> store latencies).
+template <int kThreads, int kPts, int kLevels>
+__global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
+    nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
+    int64_t stride_p, int64_t stride_k, ScatterGeom G, LevelList levels, ScatterBufs buf) {
+  static_assert(kPts * kLevels * 4 <= 32, "overflow mask is 32 bits");
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+  const int B = 1 << G.log2_bins;
+  uint32_t* cnt = lds_u;               // [kLevels][B] records of this workgroup per tile
+  uint32_t* cnt2 = cnt + kLevels * B;  // [kLevels][B] ranks inside the dynamic reservation (second sweep)
+  uint32_t* base = cnt2 + kLevels * B; // [kLevels][B] start of the dynamic reservation
+  uint32_t* lmax = base + kLevels * B; // [kLevels] max |gradient| bits
+  for (int t = threadIdx.x; t < 2 * kLevels * B; t += kThreads) cnt[t] = 0u;
+  if (threadIdx.x < kLevels) lmax[threadIdx.x] = 0u;
+  const int first = blockIdx.y * kLevels;
+  int lvl[kLevels];
+#pragma unroll
+  for (int i = 0; i < kLevels; ++i) lvl[i] = first + i < levels.count ? (int)levels.level[first + i] : -1;
+  float g0[kPts][kLevels], g1[kPts][kLevels];
+  float x[kPts], y[kPts], z[kPts];
+  bool inside[kPts];
+#pragma unroll
+  for (int j = 0; j < kPts; ++j) {  // all gradient loads in flight before anything depends on them
+    const int64_t p = ((int64_t)blockIdx.x * kPts + j) * kThreads + threadIdx.x;
+    inside[j] = p < M;
+#pragma unroll
+    for (int i = 0; i < kLevels; ++i) {
+      g0[j][i] = 0.0f;
+      g1[j][i] = 0.0f;
+      if (inside[j] && lvl[i] >= 0) {
+        const float* gptr = denc + p * stride_p + (int64_t)(2 * lvl[i]) * stride_k;
+        g0[j][i] = gptr[0];
+        g1[j][i] = gptr[stride_k];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kPts; ++j) {
+    const int64_t p = ((int64_t)blockIdx.x * kPts + j) * kThreads + threadIdx.x;
+    x[j] = y[j] = z[j] = 0.0f;
+    if (inside[j]) {
+      load_position(P, p, x[j], y[j], z[j]);
+      (void)normalise_position(transform, box, x[j], y[j], z[j]);
+    }
+  }
+  __syncthreads();
+  const uint32_t mask = (1u << grid.log2_table_size) - 1u;
+  const int sl = G.slice_log2;
+  const uint32_t local_mask = (1u << sl) - 1u;
+  const uint32_t C = G.seg_cap, Q = G.tile_cap;
+  const uint32_t static_end = G.segs * C;
+  uint32_t over = 0u;  // bit ((j * kLevels + i) * 4 + q): the record found its static segment full
+
+  auto sweep = [&](auto tag) {
+    constexpr int SW = decltype(tag)::value;
+#pragma unroll
+    for (int j = 0; j < kPts; ++j) {
+#pragma unroll
+      for (int i = 0; i < kLevels; ++i) {
+        const int slot = (j * kLevels + i) * 4;
+        if (lvl[i] < 0 || !inside[j] || (g0[j][i] == 0.0f && g1[j][i] == 0.0f)) continue;  // adding zero is a no-op
+        if (SW == 1 && ((over >> slot) & 0xfu) == 0u) continue;
+        const Cell c = locate_cell(x[j], y[j], z[j], grid.scalings[lvl[i]]);
+        if (SW == 0) {  // integer compare of |bits|: a NaN or Inf wins and marks the level non-finite
+          const uint32_t b0 = __float_as_uint(g0[j][i]) & 0x7fffffffu, b1 = __float_as_uint(g1[j][i]) & 0x7fffffffu;
+          atomicMax(lmax + i, b0 > b1 ? b0 : b1);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (SW == 1 && !((over >> (slot + q)) & 1u)) continue;
+          const PairHash h = pair_hash(c, q, mask);
+          const uint32_t bin = h.ia >> sl;
+          const uint32_t tile = ((uint32_t)lvl[i] << G.log2_bins) + bin;
+          // autograd order ((g * wz) * wy) * wx; the x factor is applied by pass 2
+          const float bz = (q & 2) ? c.w[2] : 1.0f - c.w[2];
+          const float by = (q & 1) ? c.w[1] : 1.0f - c.w[1];
+          const float a0 = (g0[j][i] * bz) * by, a1 = (g1[j][i] * bz) * by;
+          if ((h.ib >> sl) != bin) {
+            // the pair straddles two tiles (needs a carry past bit slice_log2: only when res >= 2^slice_log2, which the
+            // host avoids whenever the table allows): two single records through the spill list, in the second sweep
+            if (SW == 0) {
+              over |= 1u << (slot + q);
+            } else {
+              spill_append(buf, G.spill_cap, tile,
+                           make_uint4(__float_as_uint(a0 * (1.0f - c.w[0])), __float_as_uint(a1 * (1.0f - c.w[0])), 0u,
+                                      h.ia & local_mask));
+              spill_append(buf, G.spill_cap, ((uint32_t)lvl[i] << G.log2_bins) + (h.ib >> sl),
+                           make_uint4(__float_as_uint(a0 * c.w[0]), __float_as_uint(a1 * c.w[0]), 0u, h.ib & local_mask));
+            }
+            continue;
+          }
+          const uint4 rec = make_uint4(__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(c.w[0]),
+                                       (h.ia & local_mask) | ((h.ib & local_mask) << 14) | 0x80000000u);
+          if (SW == 0) {
+            const uint32_t rank = atomicAdd(cnt + (i << G.log2_bins) + bin, 1u);  // ds_add_rtn_u32
+            if (rank < C) buf.queues[(size_t)tile * Q + blockIdx.x * C + rank] = rec;
+            else over |= 1u << (slot + q);
+          } else {
+            const uint32_t pos = base[(i << G.log2_bins) + bin] + atomicAdd(cnt2 + (i << G.log2_bins) + bin, 1u);
+            if (pos < Q - static_end) buf.queues[(size_t)tile * Q + static_end + pos] = rec;
+            else spill_append(buf, G.spill_cap, tile, rec);
+          }
+        }
+      }
+    }
+  };
+
+  sweep(std::integral_constant<int, 0>{});
+  const int any_over = __syncthreads_or(over != 0u);
+  for (int t = threadIdx.x; t < kLevels * B; t += kThreads) {
+    const int i = t >> G.log2_bins;
+    const int level = first + i < levels.count ? (int)levels.level[first + i] : -1;
+    if (level < 0) continue;
+    const uint32_t n = cnt[t];
+    const uint32_t tile = ((uint32_t)level << G.log2_bins) + (uint32_t)(t & (B - 1));
+    buf.counts[(size_t)tile * G.segs + blockIdx.x] = n < C ? n : C;
+    if (any_over) base[t] = n > C ? atomicAdd(buf.dyn_cursor + tile, n - C) : 0u;
+  }
+  if (threadIdx.x < kLevels) {
+    const int level = first + (int)threadIdx.x < levels.count ? (int)levels.level[first + threadIdx.x] : -1;
+    if (level >= 0 && lmax[threadIdx.x] != 0u) atomicMax(buf.hdr + level, lmax[threadIdx.x]);
+  }
+  if (!any_over) return;
+  __syncthreads();
+  sweep(std::integral_constant<int, 1>{});
+}
+
+// ---- pass 1, coarse levels -----------------------------------------------------------------------------------------
+// Every thread walks kRunLen CONSECUTIVE samples and merges those that stay in one cell (a run): per-corner sums in
+// registers, in sample order. A run of one sample leaves as 4 x-pair records, a longer one as 8 single records
+// (value pair + local index). Sweep 0 counts per tile, the workgroup reserves its share of every tile's queue with one
+// returning atomic, sweep 1 recomputes the runs and stores — nothing is kept in registers or LDS between the sweeps.
+template <int kLevels>
+__global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
+    nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
+    int64_t stride_p, int64_t stride_k, ScatterGeom G, LevelList levels, ScatterBufs buf) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+  const int B = 1 << G.log2_bins;
+  uint32_t* cnt = lds_u;
+  uint32_t* cnt2 = cnt + kLevels * B;
+  uint32_t* base = cnt2 + kLevels * B;
+  uint32_t* lmax = base + kLevels * B;
+  for (int t = threadIdx.x; t < 2 * kLevels * B; t += kRunThreads) cnt[t] = 0u;
+  if (threadIdx.x < kLevels) lmax[threadIdx.x] = 0u;
+  const int first = blockIdx.y * kLevels;
+  int lvl[kLevels];
+#pragma unroll
+  for (int i = 0; i < kLevels; ++i) lvl[i] = first + i < levels.count ? (int)levels.level[first + i] : -1;
+  const int64_t p0 = ((int64_t)blockIdx.x * kRunThreads + threadIdx.x) * kRunLen;
+  float g0[kRunLen][kLevels], g1[kRunLen][kLevels];
+  float px[kRunLen], py[kRunLen], pz[kRunLen];
+#pragma unroll
+  for (int s = 0; s < kRunLen; ++s) {
+#pragma unroll
+    for (int i = 0; i < kLevels; ++i) {
+      g0[s][i] = 0.0f;
+      g1[s][i] = 0.0f;
+      if (p0 + s < M && lvl[i] >= 0) {
+        const float* gptr = denc + (p0 + s) * stride_p + (int64_t)(2 * lvl[i]) * stride_k;
+        g0[s][i] = gptr[0];
+        g1[s][i] = gptr[stride_k];
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < kRunLen; ++s) {
+    px[s] = py[s] = pz[s] = 0.0f;
+    if (p0 + s < M) {
+      load_position(P, p0 + s, px[s], py[s], pz[s]);
+      (void)normalise_position(transform, box, px[s], py[s], pz[s]);
+    }
+  }
+  __syncthreads();
+  const uint32_t mask = (1u << grid.log2_table_size) - 1u;
+  const int sl = G.slice_log2;
+  const uint32_t local_mask = (1u << sl) - 1u;
+  const uint32_t Q = G.tile_cap;
+
+  auto sweep = [&](auto tag) {
+    constexpr int SW = decltype(tag)::value;
+    auto emit = [&](int i, uint32_t tile_bin, uint4 rec) {
+      const uint32_t tile = ((uint32_t)lvl[i] << G.log2_bins) + tile_bin;
+      if (SW == 0) {
+        atomicAdd(cnt + (i << G.log2_bins) + tile_bin, 1u);
+      } else {
+        const uint32_t pos = base[(i << G.log2_bins) + tile_bin] + atomicAdd(cnt2 + (i << G.log2_bins) + tile_bin, 1u);
+        if (pos < Q) buf.queues[(size_t)tile * Q + pos] = rec;
+        else spill_append(buf, G.spill_cap, tile, rec);
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < kLevels; ++i) {
+      if (lvl[i] < 0) continue;
+      const float scale = grid.scalings[lvl[i]];
+      Cell cur{};
+      float a0[8], a1[8];       // per-corner sums of the open run (valid when len >= 2)
+      float f0 = 0.f, f1 = 0.f; // gradient of the run's first sample (len == 1: pair records)
+      int len = 0;
+      uint32_t gmax = 0u;  // max |gradient| bits (integer compare: NaN / Inf win)
+#pragma unroll
+      for (int s = 0; s <= kRunLen; ++s) {
+        bool live = false;
+        Cell c = cur;
+        if (s < kRunLen) {
+          live = (p0 + s < M) && !(g0[s][i] == 0.0f && g1[s][i] == 0.0f);
+          if (live) c = locate_cell(px[s], py[s], pz[s], scale);
+        }
+        const bool same = len > 0 && live && c.lo[0] == cur.lo[0] && c.lo[1] == cur.lo[1] && c.lo[2] == cur.lo[2] &&
+                          c.hi[0] == cur.hi[0] && c.hi[1] == cur.hi[1] && c.hi[2] == cur.hi[2];
+        if (len > 0 && (s == kRunLen || (live && !same))) {  // the run ends
+          if (len == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const PairHash h = pair_hash(cur, q, mask);
+              const float bz = (q & 2) ? cur.w[2] : 1.0f - cur.w[2];
+              const float by = (q & 1) ? cur.w[1] : 1.0f - cur.w[1];
+              const float v0 = (f0 * bz) * by, v1 = (f1 * bz) * by;
+              if ((h.ib >> sl) == (h.ia >> sl)) {
+                emit(i, h.ia >> sl,
+                     make_uint4(__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(cur.w[0]),
+                                (h.ia & local_mask) | ((h.ib & local_mask) << 14) | 0x80000000u));
+              } else {  // straddling pair: two singles
+                emit(i, h.ia >> sl, make_uint4(__float_as_uint(v0 * (1.0f - cur.w[0])),
+                                               __float_as_uint(v1 * (1.0f - cur.w[0])), 0u, h.ia & local_mask));
+                emit(i, h.ib >> sl, make_uint4(__float_as_uint(v0 * cur.w[0]), __float_as_uint(v1 * cur.w[0]), 0u,
+                                               h.ib & local_mask));
+              }
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const uint32_t idx = corner_index(cur, k, mask);
+              emit(i, idx >> sl, make_uint4(__float_as_uint(a0[k]), __float_as_uint(a1[k]), 0u, idx & local_mask));
+            }
+          }
+          len = 0;
+        }
+        if (s < kRunLen && live) {
+          if (SW == 0) {
+            const uint32_t b0 = __float_as_uint(g0[s][i]) & 0x7fffffffu, b1 = __float_as_uint(g1[s][i]) & 0x7fffffffu;
+            gmax = max(gmax, max(b0, b1));
+          }
+          if (same) {
+            if (len == 1) {  // second sample of the run: open the per-corner sums with the first one (cell weights of cur)
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const float bz = (k & 4) ? cur.w[2] : 1.0f - cur.w[2];
+                const float by = (k & 2) ? cur.w[1] : 1.0f - cur.w[1];
+                const float bx = (k & 1) ? cur.w[0] : 1.0f - cur.w[0];
+                a0[k] = ((f0 * bz) * by) * bx;
+                a1[k] = ((f1 * bz) * by) * bx;
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float bz = (k & 4) ? c.w[2] : 1.0f - c.w[2];
+              const float by = (k & 2) ? c.w[1] : 1.0f - c.w[1];
+              const float bx = (k & 1) ? c.w[0] : 1.0f - c.w[0];
+              a0[k] += ((g0[s][i] * bz) * by) * bx;
+              a1[k] += ((g1[s][i] * bz) * by) * bx;
+            }
+            len += 1;
+          } else {
+            cur = c;
+            f0 = g0[s][i];
+            f1 = g1[s][i];
+            len = 1;
+          }
+        }
+      }
+      // a merged record carries up to kRunLen gradients: the scale bound accounts for that
+      // (exponent + 2 = x kRunLen; saturates into the non-finite range only for gradients beyond 2^125)
+      if (SW == 0 && gmax != 0u) atomicMax(lmax + i, min(gmax + (2u << 23), 0x7fc00000u));
+    }
+  };
+
+  sweep(std::integral_constant<int, 0>{});
+  __syncthreads();
+  for (int t = threadIdx.x; t < kLevels * B; t += kRunThreads) {
+    const int i = t >> G.log2_bins;
+    const int level = first + i < levels.count ? (int)levels.level[first + i] : -1;
+    if (level < 0) continue;
+    const uint32_t n = cnt[t];
+    const uint32_t tile = ((uint32_t)level << G.log2_bins) + (uint32_t)(t & (B - 1));
+    base[t] = n ? atomicAdd(buf.dyn_cursor + tile, n) : 0u;
+  }
+  if (threadIdx.x < kLevels) {
+    const int level = first + (int)threadIdx.x < levels.count ? (int)levels.level[first + threadIdx.x] : -1;
+    if (level >= 0 && lmax[threadIdx.x] != 0u) atomicMax(buf.hdr + level, lmax[threadIdx.x]);
+  }
+  __syncthreads();
+  sweep(std::integral_constant<int, 1>{});
+}
+
+// ---- pass 2 ------------------------------------------------------------------------------------------------------
+// One workgroup per (level, tile): static segments, dynamic area and the folded part of the spill list are summed into
+// an LDS tile of 2 x int64 per entry; the finished tile is converted once and stored / added with coalesced accesses.
+__global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs buf, float* __restrict__ dtable,
+                                     int overwrite) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];  // [entries][2]
+  const int bin = blockIdx.x, level = blockIdx.y;
+  const uint32_t tile = ((uint32_t)level << G.log2_bins) + (uint32_t)bin;
+  const int entries = 1 << G.slice_log2;
+  {
+    uint4* z = reinterpret_cast<uint4*>(acc);
+    for (int e = threadIdx.x; e < entries; e += blockDim.x) z[e] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  const FixedScale fs = fixed_scale(buf.hdr[level], G.headroom);
+  const bool coarse = (G.coarse_mask >> level) & 1u;
+  const uint32_t Q = G.tile_cap, C = G.seg_cap;
+  const uint32_t static_end = coarse ? 0u : G.segs * C;
+  const uint32_t n_dyn = min(buf.dyn_cursor[tile], Q - static_end);
+  const uint32_t n_spill = min(min(buf.hdr[kHdrSpillCount], G.spill_cap), kSpillFold);
+  __syncthreads();
+  // self-cleaning cursor: the next call finds zeros again (the workspace state is zero-initialised once by its owner)
+  if (threadIdx.x == 0) buf.dyn_cursor[tile] = 0u;
+  const uint4* q = buf.queues + (size_t)tile * Q;
+  const int kk = fs.k;
+  auto add_rec = [&](const uint4& r) {
+    const float f0 = __uint_as_float(r.x), f1 = __uint_as_float(r.y);
+    if (r.w & 0x80000000u) {  // x-pair: the x factor of the product ((g*wz)*wy)*wx is applied here
+      const float wx = __uint_as_float(r.z), omx = 1.0f - wx;
+      unsigned long long* a = acc + 2 * (r.w & 0x3fffu);
+      unsigned long long* b = acc + 2 * ((r.w >> 14) & 0x3fffu);
+      atomicAdd(a, to_fixed(f0 * omx, kk));  // ds_add_u64, no return
+      atomicAdd(a + 1, to_fixed(f1 * omx, kk));
+      atomicAdd(b, to_fixed(f0 * wx, kk));
+      atomicAdd(b + 1, to_fixed(f1 * wx, kk));
+    } else {
+      unsigned long long* a = acc + 2 * (r.w & 0x3fffu);
+      atomicAdd(a, to_fixed(f0, kk));
+      atomicAdd(a + 1, to_fixed(f1, kk));
+    }
+  };
+  if (!fs.empty && !fs.bad) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t nw = blockDim.x >> 6;
+    if (!coarse) {
+      // static segments: a wave takes 4 segments per trip (their records are independent loads in flight together)
+      const uint32_t* cnts = buf.counts + (size_t)tile * G.segs;
+      for (uint32_t s0 = wave; s0 < G.segs; s0 += 4u * nw) {
+        uint32_t n[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t s = s0 + (uint32_t)u * nw;
+          n[u] = s < G.segs ? cnts[s] : 0u;
+        }
+        uint4 r[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint4* seg = q + (size_t)(s0 + (uint32_t)u * nw) * C;
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {
+            const uint32_t e = (uint32_t)lane + 64u * v;
+            r[u][v] = e < n[u] ? seg[e] : make_uint4(0u, 0u, 0u, 0u);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int v = 0; v < 2; ++v)
+            if ((uint32_t)lane + 64u * v < n[u]) add_rec(r[u][v]);
+          const uint4* seg = q + (size_t)(s0 + (uint32_t)u * nw) * C;
+          for (uint32_t e = (uint32_t)lane + 128u; e < n[u]; e += 64u) add_rec(seg[e]);
+        }
+      }
+    }
+    // dynamic area: contiguous, 4 records in flight per thread
+    const uint4* dq = q + static_end;
+    for (uint32_t e0 = 0; e0 < n_dyn; e0 += blockDim.x * 4u) {
+      uint4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t e = e0 + (uint32_t)u * blockDim.x + threadIdx.x;
+        r[u] = e < n_dyn ? dq[e] : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e0 + (uint32_t)u * blockDim.x + threadIdx.x < n_dyn) add_rec(r[u]);
+    }
+    // spill list (normally empty): every tile scans the folded prefix for its own records
+    for (uint32_t e = threadIdx.x; e < n_spill; e += blockDim.x)
+      if (buf.spill_tile[e] == tile) add_rec(buf.spill_rec[e]);
+  }
+  __syncthreads();
+  float4* out = reinterpret_cast<float4*>(
+      dtable + ((((size_t)level << grid.log2_table_size) + ((size_t)bin << G.slice_log2)) << 1));
+  const uint4* a4 = reinterpret_cast<const uint4*>(acc);  // one entry = (lo0, hi0, lo1, hi1)
+  const float nan = __uint_as_float(0x7fc00000u);
+  for (int i = threadIdx.x; i < entries / 2; i += blockDim.x) {  // two entries = one float4 of the gradient
+    const uint4 e0 = a4[2 * i], e1 = a4[2 * i + 1];
+    float4 v;
+    if (fs.bad) {
+      v = make_float4(nan, nan, nan, nan);
+    } else {
+      v.x = from_fixed(((unsigned long long)e0.y << 32) | e0.x, fs.k);
+      v.y = from_fixed(((unsigned long long)e0.w << 32) | e0.z, fs.k);
+      v.z = from_fixed(((unsigned long long)e1.y << 32) | e1.x, fs.k);
+      v.w = from_fixed(((unsigned long long)e1.w << 32) | e1.z, fs.k);
+    }
+    if (overwrite) {  // write-only gradient: no zero-fill before the call, no read here
+      out[i] = v;
+    } else if ((e0.x | e0.y | e0.z | e0.w | e1.x | e1.y | e1.z | e1.w) != 0u || fs.bad) {  // sole owner of the tile
+      float4 o = out[i];
+      o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+      out[i] = o;
+    }
+  }
+}
+
+// After pass 2: spill records beyond the folded prefix (a pathological batch) are applied with float atomics — exact
+// sums, but in no fixed order, so they are counted; then the per-call header state goes back to zero.
+__global__ void scatter_finish_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs buf, float* __restrict__ dtable) {
+  const uint32_t total = buf.hdr[kHdrSpillCount];  // (may exceed the capacity: the excess went out directly)
+  const uint32_t n = min(total, G.spill_cap);
+  for (uint32_t e = kSpillFold + blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const uint4 r = buf.spill_rec[e];
+    const uint32_t tile = buf.spill_tile[e];
+    const uint32_t level = tile >> G.log2_bins, bin = tile & ((1u << G.log2_bins) - 1u);
+    float* t = dtable + ((((size_t)level << grid.log2_table_size) + ((size_t)bin << G.slice_log2)) << 1);
+    const float f0 = __uint_as_float(r.x), f1 = __uint_as_float(r.y);
+    if (r.w & 0x80000000u) {
+      const float wx = __uint_as_float(r.z), omx = 1.0f - wx;
+      float* a = t + 2 * (size_t)(r.w & 0x3fffu);
+      float* b = t + 2 * (size_t)((r.w >> 14) & 0x3fffu);
+      unsafeAtomicAdd(a, f0 * omx);
+      unsafeAtomicAdd(a + 1, f1 * omx);
+      unsafeAtomicAdd(b, f0 * wx);
+      unsafeAtomicAdd(b + 1, f1 * wx);
+    } else {
+      float* a = t + 2 * (size_t)(r.w & 0x3fffu);
+      unsafeAtomicAdd(a, f0);
+      unsafeAtomicAdd(a + 1, f1);
+    }
+  }
+  __syncthreads();
+  // the last workgroup to finish (every workgroup has read the counter by then) resets the per-call state
+  if (threadIdx.x == 0 && atomicAdd(buf.hdr + kHdrTicket, 1u) == gridDim.x - 1) {
+    for (int l = 0; l < NSAMD_MAX_LEVELS; ++l) buf.hdr[l] = 0u;
+    if (total) {
+      buf.hdr[kHdrEvtSpill] += total;
+      if (n > kSpillFold) buf.hdr[kHdrEvtUnordered] += n - kSpillFold;
+    }
+    buf.hdr[kHdrSpillCount] = 0u;
+    buf.hdr[kHdrTicket] = 0u;
+  }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------------
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e != nullptr ? atoi(e) : dflt;
+}
+
+// fine-kernel shape (threads, points per thread, levels per thread); NSAMD_SCATTER_SHAPE = "TPL" digits, e.g. 124 =
+// 1024 threads x 2 points x 4 levels (experiments; read once)
+struct FineShape {
+  int threads, pts, levels;
+};
+static FineShape fine_shape() {
+  static const int code = env_int("NSAMD_SCATTER_SHAPE", 114);
+  switch (code) {
+    case 124: return FineShape{1024, 2, 4};
+    case 122: return FineShape{1024, 2, 2};
+    case 524: return FineShape{512, 2, 4};
+    case 522: return FineShape{512, 2, 2};
+    case 514: return FineShape{512, 1, 4};
+    case 112: return FineShape{1024, 1, 2};
+    default: return FineShape{1024, 1, 4};
+  }
+}
+
+static int scatter_target_tiles() {
+  static const int v = env_int("NSAMD_SCATTER_TILES", 512);
+  return v >= 64 ? v : 512;
+}
+
+constexpr int kSliceLog2Max = 13;  // 8192 entries x 2 x int64 = 128 KiB of the 160 KiB LDS
+
+ScatterPlan scatter_plan(const nsamd_grid& grid, int64_t M, bool max_spill) {
+  ScatterPlan p{};
+  if (M <= 0 || grid.num_levels <= 0 || grid.num_levels > NSAMD_MAX_LEVELS) return p;
+  int bits = 0;
+  while ((grid.num_levels << bits) < scatter_target_tiles()) ++bits;
+  int sl = grid.log2_table_size - bits;
+  // a tile at least as wide as the finest resolution keeps every x-pair inside one tile (no straddling pairs)
+  float res_max = 0.0f;
+  for (int l = 0; l < grid.num_levels; ++l) res_max = grid.scalings[l] > res_max ? grid.scalings[l] : res_max;
+  int sl_pair = 1;
+  while ((1 << sl_pair) < (int)res_max + 2 && sl_pair < kSliceLog2Max) ++sl_pair;
+  sl = sl < sl_pair ? sl_pair : sl;
+  sl = sl > kSliceLog2Max ? kSliceLog2Max : (sl < 8 ? 8 : sl);
+  if (sl > grid.log2_table_size) sl = grid.log2_table_size;
+  const int log2_bins = grid.log2_table_size - sl;
+  if (log2_bins > kMaxLog2Bins) return p;
+  const FineShape fsx = fine_shape();
+  ScatterGeom& g = p.geom;
+  g.slice_log2 = sl;
+  g.log2_bins = log2_bins;
+  g.num_levels = grid.num_levels;
+  g.block_points = (uint32_t)(fsx.threads * fsx.pts);
+  const int64_t bins = (int64_t)1 << log2_bins;
+  const int64_t segs = (M + g.block_points - 1) / g.block_points;
+  // static segment: 2x the uniform-hash expectation of 4 pair records per point and level
+  int64_t C = 2 * ((4 * (int64_t)g.block_points + bins - 1) / bins);
+  C = (C + 3) & ~(int64_t)3;
+  if (C < 16) C = 16;
+  const int64_t expect = (4 * M + bins - 1) / bins;  // pair records per tile, uniform hash
+  int64_t Q = segs * C + expect / 2 + 64;
+  if (Q < 2 * expect + expect / 2 + 64) Q = 2 * expect + expect / 2 + 64;  // run-mode levels use the whole queue
+  Q = (Q + 3) & ~(int64_t)3;
+  p.tiles = bins * grid.num_levels;
+  if (p.tiles * Q >= 0x7fffffffLL || segs >= 0x7fffffffLL || C >= 0x3fffffffLL) return p;
+  g.segs = (uint32_t)segs;
+  g.seg_cap = (uint32_t)C;
+  g.tile_cap = (uint32_t)Q;
+  // spill list: worst case (every record of the call: 4 pairs, or after run merging at most as many singles, per point
+  // and level) for write-only calls; otherwise a quarter of the expected total
+  int64_t spill = 4 * M * grid.num_levels + 64;
+  if (!max_spill) {
+    const int64_t part = M * grid.num_levels + 4096;
+    spill = spill < part ? spill : part;
+  }
+  if (spill >= 0x7fffffffLL) return p;
+  g.spill_cap = (uint32_t)spill;
+  // headroom: summands per entry <= 2 per record (a pair whose corners coincide) over queue + folded spills; +2 bits for
+  // the run kernel's merged records (bounded separately by kRunLen x max) is already in its max
+  int64_t summands = 2 * (Q + (int64_t)kSpillFold);
+  int h = 1;
+  while (((int64_t)1 << h) < summands) ++h;
+  g.headroom = h + 1;
+  if (g.headroom > 36) return p;
+  g.coarse_mask = 0u;
+  const int64_t cursor_words = (p.tiles + 3) & ~(int64_t)3;
+  const int64_t count_words = (p.tiles * segs + 3) & ~(int64_t)3;
+  p.state_words = kHdrWords + cursor_words;
+  p.total_words = kHdrWords + cursor_words + count_words + 4 * p.tiles * Q + 4 * spill + ((spill + 3) & ~(int64_t)3);
+  p.ok = true;
+  return p;
+}
+
+static ScatterBufs scatter_bufs(float* workspace, const ScatterPlan& p) {
+  ScatterBufs b;
+  uint32_t* w = reinterpret_cast<uint32_t*>(workspace);
+  b.hdr = w;
+  b.dyn_cursor = w + kHdrWords;
+  const int64_t cursor_words = (p.tiles + 3) & ~(int64_t)3;
+  b.counts = b.dyn_cursor + cursor_words;
+  const int64_t count_words = (p.tiles * (int64_t)p.geom.segs + 3) & ~(int64_t)3;
+  b.queues = reinterpret_cast<uint4*>(b.counts + count_words);  // 16-B aligned: all sizes above are multiples of 4 words
+  b.spill_rec = b.queues + (size_t)p.tiles * p.geom.tile_cap;
+  b.spill_tile = reinterpret_cast<uint32_t*>(b.spill_rec + p.geom.spill_cap);
+  b.direct_table = nullptr;
+  b.log2_table_size = 0;
+  b.log2_bins = p.geom.log2_bins;
+  b.slice_log2 = p.geom.slice_log2;
+  return b;
+}
+
+template <int kThreads, int kPts, int kLevels>
+static void launch_fine(const nsamd_points& pts, int64_t M, int transform, const nsamd_aabb& aabb, const nsamd_grid& grid,
+                        const float* denc, int64_t stride_p, int64_t stride_k, const ScatterGeom& G,
+                        const LevelList& fine, const ScatterBufs& buf, hipStream_t st) {
+  const size_t lds = sizeof(uint32_t) * (3 * (size_t)kLevels * ((size_t)1 << G.log2_bins) + kLevels);
+  dim3 g1(G.segs, (unsigned)((fine.count + kLevels - 1) / kLevels));
+  scatter_route_fine_kernel<kThreads, kPts, kLevels><<<g1, kThreads, lds, st>>>(pts, M, transform, aabb, grid, denc,
+                                                                                 stride_p, stride_k, G, fine, buf);
+}
+
+int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsamd_aabb& aabb, const nsamd_grid& grid,
+                   const float* denc, int64_t stride_p, int64_t stride_k, float* dtable, float* workspace,
+                   const ScatterPlan& plan, bool overwrite, hipStream_t st) {
+  ScatterGeom G = plan.geom;
+  ScatterBufs buf = scatter_bufs(workspace, plan);
+  buf.log2_table_size = grid.log2_table_size;
+  if (!overwrite) buf.direct_table = dtable;
+  // Levels whose cells are wide against the sample spacing go through the run-merging kernel. Measured rule of round 1
+  // (profiles/r01_scatter_*): resolution < samples per ray / 2 (at least 24); with >= 192 samples per ray every level of
+  // the (small) proposal grids pays off. NSAMD_SCATTER_COMBINE_RES > 0 overrides the threshold (1 = no run levels).
+  static const int combine_env = env_int("NSAMD_SCATTER_COMBINE_RES", 0);
+  float coarse_below = 0.0f;
+  if (pts.positions == nullptr) {
+    const float S = (float)pts.samples_per_ray;
+    coarse_below = fmaxf(24.0f, 0.5f * S);
+    if (pts.samples_per_ray >= 192) coarse_below = S;
+  }
+  if (combine_env > 0) coarse_below = (float)combine_env;
+  LevelList coarse{}, fine{};
+  for (int l = 0; l < grid.num_levels; ++l) {
+    if (grid.scalings[l] < coarse_below) {
+      G.coarse_mask |= 1u << l;
+      coarse.level[coarse.count++] = (int8_t)l;
+    } else {
+      fine.level[fine.count++] = (int8_t)l;
+    }
+  }
+  // 128 KiB of dynamic LDS need the opt-in, per device
+  static bool attr_done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return NSAMD_ERR_NO_DEVICE;
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_apply_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16u << kSliceLog2Max)) != hipSuccess)
+      return NSAMD_ERR_LAUNCH;
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
+  }
+  if (fine.count > 0) {
+    const FineShape s = fine_shape();
+    const int code = s.threads * 100 + s.pts * 10 + s.levels;
+    switch (code) {
+      case 102424: launch_fine<1024, 2, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
+      case 102422: launch_fine<1024, 2, 2>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
+      case 51224: launch_fine<512, 2, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
+      case 51222: launch_fine<512, 2, 2>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
+      case 51214: launch_fine<512, 1, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
+      case 102412: launch_fine<1024, 1, 2>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
+      default: launch_fine<1024, 1, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
+    }
+    NSAMD_CHECK_LAUNCH();
+  }
+  if (coarse.count > 0) {
+    constexpr int kL = 4;
+    const size_t lds = sizeof(uint32_t) * (3 * (size_t)kL * ((size_t)1 << G.log2_bins) + kL);
+    const int64_t per_block = (int64_t)kRunThreads * kRunLen;
+    dim3 g1((unsigned)((M + per_block - 1) / per_block), (unsigned)((coarse.count + kL - 1) / kL));
+    scatter_route_runs_kernel<kL><<<g1, kRunThreads, lds, st>>>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G,
+                                                              coarse, buf);
+    NSAMD_CHECK_LAUNCH();
+  }
+  const unsigned threads = G.slice_log2 > 11 ? 1024u : (G.slice_log2 > 9 ? 512u : 256u);
+  dim3 g2(1u << G.log2_bins, (unsigned)grid.num_levels);
+  scatter_apply_kernel<<<g2, threads, (size_t)16 << G.slice_log2, st>>>(grid, G, buf, dtable, overwrite ? 1 : 0);
+  NSAMD_CHECK_LAUNCH();
+  scatter_finish_kernel<<<32, 256, 0, st>>>(grid, G, buf, dtable);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+}  // namespace nsamd

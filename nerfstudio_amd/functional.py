@@ -167,19 +167,54 @@ def field_bwd_workspace(device) -> Tuple[Tensor, int]:
     return ws, ws.numel()
 
 
+_SCATTER_WS_MAX = 8  # cached workspaces (least recently used ones are dropped: a main-table workspace is ~0.75 GB)
+
+
+DENSITY_WS_FLOATS = 1024 * 1092  # <= 1024 workgroups x (64 x 16 + 2 x 64 + 1 padded) partial sums
+
+
+def density_bwd_workspace(device, slot: int = 0) -> Tensor:
+    """Scratch rows for the weight-gradient partials of nsamd_density_mlp_bwd (summed in a fixed order). One buffer per
+    (device, slot): calls that may overlap on different streams take different slots."""
+    key = (str(device), "density", slot)
+    ws = _FIELD_WS.get(key)
+    if ws is None:
+        ws = torch.empty(DENSITY_WS_FLOATS, device=device, dtype=torch.float32)
+        _FIELD_WS[key] = ws
+    return ws
+
+
 def _scatter_workspace(grid: HashGridSpec, device, num_points: int = 0, write_only: bool = False) -> Tuple[Optional[Tensor], int]:
-    """Device scratch for the table-gradient scatter (csrc/hashgrid.hip, "binned" path): per (level, tile) a cursor and
-    a queue of pair records; the library says how many words it wants (nsamd_hashgrid_encode_bwd_workspace). Zeroed
-    once here (the kernels leave the cursors at zero), cached per (grid, M)."""
-    words = int(N.load().nsamd_hashgrid_encode_bwd_workspace(grid.native(), num_points, 1 if write_only else 0))
-    if words <= 0:
-        return None, 0
+    """Device scratch for the table-gradient scatter (csrc/scatter.hip): per (level, tile) a queue of 16-B records, the
+    per-workgroup segment counts, a spill list. The library says how many words it wants
+    (nsamd_hashgrid_encode_bwd_workspace) and how many leading words must start as zero (..._workspace_state: header +
+    cursors, a few KB — the kernels leave them at zero); the bulk is never initialised. Cached per (grid, M, device), at
+    most _SCATTER_WS_MAX entries. One workspace serves one call at a time: callers that overlap scatters on different
+    streams must use different (grid, M) keys or serialise (train_step does)."""
     key = (grid, num_points, str(device), write_only)
     ws = _SCATTER_WS.get(key)
-    if ws is None:
-        ws = torch.zeros(words, device=device, dtype=torch.float32)
-        _SCATTER_WS[key] = ws
+    if ws is not None:
+        _SCATTER_WS[key] = _SCATTER_WS.pop(key)  # most recently used last
+        return ws, (ws.numel() if ws.numel() else 0)
+    lib = N.load()
+    words = int(lib.nsamd_hashgrid_encode_bwd_workspace(grid.native(), num_points, 1 if write_only else 0))
+    if words <= 0:
+        return None, 0
+    ws = torch.empty(words, device=device, dtype=torch.float32)
+    state = int(lib.nsamd_hashgrid_encode_bwd_workspace_state(grid.native(), num_points))
+    ws[:state].zero_()
+    while len(_SCATTER_WS) >= _SCATTER_WS_MAX:
+        _SCATTER_WS.pop(next(iter(_SCATTER_WS)))
+    _SCATTER_WS[key] = ws
     return ws, ws.numel()
+
+
+def scatter_events(ws: Tensor) -> Tuple[int, int, int]:
+    """(spilled, unordered, lost) record counts of a scatter workspace since it was created
+    (nsamd_hashgrid_scatter_events): `unordered` > 0 means some call was exact but not bit-reproducible."""
+    ev = (C.c_uint32 * 3)()
+    N.check(N.load().nsamd_hashgrid_scatter_events(N.ptr(ws), C.cast(ev, C.c_void_p), N.stream()), "scatter_events")
+    return int(ev[0]), int(ev[1]), int(ev[2])
 
 
 def _position_grads(spec: PointSpec, dpos: Tensor):
@@ -342,8 +377,10 @@ class _DensityFieldFn(torch.autograd.Function):
         refs = ctx.param_refs
         (tW0, rW0), (tb0, rb0), (tW1, rW1), (tb1, rb1) = (_grad_target(r, True) for r in refs[1:])
         mlp = N.DensityMlp(N.ptr(W0), N.ptr(b0), N.ptr(W1), N.ptr(b1), W0.shape[1], W0.shape[0], ctx.avg)
+        dws = density_bwd_workspace(table.device)
         N.check(lib.nsamd_density_mlp_bwd(N.ptr(enc), N.ptr(sel), N.ptr(pre), N.ptr(gdens), M, mlp, N.ptr(denc),
-                                          N.ptr(tW0), N.ptr(tb0), N.ptr(tW1), N.ptr(tb1), N.stream()),
+                                          N.ptr(tW0), N.ptr(tb0), N.ptr(tW1), N.ptr(tb1), N.ptr(dws), dws.numel(),
+                                          N.stream()),
                 "density_mlp_bwd")
         need_pos = any(ctx.needs_input_grad[:3])
         ttable, rtable = _grad_target(refs[0], ctx.needs_input_grad[4])

@@ -38,8 +38,16 @@ class NerfactoTrainStep:
         self.counts = (*cfg.num_proposal_samples_per_ray, cfg.num_nerf_samples_per_ray)
         self.n_prop = len(cfg.num_proposal_samples_per_ray)
         self.compute_depths = compute_depths
-        if cfg.background_color not in ("last_sample", "random", "black", "white"):
+        if cfg.background_color == "random":
+            # The reference blends `rand_like(pred) * (1 - accumulation)` into prediction AND target before the MSE
+            # (renderers.py:120-163, models/nerfacto.py:377-381); the fused render_train kernel has no per-ray random
+            # background, and treating "random" as "no background" would silently train a different objective.
+            raise NotImplementedError('NerfactoTrainStep: background_color="random" is not supported by the fused runner; '
+                                      "use NerfactoModel (module path) or last_sample / black / white")
+        if cfg.background_color not in ("last_sample", "black", "white"):
             raise ValueError(cfg.background_color)
+        if not getattr(cfg, "use_single_jitter", True):
+            raise NotImplementedError("NerfactoTrainStep: use_single_jitter=False (per-sample jitter) is not supported")
         self.bg_mode, self.bg_vals = F._bg_args(cfg.background_color, device)
         f32 = dict(device=device, dtype=torch.float32)
         e = lambda *shape: torch.empty(shape, **f32)  # noqa: E731
@@ -95,6 +103,8 @@ class NerfactoTrainStep:
         self.p_ddens = [torch.empty_like(t) for t in self.p_dens]
         self.p_denc = [torch.empty_like(t) for t in self.p_enc]
         self.field_ws, _ = F.field_bwd_workspace(device)
+        # one scratch per proposal level: their backward chains may run concurrently on different streams
+        self.density_ws = [F.density_bwd_workspace(device, slot=lvl) for lvl in range(self.n_prop)]
         # Optional (NSAMD_FIELD_SAVE_ACTS=1): the forward saves the main field's activations (896 B per sample) and the
         # backward loads them instead of recomputing the forward. Measured on MI355X: backward 186 -> 176 us but forward
         # 60 -> 76 us — the backward is bound by its workgroup barriers, not by the recomputed MFMAs — so off by default.
@@ -111,6 +121,12 @@ class NerfactoTrainStep:
         self.level_streams = [torch.cuda.Stream(device=device) for _ in range(max(self.n_prop - 1, 0))]
         self._fork, self._join = torch.cuda.Event(), torch.cuda.Event()
         self._level_join = [torch.cuda.Event() for _ in self.level_streams]
+        # Proposal levels may run their backward chains on separate streams only when they share nothing: a shared
+        # network (use_same_proposal_network) means one gradient buffer, and equal (grid, sample count) means one
+        # scatter workspace — concurrent launches would race on either.
+        keys = [(id(self.props[lvl]), self.props[lvl].encoding.spec, n * self.counts[lvl]) for lvl in range(self.n_prop)]
+        self.levels_independent = (len({k[0] for k in keys}) == self.n_prop and
+                                   len({(k[1], k[2]) for k in keys}) == self.n_prop)
         self.spacing = int(getattr(model.proposal_sampler.initial_sampler, "spacing", 0))
         # host-evaluated tables (bit-identical to the reference's CPU linspace)
         self.edges = F._linspace("edges", self.counts[0], device)
@@ -143,17 +159,19 @@ class NerfactoTrainStep:
             self._fork.record(main)
             self.side_stream.wait_event(self._fork)
             with torch.cuda.stream(self.side_stream):
-                self.backward_proposals(levels=[0])
+                self.backward_proposals(levels=[0] if self.levels_independent else None)
                 self._join.record(self.side_stream)
-            for i, ls in enumerate(self.level_streams):
-                ls.wait_event(self._fork)
-                with torch.cuda.stream(ls):
-                    self.backward_proposals(levels=[i + 1])
-                    self._level_join[i].record(ls)
+            if self.levels_independent:
+                for i, ls in enumerate(self.level_streams):
+                    ls.wait_event(self._fork)
+                    with torch.cuda.stream(ls):
+                        self.backward_proposals(levels=[i + 1])
+                        self._level_join[i].record(ls)
             self.backward_main()
             main.wait_event(self._join)
-            for ev in self._level_join:
-                main.wait_event(ev)
+            if self.levels_independent:
+                for ev in self._level_join:
+                    main.wait_event(ev)
         else:
             self.backward_main()
             if updated:
@@ -295,9 +313,11 @@ class NerfactoTrainStep:
                                   float(net.average_init_density))
                 ck(lib.nsamd_weights_bwd(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]), n, S,
                                          N.ptr(self.p_ddens[lvl]), st), "weights_bwd")
+                dws = self.density_ws[lvl]
                 ck(lib.nsamd_density_mlp_bwd(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]),
                                              N.ptr(self.p_ddens[lvl]), m, dm, N.ptr(self.p_denc[lvl]), N.ptr(self._grad(W0)),
-                                             N.ptr(self._grad(b0)), N.ptr(self._grad(W1)), N.ptr(self._grad(b1)), st),
+                                             N.ptr(self._grad(b0)), N.ptr(self._grad(W1)), N.ptr(self._grad(b1)),
+                                             N.ptr(dws), dws.numel(), st),
                    "density_mlp_bwd")
                 spec = net.encoding.spec
                 ws, ws_n = F._scatter_workspace(spec, self.f_enc.device, m)

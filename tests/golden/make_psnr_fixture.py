@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""CPU oracle training run on the procedural scene of tests/psnr_scene.py -> tests/golden/psnr_scene.npz: per-step losses,
-the update schedule / anneal values, the rendered held-out view and its PSNR. The oracle is pinned to the reference by
-the other fixtures (make_golden.py); this one pins the GPU path's TRAINING OUTCOME to the oracle's (PSNR stand-in).
-Run from the repository root:  python tests/golden/make_psnr_fixture.py   (about 2 minutes on 8 cores)."""
+"""CPU oracle training runs on the procedural scene of tests/psnr_scene.py -> tests/golden/psnr_scene_s<seed>.npz: per-step
+losses, the update schedule / anneal values, the rendered evaluation views (two training, two held out) and their PSNRs.
+The oracle is pinned to the reference by the other fixtures (make_golden.py); these pin the GPU path's TRAINING OUTCOME
+to the oracle's (PSNR stand-in), on three independent seeds.
+Run from the repository root:  python tests/golden/make_psnr_fixture.py [seed ...]   (about 3 minutes per seed)."""
 import os
 import sys
 
@@ -15,8 +16,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import psnr_scene as S  # noqa: E402
 from oracle import nerfacto_oracle as orc  # noqa: E402
 
-torch.set_num_threads(8)
-MAIN_LOG2, PROP_LOG2, SEED = 14, 12, 41
+torch.set_num_threads(int(os.environ.get("ORACLE_THREADS", "8")))
+MAIN_LOG2, PROP_LOG2, SEED0 = 14, 12, 41
 
 
 def schedule(cb_step, steps_since_update):
@@ -32,7 +33,8 @@ def anneal_at(step, slope=10.0, n=1000):
     return slope * frac / ((slope - 1) * frac + 1)
 
 
-def main():
+def main(seed):
+    SEED = SEED0 + seed
     cfg = orc.NerfactoCfg(main_grid=orc.HashGridCfg(16, 16, 2048, MAIN_LOG2),
                           prop_grids=(orc.HashGridCfg(5, 16, 128, PROP_LOG2), orc.HashGridCfg(5, 16, 256, PROP_LOG2)),
                           num_images=S.N_TRAIN, appearance_embed_dim=0)  # eval and training see the same network
@@ -45,7 +47,7 @@ def main():
     opts = {g: torch.optim.Adam(ps, lr=1e-2, eps=1e-15) for g, ps in groups.items()}
     losses, sched, anneals = [], [], []
     since, cb_step = 0, 0
-    for step, (o, d, cam, tgt, jit) in enumerate(S.batches()):
+    for step, (o, d, cam, tgt, jit) in enumerate(S.batches(seed=9 + seed)):
         upd = schedule(cb_step, since)
         an = anneal_at(step)
         for opt in opts.values():
@@ -61,11 +63,11 @@ def main():
             since = 0
         cb_step = step  # step_cb(step): AFTER_TRAIN_ITERATION
         since += 1
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         sched.append(upd)
         anneals.append(an)
         if step % 25 == 0:
-            print(f"step {step:4d} loss {float(loss):.5f} updated {upd}", flush=True)
+            print(f"seed {seed} step {step:4d} loss {float(loss.detach()):.5f} updated {upd}", flush=True)
     images, psnrs = [], []
     for cam_id in S.EVAL_CAMERAS:  # eval-mode renders (no jitter, near plane 0, clamp) of whole views
         o, d, gt = S.full_view(cam_id)
@@ -75,10 +77,11 @@ def main():
         images.append(ev["rgb"].numpy().astype(np.float32))
         psnrs.append(S.psnr(images[-1], gt))
         print(f"oracle PSNR of camera {cam_id} after {S.STEPS} steps: {psnrs[-1]:.3f} dB")
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "psnr_scene.npz"), losses=np.array(losses, np.float64),
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"psnr_scene_s{seed}.npz"), losses=np.array(losses, np.float64),
                         schedule=np.array(sched), anneals=np.array(anneals, np.float64), images=np.stack(images),
                         psnr=np.array(psnrs), cfg=np.array([MAIN_LOG2, PROP_LOG2, SEED]))
 
 
 if __name__ == "__main__":
-    main()
+    for seed_ in ([int(a) for a in sys.argv[1:]] or list(S.SEEDS)):
+        main(seed_)

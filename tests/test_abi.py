@@ -58,12 +58,16 @@ def test_argument_validation_without_gpu():
     assert lib.nsamd_hashgrid_encode_fwd(pts, 16, 0, N.Aabb(), None, g, None, 1, 16, None, None) == -1
     assert lib.nsamd_weights_fwd(None, None, 0, 8, None, None) == 0
     assert lib.nsamd_piecewise_bins(None, None, None, None, 4, 8, 7, None, None, None) == -1  # unknown spacing mode
-    # host-only workspace query: nothing below 8192 points, grows with M, 16-B aligned cursor block + 4-word records
+    # host-only workspace query: grows with M, the write-only variant adds the worst-case spill list, the zero-state
+    # prefix (header + per-tile cursors) is a few KB
     g19 = N.make_grid(16, 19, [16.0 * 1.38**i for i in range(16)])
-    assert lib.nsamd_hashgrid_encode_bwd_workspace(g19, 100, 0) == 0
+    assert lib.nsamd_hashgrid_encode_bwd_workspace(g19, 0, 0) == 0
+    assert lib.nsamd_hashgrid_encode_bwd_workspace(g19, 100, 0) > 0
     w1, w2 = lib.nsamd_hashgrid_encode_bwd_workspace(g19, 196608, 0), lib.nsamd_hashgrid_encode_bwd_workspace(g19, 2 * 196608, 0)
     assert 0 < w1 < w2 and w1 * 4 < 2**31
-    assert lib.nsamd_hashgrid_encode_bwd_workspace(g19, 196608, 1) > w1 + 4 * 8 * 196608 * 16  # + the deferred lists
+    assert lib.nsamd_hashgrid_encode_bwd_workspace(g19, 196608, 1) > w1 + 2 * 196608 * 16 * 5  # + (4 - 1) M L spill records of 20 B
+    state = lib.nsamd_hashgrid_encode_bwd_workspace_state(g19, 196608)
+    assert 64 < state <= 64 + 16 * 64 + 4 and state % 4 == 0
     assert lib.nsamd_linear_fwd(None, None, None, 4, 0, 3, 0, None, None) == -1
 
 

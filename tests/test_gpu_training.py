@@ -1,0 +1,159 @@
+"""GPU training-level tests: bit-reproducibility of the training step and the PSNR stand-in.
+
+1. Reproducibility. Every gradient sum of the training path has a fixed order or is accumulated in integers
+   (csrc/scatter.hip: 64-bit fixed point; density / field weight gradients: per-workgroup partial rows summed in index
+   order; appearance embedding: per-camera rows in ray order), so two runs from the same state give the SAME BITS. Round 1
+   drifted by +-20 % in loss after 40 steps (float atomics + Adam's eps = 1e-15 amplifying the rounding residue of
+   cancelling sums).
+2. PSNR (north_star: within 0.1 dB of the reference; reference acceptance tests/test_nerfacto_integration.py:62-72:
+   PSNR > 20 dB on evaluation views). Blender Lego is not in the container: the stand-in is the analytic scene of
+   tests/psnr_scene.py trained for 300 steps by the CPU oracle (fixtures tests/golden/psnr_scene_s*.npz, three seeds) and
+   by the GPU path on the same batches. The PSNR assertions come FIRST; the loss curves are compared through windowed
+   means — two correct implementations of a chaotic optimisation agree in statistics, not step by step."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerfacto_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(x)
+    return x.cuda()
+
+
+@pytest.fixture(scope="module")
+def F():
+    from nerfstudio_amd import _native, functional
+
+    _native.load()
+    return functional
+
+
+def _model(cfg, params):
+    from test_gpu_kernels import _hip_model
+
+    return _hip_model(cfg, params)
+
+
+def _events(F):
+    """(spilled, unordered, lost) summed over every cached scatter workspace."""
+    tot = np.zeros(3, dtype=np.int64)
+    for ws in F._SCATTER_WS.values():
+        tot += np.array(F.scatter_events(ws))
+    return tot
+
+
+def _train(F, cfg, params, n, steps, seed, batches=None):
+    """`steps` iterations of the explicit runner (both optimiser groups, nerfacto's update schedule and anneal).
+    batches: list of (o, d, cam, tgt, jitter[3, n]) or None = one synthetic batch + device-drawn jitter (seeded)."""
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.train_step import NerfactoTrainStep
+
+    model = _model(cfg, params)
+    arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
+    runner = NerfactoTrainStep(model, n, torch.device("cuda"))
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed(seed)
+    if batches is None:
+        o, d, cam, tgt = orc.synthetic_rays(n, cfg.num_images, seed=seed)
+        runner.set_batch(o.cuda(), d.cuda(), cam.cuda(), tgt.cuda())
+    losses = []
+    for step in range(steps):
+        model.set_step(step)
+        ps = model.proposal_sampler
+        updated = ps.updated_this_step()
+        runner.anneal_dev.fill_(ps._anneal)
+        if batches is not None:
+            o, d, cam, tgt, jit = batches[step]
+            runner.set_batch(dev(o), dev(d), dev(cam), dev(tgt))
+            runner.jitter.copy_(torch.from_numpy(jit))
+        arena.zero_grad(skip=runner.written_params())
+        runner.forward_backward(updated, draw_jitter=batches is None)
+        arena.step(groups=["fields", "proposal_networks"] if updated else ["fields"])
+        losses.append(np.array([float(v) for v in runner.loss_dict().values()]))
+        if updated:
+            ps.mark_updated()
+        model.after_step(step)
+    torch.cuda.synchronize()
+    return model, arena, np.array(losses)
+
+
+@pytest.mark.parametrize("size", ["small", "bench"])
+def test_training_is_bit_reproducible(F, size):
+    """Two runs from the same initial state, rays and random streams end in the SAME parameter bits, Adam moments and
+    loss values — on small tables (64 rays, hot entries, 40 steps) and at the benchmark configuration (4096 rays x
+    (256, 96, 48) samples, 2^19-entry main table, 100 cameras with appearance embedding; 12 steps, proposal networks
+    updated on the first ten). No scatter record took an unordered path."""
+    if size == "small":
+        cfg, n, steps = orc.NerfactoCfg(main_grid=orc.HashGridCfg(16, 16, 2048, 12),
+                                        prop_grids=(orc.HashGridCfg(5, 16, 128, 10), orc.HashGridCfg(5, 16, 256, 10)),
+                                        num_images=5), 64, 40
+    else:
+        cfg, n, steps = orc.NerfactoCfg(num_images=100), 4096, 12
+    runs = []
+    for _ in range(2):
+        params = orc.init_params(cfg, seed=77, table_std=0.3 if size == "small" else None)
+        model, arena, losses = _train(F, cfg, params, n, steps, seed=5)
+        runs.append((arena.flat.detach().clone(), arena.exp_avg.detach().clone(), arena.exp_avg_sq.detach().clone(), losses))
+        del model, arena
+    a, b = runs
+    assert np.isfinite(a[3]).all() and a[3][-1].sum() < a[3][0].sum()
+    assert np.array_equal(a[3], b[3]), f"loss values differ: max |d| = {np.abs(a[3] - b[3]).max():.3e}"
+    for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq"), a[:3], b[:3]):
+        assert torch.equal(x, y), f"{name} differ in {int((x != y).sum())} of {x.numel()} elements"
+    ev = _events(F)
+    assert ev[1] == 0 and ev[2] == 0, f"scatter records on an unordered path / lost: {ev}"
+
+
+def test_psnr_on_procedural_scene_matches_oracle_training(F, golden):
+    """PSNR stand-in (module docstring): per seed 300 steps of 512 fresh rays from 120 views, then eval-mode renders of
+    two training and two held-out views. Asserted, in this order:
+      (a) every GPU-path view reaches the reference acceptance level (PSNR > 20 dB), held-out views included;
+      (b) |PSNR_gpu - PSNR_oracle| <= 0.5 dB per view, and <= 0.1 dB for the mean over all views and seeds (north_star);
+      (c) the loss curves agree in windowed means (first 10 steps to 1e-3: same start; later windows of 25 steps to 10 %)."""
+    import psnr_scene as S
+
+    from nerfstudio_amd.cameras.rays import RayBundle
+
+    table, deltas = [], []
+    curves = []
+    for seed in S.SEEDS:
+        g = golden(f"psnr_scene_s{seed}")
+        main_log2, prop_log2, init_seed = (int(v) for v in g["cfg"])
+        cfg = orc.NerfactoCfg(main_grid=orc.HashGridCfg(16, 16, 2048, main_log2),
+                              prop_grids=(orc.HashGridCfg(5, 16, 128, prop_log2), orc.HashGridCfg(5, 16, 256, prop_log2)),
+                              num_images=S.N_TRAIN, appearance_embed_dim=0)
+        model, arena, losses = _train(F, cfg, orc.init_params(cfg, seed=init_seed), S.RAYS_PER_STEP, S.STEPS, seed=0,
+                                      batches=S.batches(seed=9 + seed))
+        curves.append((losses.sum(axis=1), g["losses"]))
+        model.eval()
+        for k, cam_id in enumerate(S.EVAL_CAMERAS):
+            o, d, gt = S.full_view(cam_id)
+            rb = RayBundle(origins=dev(o), directions=dev(d), pixel_area=torch.full((len(o), 1), 1e-6, device="cuda"),
+                           camera_indices=torch.zeros((len(o), 1), dtype=torch.int64, device="cuda"))
+            with torch.no_grad():
+                out = model.get_outputs_for_camera_ray_bundle(rb._map(lambda t: t.view(S.H, S.W, -1)))
+            img = out["rgb"].reshape(-1, 3).cpu().numpy()
+            p_gpu, p_ref = S.psnr(img, gt), float(g["psnr"][k])
+            table.append((seed, cam_id, "held-out" if cam_id >= S.N_TRAIN else "train", round(p_gpu, 3), round(p_ref, 3),
+                          round(S.psnr(img, g["images"][k]), 2)))
+            deltas.append(p_gpu - p_ref)
+    print("\nPSNR table (seed, camera, kind, GPU path dB, CPU oracle dB, GPU image vs oracle image dB):")
+    for row in table:
+        print("  ", row)
+    deltas = np.array(deltas)
+    print(f"  mean delta {deltas.mean():+.3f} dB, max |delta| {np.abs(deltas).max():.3f} dB")
+    assert all(row[3] > 20.0 for row in table), table                       # (a)
+    assert np.abs(deltas).max() <= 0.5 and abs(deltas.mean()) <= 0.1, deltas  # (b)
+    for got, ref in curves:                                                  # (c)
+        np.testing.assert_allclose(got[:10], ref[:10], rtol=1e-3)
+        w = 25
+        gm = got[: len(got) // w * w].reshape(-1, w).mean(axis=1)
+        rm = ref[: len(ref) // w * w].reshape(-1, w).mean(axis=1)
+        np.testing.assert_allclose(gm[1:], rm[1:], rtol=0.10)
+    ev = _events(F)
+    assert ev[1] == 0 and ev[2] == 0, ev

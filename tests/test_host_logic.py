@@ -184,6 +184,13 @@ def test_checkpoint_interchange_with_reference_layout():
         opt.load_state_dict(ckpt["optimizers"][name])
         st = opt.state[params[0]]
         assert float(st["step"]) == arena.step_counts[name] and st["exp_avg"].shape == params[0].shape
+    # the reference trainer loads `scalers` into an ENABLED GradScaler unconditionally (trainer.py:137, :439; nerfacto
+    # trains with mixed_precision=True): an empty dict raises there, so the checkpoint carries a valid scaler state
+    scaler = torch.amp.GradScaler("cpu", enabled=True)
+    scaler.load_state_dict(ckpt["scalers"])
+    assert scaler.get_scale() == 65536.0
+    resumed = {"scale": 1024.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 17}
+    assert C.make_checkpoint(a, arena, step=13, scalers=resumed)["scalers"] == resumed  # passed through unchanged
     # into a second model + arena, through DDP-style keys and some foreign entries
     torch.manual_seed(1)
     b = small()

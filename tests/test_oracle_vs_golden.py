@@ -364,21 +364,27 @@ def test_c_oracle_hash_and_cdf(golden):
 
 
 def test_psnr_fixture_is_reproducible_from_the_scene_definition(golden):
-    """tests/golden/psnr_scene.npz (oracle training run on the procedural scene): the stored PSNRs are those of the
-    stored images against the ground truth recomputed from tests/psnr_scene.py, and the batch stream is deterministic."""
+    """tests/golden/psnr_scene_s*.npz (oracle training runs on the procedural scene, three seeds): the stored PSNRs are
+    those of the stored images against the ground truth recomputed from tests/psnr_scene.py, the batch streams are
+    deterministic and differ between seeds, and the oracle itself reaches the reference's acceptance level (PSNR > 20 dB,
+    tests/test_nerfacto_integration.py:71) on training AND held-out views."""
     import numpy as np
     import psnr_scene as S
 
-    g = golden("psnr_scene")
-    assert g["losses"].shape == (S.STEPS,) and g["losses"][-1] < 0.02 * g["losses"][0]
-    for k, cam_id in enumerate(S.EVAL_CAMERAS):
-        _, _, gt = S.full_view(cam_id)
-        assert abs(S.psnr(g["images"][k], gt) - float(g["psnr"][k])) < 1e-6
-    b1, b2 = S.batches()[:2], S.batches()[:2]
-    for x, y in zip(b1, b2):
+    for seed in S.SEEDS:
+        g = golden(f"psnr_scene_s{seed}")
+        assert g["losses"].shape == (S.STEPS,) and g["losses"][-1] < 0.02 * g["losses"][0]
+        assert int(g["cfg"][2]) == 41 + seed
+        for k, cam_id in enumerate(S.EVAL_CAMERAS):
+            _, _, gt = S.full_view(cam_id)
+            assert abs(S.psnr(g["images"][k], gt) - float(g["psnr"][k])) < 1e-6
+        assert all(float(p) > 20.0 for p in g["psnr"]), g["psnr"]
+        assert float(g["psnr"][0]) > 30 and float(g["psnr"][1]) > 30
+    b1, b2, b3 = S.batches(seed=9)[:2], S.batches(seed=9)[:2], S.batches(seed=10)[:2]
+    for x, y, z in zip(b1, b2, b3):
         for u, v in zip(x, y):
             assert np.array_equal(u, v)
-    assert float(g["psnr"][0]) > 30 and float(g["psnr"][1]) > 30
+        assert not np.array_equal(x[0], z[0])
 
 
 # ---------------------------------------------------------------------------------------------------------------------
