@@ -1,7 +1,9 @@
 """Ray datastructures: the layout contract of the boundary (reference: nerfstudio/cameras/rays.py:34-295).
 
-`Frustums`, `RaySamples` and `RayBundle` keep the reference's field names and tensor shapes (`[..., S, 1]` trailing
-singleton axes, broadcast origins/directions) so code written against nerfstudio reads the same. In addition a
+`Frustums`, `RaySamples` and `RayBundle` keep the reference's field names, tensor shapes (`[..., S, 1]` trailing
+singleton axes) and `TensorDataclass` behaviour (fields broadcast to a common batch shape, batch-wise indexing / reshape /
+flatten / broadcast_to / to — utils/tensor_dataclass.py), so code written against nerfstudio reads the same; the mirror
+modules equally accept the reference's own containers (they only use the reference's field names). In addition a
 `RaySamples` produced by one of this package's samplers carries a `RayPack`: the dense per-ray arrays
 (`origins [N,3]`, `directions [N,3]`, `t_bins / s_bins [N,S+1]`) the HIP kernels consume directly — sample positions
 are never materialised in HBM on that path. Everything the reference fields expose is a zero-copy view of the pack.
@@ -15,6 +17,7 @@ import torch
 from torch import Tensor
 
 from .. import functional as F
+from ..utils.tensor_dataclass import TensorDataclass
 
 
 @dataclass
@@ -30,8 +33,8 @@ class RayPack:
     spacing: int = 0  # s -> t map of the initial sampler: 0 = uniform / linear-in-disparity piecewise, 1 = uniform
 
 
-@dataclass
-class Frustums:
+@dataclass(init=False)
+class Frustums(TensorDataclass):
     """Region of space as a frustum (cameras/rays.py:34-104)."""
 
     origins: Tensor  # [*bs,3]
@@ -41,9 +44,10 @@ class Frustums:
     pixel_area: Tensor  # [*bs,1]
     offsets: Optional[Tensor] = None
 
-    @property
-    def shape(self):
-        return torch.broadcast_shapes(self.origins.shape[:-1], self.starts.shape[:-1])
+    def __init__(self, origins, directions, starts, ends, pixel_area, offsets=None) -> None:
+        self.origins, self.directions, self.starts, self.ends = origins, directions, starts, ends
+        self.pixel_area, self.offsets = pixel_area, offsets
+        self.__post_init__()
 
     def get_positions(self) -> Tensor:
         """"Center" of each frustum: o + d * (start + end) / 2 (cameras/rays.py:50-59). Generic-path helper; the
@@ -65,8 +69,19 @@ class Frustums:
         return Frustums(origins=one3, directions=one3.clone(), starts=one1, ends=one1.clone(), pixel_area=one1.clone())
 
 
-@dataclass
-class RaySamples:
+def t_bins_of(ray_samples) -> Tensor:
+    """Dense `[*bs, S+1]` euclidean bin edges of any RaySamples (ours or the reference's): the pack when a
+    nerfstudio_amd sampler made it, else the contiguous frustum bins (ends[i] == starts[i+1] for every sampler in the
+    reference, ray_samplers.py)."""
+    pk = getattr(ray_samples, "pack", None)
+    if pk is not None:
+        return pk.t_bins
+    fr = ray_samples.frustums
+    return torch.cat([fr.starts[..., 0], fr.ends[..., -1:, 0]], dim=-1)
+
+
+@dataclass(init=False)
+class RaySamples(TensorDataclass):
     """Samples along rays (cameras/rays.py:108-188)."""
 
     frustums: Frustums
@@ -79,15 +94,20 @@ class RaySamples:
     times: Optional[Tensor] = None
     pack: Optional[RayPack] = None  # set by nerfstudio_amd samplers
 
-    @property
-    def shape(self):
-        return self.frustums.shape
+    def __init__(self, frustums, camera_indices=None, deltas=None, spacing_starts=None, spacing_ends=None,
+                 spacing_to_euclidean_fn=None, metadata=None, times=None, pack=None) -> None:
+        self.frustums, self.camera_indices, self.deltas = frustums, camera_indices, deltas
+        self.spacing_starts, self.spacing_ends, self.spacing_to_euclidean_fn = spacing_starts, spacing_ends, spacing_to_euclidean_fn
+        self.metadata, self.times, self.pack = metadata, times, pack
+        self.__post_init__()
+
+    def _map_tensors(self, fn, **overrides):
+        # the pack is the dense per-ray layout of THIS batch shape: any batch operation invalidates it
+        overrides.setdefault("pack", None)
+        return super()._map_tensors(fn, **overrides)
 
     def _t_bins(self) -> Tensor:
-        if self.pack is not None:
-            return self.pack.t_bins
-        # contiguous bins: ends[i] == starts[i+1] (true for every sampler in the reference)
-        return torch.cat([self.frustums.starts[..., 0], self.frustums.ends[..., -1:, 0]], dim=-1)
+        return t_bins_of(self)
 
     def get_weights(self, densities: Tensor) -> Tensor:
         """alpha_i * prod_{j<i}(1 - alpha_j) from densities `[N,S,1]` -> `[N,S,1]` (cameras/rays.py:129-152),
@@ -99,8 +119,8 @@ class RaySamples:
         return w.view(*densities.shape)
 
 
-@dataclass
-class RayBundle:
+@dataclass(init=False)
+class RayBundle(TensorDataclass):
     """A bundle of ray parameters (cameras/rays.py:192-295)."""
 
     origins: Tensor  # [*bs,3]
@@ -112,32 +132,20 @@ class RayBundle:
     metadata: Dict[str, Tensor] = field(default_factory=dict)
     times: Optional[Tensor] = None
 
+    def __init__(self, origins, directions, pixel_area, camera_indices=None, nears=None, fars=None, metadata=None,
+                 times=None) -> None:
+        self.origins, self.directions, self.pixel_area, self.camera_indices = origins, directions, pixel_area, camera_indices
+        self.nears, self.fars, self.times = nears, fars, times
+        self.metadata = {} if metadata is None else metadata
+        self.__post_init__()
+
     def __len__(self) -> int:
+        """Number of rays (cameras/rays.py:224-226) — the reference overrides TensorDataclass.__len__ here."""
         return torch.numel(self.origins) // self.origins.shape[-1]
 
-    @property
-    def shape(self):
-        return self.origins.shape[:-1]
-
     def _map(self, fn) -> "RayBundle":
-        kw = {}
-        for f_ in fields(self):
-            v = getattr(self, f_.name)
-            if isinstance(v, Tensor):
-                v = fn(v)
-            elif isinstance(v, dict):
-                v = {k: fn(x) if isinstance(x, Tensor) else x for k, x in v.items()}
-            kw[f_.name] = v
-        return RayBundle(**kw)
-
-    def to(self, device) -> "RayBundle":
-        return self._map(lambda t: t.to(device))
-
-    def flatten(self) -> "RayBundle":
-        return self._map(lambda t: t.reshape(-1, t.shape[-1]))
-
-    def __getitem__(self, idx) -> "RayBundle":
-        return self._map(lambda t: t[idx])
+        """`fn(tensor)` on every tensor field (batch shape may change; trailing feature axis kept by the caller)."""
+        return self._map_tensors(lambda t, k: fn(t))
 
     def set_camera_indices(self, camera_index: int) -> None:
         self.camera_indices = torch.ones_like(self.origins[..., 0:1]).long() * camera_index
@@ -155,30 +163,46 @@ class RayBundle:
         pack: Optional[RayPack] = None,
     ) -> RaySamples:
         """Samples for each ray from bin edges `[..., S, 1]` (cameras/rays.py:251-295). All fields are views."""
-        deltas = bin_ends - bin_starts
-        cam = self.camera_indices[..., None] if self.camera_indices is not None else None
-        frustums = Frustums(
-            origins=self.origins[..., None, :],
-            directions=self.directions[..., None, :],
-            starts=bin_starts,
-            ends=bin_ends,
-            pixel_area=self.pixel_area[..., None, :],
-        )
-        md = {k: v[..., None, :] if isinstance(v, Tensor) else v for k, v in self.metadata.items()} if self.metadata else None
-        return RaySamples(
-            frustums=frustums,
-            camera_indices=cam,
-            deltas=deltas,
-            spacing_starts=spacing_starts,
-            spacing_ends=spacing_ends,
-            spacing_to_euclidean_fn=spacing_to_euclidean_fn,
-            metadata=md,
-            times=None if self.times is None else self.times[..., None],
-            pack=pack,
-        )
+        return ray_samples_of(self, bin_starts, bin_ends, spacing_starts, spacing_ends, spacing_to_euclidean_fn, pack)
 
 
-def samples_from_bins(ray_bundle: RayBundle, s_bins: Tensor, t_bins: Tensor, spacing_to_euclidean_fn: Optional[Callable],
+def pack_of(ray_samples) -> Optional[RayPack]:
+    """The dense per-ray arrays behind `ray_samples` when one of this package's samplers produced it; None for the
+    reference's own RaySamples (which has no such field) and after any batch operation."""
+    return getattr(ray_samples, "pack", None)
+
+
+def ray_samples_of(ray_bundle, bin_starts: Tensor, bin_ends: Tensor, spacing_starts: Optional[Tensor] = None,
+                   spacing_ends: Optional[Tensor] = None, spacing_to_euclidean_fn: Optional[Callable] = None,
+                   pack: Optional[RayPack] = None) -> RaySamples:
+    """RayBundle.get_ray_samples (cameras/rays.py:251-295) for ANY bundle with the reference's field names — this
+    package's RayBundle or the reference's own (a sampler here may be handed either)."""
+    deltas = bin_ends - bin_starts
+    cam = ray_bundle.camera_indices[..., None] if ray_bundle.camera_indices is not None else None
+    frustums = Frustums(
+        origins=ray_bundle.origins[..., None, :],
+        directions=ray_bundle.directions[..., None, :],
+        starts=bin_starts,
+        ends=bin_ends,
+        pixel_area=ray_bundle.pixel_area[..., None, :],
+    )
+    metadata = getattr(ray_bundle, "metadata", None)
+    md = {k: v[..., None, :] if isinstance(v, Tensor) else v for k, v in metadata.items()} if metadata else None
+    times = getattr(ray_bundle, "times", None)
+    return RaySamples(
+        frustums=frustums,
+        camera_indices=cam,
+        deltas=deltas,
+        spacing_starts=spacing_starts,
+        spacing_ends=spacing_ends,
+        spacing_to_euclidean_fn=spacing_to_euclidean_fn,
+        metadata=md,
+        times=None if times is None else times[..., None],
+        pack=pack,
+    )
+
+
+def samples_from_bins(ray_bundle, s_bins: Tensor, t_bins: Tensor, spacing_to_euclidean_fn: Optional[Callable],
                       spacing: int = 0) -> RaySamples:
     """RaySamples over dense `[N,S+1]` bin-edge arrays (what the HIP samplers emit), with the pack attached."""
     pack = RayPack(
@@ -190,7 +214,8 @@ def samples_from_bins(ray_bundle: RayBundle, s_bins: Tensor, t_bins: Tensor, spa
         fars=None if ray_bundle.fars is None else ray_bundle.fars.reshape(-1),
         spacing=spacing,
     )
-    return ray_bundle.get_ray_samples(
+    return ray_samples_of(
+        ray_bundle,
         bin_starts=t_bins[..., :-1, None],
         bin_ends=t_bins[..., 1:, None],
         spacing_starts=s_bins[..., :-1, None],

@@ -465,7 +465,9 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
     nsamd_field_mlp mlp, int app_dim, const float* __restrict__ ddensity, const float* __restrict__ drgb,
     float* __restrict__ denc, nsamd_field_mlp_grads grads, float* __restrict__ partials,
-    float* __restrict__ app_partials, const float* __restrict__ acts) {
+    float* __restrict__ app_partials, const float* __restrict__ acts, int probe_skip) {
+  // probe_skip (NSAMD_FIELD_BWD_SKIP, timing experiments only — results are wrong when set): 1 = no weight-gradient
+  // MFMAs, 2 = no workgroup barriers inside the tile loop, 4 = no data-gradient GEMMs
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* W = lds;                     // kRowTotal
   float* bias = lds + kRowTotal;      // 256
@@ -534,34 +536,34 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     }
     store_rows<1>(Sd, g_rgbp, j, g);
     store_rows<4>(Sx, A.hb, j, g);
-    __syncthreads();
-    coop_dw<1>(dW_h2, &db_h2, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
+    if (!(probe_skip & 2)) __syncthreads();
+    if (!(probe_skip & 1)) coop_dw<1>(dW_h2, &db_h2, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
     v4f g_hb[4];
     zero_tiles<4>(g_hb);
-    rows_gemm_bwd<4, 1, kLd64>(W + kRowHead2, g_rgbp, g_hb, j, g);
+    if (!(probe_skip & 4)) rows_gemm_bwd<4, 1, kLd64>(W + kRowHead2, g_rgbp, g_hb, j, g);
     relu_mask<4>(g_hb, A.hb);
-    __syncthreads();
+    if (!(probe_skip & 2)) __syncthreads();
 
     // ---- head layer 1 (64 -> 64) ----
     store_rows<4>(Sd, g_hb, j, g);
     store_rows<4>(Sx, A.ha, j, g);
-    __syncthreads();
-    coop_dw<2>(dW_h1, &db_h1, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
+    if (!(probe_skip & 2)) __syncthreads();
+    if (!(probe_skip & 1)) coop_dw<2>(dW_h1, &db_h1, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
     v4f g_ha[4];
     zero_tiles<4>(g_ha);
-    rows_gemm_bwd<4, 4, kLd64>(W + kRowHead1, g_hb, g_ha, j, g);
+    if (!(probe_skip & 4)) rows_gemm_bwd<4, 4, kLd64>(W + kRowHead1, g_hb, g_ha, j, g);
     relu_mask<4>(g_ha, A.ha);
-    __syncthreads();
+    if (!(probe_skip & 2)) __syncthreads();
 
     // ---- head layer 0 (slots 64 -> 64) ----
     store_rows<4>(Sd, g_ha, j, g);
     store_rows<4>(Sx, A.hin, j, g);
-    __syncthreads();
-    coop_dw<2>(dW_h0, &db_h0, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
+    if (!(probe_skip & 2)) __syncthreads();
+    if (!(probe_skip & 1)) coop_dw<2>(dW_h0, &db_h0, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
     v4f g_hin[4];
     zero_tiles<4>(g_hin);
-    rows_gemm_bwd<4, 4, kLd64>(W + kRowHead0, g_ha, g_hin, j, g);  // tile 0 (SH) is unused: SH carries no gradient
-    __syncthreads();
+    if (!(probe_skip & 4)) rows_gemm_bwd<4, 4, kLd64>(W + kRowHead0, g_ha, g_hin, j, g);  // tile 0 (SH) is unused: SH carries no gradient
+    if (!(probe_skip & 2)) __syncthreads();
 
     // appearance-embedding gradient (slots 32..63): rows of one camera are pre-reduced over the tile's points
     if (app_table != nullptr && grads.appearance != nullptr) {
@@ -618,29 +620,29 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     }
     store_rows<1>(Sd, g_o16, j, g);
     store_rows<4>(Sx, A.h1, j, g);
-    __syncthreads();
-    coop_dw<1>(dW_b1, &db_b1, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
+    if (!(probe_skip & 2)) __syncthreads();
+    if (!(probe_skip & 1)) coop_dw<1>(dW_b1, &db_b1, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
     v4f g_h1[4];
     zero_tiles<4>(g_h1);
-    rows_gemm_bwd<4, 1, kLd64>(W + kRowBase1, g_o16, g_h1, j, g);
+    if (!(probe_skip & 4)) rows_gemm_bwd<4, 1, kLd64>(W + kRowBase1, g_o16, g_h1, j, g);
     relu_mask<4>(g_h1, A.h1);
-    __syncthreads();
+    if (!(probe_skip & 2)) __syncthreads();
 
     // ---- base layer 0 (32 -> 64) ----
     store_rows<4>(Sd, g_h1, j, g);
     store_rows<2>(Sx, A.enc, j, g);
-    __syncthreads();
-    coop_dw<1>(dW_b0, &db_b0, own_m1 == 0, scratch, 0, kCoopWaves, own_n, own_m1, j, g);
+    if (!(probe_skip & 2)) __syncthreads();
+    if (!(probe_skip & 1)) coop_dw<1>(dW_b0, &db_b0, own_m1 == 0, scratch, 0, kCoopWaves, own_n, own_m1, j, g);
     v4f g_enc[2];
     zero_tiles<2>(g_enc);
-    rows_gemm_bwd<2, 4, kLd32>(W + kRowBase0, g_h1, g_enc, j, g);
+    if (!(probe_skip & 4)) rows_gemm_bwd<2, 4, kLd32>(W + kRowBase0, g_h1, g_enc, j, g);
     if (ti.live) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) denc[(int64_t)(16 * t + 4 * g + r) * M + ti.p] = g_enc[t][r];
     }
-    __syncthreads();
+    if (!(probe_skip & 2)) __syncthreads();
   }
 
   // ---- the two point-halves of the 1 x 4 layers meet in LDS (scratch is free now) ---------------------------------
@@ -715,10 +717,73 @@ __device__ __forceinline__ float* dw_destination(int e, const nsamd_field_mlp_gr
 // version walked 64 partials per thread two at a time and took 15 us); the 16 group sums meet in LDS and one thread per
 // element does the single-writer update.
 constexpr int kReduceGroups = 16;
-__global__ __launch_bounds__(64 * kReduceGroups) void field_dw_reduce_kernel(const float* __restrict__ partials,
-                                                                             int num_partials,
-                                                                             nsamd_field_mlp_grads grads, int app_dim) {
-  __shared__ float part[kReduceGroups][64];
+constexpr int kReduceThreads = 64 * kReduceGroups;
+constexpr int kDwBlocks = (kPartialStride + 63) / 64;
+
+// Appearance-embedding gradient from the per-tile rows of the backward (blocks >= kDwBlocks of the reduce launch, one
+// per camera): thread t takes rays t, t + 1024, ... — their camera indices are fetched first, all in flight — and adds
+// the rows of the rays that belong to this camera in ray order; the partial sums are folded by a fixed butterfly per wave and the 16 wave sums are
+// added in wave order. Fixed assignment, fixed order: bit-reproducible (the float atomics this replaces were not).
+__device__ void app_reduce_block(const float* __restrict__ rows, const int64_t* __restrict__ cams, int64_t num_rays,
+                                 int tiles_per_ray, float* __restrict__ grad, int64_t cam, float* lds_part) {
+  float acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) acc[k] = 0.0f;
+  for (int64_t r0 = threadIdx.x; r0 < num_rays; r0 += (int64_t)kReduceThreads * 8) {
+    bool mine[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t r = r0 + (int64_t)u * kReduceThreads;
+      mine[u] = r < num_rays && cams[r] == cam;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (!mine[u]) continue;
+      const int64_t r = r0 + (int64_t)u * kReduceThreads;
+      for (int t = 0; t < tiles_per_ray; ++t) {
+        const v4f* row = reinterpret_cast<const v4f*>(rows + (r * tiles_per_ray + t) * 32);
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+          const v4f v = row[k4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[4 * k4 + c] += v[c];
+        }
+      }
+    }
+  }
+  // wave-level butterfly (fixed tree), then the 16 wave sums per feature in wave order
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    float v = acc[k];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    acc[k] = v;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 32; ++k) lds_part[wave * 32 + k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float tot = 0.0f;
+    for (int w = 0; w < kReduceGroups; ++w) tot += lds_part[w * 32 + threadIdx.x];
+    if (tot != 0.0f) grad[cam * 32 + threadIdx.x] += tot;
+  }
+}
+
+__global__ __launch_bounds__(kReduceThreads) void field_dw_reduce_kernel(const float* __restrict__ partials,
+                                                                          int num_partials,
+                                                                          nsamd_field_mlp_grads grads, int app_dim,
+                                                                          const float* __restrict__ app_rows,
+                                                                          const int64_t* __restrict__ cams,
+                                                                          int64_t num_rays, int tiles_per_ray) {
+  extern __shared__ __attribute__((aligned(16))) float red_lds[];
+  if (blockIdx.x >= kDwBlocks) {
+    app_reduce_block(app_rows, cams, num_rays, tiles_per_ray, grads.appearance, (int64_t)blockIdx.x - kDwBlocks, red_lds);
+    return;
+  }
+  float(*part)[64] = reinterpret_cast<float(*)[64]>(red_lds);
   const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + el;
   float s = 0.f;
@@ -744,39 +809,6 @@ __global__ __launch_bounds__(64 * kReduceGroups) void field_dw_reduce_kernel(con
       for (int g2 = 0; g2 < kReduceGroups; ++g2) t += part[g2][el];
       *dst += t;
     }
-  }
-}
-
-// Appearance-embedding gradient from the per-tile rows of the backward: one workgroup per camera adds the rows of its
-// rays — thread t takes rays t, t + 256, ... in order, the 256 partial sums meet in LDS and are added up in index
-// order. Fixed assignment, fixed order: bit-reproducible (the float atomics this replaces were not).
-__global__ __launch_bounds__(256) void field_app_reduce_kernel(const float* __restrict__ rows,
-                                                               const int64_t* __restrict__ cams, int64_t num_rays,
-                                                               int tiles_per_ray, float* __restrict__ grad) {
-  __shared__ float part[256][33];
-  const int64_t cam = blockIdx.x;
-  float acc[32];
-#pragma unroll
-  for (int k = 0; k < 32; ++k) acc[k] = 0.0f;
-  for (int64_t r = threadIdx.x; r < num_rays; r += 256) {
-    if (cams[r] != cam) continue;
-    for (int t = 0; t < tiles_per_ray; ++t) {
-      const v4f* row = reinterpret_cast<const v4f*>(rows + (r * tiles_per_ray + t) * 32);
-#pragma unroll
-      for (int k4 = 0; k4 < 8; ++k4) {
-        const v4f v = row[k4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[4 * k4 + c] += v[c];
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 32; ++k) part[threadIdx.x][k] = acc[k];
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    float s = 0.0f;
-    for (int t = 0; t < 256; ++t) s += part[t][threadIdx.x];
-    if (s != 0.0f) grad[cam * 32 + threadIdx.x] += s;
   }
 }
 
@@ -879,6 +911,7 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
       return NSAMD_ERR_LAUNCH;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
+  static const int probe_skip = getenv("NSAMD_FIELD_BWD_SKIP") ? atoi(getenv("NSAMD_FIELD_BWD_SKIP")) : 0;
   const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + kCoopWaves - 1) / kCoopWaves);
   float* partials = (workspace != nullptr && workspace_floats >= (int64_t)blocks * kPartialStride) ? workspace : nullptr;
   // per-tile rows of the appearance-embedding gradient (fixed-order reduction per camera): needs every 16-point tile
@@ -890,16 +923,14 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
     app_partials = workspace + (int64_t)blocks * kPartialStride;
   field_mlp_bwd_kernel<<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
       enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-      grads, partials, app_partials, acts);
+      grads, partials, app_partials, acts, probe_skip);
   NSAMD_CHECK_LAUNCH();
   if (partials != nullptr) {
-    field_dw_reduce_kernel<<<(kPartialStride + 63) / 64, 64 * kReduceGroups, 0, (hipStream_t)stream>>>(partials, (int)blocks, grads,
-                                                                                      app_dim);
-    NSAMD_CHECK_LAUNCH();
-  }
-  if (app_partials != nullptr) {
-    field_app_reduce_kernel<<<(unsigned)mlp.num_images, 256, 0, (hipStream_t)stream>>>(
-        app_partials, camera_indices, M / dir_group, (int)(dir_group / 16), grads.appearance);
+    // weight-gradient partials -> gradients, and (extra blocks, one per camera) the appearance rows -> embedding gradient
+    const unsigned app_blocks = app_partials != nullptr ? (unsigned)mlp.num_images : 0u;
+    const size_t red_lds = sizeof(float) * kReduceGroups * 64;
+    field_dw_reduce_kernel<<<kDwBlocks + app_blocks, kReduceThreads, red_lds, (hipStream_t)stream>>>(
+        partials, (int)blocks, grads, app_dim, app_partials, camera_indices, M / dir_group, (int)(dir_group / 16));
     NSAMD_CHECK_LAUNCH();
   }
   return NSAMD_OK;

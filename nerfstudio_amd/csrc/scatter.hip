@@ -437,32 +437,36 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t nw = blockDim.x >> 6;
     if (!coarse) {
-      // static segments: a wave takes 4 segments per trip (their records are independent loads in flight together)
+      // static segments: wave w owns segments w, w + nw, ...; their counts are fetched up front (one load per lane),
+      // so a trip of 4 segments has a single memory latency in front of its records, not two
       const uint32_t* cnts = buf.counts + (size_t)tile * G.segs;
-      for (uint32_t s0 = wave; s0 < G.segs; s0 += 4u * nw) {
-        uint32_t n[4];
+      const uint32_t mine = G.segs > wave ? (G.segs - wave + nw - 1u) / nw : 0u;
+      for (uint32_t c0 = 0; c0 < mine; c0 += 64u) {
+        const uint32_t cv = (c0 + (uint32_t)lane < mine) ? cnts[wave + (c0 + (uint32_t)lane) * nw] : 0u;
+        const uint32_t chunk = min(64u, mine - c0);
+        for (uint32_t t = 0; t < chunk; t += 4u) {
+          uint32_t n[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t s = s0 + (uint32_t)u * nw;
-          n[u] = s < G.segs ? cnts[s] : 0u;
-        }
-        uint4 r[4][2];
+          for (int u = 0; u < 4; ++u)
+            n[u] = (uint32_t)__builtin_amdgcn_readlane((int)cv, (int)min(t + (uint32_t)u, 63u));  // 0 beyond `chunk`
+          uint4 r[4][2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint4* seg = q + (size_t)(s0 + (uint32_t)u * nw) * C;
+          for (int u = 0; u < 4; ++u) {
+            const uint4* seg = q + (size_t)(wave + (c0 + t + (uint32_t)u) * nw) * C;
 #pragma unroll
-          for (int v = 0; v < 2; ++v) {
-            const uint32_t e = (uint32_t)lane + 64u * v;
-            r[u][v] = e < n[u] ? seg[e] : make_uint4(0u, 0u, 0u, 0u);
+            for (int v = 0; v < 2; ++v) {
+              const uint32_t e = (uint32_t)lane + 64u * v;
+              r[u][v] = e < n[u] ? seg[e] : make_uint4(0u, 0u, 0u, 0u);
+            }
           }
-        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < 4; ++u) {
 #pragma unroll
-          for (int v = 0; v < 2; ++v)
-            if ((uint32_t)lane + 64u * v < n[u]) add_rec(r[u][v]);
-          const uint4* seg = q + (size_t)(s0 + (uint32_t)u * nw) * C;
-          for (uint32_t e = (uint32_t)lane + 128u; e < n[u]; e += 64u) add_rec(seg[e]);
+            for (int v = 0; v < 2; ++v)
+              if ((uint32_t)lane + 64u * v < n[u]) add_rec(r[u][v]);
+            const uint4* seg = q + (size_t)(wave + (c0 + t + (uint32_t)u) * nw) * C;
+            for (uint32_t e = (uint32_t)lane + 128u; e < n[u]; e += 64u) add_rec(seg[e]);
+          }
         }
       }
     }
@@ -675,16 +679,14 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
   ScatterBufs buf = scatter_bufs(workspace, plan);
   buf.log2_table_size = grid.log2_table_size;
   if (!overwrite) buf.direct_table = dtable;
-  // Levels whose cells are wide against the sample spacing go through the run-merging kernel. Measured rule of round 1
-  // (profiles/r01_scatter_*): resolution < samples per ray / 2 (at least 24); with >= 192 samples per ray every level of
-  // the (small) proposal grids pays off. NSAMD_SCATTER_COMBINE_RES > 0 overrides the threshold (1 = no run levels).
+  // Levels whose cells are wide against the sample spacing go through the run-merging kernel: with >= 192 samples per
+  // ray (the first proposal level) consecutive samples share cells on every level of the small proposal grids and
+  // merging pays (75 vs 107 us at M = 1 M); with 96 or 48 samples per ray the plain route is faster on every level
+  // (65 vs 88 us, 178 vs 197 us for the main table; profiles/r02a_*). NSAMD_SCATTER_COMBINE_RES > 0 overrides the
+  // threshold: levels with resolution below it are merged (1 = none).
   static const int combine_env = env_int("NSAMD_SCATTER_COMBINE_RES", 0);
   float coarse_below = 0.0f;
-  if (pts.positions == nullptr) {
-    const float S = (float)pts.samples_per_ray;
-    coarse_below = fmaxf(24.0f, 0.5f * S);
-    if (pts.samples_per_ray >= 192) coarse_below = S;
-  }
+  if (pts.positions == nullptr && pts.samples_per_ray >= 192) coarse_below = (float)pts.samples_per_ray;
   if (combine_env > 0) coarse_below = (float)combine_env;
   LevelList coarse{}, fine{};
   for (int l = 0; l < grid.num_levels; ++l) {

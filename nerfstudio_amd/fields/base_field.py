@@ -6,7 +6,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import functional as F
-from ..cameras.rays import Frustums, RaySamples
+from ..cameras.rays import Frustums, RaySamples, pack_of
 from ..field_components.field_heads import FieldHeadNames
 
 
@@ -14,7 +14,7 @@ def point_spec(ray_samples: RaySamples) -> Tuple[F.PointSpec, Tuple[int, ...]]:
     """How the kernels should obtain the sample points of `ray_samples`: straight from the per-ray pack when a
     nerfstudio_amd sampler produced it (positions never touch HBM), otherwise from materialised frustum centres."""
     shape = tuple(ray_samples.frustums.shape)
-    pk = ray_samples.pack
+    pk = pack_of(ray_samples)  # None for the reference's own RaySamples: positions are materialised then
     if pk is not None and ray_samples.frustums.offsets is None and pk.origins.dim() == 2:
         return F.PointSpec(origins=pk.origins, directions=pk.directions, t_bins=pk.t_bins), shape
     return F.PointSpec(positions=ray_samples.frustums.get_positions().reshape(-1, 3)), shape

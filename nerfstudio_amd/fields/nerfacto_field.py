@@ -116,7 +116,7 @@ class NerfactoField(Field):
         spec, shape = point_spec(ray_samples)
         fr = ray_samples.frustums
         if spec.ray_mode:
-            view_dirs = ray_samples.pack.directions
+            view_dirs = spec.directions  # ray mode: the pack's per-ray directions
             dir_group = spec.samples_per_ray
             cams = ray_samples.camera_indices.reshape(view_dirs.shape[0], -1)[:, 0]
         else:

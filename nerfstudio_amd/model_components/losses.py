@@ -6,7 +6,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import functional as F
-from ..cameras.rays import RaySamples
+from ..cameras.rays import RaySamples, pack_of
 
 MSELoss = nn.MSELoss
 EPS = 1.0e-7
@@ -14,8 +14,9 @@ EPS = 1.0e-7
 
 def ray_samples_to_sdist(ray_samples: RaySamples) -> Tensor:
     """Spacing-domain bin edges `[num_rays, S+1]` (losses.py:105-110)."""
-    if ray_samples.pack is not None and ray_samples.pack.s_bins is not None:
-        return ray_samples.pack.s_bins
+    pk = pack_of(ray_samples)
+    if pk is not None and pk.s_bins is not None:
+        return pk.s_bins
     starts, ends = ray_samples.spacing_starts, ray_samples.spacing_ends
     return torch.cat([starts[..., 0], ends[..., -1:, 0]], dim=-1)
 

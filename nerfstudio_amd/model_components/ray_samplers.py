@@ -7,7 +7,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import functional as F
-from ..cameras.rays import RayBundle, RaySamples, samples_from_bins
+from ..cameras.rays import RayBundle, RaySamples, pack_of, samples_from_bins
 
 
 class Sampler(nn.Module):
@@ -106,9 +106,10 @@ class PDFSampler(Sampler):
                 jitter = torch.rand((weights.shape[0], 1), device=weights.device)
         else:
             jitter = None
-        spacing = ray_samples.pack.spacing if ray_samples.pack is not None else 0
-        if ray_samples.pack is not None and ray_samples.pack.s_bins is not None:
-            existing = ray_samples.pack.s_bins
+        pk = pack_of(ray_samples)
+        spacing = pk.spacing if pk is not None else 0
+        if pk is not None and pk.s_bins is not None:
+            existing = pk.s_bins
         else:
             existing = torch.cat([ray_samples.spacing_starts[..., 0], ray_samples.spacing_ends[..., -1:, 0]], dim=-1)
         s_bins, t_bins = F.pdf_resample(existing, weights[..., 0], num_samples, jitter, ray_bundle.nears, ray_bundle.fars,

@@ -6,7 +6,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import functional as F
-from ..cameras.rays import RaySamples
+from ..cameras.rays import RaySamples, t_bins_of
 
 BackgroundColor = Union[Literal["random", "last_sample", "black", "white"], Tensor]
 
@@ -25,6 +25,18 @@ class RGBRenderer(nn.Module):
         super().__init__()
         self.background_color: BackgroundColor = background_color
 
+    @classmethod
+    def combine_rgb(cls, rgb: Tensor, weights: Tensor, background_color: BackgroundColor = "random",
+                    ray_indices: Optional[Tensor] = None, num_rays: Optional[int] = None) -> Tensor:
+        """Composite samples along the ray (renderers.py:72-119): sum_i w_i rgb_i, plus background * (1 - sum_i w_i)
+        for "last_sample" / "white" / "black" / an RGB tensor; "random" adds nothing (as if the background were black —
+        the random colour is blended in blend_background_for_loss_computation). No nan_to_num / clamp (that is
+        forward()'s eval branch). rgb `[*bs,S,3]`, weights `[*bs,S,1]` -> `[*bs,3]`."""
+        _no_packed(ray_indices, num_rays)
+        shape, s = rgb.shape[:-2], rgb.shape[-2]
+        out, _, _ = F.composite(rgb.reshape(-1, s, 3), weights.reshape(-1, s), None, background_color, expected_depth=False)
+        return out.view(*shape, 3)
+
     def forward(self, rgb: Tensor, weights: Tensor, ray_indices: Optional[Tensor] = None,
                 num_rays: Optional[int] = None, background_color: Optional[BackgroundColor] = None) -> Tensor:
         """rgb `[*bs,S,3]`, weights `[*bs,S,1]` -> `[*bs,3]` (renderers.py:201-232)."""
@@ -35,7 +47,7 @@ class RGBRenderer(nn.Module):
         s = rgb.shape[-2]
         rgb2, w2 = rgb.reshape(-1, s, 3), weights.reshape(-1, s)
         if self.training:
-            out, _, _ = F.composite(rgb2, w2, None, background_color, expected_depth=False)
+            return self.combine_rgb(rgb, weights, background_color=background_color)
         else:
             # eval: nan_to_num on the samples, clamp the result (renderers.py:225-231); no gradient needed
             dummy_t = torch.zeros((w2.shape[0], s + 1), device=w2.device)
@@ -106,7 +118,7 @@ class DepthRenderer(nn.Module):
         shape = weights.shape[:-2]
         s = weights.shape[-2]
         w2 = weights.reshape(-1, s)
-        t_bins = ray_samples._t_bins().reshape(-1, s + 1)
+        t_bins = t_bins_of(ray_samples).reshape(-1, s + 1)
         if self.method == "median":
             return F.depth_median(w2, t_bins).view(*shape, 1)
         rgb0 = torch.zeros((w2.shape[0], s, 3), device=w2.device)

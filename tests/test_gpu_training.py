@@ -94,6 +94,7 @@ def test_training_is_bit_reproducible(F, size):
                                         num_images=5), 64, 40
     else:
         cfg, n, steps = orc.NerfactoCfg(num_images=100), 4096, 12
+    ev0 = _events(F)  # (workspaces of earlier tests stay cached: their deliberate overflows are not this test's)
     runs = []
     for _ in range(2):
         params = orc.init_params(cfg, seed=77, table_std=0.3 if size == "small" else None)
@@ -105,7 +106,7 @@ def test_training_is_bit_reproducible(F, size):
     assert np.array_equal(a[3], b[3]), f"loss values differ: max |d| = {np.abs(a[3] - b[3]).max():.3e}"
     for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq"), a[:3], b[:3]):
         assert torch.equal(x, y), f"{name} differ in {int((x != y).sum())} of {x.numel()} elements"
-    ev = _events(F)
+    ev = _events(F) - ev0
     assert ev[1] == 0 and ev[2] == 0, f"scatter records on an unordered path / lost: {ev}"
 
 
@@ -121,6 +122,7 @@ def test_psnr_on_procedural_scene_matches_oracle_training(F, golden):
 
     table, deltas = [], []
     curves = []
+    ev0 = _events(F)
     for seed in S.SEEDS:
         g = golden(f"psnr_scene_s{seed}")
         main_log2, prop_log2, init_seed = (int(v) for v in g["cfg"])
@@ -155,5 +157,5 @@ def test_psnr_on_procedural_scene_matches_oracle_training(F, golden):
         gm = got[: len(got) // w * w].reshape(-1, w).mean(axis=1)
         rm = ref[: len(ref) // w * w].reshape(-1, w).mean(axis=1)
         np.testing.assert_allclose(gm[1:], rm[1:], rtol=0.10)
-    ev = _events(F)
+    ev = _events(F) - ev0
     assert ev[1] == 0 and ev[2] == 0, ev
