@@ -152,6 +152,19 @@ __device__ __forceinline__ void load_acts(const float* __restrict__ acts, int64_
   A.rgbp[0] = src[13 * 64];
 }
 
+// head-input tile 0: the 4 SH components 4g + r of this lane's group, from the 16 of the view direction
+// (base_field.py:136-142: SH of (dir + 1) / 2). Selected by exact 0/1 blending (x * 1 + 0 + 0 + 0 = x): written as
+// selects, the compiler forms a dynamically indexed 16-float stack array — a scratch store + load per tile.
+__device__ __forceinline__ v4f sh_quad(float dx, float dy, float dz, int g) {
+  float sh[16];
+  sh4_components((dx + 1.0f) / 2.0f, (dy + 1.0f) / 2.0f, (dz + 1.0f) / 2.0f, sh);
+  const float m0 = g == 0 ? 1.0f : 0.0f, m1 = g == 1 ? 1.0f : 0.0f, m2 = g == 2 ? 1.0f : 0.0f, m3 = g == 3 ? 1.0f : 0.0f;
+  v4f out;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[r] = ((sh[r] * m0 + sh[4 + r] * m1) + sh[8 + r] * m2) + sh[12 + r] * m3;
+  return out;
+}
+
 // head input slots of a tile from saved / recomputed pieces: SH of the view direction, base outputs, appearance row
 __device__ __forceinline__ void build_head_input(const float* __restrict__ directions,
                                                  const float* __restrict__ app_table,
@@ -159,16 +172,7 @@ __device__ __forceinline__ void build_head_input(const float* __restrict__ direc
                                                  const TileInputs& ti, int lane, FieldActs& A) {
   const int g = lane >> 4;
   const float* d = directions + 3 * (ti.p / dir_group);
-  float sh[16];
-  sh4_components((d[0] + 1.0f) / 2.0f, (d[1] + 1.0f) / 2.0f, (d[2] + 1.0f) / 2.0f, sh);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float v = sh[r];
-    v = (g == 1) ? sh[4 + r] : v;
-    v = (g == 2) ? sh[8 + r] : v;
-    v = (g == 3) ? sh[12 + r] : v;
-    A.hin[0][r] = v;
-  }
+  A.hin[0] = sh_quad(d[0], d[1], d[2], g);
   A.hin[1] = A.o16[0];
   if (app_dim > 0) {
     const float* src = (app_table != nullptr) ? app_table + ti.cam * 32 : app_const;
@@ -204,17 +208,7 @@ __device__ __forceinline__ void field_forward_tile(const float* wf, const float*
 
   // head input: SH of (dir + 1) / 2  (base_field.py:136-142), geo in place, appearance embedding
   const float* d = directions + 3 * (ti.p / dir_group);
-  float sh[16];
-  sh4_components((d[0] + 1.0f) / 2.0f, (d[1] + 1.0f) / 2.0f, (d[2] + 1.0f) / 2.0f, sh);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    // select comps 4g + r without dynamic register indexing
-    float v = sh[r];
-    v = (g == 1) ? sh[4 + r] : v;
-    v = (g == 2) ? sh[8 + r] : v;
-    v = (g == 3) ? sh[12 + r] : v;
-    A.hin[0][r] = v;
-  }
+  A.hin[0] = sh_quad(d[0], d[1], d[2], g);
   A.hin[1] = A.o16[0];
   if (app_dim > 0) {
     const float* src = (app_table != nullptr) ? app_table + ti.cam * 32 : app_const;
@@ -370,10 +364,9 @@ __device__ __forceinline__ void rows_gemm_bwd(const float* Wrows, const v4f* in,
   }
 }
 
-__device__ __forceinline__ void coop_forward_tile(const float* W, const float* bias,
-                                                  const float* __restrict__ directions,
+__device__ __forceinline__ void coop_forward_tile(const float* W, const float* bias, const float (&dir)[3],
                                                   const float* __restrict__ app_table,
-                                                  const float* __restrict__ app_const, int64_t dir_group, int app_dim,
+                                                  const float* __restrict__ app_const, int app_dim,
                                                   const TileInputs& ti, int lane, FieldActs& A) {
   const int j = lane & 15, g = lane >> 4;
   load_bias<4>(bias + kBiasBase0, A.h1, g);
@@ -381,17 +374,7 @@ __device__ __forceinline__ void coop_forward_tile(const float* W, const float* b
   relu_tiles<4>(A.h1);
   load_bias<1>(bias + kBiasBase1, A.o16, g);
   rows_gemm_fwd<1, 4, kLd64>(W + kRowBase1, A.h1, A.o16, j, g);
-  const float* d = directions + 3 * (ti.p / dir_group);
-  float sh[16];
-  sh4_components((d[0] + 1.0f) / 2.0f, (d[1] + 1.0f) / 2.0f, (d[2] + 1.0f) / 2.0f, sh);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float v = sh[r];
-    v = (g == 1) ? sh[4 + r] : v;
-    v = (g == 2) ? sh[8 + r] : v;
-    v = (g == 3) ? sh[12 + r] : v;
-    A.hin[0][r] = v;
-  }
+  A.hin[0] = sh_quad(dir[0], dir[1], dir[2], g);
   A.hin[1] = A.o16[0];
   if (app_dim > 0) {
     const float* src = (app_table != nullptr) ? app_table + ti.cam * 32 : app_const;
@@ -511,17 +494,38 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
   const int64_t tiles = (M + 15) / 16;
   const int64_t per_iter = (int64_t)gridDim.x * kCoopWaves;
   const int64_t iters = (tiles + per_iter - 1) / per_iter;
+  // A tile's inputs (selector, camera, encoded features, view direction) are fetched ONE ITERATION AHEAD: with two
+  // waves per SIMD nothing else covers the ~2 us of an HBM round trip at the top of every iteration (r02b attribution:
+  // forward recomputation + loads 102 of the kernel's 206 us against 31 us of MFMA time).
+  struct TileFetch {
+    TileInputs ti;
+    v4f enc[2];
+    float dir[3];
+  };
+  auto fetch = [&](int64_t it) {
+    TileFetch f;
+    const int64_t tile = (it * gridDim.x + blockIdx.x) * kCoopWaves + wave;
+    f.ti = tile_inputs(tile < tiles ? tile : tiles - 1, lane, M, selector, cams, dir_group);
+    if (tile >= tiles) f.ti.live = false;  // idle wave of the last round: computes, contributes zeros
+    load_enc_tile(enc, M, f.ti.p, lane, f.enc);
+    const float* d = directions + 3 * (f.ti.p / dir_group);
+    f.dir[0] = d[0]; f.dir[1] = d[1]; f.dir[2] = d[2];
+    return f;
+  };
+  TileFetch next = fetch(0);
   for (int64_t it = 0; it < iters; ++it) {
     const int64_t tile = (it * gridDim.x + blockIdx.x) * kCoopWaves + wave;
-    TileInputs ti = tile_inputs(tile < tiles ? tile : tiles - 1, lane, M, selector, cams, dir_group);
-    if (tile >= tiles) ti.live = false;  // idle wave of the last round: computes, contributes zeros
+    const TileFetch cur = next;
+    const TileInputs ti = cur.ti;
+    if (it + 1 < iters) next = fetch(it + 1);
     FieldActs A;
-    load_enc_tile(enc, M, ti.p, lane, A.enc);
+    A.enc[0] = cur.enc[0];
+    A.enc[1] = cur.enc[1];
     if (acts != nullptr) {  // saved by the forward of this step: no recomputation
       load_acts(acts, tile < tiles ? tile : tiles - 1, lane, A);
       build_head_input(directions, app_table, app_const, dir_group, app_dim, ti, lane, A);
     } else {
-      coop_forward_tile(W, bias, directions, app_table, app_const, dir_group, app_dim, ti, lane, A);
+      coop_forward_tile(W, bias, cur.dir, app_table, app_const, app_dim, ti, lane, A);
     }
 
     // ---- head layer 2 (64 -> 3, sigmoid) ----

@@ -60,7 +60,9 @@ struct ScatterGeom {
   uint32_t segs;         // pass-1 workgroups along the points = ceil(M / block_points)
   uint32_t block_points; // points per pass-1 workgroup of the fine kernel
   uint32_t seg_cap;      // records per static segment
-  uint32_t tile_cap;     // records per tile queue
+  uint32_t level_cap[NSAMD_MAX_LEVELS];  // records per tile queue of a level (sparse coarse levels get more: hot tiles)
+  uint32_t level_off[NSAMD_MAX_LEVELS];  // first record of the level's queues: queue(level, bin) = off + bin * cap
+  uint32_t queue_records;                // total
   uint32_t spill_cap;    // records of the spill list
   uint32_t coarse_mask;  // bit l: level l is routed by the run kernel (no static segments)
 };

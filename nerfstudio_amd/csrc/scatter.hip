@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
   const uint32_t mask = (1u << grid.log2_table_size) - 1u;
   const int sl = G.slice_log2;
   const uint32_t local_mask = (1u << sl) - 1u;
-  const uint32_t C = G.seg_cap, Q = G.tile_cap;
+  const uint32_t C = G.seg_cap;
   const uint32_t static_end = G.segs * C;
   uint32_t over = 0u;  // bit ((j * kLevels + i) * 4 + q): the record found its static segment full
 
@@ -171,6 +171,8 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
           const PairHash h = pair_hash(c, q, mask);
           const uint32_t bin = h.ia >> sl;
           const uint32_t tile = ((uint32_t)lvl[i] << G.log2_bins) + bin;
+          const uint32_t Q = G.level_cap[lvl[i]];
+          uint4* const queue = buf.queues + ((size_t)G.level_off[lvl[i]] + (size_t)bin * Q);
           // autograd order ((g * wz) * wy) * wx; the x factor is applied by pass 2
           const float bz = (q & 2) ? c.w[2] : 1.0f - c.w[2];
           const float by = (q & 1) ? c.w[1] : 1.0f - c.w[1];
@@ -193,11 +195,11 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
                                        (h.ia & local_mask) | ((h.ib & local_mask) << 14) | 0x80000000u);
           if (SW == 0) {
             const uint32_t rank = atomicAdd(cnt + (i << G.log2_bins) + bin, 1u);  // ds_add_rtn_u32
-            if (rank < C) buf.queues[(size_t)tile * Q + blockIdx.x * C + rank] = rec;
+            if (rank < C) queue[blockIdx.x * C + rank] = rec;
             else over |= 1u << (slot + q);
           } else {
             const uint32_t pos = base[(i << G.log2_bins) + bin] + atomicAdd(cnt2 + (i << G.log2_bins) + bin, 1u);
-            if (pos < Q - static_end) buf.queues[(size_t)tile * Q + static_end + pos] = rec;
+            if (pos < Q - static_end) queue[static_end + pos] = rec;
             else spill_append(buf, G.spill_cap, tile, rec);
           }
         }
@@ -274,17 +276,17 @@ __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
   const uint32_t mask = (1u << grid.log2_table_size) - 1u;
   const int sl = G.slice_log2;
   const uint32_t local_mask = (1u << sl) - 1u;
-  const uint32_t Q = G.tile_cap;
 
   auto sweep = [&](auto tag) {
     constexpr int SW = decltype(tag)::value;
     auto emit = [&](int i, uint32_t tile_bin, uint4 rec) {
       const uint32_t tile = ((uint32_t)lvl[i] << G.log2_bins) + tile_bin;
+      const uint32_t Q = G.level_cap[lvl[i]];
       if (SW == 0) {
         atomicAdd(cnt + (i << G.log2_bins) + tile_bin, 1u);
       } else {
         const uint32_t pos = base[(i << G.log2_bins) + tile_bin] + atomicAdd(cnt2 + (i << G.log2_bins) + tile_bin, 1u);
-        if (pos < Q) buf.queues[(size_t)tile * Q + pos] = rec;
+        if (pos < Q) buf.queues[(size_t)G.level_off[lvl[i]] + (size_t)tile_bin * Q + pos] = rec;
         else spill_append(buf, G.spill_cap, tile, rec);
       }
     };
@@ -405,16 +407,19 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
     uint4* z = reinterpret_cast<uint4*>(acc);
     for (int e = threadIdx.x; e < entries; e += blockDim.x) z[e] = make_uint4(0u, 0u, 0u, 0u);
   }
-  const FixedScale fs = fixed_scale(buf.hdr[level], G.headroom);
   const bool coarse = (G.coarse_mask >> level) & 1u;
-  const uint32_t Q = G.tile_cap, C = G.seg_cap;
+  const uint32_t Q = G.level_cap[level], C = G.seg_cap;
+  // headroom of the fixed-point sums: <= 2 summands per record (a pair whose corners coincide) over the queue and the
+  // folded spill records; one more bit for the sign
+  const int headroom = 2 + (32 - __clz((int)(Q + kSpillFold - 1u)));
+  const FixedScale fs = fixed_scale(buf.hdr[level], headroom);
   const uint32_t static_end = coarse ? 0u : G.segs * C;
   const uint32_t n_dyn = min(buf.dyn_cursor[tile], Q - static_end);
   const uint32_t n_spill = min(min(buf.hdr[kHdrSpillCount], G.spill_cap), kSpillFold);
   __syncthreads();
   // self-cleaning cursor: the next call finds zeros again (the workspace state is zero-initialised once by its owner)
   if (threadIdx.x == 0) buf.dyn_cursor[tile] = 0u;
-  const uint4* q = buf.queues + (size_t)tile * Q;
+  const uint4* q = buf.queues + ((size_t)G.level_off[level] + (size_t)bin * Q);
   const int kk = fs.k;
   auto add_rec = [&](const uint4& r) {
     const float f0 = __uint_as_float(r.x), f1 = __uint_as_float(r.y);
@@ -611,14 +616,31 @@ ScatterPlan scatter_plan(const nsamd_grid& grid, int64_t M, bool max_spill) {
   C = (C + 3) & ~(int64_t)3;
   if (C < 16) C = 16;
   const int64_t expect = (4 * M + bins - 1) / bins;  // pair records per tile, uniform hash
-  int64_t Q = segs * C + expect / 2 + 64;
-  if (Q < 2 * expect + expect / 2 + 64) Q = 2 * expect + expect / 2 + 64;  // run-mode levels use the whole queue
-  Q = (Q + 3) & ~(int64_t)3;
+  // Queue capacity per tile: static segments + a dynamic area, at least 2.5x the uniform-hash expectation. Levels whose
+  // lattice (res + 1)^3 fills less than half of the table are SPARSE: their few reachable entries concentrate the updates
+  // of whole regions of space on a handful of tiles (r02b: level 0 of the bench overflowed a 2.5x queue on every step),
+  // so they get 8x.
+  int64_t Qn = segs * C + expect / 2 + 64;
+  if (Qn < 2 * expect + expect / 2 + 64) Qn = 2 * expect + expect / 2 + 64;  // run-mode levels use the whole queue
+  Qn = (Qn + 3) & ~(int64_t)3;
+  int64_t Qs = segs * C + 6 * expect + 64;
+  if (Qs < 8 * expect + 64) Qs = 8 * expect + 64;
+  Qs = (Qs + 3) & ~(int64_t)3;
   p.tiles = bins * grid.num_levels;
-  if (p.tiles * Q >= 0x7fffffffLL || segs >= 0x7fffffffLL || C >= 0x3fffffffLL) return p;
+  int64_t total = 0, Qmax = 0;
+  for (int l = 0; l < grid.num_levels; ++l) {
+    const double lattice = ((double)grid.scalings[l] + 1.0) * ((double)grid.scalings[l] + 1.0) * ((double)grid.scalings[l] + 1.0);
+    const int64_t Ql = lattice * 2.0 <= (double)((int64_t)1 << grid.log2_table_size) ? Qs : Qn;
+    if (total >= 0x7fffffffLL) return p;
+    g.level_off[l] = (uint32_t)total;
+    g.level_cap[l] = (uint32_t)Ql;
+    total += bins * Ql;
+    Qmax = Ql > Qmax ? Ql : Qmax;
+  }
+  if (total >= 0x7fffffffLL || segs >= 0x7fffffffLL || C >= 0x3fffffffLL) return p;
+  g.queue_records = (uint32_t)total;
   g.segs = (uint32_t)segs;
   g.seg_cap = (uint32_t)C;
-  g.tile_cap = (uint32_t)Q;
   // spill list: worst case (every record of the call: 4 pairs, or after run merging at most as many singles, per point
   // and level) for write-only calls; otherwise a quarter of the expected total
   int64_t spill = 4 * M * grid.num_levels + 64;
@@ -628,18 +650,13 @@ ScatterPlan scatter_plan(const nsamd_grid& grid, int64_t M, bool max_spill) {
   }
   if (spill >= 0x7fffffffLL) return p;
   g.spill_cap = (uint32_t)spill;
-  // headroom: summands per entry <= 2 per record (a pair whose corners coincide) over queue + folded spills; +2 bits for
-  // the run kernel's merged records (bounded separately by kRunLen x max) is already in its max
-  int64_t summands = 2 * (Q + (int64_t)kSpillFold);
-  int h = 1;
-  while (((int64_t)1 << h) < summands) ++h;
-  g.headroom = h + 1;
-  if (g.headroom > 36) return p;
+  if (Qmax + (int64_t)kSpillFold >= ((int64_t)1 << 30)) return p;  // the per-level headroom is derived in pass 2
+  g.headroom = 0;
   g.coarse_mask = 0u;
   const int64_t cursor_words = (p.tiles + 3) & ~(int64_t)3;
   const int64_t count_words = (p.tiles * segs + 3) & ~(int64_t)3;
   p.state_words = kHdrWords + cursor_words;
-  p.total_words = kHdrWords + cursor_words + count_words + 4 * p.tiles * Q + 4 * spill + ((spill + 3) & ~(int64_t)3);
+  p.total_words = kHdrWords + cursor_words + count_words + 4 * total + 4 * spill + ((spill + 3) & ~(int64_t)3);
   p.ok = true;
   return p;
 }
@@ -653,7 +670,7 @@ static ScatterBufs scatter_bufs(float* workspace, const ScatterPlan& p) {
   b.counts = b.dyn_cursor + cursor_words;
   const int64_t count_words = (p.tiles * (int64_t)p.geom.segs + 3) & ~(int64_t)3;
   b.queues = reinterpret_cast<uint4*>(b.counts + count_words);  // 16-B aligned: all sizes above are multiples of 4 words
-  b.spill_rec = b.queues + (size_t)p.tiles * p.geom.tile_cap;
+  b.spill_rec = b.queues + (size_t)p.geom.queue_records;
   b.spill_tile = reinterpret_cast<uint32_t*>(b.spill_rec + p.geom.spill_cap);
   b.direct_table = nullptr;
   b.log2_table_size = 0;

@@ -1,0 +1,143 @@
+"""`nerfacto-hip`: this package as an external nerfstudio method (no edits to nerfstudio).
+
+nerfstudio discovers methods from the `nerfstudio.method_configs` entry-point group or from
+`NERFSTUDIO_METHOD_CONFIGS="nerfacto-hip=nerfstudio_amd.plugin:nerfacto_hip"` (plugins/registry.py:34-78); an entry is a
+`MethodSpecification(config: TrainerConfig, description)` (plugins/types.py:28-38). `nerfacto_hip()` builds it: the
+reference's own `method_configs["nerfacto"]` (configs/method_configs.py:87-121) with the model config's `_target` pointing
+at `HipNerfactoModel` — the reference's NerfactoModel whose hot-path modules (`field`, `proposal_networks`,
+`proposal_sampler`, the renderers and the proposal losses) are replaced by the gfx950 implementations of this package
+after `populate_modules()` (models/nerfacto.py:144-253). Everything else of nerfstudio (trainer, datamanager, viewer,
+camera optimizer, metrics) is used as is; parameter names and shapes are unchanged, so checkpoints interchange.
+
+nerfstudio itself is imported lazily: this module imports (and `install_hip_modules` works on any object with the
+reference model's attributes) without nerfstudio installed; `nerfacto_hip()` raises ImportError with the reason then.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, List
+
+import numpy as np
+import torch
+
+DESCRIPTION = ("nerfacto on MI355X: hash encoding, fused density / colour MLPs, proposal sampling, compositing and the "
+               "proposal losses as hand-written gfx950 HIP kernels (nerfstudio_amd, implementation='hip')")
+
+
+def install_hip_modules(model: Any) -> None:
+    """Swap the hot-path modules of a populated (reference) NerfactoModel for this package's. Uses only what
+    `NerfactoModel.populate_modules` itself uses: `model.config` (NerfactoModelConfig fields), `model.scene_box.aabb`,
+    `model.num_train_data`. Mirrors models/nerfacto.py:147-240 line by line, with the hip classes."""
+    from .field_components.spatial_distortions import SceneContraction
+    from .fields.density_fields import HashMLPDensityField
+    from .fields.nerfacto_field import NerfactoField
+    from .model_components.ray_samplers import ProposalNetworkSampler, UniformSampler
+    from .model_components.renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
+
+    cfg = model.config
+    if getattr(cfg, "predict_normals", False) or getattr(cfg, "use_gradient_scaling", False):
+        raise NotImplementedError("nerfacto-hip: predict_normals / use_gradient_scaling are not on the accelerated path")
+    if getattr(cfg, "features_per_level", 2) != 2:
+        raise ValueError("nerfacto-hip: features_per_level must be 2")
+    aabb = model.scene_box.aabb
+    contraction = None if cfg.disable_scene_contraction else SceneContraction(order=float("inf"))
+    app_dim = cfg.appearance_embed_dim if cfg.use_appearance_embedding else 0
+    model.field = NerfactoField(
+        aabb, hidden_dim=cfg.hidden_dim, num_levels=cfg.num_levels, max_res=cfg.max_res, base_res=cfg.base_res,
+        features_per_level=cfg.features_per_level, log2_hashmap_size=cfg.log2_hashmap_size,
+        hidden_dim_color=cfg.hidden_dim_color, spatial_distortion=contraction, num_images=model.num_train_data,
+        use_average_appearance_embedding=cfg.use_average_appearance_embedding, appearance_embedding_dim=app_dim,
+        average_init_density=cfg.average_init_density, implementation="hip")
+    nets = torch.nn.ModuleList()
+    density_fns: List[Callable] = []
+    n_prop = cfg.num_proposal_iterations
+    if cfg.use_same_proposal_network:
+        assert len(cfg.proposal_net_args_list) == 1, "Only one proposal network is allowed."
+        net = HashMLPDensityField(aabb, spatial_distortion=contraction, **cfg.proposal_net_args_list[0],
+                                  average_init_density=cfg.average_init_density, implementation="hip")
+        nets.append(net)
+        density_fns.extend([net.density_fn for _ in range(n_prop)])
+    else:
+        for i in range(n_prop):
+            args = cfg.proposal_net_args_list[min(i, len(cfg.proposal_net_args_list) - 1)]
+            nets.append(HashMLPDensityField(aabb, spatial_distortion=contraction, **args,
+                                            average_init_density=cfg.average_init_density, implementation="hip"))
+        density_fns.extend([net.density_fn for net in nets])
+    model.proposal_networks, model.density_fns = nets, density_fns
+
+    def update_schedule(step):  # models/nerfacto.py:208-213
+        return np.clip(np.interp(step, [0, cfg.proposal_warmup], [0, cfg.proposal_update_every]), 1,
+                       cfg.proposal_update_every)
+
+    initial = UniformSampler(single_jitter=cfg.use_single_jitter) if cfg.proposal_initial_sampler == "uniform" else None
+    model.proposal_sampler = ProposalNetworkSampler(
+        num_nerf_samples_per_ray=cfg.num_nerf_samples_per_ray,
+        num_proposal_samples_per_ray=cfg.num_proposal_samples_per_ray,
+        num_proposal_network_iterations=cfg.num_proposal_iterations, single_jitter=cfg.use_single_jitter,
+        update_sched=update_schedule, initial_sampler=initial)
+    model.renderer_rgb = RGBRenderer(background_color=cfg.background_color)
+    model.renderer_accumulation = AccumulationRenderer()
+    model.renderer_depth = DepthRenderer(method="median")
+    model.renderer_expected_depth = DepthRenderer(method="expected")
+
+
+def hip_loss_terms(model: Any, outputs: dict, loss_dict: dict) -> dict:
+    """The proposal losses of NerfactoModel.get_loss_dict (models/nerfacto.py:363-375) through the fused kernels."""
+    from .model_components.losses import distortion_loss, interlevel_loss
+
+    cfg = model.config
+    loss_dict["interlevel_loss"] = cfg.interlevel_loss_mult * interlevel_loss(outputs["weights_list"], outputs["ray_samples_list"])
+    loss_dict["distortion_loss"] = cfg.distortion_loss_mult * distortion_loss(outputs["weights_list"], outputs["ray_samples_list"])
+    return loss_dict
+
+
+def _model_classes():
+    """(HipNerfactoModelConfig, HipNerfactoModel), built against the installed nerfstudio."""
+    from dataclasses import dataclass, field
+    from typing import Literal, Type
+
+    from nerfstudio.models.nerfacto import NerfactoModel, NerfactoModelConfig
+
+    class HipNerfactoModel(NerfactoModel):
+        """The reference NerfactoModel with the hot path on MI355X kernels."""
+
+        def populate_modules(self):
+            super().populate_modules()
+            install_hip_modules(self)
+
+        def get_metrics_dict(self, outputs, batch):
+            from .model_components.losses import distortion_loss
+
+            metrics = {}
+            gt_rgb = self.renderer_rgb.blend_background(batch["image"].to(self.device))
+            metrics["psnr"] = self.psnr(outputs["rgb"], gt_rgb)
+            if self.training:
+                metrics["distortion"] = distortion_loss(outputs["weights_list"], outputs["ray_samples_list"])
+            self.camera_optimizer.get_metrics_dict(metrics)
+            return metrics
+
+    @dataclass
+    class HipNerfactoModelConfig(NerfactoModelConfig):
+        _target: Type = field(default_factory=lambda: HipNerfactoModel)
+        implementation: Literal["tcnn", "torch", "hip"] = "hip"
+
+    return HipNerfactoModelConfig, HipNerfactoModel
+
+
+def nerfacto_hip():
+    """-> MethodSpecification for `ns-train nerfacto-hip`. Raises ImportError when nerfstudio is not importable."""
+    import copy
+    import dataclasses
+
+    try:
+        from nerfstudio.configs.method_configs import method_configs
+        from nerfstudio.plugins.types import MethodSpecification
+    except Exception as e:  # noqa: BLE001 - tyro / viser / torchmetrics missing count as "nerfstudio not importable"
+        raise ImportError(f"nerfstudio_amd.plugin: nerfstudio (with its trainer dependencies) is not importable: {e}") from e
+    cfg_cls, _ = _model_classes()
+    base = copy.deepcopy(method_configs["nerfacto"])
+    old = base.pipeline.model
+    kwargs = {f.name: getattr(old, f.name) for f in dataclasses.fields(old) if f.name not in ("_target", "implementation")}
+    base.pipeline.model = cfg_cls(**kwargs)
+    base.method_name = "nerfacto-hip"
+    base.mixed_precision = False  # fp32 kernels: no autocast, no loss scaling
+    return MethodSpecification(config=base, description=DESCRIPTION)

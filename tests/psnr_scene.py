@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 H = W = 24
-N_TRAIN, N_HELD_OUT, STEPS, RAYS_PER_STEP = 120, 2, 300, 512
+N_TRAIN, N_HELD_OUT, STEPS, RAYS_PER_STEP = 120, 20, 300, 512
 SEEDS = (0, 1, 2)  # independent runs: different initialisation (41 + s) and ray batches (9 + s)
 FOCAL = 28.0
 
@@ -79,7 +79,8 @@ def batches(seed=9):
     return out
 
 
-EVAL_CAMERAS = (0, 3, N_TRAIN, N_TRAIN + 1)  # two training views and the two held-out ones
+EVAL_CAMERAS = (0, 3, N_TRAIN, N_TRAIN + 1)  # views whose rendered images are kept in the fixtures (2 training, 2 held out)
+ALL_CAMERAS = tuple(range(N_TRAIN + N_HELD_OUT))  # per-view PSNRs are kept for all of them
 
 
 def full_view(cam_id):
