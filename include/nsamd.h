@@ -106,6 +106,17 @@ int nsamd_hashgrid_encode_bwd_set(nsamd_points pts, int64_t M, int transform, ns
                                   nsamd_grid grid, const float* denc, int64_t stride_p, int64_t stride_k, float* dtable,
                                   float* dpositions, float* workspace, int64_t workspace_floats, nsamd_stream_t stream);
 
+/* dL/d(origins, directions) of the RAYS behind the sample points (ray mode only: pts.positions == NULL): the position
+ * gradient of nsamd_hashgrid_encode_bwd's `dpositions`, reduced per ray on the device — d_origins[r] = sum_s dL/dp_s,
+ * d_directions[r] = sum_s dL/dp_s * (t_s + t_{s+1}) / 2 (positions = o + d (start + end) / 2, cameras/rays.py:50-59).
+ * This is the gradient the camera optimiser consumes (cameras/camera_optimizers.py:148-153: origins and directions are
+ * functions of the per-camera pose correction; nerfacto's default mode is SO3xR3, method_configs.py:102). [N,3] each,
+ * written (accumulate = 0) or added to (accumulate = 1, e.g. over the proposal levels and the main field). Fixed
+ * summation order: bit-reproducible. */
+int nsamd_hashgrid_encode_bwd_rays(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
+                                   nsamd_grid grid, const float* denc, int64_t stride_p, int64_t stride_k,
+                                   float* d_origins, float* d_directions, int accumulate, nsamd_stream_t stream);
+
 /* Words of scratch the binned scatter of nsamd_hashgrid_encode_bwd (write_only = 0) / nsamd_hashgrid_encode_bwd_set
  * (write_only = 1) wants for (grid, M); 0 when that path does not apply (M <= 0 or an unsupported grid). Host-only,
  * no device work. */

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "nsamd_hashgrid_encode_fwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp],
     "nsamd_hashgrid_encode_bwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, vp, i64, vp],
     "nsamd_hashgrid_encode_bwd_set": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, vp, i64, vp],
+    "nsamd_hashgrid_encode_bwd_rays": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, C.c_int, vp],
     "nsamd_hashgrid_encode_bwd_workspace": [Grid, i64, C.c_int],
     "nsamd_hashgrid_encode_bwd_workspace_state": [Grid, i64],
     "nsamd_hashgrid_scatter_events": [vp, vp, vp],

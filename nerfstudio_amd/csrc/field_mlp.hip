@@ -33,8 +33,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kWaves = 4;
 constexpr int kFieldThreads = 64 * kWaves;
-constexpr int kScratchLd = 80;                      // floats per scratch row (16 mod 32 banks)
-constexpr int kScratchTile = 16 * kScratchLd;       // one 16 x 64 tile
+constexpr int kScratchLd = 20;                      // floats per scratch row: 16 points + 4 (row stride = 4 mod 8 words:
+                                                    // conflict-free b32 column stores and b128 row reads)
+constexpr int kScratchTile = 64 * kScratchLd;       // one 64-feature x 16-point tile
 // fragment sizes in floats: (N_out padded to 16) x (K padded to 16)
 constexpr int kFragBase0 = 64 * 32, kFragBase1 = 16 * 64, kFragHead0 = 64 * 64, kFragHead1 = 64 * 64,
               kFragHead2 = 16 * 64;
@@ -284,11 +285,16 @@ __global__ __launch_bounds__(kFieldThreads, 2) void field_mlp_fwd_kernel(
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------
-// store a chain-layout vector (T tiles) as rows S[point][feature]
+// store a chain-layout vector (T tiles of 16 features) as S[feature][point]: lane (j, g) register (t, r) is feature
+// 16t + 4g + r of point j. Feature-major, so that a weight-gradient MFMA operand — 4 consecutive POINTS of one feature —
+// is one ds_read_b128 (the point-major layout of round 1 cost one ds_read_b32 per MFMA operand, 2-3 LDS round trips per
+// 1-2 MFMAs, r02b: dW 54 us against 31 us of MFMA time).
 template <int T>
 __device__ __forceinline__ void store_rows(float* S, const v4f* x, int j, int g) {
 #pragma unroll
-  for (int t = 0; t < T; ++t) *reinterpret_cast<v4f*>(S + j * kScratchLd + 16 * t + 4 * g) = x[t];
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[(16 * t + 4 * g + r) * kScratchLd + j] = x[t][r];
 }
 
 template <int N>
@@ -348,19 +354,22 @@ __device__ __forceinline__ void rows_gemm_fwd(const float* Wrows, const v4f* in,
   }
 }
 
-// out[m] += W[:][16m + j]^T . in   (data-gradient direction: MT input-feature tiles, NT neuron tiles)
+// out[m] += W[:][16m + j]^T . in   (data-gradient direction: MT input-feature tiles, NT neuron tiles). The 4 x MT
+// transposed operands of a neuron tile are fetched together (ds_read_b32 each: one copy of the weights serves both
+// directions) and then feed 4 x MT MFMAs: one LDS wait per 16 MFMAs instead of one per 4.
 template <int MT, int NT, int LD>
 __device__ __forceinline__ void rows_gemm_bwd(const float* Wrows, const v4f* in, v4f* out, int j, int g) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
+    float a[4][MT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float a[MT];
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a[m] = Wrows[(16 * t + 4 * g + r) * LD + 16 * m + j];
+      for (int m = 0; m < MT; ++m) a[r][m] = Wrows[(16 * t + 4 * g + r) * LD + 16 * m + j];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) out[m] = mfma16(a[m], in[t][r], out[m]);
-    }
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) out[m] = mfma16(a[r][m], in[t][r], out[m]);
   }
 }
 
@@ -394,24 +403,25 @@ __device__ __forceinline__ void coop_forward_tile(const float* W, const float* b
   rows_gemm_fwd<1, 4, kLd64>(W + kRowHead2, A.hb, A.rgbp, j, g);
 }
 
-// dW tile (n, m) += sum over the points of scratch areas [first, first + count): Dout^T X
+// dW tile (n, m) += sum over the points of scratch areas [first, first + count): Dout^T X. MFMA step q of an area
+// takes points 4g + q: A lane (j, g) = Dout[neuron 16n + j][point 4g + q], B lane (j, g) = X[feature 16m + j][4g + q] —
+// four steps per ds_read_b128 of each operand row.
 template <int TILES>
 __device__ __forceinline__ void coop_dw(v4f* acc, float* dbacc, bool want_db, const float* scratch, int first,
                                         int count, int n, int m0, int j, int g) {
-#pragma unroll 2  // full unrolling hoists all 96 scratch reads and spills
+#pragma unroll 2
   for (int area = first; area < first + count; ++area) {
     const float* Sd = scratch + area * 2 * kScratchTile;
     const float* Sx = Sd + kScratchTile;
+    const v4f a = *reinterpret_cast<const v4f*>(Sd + (16 * n + j) * kScratchLd + 4 * g);
+    v4f b[TILES];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float a = Sd[(4 * q + g) * kScratchLd + 16 * n + j];
-      float b[TILES];
+    for (int i = 0; i < TILES; ++i) b[i] = *reinterpret_cast<const v4f*>(Sx + (16 * (m0 + i) + j) * kScratchLd + 4 * g);
+    if (want_db) *dbacc += (a[0] + a[1]) + (a[2] + a[3]);
 #pragma unroll
-      for (int i = 0; i < TILES; ++i) b[i] = Sx[(4 * q + g) * kScratchLd + 16 * (m0 + i) + j];
-      if (want_db) *dbacc += a;
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int i = 0; i < TILES; ++i) acc[i] = mfma16(a, b[i], acc[i]);
-    }
+      for (int i = 0; i < TILES; ++i) acc[i] = mfma16(a[q], b[i][q], acc[i]);
   }
 }
 
@@ -494,38 +504,19 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
   const int64_t tiles = (M + 15) / 16;
   const int64_t per_iter = (int64_t)gridDim.x * kCoopWaves;
   const int64_t iters = (tiles + per_iter - 1) / per_iter;
-  // A tile's inputs (selector, camera, encoded features, view direction) are fetched ONE ITERATION AHEAD: with two
-  // waves per SIMD nothing else covers the ~2 us of an HBM round trip at the top of every iteration (r02b attribution:
-  // forward recomputation + loads 102 of the kernel's 206 us against 31 us of MFMA time).
-  struct TileFetch {
-    TileInputs ti;
-    v4f enc[2];
-    float dir[3];
-  };
-  auto fetch = [&](int64_t it) {
-    TileFetch f;
-    const int64_t tile = (it * gridDim.x + blockIdx.x) * kCoopWaves + wave;
-    f.ti = tile_inputs(tile < tiles ? tile : tiles - 1, lane, M, selector, cams, dir_group);
-    if (tile >= tiles) f.ti.live = false;  // idle wave of the last round: computes, contributes zeros
-    load_enc_tile(enc, M, f.ti.p, lane, f.enc);
-    const float* d = directions + 3 * (f.ti.p / dir_group);
-    f.dir[0] = d[0]; f.dir[1] = d[1]; f.dir[2] = d[2];
-    return f;
-  };
-  TileFetch next = fetch(0);
   for (int64_t it = 0; it < iters; ++it) {
     const int64_t tile = (it * gridDim.x + blockIdx.x) * kCoopWaves + wave;
-    const TileFetch cur = next;
-    const TileInputs ti = cur.ti;
-    if (it + 1 < iters) next = fetch(it + 1);
+    TileInputs ti = tile_inputs(tile < tiles ? tile : tiles - 1, lane, M, selector, cams, dir_group);
+    if (tile >= tiles) ti.live = false;  // idle wave of the last round: computes, contributes zeros
     FieldActs A;
-    A.enc[0] = cur.enc[0];
-    A.enc[1] = cur.enc[1];
+    load_enc_tile(enc, M, ti.p, lane, A.enc);
     if (acts != nullptr) {  // saved by the forward of this step: no recomputation
       load_acts(acts, tile < tiles ? tile : tiles - 1, lane, A);
       build_head_input(directions, app_table, app_const, dir_group, app_dim, ti, lane, A);
     } else {
-      coop_forward_tile(W, bias, cur.dir, app_table, app_const, app_dim, ti, lane, A);
+      const float* d = directions + 3 * (ti.p / dir_group);  // consumed two layers further down
+      const float dir[3] = {d[0], d[1], d[2]};
+      coop_forward_tile(W, bias, dir, app_table, app_const, app_dim, ti, lane, A);
     }
 
     // ---- head layer 2 (64 -> 3, sigmoid) ----

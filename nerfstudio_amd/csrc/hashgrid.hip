@@ -184,19 +184,19 @@ __global__ __launch_bounds__(kSliceThreads) void hash_encode_bwd_sliced_kernel(
   }
 }
 
-// dL/dposition: one thread per point, loops the levels (no atomics). Only needed when the camera optimiser or
-// normals are on (SURVEY.md §8a gradient-flow facts).
-__global__ __launch_bounds__(kHashBlock) void hash_encode_bwd_pos_kernel(
-    nsamd_points P, int64_t M, int transform, nsamd_aabb box, const float2* __restrict__ table, nsamd_grid grid,
-    const float* __restrict__ denc, int64_t stride_p, int64_t stride_k, float* __restrict__ dpos) {
-  const int64_t p = (int64_t)blockIdx.x * kHashBlock + threadIdx.x;
-  if (p >= M) return;
+// dL/d(raw position) of one point: back through the trilinear blend (offset = scaled - floor(scaled), slope
+// scalings[l]) of every level, the selector, the affine map and the contraction Jacobian — what autograd computes for
+// the reference (SURVEY.md §8a gradient-flow facts). No atomics.
+__device__ __forceinline__ void position_gradient(const nsamd_points& P, int64_t p, int transform, const nsamd_aabb& box,
+                                                  const float2* __restrict__ table, const nsamd_grid& grid,
+                                                  const float* __restrict__ denc, int64_t stride_p, int64_t stride_k,
+                                                  float& gx, float& gy, float& gz) {
   float rx, ry, rz;
   load_position(P, p, rx, ry, rz);
   float x = rx, y = ry, z = rz;
   const float sel = normalise_position(transform, box, x, y, z);
   const uint32_t mask = (1u << grid.log2_table_size) - 1u;
-  float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+  gx = gy = gz = 0.0f;
   for (int level = 0; level < grid.num_levels; ++level) {
     const float scale = grid.scalings[level];
     const Cell c = locate_cell(x, y, z, scale);
@@ -240,9 +240,63 @@ __global__ __launch_bounds__(kHashBlock) void hash_encode_bwd_pos_kernel(
     gy /= (box.hi[1] - box.lo[1]);
     gz /= (box.hi[2] - box.lo[2]);
   }
+}
+
+// dL/dposition per point [M,3]: one thread per point. Only needed when the camera optimiser or normals are on.
+__global__ __launch_bounds__(kHashBlock) void hash_encode_bwd_pos_kernel(
+    nsamd_points P, int64_t M, int transform, nsamd_aabb box, const float2* __restrict__ table, nsamd_grid grid,
+    const float* __restrict__ denc, int64_t stride_p, int64_t stride_k, float* __restrict__ dpos) {
+  const int64_t p = (int64_t)blockIdx.x * kHashBlock + threadIdx.x;
+  if (p >= M) return;
+  float gx, gy, gz;
+  position_gradient(P, p, transform, box, table, grid, denc, stride_p, stride_k, gx, gy, gz);
   dpos[3 * p + 0] = gx;
   dpos[3 * p + 1] = gy;
   dpos[3 * p + 2] = gz;
+}
+
+// dL/d(origins, directions) per RAY (ray mode: position = o + d * (t_i + t_{i+1}) / 2, cameras/rays.py:50-59), what
+// the camera optimiser needs (cameras/camera_optimizers.py:148-153 makes origins / directions functions of the pose
+// correction): d_origin = sum_s dL/dp_s, d_direction = sum_s dL/dp_s * (t_s + t_{s+1}) / 2. One wavefront per ray, lane
+// l takes samples l, l + 64, ... in order, the 64 partial sums meet in a fixed butterfly: bit-reproducible, and the
+// [M,3] per-point gradient never touches HBM.
+__global__ __launch_bounds__(256) void hash_encode_bwd_rays_kernel(
+    nsamd_points P, int64_t num_rays, int transform, nsamd_aabb box, const float2* __restrict__ table, nsamd_grid grid,
+    const float* __restrict__ denc, int64_t stride_p, int64_t stride_k, float* __restrict__ d_origins,
+    float* __restrict__ d_directions, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= num_rays) return;
+  const int S = P.samples_per_ray;
+  float so[3] = {0.f, 0.f, 0.f}, sd[3] = {0.f, 0.f, 0.f};
+  for (int smp = lane; smp < S; smp += 64) {
+    const int64_t p = ray * S + smp;
+    float gx, gy, gz;
+    position_gradient(P, p, transform, box, table, grid, denc, stride_p, stride_k, gx, gy, gz);
+    const float* tb = P.t_bins + ray * (S + 1) + smp;
+    const float half = (tb[0] + tb[1]) / 2.0f;
+    so[0] += gx; so[1] += gy; so[2] += gz;
+    sd[0] += gx * half; sd[1] += gy * half; sd[2] += gz * half;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      so[k] += __shfl_xor(so[k], m);
+      sd[k] += __shfl_xor(sd[k], m);
+    }
+  }
+  if (lane < 3) {
+    const float o = lane == 0 ? so[0] : (lane == 1 ? so[1] : so[2]);
+    const float d = lane == 0 ? sd[0] : (lane == 1 ? sd[1] : sd[2]);
+    if (accumulate) {
+      d_origins[3 * ray + lane] += o;
+      d_directions[3 * ray + lane] += d;
+    } else {
+      d_origins[3 * ray + lane] = o;
+      d_directions[3 * ray + lane] = d;
+    }
+  }
 }
 
 __global__ void sh4_kernel(const float* __restrict__ dirs, int64_t M, float* __restrict__ out) {
@@ -411,6 +465,28 @@ extern "C" int nsamd_hashgrid_encode_bwd_set(nsamd_points pts, int64_t M, int tr
                                              int64_t workspace_floats, nsamd_stream_t stream) {
   return hashgrid_encode_bwd_impl(pts, M, transform, aabb, table, grid, denc, stride_p, stride_k, dtable, dpositions,
                                   workspace, workspace_floats, true, stream);
+}
+
+extern "C" int nsamd_hashgrid_encode_bwd_rays(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb,
+                                              const float* table, nsamd_grid grid, const float* denc, int64_t stride_p,
+                                              int64_t stride_k, float* d_origins, float* d_directions, int accumulate,
+                                              nsamd_stream_t stream) {
+  if (M == 0) return NSAMD_OK;
+  int st = check_points(pts, M);
+  if (st) return st;
+  st = check_grid(grid);
+  if (st) return st;
+  NSAMD_REQUIRE(pts.positions == nullptr);  // ray mode only: explicit positions have no origin / direction to credit
+  NSAMD_REQUIRE(table != nullptr && denc != nullptr && d_origins != nullptr && d_directions != nullptr);
+  NSAMD_REQUIRE(transform >= 0 && transform <= 2);
+  const int64_t rays = M / pts.samples_per_ray;
+  const int64_t nb = (rays + 3) / 4;
+  if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
+  hash_encode_bwd_rays_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(
+      pts, rays, transform, aabb, reinterpret_cast<const float2*>(table), grid, denc, stride_p, stride_k, d_origins,
+      d_directions, accumulate ? 1 : 0);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
 }
 
 extern "C" int64_t nsamd_hashgrid_encode_bwd_workspace(nsamd_grid grid, int64_t M, int write_only) {

@@ -127,6 +127,18 @@ class NerfactoTrainStep:
         keys = [(id(self.props[lvl]), self.props[lvl].encoding.spec, n * self.counts[lvl]) for lvl in range(self.n_prop)]
         self.levels_independent = (len({k[0] for k in keys}) == self.n_prop and
                                    len({(k[1], k[2]) for k in keys}) == self.n_prop)
+        # ---- camera optimiser (nerfstudio's nerfacto default is SO3xR3, the benchmark recipe is "off") ----
+        # Host-side torch computes the corrected rays from `pose_adjustment` (a [num_cameras, 6] parameter); the kernels
+        # return dL/d(origins, directions) per ray (nsamd_hashgrid_encode_bwd_rays, one buffer per sampling level so that
+        # the levels' backward chains stay independent), and autograd carries it back to the parameter.
+        co = getattr(model, "camera_optimizer", None)
+        self.cam_opt = co if (co is not None and co.config.mode != "off") else None
+        if self.cam_opt is not None:
+            self.raw_origins, self.raw_directions = e(n, 3), e(n, 3)
+            self.d_origins = [e(n, 3) for _ in self.counts]
+            self.d_directions = [e(n, 3) for _ in self.counts]
+            self._corrected = None
+            self.camera_reg = torch.zeros((), **f32)
         self.spacing = int(getattr(model.proposal_sampler.initial_sampler, "spacing", 0))
         # host-evaluated tables (bit-identical to the reference's CPU linspace)
         self.edges = F._linspace("edges", self.counts[0], device)
@@ -134,8 +146,12 @@ class NerfactoTrainStep:
 
     # -------------------------------------------------------------------------------------------------------------
     def set_batch(self, origins: Tensor, directions: Tensor, camera_indices: Tensor, target_rgb: Tensor) -> None:
-        self.origins.copy_(origins)
-        self.directions.copy_(directions)
+        if self.cam_opt is not None:  # the kernels see the pose-corrected rays (apply_camera_corrections)
+            self.raw_origins.copy_(origins)
+            self.raw_directions.copy_(directions)
+        else:
+            self.origins.copy_(origins)
+            self.directions.copy_(directions)
         self.camera_indices.copy_(camera_indices.reshape(-1))
         self.target.copy_(target_rgb)
 
@@ -176,6 +192,7 @@ class NerfactoTrainStep:
             self.backward_main()
             if updated:
                 self.backward_proposals()
+        self.backward_cameras(updated)
 
     def forward_backward_main(self, updated: bool, draw_jitter: bool = True) -> None:
         """Forward of everything, the losses, and the backward of the MAIN field (87 % of the gradient bytes). With data
@@ -193,8 +210,45 @@ class NerfactoTrainStep:
         return [self.model.field.mlp_base.encoding.hash_table]
 
     def forward_and_losses(self, updated: bool, draw_jitter: bool = True) -> None:
+        self.apply_camera_corrections()
         self.forward_proposals(draw_jitter)
         self.forward_main_and_losses(updated)
+
+    # ---- camera optimiser -----------------------------------------------------------------------------------------
+    def apply_camera_corrections(self) -> None:
+        """origins + t, R @ directions with the current pose corrections (camera_optimizers.py:148-153) into the ray
+        buffers the kernels read; the autograd graph of the tiny exponential map is kept for backward_cameras."""
+        if self.cam_opt is None:
+            return
+        o, d = self.cam_opt.corrected_rays(self.raw_origins, self.raw_directions, self.camera_indices)
+        self._corrected = (o, d)
+        self.origins.copy_(o.detach())
+        self.directions.copy_(d.detach())
+
+    def _rays_backward(self, lvl: int, net, denc: Tensor) -> None:
+        """dL/d(origins, directions) of sampling level `lvl` from its encoded-feature gradient (on the current stream)."""
+        lib, m = N.load(), self.n * self.counts[lvl]
+        enc = net.mlp_base.encoding if hasattr(net.mlp_base, "encoding") else net.encoding
+        N.check(lib.nsamd_hashgrid_encode_bwd_rays(self._points(lvl), m, net._transform, net._box, N.ptr(enc.hash_table),
+                                                   enc.spec.native(), N.ptr(denc), 1, m, N.ptr(self.d_origins[lvl]),
+                                                   N.ptr(self.d_directions[lvl]), 0, N.stream()), "hashgrid_encode_bwd_rays")
+
+    def backward_cameras(self, updated: bool) -> None:
+        """Per-ray gradients of every level that received one -> `pose_adjustment.grad` (plus the L2 regulariser of
+        camera_optimizers.py:179-185, whose value is kept in `camera_reg`). Call after the backward chains have joined."""
+        if self.cam_opt is None:
+            return
+        L = self.n_prop
+        d_o, d_d = self.d_origins[L], self.d_directions[L]
+        if updated:  # the proposal networks saw the rays too (interlevel loss)
+            d_o = d_o + sum(self.d_origins[:L])
+            d_d = d_d + sum(self.d_directions[:L])
+        reg = {}
+        self.cam_opt.get_loss_dict(reg)
+        self.camera_reg = reg["camera_opt_regularizer"].detach()
+        o, d = self._corrected
+        torch.autograd.backward([o, d, reg["camera_opt_regularizer"]], [d_o, d_d, torch.ones_like(self.camera_reg)])
+        self._corrected = None
 
     def forward_proposals(self, draw_jitter: bool = True) -> None:
         """Initial bins and the proposal levels (density fields + resampling): reads only the proposal networks'
@@ -292,6 +346,8 @@ class NerfactoTrainStep:
             ck(lib.nsamd_field_mlp_bwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
                                        N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s), N.ptr(self.f_denc), grads,
                                        N.ptr(self.field_ws), self.field_ws.numel(), st), "field_mlp_bwd")
+        if self.cam_opt is not None:
+            self._rays_backward(L, fld, self.f_denc)
         ws, ws_n = F._scatter_workspace(enc.spec, self.f_enc.device, mm, write_only=True)
         ck(lib.nsamd_hashgrid_encode_bwd_set(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
                                          enc.spec.native(), N.ptr(self.f_denc), 1, mm, N.ptr(self._grad(enc.hash_table)),
@@ -319,6 +375,8 @@ class NerfactoTrainStep:
                                              N.ptr(self._grad(b0)), N.ptr(self._grad(W1)), N.ptr(self._grad(b1)),
                                              N.ptr(dws), dws.numel(), st),
                    "density_mlp_bwd")
+                if self.cam_opt is not None:
+                    self._rays_backward(lvl, net, self.p_denc[lvl])
                 spec = net.encoding.spec
                 ws, ws_n = F._scatter_workspace(spec, self.f_enc.device, m)
                 ck(lib.nsamd_hashgrid_encode_bwd(self._points(lvl), m, net._transform, net._box,
@@ -334,6 +392,8 @@ class NerfactoTrainStep:
                "distortion_loss": self.cfg.distortion_loss_mult * self.dist_per_ray.sum() / n}
         inter = sum(p.sum() for p in self.inter_per_ray) / (n * S)
         out["interlevel_loss"] = self.cfg.interlevel_loss_mult * inter
+        if self.cam_opt is not None:
+            out["camera_opt_regularizer"] = self.camera_reg
         return out
 
     def outputs(self) -> Dict[str, Tensor]:

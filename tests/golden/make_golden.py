@@ -520,6 +520,61 @@ def gen_pipeline():
     save("pipeline", **out)
 
 
+def gen_camera_opt():
+    """nerfacto with its DEFAULT camera optimiser (CameraOptimizerConfig(mode="SO3xR3"), method_configs.py:102; SE3 as well):
+    the pose correction is applied to the ray bundle (camera_optimizers.py:148-153) and the loss gradient flows back through
+    positions = o + d t (hash encoding, selector, contraction) of all three sampling levels into `pose_adjustment`.
+    Fixture: the corrected rays, rgb, the three losses + regulariser, and dL/dpose_adjustment."""
+    from nerfstudio.cameras.camera_optimizers import CameraOptimizerConfig
+
+    cfg = small_cfg(main_log2=10, prop_log2=8, num_images=5)
+    seed, std = 12, 0.5
+    params = orc.init_params(cfg, seed=seed, table_std=std)
+    N = 24
+    o, d, cam, tgt = orc.synthetic_rays(N, cfg.num_images, seed=5)
+    o[N // 2:] *= 4.0  # half the rays start outside the unit cube: contraction Jacobian on the gradient path
+    rs = np.random.RandomState(71)
+    jit = [torch.from_numpy(rs.uniform(0, 1, (N, 1)).astype(np.float32)) for _ in range(3)]
+    pose = (rs.standard_normal((cfg.num_images, 6)) * np.array([0.05] * 3 + [0.1] * 3)).astype(np.float32)
+    pose[1, 3:] = 0.0  # a camera with no rotation: the clamp branch of exp_map_SO3xR3
+    out = {"seed": seed, "table_std": std, "main_log2": 10, "prop_log2": 8, "num_images": cfg.num_images, "origins": o,
+           "directions": d, "cams": cam, "target": tgt, "j0": jit[0], "j1": jit[1], "j2": jit[2], "pose_adjustment": pose}
+    for mode in ("SO3xR3", "SE3"):
+        fld, props = build_reference(cfg, params)
+        cam_opt = CameraOptimizerConfig(mode=mode).setup(num_cameras=cfg.num_images, device="cpu")
+        with torch.no_grad():
+            cam_opt.pose_adjustment.copy_(torch.from_numpy(pose))
+        sampler = ProposalNetworkSampler(num_nerf_samples_per_ray=48, num_proposal_samples_per_ray=(256, 96),
+                                         num_proposal_network_iterations=2, single_jitter=True)
+        collider = NearFarCollider(0.05, 1000.0)
+        rgb_r = RGBRenderer("last_sample")
+        for m in (fld, props, sampler, collider, rgb_r, cam_opt):
+            m.train(True)
+        rb = RayBundle(origins=o.clone(), directions=d.clone(), pixel_area=torch.full((N, 1), 1e-6), camera_indices=cam[:, None])
+        rb = collider(rb)
+        cam_opt.apply_to_raybundle(rb)
+        with replay_rand(jit):
+            rsamp, wl, rsl = sampler(rb, density_fns=[p.density_fn for p in props])
+        fo = fld(rsamp)
+        w = rsamp.get_weights(fo[FieldHeadNames.DENSITY])
+        wl.append(w)
+        rsl.append(rsamp)
+        rgb = rgb_r(rgb=fo[FieldHeadNames.RGB], weights=w)
+        loss = {"rgb": torch.nn.functional.mse_loss(tgt, rgb), "interlevel": interlevel_loss(wl, rsl),
+                "distortion": 0.002 * distortion_loss(wl, rsl)}
+        reg = {}
+        cam_opt.get_loss_dict(reg)
+        loss["camera_opt_regularizer"] = reg["camera_opt_regularizer"]
+        rb.origins.retain_grad()
+        rb.directions.retain_grad()
+        sum(loss.values()).backward()
+        out.update({f"{mode}_origins": rb.origins, f"{mode}_directions": rb.directions, f"{mode}_rgb": rgb,
+                    f"{mode}_d_origins": rb.origins.grad, f"{mode}_d_directions": rb.directions.grad,
+                    f"{mode}_g_pose": cam_opt.pose_adjustment.grad, f"{mode}_g_main_table": fld.mlp_base.model[0].hash_table.grad,
+                    f"{mode}_losses": torch.stack([loss[k] for k in ("rgb", "interlevel", "distortion", "camera_opt_regularizer")])})
+    save("camera_opt", **out)
+
+
 def gen_raygen():
     rs = np.random.RandomState(71)
     C, H, W = 3, 40, 56

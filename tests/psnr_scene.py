@@ -64,13 +64,13 @@ def ground_truth(o, d, t_max=4.0, n=768):
     return rgb.astype(np.float32)
 
 
-def batches(seed=9):
+def batches(seed=9, steps=None):
     """STEPS training batches: (origins, directions, camera indices, target rgb, jitter [3, n]) — seeded numpy streams,
     identical on every machine."""
     rs = np.random.RandomState(seed)
     c2w = cameras()
     out = []
-    for _ in range(STEPS):
+    for _ in range(STEPS if steps is None else steps):
         cam = rs.randint(0, N_TRAIN, RAYS_PER_STEP)
         ys, xs = rs.randint(0, H, RAYS_PER_STEP), rs.randint(0, W, RAYS_PER_STEP)
         o, d = rays_of(c2w, cam, ys.astype(np.float64), xs.astype(np.float64))

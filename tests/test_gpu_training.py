@@ -7,8 +7,9 @@
    cancelling sums).
 2. PSNR (north_star: within 0.1 dB of the reference; reference acceptance tests/test_nerfacto_integration.py:62-72:
    PSNR > 20 dB on evaluation views). Blender Lego is not in the container: the stand-in is the analytic scene of
-   tests/psnr_scene.py trained for 300 steps by the CPU oracle (fixtures tests/golden/psnr_scene_s*.npz, three seeds) and
-   by the GPU path on the same batches. The PSNR assertions come FIRST; the loss curves are compared through windowed
+   tests/psnr_scene.py trained for 300 steps by the CPU oracle (fixtures tests/golden/psnr_scene_s*.npz, three seeds, each
+   with a perturbed twin run that measures the chaos of the optimisation) and by the GPU path on the same batches. The
+   PSNR assertions come FIRST and are about means over 120 / 20 views; the loss curves are compared through windowed
    means — two correct implementations of a chaotic optimisation agree in statistics, not step by step."""
 import numpy as np
 import pytest
@@ -94,7 +95,7 @@ def test_training_is_bit_reproducible(F, size):
                                         num_images=5), 64, 40
     else:
         cfg, n, steps = orc.NerfactoCfg(num_images=100), 4096, 12
-    ev0 = _events(F)  # (workspaces of earlier tests stay cached: their deliberate overflows are not this test's)
+    F._SCATTER_WS.clear()  # (workspaces of earlier tests stay cached: their deliberate overflows are not this test's)
     runs = []
     for _ in range(2):
         params = orc.init_params(cfg, seed=77, table_std=0.3 if size == "small" else None)
@@ -106,23 +107,26 @@ def test_training_is_bit_reproducible(F, size):
     assert np.array_equal(a[3], b[3]), f"loss values differ: max |d| = {np.abs(a[3] - b[3]).max():.3e}"
     for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq"), a[:3], b[:3]):
         assert torch.equal(x, y), f"{name} differ in {int((x != y).sum())} of {x.numel()} elements"
-    ev = _events(F) - ev0
+    ev = _events(F)
     assert ev[1] == 0 and ev[2] == 0, f"scatter records on an unordered path / lost: {ev}"
 
 
 def test_psnr_on_procedural_scene_matches_oracle_training(F, golden):
-    """PSNR stand-in (module docstring): per seed 300 steps of 512 fresh rays from 120 views, then eval-mode renders of
-    two training and two held-out views. Asserted, in this order:
-      (a) every GPU-path view reaches the reference acceptance level (PSNR > 20 dB), held-out views included;
-      (b) |PSNR_gpu - PSNR_oracle| <= 0.5 dB per view, and <= 0.1 dB for the mean over all views and seeds (north_star);
-      (c) the loss curves agree in windowed means (first 10 steps to 1e-3: same start; later windows of 25 steps to 10 %)."""
+    """PSNR stand-in (module docstring). Per seed: 300 steps of 512 fresh rays from 120 views on the GPU path, then
+    eval-mode renders of ALL 140 views (120 training, 20 held out). The optimisation is chaotic: the fixtures carry a TWIN
+    oracle run (initial tables perturbed by 1e-6) — single views differ by up to 3.4 dB between the two CPU runs, the mean
+    over views by <= 0.08 dB — so the statements are about means over views. Asserted, in this order:
+      (a) reference acceptance level (tests/test_nerfacto_integration.py:71): mean PSNR > 20 dB, training and held-out;
+      (b) north_star: |mean PSNR_gpu - mean PSNR_oracle| <= 0.1 dB over the three seeds (training and held-out views), and
+          <= 0.25 dB for every single seed;
+      (c) rgb-loss curves: first 10 steps equal to 1e-3 (same start), later 25-step window means within 10 % (the twin
+          oracle run stays within 6 % of the oracle)."""
     import psnr_scene as S
 
     from nerfstudio_amd.cameras.rays import RayBundle
 
-    table, deltas = [], []
-    curves = []
-    ev0 = _events(F)
+    F._SCATTER_WS.clear()
+    rows, curves = [], []
     for seed in S.SEEDS:
         g = golden(f"psnr_scene_s{seed}")
         main_log2, prop_log2, init_seed = (int(v) for v in g["cfg"])
@@ -131,31 +135,36 @@ def test_psnr_on_procedural_scene_matches_oracle_training(F, golden):
                               num_images=S.N_TRAIN, appearance_embed_dim=0)
         model, arena, losses = _train(F, cfg, orc.init_params(cfg, seed=init_seed), S.RAYS_PER_STEP, S.STEPS, seed=0,
                                       batches=S.batches(seed=9 + seed))
-        curves.append((losses.sum(axis=1), g["losses"]))
+        curves.append((losses[:, 0], g["losses"][:, 0], g["losses_twin"][:, 0]))
         model.eval()
-        for k, cam_id in enumerate(S.EVAL_CAMERAS):
+        psnr = []
+        for cam_id in S.ALL_CAMERAS:
             o, d, gt = S.full_view(cam_id)
             rb = RayBundle(origins=dev(o), directions=dev(d), pixel_area=torch.full((len(o), 1), 1e-6, device="cuda"),
                            camera_indices=torch.zeros((len(o), 1), dtype=torch.int64, device="cuda"))
             with torch.no_grad():
                 out = model.get_outputs_for_camera_ray_bundle(rb._map(lambda t: t.view(S.H, S.W, -1)))
-            img = out["rgb"].reshape(-1, 3).cpu().numpy()
-            p_gpu, p_ref = S.psnr(img, gt), float(g["psnr"][k])
-            table.append((seed, cam_id, "held-out" if cam_id >= S.N_TRAIN else "train", round(p_gpu, 3), round(p_ref, 3),
-                          round(S.psnr(img, g["images"][k]), 2)))
-            deltas.append(p_gpu - p_ref)
-    print("\nPSNR table (seed, camera, kind, GPU path dB, CPU oracle dB, GPU image vs oracle image dB):")
-    for row in table:
-        print("  ", row)
-    deltas = np.array(deltas)
-    print(f"  mean delta {deltas.mean():+.3f} dB, max |delta| {np.abs(deltas).max():.3f} dB")
-    assert all(row[3] > 20.0 for row in table), table                       # (a)
-    assert np.abs(deltas).max() <= 0.5 and abs(deltas.mean()) <= 0.1, deltas  # (b)
-    for got, ref in curves:                                                  # (c)
+            psnr.append(S.psnr(out["rgb"].reshape(-1, 3).cpu().numpy(), gt))
+        psnr = np.array(psnr)
+        tr, ho = slice(0, S.N_TRAIN), slice(S.N_TRAIN, None)
+        rows.append((seed, psnr[tr].mean(), g["psnr_views"][tr].mean(), g["psnr_views_twin"][tr].mean(), psnr[ho].mean(),
+                     g["psnr_views"][ho].mean(), g["psnr_views_twin"][ho].mean(), np.abs(psnr - g["psnr_views"]).max(),
+                     np.abs(g["psnr_views_twin"] - g["psnr_views"]).max()))
+    print("\nmean PSNR over views [dB]: seed | training: GPU path, CPU oracle, oracle twin | held-out: GPU, oracle, twin | "
+          "largest single-view |difference| GPU-oracle, twin-oracle")
+    for r in rows:
+        print("   %d | %.3f %.3f %.3f | %.3f %.3f %.3f | %.2f %.2f" % r)
+    rows = np.array(rows)
+    d_train, d_held = rows[:, 1] - rows[:, 2], rows[:, 4] - rows[:, 5]
+    print(f"   GPU - oracle, mean over seeds: training {d_train.mean():+.3f} dB, held-out {d_held.mean():+.3f} dB "
+          f"(twin - oracle: {np.mean(rows[:, 3] - rows[:, 2]):+.3f} / {np.mean(rows[:, 6] - rows[:, 5]):+.3f})")
+    assert (rows[:, 1] > 20.0).all() and (rows[:, 4] > 20.0).all(), rows                                     # (a)
+    assert abs(d_train.mean()) <= 0.1 and abs(d_held.mean()) <= 0.1, (d_train, d_held)                       # (b)
+    assert np.abs(d_train).max() <= 0.25 and np.abs(d_held).max() <= 0.25, (d_train, d_held)
+    for got, ref, twin in curves:                                                                            # (c)
         np.testing.assert_allclose(got[:10], ref[:10], rtol=1e-3)
         w = 25
-        gm = got[: len(got) // w * w].reshape(-1, w).mean(axis=1)
-        rm = ref[: len(ref) // w * w].reshape(-1, w).mean(axis=1)
-        np.testing.assert_allclose(gm[1:], rm[1:], rtol=0.10)
-    ev = _events(F) - ev0
+        wm = lambda x: x[: len(x) // w * w].reshape(-1, w).mean(axis=1)  # noqa: E731
+        np.testing.assert_allclose(wm(got)[1:], wm(ref)[1:], rtol=0.10)
+    ev = _events(F)
     assert ev[1] == 0 and ev[2] == 0, ev

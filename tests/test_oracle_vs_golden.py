@@ -373,18 +373,75 @@ def test_psnr_fixture_is_reproducible_from_the_scene_definition(golden):
 
     for seed in S.SEEDS:
         g = golden(f"psnr_scene_s{seed}")
-        assert g["losses"].shape == (S.STEPS,) and g["losses"][-1] < 0.02 * g["losses"][0]
+        assert g["losses"].shape == (S.STEPS, 3) and g["losses"][-1].sum() < 0.02 * g["losses"][0].sum()
         assert int(g["cfg"][2]) == 41 + seed
         for k, cam_id in enumerate(S.EVAL_CAMERAS):
             _, _, gt = S.full_view(cam_id)
             assert abs(S.psnr(g["images"][k], gt) - float(g["psnr"][k])) < 1e-6
-        assert all(float(p) > 20.0 for p in g["psnr"]), g["psnr"]
-        assert float(g["psnr"][0]) > 30 and float(g["psnr"][1]) > 30
-    b1, b2, b3 = S.batches(seed=9)[:2], S.batches(seed=9)[:2], S.batches(seed=10)[:2]
+            assert abs(float(g["psnr_views"][cam_id]) - float(g["psnr"][k])) < 1e-9
+        tr, ho = slice(0, S.N_TRAIN), slice(S.N_TRAIN, None)
+        assert g["psnr_views"].shape == (S.N_TRAIN + S.N_HELD_OUT,)
+        assert g["psnr_views"][tr].mean() > 30 and g["psnr_views"][ho].mean() > 20  # the reference's acceptance level
+        # the twin run (1e-6 perturbation of the initial tables): means over views agree to 0.1 dB, single views do not
+        assert abs(g["psnr_views"][tr].mean() - g["psnr_views_twin"][tr].mean()) < 0.1
+        assert abs(g["psnr_views"][ho].mean() - g["psnr_views_twin"][ho].mean()) < 0.1
+        assert np.abs(g["psnr_views"] - g["psnr_views_twin"]).max() > 0.5
+    b1, b2, b3 = S.batches(seed=9, steps=2), S.batches(seed=9, steps=2), S.batches(seed=10, steps=2)
     for x, y, z in zip(b1, b2, b3):
         for u, v in zip(x, y):
             assert np.array_equal(u, v)
         assert not np.array_equal(x[0], z[0])
+
+
+@pytest.mark.parametrize("mode", ["SO3xR3", "SE3"])
+def test_camera_optimizer_gradient_fixture(golden, mode):
+    """with nerfacto's default camera optimiser the ray origins / directions are functions of
+    `pose_adjustment` and the loss gradient reaches it through the sample positions of all three levels. The mirror
+    (nerfstudio_amd/cameras/camera_optimizers.py, lie_groups.py — host torch, runs on CPU) + the oracle must reproduce
+    the reference's corrected rays, losses, dL/d(origins, directions) and dL/dpose_adjustment (tests/golden/camera_opt.npz,
+    generated from the reference's own CameraOptimizer)."""
+    from nerfstudio_amd.cameras.camera_optimizers import CameraOptimizerConfig
+
+    g = golden("camera_opt")
+    cfg = small_cfg(g["main_log2"], g["prop_log2"], g["num_images"])
+    params = orc.init_params(cfg, seed=int(g["seed"]), table_std=float(g["table_std"]))
+    for v in params.values():
+        v.requires_grad_(True)
+    cam_opt = CameraOptimizerConfig(mode=mode).setup(num_cameras=cfg.num_images, device="cpu")
+    with torch.no_grad():
+        cam_opt.pose_adjustment.copy_(T(g["pose_adjustment"]))
+    o, d = cam_opt.corrected_rays(T(g["origins"]), T(g["directions"]), T(g["cams"]))
+    close(o, g[f"{mode}_origins"], atol=1e-7, rtol=1e-6)
+    close(d, g[f"{mode}_directions"], atol=1e-7, rtol=1e-6)
+    o.retain_grad()
+    d.retain_grad()
+    out = orc.nerfacto_forward(params, cfg, o, d, T(g["cams"]), [T(g[f"j{i}"]) for i in range(3)], training=True)
+    losses = orc.nerfacto_losses(out, T(g["target"]), cfg)
+    cam_opt.get_loss_dict(losses)
+    close(out["rgb"], g[f"{mode}_rgb"], atol=1e-5, rtol=0)
+    ref_l = g[f"{mode}_losses"]
+    for k, name in enumerate(("rgb_loss", "interlevel_loss", "distortion_loss", "camera_opt_regularizer")):
+        close(losses[name], ref_l[k], rtol=2e-4)
+    sum(losses.values()).backward()
+
+    def gclose(a, b, rel_l2, what):
+        """Relative L2: the per-ray position gradients inherit the far-field conditioning of the sample positions (t up
+        to 1000 through spacing_to_euclidean, see _check_t_bins: the oracle's t_bins agree with the reference's to 2e-3
+        there), so a handful of far rays differ by ~1 % of the largest entry while everything else agrees to 1e-4."""
+        err = float(np.linalg.norm(a.numpy() - b) / max(1e-30, np.linalg.norm(b)))
+        assert err <= rel_l2, f"{what}: relative L2 {err:.2e}"
+
+    gclose(o.grad, g[f"{mode}_d_origins"], 2e-2, "dL/d origins")
+    gclose(d.grad, g[f"{mode}_d_directions"], 1e-2, "dL/d directions")
+    gclose(cam_opt.pose_adjustment.grad, g[f"{mode}_g_pose"], 1e-2, "dL/d pose_adjustment")
+    gclose(params["field.mlp_base.model.0.hash_table"].grad, g[f"{mode}_g_main_table"], 1e-3, "dL/d main table")
+    # module contract (camera_optimizers.py:115-205)
+    assert cam_opt(torch.tensor([0, 3])).shape == (2, 3, 4) and cam_opt.get_correction_matrices().shape == (cfg.num_images, 3, 4)
+    groups = {}
+    cam_opt.get_param_groups(groups)
+    assert list(groups) == ["camera_opt"] and groups["camera_opt"][0] is cam_opt.pose_adjustment
+    off = CameraOptimizerConfig(mode="off").setup(num_cameras=3, device="cpu")
+    assert torch.equal(off(torch.tensor([1]))[0], torch.eye(4)[:3]) and off.corrected_rays(o, d, T(g["cams"]))[0] is o
 
 
 # ---------------------------------------------------------------------------------------------------------------------
