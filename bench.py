@@ -510,6 +510,87 @@ def cpu_baseline(n_rays=RAYS_PER_GPU, steps=3, threads=None, workload="bounded")
                       f"tables, fwd+losses+bwd+Adam, median of {steps} steps after 1 warm-up ({med:.2f} s/step)"}
 
 
+def dry_run(args, rank, world):
+    """CPU-only rehearsal of the multi-GPU launch (the driver's `python -m torch.distributed.run --nproc-per-node N ...
+    bench.py --gpus N` line cannot be tried on RCCL before the round ends): same argument / environment handling, a gloo
+    process group instead of RCCL, the real model + ParamArena + compact table prefix + PipelinedExchange with the kernel
+    segments replaced by rank-dependent synthetic gradients and an SGD update. Checks that every rank ends with identical
+    parameters equal to the sequential data-parallel result, then prints the JSON line (value null, "dry_run": true)."""
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.dp_schedule import PipelinedExchange
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    model = build_model(torch.device("cpu"), seed=rank)  # different init per rank: the broadcast must fix it
+    arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
+    arena.broadcast_params()
+    enc = model.field.mlp_base.encoding
+    rows, index = enc.spec.reachable_prefix()
+    arena.register_compact(enc.hash_table, rows, index)
+    start = arena.flat.clone()
+    lr, steps = 0.5, max(2, args.steps)
+    schedule = [k % 3 != 2 for k in range(steps)]
+    step = {"k": 0}
+    reach = torch.zeros(rows, dtype=torch.bool)
+    reach[index] = True
+    off_t = next(o for p, o in zip(arena.params, arena.offsets) if p is enc.hash_table)
+
+    def local_grad(r, k):
+        """Deterministic per-rank, per-step gradient of the whole arena; zero on the unreachable rows of the prefix."""
+        g = torch.full((arena.numel,), float(r + 1) * (k + 1) * 1e-3)
+        pref = g[off_t:off_t + 2 * rows].view(rows, 2)
+        pref[~reach] = 0.0
+        return g
+
+    def run(name):
+        k = step["k"]
+        if name in (("main", True), ("main", False)):
+            a, b = arena.groups["fields"]
+            arena.grad[a:b] = local_grad(rank, k)[a:b]
+        elif name == "pbwd":
+            a, b = arena.groups["proposal_networks"]
+            arena.grad[a:b] = local_grad(rank, k)[a:b]
+        elif name in ("mopt", "popt"):
+            a, b = arena.groups["fields" if name == "mopt" else "proposal_networks"]
+            arena.flat[a:b] -= lr * arena.grad[a:b] / world
+
+    ex = PipelinedExchange(arena, run)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step["k"] = k
+        ex.iteration(schedule[k])
+    ex.finish()
+    elapsed = time.perf_counter() - t0
+    expect = start.clone()
+    for k in range(steps):
+        mean = sum(local_grad(r, k) for r in range(world)) / world
+        a, b = arena.groups["fields"]
+        expect[a:b] -= lr * mean[a:b]
+        if schedule[k]:
+            a, b = arena.groups["proposal_networks"]
+            expect[a:b] -= lr * mean[a:b]
+    err = float((arena.flat - expect).abs().max())
+    assert err <= 1e-5, f"rank {rank}: pipelined exchange differs from sequential data-parallel SGD by {err}"
+    if world > 1:
+        chk = torch.tensor([float(arena.flat.double().sum())], dtype=torch.float64)
+        gathered = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(gathered, chk)
+        assert all(float(g) == float(gathered[0]) for g in gathered), "ranks ended with different parameters"
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "training rays/sec (4096 rays x 48 samples per GPU)", "value": None, "unit": "rays/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "dry_run": True,
+                          "config": {"workload": "launch rehearsal on CPU over gloo: model + arena + compact prefix + pipelined "
+                                                 "exchange, synthetic gradients", "params": arena.numel,
+                                     "compact_rows": int(index.numel()), "prefix_rows": int(rows),
+                                     "exchange_s_per_step": round(elapsed / steps, 4), "max_abs_error": err}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -528,12 +609,17 @@ def main():
                     help="bounded = BASELINE configs[1]/[2] (the metric's configuration); unbounded = configs[4] "
                          "(cameras outside the box, most samples in the contracted region)")
     ap.add_argument("--fixed-batch", action="store_true", help="train on one fixed ray batch instead of rotating the pool")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: check the launch plumbing (RANK / WORLD_SIZE / MASTER_* env, process group, the pipelined "
+                         "exchange with the compact table prefix over gloo) and print the JSON skeleton")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if args.dry_run:
+        return dry_run(args, rank, world)
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
     if args.share_gpu:
         local_rank = 0

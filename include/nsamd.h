@@ -342,6 +342,16 @@ int nsamd_raygen_pinhole(const int64_t* ray_indices, const float* c2w, const flo
                          const float* cx, const float* cy, int64_t num_rays, int32_t num_cameras, float* origins,
                          float* directions, float* pixel_area, float* directions_norm, nsamd_stream_t stream);
 
+/* Data-parallel exchange of a hash-table gradient whose coarse levels reach only a few of their rows (the torch path
+ * hashes every level, encodings.py:398-415: level l touches at most (res_l + 1)^3 of its 2^log2_T rows): pack the
+ * `n` reachable rows `index` (int64, sorted) of `rows` [*, feat] into `packed` [n, feat] before the all-reduce
+ * (gather), unpack after it (scatter). Replaces DDP's dense bucket for that part of the table
+ * (pipelines/base_pipeline.py:279-282). */
+int nsamd_rows_gather(const float* rows, const int64_t* index, int64_t n, int32_t feat, float* packed,
+                      nsamd_stream_t stream);
+int nsamd_rows_scatter(float* rows, const int64_t* index, int64_t n, int32_t feat, const float* packed,
+                       nsamd_stream_t stream);
+
 /* The step's ray batch out of `slots` pre-generated batches resident in HBM (what VanillaDataManager.next_train hands
  * the model each iteration, data/datamanagers/base_datamanager.py:506-515): pools [slots, N, 3] fp32 (origins,
  * directions, target rgb) and [slots, N] int64 (camera indices) -> the [N,3] / [N] buffers of the step. The slot index

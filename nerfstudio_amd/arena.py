@@ -25,6 +25,27 @@ from . import functional as F
 _ALIGN = 64  # floats: every tensor starts on a 256-B boundary
 
 
+def _rows_gather(view: torch.Tensor, idx: torch.Tensor, buf: torch.Tensor) -> None:
+    """buf[i] = view[idx[i]]: one nsamd kernel on the device (no torch op on the exchange path); torch on CPU (tests)."""
+    if view.is_cuda:
+        from . import _native as N
+
+        N.check(N.load().nsamd_rows_gather(N.ptr(view), N.ptr(idx), idx.numel(), view.shape[1], N.ptr(buf), N.stream()),
+                "rows_gather")
+    else:
+        torch.index_select(view, 0, idx, out=buf)
+
+
+def _rows_scatter(view: torch.Tensor, idx: torch.Tensor, buf: torch.Tensor) -> None:
+    if view.is_cuda:
+        from . import _native as N
+
+        N.check(N.load().nsamd_rows_scatter(N.ptr(view), N.ptr(idx), idx.numel(), view.shape[1], N.ptr(buf), N.stream()),
+                "rows_scatter")
+    else:
+        view.index_copy_(0, idx, buf)
+
+
 class _GroupHandle:
     """wait() for every collective of a group exchange, then put the compact rows back into the gradient."""
 
@@ -35,7 +56,7 @@ class _GroupHandle:
 
     def _finish(self) -> None:
         for view, idx, buf in self.post:
-            view.index_copy_(0, idx, buf)
+            _rows_scatter(view, idx, buf)
         self.post = []
 
     def wait(self) -> None:
@@ -163,7 +184,7 @@ class ParamArena:
             if off > cursor:
                 handles.append(dist.all_reduce(self.grad[cursor:off], op=dist.ReduceOp.SUM, group=group, async_op=async_op))
             view = self.grad[off:off + rows * feat].view(rows, feat)
-            torch.index_select(view, 0, idx, out=buf)
+            _rows_gather(view, idx, buf)
             handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op))
             post.append((view, idx, buf))
             cursor = off + rows * feat

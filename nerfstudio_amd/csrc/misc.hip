@@ -77,6 +77,25 @@ __global__ void select_batch_kernel(const float* __restrict__ slot_dev, int32_t 
   if (i < n) cameras[i] = cameras_pool[(int64_t)slot * n + i];
 }
 
+// Compact exchange of a hash-table prefix (arena.ParamArena.register_compact): the rows of the coarse levels that a
+// position can ever reach (functional.HashGridSpec.reachable_prefix) are packed into one dense buffer before the
+// all-reduce and unpacked after it. rows [*, feat] fp32, index [n] int64 (sorted), feat == 2 for the hash tables.
+__global__ void rows_gather_kernel(const float* __restrict__ rows, const int64_t* __restrict__ index, int64_t n, int feat,
+                                   float* __restrict__ packed) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * feat) return;
+  const int64_t r = i / feat;
+  packed[i] = rows[index[r] * feat + (i - r * feat)];
+}
+
+__global__ void rows_scatter_kernel(float* __restrict__ rows, const int64_t* __restrict__ index, int64_t n, int feat,
+                                    const float* __restrict__ packed) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * feat) return;
+  const int64_t r = i / feat;
+  rows[index[r] * feat + (i - r * feat)] = packed[i];
+}
+
 // torch.optim.Adam (no amsgrad / weight decay / maximize): one pass over the flat arena, 16 B per lane.
 // bias corrections are folded by the host into step_size = lr / (1 - b1^t) and inv_sqrt_bc2 = 1 / sqrt(1 - b2^t).
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -140,6 +159,30 @@ extern "C" int nsamd_raygen_pinhole(const int64_t* ray_indices, const float* c2w
   NSAMD_REQUIRE(ray_indices && c2w && fx && fy && cx && cy && origins && directions && pixel_area);
   raygen_pinhole_kernel<<<(unsigned)((num_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(
       ray_indices, c2w, fx, fy, cx, cy, num_rays, origins, directions, pixel_area, directions_norm);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_rows_gather(const float* rows, const int64_t* index, int64_t n, int32_t feat, float* packed,
+                                 nsamd_stream_t stream) {
+  NSAMD_REQUIRE(n >= 0 && feat >= 1);
+  if (n == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(rows && index && packed);
+  const int64_t nb = (n * feat + 255) / 256;
+  if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
+  rows_gather_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(rows, index, n, feat, packed);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_rows_scatter(float* rows, const int64_t* index, int64_t n, int32_t feat, const float* packed,
+                                  nsamd_stream_t stream) {
+  NSAMD_REQUIRE(n >= 0 && feat >= 1);
+  if (n == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(rows && index && packed);
+  const int64_t nb = (n * feat + 255) / 256;
+  if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
+  rows_scatter_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(rows, index, n, feat, packed);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

@@ -107,13 +107,13 @@ def _toy_batches(rank, steps):
     return [(torch.randn(8, 6, generator=g), torch.randn(8, generator=g)) for _ in range(steps)]
 
 
-def _toy_reference(world, steps, lr):
-    """Sequential semantics: mean gradient over the ranks' batches, main group every step, proposal group on update
-    steps (even steps), every parameter updated before its next use."""
+def _toy_reference(world, steps, lr, schedule):
+    """Sequential semantics: mean gradient over the ranks' batches, main group every step, proposal group on the steps
+    `schedule` marks as update steps, every parameter updated before its next use."""
     wf, wp = torch.full((6,), 0.3), torch.full((6,), -0.2)
     data = [_toy_batches(r, steps) for r in range(world)]
     for k in range(steps):
-        updated = k % 2 == 0
+        updated = schedule[k]
         gf, gp = torch.zeros(6), torch.zeros(6)
         for r in range(world):
             x, y = data[r][k]
@@ -129,7 +129,7 @@ def _toy_reference(world, steps, lr):
     return wf, wp
 
 
-def _schedule_worker(rank, world, port, q, steps, lr):
+def _schedule_worker(rank, world, port, q, steps, lr, schedule):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -169,33 +169,65 @@ def _schedule_worker(rank, world, port, q, steps, lr):
         ex = PipelinedExchange(arena, run)
         for k in range(steps):
             state["k"] = k
-            ex.iteration(updated=(k % 2 == 0))
+            ex.iteration(updated=schedule[k])
         assert ex.pending  # the last main update is still in flight ...
         ex.finish()        # ... until the pipeline is drained
         assert not ex.pending
-        q.put((rank, wf.detach().clone().numpy(), wp.detach().clone().numpy(), order[:9]))
+        q.put((rank, wf.detach().clone().numpy(), wp.detach().clone().numpy(), order))
     finally:
         dist.destroy_process_group()
 
 
-def test_pipelined_exchange_equals_sequential_data_parallel():
-    world, steps, lr = 2, 7, 0.05
+def _nerfacto_schedule(steps, warmup=6, every=3):
+    """ProposalNetworkSampler's update rule (ray_samplers.py:590 with nerfacto's schedule, models/nerfacto.py:208-213),
+    scaled down: every step while the sampler's own step < 3, then whenever more than update_sched(step) steps passed
+    since the last update — an UNEVEN pattern (gaps of 1, 2, 2, 3, 3, ...)."""
+    import numpy as np
+
+    out, since, cb = [], 0, 0
+    for k in range(steps):
+        upd = since > float(np.clip(np.interp(cb, [0, warmup], [0, every]), 1, every)) or cb < 3
+        out.append(bool(upd))
+        if upd:
+            since = 0
+        cb = k
+        since += 1
+    return out
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,steps,pattern", [(2, 7, "alternating"), (4, 12, "nerfacto")])
+def test_pipelined_exchange_equals_sequential_data_parallel(world, steps, pattern):
+    """2 ranks with alternating update steps and 4 ranks with the uneven update pattern of the nerfacto schedule: the
+    pipelined exchange (main all-reduce in flight across the step boundary, proposal slice only on update steps) ends
+    with exactly the parameters of sequential data-parallel SGD, on every rank."""
+    lr = 0.05
+    schedule = [k % 2 == 0 for k in range(steps)] if pattern == "alternating" else _nerfacto_schedule(steps)
+    if pattern == "nerfacto":
+        assert schedule[:4] == [True] * 4 and not all(schedule) and sum(schedule[4:]) >= 2
+        gaps = [j - i for i, j in zip([k for k, u in enumerate(schedule) if u][:-1], [k for k, u in enumerate(schedule) if u][1:])]
+        assert len(set(gaps)) > 1, gaps  # uneven
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_schedule_worker, args=(r, world, port, q, steps, lr)) for r in range(world)]
+    procs = [ctx.Process(target=_schedule_worker, args=(r, world, port, q, steps, lr, schedule)) for r in range(world)]
     for p in procs:
         p.start()
-    out = sorted(q.get(timeout=120) for _ in range(world))
+    out = sorted(q.get(timeout=240) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    wf_ref, wp_ref = _toy_reference(world, steps, lr)
+    wf_ref, wp_ref = _toy_reference(world, steps, lr, schedule)
     for rank, wf, wp, order in out:
         assert torch.allclose(torch.from_numpy(wf), wf_ref, atol=1e-6), (rank, wf, wf_ref)
         assert torch.allclose(torch.from_numpy(wp), wp_ref, atol=1e-6), (rank, wp, wp_ref)
-    # step 0: pfwd, main, pbwd, popt (main update pending); step 1 starts with pfwd BEFORE the pending main update
-    assert out[0][3] == ["pfwd", ("main", True), "pbwd", "popt", "pfwd", "mopt", ("main", False), "pfwd", "mopt"]
+        assert order == out[0][3]  # every rank issues the same segments in the same order (the collectives pair up)
+    order = out[0][3]
+    if pattern == "alternating":
+        # step 0: pfwd, main, pbwd, popt (main update pending); step 1 starts with pfwd BEFORE the pending main update
+        assert order[:9] == ["pfwd", ("main", True), "pbwd", "popt", "pfwd", "mopt", ("main", False), "pfwd", "mopt"]
+    assert order.count("popt") == order.count("pbwd") == sum(schedule) and order.count("mopt") == steps
+    assert order[-1] == "mopt"  # finish() drains the pending main-field update
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -252,3 +284,33 @@ def test_compact_table_prefix_exchange_equals_full_all_reduce():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert out[0][1:] == out[1][1:]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the driver's multi-GPU launch line, rehearsed on CPU (bench.py --dry-run: gloo instead of RCCL, no kernels)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.timeout(600)
+def test_bench_launch_line_dry_run_under_torchrun():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus 2 --steps K --warmup W` — exactly the driver's line plus --dry-run: argument and RANK / WORLD_SIZE / MASTER_*
+    handling, process-group setup, the real model / arena / compact prefix / pipelined exchange over gloo, ONE JSON line
+    from rank 0 with the contract's keys."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--dry-run"]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=540, cwd=root, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config"):
+        assert key in out, key
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["scaling"] == "weak"
+    assert out["config"]["max_abs_error"] <= 1e-5 and 0 < out["config"]["compact_rows"] < out["config"]["prefix_rows"]
