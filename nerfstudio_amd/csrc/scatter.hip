@@ -227,154 +227,6 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
   sweep(std::integral_constant<int, 1>{});
 }
 
-// ---- pass 1, fine levels, LDS-staged variant -------------------------------------------------------------------------
-// The direct kernel above stores every 16-B record straight to its slot: 64 different cache lines per store
-// instruction, 12.5 M separate write requests for the nerfacto main table (r02a: 83 us for 175 MB = 2.1 TB/s). Here a
-// workgroup first SORTS the records of kLPP levels by tile in LDS (counting sort: rank from ds_add_rtn, exclusive prefix
-// of the per-tile counts, ds_write_b128 into place) and then copies each tile's run out with consecutive lanes writing
-// consecutive records — full 64-B requests, 4x fewer of them. One point per thread; a workgroup does kPhases phases of
-// kLPP levels. What does not fit the workgroup's static segment goes to the tile's dynamic area (one returning atomic
-// per (workgroup, tile) that overflows — the records are still in LDS, nothing is recomputed), then to the spill list.
-template <int kThreads, int kLPP, int kPhases>
-__global__ __launch_bounds__(kThreads) void scatter_route_staged_kernel(
-    nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
-    int64_t stride_p, int64_t stride_k, ScatterGeom G, LevelList levels, ScatterBufs buf) {
-  constexpr int kLevels = kLPP * kPhases;
-  constexpr int kWaves = kThreads / 64;
-  static_assert(kLPP <= kWaves, "one wave scans one level");
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
-  const int B = 1 << G.log2_bins;
-  uint4* stage = reinterpret_cast<uint4*>(lds_u);                       // [kLPP][4 * kThreads]
-  uint32_t* cnt = lds_u + 4 * (size_t)kLPP * 4 * kThreads;              // [2][kLPP][B] (double-buffered over the phases)
-  uint32_t* pre = cnt + 2 * kLPP * B;                                   // [kLPP][B] exclusive prefix
-  uint32_t* lmax = pre + kLPP * B;                                      // [kLevels]
-  for (int t = threadIdx.x; t < 2 * kLPP * B; t += kThreads) cnt[t] = 0u;
-  if (threadIdx.x < kLevels) lmax[threadIdx.x] = 0u;
-  const int first = blockIdx.y * kLevels;
-  const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  const bool inside = p < M;
-  int lvl[kLevels];
-  float g0[kLevels], g1[kLevels];
-#pragma unroll
-  for (int i = 0; i < kLevels; ++i) {  // all gradient loads in flight before anything depends on them
-    lvl[i] = first + i < levels.count ? (int)levels.level[first + i] : -1;
-    g0[i] = g1[i] = 0.0f;
-    if (inside && lvl[i] >= 0) {
-      const float* gptr = denc + p * stride_p + (int64_t)(2 * lvl[i]) * stride_k;
-      g0[i] = gptr[0];
-      g1[i] = gptr[stride_k];
-    }
-  }
-  float x = 0.f, y = 0.f, z = 0.f;
-  if (inside) {
-    load_position(P, p, x, y, z);
-    (void)normalise_position(transform, box, x, y, z);
-  }
-  const uint32_t mask = (1u << grid.log2_table_size) - 1u;
-  const int sl = G.slice_log2;
-  const uint32_t local_mask = (1u << sl) - 1u;
-  const uint32_t C = G.seg_cap;
-  const uint32_t static_end = G.segs * C;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#pragma unroll
-  for (int ph = 0; ph < kPhases; ++ph) {
-    uint32_t* cn = cnt + (ph & 1) * kLPP * B;
-    __syncthreads();  // counters zeroed / previous phase's copy-out done with `stage`
-    uint4 rec[kLPP][4];
-    uint32_t where[kLPP][4];  // bin << 16 | rank; 0xffffffff: no record
-#pragma unroll
-    for (int l = 0; l < kLPP; ++l) {
-      const int i = ph * kLPP + l;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) where[l][q] = 0xffffffffu;
-      if (lvl[i] < 0 || !inside || (g0[i] == 0.0f && g1[i] == 0.0f)) continue;  // adding zero is a no-op
-      const Cell c = locate_cell(x, y, z, grid.scalings[lvl[i]]);
-      {
-        const uint32_t b0 = __float_as_uint(g0[i]) & 0x7fffffffu, b1 = __float_as_uint(g1[i]) & 0x7fffffffu;
-        atomicMax(lmax + i, b0 > b1 ? b0 : b1);  // integer compare of |bits|: NaN / Inf win and mark the level non-finite
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const PairHash h = pair_hash(c, q, mask);
-        const uint32_t bin = h.ia >> sl;
-        const float bz = (q & 2) ? c.w[2] : 1.0f - c.w[2];
-        const float by = (q & 1) ? c.w[1] : 1.0f - c.w[1];
-        const float a0 = (g0[i] * bz) * by, a1 = (g1[i] * bz) * by;  // autograd order ((g * wz) * wy) * wx; x in pass 2
-        if ((h.ib >> sl) != bin) {  // x-pair straddling two tiles (only when res >= 2^slice_log2): two singles, spilled
-          const uint32_t tbase = (uint32_t)lvl[i] << G.log2_bins;
-          spill_append(buf, G.spill_cap, tbase + bin,
-                       make_uint4(__float_as_uint(a0 * (1.0f - c.w[0])), __float_as_uint(a1 * (1.0f - c.w[0])), 0u,
-                                  h.ia & local_mask));
-          spill_append(buf, G.spill_cap, tbase + (h.ib >> sl),
-                       make_uint4(__float_as_uint(a0 * c.w[0]), __float_as_uint(a1 * c.w[0]), 0u, h.ib & local_mask));
-          continue;
-        }
-        rec[l][q] = make_uint4(__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(c.w[0]),
-                               (h.ia & local_mask) | ((h.ib & local_mask) << 14) | 0x80000000u);
-        where[l][q] = (bin << 16) | atomicAdd(cn + l * B + bin, 1u);  // ds_add_rtn_u32 (rank < 4 * kThreads <= 65535)
-      }
-    }
-    __syncthreads();
-    if (wave < kLPP) {  // exclusive prefix of this level's per-tile counts, one wavefront
-      uint32_t carry = 0u;
-      for (int c0 = 0; c0 < B; c0 += 64) {
-        const uint32_t v = c0 + lane < B ? cn[wave * B + c0 + lane] : 0u;
-        uint32_t inc = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const uint32_t o = __shfl_up(inc, d);
-          if (lane >= d) inc += o;
-        }
-        if (c0 + lane < B) pre[wave * B + c0 + lane] = carry + inc - v;
-        carry += __shfl(inc, 63);
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int l = 0; l < kLPP; ++l)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (where[l][q] != 0xffffffffu)
-          stage[l * 4 * kThreads + pre[l * B + (where[l][q] >> 16)] + (where[l][q] & 0xffffu)] = rec[l][q];
-    // counters of the next phase (the other buffer) — zeroed here, visible after the next barrier
-    if (ph + 1 < kPhases) {
-      uint32_t* nx = cnt + ((ph + 1) & 1) * kLPP * B;
-      for (int t = threadIdx.x; t < kLPP * B; t += kThreads) nx[t] = 0u;
-    }
-    __syncthreads();
-    // copy-out: wave w takes (level, tile) items w, w + kWaves, ...; consecutive lanes = consecutive records
-    for (int item = wave; item < kLPP * B; item += kWaves) {
-      const int l = item / B, b = item - l * B;
-      const int i = ph * kLPP + l;
-      if (lvl[i] < 0) continue;
-      const uint32_t n = cn[item], src = pre[item];
-      const uint32_t tile = ((uint32_t)lvl[i] << G.log2_bins) + (uint32_t)b;
-      const uint32_t Q = G.level_cap[lvl[i]];
-      uint4* const queue = buf.queues + ((size_t)G.level_off[lvl[i]] + (size_t)b * Q);
-      const uint4* const from = stage + l * 4 * kThreads + src;
-      const uint32_t ns = n < C ? n : C;
-      for (uint32_t r = lane; r < ns; r += 64) queue[blockIdx.x * C + r] = from[r];
-      if (lane == 0) buf.counts[(size_t)tile * G.segs + blockIdx.x] = ns;
-      if (n > C) {  // this workgroup's share of the tile's dynamic area
-        uint32_t dbase = 0u;
-        if (lane == 0) dbase = atomicAdd(buf.dyn_cursor + tile, n - C);
-        dbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)dbase);
-        for (uint32_t r = C + lane; r < n; r += 64) {
-          const uint32_t pos = dbase + (r - C);
-          if (pos < Q - static_end) queue[static_end + pos] = from[r];
-          else spill_append(buf, G.spill_cap, tile, from[r]);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < kLevels) {
-    const int level = first + (int)threadIdx.x < levels.count ? (int)levels.level[first + threadIdx.x] : -1;
-    if (level >= 0 && lmax[threadIdx.x] != 0u) atomicMax(buf.hdr + level, lmax[threadIdx.x]);
-  }
-}
-
 // ---- pass 1, coarse levels -----------------------------------------------------------------------------------------
 // Every thread walks kRunLen CONSECUTIVE samples and merges those that stay in one cell (a run): per-corner sums in
 // registers, in sample order. A run of one sample leaves as 4 x-pair records, a longer one as 8 single records
@@ -597,21 +449,25 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
       for (uint32_t c0 = 0; c0 < mine; c0 += 64u) {
         const uint32_t cv = (c0 + (uint32_t)lane < mine) ? cnts[wave + (c0 + (uint32_t)lane) * nw] : 0u;
         const uint32_t chunk = min(64u, mine - c0);
-        for (uint32_t t = 0; t < chunk; t += 4u) {
-          uint32_t n[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            n[u] = (uint32_t)__builtin_amdgcn_readlane((int)cv, (int)min(t + (uint32_t)u, 63u));  // 0 beyond `chunk`
-          uint4 r[4][2];
+        // trips of 4 segments, software-pipelined: the records of trip t + 1 are in flight while trip t goes through the
+        // LDS atomics (all 16 waves of the workgroup otherwise alternate between waiting on memory and queueing on the LDS)
+        uint32_t n[4], n_next[4];
+        uint4 r[4][2], r_next[4][2];
+        auto fetch = [&](uint32_t t, uint32_t (&nn)[4], uint4 (&rr)[4][2]) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
+            nn[u] = t < chunk ? (uint32_t)__builtin_amdgcn_readlane((int)cv, (int)min(t + (uint32_t)u, 63u)) : 0u;  // 0 beyond `chunk`
             const uint4* seg = q + (size_t)(wave + (c0 + t + (uint32_t)u) * nw) * C;
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
               const uint32_t e = (uint32_t)lane + 64u * v;
-              r[u][v] = e < n[u] ? seg[e] : make_uint4(0u, 0u, 0u, 0u);
+              rr[u][v] = e < nn[u] ? seg[e] : make_uint4(0u, 0u, 0u, 0u);
             }
           }
+        };
+        fetch(0u, n, r);
+        for (uint32_t t = 0; t < chunk; t += 4u) {
+          fetch(t + 4u, n_next, r_next);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -619,6 +475,12 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
               if ((uint32_t)lane + 64u * v < n[u]) add_rec(r[u][v]);
             const uint4* seg = q + (size_t)(wave + (c0 + t + (uint32_t)u) * nw) * C;
             for (uint32_t e = (uint32_t)lane + 128u; e < n[u]; e += 64u) add_rec(seg[e]);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            n[u] = n_next[u];
+            r[u][0] = r_next[u][0];
+            r[u][1] = r_next[u][1];
           }
         }
       }
@@ -710,24 +572,17 @@ static int env_int(const char* name, int dflt) {
   return e != nullptr ? atoi(e) : dflt;
 }
 
-// fine-kernel shape (threads, points per thread, levels per thread); NSAMD_SCATTER_SHAPE = "TPL" digits, e.g. 124 =
-// 1024 threads x 2 points x 4 levels (experiments; read once)
+// fine-kernel shape (threads, points per thread, levels per thread); NSAMD_SCATTER_SHAPE = "TPL" digits (experiments; read
+// once). Measured on MI355X (profiles/r02_scatter_variants.txt): 1024 x 1 x 4 is the fastest or within noise of it; two
+// points per thread, two levels per thread and an LDS-staged coalescing variant were slower and are gone.
 struct FineShape {
   int threads, pts, levels;
-  int staged_lpp = 0;  // > 0: the LDS-staged kernel with this many levels per phase
 };
 static FineShape fine_shape() {
   static const int code = env_int("NSAMD_SCATTER_SHAPE", 114);
   switch (code) {
-    case 124: return FineShape{1024, 2, 4};
-    case 122: return FineShape{1024, 2, 2};
-    case 524: return FineShape{512, 2, 4};
-    case 522: return FineShape{512, 2, 2};
     case 514: return FineShape{512, 1, 4};
     case 112: return FineShape{1024, 1, 2};
-    case 822: return FineShape{512, 1, 4, 2};    // staged: 512 threads, 2 levels per phase, 2 phases
-    case 814: return FineShape{1024, 1, 4, 1};   // staged: 1024 threads, 1 level per phase, 4 phases
-    case 824: return FineShape{512, 1, 8, 2};    // staged: 512 threads, 2 levels per phase, 4 phases
     default: return FineShape{1024, 1, 4};
   }
 }
@@ -831,18 +686,6 @@ static ScatterBufs scatter_bufs(float* workspace, const ScatterPlan& p) {
   return b;
 }
 
-template <int kThreads, int kLPP, int kPhases>
-static void launch_staged(const nsamd_points& pts, int64_t M, int transform, const nsamd_aabb& aabb, const nsamd_grid& grid,
-                          const float* denc, int64_t stride_p, int64_t stride_k, const ScatterGeom& G,
-                          const LevelList& fine, const ScatterBufs& buf, hipStream_t st) {
-  const size_t B = (size_t)1 << G.log2_bins;
-  const size_t lds = sizeof(uint32_t) * (4 * (size_t)kLPP * 4 * kThreads + 3 * kLPP * B + kLPP * kPhases);
-  constexpr int kLevels = kLPP * kPhases;
-  dim3 g1(G.segs, (unsigned)((fine.count + kLevels - 1) / kLevels));
-  scatter_route_staged_kernel<kThreads, kLPP, kPhases><<<g1, kThreads, lds, st>>>(pts, M, transform, aabb, grid, denc,
-                                                                                   stride_p, stride_k, G, fine, buf);
-}
-
 template <int kThreads, int kPts, int kLevels>
 static void launch_fine(const nsamd_points& pts, int64_t M, int transform, const nsamd_aabb& aabb, const nsamd_grid& grid,
                         const float* denc, int64_t stride_p, int64_t stride_k, const ScatterGeom& G,
@@ -890,16 +733,8 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
   }
   if (fine.count > 0) {
     const FineShape s = fine_shape();
-    const int code = s.staged_lpp ? -(s.threads * 100 + s.staged_lpp * 10 + s.levels / s.staged_lpp)
-                                  : s.threads * 100 + s.pts * 10 + s.levels;
+    const int code = s.threads * 100 + s.pts * 10 + s.levels;
     switch (code) {
-      case -51222: launch_staged<512, 2, 2>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
-      case -102414: launch_staged<1024, 1, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
-      case -51224: launch_staged<512, 2, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
-      case 102424: launch_fine<1024, 2, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
-      case 102422: launch_fine<1024, 2, 2>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
-      case 51224: launch_fine<512, 2, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
-      case 51222: launch_fine<512, 2, 2>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
       case 51214: launch_fine<512, 1, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
       case 102412: launch_fine<1024, 1, 2>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
       default: launch_fine<1024, 1, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
