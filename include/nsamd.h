@@ -334,6 +334,74 @@ int nsamd_proposal_losses(const float* s_bins_fine, const float* w_fine, int32_t
                           float* dw_distortion, nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Packed-sample path of instant-ngp (BASELINE configs[3]): what the reference gets from nerfacc 0.5.2
+ * (OccGridEstimator.sampling, pack_info, render_weight_from_density, render_visibility_from_density,
+ * accumulate_along_rays; call sites model_components/ray_samplers.py:481-493, models/instant_ngp.py:192-198,
+ * model_components/renderers.py:93-102, 310-314, 369-377). nerfacc is not part of /root/reference: the arithmetic is
+ * restated (oracle/packed_oracle.py); the weight / visibility / accumulation formulas are anchored on the reference's
+ * dense path, the marcher's sample placement is NOT pinned.
+ * Samples of a ray are contiguous, rays in increasing order; packed_info [N,2] int64 = (start, count) per ray.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct nsamd_occgrid {
+  const uint8_t* binaries; /* [levels, R, R, R] 0/1: level l covers the region of interest scaled by 2^l about its centre */
+  int32_t levels;
+  int32_t resolution;
+  float aabb[6];           /* region of interest: min xyz, max xyz */
+} nsamd_occgrid;
+
+/* Ray marching through the occupancy grid, two calls: _count fills counts[N] (int32), nsamd_packed_info turns them into
+ * packed_info + the total, _write emits ray_indices [n] int64, t_starts / t_ends [n]. A ray marches t = t0, t0 + dt, ...
+ * inside [max(near, t_min), min(far, t_max)] clipped to the outermost grid level, dt = clamp(t * cone_angle, step, 1e10);
+ * a step is kept when the cell (finest level containing the step's midpoint) is occupied. jitter [N] in [0,1) (nullable)
+ * shifts a ray's lattice by jitter * step (stratified training, ray_samplers.py:489). t_min / t_max nullable. */
+int nsamd_occgrid_march_count(const float* origins, const float* directions, const float* t_min, const float* t_max,
+                              int64_t num_rays, float near_plane, float far_plane, nsamd_occgrid grid, float step_size,
+                              float cone_angle, const float* jitter, int32_t* counts, nsamd_stream_t stream);
+int nsamd_occgrid_march_write(const float* origins, const float* directions, const float* t_min, const float* t_max,
+                              int64_t num_rays, float near_plane, float far_plane, nsamd_occgrid grid, float step_size,
+                              float cone_angle, const float* jitter, const int64_t* packed_info, int64_t* ray_indices,
+                              float* t_starts, float* t_ends, nsamd_stream_t stream);
+
+/* nerfacc.pack_info from per-ray counts: packed_info [N,2] int64 and total[0] (device int64) = number of samples. */
+int nsamd_packed_info(const int32_t* counts, int64_t num_rays, int64_t* packed_info, int64_t* total, nsamd_stream_t stream);
+
+/* nerfacc.render_weight_from_density: w = T (1 - exp(-sigma dt)), T = exp(-sum of sigma dt in front) — one wavefront per
+ * ray scans its segment (double running sum). transmittance nullable. Backward: dL/dweights -> dL/dsigmas. */
+int nsamd_packed_weights_fwd(const float* t_starts, const float* t_ends, const float* sigmas, const int64_t* packed_info,
+                             int64_t num_rays, float* weights, float* transmittance, nsamd_stream_t stream);
+int nsamd_packed_weights_bwd(const float* t_starts, const float* t_ends, const float* sigmas, const float* dweights,
+                             const int64_t* packed_info, int64_t num_rays, float* dsigmas, nsamd_stream_t stream);
+
+/* nerfacc.render_visibility_from_density: mask[s] = T_s >= early_stop_eps && alpha_s >= alpha_thre (uint8) and the
+ * number of kept samples per ray — the same scan, stopping a ray at the first chunk whose transmittance is below the
+ * threshold (visibility-ordered early termination). nsamd_packed_compact then moves the survivors (order kept) to the
+ * layout given by packed_info_new (from the kept counts through nsamd_packed_info). */
+int nsamd_packed_visibility(const float* t_starts, const float* t_ends, const float* sigmas, const int64_t* packed_info,
+                            int64_t num_rays, float early_stop_eps, float alpha_thre, uint8_t* mask, int32_t* kept_counts,
+                            nsamd_stream_t stream);
+int nsamd_packed_compact(const uint8_t* mask, const int64_t* packed_info_old, const int64_t* packed_info_new,
+                         int64_t num_rays, const float* t_starts, const float* t_ends, int64_t* ray_indices_out,
+                         float* t_starts_out, float* t_ends_out, nsamd_stream_t stream);
+
+/* Packed branches of RGBRenderer / AccumulationRenderer / DepthRenderer("expected") (accumulate_along_rays):
+ * rgb [n,3], weights [n] -> out_rgb [N,3], accumulation [N], depth [N] (nullable; = sum w mid / (acc + 1e-10), the
+ * caller clips it to the batch's midpoint range as renderers.py:381-383). background_mode 0: none ("random": blended in
+ * the loss), 1: the host colour background_rgb_host[3] times (1 - accumulation). eval_mode: nan_to_num + clamp.
+ * Backward: g_rgb [N,3], g_accumulation [N] (nullable) -> d_rgb [n,3] (nullable), d_weights [n]. */
+int nsamd_packed_composite_fwd(const float* rgb, const float* weights, const float* t_starts, const float* t_ends,
+                               const int64_t* packed_info, int64_t num_rays, int background_mode,
+                               const float* background_rgb_host, int eval_mode, float* out_rgb, float* out_accumulation,
+                               float* out_depth, nsamd_stream_t stream);
+int nsamd_packed_composite_bwd(const float* rgb, const float* weights, const int64_t* ray_indices, int64_t num_samples,
+                               int background_mode, const float* background_rgb_host, const float* g_rgb,
+                               const float* g_accumulation, float* d_rgb, float* d_weights, nsamd_stream_t stream);
+
+/* positions [n,3] of packed samples: o[ray] + d[ray] (t_start + t_end) / 2 (the sigma_fn of VolumetricSampler,
+ * ray_samplers.py:420-429). */
+int nsamd_packed_positions(const float* origins, const float* directions, const int64_t* ray_indices, const float* t_starts,
+                           const float* t_ends, int64_t num_samples, float* positions, nsamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Pinhole ray generation (RayGenerator.forward, model_components/ray_generators.py:41-56 ->
  * Cameras._generate_rays_from_coords perspective branch, cameras/cameras.py:598-634, 655-656, 781-787, 887-909).
  * ray_indices [N,3] int64 (camera,row,col); c2w [C,3,4]; fx,fy,cx,cy [C]. Pixel centres at +0.5.

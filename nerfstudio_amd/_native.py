@@ -48,6 +48,10 @@ class FieldMlp(C.Structure):
                 ("num_images", i32), ("average_init_density", f32)]
 
 
+class OccGrid(C.Structure):
+    _fields_ = [("binaries", vp), ("levels", i32), ("resolution", i32), ("aabb", f32 * 6)]
+
+
 class FieldMlpGrads(C.Structure):
     _fields_ = [("base_W0", vp), ("base_b0", vp), ("base_W1", vp), ("base_b1", vp), ("head_W0", vp), ("head_b0", vp),
                 ("head_W1", vp), ("head_b1", vp), ("head_W2", vp), ("head_b2", vp), ("appearance", vp)]
@@ -87,6 +91,16 @@ _SIGNATURES = {
     "nsamd_interlevel_loss": [vp, vp, i32, vp, vp, i32, i64, f32, vp, vp, vp],
     "nsamd_distortion_loss": [vp, vp, i32, i64, f32, vp, vp, vp],
     "nsamd_proposal_losses": [vp, vp, i32, i32, vp, vp, vp, i64, f32, f32, vp, vp, vp, vp, vp],
+    "nsamd_occgrid_march_count": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp],
+    "nsamd_occgrid_march_write": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp, vp, vp, vp],
+    "nsamd_packed_info": [vp, i64, vp, vp, vp],
+    "nsamd_packed_weights_fwd": [vp, vp, vp, vp, i64, vp, vp, vp],
+    "nsamd_packed_weights_bwd": [vp, vp, vp, vp, vp, i64, vp, vp],
+    "nsamd_packed_visibility": [vp, vp, vp, vp, i64, f32, f32, vp, vp, vp],
+    "nsamd_packed_compact": [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp],
+    "nsamd_packed_composite_fwd": [vp, vp, vp, vp, vp, i64, C.c_int, C.POINTER(f32), C.c_int, vp, vp, vp, vp],
+    "nsamd_packed_composite_bwd": [vp, vp, vp, i64, C.c_int, C.POINTER(f32), vp, vp, vp, vp, vp],
+    "nsamd_packed_positions": [vp, vp, vp, vp, vp, i64, vp, vp],
     "nsamd_raygen_pinhole": [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp],
     "nsamd_rows_gather": [vp, vp, i64, i32, vp, vp],
     "nsamd_rows_scatter": [vp, vp, i64, i32, vp, vp],

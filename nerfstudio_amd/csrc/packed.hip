@@ -1,0 +1,502 @@
+// Packed-sample path of instant-ngp for gfx950 (BASELINE configs[3]): occupancy-grid ray
+// marching, transmittance scan with visibility-ordered early termination, sample compaction, packed compositing.
+// Reference call sites (the arithmetic itself lives in nerfacc 0.5.2, absent from /root/reference — restated, parity of
+// the marcher UNPINNED, see oracle/packed_oracle.py):
+//   VolumetricSampler.forward              /root/reference/nerfstudio/model_components/ray_samplers.py:385-519
+//   NGPModel.get_outputs                   /root/reference/nerfstudio/models/instant_ngp.py:172-217
+//   packed branches of the renderers       /root/reference/nerfstudio/model_components/renderers.py:93-102, 310-314, 369-377
+//
+// Layout: samples of a ray are contiguous, rays in increasing order ("packed"); packed_info[r] = (start, count) int64.
+// Variable-length rows, so every per-ray kernel is one WAVEFRONT per ray walking its segment in chunks of 64 with a
+// carried running sum (double, like the dense scans of sampler.hip): the scan that gives the transmittance in front of
+// each sample is also what decides, in visibility order, where a ray stops contributing.
+#include "common.h"
+
+namespace nsamd {
+
+constexpr int kPackThreads = 256;
+constexpr int kPackWaves = kPackThreads / 64;
+
+__device__ __forceinline__ double pk_scan_inclusive(double v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double o = __shfl_up(v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// ---- occupancy-grid marching ---------------------------------------------------------------------------------------
+// Multi-level grid as nerfacc's OccGridEstimator lays it out: level l covers the region of interest scaled by 2^l about
+// its centre, `resolution`^3 cells each, binaries[level][x][y][z]. A ray marches t = t0, t0 + dt, ... with
+// dt = clamp(t * cone_angle, step, 1e10) (cone_angle 0: uniform steps); the sample [t, t + dt) is kept when the cell of
+// the FINEST level containing its midpoint is occupied. Sequential fp32 per ray, same op order as the oracle.
+__device__ __forceinline__ bool ray_box(const float o[3], const float d[3], const float lo[3], const float hi[3], float& t0,
+                                        float& t1) {
+  float a = -3.4028234663852886e38f, b = 3.4028234663852886e38f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float inv = 1.0f / d[k];  // +-inf for an axis-parallel ray: IEEE handles the slab test
+    float ta = (lo[k] - o[k]) * inv, tb = (hi[k] - o[k]) * inv;
+    if (ta > tb) { const float s = ta; ta = tb; tb = s; }
+    if (ta != ta || tb != tb) {  // 0 * inf: origin on a slab plane of a parallel axis -> inside iff lo <= o <= hi
+      if (o[k] < lo[k] || o[k] > hi[k]) return false;
+      continue;
+    }
+    a = fmaxf(a, ta);
+    b = fminf(b, tb);
+  }
+  t0 = a;
+  t1 = b;
+  return a <= b;
+}
+
+template <bool kWrite>
+__global__ __launch_bounds__(kPackThreads) void occgrid_march_kernel(
+    const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ t_min,
+    const float* __restrict__ t_max, int64_t num_rays, float near_plane, float far_plane, nsamd_occgrid grid, float step,
+    float cone_angle, const float* __restrict__ jitter, int32_t* __restrict__ counts, const int64_t* __restrict__ starts,
+    int64_t* __restrict__ ray_indices, float* __restrict__ t_starts, float* __restrict__ t_ends) {
+  const int64_t ray = (int64_t)blockIdx.x * kPackThreads + threadIdx.x;
+  if (ray >= num_rays) return;
+  const float o[3] = {origins[3 * ray], origins[3 * ray + 1], origins[3 * ray + 2]};
+  const float d[3] = {directions[3 * ray], directions[3 * ray + 1], directions[3 * ray + 2]};
+  float t_lo = near_plane, t_hi = far_plane;
+  if (t_min != nullptr) t_lo = fmaxf(t_lo, t_min[ray]);
+  if (t_max != nullptr) t_hi = fminf(t_hi, t_max[ray]);
+  const int R = grid.resolution, L = grid.levels;
+  float centre[3], half[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    centre[k] = (grid.aabb[k] + grid.aabb[3 + k]) * 0.5f;
+    half[k] = (grid.aabb[3 + k] - grid.aabb[k]) * 0.5f;
+  }
+  const float outer = (float)(1 << (L - 1));
+  float lo[3], hi[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = centre[k] - half[k] * outer;
+    hi[k] = centre[k] + half[k] * outer;
+  }
+  int32_t n = 0;
+  int64_t out = kWrite ? starts[2 * ray] : 0;  // packed_info [N,2]: (start, count)
+  float ta, tb;
+  if (ray_box(o, d, lo, hi, ta, tb)) {
+    float t = fmaxf(t_lo, ta);
+    const float t_end = fminf(t_hi, tb);
+    if (jitter != nullptr) t += jitter[ray] * step;  // stratified: the whole lattice of the ray shifts by U[0,1) * step
+    for (int it = 0; it < (1 << 20) && t < t_end; ++it) {
+      float dt = t * cone_angle;
+      dt = fminf(fmaxf(dt, step), 1e10f);
+      const float mid = t + dt * 0.5f;
+      const float p[3] = {o[0] + d[0] * mid, o[1] + d[1] * mid, o[2] + d[2] * mid};
+      // finest level whose box holds the midpoint
+      float m = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) m = fmaxf(m, fabsf(p[k] - centre[k]) / half[k]);
+      int level = 0;
+      float scale = 1.0f;
+      while (level < L - 1 && m > scale) {
+        scale *= 2.0f;
+        ++level;
+      }
+      if (m <= scale) {
+        int c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float u = (p[k] - (centre[k] - half[k] * scale)) / (2.0f * half[k] * scale) * (float)R;
+          int ci = (int)floorf(u);
+          c[k] = ci < 0 ? 0 : (ci >= R ? R - 1 : ci);
+        }
+        const size_t cell = (((size_t)level * R + c[0]) * R + c[1]) * R + c[2];
+        if (grid.binaries[cell]) {
+          if (kWrite) {
+            ray_indices[out] = ray;
+            t_starts[out] = t;
+            t_ends[out] = t + dt;
+            ++out;
+          }
+          ++n;
+        }
+      }
+      t += dt;
+    }
+  }
+  if (!kWrite) counts[ray] = n;
+}
+
+// counts [N] int32 -> packed_info [N,2] int64 (start, count) and the total in total_out[0]; one workgroup.
+__global__ __launch_bounds__(1024) void packed_info_kernel(const int32_t* __restrict__ counts, int64_t num_rays,
+                                                           int64_t* __restrict__ info, int64_t* __restrict__ total_out) {
+  __shared__ long long wave_tot[16];
+  __shared__ long long base_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (int64_t i0 = 0; i0 < num_rays; i0 += 1024) {
+    const int64_t i = i0 + threadIdx.x;
+    const long long v = i < num_rays ? counts[i] : 0;
+    long long inc = v;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const long long o = __shfl_up(inc, dd);
+      if (lane >= dd) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    long long before = base_s;
+    for (int w = 0; w < wave; ++w) before += wave_tot[w];
+    if (i < num_rays) {
+      info[2 * i] = before + inc - v;
+      info[2 * i + 1] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      long long t = base_s;
+      for (int w = 0; w < 16; ++w) t += wave_tot[w];
+      base_s = t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) total_out[0] = base_s;
+}
+
+// ---- render_weight_from_density / render_visibility_from_density over packed segments ----------------------------
+// alpha_i = 1 - exp(-sigma_i dt_i), T_i = exp(-sum_{j<i} sigma_j dt_j), w_i = T_i alpha_i (the formulas of the dense
+// RaySamples.get_weights, cameras/rays.py:129-152, without its nan_to_num). kVisibility: instead of the weights, the
+// keep-mask T_i >= early_stop_eps && alpha_i >= alpha_thre and its per-ray count — T is non-increasing along the ray, so
+// the first sample behind the threshold ends the ray (visibility-ordered early termination).
+template <bool kVisibility>
+__global__ __launch_bounds__(kPackThreads) void packed_weights_kernel(
+    const float* __restrict__ t_starts, const float* __restrict__ t_ends, const float* __restrict__ sigmas,
+    const int64_t* __restrict__ info, int64_t num_rays, float early_stop_eps, float alpha_thre,
+    float* __restrict__ weights, float* __restrict__ trans_out, uint8_t* __restrict__ mask, int32_t* __restrict__ kept) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * kPackWaves + (threadIdx.x >> 6);
+  if (ray >= num_rays) return;  // wave-uniform
+  const int64_t s0 = info[2 * ray], cnt = info[2 * ray + 1];
+  double carry = 0.0;
+  int32_t keep_n = 0;
+  for (int64_t i0 = 0; i0 < cnt; i0 += 64) {
+    const int64_t i = i0 + lane;
+    const bool in = i < cnt;
+    const float dd = in ? sigmas[s0 + i] * (t_ends[s0 + i] - t_starts[s0 + i]) : 0.0f;
+    const double incl = carry + pk_scan_inclusive((double)dd, lane);
+    double excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = carry;
+    carry = __shfl(incl, 63);
+    const float alpha = 1.0f - expf(-dd);
+    const float trans = expf(-(float)excl);
+    if (kVisibility) {
+      const bool k = in && trans >= early_stop_eps && alpha >= alpha_thre;
+      if (in) mask[s0 + i] = k ? 1 : 0;
+      keep_n += (int32_t)__builtin_popcountll(__ballot(k));
+      // every later sample has a smaller transmittance: nothing behind this chunk can be visible
+      if (__shfl(trans, 63) < early_stop_eps && i0 + 64 < cnt) {
+        for (int64_t j = i0 + 64 + lane; j < cnt; j += 64) mask[s0 + j] = 0;
+        break;
+      }
+    } else if (in) {
+      weights[s0 + i] = trans * alpha;
+      if (trans_out != nullptr) trans_out[s0 + i] = trans;
+    }
+  }
+  if (kVisibility && lane == 0) kept[ray] = keep_n;
+}
+
+// d w / d sigma: d(sigma_j dt_j) gets  g_j T_j exp(-dd_j)  -  sum_{i>j} g_i w_i  (as the dense weights_bwd_kernel), with
+// no per-ray LDS row: pass A sums the segment, pass B walks it backwards — the exclusive prefix is total minus the
+// inclusive suffix (double), the suffix of g w comes from the same reverse scan.
+__global__ __launch_bounds__(kPackThreads) void packed_weights_bwd_kernel(
+    const float* __restrict__ t_starts, const float* __restrict__ t_ends, const float* __restrict__ sigmas,
+    const float* __restrict__ dweights, const int64_t* __restrict__ info, int64_t num_rays, float* __restrict__ dsigmas) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * kPackWaves + (threadIdx.x >> 6);
+  if (ray >= num_rays) return;
+  const int64_t s0 = info[2 * ray], cnt = info[2 * ray + 1];
+  double total = 0.0;
+  for (int64_t i0 = 0; i0 < cnt; i0 += 64) {
+    const int64_t i = i0 + lane;
+    const float dd = i < cnt ? sigmas[s0 + i] * (t_ends[s0 + i] - t_starts[s0 + i]) : 0.0f;
+    total += __shfl(pk_scan_inclusive((double)dd, lane), 63);
+  }
+  double suf_dd = 0.0, suf_gw = 0.0;  // sums over the samples behind the current chunk
+  for (int64_t r0 = 0; r0 < cnt; r0 += 64) {
+    const int64_t r = r0 + lane;   // reversed position
+    const int64_t i = cnt - 1 - r; // sample
+    const bool in = r < cnt;
+    const float dt = in ? t_ends[s0 + i] - t_starts[s0 + i] : 0.0f;
+    const float dd = in ? sigmas[s0 + i] * dt : 0.0f;
+    const double incl_dd = suf_dd + pk_scan_inclusive((double)dd, lane);  // sum over samples >= i
+    const float ex = expf(-dd);
+    const float trans = expf(-(float)(total - incl_dd));
+    const float g = in ? dweights[s0 + i] : 0.0f;
+    const float gw = g * ((1.0f - ex) * trans);
+    const double incl_gw = suf_gw + pk_scan_inclusive((double)gw, lane);
+    double excl_gw = __shfl_up(incl_gw, 1);
+    if (lane == 0) excl_gw = suf_gw;
+    suf_dd = __shfl(incl_dd, 63);
+    suf_gw = __shfl(incl_gw, 63);
+    if (in) dsigmas[s0 + i] = dt * (g * trans * ex - (float)excl_gw);
+  }
+}
+
+// Keep the samples whose mask is set: new packed_info from the per-ray kept counts (packed_info_kernel), then one
+// wavefront per ray moves its survivors to their new place (order preserved).
+__global__ __launch_bounds__(kPackThreads) void packed_compact_kernel(
+    const uint8_t* __restrict__ mask, const int64_t* __restrict__ info_old, const int64_t* __restrict__ info_new,
+    int64_t num_rays, const float* __restrict__ t_starts, const float* __restrict__ t_ends,
+    int64_t* __restrict__ ray_indices_out, float* __restrict__ t_starts_out, float* __restrict__ t_ends_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * kPackWaves + (threadIdx.x >> 6);
+  if (ray >= num_rays) return;
+  const int64_t s0 = info_old[2 * ray], cnt = info_old[2 * ray + 1];
+  int64_t dst = info_new[2 * ray];
+  for (int64_t i0 = 0; i0 < cnt; i0 += 64) {
+    const int64_t i = i0 + lane;
+    const bool k = i < cnt && mask[s0 + i] != 0;
+    const unsigned long long b = __ballot(k);
+    if (k) {
+      const int64_t at = dst + __builtin_popcountll(b & ((1ull << lane) - 1ull));
+      ray_indices_out[at] = ray;
+      t_starts_out[at] = t_starts[s0 + i];
+      t_ends_out[at] = t_ends[s0 + i];
+    }
+    dst += __builtin_popcountll(b);
+  }
+}
+
+// ---- packed compositing (accumulate_along_rays; renderers.py:93-119, 310-317, 365-383) ------------------------------
+// rgb = sum w c (+ background (1 - acc) for "white" / "black" / a colour; "random": nothing), acc = sum w,
+// depth = sum w (t_start + t_end) / 2 / (acc + 1e-10). eval_mode: nan_to_num on the samples' colours, clamp to [0, 1].
+__global__ __launch_bounds__(kPackThreads) void packed_composite_fwd_kernel(
+    const float* __restrict__ rgb, const float* __restrict__ weights, const float* __restrict__ t_starts,
+    const float* __restrict__ t_ends, const int64_t* __restrict__ info, int64_t num_rays, int bg_mode, float bg0,
+    float bg1, float bg2, int eval_mode, float* __restrict__ out_rgb, float* __restrict__ out_acc,
+    float* __restrict__ out_depth) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * kPackWaves + (threadIdx.x >> 6);
+  if (ray >= num_rays) return;
+  const int64_t s0 = info[2 * ray], cnt = info[2 * ray + 1];
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, a = 0.f, dsum = 0.f;
+  for (int64_t i = lane; i < cnt; i += 64) {
+    const float w = weights[s0 + i];
+    float r0 = rgb[3 * (s0 + i)], r1 = rgb[3 * (s0 + i) + 1], r2 = rgb[3 * (s0 + i) + 2];
+    if (eval_mode) { r0 = nan_to_num(r0); r1 = nan_to_num(r1); r2 = nan_to_num(r2); }
+    c0 += w * r0; c1 += w * r1; c2 += w * r2;
+    a += w;
+    if (t_starts != nullptr) dsum += w * ((t_starts[s0 + i] + t_ends[s0 + i]) / 2.0f);
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    c0 += __shfl_xor(c0, m); c1 += __shfl_xor(c1, m); c2 += __shfl_xor(c2, m);
+    a += __shfl_xor(a, m); dsum += __shfl_xor(dsum, m);
+  }
+  if (lane == 0) {
+    if (bg_mode == 1) {  // a constant colour
+      c0 = c0 + bg0 * (1.0f - a); c1 = c1 + bg1 * (1.0f - a); c2 = c2 + bg2 * (1.0f - a);
+    }
+    if (eval_mode) {
+      c0 = fminf(fmaxf(c0, 0.0f), 1.0f); c1 = fminf(fmaxf(c1, 0.0f), 1.0f); c2 = fminf(fmaxf(c2, 0.0f), 1.0f);
+    }
+    out_rgb[3 * ray] = c0; out_rgb[3 * ray + 1] = c1; out_rgb[3 * ray + 2] = c2;
+    out_acc[ray] = a;
+    if (out_depth != nullptr) out_depth[ray] = dsum / (a + 1e-10f);
+  }
+}
+
+// gradients of (rgb, acc) w.r.t. the samples: d rgb_s = w_s g_rgb[ray],
+// d w_s = g_rgb . c_s + (g_acc - [constant background] g_rgb . bg); depth carries no gradient here (the reference renders
+// it under no_grad for the loss path: NGPModel's loss uses rgb only, models/instant_ngp.py:219-235).
+__global__ void packed_composite_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ weights,
+                                            const int64_t* __restrict__ ray_indices, int64_t n, int bg_mode, float bg0,
+                                            float bg1, float bg2, const float* __restrict__ g_rgb,
+                                            const float* __restrict__ g_acc, float* __restrict__ d_rgb,
+                                            float* __restrict__ d_weights) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const int64_t ray = ray_indices[s];
+  const float g0 = g_rgb[3 * ray], g1 = g_rgb[3 * ray + 1], g2 = g_rgb[3 * ray + 2];
+  const float w = weights[s];
+  if (d_rgb != nullptr) {
+    d_rgb[3 * s] = w * g0; d_rgb[3 * s + 1] = w * g1; d_rgb[3 * s + 2] = w * g2;
+  }
+  float dw = g0 * rgb[3 * s] + g1 * rgb[3 * s + 1] + g2 * rgb[3 * s + 2];
+  if (g_acc != nullptr) dw += g_acc[ray];
+  if (bg_mode == 1) dw -= g0 * bg0 + g1 * bg1 + g2 * bg2;
+  d_weights[s] = dw;
+}
+
+// positions of packed samples: o[ray] + d[ray] * (t_start + t_end) / 2  (the sigma_fn of VolumetricSampler,
+// ray_samplers.py:420-429, and Frustums.get_positions for the packed RaySamples)
+__global__ void packed_positions_kernel(const float* __restrict__ origins, const float* __restrict__ directions,
+                                        const int64_t* __restrict__ ray_indices, const float* __restrict__ t_starts,
+                                        const float* __restrict__ t_ends, int64_t n, float* __restrict__ positions) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const int64_t ray = ray_indices[s];
+  const float span = t_starts[s] + t_ends[s];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) positions[3 * s + k] = origins[3 * ray + k] + directions[3 * ray + k] * span / 2.0f;
+}
+
+static unsigned pack_ray_blocks(int64_t rays) { return (unsigned)((rays + kPackWaves - 1) / kPackWaves); }
+
+static int check_grid_desc(const nsamd_occgrid& g) {
+  if (g.binaries == nullptr || g.levels < 1 || g.levels > 8 || g.resolution < 1 || g.resolution > 1024)
+    return NSAMD_ERR_INVALID_ARG;
+  for (int k = 0; k < 3; ++k)
+    if (!(g.aabb[3 + k] > g.aabb[k])) return NSAMD_ERR_INVALID_ARG;
+  return NSAMD_OK;
+}
+
+}  // namespace nsamd
+
+using namespace nsamd;
+
+extern "C" int nsamd_occgrid_march_count(const float* origins, const float* directions, const float* t_min,
+                                         const float* t_max, int64_t num_rays, float near_plane, float far_plane,
+                                         nsamd_occgrid grid, float step_size, float cone_angle, const float* jitter,
+                                         int32_t* counts, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && step_size > 0.0f && cone_angle >= 0.0f);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(origins && directions && counts);
+  const int st = check_grid_desc(grid);
+  if (st) return st;
+  const int64_t nb = (num_rays + kPackThreads - 1) / kPackThreads;
+  if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
+  occgrid_march_kernel<false><<<(unsigned)nb, kPackThreads, 0, (hipStream_t)stream>>>(
+      origins, directions, t_min, t_max, num_rays, near_plane, far_plane, grid, step_size, cone_angle, jitter, counts,
+      nullptr, nullptr, nullptr, nullptr);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_occgrid_march_write(const float* origins, const float* directions, const float* t_min,
+                                         const float* t_max, int64_t num_rays, float near_plane, float far_plane,
+                                         nsamd_occgrid grid, float step_size, float cone_angle, const float* jitter,
+                                         const int64_t* packed_info, int64_t* ray_indices, float* t_starts, float* t_ends,
+                                         nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && step_size > 0.0f && cone_angle >= 0.0f);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(origins && directions && packed_info && ray_indices && t_starts && t_ends);
+  const int st = check_grid_desc(grid);
+  if (st) return st;
+  const int64_t nb = (num_rays + kPackThreads - 1) / kPackThreads;
+  if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
+  occgrid_march_kernel<true><<<(unsigned)nb, kPackThreads, 0, (hipStream_t)stream>>>(
+      origins, directions, t_min, t_max, num_rays, near_plane, far_plane, grid, step_size, cone_angle, jitter, nullptr,
+      packed_info, ray_indices, t_starts, t_ends);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_packed_info(const int32_t* counts, int64_t num_rays, int64_t* packed_info, int64_t* total,
+                                 nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && total != nullptr);
+  NSAMD_REQUIRE(num_rays == 0 || (counts && packed_info));
+  packed_info_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(counts, num_rays, packed_info, total);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_packed_weights_fwd(const float* t_starts, const float* t_ends, const float* sigmas,
+                                        const int64_t* packed_info, int64_t num_rays, float* weights, float* transmittance,
+                                        nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(t_starts && t_ends && sigmas && packed_info && weights);
+  packed_weights_kernel<false><<<pack_ray_blocks(num_rays), kPackThreads, 0, (hipStream_t)stream>>>(
+      t_starts, t_ends, sigmas, packed_info, num_rays, 0.0f, 0.0f, weights, transmittance, nullptr, nullptr);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_packed_weights_bwd(const float* t_starts, const float* t_ends, const float* sigmas,
+                                        const float* dweights, const int64_t* packed_info, int64_t num_rays,
+                                        float* dsigmas, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(t_starts && t_ends && sigmas && dweights && packed_info && dsigmas);
+  packed_weights_bwd_kernel<<<pack_ray_blocks(num_rays), kPackThreads, 0, (hipStream_t)stream>>>(
+      t_starts, t_ends, sigmas, dweights, packed_info, num_rays, dsigmas);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_packed_visibility(const float* t_starts, const float* t_ends, const float* sigmas,
+                                       const int64_t* packed_info, int64_t num_rays, float early_stop_eps,
+                                       float alpha_thre, uint8_t* mask, int32_t* kept_counts, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(t_starts && t_ends && sigmas && packed_info && mask && kept_counts);
+  packed_weights_kernel<true><<<pack_ray_blocks(num_rays), kPackThreads, 0, (hipStream_t)stream>>>(
+      t_starts, t_ends, sigmas, packed_info, num_rays, early_stop_eps, alpha_thre, nullptr, nullptr, mask, kept_counts);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_packed_compact(const uint8_t* mask, const int64_t* packed_info_old, const int64_t* packed_info_new,
+                                    int64_t num_rays, const float* t_starts, const float* t_ends, int64_t* ray_indices_out,
+                                    float* t_starts_out, float* t_ends_out, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(mask && packed_info_old && packed_info_new && t_starts && t_ends && ray_indices_out && t_starts_out &&
+                t_ends_out);
+  packed_compact_kernel<<<pack_ray_blocks(num_rays), kPackThreads, 0, (hipStream_t)stream>>>(
+      mask, packed_info_old, packed_info_new, num_rays, t_starts, t_ends, ray_indices_out, t_starts_out, t_ends_out);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_packed_composite_fwd(const float* rgb, const float* weights, const float* t_starts,
+                                          const float* t_ends, const int64_t* packed_info, int64_t num_rays,
+                                          int background_mode, const float* background_rgb_host, int eval_mode,
+                                          float* out_rgb, float* out_accumulation, float* out_depth,
+                                          nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && (background_mode == 0 || background_mode == 1));
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(rgb && weights && packed_info && out_rgb && out_accumulation);
+  NSAMD_REQUIRE(background_mode == 0 || background_rgb_host != nullptr);
+  NSAMD_REQUIRE(out_depth == nullptr || (t_starts && t_ends));
+  const float b0 = background_mode ? background_rgb_host[0] : 0.f, b1 = background_mode ? background_rgb_host[1] : 0.f,
+              b2 = background_mode ? background_rgb_host[2] : 0.f;
+  packed_composite_fwd_kernel<<<pack_ray_blocks(num_rays), kPackThreads, 0, (hipStream_t)stream>>>(
+      rgb, weights, out_depth ? t_starts : nullptr, t_ends, packed_info, num_rays, background_mode, b0, b1, b2, eval_mode,
+      out_rgb, out_accumulation, out_depth);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_packed_composite_bwd(const float* rgb, const float* weights, const int64_t* ray_indices,
+                                          int64_t num_samples, int background_mode, const float* background_rgb_host,
+                                          const float* g_rgb, const float* g_accumulation, float* d_rgb, float* d_weights,
+                                          nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_samples >= 0 && (background_mode == 0 || background_mode == 1));
+  if (num_samples == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(rgb && weights && ray_indices && g_rgb && d_weights);
+  NSAMD_REQUIRE(background_mode == 0 || background_rgb_host != nullptr);
+  const float b0 = background_mode ? background_rgb_host[0] : 0.f, b1 = background_mode ? background_rgb_host[1] : 0.f,
+              b2 = background_mode ? background_rgb_host[2] : 0.f;
+  const int64_t nb = (num_samples + 255) / 256;
+  if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
+  packed_composite_bwd_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(rgb, weights, ray_indices, num_samples,
+                                                                            background_mode, b0, b1, b2, g_rgb,
+                                                                            g_accumulation, d_rgb, d_weights);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_packed_positions(const float* origins, const float* directions, const int64_t* ray_indices,
+                                      const float* t_starts, const float* t_ends, int64_t num_samples, float* positions,
+                                      nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_samples >= 0);
+  if (num_samples == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(origins && directions && ray_indices && t_starts && t_ends && positions);
+  const int64_t nb = (num_samples + 255) / 256;
+  if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
+  packed_positions_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(origins, directions, ray_indices, t_starts,
+                                                                        t_ends, num_samples, positions);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}

@@ -784,3 +784,172 @@ def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor
     N.check(N.load().nsamd_adam_step(N.ptr(params), N.ptr(grads), N.ptr(exp_avg), N.ptr(exp_avg_sq), params.numel(),
                                      float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
                                      float(grad_scale), N.ptr(hyper_dev), N.stream()), "adam_step")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a21 / f4  packed-sample path of instant-ngp (csrc/packed.hip): occupancy-grid marching, packed transmittance scan with
+# early termination, compaction, packed compositing            (ray_samplers.py:385-519, models/instant_ngp.py:172-217)
+# ---------------------------------------------------------------------------------------------------------------
+def _occgrid_native(binaries: Tensor, roi_aabb: Sequence[float]) -> N.OccGrid:
+    g = N.OccGrid()
+    g.binaries = N.ptr(binaries)
+    g.levels, g.resolution = int(binaries.shape[0]), int(binaries.shape[1])
+    for i, v in enumerate(roi_aabb):
+        g.aabb[i] = float(v)
+    return g
+
+
+@torch.no_grad()
+def packed_info_from_counts(counts: Tensor) -> Tuple[Tensor, int]:
+    """nerfacc.pack_info from per-ray counts (int32 `[N]`) -> (`[N,2]` int64 (start, count), total). The total is read
+    back to the host (the packed arrays are allocated to size, as nerfacc does)."""
+    N.require_cuda(counts)
+    n = counts.shape[0]
+    info = torch.empty((n, 2), device=counts.device, dtype=torch.int64)
+    total = torch.zeros((1,), device=counts.device, dtype=torch.int64)
+    N.check(N.load().nsamd_packed_info(N.ptr(counts), n, N.ptr(info), N.ptr(total), N.stream()), "packed_info")
+    return info, int(total.item())
+
+
+@torch.no_grad()
+def occgrid_march(origins: Tensor, directions: Tensor, binaries: Tensor, roi_aabb: Sequence[float], step_size: float,
+                  near_plane: float = 0.0, far_plane: float = 1e10, t_min: Optional[Tensor] = None,
+                  t_max: Optional[Tensor] = None, cone_angle: float = 0.0, jitter: Optional[Tensor] = None):
+    """Ray marching through a multi-level occupancy grid (`binaries [levels,R,R,R]` uint8) -> (ray_indices int64 `[n]`,
+    t_starts, t_ends fp32 `[n]`, packed_info `[N,2]`). Count pass, prefix, write pass."""
+    N.require_cuda(origins, directions, binaries)
+    o, d = _f32c(origins), _f32c(directions)
+    assert binaries.dtype == torch.uint8 and binaries.is_contiguous() and binaries.dim() == 4
+    n = o.shape[0]
+    dev = o.device
+    grid = _occgrid_native(binaries, roi_aabb)
+    tmin = None if t_min is None else _f32c(t_min.reshape(-1))
+    tmax = None if t_max is None else _f32c(t_max.reshape(-1))
+    jit = None if jitter is None else _f32c(jitter.reshape(-1))
+    counts = torch.empty((n,), device=dev, dtype=torch.int32)
+    lib = N.load()
+    far = min(float(far_plane), 3.0e38)
+    N.check(lib.nsamd_occgrid_march_count(N.ptr(o), N.ptr(d), N.ptr(tmin), N.ptr(tmax), n, float(near_plane), far, grid,
+                                          float(step_size), float(cone_angle), N.ptr(jit), N.ptr(counts), N.stream()),
+            "occgrid_march_count")
+    info, total = packed_info_from_counts(counts)
+    ray_indices = torch.empty((total,), device=dev, dtype=torch.int64)
+    t_starts = torch.empty((total,), device=dev, dtype=torch.float32)
+    t_ends = torch.empty((total,), device=dev, dtype=torch.float32)
+    if total:
+        N.check(lib.nsamd_occgrid_march_write(N.ptr(o), N.ptr(d), N.ptr(tmin), N.ptr(tmax), n, float(near_plane), far, grid,
+                                              float(step_size), float(cone_angle), N.ptr(jit), N.ptr(info),
+                                              N.ptr(ray_indices), N.ptr(t_starts), N.ptr(t_ends), N.stream()),
+                "occgrid_march_write")
+    return ray_indices, t_starts, t_ends, info
+
+
+@torch.no_grad()
+def packed_positions(origins: Tensor, directions: Tensor, ray_indices: Tensor, t_starts: Tensor, t_ends: Tensor) -> Tensor:
+    """o[ray] + d[ray] (t_start + t_end) / 2 for packed samples -> `[n,3]`."""
+    N.require_cuda(origins, directions, ray_indices, t_starts, t_ends)
+    out = torch.empty((ray_indices.shape[0], 3), device=origins.device, dtype=torch.float32)
+    N.check(N.load().nsamd_packed_positions(N.ptr(_f32c(origins)), N.ptr(_f32c(directions)), N.ptr(ray_indices),
+                                            N.ptr(t_starts), N.ptr(t_ends), ray_indices.shape[0], N.ptr(out), N.stream()),
+            "packed_positions")
+    return out
+
+
+@torch.no_grad()
+def packed_visibility_compact(ray_indices: Tensor, t_starts: Tensor, t_ends: Tensor, sigmas: Tensor, packed_info: Tensor,
+                              early_stop_eps: float = 1e-4, alpha_thre: float = 0.0):
+    """nerfacc.render_visibility_from_density + masking (OccGridEstimator.sampling): keep the samples whose transmittance
+    is still >= early_stop_eps and whose alpha reaches alpha_thre -> (ray_indices, t_starts, t_ends, packed_info, mask)."""
+    N.require_cuda(ray_indices, t_starts, t_ends, sigmas, packed_info)
+    n_rays = packed_info.shape[0]
+    dev = t_starts.device
+    mask = torch.empty((t_starts.shape[0],), device=dev, dtype=torch.uint8)
+    kept = torch.empty((n_rays,), device=dev, dtype=torch.int32)
+    lib = N.load()
+    N.check(lib.nsamd_packed_visibility(N.ptr(t_starts), N.ptr(t_ends), N.ptr(_f32c(sigmas)), N.ptr(packed_info), n_rays,
+                                        float(early_stop_eps), float(alpha_thre), N.ptr(mask), N.ptr(kept), N.stream()),
+            "packed_visibility")
+    info2, total = packed_info_from_counts(kept)
+    ri = torch.empty((total,), device=dev, dtype=torch.int64)
+    ts = torch.empty((total,), device=dev, dtype=torch.float32)
+    te = torch.empty((total,), device=dev, dtype=torch.float32)
+    if total:
+        N.check(lib.nsamd_packed_compact(N.ptr(mask), N.ptr(packed_info), N.ptr(info2), n_rays, N.ptr(t_starts), N.ptr(t_ends),
+                                         N.ptr(ri), N.ptr(ts), N.ptr(te), N.stream()), "packed_compact")
+    return ri, ts, te, info2, mask
+
+
+class _PackedWeightsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sigmas: Tensor, t_starts: Tensor, t_ends: Tensor, packed_info: Tensor):
+        N.require_cuda(sigmas, t_starts, t_ends, packed_info)
+        sigmas = _f32c(sigmas)
+        w = torch.empty_like(sigmas)
+        N.check(N.load().nsamd_packed_weights_fwd(N.ptr(t_starts), N.ptr(t_ends), N.ptr(sigmas), N.ptr(packed_info),
+                                                  packed_info.shape[0], N.ptr(w), None, N.stream()), "packed_weights_fwd")
+        ctx.save_for_backward(sigmas, t_starts, t_ends, packed_info)
+        return w
+
+    @staticmethod
+    def backward(ctx, gw: Tensor):
+        sigmas, t_starts, t_ends, info = ctx.saved_tensors
+        ds = torch.empty_like(sigmas)
+        N.check(N.load().nsamd_packed_weights_bwd(N.ptr(t_starts), N.ptr(t_ends), N.ptr(sigmas), N.ptr(_f32c(gw)), N.ptr(info),
+                                                  info.shape[0], N.ptr(ds), N.stream()), "packed_weights_bwd")
+        return ds, None, None, None
+
+
+def packed_weights(sigmas: Tensor, t_starts: Tensor, t_ends: Tensor, packed_info: Tensor) -> Tensor:
+    """nerfacc.render_weight_from_density(...)[0] on packed samples `[n]` (differentiable w.r.t. sigmas)."""
+    return _PackedWeightsFn.apply(sigmas, t_starts, t_ends, packed_info)
+
+
+def _packed_bg(background) -> Tuple[int, Optional[object]]:
+    if isinstance(background, str):
+        if background == "last_sample":
+            raise NotImplementedError("Background color 'last_sample' not implemented for packed samples.")  # renderers.py:95-96
+        if background == "random":
+            return 0, None
+        vals = {"white": (1.0, 1.0, 1.0), "black": (0.0, 0.0, 0.0)}[background]
+    else:
+        vals = tuple(float(v) for v in background.reshape(-1)[:3].tolist())
+    return 1, (C.c_float * 3)(*vals)
+
+
+class _PackedCompositeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb: Tensor, weights: Tensor, ray_indices: Tensor, packed_info: Tensor, t_starts, t_ends, bg_mode: int,
+                bg_vals, eval_mode: bool):
+        N.require_cuda(rgb, weights, ray_indices, packed_info)
+        rgb, weights = _f32c(rgb), _f32c(weights)
+        n_rays = packed_info.shape[0]
+        dev = rgb.device
+        out = torch.empty((n_rays, 3), device=dev, dtype=torch.float32)
+        acc = torch.empty((n_rays,), device=dev, dtype=torch.float32)
+        depth = torch.empty((n_rays,), device=dev, dtype=torch.float32) if t_starts is not None else None
+        N.check(N.load().nsamd_packed_composite_fwd(N.ptr(rgb), N.ptr(weights), N.ptr(t_starts), N.ptr(t_ends),
+                                                    N.ptr(packed_info), n_rays, bg_mode, bg_vals, 1 if eval_mode else 0,
+                                                    N.ptr(out), N.ptr(acc), N.ptr(depth), N.stream()), "packed_composite_fwd")
+        ctx.save_for_backward(rgb, weights, ray_indices)
+        ctx.bg = (bg_mode, bg_vals)
+        ctx.mark_non_differentiable(*([depth] if depth is not None else []))
+        return out, acc, depth
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_acc, _g_depth):
+        rgb, weights, ray_indices = ctx.saved_tensors
+        n = weights.shape[0]
+        d_rgb = torch.empty_like(rgb) if ctx.needs_input_grad[0] else None
+        d_w = torch.empty_like(weights)
+        g_rgb = _f32c(g_rgb) if g_rgb is not None else torch.zeros((int(ray_indices.max()) + 1 if n else 0, 3), device=rgb.device)
+        N.check(N.load().nsamd_packed_composite_bwd(N.ptr(rgb), N.ptr(weights), N.ptr(ray_indices), n, ctx.bg[0], ctx.bg[1],
+                                                    N.ptr(g_rgb), N.ptr(_f32c(g_acc) if g_acc is not None else None),
+                                                    N.ptr(d_rgb), N.ptr(d_w), N.stream()), "packed_composite_bwd")
+        return d_rgb, d_w, None, None, None, None, None, None, None
+
+
+def packed_composite(rgb: Tensor, weights: Tensor, ray_indices: Tensor, packed_info: Tensor, t_starts: Optional[Tensor] = None,
+                     t_ends: Optional[Tensor] = None, background="random", eval_mode: bool = False):
+    """accumulate_along_rays compositing of packed samples -> (rgb `[N,3]`, accumulation `[N]`, depth `[N]` or None)."""
+    mode, vals = _packed_bg(background)
+    return _PackedCompositeFn.apply(rgb, weights, ray_indices, packed_info, t_starts, t_ends, mode, vals, bool(eval_mode))

@@ -1,0 +1,129 @@
+"""instant-ngp on the MI355X kernels: the wiring of the reference's NGPModel (nerfstudio/models/instant_ngp.py:40-262)
+over this package's modules — NerfactoField (hash grid + fused MLPs), the occupancy-grid VolumetricSampler, packed
+weights (transmittance scan) and the packed renderer branches (BASELINE configs[3]).
+
+What nerfacc provides to the reference (OccGridEstimator, pack_info, render_weight_from_density, accumulate_along_rays)
+is csrc/packed.hip here; see model_components/occupancy.py for what is and is not pinned.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Literal, Optional
+
+import torch
+from torch import Tensor, nn
+from torch.nn import Parameter
+
+from . import functional as F
+from .cameras.rays import RayBundle
+from .field_components.field_heads import FieldHeadNames
+from .field_components.spatial_distortions import SceneContraction
+from .fields.nerfacto_field import NerfactoField
+from .model_components.losses import MSELoss
+from .model_components.occupancy import OccGridEstimator
+from .model_components.ray_samplers import VolumetricSampler
+from .model_components.renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
+
+
+@dataclass
+class InstantNGPModelConfig:
+    """models/instant_ngp.py:40-80."""
+
+    grid_resolution: int = 128
+    grid_levels: int = 4
+    max_res: int = 2048
+    log2_hashmap_size: int = 19
+    alpha_thre: float = 0.01
+    cone_angle: float = 0.004
+    render_step_size: Optional[float] = None
+    near_plane: float = 0.05
+    far_plane: float = 1e3
+    use_appearance_embedding: bool = False
+    background_color: Literal["random", "black", "white"] = "random"
+    disable_scene_contraction: bool = False
+    eval_num_rays_per_chunk: int = 8192
+
+
+class NGPModel(nn.Module):
+    """Instant NGP model (models/instant_ngp.py:83-262). `forward(ray_bundle)` = get_outputs (no collider)."""
+
+    def __init__(self, config: InstantNGPModelConfig, aabb: Tensor, num_train_data: int) -> None:
+        super().__init__()
+        self.config = config
+        self.register_buffer("aabb", aabb.float())
+        self.num_train_data = num_train_data
+        self.populate_modules()
+
+    def populate_modules(self) -> None:
+        c = self.config
+        contraction = None if c.disable_scene_contraction else SceneContraction(order=float("inf"))
+        self.field = NerfactoField(
+            aabb=self.aabb,
+            # (sic) models/instant_ngp.py:104: the embedding is 32 wide when use_appearance_embedding is FALSE, as upstream
+            appearance_embedding_dim=0 if c.use_appearance_embedding else 32,
+            num_images=self.num_train_data, log2_hashmap_size=c.log2_hashmap_size, max_res=c.max_res,
+            spatial_distortion=contraction)
+        self.scene_aabb = Parameter(self.aabb.flatten(), requires_grad=False)
+        if c.render_step_size is None:
+            # auto step size: ~1000 samples in the base level grid (models/instant_ngp.py:113-115)
+            c.render_step_size = float(((self.scene_aabb[3:] - self.scene_aabb[:3]) ** 2).sum().sqrt().item() / 1000)
+        self.occupancy_grid = OccGridEstimator(roi_aabb=self.scene_aabb, resolution=c.grid_resolution, levels=c.grid_levels)
+        self.sampler = VolumetricSampler(occupancy_grid=self.occupancy_grid, density_fn=self.field.density_fn)
+        self.renderer_rgb = RGBRenderer(background_color=c.background_color)
+        self.renderer_accumulation = AccumulationRenderer()
+        self.renderer_depth = DepthRenderer(method="expected")
+        self.rgb_loss = MSELoss()
+
+    def update_occupancy_grid(self, step: int) -> None:
+        """BEFORE_TRAIN_ITERATION callback (models/instant_ngp.py:150-163)."""
+        self.occupancy_grid.update_every_n_steps(
+            step=step, occ_eval_fn=lambda x: self.field.density_fn(x) * float(self.config.render_step_size))
+
+    def get_param_groups(self) -> Dict[str, List[Parameter]]:
+        return {"fields": list(self.field.parameters())}
+
+    def forward(self, ray_bundle: RayBundle, jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        return self.get_outputs(ray_bundle, jitter)
+
+    def get_outputs(self, ray_bundle: RayBundle, jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        c = self.config
+        num_rays = len(ray_bundle)
+        with torch.no_grad():
+            ray_samples, ray_indices = self.sampler(ray_bundle=ray_bundle, near_plane=c.near_plane, far_plane=c.far_plane,
+                                                    render_step_size=c.render_step_size, alpha_thre=c.alpha_thre,
+                                                    cone_angle=c.cone_angle, jitter=jitter)
+        field_outputs = self.field(ray_samples)
+        # accumulation (models/instant_ngp.py:191-199): nerfacc.pack_info + render_weight_from_density
+        counts = torch.bincount(ray_indices, minlength=num_rays).to(torch.int32)
+        packed_info, _ = F.packed_info_from_counts(counts)
+        starts, ends = ray_samples.frustums.starts[..., 0].contiguous(), ray_samples.frustums.ends[..., 0].contiguous()
+        weights = F.packed_weights(field_outputs[FieldHeadNames.DENSITY][..., 0], starts, ends, packed_info)[..., None]
+        rgb = self.renderer_rgb(rgb=field_outputs[FieldHeadNames.RGB], weights=weights, ray_indices=ray_indices,
+                                num_rays=num_rays)
+        depth = self.renderer_depth(weights=weights, ray_samples=ray_samples, ray_indices=ray_indices, num_rays=num_rays)
+        accumulation = self.renderer_accumulation(weights=weights, ray_indices=ray_indices, num_rays=num_rays)
+        return {"rgb": rgb, "accumulation": accumulation, "depth": depth, "num_samples_per_ray": packed_info[:, 1]}
+
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, Tensor]:
+        image = self.renderer_rgb.blend_background(batch["image"].to(outputs["rgb"].device))
+        mse = torch.mean((outputs["rgb"].detach() - image) ** 2)
+        return {"psnr": -10.0 * torch.log10(mse), "num_samples_per_batch": outputs["num_samples_per_ray"].sum()}
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
+        image = batch["image"].to(outputs["rgb"].device)
+        pred_rgb, image = self.renderer_rgb.blend_background_for_loss_computation(
+            pred_image=outputs["rgb"], pred_accumulation=outputs["accumulation"], gt_image=image)
+        return {"rgb_loss": self.rgb_loss(image, pred_rgb)}
+
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """Chunked full-image render (models/base_model.py:178-205)."""
+        image_shape = camera_ray_bundle.origins.shape[:-1]
+        num_rays = len(camera_ray_bundle)
+        outs: Dict[str, List[Tensor]] = {}
+        for i in range(0, num_rays, self.config.eval_num_rays_per_chunk):
+            rb = camera_ray_bundle.get_row_major_sliced_ray_bundle(i, i + self.config.eval_num_rays_per_chunk)
+            for k, v in self.forward(rb).items():
+                if torch.is_tensor(v):
+                    outs.setdefault(k, []).append(v)
+        return {k: torch.cat(v).view(*image_shape, -1) for k, v in outs.items()}

@@ -204,3 +204,58 @@ class ProposalNetworkSampler(Sampler):
                 and owner.__class__.__module__.startswith("nerfstudio_amd."):
             return owner.get_density(ray_samples)[0]
         return density_fn(ray_samples.frustums.get_positions())
+
+
+class VolumetricSampler(Sampler):
+    """Sampler of the instant-ngp path (ray_samplers.py:385-519): samples along a ray by marching through the occupancy
+    grid; in training the candidates are thinned by the field's own density (transmittance-ordered early termination,
+    alpha threshold). Fuses generation and density check: call forward() directly. Returns PACKED samples."""
+
+    def __init__(self, occupancy_grid, density_fn: Optional[Callable] = None) -> None:
+        super().__init__()
+        assert occupancy_grid is not None
+        self.density_fn = density_fn
+        self.occupancy_grid = occupancy_grid
+
+    def get_sigma_fn(self, origins: Tensor, directions: Tensor, times=None) -> Optional[Callable]:
+        if self.density_fn is None or not self.training:
+            return None
+        density_fn = self.density_fn
+
+        def sigma_fn(t_starts, t_ends, ray_indices):
+            positions = F.packed_positions(origins, directions, ray_indices, t_starts, t_ends)  # ray_samplers.py:424-426
+            return density_fn(positions).squeeze(-1)
+
+        return sigma_fn
+
+    def generate_ray_samples(self) -> RaySamples:
+        raise RuntimeError(
+            "The VolumetricSampler fuses sample generation and density check together. Please call forward() directly.")
+
+    def forward(self, ray_bundle, render_step_size: float, near_plane: float = 0.0, far_plane: Optional[float] = None,
+                alpha_thre: float = 0.01, cone_angle: float = 0.0, jitter: Optional[Tensor] = None):
+        """-> (ray_samples, ray_indices): packed samples `[n]` and the ray each belongs to (ray_samplers.py:437-519)."""
+        from ..cameras.rays import Frustums
+
+        rays_o, rays_d = ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous()
+        if ray_bundle.nears is not None and ray_bundle.fars is not None:
+            t_min, t_max = ray_bundle.nears.contiguous().reshape(-1), ray_bundle.fars.contiguous().reshape(-1)
+        else:
+            t_min = t_max = None
+        if far_plane is None:
+            far_plane = 1e10
+        ray_indices, starts, ends = self.occupancy_grid.sampling(
+            rays_o=rays_o, rays_d=rays_d, t_min=t_min, t_max=t_max, sigma_fn=self.get_sigma_fn(rays_o, rays_d),
+            render_step_size=render_step_size, near_plane=near_plane, far_plane=far_plane, stratified=self.training,
+            cone_angle=cone_angle, alpha_thre=alpha_thre, jitter=jitter)
+        if starts.shape[0] == 0:
+            # a single fake sample (ray 0, [1, 1]) keeps every downstream shape valid (ray_samplers.py:494-500)
+            ray_indices = torch.zeros((1,), dtype=torch.long, device=rays_o.device)
+            starts = torch.ones((1,), dtype=torch.float32, device=rays_o.device)
+            ends = torch.ones((1,), dtype=torch.float32, device=rays_o.device)
+        cams = ray_bundle.camera_indices
+        ray_samples = RaySamples(
+            frustums=Frustums(origins=rays_o[ray_indices], directions=rays_d[ray_indices], starts=starts[..., None],
+                              ends=ends[..., None], pixel_area=ray_bundle.pixel_area[ray_indices]),
+            camera_indices=None if cams is None else cams.contiguous()[ray_indices])
+        return ray_samples, ray_indices

@@ -11,11 +11,15 @@ from ..cameras.rays import RaySamples, t_bins_of
 BackgroundColor = Union[Literal["random", "last_sample", "black", "white"], Tensor]
 
 
-def _no_packed(ray_indices, num_rays) -> None:
-    if ray_indices is not None and num_rays is not None:
-        raise NotImplementedError(
-            "packed samples (ray_indices / num_rays; the instant-ngp path through nerfacc) are not built yet "
-            "(SURVEY.md §8 f4)")
+def _packed(ray_indices, num_rays) -> bool:
+    """Packed samples from the VolumetricSampler (renderers.py:93, 310, 369): `[n, ...]` samples + the ray of each."""
+    return ray_indices is not None and num_rays is not None
+
+
+def _packed_info(ray_indices: Tensor, num_rays: int) -> Tensor:
+    """nerfacc.pack_info: `[num_rays, 2]` (start, count); samples of a ray are contiguous, rays in increasing order."""
+    counts = torch.bincount(ray_indices, minlength=num_rays).to(torch.int32)
+    return F.packed_info_from_counts(counts)[0]
 
 
 class RGBRenderer(nn.Module):
@@ -32,17 +36,26 @@ class RGBRenderer(nn.Module):
         for "last_sample" / "white" / "black" / an RGB tensor; "random" adds nothing (as if the background were black —
         the random colour is blended in blend_background_for_loss_computation). No nan_to_num / clamp (that is
         forward()'s eval branch). rgb `[*bs,S,3]`, weights `[*bs,S,1]` -> `[*bs,3]`."""
-        _no_packed(ray_indices, num_rays)
+        if _packed(ray_indices, num_rays):
+            if isinstance(background_color, str) and background_color == "last_sample":
+                raise NotImplementedError("Background color 'last_sample' not implemented for packed samples.")
+            return F.packed_composite(rgb, weights[..., 0], ray_indices, _packed_info(ray_indices, num_rays), None, None,
+                                      background_color)[0]
         shape, s = rgb.shape[:-2], rgb.shape[-2]
         out, _, _ = F.composite(rgb.reshape(-1, s, 3), weights.reshape(-1, s), None, background_color, expected_depth=False)
         return out.view(*shape, 3)
 
     def forward(self, rgb: Tensor, weights: Tensor, ray_indices: Optional[Tensor] = None,
                 num_rays: Optional[int] = None, background_color: Optional[BackgroundColor] = None) -> Tensor:
-        """rgb `[*bs,S,3]`, weights `[*bs,S,1]` -> `[*bs,3]` (renderers.py:201-232)."""
-        _no_packed(ray_indices, num_rays)
+        """rgb `[*bs,S,3]`, weights `[*bs,S,1]` -> `[*bs,3]` (renderers.py:201-232); packed: rgb `[n,3]`, weights `[n,1]`."""
         if background_color is None:
             background_color = self.background_color
+        if _packed(ray_indices, num_rays):
+            if self.training:
+                return self.combine_rgb(rgb, weights, background_color, ray_indices, num_rays)
+            with torch.no_grad():  # eval: nan_to_num on the samples, clamp the result (renderers.py:225-231)
+                return F.packed_composite(rgb, weights[..., 0], ray_indices, _packed_info(ray_indices, num_rays), None, None,
+                                          background_color, eval_mode=True)[0]
         shape = rgb.shape[:-2]
         s = rgb.shape[-2]
         rgb2, w2 = rgb.reshape(-1, s, 3), weights.reshape(-1, s)
@@ -90,7 +103,9 @@ class AccumulationRenderer(nn.Module):
 
     @classmethod
     def forward(cls, weights: Tensor, ray_indices: Optional[Tensor] = None, num_rays: Optional[int] = None) -> Tensor:
-        _no_packed(ray_indices, num_rays)
+        if _packed(ray_indices, num_rays):  # accumulate_along_rays(weights, None) (renderers.py:310-314)
+            zero = torch.zeros((weights.shape[0], 3), device=weights.device)
+            return F.packed_composite(zero, weights[..., 0], ray_indices, _packed_info(ray_indices, num_rays))[1][:, None]
         shape = weights.shape[:-2]
         s = weights.shape[-2]
         w2 = weights.reshape(-1, s)
@@ -114,7 +129,14 @@ class DepthRenderer(nn.Module):
 
     def forward(self, weights: Tensor, ray_samples: RaySamples, ray_indices: Optional[Tensor] = None,
                 num_rays: Optional[int] = None) -> Tensor:
-        _no_packed(ray_indices, num_rays)
+        if _packed(ray_indices, num_rays):
+            if self.method != "expected":
+                raise NotImplementedError("packed samples support DepthRenderer('expected') (renderers.py:365-383)")
+            starts, ends = ray_samples.frustums.starts[..., 0].contiguous(), ray_samples.frustums.ends[..., 0].contiguous()
+            zero = torch.zeros((weights.shape[0], 3), device=weights.device)
+            depth = F.packed_composite(zero, weights[..., 0], ray_indices, _packed_info(ray_indices, num_rays), starts, ends)[2]
+            steps = (starts + ends) / 2
+            return torch.clip(depth, steps.min(), steps.max())[:, None]
         shape = weights.shape[:-2]
         s = weights.shape[-2]
         w2 = weights.reshape(-1, s)

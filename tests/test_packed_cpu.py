@@ -1,0 +1,150 @@
+"""CPU tests of the instant-ngp packed path: properties of the marcher restatement (oracle/packed_oracle.py — parity with
+nerfacc's own sample placement is unpinned, see that module), the grid bookkeeping of OccGridEstimator, and the host
+contract of the mirror classes (error behaviour of the reference: ray_samplers.py:431-435, renderers.py:95-96, 370-371)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import packed_oracle as po
+
+ROI = [-1.0, -1.0, -1.0, 1.0, 1.0, 1.0]
+
+
+def _rays(n, seed, scale=0.4):
+    rs = np.random.RandomState(seed)
+    o = (rs.standard_normal((n, 3)) * scale).astype(np.float32)
+    d = rs.standard_normal((n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d
+
+
+def test_marcher_full_grid_tiles_the_ray_and_empty_grid_yields_nothing():
+    o, d = _rays(7, 0)
+    o = np.clip(o, -0.8, 0.8)  # inside the box
+    full = np.ones((1, 8, 8, 8), bool)
+    idx, ts, te = po.occgrid_march(o, d, full, ROI, 0.05, near_plane=0.1, far_plane=100.0)
+    assert len(idx) > 0 and (np.diff(idx) >= 0).all()  # packed: rays in increasing order
+    for r in range(7):
+        s, e = ts[idx == r], te[idx == r]
+        assert len(s) > 0 and abs(float(s[0]) - 0.1) < 1e-6  # origins are inside the box: marching starts at the near plane
+        np.testing.assert_allclose(e - s, 0.05, atol=1e-6)    # uniform steps (cone_angle 0)
+        np.testing.assert_array_equal(s[1:], e[:-1])          # contiguous: every step of a full grid is kept
+        mid_last = o[r] + d[r] * (s[-1] + e[-1]) / 2
+        assert np.abs(mid_last).max() <= 1.0 + 1e-5           # the last kept midpoint is still inside the box
+    idx0, _, _ = po.occgrid_march(o, d, np.zeros((1, 8, 8, 8), bool), ROI, 0.05)
+    assert len(idx0) == 0
+
+
+def test_marcher_keeps_exactly_the_steps_whose_midpoint_cell_is_occupied():
+    rs = np.random.RandomState(3)
+    B = rs.rand(3, 8, 8, 8) > 0.7  # three levels: boxes [-1,1], [-2,2], [-4,4]
+    o, d = _rays(9, 4, scale=1.5)
+    jit = rs.uniform(0, 1, 9).astype(np.float32)
+    step = 0.07
+    idx, ts, te = po.occgrid_march(o, d, B, ROI, step, near_plane=0.05, far_plane=50.0, jitter=jit, cone_angle=0.01)
+    assert len(idx) > 20
+    mid = (ts + te) / 2
+    p = o[idx] + d[idx] * mid[:, None]
+    m = np.abs(p).max(axis=1)
+    level = np.where(m <= 1, 0, np.where(m <= 2, 1, 2))
+    assert (m <= 4 + 1e-4).all()
+    scale = (2.0 ** level)[:, None]
+    cell = np.clip(np.floor((p + scale) / (2 * scale) * 8).astype(int), 0, 7)
+    assert B[level, cell[:, 0], cell[:, 1], cell[:, 2]].all()       # every kept step sits in an occupied cell
+    np.testing.assert_allclose(te - ts, np.maximum(ts * 0.01, step), atol=4e-6)  # dt = clamp(t * cone_angle, step, .); ulp(t) noise
+    # the lattice of a ray starts at max(near, box entry) + jitter * step
+    first = np.array([ts[idx == r][0] if (idx == r).any() else np.nan for r in range(9)])
+    inside = np.abs(o).max(axis=1) <= 4
+    lattice0 = 0.05 + jit * step
+    k = (first[inside] - lattice0[inside]) / step
+    assert np.nanmax(np.abs(k - np.round(k))) < 0.35  # on the ray's own lattice (cone steps grow slowly: not exact)
+    # completeness on one ray: recompute its lattice independently and compare the kept set
+    r = int(np.argmax(np.bincount(idx, minlength=9)))
+    kept = []
+    t = np.float32(max(0.05, 0.0)) + jit[r] * np.float32(step)
+    for _ in range(100000):
+        dt = np.float32(max(float(np.float32(t * np.float32(0.01))), step))
+        q = o[r] + d[r] * np.float32(t + dt * np.float32(0.5))
+        mm = np.abs(q).max()
+        if mm > 4 or t >= 50:
+            if mm > 4 and t > 8:
+                break
+        else:
+            lv = 0 if mm <= 1 else (1 if mm <= 2 else 2)
+            c = np.clip(np.floor((q + 2.0**lv) / (2 * 2.0**lv) * 8).astype(int), 0, 7)
+            if B[lv, c[0], c[1], c[2]]:
+                kept.append(t)
+        t = np.float32(t + dt)
+    np.testing.assert_allclose(ts[idx == r], np.array(kept, np.float32), rtol=2e-6)
+
+
+def test_marcher_respects_t_min_t_max_and_axis_parallel_rays():
+    full = np.ones((1, 4, 4, 4), bool)
+    o = np.array([[0.0, 0.0, -3.0], [0.5, 2.0, 0.0], [0.2, 0.2, 0.2]], np.float32)
+    d = np.array([[0.0, 0.0, 1.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0]], np.float32)  # axis-parallel: 1 / 0 = inf slabs
+    idx, ts, te = po.occgrid_march(o, d, full, ROI, 0.1, near_plane=0.0, far_plane=10.0,
+                                   t_min=np.array([0.0, 0.0, 0.3], np.float32), t_max=np.array([9.0, 9.0, 0.55], np.float32))
+    assert (idx == 1).sum() == 0                                    # misses the box (y = 2 is outside a parallel slab)
+    s0 = ts[idx == 0]
+    assert abs(float(s0[0]) - 2.0) < 1e-6 and len(s0) == 20         # enters at t = 2, 2 units at 0.1
+    s2, e2 = ts[idx == 2], te[idx == 2]
+    assert abs(float(s2[0]) - 0.3) < 1e-6 and float(s2[-1]) < 0.55  # clipped to [t_min, t_max]
+
+
+def test_occupancy_grid_update_and_thresholds_on_cpu():
+    """The grid bookkeeping is plain torch (off the per-step path) and runs on CPU: EMA maximum, mean-capped threshold."""
+    from nerfstudio_amd.model_components.occupancy import OccGridEstimator
+
+    grid = OccGridEstimator(torch.tensor(ROI), resolution=8, levels=2).train()
+    assert grid.binaries.shape == (2, 8, 8, 8) and grid.occs.shape == (1024,)
+
+    def blob(x):  # dense near the origin
+        return torch.exp(-4.0 * (x * x).sum(-1, keepdim=True)) * 0.5
+
+    torch.manual_seed(0)
+    grid.update_every_n_steps(step=0, occ_eval_fn=blob, occ_thre=0.01)
+    assert np.array_equal(grid.binaries.numpy().astype(bool).reshape(-1), po.occgrid_thresholds(grid.occs.numpy(), 0.01))
+    b = grid.binaries.numpy().astype(bool)
+    assert b[0, 3:5, 3:5, 3:5].all() and not b[1, 0, 0, 0] and 0 < b.sum() < b.size
+    before = grid.occs.clone()
+    grid.update_every_n_steps(step=5, occ_eval_fn=blob)  # not a multiple of 16: nothing happens
+    assert torch.equal(before, grid.occs)
+    grid.update_every_n_steps(step=16, occ_eval_fn=lambda x: torch.zeros(x.shape[0], 1), ema_decay=0.5)
+    assert torch.allclose(grid.occs, before * 0.5)       # warm-up: every cell refreshed, occs = max(occs * decay, 0)
+    grid.update_every_n_steps(step=512, occ_eval_fn=lambda x: torch.zeros(x.shape[0], 1), ema_decay=0.5)
+    decayed = grid.occs < before * 0.5 - 1e-30
+    assert (grid.occs <= before * 0.5 + 1e-12).all() and 0 < int(decayed.sum()) < grid.occs.numel()  # after warm-up: a subset
+    assert np.array_equal(grid.binaries.numpy().astype(bool).reshape(-1), po.occgrid_thresholds(grid.occs.numpy(), 0.01))
+    grid.eval()
+    frozen = grid.occs.clone()
+    grid.update_every_n_steps(step=32, occ_eval_fn=blob)
+    assert torch.equal(frozen, grid.occs)                 # eval: no updates
+
+
+def test_packed_mirror_error_contract_and_cuda_guard():
+    from nerfstudio_amd.cameras.rays import Frustums, RayBundle, RaySamples
+    from nerfstudio_amd.instant_ngp import InstantNGPModelConfig, NGPModel
+    from nerfstudio_amd.model_components.renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
+
+    model = NGPModel(InstantNGPModelConfig(grid_resolution=8, grid_levels=2, log2_hashmap_size=8),
+                     torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_train_data=3)
+    assert abs(model.config.render_step_size - (12**0.5) / 1000) < 1e-9  # auto step: box diagonal / 1000
+    assert list(model.get_param_groups()) == ["fields"]
+    with pytest.raises(RuntimeError, match="call forward"):
+        model.sampler.generate_ray_samples()
+    n = 5
+    w = torch.rand(n, 1)
+    ri = torch.tensor([0, 0, 1, 3, 3])
+    with pytest.raises(NotImplementedError, match="last_sample"):
+        RGBRenderer("last_sample")(rgb=torch.rand(n, 3), weights=w, ray_indices=ri, num_rays=4)
+    fr = Frustums(origins=torch.zeros(n, 3), directions=torch.ones(n, 3), starts=torch.rand(n, 1), ends=torch.rand(n, 1) + 1,
+                  pixel_area=torch.ones(n, 1))
+    with pytest.raises(NotImplementedError):
+        DepthRenderer("median")(weights=w, ray_samples=RaySamples(frustums=fr), ray_indices=ri, num_rays=4)
+    # everything else gets as far as the kernels (no CPU fallback)
+    rb = RayBundle(origins=torch.zeros(4, 3), directions=torch.ones(4, 3) / 3**0.5, pixel_area=torch.ones(4, 1),
+                   camera_indices=torch.zeros(4, 1, dtype=torch.long))
+    for call in (lambda: model(rb), lambda: RGBRenderer("white")(rgb=torch.rand(n, 3), weights=w, ray_indices=ri, num_rays=4),
+                 lambda: AccumulationRenderer()(weights=w, ray_indices=ri, num_rays=4)):
+        with pytest.raises(RuntimeError, match="MI355X"):
+            call()
