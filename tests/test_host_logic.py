@@ -102,8 +102,11 @@ def test_ray_datastructures_shapes():
     t = torch.linspace(0, 1, s + 1)[None].expand(n, s + 1).contiguous()
     rs = samples_from_bins(rb, t, t * 2, None)
     assert rs.frustums.starts.shape == (n, s, 1) and rs.deltas.shape == (n, s, 1)
-    assert rs.frustums.origins.shape == (n, 1, 3) and rs.camera_indices.shape == (n, 1, 1)
-    assert tuple(rs.frustums.shape) == (n, s)
+    # TensorDataclass semantics of the reference (utils/tensor_dataclass.py:67-92): every field is broadcast to the batch
+    # shape — as zero-copy views (stride 0 along the sample axis), the dense per-ray arrays live in the pack
+    assert rs.frustums.origins.shape == (n, s, 3) and rs.camera_indices.shape == (n, s, 1)
+    assert rs.frustums.origins.stride(1) == 0 and rs.camera_indices.stride(1) == 0
+    assert tuple(rs.frustums.shape) == (n, s) == tuple(rs.shape) and rs.pack.origins.shape == (n, 3)
     assert rs.frustums.get_positions().shape == (n, s, 3)
     # Frustums.get_positions KAT of the reference's tests/cameras/test_rays.py:11-30
     fr = Frustums(origins=torch.ones(5, 3), directions=torch.ones(5, 3) * torch.tensor([0.0, 1.0, 0.0]),
