@@ -170,3 +170,69 @@ def test_psnr_on_procedural_scene_matches_oracle_training(F, golden):
         np.testing.assert_allclose(wm(got)[1:], wm(ref)[1:], rtol=0.10)
     ev = _events(F)
     assert ev[1] == 0 and ev[2] == 0, ev
+
+
+def test_unbounded_workload_training_step_vs_oracle(F):
+    """BASELINE configs[4] (mipnerf-360-style unbounded capture; bench.py --workload unbounded): cameras on a shell of radius
+    ~3 looking inward, so most samples fall in the contracted region ||x||_inf > 1. One training step of the explicit runner
+    against the CPU oracle on the same rays / jitter / parameters — RGB within 1e-4 (north_star), losses, main-table gradient —
+    then 12 optimisation steps tracking the oracle's loss curve."""
+    import bench
+
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.train_step import NerfactoTrainStep
+
+    cfg = orc.NerfactoCfg(main_grid=orc.HashGridCfg(16, 16, 2048, 12),
+                          prop_grids=(orc.HashGridCfg(5, 16, 128, 10), orc.HashGridCfg(5, 16, 256, 10)), num_images=100)
+    n, steps = 256, 12
+    o, d, cam, tgt = (torch.from_numpy(a[:n]) for a in bench.synthetic_rays(2024, "unbounded"))
+    cam = cam[:, 0]
+    assert float(o.norm(dim=-1).min()) > 2.0  # every camera is outside the unit box
+    rs = np.random.RandomState(3)
+    jit = rs.uniform(0, 1, (steps, 3, n)).astype(np.float32)
+    params = orc.init_params(cfg, seed=5, table_std=0.3)
+    model = _model(cfg, params)
+    arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
+    runner = NerfactoTrainStep(model, n, torch.device("cuda"))
+    runner.set_batch(o.cuda(), d.cuda(), cam.cuda(), tgt.cuda())
+
+    oparams = orc.init_params(cfg, seed=5, table_std=0.3)
+    plist = list(oparams.values())
+    for p in plist:
+        p.requires_grad_(True)
+    opt = torch.optim.Adam(plist, lr=1e-2, eps=1e-15)
+    gpu_losses, ref_losses = [], []
+    for step in range(steps):
+        model.set_step(step)
+        ps = model.proposal_sampler
+        updated = ps.updated_this_step()
+        runner.anneal_dev.fill_(ps._anneal)
+        runner.jitter.copy_(torch.from_numpy(jit[step]))
+        arena.zero_grad(skip=runner.written_params())
+        runner.forward_backward(updated, draw_jitter=False)
+        opt.zero_grad(set_to_none=True)
+        j = [torch.from_numpy(jit[step, i])[:, None] for i in range(3)]
+        out = orc.nerfacto_forward(oparams, cfg, o, d, cam, j, training=True, anneal=ps._anneal, proposal_requires_grad=updated)
+        ld = orc.nerfacto_losses(out, tgt, cfg)
+        sum(ld.values()).backward()
+        if step == 0:
+            np.testing.assert_allclose(runner.outputs()["rgb"].cpu().numpy(), out["rgb"].detach().numpy(), atol=1e-4)
+            pos = orc.sample_positions(o, d, out["t_bins_list"][-1])
+            frac = float((pos.abs().amax(dim=-1) > 1).float().mean())
+            assert frac > 0.5, f"only {frac:.2f} of the final samples lie in the contracted region"
+            got = {k: float(v) for k, v in runner.loss_dict().items()}
+            for k in ("rgb_loss", "interlevel_loss", "distortion_loss"):
+                np.testing.assert_allclose(got[k], float(ld[k]), rtol=2e-4, atol=1e-9, err_msg=k)
+            a = model.field.mlp_base.encoding.hash_table.grad.cpu().numpy()
+            b = oparams["field.mlp_base.model.0.hash_table"].grad.numpy()
+            assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b)
+        arena.step(groups=["fields", "proposal_networks"] if updated else ["fields"])
+        opt.step()
+        gpu_losses.append(float(sum(runner.loss_dict().values())))
+        ref_losses.append(float(sum(v.detach() for v in ld.values())))
+        if updated:
+            ps.mark_updated()
+        model.after_step(step)
+    np.testing.assert_allclose(gpu_losses[:4], ref_losses[:4], rtol=1e-3)
+    np.testing.assert_allclose(gpu_losses, ref_losses, rtol=5e-2)
+    assert ref_losses[-1] < ref_losses[0]
