@@ -156,6 +156,17 @@ typedef struct nsamd_density_mlp {
 int nsamd_density_mlp_fwd(const float* enc, const float* selector, int64_t M, nsamd_density_mlp mlp,
                           float* density, float* pre, nsamd_stream_t stream);
 
+/* The whole proposal-network forward in ONE kernel: transform -> hash grid (every level) -> MLP -> trunc_exp, one point
+ * per lane, encoded features in registers (HashMLPDensityField.get_density, fields/density_fields.py:94-117 — what the
+ * reference runs as tcnn.NetworkWithInputEncoding, field_components/mlp.py:252-269, on its tcnn path). enc (nullable,
+ * feature-major [2L, M]), selector (nullable) and pre (nullable) are written only when given: a training step whose
+ * proposal networks receive no gradient (ray_samplers.py:590) passes NULL and skips 4 * 2L bytes per point each way.
+ * Bit-identical to nsamd_hashgrid_encode_fwd + nsamd_density_mlp_fwd. Built for (levels, hidden) in {5, 8} x {16, 64};
+ * NSAMD_ERR_UNSUPPORTED otherwise (use the two-kernel pair). */
+int nsamd_density_field_fwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
+                            nsamd_grid grid, nsamd_density_mlp mlp, float* enc, float* selector, float* density,
+                            float* pre, nsamd_stream_t stream);
+
 /* Backward: ddensity [M] -> denc feature-major [in_dim,M] (overwritten), and dW0,db0,dW1,db1 accumulated
  * (caller zero-fills). trunc_exp backward clamps the exponent to [-15,15] (activations.py:39-42).
  * workspace (nullable): >= 1024 * 1092 floats of scratch (one row of partial weight-gradient sums per workgroup,

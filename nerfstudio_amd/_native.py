@@ -70,6 +70,7 @@ _SIGNATURES = {
     "nsamd_sh4_encode": [vp, i64, vp, vp],
     "nsamd_contract_linf": [vp, i64, vp, vp],
     "nsamd_density_mlp_fwd": [vp, vp, i64, DensityMlp, vp, vp, vp],
+    "nsamd_density_field_fwd": [Points, i64, C.c_int, Aabb, vp, Grid, DensityMlp, vp, vp, vp, vp, vp],
     "nsamd_density_mlp_bwd": [vp, vp, vp, vp, i64, DensityMlp, vp, vp, vp, vp, vp, vp, i64, vp],
     "nsamd_field_mlp_fwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp],
     "nsamd_field_mlp_bwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp, i64, vp],
@@ -115,6 +116,7 @@ _RESTYPES = {"nsamd_version": C.c_char_p, "nsamd_status_string": C.c_char_p,
              "nsamd_hashgrid_encode_bwd_workspace": C.c_int64, "nsamd_hashgrid_encode_bwd_workspace_state": C.c_int64, "nsamd_field_mlp_saved_floats": C.c_int64}
 
 _lib = None
+ERR_UNSUPPORTED = -2  # nsamd_status NSAMD_ERR_UNSUPPORTED
 
 # Optional live kernel timing (bench.py's `roofline` leg): when PROFILE is a dict, every launch through the binding is
 # bracketed by a pair of HIP events recorded on torch's current stream — the stream the kernels are enqueued on.
@@ -134,7 +136,9 @@ class _Entry:
         if prof is None:
             return self.fn(*args)
         key = self.name
-        if self.name.startswith("nsamd_hashgrid_encode"):
+        if self.name == "nsamd_density_field_fwd":
+            key = f"{self.name}[M={args[1]}]"
+        elif self.name.startswith("nsamd_hashgrid_encode"):
             key = f"{self.name}[L={args[5].num_levels},M={args[1]}]"
         elif self.name.startswith("nsamd_density_mlp"):
             key = f"{self.name}[M={args[2] if self.name.endswith('fwd') else args[4]}]"

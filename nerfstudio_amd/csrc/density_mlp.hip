@@ -54,6 +54,75 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_fwd_kernel(const float*
   }
 }
 
+// Fused proposal-network forward: contraction -> hash grid (all levels) -> MLP -> trunc_exp in ONE kernel, one point per
+// lane (HashMLPDensityField.get_density, fields/density_fields.py:94-117). The encoded features stay in registers: the
+// 4 * IN bytes per point of the feature-major `enc` buffer are neither written nor read back on the steps where the
+// proposal networks get no gradient (ray_samplers.py:590: most steps after warm-up), and only written on the others
+// (the backward's weight gradient needs them). Same operation order as hash_encode_fwd_kernel + density_mlp_fwd_kernel:
+// bit-identical outputs. The proposal tables (5 levels x 2^17 entries x 8 B = 5 MB) sit in every XCD's L2.
+template <int LEVELS, int H>
+__global__ __launch_bounds__(kMlpBlock) void density_field_fwd_kernel(nsamd_points P, int64_t M, int transform,
+                                                                      nsamd_aabb box, const float2* __restrict__ table,
+                                                                      nsamd_grid grid, nsamd_density_mlp mlp,
+                                                                      float* __restrict__ enc_out,
+                                                                      float* __restrict__ selector_out,
+                                                                      float* __restrict__ density,
+                                                                      float* __restrict__ pre_out) {
+  constexpr int IN = 2 * LEVELS;
+  const int64_t p = (int64_t)blockIdx.x * kMlpBlock + threadIdx.x;
+  if (p >= M) return;
+  float x, y, z;
+  load_position(P, p, x, y, z);
+  const float sel = normalise_position(transform, box, x, y, z);
+  const uint32_t mask = (1u << grid.log2_table_size) - 1u;
+  float2 v[LEVELS][8];
+  float w[LEVELS][3];
+#pragma unroll
+  for (int l = 0; l < LEVELS; ++l) {  // all gathers in flight before the first blend
+    const Cell c = locate_cell(x, y, z, grid.scalings[l]);
+    w[l][0] = c.w[0]; w[l][1] = c.w[1]; w[l][2] = c.w[2];
+    const float2* __restrict__ tl = table + ((size_t)l << grid.log2_table_size);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[l][k] = tl[corner_index(c, k, mask)];
+  }
+  float feat[IN];
+#pragma unroll
+  for (int l = 0; l < LEVELS; ++l) {
+    const float wx = w[l][0], wy = w[l][1], wz = w[l][2];
+    const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      auto g = [&](int k) { return f == 0 ? v[l][k].x : v[l][k].y; };
+      // blend order x, y, z exactly as encodings.py:446-456
+      const float yc_zc = g(7) * wx + g(6) * ux;
+      const float yf_zc = g(5) * wx + g(4) * ux;
+      const float yf_zf = g(1) * wx + g(0) * ux;
+      const float yc_zf = g(3) * wx + g(2) * ux;
+      const float zc = yc_zc * wy + yf_zc * uy;
+      const float zf = yc_zf * wy + yf_zf * uy;
+      feat[2 * l + f] = zc * wz + zf * uz;
+    }
+  }
+  if (enc_out != nullptr) {
+#pragma unroll
+    for (int k = 0; k < IN; ++k) enc_out[(int64_t)k * M + p] = feat[k];
+  }
+  if (selector_out != nullptr) selector_out[p] = sel;
+  const float* __restrict__ W0 = mlp.W0;
+  const float* __restrict__ b0 = mlp.b0;
+  const float* __restrict__ W1 = mlp.W1;
+  float out = mlp.b1[0];
+#pragma unroll
+  for (int j = 0; j < H; ++j) {
+    float a = b0[j];
+#pragma unroll
+    for (int k = 0; k < IN; ++k) a = fmaf(W0[j * IN + k], feat[k], a);
+    out = fmaf(W1[j], fmaxf(a, 0.0f), out);
+  }
+  if (pre_out != nullptr) pre_out[p] = out;
+  density[p] = mlp.average_init_density * expf(out) * sel;
+}
+
 template <int IN, int H>
 __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ pre,
@@ -281,6 +350,40 @@ extern "C" int nsamd_density_mlp_fwd(const float* enc, const float* selector, in
 #define CALL(IN, H) launch_fwd<IN, H>(enc, selector, M, mlp, density, pre, (hipStream_t)stream)
   NSAMD_DENSITY_DISPATCH(CALL)
 #undef CALL
+}
+
+extern "C" int nsamd_density_field_fwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
+                                       nsamd_grid grid, nsamd_density_mlp mlp, float* enc, float* selector, float* density,
+                                       float* pre, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(M >= 0);
+  if (M == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(table && density && mlp.W0 && mlp.b0 && mlp.W1 && mlp.b1);
+  NSAMD_REQUIRE(transform >= 0 && transform <= 2);
+  if (pts.positions == nullptr) {
+    NSAMD_REQUIRE(pts.origins && pts.directions && pts.t_bins && pts.samples_per_ray > 0 && M % pts.samples_per_ray == 0);
+  }
+  if (grid.log2_table_size < 1 || grid.log2_table_size > 28) return NSAMD_ERR_UNSUPPORTED;
+  if (mlp.in_dim != 2 * grid.num_levels) return NSAMD_ERR_INVALID_ARG;
+  const int64_t nb = (M + kMlpBlock - 1) / kMlpBlock;
+  if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
+  const float2* t2 = reinterpret_cast<const float2*>(table);
+  if (grid.num_levels == 5 && mlp.hidden == 16) {
+    density_field_fwd_kernel<5, 16><<<(unsigned)nb, kMlpBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, t2, grid, mlp,
+                                                                                     enc, selector, density, pre);
+  } else if (grid.num_levels == 8 && mlp.hidden == 16) {
+    density_field_fwd_kernel<8, 16><<<(unsigned)nb, kMlpBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, t2, grid, mlp,
+                                                                                     enc, selector, density, pre);
+  } else if (grid.num_levels == 5 && mlp.hidden == 64) {
+    density_field_fwd_kernel<5, 64><<<(unsigned)nb, kMlpBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, t2, grid, mlp,
+                                                                                     enc, selector, density, pre);
+  } else if (grid.num_levels == 8 && mlp.hidden == 64) {
+    density_field_fwd_kernel<8, 64><<<(unsigned)nb, kMlpBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, t2, grid, mlp,
+                                                                                     enc, selector, density, pre);
+  } else {
+    return NSAMD_ERR_UNSUPPORTED;  // callers fall back to nsamd_hashgrid_encode_fwd + nsamd_density_mlp_fwd
+  }
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
 }
 
 extern "C" int nsamd_density_mlp_bwd(const float* enc, const float* selector, const float* pre,

@@ -139,6 +139,23 @@ class NerfactoField(Field):
             app_const, dir_group, enc.spec, self._transform, self._box, self.average_init_density)
         return density.view(*shape, 1), rgb.view(*shape, 3)
 
+    def density_fn(self, positions: Tensor, times: Optional[Tensor] = None) -> Tensor:
+        """Density only, on explicit positions `[*bs,3]` -> `[*bs,1]` (base_field.py:48-68) — what the occupancy grid
+        and the VolumetricSampler's sigma_fn call (models/instant_ngp.py:133,153; ray_samplers.py:420-429). No camera
+        and no view direction are involved: the fused kernel runs with a constant appearance row and a fixed direction,
+        its colour output is dropped."""
+        del times
+        shape = positions.shape[:-1]
+        pos = positions.reshape(-1, 3)
+        emb = self.embedding_appearance.embedding.weight if self.embedding_appearance is not None else None
+        app_const = torch.zeros(emb.shape[1], device=pos.device) if emb is not None else None
+        view = torch.zeros((1, 3), device=pos.device)
+        enc = self.mlp_base.encoding
+        density, _ = F.nerfacto_field(F.PointSpec(positions=pos), enc.hash_table, self.mlp_base.mlp.param_tensors(),
+                                      self.mlp_head.param_tensors(), emb, view, None, app_const, max(pos.shape[0], 1),
+                                      enc.spec, self._transform, self._box, self.average_init_density)
+        return density.view(*shape, 1)
+
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
         """Densities `[*bs,1]`; the second value carries the rgb already evaluated by the fused pipeline."""
         density, rgb = self._evaluate(ray_samples)

@@ -204,14 +204,13 @@ class NerfactoTrainStep:
     def written_params(self):
         """Parameters whose gradient this runner WRITES (hash tables, nsamd_hashgrid_encode_bwd_set): callers need not
         zero them (ParamArena.zero_grad(skip=...)). All other gradients accumulate and must be zeroed first."""
-        # Only the 67 MB main table: for the 5 MB proposal tables the zero-fill is nothing, while the write-only path's
-        # deferred list costs more than direct atomics whenever a combining table overflows (dense early-training
-        # gradients: 300 vs 231 us, profiles/r01_scatter_write_only_sweeps.log).
+        # Only the 67 MB main table: for the 5 MB proposal tables the zero-fill is nothing and the accumulating call needs
+        # no worst-case spill list.
         return [self.model.field.mlp_base.encoding.hash_table]
 
     def forward_and_losses(self, updated: bool, draw_jitter: bool = True) -> None:
         self.apply_camera_corrections()
-        self.forward_proposals(draw_jitter)
+        self.forward_proposals(draw_jitter, need_enc=updated)
         self.forward_main_and_losses(updated)
 
     # ---- camera optimiser -----------------------------------------------------------------------------------------
@@ -250,10 +249,12 @@ class NerfactoTrainStep:
         torch.autograd.backward([o, d, reg["camera_opt_regularizer"]], [d_o, d_d, torch.ones_like(self.camera_reg)])
         self._corrected = None
 
-    def forward_proposals(self, draw_jitter: bool = True) -> None:
+    def forward_proposals(self, draw_jitter: bool = True, need_enc: bool = True) -> None:
         """Initial bins and the proposal levels (density fields + resampling): reads only the proposal networks'
         parameters, so with data parallelism it can run while the main-field gradients of the previous step are still
-        being all-reduced (bench.py)."""
+        being all-reduced (bench.py). need_enc: keep the levels' encoded features / selector / pre-activation for
+        backward_proposals (False on the steps where the proposal networks get no gradient, ray_samplers.py:590: the
+        fused forward then writes nothing but the densities)."""
         lib, st, n = N.load(), N.stream(), self.n
         ck = N.check
         if draw_jitter:
@@ -269,11 +270,20 @@ class NerfactoTrainStep:
             W0, b0, W1, b1 = mlp.param_tensors()
             dm = N.DensityMlp(N.ptr(W0), N.ptr(b0), N.ptr(W1), N.ptr(b1), W0.shape[1], W0.shape[0],
                               float(net.average_init_density))
-            ck(lib.nsamd_hashgrid_encode_fwd(self._points(lvl), m, net._transform, net._box, N.ptr(net.encoding.hash_table),
-                                             net.encoding.spec.native(), N.ptr(self.p_enc[lvl]), 1, m,
-                                             N.ptr(self.p_sel[lvl]), st), "hashgrid_encode_fwd")
-            ck(lib.nsamd_density_mlp_fwd(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), m, dm, N.ptr(self.p_dens[lvl]),
-                                         N.ptr(self.p_pre[lvl]), st), "density_mlp_fwd")
+            # hash grid + MLP + trunc_exp in one launch, features in registers (nsamd_density_field_fwd); networks the
+            # fused kernel is not built for go through the two-kernel pair
+            fused = lib.nsamd_density_field_fwd(
+                self._points(lvl), m, net._transform, net._box, N.ptr(net.encoding.hash_table), net.encoding.spec.native(), dm,
+                N.ptr(self.p_enc[lvl]) if need_enc else None, N.ptr(self.p_sel[lvl]) if need_enc else None,
+                N.ptr(self.p_dens[lvl]), N.ptr(self.p_pre[lvl]) if need_enc else None, st)
+            if fused == N.ERR_UNSUPPORTED:
+                ck(lib.nsamd_hashgrid_encode_fwd(self._points(lvl), m, net._transform, net._box, N.ptr(net.encoding.hash_table),
+                                                 net.encoding.spec.native(), N.ptr(self.p_enc[lvl]), 1, m,
+                                                 N.ptr(self.p_sel[lvl]), st), "hashgrid_encode_fwd")
+                ck(lib.nsamd_density_mlp_fwd(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), m, dm, N.ptr(self.p_dens[lvl]),
+                                             N.ptr(self.p_pre[lvl]), st), "density_mlp_fwd")
+            else:
+                ck(fused, "density_field_fwd")
             S2 = self.counts[lvl + 1]
             # weights of this level, its median depth (prop_depth_i, models/nerfacto.py:346-347) and the PDF resampling
             ck(lib.nsamd_proposal_resample(N.ptr(self.t_bins[lvl]), N.ptr(self.s_bins[lvl]), N.ptr(self.p_dens[lvl]), S,

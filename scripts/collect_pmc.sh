@@ -7,11 +7,11 @@
 #                        WRITE_SIZE are reported in KiB; FETCH_SIZE counts 128-B requests at 64 B for wide coalesced
 #                        streaming reads -> doubled for the kernels that stream 16 B per lane, raw value kept too)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/final
+OUT=$R/gpurun_out/${1:-final}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kstats -o k -- python $R/bench.py --steps 20 --warmup 10 --no-cpu-baseline --profile-steps 1 > $OUT/rocprof_bench.log 2>&1
-CMD="python $R/bench.py --steps 3 --warmup 3 --no-graph --no-cpu-baseline --profile-steps 1"
+CMD="python $R/bench.py --steps 3 --warmup 3 --no-graph --no-cpu-baseline --profile-steps 1 --fixed-batch"
 export NSAMD_SIDE_STREAM=0
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_INST_LDS --output-format csv -d /tmp/pmc_sq -o sq -- $CMD > $OUT/pmc_sq.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -o f -- $CMD > $OUT/pmc_fetch.log 2>&1
@@ -59,10 +59,9 @@ print(open(os.path.join(out, "pmc_summary.csv")).read())
 def kib(k, c):
     return (mean(agg[k][c]) or 0.0) * 1024.0
 groups = {  # bench key -> (kernel substring, grid, streaming) parts; streaming = 16 B/lane coalesced reads dominate
-    "nsamd_hashgrid_encode_bwd_set[L=16,M=196608]": [("hash_bwd_bin_fine_kernel<4>", "786432", False),
-                                                      ("hash_bwd_bin_runs_kernel<4, 12>", "98304", False),
-                                                      ("hash_bwd_apply_kernel", "524288", True),
-                                                      ("hash_bwd_deferred_kernel", "16384", False)],
+    "nsamd_hashgrid_encode_bwd_set[L=16,M=196608]": [("scatter_route_fine_kernel<1024, 1, 4>", "786432", False),
+                                                      ("scatter_apply_kernel", "1048576", True),
+                                                      ("scatter_finish_kernel", "8192", False)],
     "nsamd_field_mlp_bwd": [("field_mlp_bwd_kernel", "131072", False), ("field_dw_reduce_kernel", None, False)],
     "nsamd_field_mlp_fwd": [("field_mlp_fwd_kernel", "196608", False)],
     "nsamd_adam_step": [("adam_kernel", "524288", True)],
@@ -82,6 +81,10 @@ for key, parts in groups.items():
                 found.append(k)
     traffic[key] = {"fetch_bytes_raw": fetch_raw, "fetch_bytes_calibrated": fetch_cal, "write_bytes": write,
                     "hbm_bytes": fetch_cal + write, "kernels": found}
+import sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import bench  # kernel_sources_hash(): bench.py reports a traffic figure only when it was measured on these very sources
+traffic["_kernel_sources_sha256_16"] = bench.kernel_sources_hash()
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 PY

@@ -499,6 +499,45 @@ def test_camera_optimizer_gradients_golden(F, golden, mode):
     assert float(moved.max()) <= 1e-3 * 1.001 and float(moved.max()) > 5e-4  # Adam's first step: lr * sign(g)
 
 
+def test_fused_proposal_forward_equals_the_two_kernel_pair(F):
+    """nsamd_density_field_fwd (hash grid + MLP + trunc_exp in one launch, features in registers) is bit-identical to
+    nsamd_hashgrid_encode_fwd + nsamd_density_mlp_fwd — densities, and the optional enc / selector / pre outputs — in ray
+    mode and on explicit positions, with and without the optional outputs; unsupported shapes report NSAMD_ERR_UNSUPPORTED."""
+    from nerfstudio_amd import _native as N
+
+    lib = N.load()
+    torch.manual_seed(3)
+    n, S = 211, 96
+    M = n * S
+    spec = F.HashGridSpec(5, 16, 256, 12)
+    table = (torch.randn(5 << 12, 2) * 0.5).cuda()
+    W0, b0, W1, b1 = (torch.randn(16, 10) * 0.4).cuda(), (torch.randn(16) * 0.1).cuda(), (torch.randn(1, 16) * 0.4).cuda(), torch.randn(1).cuda()
+    dm = N.DensityMlp(N.ptr(W0), N.ptr(b0), N.ptr(W1), N.ptr(b1), 10, 16, 0.01)
+    o = (torch.randn(n, 3) * 0.7).cuda()
+    d = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1).cuda()
+    _, t_bins = F.piecewise_bins(torch.full((n,), 0.05).cuda(), torch.full((n,), 1000.0).cuda(), S, torch.rand(n).cuda())
+    pos = (o[:, None] + d[:, None] * ((t_bins[:, :-1] + t_bins[:, 1:]) / 2)[..., None]).reshape(-1, 3).contiguous()
+    e = lambda *s_: torch.empty(*s_, device="cuda")  # noqa: E731
+    for P in (N.make_points(None, o, d, t_bins, S), N.make_points(positions=pos)):
+        enc_a, sel_a, den_a, pre_a = e(10, M), e(M), e(M), e(M)
+        N.check(lib.nsamd_hashgrid_encode_fwd(P, M, N.XFORM_CONTRACT, N.Aabb(), N.ptr(table), spec.native(), N.ptr(enc_a), 1, M,
+                                              N.ptr(sel_a), N.stream()), "hash")
+        N.check(lib.nsamd_density_mlp_fwd(N.ptr(enc_a), N.ptr(sel_a), M, dm, N.ptr(den_a), N.ptr(pre_a), N.stream()), "mlp")
+        enc_b, sel_b, den_b, pre_b = e(10, M), e(M), e(M), e(M)
+        N.check(lib.nsamd_density_field_fwd(P, M, N.XFORM_CONTRACT, N.Aabb(), N.ptr(table), spec.native(), dm, N.ptr(enc_b),
+                                            N.ptr(sel_b), N.ptr(den_b), N.ptr(pre_b), N.stream()), "fused")
+        for a, b in ((enc_a, enc_b), (sel_a, sel_b), (den_a, den_b), (pre_a, pre_b)):
+            assert torch.equal(a, b)
+        den_c = e(M)
+        N.check(lib.nsamd_density_field_fwd(P, M, N.XFORM_CONTRACT, N.Aabb(), N.ptr(table), spec.native(), dm, None, None,
+                                            N.ptr(den_c), None, N.stream()), "fused, densities only")
+        assert torch.equal(den_a, den_c) and float(den_a.max()) > 0
+    spec7 = F.HashGridSpec(7, 16, 256, 12)
+    dm7 = N.DensityMlp(N.ptr(W0), N.ptr(b0), N.ptr(W1), N.ptr(b1), 14, 16, 0.01)
+    assert lib.nsamd_density_field_fwd(N.make_points(positions=pos), M, N.XFORM_CONTRACT, N.Aabb(), N.ptr(table), spec7.native(),
+                                       dm7, None, None, N.ptr(e(M)), None, N.stream()) == N.ERR_UNSUPPORTED
+
+
 def test_losses_golden(F, golden):
     g = golden("losses")
     ws = [dev(g[f"w{i}"]).requires_grad_(True) for i in range(3)]
