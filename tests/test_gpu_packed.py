@@ -176,7 +176,8 @@ def test_ngp_model_outputs_vs_oracle_and_trains(F):
     from nerfstudio_amd.cameras.rays import RayBundle
     from nerfstudio_amd.instant_ngp import InstantNGPModelConfig, NGPModel
 
-    cfg = orc.NerfactoCfg(main_grid=orc.HashGridCfg(16, 16, 2048, 12), prop_grids=(), num_images=4)
+    # NGPModel builds its NerfactoField with the field's own defaults (models/instant_ngp.py:102-109): average_init_density 1
+    cfg = orc.NerfactoCfg(main_grid=orc.HashGridCfg(16, 16, 2048, 12), prop_grids=(), num_images=4, average_init_density=1.0)
     params = orc.init_params(cfg, seed=21, table_std=0.5)
     mc = InstantNGPModelConfig(grid_resolution=16, grid_levels=2, log2_hashmap_size=12, background_color="white", cone_angle=0.0,
                                render_step_size=0.02)
