@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: rocprofv3 evidence for the bench command (run via gpurun). Writes under gpurun_out/final/:
+# GPU box: rocprofv3 evidence for the bench command (run via gpurun). Writes under gpurun_out/<tag = $1, default final>/:
 #   kernel_stats.csv     per-kernel time (rocprofv3 --kernel-trace --stats of `bench.py --steps 20`, graph replay)
 #   pmc_summary.csv      SQ counters (MFMA busy, LDS waits, ...), FETCH_SIZE, WRITE_SIZE per kernel — three separate
 #                        passes with --kernel-trace only (no sys/hip/hsa tracing), as required on this pool
@@ -7,7 +7,7 @@
 #                        WRITE_SIZE are reported in KiB; FETCH_SIZE counts 128-B requests at 64 B for wide coalesced
 #                        streaming reads -> doubled for the kernels that stream 16 B per lane, raw value kept too)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/${1:-final}
+export OUT=$R/gpurun_out/${1:-final}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kstats -o k -- python $R/bench.py --steps 20 --warmup 10 --no-cpu-baseline --profile-steps 1 > $OUT/rocprof_bench.log 2>&1
@@ -19,7 +19,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tm
 cd $R
 python - <<'PY'
 import csv, glob, collections, json, os, sqlite3
-out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out", "final")
+out = os.environ["OUT"]
 # ---- kernel stats from the graph-replay run
 dbs = glob.glob("/tmp/kstats/**/*results.db", recursive=True)
 if dbs:

@@ -249,12 +249,12 @@ def test_reachable_prefix_covers_every_corner_the_oracle_can_produce():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r01_final_bench_default.json is what `python bench.py` printed on the MI355X box: every field of the
+    """profiles/r02_final_bench_default.json is what `python bench.py` printed on the MI355X box: every field of the
     driver's contract is there with the right type, the roofline fraction is achieved / peak, value = rays / step time."""
     import json
     import os
 
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_final_bench_default.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_final_bench_default.json")
     d = json.load(open(path))
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
