@@ -31,6 +31,19 @@ namespace nsamd {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Timing probe (scripts/probe_field_clocks.py builds this file alone with -DNSAMD_PROBE_CLOCKS into its own library;
+// never part of libnsamd.so): lane 0 of every wave stamps the shader clock into [wave][64 slots].
+#ifdef NSAMD_PROBE_CLOCKS
+__device__ long long* g_probe_clocks = nullptr;
+#define PROBE_STAMP(waves_per_block, slot)                                                              \
+  do {                                                                                                  \
+    if (g_probe_clocks != nullptr && (threadIdx.x & 63) == 0 && (slot) < 64)                            \
+      g_probe_clocks[((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64 + (slot)] = clock64();  \
+  } while (0)
+#else
+#define PROBE_STAMP(waves_per_block, slot) do {} while (0)
+#endif
+
 constexpr int kWaves = 4;
 constexpr int kFieldThreads = 64 * kWaves;
 constexpr int kScratchLd = 20;                      // floats per scratch row: 16 points + 4 (row stride = 4 mod 8 words:
@@ -58,22 +71,34 @@ __device__ __forceinline__ int head0_col(int s, int app_dim) {
   return (s - 32 < app_dim) ? s - 1 : -1;
 }
 
-// Wf[n][t][lane][r] = Wint[16n + j][16t + 4g + r]
-__device__ void stage_fwd_frag(float* dst, const float* __restrict__ W, int n_real, int k_real, int NT, int KT,
-                               bool head0, int app_dim) {
-  const int total = NT * KT * 256;
-  for (int e = threadIdx.x; e < total; e += kFieldThreads) {
-    const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8;
+// Wf[n][t][lane][r] = Wint[16n + j][16t + 4g + r]. Staging is split into a load half and a store half so that a
+// workgroup has the loads of ALL five layers in flight at once (48 per thread): as a load-wait-store loop the staging cost
+// 23 k clocks of a wave's 113 k (probe_field_clocks, round 2).
+template <int NT, int KT, int THREADS>
+__device__ __forceinline__ void stage_frag_load(float* v, const float* __restrict__ W, int n_real, int k_real, bool head0,
+                                                int app_dim) {
+  static_assert(THREADS % 256 == 0 && (NT * KT * 256) % THREADS == 0, "whole tiles per pass");
+  const int r = threadIdx.x & 3, lane = (threadIdx.x >> 2) & 63;
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < NT * KT * 256 / THREADS; ++i) {
+    const int tile = (threadIdx.x >> 8) + (THREADS / 256) * i;
     const int t = tile % KT, n = tile / KT;
-    const int j = lane & 15, g = lane >> 4;
     const int row = 16 * n + j, slot = 16 * t + 4 * g + r;
     const int col = head0 ? head0_col(slot, app_dim) : slot;
-    dst[e] = (row < n_real && col >= 0 && col < k_real) ? W[row * k_real + col] : 0.0f;
+    v[i] = (row < n_real && col >= 0 && col < k_real) ? W[row * k_real + col] : 0.0f;
   }
 }
 
-__device__ void stage_bias(float* dst, const float* __restrict__ b, int n_real, int n_pad) {
-  for (int e = threadIdx.x; e < n_pad; e += kFieldThreads) dst[e] = (e < n_real) ? b[e] : 0.0f;
+template <int NT, int KT, int THREADS>
+__device__ __forceinline__ void stage_frag_store(float* dst, const float* v) {
+#pragma unroll
+  for (int i = 0; i < NT * KT * 256 / THREADS; ++i) dst[i * THREADS + threadIdx.x] = v[i];
+}
+
+template <int THREADS>
+__device__ __forceinline__ void stage_bias(float* dst, const float* __restrict__ b, int n_real, int n_pad) {
+  for (int e = threadIdx.x; e < n_pad; e += THREADS) dst[e] = (e < n_real) ? b[e] : 0.0f;
 }
 
 // out[n] (+)= sum over input tiles; frag = Wf-style block for this layer: [NT][KT][64][4]
@@ -106,8 +131,14 @@ __device__ __forceinline__ void relu_tiles(v4f* x) {
     for (int r = 0; r < 4; ++r) x[n][r] = fmaxf(x[n][r], 0.0f);
 }
 
+// ray (direction / camera row) of point p: 32-bit division whenever both fit (a 64-bit divide is ~100 instructions)
+__device__ __forceinline__ int64_t ray_of(int64_t p, int64_t dir_group) {
+  return (((uint64_t)p | (uint64_t)dir_group) >> 32) ? p / dir_group : (int64_t)((uint32_t)p / (uint32_t)dir_group);
+}
+
 struct TileInputs {
   int64_t p;       // clamped point index of this lane
+  int64_t ray;     // p / dir_group
   bool live;       // point index < M
   float sel;       // selector
   int64_t cam;     // camera index (or 0)
@@ -172,7 +203,7 @@ __device__ __forceinline__ void build_head_input(const float* __restrict__ direc
                                                  const float* __restrict__ app_const, int64_t dir_group, int app_dim,
                                                  const TileInputs& ti, int lane, FieldActs& A) {
   const int g = lane >> 4;
-  const float* d = directions + 3 * (ti.p / dir_group);
+  const float* d = directions + 3 * ti.ray;
   A.hin[0] = sh_quad(d[0], d[1], d[2], g);
   A.hin[1] = A.o16[0];
   if (app_dim > 0) {
@@ -199,16 +230,18 @@ __device__ __forceinline__ void field_forward_tile(const float* wf, const float*
                                                    const float* __restrict__ directions,
                                                    const float* __restrict__ app_table,
                                                    const float* __restrict__ app_const, int64_t dir_group, int64_t M,
-                                                   int app_dim, const TileInputs& ti, int lane, FieldActs& A) {
+                                                   int app_dim, const TileInputs& ti, int lane, FieldActs& A,
+                                                   int probe_slot = 63) {
   const int g = lane >> 4;
   load_bias<4>(bias + kBiasBase0, A.h1, g);
   chain_gemm<4, 2>(wf + kOffBase0, A.enc, A.h1, lane);
   relu_tiles<4>(A.h1);
   load_bias<1>(bias + kBiasBase1, A.o16, g);
   chain_gemm<1, 4>(wf + kOffBase1, A.h1, A.o16, lane);
+  PROBE_STAMP(kWaves, probe_slot);
 
   // head input: SH of (dir + 1) / 2  (base_field.py:136-142), geo in place, appearance embedding
-  const float* d = directions + 3 * (ti.p / dir_group);
+  const float* d = directions + 3 * ti.ray;
   A.hin[0] = sh_quad(d[0], d[1], d[2], g);
   A.hin[1] = A.o16[0];
   if (app_dim > 0) {
@@ -236,24 +269,34 @@ __device__ __forceinline__ TileInputs tile_inputs(int64_t tile, int lane, int64_
   ti.live = p < M;
   ti.p = ti.live ? p : M - 1;
   ti.sel = selector ? selector[ti.p] : 1.0f;
-  ti.cam = cams ? cams[ti.p / dir_group] : 0;
+  ti.ray = ray_of(ti.p, dir_group);
+  ti.cam = cams ? cams[ti.ray] : 0;
   return ti;
 }
 
-__device__ void stage_all_fwd(float* wf, float* bias, const nsamd_field_mlp& mlp, int app_dim) {
-  stage_fwd_frag(wf + kOffBase0, mlp.base_W0, 64, 32, 4, 2, false, 0);
-  stage_fwd_frag(wf + kOffBase1, mlp.base_W1, 16, 64, 1, 4, false, 0);
-  stage_fwd_frag(wf + kOffHead0, mlp.head_W0, 64, 31 + app_dim, 4, 4, true, app_dim);
-  stage_fwd_frag(wf + kOffHead1, mlp.head_W1, 64, 64, 4, 4, false, 0);
-  stage_fwd_frag(wf + kOffHead2, mlp.head_W2, 3, 64, 1, 4, false, 0);
-  stage_bias(bias + kBiasBase0, mlp.base_b0, 64, 64);
-  stage_bias(bias + kBiasBase1, mlp.base_b1, 16, 16);
-  stage_bias(bias + kBiasHead0, mlp.head_b0, 64, 64);
-  stage_bias(bias + kBiasHead1, mlp.head_b1, 64, 64);
-  stage_bias(bias + kBiasHead2, mlp.head_b2, 3, 16);
+template <int THREADS>
+__device__ __forceinline__ void stage_all_fwd(float* wf, float* bias, const nsamd_field_mlp& mlp, int app_dim) {
+  constexpr int U = 256 * 4 / THREADS;  // loads per thread of a 4-tile layer
+  float v[12 * U];
+  stage_frag_load<4, 2, THREADS>(v, mlp.base_W0, 64, 32, false, 0);
+  stage_frag_load<1, 4, THREADS>(v + 2 * U, mlp.base_W1, 16, 64, false, 0);
+  stage_frag_load<4, 4, THREADS>(v + 3 * U, mlp.head_W0, 64, 31 + app_dim, true, app_dim);
+  stage_frag_load<4, 4, THREADS>(v + 7 * U, mlp.head_W1, 64, 64, false, 0);
+  stage_frag_load<1, 4, THREADS>(v + 11 * U, mlp.head_W2, 3, 64, false, 0);
+  stage_frag_store<4, 2, THREADS>(wf + kOffBase0, v);
+  stage_frag_store<1, 4, THREADS>(wf + kOffBase1, v + 2 * U);
+  stage_frag_store<4, 4, THREADS>(wf + kOffHead0, v + 3 * U);
+  stage_frag_store<4, 4, THREADS>(wf + kOffHead1, v + 7 * U);
+  stage_frag_store<1, 4, THREADS>(wf + kOffHead2, v + 11 * U);
+  stage_bias<THREADS>(bias + kBiasBase0, mlp.base_b0, 64, 64);
+  stage_bias<THREADS>(bias + kBiasBase1, mlp.base_b1, 16, 16);
+  stage_bias<THREADS>(bias + kBiasHead0, mlp.head_b0, 64, 64);
+  stage_bias<THREADS>(bias + kBiasHead1, mlp.head_b1, 64, 64);
+  stage_bias<THREADS>(bias + kBiasHead2, mlp.head_b2, 3, 16);
 }
 
-__global__ __launch_bounds__(kFieldThreads, 2) void field_mlp_fwd_kernel(
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 1 : 2) void field_mlp_fwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
     nsamd_field_mlp mlp, int app_dim, float* __restrict__ density, float* __restrict__ rgb,
@@ -261,19 +304,24 @@ __global__ __launch_bounds__(kFieldThreads, 2) void field_mlp_fwd_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* wf = lds;
   float* bias = lds + kFragTotal;
-  stage_all_fwd(wf, bias, mlp, app_dim);
+  PROBE_STAMP(WAVES, 0);
+  stage_all_fwd<64 * WAVES>(wf, bias, mlp, app_dim);
   __syncthreads();
+  PROBE_STAMP(WAVES, 1);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tiles = (M + 15) / 16;
   const float* app_table = cams ? mlp.appearance : nullptr;
-  for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += (int64_t)gridDim.x * kWaves) {
+  int probe_it = 0;
+  for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < tiles; tile += (int64_t)gridDim.x * WAVES) {
     // The fragments are loop-invariant LDS data: without this the compiler hoists all 192 VGPRs of them out of the
     // tile loop and the kernel drops to one wave per SIMD with nothing to hide the enc loads behind.
     asm volatile("" ::: "memory");
     const TileInputs ti = tile_inputs(tile, lane, M, selector, cams, dir_group);
     FieldActs A;
     load_enc_tile(enc, M, ti.p, lane, A.enc);
-    field_forward_tile(wf, bias, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A);
+    PROBE_STAMP(WAVES, 2 + 4 * probe_it);
+    field_forward_tile(wf, bias, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A, 3 + 4 * probe_it);
+    PROBE_STAMP(WAVES, 4 + 4 * probe_it);
     if (acts != nullptr) store_acts(acts, tile, lane, A);
     if (lane < 16 && ti.live) {  // g == 0 holds neurons 0..3 of tile 0
       density[ti.p] = mlp.average_init_density * expf(A.o16[0][0]) * ti.sel;
@@ -281,7 +329,10 @@ __global__ __launch_bounds__(kFieldThreads, 2) void field_mlp_fwd_kernel(
 #pragma unroll
       for (int c = 0; c < 3; ++c) o[c] = 1.0f / (1.0f + expf(-A.rgbp[0][c]));
     }
+    PROBE_STAMP(WAVES, 5 + 4 * probe_it);
+    ++probe_it;
   }
+  PROBE_STAMP(WAVES, 63);
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------
@@ -328,13 +379,26 @@ constexpr int kRowBase0 = 0, kRowBase1 = kRowBase0 + 64 * kLd32, kRowHead0 = kRo
               kRowHead1 = kRowHead0 + 64 * kLd64, kRowHead2 = kRowHead1 + 64 * kLd64,
               kRowTotal = kRowHead2 + 16 * kLd64;  // 13184 floats = 51.5 KiB
 
-// W (n_real x k_real, row-major in global memory) -> LDS rows [n_pad][ld], internal slot order, zero padded
-__device__ void stage_rows(float* dst, const float* __restrict__ W, int n_real, int k_real, int n_pad, int k_pad, int ld,
-                           bool head0, int app_dim) {
-  for (int e = threadIdx.x; e < n_pad * k_pad; e += kCoopThreads) {
-    const int row = e / k_pad, slot = e - row * k_pad;
+// W (n_real x k_real, row-major in global memory) -> LDS rows [n_pad][ld], internal slot order, zero padded. Load half
+// and store half, as in the forward: all 24 loads of a thread are in flight before the first LDS store.
+template <int N_PAD, int K_PAD>
+__device__ __forceinline__ void stage_rows_load(float* v, const float* __restrict__ W, int n_real, int k_real, bool head0,
+                                                int app_dim) {
+#pragma unroll
+  for (int i = 0; i < N_PAD * K_PAD / kCoopThreads; ++i) {
+    const int e = threadIdx.x + i * kCoopThreads;
+    const int row = e / K_PAD, slot = e % K_PAD;
     const int col = head0 ? head0_col(slot, app_dim) : slot;
-    dst[row * ld + slot] = (row < n_real && col >= 0 && col < k_real) ? W[row * k_real + col] : 0.0f;
+    v[i] = (row < n_real && col >= 0 && col < k_real) ? W[row * k_real + col] : 0.0f;
+  }
+}
+
+template <int N_PAD, int K_PAD, int LD>
+__device__ __forceinline__ void stage_rows_store(float* dst, const float* v) {
+#pragma unroll
+  for (int i = 0; i < N_PAD * K_PAD / kCoopThreads; ++i) {
+    const int e = threadIdx.x + i * kCoopThreads;
+    dst[(e / K_PAD) * LD + e % K_PAD] = v[i];
   }
 }
 
@@ -465,11 +529,20 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
   float* W = lds;                     // kRowTotal
   float* bias = lds + kRowTotal;      // 256
   float* scratch = bias + 256;        // kCoopWaves x 2 tiles
-  stage_rows(W + kRowBase0, mlp.base_W0, 64, 32, 64, 32, kLd32, false, 0);
-  stage_rows(W + kRowBase1, mlp.base_W1, 16, 64, 16, 64, kLd64, false, 0);
-  stage_rows(W + kRowHead0, mlp.head_W0, 64, 31 + app_dim, 64, 64, kLd64, true, app_dim);
-  stage_rows(W + kRowHead1, mlp.head_W1, 64, 64, 64, 64, kLd64, false, 0);
-  stage_rows(W + kRowHead2, mlp.head_W2, 3, 64, 16, 64, kLd64, false, 0);
+  PROBE_STAMP(kCoopWaves, 0);
+  {
+    float v[24];
+    stage_rows_load<64, 32>(v, mlp.base_W0, 64, 32, false, 0);
+    stage_rows_load<16, 64>(v + 4, mlp.base_W1, 16, 64, false, 0);
+    stage_rows_load<64, 64>(v + 6, mlp.head_W0, 64, 31 + app_dim, true, app_dim);
+    stage_rows_load<64, 64>(v + 14, mlp.head_W1, 64, 64, false, 0);
+    stage_rows_load<16, 64>(v + 22, mlp.head_W2, 3, 64, false, 0);
+    stage_rows_store<64, 32, kLd32>(W + kRowBase0, v);
+    stage_rows_store<16, 64, kLd64>(W + kRowBase1, v + 4);
+    stage_rows_store<64, 64, kLd64>(W + kRowHead0, v + 6);
+    stage_rows_store<64, 64, kLd64>(W + kRowHead1, v + 14);
+    stage_rows_store<16, 64, kLd64>(W + kRowHead2, v + 22);
+  }
   for (int e = threadIdx.x; e < 256; e += kCoopThreads) {
     float v = 0.0f;
     if (e < kBiasBase1) v = mlp.base_b0[e];
@@ -504,7 +577,9 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
   const int64_t tiles = (M + 15) / 16;
   const int64_t per_iter = (int64_t)gridDim.x * kCoopWaves;
   const int64_t iters = (tiles + per_iter - 1) / per_iter;
+  PROBE_STAMP(kCoopWaves, 1);
   for (int64_t it = 0; it < iters; ++it) {
+    PROBE_STAMP(kCoopWaves, 2 + 10 * (int)it);
     const int64_t tile = (it * gridDim.x + blockIdx.x) * kCoopWaves + wave;
     TileInputs ti = tile_inputs(tile < tiles ? tile : tiles - 1, lane, M, selector, cams, dir_group);
     if (tile >= tiles) ti.live = false;  // idle wave of the last round: computes, contributes zeros
@@ -514,10 +589,11 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
       load_acts(acts, tile < tiles ? tile : tiles - 1, lane, A);
       build_head_input(directions, app_table, app_const, dir_group, app_dim, ti, lane, A);
     } else {
-      const float* d = directions + 3 * (ti.p / dir_group);  // consumed two layers further down
+      const float* d = directions + 3 * ti.ray;  // consumed two layers further down
       const float dir[3] = {d[0], d[1], d[2]};
       coop_forward_tile(W, bias, dir, app_table, app_const, app_dim, ti, lane, A);
     }
+    PROBE_STAMP(kCoopWaves, 3 + 10 * (int)it);
 
     // ---- head layer 2 (64 -> 3, sigmoid) ----
     v4f g_rgbp[1];
@@ -538,6 +614,7 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     if (!(probe_skip & 4)) rows_gemm_bwd<4, 1, kLd64>(W + kRowHead2, g_rgbp, g_hb, j, g);
     relu_mask<4>(g_hb, A.hb);
     if (!(probe_skip & 2)) __syncthreads();
+    PROBE_STAMP(kCoopWaves, 4 + 10 * (int)it);
 
     // ---- head layer 1 (64 -> 64) ----
     store_rows<4>(Sd, g_hb, j, g);
@@ -549,6 +626,7 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     if (!(probe_skip & 4)) rows_gemm_bwd<4, 4, kLd64>(W + kRowHead1, g_hb, g_ha, j, g);
     relu_mask<4>(g_ha, A.ha);
     if (!(probe_skip & 2)) __syncthreads();
+    PROBE_STAMP(kCoopWaves, 5 + 10 * (int)it);
 
     // ---- head layer 0 (slots 64 -> 64) ----
     store_rows<4>(Sd, g_ha, j, g);
@@ -557,8 +635,10 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     if (!(probe_skip & 1)) coop_dw<2>(dW_h0, &db_h0, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
     v4f g_hin[4];
     zero_tiles<4>(g_hin);
-    if (!(probe_skip & 4)) rows_gemm_bwd<4, 4, kLd64>(W + kRowHead0, g_ha, g_hin, j, g);  // tile 0 (SH) is unused: SH carries no gradient
+    // input tile 0 is the SH block: it carries no gradient, so only columns 16..63 (tiles 1..3) are formed
+    if (!(probe_skip & 4)) rows_gemm_bwd<3, 4, kLd64>(W + kRowHead0 + 16, g_ha, g_hin + 1, j, g);
     if (!(probe_skip & 2)) __syncthreads();
+    PROBE_STAMP(kCoopWaves, 6 + 10 * (int)it);
 
     // appearance-embedding gradient (slots 32..63): rows of one camera are pre-reduced over the tile's points
     if (app_table != nullptr && grads.appearance != nullptr) {
@@ -622,6 +702,7 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     if (!(probe_skip & 4)) rows_gemm_bwd<4, 1, kLd64>(W + kRowBase1, g_o16, g_h1, j, g);
     relu_mask<4>(g_h1, A.h1);
     if (!(probe_skip & 2)) __syncthreads();
+    PROBE_STAMP(kCoopWaves, 7 + 10 * (int)it);
 
     // ---- base layer 0 (32 -> 64) ----
     store_rows<4>(Sd, g_h1, j, g);
@@ -638,7 +719,9 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
         for (int r = 0; r < 4; ++r) denc[(int64_t)(16 * t + 4 * g + r) * M + ti.p] = g_enc[t][r];
     }
     if (!(probe_skip & 2)) __syncthreads();
+    PROBE_STAMP(kCoopWaves, 8 + 10 * (int)it);
   }
+  PROBE_STAMP(kCoopWaves, 62);
 
   // ---- the two point-halves of the 1 x 4 layers meet in LDS (scratch is free now) ---------------------------------
   float* stash = scratch;  // [2 layers][4 tiles][64 lanes][4] + [2][4][64] bias partials
@@ -680,6 +763,7 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     coop_emit_bias(db_h0, own_n, j, g, pbias ? pbias + kBiasHead0 : nullptr, grads.head_b0, 64);
   }
   if (own_m1 == 0) coop_emit_bias(db_b0, own_n, j, g, pbias ? pbias + kBiasBase0 : nullptr, grads.base_b0, 64);
+  PROBE_STAMP(kCoopWaves, 63);
 }
 
 // destination of element e of the [kPartialStride] reduction layout (weights: padded [rows][slots] per layer, then
@@ -859,9 +943,22 @@ static int field_mlp_fwd_impl(const float* enc, const float* selector, const flo
   NSAMD_REQUIRE(density && rgb);
   const size_t lds = sizeof(float) * (kFragTotal + 256);
   const int64_t tiles = (M + 15) / 16;
-  const unsigned blocks = (unsigned)min((int64_t)num_cus() * 3, (tiles + kWaves - 1) / kWaves);
-  field_mlp_fwd_kernel<<<blocks, kFieldThreads, lds, (hipStream_t)stream>>>(
-      enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb, acts);
+  // One 16-wave workgroup per CU by default (4 waves per SIMD, the weights staged once per CU): 57 us on the bench shape
+  // against 59.5 (8 waves x 2 workgroups) and 65 (4 waves x 3) on the same box — NSAMD_FIELD_FWD_WAVES=8|4 selects those.
+  static const int waves = getenv("NSAMD_FIELD_FWD_WAVES") ? atoi(getenv("NSAMD_FIELD_FWD_WAVES")) : 16;
+  if (waves == 16) {
+    const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + 15) / 16);
+    field_mlp_fwd_kernel<16><<<blocks, 1024, lds, (hipStream_t)stream>>>(
+        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb, acts);
+  } else if (waves == 8) {
+    const unsigned blocks = (unsigned)min((int64_t)num_cus() * 2, (tiles + 7) / 8);
+    field_mlp_fwd_kernel<8><<<blocks, 512, lds, (hipStream_t)stream>>>(
+        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb, acts);
+  } else {
+    const unsigned blocks = (unsigned)min((int64_t)num_cus() * 3, (tiles + kWaves - 1) / kWaves);
+    field_mlp_fwd_kernel<kWaves><<<blocks, kFieldThreads, lds, (hipStream_t)stream>>>(
+        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb, acts);
+  }
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }
@@ -950,6 +1047,12 @@ extern "C" int nsamd_field_mlp_bwd_saved(const float* enc, const float* selector
   return field_mlp_bwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, ddensity,
                             drgb, denc, grads, workspace, workspace_floats, saved, stream);
 }
+
+#ifdef NSAMD_PROBE_CLOCKS
+extern "C" int nsamd_probe_set_clocks(long long* buffer) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(nsamd::g_probe_clocks), &buffer, sizeof(buffer)) == hipSuccess ? NSAMD_OK : NSAMD_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int nsamd_probe_mfma16(const float* A, const float* B, float* out, nsamd_stream_t stream) {
   NSAMD_REQUIRE(A && B && out);

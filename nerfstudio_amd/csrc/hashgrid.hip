@@ -91,6 +91,82 @@ __global__ __launch_bounds__(kHashBlock) void hash_encode_fwd_kernel(nsamd_point
   }
 }
 
+// One level per thread, two switches measured against the kernel above (NSAMD_HASH_FWD_MODE bits 1 / 2):
+//  kPair: the two x-neighbours of a cell edge differ by lo ^ hi in their hashed index whatever y and z are; when that is 1
+//         (lo even) or 0 (the point sits on a lattice plane) both entries lie in one aligned 16-B chunk, so ONE dwordx4 gather
+//         serves the pair and the second, lane-masked gather only runs for odd lo — 6 instead of 8 L1 accesses per (point,
+//         level) on average. The gathers are bound by L1 tag lookups (r02: 23.9 M accesses, 0.53 per clock per CU), not bytes.
+//  kXcd:  1-D grid, block b runs on XCD b % 8 (observed placement, speed only): XCD x sweeps levels x, 15 - x, 16 + x, ... so a
+//         level slice is filled into ONE L2 instead of all eight.
+template <bool kPair, bool kXcd>
+__global__ __launch_bounds__(kHashBlock) void hash_encode_fwd_v2_kernel(nsamd_points P, int64_t M, int transform,
+                                                                        nsamd_aabb box, const float2* __restrict__ table,
+                                                                        nsamd_grid grid, float* __restrict__ enc,
+                                                                        int64_t stride_p, int64_t stride_k,
+                                                                        float* __restrict__ selector, unsigned nb) {
+  int level;
+  int64_t pb;
+  if (kXcd) {
+    const unsigned xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
+    const unsigned li = q / nb;
+    pb = q - li * nb;
+    level = (li & 1u) ? (int)(8u * li + 7u - xcd) : (int)(8u * li + xcd);
+    if (level >= grid.num_levels) return;
+  } else {
+    level = blockIdx.y;
+    pb = blockIdx.x;
+  }
+  const int64_t p = pb * kHashBlock + threadIdx.x;
+  if (p >= M) return;
+  float x, y, z;
+  load_position(P, p, x, y, z);
+  const float sel = normalise_position(transform, box, x, y, z);
+  if (level == 0 && selector != nullptr) selector[p] = sel;
+  const uint32_t mask = (1u << grid.log2_table_size) - 1u;
+  const Cell c = locate_cell(x, y, z, grid.scalings[level]);
+  const float2* __restrict__ tl = table + ((size_t)level << grid.log2_table_size);
+  float2 v0, v1, v2, v3, v4, v5, v6, v7;
+  if (kPair) {
+    const float4* __restrict__ tl4 = reinterpret_cast<const float4*>(tl);
+    const uint32_t hy0 = (uint32_t)c.lo[1] * kPrimeY, hy1 = (uint32_t)c.hi[1] * kPrimeY;
+    const uint32_t hz0 = (uint32_t)c.lo[2] * kPrimeZ, hz1 = (uint32_t)c.hi[2] * kPrimeZ;
+    const uint32_t xl = (uint32_t)c.lo[0], xh = (uint32_t)c.hi[0];
+    const uint32_t a0 = (xl ^ hy0 ^ hz0) & mask, a1 = (xl ^ hy1 ^ hz0) & mask, a2 = (xl ^ hy0 ^ hz1) & mask,
+                   a3 = (xl ^ hy1 ^ hz1) & mask;
+    const uint32_t b0 = (xh ^ hy0 ^ hz0) & mask, b1 = (xh ^ hy1 ^ hz0) & mask, b2 = (xh ^ hy0 ^ hz1) & mask,
+                   b3 = (xh ^ hy1 ^ hz1) & mask;
+    const float4 q0 = tl4[a0 >> 1], q1 = tl4[a1 >> 1], q2 = tl4[a2 >> 1], q3 = tl4[a3 >> 1];
+    auto half = [](const float4& q, uint32_t i) { return (i & 1u) ? make_float2(q.z, q.w) : make_float2(q.x, q.y); };
+    v0 = half(q0, a0); v2 = half(q1, a1); v4 = half(q2, a2); v6 = half(q3, a3);
+    if ((((xl ^ xh) & mask) >> 1) == 0u) {
+      v1 = half(q0, b0); v3 = half(q1, b1); v5 = half(q2, b2); v7 = half(q3, b3);
+    } else {
+      v1 = tl[b0]; v3 = tl[b1]; v5 = tl[b2]; v7 = tl[b3];
+    }
+  } else {
+    v0 = tl[corner_index(c, 0, mask)]; v1 = tl[corner_index(c, 1, mask)]; v2 = tl[corner_index(c, 2, mask)];
+    v3 = tl[corner_index(c, 3, mask)]; v4 = tl[corner_index(c, 4, mask)]; v5 = tl[corner_index(c, 5, mask)];
+    v6 = tl[corner_index(c, 6, mask)]; v7 = tl[corner_index(c, 7, mask)];
+  }
+  const float wx = c.w[0], wy = c.w[1], wz = c.w[2];
+  const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+  float r[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    auto g = [&](const float2& a) { return f == 0 ? a.x : a.y; };
+    const float yc_zc = g(v7) * wx + g(v6) * ux;  // blend order x, y, z exactly as encodings.py:446-456
+    const float yf_zc = g(v5) * wx + g(v4) * ux;
+    const float yf_zf = g(v1) * wx + g(v0) * ux;
+    const float yc_zf = g(v3) * wx + g(v2) * ux;
+    const float zc = yc_zc * wy + yf_zc * uy;
+    const float zf = yc_zf * wy + yf_zf * uy;
+    r[f] = zc * wz + zf * uz;
+  }
+  float* o = enc + p * stride_p + (int64_t)(2 * level) * stride_k;
+  o[0] = r[0];
+  o[stride_k] = r[1];
+}
+
 // dL/dtable: one thread per (point, level); 16 fire-and-forget fp32 atomics (global_atomic_add_f32).
 __global__ __launch_bounds__(kHashBlock) void hash_encode_bwd_table_kernel(
     nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
@@ -372,9 +448,25 @@ extern "C" int nsamd_hashgrid_encode_fwd(nsamd_points pts, int64_t M, int transf
     hash_encode_fwd_kernel<2><<<g, kHashBlock, 0, (hipStream_t)stream>>>(
         pts, M, transform, aabb, reinterpret_cast<const float2*>(table), grid, enc, stride_p, stride_k, selector);
   } else {
-    dim3 g((unsigned)nb, (unsigned)grid.num_levels);
-    hash_encode_fwd_kernel<1><<<g, kHashBlock, 0, (hipStream_t)stream>>>(
-        pts, M, transform, aabb, reinterpret_cast<const float2*>(table), grid, enc, stride_p, stride_k, selector);
+    // pair gathers + XCD-aware level sweep: 83.8 -> 78.8 us on the main grid (81.5 with either alone), same arithmetic
+    static const int mode = env_int("NSAMD_HASH_FWD_MODE", 3);
+    const float2* t2 = reinterpret_cast<const float2*>(table);
+    const dim3 g2((unsigned)nb, (unsigned)grid.num_levels);
+    const int64_t xcd_blocks = 8 * nb * ((grid.num_levels + 7) / 8);
+    const bool xcd = (mode & 2) && grid.num_levels % 8 == 0 && xcd_blocks <= 0x7fffffffLL;
+    const dim3 g1((unsigned)xcd_blocks);
+    if ((mode & 1) && xcd)
+      hash_encode_fwd_v2_kernel<true, true><<<g1, kHashBlock, 0, (hipStream_t)stream>>>(
+          pts, M, transform, aabb, t2, grid, enc, stride_p, stride_k, selector, (unsigned)nb);
+    else if (mode & 1)
+      hash_encode_fwd_v2_kernel<true, false><<<g2, kHashBlock, 0, (hipStream_t)stream>>>(
+          pts, M, transform, aabb, t2, grid, enc, stride_p, stride_k, selector, (unsigned)nb);
+    else if (xcd)
+      hash_encode_fwd_v2_kernel<false, true><<<g1, kHashBlock, 0, (hipStream_t)stream>>>(
+          pts, M, transform, aabb, t2, grid, enc, stride_p, stride_k, selector, (unsigned)nb);
+    else
+      hash_encode_fwd_kernel<1><<<g2, kHashBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, t2, grid, enc, stride_p,
+                                                                          stride_k, selector);
   }
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
