@@ -605,38 +605,42 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
         g_rgbp[0][c] = drgb[3 * ti.p + c] * (sg * (1.0f - sg));
       }
     }
+    if (!(probe_skip & 2)) __syncthreads();  // the previous iteration's last weight-gradient reads of the scratch are done
+    // Every layer: the wave stores its (Dout, X) tiles, runs its own data-gradient GEMM (registers + weights only) while
+    // the stores drain, THEN meets the workgroup and takes its share of the weight gradient — so both barrier intervals
+    // of a layer hold MFMA work (the store -> barrier interval used to hold none).
     store_rows<1>(Sd, g_rgbp, j, g);
     store_rows<4>(Sx, A.hb, j, g);
-    if (!(probe_skip & 2)) __syncthreads();
-    if (!(probe_skip & 1)) coop_dw<1>(dW_h2, &db_h2, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
     v4f g_hb[4];
     zero_tiles<4>(g_hb);
     if (!(probe_skip & 4)) rows_gemm_bwd<4, 1, kLd64>(W + kRowHead2, g_rgbp, g_hb, j, g);
     relu_mask<4>(g_hb, A.hb);
+    if (!(probe_skip & 2)) __syncthreads();
+    if (!(probe_skip & 1)) coop_dw<1>(dW_h2, &db_h2, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 4 + 10 * (int)it);
 
     // ---- head layer 1 (64 -> 64) ----
     store_rows<4>(Sd, g_hb, j, g);
     store_rows<4>(Sx, A.ha, j, g);
-    if (!(probe_skip & 2)) __syncthreads();
-    if (!(probe_skip & 1)) coop_dw<2>(dW_h1, &db_h1, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
     v4f g_ha[4];
     zero_tiles<4>(g_ha);
     if (!(probe_skip & 4)) rows_gemm_bwd<4, 4, kLd64>(W + kRowHead1, g_hb, g_ha, j, g);
     relu_mask<4>(g_ha, A.ha);
+    if (!(probe_skip & 2)) __syncthreads();
+    if (!(probe_skip & 1)) coop_dw<2>(dW_h1, &db_h1, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 5 + 10 * (int)it);
 
     // ---- head layer 0 (slots 64 -> 64) ----
     store_rows<4>(Sd, g_ha, j, g);
     store_rows<4>(Sx, A.hin, j, g);
-    if (!(probe_skip & 2)) __syncthreads();
-    if (!(probe_skip & 1)) coop_dw<2>(dW_h0, &db_h0, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
     v4f g_hin[4];
     zero_tiles<4>(g_hin);
     // input tile 0 is the SH block: it carries no gradient, so only columns 16..63 (tiles 1..3) are formed
     if (!(probe_skip & 4)) rows_gemm_bwd<3, 4, kLd64>(W + kRowHead0 + 16, g_ha, g_hin + 1, j, g);
+    if (!(probe_skip & 2)) __syncthreads();
+    if (!(probe_skip & 1)) coop_dw<2>(dW_h0, &db_h0, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 6 + 10 * (int)it);
 
@@ -695,20 +699,18 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     }
     store_rows<1>(Sd, g_o16, j, g);
     store_rows<4>(Sx, A.h1, j, g);
-    if (!(probe_skip & 2)) __syncthreads();
-    if (!(probe_skip & 1)) coop_dw<1>(dW_b1, &db_b1, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
     v4f g_h1[4];
     zero_tiles<4>(g_h1);
     if (!(probe_skip & 4)) rows_gemm_bwd<4, 1, kLd64>(W + kRowBase1, g_o16, g_h1, j, g);
     relu_mask<4>(g_h1, A.h1);
+    if (!(probe_skip & 2)) __syncthreads();
+    if (!(probe_skip & 1)) coop_dw<1>(dW_b1, &db_b1, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 7 + 10 * (int)it);
 
     // ---- base layer 0 (32 -> 64) ----
     store_rows<4>(Sd, g_h1, j, g);
     store_rows<2>(Sx, A.enc, j, g);
-    if (!(probe_skip & 2)) __syncthreads();
-    if (!(probe_skip & 1)) coop_dw<1>(dW_b0, &db_b0, own_m1 == 0, scratch, 0, kCoopWaves, own_n, own_m1, j, g);
     v4f g_enc[2];
     zero_tiles<2>(g_enc);
     if (!(probe_skip & 4)) rows_gemm_bwd<2, 4, kLd32>(W + kRowBase0, g_h1, g_enc, j, g);
@@ -719,12 +721,15 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
         for (int r = 0; r < 4; ++r) denc[(int64_t)(16 * t + 4 * g + r) * M + ti.p] = g_enc[t][r];
     }
     if (!(probe_skip & 2)) __syncthreads();
+    if (!(probe_skip & 1)) coop_dw<1>(dW_b0, &db_b0, own_m1 == 0, scratch, 0, kCoopWaves, own_n, own_m1, j, g);
+    // no barrier here: the next writer of the scratch is the next iteration's head layer 2, behind its own barrier
     PROBE_STAMP(kCoopWaves, 8 + 10 * (int)it);
   }
   PROBE_STAMP(kCoopWaves, 62);
 
   // ---- the two point-halves of the 1 x 4 layers meet in LDS (scratch is free now) ---------------------------------
   float* stash = scratch;  // [2 layers][4 tiles][64 lanes][4] + [2][4][64] bias partials
+  __syncthreads();         // the last weight-gradient reads of the scratch are done
   if (own_half == 1) {
     *reinterpret_cast<v4f*>(stash + ((0 * 4 + own_q) * 64 + lane) * 4) = dW_h2[0];
     *reinterpret_cast<v4f*>(stash + ((1 * 4 + own_q) * 64 + lane) * 4) = dW_b1[0];
