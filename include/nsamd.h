@@ -243,14 +243,15 @@ int nsamd_linear_bwd(const float* x, const float* W, const float* y, const float
  * Samplers (model_components/ray_samplers.py). Bins are [num_rays, S+1]; `s` = normalised spacing domain,
  * `t` = euclidean distance. lin_host-free: `edges` is the device copy of torch.linspace(0,1,S+1) and `u_base` of
  * torch.linspace(0, 1-1/(S+1), S+1) (the host evaluates them with torch so the fp32 values are the reference's).
- * jitter (nullable = eval) is the raw U[0,1) draw per ray ([num_rays], single_jitter).
+ * jitter (nullable = eval) is the raw U[0,1) draw: one per ray ([num_rays], single_jitter=True, jitter_per_edge = 0) or
+ * one per bin edge ([num_rays, S+1], single_jitter=False, jitter_per_edge = 1; ray_samplers.py:104-107, 318-322).
  * ------------------------------------------------------------------------------------------------------------ */
 
 /* SpacedSampler.generate_ray_samples (ray_samplers.py:78-128): spacing 0 = UniformLinDispPiecewiseSampler
  * (:225-248, nerfacto default), 1 = UniformSampler (:131-155, the Blender benchmark recipe). */
 int nsamd_piecewise_bins(const float* nears, const float* fars, const float* edges, const float* jitter,
-                         int64_t num_rays, int32_t S, int spacing, float* s_bins, float* t_bins,
-                         nsamd_stream_t stream);
+                         int32_t jitter_per_edge, int64_t num_rays, int32_t S, int spacing, float* s_bins,
+                         float* t_bins, nsamd_stream_t stream);
 
 /* RaySamples.get_weights (cameras/rays.py:129-152): left-to-right cumsum per ray. */
 int nsamd_weights_fwd(const float* t_bins, const float* density, int64_t num_rays, int32_t S, float* weights,
@@ -258,8 +259,10 @@ int nsamd_weights_fwd(const float* t_bins, const float* density, int64_t num_ray
 int nsamd_weights_bwd(const float* t_bins, const float* density, const float* dweights, int64_t num_rays,
                       int32_t S, float* ddensity, nsamd_stream_t stream);
 
-/* PDFSampler.generate_ray_samples, include_original=False (ray_samplers.py:276-372) preceded by the anneal
- * pow(weights, anneal) (ray_samplers.py:601; skipped when anneal == 1). inds (nullable) receives the
+/* PDFSampler.generate_ray_samples (ray_samplers.py:276-372) preceded by the anneal pow(weights, anneal)
+ * (ray_samplers.py:601; skipped when anneal == 1). include_original = 0: s_bins / t_bins are [num_rays, S+1] (the
+ * proposal sampler); 1: the new edges merged with the existing ones and sorted (ray_samplers.py:356-357, vanilla-nerf's
+ * fine sampler) -> [num_rays, S_prev + S + 2]. inds (nullable) receives the
  * searchsorted(side="right") result as int32 [num_rays, S+1]. u_offset = (float)(1.0 / (2 * (S+1))) is the eval-mode
  * offset (ray_samplers.py:327), rounded double->float by the host like torch rounds the Python scalar.
  * anneal_dev (nullable): device copy of the anneal exponent; overrides `anneal` so that a captured hipGraph of the
@@ -268,8 +271,8 @@ int nsamd_weights_bwd(const float* t_bins, const float* density, const float* dw
 int nsamd_pdf_resample(const float* s_bins_prev, const float* weights, int32_t S_prev, const float* u_base,
                        const float* jitter, const float* nears, const float* fars, float anneal,
                        const float* anneal_dev, float histogram_padding, float eps, float u_offset, int spacing,
-                       int64_t num_rays, int32_t S, float* s_bins, float* t_bins, int32_t* inds,
-                       nsamd_stream_t stream);
+                       int32_t jitter_per_edge, int32_t include_original, int64_t num_rays, int32_t S, float* s_bins,
+                       float* t_bins, int32_t* inds, nsamd_stream_t stream);
 
 /* One proposal level of ProposalNetworkSampler.generate_ray_samples (ray_samplers.py:576-617) in a single launch:
  * weights = RaySamples.get_weights(density) of the level's samples (t_bins_prev), its median depth (nullable;

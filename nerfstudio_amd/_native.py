@@ -79,10 +79,10 @@ _SIGNATURES = {
     "nsamd_field_mlp_bwd_saved": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, vp, FieldMlpGrads, vp, i64, vp],
     "nsamd_linear_fwd": [vp, vp, vp, i64, i32, i32, C.c_int, vp, vp],
     "nsamd_linear_bwd": [vp, vp, vp, vp, i64, i32, i32, C.c_int, vp, vp, vp, vp],
-    "nsamd_piecewise_bins": [vp, vp, vp, vp, i64, i32, C.c_int, vp, vp, vp],
+    "nsamd_piecewise_bins": [vp, vp, vp, vp, i32, i64, i32, C.c_int, vp, vp, vp],
     "nsamd_weights_fwd": [vp, vp, i64, i32, vp, vp],
     "nsamd_weights_bwd": [vp, vp, vp, i64, i32, vp, vp],
-    "nsamd_pdf_resample": [vp, vp, i32, vp, vp, vp, vp, f32, vp, f32, f32, f32, C.c_int, i64, i32, vp, vp, vp, vp],
+    "nsamd_pdf_resample": [vp, vp, i32, vp, vp, vp, vp, f32, vp, f32, f32, f32, C.c_int, i32, i32, i64, i32, vp, vp, vp, vp],
     "nsamd_proposal_resample": [vp, vp, vp, i32, vp, vp, vp, vp, f32, vp, f32, f32, f32, C.c_int, i64, i32, vp, vp, vp, vp, vp],
     "nsamd_composite_fwd": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), C.c_int, vp, vp, vp, vp, vp, vp, vp],
     "nsamd_render_train": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -21,8 +21,8 @@ __global__ __launch_bounds__(kThreads) void piecewise_bins_kernel(const float* _
                                                                   const float* __restrict__ fars,
                                                                   const float* __restrict__ edges,
                                                                   const float* __restrict__ jitter,
-                                                                  int64_t num_rays, int S, int spacing,
-                                                                  float* __restrict__ s_bins,
+                                                                  int jitter_per_edge, int64_t num_rays, int S,
+                                                                  int spacing, float* __restrict__ s_bins,
                                                                   float* __restrict__ t_bins) {
   // one wavefront per ray (4 rays per workgroup): per-ray scalars are computed once, the edge index is a 32-bit loop
   // counter (the flat-index version spent its time in 64-bit divisions)
@@ -31,7 +31,8 @@ __global__ __launch_bounds__(kThreads) void piecewise_bins_kernel(const float* _
   if (ray >= num_rays) return;
   const float s_near = spacing_fn_mode(spacing, nears[ray]);
   const float s_far = spacing_fn_mode(spacing, fars[ray]);
-  const float jit = jitter != nullptr ? jitter[ray] : 0.0f;
+  // single_jitter: one draw per ray; otherwise one per bin edge, [num_rays, S+1] (ray_samplers.py:104-107)
+  const float jit = (jitter != nullptr && !jitter_per_edge) ? jitter[ray] : 0.0f;
   float* sb = s_bins + ray * (S + 1);
   float* tb = t_bins + ray * (S + 1);
   for (int i = lane; i <= S; i += 64) {
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(kThreads) void piecewise_bins_kernel(const float* _
       // lower = [edges[0], centres], upper = [centres, edges[S]]   (ray_samplers.py:108-110)
       const float lower = (i == 0) ? edges[0] : (edges[i] + edges[i - 1]) / 2.0f;
       const float upper = (i == S) ? edges[S] : (edges[i + 1] + edges[i]) / 2.0f;
-      b = lower + (upper - lower) * jit;
+      b = lower + (upper - lower) * (jitter_per_edge ? jitter[ray * (S + 1) + i] : jit);
     }
     sb[i] = b;
     tb[i] = spacing_to_euclidean_mode(spacing, b, s_near, s_far);
@@ -153,9 +154,9 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// PDFSampler.generate_ray_samples, include_original=False (ray_samplers.py:276-372)
+// PDFSampler.generate_ray_samples (ray_samplers.py:276-372)
 // ---------------------------------------------------------------------------------------------------------------
-// LDS: per wave  w[S_prev], cdf[S_prev + 1].
+// LDS: per wave  w[S_prev], cdf[S_prev + 1] (+ the S + 1 new edges when they are merged with the existing ones).
 // kFused: the launch also does the level's RaySamples.get_weights (weights_out) and, optionally, its median depth
 // (DepthRenderer "median", renderers.py:354-364; models/nerfacto.py:346-347 renders one per proposal level) — the three
 // launches per proposal level of the training step in one, the weight row never leaves the wave.
@@ -167,14 +168,16 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     float u_offset, int spacing, int64_t num_rays, int S,
     float* __restrict__ s_bins, float* __restrict__ t_bins, int32_t* __restrict__ inds,
     const float* __restrict__ t_bins_prev, const float* __restrict__ density, float* __restrict__ weights_out,
-    float* __restrict__ depth_median) {
+    float* __restrict__ depth_median, int jitter_per_edge, int include_original) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kWaves + wave;
   if (ray >= num_rays) return;  // wave-uniform; no workgroup barrier below
-  float* w = lds + (size_t)wave * (2 * S_prev + 1);
+  const int row_floats = 2 * S_prev + 1 + (include_original ? S + 1 : 0);
+  float* w = lds + (size_t)wave * row_floats;
   float* cdf = w + S_prev;
+  float* fresh = cdf + S_prev + 1;  // include_original only
   const float anneal = anneal_dev ? anneal_dev[0] : anneal_host;  // device copy: graph-replayable schedules
 
   if (kFused) {
@@ -245,9 +248,11 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
   const float s_near = spacing_fn_mode(spacing, nears[ray]);
   const float s_far = spacing_fn_mode(spacing, fars[ray]);
   const float* bp = s_bins_prev + ray * (S_prev + 1);
+  const int out_edges = include_original ? nb + S_prev + 1 : nb;
   for (int j = lane; j < nb; j += 64) {
     float u = u_base[j];
-    if (jitter != nullptr) u = u + jitter[ray] / (float)nb;  // rand / num_bins   (ray_samplers.py:320)
+    // rand / num_bins: one draw per ray (single_jitter) or per new edge   (ray_samplers.py:318-322)
+    if (jitter != nullptr) u = u + jitter[jitter_per_edge ? ray * nb + j : ray] / (float)nb;
     else u = u + u_offset;                                    // 1 / (2 num_bins)  (ray_samplers.py:327), host-rounded
     // searchsorted(side="right"): number of cdf entries <= u
     int lo = 0, hi = S_prev + 1;
@@ -263,9 +268,43 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     float t = nan_to_num((u - c0) / (c1 - c0), 0.0f);
     t = fminf(fmaxf(t, 0.0f), 1.0f);
     const float b = b0 + t * (b1 - b0);
-    s_bins[ray * nb + j] = b;
-    t_bins[ray * nb + j] = spacing_to_euclidean_mode(spacing, b, s_near, s_far);
+    if (include_original) {
+      fresh[j] = b;
+    } else {
+      s_bins[ray * nb + j] = b;
+      t_bins[ray * nb + j] = spacing_to_euclidean_mode(spacing, b, s_near, s_far);
+    }
     if (inds != nullptr) inds[ray * nb + j] = lo;
+  }
+  if (include_original) {
+    // sort(cat(existing, new)) (ray_samplers.py:356-357): both lists are ascending, so an element's place is its own index
+    // plus the number of elements of the other list in front of it (existing edges first on ties — equal values either way)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* so = s_bins + ray * out_edges;
+    float* to = t_bins + ray * out_edges;
+    for (int i = lane; i <= S_prev; i += 64) {  // existing edge i: new edges strictly below it
+      const float v = bp[i];
+      int lo = 0, hi = nb;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (fresh[mid] < v) lo = mid + 1;
+        else hi = mid;
+      }
+      so[i + lo] = v;
+      to[i + lo] = spacing_to_euclidean_mode(spacing, v, s_near, s_far);
+    }
+    for (int j = lane; j < nb; j += 64) {  // new edge j: existing edges at or below it
+      const float v = fresh[j];
+      int lo = 0, hi = S_prev + 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (bp[mid] <= v) lo = mid + 1;
+        else hi = mid;
+      }
+      so[j + lo] = v;
+      to[j + lo] = spacing_to_euclidean_mode(spacing, v, s_near, s_far);
+    }
   }
 }
 
@@ -276,15 +315,15 @@ using namespace nsamd;
 static inline unsigned ray_blocks(int64_t num_rays) { return (unsigned)((num_rays + kWaves - 1) / kWaves); }
 
 extern "C" int nsamd_piecewise_bins(const float* nears, const float* fars, const float* edges, const float* jitter,
-                                    int64_t num_rays, int32_t S, int spacing, float* s_bins, float* t_bins,
-                                    nsamd_stream_t stream) {
+                                    int32_t jitter_per_edge, int64_t num_rays, int32_t S, int spacing, float* s_bins,
+                                    float* t_bins, nsamd_stream_t stream) {
   NSAMD_REQUIRE(num_rays >= 0 && S > 0 && (spacing == 0 || spacing == 1));
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(nears && fars && edges && s_bins && t_bins);
   const int64_t blocks64 = (num_rays + (kThreads / 64) - 1) / (kThreads / 64);
   if (blocks64 > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
-  piecewise_bins_kernel<<<(unsigned)blocks64, kThreads, 0, (hipStream_t)stream>>>(nears, fars, edges, jitter, num_rays, S,
-                                                                                  spacing, s_bins, t_bins);
+  piecewise_bins_kernel<<<(unsigned)blocks64, kThreads, 0, (hipStream_t)stream>>>(
+      nears, fars, edges, jitter, jitter_per_edge != 0, num_rays, S, spacing, s_bins, t_bins);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }
@@ -316,16 +355,18 @@ extern "C" int nsamd_weights_bwd(const float* t_bins, const float* density, cons
 extern "C" int nsamd_pdf_resample(const float* s_bins_prev, const float* weights, int32_t S_prev,
                                   const float* u_base, const float* jitter, const float* nears, const float* fars,
                                   float anneal, const float* anneal_dev, float histogram_padding, float eps,
-                                  float u_offset, int spacing, int64_t num_rays, int32_t S, float* s_bins,
-                                  float* t_bins, int32_t* inds, nsamd_stream_t stream) {
+                                  float u_offset, int spacing, int32_t jitter_per_edge, int32_t include_original,
+                                  int64_t num_rays, int32_t S, float* s_bins, float* t_bins, int32_t* inds,
+                                  nsamd_stream_t stream) {
   NSAMD_REQUIRE(num_rays >= 0 && S > 0 && S_prev > 0 && (spacing == 0 || spacing == 1));
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(s_bins_prev && weights && u_base && nears && fars && s_bins && t_bins);
-  if (S_prev > 1024) return NSAMD_ERR_UNSUPPORTED;
-  const size_t lds = sizeof(float) * kWaves * (2 * (size_t)S_prev + 1);
+  if (S_prev > 1024 || S > 4096) return NSAMD_ERR_UNSUPPORTED;
+  const size_t lds = sizeof(float) * kWaves * (2 * (size_t)S_prev + 1 + (include_original ? (size_t)S + 1 : 0));
   pdf_resample_kernel<false><<<ray_blocks(num_rays), kThreads, lds, (hipStream_t)stream>>>(
       s_bins_prev, weights, S_prev, u_base, jitter, nears, fars, anneal, anneal_dev, histogram_padding, eps, u_offset,
-      spacing, num_rays, S, s_bins, t_bins, inds, nullptr, nullptr, nullptr, nullptr);
+      spacing, num_rays, S, s_bins, t_bins, inds, nullptr, nullptr, nullptr, nullptr, jitter_per_edge != 0,
+      include_original != 0);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }
@@ -343,7 +384,7 @@ extern "C" int nsamd_proposal_resample(const float* t_bins_prev, const float* s_
   const size_t lds = sizeof(float) * kWaves * (2 * (size_t)S_prev + 1);
   pdf_resample_kernel<true><<<ray_blocks(num_rays), kThreads, lds, (hipStream_t)stream>>>(
       s_bins_prev, nullptr, S_prev, u_base, jitter, nears, fars, anneal, anneal_dev, histogram_padding, eps, u_offset,
-      spacing, num_rays, S, s_bins, t_bins, nullptr, t_bins_prev, density, weights, depth_median);
+      spacing, num_rays, S, s_bins, t_bins, nullptr, t_bins_prev, density, weights, depth_median, 0, 0);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

@@ -7,6 +7,7 @@ from torch import Tensor, nn
 from .. import _native as N
 from .. import functional as F
 from ..cameras.rays import RaySamples
+from ..field_components.activations import trunc_exp
 from ..field_components.base_field_component import check_implementation
 from ..field_components.encodings import HashEncoding
 from ..field_components.mlp import MLP
@@ -45,9 +46,7 @@ class HashMLPDensityField(Field):
     ) -> None:
         super().__init__()
         check_implementation(implementation, "HashMLPDensityField")
-        if use_linear:
-            raise ValueError("HashMLPDensityField(use_linear=True) is not built for the hip backend")
-        if num_layers != 2:
+        if not use_linear and num_layers != 2:
             raise ValueError("the hip density head is MLP(num_layers=2): in -> hidden -> 1")
         self.register_buffer("aabb", aabb)
         self.spatial_distortion = spatial_distortion
@@ -64,21 +63,31 @@ class HashMLPDensityField(Field):
             features_per_level=features_per_level,
             implementation=implementation,
         )
-        network = MLP(
-            in_dim=self.encoding.get_out_dim(),
-            num_layers=num_layers,
-            layer_width=hidden_dim,
-            out_dim=1,
-            activation=nn.ReLU(),
-            out_activation=None,
-            implementation=implementation,
-        )
-        self.mlp_base = torch.nn.Sequential(self.encoding, network)
+        if not self.use_linear:
+            network = MLP(
+                in_dim=self.encoding.get_out_dim(),
+                num_layers=num_layers,
+                layer_width=hidden_dim,
+                out_dim=1,
+                activation=nn.ReLU(),
+                out_activation=None,
+                implementation=implementation,
+            )
+            self.mlp_base = torch.nn.Sequential(self.encoding, network)
+        else:  # density_fields.py:81-84: one dense layer on the hash features
+            self.linear = torch.nn.Linear(self.encoding.get_out_dim(), 1)
         self._transform = transform_of(spatial_distortion)
         self._box = N.make_aabb(aabb)  # host copy of the scene box: no device sync on the hot path
 
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, None]:
         spec, shape = point_spec(ray_samples)
+        if self.use_linear:
+            # gather kernel (normalisation + selector fused) -> dense layer kernel -> trunc_exp; not a fused launch: this is
+            # the reference's ablation setting (density_fields.py:107-109), the proposal networks of nerfacto use the MLP
+            enc, sel = F.spec_encode(spec, self.encoding.hash_table, self.encoding.spec, self._transform, self._box)
+            pre = F.linear(enc, self.linear.weight, self.linear.bias)
+            density = self.average_init_density * trunc_exp(pre) * sel[:, None]
+            return density.view(*shape, 1), None
         mlp: MLP = self.mlp_base[1]
         density = F.density_field(spec, self.encoding.hash_table, *mlp.param_tensors(), self.encoding.spec,
                                   self._transform, self._box, self.average_init_density)

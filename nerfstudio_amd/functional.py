@@ -273,6 +273,50 @@ def hashgrid_encode(x: Tensor, table: Tensor, grid: HashGridSpec) -> Tensor:
     return _HashEncodeFn.apply(x.reshape(-1, 3), table, grid).view(*shape, grid.out_dim)
 
 
+class _SpecEncodeFn(torch.autograd.Function):
+    """Hash features of sample points given as a PointSpec (positions or rays + bins), with the fields' position
+    normalisation (aabb or L-inf contraction) and selector fused into the gather kernel. -> (enc [M, 2L], selector [M])."""
+
+    @staticmethod
+    def forward(ctx, positions, origins, directions, t_bins, table, grid: HashGridSpec, transform: int, aabb):
+        spec = _spec_from_flat(positions, origins, directions, t_bins)
+        N.require_cuda(table)
+        M = spec.num_points
+        enc = torch.empty((M, grid.out_dim), device=table.device, dtype=torch.float32)
+        sel = torch.empty((M,), device=table.device, dtype=torch.float32)
+        box = aabb if isinstance(aabb, N.Aabb) else N.make_aabb(aabb)
+        N.check(N.load().nsamd_hashgrid_encode_fwd(spec.native(), M, transform, box, N.ptr(table), grid.native(), N.ptr(enc),
+                                                   grid.out_dim, 1, N.ptr(sel), N.stream()), "hashgrid_encode_fwd")
+        ctx.spec, ctx.grid, ctx.transform, ctx.box, ctx.table_ref = spec, grid, transform, box, table
+        ctx.save_for_backward(table)
+        ctx.mark_non_differentiable(sel)
+        return enc, sel
+
+    @staticmethod
+    def backward(ctx, genc: Tensor, _gsel):
+        (table,) = ctx.saved_tensors
+        spec: PointSpec = ctx.spec
+        M = spec.num_points
+        genc = _f32c(genc)
+        need_pos = any(ctx.needs_input_grad[:3])
+        ttable, rtable = _grad_target(ctx.table_ref, ctx.needs_input_grad[4])
+        dpos = torch.empty((M, 3), device=table.device, dtype=torch.float32) if need_pos else None
+        if ttable is not None or dpos is not None:
+            ws, ws_n = _scatter_workspace(ctx.grid, table.device, M)
+            N.check(N.load().nsamd_hashgrid_encode_bwd(spec.native(), M, ctx.transform, ctx.box, N.ptr(table),
+                                                       ctx.grid.native(), N.ptr(genc), ctx.grid.out_dim, 1, N.ptr(ttable),
+                                                       N.ptr(dpos), N.ptr(ws), ws_n, N.stream()), "hashgrid_encode_bwd")
+        gp, go, gd = _position_grads(spec, dpos) if dpos is not None else (None, None, None)
+        return gp, go, gd, None, rtable, None, None, None
+
+
+def spec_encode(spec: PointSpec, table: Tensor, grid: HashGridSpec, transform: int, aabb) -> Tuple[Tensor, Tensor]:
+    """(hash features `[M, 2L]`, selector `[M]`) of the points of `spec` after the field's position normalisation
+    (fields/density_fields.py:95-103 + encodings.py:417-458) — the encoding half of a field, for heads that are not one
+    of the fused MLP shapes."""
+    return _SpecEncodeFn.apply(spec.positions, spec.origins, spec.directions, spec.t_bins, table, grid, transform, aabb)
+
+
 def sh4_encode(directions: Tensor) -> Tensor:
     """SHEncoding(levels=4).pytorch_fwd (encodings.py:791-794); no gradient (it is @torch.no_grad there)."""
     N.require_cuda(directions)
@@ -517,17 +561,29 @@ def _linspace(kind: str, num_samples: int, device) -> Tensor:
 def piecewise_bins(nears: Tensor, fars: Tensor, num_samples: int, jitter: Optional[Tensor], spacing: int = 0
                    ) -> Tuple[Tensor, Tensor]:
     """UniformLinDispPiecewiseSampler (ray_samplers.py:78-128, 225-248). nears/fars `[N]` or `[N,1]`;
-    jitter = the single-jitter U[0,1) draw per ray or None (eval). Returns (s_bins, t_bins) `[N, S+1]`."""
+    jitter = the U[0,1) draws: `[N,1]` (single_jitter), `[N,S+1]` (one per bin edge) or None (eval). Returns
+    (s_bins, t_bins) `[N, S+1]`."""
     N.require_cuda(nears, fars, jitter)
     nears, fars = _f32c(nears.reshape(-1)), _f32c(fars.reshape(-1))
-    jitter = _f32c(jitter.reshape(-1)) if jitter is not None else None
     n = nears.shape[0]
+    per_edge = _jitter_layout(jitter, n, num_samples + 1)
+    jitter = _f32c(jitter.reshape(-1)) if jitter is not None else None
     s_bins = torch.empty((n, num_samples + 1), device=nears.device, dtype=torch.float32)
     t_bins = torch.empty_like(s_bins)
     edges = _linspace("edges", num_samples, nears.device)
-    N.check(N.load().nsamd_piecewise_bins(N.ptr(nears), N.ptr(fars), N.ptr(edges), N.ptr(jitter), n, num_samples,
+    N.check(N.load().nsamd_piecewise_bins(N.ptr(nears), N.ptr(fars), N.ptr(edges), N.ptr(jitter), per_edge, n, num_samples,
                                           int(spacing), N.ptr(s_bins), N.ptr(t_bins), N.stream()), "piecewise_bins")
     return s_bins, t_bins
+
+
+def _jitter_layout(jitter: Optional[Tensor], num_rays: int, num_edges: int) -> int:
+    """0: one draw per ray (or none), 1: one per bin edge; anything else is a caller error."""
+    if jitter is None or jitter.numel() == num_rays:
+        return 0
+    if jitter.numel() != num_rays * num_edges:
+        raise ValueError(f"jitter must hold one draw per ray ({num_rays}) or per bin edge ({num_rays} x {num_edges}), "
+                         f"got {tuple(jitter.shape)}")
+    return 1
 
 
 class _WeightsFn(torch.autograd.Function):
@@ -560,25 +616,29 @@ def weights_from_density(t_bins: Tensor, density: Tensor) -> Tensor:
 @torch.no_grad()
 def pdf_resample(s_bins_prev: Tensor, weights: Tensor, num_samples: int, jitter: Optional[Tensor], nears: Tensor,
                  fars: Tensor, anneal: float = 1.0, histogram_padding: float = 0.01, eps: float = 1e-5,
-                 return_indices: bool = False, anneal_dev: Optional[Tensor] = None, spacing: int = 0):
-    """PDFSampler.generate_ray_samples(include_original=False) (ray_samplers.py:276-372) incl. the weight anneal
-    (ray_samplers.py:601). Returns (s_bins, t_bins[, inds]) with `[N, S+1]` each; inds int32."""
+                 return_indices: bool = False, anneal_dev: Optional[Tensor] = None, spacing: int = 0,
+                 include_original: bool = False):
+    """PDFSampler.generate_ray_samples (ray_samplers.py:276-372) incl. the weight anneal (ray_samplers.py:601). Returns
+    (s_bins, t_bins[, inds]): `[N, S+1]` edges, or `[N, S_prev+S+2]` with include_original (the new edges merged into the
+    existing ones, :356-357); inds int32 `[N, S+1]` (the searchsorted result of the new edges). jitter: `[N,1]`
+    (single_jitter), `[N,S+1]` (one per new edge) or None (eval)."""
     N.require_cuda(s_bins_prev, weights, nears, fars, jitter)
     s_bins_prev, weights = _f32c(s_bins_prev), _f32c(weights.detach())
     nears, fars = _f32c(nears.reshape(-1)), _f32c(fars.reshape(-1))
-    jitter = _f32c(jitter.reshape(-1)) if jitter is not None else None
     n, s_prev = weights.shape
     nb = num_samples + 1
+    per_edge = _jitter_layout(jitter, n, nb)
+    jitter = _f32c(jitter.reshape(-1)) if jitter is not None else None
     dev = weights.device
-    s_bins = torch.empty((n, nb), device=dev, dtype=torch.float32)
+    s_bins = torch.empty((n, nb + (s_prev + 1 if include_original else 0)), device=dev, dtype=torch.float32)
     t_bins = torch.empty_like(s_bins)
     inds = torch.empty((n, nb), device=dev, dtype=torch.int32) if return_indices else None
     u_base = _linspace("u", num_samples, dev)
     N.check(N.load().nsamd_pdf_resample(N.ptr(s_bins_prev), N.ptr(weights), s_prev, N.ptr(u_base), N.ptr(jitter),
                                         N.ptr(nears), N.ptr(fars), float(anneal), N.ptr(anneal_dev),
                                         float(histogram_padding), float(eps),
-                                        1.0 / (2 * nb), int(spacing), n, num_samples, N.ptr(s_bins), N.ptr(t_bins), N.ptr(inds),
-                                        N.stream()), "pdf_resample")
+                                        1.0 / (2 * nb), int(spacing), per_edge, int(bool(include_original)), n, num_samples,
+                                        N.ptr(s_bins), N.ptr(t_bins), N.ptr(inds), N.stream()), "pdf_resample")
     return (s_bins, t_bins, inds) if return_indices else (s_bins, t_bins)
 
 

@@ -48,8 +48,9 @@ class UniformLinDispPiecewiseSampler(Sampler):
 
     def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, num_samples: Optional[int] = None,
                              jitter: Optional[Tensor] = None) -> RaySamples:
-        """`jitter` (optional, `[num_rays,1]` in [0,1)) injects the random draw — used by the parity tests; by
-        default it is drawn here with torch.rand as the reference does (ray_samplers.py:103-107)."""
+        """`jitter` (optional, in [0,1): `[num_rays,1]` with single_jitter, else `[num_rays, num_samples+1]`) injects the
+        random draw — used by the parity tests; by default it is drawn here with torch.rand as the reference does
+        (ray_samplers.py:103-107)."""
         assert ray_bundle is not None
         assert ray_bundle.nears is not None
         assert ray_bundle.fars is not None
@@ -57,10 +58,9 @@ class UniformLinDispPiecewiseSampler(Sampler):
         assert num_samples is not None
         num_rays = ray_bundle.origins.shape[0]
         if self.train_stratified and self.training:
-            if not self.single_jitter:
-                raise NotImplementedError("the hip samplers implement single_jitter=True (the nerfacto setting)")
             if jitter is None:
-                jitter = torch.rand((num_rays, 1), dtype=torch.float32, device=ray_bundle.origins.device)
+                jitter = torch.rand((num_rays, 1 if self.single_jitter else num_samples + 1), dtype=torch.float32,
+                                    device=ray_bundle.origins.device)
         else:
             jitter = None
         s_bins, t_bins = F.piecewise_bins(ray_bundle.nears, ray_bundle.fars, num_samples, jitter, self.spacing)
@@ -81,8 +81,6 @@ class PDFSampler(Sampler):
     def __init__(self, num_samples: Optional[int] = None, train_stratified: bool = True, single_jitter: bool = False,
                  include_original: bool = True, histogram_padding: float = 0.01) -> None:
         super().__init__(num_samples=num_samples)
-        if include_original:
-            raise NotImplementedError("the hip PDFSampler implements include_original=False (the proposal sampler)")
         self.train_stratified = train_stratified
         self.include_original = include_original
         self.histogram_padding = histogram_padding
@@ -100,10 +98,8 @@ class PDFSampler(Sampler):
         assert ray_samples.spacing_starts is not None and ray_samples.spacing_ends is not None, (
             "ray_sample spacing_starts and spacing_ends must be provided")
         if self.train_stratified and self.training:
-            if not self.single_jitter:
-                raise NotImplementedError("the hip samplers implement single_jitter=True (the nerfacto setting)")
             if jitter is None:
-                jitter = torch.rand((weights.shape[0], 1), device=weights.device)
+                jitter = torch.rand((weights.shape[0], 1 if self.single_jitter else num_samples + 1), device=weights.device)
         else:
             jitter = None
         pk = pack_of(ray_samples)
@@ -114,7 +110,10 @@ class PDFSampler(Sampler):
             existing = torch.cat([ray_samples.spacing_starts[..., 0], ray_samples.spacing_ends[..., -1:, 0]], dim=-1)
         s_bins, t_bins = F.pdf_resample(existing, weights[..., 0], num_samples, jitter, ray_bundle.nears, ray_bundle.fars,
                                         anneal=anneal, histogram_padding=self.histogram_padding, eps=eps,
-                                        anneal_dev=anneal_dev, spacing=spacing)
+                                        anneal_dev=anneal_dev, spacing=spacing, include_original=self.include_original)
+        if pk is None:
+            # samples of a foreign sampler: its own s -> t closure is the only statement of the spacing function
+            t_bins = ray_samples.spacing_to_euclidean_fn(s_bins)
         return samples_from_bins(ray_bundle, s_bins, t_bins, ray_samples.spacing_to_euclidean_fn, spacing)
 
 

@@ -260,7 +260,7 @@ class NerfactoTrainStep:
         if draw_jitter:
             self.jitter.uniform_()  # torch.rand per level and ray (ray_samplers.py:105, :322), drawn on the device
         S0 = self.counts[0]
-        ck(lib.nsamd_piecewise_bins(N.ptr(self.nears), N.ptr(self.fars), N.ptr(self.edges), N.ptr(self.jitter[0]), n, S0,
+        ck(lib.nsamd_piecewise_bins(N.ptr(self.nears), N.ptr(self.fars), N.ptr(self.edges), N.ptr(self.jitter[0]), 0, n, S0,
                                     self.spacing, N.ptr(self.s_bins[0]), N.ptr(self.t_bins[0]), st), "piecewise_bins")
         # ---- proposal levels ----
         for lvl in range(self.n_prop):

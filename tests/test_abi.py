@@ -52,12 +52,12 @@ def test_argument_validation_without_gpu():
     lib = N.load()
     assert lib.nsamd_sh4_encode(None, 5, None, None) == -1
     assert lib.nsamd_sh4_encode(None, 0, None, None) == 0  # empty input is a no-op
-    assert lib.nsamd_piecewise_bins(None, None, None, None, 4, 0, 0, None, None, None) == -1
+    assert lib.nsamd_piecewise_bins(None, None, None, None, 0, 4, 0, 0, None, None, None) == -1
     g = N.make_grid(40 if False else 16, 19, [16.0] * 16)
     pts = N.make_points()
     assert lib.nsamd_hashgrid_encode_fwd(pts, 16, 0, N.Aabb(), None, g, None, 1, 16, None, None) == -1
     assert lib.nsamd_weights_fwd(None, None, 0, 8, None, None) == 0
-    assert lib.nsamd_piecewise_bins(None, None, None, None, 4, 8, 7, None, None, None) == -1  # unknown spacing mode
+    assert lib.nsamd_piecewise_bins(None, None, None, None, 0, 4, 8, 7, None, None, None) == -1  # unknown spacing mode
     # host-only workspace query: grows with M, the write-only variant adds the worst-case spill list, the zero-state
     # prefix (header + per-tile cursors) is a few KB
     g19 = N.make_grid(16, 19, [16.0 * 1.38**i for i in range(16)])

@@ -188,6 +188,41 @@ def test_proposal_density_golden(F, golden):
         gclose(pos.grad, g[f"prop{i}_dpos"], 2e-3, "dpos", skip_ref_nan=True)
 
 
+@pytest.mark.parametrize("contract", [True, False])
+def test_density_field_use_linear(F, contract):
+    """HashMLPDensityField(use_linear=True) (density_fields.py:81-84, 107-109): hash features -> one dense layer ->
+    trunc_exp, against the oracle's pieces under torch autograd; state-dict names as the reference's."""
+    from nerfstudio_amd.field_components.spatial_distortions import SceneContraction
+    from nerfstudio_amd.fields.density_fields import HashMLPDensityField
+    from oracle.nerfacto_oracle import hash_level_scalings, hashgrid_encode, normalise_positions, trunc_exp
+
+    torch.manual_seed(3)
+    aabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+    fld = HashMLPDensityField(aabb, use_linear=True, spatial_distortion=SceneContraction(order=float("inf")) if contract else None,
+                              num_levels=5, max_res=128, base_res=16, log2_hashmap_size=12, average_init_density=0.7).cuda()
+    assert set(fld.state_dict()) >= {"linear.weight", "linear.bias", "encoding.hash_table"} and not hasattr(fld, "mlp_base")
+    with torch.no_grad():
+        fld.encoding.hash_table.uniform_(-0.5, 0.5)
+        fld.linear.weight.normal_(0, 0.5)
+    pos = ((torch.rand(300, 3) * 2 - 1) * (3.0 if contract else 1.2)).cuda().requires_grad_(True)
+    gout = torch.randn(300).cuda()
+    dens = fld.density_fn(pos)
+    assert dens.shape == (300, 1)
+    (dens[:, 0] * gout).sum().backward()
+    # oracle
+    table = fld.encoding.hash_table.detach().cpu().requires_grad_(True)
+    W, b = fld.linear.weight.detach().cpu().requires_grad_(True), fld.linear.bias.detach().cpu().requires_grad_(True)
+    p, sel = normalise_positions(pos.detach().cpu(), contract, aabb)
+    enc = hashgrid_encode(p, table, hash_level_scalings(5, 16, 128), 1 << 12)
+    ref = 0.7 * trunc_exp(enc @ W.t() + b)[:, 0] * sel
+    (ref * gout.cpu()).sum().backward()
+    assert 0.2 < float(sel.float().mean()) < 1.0 or contract
+    close(dens[:, 0], ref, atol=1e-6, rtol=2e-5, msg="density")
+    gclose(fld.encoding.hash_table.grad, table.grad, 1e-4, "dtable")
+    gclose(fld.linear.weight.grad, W.grad, 1e-4, "dW")
+    gclose(fld.linear.bias.grad, b.grad, 1e-4, "db")
+
+
 def test_nerfacto_field_golden(F, golden):
     from nerfstudio_amd.cameras.rays import Frustums, RaySamples
     from nerfstudio_amd.field_components.field_heads import FieldHeadNames
@@ -283,6 +318,62 @@ def test_samplers_golden_bit_exact(F, golden, mode):
     s2, t2 = F.pdf_resample(dev(g[f"{mode}_l1_s_bins"]), dev(w1), 48, dev(g["j2"]) if tr else None, nears, fars,
                             anneal=float(g["anneal"]))
     close(s2, g[f"{mode}_l2_s_bins"], atol=3e-6, rtol=0)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_sampler_variants_golden_vanilla(F, golden, mode):
+    """single_jitter=False (one draw per bin edge) and PDFSampler(include_original=True) against the REFERENCE's own
+    vanilla-nerf samplers (tests/golden/vanilla.npz: UniformSampler(64) -> PDFSampler(128, include_original=True) with
+    per-edge jitter, ray_samplers.py:104-107, 318-322, 356-357) and bit-exactly against the oracle."""
+    from oracle import vanilla_oracle as vo
+
+    g = golden("vanilla")
+    tr = mode == "train"
+    n = g["origins"].shape[0]
+    nears, fars = torch.full((n, 1), 2.0), torch.full((n, 1), 6.0)
+    j0, j1 = (T(g["j0"]), T(g["j1"])) if tr else (None, None)
+    s0, t0 = F.piecewise_bins(nears.cuda(), fars.cuda(), 64, dev(g["j0"]) if tr else None, spacing=1)
+    so, to = vo.uniform_bins(nears, fars, 64, j0)
+    exact(s0, so, "uniform s_bins vs oracle")
+    exact(t0, to, "uniform t_bins vs oracle")
+    close(t0, g[f"{mode}_t_bins_coarse"], atol=1e-6, rtol=0, msg="uniform t_bins vs reference")
+    w = T(g[f"{mode}_weights_coarse"])
+    s1, t1, i1 = F.pdf_resample(s0, w.cuda(), 128, dev(g["j1"]) if tr else None, nears.cuda(), fars.cuda(), spacing=1,
+                                include_original=True, return_indices=True)
+    assert s1.shape == (n, 64 + 128 + 2) and i1.shape == (n, 129)
+    sm, tm = vo.pdf_resample_with_original(so, w, nears, fars, 128, j1)
+    exact(s1, sm, "merged s_bins vs oracle")
+    exact(t1, tm, "merged t_bins vs oracle")
+    assert bool((s1[:, 1:] >= s1[:, :-1]).all()), "merged edges are sorted"
+    mism = int((i1.cpu().numpy() != g[f"{mode}_pdf_inds"]).sum())
+    assert mism <= 4, f"{mism} searchsorted indices differ from the reference"
+    close(s1, g[f"{mode}_s_bins_fine"], atol=2e-6, rtol=0, msg="merged s_bins vs reference")
+    close(t1, g[f"{mode}_t_bins_fine"], atol=1e-5, rtol=0, msg="merged t_bins vs reference")
+
+
+def test_sampler_variant_modules():
+    """The mirror classes with the reference's defaults (single_jitter=False, include_original=True): shapes, sortedness,
+    and the draw layout (one per edge)."""
+    from nerfstudio_amd.cameras.rays import RayBundle
+    from nerfstudio_amd.model_components.ray_samplers import PDFSampler, UniformSampler
+
+    n = 37
+    rb = RayBundle(origins=torch.zeros(n, 3).cuda(), directions=torch.nn.functional.normalize(torch.randn(n, 3), dim=-1).cuda(),
+                   pixel_area=torch.ones(n, 1).cuda(), nears=torch.full((n, 1), 2.0).cuda(), fars=torch.full((n, 1), 6.0).cuda())
+    us, ps = UniformSampler(num_samples=64), PDFSampler(num_samples=128)
+    assert us.single_jitter is False and ps.single_jitter is False and ps.include_original is True
+    us.train(), ps.train()
+    rs0 = us(rb)
+    w = torch.rand(n, 64, 1).cuda()
+    rs1 = ps(rb, rs0, w)
+    assert rs0.frustums.starts.shape == (n, 64, 1) and rs1.frustums.starts.shape == (n, 193, 1)
+    e = torch.cat([rs1.frustums.starts[..., 0], rs1.frustums.ends[:, -1:, 0]], dim=-1)
+    assert bool((e[:, 1:] >= e[:, :-1]).all()) and float(e.min()) >= 2.0 - 1e-6 and float(e.max()) <= 6.0 + 1e-6
+    # per-edge draws: the stratified bins of two rays with equal near/far differ in more than a common shift
+    d = rs0.spacing_starts[0, :, 0] - rs0.spacing_starts[1, :, 0]
+    assert float(d.std()) > 1e-4
+    with pytest.raises(ValueError, match="one draw per ray"):
+        us(rb, jitter=torch.rand(n, 7).cuda())
 
 
 def test_weights_backward_golden(F, golden):
@@ -922,7 +1013,7 @@ def test_fused_training_entry_points_equal_the_separate_ones(F):
     N.check(lib.nsamd_composite_fwd(None, N.ptr(w_a), N.ptr(t0), n, S0, N.BG_NONE, None, 0, None, None, None, N.ptr(med_a),
                                     None, None, st), "med")
     N.check(lib.nsamd_pdf_resample(N.ptr(s0), N.ptr(w_a), S0, N.ptr(u), N.ptr(jit), N.ptr(nears), N.ptr(fars), 1.0,
-                                   N.ptr(anneal), 0.01, 1e-5, 1.0 / (2 * (S1 + 1)), 0, n, S1, N.ptr(s_a), N.ptr(t_a), None, st),
+                                   N.ptr(anneal), 0.01, 1e-5, 1.0 / (2 * (S1 + 1)), 0, 0, 0, n, S1, N.ptr(s_a), N.ptr(t_a), None, st),
             "pdf")
     # fused
     w_b = e(n, S0); s_b, t_b, med_b = e(n, S1 + 1), e(n, S1 + 1), e(n)
