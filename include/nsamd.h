@@ -137,6 +137,13 @@ int nsamd_hashgrid_scatter_events(const float* workspace, uint32_t* events_host,
  * ------------------------------------------------------------------------------------------------------------ */
 int nsamd_sh4_encode(const float* dirs, int64_t M, float* out, nsamd_stream_t stream);
 
+/* NeRFEncoding.forward without covariances (field_components/encodings.py:148-189, vanilla-nerf's position / direction
+ * encoding): out [M, 6 F (+3)] = [sin(s), sin(s + pi/2), x] with s[d F + f] = (2 pi x_d) freqs[f]; freqs = the device copy
+ * of 2 ** torch.linspace(min_freq_exp, max_freq_exp, F) (host-evaluated, so the fp32 values are the reference's). The points
+ * are [M,3] positions or rays + bin edges (sample midpoints, never materialised) as for the hash kernels. No gradient. */
+int nsamd_nerf_encode(nsamd_points pts, int64_t M, const float* freqs, int32_t num_frequencies, int32_t include_input,
+                      float* out, nsamd_stream_t stream);
+
 /* SceneContraction(order=inf) forward on [M,3] (spatial_distortions.py:66-69). */
 int nsamd_contract_linf(const float* x, int64_t M, float* out, nsamd_stream_t stream);
 
@@ -231,7 +238,9 @@ int nsamd_field_mlp_bwd_saved(const float* enc, const float* selector, const flo
 
 /* ------------------------------------------------------------------------------------------------------------
  * Generic dense layer for the stand-alone MLP of the plugin API (MLP.pytorch_fwd, field_components/mlp.py:160-179):
- * y[M,N] = act(x[M,K] W[N,K]^T + b[N]); activation 0 = none, 1 = ReLU, 2 = Sigmoid; K, N <= 128; fp32 MFMA.
+ * y[M,N] = act(x[M,K] W[N,K]^T + b[N]); activation 0 = none, 1 = ReLU, 2 = Sigmoid, 3 = Softplus (the DensityFieldHead of
+ * vanilla-nerf, field_heads.py:98-108); any K, N (layers wider than 128 run as 128 x 128 blocks of W: the 8 x 256 MLP with
+ * its 319-wide skip layer, mlp.py:143-158); fp32 MFMA.
  * Backward: dx[M,K] (nullable, overwritten), dW[N,K] / db[N] accumulated (nullable); y = the forward's output.
  * ------------------------------------------------------------------------------------------------------------ */
 int nsamd_linear_fwd(const float* x, const float* W, const float* b, int64_t M, int32_t K, int32_t N, int activation,

@@ -68,6 +68,7 @@ _SIGNATURES = {
     "nsamd_hashgrid_encode_bwd_workspace_state": [Grid, i64],
     "nsamd_hashgrid_scatter_events": [vp, vp, vp],
     "nsamd_sh4_encode": [vp, i64, vp, vp],
+    "nsamd_nerf_encode": [Points, i64, vp, i32, i32, vp, vp],
     "nsamd_contract_linf": [vp, i64, vp, vp],
     "nsamd_density_mlp_fwd": [vp, vp, i64, DensityMlp, vp, vp, vp],
     "nsamd_density_field_fwd": [Points, i64, C.c_int, Aabb, vp, Grid, DensityMlp, vp, vp, vp, vp, vp],

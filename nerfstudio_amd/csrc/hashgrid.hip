@@ -396,6 +396,28 @@ __global__ void contract_kernel(const float* __restrict__ in, int64_t M, float* 
   out[3 * p + 2] = z;
 }
 
+// NeRFEncoding.pytorch_fwd without covariances (encodings.py:148-189): out[p] = [sin(s), sin(s + pi/2), x] with
+// s[d * F + f] = (2 pi x_d) * freq_f, the raw input LAST (forward() :175-176). One thread per (point, d, f): both sines
+// of its phase; the fp32 operation order is the reference's (scalar 2 pi rounded to fp32, product, sum, sin).
+__global__ __launch_bounds__(256) void nerf_encode_kernel(nsamd_points P, int64_t M, const float* __restrict__ freqs, int F,
+                                                         bool include_input, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int per = 3 * F;
+  if (e >= M * per) return;
+  const int64_t p = e / per;
+  const int k = (int)(e - p * per);
+  const int d = k / F, f = k - d * F;
+  float x[3];
+  load_position(P, p, x[0], x[1], x[2]);
+  const float xd = d == 0 ? x[0] : (d == 1 ? x[1] : x[2]);
+  const float s = (6.283185307179586f * xd) * freqs[f];
+  const int width = 2 * per + (include_input ? 3 : 0);
+  float* o = out + p * width;
+  o[k] = sinf(s);
+  o[per + k] = sinf(s + 1.5707963267948966f);
+  if (include_input && f == 0) o[2 * per + d] = xd;
+}
+
 static int check_points(const nsamd_points& P, int64_t M) {
   if (M < 0) return NSAMD_ERR_INVALID_ARG;
   if (P.positions == nullptr) {
@@ -607,6 +629,21 @@ extern "C" int nsamd_sh4_encode(const float* dirs, int64_t M, float* out, nsamd_
   NSAMD_REQUIRE(M >= 0 && (M == 0 || (dirs != nullptr && out != nullptr)));
   if (M == 0) return NSAMD_OK;
   sh4_kernel<<<(unsigned)((M + 255) / 256), 256, 0, (hipStream_t)stream>>>(dirs, M, out);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_nerf_encode(nsamd_points pts, int64_t M, const float* freqs, int32_t num_frequencies,
+                                 int32_t include_input, float* out, nsamd_stream_t stream) {
+  int st = check_points(pts, M);
+  if (st) return st;
+  NSAMD_REQUIRE(num_frequencies > 0 && num_frequencies <= 64);
+  if (M == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(freqs != nullptr && out != nullptr);
+  const int64_t threads = M * 3 * num_frequencies;
+  const int64_t blocks = (threads + 255) / 256;
+  if (blocks > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
+  nerf_encode_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(pts, M, freqs, num_frequencies, include_input != 0, out);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

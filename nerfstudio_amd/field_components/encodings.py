@@ -1,5 +1,5 @@
-"""Encodings (reference: nerfstudio/field_components/encodings.py — Encoding :36-55, HashEncoding :307-463,
-SHEncoding :752-799)."""
+"""Encodings (reference: nerfstudio/field_components/encodings.py — Encoding :36-55, Identity :58-68, NeRFEncoding
+:90-189, HashEncoding :307-463, SHEncoding :752-799)."""
 from abc import abstractmethod
 from typing import Literal, Optional
 
@@ -21,6 +21,51 @@ class Encoding(FieldComponent):
     @abstractmethod
     def forward(self, in_tensor: Tensor) -> Tensor:
         raise NotImplementedError
+
+
+class Identity(Encoding):
+    """Identity encoding (encodings.py:58-68)."""
+
+    def get_out_dim(self) -> int:
+        if self.in_dim is None:
+            raise ValueError("Input dimension has not been set")
+        return self.in_dim
+
+    def forward(self, in_tensor: Tensor) -> Tensor:
+        return in_tensor
+
+
+class NeRFEncoding(Encoding):
+    """Frequency encoding of vanilla NeRF (encodings.py:90-189): `[sin(2 pi x 2^k), sin(... + pi/2), x]`, one kernel
+    (csrc/hashgrid.hip nerf_encode_kernel). Integrated (mip-NeRF, `covs`) encodings are not built."""
+
+    def __init__(self, in_dim: int, num_frequencies: int, min_freq_exp: float, max_freq_exp: float,
+                 include_input: bool = False, implementation: Literal["hip"] = "hip") -> None:
+        super().__init__(in_dim)
+        check_implementation(implementation, "NeRFEncoding")
+        if in_dim != 3:
+            raise ValueError("the hip NeRFEncoding encodes 3-vectors (positions, directions)")
+        self.num_frequencies = num_frequencies
+        self.min_freq = min_freq_exp
+        self.max_freq = max_freq_exp
+        self.include_input = include_input
+
+    def get_out_dim(self) -> int:
+        out_dim = self.in_dim * self.num_frequencies * 2
+        if self.include_input:
+            out_dim += self.in_dim
+        return out_dim
+
+    def spec_forward(self, spec: "F.PointSpec") -> Tensor:
+        """Encoding of the points of a PointSpec (rays + bin edges: the sample midpoints are formed in the kernel)."""
+        return F.nerf_encode(spec, self.num_frequencies, self.min_freq, self.max_freq, self.include_input)
+
+    def forward(self, in_tensor: Tensor, covs: Optional[Tensor] = None) -> Tensor:
+        if covs is not None:
+            raise NotImplementedError("integrated (mip-NeRF) encodings are not built for the hip backend")
+        shape = in_tensor.shape[:-1]
+        out = self.spec_forward(F.PointSpec(positions=in_tensor.reshape(-1, 3)))
+        return out.view(*shape, self.get_out_dim())
 
 
 class HashEncoding(Encoding):

@@ -1,5 +1,12 @@
-"""Field output names (reference: nerfstudio/field_components/field_heads.py:27-41)."""
+"""Field outputs (reference: nerfstudio/field_components/field_heads.py — FieldHeadNames :27-41, FieldHead :44-93,
+DensityFieldHead :96-108, RGBFieldHead :111-123). A head is one dense layer with its activation; it runs as a single
+csrc/linear.hip launch (activation fused)."""
 from enum import Enum
+from typing import Optional
+
+from torch import Tensor, nn
+
+from .base_field_component import FieldComponent
 
 
 class FieldHeadNames(Enum):
@@ -16,3 +23,49 @@ class FieldHeadNames(Enum):
     SDF = "sdf"
     ALPHA = "alpha"
     GRADIENT = "gradient"
+
+
+_HEAD_ACTIVATIONS = {type(None): None, nn.ReLU: "relu", nn.Sigmoid: "sigmoid", nn.Softplus: "softplus"}
+
+
+class FieldHead(FieldComponent):
+    """Base field output: `net = nn.Linear(in_dim, out_dim)` (state-dict name `net.*`) + activation."""
+
+    def __init__(self, out_dim: int, field_head_name: FieldHeadNames, in_dim: Optional[int] = None,
+                 activation: Optional[nn.Module] = None) -> None:
+        super().__init__()
+        if type(activation) not in _HEAD_ACTIVATIONS:
+            raise ValueError(f"field head activation {activation!r}: the hip heads fuse None / ReLU / Sigmoid / Softplus")
+        if isinstance(activation, nn.Softplus) and (activation.beta != 1 or activation.threshold != 20):
+            raise ValueError("the fused Softplus is torch's default (beta = 1, threshold = 20)")
+        self.out_dim = out_dim
+        self.activation = activation
+        self.field_head_name = field_head_name
+        self.net = None
+        if in_dim is not None:
+            self.in_dim = in_dim
+            self._construct_net()
+
+    def set_in_dim(self, in_dim: int) -> None:
+        self.in_dim = in_dim
+        self._construct_net()
+
+    def _construct_net(self) -> None:
+        self.net = nn.Linear(self.in_dim, self.out_dim)
+
+    def forward(self, in_tensor: Tensor) -> Tensor:
+        from .. import functional as F
+
+        if not self.net:
+            raise SystemError("in_dim not set. Must be provided to constructor, or set_in_dim() should be called.")
+        return F.linear(in_tensor, self.net.weight, self.net.bias, _HEAD_ACTIVATIONS[type(self.activation)])
+
+
+class DensityFieldHead(FieldHead):
+    def __init__(self, in_dim: Optional[int] = None, activation: Optional[nn.Module] = nn.Softplus()) -> None:
+        super().__init__(in_dim=in_dim, out_dim=1, field_head_name=FieldHeadNames.DENSITY, activation=activation)
+
+
+class RGBFieldHead(FieldHead):
+    def __init__(self, in_dim: Optional[int] = None, activation: Optional[nn.Module] = nn.Sigmoid()) -> None:
+        super().__init__(in_dim=in_dim, out_dim=3, field_head_name=FieldHeadNames.RGB, activation=activation)

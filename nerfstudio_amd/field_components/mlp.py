@@ -3,7 +3,8 @@
 The parameters are plain `nn.Linear` weights/biases under the reference's names (`layers.{i}.weight`), so
 `state_dict`s interchange with the torch path. The arithmetic of the nerfacto shapes runs in the fused field kernels
 (csrc/density_mlp.hip for the proposal heads, csrc/field_mlp.hip on MFMA for the main field), which read these
-tensors in place; a stand-alone `MLP.forward` of any shape (widths <= 128) runs layer by layer on csrc/linear.hip.
+tensors in place; a stand-alone `MLP.forward` of any shape (any width, skip connections) runs layer by layer on
+csrc/linear.hip.
 """
 from typing import Literal, Optional, Set, Tuple
 
@@ -35,12 +36,10 @@ class MLP(FieldComponent):
         self.layer_width = layer_width
         self.skip_connections = skip_connections
         self._skip_connections: Set[int] = set(skip_connections) if skip_connections else set()
-        if self._skip_connections:
-            raise ValueError("nerfstudio_amd MLPs have no skip connections (none on the nerfacto path)")
         if activation is not None and not isinstance(activation, nn.ReLU):
-            raise ValueError("nerfstudio_amd MLPs use ReLU hidden activations (the nerfacto configuration)")
-        if out_activation is not None and not isinstance(out_activation, nn.Sigmoid):
-            raise ValueError("nerfstudio_amd MLPs support out_activation None or Sigmoid")
+            raise ValueError("nerfstudio_amd MLPs use ReLU hidden activations (the nerfacto / vanilla-nerf configuration)")
+        if out_activation is not None and not isinstance(out_activation, (nn.Sigmoid, nn.ReLU)):
+            raise ValueError("nerfstudio_amd MLPs support out_activation None, ReLU or Sigmoid")
         self.activation = activation
         self.out_activation = out_activation
         self.build_nn_modules()
@@ -51,7 +50,13 @@ class MLP(FieldComponent):
             layers.append(nn.Linear(self.in_dim, self.out_dim))
         else:
             for i in range(self.num_layers - 1):
-                layers.append(nn.Linear(self.in_dim if i == 0 else self.layer_width, self.layer_width))
+                if i == 0:
+                    assert i not in self._skip_connections, "Skip connection at layer 0 doesn't make sense."
+                    layers.append(nn.Linear(self.in_dim, self.layer_width))
+                elif i in self._skip_connections:  # mlp.py:151-152: the layer sees [input, hidden]
+                    layers.append(nn.Linear(self.layer_width + self.in_dim, self.layer_width))
+                else:
+                    layers.append(nn.Linear(self.layer_width, self.layer_width))
             layers.append(nn.Linear(self.layer_width, self.out_dim))
         self.layers = nn.ModuleList(layers)
 
@@ -63,17 +68,22 @@ class MLP(FieldComponent):
         return out
 
     def forward(self, in_tensor: Tensor) -> Tensor:
-        """`[*bs, in_dim] -> [*bs, out_dim]` (mlp.py:160-179): one MFMA dense-layer kernel per layer
-        (csrc/linear.hip), ReLU between layers, optional Sigmoid at the end; widths up to 128."""
+        """`[*bs, in_dim] -> [*bs, out_dim]` (mlp.py:160-179): one MFMA dense-layer kernel per 128 x 128 block of a
+        layer (csrc/linear.hip), ReLU between layers, optional ReLU / Sigmoid at the end, `cat([input, hidden])` in front of
+        the skip layers (:171-172; the concatenation is a copy, no arithmetic)."""
         from .. import functional as F
 
         x = in_tensor
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
+            if i in self._skip_connections:
+                x = torch.cat([in_tensor, x], -1)
             if i < last:
                 act = "relu" if self.activation is not None else None
+            elif self.out_activation is None:
+                act = None
             else:
-                act = "sigmoid" if self.out_activation is not None else None
+                act = "sigmoid" if isinstance(self.out_activation, nn.Sigmoid) else "relu"
             x = F.linear(x, layer.weight, layer.bias, act)
         return x
 

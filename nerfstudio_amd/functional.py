@@ -327,6 +327,29 @@ def sh4_encode(directions: Tensor) -> Tensor:
     return out.view(*shape, 16)
 
 
+_FREQS: dict = {}
+
+
+def nerf_encode(spec: PointSpec, num_frequencies: int, min_freq_exp: float, max_freq_exp: float,
+                include_input: bool = False) -> Tensor:
+    """NeRFEncoding.forward (encodings.py:148-189, no covariances) on the points of `spec` -> `[M, 6 F (+3)]`. The
+    frequencies are evaluated with torch on the host once (`2 ** linspace`), as the reference does per call. No gradient
+    w.r.t. the points (vanilla-nerf has none to take: no camera optimiser, no learned warp)."""
+    N.require_cuda(*spec.tensors())
+    if any(t is not None and t.requires_grad for t in spec.tensors()):
+        raise RuntimeError("nsamd NeRFEncoding has no backward: the encoded points must not require grad")
+    dev = next(t for t in spec.tensors() if t is not None).device
+    key = (num_frequencies, float(min_freq_exp), float(max_freq_exp), dev)
+    if key not in _FREQS:
+        _FREQS[key] = (2 ** torch.linspace(min_freq_exp, max_freq_exp, num_frequencies)).to(dev)
+    spec = _spec_from_flat(*spec.tensors())
+    M = spec.num_points
+    out = torch.empty((M, 6 * num_frequencies + (3 if include_input else 0)), device=dev, dtype=torch.float32)
+    N.check(N.load().nsamd_nerf_encode(spec.native(), M, N.ptr(_FREQS[key]), num_frequencies, int(bool(include_input)),
+                                       N.ptr(out), N.stream()), "nerf_encode")
+    return out
+
+
 def contract_linf(x: Tensor) -> Tensor:
     """SceneContraction(order=inf).forward (spatial_distortions.py:66-69), forward only (the fused fields carry
     the Jacobian inside their own backward)."""
@@ -339,9 +362,9 @@ def contract_linf(x: Tensor) -> Tensor:
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# a9  stand-alone dense layer / MLP of arbitrary width (<= 128)                      (field_components/mlp.py:160-179)
+# a9  stand-alone dense layer / MLP of arbitrary width                              (field_components/mlp.py:160-179)
 # ---------------------------------------------------------------------------------------------------------------
-_ACT = {None: 0, "relu": 1, "sigmoid": 2}
+_ACT = {None: 0, "relu": 1, "sigmoid": 2, "softplus": 3}
 
 
 class _LinearFn(torch.autograd.Function):
@@ -374,9 +397,8 @@ class _LinearFn(torch.autograd.Function):
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], activation: Optional[str] = None) -> Tensor:
-    """act(x W^T + b) on `[*bs, K]` with `weight [N,K]` (nn.Linear layout); activation None | "relu" | "sigmoid"."""
-    if weight.shape[0] > 128 or weight.shape[1] > 128:
-        raise RuntimeError("nsamd linear layers support widths up to 128")
+    """act(x W^T + b) on `[*bs, K]` with `weight [N,K]` (nn.Linear layout); activation None | "relu" | "sigmoid" |
+    "softplus"."""
     shape = x.shape[:-1]
     y = _LinearFn.apply(x.reshape(-1, x.shape[-1]), weight, bias, _ACT[activation])
     return y.view(*shape, weight.shape[0])
