@@ -320,15 +320,18 @@ int nsamd_composite_bwd(const float* rgb, const float* weights, const float* t_b
  * composited colour against target [N,3]: sq_err [N] (nullable) = per-ray sum of squared errors, d_rgb_out [N,3]
  * (nullable) = 2 (rgb_out - target) grad_scale. target may be NULL (no loss).
  * nsamd_render_train_bwd = nsamd_composite_bwd (d_rgb_out, d_weights_add) + nsamd_weights_bwd: d_rgb [N,S,3] and
- * d_density [N,S]; `weights` are the forward's. */
+ * d_density [N,S]; `weights` are the forward's.
+ * background = 3 (these two only): background_color="random" in training — rgb_out is the composite without a background
+ * (renderers.py:112-115) and the loss is taken on rgb_out + bg_rays[ray] (1 - acc), bg_rays [N,3] = the caller's
+ * rand_like(pred) draw (blend_background_for_loss_computation, renderers.py:194-196). bg_rays is NULL otherwise. */
 int nsamd_render_train(const float* rgb, const float* density, const float* t_bins, int64_t num_rays, int32_t S,
                        int background, const float* bg_rgb_host, const float* target, float grad_scale, float* weights,
                        float* rgb_out, float* acc, float* depth_expected, float* depth_median, float* workspace,
-                       float* sq_err, float* d_rgb_out, nsamd_stream_t stream);
+                       float* sq_err, float* d_rgb_out, const float* bg_rays, nsamd_stream_t stream);
 int nsamd_render_train_bwd(const float* rgb, const float* weights, const float* density, const float* t_bins,
                            int64_t num_rays, int32_t S, int background, const float* bg_rgb_host,
                            const float* d_rgb_out, const float* d_weights_add, float* d_rgb, float* d_density,
-                           nsamd_stream_t stream);
+                           const float* bg_rays, nsamd_stream_t stream);
 
 /* MSELoss (model_components/losses.py:31): loss_sum += sum((pred-target)^2) (caller zeroes; mean = /n),
  * dpred (nullable) = 2 (pred-target) grad_scale  with grad_scale = upstream / n. */

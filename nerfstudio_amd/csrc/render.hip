@@ -47,7 +47,9 @@ __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
     float* __restrict__ rgb_out, float* __restrict__ acc_out, float* __restrict__ depth_exp,
     float* __restrict__ depth_med, int32_t* __restrict__ med_idx, float* __restrict__ ws,
     const float* __restrict__ density, float* __restrict__ weights_out, const float* __restrict__ target,
-    float grad_scale, float* __restrict__ sq_err, float* __restrict__ d_rgb_out) {
+    float grad_scale, float* __restrict__ sq_err, float* __restrict__ d_rgb_out, const float* __restrict__ bg_rays) {
+  // background == 3 ("random", training): rgb_out is the composite WITHOUT a background (renderers.py:112-115) and the loss
+  // is taken on rgb_out + bg_rays[ray] * (1 - acc) (blend_background_for_loss_computation, renderers.py:194-196).
   // density != nullptr (training step, nsamd_render_train): the weights are computed here from the densities
   // (RaySamples.get_weights, as sampler.hip) and written to weights_out; target != nullptr adds the per-ray squared
   // error and the MSE gradient of the composited colour.
@@ -138,6 +140,12 @@ __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
       rgb_out[ray * 3 + 1] = sg;
       rgb_out[ray * 3 + 2] = sb;
       if (target) {  // MSELoss value (per ray) and gradient, losses.py:31
+        if (background == 3) {
+          const float rem = 1.0f - sw;
+          sr = sr + bg_rays[ray * 3 + 0] * rem;
+          sg = sg + bg_rays[ray * 3 + 1] * rem;
+          sb = sb + bg_rays[ray * 3 + 2] * rem;
+        }
         const float dr = sr - target[ray * 3 + 0], dg = sg - target[ray * 3 + 1], db = sb - target[ray * 3 + 2];
         if (sq_err) sq_err[ray] = (dr * dr + dg * dg) + db * db;
         if (d_rgb_out) {
@@ -223,7 +231,8 @@ __global__ __launch_bounds__(kRenderThreads) void composite_bwd_kernel(
     int64_t num_rays, int S, int background, float bg_r, float bg_g, float bg_b,
     const float* __restrict__ d_rgb_out, const float* __restrict__ d_acc, const float* __restrict__ d_depth,
     const float* __restrict__ ws, const float* __restrict__ d_weights_add, float* __restrict__ d_rgb,
-    float* __restrict__ d_weights, const float* __restrict__ density, float* __restrict__ d_density) {
+    float* __restrict__ d_weights, const float* __restrict__ density, float* __restrict__ d_density,
+    const float* __restrict__ bg_rays) {
   // density != nullptr (nsamd_render_train_bwd): d_weights is not stored; the gradient goes on through
   // RaySamples.get_weights to d_density (same formulas as weights_bwd_kernel in sampler.hip).
   extern __shared__ float lds[];
@@ -250,6 +259,8 @@ __global__ __launch_bounds__(kRenderThreads) void composite_bwd_kernel(
     br = c[0]; bgc = c[1]; bb = c[2];
   } else if (background == 2) {
     br = bg_r; bgc = bg_g; bb = bg_b;
+  } else if (background == 3) {  // per-ray colour of the loss blend: d(pred + bg (1 - acc)) / d w = rgb - bg
+    br = bg_rays[ray * 3 + 0]; bgc = bg_rays[ray * 3 + 1]; bb = bg_rays[ray * 3 + 2];
   }
   // expected depth = clip(num / (den + eps)); clip passes gradient inside [lo, hi] (inclusive)
   float g_num = 0.f, g_den = 0.f;
@@ -385,7 +396,7 @@ extern "C" int nsamd_composite_fwd(const float* rgb, const float* weights, const
               bb = bg_rgb_host ? bg_rgb_host[2] : 0.f;
   composite_fwd_kernel<<<blocks, kRenderThreads, 0, st>>>(
       rgb, weights, need_t ? t_bins : nullptr, num_rays, S, background, br, bg, bb, eval_mode, rgb_out, acc,
-      depth_expected, depth_median, median_idx, ws, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr);
+      depth_expected, depth_median, median_idx, ws, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr, nullptr);
   NSAMD_CHECK_LAUNCH();
   if (depth_expected) {
     depth_clip_kernel<<<(unsigned)((num_rays + 255) / 256), 256, 0, st>>>(depth_expected, num_rays, ws, (int)blocks);
@@ -410,7 +421,7 @@ extern "C" int nsamd_composite_bwd(const float* rgb, const float* weights, const
               bb = bg_rgb_host ? bg_rgb_host[2] : 0.f;
   composite_bwd_kernel<<<blocks, kRenderThreads, 0, (hipStream_t)stream>>>(
       rgb, weights, t_bins, num_rays, S, background, br, bg, bb, d_rgb_out, d_acc, d_depth, workspace, d_weights_add, d_rgb,
-      d_weights, nullptr, nullptr);
+      d_weights, nullptr, nullptr, nullptr);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }
@@ -419,12 +430,13 @@ extern "C" int nsamd_render_train(const float* rgb, const float* density, const 
                                   int32_t S, int background, const float* bg_rgb_host, const float* target,
                                   float grad_scale, float* weights, float* rgb_out, float* acc, float* depth_expected,
                                   float* depth_median, float* workspace, float* sq_err, float* d_rgb_out,
-                                  nsamd_stream_t stream) {
+                                  const float* bg_rays, nsamd_stream_t stream) {
   NSAMD_REQUIRE(num_rays >= 0 && S > 0);
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(rgb && density && t_bins && weights && rgb_out);
-  NSAMD_REQUIRE(background >= 0 && background <= 2);
+  NSAMD_REQUIRE(background >= 0 && background <= 3);
   NSAMD_REQUIRE(background != 2 || bg_rgb_host != nullptr);
+  NSAMD_REQUIRE(background != 3 || bg_rays != nullptr);
   NSAMD_REQUIRE(depth_expected == nullptr || workspace != nullptr);
   if (S > 4096) return NSAMD_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -433,7 +445,7 @@ extern "C" int nsamd_render_train(const float* rgb, const float* density, const 
               bb = bg_rgb_host ? bg_rgb_host[2] : 0.f;
   composite_fwd_kernel<<<blocks, kRenderThreads, 0, st>>>(rgb, nullptr, t_bins, num_rays, S, background, br, bg, bb, 0,
                                                           rgb_out, acc, depth_expected, depth_median, nullptr, workspace,
-                                                          density, weights, target, grad_scale, sq_err, d_rgb_out);
+                                                          density, weights, target, grad_scale, sq_err, d_rgb_out, bg_rays);
   NSAMD_CHECK_LAUNCH();
   if (depth_expected) {
     depth_clip_kernel<<<(unsigned)((num_rays + 255) / 256), 256, 0, st>>>(depth_expected, num_rays, workspace,
@@ -446,19 +458,20 @@ extern "C" int nsamd_render_train(const float* rgb, const float* density, const 
 extern "C" int nsamd_render_train_bwd(const float* rgb, const float* weights, const float* density,
                                       const float* t_bins, int64_t num_rays, int32_t S, int background,
                                       const float* bg_rgb_host, const float* d_rgb_out, const float* d_weights_add,
-                                      float* d_rgb, float* d_density, nsamd_stream_t stream) {
+                                      float* d_rgb, float* d_density, const float* bg_rays, nsamd_stream_t stream) {
   NSAMD_REQUIRE(num_rays >= 0 && S > 0);
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(rgb && weights && density && t_bins && d_rgb_out && d_rgb && d_density);
-  NSAMD_REQUIRE(background >= 0 && background <= 2);
+  NSAMD_REQUIRE(background >= 0 && background <= 3);
   NSAMD_REQUIRE(background != 2 || bg_rgb_host != nullptr);
+  NSAMD_REQUIRE(background != 3 || bg_rays != nullptr);
   if (S > 1024) return NSAMD_ERR_UNSUPPORTED;
   const unsigned blocks = (unsigned)((num_rays + kRaysPerBlock - 1) / kRaysPerBlock);
   const float br = bg_rgb_host ? bg_rgb_host[0] : 0.f, bg = bg_rgb_host ? bg_rgb_host[1] : 0.f,
               bb = bg_rgb_host ? bg_rgb_host[2] : 0.f;
   composite_bwd_kernel<<<blocks, kRenderThreads, sizeof(float) * 3 * kRaysPerBlock * (size_t)S, (hipStream_t)stream>>>(
       rgb, weights, t_bins, num_rays, S, background, br, bg, bb, d_rgb_out, nullptr, nullptr, nullptr, d_weights_add,
-      d_rgb, nullptr, density, d_density);
+      d_rgb, nullptr, density, d_density, bg_rays);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

@@ -38,19 +38,19 @@ class NerfactoTrainStep:
         self.counts = (*cfg.num_proposal_samples_per_ray, cfg.num_nerf_samples_per_ray)
         self.n_prop = len(cfg.num_proposal_samples_per_ray)
         self.compute_depths = compute_depths
-        if cfg.background_color == "random":
-            # The reference blends `rand_like(pred) * (1 - accumulation)` into prediction AND target before the MSE
-            # (renderers.py:120-163, models/nerfacto.py:377-381); the fused render_train kernel has no per-ray random
-            # background, and treating "random" as "no background" would silently train a different objective.
-            raise NotImplementedError('NerfactoTrainStep: background_color="random" is not supported by the fused runner; '
-                                      "use NerfactoModel (module path) or last_sample / black / white")
-        if cfg.background_color not in ("last_sample", "black", "white"):
+        if cfg.background_color not in ("last_sample", "black", "white", "random"):
             raise ValueError(cfg.background_color)
         if not getattr(cfg, "use_single_jitter", True):
             raise NotImplementedError("NerfactoTrainStep: use_single_jitter=False (per-sample jitter) is not supported")
-        self.bg_mode, self.bg_vals = F._bg_args(cfg.background_color, device)
         f32 = dict(device=device, dtype=torch.float32)
         e = lambda *shape: torch.empty(shape, **f32)  # noqa: E731
+        if cfg.background_color == "random":
+            # the rendered colour carries no background; the loss blends `rand_like(pred) * (1 - accumulation)` into the
+            # prediction (renderers.py:112-115, 194-196; models/nerfacto.py:377-381) — a per-ray colour the kernels read
+            self.bg_mode, self.bg_vals, self.bg_rays = 3, None, e(n, 3)
+        else:
+            self.bg_mode, self.bg_vals = F._bg_args(cfg.background_color, device)
+            self.bg_rays = None
         # ---- per-step inputs (static addresses; the caller fills them) ----
         self.origins, self.directions = e(n, 3), e(n, 3)
         self.camera_indices = torch.zeros((n,), device=device, dtype=torch.int64)
@@ -259,6 +259,8 @@ class NerfactoTrainStep:
         ck = N.check
         if draw_jitter:
             self.jitter.uniform_()  # torch.rand per level and ray (ray_samplers.py:105, :322), drawn on the device
+            if self.bg_rays is not None:
+                self.bg_rays.uniform_()  # rand_like(pred) of the loss blend (renderers.py:195)
         S0 = self.counts[0]
         ck(lib.nsamd_piecewise_bins(N.ptr(self.nears), N.ptr(self.fars), N.ptr(self.edges), N.ptr(self.jitter[0]), 0, n, S0,
                                     self.spacing, N.ptr(self.s_bins[0]), N.ptr(self.t_bins[0]), st), "piecewise_bins")
@@ -322,7 +324,7 @@ class NerfactoTrainStep:
                                   self.bg_vals, N.ptr(self.target), 1.0 / (3 * n), N.ptr(self.weights[L]), N.ptr(self.rgb),
                                   N.ptr(self.acc), N.ptr(self.depth_exp),
                                   N.ptr(self.depth_med[L]) if self.compute_depths else None, N.ptr(self.minmax_ws),
-                                  N.ptr(self.sq_err), N.ptr(self.d_rgb_out), st), "render_train")
+                                  N.ptr(self.sq_err), N.ptr(self.d_rgb_out), N.ptr(self.bg_rays), st), "render_train")
         # ---- proposal losses: value + gradient, all levels in one launch (models/nerfacto.py:363-375) ----
         ck(lib.nsamd_proposal_losses(N.ptr(self.s_bins[L]), N.ptr(self.weights[L]), S, self.n_prop, self._pl_s_bins,
                                      self._pl_weights, self._pl_S, n, float(cfg.interlevel_loss_mult) / (n * S),
@@ -345,7 +347,8 @@ class NerfactoTrainStep:
         cams = N.ptr(self.camera_indices) if emb is not None else None
         ck(lib.nsamd_render_train_bwd(N.ptr(self.f_rgb), N.ptr(self.weights[L]), N.ptr(self.f_dens), N.ptr(self.t_bins[L]),
                                       n, S, self.bg_mode, self.bg_vals, N.ptr(self.d_rgb_out), N.ptr(self.dw_dist),
-                                      N.ptr(self.d_rgb_s), N.ptr(self.d_dens_main), st), "render_train_bwd")
+                                      N.ptr(self.d_rgb_s), N.ptr(self.d_dens_main), N.ptr(self.bg_rays), st),
+           "render_train_bwd")
         grads = N.FieldMlpGrads(*(N.ptr(self._grad(p)) for p in params), N.ptr(self._grad(emb)) if emb is not None else None)
         if self.save_acts:
             ck(lib.nsamd_field_mlp_bwd_saved(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S,

@@ -833,6 +833,60 @@ def test_train_step_runner_matches_autograd_path(F):
             assert float(p.grad.abs().max()) == 0.0, k
 
 
+def test_train_step_runner_random_background(F, monkeypatch):
+    """background_color="random" on the fused runner (renderers.py:112-115, 194-196; models/nerfacto.py:377-381) against the
+    module path with the same rand_like draw: rendered colour (no background), losses, every gradient."""
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.cameras.rays import RayBundle
+    from nerfstudio_amd.model_components import renderers as R
+    from nerfstudio_amd.train_step import NerfactoTrainStep
+
+    cfg = small_cfg(12, 10, 6)
+    params = orc.init_params(cfg, seed=17, table_std=0.4)
+    n = 130
+    o, d, cam, tgt = orc.synthetic_rays(n, cfg.num_images, seed=18)
+    jit = torch.rand(3, n).cuda()
+    bg = torch.rand(n, 3).cuda()
+
+    def model():
+        m = _hip_model(cfg, params)
+        m.config.background_color = "random"
+        m.renderer_rgb.background_color = "random"
+        m.set_step(50)
+        return m
+
+    model_a = model()
+    rb = RayBundle(origins=o.cuda(), directions=d.cuda(), pixel_area=torch.full((n, 1), 1e-6).cuda(),
+                   camera_indices=cam.cuda()[:, None])
+    out = model_a(rb, jitters=[jit[i][:, None] for i in range(3)])
+    monkeypatch.setattr(R.torch, "rand_like", lambda t: bg.to(t))
+    batch = {"image": tgt.cuda()}
+    ld = model_a.get_loss_dict(out, batch, model_a.get_metrics_dict(out, batch))
+    monkeypatch.undo()
+    sum(ld.values()).backward()
+
+    model_b = model()
+    arena = ParamArena(model_b.parameters())
+    step = NerfactoTrainStep(model_b, n, torch.device("cuda"))
+    assert step.bg_mode == 3
+    step.set_batch(o.cuda(), d.cuda(), cam.cuda(), tgt.cuda())
+    step.jitter.copy_(jit)
+    step.bg_rays.copy_(bg)
+    step.anneal_dev.fill_(model_b.proposal_sampler._anneal)
+    arena.zero_grad()
+    step.forward_backward(updated=True, draw_jitter=False)
+    close(step.outputs()["rgb"], out["rgb"], atol=1e-6, rtol=0)
+    lb = step.loss_dict()
+    for k in ("rgb_loss", "interlevel_loss", "distortion_loss"):
+        close(lb[k], ld[k], rtol=1e-5, atol=1e-9, msg=k)
+    pa, pb = dict(model_a.named_parameters()), dict(model_b.named_parameters())
+    for k in pa:
+        gclose(pb[k].grad, pa[k].grad, 2e-5, k)
+    # a drawn step fills the background itself
+    step.forward_backward(updated=False, draw_jitter=True)
+    assert not torch.equal(step.bg_rays, bg) and float(step.bg_rays.min()) >= 0.0 and float(step.bg_rays.max()) < 1.0
+
+
 def test_eval_render_path_full_image(F):
     """§8 f3: RayGenerator over a full (small) image -> chunked eval render
     (Model.get_outputs_for_camera_ray_bundle, models/base_model.py:178-205) against the oracle in eval mode:
@@ -1038,7 +1092,7 @@ def test_fused_training_entry_points_equal_the_separate_ones(F):
         ws_b = e(2 + 2 * ((n + 3) // 4)); sq_b = e(n); dro_b = e(n, 3)
         N.check(lib.nsamd_render_train(N.ptr(rgb), N.ptr(dens1), N.ptr(t_a), n, S1, bg, bgv, N.ptr(target), 1.0 / (3 * n),
                                        N.ptr(w_b), N.ptr(rgb_b), N.ptr(acc_b), N.ptr(dexp_b), N.ptr(dmed_b), N.ptr(ws_b),
-                                       N.ptr(sq_b), N.ptr(dro_b), st), "rt")
+                                       N.ptr(sq_b), N.ptr(dro_b), None, st), "rt")
         for a, b, name in ((w_a, w_b, "w"), (rgb_a, rgb_b, "rgb"), (acc_a, acc_b, "acc"), (dexp_a, dexp_b, "dexp"),
                            (dmed_a, dmed_b, "dmed"), (dro_a, dro_b, "d_rgb_out")):
             assert torch.equal(a, b), (bg, name)
@@ -1050,8 +1104,30 @@ def test_fused_training_entry_points_equal_the_separate_ones(F):
         N.check(lib.nsamd_weights_bwd(N.ptr(t_a), N.ptr(dens1), N.ptr(dw_a), n, S1, N.ptr(dd_a), st), "wb")
         drgb_b, dd_b = e(n, S1, 3), e(n, S1)
         N.check(lib.nsamd_render_train_bwd(N.ptr(rgb), N.ptr(w_a), N.ptr(dens1), N.ptr(t_a), n, S1, bg, bgv, N.ptr(dro_a),
-                                           N.ptr(dw_add), N.ptr(drgb_b), N.ptr(dd_b), st), "rtb")
+                                           N.ptr(dw_add), N.ptr(drgb_b), N.ptr(dd_b), None, st), "rtb")
         assert torch.equal(drgb_a, drgb_b) and torch.equal(dd_a, dd_b), bg
+    # background_color="random" (mode 3): rgb_out carries no background, the loss is on rgb_out + bg (1 - acc); against the
+    # same formulas in torch autograd (renderers.py:112-115, 194-196)
+    bg_rays = torch.rand(n, 3, device="cuda")
+    w_r = e(n, S1); rgb_r, acc_r, sq_r, dro_r = e(n, 3), e(n), e(n), e(n, 3)
+    N.check(lib.nsamd_render_train(N.ptr(rgb), N.ptr(dens1), N.ptr(t_a), n, S1, 3, None, N.ptr(target), 1.0 / (3 * n),
+                                   N.ptr(w_r), N.ptr(rgb_r), N.ptr(acc_r), None, None, None, N.ptr(sq_r), N.ptr(dro_r),
+                                   N.ptr(bg_rays), st), "rt3")
+    drgb_r, dd_r = e(n, S1, 3), e(n, S1)
+    N.check(lib.nsamd_render_train_bwd(N.ptr(rgb), N.ptr(w_r), N.ptr(dens1), N.ptr(t_a), n, S1, 3, None, N.ptr(dro_r), None,
+                                       N.ptr(drgb_r), N.ptr(dd_r), N.ptr(bg_rays), st), "rtb3")
+    rgb_t, dens_t = rgb.detach().cpu().requires_grad_(True), dens1.detach().cpu().requires_grad_(True)
+    w_t = orc.weights_from_density(t_a.cpu(), dens_t)
+    comp = (w_t[..., None] * rgb_t).sum(-2)
+    acc_t = w_t.sum(-1, keepdim=True)
+    loss_t = ((comp + bg_rays.cpu() * (1.0 - acc_t) - target.cpu()) ** 2).mean()
+    loss_t.backward()
+    close(rgb_r, comp, atol=1e-6, rtol=0, msg="random background: rgb_out is the plain composite")
+    close(sq_r.sum() / (3 * n), loss_t, rtol=1e-5)
+    gclose(drgb_r, rgb_t.grad, 1e-5, "d rgb (random background)")
+    gclose(dd_r, dens_t.grad, 1e-4, "d density (random background)")
+    assert lib.nsamd_render_train(N.ptr(rgb), N.ptr(dens1), N.ptr(t_a), n, S1, 3, None, N.ptr(target), 1.0, N.ptr(w_r),
+                                  N.ptr(rgb_r), None, None, None, None, None, None, None, st) == -1  # mode 3 needs bg_rays
 
     # ---- proposal losses ----
     wp = [torch.rand(n, S0, device="cuda") / S0, torch.rand(n, 64, device="cuda") / 64]
