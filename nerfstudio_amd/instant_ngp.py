@@ -127,3 +127,25 @@ class NGPModel(nn.Module):
                 if torch.is_tensor(v):
                     outs.setdefault(k, []).append(v)
         return {k: torch.cat(v).view(*image_shape, -1) for k, v in outs.items()}
+
+
+class DynamicBatch:
+    """The ray-count feedback of DynamicBatchPipeline (pipelines/dynamic_batch.py:30-95): the occupancy-grid sampler places
+    a data-dependent number of samples per ray, so the pipeline rescales the NEXT batch's ray count by
+    target_num_samples / (samples the last batch produced) to keep the work per step constant. Host logic; the caller
+    (a datamanager's pixel sampler) draws `num_rays_per_batch` rays for the next step."""
+
+    def __init__(self, target_num_samples: int = 1 << 18, max_num_samples_per_ray: int = 1 << 10) -> None:
+        self.target_num_samples = int(target_num_samples)
+        self.max_num_samples_per_ray = int(max_num_samples_per_ray)
+        self.num_rays_per_batch = self.target_num_samples // self.max_num_samples_per_ray  # dynamic_batch.py:62
+
+    def update(self, metrics_dict: Dict[str, Tensor]) -> int:
+        """After a training step (dynamic_batch.py:71-95): metrics_dict = NGPModel.get_metrics_dict(...)."""
+        if "num_samples_per_batch" not in metrics_dict:
+            raise ValueError("'num_samples_per_batch' is not in metrics_dict."
+                             "Please return 'num_samples_per_batch' in the models get_metrics_dict function to use this method.")
+        num_samples_per_batch = int(metrics_dict["num_samples_per_batch"])
+        self.num_rays_per_batch = int(self.num_rays_per_batch * (self.target_num_samples / num_samples_per_batch))
+        return self.num_rays_per_batch
+

@@ -148,3 +148,17 @@ def test_packed_mirror_error_contract_and_cuda_guard():
                  lambda: AccumulationRenderer()(weights=w, ray_indices=ri, num_rays=4)):
         with pytest.raises(RuntimeError, match="MI355X"):
             call()
+
+
+def test_dynamic_batch_feedback():
+    """pipelines/dynamic_batch.py:62, 71-76: initial ray count = target / max-per-ray; then rescaled by target / produced."""
+    from nerfstudio_amd.instant_ngp import DynamicBatch
+
+    db = DynamicBatch()
+    assert db.num_rays_per_batch == (1 << 18) // (1 << 10) == 256
+    assert db.update({"num_samples_per_batch": torch.tensor(256 * 40)}) == int(256 * ((1 << 18) / (256 * 40)))  # 40 samples / ray
+    rays = db.num_rays_per_batch
+    assert db.update({"num_samples_per_batch": rays * 80}) == int(rays * ((1 << 18) / (rays * 80)))            # scene got denser
+    with pytest.raises(ValueError, match="num_samples_per_batch"):
+        db.update({"psnr": torch.tensor(1.0)})
+
