@@ -184,7 +184,10 @@ class Trainer:
 
         if self.runner is not None:
             self._select_batch()
-            self.arena.zero_grad(skip=self.runner.written_params())  # the table gradients are written, not accumulated
+            # the main table's gradient is written, not accumulated; the proposal group's gradients are neither produced nor
+            # consumed on a step that does not update it (ray_samplers.py:590-599), so its 10 MB need no zero-fill then
+            groups = ["fields", "proposal_networks"] if updated else ["fields"]
+            self.arena.zero_grad(groups, skip=self.runner.written_params())
             self.runner.forward_backward(updated)  # the two backward chains run as parallel branches
             return
         self._select_batch()

@@ -161,13 +161,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("NSAMD_LIB", LIB_PATH)  # (a probe / instrumented build of the same sources, scripts/probe_*)
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"nerfstudio_amd: native library not found at {LIB_PATH}. Build it with "
+            f"nerfstudio_amd: native library not found at {path}. Build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C nerfstudio_amd/csrc`). "
             "There is no CPU/torch fallback for implementation='hip'."
         )
-    cdll = C.CDLL(LIB_PATH)
+    cdll = C.CDLL(path)
     lib = _Lib()
     lib.cdll = cdll
     for name, argtypes in _SIGNATURES.items():

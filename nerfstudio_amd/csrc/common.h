@@ -30,6 +30,25 @@
     if (!(cond)) return NSAMD_ERR_INVALID_ARG; \
   } while (0)
 
+// Timing probes (scripts/probe_*_clocks.py build a probe library with -DNSAMD_PROBE_CLOCKS; never part of libnsamd.so):
+// lane 0 of every wave stamps the shader clock into [wave of the grid][64 slots] of a buffer set per translation unit.
+#ifdef NSAMD_PROBE_CLOCKS
+#define NSAMD_PROBE_DEFINE(tag)                                                                          \
+  static __device__ long long* g_probe_clocks = nullptr;                                                 \
+  extern "C" int nsamd_probe_set_clocks_##tag(long long* buffer) {                                       \
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_probe_clocks), &buffer, sizeof(buffer)) == hipSuccess ? 0 : -3; \
+  }
+#define PROBE_STAMP(unused, slot)                                                                        \
+  do {                                                                                                   \
+    if (g_probe_clocks != nullptr && (threadIdx.x & 63) == 0 && (slot) < 64)                             \
+      g_probe_clocks[(((long long)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64 + \
+                     (slot)] = clock64();                                                                \
+  } while (0)
+#else
+#define NSAMD_PROBE_DEFINE(tag)
+#define PROBE_STAMP(unused, slot) do {} while (0)
+#endif
+
 namespace nsamd {
 
 constexpr uint32_t kPrimeY = 2654435761u;  // encodings.py:410

@@ -27,22 +27,12 @@
 
 #include "common.h"
 
+NSAMD_PROBE_DEFINE(field)
+
 namespace nsamd {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// Timing probe (scripts/probe_field_clocks.py builds this file alone with -DNSAMD_PROBE_CLOCKS into its own library;
-// never part of libnsamd.so): lane 0 of every wave stamps the shader clock into [wave][64 slots].
-#ifdef NSAMD_PROBE_CLOCKS
-__device__ long long* g_probe_clocks = nullptr;
-#define PROBE_STAMP(waves_per_block, slot)                                                              \
-  do {                                                                                                  \
-    if (g_probe_clocks != nullptr && (threadIdx.x & 63) == 0 && (slot) < 64)                            \
-      g_probe_clocks[((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64 + (slot)] = clock64();  \
-  } while (0)
-#else
-#define PROBE_STAMP(waves_per_block, slot) do {} while (0)
-#endif
 
 constexpr int kWaves = 4;
 constexpr int kFieldThreads = 64 * kWaves;
@@ -1052,12 +1042,6 @@ extern "C" int nsamd_field_mlp_bwd_saved(const float* enc, const float* selector
   return field_mlp_bwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, ddensity,
                             drgb, denc, grads, workspace, workspace_floats, saved, stream);
 }
-
-#ifdef NSAMD_PROBE_CLOCKS
-extern "C" int nsamd_probe_set_clocks(long long* buffer) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(nsamd::g_probe_clocks), &buffer, sizeof(buffer)) == hipSuccess ? NSAMD_OK : NSAMD_ERR_LAUNCH;
-}
-#endif
 
 extern "C" int nsamd_probe_mfma16(const float* A, const float* B, float* out, nsamd_stream_t stream) {
   NSAMD_REQUIRE(A && B && out);

@@ -5,6 +5,7 @@
 // and gradient in one pass (the losses are scalars whose upstream gradient is a known constant). The eager
 // reference spends ~20 launches and several [N,S,S] temporaries on this; here it is two launches and O(N*S) bytes.
 #include "common.h"
+#include "wave.h"
 
 namespace nsamd {
 
@@ -76,13 +77,9 @@ __device__ __forceinline__ void interlevel_body(
     for (int k0 = 0; k0 < Sp; k0 += 64) {
       const int k = k0 + lane;
       double v = k < Sp ? (double)wp_in[ray * Sp + k] : 0.0;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const double t = __shfl_up(v, d);
-        if (lane >= d) v = v + t;
-      }
+      v = wave_scan_inclusive_f64(v);
       v = v + carry;
-      carry = __shfl(v, 63);
+      carry = wave_read_f64<63>(v);
       if (k < Sp) cy[k + 1] = (float)v;
     }
   }
@@ -119,13 +116,9 @@ __device__ __forceinline__ void interlevel_body(
       for (int i0 = 0; i0 < Sf; i0 += 64) {
         const int i = i0 + lane;
         double v = i < Sf ? (double)rr[i] : 0.0;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const double t = __shfl_up(v, d);
-          if (lane >= d) v = v + t;
-        }
+        v = wave_scan_inclusive_f64(v);
         v = v + carry;
-        carry = __shfl(v, 63);
+        carry = wave_read_f64<63>(v);
         if (i < Sf) R[i + 1] = v;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

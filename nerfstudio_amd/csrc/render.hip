@@ -10,6 +10,7 @@
 // min/max (no atomics: 8192 same-address device atomics cost ~100 us on this part, measured) and the finishing pass
 // re-reduces the <= few thousand partials from L2 before clipping.
 #include "common.h"
+#include "wave.h"
 
 namespace nsamd {
 
@@ -75,15 +76,11 @@ __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
     if (density) {
       const float dd = s < S ? (tb[s + 1] - tb[s]) * density[ray * S + s] : 0.0f;
       double incl = (double)dd;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const double t = __shfl_up(incl, d);
-        if (lane >= d) incl = incl + t;
-      }
+      incl = wave_scan_inclusive_f64(incl);
       incl = incl + w_carry;
-      double excl = __shfl_up(incl, 1);
+      double excl = wave_shift_up1_f64(incl);
       if (lane == 0) excl = w_carry;
-      w_carry = __shfl(incl, 63);
+      w_carry = wave_read_f64<63>(incl);
       if (s < S) {
         w = nan_to_num((1.0f - expf(-dd)) * expf(-(float)excl));
         weights_out[ray * S + s] = w;
@@ -184,13 +181,9 @@ __global__ __launch_bounds__(kRenderThreads) void composite_fwd_kernel(
     for (int s0 = 0; s0 < S && idx == S; s0 += 64) {
       const int s2 = s0 + lane;
       double v = s2 < S ? (double)w_in[s2] : 0.0;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const double t = __shfl_up(v, d);
-        if (lane >= d) v = v + t;
-      }
+      v = wave_scan_inclusive_f64(v);
       v = v + carry;
-      carry = __shfl(v, 63);
+      carry = wave_read_f64<63>(v);
       const unsigned long long hit = __ballot(s2 < S && (float)v >= 0.5f);
       if (hit != 0ull) idx = s0 + __builtin_ctzll(hit);
     }
@@ -300,15 +293,11 @@ __global__ __launch_bounds__(kRenderThreads) void composite_bwd_kernel(
       const int i = i0 + lane;
       const float dd = i < S ? (tbw[i + 1] - tbw[i]) * density[ray * S + i] : 0.0f;
       double incl = (double)dd;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const double t = __shfl_up(incl, d);
-        if (lane >= d) incl = incl + t;
-      }
+      incl = wave_scan_inclusive_f64(incl);
       incl = incl + carry;
-      double excl = __shfl_up(incl, 1);
+      double excl = wave_shift_up1_f64(incl);
       if (lane == 0) excl = carry;
-      carry = __shfl(incl, 63);
+      carry = wave_read_f64<63>(incl);
       if (i < S) {
         ex_row[i] = expf(-dd);
         tr_row[i] = expf(-(float)excl);
@@ -329,15 +318,11 @@ __global__ __launch_bounds__(kRenderThreads) void composite_bwd_kernel(
         g = finite ? dwr[i] : 0.0f;  // nan_to_num backward masks non-finite products
       }
       double incl = (double)(r < S ? g * ((1.0f - ex) * trans) : 0.0f);
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const double t = __shfl_up(incl, d);
-        if (lane >= d) incl = incl + t;
-      }
+      incl = wave_scan_inclusive_f64(incl);
       incl = incl + carry;
-      double excl = __shfl_up(incl, 1);
+      double excl = wave_shift_up1_f64(incl);
       if (lane == 0) excl = carry;
-      carry = __shfl(incl, 63);
+      carry = wave_read_f64<63>(incl);
       if (r < S) d_density[ray * S + i] = (tbw[i + 1] - tbw[i]) * (g * trans * ex - (float)excl);
     }
   }

@@ -9,6 +9,7 @@
 // latency decides: one wavefront per ray, wave-level scans, no workgroup barriers.
 // Layout: 4 rays per 256-thread workgroup (N = 4096 -> 1024 workgroups); rows are read/written coalesced.
 #include "common.h"
+#include "wave.h"
 
 namespace nsamd {
 
@@ -58,16 +59,8 @@ __global__ __launch_bounds__(kThreads) void piecewise_bins_kernel(const float* _
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kWaves = 4;  // rays per 256-thread workgroup
 
-__device__ __forceinline__ double wave_scan_inclusive(double v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const double t = __shfl_up(v, d);
-    if (lane >= d) v = v + t;
-  }
-  return v;
-}
-
-__device__ __forceinline__ double wave_broadcast(double v, int src) { return __shfl(v, src); }
+// (wave.h: DPP scans - the shuffle-based Hillis-Steele version spent ~1.5 k clocks per scan in ds_bpermute round trips)
+__device__ __forceinline__ double wave_scan_inclusive(double v, int /*lane*/) { return wave_scan_inclusive_f64(v); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // RaySamples.get_weights (cameras/rays.py:129-152)
@@ -87,9 +80,9 @@ __global__ __launch_bounds__(kThreads) void weights_fwd_kernel(const float* __re
     const int i = i0 + lane;
     const float dd = i < S ? (tb[i + 1] - tb[i]) * dn[i] : 0.0f;
     const double incl = carry + wave_scan_inclusive((double)dd, lane);
-    double excl = __shfl_up(incl, 1);
+    double excl = wave_shift_up1_f64(incl);
     if (lane == 0) excl = carry;
-    carry = wave_broadcast(incl, 63);
+    carry = wave_read_f64<63>(incl);
     if (i < S) {
       const float alpha = 1.0f - expf(-dd);
       const float trans = expf(-(float)excl);
@@ -121,9 +114,9 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
     const int i = i0 + lane;
     const float dd = i < S ? (tb[i + 1] - tb[i]) * dn[i] : 0.0f;
     const double incl = carry + wave_scan_inclusive((double)dd, lane);
-    double excl = __shfl_up(incl, 1);
+    double excl = wave_shift_up1_f64(incl);
     if (lane == 0) excl = carry;
-    carry = wave_broadcast(incl, 63);
+    carry = wave_read_f64<63>(incl);
     if (i < S) {
       const float ex = expf(-dd);
       const float trans = expf(-(float)excl);
@@ -146,9 +139,9 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
     if (r < S) { ex = ex_row[i]; trans = tr_row[i]; g = g_row[i]; }
     const float gw = g * ((1.0f - ex) * trans);
     const double incl = carry + wave_scan_inclusive((double)(r < S ? gw : 0.0f), lane);
-    double excl = __shfl_up(incl, 1);
+    double excl = wave_shift_up1_f64(incl);
     if (lane == 0) excl = carry;
-    carry = wave_broadcast(incl, 63);
+    carry = wave_read_f64<63>(incl);
     if (r < S) ddensity[ray * S + i] = (tb[i + 1] - tb[i]) * (g * trans * ex - (float)excl);
   }
 }
@@ -189,9 +182,9 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
       const int i = i0 + lane;
       const float dd = i < S_prev ? (tb[i + 1] - tb[i]) * dn[i] : 0.0f;
       const double incl = carry0 + wave_scan_inclusive((double)dd, lane);
-      double excl = __shfl_up(incl, 1);
+      double excl = wave_shift_up1_f64(incl);
       if (lane == 0) excl = carry0;
-      carry0 = wave_broadcast(incl, 63);
+      carry0 = wave_read_f64<63>(incl);
       if (i < S_prev) {
         const float alpha = 1.0f - expf(-dd);
         const float trans = expf(-(float)excl);
@@ -206,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
       for (int i0 = 0; i0 < S_prev && idx == S_prev; i0 += 64) {
         const int i = i0 + lane;
         const double incl = carry1 + wave_scan_inclusive(i < S_prev ? (double)w[i] : 0.0, lane);
-        carry1 = wave_broadcast(incl, 63);
+        carry1 = wave_read_f64<63>(incl);
         const unsigned long long hit = __ballot(i < S_prev && (float)incl >= 0.5f);
         if (hit != 0ull) idx = i0 + __builtin_ctzll(hit);
       }
@@ -225,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
       v = v + hist_pad;
       w[i] = v;
     }
-    total = total + wave_broadcast(wave_scan_inclusive((double)v, lane), 63);
+    total = total + wave_read_f64<63>(wave_scan_inclusive((double)v, lane));
   }
   const float run = (float)total;  // double-accumulated sum, rounded once (= cumsum(w)[-1] of the oracle)
   const float pad = fmaxf(eps - run, 0.0f);
@@ -238,7 +231,7 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     const int i = i0 + lane;
     const float pdf = i < S_prev ? (w[i] + wpad) / wsum : 0.0f;
     const double incl = carry + wave_scan_inclusive((double)pdf, lane);
-    carry = wave_broadcast(incl, 63);
+    carry = wave_read_f64<63>(incl);
     if (i < S_prev) cdf[i + 1] = fminf(1.0f, (float)incl);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

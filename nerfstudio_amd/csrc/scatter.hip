@@ -30,6 +30,8 @@
 
 #include "scatter.h"
 
+NSAMD_PROBE_DEFINE(scatter)
+
 namespace nsamd {
 
 constexpr int kRunLen = 4;        // consecutive samples per thread in the run kernel
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
   uint32_t* cnt2 = cnt + kLevels * B;  // [kLevels][B] ranks inside the dynamic reservation (second sweep)
   uint32_t* base = cnt2 + kLevels * B; // [kLevels][B] start of the dynamic reservation
   uint32_t* lmax = base + kLevels * B; // [kLevels] max |gradient| bits
+  PROBE_STAMP(0, 0);
   for (int t = threadIdx.x; t < 2 * kLevels * B; t += kThreads) cnt[t] = 0u;
   if (threadIdx.x < kLevels) lmax[threadIdx.x] = 0u;
   const int first = blockIdx.y * kLevels;
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
     }
   }
   __syncthreads();
+  PROBE_STAMP(0, 1);
   const uint32_t mask = (1u << grid.log2_table_size) - 1u;
   const int sl = G.slice_log2;
   const uint32_t local_mask = (1u << sl) - 1u;
@@ -208,7 +212,9 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
   };
 
   sweep(std::integral_constant<int, 0>{});
+  PROBE_STAMP(0, 2);
   const int any_over = __syncthreads_or(over != 0u);
+  PROBE_STAMP(0, 3);
   for (int t = threadIdx.x; t < kLevels * B; t += kThreads) {
     const int i = t >> G.log2_bins;
     const int level = first + i < levels.count ? (int)levels.level[first + i] : -1;
@@ -222,9 +228,11 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
     const int level = first + (int)threadIdx.x < levels.count ? (int)levels.level[first + threadIdx.x] : -1;
     if (level >= 0 && lmax[threadIdx.x] != 0u) atomicMax(buf.hdr + level, lmax[threadIdx.x]);
   }
+  PROBE_STAMP(0, 4);
   if (!any_over) return;
   __syncthreads();
   sweep(std::integral_constant<int, 1>{});
+  PROBE_STAMP(0, 5);
 }
 
 // ---- pass 1, coarse levels -----------------------------------------------------------------------------------------
@@ -403,6 +411,7 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
   const int bin = blockIdx.x, level = blockIdx.y;
   const uint32_t tile = ((uint32_t)level << G.log2_bins) + (uint32_t)bin;
   const int entries = 1 << G.slice_log2;
+  PROBE_STAMP(0, 10);
   {
     uint4* z = reinterpret_cast<uint4*>(acc);
     for (int e = threadIdx.x; e < entries; e += blockDim.x) z[e] = make_uint4(0u, 0u, 0u, 0u);
@@ -417,6 +426,7 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
   const uint32_t n_dyn = min(buf.dyn_cursor[tile], Q - static_end);
   const uint32_t n_spill = min(min(buf.hdr[kHdrSpillCount], G.spill_cap), kSpillFold);
   __syncthreads();
+  PROBE_STAMP(0, 11);
   // self-cleaning cursor: the next call finds zeros again (the workspace state is zero-initialised once by its owner)
   if (threadIdx.x == 0) buf.dyn_cursor[tile] = 0u;
   const uint4* q = buf.queues + ((size_t)G.level_off[level] + (size_t)bin * Q);
@@ -485,6 +495,7 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
         }
       }
     }
+    PROBE_STAMP(0, 12);
     // dynamic area: contiguous, 4 records in flight per thread
     const uint4* dq = q + static_end;
     for (uint32_t e0 = 0; e0 < n_dyn; e0 += blockDim.x * 4u) {
@@ -498,11 +509,14 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
       for (int u = 0; u < 4; ++u)
         if (e0 + (uint32_t)u * blockDim.x + threadIdx.x < n_dyn) add_rec(r[u]);
     }
+    PROBE_STAMP(0, 13);
     // spill list (normally empty): every tile scans the folded prefix for its own records
     for (uint32_t e = threadIdx.x; e < n_spill; e += blockDim.x)
       if (buf.spill_tile[e] == tile) add_rec(buf.spill_rec[e]);
   }
+  PROBE_STAMP(0, 14);
   __syncthreads();
+  PROBE_STAMP(0, 15);
   float4* out = reinterpret_cast<float4*>(
       dtable + ((((size_t)level << grid.log2_table_size) + ((size_t)bin << G.slice_log2)) << 1));
   const uint4* a4 = reinterpret_cast<const uint4*>(acc);  // one entry = (lo0, hi0, lo1, hi1)
@@ -526,6 +540,7 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
       out[i] = o;
     }
   }
+  PROBE_STAMP(0, 16);
 }
 
 // After pass 2: spill records beyond the folded prefix (a pathological batch) are applied with float atomics — exact

@@ -1,0 +1,46 @@
+// Wave-level (64 lanes) scans and broadcasts of doubles on the DPP path of gfx9-family hardware.
+// The generic __shfl_up / __shfl of a double compile to two ds_bpermute_b32 each — an LDS-crossbar round trip of ~100 clocks
+// — and the per-ray kernels (one wavefront per ray) are chains of such scans: a 6-step Hillis-Steele scan was ~1.5 k clocks.
+// DPP moves run at VALU rate: row_shr 1/2/4/8 scan the four rows of 16 lanes, row_bcast:15 / row_bcast:31 carry the row
+// totals across (the sequence the AMDGPU backend itself emits for wave64 scans on GFX9).
+// Association of the additions differs from Hillis-Steele; for the fp32-valued summands of this library the double partial
+// sums are exact (sampler.hip header), so the fp32-rounded results are the same numbers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nsamd {
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  int lo = (int)(unsigned)(b & 0xffffffffull), hi = (int)(unsigned)(b >> 32);
+  // old = 0, bound_ctrl: lanes without a source (row start, disabled rows) read +0.0
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ double wave_scan_inclusive_f64(double v) {
+  v = v + dpp_move_f64<0x111, 0xf>(v);  // row_shr:1
+  v = v + dpp_move_f64<0x112, 0xf>(v);  // row_shr:2
+  v = v + dpp_move_f64<0x114, 0xf>(v);  // row_shr:4
+  v = v + dpp_move_f64<0x118, 0xf>(v);  // row_shr:8   -> inclusive scan inside every row of 16
+  v = v + dpp_move_f64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = v + dpp_move_f64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+// value of the previous lane (lane 0 reads +0.0): wave_shr:1
+__device__ __forceinline__ double wave_shift_up1_f64(double v) { return dpp_move_f64<0x138, 0xf>(v); }
+
+// value of lane `LANE`, wave-uniform (v_readlane_b32 x 2)
+template <int LANE>
+__device__ __forceinline__ double wave_read_f64(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffull), LANE);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), LANE);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
+}
+
+}  // namespace nsamd
