@@ -389,6 +389,8 @@ def algorithmic_model(key):
     M_main = RAYS_PER_GPU * 48
     if key in ("nsamd_field_mlp_fwd", "nsamd_field_mlp_fwd_save"):
         return "mfma", M_main * 2 * 11392  # MACs/sample: 32*64 + 64*16 + 63*64 + 64*64 + 64*3  
+    if key == "nsamd_field_fused_fwd":
+        return "hbm", M_main * 16 * 8 * 8  # hash gathers (the bound of the fused launch; its MLP half is 4.5 GFLOP of MFMA)
     if key == "nsamd_field_mlp_bwd":
         return "mfma", M_main * 2 * 11392 * 3  # recompute + data gradient + weight gradient
     if key == "nsamd_field_mlp_bwd_saved":

@@ -236,6 +236,19 @@ int nsamd_field_mlp_bwd_saved(const float* enc, const float* selector, const flo
                               float* denc, nsamd_field_mlp_grads grads, float* workspace, int64_t workspace_floats,
                               nsamd_stream_t stream);
 
+/* nsamd_hashgrid_encode_fwd + nsamd_field_mlp_fwd in ONE launch for 16-level grids (the nerfacto main field,
+ * fields/nerfacto_field.py:203-310 with MLPWithHashEncoding, field_components/mlp.py:187-295): the hash features go
+ * from the gathers into the B operands of base layer 0 in registers; a wave's next tile of gathers is in flight while its
+ * current tile runs on the matrix cores. selector [M] and enc [32, M] (feature-major) are optional outputs (the backward of
+ * a training step reads them). Bit-identical to the two-launch path. NSAMD_ERR_UNSUPPORTED for other level counts.
+ * Measured on MI355X at the nerfacto shape (196 608 points, 2^19-entry levels): 155-160 us against 78 + 56 us for the two
+ * launches — gathering all 16 levels per wave gives up the L2 locality of the level-major sweep — so the training step
+ * keeps the two launches; this entry point is the smaller-table / single-launch alternative. */
+int nsamd_field_fused_fwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
+                          nsamd_grid grid, const float* directions, const int64_t* camera_indices,
+                          const float* appearance_const, int64_t dir_group, nsamd_field_mlp mlp, float* selector,
+                          float* enc, float* density, float* rgb, nsamd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Generic dense layer for the stand-alone MLP of the plugin API (MLP.pytorch_fwd, field_components/mlp.py:160-179):
  * y[M,N] = act(x[M,K] W[N,K]^T + b[N]); activation 0 = none, 1 = ReLU, 2 = Sigmoid, 3 = Softplus (the DensityFieldHead of

@@ -215,13 +215,36 @@ __device__ __forceinline__ void load_enc_tile(const float* __restrict__ enc, int
     for (int r = 0; r < 4; ++r) out[t][r] = enc[(int64_t)(16 * t + 4 * g + r) * M + p];
 }
 
+// view direction and appearance row of a lane's point, loaded ahead of the tile's arithmetic
+struct HeadPre {
+  float d[3];
+  v4f app[2];
+};
+
+__device__ __forceinline__ HeadPre load_head_pre(const float* __restrict__ directions, const float* __restrict__ app_table,
+                                                 const float* __restrict__ app_const, int app_dim, const TileInputs& ti,
+                                                 int g) {
+  HeadPre h;
+  const float* d = directions + 3 * ti.ray;
+  h.d[0] = d[0]; h.d[1] = d[1]; h.d[2] = d[2];
+  if (app_dim > 0) {
+    const float* src = (app_table != nullptr) ? app_table + ti.cam * 32 : app_const;
+    h.app[0] = *reinterpret_cast<const v4f*>(src + 4 * g);
+    h.app[1] = *reinterpret_cast<const v4f*>(src + 16 + 4 * g);
+  } else {
+    h.app[0] = v4f{0.f, 0.f, 0.f, 0.f};
+    h.app[1] = v4f{0.f, 0.f, 0.f, 0.f};
+  }
+  return h;
+}
+
 // A.enc must hold the tile's encoded features (load_enc_tile) on entry.
 __device__ __forceinline__ void field_forward_tile(const float* wf, const float* bias,
                                                    const float* __restrict__ directions,
                                                    const float* __restrict__ app_table,
                                                    const float* __restrict__ app_const, int64_t dir_group, int64_t M,
                                                    int app_dim, const TileInputs& ti, int lane, FieldActs& A,
-                                                   int probe_slot = 63) {
+                                                   int probe_slot = 63, const HeadPre* pre = nullptr) {
   const int g = lane >> 4;
   load_bias<4>(bias + kBiasBase0, A.h1, g);
   chain_gemm<4, 2>(wf + kOffBase0, A.enc, A.h1, lane);
@@ -231,17 +254,23 @@ __device__ __forceinline__ void field_forward_tile(const float* wf, const float*
   PROBE_STAMP(kWaves, probe_slot);
 
   // head input: SH of (dir + 1) / 2  (base_field.py:136-142), geo in place, appearance embedding
-  const float* d = directions + 3 * ti.ray;
-  A.hin[0] = sh_quad(d[0], d[1], d[2], g);
-  A.hin[1] = A.o16[0];
-  if (app_dim > 0) {
-    const float* src = (app_table != nullptr) ? app_table + ti.cam * 32 : app_const;
-    A.hin[2] = *reinterpret_cast<const v4f*>(src + 4 * g);
-    A.hin[3] = *reinterpret_cast<const v4f*>(src + 16 + 4 * g);
-  } else {
-    A.hin[2] = v4f{0.f, 0.f, 0.f, 0.f};
-    A.hin[3] = v4f{0.f, 0.f, 0.f, 0.f};
+  if (pre == nullptr) {
+    const float* d = directions + 3 * ti.ray;
+    A.hin[0] = sh_quad(d[0], d[1], d[2], g);
+    if (app_dim > 0) {
+      const float* src = (app_table != nullptr) ? app_table + ti.cam * 32 : app_const;
+      A.hin[2] = *reinterpret_cast<const v4f*>(src + 4 * g);
+      A.hin[3] = *reinterpret_cast<const v4f*>(src + 16 + 4 * g);
+    } else {
+      A.hin[2] = v4f{0.f, 0.f, 0.f, 0.f};
+      A.hin[3] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+  } else {  // fetched by the caller ahead of other memory traffic (fused kernel)
+    A.hin[0] = sh_quad(pre->d[0], pre->d[1], pre->d[2], g);
+    A.hin[2] = pre->app[0];
+    A.hin[3] = pre->app[1];
   }
+  A.hin[1] = A.o16[0];
   load_bias<4>(bias + kBiasHead0, A.ha, g);
   chain_gemm<4, 4>(wf + kOffHead0, A.hin, A.ha, lane);
   relu_tiles<4>(A.ha);
@@ -323,6 +352,123 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 1 : 2) void field_mlp_fwd
     ++probe_it;
   }
   PROBE_STAMP(WAVES, 63);
+}
+
+// ---- fused forward: hash grid (16 levels) -> base MLP -> head MLP ----------------------------------------------------
+// One launch instead of nsamd_hashgrid_encode_fwd + nsamd_field_mlp_fwd. The two halves are bound by different units — the
+// gathers by the texture-address / L1 path (~0.55 lane-gathers per clock per CU, r02 probes), the MLPs by the matrix cores —
+// so a wave issues the 32 gathers of its NEXT tile, runs the MFMA chain of the current one while they fly, and only then
+// blends them: in the chain layout lane (j, g) holds features 16t + 4g + r of point j, i.e. the two features of levels
+// 8t + 2g and 8t + 2g + 1 — four levels of one point per lane, straight into the B operands of base layer 0.
+// Same arithmetic as hash_encode_fwd_kernel (blend order x, y, z, no contraction) and as field_forward_tile: outputs and
+// the saved features are bit-identical to the two-launch path (tests/test_gpu_kernels.py).
+constexpr int kFusedWaves = 8;
+constexpr int kFusedThreads = 64 * kFusedWaves;
+
+struct GatherSet {
+  float2 v[4][8];  // 4 levels x 8 corners of this lane's point
+  float x, y, z;   // normalised position (selector applied)
+  float sel;
+};
+
+// the 4 levels of lane group g: q = 0..3 -> 2g, 2g + 1, 8 + 2g, 9 + 2g
+__device__ __forceinline__ int fused_level(int q, int g) { return 8 * (q >> 1) + 2 * g + (q & 1); }
+
+__device__ __forceinline__ void fused_issue(const nsamd_points& P, int64_t p, int transform, const nsamd_aabb& box,
+                                            const float2* __restrict__ table, int log2_table_size,
+                                            const float* scalings_lds, int g, GatherSet& G) {
+  load_position(P, p, G.x, G.y, G.z);
+  G.sel = normalise_position(transform, box, G.x, G.y, G.z);
+  const uint32_t mask = (1u << log2_table_size) - 1u;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int level = fused_level(q, g);
+    const Cell c = locate_cell(G.x, G.y, G.z, scalings_lds[level]);
+    const float2* __restrict__ tl = table + ((size_t)level << log2_table_size);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) G.v[q][k] = tl[corner_index(c, k, mask)];
+  }
+}
+
+// blend order x, y, z exactly as encodings.py:446-456 (and hash_encode_fwd_kernel)
+__device__ __forceinline__ void fused_blend(const GatherSet& G, const float* scalings_lds, int g, v4f* enc) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const Cell c = locate_cell(G.x, G.y, G.z, scalings_lds[fused_level(q, g)]);
+    const float wx = c.w[0], wy = c.w[1], wz = c.w[2];
+    const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      auto h = [&](int k) { return f == 0 ? G.v[q][k].x : G.v[q][k].y; };
+      const float yc_zc = h(7) * wx + h(6) * ux;
+      const float yf_zc = h(5) * wx + h(4) * ux;
+      const float yf_zf = h(1) * wx + h(0) * ux;
+      const float yc_zf = h(3) * wx + h(2) * ux;
+      const float zc = yc_zc * wy + yf_zc * uy;
+      const float zf = yc_zf * wy + yf_zf * uy;
+      enc[q >> 1][2 * (q & 1) + f] = zc * wz + zf * uz;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kFusedThreads, 1) void field_fused_fwd_kernel(
+    nsamd_points P, int64_t M, int transform, nsamd_aabb box, const float2* __restrict__ table, nsamd_grid grid,
+    const float* __restrict__ directions, const int64_t* __restrict__ cams, const float* __restrict__ app_const,
+    int64_t dir_group, nsamd_field_mlp mlp, int app_dim, float* __restrict__ selector_out, float* __restrict__ enc_out,
+    float* __restrict__ density, float* __restrict__ rgb) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* wf = lds;
+  float* bias = lds + kFragTotal;
+  float* scal = bias + 256;  // 16 level scalings (lane-dependent index: LDS, not the kernel-argument array)
+  stage_all_fwd<kFusedThreads>(wf, bias, mlp, app_dim);
+  if (threadIdx.x < 16) scal[threadIdx.x] = grid.scalings[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const int64_t tiles = (M + 15) / 16;
+  const int64_t stride = (int64_t)gridDim.x * kFusedWaves;
+  const float* app_table = cams ? mlp.appearance : nullptr;
+  int64_t tile = (int64_t)blockIdx.x * kFusedWaves + wave;
+  GatherSet G;
+  TileInputs ti_next;
+  HeadPre pre_next;
+  if (tile < tiles) {
+    // order matters: vmcnt retires in order, so whatever the MFMA chain waits for must be OLDER than the gathers that are
+    // meant to stay in flight behind it
+    ti_next = tile_inputs(tile, lane, M, nullptr, cams, dir_group);
+    pre_next = load_head_pre(directions, app_table, app_const, app_dim, ti_next, g);
+    fused_issue(P, min(tile * 16 + j, M - 1), transform, box, table, grid.log2_table_size, scal, g, G);
+  }
+  for (; tile < tiles; tile += stride) {
+    asm volatile("" ::: "memory");  // keep the weight fragments in LDS (see field_mlp_fwd_kernel)
+    const TileInputs ti = ti_next;
+    const HeadPre pre = pre_next;
+    FieldActs A;
+    fused_blend(G, scal, g, A.enc);  // waits for this tile's gathers
+    const float sel = G.sel;
+    // the next tile's inputs, then its gathers: they fly while the matrix cores work on this one
+    if (tile + stride < tiles) {
+      ti_next = tile_inputs(tile + stride, lane, M, nullptr, cams, dir_group);
+      pre_next = load_head_pre(directions, app_table, app_const, app_dim, ti_next, g);
+      fused_issue(P, min((tile + stride) * 16 + j, M - 1), transform, box, table, grid.log2_table_size, scal, g, G);
+    }
+    if (ti.live) {  // (after the loads above: the appearance row depends on the camera index, and waiting for that load
+                    //  must not wait for these stores)
+      if (g == 0 && selector_out != nullptr) selector_out[ti.p] = sel;
+      if (enc_out != nullptr) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) enc_out[(int64_t)(16 * t + 4 * g + r) * M + ti.p] = A.enc[t][r];
+      }
+    }
+    field_forward_tile(wf, bias, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A, 63, &pre);
+    if (lane < 16 && ti.live) {
+      density[ti.p] = mlp.average_init_density * expf(A.o16[0][0]) * sel;
+      float* o = rgb + 3 * ti.p;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] = 1.0f / (1.0f + expf(-A.rgbp[0][c]));
+    }
+  }
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------
@@ -575,6 +721,14 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     if (tile >= tiles) ti.live = false;  // idle wave of the last round: computes, contributes zeros
     FieldActs A;
     load_enc_tile(enc, M, ti.p, lane, A.enc);
+    // the upstream gradients of this tile (lanes g == 0 use them two and five phases further down): fetched with the
+    // inputs, so their latency hides behind the forward instead of opening the head-2 and base-1 phases
+    float up_rgb[3] = {0.f, 0.f, 0.f}, up_density = 0.f;
+    if (g == 0 && ti.live) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) up_rgb[c] = drgb[3 * ti.p + c];
+      up_density = ddensity[ti.p];
+    }
     if (acts != nullptr) {  // saved by the forward of this step: no recomputation
       load_acts(acts, tile < tiles ? tile : tiles - 1, lane, A);
       build_head_input(directions, app_table, app_const, dir_group, app_dim, ti, lane, A);
@@ -592,7 +746,7 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float sg = 1.0f / (1.0f + expf(-A.rgbp[0][c]));
-        g_rgbp[0][c] = drgb[3 * ti.p + c] * (sg * (1.0f - sg));
+        g_rgbp[0][c] = up_rgb[c] * (sg * (1.0f - sg));
       }
     }
     if (!(probe_skip & 2)) __syncthreads();  // the previous iteration's last weight-gradient reads of the scratch are done
@@ -683,7 +837,7 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     if (g == 0) {
       // d density / d pre = avg * sel * exp(clamp(pre,-15,15))   (activations.py:39-42); slot 16 has zero weight
       const float pre = A.o16[0][0];
-      g_o16[0][0] = ti.live ? ddensity[ti.p] * ti.sel * mlp.average_init_density *
+      g_o16[0][0] = ti.live ? up_density * ti.sel * mlp.average_init_density *
                                   expf(fminf(fmaxf(pre, -15.0f), 15.0f))
                             : 0.0f;
     }
@@ -964,6 +1118,32 @@ extern "C" int nsamd_field_mlp_fwd(const float* enc, const float* selector, cons
                                    nsamd_stream_t stream) {
   return field_mlp_fwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, density,
                             rgb, nullptr, stream);
+}
+
+extern "C" int nsamd_field_fused_fwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
+                                    nsamd_grid grid, const float* directions, const int64_t* camera_indices,
+                                    const float* appearance_const, int64_t dir_group, nsamd_field_mlp mlp,
+                                    float* selector, float* enc, float* density, float* rgb, nsamd_stream_t stream) {
+  if (M == 0) return NSAMD_OK;
+  if (grid.num_levels != 16) return NSAMD_ERR_UNSUPPORTED;  // 32 features = the K of base layer 0
+  NSAMD_REQUIRE(M > 0 && table != nullptr && transform >= 0 && transform <= 2);
+  NSAMD_REQUIRE(grid.log2_table_size >= 1 && grid.log2_table_size <= 28);
+  if (pts.positions == nullptr) {
+    NSAMD_REQUIRE(pts.origins && pts.directions && pts.t_bins && pts.samples_per_ray > 0 && M % pts.samples_per_ray == 0);
+  }
+  int app_dim = 0;
+  const float dummy = 0.0f;
+  int st = field_common_checks(&dummy, directions, dir_group, M, mlp, camera_indices, appearance_const, &app_dim);
+  if (st) return st;
+  NSAMD_REQUIRE(density && rgb);
+  const size_t lds = sizeof(float) * (kFragTotal + 256 + 16);
+  const int64_t tiles = (M + 15) / 16;
+  const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + kFusedWaves - 1) / kFusedWaves);
+  field_fused_fwd_kernel<<<blocks, kFusedThreads, lds, (hipStream_t)stream>>>(
+      pts, M, transform, aabb, reinterpret_cast<const float2*>(table), grid, directions, camera_indices, appearance_const,
+      dir_group, mlp, app_dim, selector, enc, density, rgb);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
 }
 
 extern "C" int64_t nsamd_field_mlp_saved_floats(int64_t M) { return M <= 0 ? 0 : ((M + 15) / 16) * kActSlots * 256; }

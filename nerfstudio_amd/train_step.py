@@ -111,6 +111,11 @@ class NerfactoTrainStep:
         import os
 
         self.save_acts = os.environ.get("NSAMD_FIELD_SAVE_ACTS", "0") == "1"
+        # One launch for hash grid + MLPs of the main field (nsamd_field_fused_fwd) — measured SLOWER than the two launches on
+        # MI355X (155-160 us against 78 + 56): a wave that gathers all 16 levels at once loses the level-major sweep's L2
+        # locality (each 4 MB level slice stays in one L2 while it is swept), which is worth more than hiding the gathers
+        # behind the MFMA chain. Kept as an opt-in, bit-identical alternative (profiles/r02_negative_results.txt).
+        self.fuse_main_forward = os.environ.get("NSAMD_FUSE_MAIN_FWD", "0") == "1"
         self.f_saved = e(int(N.load().nsamd_field_mlp_saved_floats(mm))) if self.save_acts else None
         # Second stream for the proposal-network backward: the two backward chains are independent, and since the
         # scatter kernels were reworked (latency-bound phases, small workgroups) they overlap: 3.87 -> 4.02 M rays/s on
@@ -309,14 +314,27 @@ class NerfactoTrainStep:
         fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), emb.shape[0] if emb is not None else 0,
                         float(fld.average_init_density))
         cams = N.ptr(self.camera_indices) if emb is not None else None
-        ck(lib.nsamd_hashgrid_encode_fwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
-                                         enc.spec.native(), N.ptr(self.f_enc), 1, mm, N.ptr(self.f_sel), st),
-           "hashgrid_encode_fwd")
-        if self.save_acts:
+        fused = N.ERR_UNSUPPORTED
+        if not self.save_acts and self.fuse_main_forward:
+            # hash grid -> base -> head in one launch (features in registers, next tile's gathers behind the MFMA chain)
+            fused = lib.nsamd_field_fused_fwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
+                                              enc.spec.native(), N.ptr(self.directions), cams, None, S, fm,
+                                              N.ptr(self.f_sel), N.ptr(self.f_enc), N.ptr(self.f_dens), N.ptr(self.f_rgb), st)
+            if fused != N.ERR_UNSUPPORTED:
+                ck(fused, "field_fused_fwd")
+        if fused != N.ERR_UNSUPPORTED:
+            pass
+        elif self.save_acts:
+            ck(lib.nsamd_hashgrid_encode_fwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
+                                             enc.spec.native(), N.ptr(self.f_enc), 1, mm, N.ptr(self.f_sel), st),
+               "hashgrid_encode_fwd")
             ck(lib.nsamd_field_mlp_fwd_save(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm,
                                             fm, N.ptr(self.f_dens), N.ptr(self.f_rgb), N.ptr(self.f_saved), st),
                "field_mlp_fwd_save")
         else:
+            ck(lib.nsamd_hashgrid_encode_fwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
+                                             enc.spec.native(), N.ptr(self.f_enc), 1, mm, N.ptr(self.f_sel), st),
+               "hashgrid_encode_fwd")
             ck(lib.nsamd_field_mlp_fwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
                                        N.ptr(self.f_dens), N.ptr(self.f_rgb), st), "field_mlp_fwd")
         # weights + compositing + MSE value/gradient in one launch (+ the global depth clip)

@@ -23,7 +23,7 @@ lib = C.CDLL(SO)
 vp, i64 = C.c_void_p, C.c_int64
 lib.nsamd_field_mlp_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, N.FieldMlp, vp, vp, vp]
 lib.nsamd_field_mlp_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, N.FieldMlp, vp, vp, vp, N.FieldMlpGrads, vp, i64, vp]
-lib.nsamd_probe_set_clocks.argtypes = [vp]
+lib.nsamd_probe_set_clocks_field.argtypes = [vp]
 
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(0)
@@ -75,10 +75,10 @@ def timed(fn, n=20):
 
 def stamps(fn, waves):
     buf = torch.zeros(waves, 64, dtype=torch.int64, device=dev)
-    assert lib.nsamd_probe_set_clocks(buf.data_ptr()) == 0
+    assert lib.nsamd_probe_set_clocks_field(buf.data_ptr()) == 0
     fn()
     torch.cuda.synchronize()
-    assert lib.nsamd_probe_set_clocks(None) == 0
+    assert lib.nsamd_probe_set_clocks_field(None) == 0
     return buf.cpu()
 
 

@@ -833,6 +833,59 @@ def test_train_step_runner_matches_autograd_path(F):
             assert float(p.grad.abs().max()) == 0.0, k
 
 
+@pytest.mark.parametrize("contract,ray_mode,with_cams", [(True, True, True), (False, False, False), (True, False, True)])
+def test_fused_main_field_forward_is_bit_identical(F, contract, ray_mode, with_cams):
+    """nsamd_field_fused_fwd (hash L16 -> base -> head in one launch, features in registers) against
+    nsamd_hashgrid_encode_fwd + nsamd_field_mlp_fwd: selector, saved features, density and rgb equal bit for bit; ragged M
+    (not a multiple of the 16-point tile); other level counts are refused."""
+    from nerfstudio_amd import _native as N
+
+    lib, st = N.load(), N.stream()
+    torch.manual_seed(5)
+    n, S = 67, 48 if ray_mode else 1
+    M = n * S if ray_mode else 1000 + 7
+    log2 = 14
+    scal = [float(np.floor(16.0 * np.exp(np.log(2048 / 16) / 15) ** i)) for i in range(16)]
+    grid = N.make_grid(16, log2, scal)
+    table = ((torch.rand(16 << log2, 2) - 0.5) * 0.8).cuda()
+    if ray_mode:
+        o = ((torch.rand(n, 3) - 0.5) * 1.5).cuda()
+        d = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1).cuda()
+        t_bins = torch.sort(torch.rand(n, S + 1) * 4.0, dim=-1).values.cuda()
+        pts = N.make_points(None, o, d, t_bins, S)
+        dirs, group, rays = d, S, n
+    else:
+        pos = ((torch.rand(M, 3) - 0.5) * (6.0 if contract else 2.4)).cuda()
+        pts = N.make_points(positions=pos)
+        dirs, group, rays = torch.nn.functional.normalize(torch.randn(M, 3), dim=-1).cuda(), 1, M
+    shapes = [(64, 32), (64,), (16, 64), (16,), (64, 63 if with_cams else 31), (64,), (64, 64), (64,), (3, 64), (3,)]
+    params = [(torch.randn(*s) * 0.3).cuda() for s in shapes]
+    emb = (torch.randn(9, 32) * 0.2).cuda() if with_cams else None
+    cams = torch.randint(0, 9, (rays,)).cuda() if with_cams else None
+    fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), 9 if with_cams else 0, 0.8)
+    box = N.make_aabb(torch.tensor([[-1.2, -1.2, -1.2], [1.2, 1.2, 1.2]]))
+    xf = N.XFORM_CONTRACT if contract else N.XFORM_AABB
+    e = lambda *sh: torch.empty(sh, device="cuda")  # noqa: E731
+    enc_a, sel_a, dens_a, rgb_a = e(32, M), e(M), e(M), e(M, 3)
+    N.check(lib.nsamd_hashgrid_encode_fwd(pts, M, xf, box, N.ptr(table), grid, N.ptr(enc_a), 1, M, N.ptr(sel_a), st), "enc")
+    N.check(lib.nsamd_field_mlp_fwd(N.ptr(enc_a), N.ptr(sel_a), N.ptr(dirs), N.ptr(cams), None, group, M, fm, N.ptr(dens_a),
+                                    N.ptr(rgb_a), st), "mlp")
+    enc_b, sel_b, dens_b, rgb_b = e(32, M), e(M), e(M), e(M, 3)
+    N.check(lib.nsamd_field_fused_fwd(pts, M, xf, box, N.ptr(table), grid, N.ptr(dirs), N.ptr(cams), None, group, fm,
+                                      N.ptr(sel_b), N.ptr(enc_b), N.ptr(dens_b), N.ptr(rgb_b), st), "fused")
+    assert 0.05 < float(sel_a.mean()) <= 1.0
+    for a, b, name in ((sel_a, sel_b, "selector"), (enc_a, enc_b, "features"), (dens_a, dens_b, "density"), (rgb_a, rgb_b, "rgb")):
+        assert torch.equal(a, b), name
+    # the optional outputs are optional
+    dens_c, rgb_c = e(M), e(M, 3)
+    N.check(lib.nsamd_field_fused_fwd(pts, M, xf, box, N.ptr(table), grid, N.ptr(dirs), N.ptr(cams), None, group, fm, None, None,
+                                      N.ptr(dens_c), N.ptr(rgb_c), st), "fused, no saved outputs")
+    assert torch.equal(dens_c, dens_a) and torch.equal(rgb_c, rgb_a)
+    g8 = N.make_grid(8, log2, scal[:8])
+    assert lib.nsamd_field_fused_fwd.fn(pts, M, xf, box, N.ptr(table), g8, N.ptr(dirs), N.ptr(cams), None, group, fm, None, None,
+                                        N.ptr(dens_c), N.ptr(rgb_c), st) == N.ERR_UNSUPPORTED
+
+
 def test_train_step_runner_random_background(F, monkeypatch):
     """background_color="random" on the fused runner (renderers.py:112-115, 194-196; models/nerfacto.py:377-381) against the
     module path with the same rand_like draw: rendered colour (no background), losses, every gradient."""
