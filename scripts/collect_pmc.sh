@@ -63,9 +63,9 @@ groups = {  # bench key -> (kernel substring, grid, streaming) parts; streaming 
                                                       ("scatter_apply_kernel", "1048576", True),
                                                       ("scatter_finish_kernel", "8192", False)],
     "nsamd_field_mlp_bwd": [("field_mlp_bwd_kernel", "131072", False), ("field_dw_reduce_kernel", None, False)],
-    "nsamd_field_mlp_fwd": [("field_mlp_fwd_kernel", "196608", False)],
+    "nsamd_field_mlp_fwd": [("field_mlp_fwd_kernel", None, False)],
     "nsamd_adam_step": [("adam_kernel", "524288", True)],
-    "nsamd_hashgrid_encode_fwd[L=16,M=196608]": [("hash_encode_fwd_kernel<1>", "3145728", False)],
+    "nsamd_hashgrid_encode_fwd[L=16,M=196608]": [("hash_encode_fwd", "3145728", False)],
 }
 traffic = {}
 for key, parts in groups.items():
