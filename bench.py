@@ -103,8 +103,10 @@ class Trainer:
     hides the all-reduce behind the proposal backward of step k AND the proposal forward of step k+1, with exactly the
     sequential semantics (every parameter is updated before its next use). `finish()` drains the pending update."""
 
-    def __init__(self, model, arena, ray_bundle, batch, world=1, use_graph=True, use_runner=True, pool=None):
+    def __init__(self, model, arena, ray_bundle, batch, world=1, use_graph=True, use_runner=True, pool=None,
+                 force_dp=False):
         self.model, self.arena, self.rb, self.batch, self.world = model, arena, ray_bundle, batch, world
+        self.dp = world > 1 or force_dp  # force_dp: the data-parallel schedule with a one-rank communicator
         self.pool = pool  # BATCH_SLOTS pre-generated batches in HBM (None: one fixed batch)
         self.step = 0
         self.opt_step = 0
@@ -135,7 +137,7 @@ class Trainer:
             self.runner.anneal_dev = self.hyper[4:5]
             if os.environ.get("NSAMD_SIDE_STREAM", "1") == "0":  # A/B switch: proposal backward on the main stream
                 self.runner.side_stream = None
-            if world > 1:
+            if self.dp:
                 from nerfstudio_amd.dp_schedule import PipelinedExchange
 
                 self.exchange = PipelinedExchange(arena, self._run, before_main_update=self._push_hyper)
@@ -228,7 +230,7 @@ class Trainer:
     # -- data-parallel segments (N > 1, runner) --------------------------------------------------------------------------
     @property
     def pipelined(self):
-        return self.world > 1 and self.runner is not None
+        return self.dp and self.runner is not None
 
     def _seg(self, name):
         """The body of one captured segment (also what the eager path runs)."""
@@ -327,7 +329,7 @@ class Trainer:
     def _eager_iteration(self, updated):
         if self.pipelined:
             self._pipelined_iteration(updated)
-        elif self.world > 1:
+        elif self.dp:
             self._plain_dp_iteration(updated)
         else:
             self._prologue(updated)
@@ -336,7 +338,7 @@ class Trainer:
         self._true_steps = dict(self.arena.step_counts)
 
     def try_capture(self):
-        if not self.use_graph or (self.world > 1 and not self.pipelined):
+        if not self.use_graph or (self.dp and not self.pipelined):
             return False
         try:
             self.capture()
@@ -614,6 +616,10 @@ def main():
                     help="bounded = BASELINE configs[1]/[2] (the metric's configuration); unbounded = configs[4] "
                          "(cameras outside the box, most samples in the contracted region)")
     ap.add_argument("--fixed-batch", action="store_true", help="train on one fixed ray batch instead of rotating the pool")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="N = 1 only: run the data-parallel schedule (pipelined exchange, compact table prefix, async "
+                         "all-reduce on the communication stream) over a ONE-rank RCCL communicator — exercises the N > 1 "
+                         "code path on a single-GPU box; the losses must equal the plain N = 1 run")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: check the launch plumbing (RANK / WORLD_SIZE / MASTER_* env, process group, the pipelined "
                          "exchange with the compact table prefix over gloo) and print the JSON skeleton")
@@ -630,7 +636,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if args.force_dp:
+        assert world == 1, "--force-dp is the single-GPU rehearsal of the data-parallel path"
+        os.environ["NSAMD_FORCE_COLLECTIVES"] = "1"
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
@@ -651,7 +663,7 @@ def main():
     # each rank its own rays (scripts/train.py:98): BATCH_SLOTS batches per rank, disjoint seeds
     rb, batch, pool = synthetic_batch(device, seed=1000 + (0 if same else 100 * rank), workload=args.workload)
     trainer = Trainer(model, arena, rb, batch, world=world, use_graph=not args.no_graph, use_runner=not args.autograd,
-                      pool=None if args.fixed_batch else pool)
+                      pool=None if args.fixed_batch else pool, force_dp=args.force_dp)
 
     for _ in range(max(1, args.warmup // 2)):  # eager warm-up: lazy kernel attributes, caches, allocator
         trainer.train_iteration()
@@ -660,7 +672,7 @@ def main():
     # way (N = 1: 1.00 ms/step eager vs 1.03 ms replayed), and replaying captured segments between eager collectives could
     # only be exercised over gloo with two ranks sharing one GPU, where it is pathologically slow (profiles/
     # r01_dp_schedule_check.log). --dp-graph opts in.
-    graphed = trainer.try_capture() if (world == 1 or args.dp_graph) else False
+    graphed = trainer.try_capture() if ((world == 1 and not args.force_dp) or args.dp_graph) else False
     for _ in range(args.warmup - max(1, args.warmup // 2)):
         trainer.train_iteration()
     trainer.finish()
@@ -727,6 +739,8 @@ def main():
                        "driver": "autograd modules" if args.autograd else "explicit kernel schedule (train_step.py)"},
             "roofline": roof,
         }
+        if args.force_dp:
+            out["config"]["force_dp"] = "data-parallel schedule over a one-rank RCCL communicator (rehearsal of the N > 1 path)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(workload=args.workload)
         if args.kernel_table:
@@ -734,7 +748,7 @@ def main():
                 print(f"{r['kernel']:64s} {r['calls_per_step']:5.1f}/step {r['ms_per_step']:9.4f} ms/step "
                       f"{r['mean_ms']:9.4f} ms/launch", file=sys.stderr)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_dp:
         dist.destroy_process_group()
 
 

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
+import os
+
 import torch
 import torch.distributed as dist
 from torch.nn import Parameter
@@ -65,6 +67,12 @@ class _GroupHandle:
                 h.wait()
         self.handles = []
         self._finish()
+
+
+def _single(group=None) -> bool:
+    """One rank: the collectives are skipped — unless NSAMD_FORCE_COLLECTIVES=1 asks for them anyway (a one-rank RCCL
+    communicator: the way to run the data-parallel path's collectives, streams and compact exchange on a single-GPU box)."""
+    return dist.get_world_size(group) == 1 and os.environ.get("NSAMD_FORCE_COLLECTIVES") != "1"
 
 
 class ParamArena:
@@ -153,7 +161,7 @@ class ParamArena:
         """Sum one contiguous slice of the gradient arena over the ranks. With async_op the collective runs on the
         communication stream (RCCL) while the caller keeps launching compute; `.wait()` the returned handle before the
         optimiser reads the slice. Returns None when there is nothing to do (single process)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or _single(group):
             return None
         return dist.all_reduce(self.grad[start:end], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
@@ -174,7 +182,7 @@ class ParamArena:
         """Sum one optimiser group's gradients over the ranks: dense spans as they lie, registered table prefixes
         through their compact buffers. Returns a handle whose wait() also scatters the reduced rows back (None when
         there is nothing to do)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or _single(group):
             return None
         a, b = self.groups[name]
         compact = sorted((c for c in getattr(self, "_compact", {}).values() if a <= c[0] < b), key=lambda c: c[0])

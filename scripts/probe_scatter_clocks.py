@@ -67,3 +67,15 @@ fin = (a[:, 16] - start).double()
 print(f"   apply workgroup finish times (clocks after the first start): min {fin.min().item():.0f} mean {fin.mean().item():.0f} max {fin.max().item():.0f}")
 st = (a[:, 10] - start).double()
 print(f"   apply workgroup start times: quartiles {[int(v) for v in torch.quantile(st, torch.tensor([0.25, 0.5, 0.75, 1.0], dtype=torch.float64)).tolist()]}")
+# per level (blockIdx.y of the apply grid): where the static-segment time goes
+bins = 64
+per_wg = t.view(-1, 16, 64)  # [workgroup = level * bins + bin][wave][slot]
+for level in range(16):
+    rows = per_wg[level * bins:(level + 1) * bins].reshape(-1, 64)
+    rows = rows[rows[:, 10] > 0]
+    if rows.shape[0] == 0:
+        continue
+    stat = (rows[:, 12] - rows[:, 11]).double()
+    life = (rows[:, 16] - rows[:, 10]).double()
+    print(f"   apply level {level:2d}: static segments mean {stat.mean().item():8.0f} max {stat.max().item():8.0f}   workgroup lifetime mean {life.mean().item():8.0f}")
+

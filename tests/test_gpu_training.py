@@ -236,3 +236,29 @@ def test_unbounded_workload_training_step_vs_oracle(F):
     np.testing.assert_allclose(gpu_losses[:4], ref_losses[:4], rtol=1e-3)
     np.testing.assert_allclose(gpu_losses, ref_losses, rtol=5e-2)
     assert ref_losses[-1] < ref_losses[0]
+
+
+def test_data_parallel_path_over_one_rank_rccl_matches_single_gpu():
+    """The N > 1 code path of bench.py — pipelined exchange (dp_schedule.py), async all-reduce of the arena slices on the
+    communication stream, compact table-prefix gather / scatter kernels — run over a ONE-rank RCCL communicator on this GPU
+    (`--force-dp`): the collectives are identities, so the training must end at exactly the loss of the plain single-GPU
+    schedule. What a one-GPU box can verify of SURVEY.md §8e before the driver's multi-GPU run."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def run(*flags):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "14", "--warmup", "4", "--no-cpu-baseline",
+                            "--profile-steps", "1", *flags], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+    plain = run("--no-graph")
+    dp = run("--force-dp")
+    assert "force_dp" in dp["config"] and dp["n_gpus"] == 1
+    assert dp["config"]["final_loss"] == plain["config"]["final_loss"], (dp["config"]["final_loss"], plain["config"]["final_loss"])
+
