@@ -488,6 +488,9 @@ int nsamd_device_info(int32_t* num_cus, int32_t* wavefront_size, int32_t* lds_by
 /* MFMA lane-layout probe used by the tests: out[16,16] = A[16,4] * B[4,16] through one v_mfma_f32_16x16x4_f32
  * with the operand/result lane mapping the field kernels assume. */
 int nsamd_probe_mfma16(const float* A, const float* B, float* out, nsamd_stream_t stream);
+/* The same for v_mfma_f32_16x16x32_bf16 (A [16,32], B [32,16] fp32 holding bf16-representable values): the lane mapping of
+ * the three-way-split forward (NSAMD_FIELD_FWD_BF16X3). */
+int nsamd_probe_mfma_bf16(const float* A, const float* B, float* out, nsamd_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -113,6 +113,7 @@ _SIGNATURES = {
     "nsamd_status_string": [C.c_int],
     "nsamd_device_info": [C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32],
     "nsamd_probe_mfma16": [vp, vp, vp, vp],
+    "nsamd_probe_mfma_bf16": [vp, vp, vp, vp],
 }
 _RESTYPES = {"nsamd_version": C.c_char_p, "nsamd_status_string": C.c_char_p,
              "nsamd_hashgrid_encode_bwd_workspace": C.c_int64, "nsamd_hashgrid_encode_bwd_workspace_state": C.c_int64, "nsamd_field_mlp_saved_floats": C.c_int64}

@@ -354,6 +354,194 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 1 : 2) void field_mlp_fwd
   PROBE_STAMP(WAVES, 63);
 }
 
+// ---- forward on the bf16 matrix cores at fp32 accuracy (three-way operand split) -------------------------------------
+// v_mfma_f32_16x16x32_bf16 retires 8192 MACs in 4 passes, v_mfma_f32_16x16x4_f32 1024 in 8: 16x the rate. Every fp32 operand
+// is split into three bf16 pieces x = h + m + l (each the RNE bf16 of what the previous ones left; the residuals are exact
+// in fp32, so the three pieces carry 24 bits), and a product w x is formed from the six piece products down to 2^-16 of it:
+// wh xh + wh xm + wm xh + wm xm + wh xl + wl xh, accumulated in fp32 like the f32 MFMA's own chain (the three dropped terms
+// are <= 2^-23 |w x|, the size of an fp32 rounding). 6 bf16 MFMAs replace 8 f32 ones per 32 inputs: 2.7x less matrix-core
+// time, paid for with ~5.5 VALU operations per activation for the split.
+// Chain layout, K = 32: the B operand of input block kb (tiles 2kb, 2kb + 1 of the f32 chain layout) is, for lane (j, g),
+// slots s = 0..7 = features 16 (2kb) + 4g + s (s < 4), 16 (2kb + 1) + 4g + s - 4 — the lane's own accumulator registers,
+// packed in pairs; the weight fragments are staged with the same slot order, so no data moves between lanes.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));  // 8 packed bf16
+
+__device__ __forceinline__ v4f mfma_bf16(const u4& a, const u4& b, v4f c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (RNE)
+  bf16x2 p;
+  p[0] = (__bf16)a;
+  p[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, p);
+}
+
+// (x0, x1) -> packed pieces: x = h + m + l up to 2^-25 |x|
+struct Pieces {
+  unsigned h, m, l;
+};
+
+__device__ __forceinline__ Pieces split3(float x0, float x1) {
+  Pieces p;
+  p.h = pack_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(p.h << 16), r1 = x1 - __uint_as_float(p.h & 0xffff0000u);  // exact
+  p.m = pack_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(p.m << 16), s1 = r1 - __uint_as_float(p.m & 0xffff0000u);  // exact
+  p.l = pack_bf16(s0, s1);
+  return p;
+}
+
+struct Op3 {
+  u4 h, m, l;
+};
+
+__device__ __forceinline__ Op3 pack_block(const v4f& t0, const v4f& t1) {
+  const Pieces a = split3(t0[0], t0[1]), b = split3(t0[2], t0[3]), c = split3(t1[0], t1[1]), d = split3(t1[2], t1[3]);
+  Op3 o;
+  o.h = u4{a.h, b.h, c.h, d.h};
+  o.m = u4{a.m, b.m, c.m, d.m};
+  o.l = u4{a.l, b.l, c.l, d.l};
+  return o;
+}
+
+// fragment sizes in u4 (16 B): [3 pieces][NT][KB][64 lanes]
+constexpr int kB3Base0 = 3 * 4 * 1 * 64, kB3Base1 = 3 * 1 * 2 * 64, kB3Head0 = 3 * 4 * 2 * 64, kB3Head1 = 3 * 4 * 2 * 64,
+              kB3Head2 = 3 * 1 * 2 * 64;
+constexpr int kB3OffBase0 = 0, kB3OffBase1 = kB3OffBase0 + kB3Base0, kB3OffHead0 = kB3OffBase1 + kB3Base1,
+              kB3OffHead1 = kB3OffHead0 + kB3Head0, kB3OffHead2 = kB3OffHead1 + kB3Head1,
+              kB3Total = kB3OffHead2 + kB3Head2;  // 4608 u4 = 72 KiB
+
+// out[n] += W[16n + .][block kb] . in[kb], smallest piece products first
+template <int NT, int KB>
+__device__ __forceinline__ void chain_gemm_bf16(const u4* frag, const Op3* in, v4f* out, int lane) {
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    u4 wh[NT], wm[NT], wl[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      wh[n] = frag[((0 * NT + n) * KB + kb) * 64 + lane];
+      wm[n] = frag[((1 * NT + n) * KB + kb) * 64 + lane];
+      wl[n] = frag[((2 * NT + n) * KB + kb) * 64 + lane];
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) out[n] = mfma_bf16(wl[n], in[kb].h, out[n]);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) out[n] = mfma_bf16(wh[n], in[kb].l, out[n]);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) out[n] = mfma_bf16(wm[n], in[kb].m, out[n]);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) out[n] = mfma_bf16(wm[n], in[kb].h, out[n]);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) out[n] = mfma_bf16(wh[n], in[kb].m, out[n]);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) out[n] = mfma_bf16(wh[n], in[kb].h, out[n]);
+  }
+}
+
+// one (n, kb) block of a layer: lane (i, g) slot s <-> W[16n + i][feature(kb, g, s)], split into the three piece arrays
+template <int NT, int KB>
+__device__ void stage_b3(u4* dst, const float* __restrict__ W, int n_real, int k_real, bool head0, int app_dim, int threads) {
+  for (int item = threadIdx.x; item < NT * KB * 64; item += threads) {
+    const int lane = item & 63, blk = item >> 6;
+    const int kb = blk % KB, n = blk / KB;
+    const int i = lane & 15, g = lane >> 4;
+    const int row = 16 * n + i;
+    float w[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) {
+      const int slot = 16 * (2 * kb + (s2 >> 2)) + 4 * g + (s2 & 3);
+      const int col = head0 ? head0_col(slot, app_dim) : slot;
+      w[s2] = (row < n_real && col >= 0 && col < k_real) ? W[row * k_real + col] : 0.0f;
+    }
+    const Pieces a = split3(w[0], w[1]), b = split3(w[2], w[3]), c = split3(w[4], w[5]), d = split3(w[6], w[7]);
+    dst[((0 * NT + n) * KB + kb) * 64 + lane] = u4{a.h, b.h, c.h, d.h};
+    dst[((1 * NT + n) * KB + kb) * 64 + lane] = u4{a.m, b.m, c.m, d.m};
+    dst[((2 * NT + n) * KB + kb) * 64 + lane] = u4{a.l, b.l, c.l, d.l};
+  }
+}
+
+constexpr int kB3Waves = 12;  // 3 waves per SIMD: 168 VGPRs each (16 waves would cap at 128 and spill)
+
+__global__ __launch_bounds__(64 * kB3Waves, 1) void field_mlp_fwd_bf16x3_kernel(
+    const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
+    const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
+    nsamd_field_mlp mlp, int app_dim, float* __restrict__ density, float* __restrict__ rgb) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  u4* wf = reinterpret_cast<u4*>(lds);
+  float* bias = lds + 4 * kB3Total;
+  constexpr int T = 64 * kB3Waves;
+  stage_b3<4, 1>(wf + kB3OffBase0, mlp.base_W0, 64, 32, false, 0, T);
+  stage_b3<1, 2>(wf + kB3OffBase1, mlp.base_W1, 16, 64, false, 0, T);
+  stage_b3<4, 2>(wf + kB3OffHead0, mlp.head_W0, 64, 31 + app_dim, true, app_dim, T);
+  stage_b3<4, 2>(wf + kB3OffHead1, mlp.head_W1, 64, 64, false, 0, T);
+  stage_b3<1, 2>(wf + kB3OffHead2, mlp.head_W2, 3, 64, false, 0, T);
+  stage_bias<T>(bias + kBiasBase0, mlp.base_b0, 64, 64);
+  stage_bias<T>(bias + kBiasBase1, mlp.base_b1, 16, 16);
+  stage_bias<T>(bias + kBiasHead0, mlp.head_b0, 64, 64);
+  stage_bias<T>(bias + kBiasHead1, mlp.head_b1, 64, 64);
+  stage_bias<T>(bias + kBiasHead2, mlp.head_b2, 3, 16);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int64_t tiles = (M + 15) / 16;
+  const float* app_table = cams ? mlp.appearance : nullptr;
+  for (int64_t tile = (int64_t)blockIdx.x * kB3Waves + wave; tile < tiles; tile += (int64_t)gridDim.x * kB3Waves) {
+    asm volatile("" ::: "memory");  // keep the fragments in LDS
+    const TileInputs ti = tile_inputs(tile, lane, M, selector, cams, dir_group);
+    v4f e[2];
+    load_enc_tile(enc, M, ti.p, lane, e);
+    const HeadPre pre = load_head_pre(directions, app_table, app_const, app_dim, ti, g);
+    Op3 x[2];
+    v4f h1[4], o16[1], ha[4], hb[4], rgbp[1];
+    x[0] = pack_block(e[0], e[1]);
+    load_bias<4>(bias + kBiasBase0, h1, g);
+    chain_gemm_bf16<4, 1>(wf + kB3OffBase0, x, h1, lane);
+    relu_tiles<4>(h1);
+    x[0] = pack_block(h1[0], h1[1]);
+    x[1] = pack_block(h1[2], h1[3]);
+    load_bias<1>(bias + kBiasBase1, o16, g);
+    chain_gemm_bf16<1, 2>(wf + kB3OffBase1, x, o16, lane);
+    x[0] = pack_block(sh_quad(pre.d[0], pre.d[1], pre.d[2], g), o16[0]);
+    x[1] = pack_block(pre.app[0], pre.app[1]);
+    load_bias<4>(bias + kBiasHead0, ha, g);
+    chain_gemm_bf16<4, 2>(wf + kB3OffHead0, x, ha, lane);
+    relu_tiles<4>(ha);
+    x[0] = pack_block(ha[0], ha[1]);
+    x[1] = pack_block(ha[2], ha[3]);
+    load_bias<4>(bias + kBiasHead1, hb, g);
+    chain_gemm_bf16<4, 2>(wf + kB3OffHead1, x, hb, lane);
+    relu_tiles<4>(hb);
+    x[0] = pack_block(hb[0], hb[1]);
+    x[1] = pack_block(hb[2], hb[3]);
+    load_bias<1>(bias + kBiasHead2, rgbp, g);
+    chain_gemm_bf16<1, 2>(wf + kB3OffHead2, x, rgbp, lane);
+    if (lane < 16 && ti.live) {
+      density[ti.p] = mlp.average_init_density * expf(o16[0][0]) * ti.sel;
+      float* o = rgb + 3 * ti.p;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] = 1.0f / (1.0f + expf(-rgbp[0][c]));
+    }
+  }
+}
+
+// one bf16 MFMA with the assumed lane mapping (layout probe for the tests): A[16][32], B[32][16] row-major fp32 holding
+// bf16-representable values
+__global__ void probe_mfma_bf16_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ out) {
+  const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+  u4 a, b;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    a[q] = pack_bf16(A[j * 32 + 8 * g + 2 * q], A[j * 32 + 8 * g + 2 * q + 1]);
+    b[q] = pack_bf16(B[(8 * g + 2 * q) * 16 + j], B[(8 * g + 2 * q + 1) * 16 + j]);
+  }
+  v4f c = {0.f, 0.f, 0.f, 0.f};
+  c = mfma_bf16(a, b, c);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[(4 * g + r) * 16 + j] = c[r];
+}
+
 // ---- fused forward: hash grid (16 levels) -> base MLP -> head MLP ----------------------------------------------------
 // One launch instead of nsamd_hashgrid_encode_fwd + nsamd_field_mlp_fwd. The two halves are bound by different units — the
 // gathers by the texture-address / L1 path (~0.55 lane-gathers per clock per CU, r02 probes), the MLPs by the matrix cores —
@@ -1095,7 +1283,23 @@ static int field_mlp_fwd_impl(const float* enc, const float* selector, const flo
   // One 16-wave workgroup per CU by default (4 waves per SIMD, the weights staged once per CU): 57 us on the bench shape
   // against 59.5 (8 waves x 2 workgroups) and 65 (4 waves x 3) on the same box — NSAMD_FIELD_FWD_WAVES=8|4 selects those.
   static const int waves = getenv("NSAMD_FIELD_FWD_WAVES") ? atoi(getenv("NSAMD_FIELD_FWD_WAVES")) : 16;
-  if (waves == 16) {
+  static const int bf16x3 = getenv("NSAMD_FIELD_FWD_BF16X3") ? atoi(getenv("NSAMD_FIELD_FWD_BF16X3")) : 0;
+  if (bf16x3 && acts == nullptr) {
+    // bf16 matrix cores, three-way split operands (fp32 accuracy)
+    const size_t lds3 = sizeof(float) * (4 * (size_t)kB3Total + 256);
+    static bool attr3[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return NSAMD_ERR_NO_DEVICE;
+    if (dev < 0 || dev >= 64 || !attr3[dev]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_fwd_bf16x3_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess)
+        return NSAMD_ERR_LAUNCH;
+      if (dev >= 0 && dev < 64) attr3[dev] = true;
+    }
+    const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + kB3Waves - 1) / kB3Waves);
+    field_mlp_fwd_bf16x3_kernel<<<blocks, 64 * kB3Waves, lds3, (hipStream_t)stream>>>(
+        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb);
+  } else if (waves == 16) {
     const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + 15) / 16);
     field_mlp_fwd_kernel<16><<<blocks, 1024, lds, (hipStream_t)stream>>>(
         enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb, acts);
@@ -1221,6 +1425,13 @@ extern "C" int nsamd_field_mlp_bwd_saved(const float* enc, const float* selector
   NSAMD_REQUIRE(M == 0 || saved != nullptr);
   return field_mlp_bwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, ddensity,
                             drgb, denc, grads, workspace, workspace_floats, saved, stream);
+}
+
+extern "C" int nsamd_probe_mfma_bf16(const float* A, const float* B, float* out, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(A && B && out);
+  probe_mfma_bf16_kernel<<<1, 64, 0, (hipStream_t)stream>>>(A, B, out);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
 }
 
 extern "C" int nsamd_probe_mfma16(const float* A, const float* B, float* out, nsamd_stream_t stream) {

@@ -98,6 +98,21 @@ def test_mfma_lane_layout(F):
     close(out, ref, atol=1e-6)
 
 
+def test_mfma_bf16_lane_layout(F):
+    """A[16,32] @ B[32,16] through one v_mfma_f32_16x16x32_bf16 with the lane mapping of the three-way-split forward: lane
+    (j, g) holds k = 8g .. 8g + 7 of row / column j, the result rows 4g .. 4g + 3 of column j (bf16-representable inputs:
+    small integers, so the product is exact)."""
+    from nerfstudio_amd import _native as N
+
+    rs = np.random.RandomState(1)
+    A = rs.randint(-8, 9, size=(16, 32)).astype(np.float32)
+    B = rs.randint(-8, 9, size=(32, 16)).astype(np.float32)
+    out = torch.empty((16, 16), device="cuda")
+    a, b = dev(A), dev(B)
+    N.check(N.load().nsamd_probe_mfma_bf16(N.ptr(a), N.ptr(b), N.ptr(out), N.stream()), "probe")
+    exact(out, A @ B, "bf16 MFMA lane layout")
+
+
 # ---------------------------------------------------------------- hash grid -----------------------------------------
 def test_hashgrid_golden(F, golden):
     from nerfstudio_amd.field_components.encodings import HashEncoding
@@ -884,6 +899,66 @@ def test_fused_main_field_forward_is_bit_identical(F, contract, ray_mode, with_c
     g8 = N.make_grid(8, log2, scal[:8])
     assert lib.nsamd_field_fused_fwd.fn(pts, M, xf, box, N.ptr(table), g8, N.ptr(dirs), N.ptr(cams), None, group, fm, None, None,
                                         N.ptr(dens_c), N.ptr(rgb_c), st) == N.ERR_UNSUPPORTED
+
+
+def test_field_forward_bf16x3_split_matches_f32(F):
+    """The main-field forward on the bf16 matrix cores with three-way split operands (NSAMD_FIELD_FWD_BF16X3=1, opt-in)
+    against the f32-MFMA forward and a float64 evaluation of the same network: the split keeps 24 bits per operand and drops
+    only products below 2^-23 of the leading one, so its error against float64 must be of the size of the f32 kernel's own.
+    Run in subprocesses: the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from nerfstudio_amd import _native as N
+lib, st = N.load(), N.stream()
+torch.manual_seed(11)
+n, S = 301, 48
+M = n * S
+enc = (torch.randn(32, M) * 0.3).cuda()
+sel = (torch.rand(M) > 0.1).float().cuda()
+dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1).cuda()
+cams = torch.randint(0, 7, (n,)).cuda()
+shapes = [(64, 32), (64,), (16, 64), (16,), (64, 63), (64,), (64, 64), (64,), (3, 64), (3,)]
+params = [(torch.randn(*s) * (0.25 if len(s) == 2 else 0.1)).cuda() for s in shapes]
+emb = (torch.randn(7, 32) * 0.3).cuda()
+fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), 7, 0.9)
+dens, rgb = torch.empty(M, device="cuda"), torch.empty(M, 3, device="cuda")
+N.check(lib.nsamd_field_mlp_fwd(N.ptr(enc), N.ptr(sel), N.ptr(dirs), N.ptr(cams), None, S, M, fm, N.ptr(dens), N.ptr(rgb), st), "fwd")
+torch.cuda.synchronize()
+np.savez(sys.argv[1], out=np.concatenate([dens.cpu().numpy()[:, None], rgb.cpu().numpy()], axis=1), enc=enc.cpu().numpy(),
+         sel=sel.cpu().numpy(), dirs=dirs.cpu().numpy(), cams=cams.cpu().numpy(), emb=emb.cpu().numpy(),
+         **{f"p{i}": p.cpu().numpy() for i, p in enumerate(params)})
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for flag in ("0", "1"):
+            path = os.path.join(tmp, f"o{flag}.npz")
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, NSAMD_FIELD_FWD_BF16X3=flag),
+                               capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(dict(np.load(path)))
+    f32, b3 = outs[0]["out"], outs[1]["out"]
+    assert np.isfinite(b3).all() and not np.array_equal(f32, b3), "the switch selected the same kernel twice"
+    # float64 evaluation of nerfacto_field.py:203-310 on the same inputs
+    d = {k: torch.from_numpy(v).double() for k, v in outs[0].items() if k != "out"}
+    x = d["enc"].t()
+    h = torch.relu(x @ d["p0"].t() + d["p1"]) @ d["p2"].t() + d["p3"]
+    dens64 = 0.9 * torch.exp(h[:, 0]) * d["sel"]
+    sh = orc.sh_levels4(((d["dirs"] + 1.0) / 2.0).float()).double().repeat_interleave(48, dim=0)
+    app = d["emb"][outs[0]["cams"]].repeat_interleave(48, dim=0)
+    hin = torch.cat([sh, h[:, 1:], app], dim=-1)
+    r64 = torch.sigmoid(torch.relu(torch.relu(hin @ d["p4"].t() + d["p5"]) @ d["p6"].t() + d["p7"]) @ d["p8"].t() + d["p9"])
+    ref = torch.cat([dens64[:, None], r64], dim=-1).numpy()
+    scale = np.maximum(np.abs(ref), 1e-3)
+    e32, e3 = np.abs(f32 - ref) / scale, np.abs(b3 - ref) / scale
+    assert e32.max() < 1e-4 and e3.max() < 1e-4, (e32.max(), e3.max())
+    assert e3.max() <= 3.0 * e32.max() + 1e-6 and e3.mean() <= 2.0 * e32.mean() + 1e-7, (e32.max(), e3.max(), e32.mean(), e3.mean())
+    np.testing.assert_allclose(b3[:, 1:], f32[:, 1:], rtol=0, atol=2e-6, err_msg="rgb")  # (north_star budget: 1e-4)
 
 
 def test_train_step_runner_random_background(F, monkeypatch):
