@@ -472,11 +472,13 @@ int nsamd_select_batch(const float* slot_dev, int32_t slots, int64_t num_rays, c
  * Fused Adam over a flat fp32 arena (engine/optimizers.py:74-193 with AdamOptimizerConfig(lr, eps=1e-15),
  * torch.optim.Adam semantics: bias-corrected, no weight decay, no amsgrad). grad_scale multiplies the gradient
  * first (1/world_size for the data-parallel mean, or the inverse loss scale). step is 1-based.
- * hyper_dev (nullable): device floats {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)} overriding the values derived
+ * The arithmetic follows torch/optim/adam.py (_single_tensor_adam) operation by operation on fp32, scalars evaluated in double
+ * and rounded once (hence the double arguments): the updated parameters and moments are the same bits as torch.optim.Adam's.
+ * hyper_dev (nullable): device floats {lr / (1 - beta1^step), sqrt(1 - beta2^step)} overriding the values derived
  * from (lr, step) — lets a captured hipGraph be replayed across steps.
  * ------------------------------------------------------------------------------------------------------------ */
-int nsamd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                    float beta1, float beta2, float eps, int32_t step, float grad_scale, const float* hyper_dev,
+int nsamd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                    double beta1, double beta2, double eps, int32_t step, float grad_scale, const float* hyper_dev,
                     nsamd_stream_t stream);
 
 /* Library / device introspection. */

@@ -108,7 +108,7 @@ _SIGNATURES = {
     "nsamd_rows_gather": [vp, vp, i64, i32, vp, vp],
     "nsamd_rows_scatter": [vp, vp, i64, i32, vp, vp],
     "nsamd_select_batch": [vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "nsamd_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, vp],
+    "nsamd_adam_step": [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i32, f32, vp, vp],
     "nsamd_version": [],
     "nsamd_status_string": [C.c_int],
     "nsamd_device_info": [C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32],

@@ -1,6 +1,6 @@
 // Shared helpers for the nsamd HIP kernels (gfx950 only).
-// Per-point / per-ray arithmetic lives in NSAMD_HD inline functions so that tests/hostsim can run the very same
-// code on the host (unit tests of kernel logic without a GPU). The product never runs them on the CPU.
+// Per-point / per-ray arithmetic lives in NSAMD_HD (host + device) inline functions shared by all kernels; the host
+// compiler only sees them when it checks the header (tests/test_abi.py). The product never runs them on the CPU.
 #pragma once
 
 #include <stdint.h>

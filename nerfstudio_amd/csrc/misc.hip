@@ -96,13 +96,20 @@ __global__ void rows_scatter_kernel(float* __restrict__ rows, const int64_t* __r
   rows[index[r] * feat + (i - r * feat)] = packed[i];
 }
 
-// torch.optim.Adam (no amsgrad / weight decay / maximize): one pass over the flat arena, 16 B per lane.
-// bias corrections are folded by the host into step_size = lr / (1 - b1^t) and inv_sqrt_bc2 = 1 / sqrt(1 - b2^t).
+// torch.optim.Adam (no amsgrad / weight decay / maximize): one pass over the flat arena, 16 B per lane — with the operation
+// order of torch/optim/adam.py _single_tensor_adam on fp32 tensors, so that the update is the SAME BITS as torch's:
+//   exp_avg.lerp_(grad, 1 - beta1)                          fma(w1, g - m, m),   w1 = float(1 - beta1) (double subtraction)
+//   exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)  fma(w2 g, g, v beta2)
+//   denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+//   param.addcdiv_(exp_avg, denom, value=-step_size)        p + ((-step_size) m) / denom
+// step_size = lr / (1 - b1^t) and bc2_sqrt = sqrt(1 - b2^t) are evaluated in double by the host and rounded once, as the
+// Python scalars are when ATen takes them; correctly rounded sqrt and division (hipcc default), no FMA contraction.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, int64_t n, float beta1, float beta2, float eps, float step_size_host,
-                            float inv_sqrt_bc2_host, const float* __restrict__ hyper_dev, float grad_scale) {
-  const float step_size = hyper_dev ? hyper_dev[0] : step_size_host;
-  const float inv_sqrt_bc2 = hyper_dev ? hyper_dev[1] : inv_sqrt_bc2_host;
+                            float* __restrict__ v, int64_t n, float beta2, float w1, float w2, float eps,
+                            float step_size_host, float bc2_sqrt_host, const float* __restrict__ hyper_dev,
+                            float grad_scale) {
+  const float neg_step = -(hyper_dev ? hyper_dev[0] : step_size_host);
+  const float bc2_sqrt = hyper_dev ? hyper_dev[1] : bc2_sqrt_host;
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -123,11 +130,11 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     float* va = reinterpret_cast<float*>(&vv);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float gr = ga[k] * grad_scale;
-      ma[k] = ma[k] + (gr - ma[k]) * (1.0f - beta1);        // exp_avg.lerp_(grad, 1 - beta1)
-      va[k] = va[k] * beta2 + (1.0f - beta2) * gr * gr;     // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-      const float denom = sqrtf(va[k]) * inv_sqrt_bc2 + eps;
-      pa[k] = pa[k] - step_size * (ma[k] / denom);
+      const float gr = grad_scale == 1.0f ? ga[k] : ga[k] * grad_scale;
+      ma[k] = fmaf(w1, gr - ma[k], ma[k]);  // ATen's lerp kernel is a fused multiply-add (cpu/LerpKernel.cpp lerp_vec)
+      va[k] = fmaf(w2 * gr, gr, va[k] * beta2);  // addcmul's (alpha t1) t2 + self is contracted in ATen's vector kernel
+      const float denom = sqrtf(va[k]) / bc2_sqrt + eps;
+      pa[k] = pa[k] + (neg_step * ma[k]) / denom;
     }
     reinterpret_cast<float4*>(p)[i] = pp;
     reinterpret_cast<float4*>(m)[i] = mm;
@@ -137,12 +144,12 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   const int64_t tail0 = n4 << 2;
   const int64_t t = tail0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) {
-    const float gr = g[t] * grad_scale;
-    const float m1 = m[t] + (gr - m[t]) * (1.0f - beta1);
-    const float v1 = v[t] * beta2 + (1.0f - beta2) * gr * gr;
+    const float gr = grad_scale == 1.0f ? g[t] : g[t] * grad_scale;
+    const float m1 = fmaf(w1, gr - m[t], m[t]);
+    const float v1 = fmaf(w2 * gr, gr, v[t] * beta2);
     m[t] = m1;
     v[t] = v1;
-    p[t] = p[t] - step_size * (m1 / (sqrtf(v1) * inv_sqrt_bc2 + eps));
+    p[t] = p[t] + (neg_step * m1) / (sqrtf(v1) / bc2_sqrt + eps);
   }
 }
 
@@ -205,20 +212,21 @@ extern "C" int nsamd_select_batch(const float* slot_dev, int32_t slots, int64_t 
 }
 
 extern "C" int nsamd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
-                               float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,
+                               double lr, double beta1, double beta2, double eps, int32_t step, float grad_scale,
                                const float* hyper_dev, nsamd_stream_t stream) {
   NSAMD_REQUIRE(n >= 0 && step >= 1);
   if (n == 0) return NSAMD_OK;
   NSAMD_REQUIRE(params && grads && exp_avg && exp_avg_sq);
   NSAMD_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0);
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
-  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
   const int64_t n4 = (n + 3) / 4;
   const unsigned blocks = (unsigned)min((int64_t)256 * 8, (n4 + 255) / 256);
-  adam_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, beta1, beta2, eps,
-                                                       step_size, inv_sqrt_bc2, hyper_dev, grad_scale);
+  adam_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, (float)beta2,
+                                                       (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, step_size,
+                                                       bc2_sqrt, hyper_dev, grad_scale);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

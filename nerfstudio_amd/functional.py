@@ -855,8 +855,9 @@ def raygen_pinhole(ray_indices: Tensor, c2w: Tensor, fx: Tensor, fy: Tensor, cx:
 
 @torch.no_grad()
 def adam_hyper(step: int, lr: float, betas=(0.9, 0.999)) -> Tuple[float, float]:
-    """(lr / (1 - b1^step), 1 / sqrt(1 - b2^step)) — the two step-dependent scalars of Adam."""
-    return lr / (1.0 - betas[0] ** step), 1.0 / math.sqrt(1.0 - betas[1] ** step)
+    """(lr / (1 - b1^step), sqrt(1 - b2^step)) — the two step-dependent scalars of Adam, in double as torch/optim/adam.py
+    evaluates them (step_size, bias_correction2_sqrt); they are rounded to fp32 once, when they reach the kernel."""
+    return lr / (1.0 - betas[0] ** step), (1.0 - betas[1] ** step) ** 0.5
 
 
 def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,
