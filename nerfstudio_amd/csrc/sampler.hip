@@ -11,6 +11,8 @@
 #include "common.h"
 #include "wave.h"
 
+NSAMD_PROBE_DEFINE(sampler)
+
 namespace nsamd {
 
 constexpr int kThreads = 256;  // 4 wavefronts
@@ -167,11 +169,35 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
   const int wave = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * kWaves + wave;
   if (ray >= num_rays) return;  // wave-uniform; no workgroup barrier below
-  const int row_floats = 2 * S_prev + 1 + (include_original ? S + 1 : 0);
+  const int row_floats = 3 * S_prev + 2 + (include_original ? S + 1 : 0);
   float* w = lds + (size_t)wave * row_floats;
   float* cdf = w + S_prev;
-  float* fresh = cdf + S_prev + 1;  // include_original only
+  float* bprev = cdf + S_prev + 1;    // the previous level's spacing-domain edges (gathered by the search below)
+  float* fresh = bprev + S_prev + 1;  // include_original only
+  PROBE_STAMP(0, 0);
+  // Everything this ray reads from global memory is requested HERE, in one burst: the kernel is one wavefront per ray and
+  // all rays are resident at once, so its duration is one wave's chain of latencies — loads issued where they are used
+  // (behind the LDS fences) put five or six exposed round trips into it.
   const float anneal = anneal_dev ? anneal_dev[0] : anneal_host;  // device copy: graph-replayable schedules
+  const int nb = S + 1;
+  const float near_ray = nears[ray], far_ray = fars[ray];
+  const float jit_ray = (jitter != nullptr && !jitter_per_edge) ? jitter[ray] : 0.0f;
+  float u_pre[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) u_pre[c] = (lane + 64 * c) < nb ? u_base[lane + 64 * c] : 0.0f;
+  const float* bp = s_bins_prev + ray * (S_prev + 1);
+  for (int i = lane; i <= S_prev; i += 64) bprev[i] = bp[i];
+  float dd_pre[4] = {0.f, 0.f, 0.f, 0.f};
+  if (kFused) {
+    const float* tb0 = t_bins_prev + ray * (S_prev + 1);
+    const float* dn0 = density + ray * S_prev;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = 64 * c + lane;
+      if (i < S_prev) dd_pre[c] = (tb0[i + 1] - tb0[i]) * dn0[i];
+    }
+  }
+  PROBE_STAMP(0, 1);
 
   if (kFused) {
     // (0) weights of the previous level  (cameras/rays.py:129-152), kept in the LDS row
@@ -180,7 +206,8 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     double carry0 = 0.0;
     for (int i0 = 0; i0 < S_prev; i0 += 64) {
       const int i = i0 + lane;
-      const float dd = i < S_prev ? (tb[i + 1] - tb[i]) * dn[i] : 0.0f;
+      const float dd = i0 == 0 ? dd_pre[0] : i0 == 64 ? dd_pre[1] : i0 == 128 ? dd_pre[2] : i0 == 192 ? dd_pre[3]
+                       : (i < S_prev ? (tb[i + 1] - tb[i]) * dn[i] : 0.0f);  // (selects, not an indexed array: no scratch)
       const double incl = carry0 + wave_scan_inclusive((double)dd, lane);
       double excl = wave_shift_up1_f64(incl);
       if (lane == 0) excl = carry0;
@@ -193,6 +220,7 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
         w[i] = wv;
       }
     }
+    PROBE_STAMP(0, 2);
     if (depth_median != nullptr) {  // searchsorted(cumsum(w), 0.5, side="left"), clamped
       double carry1 = 0.0;
       int idx = S_prev;
@@ -207,6 +235,7 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
       if (lane == 0) depth_median[ray] = (tb[idx] + tb[idx + 1]) / 2.0f;
     }
   }
+  PROBE_STAMP(0, 3);
   // (1) weights (annealed) + histogram padding, and their sum                 ray_samplers.py:601, :303-309
   double total = 0.0;
   for (int i0 = 0; i0 < S_prev; i0 += 64) {
@@ -214,12 +243,16 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     float v = 0.0f;
     if (i < S_prev) {
       v = kFused ? w[i] : weights[ray * S_prev + i];
-      if (anneal != 1.0f) v = powf(v, anneal);
+      // pow(weights, anneal) (ray_samplers.py:601) as 2^(anneal log2 v) on the hardware transcendentals (v_log_f32 /
+      // v_exp_f32, ~1 ulp each: |relative error| <~ 1e-7 (1 + anneal |log2 v|)); libm's powf is ~150 VALU instructions per
+      // element and was a quarter of this kernel (probe_sampler_clocks: 7.5 k of 26.7 k clocks). v = 0 stays 0.
+      if (anneal != 1.0f) v = __builtin_amdgcn_exp2f(anneal * __builtin_amdgcn_logf(v));
       v = v + hist_pad;
       w[i] = v;
     }
     total = total + wave_read_f64<63>(wave_scan_inclusive((double)v, lane));
   }
+  PROBE_STAMP(0, 4);
   const float run = (float)total;  // double-accumulated sum, rounded once (= cumsum(w)[-1] of the oracle)
   const float pad = fmaxf(eps - run, 0.0f);
   const float wpad = pad / (float)S_prev;
@@ -236,16 +269,15 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  PROBE_STAMP(0, 5);
   // (3) inverse-CDF sampling of the S+1 new bin edges                         ray_samplers.py:315-358
-  const int nb = S + 1;
-  const float s_near = spacing_fn_mode(spacing, nears[ray]);
-  const float s_far = spacing_fn_mode(spacing, fars[ray]);
-  const float* bp = s_bins_prev + ray * (S_prev + 1);
+  const float s_near = spacing_fn_mode(spacing, near_ray);
+  const float s_far = spacing_fn_mode(spacing, far_ray);
   const int out_edges = include_original ? nb + S_prev + 1 : nb;
   for (int j = lane; j < nb; j += 64) {
-    float u = u_base[j];
+    float u = j < 64 ? u_pre[0] : j < 128 ? u_pre[1] : u_base[j];
     // rand / num_bins: one draw per ray (single_jitter) or per new edge   (ray_samplers.py:318-322)
-    if (jitter != nullptr) u = u + jitter[jitter_per_edge ? ray * nb + j : ray] / (float)nb;
+    if (jitter != nullptr) u = u + (jitter_per_edge ? jitter[ray * nb + j] : jit_ray) / (float)nb;
     else u = u + u_offset;                                    // 1 / (2 num_bins)  (ray_samplers.py:327), host-rounded
     // searchsorted(side="right"): number of cdf entries <= u
     int lo = 0, hi = S_prev + 1;
@@ -257,7 +289,7 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     const int below = min(max(lo - 1, 0), S_prev);
     const int above = min(max(lo, 0), S_prev);
     const float c0 = cdf[below], c1 = cdf[above];
-    const float b0 = bp[below], b1 = bp[above];
+    const float b0 = bprev[below], b1 = bprev[above];
     float t = nan_to_num((u - c0) / (c1 - c0), 0.0f);
     t = fminf(fmaxf(t, 0.0f), 1.0f);
     const float b = b0 + t * (b1 - b0);
@@ -269,6 +301,7 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     }
     if (inds != nullptr) inds[ray * nb + j] = lo;
   }
+  PROBE_STAMP(0, 6);
   if (include_original) {
     // sort(cat(existing, new)) (ray_samplers.py:356-357): both lists are ascending, so an element's place is its own index
     // plus the number of elements of the other list in front of it (existing edges first on ties — equal values either way)
@@ -277,7 +310,7 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     float* so = s_bins + ray * out_edges;
     float* to = t_bins + ray * out_edges;
     for (int i = lane; i <= S_prev; i += 64) {  // existing edge i: new edges strictly below it
-      const float v = bp[i];
+      const float v = bprev[i];
       int lo = 0, hi = nb;
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -292,7 +325,7 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
       int lo = 0, hi = S_prev + 1;
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (bp[mid] <= v) lo = mid + 1;
+        if (bprev[mid] <= v) lo = mid + 1;
         else hi = mid;
       }
       so[j + lo] = v;
@@ -355,7 +388,7 @@ extern "C" int nsamd_pdf_resample(const float* s_bins_prev, const float* weights
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(s_bins_prev && weights && u_base && nears && fars && s_bins && t_bins);
   if (S_prev > 1024 || S > 4096) return NSAMD_ERR_UNSUPPORTED;
-  const size_t lds = sizeof(float) * kWaves * (2 * (size_t)S_prev + 1 + (include_original ? (size_t)S + 1 : 0));
+  const size_t lds = sizeof(float) * kWaves * (3 * (size_t)S_prev + 2 + (include_original ? (size_t)S + 1 : 0));
   pdf_resample_kernel<false><<<ray_blocks(num_rays), kThreads, lds, (hipStream_t)stream>>>(
       s_bins_prev, weights, S_prev, u_base, jitter, nears, fars, anneal, anneal_dev, histogram_padding, eps, u_offset,
       spacing, num_rays, S, s_bins, t_bins, inds, nullptr, nullptr, nullptr, nullptr, jitter_per_edge != 0,
@@ -374,7 +407,7 @@ extern "C" int nsamd_proposal_resample(const float* t_bins_prev, const float* s_
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(t_bins_prev && s_bins_prev && density && u_base && nears && fars && weights && s_bins && t_bins);
   if (S_prev > 1024) return NSAMD_ERR_UNSUPPORTED;
-  const size_t lds = sizeof(float) * kWaves * (2 * (size_t)S_prev + 1);
+  const size_t lds = sizeof(float) * kWaves * (3 * (size_t)S_prev + 2);
   pdf_resample_kernel<true><<<ray_blocks(num_rays), kThreads, lds, (hipStream_t)stream>>>(
       s_bins_prev, nullptr, S_prev, u_base, jitter, nears, fars, anneal, anneal_dev, histogram_padding, eps, u_offset,
       spacing, num_rays, S, s_bins, t_bins, nullptr, t_bins_prev, density, weights, depth_median, 0, 0);
