@@ -8,6 +8,8 @@
 // with IEEE div and no FMA contraction (this TU is built with -ffp-contract=off); (2) the launch is tiny, so
 // latency decides: one wavefront per ray, wave-level scans, no workgroup barriers.
 // Layout: 4 rays per 256-thread workgroup (N = 4096 -> 1024 workgroups); rows are read/written coalesced.
+#include <stdlib.h>
+
 #include "common.h"
 #include "wave.h"
 
@@ -243,10 +245,11 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     float v = 0.0f;
     if (i < S_prev) {
       v = kFused ? w[i] : weights[ray * S_prev + i];
-      // pow(weights, anneal) (ray_samplers.py:601) as 2^(anneal log2 v) on the hardware transcendentals (v_log_f32 /
-      // v_exp_f32, ~1 ulp each: |relative error| <~ 1e-7 (1 + anneal |log2 v|)); libm's powf is ~150 VALU instructions per
-      // element and was a quarter of this kernel (probe_sampler_clocks: 7.5 k of 26.7 k clocks). v = 0 stays 0.
-      if (anneal != 1.0f) v = __builtin_amdgcn_exp2f(anneal * __builtin_amdgcn_logf(v));
+      // pow(weights, anneal) (ray_samplers.py:601): libm's powf. It is a quarter of this kernel (probe_sampler_clocks: 7.5 k
+      // of 26.7 k clocks), and 2^(anneal log2 v) on v_log_f32 / v_exp_f32 brings the launch from 17.9 to 13.5 us — but the
+      // PSNR stand-in then ends 0.5 dB lower on one of its three scenes in every twin run (profiles/r02_negative_results.txt),
+      // so the accurate function stays.
+      if (anneal != 1.0f) v = powf(v, anneal);
       v = v + hist_pad;
       w[i] = v;
     }

@@ -399,6 +399,28 @@ def test_weights_backward_golden(F, golden):
     gclose(dens.grad, g["weights_ddensity"], 1e-5, "d weights / d density")
 
 
+@pytest.mark.parametrize("anneal", [0.0, 0.01, 0.5, 0.999])
+def test_annealed_resample_zero_and_denormal_weights(F, anneal):
+    """pow(weights, anneal) (ray_samplers.py:601) inside the resampling kernel runs on the hardware log2 / exp2: the cases
+    those instructions do not cover must still be torch.pow's — anneal = 0 (the first training step: pow(0, 0) = 1), exact
+    zeros, and DENORMAL weights (1e-38 .. 1e-45: transmittance underflow behind dense matter; under a small exponent
+    pow(1e-43, 0.01) = 0.37 shapes the early, nearly uniform proposal sampling)."""
+    n, s_prev, s_new = 64, 96, 48
+    rs = np.random.RandomState(3)
+    w = np.exp(rs.uniform(-110.0, 0.0, (n, s_prev))).astype(np.float32)   # down to 1e-48: zeros and denormals included
+    w[rs.uniform(size=w.shape) < 0.2] = 0.0
+    assert (w == 0).any() and ((w > 0) & (w < 1.17e-38)).any()
+    nears, fars = torch.full((n, 1), 0.05), torch.full((n, 1), 1000.0)
+    s0, _ = orc.piecewise_bins(nears, fars, s_prev, None)
+    jit = torch.from_numpy(rs.uniform(0, 1, (n, 1)).astype(np.float32))
+    wa = torch.pow(torch.from_numpy(w), anneal)                            # the reference's anneal, then its PDF sampler
+    so, to, _ = orc.pdf_resample(s0, wa, s_new, jit, nears, fars)
+    s1, t1 = F.pdf_resample(s0.cuda(), torch.from_numpy(w).cuda(), s_new, jit.cuda(), nears.cuda(), fars.cuda(), anneal=anneal)
+    assert bool(torch.isfinite(s1).all())
+    close(s1, so, atol=3e-6, rtol=0, msg=f"annealed resample, anneal = {anneal}")
+    close(t1, to, atol=0, rtol=2e-5)
+
+
 def test_sampler_ragged(F):
     """num_rays not a multiple of the 16-ray workgroup, S not a multiple of anything, 1 ray, 0 rays."""
     rs = np.random.RandomState(5)
