@@ -129,6 +129,9 @@ class Trainer:
         self.graphs = None
         self.use_graph = use_graph
         self.runner = None
+        self.defer = False
+        self.opt_parallel = True  # False: the deferred Adam runs on the main stream (per-kernel timing)
+        self._pending_main = False  # deferred schedule: the main-field Adam of the previous iteration is still to run
         if use_runner:  # explicit kernel schedule over static buffers (nerfstudio_amd/train_step.py); default
             from nerfstudio_amd.train_step import NerfactoTrainStep
 
@@ -137,6 +140,13 @@ class Trainer:
             self.runner.anneal_dev = self.hyper[4:5]
             if os.environ.get("NSAMD_SIDE_STREAM", "1") == "0":  # A/B switch: proposal backward on the main stream
                 self.runner.side_stream = None
+            # N = 1: the main-field Adam of iteration k (470 MB of HBM streaming) runs BESIDE the proposal forward of
+            # iteration k+1 (L2-resident gathers and per-ray scans that read only proposal-network parameters) — the
+            # single-GPU form of the pipelined schedule above; same dependencies, same bits. NSAMD_DEFER_MAIN_ADAM=0: A/B.
+            self.defer = not self.dp and os.environ.get("NSAMD_DEFER_MAIN_ADAM", "1") != "0"
+            if self.defer:
+                self.opt_stream = torch.cuda.Stream(device=dev)
+                self._opt_fork, self._opt_join = torch.cuda.Event(), torch.cuda.Event()
             if self.dp:
                 from nerfstudio_amd.dp_schedule import PipelinedExchange
 
@@ -204,6 +214,34 @@ class Trainer:
         loss = loss_dict["rgb_loss"] + loss_dict["interlevel_loss"] + loss_dict["distortion_loss"]
         loss.backward()
         self.loss_buf.copy_(loss.detach())
+
+    def _deferred_iteration_body(self, updated, pending):
+        """One iteration of the deferred schedule (N = 1, runner):
+            [Adam main k-1  ||  select batch, proposal forward k] -> main forward, losses, backward chains k
+            -> [Adam proposals k]                                                            (update steps)
+        Inside a captured hipGraph the two halves of the first line are parallel branches."""
+        r, a = self.runner, self.arena
+        main = torch.cuda.current_stream()
+        beside = pending and self.opt_parallel
+        if beside:
+            self._opt_fork.record(main)
+            self.opt_stream.wait_event(self._opt_fork)
+            with torch.cuda.stream(self.opt_stream):
+                a.step(grad_scale=1.0, groups=["fields"], hyper_dev=self.hyper_views)
+                self._opt_join.record(self.opt_stream)
+        elif pending:
+            a.step(grad_scale=1.0, groups=["fields"], hyper_dev=self.hyper_views)
+        self._select_batch()
+        r.apply_camera_corrections()
+        r.forward_proposals(need_enc=updated)
+        if beside:
+            main.wait_event(self._opt_join)
+        groups = ["fields", "proposal_networks"] if updated else ["fields"]
+        a.zero_grad(groups, skip=r.written_params())
+        r.forward_main_and_losses(updated)
+        r.backward_all(updated)
+        if updated:
+            a.step(grad_scale=1.0, groups=["proposal_networks"], hyper_dev=self.hyper_views)
 
     def _select_batch(self):
         """This step's rays out of the HBM-resident pool (slot index in device memory: replayable) — the hand-over the
@@ -278,10 +316,15 @@ class Trainer:
         """Drain the data-parallel pipeline (no-op for N = 1)."""
         if self.exchange is not None:
             self.exchange.finish()
+        if self._pending_main:  # deferred schedule: the last iteration's main-field update
+            self._push_hyper()
+            self.arena.step(grad_scale=1.0, groups=["fields"], hyper_dev=self.hyper_views)
+            self._pending_main = False
+            self._true_steps = dict(self.arena.step_counts)
 
     @property
     def _have_pending(self):
-        return self.exchange is not None and self.exchange.pending
+        return self._pending_main or (self.exchange is not None and self.exchange.pending)
 
     def _pipelined_iteration(self, updated):
         self._prologue(updated)
@@ -315,6 +358,13 @@ class Trainer:
                 with torch.cuda.graph(g):
                     self._seg(name)
                 graphs[name] = g
+        elif self.defer:
+            for upd in (True, False):
+                for pend in (True, False):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):  # the whole iteration is one graph
+                        self._deferred_iteration_body(upd, pend)
+                    graphs[("all", upd, pend)] = g
         else:
             for upd in (True, False):
                 g = torch.cuda.CUDAGraph()
@@ -331,6 +381,10 @@ class Trainer:
             self._pipelined_iteration(updated)
         elif self.dp:
             self._plain_dp_iteration(updated)
+        elif self.defer:
+            self._prologue(updated)
+            self._deferred_iteration_body(updated, self._pending_main)
+            self._pending_main = True
         else:
             self._prologue(updated)
             self._fwd_bwd(updated)
@@ -360,8 +414,14 @@ class Trainer:
             self._eager_iteration(updated)  # (pipelined: the segments replay their graphs)
         else:
             self._prologue(updated)
-            self.graphs[("all", updated)].replay()
-            for name in (("fields", "proposal_networks") if updated else ("fields",)):
+            if self.defer:
+                self.graphs[("all", updated, self._pending_main)].replay()
+                stepped = (("fields",) if self._pending_main else ()) + (("proposal_networks",) if updated else ())
+                self._pending_main = True
+            else:
+                self.graphs[("all", updated)].replay()
+                stepped = ("fields", "proposal_networks") if updated else ("fields",)
+            for name in stepped:
                 self.arena.step_counts[name] += 1  # the replayed Adam launches did step these groups
             self._true_steps = dict(self.arena.step_counts)
         self.opt_step += 1
@@ -446,6 +506,7 @@ def measure_roofline(trainer, arena, steps):
     side = getattr(runner, "side_stream", None)
     if runner is not None:
         runner.side_stream = None  # one stream: a kernel's events must not include a concurrent branch's work
+    trainer.opt_parallel = False
     N.PROFILE = {}
     for _ in range(steps):
         trainer.train_iteration()
@@ -454,6 +515,7 @@ def measure_roofline(trainer, arena, steps):
     prof = N.profile_summary(N.PROFILE)
     N.PROFILE = None
     trainer.graphs = graphs
+    trainer.opt_parallel = True
     if runner is not None:
         runner.side_stream = side
     table = []
@@ -734,7 +796,9 @@ def main():
                                       "pipelined under the proposal backward and the next proposal forward; proposal slice "
                                       "only on update steps)",
                        "params": arena.numel, "final_loss": round(float(loss), 6),
-                       "launch": ("hipGraph replay (2 captured variants)" if world == 1 else
+                       "launch": (("hipGraph replay (4 captured variants: proposal update x pending main-field Adam, which "
+                                   "runs beside the next proposal forward)" if trainer.defer else
+                                   "hipGraph replay (2 captured variants)") if world == 1 else
                                   "hipGraph replay (6 captured segments)") if graphed else "eager",
                        "driver": "autograd modules" if args.autograd else "explicit kernel schedule (train_step.py)"},
             "roofline": roof,

@@ -223,6 +223,18 @@ int nsamd_field_mlp_bwd(const float* enc, const float* selector, const float* di
                         nsamd_field_mlp_grads grads, float* workspace, int64_t workspace_floats,
                         nsamd_stream_t stream);
 
+/* nsamd_field_mlp_bwd in two launches, so that a caller can put the second on another stream: phase 1 = the gradient
+ * kernel (denc + the per-workgroup weight-gradient partials in `workspace`, which is REQUIRED here), phase 2 = the
+ * fixed-order sum of the partials into `grads` (needs nothing but workspace, grads, camera_indices and the sizes). Phase 2
+ * depends on phase 1 only; the table scatter that consumes denc (nsamd_hashgrid_encode_bwd) does not depend on phase 2
+ * (MLPWithHashEncoding backward, field_components/mlp.py:187-295: weight gradients and input gradients are independent
+ * products of the same upstream gradient). Same bits as the single call. */
+int nsamd_field_mlp_bwd_phase(const float* enc, const float* selector, const float* directions,
+                              const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
+                              nsamd_field_mlp mlp, const float* ddensity, const float* drgb, float* denc,
+                              nsamd_field_mlp_grads grads, float* workspace, int64_t workspace_floats, int phase,
+                              nsamd_stream_t stream);
+
 /* Training-step pair that trades HBM for MFMA time: the forward also writes the activations the backward needs
  * (`saved`: nsamd_field_mlp_saved_floats(M) floats = 896 B per point, chain-layout fragments), and the backward loads
  * them instead of recomputing the forward — a third of its matrix work. Same outputs as the plain pair. */

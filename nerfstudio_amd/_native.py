@@ -78,6 +78,7 @@ _SIGNATURES = {
     "nsamd_field_fused_fwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, vp, vp, i64, FieldMlp, vp, vp, vp, vp, vp],
     "nsamd_field_mlp_saved_floats": [i64],
     "nsamd_field_mlp_fwd_save": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, vp],
+    "nsamd_field_mlp_bwd_phase": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp, i64, C.c_int, vp],
     "nsamd_field_mlp_bwd_saved": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, vp, FieldMlpGrads, vp, i64, vp],
     "nsamd_linear_fwd": [vp, vp, vp, i64, i32, i32, C.c_int, vp, vp],
     "nsamd_linear_bwd": [vp, vp, vp, vp, i64, i32, i32, C.c_int, vp, vp, vp, vp],

@@ -1365,7 +1365,8 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
                               const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
                               nsamd_field_mlp mlp, const float* ddensity, const float* drgb, float* denc,
                               nsamd_field_mlp_grads grads, float* workspace, int64_t workspace_floats,
-                              const float* acts, nsamd_stream_t stream) {
+                              const float* acts, nsamd_stream_t stream, int phases = 3) {
+  // phases: 1 = the gradient kernel (denc + per-workgroup partials), 2 = the fixed-order sum of the partials, 3 = both
   if (M == 0) return NSAMD_OK;
   int app_dim = 0;
   int st = field_common_checks(enc, directions, dir_group, M, mlp, camera_indices, appearance_const, &app_dim);
@@ -1392,11 +1393,14 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
       M % dir_group == 0 && mlp.num_images <= 8192 &&
       workspace_floats >= (int64_t)blocks * kPartialStride + tiles * 32)
     app_partials = workspace + (int64_t)blocks * kPartialStride;
-  field_mlp_bwd_kernel<<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
-      enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-      grads, partials, app_partials, acts, probe_skip);
-  NSAMD_CHECK_LAUNCH();
-  if (partials != nullptr) {
+  if (phases != 3) NSAMD_REQUIRE(partials != nullptr);  // without scratch the kernel flushes with atomics: nothing to split
+  if (phases & 1) {
+    field_mlp_bwd_kernel<<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
+        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
+        grads, partials, app_partials, acts, probe_skip);
+    NSAMD_CHECK_LAUNCH();
+  }
+  if (partials != nullptr && (phases & 2)) {
     // weight-gradient partials -> gradients, and (extra blocks, one per camera) the appearance rows -> embedding gradient
     const unsigned app_blocks = app_partials != nullptr ? (unsigned)mlp.num_images : 0u;
     const size_t red_lds = sizeof(float) * kReduceGroups * 64;
@@ -1414,6 +1418,16 @@ extern "C" int nsamd_field_mlp_bwd(const float* enc, const float* selector, cons
                                    int64_t workspace_floats, nsamd_stream_t stream) {
   return field_mlp_bwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, ddensity,
                             drgb, denc, grads, workspace, workspace_floats, nullptr, stream);
+}
+
+extern "C" int nsamd_field_mlp_bwd_phase(const float* enc, const float* selector, const float* directions,
+                                         const int64_t* camera_indices, const float* appearance_const,
+                                         int64_t dir_group, int64_t M, nsamd_field_mlp mlp, const float* ddensity,
+                                         const float* drgb, float* denc, nsamd_field_mlp_grads grads, float* workspace,
+                                         int64_t workspace_floats, int phase, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(phase == 1 || phase == 2);
+  return field_mlp_bwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, ddensity,
+                            drgb, denc, grads, workspace, workspace_floats, nullptr, stream, phase);
 }
 
 extern "C" int nsamd_field_mlp_bwd_saved(const float* enc, const float* selector, const float* directions,

@@ -125,6 +125,10 @@ class NerfactoTrainStep:
         # ... and the proposal levels are independent of each other too: level i > 0 gets its own stream
         self.level_streams = [torch.cuda.Stream(device=device) for _ in range(max(self.n_prop - 1, 0))]
         self._fork, self._join = torch.cuda.Event(), torch.cuda.Event()
+        # the field backward's weight-gradient reduce on its own stream, beside the table scatter (NSAMD_SPLIT_REDUCE=0: A/B)
+        self.split_reduce = os.environ.get("NSAMD_SPLIT_REDUCE", "1") != "0"
+        self.reduce_stream = torch.cuda.Stream(device=device)
+        self._red_fork, self._red_join = torch.cuda.Event(), torch.cuda.Event()
         self._level_join = [torch.cuda.Event() for _ in self.level_streams]
         # Proposal levels may run their backward chains on separate streams only when they share nothing: a shared
         # network (use_same_proposal_network) means one gradient buffer, and equal (grid, sample count) means one
@@ -172,6 +176,11 @@ class NerfactoTrainStep:
         """One iteration up to (not including) the optimiser. `updated`: proposal networks receive gradient this step
         (ProposalNetworkSampler.updated_this_step()). Gradients ACCUMULATE into param.grad (zero them first)."""
         self.forward_and_losses(updated, draw_jitter)
+        self.backward_all(updated)
+
+    def backward_all(self, updated: bool) -> None:
+        """Everything after the losses: the main backward chain, the proposal chains on the steps that update them
+        (parallel streams where they share nothing), and the camera optimiser's share."""
         if updated and self.side_stream is not None:
             # The two backward chains are independent (disjoint gradients, separate scratch): fork the proposal chain
             # onto a second stream so that these latency-bound kernels overlap; inside a captured hipGraph this becomes
@@ -368,11 +377,25 @@ class NerfactoTrainStep:
                                       N.ptr(self.d_rgb_s), N.ptr(self.d_dens_main), N.ptr(self.bg_rays), st),
            "render_train_bwd")
         grads = N.FieldMlpGrads(*(N.ptr(self._grad(p)) for p in params), N.ptr(self._grad(emb)) if emb is not None else None)
+        split = self.split_reduce and self.side_stream is not None and not self.save_acts
         if self.save_acts:
             ck(lib.nsamd_field_mlp_bwd_saved(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S,
                                              mm, fm, N.ptr(self.f_saved), N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s),
                                              N.ptr(self.f_denc), grads, N.ptr(self.field_ws), self.field_ws.numel(), st),
                "field_mlp_bwd_saved")
+        elif split:
+            # The sum of the per-workgroup weight-gradient partials needs nothing the table scatter produces and vice
+            # versa: the gradient kernel here, the reduce on its own stream beside the scatter (joined at the end).
+            args = (N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
+                    N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s), N.ptr(self.f_denc), grads, N.ptr(self.field_ws),
+                    self.field_ws.numel())
+            ck(lib.nsamd_field_mlp_bwd_phase(*args, 1, st), "field_mlp_bwd_phase")
+            main = torch.cuda.current_stream()
+            self._red_fork.record(main)
+            self.reduce_stream.wait_event(self._red_fork)
+            with torch.cuda.stream(self.reduce_stream):
+                ck(lib.nsamd_field_mlp_bwd_phase(*args, 2, N.stream()), "field_mlp_bwd_phase")
+                self._red_join.record(self.reduce_stream)
         else:
             ck(lib.nsamd_field_mlp_bwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
                                        N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s), N.ptr(self.f_denc), grads,
@@ -383,6 +406,8 @@ class NerfactoTrainStep:
         ck(lib.nsamd_hashgrid_encode_bwd_set(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
                                          enc.spec.native(), N.ptr(self.f_denc), 1, mm, N.ptr(self._grad(enc.hash_table)),
                                          None, N.ptr(ws), ws_n, st), "hashgrid_encode_bwd")
+        if split:
+            torch.cuda.current_stream().wait_event(self._red_join)
 
     def backward_proposals(self, levels=None) -> None:
         """Backward of the proposal networks (interlevel loss only; main-level weights are detached, losses.py:119-120).

@@ -257,9 +257,10 @@ def test_data_parallel_path_over_one_rank_rccl_matches_single_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
 
-    def run(*flags):
+    def run(*flags, **extra_env):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "14", "--warmup", "4", "--no-cpu-baseline",
-                            "--profile-steps", "1", *flags], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+                            "--profile-steps", "1", *flags], capture_output=True, text=True, env=dict(env, **extra_env),
+                           timeout=600, cwd=root)
         assert r.returncode == 0, r.stderr[-3000:]
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
@@ -267,4 +268,13 @@ def test_data_parallel_path_over_one_rank_rccl_matches_single_gpu():
     dp = run("--force-dp")
     assert "force_dp" in dp["config"] and dp["n_gpus"] == 1
     assert dp["config"]["final_loss"] == plain["config"]["final_loss"], (dp["config"]["final_loss"], plain["config"]["final_loss"])
+    # The default N = 1 schedule defers the main-field Adam of iteration k to run beside the proposal forward of k + 1
+    # (bench.py Trainer._deferred_iteration_body). Same dependencies => the same bits as Adam at the end of the iteration,
+    # launched eagerly and replayed from the captured hipGraphs.
+    in_order = run("--no-graph", NSAMD_DEFER_MAIN_ADAM="0")
+    assert in_order["config"]["final_loss"] == plain["config"]["final_loss"]
+    graph = run()
+    graph_in_order = run(NSAMD_DEFER_MAIN_ADAM="0")
+    assert "4 captured variants" in graph["config"]["launch"] and "2 captured variants" in graph_in_order["config"]["launch"]
+    assert graph["config"]["final_loss"] == graph_in_order["config"]["final_loss"]
 
