@@ -125,8 +125,8 @@ class NerfactoTrainStep:
         # ... and the proposal levels are independent of each other too: level i > 0 gets its own stream
         self.level_streams = [torch.cuda.Stream(device=device) for _ in range(max(self.n_prop - 1, 0))]
         self._fork, self._join = torch.cuda.Event(), torch.cuda.Event()
-        # the field backward's weight-gradient reduce on its own stream, beside the table scatter (NSAMD_SPLIT_REDUCE=0: A/B)
-        self.split_reduce = os.environ.get("NSAMD_SPLIT_REDUCE", "1") != "0"
+        # the field backward's weight-gradient reduce on its own stream, beside the table scatter (opt-in: NSAMD_SPLIT_REDUCE=1; measured neutral)
+        self.split_reduce = os.environ.get("NSAMD_SPLIT_REDUCE", "0") == "1"
         self.reduce_stream = torch.cuda.Stream(device=device)
         self._red_fork, self._red_join = torch.cuda.Event(), torch.cuda.Event()
         self._level_join = [torch.cuda.Event() for _ in self.level_streams]
@@ -178,33 +178,43 @@ class NerfactoTrainStep:
         self.forward_and_losses(updated, draw_jitter)
         self.backward_all(updated)
 
-    def backward_all(self, updated: bool) -> None:
+    def proposal_branches(self):
+        """[(stream, join event, proposal levels)]: how the proposal backward splits over streams. Levels that share a
+        network or a scatter workspace stay on one stream; [] without a side stream."""
+        if self.side_stream is None:
+            return []
+        if not self.levels_independent:
+            return [(self.side_stream, self._join, None)]
+        return [(self.side_stream, self._join, [0])] + [(ls, ev, [i + 1]) for i, (ls, ev) in
+                                                         enumerate(zip(self.level_streams, self._level_join))]
+
+    def backward_all(self, updated: bool, launch_main=None, launch_branch=None) -> None:
         """Everything after the losses: the main backward chain, the proposal chains on the steps that update them
-        (parallel streams where they share nothing), and the camera optimiser's share."""
-        if updated and self.side_stream is not None:
-            # The two backward chains are independent (disjoint gradients, separate scratch): fork the proposal chain
-            # onto a second stream so that these latency-bound kernels overlap; inside a captured hipGraph this becomes
-            # two parallel branches.
+        (parallel streams where they share nothing), and the camera optimiser's share. `launch_main()` /
+        `launch_branch(i)` replace the kernel launches of the main chain / of branch i — bench.py passes the replay of
+        one captured hipGraph per chain: a single hipGraph runs its parallel branches one after the other on this ROCm,
+        separate graphs on separate streams do overlap."""
+        branches = self.proposal_branches() if updated else []
+        if branches:
+            # The backward chains are independent (disjoint gradients, separate scratch): fork the proposal chains onto
+            # their own streams so that these latency-bound kernels overlap with the main chain.
             main = torch.cuda.current_stream()
             self._fork.record(main)
-            self.side_stream.wait_event(self._fork)
-            with torch.cuda.stream(self.side_stream):
-                self.backward_proposals(levels=[0] if self.levels_independent else None)
-                self._join.record(self.side_stream)
-            if self.levels_independent:
-                for i, ls in enumerate(self.level_streams):
-                    ls.wait_event(self._fork)
-                    with torch.cuda.stream(ls):
-                        self.backward_proposals(levels=[i + 1])
-                        self._level_join[i].record(ls)
-            self.backward_main()
-            main.wait_event(self._join)
-            if self.levels_independent:
-                for ev in self._level_join:
-                    main.wait_event(ev)
+            for i, (stream, join, levels) in enumerate(branches):
+                stream.wait_event(self._fork)
+                with torch.cuda.stream(stream):
+                    if launch_branch is not None:
+                        launch_branch(i)
+                    else:
+                        self.backward_proposals(levels=levels)
+                    join.record(stream)
+            self.backward_main() if launch_main is None else launch_main()
+            for _, join, _ in branches:
+                main.wait_event(join)
         else:
-            self.backward_main()
+            self.backward_main() if launch_main is None else launch_main()
             if updated:
+                assert launch_branch is None
                 self.backward_proposals()
         self.backward_cameras(updated)
 
