@@ -86,19 +86,6 @@ def synthetic_batch(device, seed, workload="bounded"):
     return rb, {"image": pool["target"][0].clone()}, pool
 
 
-class _BranchedIteration:
-    """An update iteration as captured hipGraphs per chain (see Trainer.capture): replay() launches them on the runner's
-    streams with the same fork / join events as the eager schedule."""
-
-    def __init__(self, runner, front, main_backward, chains, back):
-        self.runner, self.front, self.main_backward, self.chains, self.back = runner, front, main_backward, chains, back
-
-    def replay(self):
-        self.front.replay()
-        self.runner.backward_all(True, launch_main=self.main_backward.replay, launch_branch=lambda i: self.chains[i].replay())
-        self.back.replay()
-
-
 class Trainer:
     """The reference's Trainer.train_iteration (engine/trainer.py:487-531) for this path, minus logging.
 
@@ -143,8 +130,6 @@ class Trainer:
         self.use_graph = use_graph
         self.runner = None
         self.defer = False
-        # update iterations: one captured graph per backward chain on its own stream (NSAMD_BRANCH_GRAPHS=0: one graph)
-        self.branch_graphs = os.environ.get("NSAMD_BRANCH_GRAPHS", "1") != "0"
         self.opt_parallel = True  # False: the deferred Adam runs on the main stream (per-kernel timing)
         self._pending_main = False  # deferred schedule: the main-field Adam of the previous iteration is still to run
         if use_runner:  # explicit kernel schedule over static buffers (nerfstudio_amd/train_step.py); default
@@ -157,8 +142,10 @@ class Trainer:
                 self.runner.side_stream = None
             # N = 1: the main-field Adam of iteration k (470 MB of HBM streaming) runs BESIDE the proposal forward of
             # iteration k+1 (L2-resident gathers and per-ray scans that read only proposal-network parameters) — the
-            # single-GPU form of the pipelined schedule above; same dependencies, same bits. NSAMD_DEFER_MAIN_ADAM=0: A/B.
-            self.defer = not self.dp and os.environ.get("NSAMD_DEFER_MAIN_ADAM", "0") == "1"
+            # single-GPU form of the pipelined schedule above; same dependencies, same bits. Measured on three MI355X boxes
+            # (profiles/r02_schedule_ab.txt): 1.3 / 3 / 4.5 % faster than Adam at the end of the iteration when replayed
+            # from hipGraphs, neutral with eager launches — so it is the default with graphs. NSAMD_DEFER_MAIN_ADAM=0/1: A/B.
+            self.defer = not self.dp and os.environ.get("NSAMD_DEFER_MAIN_ADAM", "1" if use_graph else "0") == "1"
             if self.defer:
                 self.opt_stream = torch.cuda.Stream(device=dev)
                 self._opt_fork, self._opt_join = torch.cuda.Event(), torch.cuda.Event()
@@ -384,30 +371,6 @@ class Trainer:
                     graphs[("all", upd, pend)] = g
         else:
             for upd in (True, False):
-                branches = self.runner.proposal_branches() if (upd and self.runner is not None and self.branch_graphs) else []
-                if branches:
-                    # An update iteration as ONE graph runs its three backward chains one after the other (this ROCm's
-                    # graph executor does not overlap parallel branches: 1053 us against 705 us without the proposal
-                    # backward, profiles/r02_schedule_ab.txt). One graph per chain, replayed on the chain's own stream:
-                    # front (forward + losses) -> {main backward || proposal level chains} -> back (optimiser).
-                    r = self.runner
-                    front, back, mainb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(front):
-                        self._select_batch()
-                        self.arena.zero_grad(["fields", "proposal_networks"], skip=r.written_params())
-                        r.forward_and_losses(True)
-                    with torch.cuda.graph(mainb):
-                        r.backward_main()
-                    chains = []
-                    for stream, _, levels in branches:
-                        g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, stream=stream):
-                            r.backward_proposals(levels=levels)
-                        chains.append(g)
-                    with torch.cuda.graph(back):
-                        self._optimise(True)
-                    graphs[("all", True)] = _BranchedIteration(r, front, mainb, chains, back)
-                    continue
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):  # the whole iteration is one graph
                     self._fwd_bwd(upd)
@@ -839,9 +802,7 @@ def main():
                        "params": arena.numel, "final_loss": round(float(loss), 6),
                        "launch": (("hipGraph replay (4 captured variants: proposal update x pending main-field Adam, which "
                                    "runs beside the next proposal forward)" if trainer.defer else
-                                   "hipGraph replay (2 captured variants" +
-                                   ("; update iterations as one graph per backward chain on parallel streams)"
-                                    if isinstance(trainer.graphs.get(("all", True)), _BranchedIteration) else ")")) if world == 1 else
+                                   "hipGraph replay (2 captured variants)") if world == 1 else
                                   "hipGraph replay (6 captured segments)") if graphed else "eager",
                        "driver": "autograd modules" if args.autograd else "explicit kernel schedule (train_step.py)"},
             "roofline": roof,

@@ -188,33 +188,27 @@ class NerfactoTrainStep:
         return [(self.side_stream, self._join, [0])] + [(ls, ev, [i + 1]) for i, (ls, ev) in
                                                          enumerate(zip(self.level_streams, self._level_join))]
 
-    def backward_all(self, updated: bool, launch_main=None, launch_branch=None) -> None:
+    def backward_all(self, updated: bool) -> None:
         """Everything after the losses: the main backward chain, the proposal chains on the steps that update them
-        (parallel streams where they share nothing), and the camera optimiser's share. `launch_main()` /
-        `launch_branch(i)` replace the kernel launches of the main chain / of branch i — bench.py passes the replay of
-        one captured hipGraph per chain: a single hipGraph runs its parallel branches one after the other on this ROCm,
-        separate graphs on separate streams do overlap."""
+        (parallel streams where they share nothing; parallel branches inside a captured hipGraph), and the camera
+        optimiser's share."""
         branches = self.proposal_branches() if updated else []
         if branches:
             # The backward chains are independent (disjoint gradients, separate scratch): fork the proposal chains onto
             # their own streams so that these latency-bound kernels overlap with the main chain.
             main = torch.cuda.current_stream()
             self._fork.record(main)
-            for i, (stream, join, levels) in enumerate(branches):
+            for stream, join, levels in branches:
                 stream.wait_event(self._fork)
                 with torch.cuda.stream(stream):
-                    if launch_branch is not None:
-                        launch_branch(i)
-                    else:
-                        self.backward_proposals(levels=levels)
+                    self.backward_proposals(levels=levels)
                     join.record(stream)
-            self.backward_main() if launch_main is None else launch_main()
+            self.backward_main()
             for _, join, _ in branches:
                 main.wait_event(join)
         else:
-            self.backward_main() if launch_main is None else launch_main()
+            self.backward_main()
             if updated:
-                assert launch_branch is None
                 self.backward_proposals()
         self.backward_cameras(updated)
 

@@ -3,7 +3,7 @@
 back: proposal networks updated / not updated x main-field Adam of the previous iteration pending / not pending. The
 replays train (parameters move), which does not matter for timing. One line per variant: median and minimum of
 PROBE_REPLAYS (default 60) replays, HIP events on the launch stream.
-Environment: NSAMD_BRANCH_GRAPHS, NSAMD_DEFER_MAIN_ADAM, NSAMD_SPLIT_REDUCE, NSAMD_SIDE_STREAM (read by bench.Trainer / NerfactoTrainStep)."""
+Environment: NSAMD_DEFER_MAIN_ADAM, NSAMD_SPLIT_REDUCE, NSAMD_SIDE_STREAM (read by bench.Trainer / NerfactoTrainStep)."""
 import os
 import sys
 
@@ -30,8 +30,7 @@ for _ in range(10):
 tr.finish()
 torch.cuda.synchronize()
 n = int(os.environ.get("PROBE_REPLAYS", "60"))
-tag = (f"defer={int(tr.defer)} split={int(tr.runner.split_reduce)} side={int(tr.runner.side_stream is not None)} "
-       f"branch_graphs={int(tr.branch_graphs)}")
+tag = f"defer={int(tr.defer)} split={int(tr.runner.split_reduce)} side={int(tr.runner.side_stream is not None)}"
 for key, g in sorted(tr.graphs.items(), key=str):
     tr._push_hyper()
     for _ in range(3):
