@@ -681,6 +681,11 @@ def main():
     ap.add_argument("--workload", choices=["bounded", "unbounded"], default="bounded",
                     help="bounded = BASELINE configs[1]/[2] (the metric's configuration); unbounded = configs[4] "
                          "(cameras outside the box, most samples in the contracted region)")
+    ap.add_argument("--start-step", type=int, default=0,
+                    help="not the headline: start the step counter (proposal update schedule, anneal, learning rate) at this "
+                         "training step — e.g. 5000 = the steady state of the schedule, proposal networks updated every 6th "
+                         "iteration (models/nerfacto.py:208-213) instead of every 2nd as in the first 1000; parameters are "
+                         "still at their initial state")
     ap.add_argument("--fixed-batch", action="store_true", help="train on one fixed ray batch instead of rotating the pool")
     ap.add_argument("--force-dp", action="store_true",
                     help="N = 1 only: run the data-parallel schedule (pipelined exchange, compact table prefix, async "
@@ -731,6 +736,9 @@ def main():
     trainer = Trainer(model, arena, rb, batch, world=world, use_graph=not args.no_graph, use_runner=not args.autograd,
                       pool=None if args.fixed_batch else pool, force_dp=args.force_dp)
 
+    if args.start_step:
+        trainer.step = args.start_step
+        model.proposal_sampler._step = args.start_step
     for _ in range(max(1, args.warmup // 2)):  # eager warm-up: lazy kernel attributes, caches, allocator
         trainer.train_iteration()
     trainer.finish()
@@ -807,6 +815,8 @@ def main():
                        "driver": "autograd modules" if args.autograd else "explicit kernel schedule (train_step.py)"},
             "roofline": roof,
         }
+        if args.start_step:
+            out["config"]["start_step"] = args.start_step
         if args.force_dp:
             out["config"]["force_dp"] = "data-parallel schedule over a one-rank RCCL communicator (rehearsal of the N > 1 path)"
         if world == 1 and not args.no_cpu_baseline:

@@ -23,8 +23,14 @@ timeout 600 python bench.py --kernel-table > $OUT/bench_default.json 2> $OUT/ben
 cat $OUT/bench_default.json | tee -a $OUT/summary.txt
 head -n 24 $OUT/bench_default_kernel_table.log | tee -a $OUT/summary.txt
 echo "== bench 300 steps" | tee -a $OUT/summary.txt
-timeout 600 python bench.py --steps 300 --warmup 10 --no-cpu-baseline > $OUT/bench_300steps.json 2>/dev/null
+timeout 600 python bench.py --steps 300 --warmup 10 --no-cpu-baseline --kernel-table --profile-steps 10 > $OUT/bench_300steps.json 2> $OUT/bench_300steps_kernel_table.log
 cut -c1-260 $OUT/bench_300steps.json | tee -a $OUT/summary.txt
+head -n 24 $OUT/bench_300steps_kernel_table.log | tee -a $OUT/summary.txt
+echo "== bench --start-step 5000 (steady state of the proposal update schedule; not the headline)" | tee -a $OUT/summary.txt
+timeout 600 python bench.py --steps 120 --warmup 12 --start-step 5000 --no-cpu-baseline > $OUT/bench_start5000.json 2>/dev/null
+cut -c1-260 $OUT/bench_start5000.json | tee -a $OUT/summary.txt
+echo "== per-kind iteration times (scripts/probe_iteration_times.py): Adam deferred (default) / in order" | tee -a $OUT/summary.txt
+for d in 1 0; do NSAMD_DEFER_MAIN_ADAM=$d timeout 300 python scripts/probe_iteration_times.py 2>/dev/null | tee -a $OUT/summary.txt; done
 echo "== bench unbounded" | tee -a $OUT/summary.txt
 timeout 600 python bench.py --workload unbounded --no-cpu-baseline --kernel-table > $OUT/bench_unbounded.json 2> $OUT/bench_unbounded_kernel_table.log
 cat $OUT/bench_unbounded.json | tee -a $OUT/summary.txt
