@@ -810,7 +810,7 @@ def main():
                        "params": arena.numel, "final_loss": round(float(loss), 6),
                        "launch": (("hipGraph replay (4 captured variants: proposal update x pending main-field Adam, which "
                                    "runs beside the next proposal forward)" if trainer.defer else
-                                   "hipGraph replay (2 captured variants)") if world == 1 else
+                                   "hipGraph replay (2 captured variants)") if not trainer.pipelined else
                                   "hipGraph replay (6 captured segments)") if graphed else "eager",
                        "driver": "autograd modules" if args.autograd else "explicit kernel schedule (train_step.py)"},
             "roofline": roof,
