@@ -673,6 +673,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--autograd", action="store_true",
                     help="drive the step through the nn.Module / autograd API instead of the explicit kernel schedule")
+    ap.add_argument("--fused-model-api", action="store_true",
+                    help="with the nn.Module driver (implies --autograd): config.fused_train_step — the Model API "
+                         "(get_outputs / get_loss_dict / loss.backward()) with the explicit kernel schedule underneath")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL on ROCm); gloo only for functional tests")
     ap.add_argument("--share-gpu", action="store_true", help="functional test: every rank uses cuda:0 (needs gloo)")
@@ -727,6 +730,9 @@ def main():
     _native.load()  # fail loudly if the HIP extension is missing
     F.DIRECT_GRAD = True  # backward kernels accumulate straight into the arena's gradient views
     model = build_model(device, seed=0)  # same init on every rank (replicated model)
+    if args.fused_model_api:
+        args.autograd = True
+        model.config.fused_train_step = True
     # the reference's optimiser groups (models/nerfacto.py:255-260), AdamOptimizerConfig(lr=1e-2, eps=1e-15) each
     arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
     arena.broadcast_params()
@@ -812,7 +818,8 @@ def main():
                                    "runs beside the next proposal forward)" if trainer.defer else
                                    "hipGraph replay (2 captured variants)") if not trainer.pipelined else
                                   "hipGraph replay (6 captured segments)") if graphed else "eager",
-                       "driver": "autograd modules" if args.autograd else "explicit kernel schedule (train_step.py)"},
+                       "driver": ("Model API over the explicit kernel schedule (fused_step.py)" if args.fused_model_api else
+                                  "autograd modules") if args.autograd else "explicit kernel schedule (train_step.py)"},
             "roofline": roof,
         }
         if args.start_step:

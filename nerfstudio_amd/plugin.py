@@ -103,10 +103,36 @@ def _model_classes():
         def populate_modules(self):
             super().populate_modules()
             install_hip_modules(self)
+            self._fused = None
+
+        # config.fused_train_step: training iterations through fused_step.FusedTrainStep (same Model API, the explicit
+        # kernel schedule underneath, gradients written straight into param.grad); everything else as the reference
+        def _fused_step(self):
+            if not (self.training and getattr(self.config, "fused_train_step", False) and torch.is_grad_enabled()):
+                return None
+            if self._fused is None:
+                from .fused_step import FusedTrainStep
+
+                self._fused = FusedTrainStep(self)
+                reason = self._fused.supported()
+                if reason is not None:
+                    raise NotImplementedError(f"fused_train_step: {reason} is only on the module path")
+            return self._fused
+
+        def get_outputs(self, ray_bundle):
+            fused = self._fused_step()
+            return fused.get_outputs(ray_bundle) if fused is not None else super().get_outputs(ray_bundle)
+
+        def get_loss_dict(self, outputs, batch, metrics_dict=None):
+            if "fused_step" in outputs:
+                return outputs["fused_step"].get_loss_dict(outputs, batch)
+            return super().get_loss_dict(outputs, batch, metrics_dict)
 
         def get_metrics_dict(self, outputs, batch):
             from .model_components.losses import distortion_loss
 
+            if "fused_step" in outputs:
+                return outputs["fused_step"].get_metrics_dict(outputs, batch)
             metrics = {}
             gt_rgb = self.renderer_rgb.blend_background(batch["image"].to(self.device))
             metrics["psnr"] = self.psnr(outputs["rgb"], gt_rgb)
@@ -119,6 +145,8 @@ def _model_classes():
     class HipNerfactoModelConfig(NerfactoModelConfig):
         _target: Type = field(default_factory=lambda: HipNerfactoModel)
         implementation: Literal["tcnn", "torch", "hip"] = "hip"
+        fused_train_step: bool = False
+        """Run training iterations on the explicit kernel schedule behind the Model API (nerfstudio_amd/fused_step.py)."""
 
     return HipNerfactoModelConfig, HipNerfactoModel
 

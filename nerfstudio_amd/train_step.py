@@ -19,7 +19,7 @@ schedule variant and replayed. Numerically identical to the autograd path (tests
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 from torch import Tensor
@@ -148,13 +148,16 @@ class NerfactoTrainStep:
             self.d_directions = [e(n, 3) for _ in self.counts]
             self._corrected = None
             self.camera_reg = torch.zeros((), **f32)
+        self.reg_in_backward = True  # backward_cameras also differentiates the pose regulariser
+        self.main_table_write_only = True  # the main table's gradient is written, not accumulated (written_params)
         self.spacing = int(getattr(model.proposal_sampler.initial_sampler, "spacing", 0))
         # host-evaluated tables (bit-identical to the reference's CPU linspace)
         self.edges = F._linspace("edges", self.counts[0], device)
         self.u_base = [None] + [F._linspace("u", s, device) for s in self.counts[1:]]
 
     # -------------------------------------------------------------------------------------------------------------
-    def set_batch(self, origins: Tensor, directions: Tensor, camera_indices: Tensor, target_rgb: Tensor) -> None:
+    def set_batch(self, origins: Tensor, directions: Tensor, camera_indices: Tensor,
+                  target_rgb: Optional[Tensor] = None) -> None:
         if self.cam_opt is not None:  # the kernels see the pose-corrected rays (apply_camera_corrections)
             self.raw_origins.copy_(origins)
             self.raw_directions.copy_(directions)
@@ -162,7 +165,22 @@ class NerfactoTrainStep:
             self.origins.copy_(origins)
             self.directions.copy_(directions)
         self.camera_indices.copy_(camera_indices.reshape(-1))
-        self.target.copy_(target_rgb)
+        if target_rgb is not None:
+            self.target.copy_(target_rgb)
+
+    def prepare_grads(self, updated: bool) -> None:
+        """For callers without a gradient arena (a trainer that runs `zero_grad(set_to_none=True)`, engine/optimizers.py:
+        160-172): give every parameter this iteration produces a gradient for a buffer. Fresh buffers are zero-filled,
+        except the main table's, which the scatter writes; a gradient that already exists is accumulated into
+        (gradient accumulation), the main table's included."""
+        fld = self.model.field
+        table = fld.mlp_base.encoding.hash_table
+        self.main_table_write_only = table.grad is None
+        owners = [fld] + (list(self.model.proposal_networks) if updated else [])
+        for mod in owners:
+            for prm in mod.parameters():
+                if prm.requires_grad and prm.grad is None:
+                    prm.grad = torch.empty_like(prm) if prm is table else torch.zeros_like(prm)
 
     def _grad(self, p: Tensor) -> Tensor:
         assert p.grad is not None and p.grad.is_contiguous(), "parameters need preallocated .grad (use arena.ParamArena)"
@@ -224,7 +242,7 @@ class NerfactoTrainStep:
         zero them (ParamArena.zero_grad(skip=...)). All other gradients accumulate and must be zeroed first."""
         # Only the 67 MB main table: for the 5 MB proposal tables the zero-fill is nothing and the accumulating call needs
         # no worst-case spill list.
-        return [self.model.field.mlp_base.encoding.hash_table]
+        return [self.model.field.mlp_base.encoding.hash_table] if self.main_table_write_only else []
 
     def forward_and_losses(self, updated: bool, draw_jitter: bool = True) -> None:
         self.apply_camera_corrections()
@@ -237,7 +255,12 @@ class NerfactoTrainStep:
         buffers the kernels read; the autograd graph of the tiny exponential map is kept for backward_cameras."""
         if self.cam_opt is None:
             return
-        o, d = self.cam_opt.corrected_rays(self.raw_origins, self.raw_directions, self.camera_indices)
+        if hasattr(self.cam_opt, "corrected_rays"):
+            o, d = self.cam_opt.corrected_rays(self.raw_origins, self.raw_directions, self.camera_indices)
+        else:  # the reference's own CameraOptimizer: forward(indices) -> [n,3,4] corrections (camera_optimizers.py:107-153)
+            c = self.cam_opt(self.camera_indices)
+            o = self.raw_origins + c[:, :3, 3]
+            d = torch.bmm(c[:, :3, :3], self.raw_directions[..., None]).squeeze(-1)
         self._corrected = (o, d)
         self.origins.copy_(o.detach())
         self.directions.copy_(d.detach())
@@ -260,11 +283,14 @@ class NerfactoTrainStep:
         if updated:  # the proposal networks saw the rays too (interlevel loss)
             d_o = d_o + sum(self.d_origins[:L])
             d_d = d_d + sum(self.d_directions[:L])
-        reg = {}
-        self.cam_opt.get_loss_dict(reg)
-        self.camera_reg = reg["camera_opt_regularizer"].detach()
         o, d = self._corrected
-        torch.autograd.backward([o, d, reg["camera_opt_regularizer"]], [d_o, d_d, torch.ones_like(self.camera_reg)])
+        if self.reg_in_backward:
+            reg = {}
+            self.cam_opt.get_loss_dict(reg)
+            self.camera_reg = reg["camera_opt_regularizer"].detach()
+            torch.autograd.backward([o, d, reg["camera_opt_regularizer"]], [d_o, d_d, torch.ones_like(self.camera_reg)])
+        else:  # the caller differentiates the regulariser itself (fused_step.FusedTrainStep)
+            torch.autograd.backward([o, d], [d_o, d_d])
         self._corrected = None
 
     def forward_proposals(self, draw_jitter: bool = True, need_enc: bool = True) -> None:
@@ -316,6 +342,11 @@ class NerfactoTrainStep:
 
     def forward_main_and_losses(self, updated: bool) -> None:
         """Main field on the final samples, compositing, and the three losses with their gradients."""
+        self.forward_main()
+        self.losses(updated)
+
+    def forward_main(self) -> None:
+        """Hash grid + MLPs of the main field on the final samples -> per-sample density and rgb."""
         lib, st, n, cfg = N.load(), N.stream(), self.n, self.cfg
         ck = N.check
         fld = self.model.field
@@ -350,6 +381,14 @@ class NerfactoTrainStep:
                "hashgrid_encode_fwd")
             ck(lib.nsamd_field_mlp_fwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
                                        N.ptr(self.f_dens), N.ptr(self.f_rgb), st), "field_mlp_fwd")
+
+    def losses(self, updated: bool) -> None:
+        """Weights, compositing (rgb / accumulation / depths: the model outputs) and the three losses with their gradients
+        against `self.target`. Reads only what forward_main left behind, so it can be repeated with another target."""
+        lib, st, n, cfg = N.load(), N.stream(), self.n, self.cfg
+        ck = N.check
+        L = self.n_prop
+        S = self.counts[L]
         # weights + compositing + MSE value/gradient in one launch (+ the global depth clip)
         ck(lib.nsamd_render_train(N.ptr(self.f_rgb), N.ptr(self.f_dens), N.ptr(self.t_bins[L]), n, S, self.bg_mode,
                                   self.bg_vals, N.ptr(self.target), 1.0 / (3 * n), N.ptr(self.weights[L]), N.ptr(self.rgb),
@@ -406,10 +445,18 @@ class NerfactoTrainStep:
                                        N.ptr(self.field_ws), self.field_ws.numel(), st), "field_mlp_bwd")
         if self.cam_opt is not None:
             self._rays_backward(L, fld, self.f_denc)
-        ws, ws_n = F._scatter_workspace(enc.spec, self.f_enc.device, mm, write_only=True)
-        ck(lib.nsamd_hashgrid_encode_bwd_set(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
-                                         enc.spec.native(), N.ptr(self.f_denc), 1, mm, N.ptr(self._grad(enc.hash_table)),
-                                         None, N.ptr(ws), ws_n, st), "hashgrid_encode_bwd")
+        if self.main_table_write_only:
+            ws, ws_n = F._scatter_workspace(enc.spec, self.f_enc.device, mm, write_only=True)
+            ck(lib.nsamd_hashgrid_encode_bwd_set(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
+                                                 enc.spec.native(), N.ptr(self.f_denc), 1, mm,
+                                                 N.ptr(self._grad(enc.hash_table)), None, N.ptr(ws), ws_n, st),
+               "hashgrid_encode_bwd")
+        else:  # accumulate into an existing gradient (prepare_grads)
+            ws, ws_n = F._scatter_workspace(enc.spec, self.f_enc.device, mm)
+            ck(lib.nsamd_hashgrid_encode_bwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
+                                             enc.spec.native(), N.ptr(self.f_denc), 1, mm,
+                                             N.ptr(self._grad(enc.hash_table)), None, N.ptr(ws), ws_n, st),
+               "hashgrid_encode_bwd")
         if split:
             torch.cuda.current_stream().wait_event(self._red_join)
 

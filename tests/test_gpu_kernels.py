@@ -894,6 +894,100 @@ def test_train_step_runner_matches_autograd_path(F):
             assert float(p.grad.abs().max()) == 0.0, k
 
 
+@pytest.mark.parametrize("camera_mode", ["off", "SO3xR3"])
+def test_fused_train_step_behind_the_model_api(F, camera_mode):
+    """config.fused_train_step: get_outputs -> get_metrics_dict -> get_loss_dict -> sum(losses).backward() driven exactly
+    as nerfstudio's pipeline / trainer drive a model (pipelines/base_pipeline.py:290-303, engine/trainer.py:514-516), with
+    the explicit kernel schedule underneath (fused_step.FusedTrainStep), against the nn.Module / autograd path: outputs,
+    metrics, losses and every parameter gradient (also the camera optimiser's); `zero_grad(set_to_none=True)` semantics
+    (a non-update iteration leaves the proposal networks without gradient), and accumulation into existing gradients."""
+    from nerfstudio_amd.cameras.camera_optimizers import CameraOptimizerConfig
+    from nerfstudio_amd.cameras.rays import RayBundle
+
+    cfg = small_cfg(12, 10, 6)
+    params = orc.init_params(cfg, seed=11, table_std=0.4)
+    n = 300
+    o, d, cam, tgt = orc.synthetic_rays(n, cfg.num_images, seed=12)
+    o[n // 2:] *= 4.0
+    jit = torch.from_numpy(np.random.RandomState(5).uniform(0, 1, (3, n)).astype(np.float32)).cuda()
+    batch = {"image": tgt.cuda()}
+
+    def build(fused):
+        m = _hip_model(cfg, params)
+        if camera_mode != "off":
+            m.camera_optimizer = CameraOptimizerConfig(mode=camera_mode).setup(num_cameras=cfg.num_images, device="cuda")
+            with torch.no_grad():  # non-trivial pose corrections, identical in both models
+                g = torch.Generator().manual_seed(3)
+                m.camera_optimizer.pose_adjustment.copy_((torch.randn(cfg.num_images, 6, generator=g) * 0.01).cuda())
+        m.config.fused_train_step = fused
+        m.set_step(137)
+        return m
+
+    def iteration(m, step_jitter=True):
+        rb = RayBundle(origins=o.cuda(), directions=d.cuda(), pixel_area=torch.full((n, 1), 1e-6).cuda(),
+                       camera_indices=cam.cuda()[:, None])
+        out = m(rb, jitters=[jit[i][:, None] for i in range(3)] if step_jitter else None)
+        metrics = m.get_metrics_dict(out, batch)
+        losses = m.get_loss_dict(out, batch, metrics)
+        import functools
+
+        functools.reduce(torch.add, losses.values()).backward()  # engine/trainer.py:514
+        return out, metrics, losses
+
+    ma, mb = build(False), build(True)
+    out_a, met_a, ld_a = iteration(ma)
+    out_b, met_b, ld_b = iteration(mb)
+    assert "fused_step" in out_b and "fused_step" not in out_a
+    close(out_b["rgb"], out_a["rgb"], atol=1e-6, rtol=0)
+    close(out_b["accumulation"], out_a["accumulation"], atol=1e-6, rtol=0)
+    close(out_b["expected_depth"], out_a["expected_depth"], rtol=1e-6)
+    exact(out_b["depth"], out_a["depth"])
+    for i in range(2):
+        exact(out_b[f"prop_depth_{i}"], out_a[f"prop_depth_{i}"])
+    assert set(ld_b) == set(ld_a) and set(met_a) <= set(met_b) | {"distortion"}
+    for k in ld_a:
+        close(ld_b[k], ld_a[k], rtol=1e-5, atol=1e-9, msg=k)
+    close(met_b["psnr"], met_a["psnr"], rtol=1e-5)
+    close(met_b["distortion"], met_a["distortion"], rtol=1e-5, atol=1e-9)
+    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
+    assert set(pa) == set(pb)
+
+    def same_gradient(k):
+        if k.startswith("camera_optimizer"):  # far rays (t ~ 1000) condition this one: relative L2, as the golden test does
+            a, b = pb[k].grad.double(), pa[k].grad.double()
+            assert float((a - b).norm() / b.norm()) <= 1e-3 and float(b.abs().max()) > 0, k
+        else:
+            gclose(pb[k].grad, pa[k].grad, 2e-5, k)
+
+    for k in pa:
+        assert pb[k].grad is not None, k
+        same_gradient(k)
+
+    # the trainer's zero_grad(set_to_none=True) (engine/optimizers.py:160-172), then a NON-update iteration: the
+    # proposal networks are run without gradient (ray_samplers.py:590-599), their .grad stays None as on the module path
+    first = {k: p.grad.clone() for k, p in pb.items()}
+    for m in (ma, mb):
+        m.zero_grad(set_to_none=True)
+        m.after_step(137)  # AFTER_TRAIN_ITERATION: steps_since_update 0 -> 1, not > update_sched(137) = 1
+        m.set_step(138)
+    assert not mb.proposal_sampler.updated_this_step()
+    iteration(ma)
+    iteration(mb)
+    for k in pa:
+        if k.startswith("proposal_networks"):
+            assert pb[k].grad is None and pa[k].grad is None, k
+        else:
+            same_gradient(k)
+    # a gradient that is already there is accumulated into — the main table's too (its scatter normally overwrites)
+    table = "field.mlp_base.encoding.hash_table"
+    once = pb[table].grad.clone()
+    mb.after_step(138), mb.set_step(138)
+    mb.proposal_sampler._steps_since_update = 0  # keep it a non-update iteration
+    iteration(mb)
+    gclose(pb[table].grad, 2.0 * once, 1e-5, "accumulated table gradient")
+    assert first[table].shape == once.shape
+
+
 @pytest.mark.parametrize("contract,ray_mode,with_cams", [(True, True, True), (False, False, False), (True, False, True)])
 def test_fused_main_field_forward_is_bit_identical(F, contract, ray_mode, with_cams):
     """nsamd_field_fused_fwd (hash L16 -> base -> head in one launch, features in registers) against
