@@ -979,7 +979,7 @@ def test_fused_train_step_behind_the_model_api(F, camera_mode):
         else:
             same_gradient(k)
     # a gradient that is already there is accumulated into — the main table's too (its scatter normally overwrites)
-    table = "field.mlp_base.encoding.hash_table"
+    table = next(k for k, prm in pb.items() if prm is mb.field.mlp_base.encoding.hash_table)
     once = pb[table].grad.clone()
     mb.after_step(138), mb.set_step(138)
     mb.proposal_sampler._steps_since_update = 0  # keep it a non-update iteration
