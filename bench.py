@@ -96,6 +96,11 @@ class Trainer:
     the ray batch, the jitter draws (graph-safe Philox), the anneal exponent and Adam's bias-corrected step size
     (`hyper`, refreshed by a 20-byte async copy from a ring of pinned host slots before each replay).
 
+    N = 1 with graphs (default): the main-field Adam of iteration k is the first node of iteration k+1's graph, on a branch
+    beside select-batch / jitter / the proposal forward (`_deferred_iteration_body`; four captured variants: proposal
+    update x pending Adam). Same dependencies as Adam at the end of the iteration, hence the same bits; `finish()` runs the
+    last pending update inside the timed region.
+
     N > 1 (data parallel): the iteration runs as segments (eager launches by default, captured hipGraphs with --dp-graph)
     and the 67 MB main-field all-reduce (RCCL, its own stream) is PIPELINED across steps (nerfstudio_amd/dp_schedule.py). The proposal forward of step k+1 reads only proposal-network parameters, so
         step k:   [proposal fwd k] -> (wait AR_main k-1) [Adam main k-1] -> [main fwd + losses + main bwd k]
