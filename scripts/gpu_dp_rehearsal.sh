@@ -1,3 +1,7 @@
+#!/bin/bash
+# GPU box: the data-parallel schedule (pipelined exchange, compact table prefix, asynchronous all-reduce on the communication
+# stream) over a ONE-rank RCCL communicator: eager segments against captured hipGraph segments (--dp-graph).
+# Results: profiles/r02_schedule_ab.txt
 cd ${GRAFT_REPO_ROOT:-/root/repo}; mkdir -p gpurun_out/dp1
 export MASTER_ADDR=127.0.0.1 MASTER_PORT=29555
 for f in "--force-dp" "--force-dp --dp-graph" "--force-dp" "--force-dp --dp-graph"; do
