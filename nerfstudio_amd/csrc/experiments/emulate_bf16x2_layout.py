@@ -1,77 +1,94 @@
-"""Lane-level emulation of the planned split-bf16 weight-gradient path (design check, CPU only)."""
-import numpy as np, torch
+#!/usr/bin/env python3
+"""Lane-level emulation (numpy, CPU) of field_mlp_bwd_bf16x2.patch: the scratch layout store_rows_bf2 writes, the operands
+load_op2 builds from it (two ds_read_b128 + v_perm_b32 de-interleave) and the v_mfma_f32_16x16x32_bf16 products of
+coop_dw_bf2, for 8 areas (waves) of 16 points: the result must be dY^T X to the two-piece precision, and the bias sums the
+sums of dY. Run it after touching any index in the patch (it restates the patch's index arithmetic, it does not parse it)."""
+import numpy as np
+import torch
 
-def bf16_bits(x):  # RNE bf16 of fp32 array -> uint16 bits
-    t = torch.from_numpy(np.asarray(x, np.float32)).to(torch.bfloat16)
+LD = 20  # kScratchLd
+
+
+def bf16_bits(x):
+    t = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(torch.bfloat16)  # RNE, as v_cvt_pk_bf16_f32
     return t.view(torch.int16).numpy().astype(np.uint16)
 
-def f32_from_hi(bits16):
+
+def widen(bits16):
     return (bits16.astype(np.uint32) << 16).view(np.float32)
 
-def pack_bf16(a, b):  # low = bf16(a), high = bf16(b)
-    return bf16_bits(a).astype(np.uint32) | (bf16_bits(b).astype(np.uint32) << 16)
 
-LD = 20
 def store_rows_bf2(S, x, T):
-    """S: uint32 [64*LD]; x: [T][4][64 lanes] values: lane (j,g) reg (t,r) = feature 16t+4g+r of point j."""
-    lanes = np.arange(64); j = lanes & 15; g = lanes >> 4
+    """x[t][r][lane]: lane (j, g) register (t, r) = feature 16t + 4g + r of point j -> S[feature][point] = h | m << 16."""
+    lanes = np.arange(64)
+    j, g = lanes & 15, lanes >> 4
     for t in range(T):
-        for r0 in (0, 2):
-            v0, v1 = x[t][r0], x[t][r0 + 1]
-            ph = pack_bf16(v0, v1)
-            res0 = (v0 - f32_from_hi((ph & 0xffff).astype(np.uint16))).astype(np.float32)
-            res1 = (v1 - (ph & 0xffff0000).view(np.float32)).astype(np.float32)
-            pm = pack_bf16(res0, res1)
-            qh, qm = ph[lanes ^ 1], pm[lanes ^ 1]   # DPP quad_perm [1,0,3,2]
-            even = (j & 1) == 0
-            wh = np.where(even, (ph & 0xffff) | (qh << 16), (qh >> 16) | (ph & 0xffff0000)).astype(np.uint32)
-            wm = np.where(even, (pm & 0xffff) | (qm << 16), (qm >> 16) | (pm & 0xffff0000)).astype(np.uint32)
-            row = 16 * t + 4 * g + r0 + np.where(even, 0, 1)
-            S[row * LD + (j >> 1)] = wh
-            S[row * LD + 8 + (j >> 1)] = wm
+        for r in range(4):
+            v = x[t][r].astype(np.float32)
+            h = bf16_bits(v)
+            m = bf16_bits((v - widen(h)).astype(np.float32))
+            S[(16 * t + 4 * g + r) * LD + j] = h.astype(np.uint32) | (m.astype(np.uint32) << 16)
 
-def read_op(S_areas, A0, row_base, lane_i, g, piece):
-    """u4 (as 8 floats) of lane (i, g): area A0 + (g>>1), words 4*(g&1).. of the h (piece 0) / m (piece 1) part."""
-    S = S_areas[A0 + (g >> 1)]
-    base = (row_base + lane_i) * LD + 8 * piece + 4 * (g & 1)
-    w = S[base:base + 4]
-    out = np.empty(8, np.float32)
-    out[0::2] = f32_from_hi((w & 0xffff).astype(np.uint16))
-    out[1::2] = (w & 0xffff0000).view(np.float32)
-    return out
 
-rs = np.random.RandomState(0)
-n_areas, T_d, T_x = 8, 4, 4
-dY = rs.standard_normal((n_areas, 16, 64)).astype(np.float32) * np.exp(rs.uniform(-6, 2, (n_areas, 16, 64))).astype(np.float32)  # [area][point][neuron]
-X = rs.standard_normal((n_areas, 16, 64)).astype(np.float32)
-Sd = [np.zeros(64 * LD, np.uint32) for _ in range(n_areas)]
-Sx = [np.zeros(64 * LD, np.uint32) for _ in range(n_areas)]
-lanes = np.arange(64); jj = lanes & 15; gg = lanes >> 4
-for a in range(n_areas):
-    xd = [[dY[a][jj, 16 * t + 4 * gg + r] for r in range(4)] for t in range(T_d)]
-    xx = [[X[a][jj, 16 * t + 4 * gg + r] for r in range(4)] for t in range(T_x)]
-    store_rows_bf2(Sd[a], xd, T_d); store_rows_bf2(Sx[a], xx, T_x)
-# coop_dw_bf2 for output tile (n, m): C[4g+r][j] per lane
-def coop(n, m):
-    C = np.zeros((16, 16), np.float64)
-    db = np.zeros(16, np.float64)
-    for A0 in range(0, n_areas, 2):
-        for g in range(4):
-            for i in range(16):
-                ah, am = read_op(Sd, A0, 16 * n, i, g, 0), read_op(Sd, A0, 16 * n, i, g, 1)
-                db[i] += float(ah.sum()) + float(am.sum())
-                for j in range(16):
-                    bh, bm = read_op(Sx, A0, 16 * m, j, g, 0), read_op(Sx, A0, 16 * m, j, g, 1)
-                    C[i, j] += float(am @ bh) + float(ah @ bm) + float(ah @ bh)
-    return C, db
-worst = 0.0
-for n in range(4):
-    for m in range(4):
-        C, db = coop(n, m)
-        ref = sum(dY[a][:, 16 * n:16 * n + 16].astype(np.float64).T @ X[a][:, 16 * m:16 * m + 16].astype(np.float64) for a in range(n_areas))
-        worst = max(worst, float(np.abs(C - ref).max() / np.abs(ref).max()))
-        dref = sum(dY[a][:, 16 * n:16 * n + 16].astype(np.float64).sum(0) for a in range(n_areas))
-        assert np.abs(db - dref).max() <= 1e-4 * np.abs(dref).max(), (n, m)
-print("max |err| / max |dW| over the 16 tiles:", worst)
-assert worst < 1e-4
-print("layout OK")
+def perm(src0, src1, sel):
+    """v_perm_b32: result byte i = byte sel[i] of the 8-byte value src0:src1 (0-3 -> src1, 4-7 -> src0)."""
+    both = (np.uint64(src0) << np.uint64(32)) | np.uint64(src1)
+    out = 0
+    for i in range(4):
+        out |= int((both >> np.uint64(8 * ((sel >> (8 * i)) & 0xff))) & np.uint64(0xff)) << (8 * i)
+    return np.uint32(out)
+
+
+def load_op2(S, base):
+    w = S[base:base + 8]
+    h = [perm(w[2 * k + 1], w[2 * k], 0x05040100) for k in range(4)]
+    m = [perm(w[2 * k + 1], w[2 * k], 0x07060302) for k in range(4)]
+
+    def slots(words):  # 8 bf16 K-slots of the packed operand, slot 2k = low half of word k
+        out = np.empty(8, np.float32)
+        for k, wd in enumerate(words):
+            out[2 * k] = widen(np.array([wd & 0xffff], np.uint16))[0]
+            out[2 * k + 1] = np.array([wd & 0xffff0000], np.uint32).view(np.float32)[0]
+        return out
+
+    return slots(h), slots(m)
+
+
+def main():
+    rs = np.random.RandomState(0)
+    areas = 8
+    dY = (rs.standard_normal((areas, 16, 64)) * np.exp(rs.uniform(-6, 2, (areas, 16, 64)))).astype(np.float32)  # [area][point][neuron]
+    X = rs.standard_normal((areas, 16, 64)).astype(np.float32)
+    Sd = [np.zeros(64 * LD, np.uint32) for _ in range(areas)]
+    Sx = [np.zeros(64 * LD, np.uint32) for _ in range(areas)]
+    lanes = np.arange(64)
+    jj, gg = lanes & 15, lanes >> 4
+    for a in range(areas):
+        store_rows_bf2(Sd[a], [[dY[a][jj, 16 * t + 4 * gg + r] for r in range(4)] for t in range(4)], 4)
+        store_rows_bf2(Sx[a], [[X[a][jj, 16 * t + 4 * gg + r] for r in range(4)] for t in range(4)], 4)
+    worst = 0.0
+    for n in range(4):
+        for m in range(4):
+            C = np.zeros((16, 16))  # C[row of A][column of B]; lane (j, g) register r holds C[4g + r][j]
+            db = np.zeros(16)
+            for pair in range(0, areas, 2):
+                for g in range(4):
+                    area, half = pair + (g >> 1), 8 * (g & 1)
+                    A = [load_op2(Sd[area], (16 * n + i) * LD + half) for i in range(16)]
+                    B = [load_op2(Sx[area], (16 * m + j) * LD + half) for j in range(16)]
+                    for i in range(16):
+                        db[i] += float(A[i][0].sum()) + float(A[i][1].sum())
+                        for j in range(16):
+                            C[i, j] += float(A[i][0] @ B[j][1]) + float(A[i][1] @ B[j][0]) + float(A[i][0] @ B[j][0])
+            ref = sum(dY[a][:, 16 * n:16 * n + 16].astype(np.float64).T @ X[a][:, 16 * m:16 * m + 16].astype(np.float64)
+                      for a in range(areas))
+            worst = max(worst, float(np.abs(C - ref).max() / np.abs(ref).max()))
+            dref = sum(dY[a][:, 16 * n:16 * n + 16].astype(np.float64).sum(0) for a in range(areas))
+            assert np.abs(db - dref).max() <= 1e-4 * np.abs(dref).max(), (n, m)
+    print(f"max |err| / max |dW| over the 16 output tiles (128 points): {worst:.2e}")
+    assert worst < 1e-4
+    print("layout OK")
+
+
+if __name__ == "__main__":
+    main()
