@@ -136,6 +136,9 @@ class Trainer:
         self.runner = None
         self.defer = False
         self.opt_parallel = True  # False: the deferred Adam runs on the main stream (per-kernel timing)
+        # False: the jitter buffer of the runner is filled by the caller before every iteration (parity tests inject the
+        # draws the CPU oracle uses; the default draws them on the device inside the iteration, graph-safe Philox)
+        self.draw_jitter = True
         self._pending_main = False  # deferred schedule: the main-field Adam of the previous iteration is still to run
         if use_runner:  # explicit kernel schedule over static buffers (nerfstudio_amd/train_step.py); default
             from nerfstudio_amd.train_step import NerfactoTrainStep
@@ -207,7 +210,7 @@ class Trainer:
             # consumed on a step that does not update it (ray_samplers.py:590-599), so its 10 MB need no zero-fill then
             groups = ["fields", "proposal_networks"] if updated else ["fields"]
             self.arena.zero_grad(groups, skip=self.runner.written_params())
-            self.runner.forward_backward(updated)  # the two backward chains run as parallel branches
+            self.runner.forward_backward(updated, self.draw_jitter)  # the backward chains run as parallel branches
             return
         self._select_batch()
         self.arena.zero_grad()
@@ -240,7 +243,7 @@ class Trainer:
             a.step(grad_scale=1.0, groups=["fields"], hyper_dev=self.hyper_views)
         self._select_batch()
         r.apply_camera_corrections()
-        r.forward_proposals(need_enc=updated)
+        r.forward_proposals(self.draw_jitter, need_enc=updated)
         if beside:
             main.wait_event(self._opt_join)
         groups = ["fields", "proposal_networks"] if updated else ["fields"]
@@ -282,7 +285,7 @@ class Trainer:
         r, a = self.runner, self.arena
         if name == "pfwd":
             self._select_batch()
-            r.forward_proposals()
+            r.forward_proposals(self.draw_jitter)
         elif name in (("main", True), ("main", False)):
             a.zero_grad(["fields"], skip=r.written_params())
             r.forward_main_and_losses(name[1])
@@ -345,19 +348,26 @@ class Trainer:
         self._optimise(updated)
 
     # -- graph capture ---------------------------------------------------------------------------------------------
-    def capture(self):
+    def warm_variants(self):
+        """One eager iteration of each schedule variant (proposal networks updated / not) on a side stream — allocator and
+        lazy-attribute warm-up ahead of a capture. They are real training iterations (parameters and Adam state move) that
+        do not advance the step counter; an eager run that is to train through the same states as a captured one calls
+        this at the same point (tests/test_gpu_bench_parity.py)."""
         torch.cuda.synchronize()
         assert not self._have_pending
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # allocator / autograd warm-up of both variants on a side stream
-            defer, self.defer = self.defer, False  # (these two iterations do not advance the step counter: run them in
-            for upd in (True, False):              # order, so that every schedule trains through the same states)
+        with torch.cuda.stream(side):
+            defer, self.defer = self.defer, False  # (in order, so that every schedule trains through the same states)
+            for upd in (True, False):
                 self._eager_iteration(upd)
             self.finish()
             self.defer = defer
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+
+    def capture(self):
+        self.warm_variants()
         graphs = {}
         if self.pipelined:
             from nerfstudio_amd.dp_schedule import SEGMENTS
@@ -462,10 +472,11 @@ def algorithmic_model(key):
         return "mfma", M_main * 2 * 11392  # MACs/sample: 32*64 + 64*16 + 63*64 + 64*64 + 64*3  
     if key == "nsamd_field_fused_fwd":
         return "hbm", M_main * 16 * 8 * 8  # hash gathers (the bound of the fused launch; its MLP half is 4.5 GFLOP of MFMA)
-    if key == "nsamd_field_mlp_bwd":
-        return "mfma", M_main * 2 * 11392 * 3  # recompute + data gradient + weight gradient
-    if key == "nsamd_field_mlp_bwd_saved":
-        return "mfma", M_main * 2 * 11392 * 2  # data gradient + weight gradient (activations loaded, not recomputed)
+    if key in ("nsamd_field_mlp_bwd", "nsamd_field_mlp_bwd_saved"):
+        # training = 3x the forward FLOPs, the forward launch takes 1x, so the backward's ALGORITHMIC share is
+        # 2x (data gradient + weight gradient). The recompute of the forward inside nsamd_field_mlp_bwd is executed work,
+        # not algorithmic work: it is reported separately (`executed_per_launch`), never in `achieved` / `frac`.
+        return "mfma", M_main * 2 * 11392 * 2
     m2 = re.search(r"\[M=(\d+)\]", key)
     if key.startswith("nsamd_density_mlp_fwd") and m2:
         return "hbm", int(m2.group(1)) * (10 * 4 + 4 + 8)  # enc row + selector in, density + pre out
@@ -474,6 +485,22 @@ def algorithmic_model(key):
     if key == "nsamd_adam_step":
         return "hbm", None  # filled in by the caller (arena size x 28 B)
     return None, None
+
+
+# flops / bytes a launch actually executes where that differs from the algorithmic figure (reported next to it)
+EXECUTED_PER_LAUNCH = {"nsamd_field_mlp_bwd": RAYS_PER_GPU * 48 * 2 * 11392 * 3}  # + the forward recompute
+
+# entry point -> the kernel name rocprofv3 --kernel-trace --stats lists for it (profiles/*_kernel_stats.csv)
+ROCPROF_KERNEL = {
+    "nsamd_field_mlp_bwd": "nsamd::field_mlp_bwd_kernel",
+    "nsamd_field_mlp_bwd_saved": "nsamd::field_mlp_bwd_kernel (saved activations)",
+    "nsamd_field_mlp_fwd": "nsamd::field_mlp_fwd_kernel",
+    "nsamd_hashgrid_encode_fwd": "nsamd::hash_encode_fwd_kernel",
+    "nsamd_hashgrid_encode_bwd_set": "nsamd::scatter_route_fine_kernel + nsamd::scatter_apply_kernel + nsamd::scatter_finish_kernel",
+    "nsamd_hashgrid_encode_bwd": "nsamd::scatter_route_* + nsamd::scatter_apply_kernel + nsamd::scatter_finish_kernel",
+    "nsamd_hashgrid_encode_bwd_gated": "nsamd::scatter_route_* + nsamd::scatter_apply_kernel + nsamd::scatter_finish_kernel",
+    "nsamd_adam_step": "nsamd::adam_kernel",
+}
 
 
 def kernel_sources_hash():
@@ -543,9 +570,14 @@ def measure_roofline(trainer, arena, steps):
             ach, peak, unit = top["work"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
             ach, peak, unit = top["work"] / sec / 1e12, F32_MFMA_PEAK_TFLOPS, "TFLOP/s"
+        base = top["kernel"].split("[")[0]
         roof = {"bound": top["bound"], "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
                 "traffic": pmc_traffic(top["kernel"]), "kernel": top["kernel"], "avg_launch_ms": round(top["mean_ms"], 4),
-                "algorithmic_per_launch": top["work"]}
+                "algorithmic_per_launch": top["work"], "rocprof_kernel": ROCPROF_KERNEL.get(base)}
+        if base in EXECUTED_PER_LAUNCH:  # the utilisation view (work the launch executes, incl. recomputation)
+            ex = EXECUTED_PER_LAUNCH[base]
+            roof["executed_per_launch"] = ex
+            roof["executed_frac"] = round(ex / sec / (1e9 if top["bound"] == "hbm" else 1e12) / peak, 4)
     return roof, table
 
 
@@ -699,6 +731,9 @@ def main():
                     help="N = 1 only: run the data-parallel schedule (pipelined exchange, compact table prefix, async "
                          "all-reduce on the communication stream) over a ONE-rank RCCL communicator — exercises the N > 1 "
                          "code path on a single-GPU box; the losses must equal the plain N = 1 run")
+    ap.add_argument("--param-checksum", action="store_true",
+                    help="add sha256 digests of the parameter arena and both Adam moments to config (bit-equality checks "
+                         "between schedule variants across processes)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: check the launch plumbing (RANK / WORLD_SIZE / MASTER_* env, process group, the pipelined "
                          "exchange with the compact table prefix over gloo) and print the JSON skeleton")
@@ -779,6 +814,12 @@ def main():
         elapsed = float(t.item())
     loss = trainer.last_loss()
     assert bool(torch.isfinite(loss)), "training diverged"
+    checksum = None
+    if args.param_checksum and rank == 0:  # state right after the timed region (before the profiling iterations)
+        import hashlib
+
+        checksum = {name: hashlib.sha256(t.detach().cpu().numpy().tobytes()).hexdigest()[:32]
+                    for name, t in (("params", arena.flat), ("exp_avg", arena.exp_avg), ("exp_avg_sq", arena.exp_avg_sq))}
     if getattr(trainer, "_seg_times", None) and rank == 0:
         for k, v in trainer._seg_times.items():
             print(f"[dp-timing] {k:16s} n={len(v):4d} median {sorted(v)[len(v) // 2]:9.3f} ms  max {max(v):9.3f} ms", file=sys.stderr)
@@ -829,6 +870,11 @@ def main():
         }
         if args.start_step:
             out["config"]["start_step"] = args.start_step
+        if checksum is not None:
+            out["config"]["param_checksum"] = checksum
+        if world > 1 or args.force_dp:  # what the process group itself reports (not the --gpus argument)
+            out["config"]["rccl_ranks"] = dist.get_world_size()
+            out["config"]["dist_backend"] = dist.get_backend()
         if args.force_dp:
             out["config"]["force_dp"] = "data-parallel schedule over a one-rank RCCL communicator (rehearsal of the N > 1 path)"
         if world == 1 and not args.no_cpu_baseline:

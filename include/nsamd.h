@@ -117,6 +117,31 @@ int nsamd_hashgrid_encode_bwd_rays(nsamd_points pts, int64_t M, int transform, n
                                    nsamd_grid grid, const float* denc, int64_t stride_p, int64_t stride_k,
                                    float* d_origins, float* d_directions, int accumulate, nsamd_stream_t stream);
 
+/* ---- zero-gradient gating of a proposal level's backward chain ---------------------------------------------------
+ * The proposal networks receive gradient only through interlevel_loss (model_components/losses.py:113-131; the main
+ * weights are detached, :119-120), and that loss is zero wherever the proposal histogram already bounds the main
+ * weights (lossfun_outer, :85-102: clip(w - w_outer, min=0)) — on the benchmark configuration the 256-sample level
+ * receives NO gradient at all during the first steps and the 96-sample level on 1-2 % of its samples
+ * (profiles/r02_study_proposal_sparsity.txt). autograd still runs the whole chain on zeros
+ * (ray_samplers.py:590-609 -> get_weights backward -> density field backward -> index_put). Here:
+ *   nsamd_weights_bwd_gate      computes dL/d density as nsamd_weights_bwd does and RAISES *gate (a uint32 in device
+ *                               memory, cleared on the stream by the call itself) when any ray carries gradient —
+ *                               a non-zero or NaN upstream gradient, or a NaN / Inf / negative optical thickness;
+ *   nsamd_density_mlp_bwd_gated, nsamd_hashgrid_encode_bwd_gated, nsamd_hashgrid_encode_bwd_rays_gated
+ *                               return at once while *gate == 0: every value they would add is an exact zero
+ *                               (finite parameters assumed), so the zero-filled gradients ARE the result. `denc` is
+ *                               then not written and not read. With the gate raised they do what their ungated
+ *                               forms do, bit for bit.
+ * The gated scatter accumulates (the caller zero-fills dtable), needs the binned workspace and takes no dpositions. */
+int nsamd_hashgrid_encode_bwd_gated(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
+                                    nsamd_grid grid, const float* denc, int64_t stride_p, int64_t stride_k,
+                                    float* dtable, float* workspace, int64_t workspace_floats, const uint32_t* gate,
+                                    nsamd_stream_t stream);
+int nsamd_hashgrid_encode_bwd_rays_gated(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb,
+                                         const float* table, nsamd_grid grid, const float* denc, int64_t stride_p,
+                                         int64_t stride_k, float* d_origins, float* d_directions, int accumulate,
+                                         const uint32_t* gate, nsamd_stream_t stream);
+
 /* Words of scratch the binned scatter of nsamd_hashgrid_encode_bwd (write_only = 0) / nsamd_hashgrid_encode_bwd_set
  * (write_only = 1) wants for (grid, M); 0 when that path does not apply (M <= 0 or an unsupported grid). Host-only,
  * no device work. */
@@ -182,6 +207,16 @@ int nsamd_density_field_fwd(nsamd_points pts, int64_t M, int transform, nsamd_aa
 int nsamd_density_mlp_bwd(const float* enc, const float* selector, const float* pre, const float* ddensity,
                           int64_t M, nsamd_density_mlp mlp, float* denc, float* dW0, float* db0, float* dW1,
                           float* db1, float* workspace, int64_t workspace_floats, nsamd_stream_t stream);
+
+/* Gated form (see "zero-gradient gating" above). Also folds the fixed-order sum of the per-workgroup partial rows into
+ * the launch (the last workgroup to arrive adds them up: same order, same bits as the follow-up reduce launch of the
+ * ungated form). workspace: nsamd_density_mlp_bwd_gated_workspace(in_dim, hidden) floats whose LAST 4 words (the
+ * arrival ticket) must be zero before the first call (every call leaves them zero). */
+int64_t nsamd_density_mlp_bwd_gated_workspace(int32_t in_dim, int32_t hidden);
+int nsamd_density_mlp_bwd_gated(const float* enc, const float* selector, const float* pre, const float* ddensity,
+                                int64_t M, nsamd_density_mlp mlp, float* denc, float* dW0, float* db0, float* dW1,
+                                float* db1, float* workspace, int64_t workspace_floats, const uint32_t* gate,
+                                nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * nerfacto main field head (NerfactoField.get_density + get_outputs, fields/nerfacto_field.py:203-310):
@@ -292,6 +327,9 @@ int nsamd_weights_fwd(const float* t_bins, const float* density, int64_t num_ray
                       nsamd_stream_t stream);
 int nsamd_weights_bwd(const float* t_bins, const float* density, const float* dweights, int64_t num_rays,
                       int32_t S, float* ddensity, nsamd_stream_t stream);
+/* The same, and *gate_out = (any ray carries gradient) — see "zero-gradient gating" under the hash encoding. */
+int nsamd_weights_bwd_gate(const float* t_bins, const float* density, const float* dweights, int64_t num_rays,
+                           int32_t S, float* ddensity, uint32_t* gate_out, nsamd_stream_t stream);
 
 /* PDFSampler.generate_ray_samples (ray_samplers.py:276-372) preceded by the anneal pow(weights, anneal)
  * (ray_samplers.py:601; skipped when anneal == 1). include_original = 0: s_bins / t_bins are [num_rays, S+1] (the

@@ -38,10 +38,16 @@ class CameraOptimizer(nn.Module):
             raise ValueError(f"unknown camera optimizer mode {config.mode!r}")
         self.config = config
         self.num_cameras = num_cameras
-        self.device = device
+        self._init_device = device  # where the parameter is created; `device` below follows `.to()`
         self.non_trainable_camera_indices = non_trainable_camera_indices
         if config.mode != "off":
             self.pose_adjustment = torch.nn.Parameter(torch.zeros((num_cameras, 6), device=device))
+
+    @property
+    def device(self):
+        """The device the corrections live on: the parameter's (a stored constructor argument goes stale after `.to()`)."""
+        p = getattr(self, "pose_adjustment", None)
+        return p.device if p is not None else torch.device(self._init_device)
 
     def forward(self, indices: Tensor) -> Tensor:
         """`[n]` camera indices -> `[n,3,4]` corrections (optimised camera -> given camera coordinates)."""

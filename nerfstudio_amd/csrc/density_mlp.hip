@@ -128,7 +128,11 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ pre,
     const float* __restrict__ ddensity, int64_t M, nsamd_density_mlp mlp, float* __restrict__ denc,
     float* __restrict__ dW0, float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1,
-    float* __restrict__ partials) {
+    float* __restrict__ partials, uint32_t* __restrict__ ticket, const uint32_t* __restrict__ gate) {
+  // Gated call (nsamd_density_mlp_bwd_gated): the flag nsamd_weights_bwd_gate raises when any ray of the level carries
+  // gradient is clear -> every upstream gradient is an exact zero, so are all results of this launch; the zero-filled
+  // weight gradients stay as they are and nothing downstream (gated the same way) reads `denc`.
+  if (gate != nullptr && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
   constexpr int LD = kMlpBlock + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* gh_T = lds;            // [H][LD]   dL/d(hidden pre-activation) per point
@@ -145,11 +149,14 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
     const int j = e / INP, k = e - j * INP;
     w0s[e] = k < IN ? mlp.W0[j * IN + k] : 0.0f;
   }
+  bool w_finite = true;  // a non-finite weight turns a zero gradient into NaN: such a network never skips a chunk
+  for (int e = threadIdx.x; e < H * INP; e += kMlpBlock) w_finite = w_finite && fabsf(w0s[e]) <= 3.4028234663852886e38f;
   for (int e = threadIdx.x; e < H; e += kMlpBlock) {
     b0s[e] = mlp.b0[e];
     w1s[e] = mlp.W1[e];
+    w_finite = w_finite && fabsf(b0s[e]) <= 3.4028234663852886e38f && fabsf(w1s[e]) <= 3.4028234663852886e38f;
   }
-  __syncthreads();
+  const bool may_skip = __syncthreads_and(w_finite) != 0;
 
   typedef float v4f __attribute__((ext_vector_type(4)));
   constexpr int NT = H / 16;  // row tiles of dW0
@@ -184,6 +191,23 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
     // d density / d pre = avg * sel * exp(clamp(pre, -15, 15))            (activations.py:39-42)
     const float g_pre =
         live ? gd_next * sel_next * mlp.average_init_density * expf(fminf(fmaxf(pre_next, -15.0f), 15.0f)) : 0.0f;
+    // A chunk whose 256 points all have a zero upstream gradient (finite weights and features) adds exact zeros to
+    // every sum: only its zero feature gradients are written (the table scatter reads them), nothing is recomputed.
+    // `g_pre != 0` is true for NaN: a non-finite gradient is never skipped. (The interlevel loss reaches 1-2 % of the
+    // second proposal level's samples, profiles/r02_study_proposal_sparsity.txt.)
+    {
+      bool carries = g_pre != 0.0f || !may_skip;
+#pragma unroll
+      for (int k = 0; k < IN; ++k) carries = carries || !(fabsf(x[k]) <= 3.4028234663852886e38f);
+      if (!__syncthreads_or(carries)) {
+        if (live) {
+#pragma unroll
+          for (int k = 0; k < IN; ++k) denc[(int64_t)k * M + p] = 0.0f;
+        }
+        fetch(c + gridDim.x);
+        continue;
+      }
+    }
     float dx[IN];
 #pragma unroll
     for (int k = 0; k < IN; ++k) dx[k] = 0.0f;
@@ -247,11 +271,66 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
     __syncthreads();
   }
   if (partials != nullptr) {
-    // one row of partial sums per workgroup, [dW0 (H x IN) | db0 (H) | dW1 (H) | db1]: density_dw_reduce_kernel adds the
-    // rows up in a fixed order, so the weight gradients are bit-reproducible (float atomics are not)
-    float* row = partials + (size_t)blockIdx.x * density_partial_stride(IN, H);
-    for (int e = threadIdx.x; e < H * IN; e += kMlpBlock) row[e] = red[(e / IN) * 16 + (e % IN)];
-    if (threadIdx.x < 2 * H + 1) row[H * IN + threadIdx.x] = accV;
+    // one row of partial sums per workgroup, [dW0 (H x IN) | db0 (H) | dW1 (H) | db1], added up in a fixed order, so the
+    // weight gradients are bit-reproducible (float atomics are not)
+    constexpr int stride = density_partial_stride(IN, H);
+    float* row = partials + (size_t)blockIdx.x * stride;
+    if (ticket == nullptr) {  // summed by a following density_dw_reduce_kernel launch
+      for (int e = threadIdx.x; e < H * IN; e += kMlpBlock) row[e] = red[(e / IN) * 16 + (e % IN)];
+      if (threadIdx.x < 2 * H + 1) row[H * IN + threadIdx.x] = accV;
+      return;
+    }
+    // ... or by the LAST workgroup of this launch to arrive (no 4-workgroup follow-up launch that has to wait for room
+    // beside the full-chip kernels of the other backward chains: it averaged 104 us of queueing in the replayed graph,
+    // profiles/r02_final_rocprofv3_kernel_stats.csv). Hand-off as MI355X_MICROARCH.md prescribes: write-through (sc1)
+    // stores of the row, drained, then the arrival ticket; the reader uses sc1 loads (L1 is never refreshed by other CUs).
+    for (int e = threadIdx.x; e < H * IN; e += kMlpBlock)
+      __hip_atomic_store(row + e, red[(e / IN) * 16 + (e % IN)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 2 * H + 1)
+      __hip_atomic_store(row + H * IN + threadIdx.x, accV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ uint32_t arrived;
+    if (threadIdx.x == 0) arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (arrived != gridDim.x - 1) return;
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-cleaning
+    // same summation order as density_dw_reduce_kernel (16 row groups per element, rows grp, grp + 16, ... in order,
+    // then the 16 group sums in order): the two forms give the same bits
+    constexpr int total = H * IN + 2 * H + 1;
+    float* part = lds;  // [kDwGroups][64]
+    const int rows = (int)gridDim.x;
+    const int el = threadIdx.x & 63, q4 = threadIdx.x >> 6;
+    for (int e0 = 0; e0 < total; e0 += 64) {
+      const int e = e0 + el;
+      __syncthreads();
+      for (int grp = q4; grp < 16; grp += kMlpBlock / 64) {
+        float sgrp = 0.f;
+        if (e < total) {
+          for (int b0i = grp; b0i < rows; b0i += 16 * 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              const int b = b0i + u * 16;
+              v[u] = b < rows ? __hip_atomic_load(partials + (size_t)b * stride + e, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT)
+                              : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) sgrp += v[u];
+          }
+        }
+        part[grp * 64 + el] = sgrp;
+      }
+      __syncthreads();
+      if (q4 == 0 && e < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) t += part[g2 * 64 + el];
+        float* dst = e < H * IN ? dW0 + e : (e < H * IN + H ? db0 + (e - H * IN) : (e < H * IN + 2 * H ? dW1 + (e - H * IN - H) : db1));
+        *dst += t;
+      }
+    }
     return;
   }
   for (int e = threadIdx.x; e < H * IN; e += kMlpBlock) unsafeAtomicAdd(dW0 + e, red[(e / IN) * 16 + (e % IN)]);
@@ -309,7 +388,7 @@ static int launch_fwd(const float* enc, const float* selector, int64_t M, nsamd_
 template <int IN, int H>
 static int launch_bwd(const float* enc, const float* selector, const float* pre, const float* ddensity, int64_t M,
                       nsamd_density_mlp mlp, float* denc, float* dW0, float* db0, float* dW1, float* db1,
-                      float* workspace, int64_t workspace_floats, hipStream_t stream) {
+                      float* workspace, int64_t workspace_floats, const uint32_t* gate, hipStream_t stream) {
   const unsigned blocks = (unsigned)min((int64_t)kMaxBlocks, (M + kMlpBlock - 1) / kMlpBlock);
   const size_t lds = sizeof(float) * ((size_t)(2 * H + IN + 1) * (kMlpBlock + 1) + 8 + (size_t)H * (((IN + 3) & ~3) + 2));
   if (lds > 64 * 1024) {  // per-device opt-in; cheap enough to repeat
@@ -319,10 +398,17 @@ static int launch_bwd(const float* enc, const float* selector, const float* pre,
   }
   constexpr int stride = density_partial_stride(IN, H);
   float* partials = (workspace != nullptr && workspace_floats >= (int64_t)blocks * stride) ? workspace : nullptr;
+  // Gated calls (the training step's) own a zero-initialised arrival ticket in the 4 words after the partial rows: the
+  // last workgroup sums the rows. Ungated calls keep the follow-up reduce launch (any scratch contents are fine).
+  uint32_t* ticket = nullptr;
+  if (gate != nullptr) {
+    NSAMD_REQUIRE(partials != nullptr && workspace_floats >= (int64_t)kMaxBlocks * stride + 4);
+    ticket = reinterpret_cast<uint32_t*>(workspace + (size_t)kMaxBlocks * stride);
+  }
   density_mlp_bwd_kernel<IN, H><<<blocks, kMlpBlock, lds, stream>>>(enc, selector, pre, ddensity, M, mlp, denc, dW0,
-                                                                   db0, dW1, db1, partials);
+                                                                   db0, dW1, db1, partials, ticket, gate);
   NSAMD_CHECK_LAUNCH();
-  if (partials != nullptr) {
+  if (partials != nullptr && ticket == nullptr) {
     const int total = H * IN + 2 * H + 1;
     density_dw_reduce_kernel<<<(total + 63) / 64, 64 * kDwGroups, 0, stream>>>(partials, (int)blocks, stride, H * IN, H,
                                                                              dW0, db0, dW1, db1);
@@ -395,7 +481,26 @@ extern "C" int nsamd_density_mlp_bwd(const float* enc, const float* selector, co
   NSAMD_REQUIRE(enc && pre && ddensity && denc && dW0 && db0 && dW1 && db1 && mlp.W0 && mlp.b0 && mlp.W1 && mlp.b1);
 #define CALL(IN, H)                                                                                          \
   launch_bwd<IN, H>(enc, selector, pre, ddensity, M, mlp, denc, dW0, db0, dW1, db1, workspace, workspace_floats, \
-                    (hipStream_t)stream)
+                    nullptr, (hipStream_t)stream)
+  NSAMD_DENSITY_DISPATCH(CALL)
+#undef CALL
+}
+
+extern "C" int64_t nsamd_density_mlp_bwd_gated_workspace(int32_t in_dim, int32_t hidden) {
+  if (in_dim <= 0 || hidden <= 0) return 0;
+  return (int64_t)kMaxBlocks * density_partial_stride(in_dim, hidden) + 4;
+}
+
+extern "C" int nsamd_density_mlp_bwd_gated(const float* enc, const float* selector, const float* pre,
+                                           const float* ddensity, int64_t M, nsamd_density_mlp mlp, float* denc,
+                                           float* dW0, float* db0, float* dW1, float* db1, float* workspace,
+                                           int64_t workspace_floats, const uint32_t* gate, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(M >= 0 && gate != nullptr);
+  if (M == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(enc && pre && ddensity && denc && dW0 && db0 && dW1 && db1 && mlp.W0 && mlp.b0 && mlp.W1 && mlp.b1);
+#define CALL(IN, H)                                                                                          \
+  launch_bwd<IN, H>(enc, selector, pre, ddensity, M, mlp, denc, dW0, db0, dW1, db1, workspace, workspace_floats, \
+                    gate, (hipStream_t)stream)
   NSAMD_DENSITY_DISPATCH(CALL)
 #undef CALL
 }

@@ -101,7 +101,8 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
                                                                const float* __restrict__ density,
                                                                const float* __restrict__ dweights,
                                                                int64_t num_rays, int S,
-                                                               float* __restrict__ ddensity) {
+                                                               float* __restrict__ ddensity,
+                                                               uint32_t* __restrict__ gate_out) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -113,6 +114,23 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
   const float* tb = t_bins + ray * (S + 1);
   const float* dn = density + ray * S;
   const float* dw = dweights + ray * S;
+  {
+    // A ray whose weights carry no gradient: with every optical thickness dt * density in [0, FLT_MAX] all forward
+    // values are finite, so dL/d density = dt * (0 * T * e - 0) = dt * 0 for every sample — no scans needed. Anything
+    // else (a non-zero or NaN upstream gradient, a NaN / Inf / negative thickness) keeps the full path: 0 * NaN must
+    // stay NaN as in autograd. The interlevel loss reaches few rays (profiles/r02_study_proposal_sparsity.txt).
+    bool carries = false;
+    for (int i = lane; i < S; i += 64) {
+      const float dd = (tb[i + 1] - tb[i]) * dn[i];
+      carries = carries || dw[i] != 0.0f || !(dd >= 0.0f && dd <= 3.4028234663852886e38f);
+    }
+    if (__ballot(carries) == 0ull) {
+      for (int i = lane; i < S; i += 64) ddensity[ray * S + i] = (tb[i + 1] - tb[i]) * 0.0f;
+      return;
+    }
+    // some ray of this launch carries gradient: the rest of the level's backward chain has work to do
+    if (gate_out != nullptr && lane == 0) __hip_atomic_store(gate_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   double carry = 0.0;
   for (int i0 = 0; i0 < S; i0 += 64) {
     const int i = i0 + lane;
@@ -368,17 +386,32 @@ extern "C" int nsamd_weights_fwd(const float* t_bins, const float* density, int6
   return NSAMD_OK;
 }
 
-extern "C" int nsamd_weights_bwd(const float* t_bins, const float* density, const float* dweights,
-                                 int64_t num_rays, int32_t S, float* ddensity, nsamd_stream_t stream) {
+static int weights_bwd_launch(const float* t_bins, const float* density, const float* dweights, int64_t num_rays,
+                              int32_t S, float* ddensity, uint32_t* gate_out, nsamd_stream_t stream) {
   NSAMD_REQUIRE(num_rays >= 0 && S > 0);
+  if (gate_out != nullptr &&  // cleared on the stream ahead of the launch (a memset node inside a captured graph)
+      hipMemsetAsync(gate_out, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
+    return NSAMD_ERR_LAUNCH;
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(t_bins && density && dweights && ddensity);
   if (S > 1024) return NSAMD_ERR_UNSUPPORTED;
   const size_t lds = sizeof(float) * 3 * kWaves * (size_t)S;
   weights_bwd_kernel<<<ray_blocks(num_rays), kThreads, lds, (hipStream_t)stream>>>(t_bins, density, dweights,
-                                                                                   num_rays, S, ddensity);
+                                                                                   num_rays, S, ddensity, gate_out);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
+}
+
+extern "C" int nsamd_weights_bwd(const float* t_bins, const float* density, const float* dweights,
+                                 int64_t num_rays, int32_t S, float* ddensity, nsamd_stream_t stream) {
+  return weights_bwd_launch(t_bins, density, dweights, num_rays, S, ddensity, nullptr, stream);
+}
+
+extern "C" int nsamd_weights_bwd_gate(const float* t_bins, const float* density, const float* dweights,
+                                      int64_t num_rays, int32_t S, float* ddensity, uint32_t* gate_out,
+                                      nsamd_stream_t stream) {
+  NSAMD_REQUIRE(gate_out != nullptr);
+  return weights_bwd_launch(t_bins, density, dweights, num_rays, S, ddensity, gate_out, stream);
 }
 
 extern "C" int nsamd_pdf_resample(const float* s_bins_prev, const float* weights, int32_t S_prev,

@@ -99,9 +99,10 @@ struct ScatterPlan {
 // Host: geometry for (grid, M); `max_spill` = true sizes the spill list for the worst case (write-only calls).
 ScatterPlan scatter_plan(const nsamd_grid& grid, int64_t M, bool max_spill);
 
-// Host: enqueue route (pass 1) + apply (pass 2) + finish on `stream`. Returns an nsamd_status.
+// Host: enqueue route (pass 1) + apply (pass 2) + finish on `stream`. Returns an nsamd_status. `gate` (nullable, device):
+// accumulating calls only — while *gate == 0 all kernels return at once (the gradient being scattered is all zeros).
 int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsamd_aabb& aabb, const nsamd_grid& grid,
                    const float* denc, int64_t stride_p, int64_t stride_k, float* dtable, float* workspace,
-                   const ScatterPlan& plan, bool overwrite, hipStream_t stream);
+                   const ScatterPlan& plan, bool overwrite, const uint32_t* gate, hipStream_t stream);
 
 }  // namespace nsamd

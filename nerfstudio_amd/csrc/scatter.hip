@@ -34,6 +34,13 @@ NSAMD_PROBE_DEFINE(scatter)
 
 namespace nsamd {
 
+// Gated calls (nsamd_hashgrid_encode_bwd_gated): `gate` points at the flag nsamd_weights_bwd_gate raises when any ray
+// of the level carries gradient. While it is clear every value of `denc` would be an exact zero (it is not even
+// written), the accumulating scatter adds nothing, and all of its kernels return at once.
+__device__ __forceinline__ bool gate_is_clear(const uint32_t* gate) {
+  return gate != nullptr && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+}
+
 constexpr int kRunLen = 4;        // consecutive samples per thread in the run kernel
 constexpr int kRunThreads = 256;  // -> 1024 points per workgroup
 constexpr int kMaxLog2Bins = 10;  // pass-1 LDS counters: 3 x 4 levels x bins x 4 B <= 48 KiB
@@ -104,8 +111,10 @@ __device__ __forceinline__ PairHash pair_hash(const Cell& c, int q, uint32_t mas
 template <int kThreads, int kPts, int kLevels>
 __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
     nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
-    int64_t stride_p, int64_t stride_k, ScatterGeom G, LevelList levels, ScatterBufs buf) {
+    int64_t stride_p, int64_t stride_k, ScatterGeom G, LevelList levels, ScatterBufs buf,
+    const uint32_t* __restrict__ gate) {
   static_assert(kPts * kLevels * 4 <= 32, "overflow mask is 32 bits");
+  if (gate_is_clear(gate)) return;  // gated call with no gradient anywhere: nothing to route (see scatter_launch)
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   const int B = 1 << G.log2_bins;
   uint32_t* cnt = lds_u;               // [kLevels][B] records of this workgroup per tile
@@ -146,7 +155,16 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
       (void)normalise_position(transform, box, x[j], y[j], z[j]);
     }
   }
-  __syncthreads();
+  // A workgroup whose points carry no gradient at all (proposal levels: the interlevel loss reaches few samples,
+  // profiles/r02_study_proposal_sparsity.txt) has nothing to route: it skips the sweep and only publishes its zero
+  // segment counts. (`x != 0` is true for NaN: a non-finite gradient is never skipped.) The test rides on the barrier
+  // that was here anyway and adds no dependence to the loads above.
+  bool carries = false;
+#pragma unroll
+  for (int j = 0; j < kPts; ++j)
+#pragma unroll
+    for (int i = 0; i < kLevels; ++i) carries = carries || g0[j][i] != 0.0f || g1[j][i] != 0.0f;
+  const int any_gradient = __syncthreads_or(carries);
   PROBE_STAMP(0, 1);
   const uint32_t mask = (1u << grid.log2_table_size) - 1u;
   const int sl = G.slice_log2;
@@ -211,7 +229,7 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
     }
   };
 
-  sweep(std::integral_constant<int, 0>{});
+  if (any_gradient) sweep(std::integral_constant<int, 0>{});
   PROBE_STAMP(0, 2);
   const int any_over = __syncthreads_or(over != 0u);
   PROBE_STAMP(0, 3);
@@ -243,7 +261,9 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
 template <int kLevels>
 __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
     nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
-    int64_t stride_p, int64_t stride_k, ScatterGeom G, LevelList levels, ScatterBufs buf) {
+    int64_t stride_p, int64_t stride_k, ScatterGeom G, LevelList levels, ScatterBufs buf,
+    const uint32_t* __restrict__ gate) {
+  if (gate_is_clear(gate)) return;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   const int B = 1 << G.log2_bins;
   uint32_t* cnt = lds_u;
@@ -280,7 +300,17 @@ __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
       (void)normalise_position(transform, box, px[s], py[s], pz[s]);
     }
   }
-  __syncthreads();
+  // no gradient anywhere in this workgroup's samples: nothing to count, reserve or emit — and this kernel keeps no
+  // per-workgroup state in the workspace, so the workgroup may simply leave (the test rides on the barrier that was
+  // here anyway; `x != 0` is true for NaN)
+  {
+    bool carries = false;
+#pragma unroll
+    for (int s = 0; s < kRunLen; ++s)
+#pragma unroll
+      for (int i = 0; i < kLevels; ++i) carries = carries || g0[s][i] != 0.0f || g1[s][i] != 0.0f;
+    if (!__syncthreads_or(carries)) return;
+  }
   const uint32_t mask = (1u << grid.log2_table_size) - 1u;
   const int sl = G.slice_log2;
   const uint32_t local_mask = (1u << sl) - 1u;
@@ -406,22 +436,28 @@ __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
 // One workgroup per (level, tile): static segments, dynamic area and the folded part of the spill list are summed into
 // an LDS tile of 2 x int64 per entry; the finished tile is converted once and stored / added with coalesced accesses.
 __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs buf, float* __restrict__ dtable,
-                                     int overwrite) {
+                                     int overwrite, const uint32_t* __restrict__ gate) {
+  if (gate_is_clear(gate)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];  // [entries][2]
   const int bin = blockIdx.x, level = blockIdx.y;
   const uint32_t tile = ((uint32_t)level << G.log2_bins) + (uint32_t)bin;
   const int entries = 1 << G.slice_log2;
   PROBE_STAMP(0, 10);
-  {
-    uint4* z = reinterpret_cast<uint4*>(acc);
-    for (int e = threadIdx.x; e < entries; e += blockDim.x) z[e] = make_uint4(0u, 0u, 0u, 0u);
-  }
   const bool coarse = (G.coarse_mask >> level) & 1u;
   const uint32_t Q = G.level_cap[level], C = G.seg_cap;
   // headroom of the fixed-point sums: <= 2 summands per record (a pair whose corners coincide) over the queue and the
   // folded spill records; one more bit for the sign
   const int headroom = 2 + (32 - __clz((int)(Q + kSpillFold - 1u)));
   const FixedScale fs = fixed_scale(buf.hdr[level], headroom);
+  if (fs.empty && !overwrite) {
+    // an accumulating call and nothing (or only flushed denormals) recorded on this level: the tile stays as it is
+    if (threadIdx.x == 0) buf.dyn_cursor[tile] = 0u;
+    return;
+  }
+  {
+    uint4* z = reinterpret_cast<uint4*>(acc);
+    for (int e = threadIdx.x; e < entries; e += blockDim.x) z[e] = make_uint4(0u, 0u, 0u, 0u);
+  }
   const uint32_t static_end = coarse ? 0u : G.segs * C;
   const uint32_t n_dyn = min(buf.dyn_cursor[tile], Q - static_end);
   const uint32_t n_spill = min(min(buf.hdr[kHdrSpillCount], G.spill_cap), kSpillFold);
@@ -545,7 +581,9 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
 
 // After pass 2: spill records beyond the folded prefix (a pathological batch) are applied with float atomics — exact
 // sums, but in no fixed order, so they are counted; then the per-call header state goes back to zero.
-__global__ void scatter_finish_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs buf, float* __restrict__ dtable) {
+__global__ void scatter_finish_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs buf, float* __restrict__ dtable,
+                                      const uint32_t* __restrict__ gate) {
+  if (gate_is_clear(gate)) return;  // nothing was routed: the per-call state is still zero
   const uint32_t total = buf.hdr[kHdrSpillCount];  // (may exceed the capacity: the excess went out directly)
   const uint32_t n = min(total, G.spill_cap);
   for (uint32_t e = kSpillFold + blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
@@ -704,16 +742,17 @@ static ScatterBufs scatter_bufs(float* workspace, const ScatterPlan& p) {
 template <int kThreads, int kPts, int kLevels>
 static void launch_fine(const nsamd_points& pts, int64_t M, int transform, const nsamd_aabb& aabb, const nsamd_grid& grid,
                         const float* denc, int64_t stride_p, int64_t stride_k, const ScatterGeom& G,
-                        const LevelList& fine, const ScatterBufs& buf, hipStream_t st) {
+                        const LevelList& fine, const ScatterBufs& buf, const uint32_t* gate, hipStream_t st) {
   const size_t lds = sizeof(uint32_t) * (3 * (size_t)kLevels * ((size_t)1 << G.log2_bins) + kLevels);
   dim3 g1(G.segs, (unsigned)((fine.count + kLevels - 1) / kLevels));
   scatter_route_fine_kernel<kThreads, kPts, kLevels><<<g1, kThreads, lds, st>>>(pts, M, transform, aabb, grid, denc,
-                                                                                 stride_p, stride_k, G, fine, buf);
+                                                                                 stride_p, stride_k, G, fine, buf, gate);
 }
 
 int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsamd_aabb& aabb, const nsamd_grid& grid,
                    const float* denc, int64_t stride_p, int64_t stride_k, float* dtable, float* workspace,
-                   const ScatterPlan& plan, bool overwrite, hipStream_t st) {
+                   const ScatterPlan& plan, bool overwrite, const uint32_t* gate, hipStream_t st) {
+  if (gate != nullptr && overwrite) return NSAMD_ERR_INVALID_ARG;  // a write-only gradient must always be written
   ScatterGeom G = plan.geom;
   ScatterBufs buf = scatter_bufs(workspace, plan);
   buf.log2_table_size = grid.log2_table_size;
@@ -750,9 +789,9 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
     const FineShape s = fine_shape();
     const int code = s.threads * 100 + s.pts * 10 + s.levels;
     switch (code) {
-      case 51214: launch_fine<512, 1, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
-      case 102412: launch_fine<1024, 1, 2>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
-      default: launch_fine<1024, 1, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, st); break;
+      case 51214: launch_fine<512, 1, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, gate, st); break;
+      case 102412: launch_fine<1024, 1, 2>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, gate, st); break;
+      default: launch_fine<1024, 1, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, gate, st); break;
     }
     NSAMD_CHECK_LAUNCH();
   }
@@ -762,14 +801,14 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
     const int64_t per_block = (int64_t)kRunThreads * kRunLen;
     dim3 g1((unsigned)((M + per_block - 1) / per_block), (unsigned)((coarse.count + kL - 1) / kL));
     scatter_route_runs_kernel<kL><<<g1, kRunThreads, lds, st>>>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G,
-                                                              coarse, buf);
+                                                              coarse, buf, gate);
     NSAMD_CHECK_LAUNCH();
   }
   const unsigned threads = G.slice_log2 > 11 ? 1024u : (G.slice_log2 > 9 ? 512u : 256u);
   dim3 g2(1u << G.log2_bins, (unsigned)grid.num_levels);
-  scatter_apply_kernel<<<g2, threads, (size_t)16 << G.slice_log2, st>>>(grid, G, buf, dtable, overwrite ? 1 : 0);
+  scatter_apply_kernel<<<g2, threads, (size_t)16 << G.slice_log2, st>>>(grid, G, buf, dtable, overwrite ? 1 : 0, gate);
   NSAMD_CHECK_LAUNCH();
-  scatter_finish_kernel<<<32, 256, 0, st>>>(grid, G, buf, dtable);
+  scatter_finish_kernel<<<32, 256, 0, st>>>(grid, G, buf, dtable, gate);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

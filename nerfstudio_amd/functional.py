@@ -170,40 +170,60 @@ def field_bwd_workspace(device) -> Tuple[Tensor, int]:
 _SCATTER_WS_MAX = 8  # cached workspaces (least recently used ones are dropped: a main-table workspace is ~0.75 GB)
 
 
-DENSITY_WS_FLOATS = 1024 * 1092  # <= 1024 workgroups x (64 x 16 + 2 x 64 + 1 padded) partial sums
+# <= 1024 workgroups x (64 x 16 + 2 x 64 + 1, padded to 16 B) partial sums + the 4-word arrival ticket of the gated call
+DENSITY_WS_FLOATS = 1024 * 1156 + 4
 
 
 def density_bwd_workspace(device, slot: int = 0) -> Tensor:
-    """Scratch rows for the weight-gradient partials of nsamd_density_mlp_bwd (summed in a fixed order). One buffer per
-    (device, slot): calls that may overlap on different streams take different slots."""
+    """Scratch rows for the weight-gradient partials of nsamd_density_mlp_bwd[_gated] (summed in a fixed order). One
+    buffer per (device, slot): calls that may overlap on different streams take different slots. Zero-initialised: the
+    gated call keeps its arrival ticket behind the rows and leaves it at zero."""
     key = (str(device), "density", slot)
     ws = _FIELD_WS.get(key)
     if ws is None:
-        ws = torch.empty(DENSITY_WS_FLOATS, device=device, dtype=torch.float32)
+        ws = torch.zeros(DENSITY_WS_FLOATS, device=device, dtype=torch.float32)
         _FIELD_WS[key] = ws
     return ws
+
+
+_SCATTER_BUCKET = 1 << 16  # workspaces are sized for M rounded up to a multiple of this many points
 
 
 def _scatter_workspace(grid: HashGridSpec, device, num_points: int = 0, write_only: bool = False) -> Tuple[Optional[Tensor], int]:
     """Device scratch for the table-gradient scatter (csrc/scatter.hip): per (level, tile) a queue of 16-B records, the
     per-workgroup segment counts, a spill list. The library says how many words it wants
     (nsamd_hashgrid_encode_bwd_workspace) and how many leading words must start as zero (..._workspace_state: header +
-    cursors, a few KB — the kernels leave them at zero); the bulk is never initialised. Cached per (grid, M, device), at
-    most _SCATTER_WS_MAX entries. One workspace serves one call at a time: callers that overlap scatters on different
-    streams must use different (grid, M) keys or serialise (train_step does)."""
-    key = (grid, num_points, str(device), write_only)
+    cursors, a few KB that depend on the grid only — the kernels leave them at zero); the bulk is never initialised.
+    Cached per (grid, M rounded up to 64 k points, device): the packed instant-ngp path changes M every step
+    (occupancy-grid sampling, DynamicBatch), and a cache keyed by the exact M would allocate a fresh ~GB workspace per
+    step. A cached workspace serves every M of its bucket — the kernels lay the buffer out for the M of
+    the call — and is re-allocated only if the library asks for more words than it holds. At most _SCATTER_WS_MAX
+    entries; evicting one waits for the device first (a side-stream scatter may still be reading it). One workspace
+    serves one call at a time: callers that overlap scatters on different streams must use different (grid, bucket)
+    keys or serialise (train_step does)."""
+    bucket = max(1, -(-int(num_points) // _SCATTER_BUCKET)) * _SCATTER_BUCKET
+    key = (grid, bucket, str(device), write_only)
+    lib = N.load()
     ws = _SCATTER_WS.get(key)
     if ws is not None:
-        _SCATTER_WS[key] = _SCATTER_WS.pop(key)  # most recently used last
-        return ws, (ws.numel() if ws.numel() else 0)
-    lib = N.load()
-    words = int(lib.nsamd_hashgrid_encode_bwd_workspace(grid.native(), num_points, 1 if write_only else 0))
+        need = int(lib.nsamd_hashgrid_encode_bwd_workspace(grid.native(), num_points, 1 if write_only else 0)) \
+            if num_points != bucket else ws.numel()
+        if 0 < need <= ws.numel():
+            _SCATTER_WS[key] = _SCATTER_WS.pop(key)  # most recently used last
+            return ws, ws.numel()
+        if need <= 0:
+            return None, 0
+        torch.cuda.synchronize(device)  # (never seen: the plan grows with M) replace it by a larger one
+        _SCATTER_WS.pop(key)
+    words = max(int(lib.nsamd_hashgrid_encode_bwd_workspace(grid.native(), m, 1 if write_only else 0))
+                for m in {bucket, max(int(num_points), 1)})
     if words <= 0:
         return None, 0
     ws = torch.empty(words, device=device, dtype=torch.float32)
-    state = int(lib.nsamd_hashgrid_encode_bwd_workspace_state(grid.native(), num_points))
+    state = int(lib.nsamd_hashgrid_encode_bwd_workspace_state(grid.native(), bucket))
     ws[:state].zero_()
     while len(_SCATTER_WS) >= _SCATTER_WS_MAX:
+        torch.cuda.synchronize(device)  # no kernel on any stream may still be using the evicted buffer
         _SCATTER_WS.pop(next(iter(_SCATTER_WS)))
     _SCATTER_WS[key] = ws
     return ws, ws.numel()

@@ -45,8 +45,12 @@ class _FusedLosses(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):  # noqa: D102
         step: "FusedTrainStep" = ctx.step
-        if step.checks_left > 0:  # the kernels hold d(sum of the terms): verify the caller asked for exactly that
-            step.checks_left -= 1
+        # the kernels hold d(sum of the terms): verify the caller asked for exactly that — on the first iterations and
+        # then on every 64th backward (a host sync each; a GradScaler switched on at resume, a changed loss coefficient or a
+        # caller that back-propagates a single term must not pass silently for long)
+        step.backward_calls += 1
+        if step.checks_left > 0 or step.backward_calls % 64 == 0:
+            step.checks_left = max(step.checks_left - 1, 0)
             for g in grads:
                 if g is None or float(g) != 1.0:
                     raise RuntimeError("FusedTrainStep: the loss terms must be summed with unit weights before backward() "
@@ -62,7 +66,8 @@ class FusedTrainStep:
         self.model = model
         self.runner = None
         self.updated = False
-        self.checks_left = 3  # upstream-gradient checks cost a host sync each: only on the first iterations
+        self.checks_left = 3  # upstream-gradient checks cost a host sync each: the first iterations, then every 64th
+        self.backward_calls = 0
 
     def supported(self) -> Optional[str]:
         """None, or the reason this model has to stay on the module path."""
@@ -108,7 +113,12 @@ class FusedTrainStep:
     def get_loss_dict(self, outputs, batch) -> Dict[str, Tensor]:
         assert outputs.get("fused_step") is self, "outputs of another forward"
         r = self.runner
-        r.target.copy_(batch["image"].reshape(-1, 3))
+        # RGBA targets are blended with the renderer's background exactly as the reference does before the loss
+        # (models/nerfacto.py:377-381 -> renderers.py:150-170 blend_background); RGB targets pass through unchanged
+        image = batch["image"].to(r.target.device)
+        if image.shape[-1] == 4:
+            image = self.model.renderer_rgb.blend_background(image)
+        r.target.copy_(image.reshape(-1, 3))
         r.losses(self.updated)
         anchor = self.model.field.mlp_base.encoding.hash_table  # any parameter: makes autograd call backward
         loss_dict = dict(zip(_LOSS_KEYS, _FusedLosses.apply(anchor, self)))

@@ -14,7 +14,7 @@ reference model's attributes) without nerfstudio installed; `nerfacto_hip()` rai
 """
 from __future__ import annotations
 
-from typing import Any, Callable, List
+from typing import Any, Optional, Callable, List
 
 import numpy as np
 import torch
@@ -80,13 +80,17 @@ def install_hip_modules(model: Any) -> None:
     model.renderer_expected_depth = DepthRenderer(method="expected")
 
 
-def hip_loss_terms(model: Any, outputs: dict, loss_dict: dict) -> dict:
-    """The proposal losses of NerfactoModel.get_loss_dict (models/nerfacto.py:363-375) through the fused kernels."""
+def hip_loss_terms(model: Any, outputs: dict, loss_dict: dict, metrics_dict: Optional[dict] = None) -> dict:
+    """The proposal losses of NerfactoModel.get_loss_dict (models/nerfacto.py:363-375) through the fused kernels; the
+    distortion term is taken from `metrics_dict["distortion"]` when get_metrics_dict already evaluated it (as the
+    reference does, :374-375)."""
     from .model_components.losses import distortion_loss, interlevel_loss
 
     cfg = model.config
     loss_dict["interlevel_loss"] = cfg.interlevel_loss_mult * interlevel_loss(outputs["weights_list"], outputs["ray_samples_list"])
-    loss_dict["distortion_loss"] = cfg.distortion_loss_mult * distortion_loss(outputs["weights_list"], outputs["ray_samples_list"])
+    dist = metrics_dict["distortion"] if metrics_dict is not None and "distortion" in metrics_dict else \
+        distortion_loss(outputs["weights_list"], outputs["ray_samples_list"])
+    loss_dict["distortion_loss"] = cfg.distortion_loss_mult * dist
     return loss_dict
 
 
@@ -124,9 +128,20 @@ def _model_classes():
             return fused.get_outputs(ray_bundle) if fused is not None else super().get_outputs(ray_bundle)
 
         def get_loss_dict(self, outputs, batch, metrics_dict=None):
+            """models/nerfacto.py:363-392 with the proposal losses on the fused HIP kernels (the reference's torch
+            `interlevel_loss` builds [N,S,S] temporaries and ~20 eager launches per level)."""
             if "fused_step" in outputs:
                 return outputs["fused_step"].get_loss_dict(outputs, batch)
-            return super().get_loss_dict(outputs, batch, metrics_dict)
+            if not self.training or self.config.predict_normals:
+                return super().get_loss_dict(outputs, batch, metrics_dict)  # (normals: the reference's own extra terms)
+            loss_dict = {}
+            image = batch["image"].to(self.device)
+            pred_rgb, gt_rgb = self.renderer_rgb.blend_background_for_loss_computation(
+                pred_image=outputs["rgb"], pred_accumulation=outputs["accumulation"], gt_image=image)
+            loss_dict["rgb_loss"] = self.rgb_loss(gt_rgb, pred_rgb)
+            hip_loss_terms(self, outputs, loss_dict, metrics_dict)
+            self.camera_optimizer.get_loss_dict(loss_dict)
+            return loss_dict
 
         def get_metrics_dict(self, outputs, batch):
             from .model_components.losses import distortion_loss

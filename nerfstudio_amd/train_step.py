@@ -19,6 +19,7 @@ schedule variant and replayed. Numerically identical to the autograd path (tests
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -47,7 +48,9 @@ class NerfactoTrainStep:
         if cfg.background_color == "random":
             # the rendered colour carries no background; the loss blends `rand_like(pred) * (1 - accumulation)` into the
             # prediction (renderers.py:112-115, 194-196; models/nerfacto.py:377-381) — a per-ray colour the kernels read
-            self.bg_mode, self.bg_vals, self.bg_rays = 3, None, e(n, 3)
+            # (zero-initialised: callers that inject the jitter — `draw_jitter=False` — and no background of their own
+            # composite against black, never against uninitialised memory)
+            self.bg_mode, self.bg_vals, self.bg_rays = 3, None, torch.zeros((n, 3), **f32)
         else:
             self.bg_mode, self.bg_vals = F._bg_args(cfg.background_color, device)
             self.bg_rays = None
@@ -89,8 +92,6 @@ class NerfactoTrainStep:
         self.dw_prop = [e(n, self.counts[lvl]) for lvl in range(self.n_prop)]
         self.d_rgb_s, self.d_dens_main = e(mm, 3), e(mm)
         # host arrays of device pointers for nsamd_proposal_losses (the buffers are static, so built once)
-        import ctypes as C
-
         def parr(ts):
             return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
 
@@ -105,11 +106,15 @@ class NerfactoTrainStep:
         self.field_ws, _ = F.field_bwd_workspace(device)
         # one scratch per proposal level: their backward chains may run concurrently on different streams
         self.density_ws = [F.density_bwd_workspace(device, slot=lvl) for lvl in range(self.n_prop)]
+        # Zero-gradient gating of the proposal chains (include/nsamd.h): one device flag per level, raised by the level's
+        # weights backward when any ray carries interlevel-loss gradient; while it is clear the rest of the chain
+        # (density MLP backward, table scatter, ray gradients) returns at once — the zero-filled gradients are the result.
+        # NSAMD_GATE_PROPOSALS=0: the ungated entry points (A/B).
+        self.gate_proposals = os.environ.get("NSAMD_GATE_PROPOSALS", "1") == "1"
+        self.prop_gates = torch.zeros(max(self.n_prop, 1) * 4, device=device, dtype=torch.int32)  # 16 B apart
         # Optional (NSAMD_FIELD_SAVE_ACTS=1): the forward saves the main field's activations (896 B per sample) and the
         # backward loads them instead of recomputing the forward. Measured on MI355X: backward 186 -> 176 us but forward
         # 60 -> 76 us — the backward is bound by its workgroup barriers, not by the recomputed MFMAs — so off by default.
-        import os
-
         self.save_acts = os.environ.get("NSAMD_FIELD_SAVE_ACTS", "0") == "1"
         # One launch for hash grid + MLPs of the main field (nsamd_field_fused_fwd) — measured SLOWER than the two launches on
         # MI355X (155-160 us against 78 + 56): a wave that gathers all 16 levels at once loses the level-major sweep's L2
@@ -265,13 +270,17 @@ class NerfactoTrainStep:
         self.origins.copy_(o.detach())
         self.directions.copy_(d.detach())
 
-    def _rays_backward(self, lvl: int, net, denc: Tensor) -> None:
+    def _gate(self, lvl: int):
+        """Device address of proposal level `lvl`'s gradient flag (None: gating off)."""
+        return self.prop_gates.data_ptr() + 16 * lvl if self.gate_proposals else None
+
+    def _rays_backward(self, lvl: int, net, denc: Tensor, gate=None) -> None:
         """dL/d(origins, directions) of sampling level `lvl` from its encoded-feature gradient (on the current stream)."""
         lib, m = N.load(), self.n * self.counts[lvl]
         enc = net.mlp_base.encoding if hasattr(net.mlp_base, "encoding") else net.encoding
-        N.check(lib.nsamd_hashgrid_encode_bwd_rays(self._points(lvl), m, net._transform, net._box, N.ptr(enc.hash_table),
-                                                   enc.spec.native(), N.ptr(denc), 1, m, N.ptr(self.d_origins[lvl]),
-                                                   N.ptr(self.d_directions[lvl]), 0, N.stream()), "hashgrid_encode_bwd_rays")
+        N.check(lib.nsamd_hashgrid_encode_bwd_rays_gated(
+            self._points(lvl), m, net._transform, net._box, N.ptr(enc.hash_table), enc.spec.native(), N.ptr(denc), 1, m,
+            N.ptr(self.d_origins[lvl]), N.ptr(self.d_directions[lvl]), 0, gate, N.stream()), "hashgrid_encode_bwd_rays")
 
     def backward_cameras(self, updated: bool) -> None:
         """Per-ray gradients of every level that received one -> `pose_adjustment.grad` (plus the L2 regulariser of
@@ -474,22 +483,38 @@ class NerfactoTrainStep:
                 W0, b0, W1, b1 = mlp.param_tensors()
                 dm = N.DensityMlp(N.ptr(W0), N.ptr(b0), N.ptr(W1), N.ptr(b1), W0.shape[1], W0.shape[0],
                                   float(net.average_init_density))
-                ck(lib.nsamd_weights_bwd(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]), n, S,
-                                         N.ptr(self.p_ddens[lvl]), st), "weights_bwd")
+                gate = self._gate(lvl)
                 dws = self.density_ws[lvl]
-                ck(lib.nsamd_density_mlp_bwd(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]),
-                                             N.ptr(self.p_ddens[lvl]), m, dm, N.ptr(self.p_denc[lvl]), N.ptr(self._grad(W0)),
-                                             N.ptr(self._grad(b0)), N.ptr(self._grad(W1)), N.ptr(self._grad(b1)),
-                                             N.ptr(dws), dws.numel(), st),
-                   "density_mlp_bwd")
-                if self.cam_opt is not None:
-                    self._rays_backward(lvl, net, self.p_denc[lvl])
                 spec = net.encoding.spec
                 ws, ws_n = F._scatter_workspace(spec, self.f_enc.device, m)
-                ck(lib.nsamd_hashgrid_encode_bwd(self._points(lvl), m, net._transform, net._box,
-                                                 N.ptr(net.encoding.hash_table), spec.native(), N.ptr(self.p_denc[lvl]), 1, m,
-                                                 N.ptr(self._grad(net.encoding.hash_table)), None, N.ptr(ws), ws_n, st),
-                   "hashgrid_encode_bwd")
+                grads = (N.ptr(self._grad(W0)), N.ptr(self._grad(b0)), N.ptr(self._grad(W1)), N.ptr(self._grad(b1)))
+                if gate is None or ws is None:  # ungated chain (A/B switch, or no binned-scatter workspace for this shape)
+                    ck(lib.nsamd_weights_bwd(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]), n,
+                                             S, N.ptr(self.p_ddens[lvl]), st), "weights_bwd")
+                    ck(lib.nsamd_density_mlp_bwd(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]),
+                                                 N.ptr(self.p_ddens[lvl]), m, dm, N.ptr(self.p_denc[lvl]), *grads,
+                                                 N.ptr(dws), dws.numel(), st), "density_mlp_bwd")
+                    if self.cam_opt is not None:
+                        self._rays_backward(lvl, net, self.p_denc[lvl])
+                    ck(lib.nsamd_hashgrid_encode_bwd(self._points(lvl), m, net._transform, net._box,
+                                                     N.ptr(net.encoding.hash_table), spec.native(), N.ptr(self.p_denc[lvl]),
+                                                     1, m, N.ptr(self._grad(net.encoding.hash_table)), None, N.ptr(ws), ws_n,
+                                                     st), "hashgrid_encode_bwd")
+                    continue
+                # the weights backward raises the level's flag when any ray carries interlevel gradient; the rest of the
+                # chain returns at once while it is clear (the zero-filled gradients are then already the result)
+                ck(lib.nsamd_weights_bwd_gate(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]), n,
+                                              S, N.ptr(self.p_ddens[lvl]), gate, st), "weights_bwd_gate")
+                ck(lib.nsamd_density_mlp_bwd_gated(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]),
+                                                   N.ptr(self.p_ddens[lvl]), m, dm, N.ptr(self.p_denc[lvl]), *grads,
+                                                   N.ptr(dws), dws.numel(), gate, st), "density_mlp_bwd_gated")
+                if self.cam_opt is not None:
+                    self._rays_backward(lvl, net, self.p_denc[lvl], gate)
+                ck(lib.nsamd_hashgrid_encode_bwd_gated(self._points(lvl), m, net._transform, net._box,
+                                                       N.ptr(net.encoding.hash_table), spec.native(),
+                                                       N.ptr(self.p_denc[lvl]), 1, m,
+                                                       N.ptr(self._grad(net.encoding.hash_table)), N.ptr(ws), ws_n, gate,
+                                                       st), "hashgrid_encode_bwd_gated")
 
     # -------------------------------------------------------------------------------------------------------------
     def loss_dict(self) -> Dict[str, Tensor]:

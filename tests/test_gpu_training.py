@@ -259,7 +259,8 @@ def test_data_parallel_path_over_one_rank_rccl_matches_single_gpu():
 
     def run(*flags, **extra_env):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "14", "--warmup", "4", "--no-cpu-baseline",
-                            "--profile-steps", "1", *flags], capture_output=True, text=True, env=dict(env, **extra_env),
+                            "--profile-steps", "1", "--param-checksum", *flags], capture_output=True, text=True,
+                           env=dict(env, **extra_env),
                            timeout=600, cwd=root)
         assert r.returncode == 0, r.stderr[-3000:]
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -268,13 +269,19 @@ def test_data_parallel_path_over_one_rank_rccl_matches_single_gpu():
     dp = run("--force-dp")
     assert "force_dp" in dp["config"] and dp["n_gpus"] == 1
     assert dp["config"]["final_loss"] == plain["config"]["final_loss"], (dp["config"]["final_loss"], plain["config"]["final_loss"])
+    # ... and, stronger, at the same parameter and Adam-moment BITS (sha256 of the arenas right after the timed region)
+    assert dp["config"]["param_checksum"] == plain["config"]["param_checksum"]
+    assert dp["config"]["rccl_ranks"] == 1 and dp["config"]["dist_backend"] == "nccl"
     # Schedule variants of the N = 1 iteration must train through the same bits (same dependencies, different launch
     # order / streams): the main-field Adam of iteration k deferred beside the proposal forward of k + 1 (the default with
     # hipGraphs) and the field's weight-gradient reduce beside the table scatter (opt-in), launched eagerly ...
     deferred = run("--no-graph", NSAMD_DEFER_MAIN_ADAM="1", NSAMD_SPLIT_REDUCE="1")
     assert deferred["config"]["final_loss"] == plain["config"]["final_loss"]
+    assert deferred["config"]["param_checksum"] == plain["config"]["param_checksum"]
     # ... and replayed from captured hipGraphs (four variants: proposal update x pending Adam) against Adam in order.
     graph = run()
     in_order = run(NSAMD_DEFER_MAIN_ADAM="0")
     assert "4 captured variants" in graph["config"]["launch"] and "2 captured variants" in in_order["config"]["launch"]
     assert graph["config"]["final_loss"] == in_order["config"]["final_loss"]
+    assert graph["config"]["param_checksum"] == in_order["config"]["param_checksum"]
+    # (graph replay against EAGER launches, bit for bit, with injected jitter: tests/test_gpu_bench_parity.py)
