@@ -109,9 +109,12 @@ class Trainer:
     sequential semantics (every parameter is updated before its next use). `finish()` drains the pending update."""
 
     def __init__(self, model, arena, ray_bundle, batch, world=1, use_graph=True, use_runner=True, pool=None,
-                 force_dp=False):
+                 force_dp=False, dp_mode="allreduce"):
         self.model, self.arena, self.rb, self.batch, self.world = model, arena, ray_bundle, batch, world
         self.dp = world > 1 or force_dp  # force_dp: the data-parallel schedule with a one-rank communicator
+        # "sharded": reduce-scatter -> Adam on the rank's 1/N arena shard -> all-gather (dp_schedule.py); "allreduce": the
+        # replicated optimiser behind an all-reduce (the reference's DDP semantics, and the default)
+        self.dp_sharded = self.dp and dp_mode == "sharded"
         self.pool = pool  # BATCH_SLOTS pre-generated batches in HBM (None: one fixed batch)
         self.step = 0
         self.opt_step = 0
@@ -160,13 +163,14 @@ class Trainer:
             if self.dp:
                 from nerfstudio_amd.dp_schedule import PipelinedExchange
 
-                self.exchange = PipelinedExchange(arena, self._run, before_main_update=self._push_hyper)
+                self.exchange = PipelinedExchange(arena, self._run, before_main_update=self._push_hyper,
+                                                  sharded=self.dp_sharded)
                 # the coarse levels of the main table can only ever touch 288 k of their 2.6 M rows: exchange those
                 # compactly (2.3 MB instead of 21 MB of the 67 MB main-field all-reduce)
                 enc = model.field.mlp_base.encoding
                 rows, index = enc.spec.reachable_prefix()
-                if index.numel() and index.numel() < rows // 2:
-                    arena.register_compact(enc.hash_table, rows, index)
+                if index.numel() and index.numel() < rows // 2 and not self.dp_sharded:
+                    arena.register_compact(enc.hash_table, rows, index)  # (the reduce-scatter takes the slice as it lies)
 
     # -- pieces of one iteration ---------------------------------------------------------------------------------
     def _prologue(self, updated):
@@ -293,10 +297,12 @@ class Trainer:
         elif name == "pbwd":
             a.zero_grad(["proposal_networks"], skip=r.written_params())
             r.backward_proposals()
-        elif name == "mopt":
-            a.step(grad_scale=1.0 / self.world, groups=["fields"], hyper_dev=self.hyper_views)
-        elif name == "popt":
-            a.step(grad_scale=1.0 / self.world, groups=["proposal_networks"], hyper_dev=self.hyper_views)
+        elif name in ("mopt", "popt"):
+            grp = "fields" if name == "mopt" else "proposal_networks"
+            if self.dp_sharded:  # this rank's 1/N of the group; the exchange all-gathers the updated parameters
+                a.step_shard(grp, grad_scale=1.0 / self.world, hyper_dev=self.hyper_views)
+            else:
+                a.step(grad_scale=1.0 / self.world, groups=[grp], hyper_dev=self.hyper_views)
         else:
             raise KeyError(name)
 
@@ -637,7 +643,8 @@ def dry_run(args, rank, world):
     arena.broadcast_params()
     enc = model.field.mlp_base.encoding
     rows, index = enc.spec.reachable_prefix()
-    arena.register_compact(enc.hash_table, rows, index)
+    if args.dp_mode != "sharded":
+        arena.register_compact(enc.hash_table, rows, index)
     start = arena.flat.clone()
     lr, steps = 0.5, max(2, args.steps)
     schedule = [k % 3 != 2 for k in range(steps)]
@@ -662,10 +669,12 @@ def dry_run(args, rank, world):
             a, b = arena.groups["proposal_networks"]
             arena.grad[a:b] = local_grad(rank, k)[a:b]
         elif name in ("mopt", "popt"):
-            a, b = arena.groups["fields" if name == "mopt" else "proposal_networks"]
+            grp = "fields" if name == "mopt" else "proposal_networks"
+            a, b = arena.shard_span(grp) if sharded else arena.groups[grp]
             arena.flat[a:b] -= lr * arena.grad[a:b] / world
 
-    ex = PipelinedExchange(arena, run)
+    sharded = args.dp_mode == "sharded"
+    ex = PipelinedExchange(arena, run, sharded=sharded)
     t0 = time.perf_counter()
     for k in range(steps):
         step["k"] = k
@@ -695,6 +704,7 @@ def dry_run(args, rank, world):
                           "dry_run": True,
                           "config": {"workload": "launch rehearsal on CPU over gloo: model + arena + compact prefix + pipelined "
                                                  "exchange, synthetic gradients", "params": arena.numel,
+                                     "dp_mode": args.dp_mode, "ranks": dist.get_world_size() if world > 1 else 1,
                                      "compact_rows": int(index.numel()), "prefix_rows": int(rows),
                                      "exchange_s_per_step": round(elapsed / steps, 4), "max_abs_error": err}}))
     if world > 1:
@@ -731,6 +741,10 @@ def main():
                     help="N = 1 only: run the data-parallel schedule (pipelined exchange, compact table prefix, async "
                          "all-reduce on the communication stream) over a ONE-rank RCCL communicator — exercises the N > 1 "
                          "code path on a single-GPU box; the losses must equal the plain N = 1 run")
+    ap.add_argument("--dp-mode", choices=["allreduce", "sharded"], default="allreduce",
+                    help="N > 1 gradient exchange: all-reduce + replicated Adam (default, the reference's DDP semantics) or "
+                         "reduce-scatter -> Adam on the rank's 1/N arena shard -> all-gather (same parameters, 1/N of the "
+                         "optimiser's HBM traffic)")
     ap.add_argument("--param-checksum", action="store_true",
                     help="add sha256 digests of the parameter arena and both Adam moments to config (bit-equality checks "
                          "between schedule variants across processes)")
@@ -780,7 +794,7 @@ def main():
     # each rank its own rays (scripts/train.py:98): BATCH_SLOTS batches per rank, disjoint seeds
     rb, batch, pool = synthetic_batch(device, seed=1000 + (0 if same else 100 * rank), workload=args.workload)
     trainer = Trainer(model, arena, rb, batch, world=world, use_graph=not args.no_graph, use_runner=not args.autograd,
-                      pool=None if args.fixed_batch else pool, force_dp=args.force_dp)
+                      pool=None if args.fixed_batch else pool, force_dp=args.force_dp, dp_mode=args.dp_mode)
 
     if args.start_step:
         trainer.step = args.start_step
@@ -873,6 +887,7 @@ def main():
         if checksum is not None:
             out["config"]["param_checksum"] = checksum
         if world > 1 or args.force_dp:  # what the process group itself reports (not the --gpus argument)
+            out["config"]["dp_mode"] = args.dp_mode
             out["config"]["rccl_ranks"] = dist.get_world_size()
             out["config"]["dist_backend"] = dist.get_backend()
         if args.force_dp:

@@ -25,6 +25,7 @@ from torch.nn import Parameter
 from . import functional as F
 
 _ALIGN = 64  # floats: every tensor starts on a 256-B boundary
+_GROUP_ALIGN = _ALIGN * 840  # floats: lcm(1..8) aligned shards per optimiser group (<= 215 KB of zero padding per group)
 
 
 def _rows_gather(view: torch.Tensor, idx: torch.Tensor, buf: torch.Tensor) -> None:
@@ -99,11 +100,19 @@ class ParamArena:
             self.params += mine
         assert self.params, "no trainable parameters"
         dev = self.params[0].device
+        # groups one after the other, each starting AND ending on a multiple of _GROUP_ALIGN floats: a group's slice then
+        # splits into equal 256-B-aligned shards for every world size up to 8 (reduce-scatter / sharded Adam / all-gather)
         self.offsets, total = [], 0
-        for p in self.params:
-            assert p.dtype == torch.float32 and p.device == dev
-            self.offsets.append(total)
-            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        spans = {}
+        for name, plist in self.group_params.items():
+            start = total
+            for p in plist:
+                assert p.dtype == torch.float32 and p.device == dev
+                self.offsets.append(total)
+                total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            total = (total + _GROUP_ALIGN - 1) // _GROUP_ALIGN * _GROUP_ALIGN
+            if plist:
+                spans[name] = (start, total)
         self.numel = total
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(total, device=dev, dtype=torch.float32)
@@ -114,7 +123,7 @@ class ParamArena:
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
-        self.groups: Dict[str, Tuple[int, int]] = {n: self.span(pl) for n, pl in self.group_params.items() if pl}
+        self.groups: Dict[str, Tuple[int, int]] = spans  # (the padding holds zeros for ever: zero gradient, zero update)
         self.step_counts: Dict[str, int] = {n: 0 for n in self.groups}
         self.lr, self.betas, self.eps = lr, betas, eps
 
@@ -199,6 +208,51 @@ class ParamArena:
         if cursor < b:
             handles.append(dist.all_reduce(self.grad[cursor:b], op=dist.ReduceOp.SUM, group=group, async_op=async_op))
         return _GroupHandle(handles if async_op else [], post)
+
+    # ---- sharded optimiser: reduce-scatter -> Adam on this rank's 1/N of the group -> all-gather -----------------------
+    # (SURVEY.md §8e "direct RS+AG" / ZeRO-1: the reference steps a replicated torch.optim.Adam on every rank after
+    # DDP's all-reduce, engine/optimizers.py:74-193 + pipelines/base_pipeline.py:279-282. Adam is elementwise, so updating
+    # only the rank's shard of (p, m, v) from the rank's shard of the summed gradient and gathering the updated parameters
+    # gives every rank exactly the parameters replicated Adam gives — with 1/N of the optimiser's HBM traffic, 544 MB per
+    # step and rank replicated. Moments outside the rank's shard are never read or written.)
+    def shard_span(self, name: str, group: Optional[dist.ProcessGroup] = None) -> Tuple[int, int]:
+        """This rank's contiguous (start, end) share of optimiser group `name` (equal shards in rank order)."""
+        a, b = self.groups[name]
+        if not (dist.is_available() and dist.is_initialized()):
+            return a, b
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        assert (b - a) % world == 0, f"group {name}: {b - a} floats do not split into {world} shards"
+        n = (b - a) // world
+        return a + rank * n, a + (rank + 1) * n
+
+    def reduce_scatter_group(self, name: str, async_op: bool = False, group: Optional[dist.ProcessGroup] = None):
+        """Sum the group's gradients over the ranks INTO this rank's shard of the gradient arena (in place: the output is
+        the rank's slice of the input, RCCL's in-place reduce-scatter). Afterwards only `shard_span(name)` of the gradient
+        holds the sum; the rest of the slice is stale. Returns the async handle (None: synchronous / nothing to do)."""
+        if not (dist.is_available() and dist.is_initialized()) or _single(group):
+            return None
+        a, b = self.groups[name]
+        sa, sb = self.shard_span(name, group)
+        return dist.reduce_scatter_tensor(self.grad[sa:sb], self.grad[a:b], op=dist.ReduceOp.SUM, group=group,
+                                          async_op=async_op)
+
+    def all_gather_group(self, name: str, async_op: bool = False, group: Optional[dist.ProcessGroup] = None):
+        """Every rank's updated parameter shard -> every rank's full parameter slice (in place)."""
+        if not (dist.is_available() and dist.is_initialized()) or _single(group):
+            return None
+        a, b = self.groups[name]
+        sa, sb = self.shard_span(name, group)
+        return dist.all_gather_into_tensor(self.flat[a:b], self.flat[sa:sb], group=group, async_op=async_op)
+
+    def step_shard(self, name: str, grad_scale: float = 1.0, lr: Optional[float] = None,
+                   hyper_dev: Optional[Dict[str, torch.Tensor]] = None, group: Optional[dist.ProcessGroup] = None) -> None:
+        """Adam on this rank's shard of group `name` only (after reduce_scatter_group, before all_gather_group). The
+        group's step counter advances as in `step`: bias corrections are identical on every rank."""
+        sa, sb = self.shard_span(name, group)
+        self.step_counts[name] += 1
+        hd = hyper_dev.get(name) if isinstance(hyper_dev, dict) else hyper_dev
+        F.adam_step(self.flat[sa:sb], self.grad[sa:sb], self.exp_avg[sa:sb], self.exp_avg_sq[sa:sb],
+                    self.step_counts[name], lr if lr is not None else self.lr, self.betas, self.eps, grad_scale, hd)
 
     def all_reduce(self, group: Optional[dist.ProcessGroup] = None) -> float:
         """Sum the gradient arena over the ranks (RCCL when the tensors are on the GPU, gloo on CPU). Returns the scale

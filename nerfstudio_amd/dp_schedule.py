@@ -12,6 +12,17 @@ boundary:
 Every parameter is updated before its next use, i.e. exactly the sequential semantics; only the order in which
 independent work is issued changes. `finish()` drains the pending update. The class only sequences: the segments
 themselves (kernel launches or replays of captured hipGraphs) are supplied by the caller.
+
+`sharded=True` (SURVEY.md §8e "direct RS+AG", ZeRO-1): the all-reduce of a group becomes a REDUCE-SCATTER into the rank's
+1/N shard of the gradient slice, the caller's "mopt" / "popt" segments run Adam on that shard only
+(arena.ParamArena.step_shard: 1/N of the optimiser's 544 MB of HBM traffic per step and rank), and an ALL-GATHER of the
+updated parameter shards follows the update:
+
+    step k:   [proposal fwd k] -> wait RS_main(k-1), [Adam main shard k-1], AG_main -> [main fwd + losses + main bwd k]
+              -> RS_main(k) async -> (update steps) [proposal bwd k] -> RS_props(k) -> [Adam props shard k] -> AG_props
+
+Adam is elementwise, so every rank ends each step with the parameters replicated Adam gives (bit for bit when the
+reduce-scatter sums in the all-reduce's order: tests/test_distributed_cpu.py, gloo, world 2 and 4).
 """
 from __future__ import annotations
 
@@ -29,33 +40,46 @@ class PipelinedExchange:
     called right before a pending main update is applied (the caller refreshes step-dependent optimiser scalars)."""
 
     def __init__(self, arena, run: Callable[[object], None], main_group: str = "fields",
-                 proposal_group: str = "proposal_networks", before_main_update: Optional[Callable[[], None]] = None) -> None:
+                 proposal_group: str = "proposal_networks", before_main_update: Optional[Callable[[], None]] = None,
+                 sharded: bool = False) -> None:
         self.arena, self.run = arena, run
         self.main_group, self.proposal_group = main_group, proposal_group
         self.before_main_update = before_main_update
+        self.sharded = sharded
         self._handle = None
         self.pending = False  # a main-field all-reduce is in flight and its Adam update has not been applied
+
+    def _reduce(self, group: str):
+        """Start the gradient exchange of one optimiser group; -> handle (None: nothing in flight)."""
+        if self.sharded:
+            return self.arena.reduce_scatter_group(group, async_op=True)
+        return self.arena.all_reduce_group(group, async_op=True)
+
+    def _update(self, group: str, segment: str) -> None:
+        """The group's optimiser segment (on the rank's shard when sharded, then the parameter all-gather)."""
+        self.run(segment)
+        if self.sharded:
+            self.arena.all_gather_group(group)
 
     def _finish_main(self) -> None:
         if self.pending:
             if self._handle is not None:
                 self._handle.wait()
-            self.run("mopt")
+            self._update(self.main_group, "mopt")
             self._handle, self.pending = None, False
 
     def iteration(self, updated: bool) -> None:
-        a = self.arena
         self.run("pfwd")          # overlaps the all-reduce of the previous step's main-field gradients
         self._finish_main()
         self.run(("main", updated))
-        self._handle = a.all_reduce_group(self.main_group, async_op=True)
+        self._handle = self._reduce(self.main_group)
         self.pending = True
         if updated:
             self.run("pbwd")      # ... and so does this
-            h = a.all_reduce_group(self.proposal_group, async_op=True)
+            h = self._reduce(self.proposal_group)
             if h is not None:
                 h.wait()
-            self.run("popt")
+            self._update(self.proposal_group, "popt")
 
     def finish(self) -> None:
         """Drain the pipeline: afterwards every parameter reflects every step taken."""

@@ -48,12 +48,15 @@ def _worker(rank, world, port, q):
         # grouped arena: asynchronous all-reduce of ONE group's slice leaves the other group's gradients local
         g = ParamArena({"fields": [torch.nn.Parameter(torch.full((70,), float(rank + 1)))],
                         "proposal_networks": [torch.nn.Parameter(torch.full((5, 3), 10.0 * (rank + 1)))]})
-        assert list(g.groups) == ["fields", "proposal_networks"] and g.groups["fields"] == (0, 128) and g.groups["proposal_networks"] == (128, 192)
+        from nerfstudio_amd.arena import _GROUP_ALIGN as GA  # groups start and end on shardable boundaries
+
+        assert list(g.groups) == ["fields", "proposal_networks"] and g.groups["fields"] == (0, GA) and g.groups["proposal_networks"] == (GA, 2 * GA)
+        assert all(GA % (64 * w) == 0 for w in range(1, 9))
         for p_ in g.params:
             p_.grad.copy_(p_.data)
         h = g.all_reduce_span(*g.groups["fields"], async_op=True)
         h.wait()
-        assert float(g.grad[:70].sum()) == 70 * 3.0 and float(g.grad[128:143].sum()) == 15 * 10.0 * (rank + 1)
+        assert float(g.grad[:70].sum()) == 70 * 3.0 and float(g.grad[GA:GA + 15].sum()) == 15 * 10.0 * (rank + 1)
         q.put((rank, [r.numpy() for r in ref0], local.numpy(), summed.numpy(), arena.numel))
     finally:
         dist.destroy_process_group()
@@ -89,7 +92,11 @@ def test_arena_single_process_layout():
     a = torch.nn.Parameter(torch.arange(10.0))
     b = torch.nn.Parameter(torch.ones(3, 70))
     arena = ParamArena([a, b])
-    assert arena.offsets == [0, 64] and arena.numel == 64 + 256
+    from nerfstudio_amd.arena import _GROUP_ALIGN
+
+    # tensors on 256-B boundaries; the (single) group padded to the shardable boundary with zeros
+    assert arena.offsets == [0, 64] and arena.numel == _GROUP_ALIGN and arena.groups == {"all": (0, _GROUP_ALIGN)}
+    assert float(arena.flat[64 + 210:].abs().sum()) == 0
     assert a.data_ptr() == arena.flat.data_ptr() and b.data_ptr() == arena.flat.data_ptr() + 4 * 64
     assert torch.equal(arena.flat[:10], torch.arange(10.0)) and float(arena.flat[10:64].abs().sum()) == 0
     (a.sum() * 2 + b.sum()).backward()
@@ -231,6 +238,110 @@ def test_pipelined_exchange_equals_sequential_data_parallel(world, steps, patter
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# Sharded optimiser (reduce-scatter -> Adam on the rank's 1/N shard -> all-gather) == replicated Adam behind an all-reduce
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_adam(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-15, grad_scale=1.0, hyper_dev=None):
+    """torch.optim.Adam's update (torch/optim/adam.py, single tensor, no amsgrad / weight decay) on arena slices — the
+    CPU stand-in for csrc/misc.hip's kernel in these gloo tests (elementwise, like the kernel)."""
+    import math
+
+    b1, b2 = betas
+    g = grads * grad_scale
+    exp_avg.lerp_(g, 1 - b1)
+    exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    denom = (exp_avg_sq.sqrt() / math.sqrt(bc2)).add_(eps)
+    params.addcdiv_(exp_avg, denom, value=-lr / bc1)
+
+
+def _sharded_worker(rank, world, port, q, steps, schedule):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerfstudio_amd import functional as F
+        from nerfstudio_amd.arena import ParamArena
+        from nerfstudio_amd.dp_schedule import PipelinedExchange
+
+        F.adam_step = _cpu_adam
+        out = {}
+        for mode in ("allreduce", "sharded"):
+            torch.manual_seed(5)
+            table = torch.nn.Parameter(torch.randn(90000, 2) * 1e-2)   # "hash table": most of the group
+            w = torch.nn.Parameter(torch.randn(64, 32) * 0.1)
+            pt = torch.nn.Parameter(torch.randn(40000, 2) * 1e-2)
+            pw = torch.nn.Parameter(torch.randn(16, 10) * 0.1)
+            arena = ParamArena({"fields": [table, w], "proposal_networks": [pt, pw]}, lr=1e-2, eps=1e-15)
+            state = {"k": 0}
+
+            def run(name, arena=arena, mode=mode):
+                k = state["k"]
+                if name in (("main", True), ("main", False), "pbwd"):
+                    grp = "proposal_networks" if name == "pbwd" else "fields"
+                    a, b = arena.groups[grp]
+                    g = torch.Generator().manual_seed(1000 * rank + 10 * k + (name == "pbwd"))
+                    arena.grad[a:b] = torch.randn(b - a, generator=g) * (1e-3 if grp == "fields" else 1e-4)
+                    used = sum((p.numel() + 63) // 64 * 64 for p in arena.group_params[grp])
+                    arena.grad[a + used:b] = 0.0  # the group's alignment padding never carries gradient
+                elif name in ("mopt", "popt"):
+                    grp = "fields" if name == "mopt" else "proposal_networks"
+                    if mode == "sharded":
+                        arena.step_shard(grp, grad_scale=1.0 / world)
+                    else:
+                        arena.step(grad_scale=1.0 / world, groups=[grp])
+
+            ex = PipelinedExchange(arena, run, sharded=(mode == "sharded"))
+            for k in range(steps):
+                state["k"] = k
+                ex.iteration(updated=schedule[k])
+            ex.finish()
+            out[mode] = (arena.flat.clone(), arena.exp_avg.clone(), arena.exp_avg_sq.clone(),
+                         {n: arena.shard_span(n) for n in arena.groups}, dict(arena.step_counts))
+        q.put((rank, {m: tuple(t.numpy() if torch.is_tensor(t) else t for t in v) for m, v in out.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,steps,pattern", [(2, 7, "alternating"), (4, 12, "nerfacto")])
+def test_sharded_adam_equals_replicated_adam_bit_for_bit(world, steps, pattern):
+    """arena mode "sharded" (reduce-scatter -> Adam on the rank's 1/N shard -> all-gather; dp_schedule.PipelinedExchange
+    with sharded=True) against the replicated Adam behind the all-reduce, same per-rank gradients, world 2 with alternating
+    update steps and world 4 with the uneven nerfacto update pattern: the PARAMETERS are equal bit for bit on every rank
+    and between the ranks, the rank's shard of both moments equals the replicated moments, moments outside the shard were
+    never touched, and both groups' step counters agree."""
+    import numpy as np
+
+    schedule = [k % 2 == 0 for k in range(steps)] if pattern == "alternating" else _nerfacto_schedule(steps)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, steps, schedule)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = res[0]["allreduce"][0]
+    assert np.abs(ref).max() > 0 and not np.array_equal(ref, 0 * ref)
+    for rank in range(world):
+        flat_a, m_a, v_a, _, steps_a = res[rank]["allreduce"]
+        flat_s, m_s, v_s, spans, steps_s = res[rank]["sharded"]
+        np.testing.assert_array_equal(flat_a, ref)            # replicated: every rank the same
+        np.testing.assert_array_equal(flat_s.view(np.int32), ref.view(np.int32))  # sharded: the same BITS
+        assert steps_a == steps_s and steps_s["fields"] == steps and steps_s["proposal_networks"] == sum(schedule)
+        for name, (sa, sb) in spans.items():
+            np.testing.assert_array_equal(m_s[sa:sb], m_a[sa:sb])
+            np.testing.assert_array_equal(v_s[sa:sb], v_a[sa:sb])
+        own = np.zeros(flat_s.shape, dtype=bool)
+        for sa, sb in spans.values():
+            own[sa:sb] = True
+        assert not m_s[~own].any() and not v_s[~own].any(), "moments outside the rank's shards must stay untouched"
+        assert m_a[~own].any()  # (the replicated optimiser does hold them)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # ParamArena.all_reduce_group with a registered compact table prefix == plain all-reduce of the whole slice
 # ---------------------------------------------------------------------------------------------------------------------
 def _compact_worker(rank, world, port, q):
@@ -290,7 +401,8 @@ def test_compact_table_prefix_exchange_equals_full_all_reduce():
 # the driver's multi-GPU launch line, rehearsed on CPU (bench.py --dry-run: gloo instead of RCCL, no kernels)
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.timeout(600)
-def test_bench_launch_line_dry_run_under_torchrun():
+@pytest.mark.parametrize("dp_mode", ["allreduce", "sharded"])
+def test_bench_launch_line_dry_run_under_torchrun(dp_mode):
     """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py
     --gpus 2 --steps K --warmup W` — exactly the driver's line plus --dry-run: argument and RANK / WORLD_SIZE / MASTER_*
     handling, process-group setup, the real model / arena / compact prefix / pipelined exchange over gloo, ONE JSON line
@@ -302,7 +414,7 @@ def test_bench_launch_line_dry_run_under_torchrun():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-           "--dry-run"]
+           "--dry-run", "--dp-mode", dp_mode]
     env = dict(os.environ, OMP_NUM_THREADS="2")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=540, cwd=root, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
@@ -314,3 +426,4 @@ def test_bench_launch_line_dry_run_under_torchrun():
         assert key in out, key
     assert out["n_gpus"] == 2 and out["dry_run"] is True and out["scaling"] == "weak"
     assert out["config"]["max_abs_error"] <= 1e-5 and 0 < out["config"]["compact_rows"] < out["config"]["prefix_rows"]
+    assert out["config"]["dp_mode"] == dp_mode and out["config"]["ranks"] == 2
