@@ -163,8 +163,11 @@ class Trainer:
             if self.dp:
                 from nerfstudio_amd.dp_schedule import PipelinedExchange
 
+                # the pending main-field Adam waits for its all-reduce on its own stream, beside the next proposal forward
+                # (NSAMD_DP_UPDATE_STREAM=0: on the launch stream after it, the round-2 order)
+                upd = torch.cuda.Stream(device=dev) if os.environ.get("NSAMD_DP_UPDATE_STREAM", "1") == "1" else None
                 self.exchange = PipelinedExchange(arena, self._run, before_main_update=self._push_hyper,
-                                                  sharded=self.dp_sharded)
+                                                  sharded=self.dp_sharded, update_stream=upd)
                 # the coarse levels of the main table can only ever touch 288 k of their 2.6 M rows: exchange those
                 # compactly (2.3 MB instead of 21 MB of the 67 MB main-field all-reduce)
                 enc = model.field.mlp_base.encoding

@@ -208,11 +208,8 @@ int nsamd_density_mlp_bwd(const float* enc, const float* selector, const float* 
                           int64_t M, nsamd_density_mlp mlp, float* denc, float* dW0, float* db0, float* dW1,
                           float* db1, float* workspace, int64_t workspace_floats, nsamd_stream_t stream);
 
-/* Gated form (see "zero-gradient gating" above). Also folds the fixed-order sum of the per-workgroup partial rows into
- * the launch (the last workgroup to arrive adds them up: same order, same bits as the follow-up reduce launch of the
- * ungated form). workspace: nsamd_density_mlp_bwd_gated_workspace(in_dim, hidden) floats whose LAST 4 words (the
- * arrival ticket) must be zero before the first call (every call leaves them zero). */
-int64_t nsamd_density_mlp_bwd_gated_workspace(int32_t in_dim, int32_t hidden);
+/* Gated form (see "zero-gradient gating" above): returns at once while *gate == 0, else identical to
+ * nsamd_density_mlp_bwd (same workspace contract). */
 int nsamd_density_mlp_bwd_gated(const float* enc, const float* selector, const float* pre, const float* ddensity,
                                 int64_t M, nsamd_density_mlp mlp, float* denc, float* dW0, float* db0, float* dW1,
                                 float* db1, float* workspace, int64_t workspace_floats, const uint32_t* gate,

@@ -75,7 +75,6 @@ _SIGNATURES = {
     "nsamd_density_mlp_fwd": [vp, vp, i64, DensityMlp, vp, vp, vp],
     "nsamd_density_field_fwd": [Points, i64, C.c_int, Aabb, vp, Grid, DensityMlp, vp, vp, vp, vp, vp],
     "nsamd_density_mlp_bwd": [vp, vp, vp, vp, i64, DensityMlp, vp, vp, vp, vp, vp, vp, i64, vp],
-    "nsamd_density_mlp_bwd_gated_workspace": [i32, i32],
     "nsamd_density_mlp_bwd_gated": [vp, vp, vp, vp, i64, DensityMlp, vp, vp, vp, vp, vp, vp, i64, vp, vp],
     "nsamd_field_mlp_fwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp],
     "nsamd_field_mlp_bwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp, i64, vp],
@@ -122,8 +121,7 @@ _SIGNATURES = {
     "nsamd_probe_mfma_bf16": [vp, vp, vp, vp],
 }
 _RESTYPES = {"nsamd_version": C.c_char_p, "nsamd_status_string": C.c_char_p,
-             "nsamd_hashgrid_encode_bwd_workspace": C.c_int64, "nsamd_hashgrid_encode_bwd_workspace_state": C.c_int64, "nsamd_field_mlp_saved_floats": C.c_int64,
-             "nsamd_density_mlp_bwd_gated_workspace": C.c_int64}
+             "nsamd_hashgrid_encode_bwd_workspace": C.c_int64, "nsamd_hashgrid_encode_bwd_workspace_state": C.c_int64, "nsamd_field_mlp_saved_floats": C.c_int64}
 
 _lib = None
 ERR_UNSUPPORTED = -2  # nsamd_status NSAMD_ERR_UNSUPPORTED

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ pre,
     const float* __restrict__ ddensity, int64_t M, nsamd_density_mlp mlp, float* __restrict__ denc,
     float* __restrict__ dW0, float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1,
-    float* __restrict__ partials, uint32_t* __restrict__ ticket, const uint32_t* __restrict__ gate) {
+    float* __restrict__ partials, const uint32_t* __restrict__ gate) {
   // Gated call (nsamd_density_mlp_bwd_gated): the flag nsamd_weights_bwd_gate raises when any ray of the level carries
   // gradient is clear -> every upstream gradient is an exact zero, so are all results of this launch; the zero-filled
   // weight gradients stay as they are and nothing downstream (gated the same way) reads `denc`.
@@ -271,66 +271,13 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
     __syncthreads();
   }
   if (partials != nullptr) {
-    // one row of partial sums per workgroup, [dW0 (H x IN) | db0 (H) | dW1 (H) | db1], added up in a fixed order, so the
-    // weight gradients are bit-reproducible (float atomics are not)
-    constexpr int stride = density_partial_stride(IN, H);
-    float* row = partials + (size_t)blockIdx.x * stride;
-    if (ticket == nullptr) {  // summed by a following density_dw_reduce_kernel launch
-      for (int e = threadIdx.x; e < H * IN; e += kMlpBlock) row[e] = red[(e / IN) * 16 + (e % IN)];
-      if (threadIdx.x < 2 * H + 1) row[H * IN + threadIdx.x] = accV;
-      return;
-    }
-    // ... or by the LAST workgroup of this launch to arrive (no 4-workgroup follow-up launch that has to wait for room
-    // beside the full-chip kernels of the other backward chains: it averaged 104 us of queueing in the replayed graph,
-    // profiles/r02_final_rocprofv3_kernel_stats.csv). Hand-off as MI355X_MICROARCH.md prescribes: write-through (sc1)
-    // stores of the row, drained, then the arrival ticket; the reader uses sc1 loads (L1 is never refreshed by other CUs).
-    for (int e = threadIdx.x; e < H * IN; e += kMlpBlock)
-      __hip_atomic_store(row + e, red[(e / IN) * 16 + (e % IN)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x < 2 * H + 1)
-      __hip_atomic_store(row + H * IN + threadIdx.x, accV, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    __shared__ uint32_t arrived;
-    if (threadIdx.x == 0) arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (arrived != gridDim.x - 1) return;
-    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-cleaning
-    // same summation order as density_dw_reduce_kernel (16 row groups per element, rows grp, grp + 16, ... in order,
-    // then the 16 group sums in order): the two forms give the same bits
-    constexpr int total = H * IN + 2 * H + 1;
-    float* part = lds;  // [kDwGroups][64]
-    const int rows = (int)gridDim.x;
-    const int el = threadIdx.x & 63, q4 = threadIdx.x >> 6;
-    for (int e0 = 0; e0 < total; e0 += 64) {
-      const int e = e0 + el;
-      __syncthreads();
-      for (int grp = q4; grp < 16; grp += kMlpBlock / 64) {
-        float sgrp = 0.f;
-        if (e < total) {
-          for (int b0i = grp; b0i < rows; b0i += 16 * 16) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-              const int b = b0i + u * 16;
-              v[u] = b < rows ? __hip_atomic_load(partials + (size_t)b * stride + e, __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT)
-                              : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) sgrp += v[u];
-          }
-        }
-        part[grp * 64 + el] = sgrp;
-      }
-      __syncthreads();
-      if (q4 == 0 && e < total) {
-        float t = 0.f;
-#pragma unroll
-        for (int g2 = 0; g2 < 16; ++g2) t += part[g2 * 64 + el];
-        float* dst = e < H * IN ? dW0 + e : (e < H * IN + H ? db0 + (e - H * IN) : (e < H * IN + 2 * H ? dW1 + (e - H * IN - H) : db1));
-        *dst += t;
-      }
-    }
+    // one row of partial sums per workgroup, [dW0 (H x IN) | db0 (H) | dW1 (H) | db1]: density_dw_reduce_kernel adds the
+    // rows up in a fixed order, so the weight gradients are bit-reproducible (float atomics are not). (Folding that sum
+    // into this launch — last workgroup to arrive — was measured: 58 -> 104 us, one 256-thread workgroup has 1/16 of the
+    // follow-up launch's loads in flight; profiles/r03_negative_results.txt.)
+    float* row = partials + (size_t)blockIdx.x * density_partial_stride(IN, H);
+    for (int e = threadIdx.x; e < H * IN; e += kMlpBlock) row[e] = red[(e / IN) * 16 + (e % IN)];
+    if (threadIdx.x < 2 * H + 1) row[H * IN + threadIdx.x] = accV;
     return;
   }
   for (int e = threadIdx.x; e < H * IN; e += kMlpBlock) unsafeAtomicAdd(dW0 + e, red[(e / IN) * 16 + (e % IN)]);
@@ -347,7 +294,9 @@ __global__ __launch_bounds__(64 * kDwGroups) void density_dw_reduce_kernel(const
                                                                             float* __restrict__ dW0,
                                                                             float* __restrict__ db0,
                                                                             float* __restrict__ dW1,
-                                                                            float* __restrict__ db1) {
+                                                                            float* __restrict__ db1,
+                                                                            const uint32_t* __restrict__ gate) {
+  if (gate != nullptr && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
   __shared__ float part[kDwGroups][64];
   const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + el;
@@ -398,20 +347,13 @@ static int launch_bwd(const float* enc, const float* selector, const float* pre,
   }
   constexpr int stride = density_partial_stride(IN, H);
   float* partials = (workspace != nullptr && workspace_floats >= (int64_t)blocks * stride) ? workspace : nullptr;
-  // Gated calls (the training step's) own a zero-initialised arrival ticket in the 4 words after the partial rows: the
-  // last workgroup sums the rows. Ungated calls keep the follow-up reduce launch (any scratch contents are fine).
-  uint32_t* ticket = nullptr;
-  if (gate != nullptr) {
-    NSAMD_REQUIRE(partials != nullptr && workspace_floats >= (int64_t)kMaxBlocks * stride + 4);
-    ticket = reinterpret_cast<uint32_t*>(workspace + (size_t)kMaxBlocks * stride);
-  }
   density_mlp_bwd_kernel<IN, H><<<blocks, kMlpBlock, lds, stream>>>(enc, selector, pre, ddensity, M, mlp, denc, dW0,
-                                                                   db0, dW1, db1, partials, ticket, gate);
+                                                                   db0, dW1, db1, partials, gate);
   NSAMD_CHECK_LAUNCH();
-  if (partials != nullptr && ticket == nullptr) {
+  if (partials != nullptr) {
     const int total = H * IN + 2 * H + 1;
     density_dw_reduce_kernel<<<(total + 63) / 64, 64 * kDwGroups, 0, stream>>>(partials, (int)blocks, stride, H * IN, H,
-                                                                             dW0, db0, dW1, db1);
+                                                                             dW0, db0, dW1, db1, gate);
     NSAMD_CHECK_LAUNCH();
   }
   return NSAMD_OK;
@@ -484,11 +426,6 @@ extern "C" int nsamd_density_mlp_bwd(const float* enc, const float* selector, co
                     nullptr, (hipStream_t)stream)
   NSAMD_DENSITY_DISPATCH(CALL)
 #undef CALL
-}
-
-extern "C" int64_t nsamd_density_mlp_bwd_gated_workspace(int32_t in_dim, int32_t hidden) {
-  if (in_dim <= 0 || hidden <= 0) return 0;
-  return (int64_t)kMaxBlocks * density_partial_stride(in_dim, hidden) + 4;
 }
 
 extern "C" int nsamd_density_mlp_bwd_gated(const float* enc, const float* selector, const float* pre,

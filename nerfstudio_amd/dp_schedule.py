@@ -41,11 +41,16 @@ class PipelinedExchange:
 
     def __init__(self, arena, run: Callable[[object], None], main_group: str = "fields",
                  proposal_group: str = "proposal_networks", before_main_update: Optional[Callable[[], None]] = None,
-                 sharded: bool = False) -> None:
+                 sharded: bool = False, update_stream=None) -> None:
         self.arena, self.run = arena, run
         self.main_group, self.proposal_group = main_group, proposal_group
         self.before_main_update = before_main_update
         self.sharded = sharded
+        # Optional second device stream for the pending main-field update: it alone waits for the exchange, so the
+        # proposal forward of the next step starts at once on the caller's stream and the 470 MB Adam pass runs BESIDE
+        # it as soon as the gradients have arrived (the N = 1 schedule's "deferred Adam" — bench.py — carried over to
+        # N > 1). None (CPU tests, gloo): the update follows the proposal forward on the caller's stream.
+        self.update_stream = update_stream
         self._handle = None
         self.pending = False  # a main-field all-reduce is in flight and its Adam update has not been applied
 
@@ -69,8 +74,18 @@ class PipelinedExchange:
             self._handle, self.pending = None, False
 
     def iteration(self, updated: bool) -> None:
-        self.run("pfwd")          # overlaps the all-reduce of the previous step's main-field gradients
-        self._finish_main()
+        if self.update_stream is not None and self.pending:
+            import torch
+
+            cur = torch.cuda.current_stream()
+            self.update_stream.wait_stream(cur)  # the step-dependent optimiser scalars were pushed on `cur`
+            with torch.cuda.stream(self.update_stream):
+                self._finish_main()  # wait() parks THIS stream until the exchange is done, then the update runs on it
+            self.run("pfwd")      # meanwhile, on the caller's stream: reads only proposal-network parameters
+            cur.wait_stream(self.update_stream)
+        else:
+            self.run("pfwd")      # overlaps the all-reduce of the previous step's main-field gradients
+            self._finish_main()
         self.run(("main", updated))
         self._handle = self._reduce(self.main_group)
         self.pending = True

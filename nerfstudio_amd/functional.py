@@ -170,18 +170,16 @@ def field_bwd_workspace(device) -> Tuple[Tensor, int]:
 _SCATTER_WS_MAX = 8  # cached workspaces (least recently used ones are dropped: a main-table workspace is ~0.75 GB)
 
 
-# <= 1024 workgroups x (64 x 16 + 2 x 64 + 1, padded to 16 B) partial sums + the 4-word arrival ticket of the gated call
-DENSITY_WS_FLOATS = 1024 * 1156 + 4
+DENSITY_WS_FLOATS = 1024 * 1156  # <= 1024 workgroups x (64 x 16 + 2 x 64 + 1, padded to 16 B) partial sums
 
 
 def density_bwd_workspace(device, slot: int = 0) -> Tensor:
     """Scratch rows for the weight-gradient partials of nsamd_density_mlp_bwd[_gated] (summed in a fixed order). One
-    buffer per (device, slot): calls that may overlap on different streams take different slots. Zero-initialised: the
-    gated call keeps its arrival ticket behind the rows and leaves it at zero."""
+    buffer per (device, slot): calls that may overlap on different streams take different slots."""
     key = (str(device), "density", slot)
     ws = _FIELD_WS.get(key)
     if ws is None:
-        ws = torch.zeros(DENSITY_WS_FLOATS, device=device, dtype=torch.float32)
+        ws = torch.empty(DENSITY_WS_FLOATS, device=device, dtype=torch.float32)
         _FIELD_WS[key] = ws
     return ws
 

@@ -7,8 +7,9 @@ that path that depend on M and T (the scatter's per-level queue capacities, the 
 fixed-point scale), so here:
 
 1. one proposal-UPDATE and one NON-update iteration REPLAYED from the captured graphs (deferred Adam pending) against the
-   CPU oracle evaluated on the same rays / jitter / parameters: rgb <= 1e-4 L-inf (north_star), the three losses, the
-   relative L2 of every gradient tensor (the main table PER LEVEL), no scatter record on an unordered path;
+   CPU oracle evaluated on the same rays / jitter / parameters: rgb <= 1e-4 L-inf (north_star), the three losses, every
+   gradient tensor (the main table PER LEVEL) as close to the float64 evaluation of the same graph as the fp32 reference
+   itself is, no scatter record on an unordered path;
 2. six iterations replayed from the graphs against the same six launched eagerly (Adam in order, one stream):
    parameters and both Adam moments equal BIT FOR BIT (DESIGN §4.2 claims "same bits"; round 2 compared a loss rounded to
    six decimals);
@@ -112,49 +113,69 @@ def test_bench_configuration_parity_through_replayed_graph(F, init):
         # still pending), the proposal networks as they were before the proposal Adam at the end of the replayed graph ----
         after = arena.flat[pa:pb].clone()
         arena.flat[pa:pb].copy_(before)
-        oparams = _oracle_params(model, keys)
+        base_params = _oracle_params(model, keys)
         arena.flat[pa:pb].copy_(after)
         if forced:
             assert not torch.equal(before, after), "the update iteration's graph steps the proposal networks"
         else:
             assert torch.equal(before, after), "a non-update iteration leaves the proposal networks alone"
-        for p in oparams.values():
-            p.requires_grad_(True)
         o, d, cam, tgt = (torch.from_numpy(a) for a in bench.synthetic_rays(1000 + slot))
         j = [torch.from_numpy(jit[i])[:, None] for i in range(3)]
-        out = orc.nerfacto_forward(oparams, cfg, o, d, cam[:, 0], j, training=True, anneal=ps._anneal,
-                                   proposal_requires_grad=forced)
-        ld = orc.nerfacto_losses(out, tgt, cfg)
-        sum(ld.values()).backward()
+
+        def oracle(dtype):
+            prm = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in base_params.items()}
+            res = orc.nerfacto_forward(prm, cfg, o.to(dtype), d.to(dtype), cam[:, 0], [x.to(dtype) for x in j], training=True,
+                                       anneal=ps._anneal, proposal_requires_grad=forced)
+            losses = orc.nerfacto_losses(res, tgt.to(dtype), cfg)
+            sum(losses.values()).backward()
+            return prm, res, losses
+
+        oparams, out, ld = oracle(torch.float32)          # the reference's own arithmetic (torch path, fp32)
+        truth = oracle(torch.float64)[0]                  # the same graph in float64: the arbiter for the gradients
         err = float(np.abs(got_rgb - out["rgb"].detach().numpy()).max())
         assert err <= 1e-4, f"rgb L-inf {err:.2e} (updated={forced})"
         for k in ("rgb_loss", "interlevel_loss", "distortion_loss"):
             np.testing.assert_allclose(got_losses[k], float(ld[k]), rtol=5e-4, atol=1e-9, err_msg=f"{k} (updated={forced})")
-        report = {}
+        # Gradients, per tensor (the main table per LEVEL: queue capacities and the fixed-point scale are per level).
+        # Two fp32 evaluations of this graph differ by 1e-6-level forward differences that flip the ReLU of the occasional
+        # ~0 pre-activation, and each flip moves the gradient of its sample by a finite amount (tests/test_gpu_kernels.py::
+        # gclose_e2e) — with N(0, 0.3) tables the REFERENCE's own fp32 gradient is 0.3-1 % (relative L2) away from the
+        # float64 evaluation of the same graph. So the float64 gradient is the arbiter: the kernels must be as close to
+        # it as the fp32 reference is (<= 2x its distance, floor 1e-3), and within 2e-2 of the fp32 reference itself.
+        report, bad = {}, []
+
+        def check(name, got, ref32, ref64):
+            if np.abs(ref64).max() == 0.0:  # an exact zero must be an exact zero
+                report[name] = (float(np.abs(got).max()), 0.0, 0.0)
+                if np.abs(got).max() != 0.0:
+                    bad.append(name)
+                return
+            e_gpu, e_ref, e_pair = _rel_l2(got, ref64), _rel_l2(ref32, ref64), _rel_l2(got, ref32)
+            report[name] = (e_gpu, e_ref, e_pair)
+            if not (e_gpu <= max(2.0 * e_ref, 1e-3) and e_pair <= 2e-2):
+                bad.append(name)
+
         for k in keys:
             ref = oparams[k].grad
             if k.startswith("proposal_networks") and not forced:
                 assert ref is None or float(ref.abs().max()) == 0.0
                 continue
-            ref = ref.numpy()
-            if k == "field.mlp_base.model.0.hash_table":  # every level on its own (queue capacities differ per level)
+            r32, r64 = ref.numpy(), truth[k].grad.numpy()
+            if k == "field.mlp_base.model.0.hash_table":
                 T = 1 << cfg.main_grid.log2_hashmap_size
                 for lvl in range(cfg.main_grid.num_levels):
-                    a, b = grads[k][lvl * T:(lvl + 1) * T], ref[lvl * T:(lvl + 1) * T]
-                    report[f"{k}[level {lvl}]"] = _rel_l2(a, b) if np.abs(b).max() > 0 else float(np.abs(a).max())
-            elif np.abs(ref).max() == 0.0:
-                report[k] = float(np.abs(grads[k]).max())  # must be an exact zero as well
+                    sl = slice(lvl * T, (lvl + 1) * T)
+                    check(f"{k}[level {lvl}]", grads[k][sl], r32[sl], r64[sl])
             else:
-                report[k] = _rel_l2(grads[k], ref)
-        worst = max(report.items(), key=lambda kv: kv[1])
-        # end-to-end gradients differ from the oracle's through 1e-6-level forward differences that flip the occasional
-        # ReLU of a ~0 pre-activation (tests/test_gpu_kernels.py::gclose_e2e): relative L2 <= 1e-2 per tensor / level
-        assert worst[1] <= 1e-2, f"updated={forced}: worst {worst}\n{report}"
+                check(k, grads[k], r32, r64)
+        worst = max(report.items(), key=lambda kv: kv[1][0])
+        assert not bad, (f"updated={forced}: {bad}\n" +
+                         "\n".join(f"  {n}: gpu-f64 {v[0]:.2e}  ref32-f64 {v[1]:.2e}  gpu-ref32 {v[2]:.2e}" for n, v in report.items()))
         checked.append((forced, err, worst))
     for ws in F._SCATTER_WS.values():
         ev = F.scatter_events(ws)
         assert ev[1] == 0 and ev[2] == 0, f"scatter records on an unordered path / lost: {ev}"
-    print("\nbench-size parity [init %s] (updated, rgb L-inf, worst gradient rel-L2):" % init, checked)
+    print("\nbench-size parity [init %s] (updated, rgb L-inf, worst tensor: (gpu-f64, ref32-f64, gpu-ref32) rel-L2):" % init, checked)
 
 
 def test_graph_replay_trains_through_the_same_bits_as_eager_launches(F):
