@@ -128,8 +128,12 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
       for (int i = lane; i < S; i += 64) ddensity[ray * S + i] = (tb[i + 1] - tb[i]) * 0.0f;
       return;
     }
-    // some ray of this launch carries gradient: the rest of the level's backward chain has work to do
-    if (gate_out != nullptr && lane == 0) __hip_atomic_store(gate_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // some ray of this launch carries gradient: the rest of the level's backward chain has work to do. A PLAIN store of
+    // the same value from every carrying wave (merged in the L2s, written back at the end of the kernel, which is what the
+    // consumers — later kernels on the stream — need): write-through / atomic stores to ONE address are one fabric write
+    // each (~88 per us chip-wide, MI355X_MICROARCH.md) — 4096 carrying rays cost tens of us that way (measured).
+    if (gate_out != nullptr && lane == 0 && *reinterpret_cast<volatile uint32_t*>(gate_out) == 0u)
+      *reinterpret_cast<volatile uint32_t*>(gate_out) = 1u;
   }
   double carry = 0.0;
   for (int i0 = 0; i0 < S; i0 += 64) {
