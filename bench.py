@@ -115,6 +115,7 @@ class Trainer:
         # "sharded": reduce-scatter -> Adam on the rank's 1/N arena shard -> all-gather (dp_schedule.py); "allreduce": the
         # replicated optimiser behind an all-reduce (the reference's DDP semantics, and the default)
         self.dp_sharded = self.dp and dp_mode == "sharded"
+        self.dp_fork = False  # set below: proposal backward chains beside the main chain in the data-parallel schedule
         self.pool = pool  # BATCH_SLOTS pre-generated batches in HBM (None: one fixed batch)
         self.step = 0
         self.opt_step = 0
@@ -165,9 +166,12 @@ class Trainer:
 
                 # the pending main-field Adam waits for its all-reduce on its own stream, beside the next proposal forward
                 # (NSAMD_DP_UPDATE_STREAM=0: on the launch stream after it, the round-2 order)
-                upd = torch.cuda.Stream(device=dev) if os.environ.get("NSAMD_DP_UPDATE_STREAM", "1") == "1" else None
+                # (measured on a one-rank communicator, profiles/r03_dp_rehearsal.txt: 0.992 vs 0.969 ms — off by default)
+                upd = torch.cuda.Stream(device=dev) if os.environ.get("NSAMD_DP_UPDATE_STREAM", "0") == "1" else None
                 self.exchange = PipelinedExchange(arena, self._run, before_main_update=self._push_hyper,
                                                   sharded=self.dp_sharded, update_stream=upd)
+                # eager segments only (a captured segment must end with its streams joined); NSAMD_DP_FORK=0: round-2 order
+                self.dp_fork = os.environ.get("NSAMD_DP_FORK", "1") == "1" and self.runner.side_stream is not None
                 # the coarse levels of the main table can only ever touch 288 k of their 2.6 M rows: exchange those
                 # compactly (2.3 MB instead of 21 MB of the 67 MB main-field all-reduce)
                 enc = model.field.mlp_base.encoding
@@ -294,12 +298,23 @@ class Trainer:
             self._select_batch()
             r.forward_proposals(self.draw_jitter)
         elif name in (("main", True), ("main", False)):
-            a.zero_grad(["fields"], skip=r.written_params())
-            r.forward_main_and_losses(name[1])
-            r.backward_main()
+            if name[1] and self.dp_fork:
+                # update step, eager launches: the proposal chains start on their side streams here, beside the main chain
+                # (as in the N = 1 schedule) — and, since the exchange starts the main-field collective right after this
+                # segment, beside that too; "pbwd" only joins them
+                a.zero_grad(["fields", "proposal_networks"], skip=r.written_params())
+                r.forward_main_and_losses(True)
+                r.backward_fork(True)
+            else:
+                a.zero_grad(["fields"], skip=r.written_params())
+                r.forward_main_and_losses(name[1])
+                r.backward_main()
         elif name == "pbwd":
-            a.zero_grad(["proposal_networks"], skip=r.written_params())
-            r.backward_proposals()
+            if self.dp_fork:
+                r.backward_join(True)
+            else:
+                a.zero_grad(["proposal_networks"], skip=r.written_params())
+                r.backward_proposals()
         elif name in ("mopt", "popt"):
             grp = "fields" if name == "mopt" else "proposal_networks"
             if self.dp_sharded:  # this rank's 1/N of the group; the exchange all-gathers the updated parameters
@@ -381,6 +396,7 @@ class Trainer:
         if self.pipelined:
             from nerfstudio_amd.dp_schedule import SEGMENTS
 
+            self.dp_fork = False  # captured segments keep the proposal backward in its own segment
             for name in SEGMENTS:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):

@@ -132,15 +132,21 @@ int nsamd_hashgrid_encode_bwd_rays(nsamd_points pts, int64_t M, int transform, n
  *                               (finite parameters assumed), so the zero-filled gradients ARE the result. `denc` is
  *                               then not written and not read. With the gate raised they do what their ungated
  *                               forms do, bit for bit.
+ * `ray_mask` (nullable; [num_rays] bytes written by nsamd_weights_bwd_gate's `ray_mask_out`: 1 = the ray carries gradient)
+ * is the per-ray form of the flag for levels that are only PARTLY without gradient (measured on the benchmark run,
+ * profiles/r03_proposal_sparsity.txt: a few per cent of the rays between the dense phases): the gated kernels neither load
+ * nor write anything that belongs to a ray whose byte is 0 — density_mlp_bwd_gated skips the 256-point chunks without a
+ * marked ray (their `denc` stays unwritten), the scatter's route pass and the ray-gradient kernel treat such samples as
+ * the zeros they are. Ray mode only (pts.positions == NULL).
  * The gated scatter accumulates (the caller zero-fills dtable), needs the binned workspace and takes no dpositions. */
 int nsamd_hashgrid_encode_bwd_gated(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
                                     nsamd_grid grid, const float* denc, int64_t stride_p, int64_t stride_k,
                                     float* dtable, float* workspace, int64_t workspace_floats, const uint32_t* gate,
-                                    nsamd_stream_t stream);
+                                    const uint8_t* ray_mask, nsamd_stream_t stream);
 int nsamd_hashgrid_encode_bwd_rays_gated(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb,
                                          const float* table, nsamd_grid grid, const float* denc, int64_t stride_p,
                                          int64_t stride_k, float* d_origins, float* d_directions, int accumulate,
-                                         const uint32_t* gate, nsamd_stream_t stream);
+                                         const uint32_t* gate, const uint8_t* ray_mask, nsamd_stream_t stream);
 
 /* Words of scratch the binned scatter of nsamd_hashgrid_encode_bwd (write_only = 0) / nsamd_hashgrid_encode_bwd_set
  * (write_only = 1) wants for (grid, M); 0 when that path does not apply (M <= 0 or an unsupported grid). Host-only,
@@ -213,7 +219,7 @@ int nsamd_density_mlp_bwd(const float* enc, const float* selector, const float* 
 int nsamd_density_mlp_bwd_gated(const float* enc, const float* selector, const float* pre, const float* ddensity,
                                 int64_t M, nsamd_density_mlp mlp, float* denc, float* dW0, float* db0, float* dW1,
                                 float* db1, float* workspace, int64_t workspace_floats, const uint32_t* gate,
-                                nsamd_stream_t stream);
+                                const uint8_t* ray_mask, int32_t samples_per_ray, nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * nerfacto main field head (NerfactoField.get_density + get_outputs, fields/nerfacto_field.py:203-310):
@@ -326,7 +332,7 @@ int nsamd_weights_bwd(const float* t_bins, const float* density, const float* dw
                       int32_t S, float* ddensity, nsamd_stream_t stream);
 /* The same, and *gate_out = (any ray carries gradient) — see "zero-gradient gating" under the hash encoding. */
 int nsamd_weights_bwd_gate(const float* t_bins, const float* density, const float* dweights, int64_t num_rays,
-                           int32_t S, float* ddensity, uint32_t* gate_out, nsamd_stream_t stream);
+                           int32_t S, float* ddensity, uint32_t* gate_out, uint8_t* ray_mask_out, nsamd_stream_t stream);
 
 /* PDFSampler.generate_ray_samples (ray_samplers.py:276-372) preceded by the anneal pow(weights, anneal)
  * (ray_samplers.py:601; skipped when anneal == 1). include_original = 0: s_bins / t_bins are [num_rays, S+1] (the
@@ -433,6 +439,10 @@ typedef struct nsamd_occgrid {
   int32_t levels;
   int32_t resolution;
   float aabb[6];           /* region of interest: min xyz, max xyz */
+  const uint32_t* coarse;  /* nullable: one bit per 4x4x4 block of cells and level (nsamd_occgrid_binarise writes it;
+                              nsamd_occgrid_coarse_words(levels, resolution) words, bit b of word w = block 32 w + b in
+                              [level, bx, by, bz] order). The marcher stages it in LDS and skips the byte grid for steps
+                              whose block is empty — same samples, by construction. */
 } nsamd_occgrid;
 
 /* Ray marching through the occupancy grid, two calls: _count fills counts[N] (int32), nsamd_packed_info turns them into
@@ -447,6 +457,23 @@ int nsamd_occgrid_march_write(const float* origins, const float* directions, con
                               int64_t num_rays, float near_plane, float far_plane, nsamd_occgrid grid, float step_size,
                               float cone_angle, const float* jitter, const int64_t* packed_info, int64_t* ray_indices,
                               float* t_starts, float* t_ends, nsamd_stream_t stream);
+
+/* Occupancy-grid maintenance — what nerfacc's OccGridEstimator.update_every_n_steps does around `occ_eval_fn` (call site
+ * models/instant_ngp.py:151-156; nerfacc 0.5.2 restated, see above):
+ *   _cell_positions   positions [M,3] inside the cells `cells` [M] (flat index over [levels, R, R, R]; NULL: cell i = i) at
+ *                     the fractional offsets jitter [M,3] in [0,1) — the points the density is evaluated at;
+ *   _update           occs[c] = max(occs[c] * ema_decay, the new estimates of cell c)  for the listed cells (repeats
+ *                     allowed, the result does not depend on the thread order); scratch: total_cells floats;
+ *   _binarise         binaries = occs > min(mean(occs), occ_thre) (mean in double, fixed summation order) and the coarse
+ *                     bitfield of the result (nullable); scratch: 1024 doubles; threshold_out (nullable) [2] = (threshold,
+ *                     mean) in device memory. */
+int64_t nsamd_occgrid_coarse_words(int32_t levels, int32_t resolution);
+int nsamd_occgrid_cell_positions(const int64_t* cells, int64_t M, nsamd_occgrid grid, const float* jitter, float* positions,
+                                 nsamd_stream_t stream);
+int nsamd_occgrid_update(float* occs, int64_t total_cells, const int64_t* cells, const float* occ_new, int64_t M,
+                         float ema_decay, float* scratch, nsamd_stream_t stream);
+int nsamd_occgrid_binarise(const float* occs, int32_t levels, int32_t resolution, float occ_thre, uint8_t* binaries,
+                           uint32_t* coarse, double* scratch, float* threshold_out, nsamd_stream_t stream);
 
 /* nerfacc.pack_info from per-ray counts: packed_info [N,2] int64 and total[0] (device int64) = number of samples. */
 int nsamd_packed_info(const int32_t* counts, int64_t num_rays, int64_t* packed_info, int64_t* total, nsamd_stream_t stream);

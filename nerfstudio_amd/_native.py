@@ -49,7 +49,7 @@ class FieldMlp(C.Structure):
 
 
 class OccGrid(C.Structure):
-    _fields_ = [("binaries", vp), ("levels", i32), ("resolution", i32), ("aabb", f32 * 6)]
+    _fields_ = [("binaries", vp), ("levels", i32), ("resolution", i32), ("aabb", f32 * 6), ("coarse", vp)]
 
 
 class FieldMlpGrads(C.Structure):
@@ -64,8 +64,8 @@ _SIGNATURES = {
     "nsamd_hashgrid_encode_bwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, vp, i64, vp],
     "nsamd_hashgrid_encode_bwd_set": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, vp, i64, vp],
     "nsamd_hashgrid_encode_bwd_rays": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, C.c_int, vp],
-    "nsamd_hashgrid_encode_bwd_gated": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, i64, vp, vp],
-    "nsamd_hashgrid_encode_bwd_rays_gated": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, C.c_int, vp, vp],
+    "nsamd_hashgrid_encode_bwd_gated": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, i64, vp, vp, vp],
+    "nsamd_hashgrid_encode_bwd_rays_gated": [Points, i64, C.c_int, Aabb, vp, Grid, vp, i64, i64, vp, vp, C.c_int, vp, vp, vp],
     "nsamd_hashgrid_encode_bwd_workspace": [Grid, i64, C.c_int],
     "nsamd_hashgrid_encode_bwd_workspace_state": [Grid, i64],
     "nsamd_hashgrid_scatter_events": [vp, vp, vp],
@@ -75,7 +75,7 @@ _SIGNATURES = {
     "nsamd_density_mlp_fwd": [vp, vp, i64, DensityMlp, vp, vp, vp],
     "nsamd_density_field_fwd": [Points, i64, C.c_int, Aabb, vp, Grid, DensityMlp, vp, vp, vp, vp, vp],
     "nsamd_density_mlp_bwd": [vp, vp, vp, vp, i64, DensityMlp, vp, vp, vp, vp, vp, vp, i64, vp],
-    "nsamd_density_mlp_bwd_gated": [vp, vp, vp, vp, i64, DensityMlp, vp, vp, vp, vp, vp, vp, i64, vp, vp],
+    "nsamd_density_mlp_bwd_gated": [vp, vp, vp, vp, i64, DensityMlp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp],
     "nsamd_field_mlp_fwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp],
     "nsamd_field_mlp_bwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp, i64, vp],
     "nsamd_field_fused_fwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, vp, vp, i64, FieldMlp, vp, vp, vp, vp, vp],
@@ -88,7 +88,7 @@ _SIGNATURES = {
     "nsamd_piecewise_bins": [vp, vp, vp, vp, i32, i64, i32, C.c_int, vp, vp, vp],
     "nsamd_weights_fwd": [vp, vp, i64, i32, vp, vp],
     "nsamd_weights_bwd": [vp, vp, vp, i64, i32, vp, vp],
-    "nsamd_weights_bwd_gate": [vp, vp, vp, i64, i32, vp, vp, vp],
+    "nsamd_weights_bwd_gate": [vp, vp, vp, i64, i32, vp, vp, vp, vp],
     "nsamd_pdf_resample": [vp, vp, i32, vp, vp, vp, vp, f32, vp, f32, f32, f32, C.c_int, i32, i32, i64, i32, vp, vp, vp, vp],
     "nsamd_proposal_resample": [vp, vp, vp, i32, vp, vp, vp, vp, f32, vp, f32, f32, f32, C.c_int, i64, i32, vp, vp, vp, vp, vp],
     "nsamd_composite_fwd": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), C.c_int, vp, vp, vp, vp, vp, vp, vp],
@@ -101,6 +101,10 @@ _SIGNATURES = {
     "nsamd_proposal_losses": [vp, vp, i32, i32, vp, vp, vp, i64, f32, f32, vp, vp, vp, vp, vp],
     "nsamd_occgrid_march_count": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp],
     "nsamd_occgrid_march_write": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp, vp, vp, vp],
+    "nsamd_occgrid_coarse_words": [i32, i32],
+    "nsamd_occgrid_cell_positions": [vp, i64, OccGrid, vp, vp, vp],
+    "nsamd_occgrid_update": [vp, i64, vp, vp, i64, f32, vp, vp],
+    "nsamd_occgrid_binarise": [vp, i32, i32, f32, vp, vp, vp, vp, vp],
     "nsamd_packed_info": [vp, i64, vp, vp, vp],
     "nsamd_packed_weights_fwd": [vp, vp, vp, vp, i64, vp, vp, vp],
     "nsamd_packed_weights_bwd": [vp, vp, vp, vp, vp, i64, vp, vp],
@@ -121,7 +125,8 @@ _SIGNATURES = {
     "nsamd_probe_mfma_bf16": [vp, vp, vp, vp],
 }
 _RESTYPES = {"nsamd_version": C.c_char_p, "nsamd_status_string": C.c_char_p,
-             "nsamd_hashgrid_encode_bwd_workspace": C.c_int64, "nsamd_hashgrid_encode_bwd_workspace_state": C.c_int64, "nsamd_field_mlp_saved_floats": C.c_int64}
+             "nsamd_hashgrid_encode_bwd_workspace": C.c_int64, "nsamd_hashgrid_encode_bwd_workspace_state": C.c_int64, "nsamd_field_mlp_saved_floats": C.c_int64,
+             "nsamd_occgrid_coarse_words": C.c_int64}
 
 _lib = None
 ERR_UNSUPPORTED = -2  # nsamd_status NSAMD_ERR_UNSUPPORTED

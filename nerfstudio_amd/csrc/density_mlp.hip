@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ pre,
     const float* __restrict__ ddensity, int64_t M, nsamd_density_mlp mlp, float* __restrict__ denc,
     float* __restrict__ dW0, float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1,
-    float* __restrict__ partials, const uint32_t* __restrict__ gate) {
+    float* __restrict__ partials, const uint32_t* __restrict__ gate, const uint8_t* __restrict__ ray_mask, int spr) {
   // Gated call (nsamd_density_mlp_bwd_gated): the flag nsamd_weights_bwd_gate raises when any ray of the level carries
   // gradient is clear -> every upstream gradient is an exact zero, so are all results of this launch; the zero-filled
   // weight gradients stay as they are and nothing downstream (gated the same way) reads `denc`.
@@ -172,9 +172,21 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
   // inputs are fetched during the latter, otherwise every chunk starts with an exposed HBM round trip.
   float x_next[IN];
   float gd_next = 0.0f, sel_next = 1.0f, pre_next = 0.0f;
+  // Gated call with a per-ray mask (nsamd_weights_bwd_gate): a chunk none of whose rays carries gradient is not even
+  // loaded — its density gradients are exact zeros, and the table scatter, which takes the same mask, never reads its
+  // `denc`. The predicate depends on the chunk only: uniform over the workgroup.
+  bool act_next = true;
+  auto chunk_active = [&](int64_t c) {
+    if (ray_mask == nullptr) return true;
+    const int64_t p0 = c * kMlpBlock, p1 = (p0 + kMlpBlock < M ? p0 + kMlpBlock : M) - 1;
+    bool any = false;
+    for (int64_t r = p0 / spr; r <= p1 / spr; ++r) any = any || ray_mask[r] != 0;
+    return any;
+  };
   auto fetch = [&](int64_t c) {
     const int64_t p = c * kMlpBlock + threadIdx.x;
-    const bool live = c < chunks && p < M;
+    act_next = c < chunks && chunk_active(c);
+    const bool live = act_next && p < M;
 #pragma unroll
     for (int k = 0; k < IN; ++k) x_next[k] = live ? enc[(int64_t)k * M + p] : 0.0f;
     gd_next = live ? ddensity[p] : 0.0f;
@@ -183,6 +195,10 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
   };
   fetch(blockIdx.x);
   for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    if (!act_next) {  // no ray of this chunk carries gradient (workgroup-uniform): nothing to add, nothing to write
+      fetch(c + gridDim.x);
+      continue;
+    }
     const int64_t p = c * kMlpBlock + threadIdx.x;
     const bool live = p < M;
     float x[IN];
@@ -337,7 +353,8 @@ static int launch_fwd(const float* enc, const float* selector, int64_t M, nsamd_
 template <int IN, int H>
 static int launch_bwd(const float* enc, const float* selector, const float* pre, const float* ddensity, int64_t M,
                       nsamd_density_mlp mlp, float* denc, float* dW0, float* db0, float* dW1, float* db1,
-                      float* workspace, int64_t workspace_floats, const uint32_t* gate, hipStream_t stream) {
+                      float* workspace, int64_t workspace_floats, const uint32_t* gate, const uint8_t* ray_mask, int spr,
+                      hipStream_t stream) {
   const unsigned blocks = (unsigned)min((int64_t)kMaxBlocks, (M + kMlpBlock - 1) / kMlpBlock);
   const size_t lds = sizeof(float) * ((size_t)(2 * H + IN + 1) * (kMlpBlock + 1) + 8 + (size_t)H * (((IN + 3) & ~3) + 2));
   if (lds > 64 * 1024) {  // per-device opt-in; cheap enough to repeat
@@ -348,7 +365,7 @@ static int launch_bwd(const float* enc, const float* selector, const float* pre,
   constexpr int stride = density_partial_stride(IN, H);
   float* partials = (workspace != nullptr && workspace_floats >= (int64_t)blocks * stride) ? workspace : nullptr;
   density_mlp_bwd_kernel<IN, H><<<blocks, kMlpBlock, lds, stream>>>(enc, selector, pre, ddensity, M, mlp, denc, dW0,
-                                                                   db0, dW1, db1, partials, gate);
+                                                                   db0, dW1, db1, partials, gate, ray_mask, spr);
   NSAMD_CHECK_LAUNCH();
   if (partials != nullptr) {
     const int total = H * IN + 2 * H + 1;
@@ -423,7 +440,7 @@ extern "C" int nsamd_density_mlp_bwd(const float* enc, const float* selector, co
   NSAMD_REQUIRE(enc && pre && ddensity && denc && dW0 && db0 && dW1 && db1 && mlp.W0 && mlp.b0 && mlp.W1 && mlp.b1);
 #define CALL(IN, H)                                                                                          \
   launch_bwd<IN, H>(enc, selector, pre, ddensity, M, mlp, denc, dW0, db0, dW1, db1, workspace, workspace_floats, \
-                    nullptr, (hipStream_t)stream)
+                    nullptr, nullptr, 1, (hipStream_t)stream)
   NSAMD_DENSITY_DISPATCH(CALL)
 #undef CALL
 }
@@ -431,13 +448,15 @@ extern "C" int nsamd_density_mlp_bwd(const float* enc, const float* selector, co
 extern "C" int nsamd_density_mlp_bwd_gated(const float* enc, const float* selector, const float* pre,
                                            const float* ddensity, int64_t M, nsamd_density_mlp mlp, float* denc,
                                            float* dW0, float* db0, float* dW1, float* db1, float* workspace,
-                                           int64_t workspace_floats, const uint32_t* gate, nsamd_stream_t stream) {
+                                           int64_t workspace_floats, const uint32_t* gate, const uint8_t* ray_mask,
+                                           int32_t samples_per_ray, nsamd_stream_t stream) {
   NSAMD_REQUIRE(M >= 0 && gate != nullptr);
+  NSAMD_REQUIRE(ray_mask == nullptr || (samples_per_ray > 0 && M % samples_per_ray == 0));
   if (M == 0) return NSAMD_OK;
   NSAMD_REQUIRE(enc && pre && ddensity && denc && dW0 && db0 && dW1 && db1 && mlp.W0 && mlp.b0 && mlp.W1 && mlp.b1);
 #define CALL(IN, H)                                                                                          \
   launch_bwd<IN, H>(enc, selector, pre, ddensity, M, mlp, denc, dW0, db0, dW1, db1, workspace, workspace_floats, \
-                    gate, (hipStream_t)stream)
+                    gate, ray_mask, ray_mask ? samples_per_ray : 1, (hipStream_t)stream)
   NSAMD_DENSITY_DISPATCH(CALL)
 #undef CALL
 }

@@ -339,11 +339,13 @@ __global__ __launch_bounds__(kHashBlock) void hash_encode_bwd_pos_kernel(
 __global__ __launch_bounds__(256) void hash_encode_bwd_rays_kernel(
     nsamd_points P, int64_t num_rays, int transform, nsamd_aabb box, const float2* __restrict__ table, nsamd_grid grid,
     const float* __restrict__ denc, int64_t stride_p, int64_t stride_k, float* __restrict__ d_origins,
-    float* __restrict__ d_directions, int accumulate, const uint32_t* __restrict__ gate) {
+    float* __restrict__ d_directions, int accumulate, const uint32_t* __restrict__ gate,
+    const uint8_t* __restrict__ ray_mask) {
   const int lane = threadIdx.x & 63;
   const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= num_rays) return;
-  if (gate != nullptr && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+  if ((gate != nullptr && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) ||
+      (ray_mask != nullptr && ray_mask[ray] == 0)) {
     // gated call, no gradient on this level: `denc` (not written) stands for zeros, so do the ray gradients
     if (!accumulate && lane < 3) {
       d_origins[3 * ray + lane] = 0.0f;
@@ -505,7 +507,7 @@ extern "C" int nsamd_hashgrid_encode_fwd(nsamd_points pts, int64_t M, int transf
 static int hashgrid_encode_bwd_impl(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
                                     nsamd_grid grid, const float* denc, int64_t stride_p, int64_t stride_k,
                                     float* dtable, float* dpositions, float* workspace, int64_t workspace_floats,
-                                    bool overwrite, const uint32_t* gate, nsamd_stream_t stream) {
+                                    bool overwrite, const uint32_t* gate, const uint8_t* ray_mask, nsamd_stream_t stream) {
   if (M == 0 && !overwrite) return NSAMD_OK;
   int st = check_points(pts, M);
   if (st) return st;
@@ -535,7 +537,7 @@ static int hashgrid_encode_bwd_impl(nsamd_points pts, int64_t M, int transform, 
   if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
   if (dtable != nullptr && plan.ok) {
     st = scatter_launch(pts, M, transform, aabb, grid, denc, stride_p, stride_k, dtable, workspace, plan, overwrite,
-                        gate, (hipStream_t)stream);
+                        gate, ray_mask, (hipStream_t)stream);
     if (st) return st;
   } else if (gate != nullptr) {
     return NSAMD_ERR_INVALID_ARG;  // gated calls exist for the binned scatter only (the training step's workspaces)
@@ -580,17 +582,17 @@ extern "C" int nsamd_hashgrid_encode_bwd(nsamd_points pts, int64_t M, int transf
                                          int64_t stride_k, float* dtable, float* dpositions, float* workspace,
                                          int64_t workspace_floats, nsamd_stream_t stream) {
   return hashgrid_encode_bwd_impl(pts, M, transform, aabb, table, grid, denc, stride_p, stride_k, dtable, dpositions,
-                                  workspace, workspace_floats, false, nullptr, stream);
+                                  workspace, workspace_floats, false, nullptr, nullptr, stream);
 }
 
 extern "C" int nsamd_hashgrid_encode_bwd_gated(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb,
                                                const float* table, nsamd_grid grid, const float* denc,
                                                int64_t stride_p, int64_t stride_k, float* dtable, float* workspace,
                                                int64_t workspace_floats, const uint32_t* gate,
-                                               nsamd_stream_t stream) {
+                                               const uint8_t* ray_mask, nsamd_stream_t stream) {
   NSAMD_REQUIRE(gate != nullptr && dtable != nullptr && workspace != nullptr);
   return hashgrid_encode_bwd_impl(pts, M, transform, aabb, table, grid, denc, stride_p, stride_k, dtable, nullptr,
-                                  workspace, workspace_floats, false, gate, stream);
+                                  workspace, workspace_floats, false, gate, ray_mask, stream);
 }
 
 extern "C" int nsamd_hashgrid_encode_bwd_set(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb,
@@ -598,7 +600,7 @@ extern "C" int nsamd_hashgrid_encode_bwd_set(nsamd_points pts, int64_t M, int tr
                                              int64_t stride_k, float* dtable, float* dpositions, float* workspace,
                                              int64_t workspace_floats, nsamd_stream_t stream) {
   return hashgrid_encode_bwd_impl(pts, M, transform, aabb, table, grid, denc, stride_p, stride_k, dtable, dpositions,
-                                  workspace, workspace_floats, true, nullptr, stream);
+                                  workspace, workspace_floats, true, nullptr, nullptr, stream);
 }
 
 extern "C" int nsamd_hashgrid_encode_bwd_rays(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb,
@@ -606,14 +608,14 @@ extern "C" int nsamd_hashgrid_encode_bwd_rays(nsamd_points pts, int64_t M, int t
                                               int64_t stride_k, float* d_origins, float* d_directions, int accumulate,
                                               nsamd_stream_t stream) {
   return nsamd_hashgrid_encode_bwd_rays_gated(pts, M, transform, aabb, table, grid, denc, stride_p, stride_k, d_origins,
-                                              d_directions, accumulate, nullptr, stream);
+                                              d_directions, accumulate, nullptr, nullptr, stream);
 }
 
 extern "C" int nsamd_hashgrid_encode_bwd_rays_gated(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb,
                                                     const float* table, nsamd_grid grid, const float* denc,
                                                     int64_t stride_p, int64_t stride_k, float* d_origins,
                                                     float* d_directions, int accumulate, const uint32_t* gate,
-                                                    nsamd_stream_t stream) {
+                                                    const uint8_t* ray_mask, nsamd_stream_t stream) {
   if (M == 0) return NSAMD_OK;
   int st = check_points(pts, M);
   if (st) return st;
@@ -627,7 +629,7 @@ extern "C" int nsamd_hashgrid_encode_bwd_rays_gated(nsamd_points pts, int64_t M,
   if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
   hash_encode_bwd_rays_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(
       pts, rays, transform, aabb, reinterpret_cast<const float2*>(table), grid, denc, stride_p, stride_k, d_origins,
-      d_directions, accumulate ? 1 : 0, gate);
+      d_directions, accumulate ? 1 : 0, gate, ray_mask);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

@@ -51,20 +51,44 @@ __device__ __forceinline__ bool ray_box(const float o[3], const float d[3], cons
   return a <= b;
 }
 
+// One WAVEFRONT per ray. The lattice of a ray is defined by the sequential fp32 recurrence
+//     t_0 = max(near, box entry) [+ jitter * step],   dt_k = clamp(t_k * cone_angle, step, 1e10),   t_{k+1} = t_k + dt_k
+// (what one thread per ray walks in oracle/packed_oracle.py::occgrid_march). 64 consecutive steps are handled per trip:
+// lane j re-runs the recurrence j times from the trip's first step (63 masked iterations of 4 dependent VALU ops in
+// lock-step: the SAME fp32 operations in the same order as the scalar walk, hence bit-identical t_k), then all 64 lanes
+// do their cell lookups at once — ONE memory latency per 64 steps instead of one per step — a ballot gives the kept
+// steps, a popcount prefix their packed slots. Round 2 walked a ray per THREAD: 4096 rays = 64 wavefronts on a
+// 1024-SIMD chip, each step behind its own L2 round trip.
+//
+// Empty-space skipping: `coarse` (nullable) is a bitfield with one bit per 4x4x4 block of cells and level
+// (nsamd_occgrid_binarise builds it beside the binaries: 4 KiB per level at R = 128), staged in LDS by the workgroup. A
+// lane whose block is empty knows its cell is empty without touching the 2 MiB-per-level byte grid — the result is the
+// same by construction (an empty block has no occupied cell).
+constexpr int kMarchThreads = 512;
+constexpr int kMarchWaves = kMarchThreads / 64;
+constexpr int kCoarseShift = 2;  // 4^3 cells per coarse block
+
 template <bool kWrite>
-__global__ __launch_bounds__(kPackThreads) void occgrid_march_kernel(
+__global__ __launch_bounds__(kMarchThreads) void occgrid_march_kernel(
     const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ t_min,
     const float* __restrict__ t_max, int64_t num_rays, float near_plane, float far_plane, nsamd_occgrid grid, float step,
     float cone_angle, const float* __restrict__ jitter, int32_t* __restrict__ counts, const int64_t* __restrict__ starts,
-    int64_t* __restrict__ ray_indices, float* __restrict__ t_starts, float* __restrict__ t_ends) {
-  const int64_t ray = (int64_t)blockIdx.x * kPackThreads + threadIdx.x;
-  if (ray >= num_rays) return;
+    int64_t* __restrict__ ray_indices, float* __restrict__ t_starts, float* __restrict__ t_ends, int coarse_words) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t coarse_lds[];
+  const int R = grid.resolution, L = grid.levels;
+  const bool use_coarse = grid.coarse != nullptr && coarse_words > 0;
+  if (use_coarse) {
+    for (int i = threadIdx.x; i < coarse_words; i += kMarchThreads) coarse_lds[i] = grid.coarse[i];
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * kMarchWaves + (threadIdx.x >> 6);
+  if (ray >= num_rays) return;  // wave-uniform; no workgroup barrier below
   const float o[3] = {origins[3 * ray], origins[3 * ray + 1], origins[3 * ray + 2]};
   const float d[3] = {directions[3 * ray], directions[3 * ray + 1], directions[3 * ray + 2]};
   float t_lo = near_plane, t_hi = far_plane;
   if (t_min != nullptr) t_lo = fmaxf(t_lo, t_min[ray]);
   if (t_max != nullptr) t_hi = fminf(t_hi, t_max[ray]);
-  const int R = grid.resolution, L = grid.levels;
   float centre[3], half[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -78,6 +102,7 @@ __global__ __launch_bounds__(kPackThreads) void occgrid_march_kernel(
     lo[k] = centre[k] - half[k] * outer;
     hi[k] = centre[k] + half[k] * outer;
   }
+  const int RC = R >> kCoarseShift;  // coarse blocks per axis
   int32_t n = 0;
   int64_t out = kWrite ? starts[2 * ray] : 0;  // packed_info [N,2]: (start, count)
   float ta, tb;
@@ -85,44 +110,67 @@ __global__ __launch_bounds__(kPackThreads) void occgrid_march_kernel(
     float t = fmaxf(t_lo, ta);
     const float t_end = fminf(t_hi, tb);
     if (jitter != nullptr) t += jitter[ray] * step;  // stratified: the whole lattice of the ray shifts by U[0,1) * step
-    for (int it = 0; it < (1 << 20) && t < t_end; ++it) {
-      float dt = t * cone_angle;
+    for (int it = 0; it < (1 << 20) && t < t_end; it += 64) {
+      // lane j: t_{it + j} by j applications of the recurrence (all lanes in lock-step, the surplus masked)
+      float tj = t;
+#pragma unroll 7
+      for (int i = 0; i < 63; ++i) {
+        float dti = tj * cone_angle;
+        dti = fminf(fmaxf(dti, step), 1e10f);
+        const float nt = tj + dti;
+        tj = i < lane ? nt : tj;
+      }
+      float dt = tj * cone_angle;
       dt = fminf(fmaxf(dt, step), 1e10f);
-      const float mid = t + dt * 0.5f;
-      const float p[3] = {o[0] + d[0] * mid, o[1] + d[1] * mid, o[2] + d[2] * mid};
-      // finest level whose box holds the midpoint
-      float m = 0.0f;
+      const bool live = tj < t_end && it + lane < (1 << 20);
+      bool keep = false;
+      if (live) {
+        const float mid = tj + dt * 0.5f;
+        const float p[3] = {o[0] + d[0] * mid, o[1] + d[1] * mid, o[2] + d[2] * mid};
+        // finest level whose box holds the midpoint
+        float m = 0.0f;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) m = fmaxf(m, fabsf(p[k] - centre[k]) / half[k]);
-      int level = 0;
-      float scale = 1.0f;
-      while (level < L - 1 && m > scale) {
-        scale *= 2.0f;
-        ++level;
-      }
-      if (m <= scale) {
-        int c[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float u = (p[k] - (centre[k] - half[k] * scale)) / (2.0f * half[k] * scale) * (float)R;
-          int ci = (int)floorf(u);
-          c[k] = ci < 0 ? 0 : (ci >= R ? R - 1 : ci);
+        for (int k = 0; k < 3; ++k) m = fmaxf(m, fabsf(p[k] - centre[k]) / half[k]);
+        int level = 0;
+        float scale = 1.0f;
+        while (level < L - 1 && m > scale) {
+          scale *= 2.0f;
+          ++level;
         }
-        const size_t cell = (((size_t)level * R + c[0]) * R + c[1]) * R + c[2];
-        if (grid.binaries[cell]) {
-          if (kWrite) {
-            ray_indices[out] = ray;
-            t_starts[out] = t;
-            t_ends[out] = t + dt;
-            ++out;
+        if (m <= scale) {
+          int c[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float u = (p[k] - (centre[k] - half[k] * scale)) / (2.0f * half[k] * scale) * (float)R;
+            int ci = (int)floorf(u);
+            c[k] = ci < 0 ? 0 : (ci >= R ? R - 1 : ci);
           }
-          ++n;
+          bool maybe = true;
+          if (use_coarse) {
+            const int cb = ((level * RC + (c[0] >> kCoarseShift)) * RC + (c[1] >> kCoarseShift)) * RC + (c[2] >> kCoarseShift);
+            maybe = (coarse_lds[cb >> 5] >> (cb & 31)) & 1u;
+          }
+          if (maybe) {
+            const size_t cell = (((size_t)level * R + c[0]) * R + c[1]) * R + c[2];
+            keep = grid.binaries[cell] != 0;
+          }
         }
       }
-      t += dt;
+      const unsigned long long kept = __ballot(keep);
+      if (kWrite && keep) {
+        const int64_t slot = out + __builtin_popcountll(kept & ((1ull << lane) - 1ull));
+        ray_indices[slot] = ray;
+        t_starts[slot] = tj;
+        t_ends[slot] = tj + dt;
+      }
+      const int c64 = __builtin_popcountll(kept);
+      out += c64;
+      n += c64;
+      // first step of the next trip: t_{it + 64} = t_{it + 63} + dt_{it + 63}
+      t = __shfl(tj + dt, 63);
     }
   }
-  if (!kWrite) counts[ray] = n;
+  if (!kWrite && lane == 0) counts[ray] = n;
 }
 
 // counts [N] int32 -> packed_info [N,2] int64 (start, count) and the total in total_out[0]; one workgroup.
@@ -342,6 +390,119 @@ __global__ void packed_positions_kernel(const float* __restrict__ origins, const
 
 static unsigned pack_ray_blocks(int64_t rays) { return (unsigned)((rays + kPackWaves - 1) / kPackWaves); }
 
+// ---- occupancy-grid maintenance (nerfacc OccGridEstimator.update_every_n_steps / _update) ---------------------------
+// x[i] = position inside cell `cells[i]` (flat index over [levels, R, R, R]; nullptr: cell i) at the fractional offset
+// jitter[i] in [0,1)^3: level l covers the region of interest scaled by 2^l about its centre.
+__global__ __launch_bounds__(256) void occgrid_cell_positions_kernel(const int64_t* __restrict__ cells, int64_t M,
+                                                                     nsamd_occgrid grid, const float* __restrict__ jitter,
+                                                                     float* __restrict__ x) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const int64_t R = grid.resolution, per = R * R * R;
+  const int64_t flat = cells != nullptr ? cells[i] : i;
+  const int64_t level = flat / per, cell = flat - level * per;
+  const int64_t ix[3] = {cell / (R * R), (cell / R) % R, cell % R};
+  const float grow = (float)(1 << (int)level);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float u = ((float)ix[k] + jitter[3 * i + k]) / (float)R;  // in [0,1) of the level's box
+    const float centre = (grid.aabb[k] + grid.aabb[3 + k]) / 2.0f;
+    const float half = (grid.aabb[3 + k] - grid.aabb[k]) / 2.0f * grow;
+    x[3 * i + k] = (centre - half) + (u * 2.0f) * half;
+  }
+}
+
+// occs[c] = max(old[c] * decay, every new estimate of c): `old` is a snapshot of occs taken before the call, so repeated
+// cells (the refresh draws random cells WITH replacement) all write the same decayed value, and the estimates — all
+// >= 0, so their float bits order like integers — are folded in with an integer atomicMax: the result does not depend
+// on the order of the threads. NaN estimates (a diverged field) compare above every number and stay.
+__global__ __launch_bounds__(256) void occgrid_decay_kernel(float* __restrict__ occs, const float* __restrict__ old,
+                                                            const int64_t* __restrict__ cells, int64_t M, float decay) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const int64_t c = cells != nullptr ? cells[i] : i;
+  occs[c] = old[c] * decay;
+}
+__global__ __launch_bounds__(256) void occgrid_max_kernel(float* __restrict__ occs, const int64_t* __restrict__ cells,
+                                                          const float* __restrict__ occ_new, int64_t M) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const int64_t c = cells != nullptr ? cells[i] : i;
+  const float v = fmaxf(occ_new[i], 0.0f);  // (NaN -> 0 under fmaxf; estimates are density x step >= 0)
+  atomicMax(reinterpret_cast<int*>(occs) + c, __float_as_int(occ_new[i] != occ_new[i] ? occ_new[i] : v));
+}
+
+// mean(occs) in double with a fixed summation order (kSumBlocks contiguous ranges, a fixed tree inside each, the partials
+// added in index order), threshold = min(mean, occ_thre) rounded to fp32 once, binaries = occs > threshold, and the
+// coarse bitfield the marcher stages in LDS (one bit per 4x4x4 block of cells).
+constexpr int kSumBlocks = 1024;
+__global__ __launch_bounds__(256) void occgrid_sum_kernel(const float* __restrict__ occs, int64_t total,
+                                                          double* __restrict__ partial) {
+  __shared__ double red[256];
+  const int64_t per = (total + kSumBlocks - 1) / kSumBlocks;
+  const int64_t a = (int64_t)blockIdx.x * per, b = a + per < total ? a + per : total;
+  double s = 0.0;
+  for (int64_t i = a + threadIdx.x; i < b; i += 256) s += (double)occs[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void occgrid_binarise_kernel(const float* __restrict__ occs, int64_t total, float occ_thre,
+                                                               const double* __restrict__ partial,
+                                                               uint8_t* __restrict__ binaries, float* __restrict__ thre_out) {
+  __shared__ float thre_s;
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int k = 0; k < kSumBlocks; ++k) s += partial[k];
+    const double mean = s / (double)total;
+    thre_s = (float)(mean < (double)occ_thre ? mean : (double)occ_thre);
+    if (blockIdx.x == 0 && thre_out != nullptr) {
+      thre_out[0] = thre_s;
+      thre_out[1] = (float)mean;
+    }
+  }
+  __syncthreads();
+  const float thre = thre_s;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    binaries[i] = occs[i] > thre ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void occgrid_coarse_kernel(const uint8_t* __restrict__ binaries, int levels, int R,
+                                                             uint32_t* __restrict__ coarse, int words) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= words) return;
+  const int RC = R >> kCoarseShift;
+  const int blocks = levels * RC * RC * RC;
+  uint32_t bits = 0u;
+  for (int b = 0; b < 32; ++b) {
+    const int cb = w * 32 + b;
+    if (cb >= blocks) break;
+    const int level = cb / (RC * RC * RC), r = cb % (RC * RC * RC);
+    const int bx = r / (RC * RC), by = (r / RC) % RC, bz = r % RC;
+    bool any = false;
+    for (int x = 0; x < (1 << kCoarseShift) && !any; ++x)
+      for (int y = 0; y < (1 << kCoarseShift) && !any; ++y) {
+        // 4 consecutive cells along z = one aligned 32-bit word of the byte grid
+        const size_t cell = (((size_t)level * R + (bx << kCoarseShift) + x) * R + (by << kCoarseShift) + y) * R + (bz << kCoarseShift);
+        any = *reinterpret_cast<const uint32_t*>(binaries + cell) != 0u;
+      }
+    bits |= any ? 1u << b : 0u;
+  }
+  coarse[w] = bits;
+}
+
+// words of the coarse bitfield the marcher can use for this grid (0: none — no coarse pointer, a resolution that is not
+// a multiple of 4, or more than 64 KiB of bits)
+static int coarse_words(const nsamd_occgrid& g) {
+  if (g.coarse == nullptr || (g.resolution & ((1 << kCoarseShift) - 1)) != 0) return 0;
+  const int64_t rc = g.resolution >> kCoarseShift;
+  const int64_t words = ((int64_t)g.levels * rc * rc * rc + 31) / 32;
+  return words * 4 <= 64 * 1024 ? (int)words : 0;
+}
+
 static int check_grid_desc(const nsamd_occgrid& g) {
   if (g.binaries == nullptr || g.levels < 1 || g.levels > 8 || g.resolution < 1 || g.resolution > 1024)
     return NSAMD_ERR_INVALID_ARG;
@@ -363,11 +524,12 @@ extern "C" int nsamd_occgrid_march_count(const float* origins, const float* dire
   NSAMD_REQUIRE(origins && directions && counts);
   const int st = check_grid_desc(grid);
   if (st) return st;
-  const int64_t nb = (num_rays + kPackThreads - 1) / kPackThreads;
+  const int64_t nb = (num_rays + kMarchWaves - 1) / kMarchWaves;
   if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
-  occgrid_march_kernel<false><<<(unsigned)nb, kPackThreads, 0, (hipStream_t)stream>>>(
+  const int cw = coarse_words(grid);
+  occgrid_march_kernel<false><<<(unsigned)nb, kMarchThreads, sizeof(uint32_t) * (size_t)cw, (hipStream_t)stream>>>(
       origins, directions, t_min, t_max, num_rays, near_plane, far_plane, grid, step_size, cone_angle, jitter, counts,
-      nullptr, nullptr, nullptr, nullptr);
+      nullptr, nullptr, nullptr, nullptr, cw);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }
@@ -382,12 +544,70 @@ extern "C" int nsamd_occgrid_march_write(const float* origins, const float* dire
   NSAMD_REQUIRE(origins && directions && packed_info && ray_indices && t_starts && t_ends);
   const int st = check_grid_desc(grid);
   if (st) return st;
-  const int64_t nb = (num_rays + kPackThreads - 1) / kPackThreads;
+  const int64_t nb = (num_rays + kMarchWaves - 1) / kMarchWaves;
   if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
-  occgrid_march_kernel<true><<<(unsigned)nb, kPackThreads, 0, (hipStream_t)stream>>>(
+  const int cw = coarse_words(grid);
+  occgrid_march_kernel<true><<<(unsigned)nb, kMarchThreads, sizeof(uint32_t) * (size_t)cw, (hipStream_t)stream>>>(
       origins, directions, t_min, t_max, num_rays, near_plane, far_plane, grid, step_size, cone_angle, jitter, nullptr,
-      packed_info, ray_indices, t_starts, t_ends);
+      packed_info, ray_indices, t_starts, t_ends, cw);
   NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int64_t nsamd_occgrid_coarse_words(int32_t levels, int32_t resolution) {
+  nsamd_occgrid g{};
+  g.levels = levels;
+  g.resolution = resolution;
+  g.coarse = reinterpret_cast<const uint32_t*>(&g);  // (only tested against nullptr)
+  return coarse_words(g);
+}
+
+extern "C" int nsamd_occgrid_cell_positions(const int64_t* cells, int64_t M, nsamd_occgrid grid, const float* jitter,
+                                            float* positions, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(M >= 0);
+  if (M == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(jitter && positions && grid.levels >= 1 && grid.levels <= 8 && grid.resolution >= 1);
+  const int64_t nb = (M + 255) / 256;
+  if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
+  occgrid_cell_positions_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(cells, M, grid, jitter, positions);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_occgrid_update(float* occs, int64_t total_cells, const int64_t* cells, const float* occ_new, int64_t M,
+                                    float ema_decay, float* scratch, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(M >= 0 && total_cells > 0);
+  if (M == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(occs && occ_new && scratch);
+  const int64_t nb = (M + 255) / 256;
+  if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
+  if (hipMemcpyAsync(scratch, occs, sizeof(float) * (size_t)total_cells, hipMemcpyDeviceToDevice, (hipStream_t)stream) !=
+      hipSuccess)
+    return NSAMD_ERR_LAUNCH;
+  occgrid_decay_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(occs, scratch, cells, M, ema_decay);
+  NSAMD_CHECK_LAUNCH();
+  occgrid_max_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(occs, cells, occ_new, M);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_occgrid_binarise(const float* occs, int32_t levels, int32_t resolution, float occ_thre,
+                                      uint8_t* binaries, uint32_t* coarse, double* scratch, float* threshold_out,
+                                      nsamd_stream_t stream) {
+  NSAMD_REQUIRE(occs && binaries && scratch && levels >= 1 && levels <= 8 && resolution >= 1 && resolution <= 1024);
+  const int64_t total = (int64_t)levels * resolution * resolution * resolution;
+  occgrid_sum_kernel<<<kSumBlocks, 256, 0, (hipStream_t)stream>>>(occs, total, scratch);
+  NSAMD_CHECK_LAUNCH();
+  const int64_t nb = (total + 255) / 256;
+  occgrid_binarise_kernel<<<(unsigned)(nb < 4096 ? nb : 4096), 256, 0, (hipStream_t)stream>>>(occs, total, occ_thre, scratch,
+                                                                                              binaries, threshold_out);
+  NSAMD_CHECK_LAUNCH();
+  if (coarse != nullptr) {
+    const int words = (int)nsamd_occgrid_coarse_words(levels, resolution);
+    NSAMD_REQUIRE(words > 0);
+    occgrid_coarse_kernel<<<(words + 255) / 256, 256, 0, (hipStream_t)stream>>>(binaries, levels, resolution, coarse, words);
+    NSAMD_CHECK_LAUNCH();
+  }
   return NSAMD_OK;
 }
 

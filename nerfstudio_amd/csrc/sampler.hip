@@ -102,7 +102,8 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
                                                                const float* __restrict__ dweights,
                                                                int64_t num_rays, int S,
                                                                float* __restrict__ ddensity,
-                                                               uint32_t* __restrict__ gate_out) {
+                                                               uint32_t* __restrict__ gate_out,
+                                                               uint8_t* __restrict__ ray_mask) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -124,7 +125,9 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
       const float dd = (tb[i + 1] - tb[i]) * dn[i];
       carries = carries || dw[i] != 0.0f || !(dd >= 0.0f && dd <= 3.4028234663852886e38f);
     }
-    if (__ballot(carries) == 0ull) {
+    const bool ray_carries = __ballot(carries) != 0ull;
+    if (ray_mask != nullptr && lane == 0) ray_mask[ray] = ray_carries ? 1 : 0;  // per-ray form of the flag (see nsamd.h)
+    if (!ray_carries) {
       for (int i = lane; i < S; i += 64) ddensity[ray * S + i] = (tb[i + 1] - tb[i]) * 0.0f;
       return;
     }
@@ -391,7 +394,7 @@ extern "C" int nsamd_weights_fwd(const float* t_bins, const float* density, int6
 }
 
 static int weights_bwd_launch(const float* t_bins, const float* density, const float* dweights, int64_t num_rays,
-                              int32_t S, float* ddensity, uint32_t* gate_out, nsamd_stream_t stream) {
+                              int32_t S, float* ddensity, uint32_t* gate_out, uint8_t* ray_mask, nsamd_stream_t stream) {
   NSAMD_REQUIRE(num_rays >= 0 && S > 0);
   if (gate_out != nullptr &&  // cleared on the stream ahead of the launch (a memset node inside a captured graph)
       hipMemsetAsync(gate_out, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
@@ -401,21 +404,21 @@ static int weights_bwd_launch(const float* t_bins, const float* density, const f
   if (S > 1024) return NSAMD_ERR_UNSUPPORTED;
   const size_t lds = sizeof(float) * 3 * kWaves * (size_t)S;
   weights_bwd_kernel<<<ray_blocks(num_rays), kThreads, lds, (hipStream_t)stream>>>(t_bins, density, dweights,
-                                                                                   num_rays, S, ddensity, gate_out);
+                                                                                   num_rays, S, ddensity, gate_out, ray_mask);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }
 
 extern "C" int nsamd_weights_bwd(const float* t_bins, const float* density, const float* dweights,
                                  int64_t num_rays, int32_t S, float* ddensity, nsamd_stream_t stream) {
-  return weights_bwd_launch(t_bins, density, dweights, num_rays, S, ddensity, nullptr, stream);
+  return weights_bwd_launch(t_bins, density, dweights, num_rays, S, ddensity, nullptr, nullptr, stream);
 }
 
 extern "C" int nsamd_weights_bwd_gate(const float* t_bins, const float* density, const float* dweights,
                                       int64_t num_rays, int32_t S, float* ddensity, uint32_t* gate_out,
-                                      nsamd_stream_t stream) {
+                                      uint8_t* ray_mask_out, nsamd_stream_t stream) {
   NSAMD_REQUIRE(gate_out != nullptr);
-  return weights_bwd_launch(t_bins, density, dweights, num_rays, S, ddensity, gate_out, stream);
+  return weights_bwd_launch(t_bins, density, dweights, num_rays, S, ddensity, gate_out, ray_mask_out, stream);
 }
 
 extern "C" int nsamd_pdf_resample(const float* s_bins_prev, const float* weights, int32_t S_prev,

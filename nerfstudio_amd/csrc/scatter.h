@@ -100,9 +100,11 @@ struct ScatterPlan {
 ScatterPlan scatter_plan(const nsamd_grid& grid, int64_t M, bool max_spill);
 
 // Host: enqueue route (pass 1) + apply (pass 2) + finish on `stream`. Returns an nsamd_status. `gate` (nullable, device):
-// accumulating calls only — while *gate == 0 all kernels return at once (the gradient being scattered is all zeros).
+// accumulating calls only — while *gate == 0 all kernels return at once (the gradient being scattered is all zeros);
+// `ray_mask` (nullable, [rays] bytes, ray mode + gate only): samples of rays whose byte is 0 are zeros and are not loaded.
 int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsamd_aabb& aabb, const nsamd_grid& grid,
                    const float* denc, int64_t stride_p, int64_t stride_k, float* dtable, float* workspace,
-                   const ScatterPlan& plan, bool overwrite, const uint32_t* gate, hipStream_t stream);
+                   const ScatterPlan& plan, bool overwrite, const uint32_t* gate, const uint8_t* ray_mask,
+                   hipStream_t stream);
 
 }  // namespace nsamd

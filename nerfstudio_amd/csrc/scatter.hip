@@ -112,7 +112,7 @@ template <int kThreads, int kPts, int kLevels>
 __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
     nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
     int64_t stride_p, int64_t stride_k, ScatterGeom G, LevelList levels, ScatterBufs buf,
-    const uint32_t* __restrict__ gate) {
+    const uint32_t* __restrict__ gate, const uint8_t* __restrict__ ray_mask) {
   static_assert(kPts * kLevels * 4 <= 32, "overflow mask is 32 bits");
   if (gate_is_clear(gate)) return;  // gated call with no gradient anywhere: nothing to route (see scatter_launch)
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
@@ -135,6 +135,8 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
   for (int j = 0; j < kPts; ++j) {  // all gradient loads in flight before anything depends on them
     const int64_t p = ((int64_t)blockIdx.x * kPts + j) * kThreads + threadIdx.x;
     inside[j] = p < M;
+    // per-ray mask of a gated call: samples of rays without gradient are exact zeros that were never written — not loaded
+    if (inside[j] && ray_mask != nullptr) inside[j] = ray_mask[p / P.samples_per_ray] != 0;
 #pragma unroll
     for (int i = 0; i < kLevels; ++i) {
       g0[j][i] = 0.0f;
@@ -262,7 +264,7 @@ template <int kLevels>
 __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
     nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
     int64_t stride_p, int64_t stride_k, ScatterGeom G, LevelList levels, ScatterBufs buf,
-    const uint32_t* __restrict__ gate) {
+    const uint32_t* __restrict__ gate, const uint8_t* __restrict__ ray_mask) {
   if (gate_is_clear(gate)) return;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   const int B = 1 << G.log2_bins;
@@ -281,11 +283,13 @@ __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
   float px[kRunLen], py[kRunLen], pz[kRunLen];
 #pragma unroll
   for (int s = 0; s < kRunLen; ++s) {
+    // (per-ray mask of a gated call: rays without gradient are not loaded, see the fine kernel)
+    const bool act = p0 + s < M && (ray_mask == nullptr || ray_mask[(p0 + s) / P.samples_per_ray] != 0);
 #pragma unroll
     for (int i = 0; i < kLevels; ++i) {
       g0[s][i] = 0.0f;
       g1[s][i] = 0.0f;
-      if (p0 + s < M && lvl[i] >= 0) {
+      if (act && lvl[i] >= 0) {
         const float* gptr = denc + (p0 + s) * stride_p + (int64_t)(2 * lvl[i]) * stride_k;
         g0[s][i] = gptr[0];
         g1[s][i] = gptr[stride_k];
@@ -742,17 +746,19 @@ static ScatterBufs scatter_bufs(float* workspace, const ScatterPlan& p) {
 template <int kThreads, int kPts, int kLevels>
 static void launch_fine(const nsamd_points& pts, int64_t M, int transform, const nsamd_aabb& aabb, const nsamd_grid& grid,
                         const float* denc, int64_t stride_p, int64_t stride_k, const ScatterGeom& G,
-                        const LevelList& fine, const ScatterBufs& buf, const uint32_t* gate, hipStream_t st) {
+                        const LevelList& fine, const ScatterBufs& buf, const uint32_t* gate, const uint8_t* ray_mask,
+                        hipStream_t st) {
   const size_t lds = sizeof(uint32_t) * (3 * (size_t)kLevels * ((size_t)1 << G.log2_bins) + kLevels);
   dim3 g1(G.segs, (unsigned)((fine.count + kLevels - 1) / kLevels));
   scatter_route_fine_kernel<kThreads, kPts, kLevels><<<g1, kThreads, lds, st>>>(pts, M, transform, aabb, grid, denc,
-                                                                                 stride_p, stride_k, G, fine, buf, gate);
+                                                                                 stride_p, stride_k, G, fine, buf, gate, ray_mask);
 }
 
 int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsamd_aabb& aabb, const nsamd_grid& grid,
                    const float* denc, int64_t stride_p, int64_t stride_k, float* dtable, float* workspace,
-                   const ScatterPlan& plan, bool overwrite, const uint32_t* gate, hipStream_t st) {
+                   const ScatterPlan& plan, bool overwrite, const uint32_t* gate, const uint8_t* ray_mask, hipStream_t st) {
   if (gate != nullptr && overwrite) return NSAMD_ERR_INVALID_ARG;  // a write-only gradient must always be written
+  if (ray_mask != nullptr && (gate == nullptr || pts.positions != nullptr)) return NSAMD_ERR_INVALID_ARG;  // ray mode only
   ScatterGeom G = plan.geom;
   ScatterBufs buf = scatter_bufs(workspace, plan);
   buf.log2_table_size = grid.log2_table_size;
@@ -789,9 +795,9 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
     const FineShape s = fine_shape();
     const int code = s.threads * 100 + s.pts * 10 + s.levels;
     switch (code) {
-      case 51214: launch_fine<512, 1, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, gate, st); break;
-      case 102412: launch_fine<1024, 1, 2>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, gate, st); break;
-      default: launch_fine<1024, 1, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, gate, st); break;
+      case 51214: launch_fine<512, 1, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, gate, ray_mask, st); break;
+      case 102412: launch_fine<1024, 1, 2>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, gate, ray_mask, st); break;
+      default: launch_fine<1024, 1, 4>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G, fine, buf, gate, ray_mask, st); break;
     }
     NSAMD_CHECK_LAUNCH();
   }
@@ -801,7 +807,7 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
     const int64_t per_block = (int64_t)kRunThreads * kRunLen;
     dim3 g1((unsigned)((M + per_block - 1) / per_block), (unsigned)((coarse.count + kL - 1) / kL));
     scatter_route_runs_kernel<kL><<<g1, kRunThreads, lds, st>>>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G,
-                                                              coarse, buf, gate);
+                                                              coarse, buf, gate, ray_mask);
     NSAMD_CHECK_LAUNCH();
   }
   const unsigned threads = G.slice_log2 > 11 ? 1024u : (G.slice_log2 > 9 ? 512u : 256u);

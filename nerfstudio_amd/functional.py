@@ -891,13 +891,51 @@ def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor
 # a21 / f4  packed-sample path of instant-ngp (csrc/packed.hip): occupancy-grid marching, packed transmittance scan with
 # early termination, compaction, packed compositing            (ray_samplers.py:385-519, models/instant_ngp.py:172-217)
 # ---------------------------------------------------------------------------------------------------------------
-def _occgrid_native(binaries: Tensor, roi_aabb: Sequence[float]) -> N.OccGrid:
+def _occgrid_native(binaries: Tensor, roi_aabb: Sequence[float], coarse: Optional[Tensor] = None) -> N.OccGrid:
     g = N.OccGrid()
     g.binaries = N.ptr(binaries)
     g.levels, g.resolution = int(binaries.shape[0]), int(binaries.shape[1])
     for i, v in enumerate(roi_aabb):
         g.aabb[i] = float(v)
+    g.coarse = N.ptr(coarse) if coarse is not None and coarse.numel() else None
     return g
+
+
+def occgrid_coarse_words(levels: int, resolution: int) -> int:
+    """Words of the coarse (4x4x4-block) occupancy bitfield for a grid shape; 0 = the marcher takes none."""
+    return int(N.load().nsamd_occgrid_coarse_words(int(levels), int(resolution)))
+
+
+@torch.no_grad()
+def occgrid_cell_positions(cells: Optional[Tensor], num: int, binaries: Tensor, roi_aabb: Sequence[float], jitter: Tensor) -> Tensor:
+    """Positions `[num,3]` inside the grid cells `cells` (flat int64 indices; None = cells 0..num-1) at the fractional
+    offsets `jitter [num,3]` (nsamd_occgrid_cell_positions)."""
+    N.require_cuda(binaries, jitter, cells)
+    x = torch.empty((num, 3), device=jitter.device, dtype=torch.float32)
+    N.check(N.load().nsamd_occgrid_cell_positions(N.ptr(cells), num, _occgrid_native(binaries, roi_aabb), N.ptr(_f32c(jitter)),
+                                                  N.ptr(x), N.stream()), "occgrid_cell_positions")
+    return x
+
+
+@torch.no_grad()
+def occgrid_update(occs: Tensor, cells: Optional[Tensor], occ_new: Tensor, ema_decay: float, scratch: Tensor) -> None:
+    """occs[c] = max(occs[c] * decay, new estimates of c) for the listed cells, in place (nsamd_occgrid_update)."""
+    N.require_cuda(occs, occ_new, scratch, cells)
+    assert scratch.numel() >= occs.numel() and occs.is_contiguous()
+    N.check(N.load().nsamd_occgrid_update(N.ptr(occs), occs.numel(), N.ptr(cells), N.ptr(_f32c(occ_new.reshape(-1))),
+                                          occ_new.numel(), float(ema_decay), N.ptr(scratch), N.stream()), "occgrid_update")
+
+
+@torch.no_grad()
+def occgrid_binarise(occs: Tensor, binaries: Tensor, coarse: Optional[Tensor], occ_thre: float, scratch: Tensor,
+                     threshold_out: Optional[Tensor] = None) -> None:
+    """binaries = occs > min(mean(occs), occ_thre) and its coarse bitfield (nsamd_occgrid_binarise). scratch: >= 1024
+    float64; threshold_out: optional `[2]` fp32 (threshold, mean)."""
+    N.require_cuda(occs, binaries, scratch, coarse, threshold_out)
+    assert scratch.dtype == torch.float64 and scratch.numel() >= 1024
+    N.check(N.load().nsamd_occgrid_binarise(N.ptr(occs), int(binaries.shape[0]), int(binaries.shape[1]), float(occ_thre),
+                                            N.ptr(binaries), N.ptr(coarse) if coarse is not None and coarse.numel() else None,
+                                            N.ptr(scratch), N.ptr(threshold_out), N.stream()), "occgrid_binarise")
 
 
 @torch.no_grad()
@@ -915,15 +953,17 @@ def packed_info_from_counts(counts: Tensor) -> Tuple[Tensor, int]:
 @torch.no_grad()
 def occgrid_march(origins: Tensor, directions: Tensor, binaries: Tensor, roi_aabb: Sequence[float], step_size: float,
                   near_plane: float = 0.0, far_plane: float = 1e10, t_min: Optional[Tensor] = None,
-                  t_max: Optional[Tensor] = None, cone_angle: float = 0.0, jitter: Optional[Tensor] = None):
+                  t_max: Optional[Tensor] = None, cone_angle: float = 0.0, jitter: Optional[Tensor] = None,
+                  coarse: Optional[Tensor] = None):
     """Ray marching through a multi-level occupancy grid (`binaries [levels,R,R,R]` uint8) -> (ray_indices int64 `[n]`,
-    t_starts, t_ends fp32 `[n]`, packed_info `[N,2]`). Count pass, prefix, write pass."""
+    t_starts, t_ends fp32 `[n]`, packed_info `[N,2]`). Count pass, prefix, write pass. `coarse`: the grid's 4x4x4-block
+    bitfield (occgrid_binarise) — empty-space skipping, same samples."""
     N.require_cuda(origins, directions, binaries)
     o, d = _f32c(origins), _f32c(directions)
     assert binaries.dtype == torch.uint8 and binaries.is_contiguous() and binaries.dim() == 4
     n = o.shape[0]
     dev = o.device
-    grid = _occgrid_native(binaries, roi_aabb)
+    grid = _occgrid_native(binaries, roi_aabb, coarse)
     tmin = None if t_min is None else _f32c(t_min.reshape(-1))
     tmax = None if t_max is None else _f32c(t_max.reshape(-1))
     jit = None if jitter is None else _f32c(jitter.reshape(-1))

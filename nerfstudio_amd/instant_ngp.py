@@ -94,8 +94,10 @@ class NGPModel(nn.Module):
                                                     cone_angle=c.cone_angle, jitter=jitter)
         field_outputs = self.field(ray_samples)
         # accumulation (models/instant_ngp.py:191-199): nerfacc.pack_info + render_weight_from_density
-        counts = torch.bincount(ray_indices, minlength=num_rays).to(torch.int32)
-        packed_info, _ = F.packed_info_from_counts(counts)
+        packed_info = getattr(ray_indices, "_nsamd_packed_info", None)  # the sampler's own rows (no recount, no host sync)
+        if packed_info is None or packed_info.shape[0] != num_rays:
+            counts = torch.bincount(ray_indices, minlength=num_rays).to(torch.int32)
+            packed_info, _ = F.packed_info_from_counts(counts)
         starts, ends = ray_samples.frustums.starts[..., 0].contiguous(), ray_samples.frustums.ends[..., 0].contiguous()
         weights = F.packed_weights(field_outputs[FieldHeadNames.DENSITY][..., 0], starts, ends, packed_info)[..., None]
         rgb = self.renderer_rgb(rgb=field_outputs[FieldHeadNames.RGB], weights=weights, ray_indices=ray_indices,

@@ -252,6 +252,12 @@ class VolumetricSampler(Sampler):
             ray_indices = torch.zeros((1,), dtype=torch.long, device=rays_o.device)
             starts = torch.ones((1,), dtype=torch.float32, device=rays_o.device)
             ends = torch.ones((1,), dtype=torch.float32, device=rays_o.device)
+        else:
+            # the (start, count) rows the marcher / compaction already hold ride along on the index tensor: the packed
+            # renderers and NGPModel.get_outputs take them instead of recomputing them
+            info = getattr(self.occupancy_grid, "last_packed_info", None)
+            if info is not None and info.shape[0] == rays_o.shape[0]:
+                ray_indices._nsamd_packed_info = info
         cams = ray_bundle.camera_indices
         ray_samples = RaySamples(
             frustums=Frustums(origins=rays_o[ray_indices], directions=rays_d[ray_indices], starts=starts[..., None],

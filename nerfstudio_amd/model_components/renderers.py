@@ -18,6 +18,9 @@ def _packed(ray_indices, num_rays) -> bool:
 
 def _packed_info(ray_indices: Tensor, num_rays: int) -> Tensor:
     """nerfacc.pack_info: `[num_rays, 2]` (start, count); samples of a ray are contiguous, rays in increasing order."""
+    cached = getattr(ray_indices, "_nsamd_packed_info", None)  # VolumetricSampler leaves the marcher's own (start, count)
+    if cached is not None and cached.shape[0] == num_rays:      # rows here: no bincount + prefix + host sync per renderer
+        return cached
     counts = torch.bincount(ray_indices, minlength=num_rays).to(torch.int32)
     return F.packed_info_from_counts(counts)[0]
 

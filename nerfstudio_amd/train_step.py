@@ -112,6 +112,8 @@ class NerfactoTrainStep:
         # NSAMD_GATE_PROPOSALS=0: the ungated entry points (A/B).
         self.gate_proposals = os.environ.get("NSAMD_GATE_PROPOSALS", "1") == "1"
         self.prop_gates = torch.zeros(max(self.n_prop, 1) * 4, device=device, dtype=torch.int32)  # 16 B apart
+        # ... and its per-ray form (1 = the ray carries gradient): levels that are only partly without gradient
+        self.prop_ray_masks = [torch.zeros(n, device=device, dtype=torch.uint8) for _ in range(self.n_prop)]
         # Optional (NSAMD_FIELD_SAVE_ACTS=1): the forward saves the main field's activations (896 B per sample) and the
         # backward loads them instead of recomputing the forward. Measured on MI355X: backward 186 -> 176 us but forward
         # 60 -> 76 us — the backward is bound by its workgroup barriers, not by the recomputed MFMAs — so off by default.
@@ -215,7 +217,15 @@ class NerfactoTrainStep:
         """Everything after the losses: the main backward chain, the proposal chains on the steps that update them
         (parallel streams where they share nothing; parallel branches inside a captured hipGraph), and the camera
         optimiser's share."""
+        self.backward_fork(updated)
+        self.backward_join(updated)
+
+    def backward_fork(self, updated: bool) -> None:
+        """First half of backward_all: the proposal chains go onto their side streams (not yet joined), the main chain runs
+        on the current stream. A data-parallel caller starts the main-field gradient exchange between this and
+        backward_join — the proposal chains then run beside the main chain AND beside the collective."""
         branches = self.proposal_branches() if updated else []
+        self._open_branches = branches
         if branches:
             # The backward chains are independent (disjoint gradients, separate scratch): fork the proposal chains onto
             # their own streams so that these latency-bound kernels overlap with the main chain.
@@ -227,12 +237,17 @@ class NerfactoTrainStep:
                     self.backward_proposals(levels=levels)
                     join.record(stream)
             self.backward_main()
-            for _, join, _ in branches:
-                main.wait_event(join)
         else:
             self.backward_main()
             if updated:
                 self.backward_proposals()
+
+    def backward_join(self, updated: bool) -> None:
+        """Second half of backward_all: wait for the proposal chains, then the camera optimiser's share."""
+        main = torch.cuda.current_stream()
+        for _, join, _ in getattr(self, "_open_branches", []):
+            main.wait_event(join)
+        self._open_branches = []
         self.backward_cameras(updated)
 
     def forward_backward_main(self, updated: bool, draw_jitter: bool = True) -> None:
@@ -274,13 +289,14 @@ class NerfactoTrainStep:
         """Device address of proposal level `lvl`'s gradient flag (None: gating off)."""
         return self.prop_gates.data_ptr() + 16 * lvl if self.gate_proposals else None
 
-    def _rays_backward(self, lvl: int, net, denc: Tensor, gate=None) -> None:
+    def _rays_backward(self, lvl: int, net, denc: Tensor, gate=None, ray_mask=None) -> None:
         """dL/d(origins, directions) of sampling level `lvl` from its encoded-feature gradient (on the current stream)."""
         lib, m = N.load(), self.n * self.counts[lvl]
         enc = net.mlp_base.encoding if hasattr(net.mlp_base, "encoding") else net.encoding
         N.check(lib.nsamd_hashgrid_encode_bwd_rays_gated(
             self._points(lvl), m, net._transform, net._box, N.ptr(enc.hash_table), enc.spec.native(), N.ptr(denc), 1, m,
-            N.ptr(self.d_origins[lvl]), N.ptr(self.d_directions[lvl]), 0, gate, N.stream()), "hashgrid_encode_bwd_rays")
+            N.ptr(self.d_origins[lvl]), N.ptr(self.d_directions[lvl]), 0, gate, ray_mask, N.stream()),
+            "hashgrid_encode_bwd_rays")
 
     def backward_cameras(self, updated: bool) -> None:
         """Per-ray gradients of every level that received one -> `pose_adjustment.grad` (plus the L2 regulariser of
@@ -415,6 +431,19 @@ class NerfactoTrainStep:
         """composite -> weights -> field MLPs -> main hash table (MSE + distortion gradients)."""
         lib, st, n = N.load(), N.stream(), self.n
         ck = N.check
+        L = self.n_prop
+        S = self.counts[L]
+        ck(lib.nsamd_render_train_bwd(N.ptr(self.f_rgb), N.ptr(self.weights[L]), N.ptr(self.f_dens), N.ptr(self.t_bins[L]),
+                                      n, S, self.bg_mode, self.bg_vals, N.ptr(self.d_rgb_out), N.ptr(self.dw_dist),
+                                      N.ptr(self.d_rgb_s), N.ptr(self.d_dens_main), N.ptr(self.bg_rays), st),
+           "render_train_bwd")
+        self.backward_field_and_table()
+
+    def backward_field_and_table(self) -> None:
+        """Second half of backward_main: the main field's MLPs (from `d_dens_main`, `d_rgb_s`) and the table scatter. Separate
+        so that tests can drive the field backward with upstream gradients of their own."""
+        lib, st, n = N.load(), N.stream(), self.n
+        ck = N.check
         fld = self.model.field
         L = self.n_prop
         S, mm = self.counts[L], self.m_main
@@ -424,10 +453,6 @@ class NerfactoTrainStep:
         fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), emb.shape[0] if emb is not None else 0,
                         float(fld.average_init_density))
         cams = N.ptr(self.camera_indices) if emb is not None else None
-        ck(lib.nsamd_render_train_bwd(N.ptr(self.f_rgb), N.ptr(self.weights[L]), N.ptr(self.f_dens), N.ptr(self.t_bins[L]),
-                                      n, S, self.bg_mode, self.bg_vals, N.ptr(self.d_rgb_out), N.ptr(self.dw_dist),
-                                      N.ptr(self.d_rgb_s), N.ptr(self.d_dens_main), N.ptr(self.bg_rays), st),
-           "render_train_bwd")
         grads = N.FieldMlpGrads(*(N.ptr(self._grad(p)) for p in params), N.ptr(self._grad(emb)) if emb is not None else None)
         split = self.split_reduce and self.side_stream is not None and not self.save_acts
         if self.save_acts:
@@ -503,18 +528,19 @@ class NerfactoTrainStep:
                     continue
                 # the weights backward raises the level's flag when any ray carries interlevel gradient; the rest of the
                 # chain returns at once while it is clear (the zero-filled gradients are then already the result)
+                mask = N.ptr(self.prop_ray_masks[lvl])
                 ck(lib.nsamd_weights_bwd_gate(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]), n,
-                                              S, N.ptr(self.p_ddens[lvl]), gate, st), "weights_bwd_gate")
+                                              S, N.ptr(self.p_ddens[lvl]), gate, mask, st), "weights_bwd_gate")
                 ck(lib.nsamd_density_mlp_bwd_gated(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]),
                                                    N.ptr(self.p_ddens[lvl]), m, dm, N.ptr(self.p_denc[lvl]), *grads,
-                                                   N.ptr(dws), dws.numel(), gate, st), "density_mlp_bwd_gated")
+                                                   N.ptr(dws), dws.numel(), gate, mask, S, st), "density_mlp_bwd_gated")
                 if self.cam_opt is not None:
-                    self._rays_backward(lvl, net, self.p_denc[lvl], gate)
+                    self._rays_backward(lvl, net, self.p_denc[lvl], gate, mask)
                 ck(lib.nsamd_hashgrid_encode_bwd_gated(self._points(lvl), m, net._transform, net._box,
                                                        N.ptr(net.encoding.hash_table), spec.native(),
                                                        N.ptr(self.p_denc[lvl]), 1, m,
                                                        N.ptr(self._grad(net.encoding.hash_table)), N.ptr(ws), ws_n, gate,
-                                                       st), "hashgrid_encode_bwd_gated")
+                                                       mask, st), "hashgrid_encode_bwd_gated")
 
     # -------------------------------------------------------------------------------------------------------------
     def loss_dict(self) -> Dict[str, Tensor]:

@@ -181,5 +181,7 @@ def occgrid_thresholds(occs, occ_thre: float = 0.01):
 
     occs = np.asarray(occs, np.float32)
     seen = occs >= 0
-    thre = min(float(occs[seen].mean()) if seen.any() else 0.0, occ_thre)
+    # the mean in double (the product's kernel and its torch path both sum in double), the threshold rounded to fp32 once
+    mean = float(occs[seen].astype(np.float64).mean()) if seen.any() else 0.0
+    thre = np.float32(min(mean, float(np.float32(occ_thre))))
     return occs > thre

@@ -127,11 +127,25 @@ def test_bench_configuration_parity_through_replayed_graph(F, init):
             res = orc.nerfacto_forward(prm, cfg, o.to(dtype), d.to(dtype), cam[:, 0], [x.to(dtype) for x in j], training=True,
                                        anneal=ps._anneal, proposal_requires_grad=forced)
             losses = orc.nerfacto_losses(res, tgt.to(dtype), cfg)
+            res["density"].retain_grad()      # upstream gradients of the main field: what render_train_bwd produces
+            res["rgb_samples"].retain_grad()
             sum(losses.values()).backward()
             return prm, res, losses
 
         oparams, out, ld = oracle(torch.float32)          # the reference's own arithmetic (torch path, fp32)
-        truth = oracle(torch.float64)[0]                  # the same graph in float64: the arbiter for the gradients
+        truth, out64, _ = oracle(torch.float64)           # the same graph in float64: the arbiter for the gradients
+        # per-sample forward values and the upstream gradients the field backward consumes (diagnostics + assertions)
+        S_f = tr.runner.counts[-1]
+        stage = {}
+        for name, got_t, key, is_grad in (("density", tr.runner.f_dens, "density", False), ("rgb samples", tr.runner.f_rgb, "rgb_samples", False),
+                                          ("dL/d density", tr.runner.d_dens_main, "density", True),
+                                          ("dL/d rgb samples", tr.runner.d_rgb_s, "rgb_samples", True)):
+            g = got_t.detach().cpu().double().numpy().reshape(-1)
+            r32 = (out[key].grad if is_grad else out[key]).detach().double().numpy().reshape(-1)
+            r64 = (out64[key].grad if is_grad else out64[key]).detach().numpy().reshape(-1)
+            stage[name] = (_rel_l2(g, r64), _rel_l2(r32, r64))
+        print(f"\n[updated={forced}] per-sample stages, rel-L2 vs float64 (kernels, fp32 reference): " +
+              ", ".join(f"{k}: {v[0]:.1e} / {v[1]:.1e}" for k, v in stage.items()))
         err = float(np.abs(got_rgb - out["rgb"].detach().numpy()).max())
         assert err <= 1e-4, f"rgb L-inf {err:.2e} (updated={forced})"
         for k in ("rgb_loss", "interlevel_loss", "distortion_loss"):
@@ -254,8 +268,8 @@ def test_gated_proposal_chain_equals_ungated(F, case):
         torch.cuda.synchronize()
         a, b = arena.groups["proposal_networks"]
         results.append((arena.grad[a:b].clone(), [t.clone() for t in step.p_denc], [t.clone() for t in step.p_ddens],
-                        step.prop_gates.clone()))
-    (g_grad, g_denc, g_ddens, flags), (u_grad, u_denc, u_ddens, _) = results
+                        step.prop_gates.clone(), [t.clone() for t in step.prop_ray_masks]))
+    (g_grad, g_denc, g_ddens, flags, masks), (u_grad, u_denc, u_ddens, _, _) = results
 
     def same(a, b):  # bit equality of every non-NaN value, NaN exactly where the other has NaN
         na, nb = torch.isnan(a), torch.isnan(b)
@@ -269,14 +283,23 @@ def test_gated_proposal_chain_equals_ungated(F, case):
             z[137] = 0.0
             assert float(z.abs().max()) == 0.0 and float(g_ddens[lvl].view(n, -1)[137].abs().max()) > 0.0
     if case == "all_zero":
-        assert int(flags[0]) == 0 and int(flags[4]) == 0
+        assert int(flags[0]) == 0 and int(flags[4]) == 0 and not any(bool(m.any()) for m in masks)
         assert float(g_grad.abs().max()) == 0.0
         for lvl in range(2):
             assert bool((g_denc[lvl] == 123.0).all()), "a gated chain with a clear flag must not write denc"
     else:
         assert int(flags[0]) == 1 and int(flags[4]) == 1
         for lvl in range(2):
-            assert same(g_denc[lvl], u_denc[lvl])
+            # the per-ray mask marks exactly the carrying ray; the feature gradients of its samples are what the scatter
+            # reads (chunks without a marked ray are not even written: the sentinel survives there)
+            carrying = 137 if case == "one_ray" else 5
+            expect = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            expect[carrying] = 1
+            assert torch.equal(masks[lvl], expect)
+            S_l = step.counts[lvl]
+            rows = slice(carrying * S_l, (carrying + 1) * S_l)
+            assert same(g_denc[lvl][:, rows].contiguous(), u_denc[lvl][:, rows].contiguous())
+            assert bool((g_denc[lvl] == 123.0).any()), "chunks without a marked ray must stay unwritten"
         if case == "one_ray":
             assert float(g_grad.abs().max()) > 0.0
         else:
@@ -287,8 +310,10 @@ def test_field_mlp_backward_at_bench_size_vs_float64(F):
     """The main-field MLP kernels alone at M = 196 608 (4096 rays x 48), fed the training step's own buffers (encoded
     features, selector, directions, camera ids, upstream dL/d density and dL/d rgb): every weight gradient, the
     appearance-embedding gradient and the encoded-feature gradient against a float64 evaluation of the same MLPs on the
-    same inputs, next to what torch's fp32 CPU evaluation achieves against it. Identical inputs, so no sampling or
-    compositing difference enters; ReLU flips can (fp32 pre-activations of magnitude ~1e-8)."""
+    same inputs, next to what torch's fp32 CPU evaluation achieves against it. A ReLU whose pre-activation is within 1e-5
+    of zero may come out on either side in fp32 (MFMA k-order vs BLAS blocking) and then moves its sample's gradient by a
+    finite amount — no arithmetic error, and no statement about the kernel: the samples that own such a unit (a fraction
+    of a percent) are taken out of BOTH sides by zeroing their upstream gradients, so what is left measures arithmetic."""
     from test_gpu_kernels import _hip_model
 
     from nerfstudio_amd.arena import ParamArena
@@ -314,19 +339,40 @@ def test_field_mlp_backward_at_bench_size_vs_float64(F):
     sel = step.f_sel.cpu()
     dirs = d.repeat_interleave(S, dim=0)             # per-sample view directions
     cams = cam.repeat_interleave(S, dim=0)
-    g_dens, g_rgb = step.d_dens_main.cpu(), step.d_rgb_s.cpu()
     keys = [k for k in params if k.startswith("field.") and "hash_table" not in k]
+
+    def forward(prm, x, dtype):
+        pre0 = x @ prm["field.mlp_base.model.1.layers.0.weight"].t() + prm["field.mlp_base.model.1.layers.0.bias"]
+        h = torch.relu(pre0) @ prm["field.mlp_base.model.1.layers.1.weight"].t() + prm["field.mlp_base.model.1.layers.1.bias"]
+        density = cfg.average_init_density * orc.trunc_exp(h[:, 0]) * sel.to(dtype)
+        sh = orc.sh_levels4((dirs.to(dtype) + 1.0) / 2.0)
+        app = prm["field.embedding_appearance.embedding.weight"][cams]
+        p0 = torch.cat([sh, h[:, 1:], app], dim=-1) @ prm["field.mlp_head.layers.0.weight"].t() + prm["field.mlp_head.layers.0.bias"]
+        p1 = torch.relu(p0) @ prm["field.mlp_head.layers.1.weight"].t() + prm["field.mlp_head.layers.1.bias"]
+        rgb = torch.sigmoid(torch.relu(p1) @ prm["field.mlp_head.layers.2.weight"].t() + prm["field.mlp_head.layers.2.bias"])
+        return density, rgb, (pre0, p0, p1)
+
+    with torch.no_grad():
+        pres = forward({k: params[k].double() for k in keys}, enc.double(), torch.float64)[2]
+        ambiguous = torch.zeros(enc.shape[0], dtype=torch.bool)
+        for p_ in pres:
+            ambiguous |= (p_.abs() < 1e-5).any(dim=1)
+    frac = float(ambiguous.float().mean())
+    assert 0 < int(ambiguous.sum()) and frac < 0.02, frac
+    amb_dev = ambiguous.cuda()
+    step.d_dens_main[amb_dev] = 0.0
+    step.d_rgb_s[amb_dev] = 0.0
+    g_dens, g_rgb = step.d_dens_main.cpu(), step.d_rgb_s.cpu()
+    arena.zero_grad(["fields"], skip=step.written_params())
+    step.backward_field_and_table()  # the field MLP backward (+ table scatter) on the edited upstream gradients
+    torch.cuda.synchronize()
     got = _grads_by_oracle_name(model, keys)
     got["denc"] = step.f_denc.t().contiguous().cpu().numpy()
 
     def evaluate(dtype):
         prm = {k: params[k].detach().to(dtype).clone().requires_grad_(True) for k in keys}
         x = enc.to(dtype).clone().requires_grad_(True)
-        h = orc.mlp_forward(x, prm, "field.mlp_base.model.1.")
-        density = cfg.average_init_density * orc.trunc_exp(h[:, 0]) * sel.to(dtype)
-        sh = orc.sh_levels4((dirs.to(dtype) + 1.0) / 2.0)
-        app = prm["field.embedding_appearance.embedding.weight"][cams]
-        rgb = orc.mlp_forward(torch.cat([sh, h[:, 1:], app], dim=-1), prm, "field.mlp_head.", out_activation="sigmoid")
+        density, rgb, _ = forward(prm, x, dtype)
         ((density * g_dens.to(dtype)).sum() + (rgb * g_rgb.to(dtype)).sum()).backward()
         out = {k: v.grad.numpy() for k, v in prm.items()}
         out["denc"] = x.grad.numpy()
@@ -337,7 +383,8 @@ def test_field_mlp_backward_at_bench_size_vs_float64(F):
     for k in list(keys) + ["denc"]:
         e_gpu, e_ref = _rel_l2(got[k], r64[k]), _rel_l2(r32[k], r64[k])
         rows.append(f"  {k}: gpu-f64 {e_gpu:.2e}  cpu32-f64 {e_ref:.2e}")
-        if not e_gpu <= max(3.0 * e_ref, 2e-4):
+        if not e_gpu <= max(3.0 * e_ref, 2e-6):
             bad.append(k)
-    print("\nfield MLP backward at M = 196608 against float64:\n" + "\n".join(rows))
+    print(f"\nfield MLP backward at M = 196608 against float64 ({int(ambiguous.sum())} samples = {100 * frac:.2f} % with a "
+          "ReLU pre-activation within 1e-5 of zero excluded):\n" + "\n".join(rows))
     assert not bad, f"{bad}\n" + "\n".join(rows)

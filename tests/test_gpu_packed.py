@@ -239,3 +239,110 @@ def test_ngp_model_outputs_vs_oracle_and_trains(F):
     with torch.no_grad():
         ev = model.get_outputs_for_camera_ray_bundle(rb._map(lambda t: t.view(8, 12, -1)))
     assert ev["rgb"].shape == (8, 12, 3) and float(ev["rgb"].min()) >= 0 and float(ev["rgb"].max()) <= 1
+
+
+@pytest.mark.parametrize("levels,res", [(4, 16), (2, 32)])
+def test_marcher_with_coarse_occupancy_bits_places_the_same_samples(F, levels, res):
+    """Empty-space skipping (the 4x4x4-block occupancy bitfield staged in LDS) is invisible in the result: the marcher
+    with and without it, on a clustered grid (most blocks empty) and on a random one, emits identical samples; and the
+    bitfield nsamd_occgrid_binarise builds is the OR of each block's cells."""
+    rs = np.random.RandomState(7 + res)
+    n = 301
+    o, d = _rays(n, 5, scale=1.5)
+    jit = rs.uniform(0, 1, n).astype(np.float32)
+    for kind in ("clustered", "random"):
+        if kind == "clustered":
+            occ = np.zeros((levels, res, res, res), np.float32)
+            c = res // 2
+            occ[:, c - 3:c + 2, c - 1:c + 4, c - 2:c + 3] = rs.uniform(0.2, 1.0, (levels, 5, 5, 5))
+            occ[0, 1, 2, 3] = 1.0          # a lone cell far from the blob
+        else:
+            occ = (rs.rand(levels, res, res, res) > 0.9) * rs.uniform(0.2, 1.0, (levels, res, res, res))
+        occs = dev(occ.astype(np.float32).reshape(-1))
+        binaries = torch.zeros((levels, res, res, res), dtype=torch.uint8, device="cuda")
+        words = F.occgrid_coarse_words(levels, res)
+        assert words == (levels * (res // 4) ** 3 + 31) // 32
+        coarse = torch.full((words,), -1, dtype=torch.int32, device="cuda")
+        stats = torch.zeros(2, device="cuda")
+        F.occgrid_binarise(occs, binaries, coarse, 0.01, torch.zeros(1024, dtype=torch.float64, device="cuda"), stats)
+        B = po.occgrid_thresholds(occ.reshape(-1), 0.01).reshape(levels, res, res, res)
+        np.testing.assert_array_equal(binaries.cpu().numpy().astype(bool), B)
+        np.testing.assert_allclose(float(stats[1]), occ.astype(np.float64).mean(), rtol=1e-6)
+        blocks = B.reshape(levels, res // 4, 4, res // 4, 4, res // 4, 4).any(axis=(2, 4, 6)).reshape(-1)
+        bits = ((coarse.cpu().numpy().astype(np.int64)[:, None] >> np.arange(32)) & 1).astype(bool).reshape(-1)[: blocks.size]
+        np.testing.assert_array_equal(bits, blocks)
+        if kind == "clustered":
+            assert blocks.mean() < 0.2
+        with_bits = F.occgrid_march(dev(o), dev(d), binaries, ROI, 0.02, 0.05, 50.0, None, None, 0.004, dev(jit), coarse=coarse)
+        without = F.occgrid_march(dev(o), dev(d), binaries, ROI, 0.02, 0.05, 50.0, None, None, 0.004, dev(jit))
+        ref = po.occgrid_march(o, d, B, ROI, 0.02, near_plane=0.05, far_plane=50.0, cone_angle=0.004, jitter=jit)
+        assert len(ref[0]) > 100
+        for a, b, c_ in zip(with_bits[:3], without[:3], ref):
+            np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+            np.testing.assert_array_equal(a.cpu().numpy(), c_)
+
+
+def test_occupancy_grid_refresh_kernels_equal_the_torch_path(F):
+    """OccGridEstimator.update_every_n_steps on the GPU (cell positions, decayed maximum with repeated cells, mean /
+    threshold / binaries — csrc/packed.hip) against the same module on CPU tensors (plain torch), fed the same cells, offsets
+    and density estimates: positions, occs and binaries equal bit for bit, warm-up refresh and partial refresh."""
+    from nerfstudio_amd.model_components.occupancy import OccGridEstimator
+
+    def blob(x):  # a density-like field; evaluated on the CPU for both grids (identical estimates)
+        x = x.detach().cpu()
+        return (torch.exp(-3.0 * (x * x).sum(-1, keepdim=True)) * 0.4).float()
+
+    res, levels = 16, 3
+    total = levels * res ** 3
+    g_cpu = OccGridEstimator(torch.tensor(ROI), resolution=res, levels=levels).train()
+    g_gpu = OccGridEstimator(torch.tensor(ROI), resolution=res, levels=levels).cuda().train()
+    gen = torch.Generator().manual_seed(3)
+    # positions of every cell / of a list with repeats
+    jit_all = torch.rand((total, 3), generator=gen)
+    x_cpu = g_cpu._cell_positions(None, total, jit_all)
+    x_gpu = g_gpu._cell_positions(None, total, jit_all.cuda())
+    assert torch.equal(x_cpu, x_gpu.cpu())
+    cells = torch.randint(total, (5000,), generator=gen)
+    cells[100:200] = cells[0:100]  # repeats
+    jit = torch.rand((5000, 3), generator=gen)
+    assert torch.equal(g_cpu._cell_positions(cells, 5000, jit), g_gpu._cell_positions(cells.cuda(), 5000, jit.cuda()).cpu())
+    # a warm-up refresh and two partial ones through the public entry point, with the random draws pinned
+    for step, seed in ((0, 1), (256, 2), (272, 3)):
+        outs = []
+        for g in (g_cpu, g_gpu):
+            torch.manual_seed(seed)
+            if g is g_gpu:
+                torch.cuda.manual_seed(seed)
+            if step >= 256:  # same cells / offsets on both: draw on the CPU, replay on the GPU
+                k = total // 4
+                gen2 = torch.Generator().manual_seed(100 + seed)
+                uniform = torch.randint(total, (k,), generator=gen2)
+                occupied = torch.nonzero(g_cpu.binaries.reshape(-1)).reshape(-1)
+                flat = torch.cat([uniform, occupied[:k]])
+                offs = torch.rand((flat.numel(), 3), generator=gen2)
+                x = g._cell_positions(flat.to(g.occs.device), flat.numel(), offs.to(g.occs.device))
+                occ = blob(x).reshape(-1).to(g.occs.device)
+                if g.occs.is_cuda:
+                    F.occgrid_update(g.occs, flat.cuda(), occ, 0.95, g._buf("old", total, torch.float32))
+                else:
+                    new = g.occs.clone()
+                    new[flat] = g.occs[flat] * 0.95
+                    g.occs.copy_(new.scatter_reduce(0, flat, occ, "amax", include_self=True))
+                g._refresh_derived(0.01)
+            else:
+                offs = torch.rand((total, 3), generator=torch.Generator().manual_seed(50))
+                x = g._cell_positions(None, total, offs.to(g.occs.device))
+                occ = blob(x).reshape(-1).to(g.occs.device)
+                if g.occs.is_cuda:
+                    F.occgrid_update(g.occs, None, occ, 0.95, g._buf("old", total, torch.float32))
+                else:
+                    g.occs.copy_(torch.maximum(g.occs * 0.95, occ))
+                g._refresh_derived(0.01)
+            outs.append((g.occs.detach().cpu().clone(), g.binaries.detach().cpu().clone(), g._occ_mean))
+        assert torch.equal(outs[0][0], outs[1][0]), f"occs differ at step {step}"
+        assert torch.equal(outs[0][1], outs[1][1]), f"binaries differ at step {step}"
+        assert abs(outs[0][2] - outs[1][2]) <= 1e-7 * max(abs(outs[0][2]), 1e-9)
+        assert 0 < int(outs[0][1].sum()) < total
+    # and the public entry point runs end to end on the device
+    g_gpu.update_every_n_steps(step=288, occ_eval_fn=lambda x: blob(x).cuda())
+    assert g_gpu._coarse is not None and g_gpu._coarse_version == g_gpu.binaries._version
