@@ -645,6 +645,224 @@ def cpu_baseline(n_rays=RAYS_PER_GPU, steps=3, threads=None, workload="bounded")
                       f"tables, fwd+losses+bwd+Adam, median of {steps} steps after 1 warm-up ({med:.2f} s/step)"}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# --workload ngp: BASELINE configs[3] — instant-ngp: occupancy-grid ray marching + early termination (packed samples)
+# ---------------------------------------------------------------------------------------------------------------------
+NGP_DENSITY = 60.0  # synthetic field: sigma ~ 60 -> alpha ~ 0.19 per step, a ray is opaque (T < 1e-4) after ~45 samples
+
+
+def ngp_lattice_steps(o, d, step, cone, near, far, levels):
+    """Lattice steps every ray walks through the outermost grid level (numpy, fp32, the marcher's own recurrence without the
+    cell lookups): the algorithmic work of the occupancy march — one occupancy byte per step."""
+    f = np.float32
+    half = f(1 << (levels - 1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = (f(1.0) / d).astype(f)
+        ta, tb = ((-half - o) * inv).astype(f), ((half - o) * inv).astype(f)
+    lo, hi = np.minimum(ta, tb), np.maximum(ta, tb)
+    t0 = np.maximum(np.nanmax(lo, axis=1), f(near)).astype(f)
+    t1 = np.minimum(np.nanmin(hi, axis=1), f(far)).astype(f)
+    t, n = t0.copy(), np.zeros(len(o), np.int64)
+    alive = t < t1
+    while alive.any():
+        n += alive
+        dt = np.minimum(np.maximum((t * f(cone)).astype(f), f(step)), f(1e10)).astype(f)
+        t = np.where(alive, (t + dt).astype(f), t)
+        alive &= t < t1
+    return n
+
+
+def run_ngp(args, device):
+    """One step = NGPModel's training iteration on 4096 synthetic rays: occupancy-grid march (count / prefix / write), density
+    on the candidates, packed transmittance scan with early termination + compaction, NerfactoField on the survivors, packed
+    weights + compositing, MSE, backward (packed scans, field MLPs, table scatter), fused Adam. Through the module / autograd
+    path of nerfstudio_amd.instant_ngp (eager launches; the packed arrays are allocated to size each step, as the reference
+    does). The occupancy grid is SYNTHETIC and FIXED (random 5 %-occupied 128^3 x 4 levels) and the random
+    field's density is lifted to ~60 so that rays become opaque after ~45 kept samples: the refresh of the grid (every 16th
+    step in training) would replace the synthetic grid by the random field's own and is timed separately
+    (config.grid_refresh_ms)."""
+    from nerfstudio_amd import _native as N
+    from nerfstudio_amd import functional as F
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.cameras.rays import RayBundle
+    from nerfstudio_amd.instant_ngp import InstantNGPModelConfig, NGPModel
+
+    torch.manual_seed(0)
+    cfg = InstantNGPModelConfig()  # grid 128^3 x 4 levels, T = 2^19, cone_angle 0.004, alpha_thre 0.01, random background
+    model = NGPModel(cfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_train_data=100).to(device).train()
+    with torch.no_grad():  # lift the density head: sigma = exp(pre), pre ~ log(NGP_DENSITY)
+        model.field.mlp_base.mlp.layers[-1].bias[0] = float(np.log(NGP_DENSITY))
+    grid = model.occupancy_grid
+    g = torch.Generator(device="cpu").manual_seed(7)
+    occupied = torch.rand(grid.occs.shape, generator=g) < 0.05
+    grid.occs.copy_(torch.where(occupied, torch.tensor(1.0), torch.tensor(0.0)).to(device))
+    grid._refresh_derived(0.01)
+    assert abs(float(grid.binaries.float().mean()) - 0.05) < 5e-3
+    arena = ParamArena({"fields": list(model.field.parameters())}, lr=1e-2, eps=1e-15)
+    o, d, cam, tgt = synthetic_rays(1000)
+    n = RAYS_PER_GPU
+    rb = RayBundle(origins=torch.from_numpy(o).to(device), directions=torch.from_numpy(d).to(device),
+                   pixel_area=torch.full((n, 1), 1e-6, device=device), camera_indices=torch.from_numpy(cam).to(device))
+    batch = {"image": torch.from_numpy(tgt).to(device)}
+    samples = []
+
+    def step():
+        arena.zero_grad()
+        out = model(rb)
+        loss = model.get_loss_dict(out, batch)["rgb_loss"]
+        loss.backward()
+        arena.step()
+        samples.append(out["num_samples_per_ray"])
+        return loss
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert bool(torch.isfinite(loss)), "training diverged"
+    kept = float(torch.stack(samples[-args.steps:]).float().sum(dim=1).mean())
+    # ---- per-kernel table (eager launches through the binding, HIP events on the launch stream) ----
+    N.PROFILE = {}
+    prof_steps = max(1, args.profile_steps)
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
+    prof = N.profile_summary(N.PROFILE)
+    N.PROFILE = None
+    table = sorted(((k, c / prof_steps, tot / prof_steps, mean) for k, (c, tot, mean) in prof.items()), key=lambda r: -r[2])
+    if args.kernel_table:
+        for k, c, ms, mean in table:
+            print(f"{k:64s} {c:5.1f}/step {ms:9.4f} ms/step {mean:9.4f} ms/launch", file=sys.stderr)
+    # candidates (before the visibility scan): one more march
+    cand = F.occgrid_march(rb.origins, rb.directions, grid.binaries, grid._roi, cfg.render_step_size, cfg.near_plane,
+                           cfg.far_plane, None, None, cfg.cone_angle, torch.rand(n, device=device), coarse=grid._coarse)
+    n_cand = int(cand[0].numel())
+    lattice = int(ngp_lattice_steps(o, d, cfg.render_step_size, cfg.cone_angle, cfg.near_plane, cfg.far_plane, cfg.grid_levels).sum())
+    # roofline of the dominant PACKED kernel: the occupancy march (count + write launches). Algorithmic bytes per launch pair:
+    # one occupancy byte per lattice step and pass, 16 B per emitted sample (ray index, t_start, t_end), 24 B in + 20 B out
+    # per ray (origin, direction; count, packed_info row)
+    march_ms = sum(mean for k, _, _, mean in table if k.startswith("nsamd_occgrid_march"))
+    packed = [(k, ms) for k, _, ms, _ in table if "occgrid" in k or "packed" in k]
+    march_bytes = 2 * lattice + 16 * n_cand + 44 * n
+    roof = {"bound": "hbm", "achieved": round(march_bytes / (march_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(march_bytes / (march_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+            "kernel": "nsamd_occgrid_march_count + nsamd_occgrid_march_write", "avg_launch_ms": round(march_ms, 4),
+            "algorithmic_per_launch": march_bytes, "rocprof_kernel": "nsamd::occgrid_march_kernel<false> + <true>",
+            "note": "latency-bound by construction: 1 B of grid per lattice step; lattice steps/s = "
+                    f"{2 * lattice / (march_ms * 1e-3):.3e}"}
+    top = next(((k, mean) for k, _, _, mean in table if algorithmic_model_ngp(k, kept) is not None), None)
+    roof_step = None
+    if top is not None:
+        bound, work = algorithmic_model_ngp(top[0], kept)
+        ach = work / (top[1] * 1e-3) / (1e9 if bound == "hbm" else 1e12)
+        peak = HBM_PEAK_GBS if bound == "hbm" else F32_MFMA_PEAK_TFLOPS
+        roof_step = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                     "frac": round(ach / peak, 4), "kernel": top[0], "avg_launch_ms": round(top[1], 4),
+                     "algorithmic_per_launch": int(work)}
+    # grid refresh (excluded from the step, see the docstring): timed once on a copy of the state
+    occs0, bin0 = grid.occs.clone(), grid.binaries.clone()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    grid.update_every_n_steps(step=512, occ_eval_fn=lambda x: model.field.density_fn(x) * float(cfg.render_step_size))
+    torch.cuda.synchronize()
+    refresh_ms = (time.perf_counter() - t1) * 1e3
+    grid.occs.copy_(occs0)
+    grid.binaries.copy_(bin0)
+    ms = elapsed / args.steps * 1e3
+    out = {
+        "metric": "training rays/sec (4096 rays per GPU, instant-ngp packed path)",
+        "value": round(RAYS_PER_GPU / (elapsed / args.steps), 1), "unit": "rays/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "instant-ngp 1xMI355X (BASELINE configs[3]): occupancy-grid ray marching (128^3 x 4 levels, random 5 % "
+                               "occupied, fixed), packed transmittance scan with early termination + compaction, NerfactoField "
+                               "(L=16 hash T=2^19, 64x2 MLP) on the surviving samples, packed compositing, MSE, backward, Adam; "
+                               "4096 rays/batch",
+                   "rays_per_gpu": RAYS_PER_GPU, "lattice_steps_per_ray": round(lattice / n, 1),
+                   "candidate_samples_per_ray": round(n_cand / n, 2), "kept_samples_per_ray": round(kept / n, 2),
+                   "field_density": NGP_DENSITY, "render_step_size": cfg.render_step_size, "cone_angle": cfg.cone_angle,
+                   "alpha_thre": cfg.alpha_thre, "params": arena.numel, "final_loss": round(float(loss), 6),
+                   "grid_refresh_ms": round(refresh_ms, 3), "launch": "eager (module / autograd path)",
+                   "packed_kernels_ms_per_step": {k: round(v, 4) for k, v in packed}},
+        "roofline": roof, "roofline_step": roof_step,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_ngp(o, d, cam, tgt, grid.binaries.cpu().numpy().astype(bool), cfg)
+    print(json.dumps(out))
+
+
+def algorithmic_model_ngp(key, kept_samples):
+    """Algorithmic work of the field kernels on the packed samples (M = kept samples of the step, SURVEY.md §8d per-sample
+    figures)."""
+    M = float(kept_samples)
+    base = key.split("[")[0]
+    if base == "nsamd_hashgrid_encode_fwd" and "L=16" in key:
+        import re
+
+        m = re.search(r"M=(\d+)", key)
+        return "hbm", float(m.group(1)) * 16 * 8 * 8
+    if base in ("nsamd_hashgrid_encode_bwd", "nsamd_hashgrid_encode_bwd_set") and "L=16" in key:
+        return "hbm", M * 16 * 8 * 16
+    if base == "nsamd_field_mlp_fwd":
+        return "mfma", M * 2 * 11392
+    if base == "nsamd_field_mlp_bwd":
+        return "mfma", M * 2 * 11392 * 2
+    return None
+
+
+def cpu_baseline_ngp(o, d, cam, tgt, binaries, cfg, n_rays=256, steps=2):
+    """The packed path's CPU restatement (oracle/packed_oracle.py marcher + visibility, oracle field, packed compositing,
+    MSE, backward, torch Adam) on a bounded sample: `n_rays` of the same rays against the same grid (the numpy marcher walks
+    rays step by step: ~10 s per 256 rays)."""
+    from oracle import nerfacto_oracle as orc
+    from oracle import packed_oracle as po
+
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
+    ocfg = orc.NerfactoCfg(prop_grids=(), num_images=100, average_init_density=1.0)
+    params = orc.init_params(ocfg, seed=0)
+    params = {k: v for k, v in params.items() if k.startswith("field.")}
+    with torch.no_grad():
+        params["field.mlp_base.model.1.layers.1.bias"][0] = float(np.log(NGP_DENSITY))
+    for p in params.values():
+        p.requires_grad_(True)
+    opt = torch.optim.Adam(list(params.values()), lr=1e-2, eps=1e-15)
+    o, d, cam, tgt = o[:n_rays], d[:n_rays], cam[:n_rays, 0], tgt[:n_rays]
+    to, td, tcam, ttgt = torch.from_numpy(o), torch.from_numpy(d), torch.from_numpy(cam), torch.from_numpy(tgt)
+    rs = np.random.RandomState(3)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        jit = rs.uniform(0, 1, n_rays).astype(np.float32)
+        idx, ts, te = po.occgrid_march(o, d, binaries, [-1, -1, -1, 1, 1, 1], cfg.render_step_size, near_plane=cfg.near_plane,
+                                       far_plane=cfg.far_plane, cone_angle=cfg.cone_angle, jitter=jit)
+        idx, ts, te = torch.from_numpy(idx), torch.from_numpy(ts), torch.from_numpy(te)
+        pos = to[idx] + td[idx] * ((ts + te) / 2)[:, None]
+        with torch.no_grad():
+            sig = orc.nerfacto_field(pos, td[idx], tcam[idx], params, ocfg, training=True)[0]
+            keep = po.render_visibility_from_density(ts, te, sig, idx, n_rays, 1e-4, min(cfg.alpha_thre, float(binaries.mean())))
+        idx, ts, te = idx[keep], ts[keep], te[keep]
+        pos = to[idx] + td[idx] * ((ts + te) / 2)[:, None]
+        opt.zero_grad(set_to_none=True)
+        dens, rgb_s, _ = orc.nerfacto_field(pos, td[idx], tcam[idx], params, ocfg, training=True)
+        w = po.render_weight_from_density(ts, te, dens, idx, n_rays)[0]
+        comp, acc, _ = po.composite_packed(rgb_s, w, ts, te, idx, n_rays, background="random", training=True)
+        bg = torch.rand_like(comp)
+        loss = torch.mean((ttgt - (comp + bg * (1.0 - acc))) ** 2)
+        loss.backward()
+        opt.step()
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": round(n_rays / med, 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_rays} of the step's 4096 rays against the same occupancy grid: numpy marcher + visibility, oracle field, "
+                      f"packed compositing, MSE, backward, Adam over the field's parameters; median of {steps} steps after 1 "
+                      f"warm-up ({med:.2f} s/step)"}
+
+
 def dry_run(args, rank, world):
     """CPU-only rehearsal of the multi-GPU launch (the driver's `python -m torch.distributed.run --nproc-per-node N ...
     bench.py --gpus N` line cannot be tried on RCCL before the round ends): same argument / environment handling, a gloo
@@ -747,9 +965,10 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="functional test: every rank uses cuda:0 (needs gloo)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--dp-graph", action="store_true", help="N > 1: replay captured hipGraph segments instead of eager launches")
-    ap.add_argument("--workload", choices=["bounded", "unbounded"], default="bounded",
+    ap.add_argument("--workload", choices=["bounded", "unbounded", "ngp"], default="bounded",
                     help="bounded = BASELINE configs[1]/[2] (the metric's configuration); unbounded = configs[4] "
-                         "(cameras outside the box, most samples in the contracted region)")
+                         "(cameras outside the box, most samples in the contracted region); ngp = configs[3] (instant-ngp: "
+                         "occupancy-grid marching + early termination, packed samples; N = 1 only)")
     ap.add_argument("--start-step", type=int, default=0,
                     help="not the headline: start the step counter (proposal update schedule, anneal, learning rate) at this "
                          "training step — e.g. 5000 = the steady state of the schedule, proposal networks updated every 6th "
@@ -802,6 +1021,9 @@ def main():
 
     _native.load()  # fail loudly if the HIP extension is missing
     F.DIRECT_GRAD = True  # backward kernels accumulate straight into the arena's gradient views
+    if args.workload == "ngp":
+        assert world == 1 and not args.force_dp, "--workload ngp is a single-GPU line"
+        return run_ngp(args, device)
     model = build_model(device, seed=0)  # same init on every rank (replicated model)
     if args.fused_model_api:
         args.autograd = True

@@ -281,15 +281,16 @@ __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
   const int64_t p0 = ((int64_t)blockIdx.x * kRunThreads + threadIdx.x) * kRunLen;
   float g0[kRunLen][kLevels], g1[kRunLen][kLevels];
   float px[kRunLen], py[kRunLen], pz[kRunLen];
+  bool act[kRunLen];
 #pragma unroll
   for (int s = 0; s < kRunLen; ++s) {
     // (per-ray mask of a gated call: rays without gradient are not loaded, see the fine kernel)
-    const bool act = p0 + s < M && (ray_mask == nullptr || ray_mask[(p0 + s) / P.samples_per_ray] != 0);
+    act[s] = p0 + s < M && (ray_mask == nullptr || ray_mask[(p0 + s) / P.samples_per_ray] != 0);
 #pragma unroll
     for (int i = 0; i < kLevels; ++i) {
       g0[s][i] = 0.0f;
       g1[s][i] = 0.0f;
-      if (act && lvl[i] >= 0) {
+      if (act[s] && lvl[i] >= 0) {
         const float* gptr = denc + (p0 + s) * stride_p + (int64_t)(2 * lvl[i]) * stride_k;
         g0[s][i] = gptr[0];
         g1[s][i] = gptr[stride_k];
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
 #pragma unroll
   for (int s = 0; s < kRunLen; ++s) {
     px[s] = py[s] = pz[s] = 0.0f;
-    if (p0 + s < M) {
+    if (act[s]) {
       load_position(P, p0 + s, px[s], py[s], pz[s]);
       (void)normalise_position(transform, box, px[s], py[s], pz[s]);
     }

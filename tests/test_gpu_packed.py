@@ -253,8 +253,8 @@ def test_marcher_with_coarse_occupancy_bits_places_the_same_samples(F, levels, r
     for kind in ("clustered", "random"):
         if kind == "clustered":
             occ = np.zeros((levels, res, res, res), np.float32)
-            c = res // 2
-            occ[:, c - 3:c + 2, c - 1:c + 4, c - 2:c + 3] = rs.uniform(0.2, 1.0, (levels, 5, 5, 5))
+            c, h = res // 2, res // 4
+            occ[:, c - h:c + h - 1, c - h + 1:c + h, c - h:c + h] = rs.uniform(0.2, 1.0, (levels, 2 * h - 1, 2 * h - 1, 2 * h))
             occ[0, 1, 2, 3] = 1.0          # a lone cell far from the blob
         else:
             occ = (rs.rand(levels, res, res, res) > 0.9) * rs.uniform(0.2, 1.0, (levels, res, res, res))
@@ -272,11 +272,11 @@ def test_marcher_with_coarse_occupancy_bits_places_the_same_samples(F, levels, r
         bits = ((coarse.cpu().numpy().astype(np.int64)[:, None] >> np.arange(32)) & 1).astype(bool).reshape(-1)[: blocks.size]
         np.testing.assert_array_equal(bits, blocks)
         if kind == "clustered":
-            assert blocks.mean() < 0.2
+            assert blocks.mean() < 0.35
         with_bits = F.occgrid_march(dev(o), dev(d), binaries, ROI, 0.02, 0.05, 50.0, None, None, 0.004, dev(jit), coarse=coarse)
         without = F.occgrid_march(dev(o), dev(d), binaries, ROI, 0.02, 0.05, 50.0, None, None, 0.004, dev(jit))
         ref = po.occgrid_march(o, d, B, ROI, 0.02, near_plane=0.05, far_plane=50.0, cone_angle=0.004, jitter=jit)
-        assert len(ref[0]) > 100
+        assert len(ref[0]) > 50
         for a, b, c_ in zip(with_bits[:3], without[:3], ref):
             np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
             np.testing.assert_array_equal(a.cpu().numpy(), c_)
@@ -290,7 +290,7 @@ def test_occupancy_grid_refresh_kernels_equal_the_torch_path(F):
 
     def blob(x):  # a density-like field; evaluated on the CPU for both grids (identical estimates)
         x = x.detach().cpu()
-        return (torch.exp(-3.0 * (x * x).sum(-1, keepdim=True)) * 0.4).float()
+        return (torch.exp(-3.0 * (x * x).sum(-1, keepdim=True)) * 0.4 + 1e-6).float()  # (no denormals: density x step never is)
 
     res, levels = 16, 3
     total = levels * res ** 3
