@@ -261,7 +261,20 @@ class NerfactoModel(nn.Module):
 
     @torch.no_grad()
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
-        """Chunked full-image render (models/base_model.py:178-205)."""
+        """Chunked full-image render (models/base_model.py:178-205). In eval mode on the GPU the chunk loop is device-side
+        (eval_render.EvalRenderer: one captured kernel schedule per chunk over static buffers, outputs copied into
+        preallocated image buffers — no per-chunk module graph, no torch.cat); NSAMD_EVAL_RUNNER=0, training mode or an
+        unsupported configuration take the reference's Python loop over `forward`."""
+        import os
+
+        from . import eval_render
+
+        if (not self.training and camera_ray_bundle.origins.is_cuda and os.environ.get("NSAMD_EVAL_RUNNER", "1") == "1"
+                and eval_render.supported(self) is None and getattr(self.config, "use_single_jitter", True)):
+            runner = getattr(self, "_eval_runner", None)
+            if runner is None or runner.chunk != self.config.eval_num_rays_per_chunk:
+                runner = self._eval_runner = eval_render.EvalRenderer(self)
+            return runner.render(camera_ray_bundle)
         image_shape = camera_ray_bundle.origins.shape[:-1]
         num_rays = len(camera_ray_bundle)
         chunk = self.config.eval_num_rays_per_chunk

@@ -22,7 +22,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--height", type=int, default=800)
 ap.add_argument("--width", type=int, default=800)
 ap.add_argument("--frames", type=int, default=5)
+ap.add_argument("--module-loop", action="store_true", help="the reference-shaped Python chunk loop + torch.cat (NSAMD_EVAL_RUNNER=0)")
 args = ap.parse_args()
+if args.module_loop:
+    os.environ["NSAMD_EVAL_RUNNER"] = "0"
 dev = torch.device("cuda", 0)
 model = bench.build_model(dev, seed=0).eval()
 
@@ -60,6 +63,12 @@ for _ in range(args.frames):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.frames
 assert out["rgb"].shape[:2] == (H, W) and bool(torch.isfinite(out["rgb"]).all())
+# forward-only HBM ceiling = 8 TB/s / 161.9 kB of hash gathers + ray I/O per ray = 49.4 M rays/s
+CEILING = 8.0e12 / 161.9e3
 print(json.dumps({"metric": "eval render rays/sec (nerfacto, 256 -> 96 -> 48 samples per ray)", "value": round(H * W / dt, 1),
                   "unit": "rays/s", "ms_per_frame": round(dt * 1e3, 2), "image": [H, W],
-                  "chunk": model.config.eval_num_rays_per_chunk, "launch": "eager", "data": "synthetic", "dtype": "f32"}))
+                  "chunk": model.config.eval_num_rays_per_chunk,
+                  "launch": "Python loop over forward + torch.cat (eager)" if args.module_loop else
+                            "device-side chunk loop: one captured kernel schedule per chunk (eval_render.py)",
+                  "forward_ceiling_rays_per_s": round(CEILING, 1), "frac_of_forward_ceiling": round(H * W / dt / CEILING, 4),
+                  "data": "synthetic", "dtype": "f32"}))

@@ -1197,6 +1197,47 @@ def test_eval_render_path_full_image(F):
     close(out["depth"].reshape(-1, 1), ref["depth"], rtol=2e-3)
 
 
+def test_eval_renderer_equals_the_module_chunk_loop(F, monkeypatch):
+    """eval_render.EvalRenderer (device-side chunk loop: one captured kernel schedule per chunk, outputs copied into
+    preallocated image buffers) against the reference-shaped Python loop over `forward` + torch.cat: every output of a
+    frame whose ray count is not a multiple of the chunk — bit for bit (same kernels, same order), eager and replayed,
+    and again after the parameters changed (the captured graph reads them from the same arena)."""
+    from nerfstudio_amd.cameras.rays import RayBundle
+    from nerfstudio_amd.eval_render import EvalRenderer
+
+    cfg = small_cfg(12, 10, 5)
+    model = _hip_model(cfg, orc.init_params(cfg, seed=3, table_std=0.4), training=False)
+    model.config.eval_num_rays_per_chunk = 512
+    model.proposal_sampler.set_anneal(0.37)
+    H, W = 37, 41  # 1517 rays: 2 full chunks + 493
+    o, d, cam, _ = orc.synthetic_rays(H * W, cfg.num_images, seed=9)
+    o[::3] *= 3.0
+    rb = RayBundle(origins=o.cuda().view(H, W, 3), directions=d.cuda().view(H, W, 3),
+                   pixel_area=torch.full((H, W, 1), 1e-6).cuda(), camera_indices=torch.zeros((H, W, 1), dtype=torch.int64).cuda())
+    monkeypatch.setenv("NSAMD_EVAL_RUNNER", "0")
+    ref = model.get_outputs_for_camera_ray_bundle(rb)
+    monkeypatch.setenv("NSAMD_EVAL_RUNNER", "1")
+    keys = {"rgb", "accumulation", "depth", "expected_depth", "prop_depth_0", "prop_depth_1"}
+    assert keys <= set(ref)
+    for use_graph in (False, True):
+        out = EvalRenderer(model, use_graph=use_graph).render(rb)
+        for k in keys:
+            assert out[k].shape == ref[k].shape, k
+            assert torch.equal(out[k], ref[k]), f"{k} ({'graph' if use_graph else 'eager'}): max |d| = {float((out[k] - ref[k]).abs().max()):.3e}"
+    # through the model entry point, twice (the second frame replays the captured chunk), then with changed parameters
+    a = model.get_outputs_for_camera_ray_bundle(rb)
+    b = model.get_outputs_for_camera_ray_bundle(rb)
+    assert model._eval_runner.graph is not None and all(torch.equal(a[k], ref[k]) and torch.equal(b[k], ref[k]) for k in keys)
+    with torch.no_grad():
+        model.field.mlp_base.encoding.hash_table.mul_(1.3)
+        model.field.embedding_appearance.embedding.weight.add_(0.05)
+    monkeypatch.setenv("NSAMD_EVAL_RUNNER", "0")
+    ref2 = model.get_outputs_for_camera_ray_bundle(rb)
+    monkeypatch.setenv("NSAMD_EVAL_RUNNER", "1")
+    c = model.get_outputs_for_camera_ray_bundle(rb)
+    assert not torch.equal(ref2["rgb"], ref["rgb"]) and all(torch.equal(c[k], ref2[k]) for k in keys)
+
+
 def test_training_trajectory_matches_oracle(F):
     """30 full training steps (forward, 3 losses, backward, Adam) on the GPU runner and on the CPU oracle from the same
     initialisation, rays and jitter draws: the loss curves must track each other (tight at first, ulp-level
