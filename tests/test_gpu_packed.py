@@ -309,17 +309,16 @@ def test_occupancy_grid_refresh_kernels_equal_the_torch_path(F):
     # a warm-up refresh and two partial ones through the public entry point, with the random draws pinned
     for step, seed in ((0, 1), (256, 2), (272, 3)):
         outs = []
+        if step >= 256:  # same cells / offsets on both grids: drawn once, on the CPU, from the state BEFORE the refresh
+            k = total // 4
+            gen2 = torch.Generator().manual_seed(100 + seed)
+            uniform = torch.randint(total, (k,), generator=gen2)
+            occupied = torch.nonzero(g_cpu.binaries.reshape(-1)).reshape(-1)
+            flat = torch.cat([uniform, occupied[:k]])
+            offs = torch.rand((flat.numel(), 3), generator=gen2)
+            assert flat.numel() > flat.unique().numel()  # repeated cells are part of the case
         for g in (g_cpu, g_gpu):
-            torch.manual_seed(seed)
-            if g is g_gpu:
-                torch.cuda.manual_seed(seed)
-            if step >= 256:  # same cells / offsets on both: draw on the CPU, replay on the GPU
-                k = total // 4
-                gen2 = torch.Generator().manual_seed(100 + seed)
-                uniform = torch.randint(total, (k,), generator=gen2)
-                occupied = torch.nonzero(g_cpu.binaries.reshape(-1)).reshape(-1)
-                flat = torch.cat([uniform, occupied[:k]])
-                offs = torch.rand((flat.numel(), 3), generator=gen2)
+            if step >= 256:
                 x = g._cell_positions(flat.to(g.occs.device), flat.numel(), offs.to(g.occs.device))
                 occ = blob(x).reshape(-1).to(g.occs.device)
                 if g.occs.is_cuda:
