@@ -459,13 +459,27 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
     if (threadIdx.x == 0) buf.dyn_cursor[tile] = 0u;
     return;
   }
+  const uint32_t static_end = coarse ? 0u : G.segs * C;
+  const uint32_t n_dyn = min(buf.dyn_cursor[tile], Q - static_end);
+  const uint32_t n_spill = min(min(buf.hdr[kHdrSpillCount], G.spill_cap), kSpillFold);
+  if (!overwrite && n_spill == 0u) {
+    // Accumulating call: a tile nothing was routed into (the proposal levels while few rays carry gradient,
+    // profiles/r03_proposal_sparsity.txt) keeps its gradient as it is — no LDS fill, no conversion, no read-modify-write.
+    // Static segments: one count per pass-1 workgroup, read once here (the accumulation below reads them again from L2).
+    bool any = n_dyn != 0u;
+    if (!coarse && !any) {
+      const uint32_t* cnts = buf.counts + (size_t)tile * G.segs;
+      for (uint32_t sgi = threadIdx.x; sgi < G.segs; sgi += blockDim.x) any = any || cnts[sgi] != 0u;
+    }
+    if (!__syncthreads_or(any)) {
+      if (threadIdx.x == 0) buf.dyn_cursor[tile] = 0u;
+      return;
+    }
+  }
   {
     uint4* z = reinterpret_cast<uint4*>(acc);
     for (int e = threadIdx.x; e < entries; e += blockDim.x) z[e] = make_uint4(0u, 0u, 0u, 0u);
   }
-  const uint32_t static_end = coarse ? 0u : G.segs * C;
-  const uint32_t n_dyn = min(buf.dyn_cursor[tile], Q - static_end);
-  const uint32_t n_spill = min(min(buf.hdr[kHdrSpillCount], G.spill_cap), kSpillFold);
   __syncthreads();
   PROBE_STAMP(0, 11);
   // self-cleaning cursor: the next call finds zeros again (the workspace state is zero-initialised once by its owner)
@@ -803,12 +817,20 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
     NSAMD_CHECK_LAUNCH();
   }
   if (coarse.count > 0) {
-    constexpr int kL = 4;
-    const size_t lds = sizeof(uint32_t) * (3 * (size_t)kL * ((size_t)1 << G.log2_bins) + kL);
+    // levels per thread of the run kernel (NSAMD_RUNS_LEVELS = 1 / 2 / 4, read once): fewer levels per thread = more, shorter
+    // workgroups — its time is the latency of one workgroup's two sweeps (profiles/r03_sparse_regime_kernel_stats.csv)
+    static const int runs_levels = env_int("NSAMD_RUNS_LEVELS", 4);
     const int64_t per_block = (int64_t)kRunThreads * kRunLen;
-    dim3 g1((unsigned)((M + per_block - 1) / per_block), (unsigned)((coarse.count + kL - 1) / kL));
-    scatter_route_runs_kernel<kL><<<g1, kRunThreads, lds, st>>>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G,
-                                                              coarse, buf, gate, ray_mask);
+    auto launch_runs = [&](auto tag) {
+      constexpr int kL = decltype(tag)::value;
+      const size_t lds = sizeof(uint32_t) * (3 * (size_t)kL * ((size_t)1 << G.log2_bins) + kL);
+      dim3 g1((unsigned)((M + per_block - 1) / per_block), (unsigned)((coarse.count + kL - 1) / kL));
+      scatter_route_runs_kernel<kL><<<g1, kRunThreads, lds, st>>>(pts, M, transform, aabb, grid, denc, stride_p, stride_k, G,
+                                                                coarse, buf, gate, ray_mask);
+    };
+    if (runs_levels == 1) launch_runs(std::integral_constant<int, 1>{});
+    else if (runs_levels == 2) launch_runs(std::integral_constant<int, 2>{});
+    else launch_runs(std::integral_constant<int, 4>{});
     NSAMD_CHECK_LAUNCH();
   }
   const unsigned threads = G.slice_log2 > 11 ? 1024u : (G.slice_log2 > 9 ? 512u : 256u);
