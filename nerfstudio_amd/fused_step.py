@@ -82,6 +82,9 @@ class FusedTrainStep:
         from .train_step import NerfactoTrainStep
 
         if self.runner is None or self.runner.n != num_rays:
+            from . import _native as N
+
+            N.require_cuda(torch.empty(0, device=device))  # the kernel wrappers' loud error, before any device object is built
             self.runner = NerfactoTrainStep(self.model, num_rays, device)
             self.runner.reg_in_backward = False  # get_loss_dict hands the regulariser to autograd
         return self.runner
