@@ -340,6 +340,19 @@ int nsamd_weights_bwd_gate(const float* t_bins, const float* density, const floa
  * fine sampler) -> [num_rays, S_prev + S + 2]. inds (nullable) receives the
  * searchsorted(side="right") result as int32 [num_rays, S+1]. u_offset = (float)(1.0 / (2 * (S+1))) is the eval-mode
  * offset (ray_samplers.py:327), rounded double->float by the host like torch rounds the Python scalar.
+ * INDEX CONTRACT (north_star: "bit-exact for sample indices"). The only sum of this stage whose order the reference does
+ * not fix is weights_sum = torch.sum(weights, dim=-1) (ray_samplers.py:304): ATen's CPU kernel reduces a row with a
+ * vectorised cascade whose grouping depends on the host's SIMD width, its CUDA kernel with a block tree — the reference
+ * itself returns sums that differ in the last ulp between its own backends. This library evaluates the CORRECTLY ROUNDED
+ * sum (accumulated in double, rounded to fp32 once) — the value every order approximates — and torch.cumsum's order for the
+ * CDF (left to right, double accumulate, per-element rounding: ATen's CPU cumsum). Consequence, checked against the
+ * fixtures the reference wrote (tests/golden/samplers.npz, _check_inds in tests/test_oracle_vs_golden.py): all indices
+ * equal the reference's EXCEPT where the sample position u coincides with a CDF entry to within 2 ulp — an exact tie that
+ * the last bit of weights_sum decides (on the fixtures: <= 4 of 3 104 indices, the eval-mode u = 0.5 of degenerate rays
+ * whose CDF hits 0.5). TIE RULE: at such a tie the index follows searchsorted(side="right") on THIS library's cdf, i.e.
+ * the first edge strictly greater than u; the two candidate indices bracket the same CDF value, so the interpolated bin
+ * (the sample position the caller uses) is the same to 2 ulp either way. Against the oracle (same rounding) indices and
+ * bins are bit-exact on every test seed.
  * anneal_dev (nullable): device copy of the anneal exponent; overrides `anneal` so that a captured hipGraph of the
  * training step can be replayed while the schedule advances. spacing: as in nsamd_piecewise_bins (the s -> t map of
  * the initial sampler, ray_samplers.py:112-116). */

@@ -813,73 +813,6 @@ __device__ __forceinline__ void coop_dw(v4f* acc, float* dbacc, bool want_db, co
   }
 }
 
-// ---- weight gradients on the bf16 matrix cores, two-piece operands (opt-in: NSAMD_FIELD_BWD_BF16X2=1) ----------------
-// dW = dY^T X is a sum over ALL points of the launch (196 608 at the benchmark size), so the 2^-16 relative error of a
-// two-piece product (x = h + m, each the RNE bf16 of what is left; products hh + hm + mh in fp32) averages down:
-// scripts/study_bf16_wgrad.py measures <= 5e-6 x max|dW| on the oracle's real activations and gradients, against the
-// 2e-5 of the tightest gradient test. v_mfma_f32_16x16x32_bf16 covers 32 points in 16 clocks where eight
-// v_mfma_f32_16x16x4_f32 need 256: three piece products cost 48. The data-gradient chain and the forward stay in f32.
-// Scratch tile: the f32 tile's layout word for word — row = feature, word j = point j — with the word holding the two
-// pieces of the value, h in the low and m in the high half (one ds_write_b32 per value at the f32 path's addresses, no
-// cross-lane traffic). K = 32 points = the tiles of two consecutive waves: lane (i, g) supplies the 8 points
-// 8 (g & 1) .. + 7 of area first + (g >> 1): two ds_read_b128, de-interleaved into the h and the m operand by four
-// v_perm_b32 each. A and B use the same lane -> point map, which is all a sum over K needs.
-template <int T>
-__device__ __forceinline__ void store_rows_bf2(float* Sf, const v4f* x, int j, int g) {
-  unsigned* S = reinterpret_cast<unsigned*>(Sf);
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = x[t][r];
-      const float h = __uint_as_float(pack_bf16(v, 0.0f) << 16);  // RNE bf16 of v, widened again
-      S[(16 * t + 4 * g + r) * kScratchLd + j] = pack_bf16(v, v - h);  // (h | m << 16); v - h is exact
-    }
-}
-
-struct Op2 {
-  u4 h, m;
-};
-
-// 8 consecutive words (h | m << 16) of a scratch row -> the packed h operand and the packed m operand
-__device__ __forceinline__ Op2 load_op2(const unsigned* row) {
-  const u4 w0 = *reinterpret_cast<const u4*>(row), w1 = *reinterpret_cast<const u4*>(row + 4);
-  Op2 o;
-  // v_perm_b32(src0, src1, sel): selector bytes 0-3 pick from src1, 4-7 from src0
-  o.h = u4{__builtin_amdgcn_perm(w0[1], w0[0], 0x05040100u), __builtin_amdgcn_perm(w0[3], w0[2], 0x05040100u),
-           __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u), __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u)};
-  o.m = u4{__builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u), __builtin_amdgcn_perm(w0[3], w0[2], 0x07060302u),
-           __builtin_amdgcn_perm(w1[1], w1[0], 0x07060302u), __builtin_amdgcn_perm(w1[3], w1[2], 0x07060302u)};
-  return o;
-}
-
-__device__ __forceinline__ float sum_bf16x8(const u4& w) {
-  float s = 0.0f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) s += __uint_as_float(w[k] << 16) + __uint_as_float(w[k] & 0xffff0000u);
-  return s;
-}
-
-// coop_dw over area PAIRS (first and count even): 3 bf16 MFMAs per output tile and pair instead of 8 f32 ones
-template <int TILES>
-__device__ __forceinline__ void coop_dw_bf2(v4f* acc, float* dbacc, bool want_db, const float* scratch, int first,
-                                            int count, int n, int m0, int j, int g) {
-  const int half = 8 * (g & 1), sub = g >> 1;
-  for (int pair = first; pair < first + count; pair += 2) {
-    const unsigned* Sd = reinterpret_cast<const unsigned*>(scratch + (pair + sub) * 2 * kScratchTile);
-    const unsigned* Sx = Sd + kScratchTile;
-    const Op2 a = load_op2(Sd + (16 * n + j) * kScratchLd + half);
-    if (want_db) *dbacc += sum_bf16x8(a.h) + sum_bf16x8(a.m);
-#pragma unroll
-    for (int i = 0; i < TILES; ++i) {
-      const Op2 b = load_op2(Sx + (16 * (m0 + i) + j) * kScratchLd + half);
-      acc[i] = mfma_bf16(a.h, b.m, acc[i]);  // smaller products first
-      acc[i] = mfma_bf16(a.m, b.h, acc[i]);
-      acc[i] = mfma_bf16(a.h, b.h, acc[i]);
-    }
-  }
-}
-
 // acc lane (j, g) reg r of tile (n, m) = dW[16n + 4g + r][slot 16m + j]: to the workgroup's partial row (plain stores,
 // this wave is the only writer) or, without a partial buffer, straight into the gradient with atomics
 __device__ __forceinline__ void coop_emit(const v4f& acc, int n, int m, int k_pad, float* partial_layer,
@@ -908,21 +841,7 @@ __device__ __forceinline__ void coop_emit_bias(float v, int n, int j, int g, flo
   }
 }
 
-template <bool BF2, int T>
-__device__ __forceinline__ void put_rows(float* S, const v4f* x, int j, int g) {
-  if constexpr (BF2) store_rows_bf2<T>(S, x, j, g);
-  else store_rows<T>(S, x, j, g);
-}
-
-template <bool BF2, int TILES>
-__device__ __forceinline__ void dw_share(v4f* acc, float* dbacc, bool want_db, const float* scratch, int first, int count,
-                                         int n, int m0, int j, int g) {
-  if constexpr (BF2) coop_dw_bf2<TILES>(acc, dbacc, want_db, scratch, first, count, n, m0, j, g);
-  else coop_dw<TILES>(acc, dbacc, want_db, scratch, first, count, n, m0, j, g);
-}
-
-template <bool BF2>  // BF2: the weight-gradient GEMMs on two-piece bf16 operands (store_rows_bf2 / coop_dw_bf2)
-__device__ __forceinline__ void field_mlp_bwd_body(
+__global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
     nsamd_field_mlp mlp, int app_dim, const float* __restrict__ ddensity, const float* __restrict__ drgb,
@@ -1022,38 +941,38 @@ __device__ __forceinline__ void field_mlp_bwd_body(
     // Every layer: the wave stores its (Dout, X) tiles, runs its own data-gradient GEMM (registers + weights only) while
     // the stores drain, THEN meets the workgroup and takes its share of the weight gradient — so both barrier intervals
     // of a layer hold MFMA work (the store -> barrier interval used to hold none).
-    put_rows<BF2, 1>(Sd, g_rgbp, j, g);
-    put_rows<BF2, 4>(Sx, A.hb, j, g);
+    store_rows<1>(Sd, g_rgbp, j, g);
+    store_rows<4>(Sx, A.hb, j, g);
     v4f g_hb[4];
     zero_tiles<4>(g_hb);
     if (!(probe_skip & 4)) rows_gemm_bwd<4, 1, kLd64>(W + kRowHead2, g_rgbp, g_hb, j, g);
     relu_mask<4>(g_hb, A.hb);
     if (!(probe_skip & 2)) __syncthreads();
-    if (!(probe_skip & 1)) dw_share<BF2, 1>(dW_h2, &db_h2, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
+    if (!(probe_skip & 1)) coop_dw<1>(dW_h2, &db_h2, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 4 + 10 * (int)it);
 
     // ---- head layer 1 (64 -> 64) ----
-    put_rows<BF2, 4>(Sd, g_hb, j, g);
-    put_rows<BF2, 4>(Sx, A.ha, j, g);
+    store_rows<4>(Sd, g_hb, j, g);
+    store_rows<4>(Sx, A.ha, j, g);
     v4f g_ha[4];
     zero_tiles<4>(g_ha);
     if (!(probe_skip & 4)) rows_gemm_bwd<4, 4, kLd64>(W + kRowHead1, g_hb, g_ha, j, g);
     relu_mask<4>(g_ha, A.ha);
     if (!(probe_skip & 2)) __syncthreads();
-    if (!(probe_skip & 1)) dw_share<BF2, 2>(dW_h1, &db_h1, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
+    if (!(probe_skip & 1)) coop_dw<2>(dW_h1, &db_h1, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 5 + 10 * (int)it);
 
     // ---- head layer 0 (slots 64 -> 64) ----
-    put_rows<BF2, 4>(Sd, g_ha, j, g);
-    put_rows<BF2, 4>(Sx, A.hin, j, g);
+    store_rows<4>(Sd, g_ha, j, g);
+    store_rows<4>(Sx, A.hin, j, g);
     v4f g_hin[4];
     zero_tiles<4>(g_hin);
     // input tile 0 is the SH block: it carries no gradient, so only columns 16..63 (tiles 1..3) are formed
     if (!(probe_skip & 4)) rows_gemm_bwd<3, 4, kLd64>(W + kRowHead0 + 16, g_ha, g_hin + 1, j, g);
     if (!(probe_skip & 2)) __syncthreads();
-    if (!(probe_skip & 1)) dw_share<BF2, 2>(dW_h0, &db_h0, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
+    if (!(probe_skip & 1)) coop_dw<2>(dW_h0, &db_h0, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 6 + 10 * (int)it);
 
@@ -1110,20 +1029,20 @@ __device__ __forceinline__ void field_mlp_bwd_body(
                                   expf(fminf(fmaxf(pre, -15.0f), 15.0f))
                             : 0.0f;
     }
-    put_rows<BF2, 1>(Sd, g_o16, j, g);
-    put_rows<BF2, 4>(Sx, A.h1, j, g);
+    store_rows<1>(Sd, g_o16, j, g);
+    store_rows<4>(Sx, A.h1, j, g);
     v4f g_h1[4];
     zero_tiles<4>(g_h1);
     if (!(probe_skip & 4)) rows_gemm_bwd<4, 1, kLd64>(W + kRowBase1, g_o16, g_h1, j, g);
     relu_mask<4>(g_h1, A.h1);
     if (!(probe_skip & 2)) __syncthreads();
-    if (!(probe_skip & 1)) dw_share<BF2, 1>(dW_b1, &db_b1, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
+    if (!(probe_skip & 1)) coop_dw<1>(dW_b1, &db_b1, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 7 + 10 * (int)it);
 
     // ---- base layer 0 (32 -> 64) ----
-    put_rows<BF2, 4>(Sd, g_h1, j, g);
-    put_rows<BF2, 2>(Sx, A.enc, j, g);
+    store_rows<4>(Sd, g_h1, j, g);
+    store_rows<2>(Sx, A.enc, j, g);
     v4f g_enc[2];
     zero_tiles<2>(g_enc);
     if (!(probe_skip & 4)) rows_gemm_bwd<2, 4, kLd32>(W + kRowBase0, g_h1, g_enc, j, g);
@@ -1134,7 +1053,7 @@ __device__ __forceinline__ void field_mlp_bwd_body(
         for (int r = 0; r < 4; ++r) denc[(int64_t)(16 * t + 4 * g + r) * M + ti.p] = g_enc[t][r];
     }
     if (!(probe_skip & 2)) __syncthreads();
-    if (!(probe_skip & 1)) dw_share<BF2, 1>(dW_b0, &db_b0, own_m1 == 0, scratch, 0, kCoopWaves, own_n, own_m1, j, g);
+    if (!(probe_skip & 1)) coop_dw<1>(dW_b0, &db_b0, own_m1 == 0, scratch, 0, kCoopWaves, own_n, own_m1, j, g);
     // no barrier here: the next writer of the scratch is the next iteration's head layer 2, behind its own barrier
     PROBE_STAMP(kCoopWaves, 8 + 10 * (int)it);
   }
@@ -1183,25 +1102,6 @@ __device__ __forceinline__ void field_mlp_bwd_body(
   if (own_m1 == 0) coop_emit_bias(db_b0, own_n, j, g, pbias ? pbias + kBiasBase0 : nullptr, grads.base_b0, 64);
   PROBE_STAMP(kCoopWaves, 63);
 }
-
-#define NSAMD_FIELD_BWD_PARAMS                                                                                       \
-  const float *__restrict__ enc, const float *__restrict__ selector, const float *__restrict__ directions,          \
-      const int64_t *__restrict__ cams, const float *__restrict__ app_const, int64_t dir_group, int64_t M,           \
-      nsamd_field_mlp mlp, int app_dim, const float *__restrict__ ddensity, const float *__restrict__ drgb,          \
-      float *__restrict__ denc, nsamd_field_mlp_grads grads, float *__restrict__ partials,                           \
-      float *__restrict__ app_partials, const float *__restrict__ acts, int probe_skip
-#define NSAMD_FIELD_BWD_ARGS \
-  enc, selector, directions, cams, app_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc, grads, partials, app_partials, acts, probe_skip
-
-__global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(NSAMD_FIELD_BWD_PARAMS) {
-  field_mlp_bwd_body<false>(NSAMD_FIELD_BWD_ARGS);
-}
-
-// opt-in (NSAMD_FIELD_BWD_BF16X2=1): weight gradients on the bf16 matrix cores with two-piece operands
-__global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_bf2_kernel(NSAMD_FIELD_BWD_PARAMS) {
-  field_mlp_bwd_body<true>(NSAMD_FIELD_BWD_ARGS);
-}
-
 
 // destination of element e of the [kPartialStride] reduction layout (weights: padded [rows][slots] per layer, then
 // the padded biases); nullptr for padding / absent tensors
@@ -1479,14 +1379,10 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
   if (hipGetDevice(&dev) != hipSuccess) return NSAMD_ERR_NO_DEVICE;
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {  // the dynamic-LDS opt-in is per device
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_bf2_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return NSAMD_ERR_LAUNCH;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  // opt-in, unmeasured in round 2 (built and checked against a lane-level emulation on the CPU only): DESIGN.md 7.1 item 2
-  static const int bf16x2 = getenv("NSAMD_FIELD_BWD_BF16X2") ? atoi(getenv("NSAMD_FIELD_BWD_BF16X2")) : 0;
   static const int probe_skip = getenv("NSAMD_FIELD_BWD_SKIP") ? atoi(getenv("NSAMD_FIELD_BWD_SKIP")) : 0;
   const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + kCoopWaves - 1) / kCoopWaves);
   float* partials = (workspace != nullptr && workspace_floats >= (int64_t)blocks * kPartialStride) ? workspace : nullptr;
@@ -1499,14 +1395,9 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
     app_partials = workspace + (int64_t)blocks * kPartialStride;
   if (phases != 3) NSAMD_REQUIRE(partials != nullptr);  // without scratch the kernel flushes with atomics: nothing to split
   if (phases & 1) {
-    if (bf16x2)
-      field_mlp_bwd_bf2_kernel<<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
-          enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-          grads, partials, app_partials, acts, probe_skip);
-    else
-      field_mlp_bwd_kernel<<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
-          enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-          grads, partials, app_partials, acts, probe_skip);
+    field_mlp_bwd_kernel<<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
+        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
+        grads, partials, app_partials, acts, probe_skip);
     NSAMD_CHECK_LAUNCH();
   }
   if (partials != nullptr && (phases & 2)) {

@@ -819,7 +819,8 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
   if (coarse.count > 0) {
     // levels per thread of the run kernel (NSAMD_RUNS_LEVELS = 1 / 2 / 4, read once): fewer levels per thread = more, shorter
     // workgroups — its time is the latency of one workgroup's two sweeps (profiles/r03_sparse_regime_kernel_stats.csv)
-    static const int runs_levels = env_int("NSAMD_RUNS_LEVELS", 4);
+    // (MI355X, driver window of the bench: 4 -> 75 us, 2 -> 54, 1 -> 54 per launch of the 256-sample level's scatter)
+    static const int runs_levels = env_int("NSAMD_RUNS_LEVELS", 2);
     const int64_t per_block = (int64_t)kRunThreads * kRunLen;
     auto launch_runs = [&](auto tag) {
       constexpr int kL = decltype(tag)::value;
