@@ -23,6 +23,7 @@ import torch.distributed as dist
 from torch.nn import Parameter
 
 from . import functional as F
+from .utils import profiler
 
 _ALIGN = 64  # floats: every tensor starts on a 256-B boundary
 _GROUP_ALIGN = _ALIGN * 840  # floats: lcm(1..8) aligned shards per optimiser group (<= 215 KB of zero padding per group)
@@ -187,6 +188,7 @@ class ParamArena:
         self._compact = getattr(self, "_compact", {})
         self._compact[id(param)] = (off, prefix_rows, feat, idx, torch.zeros((idx.numel(), feat), device=self.grad.device))
 
+    @profiler.time_function
     def all_reduce_group(self, name: str, async_op: bool = False, group: Optional[dist.ProcessGroup] = None):
         """Sum one optimiser group's gradients over the ranks: dense spans as they lie, registered table prefixes
         through their compact buffers. Returns a handle whose wait() also scatters the reduced rows back (None when
@@ -235,6 +237,7 @@ class ParamArena:
         n = (b - a) // world
         return a + rank * n, a + (rank + 1) * n
 
+    @profiler.time_function
     def reduce_scatter_group(self, name: str, async_op: bool = False, group: Optional[dist.ProcessGroup] = None):
         """Sum the group's gradients over the ranks INTO this rank's shard of the gradient arena (in place: the output is
         the rank's slice of the input, RCCL's in-place reduce-scatter). Afterwards only `shard_span(name)` of the gradient
@@ -246,6 +249,7 @@ class ParamArena:
         return dist.reduce_scatter_tensor(self.grad[sa:sb], self.grad[a:b], op=dist.ReduceOp.SUM, group=group,
                                           async_op=async_op)
 
+    @profiler.time_function
     def all_gather_group(self, name: str, async_op: bool = False, group: Optional[dist.ProcessGroup] = None):
         """Every rank's updated parameter shard -> every rank's full parameter slice (in place)."""
         if not (dist.is_available() and dist.is_initialized()) or _single(group):
@@ -254,6 +258,7 @@ class ParamArena:
         sa, sb = self.shard_span(name, group)
         return dist.all_gather_into_tensor(self.flat[a:b], self.flat[sa:sb], group=group, async_op=async_op)
 
+    @profiler.time_function
     def step_shard(self, name: str, grad_scale: float = 1.0, lr: Optional[float] = None,
                    hyper_dev: Optional[Dict[str, torch.Tensor]] = None, group: Optional[dist.ProcessGroup] = None) -> None:
         """Adam on this rank's shard of group `name` only (after reduce_scatter_group, before all_gather_group). The
@@ -280,6 +285,7 @@ class ParamArena:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.broadcast(self.flat, src=src, group=group)
 
+    @profiler.time_function
     def step(self, grad_scale: float = 1.0, lr: Optional[float] = None, groups: Optional[Sequence[str]] = None,
              hyper_dev: Optional[Dict[str, torch.Tensor]] = None) -> None:
         """One Adam update (csrc/misc.hip) per selected group (default: all), each with its own bias-correction step.

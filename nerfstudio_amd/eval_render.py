@@ -25,7 +25,8 @@ import torch
 from torch import Tensor
 
 from . import _native as N
-from . import functional as F
+from . import functional as F  # noqa: F401
+from .utils import profiler
 
 
 class EvalRenderer:
@@ -128,6 +129,7 @@ class EvalRenderer:
         self.graph.replay()
 
     # ---- a frame ----------------------------------------------------------------------------------------------------------
+    @profiler.time_function
     @torch.no_grad()
     def render(self, camera_ray_bundle) -> Dict[str, Tensor]:
         """-> the reference's output dict for a camera (`rgb`, `accumulation`, `depth`, `expected_depth`, `prop_depth_i`),

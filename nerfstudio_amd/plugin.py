@@ -176,6 +176,9 @@ def nerfacto_hip():
         from nerfstudio.plugins.types import MethodSpecification
     except Exception as e:  # noqa: BLE001 - tyro / viser / torchmetrics missing count as "nerfstudio not importable"
         raise ImportError(f"nerfstudio_amd.plugin: nerfstudio (with its trainer dependencies) is not importable: {e}") from e
+    from .utils import profiler
+
+    profiler.hook_reference_profiler()  # the reference's own time_function hooks open roctx ranges (NSAMD_ROCTX=1)
     cfg_cls, _ = _model_classes()
     base = copy.deepcopy(method_configs["nerfacto"])
     old = base.pipeline.model

@@ -28,6 +28,7 @@ from torch import Tensor
 from . import _native as N
 from . import functional as F
 from .nerfacto import NerfactoModel
+from .utils import profiler
 
 
 class NerfactoTrainStep:
@@ -298,6 +299,7 @@ class NerfactoTrainStep:
             N.ptr(self.d_origins[lvl]), N.ptr(self.d_directions[lvl]), 0, gate, ray_mask, N.stream()),
             "hashgrid_encode_bwd_rays")
 
+    @profiler.time_function
     def backward_cameras(self, updated: bool) -> None:
         """Per-ray gradients of every level that received one -> `pose_adjustment.grad` (plus the L2 regulariser of
         camera_optimizers.py:179-185, whose value is kept in `camera_reg`). Call after the backward chains have joined."""
@@ -318,6 +320,7 @@ class NerfactoTrainStep:
             torch.autograd.backward([o, d], [d_o, d_d])
         self._corrected = None
 
+    @profiler.time_function
     def forward_proposals(self, draw_jitter: bool = True, need_enc: bool = True) -> None:
         """Initial bins and the proposal levels (density fields + resampling): reads only the proposal networks'
         parameters, so with data parallelism it can run while the main-field gradients of the previous step are still
@@ -370,6 +373,7 @@ class NerfactoTrainStep:
         self.forward_main()
         self.losses(updated)
 
+    @profiler.time_function
     def forward_main(self) -> None:
         """Hash grid + MLPs of the main field on the final samples -> per-sample density and rgb."""
         lib, st, n, cfg = N.load(), N.stream(), self.n, self.cfg
@@ -407,6 +411,7 @@ class NerfactoTrainStep:
             ck(lib.nsamd_field_mlp_fwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
                                        N.ptr(self.f_dens), N.ptr(self.f_rgb), st), "field_mlp_fwd")
 
+    @profiler.time_function
     def losses(self, updated: bool) -> None:
         """Weights, compositing (rgb / accumulation / depths: the model outputs) and the three losses with their gradients
         against `self.target`. Reads only what forward_main left behind, so it can be repeated with another target."""
@@ -427,6 +432,7 @@ class NerfactoTrainStep:
                                      self._pl_dw if updated else None, N.ptr(self.dist_per_ray), N.ptr(self.dw_dist), st),
            "proposal_losses")
 
+    @profiler.time_function
     def backward_main(self) -> None:
         """composite -> weights -> field MLPs -> main hash table (MSE + distortion gradients)."""
         lib, st, n = N.load(), N.stream(), self.n
@@ -494,6 +500,7 @@ class NerfactoTrainStep:
         if split:
             torch.cuda.current_stream().wait_event(self._red_join)
 
+    @profiler.time_function
     def backward_proposals(self, levels=None) -> None:
         """Backward of the proposal networks (interlevel loss only; main-level weights are detached, losses.py:119-120).
         Needs the dw_prop written by forward_backward_main(updated=True). `levels`: subset of proposal levels (their

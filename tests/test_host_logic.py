@@ -268,3 +268,54 @@ def test_committed_bench_line_follows_the_contract():
     assert r["traffic"] is None or r["traffic"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+
+
+def test_profiler_hooks_time_function_and_roctx_ranges(monkeypatch):
+    """utils/profiler.py: the reference's two forms of `time_function` (decorator / context), its running-mean Profiler, and
+    the roctx ranges behind the same hooks (push / pop pair up, nest, survive exceptions; straight-through when nothing
+    listens)."""
+    from nerfstudio_amd.utils import profiler as P
+
+    calls = []
+
+    class FakeRoctx:
+        def roctxRangePushA(self, name):
+            calls.append(("push", name.decode()))
+            return 0
+
+        def roctxRangePop(self):
+            calls.append(("pop",))
+            return 0
+
+    monkeypatch.setattr(P, "_ROCTX", FakeRoctx())
+    monkeypatch.setattr(P, "PROFILER", [])
+
+    @P.time_function
+    def work(x):
+        with P.time_function("inner block"):
+            return x * 2
+
+    P.enable_ranges(False)
+    assert work(3) == 6 and calls == []  # nobody listens: no range, no timing
+    assert P.enable_ranges(True) and P.ranges_enabled()
+    assert work(4) == 8
+    assert calls == [("push", work.__qualname__), ("push", "inner block"), ("pop",), ("pop",)]
+    calls.clear()
+
+    @P.time_function
+    def boom():
+        raise KeyError("x")
+
+    with pytest.raises(KeyError):
+        boom()
+    assert calls == [("push", boom.__qualname__), ("pop",)]
+    prof = P.setup_profiler()
+    for _ in range(3):
+        work(1)
+    assert prof.profiler_dict[work.__qualname__]["step"] == 3 and prof.profiler_dict["inner block"]["step"] == 3
+    P.enable_ranges(False)
+    # the phases of the explicit kernel schedule carry the hook
+    from nerfstudio_amd.train_step import NerfactoTrainStep
+
+    for name in ("forward_proposals", "forward_main", "losses", "backward_main", "backward_proposals"):
+        assert hasattr(getattr(NerfactoTrainStep, name), "__wrapped__"), name

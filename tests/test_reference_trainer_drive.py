@@ -208,3 +208,46 @@ def test_restated_trainer_drives_the_hip_model_on_the_gpu(fused):
         a, b = finals[False], finals[True]
         np.testing.assert_allclose(a[1], b[1], rtol=1e-4)
         assert float((a[0] - b[0]).abs().max()) <= 1e-4 * max(1.0, float(a[0].abs().max()))
+
+
+@needs_reference
+def test_reference_profiler_hooks_open_roctx_ranges(monkeypatch):
+    """profiler.hook_reference_profiler(): the reference's OWN `@profiler.time_function` hooks — train_iteration
+    (engine/trainer.py:486) and get_train_loss_dict (pipelines/base_pipeline.py:289) — open / close roctx ranges around the
+    reference's unmodified code."""
+    refdrive.install()
+    from nerfstudio.engine.optimizers import AdamOptimizerConfig, Optimizers
+    from nerfstudio.engine.trainer import Trainer
+    from nerfstudio.pipelines.base_pipeline import VanillaPipeline
+
+    from nerfstudio_amd.utils import profiler as P
+
+    calls = []
+
+    class FakeRoctx:
+        def roctxRangePushA(self, name):
+            calls.append(("push", name.decode()))
+            return 0
+
+        def roctxRangePop(self):
+            calls.append(("pop",))
+            return 0
+
+    monkeypatch.setattr(P, "_ROCTX", FakeRoctx())
+    assert P.hook_reference_profiler() and P.hook_reference_profiler()  # idempotent
+    P.enable_ranges(True)
+    try:
+        model = _ToyModel()
+        opts = Optimizers({k: {"optimizer": AdamOptimizerConfig(lr=1e-2, eps=1e-15), "scheduler": None}
+                           for k in ("fields", "proposal_networks")}, model.get_param_groups())
+        g = torch.Generator().manual_seed(1)
+        pipeline = object.__new__(VanillaPipeline)
+        torch.nn.Module.__init__(pipeline)
+        pipeline.datamanager = _Datamanager([({"x": torch.randn(8, 6, generator=g)}, {"image": torch.rand(8, 3, generator=g)})])
+        pipeline._model, pipeline.world_size = model, 1
+        Trainer.train_iteration(_fake_trainer(pipeline, opts, "cpu"), 0)
+    finally:
+        P.enable_ranges(False)
+    names = [c[1] for c in calls if c[0] == "push"]
+    assert names == ["Trainer.train_iteration", "VanillaPipeline.get_train_loss_dict"], names
+    assert [c[0] for c in calls] == ["push", "push", "pop", "pop"]
