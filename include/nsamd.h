@@ -412,6 +412,12 @@ int nsamd_render_train_bwd(const float* rgb, const float* weights, const float* 
                            const float* d_rgb_out, const float* d_weights_add, float* d_rgb, float* d_density,
                            const float* bg_rays, nsamd_stream_t stream);
 
+/* scale_gradients_by_distance_squared (model_components/losses.py:534-569; NerfactoModelConfig.use_gradient_scaling,
+ * models/nerfacto.py:321-322): the gradients reaching the field's per-sample outputs are multiplied by
+ * clamp(((t_start + t_end) / 2)^2, 0, 1), in place. d_density [N,S] and d_rgb [N,S,3] nullable. */
+int nsamd_distance_gradient_scale(const float* t_bins, int64_t num_rays, int32_t S, float* d_density, float* d_rgb,
+                                  nsamd_stream_t stream);
+
 /* MSELoss (model_components/losses.py:31): loss_sum += sum((pred-target)^2) (caller zeroes; mean = /n),
  * dpred (nullable) = 2 (pred-target) grad_scale  with grad_scale = upstream / n. */
 int nsamd_mse_loss(const float* pred, const float* target, int64_t n, float grad_scale, float* loss_sum, float* dpred,

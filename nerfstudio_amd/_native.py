@@ -95,6 +95,7 @@ _SIGNATURES = {
     "nsamd_render_train": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "nsamd_render_train_bwd": [vp, vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, vp, vp, vp, vp, vp],
     "nsamd_composite_bwd": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, vp, vp, vp, vp, vp, vp, vp],
+    "nsamd_distance_gradient_scale": [vp, i64, i32, vp, vp, vp],
     "nsamd_mse_loss": [vp, vp, i64, f32, vp, vp, vp],
     "nsamd_interlevel_loss": [vp, vp, i32, vp, vp, i32, i64, f32, vp, vp, vp],
     "nsamd_distortion_loss": [vp, vp, i32, i64, f32, vp, vp, vp],

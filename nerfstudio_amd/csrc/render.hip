@@ -345,6 +345,26 @@ __global__ void mse_loss_kernel(const float* __restrict__ pred, const float* __r
   if (threadIdx.x == 0 && loss_sum) unsafeAtomicAdd(loss_sum, part[0] + part[1] + part[2] + part[3]);
 }
 
+// scale_gradients_by_distance_squared (model_components/losses.py:534-569, models/nerfacto.py:321-322): the forward is the
+// identity; the gradients that reach the field's outputs are multiplied by clamp(((start + end) / 2)^2, 0, 1) per sample.
+__global__ __launch_bounds__(256) void distance_gradient_scale_kernel(const float* __restrict__ t_bins, int64_t num_rays, int S,
+                                                                      float* __restrict__ d_density,
+                                                                      float* __restrict__ d_rgb) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= num_rays * S) return;
+  const int64_t ray = i / S;
+  const int s_ = (int)(i - ray * S);
+  const float* tb = t_bins + ray * (S + 1) + s_;
+  const float mid = (tb[0] + tb[1]) / 2.0f;
+  const float scale = fminf(fmaxf(mid * mid, 0.0f), 1.0f);
+  if (d_density != nullptr) d_density[i] = d_density[i] * scale;
+  if (d_rgb != nullptr) {
+    d_rgb[3 * i] = d_rgb[3 * i] * scale;
+    d_rgb[3 * i + 1] = d_rgb[3 * i + 1] * scale;
+    d_rgb[3 * i + 2] = d_rgb[3 * i + 2] * scale;
+  }
+}
+
 }  // namespace nsamd
 
 using namespace nsamd;
@@ -457,6 +477,18 @@ extern "C" int nsamd_render_train_bwd(const float* rgb, const float* weights, co
   composite_bwd_kernel<<<blocks, kRenderThreads, sizeof(float) * 3 * kRaysPerBlock * (size_t)S, (hipStream_t)stream>>>(
       rgb, weights, t_bins, num_rays, S, background, br, bg, bb, d_rgb_out, nullptr, nullptr, nullptr, d_weights_add,
       d_rgb, nullptr, density, d_density, bg_rays);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_distance_gradient_scale(const float* t_bins, int64_t num_rays, int32_t S, float* d_density, float* d_rgb,
+                                             nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && S > 0);
+  if (num_rays == 0 || (d_density == nullptr && d_rgb == nullptr)) return NSAMD_OK;
+  NSAMD_REQUIRE(t_bins != nullptr);
+  const int64_t nb = (num_rays * S + 255) / 256;
+  if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
+  distance_gradient_scale_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(t_bins, num_rays, S, d_density, d_rgb);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

@@ -682,6 +682,33 @@ def pdf_resample(s_bins_prev: Tensor, weights: Tensor, num_samples: int, jitter:
     return (s_bins, t_bins, inds) if return_indices else (s_bins, t_bins)
 
 
+class _DistanceGradientScaleFn(torch.autograd.Function):
+    """scale_gradients_by_distance_squared (model_components/losses.py:534-569): identity forward; the gradient is multiplied
+    by clamp(((start + end) / 2)^2, 0, 1) per sample (nsamd_distance_gradient_scale)."""
+
+    @staticmethod
+    def forward(ctx, density: Tensor, rgb: Tensor, t_bins: Tensor):
+        ctx.save_for_backward(t_bins)
+        return density.view_as(density), rgb.view_as(rgb)
+
+    @staticmethod
+    def backward(ctx, g_density, g_rgb):
+        (t_bins,) = ctx.saved_tensors
+        n, s1 = t_bins.shape
+        gd = _f32c(g_density).clone() if g_density is not None else None
+        gr = _f32c(g_rgb).clone() if g_rgb is not None else None
+        N.check(N.load().nsamd_distance_gradient_scale(N.ptr(t_bins), n, s1 - 1, N.ptr(gd), N.ptr(gr), N.stream()),
+                "distance_gradient_scale")
+        return gd, gr, None
+
+
+def scale_gradients_by_distance_squared(density: Tensor, rgb: Tensor, t_bins: Tensor) -> Tuple[Tensor, Tensor]:
+    """density `[N,S,1]`, rgb `[N,S,3]` of a ray batch with euclidean bin edges t_bins `[N,S+1]` -> the same values whose
+    gradients are scaled by the squared distance (NerfactoModelConfig.use_gradient_scaling)."""
+    N.require_cuda(density, rgb, t_bins)
+    return _DistanceGradientScaleFn.apply(density, rgb, _f32c(t_bins))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # a16-a18  compositing
 # ---------------------------------------------------------------------------------------------------------------

@@ -72,10 +72,8 @@ class FusedTrainStep:
     def supported(self) -> Optional[str]:
         """None, or the reason this model has to stay on the module path."""
         cfg = self.model.config
-        if not getattr(cfg, "use_single_jitter", True):
-            return "use_single_jitter=False"
-        if getattr(cfg, "predict_normals", False) or getattr(cfg, "use_gradient_scaling", False):
-            return "predict_normals / use_gradient_scaling"
+        if getattr(cfg, "predict_normals", False):
+            return "predict_normals"
         return None
 
     def _runner_for(self, num_rays: int, device):
@@ -101,7 +99,10 @@ class FusedTrainStep:
         r.anneal_dev.fill_(float(ps._anneal))  # BEFORE_TRAIN_ITERATION callback's value (models/nerfacto.py:270-280)
         if jitters is not None:  # parity tests inject the draws of the module path
             for lvl, j in enumerate(jitters):
-                r.jitter[lvl].copy_(j.reshape(-1))
+                if getattr(r, "jitter_edges", None) is not None:  # use_single_jitter=False: one draw per bin edge
+                    r.jitter_edges[lvl].copy_(j.reshape(r.jitter_edges[lvl].shape))
+                else:
+                    r.jitter[lvl].copy_(j.reshape(-1))
         r.apply_camera_corrections()
         r.forward_proposals(draw_jitter=jitters is None, need_enc=self.updated)
         r.forward_main()

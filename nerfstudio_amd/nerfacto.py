@@ -63,6 +63,8 @@ class NerfactoModelConfig:
     proposal_weights_anneal_slope: float = 10.0
     proposal_weights_anneal_max_num_iters: int = 1000
     use_single_jitter: bool = True
+    use_gradient_scaling: bool = False
+    """Scale the field gradients by the squared ray distance (models/nerfacto.py:114-115, :321-322)."""
     disable_scene_contraction: bool = False
     implementation: Literal["hip"] = "hip"
     appearance_embed_dim: int = 32
@@ -206,6 +208,13 @@ class NerfactoModel(nn.Module):
         ray_samples, weights_list, ray_samples_list = self.proposal_sampler(ray_bundle, density_fns=self.density_fns,
                                                                             jitters=jitters)
         field_outputs = self.field.forward(ray_samples)
+        if self.config.use_gradient_scaling:  # models/nerfacto.py:321-322
+            from . import functional as F
+
+            dens, rgb_s = F.scale_gradients_by_distance_squared(field_outputs[FieldHeadNames.DENSITY], field_outputs[FieldHeadNames.RGB],
+                                                                ray_samples.pack.t_bins)
+            field_outputs = dict(field_outputs)
+            field_outputs[FieldHeadNames.DENSITY], field_outputs[FieldHeadNames.RGB] = dens, rgb_s
         weights = ray_samples.get_weights(field_outputs[FieldHeadNames.DENSITY])
         weights_list.append(weights)
         ray_samples_list.append(ray_samples)
@@ -270,7 +279,7 @@ class NerfactoModel(nn.Module):
         from . import eval_render
 
         if (not self.training and camera_ray_bundle.origins.is_cuda and os.environ.get("NSAMD_EVAL_RUNNER", "1") == "1"
-                and eval_render.supported(self) is None and getattr(self.config, "use_single_jitter", True)):
+                and eval_render.supported(self) is None):
             runner = getattr(self, "_eval_runner", None)
             if runner is None or runner.chunk != self.config.eval_num_rays_per_chunk:
                 runner = self._eval_runner = eval_render.EvalRenderer(self)

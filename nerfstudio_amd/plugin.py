@@ -34,8 +34,9 @@ def install_hip_modules(model: Any) -> None:
     from .model_components.renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
 
     cfg = model.config
-    if getattr(cfg, "predict_normals", False) or getattr(cfg, "use_gradient_scaling", False):
-        raise NotImplementedError("nerfacto-hip: predict_normals / use_gradient_scaling are not on the accelerated path")
+    if getattr(cfg, "predict_normals", False):
+        raise NotImplementedError("nerfacto-hip: predict_normals is not on the accelerated path (analytic normals through the "
+                                  "hash encoding are not built)")
     if getattr(cfg, "features_per_level", 2) != 2:
         raise ValueError("nerfacto-hip: features_per_level must be 2")
     aabb = model.scene_box.aabb

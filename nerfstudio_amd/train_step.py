@@ -42,8 +42,10 @@ class NerfactoTrainStep:
         self.compute_depths = compute_depths
         if cfg.background_color not in ("last_sample", "black", "white", "random"):
             raise ValueError(cfg.background_color)
-        if not getattr(cfg, "use_single_jitter", True):
-            raise NotImplementedError("NerfactoTrainStep: use_single_jitter=False (per-sample jitter) is not supported")
+        # use_single_jitter=False (ray_samplers.py:104-107, 318-322): one draw per bin EDGE instead of one per ray — the
+        # per-level jitter buffers become [n, S+1] and the resampling goes through the unfused kernels
+        self.single_jitter = bool(getattr(cfg, "use_single_jitter", True))
+        self.gradient_scaling = bool(getattr(cfg, "use_gradient_scaling", False))
         f32 = dict(device=device, dtype=torch.float32)
         e = lambda *shape: torch.empty(shape, **f32)  # noqa: E731
         if cfg.background_color == "random":
@@ -61,7 +63,8 @@ class NerfactoTrainStep:
         self.target = e(n, 3)
         self.nears = torch.full((n,), float(cfg.near_plane), **f32)  # NearFarCollider, training mode
         self.fars = torch.full((n,), float(cfg.far_plane), **f32)
-        self.jitter = e(self.n_prop + 1, n)
+        self.jitter = e(self.n_prop + 1, n)  # single jitter: one draw per level and ray
+        self.jitter_edges = None if self.single_jitter else [e(n, s + 1) for s in self.counts]  # per edge: [n, S+1] per level
         self.anneal_dev = torch.ones((1,), **f32)
         # ---- sampler state ----
         self.s_bins = [e(n, s + 1) for s in self.counts]
@@ -329,12 +332,18 @@ class NerfactoTrainStep:
         fused forward then writes nothing but the densities)."""
         lib, st, n = N.load(), N.stream(), self.n
         ck = N.check
+        per_edge = not self.single_jitter
         if draw_jitter:
-            self.jitter.uniform_()  # torch.rand per level and ray (ray_samplers.py:105, :322), drawn on the device
+            if per_edge:
+                for j in self.jitter_edges:
+                    j.uniform_()
+            else:
+                self.jitter.uniform_()  # torch.rand per level and ray (ray_samplers.py:105, :322), drawn on the device
             if self.bg_rays is not None:
                 self.bg_rays.uniform_()  # rand_like(pred) of the loss blend (renderers.py:195)
         S0 = self.counts[0]
-        ck(lib.nsamd_piecewise_bins(N.ptr(self.nears), N.ptr(self.fars), N.ptr(self.edges), N.ptr(self.jitter[0]), 0, n, S0,
+        jit0 = self.jitter_edges[0] if per_edge else self.jitter[0]
+        ck(lib.nsamd_piecewise_bins(N.ptr(self.nears), N.ptr(self.fars), N.ptr(self.edges), N.ptr(jit0), int(per_edge), n, S0,
                                     self.spacing, N.ptr(self.s_bins[0]), N.ptr(self.t_bins[0]), st), "piecewise_bins")
         # ---- proposal levels ----
         for lvl in range(self.n_prop):
@@ -359,6 +368,19 @@ class NerfactoTrainStep:
             else:
                 ck(fused, "density_field_fwd")
             S2 = self.counts[lvl + 1]
+            if per_edge:
+                # one draw per new bin edge: the fused launch below draws per ray, so this (non-default) configuration takes
+                # its three constituents — same numbers (nsamd.h)
+                ck(lib.nsamd_weights_fwd(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), n, S, N.ptr(self.weights[lvl]), st),
+                   "weights_fwd")
+                if self.compute_depths:
+                    ck(lib.nsamd_composite_fwd(None, N.ptr(self.weights[lvl]), N.ptr(self.t_bins[lvl]), n, S, N.BG_NONE, None, 0,
+                                               None, None, None, N.ptr(self.depth_med[lvl]), None, None, st), "composite_fwd(median)")
+                ck(lib.nsamd_pdf_resample(N.ptr(self.s_bins[lvl]), N.ptr(self.weights[lvl]), S, N.ptr(self.u_base[lvl + 1]),
+                                          N.ptr(self.jitter_edges[lvl + 1]), N.ptr(self.nears), N.ptr(self.fars), 1.0,
+                                          N.ptr(self.anneal_dev), 0.01, 1e-5, 1.0 / (2 * (S2 + 1)), self.spacing, 1, 0, n, S2,
+                                          N.ptr(self.s_bins[lvl + 1]), N.ptr(self.t_bins[lvl + 1]), None, st), "pdf_resample")
+                continue
             # weights of this level, its median depth (prop_depth_i, models/nerfacto.py:346-347) and the PDF resampling
             ck(lib.nsamd_proposal_resample(N.ptr(self.t_bins[lvl]), N.ptr(self.s_bins[lvl]), N.ptr(self.p_dens[lvl]), S,
                                            N.ptr(self.u_base[lvl + 1]), N.ptr(self.jitter[lvl + 1]), N.ptr(self.nears),
@@ -443,6 +465,9 @@ class NerfactoTrainStep:
                                       n, S, self.bg_mode, self.bg_vals, N.ptr(self.d_rgb_out), N.ptr(self.dw_dist),
                                       N.ptr(self.d_rgb_s), N.ptr(self.d_dens_main), N.ptr(self.bg_rays), st),
            "render_train_bwd")
+        if self.gradient_scaling:  # scale_gradients_by_distance_squared on the field's outputs (models/nerfacto.py:321-322)
+            ck(lib.nsamd_distance_gradient_scale(N.ptr(self.t_bins[L]), n, S, N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s), st),
+               "distance_gradient_scale")
         self.backward_field_and_table()
 
     def backward_field_and_table(self) -> None:

@@ -183,6 +183,26 @@ class _TruncExpFn(torch.autograd.Function):
 
 trunc_exp = _TruncExpFn.apply
 
+
+class _GradientScalerFn(torch.autograd.Function):
+    """Identity forward; the gradient is multiplied by `scaling` (model_components/losses.py:534-547)."""
+
+    @staticmethod
+    def forward(ctx, value, scaling):
+        ctx.save_for_backward(scaling)
+        return value.view_as(value)
+
+    @staticmethod
+    def backward(ctx, g):
+        (scaling,) = ctx.saved_tensors
+        return g * scaling, None
+
+
+def scale_gradients_by_distance_squared(density: Tensor, rgb: Tensor, t_bins: Tensor) -> Tuple[Tensor, Tensor]:
+    """model_components/losses.py:550-569 on density `[N,S]` / rgb `[N,S,3]`: scaling = clamp(((start + end) / 2)^2, 0, 1)."""
+    scaling = torch.square((t_bins[:, :-1] + t_bins[:, 1:]) / 2).clamp(0, 1)
+    return _GradientScalerFn.apply(density, scaling), _GradientScalerFn.apply(rgb, scaling[..., None])
+
 # ---------------------------------------------------------------------------------------------------------------
 # configuration records (hyper-parameters only; defaults = nerfacto method config, method_configs.py:87-121)
 # ---------------------------------------------------------------------------------------------------------------
@@ -588,9 +608,11 @@ def nerfacto_forward(
     anneal: float = 1.0,
     proposal_requires_grad: bool = True,
     aabb: Optional[Tensor] = None,
+    use_gradient_scaling: bool = False,
 ) -> Dict[str, object]:
     """Full hot path for one ray batch. `jitters` = one `[N,1]` uniform draw per sampling level (len = 1 + number of
-    proposal levels) in training; ignored (eval sampling) when `training` is False. camera_indices `[N]`."""
+    proposal levels; `[N, S+1]` = one per bin edge, use_single_jitter=False) in training; ignored (eval sampling) when
+    `training` is False. camera_indices `[N]`. use_gradient_scaling: models/nerfacto.py:321-322."""
     N = origins.shape[0]
     near = cfg.near_plane if training else 0.0  # scene_colliders.py:186-191 (reset_near_plane in eval)
     nears = torch.full((N, 1), near)
@@ -629,6 +651,8 @@ def nerfacto_forward(
     cams = camera_indices.reshape(N, 1).expand(N, S).reshape(-1)
     density, rgb, _ = nerfacto_field(pos, dirs, cams, params, cfg, training=training, aabb=aabb)
     density, rgb = density.reshape(N, S), rgb.reshape(N, S, 3)
+    if use_gradient_scaling:
+        density, rgb = scale_gradients_by_distance_squared(density, rgb, t_bins)
     weights = weights_from_density(t_bins, density)
     weights_list.append(weights)
     s_bins_list.append(s_bins)

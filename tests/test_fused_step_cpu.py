@@ -162,9 +162,15 @@ def test_model_routes_through_the_fused_step_only_when_asked_and_training():
     model.eval()
     assert model._fused_step() is None
     model.train()
+    # options the explicit schedule takes since round 3 (per-edge jitter, gradient scaling) do not reject any more; what is
+    # still outside it says so loudly
     model.config.use_single_jitter = False
+    model.config.use_gradient_scaling = True
     model._fused = None
-    with pytest.raises(NotImplementedError, match="use_single_jitter"):
+    assert isinstance(model._fused_step(), FusedTrainStep)
+    model.config.predict_normals = True
+    model._fused = None
+    with pytest.raises(NotImplementedError, match="predict_normals"):
         model._fused_step()
 
 
