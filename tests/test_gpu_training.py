@@ -358,6 +358,7 @@ def test_checkpoint_round_trip_resumes_bit_exactly(F, tmp_path):
     C.load_optimizer_states(model_b, arena_b, loaded["optimizers"])
     # (the sampler's schedule counters are trainer state the reference rebuilds from `step`: callbacks run from step + 1)
     model_b.proposal_sampler._steps_since_update, model_b.proposal_sampler._step = sampler_state
+    model_b.set_step(k1 - 1)  # BEFORE_TRAIN_ITERATION callback of the checkpoint's step: the proposal-weight anneal exponent
     assert arena_b.step_counts == {"fields": k1, "proposal_networks": k1}  # all seven steps were update steps (step < 10)
     img_b = render(model_b)
     for k in img_a:
