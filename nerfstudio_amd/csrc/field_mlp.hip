@@ -846,7 +846,7 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
     nsamd_field_mlp mlp, int app_dim, const float* __restrict__ ddensity, const float* __restrict__ drgb,
     float* __restrict__ denc, nsamd_field_mlp_grads grads, float* __restrict__ partials,
-    float* __restrict__ app_partials, const float* __restrict__ acts, int probe_skip) {
+    float* __restrict__ app_partials, int app_rows_per_point, const float* __restrict__ acts, int probe_skip) {
   // probe_skip (NSAMD_FIELD_BWD_SKIP, timing experiments only — results are wrong when set): 1 = no weight-gradient
   // MFMAs, 2 = no workgroup barriers inside the tile loop, 4 = no data-gradient GEMMs
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -978,7 +978,16 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
 
     // appearance-embedding gradient (slots 32..63): rows of one camera are pre-reduced over the tile's points
     if (app_table != nullptr && grads.appearance != nullptr) {
-      if (app_partials != nullptr) {
+      if (app_partials != nullptr && app_rows_per_point) {
+        // per-sample cameras (packed instant-ngp samples, explicit positions: a 16-point tile spans several rays): every
+        // point writes its own 32 gradients; the reduce launch adds the rows of each camera in point order — no atomics
+        // (4.3 M float atomics per step on the instant-ngp workload: field_mlp_bwd 363 -> see profiles/r03_bench_ngp*)
+        if (ti.live) {
+#pragma unroll
+          for (int t = 2; t < 4; ++t)
+            *reinterpret_cast<v4f*>(app_partials + ti.p * 32 + 16 * (t - 2) + 4 * g) = g_hin[t];
+        }
+      } else if (app_partials != nullptr) {
         // every tile lies inside one ray (the host checked samples-per-ray % 16 == 0): its 32 sums go to a scratch row
         // and field_app_reduce_kernel adds the rows of each camera in a fixed order — bit-reproducible, no atomics
 #pragma unroll
@@ -1389,15 +1398,21 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
   // per-tile rows of the appearance-embedding gradient (fixed-order reduction per camera): needs every 16-point tile
   // inside one ray and room behind the weight-gradient partials; otherwise float atomics (sums in no fixed order)
   float* app_partials = nullptr;
+  int app_rows_per_point = 0;
   if (partials != nullptr && camera_indices != nullptr && grads.appearance != nullptr && dir_group % 16 == 0 &&
       M % dir_group == 0 && mlp.num_images <= 8192 &&
-      workspace_floats >= (int64_t)blocks * kPartialStride + tiles * 32)
+      workspace_floats >= (int64_t)blocks * kPartialStride + tiles * 32) {
     app_partials = workspace + (int64_t)blocks * kPartialStride;
+  } else if (partials != nullptr && camera_indices != nullptr && grads.appearance != nullptr && dir_group == 1 &&
+             mlp.num_images <= 8192 && workspace_floats >= (int64_t)blocks * kPartialStride + M * 32) {
+    app_partials = workspace + (int64_t)blocks * kPartialStride;  // one row per POINT (a camera index per sample)
+    app_rows_per_point = 1;
+  }
   if (phases != 3) NSAMD_REQUIRE(partials != nullptr);  // without scratch the kernel flushes with atomics: nothing to split
   if (phases & 1) {
     field_mlp_bwd_kernel<<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
         enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-        grads, partials, app_partials, acts, probe_skip);
+        grads, partials, app_partials, app_rows_per_point, acts, probe_skip);
     NSAMD_CHECK_LAUNCH();
   }
   if (partials != nullptr && (phases & 2)) {
@@ -1405,7 +1420,8 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
     const unsigned app_blocks = app_partials != nullptr ? (unsigned)mlp.num_images : 0u;
     const size_t red_lds = sizeof(float) * kReduceGroups * 64;
     field_dw_reduce_kernel<<<kDwBlocks + app_blocks, kReduceThreads, red_lds, (hipStream_t)stream>>>(
-        partials, (int)blocks, grads, app_dim, app_partials, camera_indices, M / dir_group, (int)(dir_group / 16));
+        partials, (int)blocks, grads, app_dim, app_partials, camera_indices, app_rows_per_point ? M : M / dir_group,
+        app_rows_per_point ? 1 : (int)(dir_group / 16));
     NSAMD_CHECK_LAUNCH();
   }
   return NSAMD_OK;
