@@ -587,9 +587,9 @@ def measure_roofline(trainer, arena, steps):
         table.append({"kernel": key, "calls_per_step": calls / steps, "ms_per_step": total_ms / steps, "mean_ms": mean_ms,
                       "bound": bound, "work": work})
     table.sort(key=lambda r: -r["ms_per_step"])
-    top = next((r for r in table if r["bound"] is not None and r["work"]), None)
-    roof = None
-    if top is not None:
+    ranked = [r for r in table if r["bound"] is not None and r["work"]]
+
+    def entry(top):
         sec = top["mean_ms"] * 1e-3
         if top["bound"] == "hbm":
             ach, peak, unit = top["work"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
@@ -603,6 +603,13 @@ def measure_roofline(trainer, arena, steps):
             ex = EXECUTED_PER_LAUNCH[base]
             roof["executed_per_launch"] = ex
             roof["executed_frac"] = round(ex / sec / (1e9 if top["bound"] == "hbm" else 1e12) / peak, 4)
+        return roof
+
+    roof = entry(ranked[0]) if ranked else None
+    # The main-field MLP backward and the main-table scatter are within a few percent of each other per step (0.19 ms
+    # both): which one is "the dominant kernel" flips between runs. The runner-up rides along so that both are in every line.
+    if roof is not None and len(ranked) > 1:
+        roof["runner_up"] = entry(ranked[1])
     return roof, table
 
 

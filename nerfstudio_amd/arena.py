@@ -25,6 +25,7 @@ from torch.nn import Parameter
 from . import functional as F
 from .utils import profiler
 
+_COALESCE = [os.environ.get("NSAMD_COALESCE_ALLREDUCE", "1") == "1"]  # one collective call per optimiser group (see all_reduce_group)
 _ALIGN = 64  # floats: every tensor starts on a 256-B boundary
 _GROUP_ALIGN = _ALIGN * 840  # floats: lcm(1..8) aligned shards per optimiser group (<= 215 KB of zero padding per group)
 
@@ -211,13 +212,21 @@ class ParamArena:
             pieces.append(self.grad[cursor:b])
         # ONE collective call for all pieces of the group (RCCL: one grouped launch instead of one kernel + one stream
         # hand-over per piece — on the one-rank rehearsal every collective launch is ~15-25 us of exposed latency)
-        if len(pieces) > 1 and hasattr(dist, "all_reduce_coalesced") and os.environ.get("NSAMD_COALESCE_ALLREDUCE", "1") == "1":
+        handles = None
+        if len(pieces) > 1 and hasattr(dist, "all_reduce_coalesced") and _COALESCE[0]:
             import warnings
 
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")  # (deprecation notice of the list form; the semantics are what is wanted)
-                handles = [dist.all_reduce_coalesced(pieces, op=dist.ReduceOp.SUM, group=group, async_op=async_op)]
-        else:
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")  # (deprecation notice of the list form; the semantics are what is wanted)
+                    handles = [dist.all_reduce_coalesced(pieces, op=dist.ReduceOp.SUM, group=group, async_op=async_op)]
+            except (RuntimeError, NotImplementedError, TypeError) as e:
+                # a backend without the coalesced form (only ever exercised over gloo and a one-rank RCCL communicator
+                # here): one call per piece from now on — raised BEFORE anything was enqueued, so nothing is reduced twice
+                _COALESCE[0] = False
+                print(f"[nerfstudio_amd.arena] all_reduce_coalesced unavailable ({type(e).__name__}: {e}); "
+                      "falling back to one all_reduce per piece", flush=True)
+        if handles is None:
             handles = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op) for t in pieces]
         return _GroupHandle(handles if async_op else [], post)
 

@@ -948,7 +948,9 @@ def test_gradient_scaling_and_per_edge_jitter_module_path_runner_and_oracle(F):
     ref2 = orc.nerfacto_forward(oparams2, cfg, o, d, cam, jit, training=True, anneal=model_a.proposal_sampler._anneal)
     sum(orc.nerfacto_losses(ref2, tgt, cfg).values()).backward()
     g1, g2 = oparams["field.mlp_base.model.0.hash_table"].grad, oparams2["field.mlp_base.model.0.hash_table"].grad
-    assert float((g1 - g2).norm() / g2.norm()) > 0.05
+    # (most of this batch's samples lie beyond distance 1, where the scale is clamped to 1: the difference is 0.8 % here —
+    # 16x the tolerance of the comparison above, so a path that dropped the scaling would fail it)
+    assert float((g1 - g2).norm() / g2.norm()) > 4 * 5e-4
     # ---- the explicit kernel schedule with the same options
     model_b = build()
     arena = ParamArena(model_b.parameters())
