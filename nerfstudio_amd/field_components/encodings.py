@@ -64,7 +64,14 @@ class NeRFEncoding(Encoding):
         if covs is not None:
             raise NotImplementedError("integrated (mip-NeRF) encodings are not built for the hip backend")
         shape = in_tensor.shape[:-1]
-        out = self.spec_forward(F.PointSpec(positions=in_tensor.reshape(-1, 3)))
+        if in_tensor.requires_grad and torch.is_grad_enabled():
+            # the kernel has no backward; points that carry gradient (pose corrections of a camera optimiser behind the
+            # predicted-normals head) take the same arithmetic through torch (encodings.py:148-166)
+            freqs = (2 ** torch.linspace(self.min_freq, self.max_freq, self.num_frequencies)).to(in_tensor.device)
+            scaled = ((2 * torch.pi * in_tensor)[..., None] * freqs).reshape(*shape, -1)
+            out = torch.sin(torch.cat([scaled, scaled + torch.pi / 2.0], dim=-1))
+            return torch.cat([out, in_tensor], dim=-1) if self.include_input else out
+        out = self.spec_forward(F.PointSpec(positions=in_tensor.detach().reshape(-1, 3)))
         return out.view(*shape, self.get_out_dim())
 
 

@@ -1,9 +1,10 @@
 """Field outputs (reference: nerfstudio/field_components/field_heads.py — FieldHeadNames :27-41, FieldHead :44-93,
-DensityFieldHead :96-108, RGBFieldHead :111-123). A head is one dense layer with its activation; it runs as a single
-csrc/linear.hip launch (activation fused)."""
+DensityFieldHead :96-108, RGBFieldHead :111-123, PredNormalsFieldHead :190-206). A head is one dense layer with its
+activation; it runs as a single csrc/linear.hip launch (activation fused; tanh follows the launch as a torch op)."""
 from enum import Enum
 from typing import Optional
 
+import torch
 from torch import Tensor, nn
 
 from .base_field_component import FieldComponent
@@ -25,7 +26,7 @@ class FieldHeadNames(Enum):
     GRADIENT = "gradient"
 
 
-_HEAD_ACTIVATIONS = {type(None): None, nn.ReLU: "relu", nn.Sigmoid: "sigmoid", nn.Softplus: "softplus"}
+_HEAD_ACTIVATIONS = {type(None): None, nn.ReLU: "relu", nn.Sigmoid: "sigmoid", nn.Softplus: "softplus", nn.Tanh: "tanh"}
 
 
 class FieldHead(FieldComponent):
@@ -35,7 +36,7 @@ class FieldHead(FieldComponent):
                  activation: Optional[nn.Module] = None) -> None:
         super().__init__()
         if type(activation) not in _HEAD_ACTIVATIONS:
-            raise ValueError(f"field head activation {activation!r}: the hip heads fuse None / ReLU / Sigmoid / Softplus")
+            raise ValueError(f"field head activation {activation!r}: the hip heads take None / ReLU / Sigmoid / Softplus / Tanh")
         if isinstance(activation, nn.Softplus) and (activation.beta != 1 or activation.threshold != 20):
             raise ValueError("the fused Softplus is torch's default (beta = 1, threshold = 20)")
         self.out_dim = out_dim
@@ -58,7 +59,10 @@ class FieldHead(FieldComponent):
 
         if not self.net:
             raise SystemError("in_dim not set. Must be provided to constructor, or set_in_dim() should be called.")
-        return F.linear(in_tensor, self.net.weight, self.net.bias, _HEAD_ACTIVATIONS[type(self.activation)])
+        act = _HEAD_ACTIVATIONS[type(self.activation)]
+        if act == "tanh":
+            return torch.tanh(F.linear(in_tensor, self.net.weight, self.net.bias, None))
+        return F.linear(in_tensor, self.net.weight, self.net.bias, act)
 
 
 class DensityFieldHead(FieldHead):
@@ -69,3 +73,13 @@ class DensityFieldHead(FieldHead):
 class RGBFieldHead(FieldHead):
     def __init__(self, in_dim: Optional[int] = None, activation: Optional[nn.Module] = nn.Sigmoid()) -> None:
         super().__init__(in_dim=in_dim, out_dim=3, field_head_name=FieldHeadNames.RGB, activation=activation)
+
+
+class PredNormalsFieldHead(FieldHead):
+    """Predicted normals (field_heads.py:190-206): tanh head, then normalised to unit length."""
+
+    def __init__(self, in_dim: Optional[int] = None, activation: Optional[nn.Module] = nn.Tanh()) -> None:
+        super().__init__(in_dim=in_dim, out_dim=3, field_head_name=FieldHeadNames.PRED_NORMALS, activation=activation)
+
+    def forward(self, in_tensor: Tensor) -> Tensor:
+        return torch.nn.functional.normalize(super().forward(in_tensor), dim=-1)

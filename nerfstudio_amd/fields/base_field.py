@@ -27,6 +27,7 @@ class Field(nn.Module):
         super().__init__()
         self._sample_locations = None
         self._density_before_activation = None
+        self._compute_normals = False
 
     def density_fn(self, positions: Tensor, times: Optional[Tensor] = None) -> Tensor:
         """Density only, on explicit positions `[*bs,3]` -> `[*bs,1]` (base_field.py:48-68)."""
@@ -48,7 +49,17 @@ class Field(nn.Module):
         """Densities `[*bs,1]` and an optional feature tensor."""
 
     def get_normals(self) -> Tensor:
-        raise NotImplementedError("analytic normals are not on the nerfacto hot path (predict_normals=False)")
+        """Analytic normals (base_field.py:79-99): minus the normalised gradient of the density pre-activation with respect
+        to the sample locations the field recorded in `get_density` — for the hash-grid fields the NORMALISED positions
+        (after contraction / box scaling and the selector, nerfacto_field.py:215-217). First order only (no create_graph):
+        the normals are constants for the losses built on them, exactly as in the reference."""
+        assert self._sample_locations is not None, "Sample locations must be set before calling get_normals."
+        assert self._density_before_activation is not None, "Density must be set before calling get_normals."
+        assert self._sample_locations.shape[:-1] == self._density_before_activation.shape[:-1], (
+            "Sample locations and density must have the same shape besides the last dimension.")
+        normals = torch.autograd.grad(self._density_before_activation, self._sample_locations,
+                                      grad_outputs=torch.ones_like(self._density_before_activation), retain_graph=True)[0]
+        return -torch.nn.functional.normalize(normals, dim=-1)
 
     @abstractmethod
     def get_outputs(self, ray_samples: RaySamples, density_embedding: Optional[Tensor] = None
@@ -56,11 +67,22 @@ class Field(nn.Module):
         """Field outputs conditioned on the density embedding."""
 
     def forward(self, ray_samples: RaySamples, compute_normals: bool = False) -> Dict[FieldHeadNames, Tensor]:
-        if compute_normals:
-            raise NotImplementedError("compute_normals is not supported by the hip backend")
-        density, density_embedding = self.get_density(ray_samples)
-        field_outputs = self.get_outputs(ray_samples, density_embedding=density_embedding)
-        field_outputs[FieldHeadNames.DENSITY] = density
+        """base_field.py:113-133. `compute_normals` tells `get_density` (through `self._compute_normals`) to keep the graph
+        from the sample locations to the density pre-activation — also under `torch.no_grad()` (eval renders)."""
+        self._compute_normals = bool(compute_normals)
+        try:
+            if compute_normals:
+                with torch.enable_grad():
+                    density, density_embedding = self.get_density(ray_samples)
+            else:
+                density, density_embedding = self.get_density(ray_samples)
+            field_outputs = self.get_outputs(ray_samples, density_embedding=density_embedding)
+            field_outputs[FieldHeadNames.DENSITY] = density
+            if compute_normals:
+                with torch.enable_grad():
+                    field_outputs[FieldHeadNames.NORMALS] = self.get_normals()
+        finally:
+            self._compute_normals = False
         return field_outputs
 
 

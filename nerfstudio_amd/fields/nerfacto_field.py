@@ -9,11 +9,12 @@ from .. import functional as F
 from ..cameras.rays import RaySamples
 from ..field_components.base_field_component import check_implementation
 from ..field_components.embedding import Embedding
-from ..field_components.encodings import SHEncoding
-from ..field_components.field_heads import FieldHeadNames
+from ..field_components.activations import trunc_exp
+from ..field_components.encodings import NeRFEncoding, SHEncoding
+from ..field_components.field_heads import FieldHeadNames, PredNormalsFieldHead
 from ..field_components.mlp import MLP, MLPWithHashEncoding
 from ..field_components.spatial_distortions import SpatialDistortion
-from .base_field import Field, point_spec
+from .base_field import Field, get_normalized_directions, point_spec
 from .density_fields import transform_of
 
 
@@ -22,10 +23,18 @@ class NerfactoField(Field):
 
     Arguments as the reference (nerfacto_field.py:72-98). The hip backend builds the nerfacto shape
     (hidden_dim = hidden_dim_color = 64, geo_feat_dim = 15, num_levels*features = 32, num_layers 2 / 3,
-    appearance_embedding_dim 32 or 0); the transient / semantic / normal heads belong to other methods.
+    appearance_embedding_dim 32 or 0); the transient / semantic heads belong to other methods.
 
     `get_density` + `get_outputs` are ONE pipeline on the GPU (hash encode -> MFMA MLP chain), so `get_density`
     evaluates both and hands rgb to `get_outputs` through the density embedding slot.
+
+    Normals (`use_pred_normals`, `forward(..., compute_normals=True)`; nerfacto_field.py:181-191, 215-223, 287-295,
+    base_field.py:79-99): the analytic normals need the gradient of the density pre-activation with respect to the
+    normalised sample positions and the predicted ones the geometry features — neither leaves the fused pipeline, so
+    these two options evaluate the field as the reference composes it: position normalisation (torch, differentiable) ->
+    hash-encode kernel (its backward returns dL/dx) -> dense-layer kernels (csrc/linear.hip) -> trunc_exp; SH kernel +
+    embedding lookup -> colour MLP; frequency encoding + geometry features -> normals MLP -> tanh head. Same parameters,
+    same names, same arithmetic up to fp32 rounding; not the benchmarked path.
     """
 
     aabb: Tensor
@@ -60,8 +69,8 @@ class NerfactoField(Field):
     ) -> None:
         super().__init__()
         check_implementation(implementation, "NerfactoField")
-        if use_transient_embedding or use_semantics or use_pred_normals:
-            raise ValueError("transient / semantic / predicted-normal heads are not part of the hip nerfacto field")
+        if use_transient_embedding or use_semantics:
+            raise ValueError("transient / semantic heads are not part of the hip nerfacto field")
         if (hidden_dim, hidden_dim_color, geo_feat_dim, num_layers, num_layers_color) != (64, 64, 15, 2, 3) or \
                 num_levels * features_per_level != 32 or appearance_embedding_dim not in (0, 32):
             raise ValueError(
@@ -84,6 +93,8 @@ class NerfactoField(Field):
         self.average_init_density = average_init_density
         self.step = 0
         self.direction_encoding = SHEncoding(levels=4, implementation=implementation)
+        self.position_encoding = NeRFEncoding(in_dim=3, num_frequencies=2, min_freq_exp=0, max_freq_exp=2 - 1,
+                                              implementation=implementation)
         self.mlp_base = MLPWithHashEncoding(
             num_levels=num_levels,
             min_res=base_res,
@@ -97,6 +108,17 @@ class NerfactoField(Field):
             out_activation=None,
             implementation=implementation,
         )
+        if self.use_pred_normals:  # nerfacto_field.py:181-191
+            self.mlp_pred_normals = MLP(
+                in_dim=self.geo_feat_dim + self.position_encoding.get_out_dim(),
+                num_layers=3,
+                layer_width=64,
+                out_dim=hidden_dim_transient,
+                activation=nn.ReLU(),
+                out_activation=None,
+                implementation=implementation,
+            )
+            self.field_head_pred_normals = PredNormalsFieldHead(in_dim=self.mlp_pred_normals.get_out_dim())
         self.mlp_head = MLP(
             in_dim=self.direction_encoding.get_out_dim() + self.geo_feat_dim + self.appearance_embedding_dim,
             num_layers=num_layers_color,
@@ -156,12 +178,69 @@ class NerfactoField(Field):
                                       enc.spec, self._transform, self._box, self.average_init_density)
         return density.view(*shape, 1)
 
+    # ---- the field as the reference composes it (normals) ----------------------------------------------------------
+    def _composed(self) -> bool:
+        return self.use_pred_normals or self._compute_normals
+
+    def _normalised_positions(self, raw: Tensor) -> Tuple[Tensor, Tensor]:
+        """nerfacto_field.py:205-214 in torch ops (differentiable with respect to the raw positions)."""
+        if self.spatial_distortion is not None:
+            mag = torch.linalg.norm(raw, ord=float("inf"), dim=-1)[..., None]  # spatial_distortions.py:66-69
+            pos = (torch.where(mag < 1, raw, (2 - (1 / mag)) * (raw / mag)) + 2.0) / 4.0
+        else:
+            pos = (raw - self.aabb[0]) / (self.aabb[1] - self.aabb[0])  # data/scene_box.py:62-71
+        selector = ((pos > 0.0) & (pos < 1.0)).all(dim=-1)
+        return pos * selector[..., None], selector
+
+    def _density_composed(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
+        positions, selector = self._normalised_positions(ray_samples.frustums.get_positions())
+        self._sample_locations = positions
+        if not self._sample_locations.requires_grad:
+            self._sample_locations.requires_grad = True
+        h = self.mlp_base(positions.view(-1, 3)).view(*ray_samples.frustums.shape, -1)
+        density_before_activation, base_mlp_out = torch.split(h, [1, self.geo_feat_dim], dim=-1)
+        self._density_before_activation = density_before_activation
+        density = self.average_init_density * trunc_exp(density_before_activation)
+        return density * selector[..., None], base_mlp_out
+
+    def _outputs_composed(self, ray_samples: RaySamples, density_embedding: Tensor) -> Dict[FieldHeadNames, Tensor]:
+        if ray_samples.camera_indices is None:
+            raise AttributeError("Camera indices are not provided.")
+        fr = ray_samples.frustums
+        shape = tuple(fr.shape)
+        outputs = {}
+        directions = get_normalized_directions(fr.directions.expand(*shape, 3))
+        d = self.direction_encoding(directions.reshape(-1, 3))
+        feats = [d, density_embedding.reshape(-1, self.geo_feat_dim)]
+        if self.embedding_appearance is not None:
+            if self.training:
+                cams = ray_samples.camera_indices.expand(*shape, 1).reshape(-1)
+                feats.append(self.embedding_appearance(cams))
+            else:  # nerfacto_field.py:253-261
+                emb = self.embedding_appearance.embedding.weight
+                row = emb.mean(dim=0) if self.use_average_appearance_embedding else torch.zeros_like(emb[0])
+                feats.append(row.detach().expand(d.shape[0], -1))
+        if self.use_pred_normals:  # nerfacto_field.py:287-295: encoded RAW positions + geometry features
+            positions_flat = self.position_encoding(fr.get_positions().reshape(-1, 3))
+            x = self.mlp_pred_normals(torch.cat([positions_flat, feats[1]], dim=-1)).view(*shape, -1)
+            outputs[FieldHeadNames.PRED_NORMALS] = self.field_head_pred_normals(x)
+        rgb = self.mlp_head(torch.cat(feats, dim=-1)).view(*shape, -1)
+        outputs[FieldHeadNames.RGB] = rgb
+        return outputs
+
+    # -----------------------------------------------------------------------------------------------------------------
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
-        """Densities `[*bs,1]`; the second value carries the rgb already evaluated by the fused pipeline."""
+        """Densities `[*bs,1]`; the second value carries the rgb already evaluated by the fused pipeline (or, on the
+        composed path of the normals options, the geometry features as in the reference)."""
+        self._composed_active = self._composed()
+        if self._composed_active:
+            return self._density_composed(ray_samples)
         density, rgb = self._evaluate(ray_samples)
         return density, rgb
 
     def get_outputs(self, ray_samples: RaySamples, density_embedding: Optional[Tensor] = None
                     ) -> Dict[FieldHeadNames, Tensor]:
         assert density_embedding is not None
+        if getattr(self, "_composed_active", False):
+            return self._outputs_composed(ray_samples, density_embedding)
         return {FieldHeadNames.RGB: density_embedding}

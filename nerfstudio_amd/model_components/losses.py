@@ -1,5 +1,7 @@
 """Losses on the nerfacto path (reference: nerfstudio/model_components/losses.py — MSELoss :31, interlevel_loss
-:113-131, distortion_loss :149-154). Per-ray fused value+gradient kernels (csrc/losses.hip)."""
+:113-131, distortion_loss :149-154, orientation_loss :201-214, pred_normal_loss :217-222). The proposal losses are per-ray
+fused value+gradient kernels (csrc/losses.hip); the two normals terms (predict_normals, off by default) are a handful of
+elementwise torch ops on tensors the field already produced."""
 from typing import List
 
 import torch
@@ -31,3 +33,15 @@ def interlevel_loss(weights_list: List[Tensor], ray_samples_list: List[RaySample
 def distortion_loss(weights_list: List[Tensor], ray_samples_list: List[RaySamples]) -> Tensor:
     """Distortion loss of mip-NeRF 360 on the final level (losses.py:149-154)."""
     return F.distortion_loss(weights_list[-1][..., 0], ray_samples_to_sdist(ray_samples_list[-1]))
+
+
+def orientation_loss(weights: Tensor, normals: Tensor, viewdirs: Tensor) -> Tensor:
+    """Ref-NeRF orientation loss (losses.py:201-214): visible normals should face the camera. weights `[*bs,S,1]`, normals
+    `[*bs,S,3]`, viewdirs `[*bs,3]` -> `[*bs]`."""
+    n_dot_v = (normals * (viewdirs * -1)[..., None, :]).sum(dim=-1)
+    return (weights[..., 0] * torch.fmin(torch.zeros_like(n_dot_v), n_dot_v) ** 2).sum(dim=-1)
+
+
+def pred_normal_loss(weights: Tensor, normals: Tensor, pred_normals: Tensor) -> Tensor:
+    """Predicted normals against the ones computed from the density (losses.py:217-222) -> `[*bs]`."""
+    return (weights[..., 0] * (1.0 - torch.sum(normals * pred_normals, dim=-1))).sum(dim=-1)

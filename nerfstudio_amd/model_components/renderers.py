@@ -149,3 +149,15 @@ class DepthRenderer(nn.Module):
         rgb0 = torch.zeros((w2.shape[0], s, 3), device=w2.device)
         depth = F.composite(rgb0, w2, t_bins, "random", expected_depth=True)[2]
         return depth.view(*shape, 1)
+
+
+class NormalsRenderer(nn.Module):
+    """Weighted sum of the per-sample normals along a ray (renderers.py:429-449), normalised with the reference's
+    `safe_normalize` (utils/math.py:214-227: v / (|v| + 1e-10))."""
+
+    @classmethod
+    def forward(cls, normals: Tensor, weights: Tensor, normalize: bool = True) -> Tensor:
+        n = torch.sum(weights * normals, dim=-2)
+        if normalize:
+            n = n / (torch.norm(n, dim=-1, keepdim=True) + 1e-10)
+        return n

@@ -21,10 +21,11 @@ from .field_components.field_heads import FieldHeadNames
 from .field_components.spatial_distortions import SceneContraction
 from .fields.density_fields import HashMLPDensityField
 from .fields.nerfacto_field import NerfactoField
-from .model_components.losses import MSELoss, distortion_loss, interlevel_loss
+from .model_components.losses import MSELoss, distortion_loss, interlevel_loss, orientation_loss, pred_normal_loss
 from .cameras.camera_optimizers import CameraOptimizer, CameraOptimizerConfig
 from .model_components.ray_samplers import ProposalNetworkSampler
-from .model_components.renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
+from .model_components.renderers import AccumulationRenderer, DepthRenderer, NormalsRenderer, RGBRenderer
+from .model_components.shaders import NormalsShader
 from .model_components.scene_colliders import NearFarCollider
 
 
@@ -57,6 +58,11 @@ class NerfactoModelConfig:
     )
     interlevel_loss_mult: float = 1.0
     distortion_loss_mult: float = 0.002
+    orientation_loss_mult: float = 0.0001
+    pred_normal_loss_mult: float = 0.001
+    predict_normals: bool = False
+    """Analytic normals from the density gradient + the predicted-normals head (models/nerfacto.py:103-120, :325-345,
+    :379-388). The field then runs as the reference composes it (fields/nerfacto_field.py here), not as the fused pipeline."""
     use_proposal_weight_anneal: bool = True
     use_appearance_embedding: bool = True
     use_average_appearance_embedding: bool = True
@@ -109,6 +115,7 @@ class NerfactoModel(nn.Module):
             use_average_appearance_embedding=c.use_average_appearance_embedding,
             appearance_embedding_dim=c.appearance_embed_dim if c.use_appearance_embedding else 0,
             average_init_density=c.average_init_density,
+            use_pred_normals=c.predict_normals,
             implementation=c.implementation,
         )
         # pose corrections of the training cameras (models/nerfacto.py:178-180; the parameter lives on the model's device)
@@ -149,6 +156,8 @@ class NerfactoModel(nn.Module):
         self.renderer_accumulation = AccumulationRenderer()
         self.renderer_depth = DepthRenderer(method="median")
         self.renderer_expected_depth = DepthRenderer(method="expected")
+        self.renderer_normals = NormalsRenderer()
+        self.normals_shader = NormalsShader()
         self.rgb_loss = MSELoss()
         self.step = 0
         self._fused = None  # fused_step.FusedTrainStep, built on first use (config.fused_train_step)
@@ -207,7 +216,7 @@ class NerfactoModel(nn.Module):
         ray_samples: RaySamples
         ray_samples, weights_list, ray_samples_list = self.proposal_sampler(ray_bundle, density_fns=self.density_fns,
                                                                             jitters=jitters)
-        field_outputs = self.field.forward(ray_samples)
+        field_outputs = self.field.forward(ray_samples, compute_normals=self.config.predict_normals)
         if self.config.use_gradient_scaling:  # models/nerfacto.py:321-322
             from . import functional as F
 
@@ -234,9 +243,19 @@ class NerfactoModel(nn.Module):
             depth = self.renderer_depth(weights=weights, ray_samples=ray_samples)
         outputs: Dict[str, object] = {"rgb": rgb, "accumulation": accumulation, "depth": depth,
                                       "expected_depth": expected_depth}
+        if self.config.predict_normals:  # models/nerfacto.py:325-329
+            normals = self.renderer_normals(normals=field_outputs[FieldHeadNames.NORMALS], weights=weights)
+            pred_normals = self.renderer_normals(field_outputs[FieldHeadNames.PRED_NORMALS], weights=weights)
+            outputs["normals"] = self.normals_shader(normals)
+            outputs["pred_normals"] = self.normals_shader(pred_normals)
         if self.training:
             outputs["weights_list"] = weights_list
             outputs["ray_samples_list"] = ray_samples_list
+        if self.training and self.config.predict_normals:  # models/nerfacto.py:335-344
+            outputs["rendered_orientation_loss"] = orientation_loss(
+                weights.detach(), field_outputs[FieldHeadNames.NORMALS], ray_bundle.directions)
+            outputs["rendered_pred_normal_loss"] = pred_normal_loss(
+                weights.detach(), field_outputs[FieldHeadNames.NORMALS].detach(), field_outputs[FieldHeadNames.PRED_NORMALS])
         for i in range(self.config.num_proposal_iterations):
             outputs[f"prop_depth_{i}"] = self.renderer_depth(weights=weights_list[i], ray_samples=ray_samples_list[i])
         return outputs
@@ -265,6 +284,11 @@ class NerfactoModel(nn.Module):
                 outputs["weights_list"], outputs["ray_samples_list"])
             assert metrics_dict is not None and "distortion" in metrics_dict
             loss_dict["distortion_loss"] = self.config.distortion_loss_mult * metrics_dict["distortion"]
+            if self.config.predict_normals:  # models/nerfacto.py:379-388
+                loss_dict["orientation_loss"] = self.config.orientation_loss_mult * torch.mean(
+                    outputs["rendered_orientation_loss"])
+                loss_dict["pred_normal_loss"] = self.config.pred_normal_loss_mult * torch.mean(
+                    outputs["rendered_pred_normal_loss"])
             self.camera_optimizer.get_loss_dict(loss_dict)  # L2 regulariser on the pose corrections
         return loss_dict
 

@@ -34,9 +34,6 @@ def install_hip_modules(model: Any) -> None:
     from .model_components.renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
 
     cfg = model.config
-    if getattr(cfg, "predict_normals", False):
-        raise NotImplementedError("nerfacto-hip: predict_normals is not on the accelerated path (analytic normals through the "
-                                  "hash encoding are not built)")
     if getattr(cfg, "features_per_level", 2) != 2:
         raise ValueError("nerfacto-hip: features_per_level must be 2")
     aabb = model.scene_box.aabb
@@ -47,7 +44,8 @@ def install_hip_modules(model: Any) -> None:
         features_per_level=cfg.features_per_level, log2_hashmap_size=cfg.log2_hashmap_size,
         hidden_dim_color=cfg.hidden_dim_color, spatial_distortion=contraction, num_images=model.num_train_data,
         use_average_appearance_embedding=cfg.use_average_appearance_embedding, appearance_embedding_dim=app_dim,
-        average_init_density=cfg.average_init_density, implementation="hip")
+        average_init_density=cfg.average_init_density, use_pred_normals=getattr(cfg, "predict_normals", False),
+        implementation="hip")
     nets = torch.nn.ModuleList()
     density_fns: List[Callable] = []
     n_prop = cfg.num_proposal_iterations
@@ -133,14 +131,19 @@ def _model_classes():
             `interlevel_loss` builds [N,S,S] temporaries and ~20 eager launches per level)."""
             if "fused_step" in outputs:
                 return outputs["fused_step"].get_loss_dict(outputs, batch)
-            if not self.training or self.config.predict_normals:
-                return super().get_loss_dict(outputs, batch, metrics_dict)  # (normals: the reference's own extra terms)
+            if not self.training:
+                return super().get_loss_dict(outputs, batch, metrics_dict)
             loss_dict = {}
             image = batch["image"].to(self.device)
             pred_rgb, gt_rgb = self.renderer_rgb.blend_background_for_loss_computation(
                 pred_image=outputs["rgb"], pred_accumulation=outputs["accumulation"], gt_image=image)
             loss_dict["rgb_loss"] = self.rgb_loss(gt_rgb, pred_rgb)
             hip_loss_terms(self, outputs, loss_dict, metrics_dict)
+            if self.config.predict_normals:  # models/nerfacto.py:379-388 (the terms were rendered by get_outputs, :335-344)
+                loss_dict["orientation_loss"] = self.config.orientation_loss_mult * torch.mean(
+                    outputs["rendered_orientation_loss"])
+                loss_dict["pred_normal_loss"] = self.config.pred_normal_loss_mult * torch.mean(
+                    outputs["rendered_pred_normal_loss"])
             self.camera_optimizer.get_loss_dict(loss_dict)
             return loss_dict
 

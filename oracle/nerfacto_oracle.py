@@ -251,6 +251,9 @@ class NerfactoCfg:
     distortion_loss_mult: float = 0.002
     histogram_padding: float = 0.01
     use_average_appearance_embedding: bool = True
+    predict_normals: bool = False  # models/nerfacto.py:119-120
+    orientation_loss_mult: float = 0.0001  # :103-104
+    pred_normal_loss_mult: float = 0.001  # :105-106
 
 
 def init_params(cfg: NerfactoCfg, seed: int = 0, table_std: Optional[float] = None) -> Dict[str, Tensor]:
@@ -295,6 +298,13 @@ def init_params(cfg: NerfactoCfg, seed: int = 0, table_std: Optional[float] = No
         # reference's state_dict (`encoding.hash_table` and `mlp_base.0.hash_table` alias the same Parameter).
         linear(f"proposal_networks.{i}.mlp_base.1.", 0, g.out_dim, cfg.prop_hidden_dim)
         linear(f"proposal_networks.{i}.mlp_base.1.", 1, cfg.prop_hidden_dim, 1)
+    if cfg.predict_normals:  # nerfacto_field.py:181-191 (drawn LAST: the stream of every other tensor is unchanged)
+        linear("field.mlp_pred_normals.", 0, cfg.geo_feat_dim + 12, 64)
+        linear("field.mlp_pred_normals.", 1, 64, 64)
+        linear("field.mlp_pred_normals.", 2, 64, 64)
+        bound = 1.0 / math.sqrt(64)
+        p["field.field_head_pred_normals.net.weight"] = torch.from_numpy(rs.uniform(-bound, bound, size=(3, 64)).astype(np.float32))
+        p["field.field_head_pred_normals.net.bias"] = torch.from_numpy(rs.uniform(-bound, bound, size=(3,)).astype(np.float32))
     return p
 
 
@@ -329,6 +339,14 @@ def proposal_density(
     return (dens * sel).reshape(shape)
 
 
+def nerf_encode(x: Tensor, num_frequencies: int, min_freq_exp: float, max_freq_exp: float) -> Tensor:
+    """`NeRFEncoding.pytorch_fwd` without covariances (encodings.py:148-166): sin of [2 pi x 2^k, ... + pi/2]."""
+    freqs = 2 ** torch.linspace(min_freq_exp, max_freq_exp, num_frequencies)
+    scaled = (2 * torch.pi * x)[..., None] * freqs
+    scaled = scaled.reshape(*scaled.shape[:-2], -1)
+    return torch.sin(torch.cat([scaled, scaled + torch.pi / 2.0], dim=-1))
+
+
 def nerfacto_field(
     positions: Tensor,
     directions: Tensor,
@@ -337,16 +355,28 @@ def nerfacto_field(
     cfg: NerfactoCfg,
     training: bool = True,
     aabb: Optional[Tensor] = None,
+    normals_out: Optional[Dict[str, Tensor]] = None,
 ) -> Tuple[Tensor, Tensor, Tensor]:
     """`NerfactoField.forward` = get_density + get_outputs (fields/nerfacto_field.py:203-310).
 
     positions/directions `[M,3]`, camera_indices `[M]` int64 -> density `[M]`, rgb `[M,3]`, geo features `[M,15]`.
+    `normals_out` (a dict, cfg.predict_normals): receives "normals" — minus the normalised gradient of the density
+    pre-activation with respect to the NORMALISED, selector-masked positions, first order only (base_field.py:79-99,
+    nerfacto_field.py:215-223) — and "pred_normals" (nerfacto_field.py:287-295, field_heads.py:190-206), `[M,3]` each.
     """
     g = cfg.main_grid
     pos, sel = normalise_positions(positions, cfg.use_scene_contraction, aabb)
+    want_normals = normals_out is not None
+    if want_normals:
+        grad_mode = torch.enable_grad()
+        grad_mode.__enter__()
+        if not pos.requires_grad:
+            pos.requires_grad_(True)
     enc = hashgrid_encode(pos, params["field.mlp_base.model.0.hash_table"], g.scalings(), g.table_size)
     h = mlp_forward(enc, params, "field.mlp_base.model.1.")
     pre, geo = h[:, 0], h[:, 1:]
+    if want_normals:
+        grad_mode.__exit__(None, None, None)
     density = cfg.average_init_density * trunc_exp(pre) * sel
 
     sh = sh_levels4((directions + 1.0) / 2.0)  # base_field.py:136-142; SH is no-grad (encodings.py:791)
@@ -361,6 +391,14 @@ def nerfacto_field(
             app = torch.zeros((positions.shape[0], cfg.appearance_embed_dim))  # :259-261
         feats.append(app)
     rgb = mlp_forward(torch.cat(feats, dim=-1), params, "field.mlp_head.", out_activation="sigmoid")
+    if want_normals:
+        x = torch.cat([nerf_encode(positions, 2, 0.0, 1.0), geo], dim=-1)
+        x = mlp_forward(x, params, "field.mlp_pred_normals.")
+        x = torch.tanh(x @ params["field.field_head_pred_normals.net.weight"].t() + params["field.field_head_pred_normals.net.bias"])
+        normals_out["pred_normals"] = torch.nn.functional.normalize(x, dim=-1)
+        with torch.enable_grad():
+            grad = torch.autograd.grad(pre, pos, grad_outputs=torch.ones_like(pre), retain_graph=True)[0]
+        normals_out["normals"] = -torch.nn.functional.normalize(grad, dim=-1)
     return density, rgb, geo
 
 
@@ -649,7 +687,8 @@ def nerfacto_forward(
     pos = sample_positions(origins, directions, t_bins).reshape(-1, 3)
     dirs = directions[:, None, :].expand(N, S, 3).reshape(-1, 3)
     cams = camera_indices.reshape(N, 1).expand(N, S).reshape(-1)
-    density, rgb, _ = nerfacto_field(pos, dirs, cams, params, cfg, training=training, aabb=aabb)
+    nrm: Optional[Dict[str, Tensor]] = {} if cfg.predict_normals else None
+    density, rgb, _ = nerfacto_field(pos, dirs, cams, params, cfg, training=training, aabb=aabb, normals_out=nrm)
     density, rgb = density.reshape(N, S), rgb.reshape(N, S, 3)
     if use_gradient_scaling:
         density, rgb = scale_gradients_by_distance_squared(density, rgb, t_bins)
@@ -671,6 +710,21 @@ def nerfacto_forward(
     }
     for i in range(n_prop):
         out[f"prop_depth_{i}"] = depth_median(weights_list[i], t_bins_list[i])[0]
+    if nrm is not None:  # models/nerfacto.py:325-344
+        n_s, p_s = nrm["normals"].reshape(N, S, 3), nrm["pred_normals"].reshape(N, S, 3)
+        out["normals_samples"], out["pred_normals_samples"] = n_s, p_s
+
+        def render(v: Tensor) -> Tensor:  # NormalsRenderer + safe_normalize (renderers.py:429-449, utils/math.py:214-227)
+            n = torch.sum(weights[..., None] * v, dim=-2)
+            n = n / (torch.norm(n, dim=-1, keepdim=True) + 1e-10)
+            return (n + 1) / 2  # NormalsShader (shaders.py:75)
+
+        out["normals"], out["pred_normals"] = render(n_s), render(p_s)
+        if training:
+            wd = weights.detach()
+            n_dot_v = (n_s * (directions * -1)[:, None, :]).sum(dim=-1)  # losses.py:201-214
+            out["rendered_orientation_loss"] = (wd * torch.fmin(torch.zeros_like(n_dot_v), n_dot_v) ** 2).sum(dim=-1)
+            out["rendered_pred_normal_loss"] = (wd * (1.0 - torch.sum(n_s.detach() * p_s, dim=-1))).sum(dim=-1)  # :217-222
     return out
 
 
@@ -678,11 +732,15 @@ def nerfacto_losses(out: Dict[str, object], target_rgb: Tensor, cfg: NerfactoCfg
     """models/nerfacto.py:363-375 with `MSELoss` (losses.py:31); background "last_sample" needs no GT blending
     for RGB targets."""
     wl, sl = out["weights_list"], out["s_bins_list"]
-    return {
+    losses = {
         "rgb_loss": torch.mean((target_rgb - out["rgb"]) ** 2),
         "interlevel_loss": cfg.interlevel_loss_mult * interlevel_loss(wl, sl),
         "distortion_loss": cfg.distortion_loss_mult * distortion_loss(wl[-1], sl[-1]),
     }
+    if cfg.predict_normals:  # models/nerfacto.py:379-388
+        losses["orientation_loss"] = cfg.orientation_loss_mult * torch.mean(out["rendered_orientation_loss"])
+        losses["pred_normal_loss"] = cfg.pred_normal_loss_mult * torch.mean(out["rendered_pred_normal_loss"])
+    return losses
 
 
 def synthetic_rays(num_rays: int, num_images: int, seed: int = 0, origin_scale: float = 0.5):
