@@ -712,8 +712,25 @@ def run_ngp(args, device):
                    pixel_area=torch.full((n, 1), 1e-6, device=device), camera_indices=torch.from_numpy(cam).to(device))
     batch = {"image": torch.from_numpy(tgt).to(device)}
     samples = []
+    runner = None
+    if not args.ngp_module_path:
+        # the explicit kernel schedule over capacity-sized buffers (nerfstudio_amd/ngp_step.py); --ngp-module-path: the same
+        # iteration through the nn.Module / autograd classes (host-bound: profiles/r03_final_bench_ngp.json)
+        from nerfstudio_amd.ngp_step import NgpTrainStep
+
+        runner = NgpTrainStep(model, n, device)
+        runner.set_batch(rb.origins, rb.directions, rb.camera_indices, batch["image"])
+        table_param = model.field.mlp_base.encoding.hash_table
 
     def step():
+        if runner is not None:
+            arena.zero_grad(skip=[table_param])  # the scatter writes the table's gradient
+            runner.forward()
+            loss = runner.loss()
+            runner.backward()
+            arena.step()
+            samples.append(runner.num_kept)
+            return loss
         arena.zero_grad()
         out = model(rb)
         loss = model.get_loss_dict(out, batch)["rgb_loss"]
@@ -731,7 +748,8 @@ def run_ngp(args, device):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert bool(torch.isfinite(loss)), "training diverged"
-    kept = float(torch.stack(samples[-args.steps:]).float().sum(dim=1).mean())
+    kept = float(np.mean(samples[-args.steps:])) if runner is not None else \
+        float(torch.stack(samples[-args.steps:]).float().sum(dim=1).mean())
     # ---- per-kernel table (eager launches through the binding, HIP events on the launch stream) ----
     N.PROFILE = {}
     prof_steps = max(1, args.profile_steps)
@@ -793,7 +811,9 @@ def run_ngp(args, device):
                    "candidate_samples_per_ray": round(n_cand / n, 2), "kept_samples_per_ray": round(kept / n, 2),
                    "field_density": NGP_DENSITY, "render_step_size": cfg.render_step_size, "cone_angle": cfg.cone_angle,
                    "alpha_thre": cfg.alpha_thre, "params": arena.numel, "final_loss": round(float(loss), 6),
-                   "grid_refresh_ms": round(refresh_ms, 3), "launch": "eager (module / autograd path)",
+                   "grid_refresh_ms": round(refresh_ms, 3),
+                   "launch": "eager (module / autograd path)" if runner is None else
+                   "explicit kernel schedule over capacity-sized buffers (ngp_step.py): eager launches, two host reads of a sample count per step",
                    "packed_kernels_ms_per_step": {k: round(v, 4) for k, v in packed}},
         "roofline": roof, "roofline_step": roof_step,
     }
@@ -972,6 +992,8 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="functional test: every rank uses cuda:0 (needs gloo)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--dp-graph", action="store_true", help="N > 1: replay captured hipGraph segments instead of eager launches")
+    ap.add_argument("--ngp-module-path", action="store_true",
+                    help="--workload ngp through the nn.Module / autograd classes instead of the explicit schedule (ngp_step.py)")
     ap.add_argument("--workload", choices=["bounded", "unbounded", "ngp"], default="bounded",
                     help="bounded = BASELINE configs[1]/[2] (the metric's configuration); unbounded = configs[4] "
                          "(cameras outside the box, most samples in the contracted region); ngp = configs[3] (instant-ngp: "

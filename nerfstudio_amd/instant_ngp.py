@@ -42,6 +42,9 @@ class InstantNGPModelConfig:
     background_color: Literal["random", "black", "white"] = "random"
     disable_scene_contraction: bool = False
     eval_num_rays_per_chunk: int = 8192
+    # Training iterations on the explicit kernel schedule behind this same Model API (ngp_step.NgpFusedStep): static
+    # capacity-sized buffers, back-to-back launches, the two sample counts as the only host reads. Not a reference field.
+    fused_train_step: bool = False
 
 
 class NGPModel(nn.Module):
@@ -85,7 +88,19 @@ class NGPModel(nn.Module):
     def forward(self, ray_bundle: RayBundle, jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
         return self.get_outputs(ray_bundle, jitter)
 
+    def _fused_step(self):
+        if not (self.training and self.config.fused_train_step and torch.is_grad_enabled()):
+            return None
+        if getattr(self, "_fused", None) is None:
+            from .ngp_step import NgpFusedStep
+
+            self._fused = NgpFusedStep(self)
+        return self._fused
+
     def get_outputs(self, ray_bundle: RayBundle, jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        fused = self._fused_step()
+        if fused is not None:
+            return fused.get_outputs(ray_bundle, jitter)
         c = self.config
         num_rays = len(ray_bundle)
         with torch.no_grad():
@@ -112,6 +127,8 @@ class NGPModel(nn.Module):
         return {"psnr": -10.0 * torch.log10(mse), "num_samples_per_batch": outputs["num_samples_per_ray"].sum()}
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
+        if "ngp_step" in outputs:
+            return outputs["ngp_step"].get_loss_dict(outputs, batch)
         image = batch["image"].to(outputs["rgb"].device)
         pred_rgb, image = self.renderer_rgb.blend_background_for_loss_computation(
             pred_image=outputs["rgb"], pred_accumulation=outputs["accumulation"], gt_image=image)

@@ -90,6 +90,13 @@ class OccGridEstimator(nn.Module):
         self._coarse.copy_(torch.where(words >= 2**31, words - 2**32, words).to(torch.int32))
         self._coarse_version = self.binaries._version
 
+    def ensure_derived(self) -> None:
+        """The derived state (coarse bitfield, cached mean) is current — called before every march."""
+        if self._occ_mean is None or (self._coarse is None and self.occs.is_cuda):
+            self._refresh_derived()
+        elif self.occs.is_cuda and self._coarse_version != self.binaries._version:
+            self._rebuild_coarse_from_binaries()  # the binaries were written by hand since the bitfield was built
+
     # ---- sampling ---------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None, near_plane: float = 0.0,
@@ -102,10 +109,7 @@ class OccGridEstimator(nn.Module):
         alpha below `alpha_thre` are dropped (render_visibility_from_density) and the survivors are compacted."""
         if stratified and jitter is None:
             jitter = torch.rand(rays_o.shape[0], device=rays_o.device)
-        if self._occ_mean is None or (self._coarse is None and self.occs.is_cuda):
-            self._refresh_derived()
-        elif self.occs.is_cuda and self._coarse_version != self.binaries._version:
-            self._rebuild_coarse_from_binaries()  # the binaries were written by hand since the bitfield was built
+        self.ensure_derived()
         ray_indices, t_starts, t_ends, info = F.occgrid_march(
             rays_o, rays_d, self.binaries, self._roi, render_step_size, near_plane, far_plane, t_min, t_max, cone_angle,
             jitter if stratified else None, coarse=self._coarse)

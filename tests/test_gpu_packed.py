@@ -241,6 +241,99 @@ def test_ngp_model_outputs_vs_oracle_and_trains(F):
     assert ev["rgb"].shape == (8, 12, 3) and float(ev["rgb"].min()) >= 0 and float(ev["rgb"].max()) <= 1
 
 
+@pytest.mark.parametrize("background", ["random", "white"])
+def test_ngp_explicit_schedule_equals_the_module_path(F, background):
+    """ngp_step.NgpTrainStep (static capacity-sized buffers, back-to-back launches) against NGPModel's nn.Module / autograd
+    path on the same rays, lattice offsets and background draw: identical sample placement (integers), outputs / loss /
+    gradients to fp32 rounding (the kept samples' positions are an fma in one route and mul + add in the other); then the
+    same schedule behind the Model API (config.fused_train_step) gives the runner's own bits, and trains."""
+    from nerfstudio_amd.cameras.rays import RayBundle
+    from nerfstudio_amd.instant_ngp import InstantNGPModelConfig, NGPModel
+    from nerfstudio_amd.ngp_step import NgpTrainStep
+
+    cfg = orc.NerfactoCfg(main_grid=orc.HashGridCfg(16, 16, 2048, 12), prop_grids=(), num_images=4, average_init_density=1.0)
+    params = orc.init_params(cfg, seed=23, table_std=0.5)
+    mc = InstantNGPModelConfig(grid_resolution=16, grid_levels=2, log2_hashmap_size=12, background_color=background,
+                               cone_angle=0.004, render_step_size=0.02)
+    model = NGPModel(mc, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), cfg.num_images)
+    missing, unexpected = model.load_state_dict({k: v.detach().clone() for k, v in params.items() if k.startswith("field.")},
+                                                strict=False)
+    assert not unexpected, unexpected
+    model = model.cuda().train()
+    n = 160
+    o, d, cam, tgt = orc.synthetic_rays(n, cfg.num_images, seed=6)
+    o, d, cam, tgt = o.cuda(), d.cuda(), cam.cuda(), tgt.cuda()
+    rb = RayBundle(origins=o, directions=d, pixel_area=torch.full((n, 1), 1e-6).cuda(), camera_indices=cam[:, None])
+    batch = {"image": tgt}
+    model.update_occupancy_grid(step=0)
+    torch.manual_seed(1)
+    jit = torch.rand(n, device="cuda")
+    names = [k for k, _ in model.field.named_parameters()]
+
+    def grads():
+        return {k: p.grad.detach().clone() for k, p in model.field.named_parameters()}
+
+    # ---- module path
+    model.zero_grad(set_to_none=True)
+    out = model(rb, jitter=jit)
+    torch.manual_seed(5)
+    loss_m = model.get_loss_dict(out, batch)["rgb_loss"]
+    loss_m.backward()
+    g_m = grads()
+    # ---- explicit schedule, capacities far too small on purpose: the buffers grow on the first batch
+    model.zero_grad(set_to_none=True)
+    r = NgpTrainStep(model, n, o.device, cap_candidates=16, cap_kept=16)
+    r.set_batch(o, d, cam, tgt)
+    r.forward(jit)
+    assert r.cap_c >= r.num_candidates > 16 and r.cap_k >= r.num_kept > 16
+    torch.manual_seed(5)
+    loss_r = r.loss()
+    r.backward()
+    g_r = grads()
+    res = r.outputs()
+    assert torch.equal(res["num_samples_per_ray"], out["num_samples_per_ray"]) and r.num_kept == int(out["num_samples_per_ray"].sum())
+    np.testing.assert_allclose(res["rgb"].cpu().numpy(), out["rgb"].detach().cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(res["accumulation"].cpu().numpy(), out["accumulation"].detach().cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(res["depth"].cpu().numpy(), out["depth"].detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(float(loss_r), float(loss_m.detach()), rtol=1e-5)
+    for k in names:
+        a, b = g_r[k].cpu().numpy(), g_m[k].cpu().numpy()
+        assert np.linalg.norm(a - b) <= 1e-3 * max(np.linalg.norm(b), 1e-20), (k, np.linalg.norm(a - b), np.linalg.norm(b))
+    # ---- the same schedule behind the Model API: the runner's own bits
+    model.config.fused_train_step = True
+    model.zero_grad(set_to_none=True)
+    out2 = model(rb, jitter=jit)
+    assert "ngp_step" in out2 and torch.equal(out2["rgb"], res["rgb"])
+    torch.manual_seed(5)
+    loss_f = model.get_loss_dict(out2, batch)["rgb_loss"]
+    assert loss_f.requires_grad and float(loss_f.detach()) == float(loss_r)
+    loss_f.backward()
+    g_f = grads()
+    for k in names:
+        assert torch.equal(g_f[k], g_r[k]), k
+    metrics = model.get_metrics_dict(out2, batch)
+    assert int(metrics["num_samples_per_batch"]) == r.num_kept and np.isfinite(float(metrics["psnr"]))
+    with pytest.raises(RuntimeError, match="unit weight"):
+        out3 = model(rb, jitter=jit)
+        (2.0 * model.get_loss_dict(out3, batch)["rgb_loss"]).backward()
+    # ---- and it trains (torch Adam on the gradients the schedule leaves in .grad; zero_grad(set_to_none) as the trainer's)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, eps=1e-15)
+    losses = []
+    for step in range(40):
+        model.update_occupancy_grid(step)
+        opt.zero_grad(set_to_none=True)
+        res = model(rb)
+        loss = model.get_loss_dict(res, batch)["rgb_loss"]
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), losses[::8]
+    # evaluation and no_grad calls stay on the module path
+    model.eval()
+    with torch.no_grad():
+        assert "ngp_step" not in model(rb)
+
+
 @pytest.mark.parametrize("levels,res", [(4, 16), (2, 32)])
 def test_marcher_with_coarse_occupancy_bits_places_the_same_samples(F, levels, res):
     """Empty-space skipping (the 4x4x4-block occupancy bitfield staged in LDS) is invisible in the result: the marcher
