@@ -790,11 +790,12 @@ def run_ngp(args, device):
                      "algorithmic_per_launch": int(work)}
     # grid refresh (excluded from the step, see the docstring): timed once on a copy of the state
     occs0, bin0 = grid.occs.clone(), grid.binaries.clone()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    grid.update_every_n_steps(step=512, occ_eval_fn=lambda x: model.field.density_fn(x) * float(cfg.render_step_size))
-    torch.cuda.synchronize()
-    refresh_ms = (time.perf_counter() - t1) * 1e3
+    for timed in (False, True):  # (the first call pays the allocator's first 4 M-point buffers)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        grid.update_every_n_steps(step=512, occ_eval_fn=lambda x: model.field.density_fn(x) * float(cfg.render_step_size))
+        torch.cuda.synchronize()
+        refresh_ms = (time.perf_counter() - t1) * 1e3
     grid.occs.copy_(occs0)
     grid.binaries.copy_(bin0)
     ms = elapsed / args.steps * 1e3

@@ -7,7 +7,7 @@ mkdir -p $out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 {
 echo "== pytest (normals, packed)"
-timeout 900 python -m pytest tests/test_normals.py tests/test_gpu_packed.py -m gpu -x -q 2>&1 | tail -25
+timeout 900 python -m pytest tests/test_normals.py tests/test_gpu_packed.py -m gpu -q 2>&1 | tail -25
 echo "== bench --workload ngp (explicit schedule)"
 timeout 600 python bench.py --workload ngp --steps 30 --warmup 10 --kernel-table 2> $out/bench_ngp_kernel_table.log | grep '^{' | tee $out/bench_ngp.json | cut -c1-1500
 head -45 $out/bench_ngp_kernel_table.log | cut -c1-140
