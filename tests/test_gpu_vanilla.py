@@ -46,8 +46,21 @@ def test_nerf_encoding_golden(golden):
         np.testing.assert_allclose(out.cpu().numpy(), g[name], rtol=0, atol=2e-6, err_msg=name)
     # batch shape preserved; rays + bin edges give the encoding of the sample midpoints
     assert NeRFEncoding(3, 4, 0.0, 4.0, True)(torch.zeros(5, 7, 3).cuda()).shape == (5, 7, 27)
+    # points that carry gradient (pose corrections behind the predicted-normals head) take the same arithmetic through torch:
+    # same values, and a gradient; the kernel entry itself still refuses them
+    enc = NeRFEncoding(3, 4, 0.0, 4.0, True)
+    xg = x.clone().requires_grad_(True)
+    out_g = enc(xg)
+    np.testing.assert_allclose(out_g.detach().cpu().numpy(), enc(x).cpu().numpy(), rtol=0, atol=2e-6)
+    out_g[:, :24].sum().backward()
+    freqs = 2 ** torch.linspace(0.0, 4.0, 4).cuda()
+    arg = (2 * torch.pi * x)[..., None] * freqs
+    want = (2 * torch.pi * freqs * (torch.cos(arg) + torch.cos(arg + torch.pi / 2))).sum(-1)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-3)
+    from nerfstudio_amd import functional as Fn
+
     with pytest.raises(RuntimeError, match="no backward"):
-        NeRFEncoding(3, 4, 0.0, 4.0)(x.clone().requires_grad_(True))
+        Fn.nerf_encode(Fn.PointSpec(positions=x.clone().requires_grad_(True)), 4, 0.0, 4.0)
 
 
 def test_wide_mlp_with_skip_connection():
