@@ -139,6 +139,7 @@ class Trainer:
         self.use_graph = use_graph
         self.runner = None
         self.defer = False
+        self.defer_scatter = False
         self.opt_parallel = True  # False: the deferred Adam runs on the main stream (per-kernel timing)
         # False: the jitter buffer of the runner is filled by the caller before every iteration (parity tests inject the
         # draws the CPU oracle uses; the default draws them on the device inside the iteration, graph-safe Philox)
@@ -158,9 +159,18 @@ class Trainer:
             # (profiles/r02_schedule_ab.txt): 1.3 / 3 / 4.5 % faster than Adam at the end of the iteration when replayed
             # from hipGraphs, neutral with eager launches — so it is the default with graphs. NSAMD_DEFER_MAIN_ADAM=0/1: A/B.
             self.defer = not self.dp and os.environ.get("NSAMD_DEFER_MAIN_ADAM", "1" if use_graph else "0") == "1"
+            # NSAMD_DEFER_SCATTER=1 (opt-in, measured and NOT adopted: profiles/r03_negative_results.txt item 8) defers the
+            # main TABLE SCATTER of iteration k as well: [scatter k -> Adam main k] becomes one branch of iteration k+1's
+            # graph beside [select batch, proposal forward k+1]; the scatter reads copies of iteration k's ray origins /
+            # directions / bin edges (0.9 MB, taken beside the main forward) because the next batch overwrites them. Same
+            # bits (parameter checksums equal), but 1-2 % SLOWER in the driver window: the route kernel's 768 x 1024-thread
+            # workgroups hold every wave slot, the small latency-bound kernels of the proposal forward wait for slots and
+            # their branch becomes the long one.
+            self.defer_scatter = self.defer and os.environ.get("NSAMD_DEFER_SCATTER", "0") == "1"
             if self.defer:
                 self.opt_stream = torch.cuda.Stream(device=dev)
                 self._opt_fork, self._opt_join = torch.cuda.Event(), torch.cuda.Event()
+                self._sh_fork, self._sh_join = torch.cuda.Event(), torch.cuda.Event()
             if self.dp:
                 from nerfstudio_amd.dp_schedule import PipelinedExchange
 
@@ -244,23 +254,44 @@ class Trainer:
         r, a = self.runner, self.arena
         main = torch.cuda.current_stream()
         beside = pending and self.opt_parallel
+
+        def pending_update():  # what iteration k-1 left behind: [its table scatter ->] its main-field Adam
+            if self.defer_scatter:
+                r.backward_table(shadow=True)
+            a.step(grad_scale=1.0, groups=["fields"], hyper_dev=self.hyper_views)
+
         if beside:
             self._opt_fork.record(main)
             self.opt_stream.wait_event(self._opt_fork)
             with torch.cuda.stream(self.opt_stream):
-                a.step(grad_scale=1.0, groups=["fields"], hyper_dev=self.hyper_views)
+                pending_update()
                 self._opt_join.record(self.opt_stream)
         elif pending:
-            a.step(grad_scale=1.0, groups=["fields"], hyper_dev=self.hyper_views)
+            pending_update()
         self._select_batch()
         r.apply_camera_corrections()
         r.forward_proposals(self.draw_jitter, need_enc=updated)
         if beside:
             main.wait_event(self._opt_join)
+        if self.defer_scatter:  # the final samples are known: copy what defines them, beside the main forward
+            if self.opt_parallel:
+                self._sh_fork.record(main)
+                self.opt_stream.wait_event(self._sh_fork)
+                with torch.cuda.stream(self.opt_stream):
+                    r.shadow_points()
+                    self._sh_join.record(self.opt_stream)
+            else:
+                r.shadow_points()
         groups = ["fields", "proposal_networks"] if updated else ["fields"]
         a.zero_grad(groups, skip=r.written_params())
         r.forward_main_and_losses(updated)
-        r.backward_all(updated)
+        r.defer_table = self.defer_scatter
+        try:
+            r.backward_all(updated)
+        finally:
+            r.defer_table = False
+        if self.defer_scatter and self.opt_parallel:
+            main.wait_event(self._sh_join)
         if updated:
             a.step(grad_scale=1.0, groups=["proposal_networks"], hyper_dev=self.hyper_views)
 
@@ -350,8 +381,10 @@ class Trainer:
         """Drain the data-parallel pipeline (no-op for N = 1)."""
         if self.exchange is not None:
             self.exchange.finish()
-        if self._pending_main:  # deferred schedule: the last iteration's main-field update
+        if self._pending_main:  # deferred schedule: the last iteration's [table scatter and] main-field update
             self._push_hyper()
+            if self.defer_scatter:
+                self.runner.backward_table(shadow=True)
             self.arena.step(grad_scale=1.0, groups=["fields"], hyper_dev=self.hyper_views)
             self._pending_main = False
             self._true_steps = dict(self.arena.step_counts)
@@ -1145,8 +1178,9 @@ def main():
                                       "pipelined under the proposal backward and the next proposal forward; proposal slice "
                                       "only on update steps)",
                        "params": arena.numel, "final_loss": round(float(loss), 6),
-                       "launch": (("hipGraph replay (4 captured variants: proposal update x pending main-field Adam, which "
-                                   "runs beside the next proposal forward)" if trainer.defer else
+                       "launch": (("hipGraph replay (4 captured variants: proposal update x pending main-field "
+                                   + ("table scatter + Adam, which run" if trainer.defer_scatter else "Adam, which runs")
+                                   + " beside the next proposal forward)" if trainer.defer else
                                    "hipGraph replay (2 captured variants)") if not trainer.pipelined else
                                   "hipGraph replay (6 captured segments)") if graphed else "eager",
                        "driver": ("Model API over the explicit kernel schedule (fused_step.py)" if args.fused_model_api else

@@ -161,6 +161,10 @@ class NerfactoTrainStep:
             self.camera_reg = torch.zeros((), **f32)
         self.reg_in_backward = True  # backward_cameras also differentiates the pose regulariser
         self.main_table_write_only = True  # the main table's gradient is written, not accumulated (written_params)
+        # True: backward_field_and_table leaves the table scatter to the caller (`backward_table`): bench.py's deferred
+        # schedule runs it beside the NEXT iteration's proposal forward, from the copies `shadow_points` took
+        self.defer_table = False
+        self.sh_origins = self.sh_directions = self.sh_t_bins = None
         self.spacing = int(getattr(model.proposal_sampler.initial_sampler, "spacing", 0))
         # host-evaluated tables (bit-identical to the reference's CPU linspace)
         self.edges = F._linspace("edges", self.counts[0], device)
@@ -510,20 +514,44 @@ class NerfactoTrainStep:
                                        N.ptr(self.field_ws), self.field_ws.numel(), st), "field_mlp_bwd")
         if self.cam_opt is not None:
             self._rays_backward(L, fld, self.f_denc)
+        if not self.defer_table:
+            self.backward_table()
+        if split:
+            torch.cuda.current_stream().wait_event(self._red_join)
+
+    def backward_table(self, shadow: bool = False) -> None:
+        """The main table's gradient scatter from `f_denc`. `shadow`: the sample points come from the copies `shadow_points`
+        took (a caller that runs this scatter AFTER the next batch has been selected: bench.py's deferred schedule)."""
+        lib, st = N.load(), N.stream()
+        ck = N.check
+        fld = self.model.field
+        L = self.n_prop
+        mm = self.m_main
+        enc = fld.mlp_base.encoding
+        pts = N.make_points(None, self.sh_origins, self.sh_directions, self.sh_t_bins, self.counts[L]) if shadow else self._points(L)
         if self.main_table_write_only:
             ws, ws_n = F._scatter_workspace(enc.spec, self.f_enc.device, mm, write_only=True)
-            ck(lib.nsamd_hashgrid_encode_bwd_set(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
+            ck(lib.nsamd_hashgrid_encode_bwd_set(pts, mm, fld._transform, fld._box, N.ptr(enc.hash_table),
                                                  enc.spec.native(), N.ptr(self.f_denc), 1, mm,
                                                  N.ptr(self._grad(enc.hash_table)), None, N.ptr(ws), ws_n, st),
                "hashgrid_encode_bwd")
         else:  # accumulate into an existing gradient (prepare_grads)
             ws, ws_n = F._scatter_workspace(enc.spec, self.f_enc.device, mm)
-            ck(lib.nsamd_hashgrid_encode_bwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
+            ck(lib.nsamd_hashgrid_encode_bwd(pts, mm, fld._transform, fld._box, N.ptr(enc.hash_table),
                                              enc.spec.native(), N.ptr(self.f_denc), 1, mm,
                                              N.ptr(self._grad(enc.hash_table)), None, N.ptr(ws), ws_n, st),
                "hashgrid_encode_bwd")
-        if split:
-            torch.cuda.current_stream().wait_event(self._red_join)
+
+    def shadow_points(self) -> None:
+        """Copies of what defines the final samples (ray origins, directions, bin edges: 0.9 MB) for a table scatter that
+        runs after the next batch has overwritten them (`backward_table(shadow=True)`)."""
+        L = self.n_prop
+        if self.sh_origins is None:
+            self.sh_origins, self.sh_directions = torch.empty_like(self.origins), torch.empty_like(self.directions)
+            self.sh_t_bins = torch.empty_like(self.t_bins[L])
+        self.sh_origins.copy_(self.origins)
+        self.sh_directions.copy_(self.directions)
+        self.sh_t_bins.copy_(self.t_bins[L])
 
     @profiler.time_function
     def backward_proposals(self, levels=None) -> None:
