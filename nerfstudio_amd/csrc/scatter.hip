@@ -272,6 +272,7 @@ __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
   uint32_t* cnt2 = cnt + kLevels * B;
   uint32_t* base = cnt2 + kLevels * B;
   uint32_t* lmax = base + kLevels * B;
+  PROBE_STAMP(0, 20);
   for (int t = threadIdx.x; t < 2 * kLevels * B; t += kRunThreads) cnt[t] = 0u;
   if (threadIdx.x < kLevels) lmax[threadIdx.x] = 0u;
   const int first = blockIdx.y * kLevels;
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
       for (int i = 0; i < kLevels; ++i) carries = carries || g0[s][i] != 0.0f || g1[s][i] != 0.0f;
     if (!__syncthreads_or(carries)) return;
   }
+  PROBE_STAMP(0, 21);
   const uint32_t mask = (1u << grid.log2_table_size) - 1u;
   const int sl = G.slice_log2;
   const uint32_t local_mask = (1u << sl) - 1u;
@@ -420,6 +422,7 @@ __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
   };
 
   sweep(std::integral_constant<int, 0>{});
+  PROBE_STAMP(0, 22);
   __syncthreads();
   for (int t = threadIdx.x; t < kLevels * B; t += kRunThreads) {
     const int i = t >> G.log2_bins;
@@ -434,7 +437,9 @@ __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
     if (level >= 0 && lmax[threadIdx.x] != 0u) atomicMax(buf.hdr + level, lmax[threadIdx.x]);
   }
   __syncthreads();
+  PROBE_STAMP(0, 23);
   sweep(std::integral_constant<int, 1>{});
+  PROBE_STAMP(0, 24);
 }
 
 // ---- pass 2 ------------------------------------------------------------------------------------------------------
@@ -513,16 +518,27 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
       const uint32_t mine = G.segs > wave ? (G.segs - wave + nw - 1u) / nw : 0u;
       for (uint32_t c0 = 0; c0 < mine; c0 += 64u) {
         const uint32_t cv = (c0 + (uint32_t)lane < mine) ? cnts[wave + (c0 + (uint32_t)lane) * nw] : 0u;
-        const uint32_t chunk = min(64u, mine - c0);
-        // trips of 4 segments, software-pipelined: the records of trip t + 1 are in flight while trip t goes through the
+        // Only the NON-EMPTY segments are visited (their lanes in a ballot; wave-uniform, scalar bit scans): an accumulating
+        // call on few points (the proposal levels while few rays carry gradient) leaves most of a tile's 384 segments
+        // empty, and walking them cost ~2.2 k clocks of pure instruction issue per trip of four
+        // (scripts/probe_gated_scatter_clocks.py: 27 k clocks per tile with next to nothing to add).
+        unsigned long long rem = __ballot(cv != 0u);
+        // trips of 4 segments, software-pipelined: the records of the next trip are in flight while this one goes through the
         // LDS atomics (all 16 waves of the workgroup otherwise alternate between waiting on memory and queueing on the LDS)
-        uint32_t n[4], n_next[4];
+        uint32_t n[4], n_next[4], sg[4], sg_next[4];
         uint4 r[4][2], r_next[4][2];
-        auto fetch = [&](uint32_t t, uint32_t (&nn)[4], uint4 (&rr)[4][2]) {
+        auto fetch = [&](uint32_t (&nn)[4], uint32_t (&ss)[4], uint4 (&rr)[4][2]) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            nn[u] = t < chunk ? (uint32_t)__builtin_amdgcn_readlane((int)cv, (int)min(t + (uint32_t)u, 63u)) : 0u;  // 0 beyond `chunk`
-            const uint4* seg = q + (size_t)(wave + (c0 + t + (uint32_t)u) * nw) * C;
+            nn[u] = 0u;
+            ss[u] = 0u;
+            if (rem != 0ull) {
+              const int j = __builtin_ctzll(rem);
+              rem &= rem - 1ull;
+              nn[u] = (uint32_t)__builtin_amdgcn_readlane((int)cv, j);
+              ss[u] = wave + (c0 + (uint32_t)j) * nw;
+            }
+            const uint4* seg = q + (size_t)ss[u] * C;
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
               const uint32_t e = (uint32_t)lane + 64u * v;
@@ -530,20 +546,21 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
             }
           }
         };
-        fetch(0u, n, r);
-        for (uint32_t t = 0; t < chunk; t += 4u) {
-          fetch(t + 4u, n_next, r_next);
+        fetch(n, sg, r);
+        while (n[0] != 0u) {  // (segments are taken in order: an empty first slot means none is left)
+          fetch(n_next, sg_next, r_next);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
 #pragma unroll
             for (int v = 0; v < 2; ++v)
               if ((uint32_t)lane + 64u * v < n[u]) add_rec(r[u][v]);
-            const uint4* seg = q + (size_t)(wave + (c0 + t + (uint32_t)u) * nw) * C;
+            const uint4* seg = q + (size_t)sg[u] * C;
             for (uint32_t e = (uint32_t)lane + 128u; e < n[u]; e += 64u) add_rec(seg[e]);
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             n[u] = n_next[u];
+            sg[u] = sg_next[u];
             r[u][0] = r_next[u][0];
             r[u][1] = r_next[u][1];
           }
