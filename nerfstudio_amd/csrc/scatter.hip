@@ -41,6 +41,24 @@ __device__ __forceinline__ bool gate_is_clear(const uint32_t* gate) {
   return gate != nullptr && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
 }
 
+// Queue records are written once (pass 1) and read once (pass 2, another launch): streaming accesses, kept out of the way of
+// the table rows and gradients that do get re-used (NSAMD_SCATTER_NT=0 at build time: plain accesses, for A/B).
+#ifndef NSAMD_SCATTER_NT
+#define NSAMD_SCATTER_NT 1
+#endif
+typedef uint32_t rec_vec __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void rec_store(uint4* dst, const uint4& r) {
+  *dst = r;  // (nontemporal STORES: 175 -> 399 us for the main table — the scattered 16-B records lose L2's write combining)
+}
+__device__ __forceinline__ uint4 rec_load(const uint4* src) {
+#if NSAMD_SCATTER_NT
+  const rec_vec v = __builtin_nontemporal_load(reinterpret_cast<const rec_vec*>(src));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *src;
+#endif
+}
+
 constexpr int kRunLen = 4;        // consecutive samples per thread in the run kernel
 constexpr int kRunThreads = 256;  // -> 1024 points per workgroup
 constexpr int kMaxLog2Bins = 10;  // pass-1 LDS counters: 3 x 4 levels x bins x 4 B <= 48 KiB
@@ -219,11 +237,11 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
                                        (h.ia & local_mask) | ((h.ib & local_mask) << 14) | 0x80000000u);
           if (SW == 0) {
             const uint32_t rank = atomicAdd(cnt + (i << G.log2_bins) + bin, 1u);  // ds_add_rtn_u32
-            if (rank < C) queue[blockIdx.x * C + rank] = rec;
+            if (rank < C) rec_store(queue + (blockIdx.x * C + rank), rec);
             else over |= 1u << (slot + q);
           } else {
             const uint32_t pos = base[(i << G.log2_bins) + bin] + atomicAdd(cnt2 + (i << G.log2_bins) + bin, 1u);
-            if (pos < Q - static_end) queue[static_end + pos] = rec;
+            if (pos < Q - static_end) rec_store(queue + (static_end + pos), rec);
             else spill_append(buf, G.spill_cap, tile, rec);
           }
         }
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
         atomicAdd(cnt + (i << G.log2_bins) + tile_bin, 1u);
       } else {
         const uint32_t pos = base[(i << G.log2_bins) + tile_bin] + atomicAdd(cnt2 + (i << G.log2_bins) + tile_bin, 1u);
-        if (pos < Q) buf.queues[(size_t)G.level_off[lvl[i]] + (size_t)tile_bin * Q + pos] = rec;
+        if (pos < Q) rec_store(buf.queues + ((size_t)G.level_off[lvl[i]] + (size_t)tile_bin * Q + pos), rec);
         else spill_append(buf, G.spill_cap, tile, rec);
       }
     };
@@ -542,7 +560,7 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
               const uint32_t e = (uint32_t)lane + 64u * v;
-              rr[u][v] = e < nn[u] ? seg[e] : make_uint4(0u, 0u, 0u, 0u);
+              rr[u][v] = e < nn[u] ? rec_load(seg + e) : make_uint4(0u, 0u, 0u, 0u);
             }
           }
         };
@@ -555,7 +573,7 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
             for (int v = 0; v < 2; ++v)
               if ((uint32_t)lane + 64u * v < n[u]) add_rec(r[u][v]);
             const uint4* seg = q + (size_t)sg[u] * C;
-            for (uint32_t e = (uint32_t)lane + 128u; e < n[u]; e += 64u) add_rec(seg[e]);
+            for (uint32_t e = (uint32_t)lane + 128u; e < n[u]; e += 64u) add_rec(rec_load(seg + e));
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -575,7 +593,7 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const uint32_t e = e0 + (uint32_t)u * blockDim.x + threadIdx.x;
-        r[u] = e < n_dyn ? dq[e] : make_uint4(0u, 0u, 0u, 0u);
+        r[u] = e < n_dyn ? rec_load(dq + e) : make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
