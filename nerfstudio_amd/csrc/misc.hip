@@ -104,6 +104,29 @@ __global__ void rows_scatter_kernel(float* __restrict__ rows, const int64_t* __r
 //   param.addcdiv_(exp_avg, denom, value=-step_size)        p + ((-step_size) m) / denom
 // step_size = lr / (1 - b1^t) and bc2_sqrt = sqrt(1 - b2^t) are evaluated in double by the host and rounded once, as the
 // Python scalars are when ATen takes them; correctly rounded sqrt and division (hipcc default), no FMA contraction.
+// The moments (2 x 67 MB for the main table) are touched exactly once per step: streamed past the caches with
+// non-temporal accesses, so that the parameters and the gradient — which the next launches read again — keep their place
+// (NSAMD_ADAM_NT=0 at build time: plain accesses, for A/B).
+#ifndef NSAMD_ADAM_NT
+#define NSAMD_ADAM_NT 1
+#endif
+typedef float adam_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 stream_load4(const float* base, int64_t i) {
+#if NSAMD_ADAM_NT
+  const adam_v4 v = __builtin_nontemporal_load(reinterpret_cast<const adam_v4*>(base) + i);
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return reinterpret_cast<const float4*>(base)[i];
+#endif
+}
+__device__ __forceinline__ void stream_store4(float* base, int64_t i, const float4& x) {
+#if NSAMD_ADAM_NT
+  __builtin_nontemporal_store(adam_v4{x.x, x.y, x.z, x.w}, reinterpret_cast<adam_v4*>(base) + i);
+#else
+  reinterpret_cast<float4*>(base)[i] = x;
+#endif
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float beta2, float w1, float w2, float eps,
                             float step_size_host, float bc2_sqrt_host, const float* __restrict__ hyper_dev,
@@ -114,8 +137,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const float4 gg = reinterpret_cast<const float4*>(g)[i];
-    float4 mm = reinterpret_cast<float4*>(m)[i];
-    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float4 mm = stream_load4(m, i);
+    float4 vv = stream_load4(v, i);
     // Rows that never received a gradient (g = m = v = 0) get a zero update: leave them alone. The torch path hashes
     // the coarse levels too, which can only ever reach (res + 1)^3 of their 2^19 slots (332 k of 2.6 M
     // rows on levels 0-4) — whole cache lines of the arena are never touched, and this skips their p read and the
@@ -137,8 +160,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
       pa[k] = pa[k] + (neg_step * ma[k]) / denom;
     }
     reinterpret_cast<float4*>(p)[i] = pp;
-    reinterpret_cast<float4*>(m)[i] = mm;
-    reinterpret_cast<float4*>(v)[i] = vv;
+    stream_store4(m, i, mm);
+    stream_store4(v, i, vv);
   }
   // tail (n not a multiple of 4)
   const int64_t tail0 = n4 << 2;
