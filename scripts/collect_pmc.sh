@@ -10,12 +10,12 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 export OUT=$R/gpurun_out/${1:-final}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kstats -o k -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 1 > $OUT/rocprof_bench.log 2>&1
+timeout ${PMC_STATS_TIMEOUT:-600} rocprofv3 --kernel-trace --stats -d /tmp/kstats -o k -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 1 > $OUT/rocprof_bench.log 2>&1
 CMD="python $R/bench.py --steps 3 --warmup 3 --no-graph --no-cpu-baseline --profile-steps 1 --fixed-batch"
 export NSAMD_SIDE_STREAM=0
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_INST_LDS --output-format csv -d /tmp/pmc_sq -o sq -- $CMD > $OUT/pmc_sq.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -o f -- $CMD > $OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -o w -- $CMD > $OUT/pmc_write.log 2>&1
+timeout ${PMC_PASS_TIMEOUT:-600} rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_INST_LDS --output-format csv -d /tmp/pmc_sq -o sq -- $CMD > $OUT/pmc_sq.log 2>&1
+timeout ${PMC_PASS_TIMEOUT:-600} rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -o f -- $CMD > $OUT/pmc_fetch.log 2>&1
+timeout ${PMC_PASS_TIMEOUT:-600} rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -o w -- $CMD > $OUT/pmc_write.log 2>&1
 cd $R
 python - <<'PY'
 import csv, glob, collections, json, os, sqlite3
