@@ -25,6 +25,22 @@ class FieldHeadNames(Enum):
     ALPHA = "alpha"
     GRADIENT = "gradient"
 
+    # A field of this package can sit inside the REFERENCE's model classes (plugin.HipNerfactoModel inherits the
+    # reference's get_outputs, which indexes `field_outputs[FieldHeadNames.DENSITY]` with the reference's own enum class,
+    # models/nerfacto.py:304-324): members compare and hash equal to the same-named member of any `FieldHeadNames` enum,
+    # so the dictionaries interchange in both directions without importing nerfstudio here.
+    def __eq__(self, other):
+        if self is other:
+            return True
+        return isinstance(other, Enum) and type(other).__name__ == "FieldHeadNames" and other.name == self.name \
+            and other.value == self.value
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __hash__(self):
+        return hash(self._name_)  # (= Enum's own hash: equal for the reference's member of the same name)
+
 
 _HEAD_ACTIVATIONS = {type(None): None, nn.ReLU: "relu", nn.Sigmoid: "sigmoid", nn.Softplus: "softplus", nn.Tanh: "tanh"}
 

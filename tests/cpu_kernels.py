@@ -1,0 +1,171 @@
+"""CPU stand-ins for the kernel wrappers of nerfstudio_amd.functional, built from the oracle's torch restatements
+(oracle/nerfacto_oracle.py). TEST INFRASTRUCTURE: they let the host side of the package — the nn.Module mirror of the
+reference interface, the plugin model that lives inside the reference's own classes — run end to end on the CPU, so that
+interface mismatches (argument order, shapes, dictionary keys, autograd wiring, parameter names) show up where no GPU is
+present. Nothing in the product imports this; on a GPU box the same calls go to the kernels.
+
+    with cpu_kernels.installed(monkeypatch): ...
+
+Same signatures and return conventions as the functions they replace (functional.py); differentiable wherever the kernel
+wrapper is.
+"""
+from typing import Optional, Sequence
+
+import torch
+from torch import Tensor
+
+from oracle import nerfacto_oracle as orc
+
+
+def _positions(spec) -> Tensor:
+    if spec.positions is not None:
+        return spec.positions
+    mid = ((spec.t_bins[:, :-1] + spec.t_bins[:, 1:]) / 2)[..., None]
+    return (spec.origins[:, None, :] + spec.directions[:, None, :] * mid).reshape(-1, 3)
+
+
+def _normalise(pos: Tensor, transform: int, aabb):
+    from nerfstudio_amd import _native as N
+
+    if transform == N.XFORM_NONE:
+        return pos, torch.ones(pos.shape[0], dtype=torch.bool)
+    if transform == N.XFORM_CONTRACT:
+        return orc.normalise_positions(pos, True)
+    box = aabb
+    if not torch.is_tensor(box):  # the fields hand their host copy of the box (N.Aabb)
+        box = torch.tensor([list(box.lo), list(box.hi)], dtype=torch.float32)
+    return orc.normalise_positions(pos, False, box.reshape(2, 3))
+
+
+def _mlp(x: Tensor, params: Sequence[Tensor], out_activation: Optional[str] = None) -> Tensor:
+    layers = list(zip(params[0::2], params[1::2]))
+    for i, (W, b) in enumerate(layers):
+        x = x @ W.t() + b
+        if i < len(layers) - 1:
+            x = torch.relu(x)
+    return torch.sigmoid(x) if out_activation == "sigmoid" else x
+
+
+def density_field(spec, table, W0, b0, W1, b1, grid, transform, aabb, average_init_density):
+    pos, sel = _normalise(_positions(spec), transform, aabb)
+    enc = orc.hashgrid_encode(pos, table, grid.scalings(), grid.table_size)
+    pre = _mlp(enc, [W0, b0, W1, b1])[:, 0]
+    return average_init_density * orc.trunc_exp(pre) * sel
+
+
+def nerfacto_field(spec, table, base_params, head_params, appearance, view_dirs, camera_indices, appearance_const, dir_group,
+                   grid, transform, aabb, average_init_density):
+    pos, sel = _normalise(_positions(spec), transform, aabb)
+    M = pos.shape[0]
+    enc = orc.hashgrid_encode(pos, table, grid.scalings(), grid.table_size)
+    h = _mlp(enc, list(base_params))
+    density = average_init_density * orc.trunc_exp(h[:, 0]) * sel
+    rows = torch.arange(M) // int(dir_group)
+    feats = [orc.sh_levels4((view_dirs.detach()[rows] + 1.0) / 2.0), h[:, 1:]]
+    if appearance is not None:
+        if camera_indices is not None:
+            feats.append(appearance[camera_indices.reshape(-1)[rows]])
+        else:
+            feats.append(appearance_const.detach()[None].expand(M, -1))
+    rgb = _mlp(torch.cat(feats, dim=-1), list(head_params), "sigmoid")
+    return density, rgb
+
+
+def piecewise_bins(nears, fars, num_samples, jitter, spacing=0):
+    n = nears.reshape(-1, 1)
+    with torch.no_grad():
+        return orc.piecewise_bins(n, fars.reshape(-1, 1), num_samples, jitter, uniform=bool(spacing))
+
+
+def pdf_resample(s_bins_prev, weights, num_samples, jitter, nears, fars, anneal=1.0, histogram_padding=0.01, eps=1e-5,
+                 return_indices=False, anneal_dev=None, spacing=0, include_original=False):
+    assert not include_original and not spacing, "stand-in: the nerfacto configuration"
+    a = float(anneal_dev) if anneal_dev is not None else float(anneal)
+    with torch.no_grad():
+        s, t, inds = orc.pdf_resample(s_bins_prev, torch.pow(weights.detach(), a), num_samples, jitter, nears.reshape(-1, 1),
+                                      fars.reshape(-1, 1), histogram_padding=histogram_padding, eps=eps)
+    return (s, t, inds.to(torch.int32)) if return_indices else (s, t)
+
+
+def weights_from_density(t_bins, density):
+    return orc.weights_from_density(t_bins, density)
+
+
+def composite(rgb, weights, t_bins=None, background="last_sample", expected_depth=True):
+    assert isinstance(background, str), "stand-in: named backgrounds"
+    out = orc.composite_rgb(rgb, weights, background, training=True)
+    depth = orc.depth_expected(weights, t_bins)[:, 0] if (expected_depth and t_bins is not None) else None
+    return out, orc.accumulation(weights)[:, 0], depth
+
+
+def composite_eval(rgb, weights, t_bins, background="last_sample"):
+    with torch.no_grad():
+        return (orc.composite_rgb(rgb, weights, background, training=False), orc.accumulation(weights)[:, 0],
+                orc.depth_expected(weights, t_bins)[:, 0], orc.depth_median(weights, t_bins)[0][:, 0])
+
+
+def depth_median(weights, t_bins, return_index=False):
+    with torch.no_grad():
+        d, idx = orc.depth_median(weights.detach(), t_bins)
+    return (d[:, 0], idx.reshape(-1).to(torch.int32)) if return_index else d[:, 0]
+
+
+def accumulation(weights):
+    with torch.no_grad():
+        return orc.accumulation(weights)[:, 0]
+
+
+def interlevel_loss(weights_list, s_bins_list):
+    return orc.interlevel_loss(list(weights_list), list(s_bins_list))
+
+
+def distortion_loss(weights, s_bins):
+    return orc.distortion_loss(weights, s_bins)
+
+
+def scale_gradients_by_distance_squared(density, rgb, t_bins):
+    n, s1 = t_bins.shape
+    d, r = orc.scale_gradients_by_distance_squared(density.reshape(n, s1 - 1), rgb.reshape(n, s1 - 1, 3), t_bins)
+    return d.view_as(density), r.view_as(rgb)
+
+
+def hashgrid_encode(x, table, grid):
+    shape = x.shape[:-1]
+    return orc.hashgrid_encode(x.reshape(-1, 3), table, grid.scalings(), grid.table_size).view(*shape, grid.out_dim)
+
+
+def linear(x, W, b, activation=None):
+    y = x @ W.t() + (b if b is not None else 0.0)
+    return {None: lambda v: v, "relu": torch.relu, "sigmoid": torch.sigmoid, "softplus": torch.nn.functional.softplus}[activation](y)
+
+
+def sh4_encode(d):
+    return orc.sh_levels4(d.detach())
+
+
+def nerf_encode(spec, num_frequencies, min_freq_exp, max_freq_exp, include_input=False):
+    x = _positions(spec)
+    out = orc.nerf_encode(x, num_frequencies, min_freq_exp, max_freq_exp)
+    return torch.cat([out, x], dim=-1) if include_input else out
+
+
+_NAMES = ("density_field", "nerfacto_field", "piecewise_bins", "pdf_resample", "weights_from_density", "composite",
+          "composite_eval", "depth_median", "accumulation", "interlevel_loss", "distortion_loss",
+          "scale_gradients_by_distance_squared", "hashgrid_encode", "linear", "sh4_encode", "nerf_encode")
+
+
+class installed:
+    """Context manager: nerfstudio_amd.functional's kernel wrappers replaced by the stand-ins above (via monkeypatch)."""
+
+    def __init__(self, monkeypatch):
+        self.mp = monkeypatch
+
+    def __enter__(self):
+        from nerfstudio_amd import functional as F
+
+        for name in _NAMES:
+            self.mp.setattr(F, name, globals()[name])
+        return self
+
+    def __exit__(self, *a):
+        return False

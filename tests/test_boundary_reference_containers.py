@@ -177,3 +177,40 @@ def test_method_plugin_uses_only_reference_config_fields_and_builds_the_hip_modu
     # registration strings a maintainer uses
     text = open(os.path.join(os.path.dirname(HERE), "pyproject.toml")).read()
     assert 'nerfacto-hip = "nerfstudio_amd.plugin:nerfacto_hip"' in text and "nerfstudio.method_configs" in text
+
+
+def test_field_output_dicts_interchange_with_the_reference_enum(ref):
+    """plugin.HipNerfactoModel inherits the REFERENCE's get_outputs, which indexes the dictionary a field of THIS package
+    returned with the reference's own `FieldHeadNames` class (models/nerfacto.py:304-324); and the reference's
+    scale_gradients_by_distance_squared rebuilds such a dictionary key by key (model_components/losses.py:534-569). The two
+    enum classes are distinct objects: members of the same name must find each other in both directions."""
+    from nerfstudio.field_components.field_heads import FieldHeadNames as RefNames
+    from nerfstudio.model_components.losses import scale_gradients_by_distance_squared
+
+    from nerfstudio_amd.field_components.field_heads import FieldHeadNames as OurNames
+
+    assert {m.name: m.value for m in RefNames} == {m.name: m.value for m in OurNames}
+    ours = {OurNames.DENSITY: torch.ones(2, 3, 1), OurNames.RGB: torch.zeros(2, 3, 3), OurNames.NORMALS: torch.ones(2, 3, 3)}
+    for m in (RefNames.DENSITY, RefNames.RGB, RefNames.NORMALS):
+        assert m in ours and ours[m] is ours[OurNames[m.name]]
+    assert RefNames.PRED_NORMALS not in ours and OurNames.RGB != RefNames.DENSITY and not (OurNames.RGB != RefNames.RGB)
+    theirs = {RefNames.DENSITY: 1, RefNames.RGB: 2}
+    assert theirs[OurNames.DENSITY] == 1 and theirs[OurNames.RGB] == 2 and OurNames.SH not in theirs
+    assert len({OurNames.RGB, RefNames.RGB}) == 1 and OurNames("rgb") is OurNames.RGB
+    # the reference's gradient scaling over a dictionary of this package's keys and the reference's RaySamples
+    rs = _ref_samples(ref, _ref_bundle(ref, n=2), s=3)
+    outs = {OurNames.DENSITY: torch.ones(2, 3, 1, requires_grad=True), OurNames.RGB: torch.ones(2, 3, 3, requires_grad=True)}
+    scaled = scale_gradients_by_distance_squared(outs, rs)
+    assert torch.equal(scaled[RefNames.DENSITY], outs[OurNames.DENSITY]) and RefNames.RGB in scaled
+
+
+def test_field_head_names_match_any_enum_of_that_name_only():
+    """(no reference needed) equality is by class NAME + member name + value: an unrelated enum with an equal value is not it."""
+    import enum
+
+    from nerfstudio_amd.field_components.field_heads import FieldHeadNames as OurNames
+
+    Same = enum.Enum("FieldHeadNames", {"RGB": "rgb", "DENSITY": "density"})
+    Other = enum.Enum("Colours", {"RGB": "rgb"})
+    assert OurNames.RGB == Same.RGB and Same.RGB == OurNames.RGB and {OurNames.RGB: 1}[Same.RGB] == 1
+    assert OurNames.RGB != Other.RGB and Other.RGB not in {OurNames.RGB: 1} and OurNames.RGB != "rgb"

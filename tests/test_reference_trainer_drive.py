@@ -251,3 +251,137 @@ def test_reference_profiler_hooks_open_roctx_ranges(monkeypatch):
     names = [c[1] for c in calls if c[0] == "push"]
     assert names == ["Trainer.train_iteration", "VanillaPipeline.get_train_loss_dict"], names
     assert [c[0] for c in calls] == ["push", "push", "pop", "pop"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU: the plugin model under the reference's OWN model code, end to end, with the kernel wrappers replaced by the oracle's
+# torch restatements (tests/cpu_kernels.py) — everything between the launch guard and the loss that no GPU-less run reaches
+# otherwise: the reference's get_outputs indexing this package's field outputs, its renderers' call signatures, its loss
+# dictionary, autograd through the mirrored modules into the reference's Optimizers.
+# ---------------------------------------------------------------------------------------------------------------------
+def _plugin_model(predict_normals=False, n_images=7):
+    from nerfstudio.data.scene_box import SceneBox
+
+    from nerfstudio_amd import plugin
+    from oracle import nerfacto_oracle as orc
+
+    cfg_cls, model_cls = plugin._model_classes()
+    args = [{"hidden_dim": 16, "log2_hashmap_size": 8, "num_levels": 5, "max_res": r, "use_linear": False} for r in (128, 256)]
+    cfg = cfg_cls(log2_hashmap_size=10, proposal_net_args_list=args, predict_normals=predict_normals)
+    model = model_cls(config=cfg, scene_box=SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), num_train_data=n_images,
+                      metadata={})
+    ocfg = orc.NerfactoCfg(main_grid=orc.HashGridCfg(16, 16, 2048, 10),
+                           prop_grids=(orc.HashGridCfg(5, 16, 128, 8), orc.HashGridCfg(5, 16, 256, 8)), num_images=n_images)
+    ocfg.predict_normals = predict_normals
+    # (the class defaults of the reference's config, not the `nerfacto` method's overrides: average_init_density = 1)
+    ocfg.average_init_density = float(cfg.average_init_density)
+    assert (cfg.interlevel_loss_mult, cfg.distortion_loss_mult, cfg.background_color) == (1.0, 0.002, "last_sample")
+    params = orc.init_params(ocfg, seed=31, table_std=0.5)
+    sd = {k: v.clone() for k, v in params.items()}
+    for i in range(2):
+        sd[f"proposal_networks.{i}.mlp_base.0.hash_table"] = sd[f"proposal_networks.{i}.encoding.hash_table"]
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(any(s in m for s in ("aabb", "max_res", "num_levels", "log2_hashmap_size", "camera_optimizer", "lpips", "psnr",
+                                    "ssim", "collider", "device_indicator")) for m in missing), missing
+    return model, ocfg, params
+
+
+@needs_reference
+def test_reference_model_code_runs_the_plugin_end_to_end_on_cpu_stand_ins(monkeypatch):
+    refdrive.install()
+    import cpu_kernels
+    from nerfstudio.cameras.rays import RayBundle
+    from nerfstudio.engine.optimizers import AdamOptimizerConfig, Optimizers
+    from nerfstudio.engine.schedulers import ExponentialDecaySchedulerConfig
+    from nerfstudio.engine.trainer import Trainer
+    from nerfstudio.pipelines.base_pipeline import VanillaPipeline
+
+    from oracle import nerfacto_oracle as orc
+
+    model, ocfg, params = _plugin_model()
+    model.train()
+    n = 24
+    o, d, cam, tgt = orc.synthetic_rays(n, ocfg.num_images, seed=8)
+
+    def bundle():
+        return RayBundle(origins=o.clone(), directions=d.clone(), pixel_area=torch.full((n, 1), 1e-6), camera_indices=cam[:, None])
+
+    with cpu_kernels.installed(monkeypatch):
+        # ---- one forward / loss / backward through the reference's NerfactoModel code, against the oracle on the same draws
+        torch.manual_seed(3)
+        jit = [torch.rand((n, 1)) for _ in range(3)]  # the sampler's draws, in its order (ray_samplers.py:105, :322)
+        torch.manual_seed(3)
+        out = model(bundle())  # Model.forward: the reference's collider, then ITS get_outputs over this package's modules
+        batch = {"image": tgt}
+        metrics = model.get_metrics_dict(out, batch)
+        losses = model.get_loss_dict(out, batch, metrics)
+        assert {"rgb_loss", "interlevel_loss", "distortion_loss"} <= set(losses)
+        sum(losses.values()).backward()
+        p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        ref = orc.nerfacto_forward(p, ocfg, o, d, cam, jit, training=True, anneal=float(model.proposal_sampler._anneal))
+        lr = orc.nerfacto_losses(ref, tgt, ocfg)
+        sum(lr.values()).backward()
+        np.testing.assert_allclose(out["rgb"].detach().numpy(), ref["rgb"].detach().numpy(), atol=1e-6)
+        np.testing.assert_allclose(out["accumulation"].detach().numpy(), ref["accumulation"].detach().numpy(), atol=1e-6)
+        np.testing.assert_allclose(out["depth"].numpy(), ref["depth"].numpy(), atol=1e-5)
+        for k in ("rgb_loss", "interlevel_loss", "distortion_loss"):
+            np.testing.assert_allclose(float(losses[k].detach()), float(lr[k].detach()), rtol=1e-5, atol=1e-12, err_msg=k)
+        named = dict(model.named_parameters())
+        for k in ("field.mlp_base.model.0.hash_table", "field.mlp_head.layers.0.weight", "field.embedding_appearance.embedding.weight",
+                  "proposal_networks.0.encoding.hash_table", "proposal_networks.1.mlp_base.1.layers.0.weight"):
+            a, b = named[k].grad.numpy(), p[k].grad.numpy()
+            assert np.linalg.norm(a - b) <= 1e-5 * max(np.linalg.norm(b), 1e-30), k
+        # ---- two iterations of the reference's trainer over it: every group steps, the loss is finite
+        groups = model.get_param_groups()
+        opts = Optimizers({k: {"optimizer": AdamOptimizerConfig(lr=1e-2, eps=1e-15),
+                               "scheduler": ExponentialDecaySchedulerConfig(lr_final=1e-4, max_steps=200000)} for k in groups}, groups)
+        pipeline = object.__new__(VanillaPipeline)
+        torch.nn.Module.__init__(pipeline)
+        dm = _Datamanager([None])
+        dm.next_train = lambda step: (bundle(), batch)  # a fresh bundle per step (the camera optimiser edits it in place)
+        pipeline.datamanager, pipeline._model, pipeline.world_size = dm, model, 1
+        trainer = _fake_trainer(pipeline, opts, "cpu")
+        before = named["field.mlp_head.layers.0.weight"].detach().clone()
+        vals = [float(Trainer.train_iteration(trainer, s)[0]) for s in range(2)]
+        assert np.isfinite(vals).all() and not torch.equal(before, named["field.mlp_head.layers.0.weight"].detach())
+        # ---- the reference's chunked eval render over the plugin (models/base_model.py:178-205)
+        model.eval()
+        img = model.get_outputs_for_camera_ray_bundle(
+            RayBundle(origins=o.reshape(4, 6, 3), directions=d.reshape(4, 6, 3), pixel_area=torch.full((4, 6, 1), 1e-6),
+                      camera_indices=cam.reshape(4, 6, 1)))
+        assert img["rgb"].shape == (4, 6, 3) and img["depth"].shape == (4, 6, 1) and float(img["rgb"].min()) >= 0
+
+
+@needs_reference
+def test_reference_model_code_runs_the_plugin_with_predicted_normals(monkeypatch):
+    """config.predict_normals under the reference's own get_outputs / get_loss_dict (models/nerfacto.py:304, :325-344, :379-388):
+    its NormalsRenderer / NormalsShader / orientation_loss / pred_normal_loss over this package's composed field."""
+    refdrive.install()
+    import cpu_kernels
+    from nerfstudio.cameras.rays import RayBundle
+
+    from oracle import nerfacto_oracle as orc
+
+    model, ocfg, params = _plugin_model(predict_normals=True)
+    assert "field.mlp_pred_normals.layers.2.weight" in dict(model.named_parameters())
+    model.train()
+    n = 12
+    o, d, cam, tgt = orc.synthetic_rays(n, ocfg.num_images, seed=9)
+    with cpu_kernels.installed(monkeypatch):
+        torch.manual_seed(4)
+        jit = [torch.rand((n, 1)) for _ in range(3)]
+        torch.manual_seed(4)
+        out = model(RayBundle(origins=o.clone(), directions=d.clone(), pixel_area=torch.full((n, 1), 1e-6), camera_indices=cam[:, None]))
+        batch = {"image": tgt}
+        losses = model.get_loss_dict(out, batch, model.get_metrics_dict(out, batch))
+        assert {"orientation_loss", "pred_normal_loss"} <= set(losses) and out["normals"].shape == (n, 3)
+        sum(losses.values()).backward()
+        p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        ref = orc.nerfacto_forward(p, ocfg, o, d, cam, jit, training=True, anneal=float(model.proposal_sampler._anneal))
+        lr = orc.nerfacto_losses(ref, tgt, ocfg)
+        np.testing.assert_allclose(out["normals"].detach().numpy(), ref["normals"].detach().numpy(), atol=1e-5)
+        np.testing.assert_allclose(out["pred_normals"].detach().numpy(), ref["pred_normals"].detach().numpy(), atol=1e-5)
+        for k in ("rgb_loss", "orientation_loss", "pred_normal_loss"):
+            np.testing.assert_allclose(float(losses[k].detach()), float(lr[k].detach()), rtol=1e-4, atol=1e-12, err_msg=k)
+        assert dict(model.named_parameters())["field.mlp_pred_normals.layers.0.weight"].grad.abs().sum() > 0
