@@ -385,3 +385,50 @@ def test_reference_model_code_runs_the_plugin_with_predicted_normals(monkeypatch
         for k in ("rgb_loss", "orientation_loss", "pred_normal_loss"):
             np.testing.assert_allclose(float(losses[k].detach()), float(lr[k].detach()), rtol=1e-4, atol=1e-12, err_msg=k)
         assert dict(model.named_parameters())["field.mlp_pred_normals.layers.0.weight"].grad.abs().sum() > 0
+
+
+@needs_reference
+@pytest.mark.parametrize("options", [
+    {"use_gradient_scaling": True}, {"use_single_jitter": False}, {"disable_scene_contraction": True},
+    {"use_same_proposal_network": True}, {"background_color": "random"}, {"background_color": "white"},
+    {"use_appearance_embedding": False}, {"camera_optimizer": "off"}], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+def test_reference_model_code_runs_the_plugin_under_its_config_options(monkeypatch, options):
+    """Every NerfactoModelConfig switch the plugin passes on, under the reference's own train forward / losses / backward
+    and eval forward (CPU stand-ins for the kernels): no KeyError / TypeError / shape error anywhere on the way."""
+    refdrive.install()
+    import cpu_kernels
+    from nerfstudio.cameras.camera_optimizers import CameraOptimizerConfig
+    from nerfstudio.cameras.rays import RayBundle
+    from nerfstudio.data.scene_box import SceneBox
+
+    from nerfstudio_amd import plugin
+    from oracle import nerfacto_oracle as orc
+
+    cfg_cls, model_cls = plugin._model_classes()
+    args = [{"hidden_dim": 16, "log2_hashmap_size": 8, "num_levels": 5, "max_res": r, "use_linear": False} for r in (128, 256)]
+    kw = dict(log2_hashmap_size=10, proposal_net_args_list=args)
+    kw.update(options)
+    if options.get("use_same_proposal_network"):
+        kw["proposal_net_args_list"] = args[:1]
+    if options.get("camera_optimizer") == "off":
+        kw["camera_optimizer"] = CameraOptimizerConfig(mode="off")
+    model = model_cls(config=cfg_cls(**kw), scene_box=SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), num_train_data=7,
+                      metadata={})
+    n = 12
+    o, d, cam, tgt = orc.synthetic_rays(n, 7, seed=8)
+
+    def bundle():
+        return RayBundle(origins=o.clone(), directions=d.clone(), pixel_area=torch.full((n, 1), 1e-6), camera_indices=cam[:, None])
+
+    with cpu_kernels.installed(monkeypatch):
+        model.train()
+        out = model(bundle())
+        batch = {"image": tgt}
+        losses = model.get_loss_dict(out, batch, model.get_metrics_dict(out, batch))
+        total = sum(losses.values())
+        total.backward()
+        assert bool(torch.isfinite(total)) and model.field.mlp_head.layers[0].weight.grad.abs().sum() > 0
+        model.eval()
+        with torch.no_grad():
+            ev = model(bundle())
+        assert ev["rgb"].shape == (n, 3) and "weights_list" not in ev
