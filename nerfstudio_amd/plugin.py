@@ -126,6 +126,28 @@ def _model_classes():
             fused = self._fused_step()
             return fused.get_outputs(ray_bundle) if fused is not None else super().get_outputs(ray_bundle)
 
+        @torch.no_grad()
+        def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle):
+            """models/base_model.py:178-205. In eval mode, with the rays already on the model's GPU, the chunk loop is the
+            device-side one (eval_render.EvalRenderer: one captured kernel schedule per chunk over static buffers, no
+            per-chunk module graph, no torch.cat — 30.5 against 23.3 M rays/s, profiles/r03_final2_bench_render_*.json; same
+            outputs bit for bit, tests/test_gpu_kernels.py); anything else takes the reference's own loop.
+            NSAMD_EVAL_RUNNER=0 switches it off."""
+            import os
+
+            from . import eval_render
+
+            col = getattr(self, "collider", None)
+            if (not self.training and camera_ray_bundle.origins.is_cuda and os.environ.get("NSAMD_EVAL_RUNNER", "1") == "1"
+                    and camera_ray_bundle.origins.device == self.device and eval_render.supported(self) is None
+                    and getattr(col, "near_plane", None) == self.config.near_plane
+                    and getattr(col, "far_plane", None) == self.config.far_plane):
+                runner = getattr(self, "_eval_runner", None)
+                if runner is None or runner.chunk != self.config.eval_num_rays_per_chunk:
+                    runner = self._eval_runner = eval_render.EvalRenderer(self)
+                return runner.render(camera_ray_bundle)
+            return super().get_outputs_for_camera_ray_bundle(camera_ray_bundle)
+
         def get_loss_dict(self, outputs, batch, metrics_dict=None):
             """models/nerfacto.py:363-392 with the proposal losses on the fused HIP kernels (the reference's torch
             `interlevel_loss` builds [N,S,S] temporaries and ~20 eager launches per level)."""
