@@ -38,6 +38,8 @@ class InstantNGPModelConfig:
     render_step_size: Optional[float] = None
     near_plane: float = 0.05
     far_plane: float = 1e3
+    use_gradient_scaling: bool = False
+    """Scale the field gradients by the squared ray distance (models/instant_ngp.py:72-73, :189-190)."""
     use_appearance_embedding: bool = False
     background_color: Literal["random", "black", "white"] = "random"
     disable_scene_contraction: bool = False
@@ -45,6 +47,51 @@ class InstantNGPModelConfig:
     # Training iterations on the explicit kernel schedule behind this same Model API (ngp_step.NgpFusedStep): static
     # capacity-sized buffers, back-to-back launches, the two sample counts as the only host reads. Not a reference field.
     fused_train_step: bool = False
+
+
+class _PackedGradientScale(torch.autograd.Function):
+    """scale_gradients_by_distance_squared (model_components/losses.py:538-569) for packed samples: identity forward, the
+    gradient multiplied by clamp(((start + end) / 2)^2, 0, 1) per sample (elementwise torch ops: `[n]` values)."""
+
+    @staticmethod
+    def forward(ctx, value: Tensor, scaling: Tensor):
+        ctx.save_for_backward(scaling)
+        return value.view_as(value)
+
+    @staticmethod
+    def backward(ctx, g):
+        (scaling,) = ctx.saved_tensors
+        return g * scaling, None
+
+
+def ngp_outputs(model, ray_bundle: RayBundle, jitter: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """NGPModel.get_outputs (models/instant_ngp.py:172-217) over this package's sampler / field / packed kernels — shared by
+    `NGPModel` here and by the plugin's subclass of the reference's NGPModel (plugin.py). `model` needs `config`
+    (near_plane, far_plane, render_step_size, alpha_thre, cone_angle[, use_gradient_scaling]), `sampler`, `field` and the
+    three renderers."""
+    c = model.config
+    num_rays = len(ray_bundle)
+    with torch.no_grad():
+        kw = {} if jitter is None else {"jitter": jitter}
+        ray_samples, ray_indices = model.sampler(ray_bundle=ray_bundle, near_plane=c.near_plane, far_plane=c.far_plane,
+                                                 render_step_size=c.render_step_size, alpha_thre=c.alpha_thre,
+                                                 cone_angle=c.cone_angle, **kw)
+    field_outputs = model.field(ray_samples)
+    if getattr(c, "use_gradient_scaling", False):
+        mid = (ray_samples.frustums.starts + ray_samples.frustums.ends) / 2
+        scaling = torch.square(mid).clamp(0, 1)
+        field_outputs = {k: _PackedGradientScale.apply(v, scaling) for k, v in field_outputs.items()}
+    # accumulation (models/instant_ngp.py:191-199): nerfacc.pack_info + render_weight_from_density
+    packed_info = getattr(ray_indices, "_nsamd_packed_info", None)  # the sampler's own rows (no recount, no host sync)
+    if packed_info is None or packed_info.shape[0] != num_rays:
+        counts = torch.bincount(ray_indices, minlength=num_rays).to(torch.int32)
+        packed_info, _ = F.packed_info_from_counts(counts)
+    starts, ends = ray_samples.frustums.starts[..., 0].contiguous(), ray_samples.frustums.ends[..., 0].contiguous()
+    weights = F.packed_weights(field_outputs[FieldHeadNames.DENSITY][..., 0], starts, ends, packed_info)[..., None]
+    rgb = model.renderer_rgb(rgb=field_outputs[FieldHeadNames.RGB], weights=weights, ray_indices=ray_indices, num_rays=num_rays)
+    depth = model.renderer_depth(weights=weights, ray_samples=ray_samples, ray_indices=ray_indices, num_rays=num_rays)
+    accumulation = model.renderer_accumulation(weights=weights, ray_indices=ray_indices, num_rays=num_rays)
+    return {"rgb": rgb, "accumulation": accumulation, "depth": depth, "num_samples_per_ray": packed_info[:, 1]}
 
 
 class NGPModel(nn.Module):
@@ -91,6 +138,8 @@ class NGPModel(nn.Module):
     def _fused_step(self):
         if not (self.training and self.config.fused_train_step and torch.is_grad_enabled()):
             return None
+        if getattr(self.config, "use_gradient_scaling", False):
+            raise NotImplementedError("fused_train_step: use_gradient_scaling is only on the module path")
         if getattr(self, "_fused", None) is None:
             from .ngp_step import NgpFusedStep
 
@@ -101,25 +150,7 @@ class NGPModel(nn.Module):
         fused = self._fused_step()
         if fused is not None:
             return fused.get_outputs(ray_bundle, jitter)
-        c = self.config
-        num_rays = len(ray_bundle)
-        with torch.no_grad():
-            ray_samples, ray_indices = self.sampler(ray_bundle=ray_bundle, near_plane=c.near_plane, far_plane=c.far_plane,
-                                                    render_step_size=c.render_step_size, alpha_thre=c.alpha_thre,
-                                                    cone_angle=c.cone_angle, jitter=jitter)
-        field_outputs = self.field(ray_samples)
-        # accumulation (models/instant_ngp.py:191-199): nerfacc.pack_info + render_weight_from_density
-        packed_info = getattr(ray_indices, "_nsamd_packed_info", None)  # the sampler's own rows (no recount, no host sync)
-        if packed_info is None or packed_info.shape[0] != num_rays:
-            counts = torch.bincount(ray_indices, minlength=num_rays).to(torch.int32)
-            packed_info, _ = F.packed_info_from_counts(counts)
-        starts, ends = ray_samples.frustums.starts[..., 0].contiguous(), ray_samples.frustums.ends[..., 0].contiguous()
-        weights = F.packed_weights(field_outputs[FieldHeadNames.DENSITY][..., 0], starts, ends, packed_info)[..., None]
-        rgb = self.renderer_rgb(rgb=field_outputs[FieldHeadNames.RGB], weights=weights, ray_indices=ray_indices,
-                                num_rays=num_rays)
-        depth = self.renderer_depth(weights=weights, ray_samples=ray_samples, ray_indices=ray_indices, num_rays=num_rays)
-        accumulation = self.renderer_accumulation(weights=weights, ray_indices=ray_indices, num_rays=num_rays)
-        return {"rgb": rgb, "accumulation": accumulation, "depth": depth, "num_samples_per_ray": packed_info[:, 1]}
+        return ngp_outputs(self, ray_bundle, jitter)
 
     def get_metrics_dict(self, outputs, batch) -> Dict[str, Tensor]:
         image = self.renderer_rgb.blend_background(batch["image"].to(outputs["rgb"].device))

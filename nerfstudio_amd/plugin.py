@@ -192,6 +192,115 @@ def _model_classes():
     return HipNerfactoModelConfig, HipNerfactoModel
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# instant-ngp (BASELINE configs[3]): the same construction for the reference's NGPModel
+# ---------------------------------------------------------------------------------------------------------------------
+NGP_DESCRIPTION = ("instant-ngp on MI355X: occupancy-grid marching, packed transmittance scan with early termination, hash "
+                   "encoding + fused MLPs and packed compositing as hand-written gfx950 HIP kernels (nerfstudio_amd)")
+
+
+def install_hip_ngp_modules(model: Any) -> None:
+    """Swap the hot-path modules of a populated (reference) NGPModel for this package's; mirrors models/instant_ngp.py:96-137
+    with the hip classes. What nerfacc provides there (OccGridEstimator) is model_components/occupancy.py here."""
+    from .field_components.spatial_distortions import SceneContraction
+    from .fields.nerfacto_field import NerfactoField
+    from .model_components.occupancy import OccGridEstimator
+    from .model_components.ray_samplers import VolumetricSampler
+    from .model_components.renderers import AccumulationRenderer, DepthRenderer, RGBRenderer
+
+    cfg = model.config
+    if not isinstance(cfg.grid_resolution, int):
+        raise ValueError("instant-ngp-hip: grid_resolution must be one integer (a cubic grid)")
+    contraction = None if cfg.disable_scene_contraction else SceneContraction(order=float("inf"))
+    model.field = NerfactoField(
+        aabb=model.scene_box.aabb,
+        # (sic) models/instant_ngp.py:104: the embedding is 32 wide when use_appearance_embedding is FALSE, as upstream
+        appearance_embedding_dim=0 if cfg.use_appearance_embedding else 32,
+        num_images=model.num_train_data, log2_hashmap_size=cfg.log2_hashmap_size, max_res=cfg.max_res,
+        spatial_distortion=contraction)
+    if cfg.render_step_size is None:  # (the reference's populate_modules has normally set it already, :113-115)
+        a = model.scene_box.aabb.flatten()
+        cfg.render_step_size = float(((a[3:] - a[:3]) ** 2).sum().sqrt().item() / 1000)
+    model.occupancy_grid = OccGridEstimator(roi_aabb=model.scene_box.aabb.flatten(), resolution=cfg.grid_resolution,
+                                            levels=cfg.grid_levels)
+    model.sampler = VolumetricSampler(occupancy_grid=model.occupancy_grid, density_fn=model.field.density_fn)
+    model.renderer_rgb = RGBRenderer(background_color=cfg.background_color)
+    model.renderer_accumulation = AccumulationRenderer()
+    model.renderer_depth = DepthRenderer(method="expected")
+
+
+def _ngp_model_classes():
+    """(HipInstantNGPModelConfig, HipNGPModel), built against the installed nerfstudio (which imports nerfacc)."""
+    from dataclasses import dataclass, field
+    from typing import Type
+
+    from nerfstudio.models.instant_ngp import InstantNGPModelConfig, NGPModel
+
+    class HipNGPModel(NGPModel):
+        """The reference NGPModel with the hot path on MI355X kernels: its callbacks (occupancy refresh every step's
+        BEFORE_TRAIN_ITERATION, models/instant_ngp.py:150-163), parameter groups, metrics and loss are the reference's own
+        code over the swapped modules; get_outputs is this package's (the reference's calls nerfacc directly, :191-198)."""
+
+        def populate_modules(self):
+            super().populate_modules()
+            install_hip_ngp_modules(self)
+            self._fused = None
+
+        def _fused_step(self):
+            if not (self.training and getattr(self.config, "fused_train_step", False) and torch.is_grad_enabled()):
+                return None
+            if getattr(self.config, "use_gradient_scaling", False):
+                raise NotImplementedError("fused_train_step: use_gradient_scaling is only on the module path")
+            if self._fused is None:
+                from .ngp_step import NgpFusedStep
+
+                self._fused = NgpFusedStep(self)
+            return self._fused
+
+        def get_outputs(self, ray_bundle):
+            from .instant_ngp import ngp_outputs
+
+            fused = self._fused_step()
+            return fused.get_outputs(ray_bundle) if fused is not None else ngp_outputs(self, ray_bundle)
+
+        def get_loss_dict(self, outputs, batch, metrics_dict=None):
+            if "ngp_step" in outputs:
+                return outputs["ngp_step"].get_loss_dict(outputs, batch)
+            return super().get_loss_dict(outputs, batch, metrics_dict)
+
+    @dataclass
+    class HipInstantNGPModelConfig(InstantNGPModelConfig):
+        _target: Type = field(default_factory=lambda: HipNGPModel)
+        fused_train_step: bool = False
+        """Run training iterations on the explicit kernel schedule behind the Model API (nerfstudio_amd/ngp_step.py)."""
+
+    return HipInstantNGPModelConfig, HipNGPModel
+
+
+def instant_ngp_hip():
+    """-> MethodSpecification for `ns-train instant-ngp-hip` (the reference's `instant-ngp` recipe, method_configs.py:251-273:
+    DynamicBatchPipeline, one Adam group). Raises ImportError when nerfstudio is not importable."""
+    import copy
+    import dataclasses
+
+    try:
+        from nerfstudio.configs.method_configs import method_configs
+        from nerfstudio.plugins.types import MethodSpecification
+    except Exception as e:  # noqa: BLE001
+        raise ImportError(f"nerfstudio_amd.plugin: nerfstudio (with its trainer dependencies) is not importable: {e}") from e
+    from .utils import profiler
+
+    profiler.hook_reference_profiler()
+    cfg_cls, _ = _ngp_model_classes()
+    base = copy.deepcopy(method_configs["instant-ngp"])
+    old = base.pipeline.model
+    kwargs = {f.name: getattr(old, f.name) for f in dataclasses.fields(old) if f.name != "_target"}
+    base.pipeline.model = cfg_cls(**kwargs)
+    base.method_name = "instant-ngp-hip"
+    base.mixed_precision = False  # fp32 kernels: no autocast, no loss scaling
+    return MethodSpecification(config=base, description=NGP_DESCRIPTION)
+
+
 def nerfacto_hip():
     """-> MethodSpecification for `ns-train nerfacto-hip`. Raises ImportError when nerfstudio is not importable."""
     import copy
@@ -213,3 +322,19 @@ def nerfacto_hip():
     base.method_name = "nerfacto-hip"
     base.mixed_precision = False  # fp32 kernels: no autocast, no loss scaling
     return MethodSpecification(config=base, description=DESCRIPTION)
+
+
+# nerfstudio's registry loads an ENTRY POINT with `EntryPoint.load()` and keeps it only if the loaded object already IS a
+# MethodSpecification (plugins/registry.py:41-51; only the NERFSTUDIO_METHOD_CONFIGS branch calls callables, :64-66). The
+# specifications need nerfstudio itself, which this module does not import at import time: they are module attributes
+# built on first access (PEP 562) — what pyproject.toml's entry points name.
+_LAZY_SPECS = {"nerfacto_hip_spec": nerfacto_hip, "instant_ngp_hip_spec": instant_ngp_hip}
+
+
+def __getattr__(name: str):
+    builder = _LAZY_SPECS.get(name)
+    if builder is None:
+        raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+    spec = builder()
+    globals()[name] = spec
+    return spec

@@ -149,7 +149,67 @@ def nerf_encode(spec, num_frequencies, min_freq_exp, max_freq_exp, include_input
     return torch.cat([out, x], dim=-1) if include_input else out
 
 
-_NAMES = ("density_field", "nerfacto_field", "piecewise_bins", "pdf_resample", "weights_from_density", "composite",
+# ---- the packed (instant-ngp) path: oracle/packed_oracle.py -------------------------------------------------------------
+def _ray_indices_of(packed_info: Tensor) -> Tensor:
+    return torch.repeat_interleave(torch.arange(packed_info.shape[0]), packed_info[:, 1])
+
+
+def packed_info_from_counts(counts):
+    c = counts.to(torch.int64)
+    starts = torch.cumsum(c, 0) - c
+    return torch.stack([starts, c], dim=-1), int(c.sum())
+
+
+def occgrid_march(origins, directions, binaries, roi_aabb, step_size, near_plane=0.0, far_plane=1e10, t_min=None, t_max=None,
+                  cone_angle=0.0, jitter=None, coarse=None):
+    from oracle import packed_oracle as po
+
+    n = origins.shape[0]
+    ri, ts, te = po.occgrid_march(origins.numpy(), directions.numpy(), binaries.numpy().astype(bool), list(roi_aabb), step_size,
+                                  near_plane=near_plane, far_plane=min(float(far_plane), 3.0e38),
+                                  t_min=None if t_min is None else t_min.numpy(), t_max=None if t_max is None else t_max.numpy(),
+                                  cone_angle=cone_angle, jitter=None if jitter is None else jitter.reshape(-1).numpy())
+    ri = torch.from_numpy(ri).to(torch.int64)
+    info = packed_info_from_counts(torch.bincount(ri, minlength=n))[0]
+    return ri, torch.from_numpy(ts), torch.from_numpy(te), info
+
+
+def packed_positions(origins, directions, ray_indices, t_starts, t_ends):
+    return origins[ray_indices] + directions[ray_indices] * ((t_starts + t_ends) / 2)[:, None]
+
+
+def packed_visibility_compact(ray_indices, t_starts, t_ends, sigmas, packed_info, early_stop_eps=1e-4, alpha_thre=0.0):
+    from oracle import packed_oracle as po
+
+    n = packed_info.shape[0]
+    mask = po.render_visibility_from_density(t_starts, t_ends, sigmas.detach(), ray_indices, n, early_stop_eps, alpha_thre)
+    ri = ray_indices[mask]
+    info2 = packed_info_from_counts(torch.bincount(ri, minlength=n))[0]
+    return ri, t_starts[mask], t_ends[mask], info2, mask.to(torch.uint8)
+
+
+def packed_weights(sigmas, t_starts, t_ends, packed_info):
+    from oracle import packed_oracle as po
+
+    return po.render_weight_from_density(t_starts, t_ends, sigmas, _ray_indices_of(packed_info), packed_info.shape[0])[0]
+
+
+def packed_composite(rgb, weights, ray_indices, packed_info, t_starts=None, t_ends=None, background="random", eval_mode=False):
+    from oracle import packed_oracle as po
+
+    n = packed_info.shape[0]
+    bg = background if isinstance(background, str) else "random"
+    comp, acc, _ = po.composite_packed(rgb, weights, t_starts if t_starts is not None else torch.zeros_like(weights),
+                                       t_ends if t_ends is not None else torch.ones_like(weights), ray_indices, n, bg,
+                                       training=not eval_mode)
+    depth = None
+    if t_starts is not None:  # (unclipped: the DepthRenderer clips, renderers.py:381-383)
+        depth = (po.accumulate_along_rays(weights, ((t_starts + t_ends) / 2)[:, None], ray_indices, n) / (acc + 1e-10))[:, 0]
+    return comp, acc[:, 0], depth
+
+
+_NAMES = ("packed_info_from_counts", "occgrid_march", "packed_positions", "packed_visibility_compact", "packed_weights",
+          "packed_composite", "density_field", "nerfacto_field", "piecewise_bins", "pdf_resample", "weights_from_density", "composite",
           "composite_eval", "depth_median", "accumulation", "interlevel_loss", "distortion_loss",
           "scale_gradients_by_distance_squared", "hashgrid_encode", "linear", "sh4_encode", "nerf_encode")
 

@@ -20,7 +20,7 @@ STUBS = os.path.join(os.path.dirname(HERE), "golden", "_refstubs")
 _PERMISSIVE_ROOTS = {"cv2", "tyro", "viser", "torchvision", "imageio", "appdirs", "newrawpy", "rawpy", "pyquaternion", "mediapy",
                      "open3d", "trimesh", "pymeshlab", "xatlas", "plotly", "nuscenes", "comet_ml", "wandb", "splines", "h5py",
                      "msgpack_numpy", "gsplat", "tinycudann", "pytorch_msssim", "torchmetrics", "tensorboard", "gdown", "skimage",
-                     "pycolmap", "hloc", "lpips", "timm", "nerfacc", "tensorly", "jaxtyping_placeholder", "matplotlib", "PIL", "scipy_placeholder"}
+                     "pycolmap", "hloc", "lpips", "fpsample", "timm", "nerfacc", "tensorly", "jaxtyping_placeholder", "matplotlib", "PIL", "scipy_placeholder"}
 
 
 class Placeholder(types.ModuleType):

@@ -176,7 +176,10 @@ def test_method_plugin_uses_only_reference_config_fields_and_builds_the_hip_modu
         plugin.nerfacto_hip()
     # registration strings a maintainer uses
     text = open(os.path.join(os.path.dirname(HERE), "pyproject.toml")).read()
-    assert 'nerfacto-hip = "nerfstudio_amd.plugin:nerfacto_hip"' in text and "nerfstudio.method_configs" in text
+    assert 'nerfacto-hip = "nerfstudio_amd.plugin:nerfacto_hip_spec"' in text and "nerfstudio.method_configs" in text
+    assert 'instant-ngp-hip = "nerfstudio_amd.plugin:instant_ngp_hip_spec"' in text
+    with pytest.raises(AttributeError):
+        plugin.no_such_spec  # noqa: B018  (the lazy attributes are the two specifications only)
 
 
 def test_field_output_dicts_interchange_with_the_reference_enum(ref):
