@@ -32,6 +32,18 @@ from torch import Tensor
 _LOSS_KEYS = ("rgb_loss", "interlevel_loss", "distortion_loss")
 
 
+def ddp_reason() -> Optional[str]:
+    """The fused steps write parameter gradients straight into `param.grad`: DistributedDataParallel's reducer, which hooks
+    autograd's gradient accumulation (pipelines/base_pipeline.py:279-282 wraps the model in DDP when world_size > 1), would
+    never see them and the ranks would silently diverge. More than one rank takes the module path under DDP, or bench.py's
+    arena exchange (arena.ParamArena + dp_schedule.PipelinedExchange)."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return "world size > 1 under DistributedDataParallel"
+    return None
+
+
 class _FusedLosses(torch.autograd.Function):
     """forward: the loss values the kernels already computed; backward: the runner's backward chains."""
 
@@ -74,7 +86,7 @@ class FusedTrainStep:
         cfg = self.model.config
         if getattr(cfg, "predict_normals", False):
             return "predict_normals"
-        return None
+        return ddp_reason()
 
     def _runner_for(self, num_rays: int, device):
         from .train_step import NerfactoTrainStep

@@ -140,6 +140,10 @@ class NGPModel(nn.Module):
             return None
         if getattr(self.config, "use_gradient_scaling", False):
             raise NotImplementedError("fused_train_step: use_gradient_scaling is only on the module path")
+        from .fused_step import ddp_reason
+
+        if ddp_reason() is not None:
+            raise NotImplementedError(f"fused_train_step: {ddp_reason()} is only on the module path")
         if getattr(self, "_fused", None) is None:
             from .ngp_step import NgpFusedStep
 

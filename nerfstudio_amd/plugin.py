@@ -251,6 +251,10 @@ def _ngp_model_classes():
                 return None
             if getattr(self.config, "use_gradient_scaling", False):
                 raise NotImplementedError("fused_train_step: use_gradient_scaling is only on the module path")
+            from .fused_step import ddp_reason
+
+            if ddp_reason() is not None:
+                raise NotImplementedError(f"fused_train_step: {ddp_reason()} is only on the module path")
             if self._fused is None:
                 from .ngp_step import NgpFusedStep
 

@@ -427,3 +427,51 @@ def test_bench_launch_line_dry_run_under_torchrun(dp_mode):
     assert out["n_gpus"] == 2 and out["dry_run"] is True and out["scaling"] == "weak"
     assert out["config"]["max_abs_error"] <= 1e-5 and 0 < out["config"]["compact_rows"] < out["config"]["prefix_rows"]
     assert out["config"]["dp_mode"] == dp_mode and out["config"]["ranks"] == 2
+
+
+def _ddp_guard_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerfstudio_amd.fused_step import ddp_reason
+        from nerfstudio_amd.instant_ngp import InstantNGPModelConfig, NGPModel
+        from nerfstudio_amd.nerfacto import NerfactoModel, NerfactoModelConfig
+
+        aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+        args = [{"hidden_dim": 16, "log2_hashmap_size": 7, "num_levels": 5, "max_res": r, "use_linear": False} for r in (32, 64)]
+        m = NerfactoModel(NerfactoModelConfig(log2_hashmap_size=8, proposal_net_args_list=args, fused_train_step=True), aabb, 3).train()
+        g = NGPModel(InstantNGPModelConfig(grid_resolution=8, grid_levels=1, log2_hashmap_size=8, fused_train_step=True), aabb, 3).train()
+        msgs = []
+        for model in (m, g):
+            try:
+                model._fused_step()
+                msgs.append("no error")
+            except NotImplementedError as e:
+                msgs.append(str(e))
+        q.put((rank, ddp_reason(), msgs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_fused_steps_refuse_more_than_one_rank():
+    """The fused steps write gradients straight into param.grad — DistributedDataParallel's reducer (which the reference's
+    pipeline wraps the model in when world_size > 1, pipelines/base_pipeline.py:279-282) would never see them and the ranks
+    would diverge silently. With a process group of two ranks both models say so instead."""
+    from nerfstudio_amd.fused_step import ddp_reason
+
+    assert ddp_reason() is None  # no process group: a single process may use them
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_guard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, reason, msgs in got:
+        assert reason and "DistributedDataParallel" in reason
+        assert all("DistributedDataParallel" in msg and "module path" in msg for msg in msgs), msgs
