@@ -33,6 +33,14 @@ class RayPack:
     spacing: int = 0  # s -> t map of the initial sampler: 0 = uniform / linear-in-disparity piecewise, 1 = uniform
 
 
+@dataclass
+class Gaussians:
+    """Mean `[*bs,3]` and covariance `[*bs,3,3]` of a 3-D Gaussian (utils/math.py:29-39)."""
+
+    mean: Tensor
+    cov: Tensor
+
+
 @dataclass(init=False)
 class Frustums(TensorDataclass):
     """Region of space as a frustum (cameras/rays.py:34-104)."""
@@ -59,6 +67,24 @@ class Frustums(TensorDataclass):
 
     def get_start_positions(self) -> Tensor:
         return self.origins + self.directions * self.starts
+
+    def get_gaussian_blob(self) -> Gaussians:
+        """mip-NeRF's Gaussian approximation of the conical frustum (cameras/rays.py:66-81 -> utils/math.py:95-121: eq. 7 of
+        arXiv:2103.13415 in its stable form, c = interval centre, h = half width): for integrated encodings, which are not
+        on the nerfacto path — a few elementwise torch ops, part of the Frustums interface for completeness. The cone's radius
+        at distance 1 is the one whose disc has the pixel's area."""
+        if self.offsets is not None:
+            raise NotImplementedError()
+        radius = torch.sqrt(self.pixel_area) / 1.7724538509055159  # sqrt(area / pi)
+        c, h = (self.starts + self.ends) / 2.0, (self.ends - self.starts) / 2.0
+        q = 3.0 * c**2 + h**2
+        mean = self.origins + self.directions * (c + (2.0 * c * h**2) / q)
+        var_along = h**2 / 3 - (4 / 15) * (h**4 * (12 * c**2 - h**2)) / q**2
+        var_across = radius**2 * (c**2 / 4 + (5 / 12) * h**2 - (4 / 15) * h**4 / q)
+        d = self.directions
+        along = d[..., :, None] * d[..., None, :]
+        across = torch.eye(3, device=d.device) - d[..., :, None] * (d / torch.clamp((d**2).sum(-1, keepdim=True), min=1e-10))[..., None, :]
+        return Gaussians(mean=mean, cov=var_along[..., None] * along + var_across[..., None] * across)
 
     def set_offsets(self, offsets: Tensor) -> None:
         self.offsets = offsets

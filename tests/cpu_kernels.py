@@ -79,11 +79,15 @@ def piecewise_bins(nears, fars, num_samples, jitter, spacing=0):
 
 def pdf_resample(s_bins_prev, weights, num_samples, jitter, nears, fars, anneal=1.0, histogram_padding=0.01, eps=1e-5,
                  return_indices=False, anneal_dev=None, spacing=0, include_original=False):
-    assert not include_original and not spacing, "stand-in: the nerfacto configuration"
+    assert spacing in (0, 1), "stand-in: piecewise (nerfacto) or uniform spacing"
     a = float(anneal_dev) if anneal_dev is not None else float(anneal)
+    n, f = nears.reshape(-1, 1), fars.reshape(-1, 1)
     with torch.no_grad():
-        s, t, inds = orc.pdf_resample(s_bins_prev, torch.pow(weights.detach(), a), num_samples, jitter, nears.reshape(-1, 1),
-                                      fars.reshape(-1, 1), histogram_padding=histogram_padding, eps=eps)
+        s, t, inds = orc.pdf_resample(s_bins_prev, torch.pow(weights.detach(), a), num_samples, jitter, n, f,
+                                      histogram_padding=histogram_padding, eps=eps, uniform=bool(spacing))
+        if include_original:  # the new edges merged into the existing ones (ray_samplers.py:356-357)
+            s = torch.sort(torch.cat([s_bins_prev, s], dim=-1), dim=-1)[0]
+            t = orc.spacing_to_euclidean(s, n, f, uniform=bool(spacing))
     return (s, t, inds.to(torch.int32)) if return_indices else (s, t)
 
 
