@@ -36,12 +36,14 @@ def distortion_loss(weights_list: List[Tensor], ray_samples_list: List[RaySample
 
 
 def orientation_loss(weights: Tensor, normals: Tensor, viewdirs: Tensor) -> Tensor:
-    """Ref-NeRF orientation loss (losses.py:201-214): visible normals should face the camera. weights `[*bs,S,1]`, normals
-    `[*bs,S,3]`, viewdirs `[*bs,3]` -> `[*bs]`."""
-    n_dot_v = (normals * (viewdirs * -1)[..., None, :]).sum(dim=-1)
-    return (weights[..., 0] * torch.fmin(torch.zeros_like(n_dot_v), n_dot_v) ** 2).sum(dim=-1)
+    """Ref-NeRF orientation loss (losses.py:201-214): a visible normal should not point away from the camera. weights
+    `[*bs,S,1]`, normals `[*bs,S,3]`, viewdirs `[*bs,3]` -> `[*bs]`: sum_s w_s min(0, n_s . (-d))^2."""
+    towards_camera = -(normals * viewdirs[..., None, :]).sum(dim=-1)  # n . (-d); negation is exact
+    back_facing = torch.fmin(towards_camera, torch.zeros_like(towards_camera))  # (fmin: a NaN dot product counts as 0)
+    return (weights[..., 0] * back_facing**2).sum(dim=-1)
 
 
 def pred_normal_loss(weights: Tensor, normals: Tensor, pred_normals: Tensor) -> Tensor:
-    """Predicted normals against the ones computed from the density (losses.py:217-222) -> `[*bs]`."""
-    return (weights[..., 0] * (1.0 - torch.sum(normals * pred_normals, dim=-1))).sum(dim=-1)
+    """Predicted normals against the ones computed from the density (losses.py:217-222): sum_s w_s (1 - n_s . p_s) -> `[*bs]`."""
+    agreement = (normals * pred_normals).sum(dim=-1)
+    return (weights[..., 0] * (1.0 - agreement)).sum(dim=-1)

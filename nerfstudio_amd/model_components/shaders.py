@@ -5,11 +5,10 @@ from torch import Tensor, nn
 
 
 class NormalsShader(nn.Module):
-    """Normals as colours: (n + 1) / 2, optionally scaled by per-pixel weights (shaders.py:60-78)."""
+    """Unit normals as colours: every component moved from [-1, 1] to [0, 1]; optional per-pixel weights (an accumulation
+    mask) scale the result (shaders.py:60-78)."""
 
     @classmethod
     def forward(cls, normals: Tensor, weights: Optional[Tensor] = None) -> Tensor:
-        normals = (normals + 1) / 2
-        if weights is not None:
-            normals = normals * weights
-        return normals
+        colours = 0.5 * normals + 0.5  # (= (n + 1) / 2 bit for bit: halving is exact)
+        return colours if weights is None else colours * weights
