@@ -37,7 +37,7 @@ class NgpTrainStep:
 
     def __init__(self, model, num_rays: int, device, cap_candidates: int = 0, cap_kept: int = 0) -> None:
         N.require_cuda(torch.empty(0, device=device))
-        self.model, self.n, self.dev = model, int(num_rays), device
+        self.model, self.dev = model, device
         cfg = model.config
         self.cfg = cfg
         fld = model.field
@@ -46,23 +46,11 @@ class NgpTrainStep:
         self.L2 = enc.spec.out_dim
         if self.L2 != 32:
             raise RuntimeError("NgpTrainStep: the main-field kernels take 16 levels x 2 features")
+        self.n, self.cap_n, self._ray = 0, 0, {}
+        self._set_num_rays(int(num_rays))
         n = self.n
-        f32, i64, i32 = torch.float32, torch.int64, torch.int32
-
-        def buf(*shape, dtype=f32):
-            return torch.empty(shape, device=device, dtype=dtype)
-
-        self.origins, self.directions, self.target = buf(n, 3), buf(n, 3), buf(n, 3)
-        self.cams = torch.zeros(n, device=device, dtype=i64)
-        self.jitter = buf(n)
-        self.counts, self.kept = buf(n, dtype=i32), buf(n, dtype=i32)
-        self.info, self.info2 = buf(n, 2, dtype=i64), buf(n, 2, dtype=i64)
-        self.totals = torch.zeros(2, device=device, dtype=i64)
-        self.totals_host = torch.zeros(2, dtype=i64).pin_memory()
-        self.rgb, self.acc, self.depth = buf(n, 3), buf(n), buf(n)
-        self.bg = torch.zeros(n, 3, device=device)
-        self.pred = buf(n, 3)
-        self.g_rgb, self.g_acc = buf(n, 3), buf(n)
+        self.totals = torch.zeros(2, device=device, dtype=torch.int64)
+        self.totals_host = torch.zeros(2, dtype=torch.int64).pin_memory()
         self.loss_sum = torch.zeros(1, device=device)
         self.view0 = torch.zeros(1, 3, device=device)  # density_fn: no direction, a constant appearance row
         emb = fld.embedding_appearance.embedding.weight if fld.embedding_appearance is not None else None
@@ -79,6 +67,28 @@ class NgpTrainStep:
         self.bg_mode, self.bg_vals = F._packed_bg(bgc)
 
     # ---- buffers -----------------------------------------------------------------------------------------------------
+    # per-ray arrays: name -> (trailing shape, dtype). The attributes of these names are the first `n` rows of capacity-sized
+    # buffers: DynamicBatchPipeline changes the number of rays of a batch every step (pipelines/dynamic_batch.py:71-95), and
+    # a change within the capacity costs nothing (grown 1.5 x beyond it).
+    _RAY_BUFFERS = (("origins", (3,), torch.float32), ("directions", (3,), torch.float32), ("target", (3,), torch.float32),
+                    ("cams", (), torch.int64), ("jitter", (), torch.float32), ("counts", (), torch.int32),
+                    ("kept", (), torch.int32), ("info", (2,), torch.int64), ("info2", (2,), torch.int64),
+                    ("rgb", (3,), torch.float32), ("acc", (), torch.float32), ("depth", (), torch.float32),
+                    ("bg", (3,), torch.float32), ("pred", (3,), torch.float32), ("g_rgb", (3,), torch.float32),
+                    ("g_acc", (), torch.float32))
+
+    def _set_num_rays(self, n: int) -> None:
+        if n <= 0:
+            raise ValueError("NgpTrainStep: a batch needs at least one ray")
+        if n > self.cap_n:
+            self.cap_n = max(n, int(1.5 * self.cap_n))
+            self._ray = {name: torch.zeros((self.cap_n, *shape), device=self.dev, dtype=dtype) for name, shape, dtype in self._RAY_BUFFERS}
+            self.n = 0
+        if n != self.n:
+            for name, _, _ in self._RAY_BUFFERS:
+                setattr(self, name, self._ray[name][:n])
+            self.n = n
+
     def _grow_candidates(self, cap: int) -> None:
         if cap <= self.cap_c:
             return
@@ -118,6 +128,8 @@ class NgpTrainStep:
 
     # ---- batch ---------------------------------------------------------------------------------------------------------
     def set_batch(self, origins: Tensor, directions: Tensor, camera_indices: Optional[Tensor], target: Optional[Tensor] = None) -> None:
+        """A batch of any number of rays (see `_set_num_rays`)."""
+        self._set_num_rays(int(origins.reshape(-1, 3).shape[0]))
         self.origins.copy_(origins.reshape(-1, 3))
         self.directions.copy_(directions.reshape(-1, 3))
         if camera_indices is not None:
@@ -324,7 +336,7 @@ class NgpFusedStep:
 
     def get_outputs(self, ray_bundle, jitter: Optional[Tensor] = None) -> Dict[str, object]:
         o = ray_bundle.origins.reshape(-1, 3)
-        if self.runner is None or self.runner.n != o.shape[0]:
+        if self.runner is None:
             self.runner = NgpTrainStep(self.model, o.shape[0], o.device)
         r = self.runner
         cams = ray_bundle.camera_indices

@@ -316,6 +316,25 @@ def test_ngp_explicit_schedule_equals_the_module_path(F, background):
     with pytest.raises(RuntimeError, match="unit weight"):
         out3 = model(rb, jitter=jit)
         (2.0 * model.get_loss_dict(out3, batch)["rgb_loss"]).backward()
+    # ---- DynamicBatchPipeline changes the ray count every step (pipelines/dynamic_batch.py:71-95): fewer rays reuse the
+    # buffers, more grow them; same runner object, same results as the module path
+    fused_obj = model._fused
+    for n2 in (96, 300):
+        o2, d2, cam2, tgt2 = (t.cuda() for t in orc.synthetic_rays(n2, cfg.num_images, seed=20 + n2))
+        rb2 = RayBundle(origins=o2, directions=d2, pixel_area=torch.full((n2, 1), 1e-6).cuda(), camera_indices=cam2[:, None])
+        jit2 = torch.rand(n2, device="cuda")
+        model.zero_grad(set_to_none=True)
+        model.config.fused_train_step = False
+        ref2 = model(rb2, jitter=jit2)
+        model.config.fused_train_step = True
+        got2 = model(rb2, jitter=jit2)
+        assert model._fused is fused_obj and fused_obj.runner.n == n2 <= fused_obj.runner.cap_n
+        assert got2["rgb"].shape == (n2, 3) and torch.equal(got2["num_samples_per_ray"], ref2["num_samples_per_ray"])
+        np.testing.assert_allclose(got2["rgb"].cpu().numpy(), ref2["rgb"].detach().cpu().numpy(), atol=2e-6)
+        np.testing.assert_allclose(got2["depth"].cpu().numpy(), ref2["depth"].detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+        model.get_loss_dict(got2, {"image": tgt2})["rgb_loss"].backward()
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.field.parameters())
+    assert fused_obj.runner.cap_n >= 300
     # ---- and it trains (torch Adam on the gradients the schedule leaves in .grad; zero_grad(set_to_none) as the trainer's)
     opt = torch.optim.Adam(model.parameters(), lr=1e-2, eps=1e-15)
     losses = []
