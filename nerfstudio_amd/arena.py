@@ -87,8 +87,12 @@ class ParamArena:
     stay untouched on the steps where the sampler runs them under no_grad (ray_samplers.py:590,604-609)."""
 
     def __init__(self, params: Union[Iterable[Parameter], Dict[str, Iterable[Parameter]]], lr: float = 1e-2,
-                 betas=(0.9, 0.999), eps: float = 1e-15) -> None:
+                 betas=(0.9, 0.999), eps: float = 1e-15, bind_grads: bool = True) -> None:
+        """bind_grads=False: `param.grad` stays None — the gradients live in the arena only (`grad_lookup`). For a trainer
+        whose own optimisers must find nothing to step because the arena's fused Adam does (pipeline.HipPipeline under the
+        reference's Trainer: engine/optimizers.py:160-172 steps a group only when a `.grad` is not None)."""
         groups = params if isinstance(params, dict) else {"all": params}
+        self.bind_grads = bind_grads
         self.params: List[Parameter] = []
         self.group_params: Dict[str, List[Parameter]] = {}
         seen = set()
@@ -124,7 +128,7 @@ class ParamArena:
             n = p.numel()
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
-            p.grad = self.grad[off:off + n].view(p.shape)
+            p.grad = self.grad[off:off + n].view(p.shape) if bind_grads else None
         self.groups: Dict[str, Tuple[int, int]] = spans  # (the padding holds zeros for ever: zero gradient, zero update)
         self.step_counts: Dict[str, int] = {n: 0 for n in self.groups}
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -154,9 +158,20 @@ class ParamArena:
             spans = cut
         for a, b in spans:
             self.grad[a:b].zero_()
+        if not self.bind_grads:
+            return
         for p, off in zip(self.params, self.offsets):  # autograd may have replaced .grad; re-point the views
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + p.numel()].view(p.shape)
+
+    def grad_view(self, param: Parameter) -> torch.Tensor:
+        """The arena's gradient view of `param` (what `param.grad` is with bind_grads)."""
+        off = next(o for p, o in zip(self.params, self.offsets) if p is param)
+        return self.grad[off:off + param.numel()].view(param.shape)
+
+    def grad_lookup(self) -> Dict[int, torch.Tensor]:
+        """{id(parameter): gradient view}: where the kernel schedules write (train_step.NerfactoTrainStep.grad_lookup)."""
+        return {id(p): self.grad[off:off + p.numel()].view(p.shape) for p, off in zip(self.params, self.offsets)}
 
     def span(self, params: Iterable[Parameter]):
         """(start, end) float offsets of the contiguous arena range holding `params` (they must be adjacent, which is

@@ -102,3 +102,94 @@ class PipelinedExchange:
             if self.before_main_update is not None:
                 self.before_main_update()
             self._finish_main()
+
+
+def rehearse_on_cpu(build_model, steps, warmup, dp_mode, rank, world):
+    """CPU-only rehearsal of the multi-GPU launch (the driver's `python -m torch.distributed.run --nproc-per-node N ...
+    bench.py --gpus N` line cannot be tried on RCCL before the round ends): same argument / environment handling, a gloo
+    process group instead of RCCL, the real model + ParamArena + compact table prefix + PipelinedExchange with the kernel
+    segments replaced by rank-dependent synthetic gradients and an SGD update. Checks that every rank ends with identical
+    parameters equal to the sequential data-parallel result, then prints the JSON line (value null, "dry_run": true)."""
+    import json
+    import os
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    from .arena import ParamArena
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    model = build_model(torch.device("cpu"), seed=rank)  # different init per rank: the broadcast must fix it
+    arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
+    arena.broadcast_params()
+    enc = model.field.mlp_base.encoding
+    rows, index = enc.spec.reachable_prefix()
+    if dp_mode != "sharded":
+        arena.register_compact(enc.hash_table, rows, index)
+    start = arena.flat.clone()
+    requested, lr, steps = steps, 0.5, max(2, steps)
+    schedule = [k % 3 != 2 for k in range(steps)]
+    step = {"k": 0}
+    reach = torch.zeros(rows, dtype=torch.bool)
+    reach[index] = True
+    off_t = next(o for p, o in zip(arena.params, arena.offsets) if p is enc.hash_table)
+
+    def local_grad(r, k):
+        """Deterministic per-rank, per-step gradient of the whole arena; zero on the unreachable rows of the prefix."""
+        g = torch.full((arena.numel,), float(r + 1) * (k + 1) * 1e-3)
+        pref = g[off_t:off_t + 2 * rows].view(rows, 2)
+        pref[~reach] = 0.0
+        return g
+
+    def run(name):
+        k = step["k"]
+        if name in (("main", True), ("main", False)):
+            a, b = arena.groups["fields"]
+            arena.grad[a:b] = local_grad(rank, k)[a:b]
+        elif name == "pbwd":
+            a, b = arena.groups["proposal_networks"]
+            arena.grad[a:b] = local_grad(rank, k)[a:b]
+        elif name in ("mopt", "popt"):
+            grp = "fields" if name == "mopt" else "proposal_networks"
+            a, b = arena.shard_span(grp) if sharded else arena.groups[grp]
+            arena.flat[a:b] -= lr * arena.grad[a:b] / world
+
+    sharded = dp_mode == "sharded"
+    ex = PipelinedExchange(arena, run, sharded=sharded)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step["k"] = k
+        ex.iteration(schedule[k])
+    ex.finish()
+    elapsed = time.perf_counter() - t0
+    expect = start.clone()
+    for k in range(steps):
+        mean = sum(local_grad(r, k) for r in range(world)) / world
+        a, b = arena.groups["fields"]
+        expect[a:b] -= lr * mean[a:b]
+        if schedule[k]:
+            a, b = arena.groups["proposal_networks"]
+            expect[a:b] -= lr * mean[a:b]
+    err = float((arena.flat - expect).abs().max())
+    assert err <= 1e-5, f"rank {rank}: pipelined exchange differs from sequential data-parallel SGD by {err}"
+    if world > 1:
+        chk = torch.tensor([float(arena.flat.double().sum())], dtype=torch.float64)
+        gathered = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(gathered, chk)
+        assert all(float(g) == float(gathered[0]) for g in gathered), "ranks ended with different parameters"
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "training rays/sec (4096 rays x 48 samples per GPU)", "value": None, "unit": "rays/s",
+                          "n_gpus": world, "steps": requested, "warmup": warmup, "ms_per_step": None,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "dry_run": True,
+                          "config": {"workload": "launch rehearsal on CPU over gloo: model + arena + compact prefix + pipelined "
+                                                 "exchange, synthetic gradients", "params": arena.numel,
+                                     "dp_mode": dp_mode, "ranks": dist.get_world_size() if world > 1 else 1,
+                                     "compact_rows": int(index.numel()), "prefix_rows": int(rows),
+                                     "exchange_s_per_step": round(elapsed / steps, 4), "max_abs_error": err}}))
+    if world > 1:
+        dist.destroy_process_group()

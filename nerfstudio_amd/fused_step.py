@@ -129,11 +129,15 @@ class FusedTrainStep:
     def get_loss_dict(self, outputs, batch) -> Dict[str, Tensor]:
         assert outputs.get("fused_step") is self, "outputs of another forward"
         r = self.runner
-        # RGBA targets are blended with the renderer's background exactly as the reference does before the loss
-        # (models/nerfacto.py:377-381 -> renderers.py:150-170 blend_background); RGB targets pass through unchanged
+        # RGBA targets are blended with the background the PREDICTION is blended with (models/nerfacto.py:377-381 ->
+        # renderers.py:175-199): "last_sample" counts as black, a named / tensor colour as itself, and "random" is the
+        # per-ray colour this iteration drew for the prediction (`bg_rays`, which the loss kernel adds as bg (1 - acc)) —
+        # not black, which would pull transparent pixels towards black against a random-coloured prediction.
+        # RGB targets pass through unchanged.
         image = batch["image"].to(r.target.device)
         if image.shape[-1] == 4:
-            image = self.model.renderer_rgb.blend_background(image)
+            image = image.reshape(-1, 4)
+            image = self.model.renderer_rgb.blend_background(image, background_color=r.bg_rays if r.bg_rays is not None else None)
         r.target.copy_(image.reshape(-1, 3))
         r.losses(self.updated)
         anchor = self.model.field.mlp_base.encoding.hash_table  # any parameter: makes autograd call backward

@@ -49,6 +49,14 @@ class OccGridEstimator(nn.Module):
         super()._load_from_state_dict(*args, **kwargs)
         self._roi_host, self._coarse, self._occ_mean = None, None, None
 
+    def _apply(self, fn, *args, **kwargs):
+        """`.to()` / `.cuda()` / `.float()` replace the buffers by new tensors (whose version counters start over, possibly
+        at the cached one): everything derived from them is rebuilt on the next use."""
+        out = super()._apply(fn, *args, **kwargs)
+        self._roi_host, self._coarse, self._occ_mean, self._coarse_version = None, None, None, -1
+        self._scratch = {}
+        return out
+
     def _buf(self, name: str, numel: int, dtype) -> Tensor:
         t = self._scratch.get(name)
         if t is None or t.numel() < numel or t.device != self.occs.device:
@@ -92,8 +100,12 @@ class OccGridEstimator(nn.Module):
 
     def ensure_derived(self) -> None:
         """The derived state (coarse bitfield, cached mean) is current — called before every march."""
-        if self._occ_mean is None or (self._coarse is None and self.occs.is_cuda):
+        stale = (self._occ_mean is None or (self._coarse is None and self.occs.is_cuda) or
+                 (self._coarse is not None and self._coarse.device != self.occs.device) or
+                 getattr(self, "_derived_from", None) != (self.binaries.data_ptr(), self.occs.data_ptr()))
+        if stale:  # first use, or the buffers were re-homed / reassigned since the derived state was built
             self._refresh_derived()
+            self._derived_from = (self.binaries.data_ptr(), self.occs.data_ptr())
         elif self.occs.is_cuda and self._coarse_version != self.binaries._version:
             self._rebuild_coarse_from_binaries()  # the binaries were written by hand since the bitfield was built
 
@@ -137,6 +149,10 @@ class OccGridEstimator(nn.Module):
         half = (self.aabb[3:] - self.aabb[:3]) / 2 * (2.0 ** level_idx.float())[:, None]
         return (centre - half) + (u * 2) * half
 
+    def refreshes_at(self, step: int, n: int = 16) -> bool:
+        """`update_every_n_steps(step)` would refresh the grid (a caller that wants to time / account for the refreshes)."""
+        return bool(self.training and step % n == 0)
+
     @torch.no_grad()
     def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2, ema_decay: float = 0.95,
                              warmup_steps: int = 256, n: int = 16) -> None:
@@ -150,12 +166,20 @@ class OccGridEstimator(nn.Module):
         if step < warmup_steps:
             flat, num = None, total
         else:
-            k = total // 4
-            uniform = torch.randint(total, (k,), device=dev)
-            occupied = torch.nonzero(self.binaries.reshape(-1)).reshape(-1)
-            if occupied.numel() > k:
-                occupied = occupied[torch.randint(occupied.numel(), (k,), device=dev)]
-            flat = torch.cat([uniform, occupied])
+            # per LEVEL: cells_per_lvl // 4 uniform draws + at most as many of that level's occupied cells (nerfacc's
+            # `_sample_uniform_and_occupied_cells`; a pooled draw would let the level with the most occupied cells use up
+            # the occupied quota and refresh the coarse levels less often — ADVICE r03)
+            k = self.cells_per_lvl // 4
+            parts = []
+            flags = self.binaries.reshape(self.levels, -1)
+            for lvl in range(self.levels):
+                base = lvl * self.cells_per_lvl
+                parts.append(torch.randint(self.cells_per_lvl, (k,), device=dev) + base)
+                occupied = torch.nonzero(flags[lvl]).reshape(-1)
+                if occupied.numel() > k:
+                    occupied = occupied[torch.randint(occupied.numel(), (k,), device=dev)]
+                parts.append(occupied + base)
+            flat = torch.cat(parts)
             num = flat.numel()
         x = self._cell_positions(flat, num, torch.rand((num, 3), device=dev))
         occ = occ_eval_fn(x).reshape(-1).float()

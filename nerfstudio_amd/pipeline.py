@@ -1,0 +1,317 @@
+"""`HipPipeline`: the `nerfacto-hip` method's pipeline — the reference's `VanillaPipeline` with the training iteration on
+the captured kernel schedule (trainer.HipTrainer) and, for more than one rank, the arena's pipelined gradient exchange
+INSTEAD OF DistributedDataParallel.
+
+Reference seam (nothing of nerfstudio is edited):
+    Trainer.train_iteration (engine/trainer.py:487-531)
+        optimizers.zero_grad_some            -> `param.grad` is None throughout: the gradients live in the arena
+        pipeline.get_train_loss_dict(step)   -> THIS: datamanager.next_train -> static buffers -> ONE graph replay (forward,
+                                                losses, backward, fused Adam of the arena) -> loss / metrics dictionaries
+        loss.backward()                      -> a no-op node (the backward already ran inside the replay)
+        optimizers.optimizer_scaler_step_some-> finds no gradient and steps nothing (engine/optimizers.py:160-172)
+        optimizers.scheduler_step_all        -> the reference's schedulers keep computing the learning rates; the arena's
+                                                Adam reads them from the torch optimisers' `param_groups` every iteration
+    base_pipeline.py:279-282 wraps the model in DDP(find_unused_parameters=True) when world_size > 1; DDP never sees
+    gradients that kernels write into an arena, so this pipeline does not wrap: rank-local rays, replicated model,
+    dp_schedule.PipelinedExchange over arena.ParamArena (all-reduce of contiguous slices, pipelined across steps).
+
+The optimiser state is shared, not duplicated: `Optimizers.optimizers[group].state[p]` holds VIEWS of the arena's moments, so
+the reference's checkpoint code (engine/trainer.py:456-478) saves what the fused Adam produced, and a resumed run's
+`load_optimizers` state is copied into the arena before the first iteration.
+
+Anything the captured schedule does not cover (predict_normals, a non-Adam optimiser, weight decay, gradient clipping,
+gradient accumulation, mixed precision, RGBA targets over a random background, CPU tensors) takes the reference's own
+`get_train_loss_dict` body over the module path — with one rank; with more the pipeline refuses loudly, because neither DDP
+nor the arena would then reduce the gradients.
+
+nerfstudio itself is imported lazily (`pipeline_classes()`), as in plugin.py.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import torch
+
+_LOSS_KEYS = ("rgb_loss", "interlevel_loss", "distortion_loss")
+
+
+class _AlreadyBackpropagated(torch.autograd.Function):
+    """Loss values of an iteration whose backward (and optimiser step) already ran inside the replayed graph: the trainer's
+    `loss.backward()` (engine/trainer.py:515) finds a node and nothing to do."""
+
+    @staticmethod
+    def forward(ctx, anchor, *values):  # noqa: D102
+        return tuple(v.clone() for v in values)
+
+    @staticmethod
+    def backward(ctx, *grads):  # noqa: D102
+        return (None,) * (1 + len(grads))
+
+
+def unsupported_model_reason(model) -> Optional[str]:
+    """Configuration-level reasons the captured schedule cannot run this model (None: it can). use_gradient_scaling and
+    per-edge jitter are covered by the explicit schedule (train_step.py); the normals options are module path only."""
+    return "predict_normals" if getattr(model.config, "predict_normals", False) else None
+
+
+class TrainEngine:
+    """Owns the arena, the HipTrainer and the bookkeeping that ties them to a trainer's `Optimizers`."""
+
+    EAGER_ITERATIONS = 2
+
+    def __init__(self, pipeline, optimizers, trainer=None, runner_factory=None) -> None:
+        self.pipeline, self.optimizers, self.host_trainer = pipeline, optimizers, trainer
+        self.runner_factory = runner_factory  # tests: a CPU stand-in for train_step.NerfactoTrainStep
+        self.trainer = None  # trainer.HipTrainer, built on the first batch
+        self.arena = None
+        self.reason: Optional[str] = None
+        self._lr_hist: Dict[str, Dict[int, float]] = {}
+        self._anchor = None
+
+    # ---- what the reference's Optimizers say ---------------------------------------------------------------------------
+    def _optimizer_reason(self) -> Optional[str]:
+        groups = self.optimizers.optimizers
+        hyper = None
+        for name, opt in groups.items():
+            if type(opt) is not torch.optim.Adam:
+                return f"optimizer of '{name}' is {type(opt).__name__}, not torch.optim.Adam"
+            pg = opt.param_groups
+            if len(pg) != 1:
+                return f"'{name}' has {len(pg)} param_groups"
+            g = pg[0]
+            if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+                return f"'{name}': weight decay / amsgrad / maximize"
+            cfg = self.optimizers.config.get(name, {}).get("optimizer", None)
+            if getattr(cfg, "max_norm", None) is not None:
+                return f"'{name}': gradient clipping (max_norm)"
+            h = (tuple(g["betas"]), float(g["eps"]))
+            if hyper is not None and h != hyper:
+                return "optimiser groups with different betas / eps"
+            hyper = h
+        ht = self.host_trainer
+        if ht is not None:
+            if getattr(ht, "mixed_precision", False):
+                return "mixed precision"
+            gas = getattr(ht, "gradient_accumulation_steps", None)
+            if gas is not None and any(gas[k] != 1 for k in groups):
+                return "gradient accumulation"
+        return None
+
+    def _lr(self, group: str, iteration: int) -> float:
+        """Learning rate of `group` at `iteration`: what the reference's scheduler had set when that iteration ran (the
+        deferred main-field Adam of iteration k-1 runs inside iteration k)."""
+        hist = self._lr_hist.get(group, {})
+        if iteration in hist:
+            return hist[iteration]
+        return float(self.optimizers.optimizers[group].param_groups[0]["lr"])
+
+    def _record_lrs(self, step: int) -> None:
+        for name, opt in self.optimizers.optimizers.items():
+            hist = self._lr_hist.setdefault(name, {})
+            hist[step] = float(opt.param_groups[0]["lr"])
+            for old in [k for k in hist if k < step - 3]:
+                del hist[old]
+
+    # ---- construction on the first batch ---------------------------------------------------------------------------------
+    def build(self, ray_bundle, batch) -> Optional[str]:
+        from .arena import ParamArena
+        from .trainer import HipTrainer
+
+        model = self.pipeline.model
+        reason = unsupported_model_reason(model) or self._optimizer_reason()
+        o = ray_bundle.origins
+        if reason is None and not o.is_cuda and self.runner_factory is None:
+            reason = "rays on the CPU"
+        if reason is None and batch["image"].shape[-1] == 4 and model.config.background_color == "random":
+            reason = "RGBA targets over a random background"
+        if reason is not None:
+            self.reason = reason
+            return reason
+        params = self.optimizers.parameters
+        order = [g for g in ("fields", "proposal_networks", "camera_opt") if g in params]
+        extra = [g for g in params if g not in order]
+        if extra:
+            self.reason = f"parameter groups {extra} the schedule does not train"
+            return self.reason
+        first = self.optimizers.optimizers[order[0]].param_groups[0]
+        self.arena = arena = ParamArena({g: list(params[g]) for g in order}, lr=float(first["lr"]), betas=tuple(first["betas"]),
+                                        eps=float(first["eps"]), bind_grads=False)
+        if self.pipeline.world_size > 1:
+            arena.broadcast_params()  # what DDP does at wrap time
+        self._adopt_optimizer_state()
+        world = int(self.pipeline.world_size)
+        runner = self.runner_factory(model, o.reshape(-1, 3).shape[0], o.device) if self.runner_factory is not None else None
+        rb = ray_bundle.reshape(-1) if hasattr(ray_bundle, "reshape") and o.dim() > 2 else ray_bundle
+        flat = {"image": self._target(batch)}
+        self.trainer = HipTrainer(model, arena, rb, flat, world=world, use_graph=True, use_runner=True, pool=None,
+                                  lr_source=self._lr, drive_callbacks=False, runner=runner)
+        self._anchor = torch.zeros((), device=o.device, requires_grad=True)
+        return None
+
+    def _target(self, batch) -> torch.Tensor:
+        """RGB target of the loss; RGBA is blended with the renderer's background as models/nerfacto.py:377-381 does."""
+        model = self.pipeline.model
+        image = batch["image"].to(next(model.parameters()).device)
+        if image.shape[-1] == 4:
+            image = model.renderer_rgb.blend_background(image)
+        return image.reshape(-1, 3)
+
+    def _adopt_optimizer_state(self) -> None:
+        """torch.optim.Adam state <-> arena: moments a checkpoint loaded are copied in, then the state tensors become views of
+        the arena's moments, and `state_dict()` refreshes the step counters (and applies any pending update) first."""
+        arena = self.arena
+        for name, opt in self.optimizers.optimizers.items():
+            plist = opt.param_groups[0]["params"]
+            steps = 0
+            for p in plist:
+                off = next(o for q, o in zip(arena.params, arena.offsets) if q is p)
+                n = p.numel()
+                st = opt.state.get(p, None)
+                if st:  # resumed (engine/trainer.py:410-417 -> Optimizers.load_optimizers)
+                    arena.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                    arena.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps = max(steps, int(float(st["step"])))
+                opt.state[p] = {"step": torch.tensor(float(steps)),
+                                "exp_avg": arena.exp_avg[off:off + n].view(p.shape),
+                                "exp_avg_sq": arena.exp_avg_sq[off:off + n].view(p.shape)}
+            arena.step_counts[name] = steps
+            original = opt.state_dict
+
+            def state_dict(opt=opt, name=name, original=original):
+                self.flush()
+                for st in opt.state.values():
+                    st["step"].fill_(float(self.arena.step_counts[name]))
+                return original()
+
+            opt.state_dict = state_dict
+
+    # ---- per iteration ---------------------------------------------------------------------------------------------------
+    def flush(self) -> None:
+        """Apply a pending (deferred / pipelined) main-field update: call before anything reads the parameters."""
+        if self.trainer is not None:
+            self.trainer.finish()
+
+    def train_iteration(self, step: int, ray_bundle, batch):
+        if ray_bundle.origins.reshape(-1, 3).shape[0] != self.trainer.runner.n:
+            self.flush()  # a datamanager that changes its batch size: new static buffers, new graphs
+            self.build_trainer_only(ray_bundle, batch)
+        t = self.trainer
+        self._record_lrs(step)
+        t.step = step
+        # the first iterations run eagerly (they are the warm-up a capture needs, and every one of them is a real training
+        # iteration on its own batch); then the schedule variants are captured once and replayed from there on
+        self._eager_done = getattr(self, "_eager_done", 0)
+        if t.graphs is None and t.use_graph and self._eager_done >= self.EAGER_ITERATIONS and not getattr(t, "_capture_tried", False):
+            t._capture_tried = True
+            t.try_capture(warm=False)
+        self._eager_done += 1
+        t.set_batch(ray_bundle, {"image": self._target(batch)})
+        t.train_iteration()
+        r = t.runner
+        ld = r.loss_dict()
+        values = _AlreadyBackpropagated.apply(self._anchor, *(ld[k] for k in _LOSS_KEYS))
+        loss_dict = dict(zip(_LOSS_KEYS, values))
+        model = self.pipeline.model
+        if "camera_opt_regularizer" in ld:  # differentiated inside the iteration (train_step.backward_cameras)
+            loss_dict["camera_opt_regularizer"] = _AlreadyBackpropagated.apply(self._anchor, ld["camera_opt_regularizer"])[0]
+        outputs = r.outputs()
+        mse = torch.mean((outputs["rgb"].detach() - r.target) ** 2)
+        metrics = {"psnr": -10.0 * torch.log10(mse), "distortion": r.dist_per_ray.sum() / r.n}
+        cam = getattr(model, "camera_optimizer", None)
+        if cam is not None:
+            cam.get_metrics_dict(metrics)
+        return outputs, loss_dict, metrics
+
+    def build_trainer_only(self, ray_bundle, batch) -> None:
+        from .trainer import HipTrainer
+
+        o = ray_bundle.origins
+        model = self.pipeline.model
+        self._eager_done = 0
+        runner = self.runner_factory(model, o.reshape(-1, 3).shape[0], o.device) if self.runner_factory is not None else None
+        self.trainer = HipTrainer(model, self.arena, ray_bundle, {"image": self._target(batch)}, world=int(self.pipeline.world_size),
+                                  use_graph=True, use_runner=True, pool=None, lr_source=self._lr, drive_callbacks=False,
+                                  runner=runner)
+
+
+def pipeline_classes():
+    """(HipPipelineConfig, HipPipeline), built against the installed nerfstudio."""
+    from dataclasses import dataclass, field
+    from typing import Type
+
+    import torch.distributed as dist
+    from nerfstudio.pipelines.base_pipeline import Pipeline, VanillaPipeline, VanillaPipelineConfig
+
+    class HipPipeline(VanillaPipeline):
+        """VanillaPipeline (pipelines/base_pipeline.py:206-460) with the training iteration on trainer.HipTrainer."""
+
+        def __init__(self, config, device, test_mode="val", world_size=1, local_rank=0, grad_scaler=None):
+            # what VanillaPipeline.__init__ builds (:231-282) — datamanager for this rank, model on the device — WITHOUT the
+            # DistributedDataParallel wrapper: the arena's exchange reduces the gradients (module docstring)
+            Pipeline.__init__(self)
+            self.config, self.test_mode = config, test_mode
+            self.datamanager = config.datamanager.setup(device=device, test_mode=test_mode, world_size=world_size,
+                                                        local_rank=local_rank)
+            assert self.datamanager.train_dataset is not None, "Missing input dataset"
+            seed_pts = None
+            meta = getattr(getattr(self.datamanager, "train_dataparser_outputs", None), "metadata", None)
+            if meta is not None and "points3D_xyz" in meta:
+                seed_pts = (meta["points3D_xyz"], meta["points3D_rgb"])
+            ds = self.datamanager.train_dataset
+            self._model = config.model.setup(scene_box=ds.scene_box, num_train_data=len(ds), metadata=ds.metadata, device=device,
+                                             grad_scaler=grad_scaler, seed_points=seed_pts)
+            self.model.to(device)
+            self.world_size = world_size
+            self._engine: Optional[TrainEngine] = None
+            self._engine_off = not getattr(config, "graph_train_step", True) or unsupported_model_reason(self.model) is not None
+            if world_size > 1:
+                if self._engine_off:
+                    raise NotImplementedError(
+                        "nerfacto-hip with more than one rank trains through the captured schedule and the arena's gradient "
+                        f"exchange only; this configuration needs the module path ({unsupported_model_reason(self.model)})")
+                dist.barrier(device_ids=[local_rank] if torch.cuda.is_available() else None)
+
+        # -- the trainer hands over its Optimizers here (engine/trainer.py:196-204) ------------------------------------
+        def get_training_callbacks(self, training_callback_attributes):
+            opts = getattr(training_callback_attributes, "optimizers", None)
+            if opts is not None and not self._engine_off:
+                self._engine = TrainEngine(self, opts, getattr(training_callback_attributes, "trainer", None))
+            return super().get_training_callbacks(training_callback_attributes)
+
+        def get_train_loss_dict(self, step: int):
+            eng = self._engine
+            if eng is None or eng.reason is not None:
+                return self._module_path(step, *self.datamanager.next_train(step))
+            ray_bundle, batch = self.datamanager.next_train(step)
+            if eng.trainer is None and eng.build(ray_bundle, batch) is not None:
+                return self._module_path(step, ray_bundle, batch)
+            return eng.train_iteration(step, ray_bundle, batch)
+
+        def _module_path(self, step, ray_bundle, batch):
+            if self.world_size > 1:
+                raise NotImplementedError("nerfacto-hip with more than one rank: the captured schedule cannot run this setup "
+                                          f"({getattr(self._engine, 'reason', 'no optimizers were handed over')})")
+            model_outputs = self._model(ray_bundle)
+            metrics_dict = self.model.get_metrics_dict(model_outputs, batch)
+            loss_dict = self.model.get_loss_dict(model_outputs, batch, metrics_dict)
+            return model_outputs, loss_dict, metrics_dict
+
+        # -- every reader of the parameters first applies a pending update ------------------------------------------------
+        def train(self, mode: bool = True):
+            if not mode and getattr(self, "_engine", None) is not None:
+                self._engine.flush()
+            return super().train(mode)
+
+        def state_dict(self, *args, **kwargs):
+            if getattr(self, "_engine", None) is not None:
+                self._engine.flush()
+            return super().state_dict(*args, **kwargs)
+
+    @dataclass
+    class HipPipelineConfig(VanillaPipelineConfig):
+        _target: Type = field(default_factory=lambda: HipPipeline)
+        graph_train_step: bool = True
+        """Training iterations as replayed hipGraphs with the arena's fused Adam (nerfstudio_amd/trainer.py); False: the
+        module path under the trainer's own optimisers."""
+
+    return HipPipelineConfig, HipPipeline

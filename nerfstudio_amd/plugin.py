@@ -323,6 +323,13 @@ def nerfacto_hip():
     old = base.pipeline.model
     kwargs = {f.name: getattr(old, f.name) for f in dataclasses.fields(old) if f.name not in ("_target", "implementation")}
     base.pipeline.model = cfg_cls(**kwargs)
+    # the pipeline whose `get_train_loss_dict` replays the captured training iteration (pipeline.py): same fields as the
+    # reference's VanillaPipelineConfig (datamanager, model), another `_target`
+    from .pipeline import pipeline_classes
+
+    pipe_cls, _ = pipeline_classes()
+    old_pipe = base.pipeline
+    base.pipeline = pipe_cls(**{f.name: getattr(old_pipe, f.name) for f in dataclasses.fields(old_pipe) if f.name != "_target"})
     base.method_name = "nerfacto-hip"
     base.mixed_precision = False  # fp32 kernels: no autocast, no loss scaling
     return MethodSpecification(config=base, description=DESCRIPTION)

@@ -160,6 +160,10 @@ class NerfactoTrainStep:
             self._corrected = None
             self.camera_reg = torch.zeros((), **f32)
         self.reg_in_backward = True  # backward_cameras also differentiates the pose regulariser
+        # True: `backward_join` leaves the camera optimiser's share to the caller (`backward_cameras(updated, force=True)`
+        # after a replayed graph: the exponential map's autograd graph is host-side torch and stays out of the capture)
+        self.cameras_outside = False
+        self.grad_lookup = None  # {id(parameter): gradient buffer} of an arena that does not bind `param.grad`
         self.main_table_write_only = True  # the main table's gradient is written, not accumulated (written_params)
         # True: backward_field_and_table leaves the table scatter to the caller (`backward_table`): bench.py's deferred
         # schedule runs it beside the NEXT iteration's proposal forward, from the copies `shadow_points` took
@@ -198,6 +202,10 @@ class NerfactoTrainStep:
                     prm.grad = torch.empty_like(prm) if prm is table else torch.zeros_like(prm)
 
     def _grad(self, p: Tensor) -> Tensor:
+        if self.grad_lookup is not None:  # an arena that keeps `param.grad` unset (arena.ParamArena(bind_grads=False))
+            g = self.grad_lookup.get(id(p))
+            if g is not None:
+                return g
         assert p.grad is not None and p.grad.is_contiguous(), "parameters need preallocated .grad (use arena.ParamArena)"
         return p.grad
 
@@ -307,10 +315,10 @@ class NerfactoTrainStep:
             "hashgrid_encode_bwd_rays")
 
     @profiler.time_function
-    def backward_cameras(self, updated: bool) -> None:
+    def backward_cameras(self, updated: bool, force: bool = False) -> None:
         """Per-ray gradients of every level that received one -> `pose_adjustment.grad` (plus the L2 regulariser of
         camera_optimizers.py:179-185, whose value is kept in `camera_reg`). Call after the backward chains have joined."""
-        if self.cam_opt is None:
+        if self.cam_opt is None or (self.cameras_outside and not force):
             return
         L = self.n_prop
         d_o, d_d = self.d_origins[L], self.d_directions[L]
@@ -318,13 +326,21 @@ class NerfactoTrainStep:
             d_o = d_o + sum(self.d_origins[:L])
             d_d = d_d + sum(self.d_directions[:L])
         o, d = self._corrected
+        outs, ups = [o, d], [d_o, d_d]
         if self.reg_in_backward:
             reg = {}
             self.cam_opt.get_loss_dict(reg)
             self.camera_reg = reg["camera_opt_regularizer"].detach()
-            torch.autograd.backward([o, d, reg["camera_opt_regularizer"]], [d_o, d_d, torch.ones_like(self.camera_reg)])
-        else:  # the caller differentiates the regulariser itself (fused_step.FusedTrainStep)
-            torch.autograd.backward([o, d], [d_o, d_d])
+            outs.append(reg["camera_opt_regularizer"])
+            ups.append(torch.ones_like(self.camera_reg))
+        # (else: the caller differentiates the regulariser itself — fused_step.FusedTrainStep)
+        pose = [p for p in self.cam_opt.parameters() if p.requires_grad]
+        if self.grad_lookup is not None and all(id(p) in self.grad_lookup for p in pose):
+            for p, g in zip(pose, torch.autograd.grad(outs, pose, ups, allow_unused=True)):
+                if g is not None:
+                    self.grad_lookup[id(p)].add_(g)
+        else:
+            torch.autograd.backward(outs, ups)
         self._corrected = None
 
     @profiler.time_function

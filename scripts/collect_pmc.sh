@@ -10,8 +10,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 export OUT=$R/gpurun_out/${1:-final}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout ${PMC_STATS_TIMEOUT:-600} rocprofv3 --kernel-trace --stats -d /tmp/kstats -o k -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 1 > $OUT/rocprof_bench.log 2>&1
-CMD="python $R/bench.py --steps 3 --warmup 3 --no-graph --no-cpu-baseline --profile-steps 1 --fixed-batch"
+timeout ${PMC_STATS_TIMEOUT:-600} rocprofv3 --kernel-trace --stats -d /tmp/kstats -o k -- python $R/bench.py --steps 20 --warmup 5 --windows 1 --long-steps 0 --no-cpu-baseline --profile-steps 1 > $OUT/rocprof_bench.log 2>&1
+CMD="python $R/bench.py --steps 3 --warmup 3 --windows 1 --long-steps 0 --no-graph --no-cpu-baseline --profile-steps 1 --fixed-batch"
 export NSAMD_SIDE_STREAM=0
 timeout ${PMC_PASS_TIMEOUT:-600} rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_INST_LDS --output-format csv -d /tmp/pmc_sq -o sq -- $CMD > $OUT/pmc_sq.log 2>&1
 timeout ${PMC_PASS_TIMEOUT:-600} rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fetch -o f -- $CMD > $OUT/pmc_fetch.log 2>&1
@@ -83,8 +83,8 @@ for key, parts in groups.items():
                     "hbm_bytes": fetch_cal + write, "kernels": found}
 import sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-import bench  # kernel_sources_hash(): bench.py reports a traffic figure only when it was measured on these very sources
-traffic["_kernel_sources_sha256_16"] = bench.kernel_sources_hash()
+from nerfstudio_amd.utils import roofline  # bench.py reports a traffic figure only when it was measured on these very sources
+traffic["_kernel_sources_sha256_16"] = roofline.kernel_sources_hash()
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 PY

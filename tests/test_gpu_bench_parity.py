@@ -1,6 +1,7 @@
 """Parity at the BENCHMARK's own size, through the BENCHMARK's own path.
 
-bench.py measures `bench.Trainer`: the explicit kernel schedule (train_step.NerfactoTrainStep) captured in hipGraphs — four
+bench.py measures `nerfstudio_amd.trainer.HipTrainer` (the object the `nerfacto-hip` pipeline drives under the reference's own
+trainer): the explicit kernel schedule (train_step.NerfactoTrainStep) captured in hipGraphs — four
 variants, proposal update x pending main-field Adam — at 4096 rays x (256, 96, 48) samples, T = 2^19 / 2^17, 100 cameras,
 ray batches selected out of the HBM-resident pool by a device-side slot index. The small fixtures do not reach the parts of
 that path that depend on M and T (the scatter's per-level queue capacities, the 8x coarse queues, the spill path, the
@@ -37,17 +38,18 @@ def F():
 
 
 def _bench_trainer(F, params, cfg, use_graph, seed=1000):
-    """bench.py's own objects: model (oracle parameters loaded), arena, ray pool, Trainer."""
+    """bench.py's own workload (model with the oracle's parameters loaded, arena, ray pool) on the product's trainer."""
     import bench
     from test_gpu_kernels import _hip_model
 
     from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.trainer import HipTrainer
 
     dev = torch.device("cuda")
     model = _hip_model(cfg, params)
     arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
     rb, batch, pool = bench.synthetic_batch(dev, seed=seed)
-    trainer = bench.Trainer(model, arena, rb, batch, world=1, use_graph=use_graph, use_runner=True, pool=pool)
+    trainer = HipTrainer(model, arena, rb, batch, world=1, use_graph=use_graph, use_runner=True, pool=pool)
     trainer.draw_jitter = False  # the jitter buffer is filled by the test (the oracle gets the same draws)
     return bench, model, arena, trainer
 
