@@ -59,9 +59,10 @@ class TrainEngine:
 
     EAGER_ITERATIONS = 2
 
-    def __init__(self, pipeline, optimizers, trainer=None, runner_factory=None) -> None:
+    def __init__(self, pipeline, optimizers, trainer=None, runner_factory=None, on_build=None) -> None:
         self.pipeline, self.optimizers, self.host_trainer = pipeline, optimizers, trainer
         self.runner_factory = runner_factory  # tests: a CPU stand-in for train_step.NerfactoTrainStep
+        self.on_build = on_build  # tests: called with the HipTrainer right after it was built (inject jitter draws)
         self.trainer = None  # trainer.HipTrainer, built on the first batch
         self.arena = None
         self.reason: Optional[str] = None
@@ -115,7 +116,6 @@ class TrainEngine:
     # ---- construction on the first batch ---------------------------------------------------------------------------------
     def build(self, ray_bundle, batch) -> Optional[str]:
         from .arena import ParamArena
-        from .trainer import HipTrainer
 
         model = self.pipeline.model
         reason = unsupported_model_reason(model) or self._optimizer_reason()
@@ -139,13 +139,8 @@ class TrainEngine:
         if self.pipeline.world_size > 1:
             arena.broadcast_params()  # what DDP does at wrap time
         self._adopt_optimizer_state()
-        world = int(self.pipeline.world_size)
-        runner = self.runner_factory(model, o.reshape(-1, 3).shape[0], o.device) if self.runner_factory is not None else None
-        rb = ray_bundle.reshape(-1) if hasattr(ray_bundle, "reshape") and o.dim() > 2 else ray_bundle
-        flat = {"image": self._target(batch)}
-        self.trainer = HipTrainer(model, arena, rb, flat, world=world, use_graph=True, use_runner=True, pool=None,
-                                  lr_source=self._lr, drive_callbacks=False, runner=runner)
         self._anchor = torch.zeros((), device=o.device, requires_grad=True)
+        self.build_trainer_only(ray_bundle, batch)
         return None
 
     def _target(self, batch) -> torch.Tensor:
@@ -223,15 +218,56 @@ class TrainEngine:
         return outputs, loss_dict, metrics
 
     def build_trainer_only(self, ray_bundle, batch) -> None:
+        """Static buffers + schedule for batches of this many rays (the arena and the optimiser state stay)."""
         from .trainer import HipTrainer
 
-        o = ray_bundle.origins
+        o = ray_bundle.origins.reshape(-1, 3)
         model = self.pipeline.model
         self._eager_done = 0
-        runner = self.runner_factory(model, o.reshape(-1, 3).shape[0], o.device) if self.runner_factory is not None else None
-        self.trainer = HipTrainer(model, self.arena, ray_bundle, {"image": self._target(batch)}, world=int(self.pipeline.world_size),
+        runner = self.runner_factory(model, o.shape[0], o.device) if self.runner_factory is not None else None
+        rb = ray_bundle.reshape(-1) if ray_bundle.origins.dim() > 2 else ray_bundle
+        self.trainer = HipTrainer(model, self.arena, rb, {"image": self._target(batch)}, world=int(self.pipeline.world_size),
                                   use_graph=True, use_runner=True, pool=None, lr_source=self._lr, drive_callbacks=False,
                                   runner=runner)
+        if self.on_build is not None:
+            self.on_build(self.trainer)
+
+
+class EngineSeam:
+    """What HipPipeline adds to VanillaPipeline, free of nerfstudio imports (the GPU tests compose it with a stand-in
+    pipeline where the reference is absent). Expects `self.datamanager`, `self.model`, `self._model`, `self.world_size`."""
+
+    _engine: Optional[TrainEngine] = None
+    _engine_off: bool = False
+
+    def attach_optimizers(self, optimizers, trainer=None, **engine_kwargs) -> None:
+        """The trainer's `Optimizers` (engine/trainer.py:196-204 hands them to `get_training_callbacks`)."""
+        if optimizers is not None and not self._engine_off:
+            self._engine = TrainEngine(self, optimizers, trainer, **engine_kwargs)
+
+    def get_train_loss_dict(self, step: int):
+        eng = self._engine
+        if eng is None or eng.reason is not None:
+            return self._module_path(step, *self.datamanager.next_train(step))
+        ray_bundle, batch = self.datamanager.next_train(step)
+        if eng.trainer is None and eng.build(ray_bundle, batch) is not None:
+            return self._module_path(step, ray_bundle, batch)
+        return eng.train_iteration(step, ray_bundle, batch)
+
+    def _module_path(self, step, ray_bundle, batch):
+        """The reference's own body (pipelines/base_pipeline.py:290-303) over the module path — one rank only."""
+        if self.world_size > 1:
+            raise NotImplementedError("nerfacto-hip with more than one rank: the captured schedule cannot run this setup "
+                                      f"({getattr(self._engine, 'reason', None) or 'no optimizers were handed over'})")
+        model_outputs = self._model(ray_bundle)
+        metrics_dict = self.model.get_metrics_dict(model_outputs, batch)
+        loss_dict = self.model.get_loss_dict(model_outputs, batch, metrics_dict)
+        return model_outputs, loss_dict, metrics_dict
+
+    def flush_engine(self) -> None:
+        """Every reader of the parameters (evaluation, checkpoint) first applies a pending update."""
+        if self._engine is not None:
+            self._engine.flush()
 
 
 def pipeline_classes():
@@ -242,7 +278,7 @@ def pipeline_classes():
     import torch.distributed as dist
     from nerfstudio.pipelines.base_pipeline import Pipeline, VanillaPipeline, VanillaPipelineConfig
 
-    class HipPipeline(VanillaPipeline):
+    class HipPipeline(EngineSeam, VanillaPipeline):
         """VanillaPipeline (pipelines/base_pipeline.py:206-460) with the training iteration on trainer.HipTrainer."""
 
         def __init__(self, config, device, test_mode="val", world_size=1, local_rank=0, grad_scaler=None):
@@ -262,7 +298,7 @@ def pipeline_classes():
                                              grad_scaler=grad_scaler, seed_points=seed_pts)
             self.model.to(device)
             self.world_size = world_size
-            self._engine: Optional[TrainEngine] = None
+            self._engine = None
             self._engine_off = not getattr(config, "graph_train_step", True) or unsupported_model_reason(self.model) is not None
             if world_size > 1:
                 if self._engine_off:
@@ -271,40 +307,18 @@ def pipeline_classes():
                         f"exchange only; this configuration needs the module path ({unsupported_model_reason(self.model)})")
                 dist.barrier(device_ids=[local_rank] if torch.cuda.is_available() else None)
 
-        # -- the trainer hands over its Optimizers here (engine/trainer.py:196-204) ------------------------------------
         def get_training_callbacks(self, training_callback_attributes):
-            opts = getattr(training_callback_attributes, "optimizers", None)
-            if opts is not None and not self._engine_off:
-                self._engine = TrainEngine(self, opts, getattr(training_callback_attributes, "trainer", None))
+            self.attach_optimizers(getattr(training_callback_attributes, "optimizers", None),
+                                   getattr(training_callback_attributes, "trainer", None))
             return super().get_training_callbacks(training_callback_attributes)
 
-        def get_train_loss_dict(self, step: int):
-            eng = self._engine
-            if eng is None or eng.reason is not None:
-                return self._module_path(step, *self.datamanager.next_train(step))
-            ray_bundle, batch = self.datamanager.next_train(step)
-            if eng.trainer is None and eng.build(ray_bundle, batch) is not None:
-                return self._module_path(step, ray_bundle, batch)
-            return eng.train_iteration(step, ray_bundle, batch)
-
-        def _module_path(self, step, ray_bundle, batch):
-            if self.world_size > 1:
-                raise NotImplementedError("nerfacto-hip with more than one rank: the captured schedule cannot run this setup "
-                                          f"({getattr(self._engine, 'reason', 'no optimizers were handed over')})")
-            model_outputs = self._model(ray_bundle)
-            metrics_dict = self.model.get_metrics_dict(model_outputs, batch)
-            loss_dict = self.model.get_loss_dict(model_outputs, batch, metrics_dict)
-            return model_outputs, loss_dict, metrics_dict
-
-        # -- every reader of the parameters first applies a pending update ------------------------------------------------
-        def train(self, mode: bool = True):
-            if not mode and getattr(self, "_engine", None) is not None:
-                self._engine.flush()
+        def train(self, mode: bool = True):  # every evaluation entry point starts with `self.eval()` (:305-460)
+            if not mode:
+                self.flush_engine()
             return super().train(mode)
 
-        def state_dict(self, *args, **kwargs):
-            if getattr(self, "_engine", None) is not None:
-                self._engine.flush()
+        def state_dict(self, *args, **kwargs):  # engine/trainer.py:456-478 save_checkpoint
+            self.flush_engine()
             return super().state_dict(*args, **kwargs)
 
     @dataclass

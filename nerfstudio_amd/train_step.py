@@ -330,7 +330,8 @@ class NerfactoTrainStep:
         if self.reg_in_backward:
             reg = {}
             self.cam_opt.get_loss_dict(reg)
-            self.camera_reg = reg["camera_opt_regularizer"].detach()
+            # a STATIC buffer: every captured schedule variant must leave the value where `loss_dict` reads it
+            self.camera_reg.copy_(reg["camera_opt_regularizer"].detach())
             outs.append(reg["camera_opt_regularizer"])
             ups.append(torch.ones_like(self.camera_reg))
         # (else: the caller differentiates the regulariser itself — fused_step.FusedTrainStep)

@@ -29,10 +29,12 @@ forward of step k+1 reads only proposal-network parameters, so
 hides the exchange behind the proposal backward of step k AND the proposal forward of step k+1, with exactly the sequential
 semantics (every parameter is updated before its next use).
 
-Camera optimiser on (models/nerfacto.py:131, the reference's nerfacto default): the [num_cameras, 6] exponential map is a
-dozen host-side torch ops with an autograd graph, so it stays OUTSIDE the captured graphs — batch selection and pose
-corrections before the replay, the rays' share of `pose_adjustment.grad` and the group's Adam after it; the kernels inside
-the graph read the corrected rays and leave dL/d(origins, directions) per ray.
+Camera optimiser on (models/nerfacto.py:131, the reference's nerfacto default): the [num_cameras, 6] exponential map and its
+autograd backward are ~100 tiny torch kernels. N = 1: they are captured with everything else (a whole-iteration capture holds
+forward, autograd backward and optimiser alike) — launched eagerly around the replay they made the step host-bound (1.80 ms
+against 0.76, profiles/r04_camera_optimizer.txt). N > 1 (eager segments) or NSAMD_CAMERAS_OUTSIDE=1: batch selection and pose
+corrections before the segments, the rays' share of `pose_adjustment.grad`, the group's exchange and Adam after them; the
+kernels read the corrected rays and leave dL/d(origins, directions) per ray either way.
 """
 from __future__ import annotations
 
@@ -109,6 +111,7 @@ class HipTrainer:
         self.draw_jitter = True
         self._pending_main = False  # deferred schedule: the main-field Adam of the previous iteration is still to run
         self.cam_group = "camera_opt" if "camera_opt" in arena.groups else None
+        self.cam_inside = False  # the camera optimiser's torch ops and Adam are part of the (captured) iteration body
         if use_runner or runner is not None:  # explicit kernel schedule over static buffers (train_step.py); default
             if self.runner is None:
                 from .train_step import NerfactoTrainStep
@@ -118,7 +121,9 @@ class HipTrainer:
             r.grad_lookup = arena.grad_lookup()
             r.set_batch(ray_bundle.origins, ray_bundle.directions, ray_bundle.camera_indices, batch["image"])
             r.anneal_dev = self.hyper[_HYPER_ANNEAL:_HYPER_ANNEAL + 1]
-            r.cameras_outside = getattr(r, "cam_opt", None) is not None  # see the module docstring
+            cam_on = getattr(r, "cam_opt", None) is not None
+            self.cam_inside = cam_on and self.cam_group is not None and not self.dp and os.environ.get("NSAMD_CAMERAS_OUTSIDE", "0") != "1"
+            r.cameras_outside = cam_on and not self.cam_inside  # see the module docstring
             if os.environ.get("NSAMD_SIDE_STREAM", "1") == "0":  # A/B switch: proposal backward on the main stream
                 r.side_stream = None
             # N = 1: the main-field Adam of iteration k (470 MB of HBM streaming) runs BESIDE the proposal forward of
@@ -227,6 +232,8 @@ class HipTrainer:
     def _zero(self, updated, groups=None):
         if groups is None:
             groups = ["fields", "proposal_networks"] if updated else ["fields"]
+            if self.cam_inside:
+                groups = groups + [self.cam_group]
         self.arena.zero_grad(groups, skip=self.runner.written_params())
 
     def _deferred_iteration_body(self, updated, pending):
@@ -276,8 +283,9 @@ class HipTrainer:
             r.defer_table = False
         if self.defer_scatter and self.opt_parallel:
             main.wait_event(self._sh_join)
-        if updated:
-            a.step(grad_scale=1.0, groups=["proposal_networks"], hyper_dev=self.hyper_views)
+        late = (["proposal_networks"] if updated else []) + ([self.cam_group] if self.cam_inside else [])
+        if late:
+            a.step(grad_scale=1.0, groups=late, hyper_dev=self.hyper_views)
 
     def _select_batch(self):
         """This step's rays out of the HBM-resident pool (slot index in device memory: replayable) — the hand-over the
@@ -300,7 +308,7 @@ class HipTrainer:
 
     def _optimise(self, updated):
         # the reference steps an optimiser group only when it received gradients (engine/optimizers.py:160-172)
-        groups = ["fields", "proposal_networks"] if updated else ["fields"]
+        groups = (["fields", "proposal_networks"] if updated else ["fields"]) + ([self.cam_group] if self.cam_inside else [])
         self.arena.step(grad_scale=1.0 / self.world, groups=groups, hyper_dev=self.hyper_views)
 
     # -- camera optimiser: the host-side halves around the captured part ---------------------------------------------------
@@ -535,6 +543,8 @@ class HipTrainer:
             else:
                 self.graphs[("all", updated)].replay()
                 stepped = ("fields", "proposal_networks") if updated else ("fields",)
+            if self.cam_inside:
+                stepped = stepped + (self.cam_group,)
             for name in stepped:
                 self.arena.step_counts[name] += 1  # the replayed Adam launches did step these groups
             if self._cams_outside:

@@ -457,3 +457,104 @@ def test_occupancy_grid_refresh_kernels_equal_the_torch_path(F):
     # and the public entry point runs end to end on the device
     g_gpu.update_every_n_steps(step=288, occ_eval_fn=lambda x: blob(x).cuda())
     assert g_gpu._coarse is not None and g_gpu._coarse_version == g_gpu.binaries._version
+
+
+def test_ngp_bench_size_parity_vs_oracle(F):
+    """BASELINE configs[3] at the BENCHMARK's own size, through the benchmark's own objects (scripts/bench_ngp.build_ngp:
+    128^3 x 4 occupancy grid, 4096 rays, T = 2^19, the lifted synthetic field) — what tests/test_gpu_bench_parity.py is to
+    the nerfacto line. One iteration of ngp_step.NgpTrainStep with injected lattice offsets and background draws:
+      * the candidates of the first 192 rays bit-exact against the marcher restatement (the numpy marcher walks step by step);
+      * the visibility mask bit-exact against the oracle's scan over the kernels' own candidate densities;
+      * rgb / accumulation <= 1e-4 L-inf, the loss, and EVERY field gradient (the table per level) against the oracle
+        evaluated on the kernels' own packed samples — bounded by 4 x the fp32 reference's own distance from a float64
+        evaluation of the same graph (floor 5e-4), as on the nerfacto line;
+      * the occupancy refresh of the training iteration runs on this state and (with the bench's hook) leaves the grid as it was."""
+    import bench
+    from scripts.bench_ngp import build_ngp
+
+    dev_ = torch.device("cuda")
+    F._SCATTER_WS.clear()
+    model, arena, tr, (o, d, cam, tgt) = build_ngp(dev_, bench.synthetic_rays)
+    cfg, grid, r, n = model.config, model.occupancy_grid, tr.runner, bench.RAYS_PER_GPU
+    assert tuple(grid.binaries.shape) == (4, 128, 128, 128) and model.field.mlp_base.encoding.spec.log2_hashmap_size == 19
+    before = grid.binaries.clone()
+    tr.update_occupancy_grid(512)  # a refresh step of the schedule: 2.5 M cell densities, decayed maximum, threshold, bitfield
+    assert len(tr.refreshes) == 1 and torch.equal(grid.binaries, before)
+    rs = np.random.RandomState(17)
+    jit = torch.from_numpy(rs.uniform(0, 1, n).astype(np.float32)).cuda()
+    bg = torch.from_numpy(rs.uniform(0, 1, (n, 3)).astype(np.float32))
+    arena.zero_grad(skip=[tr.table])
+    r.forward(jit)
+    loss = r.loss(background=bg.cuda())
+    r.backward()
+    torch.cuda.synchronize()
+    mc, mk = r.num_candidates, r.num_kept
+    assert mc > 20 * n and 10 * n < mk < mc
+    # ---- marcher: the first rays' candidates, integers and bin edges bit for bit
+    sub = 192
+    B = grid.binaries.cpu().numpy().astype(bool)
+    ref = po.occgrid_march(o[:sub], d[:sub], B, ROI, cfg.render_step_size, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
+                           cone_angle=cfg.cone_angle, jitter=jit[:sub].cpu().numpy())
+    info = r.info.cpu().numpy()
+    m_sub = int(info[sub - 1, 0] + info[sub - 1, 1])
+    np.testing.assert_array_equal(r.c_ri[:m_sub].cpu().numpy(), ref[0])
+    np.testing.assert_array_equal(r.c_ts[:m_sub].cpu().numpy(), ref[1])
+    np.testing.assert_array_equal(r.c_te[:m_sub].cpu().numpy(), ref[2])
+    # ---- visibility scan + early termination on the kernels' own candidate densities
+    c_ri, c_ts, c_te, c_sigma = (t[:mc].cpu() for t in (r.c_ri, r.c_ts, r.c_te, r.c_sigma))
+    alpha = min(float(cfg.alpha_thre), float(grid._occ_mean))
+    keep = po.render_visibility_from_density(c_ts, c_te, c_sigma, c_ri, n, 1e-4, alpha)
+    assert int(keep.sum()) == mk and torch.equal(keep, r.c_mask[:mc].cpu().bool())
+    # ---- the field, packed weights and compositing on the kernels' kept samples
+    idx, ts, te = r.k_ri[:mk].cpu(), r.k_ts[:mk].cpu(), r.k_te[:mk].cpu()
+    assert torch.equal(idx, c_ri[keep]) and torch.equal(ts, c_ts[keep])
+    ocfg = orc.NerfactoCfg(prop_grids=(), num_images=100, average_init_density=1.0)
+    keys = [k for k in orc.init_params(ocfg, seed=0) if k.startswith("field.")]
+    sd = model.state_dict()
+    base = {k: sd[k].detach().cpu().clone() for k in keys}
+    to, td, tcam, ttgt = (torch.from_numpy(a) for a in (o, d, cam[:, 0], tgt))
+
+    def oracle(dtype):
+        prm = {k: v.to(dtype).clone().requires_grad_(True) for k, v in base.items()}
+        t0, t1 = ts.to(dtype), te.to(dtype)
+        pos = to.to(dtype)[idx] + td.to(dtype)[idx] * ((t0 + t1) / 2)[:, None]
+        dens, rgb_s, _ = orc.nerfacto_field(pos, td.to(dtype)[idx], tcam[idx], prm, ocfg, training=True)
+        w = po.render_weight_from_density(t0, t1, dens, idx, n)[0]
+        comp, acc, dep = po.composite_packed(rgb_s, w, t0, t1, idx, n, background="random", training=True)
+        pred = comp + bg.to(dtype) * (1.0 - acc)
+        val = torch.mean((pred - ttgt.to(dtype)) ** 2)
+        val.backward()
+        return prm, comp.detach(), acc.detach(), val.detach()
+
+    p32, comp, acc, val = oracle(torch.float32)
+    p64, _, _, _ = oracle(torch.float64)
+    rgb_err = float((r.rgb.cpu() - comp).abs().max())
+    acc_err = float((r.acc.cpu() - acc[:, 0]).abs().max())
+    assert rgb_err <= 1e-4 and acc_err <= 1e-4, (rgb_err, acc_err)       # north_star: 1e-4 RGB L-inf
+    np.testing.assert_allclose(float(loss), float(val), rtol=2e-5)
+    named = dict(model.named_parameters())
+    worst = ("", 0.0, 0.0)
+    T = 1 << 19
+
+    def rel(a, b):
+        return float(np.linalg.norm(a - b) / max(1e-30, np.linalg.norm(b)))
+
+    for k in keys:
+        got = named[k].grad.detach().cpu().numpy().astype(np.float64)
+        g32, g64 = p32[k].grad.numpy().astype(np.float64), p64[k].grad.numpy()
+        parts = [(k, got, g32, g64)]
+        if k.endswith("hash_table"):  # the main table level by level (its levels differ by orders of magnitude)
+            parts = [(f"{k}[L{l}]", got[l * T:(l + 1) * T], g32[l * T:(l + 1) * T], g64[l * T:(l + 1) * T]) for l in range(16)]
+        for name, a, b32, b64 in parts:
+            if np.linalg.norm(b64) == 0:
+                assert np.linalg.norm(a) == 0, name
+                continue
+            e_gpu, e_ref = rel(a, b64), rel(b32, b64)
+            assert e_gpu <= 4 * max(e_ref, 5e-4), f"{name}: |gpu - f64| = {e_gpu:.2e}, |ref32 - f64| = {e_ref:.2e}"
+            if e_gpu > worst[1]:
+                worst = (name, e_gpu, e_ref)
+    for ws in F._SCATTER_WS.values():
+        ev = F.scatter_events(ws)
+        assert ev[1] == 0 and ev[2] == 0, f"scatter records on an unordered path / lost: {ev}"
+    print(f"\nngp bench-size parity: {mc} candidates, {mk} kept; rgb L-inf {rgb_err:.2e}, acc {acc_err:.2e}, loss {float(loss):.6f}; "
+          f"worst gradient {worst[0]}: (gpu-f64, ref32-f64) rel-L2 = ({worst[1]:.2e}, {worst[2]:.2e}); refresh {tr.refreshes[0]:.2f} ms")

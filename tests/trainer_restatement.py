@@ -66,7 +66,10 @@ def train_iteration(trainer, step: int):
     trainer.optimizers.zero_grad_some(needs_zero)
     device_type = trainer.device.split(":")[0]
     with torch.autocast(device_type=device_type, enabled=trainer.mixed_precision):
-        _, loss_dict, metrics_dict = get_train_loss_dict(trainer.pipeline, step)
+        # `self.pipeline.get_train_loss_dict(step=step)`: the pipeline's own method when it has one (a pipeline that overrides
+        # it — nerfstudio_amd.pipeline.EngineSeam — must be reached), else the restated VanillaPipeline body
+        own = getattr(trainer.pipeline, "get_train_loss_dict", None)
+        _, loss_dict, metrics_dict = own(step=step) if own is not None else get_train_loss_dict(trainer.pipeline, step)
         loss = functools.reduce(torch.add, loss_dict.values())
     trainer.grad_scaler.scale(loss).backward()
     needs_step = [g for g in trainer.optimizers.parameters.keys()
