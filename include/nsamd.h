@@ -261,6 +261,26 @@ int nsamd_field_mlp_bwd(const float* enc, const float* selector, const float* di
                         nsamd_field_mlp_grads grads, float* workspace, int64_t workspace_floats,
                         nsamd_stream_t stream);
 
+/* nsamd_field_mlp_bwd + nsamd_hashgrid_encode_bwd_set in one: the backward of the main field INCLUDING its hash table's
+ * gradient (the backward of HashEncoding.pytorch_fwd, field_components/encodings.py:417-458, of the features this field
+ * was evaluated on). The data gradient of base layer 0 is the encoded-feature gradient, and the persistent workgroups of
+ * the MLP kernel emit the scatter's pass-1 records from their registers — one static queue segment per (workgroup, table
+ * tile), slot = LDS rank — instead of storing `denc`, launching the route pass and having it load the gradients again and
+ * recompute every cell. The order-independent fixed-point apply pass of the scatter follows unchanged, so the table
+ * gradient is what nsamd_hashgrid_encode_bwd_set(denc) writes up to the position of the fixed-point truncation
+ * (deterministic, run-to-run bit-identical; `dtable` [L*T,2] is WRITTEN, no zero-fill needed).
+ * pts / transform / aabb / grid: the points and grid `enc` was encoded with (nsamd_hashgrid_encode_fwd); 16 levels.
+ * denc: NULL, or feature-major [32,M] when the caller wants the feature gradient as well (camera optimiser).
+ * scatter_workspace: nsamd_field_mlp_bwd_scatter_workspace(grid, M, &state) floats, the first `state` of them zero
+ * before the first call (the kernels leave them zero). Returns NSAMD_ERR_UNSUPPORTED for other level counts. */
+int64_t nsamd_field_mlp_bwd_scatter_workspace(nsamd_grid grid, int64_t M, int64_t* state_words);
+int nsamd_field_mlp_bwd_scatter(nsamd_points pts, int transform, nsamd_aabb aabb, nsamd_grid grid, const float* enc,
+                                const float* selector, const float* directions, const int64_t* camera_indices,
+                                const float* appearance_const, int64_t dir_group, int64_t M, nsamd_field_mlp mlp,
+                                const float* ddensity, const float* drgb, float* denc, nsamd_field_mlp_grads grads,
+                                float* workspace, int64_t workspace_floats, float* dtable, float* scatter_workspace,
+                                int64_t scatter_workspace_floats, nsamd_stream_t stream);
+
 /* nsamd_field_mlp_bwd in two launches, so that a caller can put the second on another stream: phase 1 = the gradient
  * kernel (denc + the per-workgroup weight-gradient partials in `workspace`, which is REQUIRED here), phase 2 = the
  * fixed-order sum of the partials into `grads` (needs nothing but workspace, grads, camera_indices and the sizes). Phase 2

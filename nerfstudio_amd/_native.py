@@ -78,6 +78,9 @@ _SIGNATURES = {
     "nsamd_density_mlp_bwd_gated": [vp, vp, vp, vp, i64, DensityMlp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp],
     "nsamd_field_mlp_fwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp],
     "nsamd_field_mlp_bwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp, i64, vp],
+    "nsamd_field_mlp_bwd_scatter": [Points, C.c_int, Aabb, Grid, vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp,
+                                    i64, vp, vp, i64, vp],
+    "nsamd_field_mlp_bwd_scatter_workspace": [Grid, i64, C.POINTER(C.c_int64)],
     "nsamd_field_fused_fwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, vp, vp, i64, FieldMlp, vp, vp, vp, vp, vp],
     "nsamd_field_mlp_saved_floats": [i64],
     "nsamd_field_mlp_fwd_save": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, vp],
@@ -127,6 +130,7 @@ _SIGNATURES = {
 }
 _RESTYPES = {"nsamd_version": C.c_char_p, "nsamd_status_string": C.c_char_p,
              "nsamd_hashgrid_encode_bwd_workspace": C.c_int64, "nsamd_hashgrid_encode_bwd_workspace_state": C.c_int64, "nsamd_field_mlp_saved_floats": C.c_int64,
+             "nsamd_field_mlp_bwd_scatter_workspace": C.c_int64,
              "nsamd_occgrid_coarse_words": C.c_int64}
 
 _lib = None

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "scatter.h"
 
 NSAMD_PROBE_DEFINE(field)
 
@@ -761,19 +762,32 @@ __device__ __forceinline__ void rows_gemm_bwd(const float* Wrows, const v4f* in,
   }
 }
 
+struct NoBetween {
+  template <int I>
+  __device__ __forceinline__ void at() const {}
+};
+
+// `between.at<I>()` runs after GEMM I (0..4) of the chain: the producer mode of the backward slots its record stores there
+template <class Between = NoBetween>
 __device__ __forceinline__ void coop_forward_tile(const float* W, const float* bias, const float (&dir)[3],
                                                   const float* __restrict__ app_table,
                                                   const float* __restrict__ app_const, int app_dim,
-                                                  const TileInputs& ti, int lane, FieldActs& A) {
+                                                  const TileInputs& ti, int lane, FieldActs& A, const v4f* app_pre = nullptr,
+                                                  const Between& between = Between()) {
   const int j = lane & 15, g = lane >> 4;
   load_bias<4>(bias + kBiasBase0, A.h1, g);
   rows_gemm_fwd<4, 2, kLd32>(W + kRowBase0, A.enc, A.h1, j, g);
+  between.template at<0>();
   relu_tiles<4>(A.h1);
   load_bias<1>(bias + kBiasBase1, A.o16, g);
   rows_gemm_fwd<1, 4, kLd64>(W + kRowBase1, A.h1, A.o16, j, g);
+  between.template at<1>();
   A.hin[0] = sh_quad(dir[0], dir[1], dir[2], g);
   A.hin[1] = A.o16[0];
-  if (app_dim > 0) {
+  if (app_pre != nullptr) {  // fetched by the caller ahead of other memory traffic
+    A.hin[2] = app_pre[0];
+    A.hin[3] = app_pre[1];
+  } else if (app_dim > 0) {
     const float* src = (app_table != nullptr) ? app_table + ti.cam * 32 : app_const;
     A.hin[2] = *reinterpret_cast<const v4f*>(src + 4 * g);
     A.hin[3] = *reinterpret_cast<const v4f*>(src + 16 + 4 * g);
@@ -783,12 +797,15 @@ __device__ __forceinline__ void coop_forward_tile(const float* W, const float* b
   }
   load_bias<4>(bias + kBiasHead0, A.ha, g);
   rows_gemm_fwd<4, 4, kLd64>(W + kRowHead0, A.hin, A.ha, j, g);
+  between.template at<2>();
   relu_tiles<4>(A.ha);
   load_bias<4>(bias + kBiasHead1, A.hb, g);
   rows_gemm_fwd<4, 4, kLd64>(W + kRowHead1, A.ha, A.hb, j, g);
+  between.template at<3>();
   relu_tiles<4>(A.hb);
   load_bias<1>(bias + kBiasHead2, A.rgbp, g);
   rows_gemm_fwd<1, 4, kLd64>(W + kRowHead2, A.hb, A.rgbp, j, g);
+  between.template at<4>();
 }
 
 // dW tile (n, m) += sum over the points of scratch areas [first, first + count): Dout^T X. MFMA step q of an area
@@ -841,18 +858,269 @@ __device__ __forceinline__ void coop_emit_bias(float v, int n, int j, int g, flo
   }
 }
 
+
+// ---- the scatter's pass 1 inside the backward ("producer" mode, nsamd_field_mlp_bwd_scatter) ---------------------------
+// The data gradient of base layer 0 IS the encoded-feature gradient the table scatter routes: lane (j, g) holds, for point j,
+// the two features of levels 8t + 2g and 8t + 2g + 1 — so instead of storing `denc` (25 MB), launching the route kernel and
+// having it load the gradients again, recompute every cell and write the 201 MB of records in a memory-bound launch of its
+// own (75-80 us), each lane derives the x-pair records of its four (point, level) pairs here and stores them straight into
+// the tile queues, where the stores overlap the other waves' MFMA work. The workgroups are persistent, so a workgroup OWNS one
+// static segment per (level, tile): slot = segment base + ds_add_rtn rank, the rank counters live in LDS for the whole
+// launch (4 KiB), and no record needs a global atomic unless its segment is full (then: the tile's dynamic area, then the
+// spill list — exactly the route kernel's fallbacks; scatter.hip's apply pass cannot tell the difference).
+struct RouteArgs {
+  nsamd_points P;
+  int transform;
+  nsamd_aabb box;
+  nsamd_grid grid;
+  ScatterGeom G;
+  ScatterBufs buf;
+};
+
+constexpr int kProducerSegCap = 256;  // records per (tile, workgroup) static segment: scripts/study_fused_route_overflow.py
+constexpr int kRouteLevels = 16;  // the main field's grid: 32 features = the K of base layer 0
+constexpr int kRouteCnt = kRouteLevels * (1 << kProducerMaxLog2Bins);
+
+// Everything the record emission reads, in LDS (filled once per workgroup from the kernel arguments): held as kernel
+// arguments the ~60 scalars stay live across the whole tile loop and spill (98 SGPRs / 27 VGPRs spilled in the first build).
+struct RouteLds {
+  uint32_t cnt[kRouteCnt];          // [levels][bins] records of this workgroup per tile (rank counters)
+  uint32_t lmax[kRouteLevels];  // max |gradient| bits per level
+  float scal[kRouteLevels];
+  uint32_t loff[kRouteLevels];
+  nsamd_points P;
+  nsamd_aabb box;
+  int32_t transform, num_levels, log2_table_size, slice_log2, log2_bins;
+  uint32_t seg_cap, static_end, level_cap, spill_cap, segs;
+  uint4* queues;
+  uint32_t* dyn_cursor;
+  uint32_t* hdr;
+  uint4* spill_rec;
+  uint32_t* spill_tile;
+  uint32_t* counts;
+  float stash[kCoopWaves][11][64];  // per wave: a tile's 8 feature gradients + normalised position, until its records are out
+};
+constexpr int kRouteLdsWords = (sizeof(RouteLds) + 3) / 4;
+static_assert(sizeof(float) * (kRowTotal + 256 + kCoopWaves * 2 * kScratchTile) + sizeof(RouteLds) <= 160 * 1024, "160 KiB of LDS per CU");
+
+__device__ __forceinline__ void route_lds_init(RouteLds* L, const RouteArgs& R) {
+  for (int e = threadIdx.x; e < kRouteCnt + kRouteLevels; e += kCoopThreads) L->cnt[e] = 0u;  // cnt, then lmax
+  if (threadIdx.x < kRouteLevels) {
+    L->scal[threadIdx.x] = R.grid.scalings[threadIdx.x];
+    L->loff[threadIdx.x] = R.G.level_off[threadIdx.x];
+  }
+  if (threadIdx.x == 0) {
+    L->P = R.P;
+    L->box = R.box;
+    L->transform = R.transform;
+    L->num_levels = R.grid.num_levels;
+    L->log2_table_size = R.grid.log2_table_size;
+    L->slice_log2 = R.G.slice_log2;
+    L->log2_bins = R.G.log2_bins;
+    L->seg_cap = R.G.seg_cap;
+    L->static_end = R.G.segs * R.G.seg_cap;
+    L->level_cap = R.G.level_cap[0];
+    L->spill_cap = R.G.spill_cap;
+    L->segs = R.G.segs;
+    L->queues = R.buf.queues;
+    L->dyn_cursor = R.buf.dyn_cursor;
+    L->hdr = R.buf.hdr;
+    L->spill_rec = R.buf.spill_rec;
+    L->spill_tile = R.buf.spill_tile;
+    L->counts = R.buf.counts;
+  }
+}
+
+// cold path: a record that found no room in its segment nor in the tile's dynamic area (or a pair straddling two tiles) goes
+// to the spill list — inline, one returning atomic per record: a CALL here would make every register that is live around
+// the emission (the next tile's activations) a caller-saved spill. The list holds the worst case (write-only gradient).
+__device__ __forceinline__ void route_spill(RouteLds* L, uint32_t tile, uint4 rec) {
+  const uint32_t pos = atomicAdd(L->hdr + kHdrSpillCount, 1u);
+  if (pos < L->spill_cap) {
+    L->spill_rec[pos] = rec;
+    L->spill_tile[pos] = tile;
+  } else {
+    atomicAdd(L->hdr + kHdrEvtLost, 1u);
+  }
+}
+
+constexpr uint32_t kRankSkip = 0xffffffffu;
+
+// Slow path of one record (pair q of a level): the pair straddles two tiles, or its static segment is full — the tile's
+// dynamic area (one returning global atomic), then the spill list. Re-derives the record; reached by a handful of records
+// per launch at most (scripts/study_fused_route_overflow.py), so all it must be is correct and out of the hot path's way.
+__device__ __noinline__ void route_record_slow(RouteLds* L, float x, float y, float z, float g0, float g1, int level, int q,
+                                               bool segment_full) {
+  const uint32_t mask = (1u << L->log2_table_size) - 1u;
+  const int sl = L->slice_log2, lb = L->log2_bins;
+  const uint32_t local_mask = (1u << sl) - 1u;
+  const Cell c = locate_cell(x, y, z, L->scal[level]);
+  const PairHash h = pair_hash(c, q, mask);
+  const uint32_t bin = h.ia >> sl, tile0 = (uint32_t)level << lb;
+  const float bz = (q & 2) ? c.w[2] : 1.0f - c.w[2];
+  const float by = (q & 1) ? c.w[1] : 1.0f - c.w[1];
+  const float a0 = (g0 * bz) * by, a1 = (g1 * bz) * by;
+  if ((h.ib >> sl) != bin) {
+    const float omx = 1.0f - c.w[0];
+    route_spill(L, tile0 + bin, make_uint4(__float_as_uint(a0 * omx), __float_as_uint(a1 * omx), 0u, h.ia & local_mask));
+    route_spill(L, tile0 + (h.ib >> sl), make_uint4(__float_as_uint(a0 * c.w[0]), __float_as_uint(a1 * c.w[0]), 0u, h.ib & local_mask));
+    return;
+  }
+  if (!segment_full) return;
+  const uint4 rec = make_uint4(__float_as_uint(a0), __float_as_uint(a1), __float_as_uint(c.w[0]),
+                               (h.ia & local_mask) | ((h.ib & local_mask) << 14) | 0x80000000u);
+  const uint32_t Q = L->level_cap, static_end = L->static_end;
+  const uint32_t pos = atomicAdd(L->dyn_cursor + (tile0 + bin), 1u);
+  if (pos < Q - static_end) rec_store(L->queues + (L->loff[level] + bin * Q + static_end + pos), rec);
+  else route_spill(L, tile0 + bin, rec);
+}
+
+// ONE record — pair Q of the lane's level K (K = 0..3 -> chain-layout slot (t, rr) = (K >> 1, K & 1), level 8 t + 2 g + rr) —
+// of the tile whose feature gradients and normalised positions sit in this wave's stash rows. The 16 records of a tile leave
+// one at a time, SPREAD over the next tile's iteration between its GEMMs: all waves storing their 16 records at once is a burst
+// of 8192 scattered 16-B write requests per CU that drains at the L2's request rate (~16 k clocks per tile with every matrix
+// core idle, profiles/r04_fused_route_probe.txt) — one store per wave every ~3 k clocks disappears beside the MFMA work.
+template <int K, int Q>
+__device__ __forceinline__ void route_step(RouteLds* L, const float (*stash)[64], int lane, int probe_skip) {
+  constexpr int t = K >> 1, rr = K & 1;
+  const int g = lane >> 4;
+  const int level = 8 * t + 2 * g + rr;
+  const float g0 = stash[4 * t + 2 * rr][lane], g1 = stash[4 * t + 2 * rr + 1][lane];
+  if (level >= L->num_levels || (g0 == 0.0f && g1 == 0.0f)) return;  // adding zero is a no-op (NaN != 0: kept); dead lanes hold zeros
+  const float x = stash[8][lane], y = stash[9][lane], z = stash[10][lane];
+  const Cell c = locate_cell(x, y, z, L->scal[level]);
+  if (Q == 0) {  // integer compare of |bits|: a NaN or Inf wins and marks the level non-finite
+    const uint32_t b0 = __float_as_uint(g0) & 0x7fffffffu, b1 = __float_as_uint(g1) & 0x7fffffffu;
+    atomicMax(L->lmax + level, b0 > b1 ? b0 : b1);
+  }
+  const uint32_t mask = (1u << L->log2_table_size) - 1u;
+  const int sl = L->slice_log2;
+  const uint32_t local_mask = (1u << sl) - 1u;
+  const PairHash h = pair_hash(c, Q, mask);
+  const uint32_t bin = h.ia >> sl;
+  const bool straddle = (h.ib >> sl) != bin;
+  const uint32_t C = L->seg_cap;
+  const uint32_t rank = (probe_skip & 16) ? (uint32_t)(threadIdx.x & 127)
+                                          : atomicAdd(L->cnt + ((uint32_t)level << L->log2_bins) + bin, 1u);  // ds_add_rtn_u32
+  // autograd order ((g * wz) * wy) * wx; the x factor is applied by pass 2
+  const float bz = (Q & 2) ? c.w[2] : 1.0f - c.w[2];
+  const float by = (Q & 1) ? c.w[1] : 1.0f - c.w[1];
+  // (a straddling pair has taken a rank like any other: its slot gets a record that adds zero, the two halves leave
+  //  through the slow path)
+  const uint4 rec = make_uint4(straddle ? 0u : __float_as_uint((g0 * bz) * by), straddle ? 0u : __float_as_uint((g1 * bz) * by),
+                               __float_as_uint(c.w[0]),
+                               (h.ia & local_mask) | ((straddle ? h.ia : h.ib) & local_mask) << 14 | 0x80000000u);
+  const bool full = rank >= C;
+  // (record indices fit 32 bits: the plan checks queue_records < 2^31)
+  if (!full && !(probe_skip & 8)) rec_store(L->queues + (L->loff[level] + blockIdx.x * C + bin * L->level_cap + rank), rec);
+  if (straddle || full) route_record_slow(L, x, y, z, g0, g1, level, Q, full && !straddle);
+}
+
+// every record of the stashed tile at once (after the last tile of a workgroup; emission of a tile normally rides on the next one)
+__device__ __forceinline__ void route_flush(RouteLds* L, const float (*stash)[64], int lane, int probe_skip) {
+  route_step<0, 0>(L, stash, lane, probe_skip); route_step<0, 1>(L, stash, lane, probe_skip);
+  route_step<0, 2>(L, stash, lane, probe_skip); route_step<0, 3>(L, stash, lane, probe_skip);
+  route_step<1, 0>(L, stash, lane, probe_skip); route_step<1, 1>(L, stash, lane, probe_skip);
+  route_step<1, 2>(L, stash, lane, probe_skip); route_step<1, 3>(L, stash, lane, probe_skip);
+  route_step<2, 0>(L, stash, lane, probe_skip); route_step<2, 1>(L, stash, lane, probe_skip);
+  route_step<2, 2>(L, stash, lane, probe_skip); route_step<2, 3>(L, stash, lane, probe_skip);
+  route_step<3, 0>(L, stash, lane, probe_skip); route_step<3, 1>(L, stash, lane, probe_skip);
+  route_step<3, 2>(L, stash, lane, probe_skip); route_step<3, 3>(L, stash, lane, probe_skip);
+}
+
+// Raw position of this lane's point of a tile (ray mode: one 32-bit division per lane for the ray index); false: no point.
+__device__ __forceinline__ bool route_load_position(const RouteLds* L, int64_t tile, int64_t tiles, int64_t M,
+                                                    int64_t dir_group, int lane, float& x, float& y, float& z) {
+  const int64_t p = tile * 16 + (lane & 15);
+  x = y = z = 0.0f;
+  if (!(tile < tiles && p < M)) return false;
+  if (L->P.positions != nullptr || (int64_t)L->P.samples_per_ray != dir_group) {
+    load_position(L->P, p, x, y, z);
+  } else {
+    const int64_t S = dir_group, ray = ray_of(p, S), s = p - ray * S;
+    const float* tb = L->P.t_bins + ray * (S + 1) + s;
+    const float span = tb[0] + tb[1];
+    const float* o = L->P.origins + 3 * ray;
+    const float* d = L->P.directions + 3 * ray;
+    x = o[0] + d[0] * span / 2.0f;
+    y = o[1] + d[1] * span / 2.0f;
+    z = o[2] + d[2] * span / 2.0f;
+  }
+  return true;
+}
+
+// Everything a tile's backward reads from global memory, fetched in one go (producer mode: right after the previous tile's
+// base-layer-0 barrier and BEFORE that tile's records are stored — vector memory operations of a wave retire in order, so
+// loads issued behind the 16 scattered record stores would wait for the whole burst to drain through the L2).
+struct TileFetch {
+  TileInputs ti;
+  v4f enc[2];
+  float up_rgb[3], up_density;
+  float dir[3];
+  v4f app[2];
+};
+
+__device__ __forceinline__ void fetch_tile(TileFetch& f, int64_t tile, int64_t tiles, int lane, int64_t M,
+                                           const float* __restrict__ enc, const float* __restrict__ selector,
+                                           const float* __restrict__ directions, const int64_t* __restrict__ cams,
+                                           const float* __restrict__ app_table, const float* __restrict__ app_const,
+                                           int app_dim, int64_t dir_group, const float* __restrict__ ddensity,
+                                           const float* __restrict__ drgb) {
+  const int g = lane >> 4;
+  f.ti = tile_inputs(tile < tiles ? tile : tiles - 1, lane, M, selector, cams, dir_group);
+  if (tile >= tiles) f.ti.live = false;  // idle wave of the last round: computes, contributes zeros
+  load_enc_tile(enc, M, f.ti.p, lane, f.enc);
+  f.up_rgb[0] = f.up_rgb[1] = f.up_rgb[2] = f.up_density = 0.f;
+  if (g == 0 && f.ti.live) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) f.up_rgb[c] = drgb[3 * f.ti.p + c];
+    f.up_density = ddensity[f.ti.p];
+  }
+  const float* d = directions + 3 * f.ti.ray;
+  f.dir[0] = d[0]; f.dir[1] = d[1]; f.dir[2] = d[2];
+  if (app_dim > 0) {
+    const float* src = (app_table != nullptr) ? app_table + f.ti.cam * 32 : app_const;
+    f.app[0] = *reinterpret_cast<const v4f*>(src + 4 * g);
+    f.app[1] = *reinterpret_cast<const v4f*>(src + 16 + 4 * g);
+  } else {
+    f.app[0] = v4f{0.f, 0.f, 0.f, 0.f};
+    f.app[1] = v4f{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// the record stores that ride on a tile's forward recomputation: records 0..5 of the previous tile (see route_step)
+struct RouteBetween {
+  RouteLds* L;
+  const float (*stash)[64];
+  int lane, probe_skip;
+  bool on;
+  template <int I>
+  __device__ __forceinline__ void at() const {
+    if (!on) return;
+    if (I == 0) route_step<0, 0>(L, stash, lane, probe_skip);
+    if (I == 1) route_step<0, 1>(L, stash, lane, probe_skip);
+    if (I == 2) { route_step<0, 2>(L, stash, lane, probe_skip); route_step<0, 3>(L, stash, lane, probe_skip); }
+    if (I == 3) { route_step<1, 0>(L, stash, lane, probe_skip); route_step<1, 1>(L, stash, lane, probe_skip); }
+    if (I == 4) route_step<1, 2>(L, stash, lane, probe_skip);
+  }
+};
+
+template <bool ROUTE>
 __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
     nsamd_field_mlp mlp, int app_dim, const float* __restrict__ ddensity, const float* __restrict__ drgb,
     float* __restrict__ denc, nsamd_field_mlp_grads grads, float* __restrict__ partials,
-    float* __restrict__ app_partials, int app_rows_per_point, const float* __restrict__ acts, int probe_skip) {
+    float* __restrict__ app_partials, int app_rows_per_point, const float* __restrict__ acts, int probe_skip,
+    RouteArgs R) {
   // probe_skip (NSAMD_FIELD_BWD_SKIP, timing experiments only — results are wrong when set): 1 = no weight-gradient
   // MFMAs, 2 = no workgroup barriers inside the tile loop, 4 = no data-gradient GEMMs
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* W = lds;                     // kRowTotal
   float* bias = lds + kRowTotal;      // 256
   float* scratch = bias + 256;        // kCoopWaves x 2 tiles
+  RouteLds* RL = reinterpret_cast<RouteLds*>(scratch + kCoopWaves * 2 * kScratchTile);  // (ROUTE only: behind the scratch)
+  if (ROUTE) route_lds_init(RL, R);
   PROBE_STAMP(kCoopWaves, 0);
   {
     float v[24];
@@ -902,30 +1170,56 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
   const int64_t per_iter = (int64_t)gridDim.x * kCoopWaves;
   const int64_t iters = (tiles + per_iter - 1) / per_iter;
   PROBE_STAMP(kCoopWaves, 1);
+  TileFetch nxt;  // (ROUTE) the next tile's inputs, fetched ahead of the current tile's record stores
+  if (ROUTE && iters > 0)
+    fetch_tile(nxt, (int64_t)blockIdx.x * kCoopWaves + wave, tiles, lane, M, enc, selector, directions, cams, app_table, app_const,
+               app_dim, dir_group, ddensity, drgb);
   for (int64_t it = 0; it < iters; ++it) {
     PROBE_STAMP(kCoopWaves, 2 + 10 * (int)it);
     const int64_t tile = (it * gridDim.x + blockIdx.x) * kCoopWaves + wave;
-    TileInputs ti = tile_inputs(tile < tiles ? tile : tiles - 1, lane, M, selector, cams, dir_group);
-    if (tile >= tiles) ti.live = false;  // idle wave of the last round: computes, contributes zeros
+    TileInputs ti;
     FieldActs A;
-    load_enc_tile(enc, M, ti.p, lane, A.enc);
-    // the upstream gradients of this tile (lanes g == 0 use them two and five phases further down): fetched with the
-    // inputs, so their latency hides behind the forward instead of opening the head-2 and base-1 phases
     float up_rgb[3] = {0.f, 0.f, 0.f}, up_density = 0.f;
-    if (g == 0 && ti.live) {
+    if (ROUTE) {
+      ti = nxt.ti;
+      A.enc[0] = nxt.enc[0];
+      A.enc[1] = nxt.enc[1];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) up_rgb[c] = drgb[3 * ti.p + c];
-      up_density = ddensity[ti.p];
-    }
-    if (acts != nullptr) {  // saved by the forward of this step: no recomputation
-      load_acts(acts, tile < tiles ? tile : tiles - 1, lane, A);
-      build_head_input(directions, app_table, app_const, dir_group, app_dim, ti, lane, A);
+      for (int c = 0; c < 3; ++c) up_rgb[c] = nxt.up_rgb[c];
+      up_density = nxt.up_density;
+      const float dir[3] = {nxt.dir[0], nxt.dir[1], nxt.dir[2]};
+      const v4f app[2] = {nxt.app[0], nxt.app[1]};
+      // records 0..6 of the PREVIOUS tile leave between this tile's forward GEMMs, the other nine between the phases below
+      const RouteBetween rb{RL, RL->stash[wave], lane, probe_skip, it > 0 && !(probe_skip & 32)};
+      coop_forward_tile(W, bias, dir, app_table, app_const, app_dim, ti, lane, A, app, rb);
     } else {
-      const float* d = directions + 3 * ti.ray;  // consumed two layers further down
-      const float dir[3] = {d[0], d[1], d[2]};
-      coop_forward_tile(W, bias, dir, app_table, app_const, app_dim, ti, lane, A);
+      ti = tile_inputs(tile < tiles ? tile : tiles - 1, lane, M, selector, cams, dir_group);
+      if (tile >= tiles) ti.live = false;  // idle wave of the last round: computes, contributes zeros
+      load_enc_tile(enc, M, ti.p, lane, A.enc);
+      // the upstream gradients of this tile (lanes g == 0 use them two and five phases further down): fetched with the
+      // inputs, so their latency hides behind the forward instead of opening the head-2 and base-1 phases
+      if (g == 0 && ti.live) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) up_rgb[c] = drgb[3 * ti.p + c];
+        up_density = ddensity[ti.p];
+      }
+      if (acts != nullptr) {  // saved by the forward of this step: no recomputation
+        load_acts(acts, tile < tiles ? tile : tiles - 1, lane, A);
+        build_head_input(directions, app_table, app_const, dir_group, app_dim, ti, lane, A);
+      } else {
+        const float* d = directions + 3 * ti.ray;  // consumed two layers further down
+        const float dir[3] = {d[0], d[1], d[2]};
+        coop_forward_tile(W, bias, dir, app_table, app_const, app_dim, ti, lane, A);
+      }
     }
     PROBE_STAMP(kCoopWaves, 3 + 10 * (int)it);
+    const bool emit = ROUTE && it > 0 && !(probe_skip & 32);  // the previous tile's records are still going out
+#define NSAMD_ROUTE_STEP(K, Q)                                                    \
+  do {                                                                           \
+    if (ROUTE) {                                                                 \
+      if (emit) route_step<K, Q>(RL, RL->stash[wave], lane, probe_skip);         \
+    }                                                                            \
+  } while (0)
 
     // ---- head layer 2 (64 -> 3, sigmoid) ----
     v4f g_rgbp[1];
@@ -947,8 +1241,10 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     zero_tiles<4>(g_hb);
     if (!(probe_skip & 4)) rows_gemm_bwd<4, 1, kLd64>(W + kRowHead2, g_rgbp, g_hb, j, g);
     relu_mask<4>(g_hb, A.hb);
+    NSAMD_ROUTE_STEP(1, 3);
     if (!(probe_skip & 2)) __syncthreads();
     if (!(probe_skip & 1)) coop_dw<1>(dW_h2, &db_h2, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
+    NSAMD_ROUTE_STEP(2, 0);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 4 + 10 * (int)it);
 
@@ -959,8 +1255,10 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     zero_tiles<4>(g_ha);
     if (!(probe_skip & 4)) rows_gemm_bwd<4, 4, kLd64>(W + kRowHead1, g_hb, g_ha, j, g);
     relu_mask<4>(g_ha, A.ha);
+    NSAMD_ROUTE_STEP(2, 1);
     if (!(probe_skip & 2)) __syncthreads();
     if (!(probe_skip & 1)) coop_dw<2>(dW_h1, &db_h1, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
+    NSAMD_ROUTE_STEP(2, 2);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 5 + 10 * (int)it);
 
@@ -971,8 +1269,10 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     zero_tiles<4>(g_hin);
     // input tile 0 is the SH block: it carries no gradient, so only columns 16..63 (tiles 1..3) are formed
     if (!(probe_skip & 4)) rows_gemm_bwd<3, 4, kLd64>(W + kRowHead0 + 16, g_ha, g_hin + 1, j, g);
+    NSAMD_ROUTE_STEP(2, 3);
     if (!(probe_skip & 2)) __syncthreads();
     if (!(probe_skip & 1)) coop_dw<2>(dW_h0, &db_h0, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
+    NSAMD_ROUTE_STEP(3, 0);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 6 + 10 * (int)it);
 
@@ -1044,8 +1344,10 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     zero_tiles<4>(g_h1);
     if (!(probe_skip & 4)) rows_gemm_bwd<4, 1, kLd64>(W + kRowBase1, g_o16, g_h1, j, g);
     relu_mask<4>(g_h1, A.h1);
+    NSAMD_ROUTE_STEP(3, 1);
     if (!(probe_skip & 2)) __syncthreads();
     if (!(probe_skip & 1)) coop_dw<1>(dW_b1, &db_b1, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
+    NSAMD_ROUTE_STEP(3, 2);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 7 + 10 * (int)it);
 
@@ -1055,22 +1357,53 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     v4f g_enc[2];
     zero_tiles<2>(g_enc);
     if (!(probe_skip & 4)) rows_gemm_bwd<2, 4, kLd32>(W + kRowBase0, g_h1, g_enc, j, g);
-    if (ti.live) {
+    if (ti.live && denc != nullptr) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) denc[(int64_t)(16 * t + 4 * g + r) * M + ti.p] = g_enc[t][r];
     }
+    // The scatter's pass-1 records (see RouteArgs / route_step): the last record of the PREVIOUS tile leaves, then this
+    // tile's feature gradients and normalised positions take its place in the wave's stash; they go out one record at a time
+    // during the next tile's iteration (after the last one: route_flush below).
+    NSAMD_ROUTE_STEP(3, 3);
+    if (ROUTE) {  // (a wave reads only its own rows of the stash back: no barrier is involved)
+      float px, py, pz;
+      const bool plive = route_load_position(RL, tile, tiles, M, dir_group, lane, px, py, pz);
+      (void)normalise_position(RL->transform, RL->box, px, py, pz);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) RL->stash[wave][4 * t + r][lane] = plive ? g_enc[t][r] : 0.0f;
+      RL->stash[wave][8][lane] = px;
+      RL->stash[wave][9][lane] = py;
+      RL->stash[wave][10][lane] = pz;
+    }
     if (!(probe_skip & 2)) __syncthreads();
+    if (ROUTE && it + 1 < iters)  // the next tile's inputs (see TileFetch)
+      fetch_tile(nxt, tile + per_iter, tiles, lane, M, enc, selector, directions, cams, app_table, app_const, app_dim, dir_group,
+                 ddensity, drgb);
+    PROBE_STAMP(kCoopWaves, 9 + 10 * (int)it);
     if (!(probe_skip & 1)) coop_dw<1>(dW_b0, &db_b0, own_m1 == 0, scratch, 0, kCoopWaves, own_n, own_m1, j, g);
     // no barrier here: the next writer of the scratch is the next iteration's head layer 2, behind its own barrier
     PROBE_STAMP(kCoopWaves, 8 + 10 * (int)it);
+#undef NSAMD_ROUTE_STEP
   }
+  if (ROUTE && iters > 0 && !(probe_skip & 32)) route_flush(RL, RL->stash[wave], lane, probe_skip);  // the last tile's records
   PROBE_STAMP(kCoopWaves, 62);
 
   // ---- the two point-halves of the 1 x 4 layers meet in LDS (scratch is free now) ---------------------------------
   float* stash = scratch;  // [2 layers][4 tiles][64 lanes][4] + [2][4][64] bias partials
-  __syncthreads();         // the last weight-gradient reads of the scratch are done
+  __syncthreads();         // the last weight-gradient reads of the scratch are done (and every record has its rank)
+  if (ROUTE) {  // this workgroup's segment counts and its share of the levels' gradient maxima
+    const int B = 1 << RL->log2_bins;
+    for (int e = threadIdx.x; e < RL->num_levels * B; e += kCoopThreads) {  // e = tile = (level << log2_bins) + bin
+      const uint32_t n = RL->cnt[e];
+      RL->counts[(size_t)e * RL->segs + blockIdx.x] = n < RL->seg_cap ? n : RL->seg_cap;
+    }
+    if (threadIdx.x < (unsigned)RL->num_levels && RL->lmax[threadIdx.x] != 0u)
+      atomicMax(RL->hdr + threadIdx.x, RL->lmax[threadIdx.x]);
+  }
   if (own_half == 1) {
     *reinterpret_cast<v4f*>(stash + ((0 * 4 + own_q) * 64 + lane) * 4) = dW_h2[0];
     *reinterpret_cast<v4f*>(stash + ((1 * 4 + own_q) * 64 + lane) * 4) = dW_b1[0];
@@ -1374,21 +1707,24 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
                               const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
                               nsamd_field_mlp mlp, const float* ddensity, const float* drgb, float* denc,
                               nsamd_field_mlp_grads grads, float* workspace, int64_t workspace_floats,
-                              const float* acts, nsamd_stream_t stream, int phases = 3) {
+                              const float* acts, nsamd_stream_t stream, int phases = 3, const RouteArgs* route_in = nullptr,
+                              float* dtable = nullptr, float* scatter_ws = nullptr, int64_t scatter_ws_floats = 0) {
   // phases: 1 = the gradient kernel (denc + per-workgroup partials), 2 = the fixed-order sum of the partials, 3 = both
   if (M == 0) return NSAMD_OK;
   int app_dim = 0;
   int st = field_common_checks(enc, directions, dir_group, M, mlp, camera_indices, appearance_const, &app_dim);
   if (st) return st;
-  NSAMD_REQUIRE(ddensity && drgb && denc);
+  NSAMD_REQUIRE(ddensity && drgb && (denc || route_in));
   const int64_t tiles = (M + 15) / 16;
   const size_t lds = sizeof(float) * (kRowTotal + 256 + kCoopWaves * 2 * kScratchTile);
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return NSAMD_ERR_NO_DEVICE;
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {  // the dynamic-LDS opt-in is per device
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + sizeof(uint32_t) * kRouteLdsWords)) != hipSuccess)
       return NSAMD_ERR_LAUNCH;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
@@ -1409,10 +1745,25 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
     app_rows_per_point = 1;
   }
   if (phases != 3) NSAMD_REQUIRE(partials != nullptr);  // without scratch the kernel flushes with atomics: nothing to split
-  if (phases & 1) {
-    field_mlp_bwd_kernel<<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
+  ScatterPlan plan{};
+  if (route_in != nullptr) {
+    // producer mode: the kernel emits the scatter's pass-1 records (one static segment per workgroup and tile)
+    NSAMD_REQUIRE(phases == 3 && acts == nullptr && dtable != nullptr && scatter_ws != nullptr && partials != nullptr);
+    plan = scatter_plan_producers(route_in->grid, M, (int)blocks, kProducerSegCap);
+    if (!plan.ok) return NSAMD_ERR_UNSUPPORTED;
+    NSAMD_REQUIRE(scatter_ws_floats >= plan.total_words);
+    RouteArgs R = *route_in;
+    R.G = plan.geom;
+    R.buf = scatter_bufs(scatter_ws, plan);
+    R.buf.log2_table_size = R.grid.log2_table_size;
+    field_mlp_bwd_kernel<true><<<blocks, kCoopThreads, lds + sizeof(uint32_t) * kRouteLdsWords, (hipStream_t)stream>>>(
         enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-        grads, partials, app_partials, app_rows_per_point, acts, probe_skip);
+        grads, partials, app_partials, app_rows_per_point, acts, probe_skip, R);
+    NSAMD_CHECK_LAUNCH();
+  } else if (phases & 1) {
+    field_mlp_bwd_kernel<false><<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
+        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
+        grads, partials, app_partials, app_rows_per_point, acts, probe_skip, RouteArgs{});
     NSAMD_CHECK_LAUNCH();
   }
   if (partials != nullptr && (phases & 2)) {
@@ -1424,7 +1775,46 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
         app_rows_per_point ? 1 : (int)(dir_group / 16));
     NSAMD_CHECK_LAUNCH();
   }
+  if (route_in != nullptr)  // pass 2 over the records the kernel left in the queues: the table's gradient is WRITTEN
+    return scatter_apply_launch(route_in->grid, plan, scatter_ws, dtable, /*overwrite=*/true, (hipStream_t)stream);
   return NSAMD_OK;
+}
+
+static unsigned field_bwd_blocks(int64_t M) {
+  const int64_t tiles = (M + 15) / 16;
+  return (unsigned)min((int64_t)num_cus(), (tiles + kCoopWaves - 1) / kCoopWaves);
+}
+
+extern "C" int64_t nsamd_field_mlp_bwd_scatter_workspace(nsamd_grid grid, int64_t M, int64_t* state_words) {
+  if (M <= 0 || grid.num_levels != 16) return 0;
+  const ScatterPlan p = scatter_plan_producers(grid, M, (int)field_bwd_blocks(M), kProducerSegCap);
+  if (!p.ok) return 0;
+  if (state_words != nullptr) *state_words = p.state_words;
+  return p.total_words;
+}
+
+extern "C" int nsamd_field_mlp_bwd_scatter(nsamd_points pts, int transform, nsamd_aabb aabb, nsamd_grid grid,
+                                           const float* enc, const float* selector, const float* directions,
+                                           const int64_t* camera_indices, const float* appearance_const,
+                                           int64_t dir_group, int64_t M, nsamd_field_mlp mlp, const float* ddensity,
+                                           const float* drgb, float* denc, nsamd_field_mlp_grads grads, float* workspace,
+                                           int64_t workspace_floats, float* dtable, float* scatter_workspace,
+                                           int64_t scatter_workspace_floats, nsamd_stream_t stream) {
+  if (M == 0) return NSAMD_OK;
+  if (grid.num_levels != 16) return NSAMD_ERR_UNSUPPORTED;  // 32 features = the K of base layer 0
+  NSAMD_REQUIRE(M > 0 && transform >= 0 && transform <= 2 && grid.log2_table_size >= 1 && grid.log2_table_size <= 28);
+  if (pts.positions == nullptr) {
+    NSAMD_REQUIRE(pts.origins && pts.directions && pts.t_bins && pts.samples_per_ray > 0 && M % pts.samples_per_ray == 0);
+  }
+  NSAMD_REQUIRE(dtable != nullptr && scatter_workspace != nullptr && workspace != nullptr);
+  RouteArgs R{};
+  R.P = pts;
+  R.transform = transform;
+  R.box = aabb;
+  R.grid = grid;
+  return field_mlp_bwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, ddensity, drgb,
+                            denc, grads, workspace, workspace_floats, nullptr, stream, 3, &R, dtable, scatter_workspace,
+                            scatter_workspace_floats);
 }
 
 extern "C" int nsamd_field_mlp_bwd(const float* enc, const float* selector, const float* directions,

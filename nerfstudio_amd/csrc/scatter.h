@@ -86,7 +86,90 @@ constexpr int kHdrTicket = 33;       // finish kernel: last workgroup resets the
 constexpr int kHdrEvtSpill = 40;     // sticky: spill records seen since the workspace was created
 constexpr int kHdrEvtUnordered = 41; // sticky: spill records applied with float atomics (beyond the fold limit)
 constexpr int kHdrEvtLost = 42;      // sticky: records that found no room at all (cannot happen with a worst-case list)
+constexpr int kProducerMaxLog2Bins = 6;  // producer kernels keep [levels][2^log2_bins] rank counters in LDS (4 KiB)
 constexpr uint32_t kSpillFold = 8192;  // spill records pass 2 folds into its tiles (exact, order-independent)
+
+#if defined(__HIPCC__)
+// ---- device helpers shared by the route kernels (scatter.hip) and the field backward's record emission (field_mlp.hip) ----
+// Queue records are written once (pass 1) and read once (pass 2, another launch): streaming accesses, kept out of the way of
+// the table rows and gradients that do get re-used (NSAMD_SCATTER_NT=0 at build time: plain accesses, for A/B).
+#ifndef NSAMD_SCATTER_NT
+#define NSAMD_SCATTER_NT 1
+#endif
+typedef uint32_t rec_vec __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void rec_store(uint4* dst, const uint4& r) {
+  *dst = r;  // (nontemporal STORES: 175 -> 399 us for the main table — the scattered 16-B records lose L2's write combining)
+}
+__device__ __forceinline__ uint4 rec_load(const uint4* src) {
+#if NSAMD_SCATTER_NT
+  const rec_vec v = __builtin_nontemporal_load(reinterpret_cast<const rec_vec*>(src));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *src;
+#endif
+}
+
+// Append a record that found no room in its tile (or an x-pair straddling two tiles). One returning atomic per
+// wavefront; out of line: this is the cold path of ~50 call sites. False when the list is full.
+static __device__ __noinline__ bool spill_list_append(uint32_t* hdr, uint4* spill_rec, uint32_t* spill_tile, uint32_t cap,
+                                               uint32_t tile, uint4 rec) {
+  const unsigned long long active = __ballot(1);
+  const int lane = threadIdx.x & 63;
+  const int leader = __builtin_ctzll(active);
+  const uint32_t n = (uint32_t)__builtin_popcountll(active);
+  const uint32_t mine = (uint32_t)__builtin_popcountll(active & ((1ull << lane) - 1ull));
+  uint32_t base = 0u;
+  if (lane == leader) base = atomicAdd(hdr + kHdrSpillCount, n);
+  base = __shfl(base, leader);
+  const uint32_t pos = base + mine;
+  if (pos >= cap) return false;
+  spill_rec[pos] = rec;
+  spill_tile[pos] = tile;
+  return true;
+}
+
+// Last resort of an ACCUMULATING call whose (bounded) spill list is full: float atomics straight into the gradient —
+// exact, but in no fixed order (counted). `table_level_tile` = start of the tile in the gradient.
+static __device__ __noinline__ void spill_direct(float* t, uint32_t* hdr, uint4 rec) {
+  const float f0 = __uint_as_float(rec.x), f1 = __uint_as_float(rec.y);
+  if (rec.w & 0x80000000u) {
+    const float wx = __uint_as_float(rec.z), omx = 1.0f - wx;
+    float* a = t + 2 * (size_t)(rec.w & 0x3fffu);
+    float* b = t + 2 * (size_t)((rec.w >> 14) & 0x3fffu);
+    unsafeAtomicAdd(a, f0 * omx);
+    unsafeAtomicAdd(a + 1, f1 * omx);
+    unsafeAtomicAdd(b, f0 * wx);
+    unsafeAtomicAdd(b + 1, f1 * wx);
+  } else {
+    float* a = t + 2 * (size_t)(rec.w & 0x3fffu);
+    unsafeAtomicAdd(a, f0);
+    unsafeAtomicAdd(a + 1, f1);
+  }
+  atomicAdd(hdr + kHdrEvtUnordered, 1u);
+}
+
+__device__ __forceinline__ void spill_append(const ScatterBufs& buf, uint32_t cap, uint32_t tile, const uint4& rec) {
+  if (spill_list_append(buf.hdr, buf.spill_rec, buf.spill_tile, cap, tile, rec)) return;
+  if (buf.direct_table != nullptr) {
+    const uint32_t level = tile >> buf.log2_bins, bin = tile & ((1u << buf.log2_bins) - 1u);
+    spill_direct(buf.direct_table + ((((size_t)level << buf.log2_table_size) + ((size_t)bin << buf.slice_log2)) << 1),
+                 buf.hdr, rec);
+  } else {
+    atomicAdd(buf.hdr + kHdrEvtLost, 1u);  // cannot happen: write-only calls size the list for the worst case
+  }
+}
+
+struct PairHash {
+  uint32_t ia, ib;
+};
+
+// hashes of the x-pair q (bit0: y is ceil, bit1: z is ceil) of a cell
+__device__ __forceinline__ PairHash pair_hash(const Cell& c, int q, uint32_t mask) {
+  const uint32_t yz = ((uint32_t)((q & 1) ? c.hi[1] : c.lo[1]) * kPrimeY) ^ ((uint32_t)((q & 2) ? c.hi[2] : c.lo[2]) * kPrimeZ);
+  return PairHash{((uint32_t)c.lo[0] ^ yz) & mask, ((uint32_t)c.hi[0] ^ yz) & mask};
+}
+
+#endif  // __HIPCC__
 
 struct ScatterPlan {
   bool ok;
@@ -98,6 +181,19 @@ struct ScatterPlan {
 
 // Host: geometry for (grid, M); `max_spill` = true sizes the spill list for the worst case (write-only calls).
 ScatterPlan scatter_plan(const nsamd_grid& grid, int64_t M, bool max_spill);
+
+// Host: geometry for records emitted by `workgroups` PERSISTENT producer workgroups (the main field's backward kernel emits
+// the pass-1 records of its own points: nsamd_field_mlp_bwd_scatter): one static segment of `seg_cap` records per
+// (tile, workgroup) — a workgroup's LDS rank IS the slot —, a dynamic area behind them, a worst-case spill list.
+ScatterPlan scatter_plan_producers(const nsamd_grid& grid, int64_t M, int workgroups, int seg_cap);
+
+// Host: the workspace's regions for a plan.
+ScatterBufs scatter_bufs(float* workspace, const ScatterPlan& p);
+
+// Host: enqueue apply (pass 2) + finish for records that are already in the queues of `plan` (every level routed through
+// static segments + dynamic area; counts[tile][seg] and hdr[level] written by the producer).
+int scatter_apply_launch(const nsamd_grid& grid, const ScatterPlan& plan, float* workspace, float* dtable, bool overwrite,
+                         hipStream_t stream);
 
 // Host: enqueue route (pass 1) + apply (pass 2) + finish on `stream`. Returns an nsamd_status. `gate` (nullable, device):
 // accumulating calls only — while *gate == 0 all kernels return at once (the gradient being scattered is all zeros);

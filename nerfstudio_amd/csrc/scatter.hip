@@ -41,87 +41,9 @@ __device__ __forceinline__ bool gate_is_clear(const uint32_t* gate) {
   return gate != nullptr && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
 }
 
-// Queue records are written once (pass 1) and read once (pass 2, another launch): streaming accesses, kept out of the way of
-// the table rows and gradients that do get re-used (NSAMD_SCATTER_NT=0 at build time: plain accesses, for A/B).
-#ifndef NSAMD_SCATTER_NT
-#define NSAMD_SCATTER_NT 1
-#endif
-typedef uint32_t rec_vec __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void rec_store(uint4* dst, const uint4& r) {
-  *dst = r;  // (nontemporal STORES: 175 -> 399 us for the main table — the scattered 16-B records lose L2's write combining)
-}
-__device__ __forceinline__ uint4 rec_load(const uint4* src) {
-#if NSAMD_SCATTER_NT
-  const rec_vec v = __builtin_nontemporal_load(reinterpret_cast<const rec_vec*>(src));
-  return make_uint4(v.x, v.y, v.z, v.w);
-#else
-  return *src;
-#endif
-}
-
 constexpr int kRunLen = 4;        // consecutive samples per thread in the run kernel
 constexpr int kRunThreads = 256;  // -> 1024 points per workgroup
 constexpr int kMaxLog2Bins = 10;  // pass-1 LDS counters: 3 x 4 levels x bins x 4 B <= 48 KiB
-
-// Append a record that found no room in its tile (or an x-pair straddling two tiles). One returning atomic per
-// wavefront; out of line: this is the cold path of ~50 call sites. False when the list is full.
-__device__ __noinline__ bool spill_list_append(uint32_t* hdr, uint4* spill_rec, uint32_t* spill_tile, uint32_t cap,
-                                               uint32_t tile, uint4 rec) {
-  const unsigned long long active = __ballot(1);
-  const int lane = threadIdx.x & 63;
-  const int leader = __builtin_ctzll(active);
-  const uint32_t n = (uint32_t)__builtin_popcountll(active);
-  const uint32_t mine = (uint32_t)__builtin_popcountll(active & ((1ull << lane) - 1ull));
-  uint32_t base = 0u;
-  if (lane == leader) base = atomicAdd(hdr + kHdrSpillCount, n);
-  base = __shfl(base, leader);
-  const uint32_t pos = base + mine;
-  if (pos >= cap) return false;
-  spill_rec[pos] = rec;
-  spill_tile[pos] = tile;
-  return true;
-}
-
-// Last resort of an ACCUMULATING call whose (bounded) spill list is full: float atomics straight into the gradient —
-// exact, but in no fixed order (counted). `table_level_tile` = start of the tile in the gradient.
-__device__ __noinline__ void spill_direct(float* t, uint32_t* hdr, uint4 rec) {
-  const float f0 = __uint_as_float(rec.x), f1 = __uint_as_float(rec.y);
-  if (rec.w & 0x80000000u) {
-    const float wx = __uint_as_float(rec.z), omx = 1.0f - wx;
-    float* a = t + 2 * (size_t)(rec.w & 0x3fffu);
-    float* b = t + 2 * (size_t)((rec.w >> 14) & 0x3fffu);
-    unsafeAtomicAdd(a, f0 * omx);
-    unsafeAtomicAdd(a + 1, f1 * omx);
-    unsafeAtomicAdd(b, f0 * wx);
-    unsafeAtomicAdd(b + 1, f1 * wx);
-  } else {
-    float* a = t + 2 * (size_t)(rec.w & 0x3fffu);
-    unsafeAtomicAdd(a, f0);
-    unsafeAtomicAdd(a + 1, f1);
-  }
-  atomicAdd(hdr + kHdrEvtUnordered, 1u);
-}
-
-__device__ __forceinline__ void spill_append(const ScatterBufs& buf, uint32_t cap, uint32_t tile, const uint4& rec) {
-  if (spill_list_append(buf.hdr, buf.spill_rec, buf.spill_tile, cap, tile, rec)) return;
-  if (buf.direct_table != nullptr) {
-    const uint32_t level = tile >> buf.log2_bins, bin = tile & ((1u << buf.log2_bins) - 1u);
-    spill_direct(buf.direct_table + ((((size_t)level << buf.log2_table_size) + ((size_t)bin << buf.slice_log2)) << 1),
-                 buf.hdr, rec);
-  } else {
-    atomicAdd(buf.hdr + kHdrEvtLost, 1u);  // cannot happen: write-only calls size the list for the worst case
-  }
-}
-
-struct PairHash {
-  uint32_t ia, ib;
-};
-
-// hashes of the x-pair q (bit0: y is ceil, bit1: z is ceil) of a cell
-__device__ __forceinline__ PairHash pair_hash(const Cell& c, int q, uint32_t mask) {
-  const uint32_t yz = ((uint32_t)((q & 1) ? c.hi[1] : c.lo[1]) * kPrimeY) ^ ((uint32_t)((q & 2) ? c.hi[2] : c.lo[2]) * kPrimeZ);
-  return PairHash{((uint32_t)c.lo[0] ^ yz) & mask, ((uint32_t)c.hi[0] ^ yz) & mask};
-}
 
 // ---- pass 1, fine levels -------------------------------------------------------------------------------------------
 // kThreads x kPts points per workgroup, kLevels levels per thread (position computed once, 4 * kLevels * kPts
@@ -775,7 +697,85 @@ ScatterPlan scatter_plan(const nsamd_grid& grid, int64_t M, bool max_spill) {
   return p;
 }
 
-static ScatterBufs scatter_bufs(float* workspace, const ScatterPlan& p) {
+ScatterPlan scatter_plan_producers(const nsamd_grid& grid, int64_t M, int workgroups, int seg_cap) {
+  ScatterPlan p{};
+  if (M <= 0 || workgroups <= 0 || seg_cap < 16 || grid.num_levels <= 0 || grid.num_levels > NSAMD_MAX_LEVELS) return p;
+  // tiles as scatter_plan chooses them: wide enough for every x-pair to stay inside one tile, 128 KiB of LDS at most
+  int bits = 0;
+  while ((grid.num_levels << bits) < scatter_target_tiles()) ++bits;
+  int sl = grid.log2_table_size - bits;
+  float res_max = 0.0f;
+  for (int l = 0; l < grid.num_levels; ++l) res_max = grid.scalings[l] > res_max ? grid.scalings[l] : res_max;
+  int sl_pair = 1;
+  while ((1 << sl_pair) < (int)res_max + 2 && sl_pair < kSliceLog2Max) ++sl_pair;
+  sl = sl < sl_pair ? sl_pair : sl;
+  sl = sl > kSliceLog2Max ? kSliceLog2Max : (sl < 8 ? 8 : sl);
+  if (sl > grid.log2_table_size) sl = grid.log2_table_size;
+  const int log2_bins = grid.log2_table_size - sl;
+  if (log2_bins > kProducerMaxLog2Bins) return p;  // the producer keeps one LDS counter per (level, tile)
+  ScatterGeom& g = p.geom;
+  g.slice_log2 = sl;
+  g.log2_bins = log2_bins;
+  g.num_levels = grid.num_levels;
+  g.block_points = 0u;
+  const int64_t bins = (int64_t)1 << log2_bins;
+  const int64_t segs = workgroups, C = (seg_cap + 3) & ~3;
+  const int64_t expect = (4 * M + bins - 1) / bins;  // pair records per tile, uniform hash
+  // static segments (scripts/study_fused_route_overflow.py: a 256-record segment holds every level of the benchmark's
+  // batches but ~60 records of level 0) + a dynamic area for what overflows them
+  int64_t Q = segs * C + expect / 2 + 64;
+  Q = (Q + 3) & ~(int64_t)3;
+  p.tiles = bins * grid.num_levels;
+  int64_t total = 0;
+  for (int l = 0; l < grid.num_levels; ++l) {
+    if (total >= 0x7fffffffLL) return p;
+    g.level_off[l] = (uint32_t)total;
+    g.level_cap[l] = (uint32_t)Q;
+    total += bins * Q;
+  }
+  if (total >= 0x7fffffffLL || Q + (int64_t)kSpillFold >= ((int64_t)1 << 30)) return p;
+  g.queue_records = (uint32_t)total;
+  g.segs = (uint32_t)segs;
+  g.seg_cap = (uint32_t)C;
+  const int64_t spill = 4 * M * grid.num_levels + 64;  // worst case: the gradient is write-only, nothing may be lost
+  if (spill >= 0x7fffffffLL) return p;
+  g.spill_cap = (uint32_t)spill;
+  g.headroom = 0;
+  g.coarse_mask = 0u;
+  const int64_t cursor_words = (p.tiles + 3) & ~(int64_t)3;
+  const int64_t count_words = (p.tiles * segs + 3) & ~(int64_t)3;
+  p.state_words = kHdrWords + cursor_words;
+  p.total_words = kHdrWords + cursor_words + count_words + 4 * total + 4 * spill + ((spill + 3) & ~(int64_t)3);
+  p.ok = true;
+  return p;
+}
+
+static int apply_lds_attribute() {
+  {
+    const int rc = apply_lds_attribute();
+    if (rc) return rc;
+  }
+  return NSAMD_OK;
+}
+
+int scatter_apply_launch(const nsamd_grid& grid, const ScatterPlan& plan, float* workspace, float* dtable, bool overwrite,
+                         hipStream_t st) {
+  ScatterGeom G = plan.geom;
+  ScatterBufs buf = scatter_bufs(workspace, plan);
+  buf.log2_table_size = grid.log2_table_size;
+  if (!overwrite) buf.direct_table = dtable;
+  int rc = apply_lds_attribute();
+  if (rc) return rc;
+  const unsigned threads = G.slice_log2 > 11 ? 1024u : (G.slice_log2 > 9 ? 512u : 256u);
+  dim3 g2(1u << G.log2_bins, (unsigned)grid.num_levels);
+  scatter_apply_kernel<<<g2, threads, (size_t)16 << G.slice_log2, st>>>(grid, G, buf, dtable, overwrite ? 1 : 0, nullptr);
+  NSAMD_CHECK_LAUNCH();
+  scatter_finish_kernel<<<32, 256, 0, st>>>(grid, G, buf, dtable, nullptr);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+ScatterBufs scatter_bufs(float* workspace, const ScatterPlan& p) {
   ScatterBufs b;
   uint32_t* w = reinterpret_cast<uint32_t*>(workspace);
   b.hdr = w;
@@ -831,15 +831,9 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
       fine.level[fine.count++] = (int8_t)l;
     }
   }
-  // 128 KiB of dynamic LDS need the opt-in, per device
-  static bool attr_done[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return NSAMD_ERR_NO_DEVICE;
-  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_apply_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16u << kSliceLog2Max)) != hipSuccess)
-      return NSAMD_ERR_LAUNCH;
-    if (dev >= 0 && dev < 64) attr_done[dev] = true;
+  {
+    const int rc = apply_lds_attribute();
+    if (rc) return rc;
   }
   if (fine.count > 0) {
     const FineShape s = fine_shape();

@@ -227,6 +227,39 @@ def _scatter_workspace(grid: HashGridSpec, device, num_points: int = 0, write_on
     return ws, ws.numel()
 
 
+def _producer_scatter_workspace(grid: HashGridSpec, device, num_points: int) -> Tuple[Optional[Tensor], int]:
+    """Scratch of nsamd_field_mlp_bwd_scatter (the main field's backward emits the scatter's records itself): one static
+    segment per (MLP workgroup, table tile) + dynamic areas + the worst-case spill list, ~1.4 GB for the nerfacto main table at
+    196 608 points — untouched bulk, only the leading state words are ever initialised. Cached like `_scatter_workspace`."""
+    bucket = max(1, -(-int(num_points) // _SCATTER_BUCKET)) * _SCATTER_BUCKET
+    key = (grid, bucket, str(device), "producer")
+    lib = N.load()
+    ws = _SCATTER_WS.get(key)
+    state = C.c_int64(0)
+    if ws is not None:
+        need = int(lib.nsamd_field_mlp_bwd_scatter_workspace(grid.native(), num_points, C.byref(state)))
+        if 0 < need <= ws.numel():
+            _SCATTER_WS[key] = _SCATTER_WS.pop(key)
+            return ws, ws.numel()
+        if need <= 0:
+            return None, 0
+        torch.cuda.synchronize(device)
+        _SCATTER_WS.pop(key)
+    words, states = 0, 0
+    for m in {bucket, max(int(num_points), 1)}:
+        w = int(lib.nsamd_field_mlp_bwd_scatter_workspace(grid.native(), m, C.byref(state)))
+        words, states = max(words, w), max(states, int(state.value))
+    if words <= 0:
+        return None, 0
+    ws = torch.empty(words, device=device, dtype=torch.float32)
+    ws[:states].zero_()
+    while len(_SCATTER_WS) >= _SCATTER_WS_MAX:
+        torch.cuda.synchronize(device)
+        _SCATTER_WS.pop(next(iter(_SCATTER_WS)))
+    _SCATTER_WS[key] = ws
+    return ws, ws.numel()
+
+
 def scatter_events(ws: Tensor) -> Tuple[int, int, int]:
     """(spilled, unordered, lost) record counts of a scatter workspace since it was created
     (nsamd_hashgrid_scatter_events): `unordered` > 0 means some call was exact but not bit-reproducible."""

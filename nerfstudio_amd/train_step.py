@@ -127,6 +127,9 @@ class NerfactoTrainStep:
         # locality (each 4 MB level slice stays in one L2 while it is swept), which is worth more than hiding the gathers
         # behind the MFMA chain. Kept as an opt-in, bit-identical alternative (profiles/r02_negative_results.txt).
         self.fuse_main_forward = os.environ.get("NSAMD_FUSE_MAIN_FWD", "0") == "1"
+        # The main field's backward emits the table scatter's pass-1 records itself (nsamd_field_mlp_bwd_scatter: no `denc`
+        # round trip, no route launch); NSAMD_FUSE_ROUTE=0: the two entry points (A/B).
+        self.fuse_route = os.environ.get("NSAMD_FUSE_ROUTE", "1") == "1"
         self.f_saved = e(int(N.load().nsamd_field_mlp_saved_floats(mm))) if self.save_acts else None
         # Second stream for the proposal-network backward: the two backward chains are independent, and since the
         # scatter kernels were reworked (latency-bound phases, small workgroups) they overlap: 3.87 -> 4.02 M rays/s on
@@ -507,6 +510,20 @@ class NerfactoTrainStep:
         cams = N.ptr(self.camera_indices) if emb is not None else None
         grads = N.FieldMlpGrads(*(N.ptr(self._grad(p)) for p in params), N.ptr(self._grad(emb)) if emb is not None else None)
         split = self.split_reduce and self.side_stream is not None and not self.save_acts
+        if (self.fuse_route and self.main_table_write_only and not self.defer_table and not self.save_acts and not split
+                and enc.spec.num_levels == 16):
+            sws, sws_n = F._producer_scatter_workspace(enc.spec, self.f_enc.device, mm)
+            if sws is not None:
+                want_denc = self.cam_opt is not None  # the camera optimiser's share needs the feature gradient as well
+                ck(lib.nsamd_field_mlp_bwd_scatter(self._points(L), fld._transform, fld._box, enc.spec.native(),
+                                                   N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm,
+                                                   fm, N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s),
+                                                   N.ptr(self.f_denc) if want_denc else None, grads, N.ptr(self.field_ws),
+                                                   self.field_ws.numel(), N.ptr(self._grad(enc.hash_table)), N.ptr(sws), sws_n,
+                                                   st), "field_mlp_bwd_scatter")
+                if self.cam_opt is not None:
+                    self._rays_backward(L, fld, self.f_denc)
+                return
         if self.save_acts:
             ck(lib.nsamd_field_mlp_bwd_saved(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S,
                                              mm, fm, N.ptr(self.f_saved), N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s),

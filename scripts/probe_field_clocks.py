@@ -18,12 +18,18 @@ SO = os.path.join(ROOT, "nerfstudio_amd", "libnsamd_probe_field.so")
 if "--no-build" not in sys.argv or not os.path.exists(SO):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                            "-munsafe-fp-atomics", "-fPIC", "-DNSAMD_PROBE_CLOCKS", "-shared",
-                           os.path.join(ROOT, "nerfstudio_amd", "csrc", "field_mlp.hip"), "-o", SO])
+                           os.path.join(ROOT, "nerfstudio_amd", "csrc", "field_mlp.hip"),
+                           os.path.join(ROOT, "nerfstudio_amd", "csrc", "scatter.hip"), "-o", SO])
 lib = C.CDLL(SO)
 vp, i64 = C.c_void_p, C.c_int64
 lib.nsamd_field_mlp_fwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, N.FieldMlp, vp, vp, vp]
 lib.nsamd_field_mlp_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, N.FieldMlp, vp, vp, vp, N.FieldMlpGrads, vp, i64, vp]
 lib.nsamd_probe_set_clocks_field.argtypes = [vp]
+lib.nsamd_field_mlp_bwd_scatter.argtypes = [N.Points, C.c_int, N.Aabb, N.Grid, vp, vp, vp, vp, vp, i64, i64, N.FieldMlp, vp, vp, vp,
+                                            N.FieldMlpGrads, vp, i64, vp, vp, i64, vp]
+lib.nsamd_field_mlp_bwd_scatter_workspace.argtypes = [N.Grid, i64, C.POINTER(C.c_int64)]
+lib.nsamd_field_mlp_bwd_scatter_workspace.restype = C.c_int64
+ROUTE = "--route" in sys.argv  # the backward that emits the scatter's pass-1 records (nsamd_field_mlp_bwd_scatter)
 
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(0)
@@ -59,6 +65,26 @@ def fwd():
 def bwd():
     assert lib.nsamd_field_mlp_bwd(enc.data_ptr(), sel.data_ptr(), dirs.data_ptr(), cams.data_ptr(), None, S, M, fm,
                                    ddens.data_ptr(), drgb.data_ptr(), denc.data_ptr(), grads, ws.data_ptr(), ws.numel(), st) == 0
+
+
+if ROUTE:
+    from nerfstudio_amd import functional as F
+
+    spec = F.HashGridSpec(num_levels=16, min_res=16, max_res=2048, log2_hashmap_size=19)
+    origins = rnd(rays, 3, scale=0.5)
+    tb = torch.sort(torch.rand(rays, S + 1, generator=g) * 2.0 + 0.05, dim=-1)[0].to(dev)
+    pts = N.make_points(None, origins, dirs, tb, S)
+    state = C.c_int64(0)
+    words = lib.nsamd_field_mlp_bwd_scatter_workspace(spec.native(), M, C.byref(state))
+    sws = torch.empty(words, device=dev)
+    sws[:state.value].zero_()
+    dtable = torch.empty(16 << 19, 2, device=dev)
+    box = N.make_aabb(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]))
+
+    def bwd():  # noqa: F811
+        assert lib.nsamd_field_mlp_bwd_scatter(pts, N.XFORM_CONTRACT, box, spec.native(), enc.data_ptr(), sel.data_ptr(),
+                                               dirs.data_ptr(), cams.data_ptr(), None, S, M, fm, ddens.data_ptr(), drgb.data_ptr(),
+                                               None, grads, ws.data_ptr(), ws.numel(), dtable.data_ptr(), sws.data_ptr(), words, st) == 0
 
 
 def timed(fn, n=20):
@@ -98,7 +124,7 @@ def report(name, t, labels):
 
 
 print(f"fwd {timed(fwd):.1f} us   bwd {timed(bwd):.1f} us   (no clock buffer set)")
-W = int(os.environ.get("NSAMD_FIELD_FWD_WAVES", "4"))
+W = int(os.environ.get("NSAMD_FIELD_FWD_WAVES", "16"))
 f = stamps(fwd, {4: 768 * 4, 8: 512 * 8, 16: 256 * 16}[W])
 labels = [(1, "stage weights + barrier")]
 for it in range(4 if W == 4 else 3):
@@ -111,8 +137,10 @@ labels = [(1, "stage weights + barrier")]
 for it in range(6):
     k = 10 * it
     labels += [(2 + k, f"it {it}: top"), (3 + k, f"it {it}: inputs + forward"), (4 + k, f"it {it}: head2 phase"),
-               (5 + k, f"it {it}: head1 phase"), (6 + k, f"it {it}: head0 phase"), (7 + k, f"it {it}: app + base1 phase"),
-               (8 + k, f"it {it}: base0 phase + store")]
+               (5 + k, f"it {it}: head1 phase"), (6 + k, f"it {it}: head0 phase"), (7 + k, f"it {it}: app + base1 phase")]
+    labels += [
+               (9 + k, f"it {it}: base0 dgrad + record emission")] if ROUTE else []
+    labels += [(8 + k, f"it {it}: base0 phase + store")]
 labels += [(62, "loop end"), (63, "emit partials")]
 report("field_mlp_bwd", b, labels)
 print(f"fwd {timed(fwd):.1f} us   bwd {timed(bwd):.1f} us   (after)")

@@ -425,3 +425,62 @@ def test_field_mlp_backward_at_bench_size_vs_float64(F):
     print(f"\nfield MLP backward at M = 196608 against float64 ({int(ambiguous.sum())} samples = {100 * frac:.2f} % with a "
           "ReLU pre-activation within 1e-5 of zero excluded):\n" + "\n".join(rows))
     assert not bad, f"{bad}\n" + "\n".join(rows)
+
+
+@pytest.mark.parametrize("init", ["default", "n(0,0.3)"])
+def test_backward_that_emits_the_scatter_records_equals_the_two_launches(F, init):
+    """nsamd_field_mlp_bwd_scatter (the main field's backward emits the table scatter's pass-1 records from its registers)
+    against nsamd_field_mlp_bwd + nsamd_hashgrid_encode_bwd_set at the benchmark's size: the same records reach the same
+    order-independent fixed-point sums, so every MLP gradient is bit-equal and the table gradient differs at most by where
+    the fixed-point truncation sits (the queue capacity sets the headroom): <= 1e-6 of the level's largest entry. No record
+    on an unordered path, and two calls give the same bits."""
+    from test_gpu_kernels import _hip_model
+
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.train_step import NerfactoTrainStep
+    import bench
+
+    cfg = orc.NerfactoCfg()
+    params = orc.init_params(cfg, seed=0, table_std=None if init == "default" else 0.3)
+    F._SCATTER_WS.clear()
+    dev = torch.device("cuda")
+    model = _hip_model(cfg, params)
+    arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
+    n = bench.RAYS_PER_GPU
+    o, d, cam, tgt = (torch.from_numpy(a).to(dev) for a in bench.synthetic_rays(1003))
+    r = NerfactoTrainStep(model, n, dev)
+    r.side_stream = None
+    r.set_batch(o, d, cam[:, 0], tgt)
+    rs = np.random.RandomState(4)
+    r.jitter.copy_(torch.from_numpy(rs.uniform(0, 1, (3, n)).astype(np.float32)))
+    r.forward_and_losses(False, draw_jitter=False)
+    a, b = arena.groups["fields"]
+    table = model.field.mlp_base.encoding.hash_table
+    off = next(o_ for p_, o_ in zip(arena.params, arena.offsets) if p_ is table)
+    T, out = 1 << 19, {}
+    for mode in ("two", "fused", "fused_again"):
+        r.fuse_route = mode != "two"
+        arena.zero_grad(["fields"])
+        arena.grad[off:off + table.numel()].fill_(float("nan"))  # write-only: every entry must be written
+        r.backward_main()
+        torch.cuda.synchronize()
+        out[mode] = arena.grad[a:b].clone()
+    assert any(k[3] == "producer" for k in F._SCATTER_WS), "the fused entry point was not taken"
+    two, fused, again = out["two"], out["fused"], out["fused_again"]
+    assert not torch.isnan(fused).any()
+    assert torch.equal(fused, again), "two calls of the fused backward differ"
+    lo, hi = off - a, off - a + table.numel()
+    assert torch.equal(two[:lo], fused[:lo]) and torch.equal(two[hi:], fused[hi:]), "MLP / embedding gradients differ"
+    t2, tf = two[lo:hi].view(16, T, 2), fused[lo:hi].view(16, T, 2)
+    worst = 0.0
+    for l in range(16):
+        m = float(t2[l].abs().max())
+        assert m > 0
+        e = float((t2[l] - tf[l]).abs().max()) / m
+        worst = max(worst, e)
+        assert e <= 1e-6, f"level {l}: table gradient differs by {e:.2e} of the level's largest entry"
+    for key, ws in F._SCATTER_WS.items():
+        ev = F.scatter_events(ws)
+        assert ev[1] == 0 and ev[2] == 0, f"scatter records on an unordered path / lost: {key[3]} {ev}"
+    spilled = {k[3]: F.scatter_events(ws)[0] for k, ws in F._SCATTER_WS.items()}
+    print(f"\nfused route [{init}]: worst table-gradient difference {worst:.2e} of a level's maximum; spilled records {spilled}")
