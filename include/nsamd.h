@@ -280,6 +280,15 @@ int nsamd_field_mlp_bwd_scatter(nsamd_points pts, int transform, nsamd_aabb aabb
                                 const float* ddensity, const float* drgb, float* denc, nsamd_field_mlp_grads grads,
                                 float* workspace, int64_t workspace_floats, float* dtable, float* scatter_workspace,
                                 int64_t scatter_workspace_floats, nsamd_stream_t stream);
+/* The same call one launch group at a time (per-kernel timing of the benchmark's roofline leg; the groups in order give the
+ * single call's bits): phase 1 = the gradient kernel with the record emission, 2 = the weight-gradient reduce, 4 = the
+ * scatter's apply + finish passes over the records phase 1 left in the queues. */
+int nsamd_field_mlp_bwd_scatter_phase(nsamd_points pts, int transform, nsamd_aabb aabb, nsamd_grid grid, const float* enc,
+                                      const float* selector, const float* directions, const int64_t* camera_indices,
+                                      const float* appearance_const, int64_t dir_group, int64_t M, nsamd_field_mlp mlp,
+                                      const float* ddensity, const float* drgb, float* denc, nsamd_field_mlp_grads grads,
+                                      float* workspace, int64_t workspace_floats, float* dtable, float* scatter_workspace,
+                                      int64_t scatter_workspace_floats, int phase, nsamd_stream_t stream);
 
 /* nsamd_field_mlp_bwd in two launches, so that a caller can put the second on another stream: phase 1 = the gradient
  * kernel (denc + the per-workgroup weight-gradient partials in `workspace`, which is REQUIRED here), phase 2 = the
@@ -350,9 +359,12 @@ int nsamd_weights_fwd(const float* t_bins, const float* density, int64_t num_ray
                       nsamd_stream_t stream);
 int nsamd_weights_bwd(const float* t_bins, const float* density, const float* dweights, int64_t num_rays,
                       int32_t S, float* ddensity, nsamd_stream_t stream);
-/* The same, and *gate_out = (any ray carries gradient) — see "zero-gradient gating" under the hash encoding. */
+/* The same, and *gate_out = (any ray carries gradient) — see "zero-gradient gating" under the hash encoding.
+ * gate_precleared != 0: the caller has zeroed *gate_out on the stream since its last use (a training schedule clears all its
+ * flags in one fill off the critical path instead of one 4-byte memset node per level); 0: the call clears it itself. */
 int nsamd_weights_bwd_gate(const float* t_bins, const float* density, const float* dweights, int64_t num_rays,
-                           int32_t S, float* ddensity, uint32_t* gate_out, uint8_t* ray_mask_out, nsamd_stream_t stream);
+                           int32_t S, float* ddensity, uint32_t* gate_out, uint8_t* ray_mask_out, int32_t gate_precleared,
+                           nsamd_stream_t stream);
 
 /* PDFSampler.generate_ray_samples (ray_samplers.py:276-372) preceded by the anneal pow(weights, anneal)
  * (ray_samplers.py:601; skipped when anneal == 1). include_original = 0: s_bins / t_bins are [num_rays, S+1] (the
@@ -580,6 +592,31 @@ int nsamd_rows_scatter(float* rows, const int64_t* index, int64_t n, int32_t fea
 int nsamd_select_batch(const float* slot_dev, int32_t slots, int64_t num_rays, const float* origins_pool,
                        const float* directions_pool, const int64_t* cameras_pool, const float* target_pool,
                        float* origins, float* directions, int64_t* cameras, float* target, nsamd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Camera-pose corrections (CameraOptimizer, cameras/camera_optimizers.py:85-185; exponential maps cameras/lie_groups.py:
+ * 25-60 SO3xR3, :63-117 SE3). pose [num_cameras,6] = (translation, rotation vector) per camera, mode 1 = SO3xR3, 2 = SE3.
+ *   nsamd_camera_apply     apply_to_raybundle (:148-153): origins = raw_origins + t(c), directions = R(c) raw_directions
+ *                          for the camera c of every ray; fp32, the reference's operations in the reference's order.
+ *   nsamd_camera_backward  what autograd does with dL/d(origins, directions) of those rays — the index_add over the rays
+ *                          of a camera, bmm backward, the exponential map's backward — plus the gradient of the L2
+ *                          regulariser (:179-185): dpose [num_cameras,6] += d(loss + regulariser)/d pose; *regulariser
+ *                          (nullable) = mean|t| trans_l2_penalty + mean|w| rot_l2_penalty. `upstream` lists the per-ray
+ *                          gradient buffers of the sampling levels that saw the rays (nsamd_hashgrid_encode_bwd_rays,
+ *                          one pair per level, summed per ray in list order). Per-camera sums in double in a fixed order:
+ *                          bit-reproducible. `non_trainable_camera_indices` is not supported here (callers keep torch).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct nsamd_ray_grads {
+  const float* d_origins[4];    /* [n,3] each */
+  const float* d_directions[4]; /* [n,3] each */
+  int32_t count;
+} nsamd_ray_grads;
+int nsamd_camera_apply(const float* pose, int32_t mode, int32_t num_cameras, const float* raw_origins,
+                       const float* raw_directions, const int64_t* camera_indices, int64_t n, float* origins,
+                       float* directions, nsamd_stream_t stream);
+int nsamd_camera_backward(const float* pose, int32_t mode, int32_t num_cameras, const float* raw_directions,
+                          const int64_t* camera_indices, int64_t n, nsamd_ray_grads upstream, float trans_l2_penalty,
+                          float rot_l2_penalty, float* dpose, float* regulariser, nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fused Adam over a flat fp32 arena (engine/optimizers.py:74-193 with AdamOptimizerConfig(lr, eps=1e-15),

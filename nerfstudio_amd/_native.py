@@ -52,6 +52,10 @@ class OccGrid(C.Structure):
     _fields_ = [("binaries", vp), ("levels", i32), ("resolution", i32), ("aabb", f32 * 6), ("coarse", vp)]
 
 
+class RayGrads(C.Structure):
+    _fields_ = [("d_origins", vp * 4), ("d_directions", vp * 4), ("count", i32)]
+
+
 class FieldMlpGrads(C.Structure):
     _fields_ = [("base_W0", vp), ("base_b0", vp), ("base_W1", vp), ("base_b1", vp), ("head_W0", vp), ("head_b0", vp),
                 ("head_W1", vp), ("head_b1", vp), ("head_W2", vp), ("head_b2", vp), ("appearance", vp)]
@@ -80,6 +84,8 @@ _SIGNATURES = {
     "nsamd_field_mlp_bwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp, i64, vp],
     "nsamd_field_mlp_bwd_scatter": [Points, C.c_int, Aabb, Grid, vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp,
                                     i64, vp, vp, i64, vp],
+    "nsamd_field_mlp_bwd_scatter_phase": [Points, C.c_int, Aabb, Grid, vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads,
+                                          vp, i64, vp, vp, i64, C.c_int, vp],
     "nsamd_field_mlp_bwd_scatter_workspace": [Grid, i64, C.POINTER(C.c_int64)],
     "nsamd_field_fused_fwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, vp, vp, i64, FieldMlp, vp, vp, vp, vp, vp],
     "nsamd_field_mlp_saved_floats": [i64],
@@ -91,7 +97,7 @@ _SIGNATURES = {
     "nsamd_piecewise_bins": [vp, vp, vp, vp, i32, i64, i32, C.c_int, vp, vp, vp],
     "nsamd_weights_fwd": [vp, vp, i64, i32, vp, vp],
     "nsamd_weights_bwd": [vp, vp, vp, i64, i32, vp, vp],
-    "nsamd_weights_bwd_gate": [vp, vp, vp, i64, i32, vp, vp, vp, vp],
+    "nsamd_weights_bwd_gate": [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp],
     "nsamd_pdf_resample": [vp, vp, i32, vp, vp, vp, vp, f32, vp, f32, f32, f32, C.c_int, i32, i32, i64, i32, vp, vp, vp, vp],
     "nsamd_proposal_resample": [vp, vp, vp, i32, vp, vp, vp, vp, f32, vp, f32, f32, f32, C.c_int, i64, i32, vp, vp, vp, vp, vp],
     "nsamd_composite_fwd": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), C.c_int, vp, vp, vp, vp, vp, vp, vp],
@@ -121,6 +127,8 @@ _SIGNATURES = {
     "nsamd_rows_gather": [vp, vp, i64, i32, vp, vp],
     "nsamd_rows_scatter": [vp, vp, i64, i32, vp, vp],
     "nsamd_select_batch": [vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "nsamd_camera_apply": [vp, i32, i32, vp, vp, vp, i64, vp, vp, vp],
+    "nsamd_camera_backward": [vp, i32, i32, vp, vp, i64, RayGrads, f32, f32, vp, vp, vp],
     "nsamd_adam_step": [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i32, f32, vp, vp],
     "nsamd_version": [],
     "nsamd_status_string": [C.c_int],
@@ -160,6 +168,10 @@ class _Entry:
             key = f"{self.name}[L={args[5].num_levels},M={args[1]}]"
         elif self.name.startswith("nsamd_density_mlp"):
             key = f"{self.name}[M={args[2] if self.name.endswith('fwd') else args[4]}]"
+        elif self.name == "nsamd_field_mlp_bwd_scatter_phase":
+            key = f"{self.name}[{ {1: 'gradients+records', 2: 'dw_reduce', 4: 'apply'}.get(args[21], args[21]) }]"
+        elif self.name == "nsamd_adam_step":
+            key = f"{self.name}[n={args[4]}]"
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()

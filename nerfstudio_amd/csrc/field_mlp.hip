@@ -1748,7 +1748,7 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
   ScatterPlan plan{};
   if (route_in != nullptr) {
     // producer mode: the kernel emits the scatter's pass-1 records (one static segment per workgroup and tile)
-    NSAMD_REQUIRE(phases == 3 && acts == nullptr && dtable != nullptr && scatter_ws != nullptr && partials != nullptr);
+    NSAMD_REQUIRE(acts == nullptr && dtable != nullptr && scatter_ws != nullptr && partials != nullptr);
     plan = scatter_plan_producers(route_in->grid, M, (int)blocks, kProducerSegCap);
     if (!plan.ok) return NSAMD_ERR_UNSUPPORTED;
     NSAMD_REQUIRE(scatter_ws_floats >= plan.total_words);
@@ -1756,10 +1756,12 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
     R.G = plan.geom;
     R.buf = scatter_bufs(scatter_ws, plan);
     R.buf.log2_table_size = R.grid.log2_table_size;
-    field_mlp_bwd_kernel<true><<<blocks, kCoopThreads, lds + sizeof(uint32_t) * kRouteLdsWords, (hipStream_t)stream>>>(
-        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-        grads, partials, app_partials, app_rows_per_point, acts, probe_skip, R);
-    NSAMD_CHECK_LAUNCH();
+    if (phases & 1) {
+      field_mlp_bwd_kernel<true><<<blocks, kCoopThreads, lds + sizeof(uint32_t) * kRouteLdsWords, (hipStream_t)stream>>>(
+          enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
+          grads, partials, app_partials, app_rows_per_point, acts, probe_skip, R);
+      NSAMD_CHECK_LAUNCH();
+    }
   } else if (phases & 1) {
     field_mlp_bwd_kernel<false><<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
         enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
@@ -1775,7 +1777,7 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
         app_rows_per_point ? 1 : (int)(dir_group / 16));
     NSAMD_CHECK_LAUNCH();
   }
-  if (route_in != nullptr)  // pass 2 over the records the kernel left in the queues: the table's gradient is WRITTEN
+  if (route_in != nullptr && (phases & 4))  // pass 2 over the records the kernel left in the queues: the table's gradient is WRITTEN
     return scatter_apply_launch(route_in->grid, plan, scatter_ws, dtable, /*overwrite=*/true, (hipStream_t)stream);
   return NSAMD_OK;
 }
@@ -1793,13 +1795,15 @@ extern "C" int64_t nsamd_field_mlp_bwd_scatter_workspace(nsamd_grid grid, int64_
   return p.total_words;
 }
 
-extern "C" int nsamd_field_mlp_bwd_scatter(nsamd_points pts, int transform, nsamd_aabb aabb, nsamd_grid grid,
-                                           const float* enc, const float* selector, const float* directions,
-                                           const int64_t* camera_indices, const float* appearance_const,
-                                           int64_t dir_group, int64_t M, nsamd_field_mlp mlp, const float* ddensity,
-                                           const float* drgb, float* denc, nsamd_field_mlp_grads grads, float* workspace,
-                                           int64_t workspace_floats, float* dtable, float* scatter_workspace,
-                                           int64_t scatter_workspace_floats, nsamd_stream_t stream) {
+extern "C" int nsamd_field_mlp_bwd_scatter_phase(nsamd_points pts, int transform, nsamd_aabb aabb, nsamd_grid grid,
+                                                 const float* enc, const float* selector, const float* directions,
+                                                 const int64_t* camera_indices, const float* appearance_const,
+                                                 int64_t dir_group, int64_t M, nsamd_field_mlp mlp, const float* ddensity,
+                                                 const float* drgb, float* denc, nsamd_field_mlp_grads grads,
+                                                 float* workspace, int64_t workspace_floats, float* dtable,
+                                                 float* scatter_workspace, int64_t scatter_workspace_floats, int phase,
+                                                 nsamd_stream_t stream) {
+  NSAMD_REQUIRE(phase == 1 || phase == 2 || phase == 4 || phase == 7);
   if (M == 0) return NSAMD_OK;
   if (grid.num_levels != 16) return NSAMD_ERR_UNSUPPORTED;  // 32 features = the K of base layer 0
   NSAMD_REQUIRE(M > 0 && transform >= 0 && transform <= 2 && grid.log2_table_size >= 1 && grid.log2_table_size <= 28);
@@ -1813,8 +1817,20 @@ extern "C" int nsamd_field_mlp_bwd_scatter(nsamd_points pts, int transform, nsam
   R.box = aabb;
   R.grid = grid;
   return field_mlp_bwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, ddensity, drgb,
-                            denc, grads, workspace, workspace_floats, nullptr, stream, 3, &R, dtable, scatter_workspace,
+                            denc, grads, workspace, workspace_floats, nullptr, stream, phase, &R, dtable, scatter_workspace,
                             scatter_workspace_floats);
+}
+
+extern "C" int nsamd_field_mlp_bwd_scatter(nsamd_points pts, int transform, nsamd_aabb aabb, nsamd_grid grid,
+                                           const float* enc, const float* selector, const float* directions,
+                                           const int64_t* camera_indices, const float* appearance_const,
+                                           int64_t dir_group, int64_t M, nsamd_field_mlp mlp, const float* ddensity,
+                                           const float* drgb, float* denc, nsamd_field_mlp_grads grads, float* workspace,
+                                           int64_t workspace_floats, float* dtable, float* scatter_workspace,
+                                           int64_t scatter_workspace_floats, nsamd_stream_t stream) {
+  return nsamd_field_mlp_bwd_scatter_phase(pts, transform, aabb, grid, enc, selector, directions, camera_indices,
+                                           appearance_const, dir_group, M, mlp, ddensity, drgb, denc, grads, workspace,
+                                           workspace_floats, dtable, scatter_workspace, scatter_workspace_floats, 7, stream);
 }
 
 extern "C" int nsamd_field_mlp_bwd(const float* enc, const float* selector, const float* directions,

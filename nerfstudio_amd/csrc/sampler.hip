@@ -394,9 +394,10 @@ extern "C" int nsamd_weights_fwd(const float* t_bins, const float* density, int6
 }
 
 static int weights_bwd_launch(const float* t_bins, const float* density, const float* dweights, int64_t num_rays,
-                              int32_t S, float* ddensity, uint32_t* gate_out, uint8_t* ray_mask, nsamd_stream_t stream) {
+                              int32_t S, float* ddensity, uint32_t* gate_out, uint8_t* ray_mask, nsamd_stream_t stream,
+                              bool gate_precleared = false) {
   NSAMD_REQUIRE(num_rays >= 0 && S > 0);
-  if (gate_out != nullptr &&  // cleared on the stream ahead of the launch (a memset node inside a captured graph)
+  if (gate_out != nullptr && !gate_precleared &&  // cleared on the stream ahead of the launch (a memset node inside a captured graph)
       hipMemsetAsync(gate_out, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
     return NSAMD_ERR_LAUNCH;
   if (num_rays == 0) return NSAMD_OK;
@@ -416,9 +417,10 @@ extern "C" int nsamd_weights_bwd(const float* t_bins, const float* density, cons
 
 extern "C" int nsamd_weights_bwd_gate(const float* t_bins, const float* density, const float* dweights,
                                       int64_t num_rays, int32_t S, float* ddensity, uint32_t* gate_out,
-                                      uint8_t* ray_mask_out, nsamd_stream_t stream) {
+                                      uint8_t* ray_mask_out, int32_t gate_precleared, nsamd_stream_t stream) {
   NSAMD_REQUIRE(gate_out != nullptr);
-  return weights_bwd_launch(t_bins, density, dweights, num_rays, S, ddensity, gate_out, ray_mask_out, stream);
+  return weights_bwd_launch(t_bins, density, dweights, num_rays, S, ddensity, gate_out, ray_mask_out, stream,
+                            gate_precleared != 0);
 }
 
 extern "C" int nsamd_pdf_resample(const float* s_bins_prev, const float* weights, int32_t S_prev,

@@ -116,6 +116,7 @@ class NerfactoTrainStep:
         # NSAMD_GATE_PROPOSALS=0: the ungated entry points (A/B).
         self.gate_proposals = os.environ.get("NSAMD_GATE_PROPOSALS", "1") == "1"
         self.prop_gates = torch.zeros(max(self.n_prop, 1) * 4, device=device, dtype=torch.int32)  # 16 B apart
+        self.gates_precleared = False  # True: the caller zeroes `prop_gates` before every proposal backward (trainer.HipTrainer)
         # ... and its per-ray form (1 = the ray carries gradient): levels that are only partly without gradient
         self.prop_ray_masks = [torch.zeros(n, device=device, dtype=torch.uint8) for _ in range(self.n_prop)]
         # Optional (NSAMD_FIELD_SAVE_ACTS=1): the forward saves the main field's activations (896 B per sample) and the
@@ -130,6 +131,7 @@ class NerfactoTrainStep:
         # The main field's backward emits the table scatter's pass-1 records itself (nsamd_field_mlp_bwd_scatter: no `denc`
         # round trip, no route launch); NSAMD_FUSE_ROUTE=0: the two entry points (A/B).
         self.fuse_route = os.environ.get("NSAMD_FUSE_ROUTE", "1") == "1"
+        self.keep_denc = False  # True: the fused launch also stores the encoded-feature gradient in `f_denc` (tests read it)
         self.f_saved = e(int(N.load().nsamd_field_mlp_saved_floats(mm))) if self.save_acts else None
         # Second stream for the proposal-network backward: the two backward chains are independent, and since the
         # scatter kernels were reworked (latency-bound phases, small workgroups) they overlap: 3.87 -> 4.02 M rays/s on
@@ -156,7 +158,18 @@ class NerfactoTrainStep:
         # the levels' backward chains stay independent), and autograd carries it back to the parameter.
         co = getattr(model, "camera_optimizer", None)
         self.cam_opt = co if (co is not None and co.config.mode != "off") else None
+        # The exponential map, the pose-to-ray arithmetic and their backward as two launches (nsamd_camera_apply /
+        # nsamd_camera_backward) instead of ~100 eager torch kernels + autograd nodes: any optimiser with the reference's
+        # parameterisation (a [num_cameras, 6] `pose_adjustment`, mode SO3xR3 / SE3, every camera trainable) — this
+        # package's or the reference's own. NSAMD_CAMERA_KERNELS=0: the torch route (A/B).
+        self.cam_kernels = False
         if self.cam_opt is not None:
+            pose = getattr(co, "pose_adjustment", None)
+            self.cam_kernels = (os.environ.get("NSAMD_CAMERA_KERNELS", "1") == "1" and pose is not None and pose.is_cuda
+                                and pose.dtype == torch.float32 and pose.dim() == 2 and pose.shape[1] == 6
+                                and co.config.mode in ("SO3xR3", "SE3")
+                                and getattr(co, "non_trainable_camera_indices", None) is None)
+            self.cam_mode = {"SO3xR3": 1, "SE3": 2}.get(co.config.mode, 0)
             self.raw_origins, self.raw_directions = e(n, 3), e(n, 3)
             self.d_origins = [e(n, 3) for _ in self.counts]
             self.d_directions = [e(n, 3) for _ in self.counts]
@@ -294,6 +307,12 @@ class NerfactoTrainStep:
         buffers the kernels read; the autograd graph of the tiny exponential map is kept for backward_cameras."""
         if self.cam_opt is None:
             return
+        if self.cam_kernels:
+            pose = self.cam_opt.pose_adjustment
+            N.check(N.load().nsamd_camera_apply(N.ptr(pose), self.cam_mode, pose.shape[0], N.ptr(self.raw_origins),
+                                                N.ptr(self.raw_directions), N.ptr(self.camera_indices), self.n,
+                                                N.ptr(self.origins), N.ptr(self.directions), N.stream()), "camera_apply")
+            return
         if hasattr(self.cam_opt, "corrected_rays"):
             o, d = self.cam_opt.corrected_rays(self.raw_origins, self.raw_directions, self.camera_indices)
         else:  # the reference's own CameraOptimizer: forward(indices) -> [n,3,4] corrections (camera_optimizers.py:107-153)
@@ -324,6 +343,26 @@ class NerfactoTrainStep:
         if self.cam_opt is None or (self.cameras_outside and not force):
             return
         L = self.n_prop
+        if self.cam_kernels:
+            pose = self.cam_opt.pose_adjustment
+            if self.grad_lookup is not None and id(pose) in self.grad_lookup:
+                g = self.grad_lookup[id(pose)]
+            else:
+                if pose.grad is None:
+                    pose.grad = torch.zeros_like(pose)
+                g = pose.grad
+            levels = (list(range(L)) if updated else []) + [L]  # the proposal networks saw the rays too (interlevel loss)
+            up = N.RayGrads()
+            for k, lvl in enumerate(levels):
+                up.d_origins[k], up.d_directions[k] = N.ptr(self.d_origins[lvl]), N.ptr(self.d_directions[lvl])
+            up.count = len(levels)
+            cfg = self.cam_opt.config
+            reg = self.reg_in_backward  # (else the caller differentiates the regulariser itself — fused_step.FusedTrainStep)
+            N.check(N.load().nsamd_camera_backward(
+                N.ptr(pose), self.cam_mode, pose.shape[0], N.ptr(self.raw_directions), N.ptr(self.camera_indices), self.n, up,
+                float(cfg.trans_l2_penalty) if reg else 0.0, float(cfg.rot_l2_penalty) if reg else 0.0, N.ptr(g),
+                N.ptr(self.camera_reg) if reg else None, N.stream()), "camera_backward")
+            return
         d_o, d_d = self.d_origins[L], self.d_directions[L]
         if updated:  # the proposal networks saw the rays too (interlevel loss)
             d_o = d_o + sum(self.d_origins[:L])
@@ -514,13 +553,16 @@ class NerfactoTrainStep:
                 and enc.spec.num_levels == 16):
             sws, sws_n = F._producer_scatter_workspace(enc.spec, self.f_enc.device, mm)
             if sws is not None:
-                want_denc = self.cam_opt is not None  # the camera optimiser's share needs the feature gradient as well
-                ck(lib.nsamd_field_mlp_bwd_scatter(self._points(L), fld._transform, fld._box, enc.spec.native(),
-                                                   N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm,
-                                                   fm, N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s),
-                                                   N.ptr(self.f_denc) if want_denc else None, grads, N.ptr(self.field_ws),
-                                                   self.field_ws.numel(), N.ptr(self._grad(enc.hash_table)), N.ptr(sws), sws_n,
-                                                   st), "field_mlp_bwd_scatter")
+                want_denc = self.cam_opt is not None or self.keep_denc  # the camera optimiser's share needs the feature gradient as well
+                args = (self._points(L), fld._transform, fld._box, enc.spec.native(), N.ptr(self.f_enc), N.ptr(self.f_sel),
+                        N.ptr(self.directions), cams, None, S, mm, fm, N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s),
+                        N.ptr(self.f_denc) if want_denc else None, grads, N.ptr(self.field_ws), self.field_ws.numel(),
+                        N.ptr(self._grad(enc.hash_table)), N.ptr(sws), sws_n)
+                if N.PROFILE is not None:  # the per-kernel table (utils/roofline.py): one launch group at a time, same bits
+                    for phase in (1, 2, 4):
+                        ck(lib.nsamd_field_mlp_bwd_scatter_phase(*args, phase, st), "field_mlp_bwd_scatter_phase")
+                else:
+                    ck(lib.nsamd_field_mlp_bwd_scatter(*args, st), "field_mlp_bwd_scatter")
                 if self.cam_opt is not None:
                     self._rays_backward(L, fld, self.f_denc)
                 return
@@ -624,7 +666,8 @@ class NerfactoTrainStep:
                 # chain returns at once while it is clear (the zero-filled gradients are then already the result)
                 mask = N.ptr(self.prop_ray_masks[lvl])
                 ck(lib.nsamd_weights_bwd_gate(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]), n,
-                                              S, N.ptr(self.p_ddens[lvl]), gate, mask, st), "weights_bwd_gate")
+                                              S, N.ptr(self.p_ddens[lvl]), gate, mask, int(self.gates_precleared), st),
+                   "weights_bwd_gate")
                 ck(lib.nsamd_density_mlp_bwd_gated(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]),
                                                    N.ptr(self.p_ddens[lvl]), m, dm, N.ptr(self.p_denc[lvl]), *grads,
                                                    N.ptr(dws), dws.numel(), gate, mask, S, st), "density_mlp_bwd_gated")

@@ -119,6 +119,8 @@ class HipTrainer:
                 self.runner = NerfactoTrainStep(model, ray_bundle.origins.shape[0], dev)
             r = self.runner
             r.grad_lookup = arena.grad_lookup()
+            if hasattr(r, "prop_gates"):
+                r.gates_precleared = True  # `_zero` clears the proposal levels' gradient flags with the gradients
             r.set_batch(ray_bundle.origins, ray_bundle.directions, ray_bundle.camera_indices, batch["image"])
             r.anneal_dev = self.hyper[_HYPER_ANNEAL:_HYPER_ANNEAL + 1]
             cam_on = getattr(r, "cam_opt", None) is not None
@@ -235,6 +237,8 @@ class HipTrainer:
             if self.cam_inside:
                 groups = groups + [self.cam_group]
         self.arena.zero_grad(groups, skip=self.runner.written_params())
+        if updated and getattr(self.runner, "gates_precleared", False):
+            self.runner.prop_gates.zero_()  # (instead of one 4-byte memset node per level ahead of its weights backward)
 
     def _deferred_iteration_body(self, updated, pending):
         """One iteration of the deferred schedule (N = 1, runner):
@@ -250,6 +254,11 @@ class HipTrainer:
             if self.defer_scatter:
                 r.backward_table(shadow=True)
             a.step(grad_scale=1.0, groups=["fields"], hyper_dev=self.hyper_views)
+            if beside:
+                # ... and, off the critical path, this iteration's zero-fills: the Adam above was the last reader of the
+                # field gradients, the proposal / camera groups were consumed at the end of their last update iteration, and
+                # nothing before the join below writes a gradient
+                self._zero(updated)
 
         if beside:
             self._opt_fork.record(main)
@@ -274,7 +283,8 @@ class HipTrainer:
                     self._sh_join.record(self.opt_stream)
             else:
                 r.shadow_points()
-        self._zero(updated)
+        if not beside:
+            self._zero(updated)
         r.forward_main_and_losses(updated)
         r.defer_table = self.defer_scatter
         try:

@@ -31,7 +31,12 @@ def algorithmic_model(key, main_points):
         return "mfma", main_points * 2 * FIELD_MACS
     if key == "nsamd_field_fused_fwd":
         return "hbm", main_points * 16 * 8 * 8  # hash gathers (the bound of the fused launch)
-    if key in ("nsamd_field_mlp_bwd", "nsamd_field_mlp_bwd_saved", "nsamd_field_mlp_bwd_route"):
+    if key == "nsamd_field_mlp_bwd_scatter_phase[apply]":
+        # the table scatter whose route pass runs inside the field backward: the read-modify-write of 8 corners x 8 B per
+        # (sample, level) is still this op's algorithmic figure; the records (M x L x 4 x-pairs x 16 B, written by the
+        # gradient kernel, read here) are implementation traffic and not counted
+        return "hbm", main_points * 16 * 8 * 16
+    if key in ("nsamd_field_mlp_bwd", "nsamd_field_mlp_bwd_saved", "nsamd_field_mlp_bwd_scatter_phase[gradients+records]"):
         # training = 3x the forward FLOPs, the forward launch takes 1x, so the backward's ALGORITHMIC share is
         # 2x (data gradient + weight gradient); the recompute of the forward inside the kernel is executed, not algorithmic
         return "mfma", main_points * 2 * FIELD_MACS * 2
@@ -40,8 +45,9 @@ def algorithmic_model(key, main_points):
         return "hbm", int(m2.group(1)) * (10 * 4 + 4 + 8)  # enc row + selector in, density + pre out
     if key.startswith("nsamd_density_mlp_bwd") and m2:
         return "hbm", int(m2.group(1)) * (10 * 4 * 2 + 4 * 3)
-    if key == "nsamd_adam_step":
-        return "hbm", None  # filled in by the caller (arena size x 28 B)
+    m3 = re.search(r"nsamd_adam_step\[n=(\d+)\]", key)
+    if m3:
+        return "hbm", int(m3.group(1)) * 28  # p, g, m, v read + p, m, v written
     return None, None
 
 
@@ -57,14 +63,16 @@ def step_algorithmic_bytes(rays, counts=(256, 96, 48), main_levels=16, prop_leve
 
 # flops / bytes a launch actually executes where that differs from the algorithmic figure (reported next to it)
 def executed_per_launch(key, main_points):
-    if key == "nsamd_field_mlp_bwd":
+    if key in ("nsamd_field_mlp_bwd", "nsamd_field_mlp_bwd_scatter_phase"):
         return main_points * 2 * FIELD_MACS * 3  # + the forward recompute
     return None
 
 
 # entry point -> the kernel name rocprofv3 --kernel-trace --stats lists for it (profiles/*_kernel_stats.csv)
 ROCPROF_KERNEL = {
-    "nsamd_field_mlp_bwd": "nsamd::field_mlp_bwd_kernel",
+    "nsamd_field_mlp_bwd": "nsamd::field_mlp_bwd_kernel<false>",
+    "nsamd_field_mlp_bwd_scatter_phase[gradients+records]": "nsamd::field_mlp_bwd_kernel<true>",
+    "nsamd_field_mlp_bwd_scatter_phase[apply]": "nsamd::scatter_apply_kernel + nsamd::scatter_finish_kernel",
     "nsamd_field_mlp_bwd_saved": "nsamd::field_mlp_bwd_kernel (saved activations)",
     "nsamd_field_mlp_fwd": "nsamd::field_mlp_fwd_kernel",
     "nsamd_hashgrid_encode_fwd": "nsamd::hash_encode_fwd_kernel",
@@ -123,9 +131,17 @@ def roofline_entry(kernel, mean_ms, bound, work, main_points):
     else:
         ach, peak, unit = work / sec / 1e12, F32_MFMA_PEAK_TFLOPS, "TFLOP/s"
     base = kernel.split("[")[0]
+    rk = ROCPROF_KERNEL.get(kernel, ROCPROF_KERNEL.get(base))
     roof = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
             "traffic": pmc_traffic(kernel), "kernel": kernel, "avg_launch_ms": round(mean_ms, 4),
-            "algorithmic_per_launch": int(work), "rocprof_kernel": ROCPROF_KERNEL.get(base)}
+            "algorithmic_per_launch": int(work), "rocprof_kernel": rk}
+    if kernel == "nsamd_field_mlp_bwd_scatter_phase[gradients+records]":
+        # this launch also carries the table scatter's ROUTE pass: it derives and stores the x-pair records
+        # — HBM work that `achieved` (flops only) does not credit; `roofline_min_ms` adds its streaming time at the HBM peak
+        rec = main_points * 16 * 4 * 16
+        roof["fused_route_pass"] = {"record_bytes": int(rec),
+                                    "roofline_min_ms": round((work / (F32_MFMA_PEAK_TFLOPS * 1e12) + rec / (HBM_PEAK_GBS * 1e9)) * 1e3, 4),
+                                    "frac_of_roofline_min": round((work / (F32_MFMA_PEAK_TFLOPS * 1e12) + rec / (HBM_PEAK_GBS * 1e9)) / sec, 4)}
     ex = executed_per_launch(base, main_points)
     if ex is not None:  # the utilisation view (work the launch executes, incl. recomputation)
         roof["executed_per_launch"] = ex
@@ -157,8 +173,6 @@ def measure_roofline(trainer, arena, steps, main_points):
     table = []
     for key, (calls, total_ms, mean_ms) in prof.items():
         bound, work = algorithmic_model(key, main_points)
-        if key == "nsamd_adam_step":
-            work = arena.numel * 28
         table.append({"kernel": key, "calls_per_step": calls / steps, "ms_per_step": total_ms / steps, "mean_ms": mean_ms,
                       "bound": bound, "work": work})
     table.sort(key=lambda r: -r["ms_per_step"])

@@ -11,6 +11,7 @@
 struct uint4 { unsigned x, y, z, w; };
 typedef void* hipStream_t;
 #include "../../nerfstudio_amd/csrc/scatter.h"
+#include "../../nerfstudio_amd/csrc/camera.h"
 
 using namespace nsamd;
 
@@ -102,6 +103,33 @@ float hc_fixed_sum(const float* v, const int64_t* order, int64_t n, int k) {
   unsigned long long acc = 0ull;
   for (int64_t i = 0; i < n; ++i) acc += to_fixed(v[order[i]], k);
   return from_fixed(acc, k);
+}
+
+// ---- camera-pose corrections (csrc/camera.h) ----
+void hc_cam_exp_map(int mode, const float* pose, int64_t n, float* out /* [n,3,4] = [R|t] */) {
+  for (int64_t c = 0; c < n; ++c) {
+    float R[9], t[3];
+    cam_exp_map(mode, pose + 6 * c, R, t);
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) out[12 * c + 4 * i + j] = R[3 * i + j];
+      out[12 * c + 4 * i + 3] = t[i];
+    }
+  }
+}
+
+// upstream [n,3,4] = dL/d[R|t] -> dpose [n,6]; reg != 0: the regulariser's gradient is added (penalties / n as the mean does)
+void hc_cam_exp_map_bwd(int mode, const float* pose, const float* upstream, int64_t n, float trans_pen, float rot_pen,
+                        int reg, float* dpose) {
+  for (int64_t c = 0; c < n; ++c) {
+    double G[9], g[3], dp[6], dr[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) G[3 * i + j] = upstream[12 * c + 4 * i + j];
+      g[i] = upstream[12 * c + 4 * i + 3];
+    }
+    cam_exp_map_bwd(mode, pose + 6 * c, G, g, dp);
+    if (reg) cam_reg_bwd(pose + 6 * c, (double)trans_pen / n, (double)rot_pen / n, dr);
+    for (int k = 0; k < 6; ++k) dpose[6 * c + k] = (float)dp[k] + (float)dr[k];
+  }
 }
 
 }  // extern "C"

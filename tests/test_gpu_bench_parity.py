@@ -363,6 +363,7 @@ def test_field_mlp_backward_at_bench_size_vs_float64(F):
     n = 4096
     step = NerfactoTrainStep(model, n, torch.device("cuda"))
     step.side_stream = None
+    step.keep_denc = True  # the default launch (field backward + scatter records) leaves `f_denc` unwritten otherwise
     o, d, cam, tgt = orc.synthetic_rays(n, cfg.num_images, seed=21)
     step.set_batch(o.cuda(), d.cuda(), cam.cuda(), tgt.cuda())
     rs = np.random.RandomState(5)

@@ -45,6 +45,8 @@ def hc(tmp_path_factory):
     lib.hc_to_fixed.argtypes = [F32P, C.c_int64, C.c_int, I64P]
     lib.hc_fixed_sum.argtypes = [F32P, I64P, C.c_int64, C.c_int]
     lib.hc_fixed_sum.restype = C.c_float
+    lib.hc_cam_exp_map.argtypes = [C.c_int, F32P, C.c_int64, F32P]
+    lib.hc_cam_exp_map_bwd.argtypes = [C.c_int, F32P, F32P, C.c_int64, C.c_float, C.c_float, C.c_int, F32P]
     return lib
 
 
@@ -245,3 +247,50 @@ def test_fixed_sums_do_not_depend_on_the_order(hc):
     float_sums = {np.float32(np.sum(v[np.random.RandomState(s).permutation(v.shape[0])], dtype=np.float32)).tobytes()
                   for s in range(6)}
     assert len(float_sums) > 1  # the same data summed in fp32 does depend on the order
+
+
+@pytest.mark.parametrize("mode", ["SO3xR3", "SE3"])
+def test_camera_exponential_maps_and_their_backward(hc, mode):
+    """csrc/camera.h (nsamd_camera_apply / nsamd_camera_backward run these per camera on the device) against this package's
+    torch mirror of cameras/lie_groups.py:25-117 — itself pinned to the reference's CameraOptimizer by
+    tests/golden/camera_opt.npz — and torch autograd through it: every branch (the 1e-4 clamp of SO3xR3, the Taylor forms of
+    SE3 below |w| = 1e-2, the exact zero the parameter starts from), and the L2 regulariser of camera_optimizers.py:179-185."""
+    from nerfstudio_amd.cameras.camera_optimizers import CameraOptimizer, CameraOptimizerConfig
+    from nerfstudio_amd.cameras.lie_groups import exp_map_SE3, exp_map_SO3xR3
+
+    rs = np.random.RandomState(3)
+    n = 64
+    pose = rs.normal(0, 0.3, (n, 6)).astype(np.float32)
+    pose[:8, 3:] *= 1e-3                      # |w| ~ 5e-4: below both branch points
+    pose[8:16, 3:] *= 2e-2                    # |w| ~ 1e-2: around them
+    pose[16] = 0.0                            # the initial state of the parameter
+    pose[17, 3:] = 0.0                        # pure translation
+    pose[18, :3] = 0.0                        # pure rotation
+    up = rs.normal(0, 1, (n, 3, 4)).astype(np.float32)
+    fn = exp_map_SO3xR3 if mode == "SO3xR3" else exp_map_SE3
+    p = torch.from_numpy(pose.astype(np.float64)).requires_grad_(True)
+    out64 = fn(p)
+    (out64 * torch.from_numpy(up.astype(np.float64))).sum().backward()
+    want_out32 = fn(torch.from_numpy(pose)).numpy()
+    code = 1 if mode == "SO3xR3" else 2
+    got = np.zeros((n, 3, 4), np.float32)
+    hc.hc_cam_exp_map(code, pose, n, got.reshape(-1))
+    # forward: fp32, the reference's operations -> within a few ulp of the fp32 torch evaluation; float64 is further away
+    # where the reference's own fp32 forms cancel ((1 - cos t) / t^2 right above the Taylor branch point)
+    np.testing.assert_allclose(got, want_out32, rtol=0, atol=3e-7)
+    np.testing.assert_allclose(got, out64.detach().numpy(), rtol=0, atol=2e-6)
+    gp = np.zeros((n, 6), np.float32)
+    hc.hc_cam_exp_map_bwd(code, pose, up.reshape(-1), n, 0.0, 0.0, 0, gp.reshape(-1))
+    want = p.grad.numpy()
+    np.testing.assert_allclose(gp, want, rtol=2e-5, atol=2e-6)
+    # + the regulariser (mean over cameras of the two norms; zero gradient where a norm is zero, as torch masks it)
+    cfg = CameraOptimizerConfig(mode=mode, trans_l2_penalty=1e-2, rot_l2_penalty=1e-3)
+    opt = CameraOptimizer(cfg, num_cameras=n, device="cpu").double()
+    with torch.no_grad():
+        opt.pose_adjustment.copy_(torch.from_numpy(pose.astype(np.float64)))
+    ld = {}
+    opt.get_loss_dict(ld)
+    c = opt(torch.arange(n))
+    ((c * torch.from_numpy(up.astype(np.float64))).sum() + ld["camera_opt_regularizer"]).backward()
+    hc.hc_cam_exp_map_bwd(code, pose, up.reshape(-1), n, 1e-2, 1e-3, 1, gp.reshape(-1))
+    np.testing.assert_allclose(gp, opt.pose_adjustment.grad.numpy(), rtol=2e-5, atol=2e-6)
