@@ -6,6 +6,7 @@ That gradient is produced on the device (nsamd_hashgrid_encode_bwd_rays: dL/dpos
 selector, the affine map and the contraction Jacobian, reduced per ray); the `[num_cameras, 6]` parameter, the
 exponential map and the regulariser are host-side torch, as in the reference.
 """
+import os
 from dataclasses import dataclass
 from typing import Literal, Optional, Union
 
@@ -64,6 +65,15 @@ class CameraOptimizer(nn.Module):
         """origins + t, R @ directions for rays `[n,3]` of cameras `[n]` (the arithmetic of apply_to_raybundle)."""
         if self.config.mode == "off":
             return origins, directions
+        pose = self.pose_adjustment
+        if (pose.is_cuda and pose.dtype == torch.float32 and self.non_trainable_camera_indices is None and origins.is_cuda
+                and not origins.requires_grad and not directions.requires_grad and origins.dim() == 2
+                and os.environ.get("NSAMD_CAMERA_KERNELS", "1") == "1"):
+            # the two camera kernels (functional.camera_correct_rays) — the same launches the explicit schedule makes, so
+            # both routes hand identical rays to the field
+            from .. import functional as F
+
+            return F.camera_correct_rays(pose, self.config.mode, origins, directions, camera_indices)
         c = self(camera_indices.reshape(-1))
         return origins + c[:, :3, 3], torch.bmm(c[:, :3, :3], directions[..., None]).squeeze(-1)
 

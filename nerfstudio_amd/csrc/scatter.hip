@@ -478,11 +478,15 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
               nn[u] = (uint32_t)__builtin_amdgcn_readlane((int)cv, j);
               ss[u] = wave + (c0 + (uint32_t)j) * nw;
             }
+            // UNCONDITIONAL loads (a lane past the count re-reads the segment's first record: same line, no extra traffic):
+            // a lane-predicated load compiles to a branch around it, and with loads inside branches the compiler settles
+            // every wait of this loop with s_waitcnt vmcnt(0) — the prefetch of the next trip was waited for together with
+            // the current one (read off the ISA; the "software pipeline" was four exposed memory latencies per tile and wave)
             const uint4* seg = q + (size_t)ss[u] * C;
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
               const uint32_t e = (uint32_t)lane + 64u * v;
-              rr[u][v] = e < nn[u] ? rec_load(seg + e) : make_uint4(0u, 0u, 0u, 0u);
+              rr[u][v] = rec_load(seg + (e < nn[u] ? e : 0u));
             }
           }
         };
@@ -515,7 +519,7 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const uint32_t e = e0 + (uint32_t)u * blockDim.x + threadIdx.x;
-        r[u] = e < n_dyn ? rec_load(dq + e) : make_uint4(0u, 0u, 0u, 0u);
+        r[u] = rec_load(dq + (e < n_dyn ? e : 0u));  // (unconditional: see the static segments)
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -750,10 +754,16 @@ ScatterPlan scatter_plan_producers(const nsamd_grid& grid, int64_t M, int workgr
   return p;
 }
 
+// 128 KiB of dynamic LDS need the opt-in, per device
 static int apply_lds_attribute() {
-  {
-    const int rc = apply_lds_attribute();
-    if (rc) return rc;
+  static bool attr_done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return NSAMD_ERR_NO_DEVICE;
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_apply_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16u << kSliceLog2Max)) != hipSuccess)
+      return NSAMD_ERR_LAUNCH;
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
   return NSAMD_OK;
 }

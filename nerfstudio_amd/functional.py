@@ -909,6 +909,53 @@ def distortion_loss(weights: Tensor, s_bins: Tensor) -> Tensor:
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# a3  camera-pose corrections of the rays
+# ---------------------------------------------------------------------------------------------------------------
+CAMERA_MODES = {"SO3xR3": 1, "SE3": 2}
+
+
+class _CameraRaysFn(torch.autograd.Function):
+    """CameraOptimizer.apply_to_raybundle (cameras/camera_optimizers.py:148-153) on the pose parameter: one launch forward
+    (nsamd_camera_apply), one launch backward (nsamd_camera_backward: per-camera sums of dL/d(origins, directions) in double
+    in a fixed order, then the exponential map's closed-form backward) instead of the index / exp-map / bmm chain of torch
+    kernels and their autograd nodes. The regulariser (:179-185) stays with the caller's loss dict."""
+
+    @staticmethod
+    def forward(ctx, pose: Tensor, origins: Tensor, directions: Tensor, cams: Tensor, mode: int):
+        N.require_cuda(pose, origins, directions, cams)
+        raw_o, raw_d = _f32c(origins.reshape(-1, 3)), _f32c(directions.reshape(-1, 3))
+        idx = cams.reshape(-1).contiguous().to(torch.int64)
+        p = _f32c(pose)
+        n = raw_o.shape[0]
+        o, d = torch.empty_like(raw_o), torch.empty_like(raw_d)
+        N.check(N.load().nsamd_camera_apply(N.ptr(p), mode, p.shape[0], N.ptr(raw_o), N.ptr(raw_d), N.ptr(idx), n, N.ptr(o),
+                                            N.ptr(d), N.stream()), "camera_apply")
+        ctx.save_for_backward(p, raw_d, idx)
+        ctx.mode = mode
+        ctx.pose_param = pose
+        return o.reshape(origins.shape), d.reshape(directions.shape)
+
+    @staticmethod
+    def backward(ctx, g_o: Optional[Tensor], g_d: Optional[Tensor]):
+        p, raw_d, idx = ctx.saved_tensors
+        n = raw_d.shape[0]
+        g_o = torch.zeros_like(raw_d) if g_o is None else _f32c(g_o.reshape(-1, 3))
+        g_d = torch.zeros_like(raw_d) if g_d is None else _f32c(g_d.reshape(-1, 3))
+        buf, ret = _grad_target(ctx.pose_param, True)
+        up = N.RayGrads()
+        up.d_origins[0], up.d_directions[0], up.count = N.ptr(g_o), N.ptr(g_d), 1
+        N.check(N.load().nsamd_camera_backward(N.ptr(p), ctx.mode, p.shape[0], N.ptr(raw_d), N.ptr(idx), n, up, 0.0, 0.0,
+                                               N.ptr(buf), None, N.stream()), "camera_backward")
+        return ret, None, None, None, None
+
+
+def camera_correct_rays(pose: Tensor, mode: str, origins: Tensor, directions: Tensor, camera_indices: Tensor):
+    """origins + t(c), R(c) directions for the camera c of every ray; `pose` [num_cameras, 6] = (translation, rotation
+    vector), mode "SO3xR3" / "SE3" (cameras/lie_groups.py:25-117). The rays themselves are treated as constants."""
+    return _CameraRaysFn.apply(pose, origins, directions, camera_indices, CAMERA_MODES[mode])
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # a1  pinhole ray generation
 # ---------------------------------------------------------------------------------------------------------------
 @torch.no_grad()

@@ -518,8 +518,9 @@ class NerfactoTrainStep:
            "proposal_losses")
 
     @profiler.time_function
-    def backward_main(self) -> None:
-        """composite -> weights -> field MLPs -> main hash table (MSE + distortion gradients)."""
+    def backward_main(self, field: bool = True) -> None:
+        """composite -> weights -> field MLPs -> main hash table (MSE + distortion gradients). `field=False`: stop before
+        the field's MLPs (the caller runs `backward_field_and_table`)."""
         lib, st, n = N.load(), N.stream(), self.n
         ck = N.check
         L = self.n_prop
@@ -531,7 +532,8 @@ class NerfactoTrainStep:
         if self.gradient_scaling:  # scale_gradients_by_distance_squared on the field's outputs (models/nerfacto.py:321-322)
             ck(lib.nsamd_distance_gradient_scale(N.ptr(self.t_bins[L]), n, S, N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s), st),
                "distance_gradient_scale")
-        self.backward_field_and_table()
+        if field:
+            self.backward_field_and_table()
 
     def backward_field_and_table(self) -> None:
         """Second half of backward_main: the main field's MLPs (from `d_dens_main`, `d_rgb_s`) and the table scatter. Separate

@@ -636,17 +636,37 @@ def test_camera_optimizer_gradients_golden(F, golden, mode):
     ld = runner.loss_dict()
     for k, name in enumerate(("rgb_loss", "interlevel_loss", "distortion_loss", "camera_opt_regularizer")):
         close(ld[name], ref_losses[k], rtol=1e-3)
-    # ... bit-reproducibly (per-camera sums in a fixed order), and equal to the torch route (autograd over the exponential
-    # map, NSAMD_CAMERA_KERNELS=0) to rounding
+    # ... bit-reproducibly (per-camera sums in a fixed order) ...
     first = g_pose.detach().clone()
     arena.zero_grad(skip=runner.written_params())
     runner.forward_backward(True, draw_jitter=False)
     assert torch.equal(g_pose, first)
-    runner.cam_kernels = False
-    arena.zero_grad(skip=runner.written_params())
-    runner.forward_backward(True, draw_jitter=False)
-    assert rel(g_pose, first.cpu().numpy()) <= 1e-5, rel(g_pose, first.cpu().numpy())
-    close(runner.loss_dict()["camera_opt_regularizer"], ref_losses[3], rtol=1e-3)
+    # ... equal to torch autograd over the mirror's exponential map on the SAME per-ray upstream gradients (the backward
+    # kernel alone: identical inputs, so this one is tight) ...
+    from nerfstudio_amd.cameras.lie_groups import exp_map_SE3, exp_map_SO3xR3
+
+    co = model.camera_optimizer
+    p2 = co.pose_adjustment.detach().clone().requires_grad_(True)
+    c = (exp_map_SO3xR3 if mode == "SO3xR3" else exp_map_SE3)(p2[runner.camera_indices])
+    o2 = runner.raw_origins + c[:, :3, 3]
+    d2 = torch.bmm(c[:, :3, :3], runner.raw_directions[..., None]).squeeze(-1)
+    reg2 = (p2[:, :3].norm(dim=-1).mean() * co.config.trans_l2_penalty + p2[:, 3:].norm(dim=-1).mean() * co.config.rot_l2_penalty)
+    ((o2 * d_o).sum() + (d2 * d_d).sum() + reg2).backward()
+    assert rel(first, p2.grad.cpu().numpy()) <= 1e-5, rel(first, p2.grad.cpu().numpy())
+    # ... and to the all-torch route (NSAMD_CAMERA_KERNELS=0: index / exp map / bmm and autograd through them) within what an
+    # ulp on a ray does to this gradient: the two routes round origins / directions differently in the last bit, samples at
+    # t ~ 1000 move, cells flip (the conditioning the golden bound above carries as well)
+    import os
+
+    os.environ["NSAMD_CAMERA_KERNELS"] = "0"
+    try:
+        runner.cam_kernels = False
+        arena.zero_grad(skip=runner.written_params())
+        runner.forward_backward(True, draw_jitter=False)
+        assert runner._corrected is None and rel(g_pose, first.cpu().numpy()) <= 5e-3, rel(g_pose, first.cpu().numpy())
+        close(runner.loss_dict()["camera_opt_regularizer"], ref_losses[3], rtol=1e-3)
+    finally:
+        del os.environ["NSAMD_CAMERA_KERNELS"]
     runner.cam_kernels = True
     arena.zero_grad(skip=runner.written_params())
     runner.forward_backward(True, draw_jitter=False)
