@@ -25,6 +25,30 @@
   } while (0)
 #endif
 
+#if defined(__HIPCC__)
+// A pointer the compiler cannot trace back to a kernel argument (read from LDS, from a struct in memory, passed to a
+// non-inlined function) is GENERIC, and its accesses compile to FLAT instructions. Those count in vmcnt AND lgkmcnt, and a
+// wave's next `s_waitcnt lgkmcnt` — every LDS operand fetch of the MFMA loops — then waits for the flat access to come back
+// from memory: a fire-and-forget record store turns into a full L2 round trip on the matrix pipeline's critical path (read off
+// the ISA of the field backward that emits scatter records). Device buffers are global memory: say so.
+#define NSAMD_GLOBAL_AS __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const NSAMD_GLOBAL_AS T* global_ptr(const T* p) {
+  return (const NSAMD_GLOBAL_AS T*)p;
+}
+template <class T>
+__device__ __forceinline__ NSAMD_GLOBAL_AS T* global_ptr(T* p) {
+  return (NSAMD_GLOBAL_AS T*)p;
+}
+#endif
+
+// compiler barrier between two loads that must not be merged into one wider load (device code; nothing on the host)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NSAMD_KEEP_LOADS_APART() asm volatile("" ::: "memory")
+#else
+#define NSAMD_KEEP_LOADS_APART() do {} while (0)
+#endif
+
 #define NSAMD_REQUIRE(cond) \
   do {                      \
     if (!(cond)) return NSAMD_ERR_INVALID_ARG; \
@@ -72,6 +96,44 @@ NSAMD_HD void load_position(const nsamd_points& P, int64_t p, float& x, float& y
     y = o[1] + d[1] * span / 2.0f;
     z = o[2] + d[2] * span / 2.0f;
   }
+}
+
+// The same position with its eight loads issued back to back as single dwords (compiler barriers keep them from being merged
+// and re-ordered): ONE memory round trip. In the order of `load_position` — bin edges, their sum, then origin and direction —
+// the compiler waits for the edges before it issues the other loads (two round trips in a row), and merged into dwordx3 the
+// triples land in register tuples that are re-packed right behind the load (another wait). Worth it where the kernel is a chain
+// of latencies with few memory instructions per lane (the main-grid hash forward: 93.0 -> 89.3 us); NOT where the load / gather
+// instructions themselves are the bound (the fused proposal field, 40 gathers per lane: 43 -> 57 us with five more loads).
+NSAMD_HD void load_position_burst(const nsamd_points& P, int64_t p, float& x, float& y, float& z) {
+  if (P.positions != nullptr) {
+    load_position(P, p, x, y, z);
+    return;
+  }
+  const int64_t S = P.samples_per_ray;
+  const int64_t ray = p / S;
+  const int64_t s = p - ray * S;
+  const float* tb = P.t_bins + ray * (S + 1) + s;
+  const float* o = P.origins + 3 * ray;
+  const float* d = P.directions + 3 * ray;
+  const float o0 = o[0];
+  NSAMD_KEEP_LOADS_APART();
+  const float o1 = o[1];
+  NSAMD_KEEP_LOADS_APART();
+  const float o2 = o[2];
+  NSAMD_KEEP_LOADS_APART();
+  const float d0 = d[0];
+  NSAMD_KEEP_LOADS_APART();
+  const float d1 = d[1];
+  NSAMD_KEEP_LOADS_APART();
+  const float d2 = d[2];
+  NSAMD_KEEP_LOADS_APART();
+  const float t0 = tb[0];
+  NSAMD_KEEP_LOADS_APART();
+  const float t1 = tb[1];
+  const float span = t0 + t1;  // starts + ends
+  x = o0 + d0 * span / 2.0f;
+  y = o1 + d1 * span / 2.0f;
+  z = o2 + d2 * span / 2.0f;
 }
 
 // ---- L-inf scene contraction (spatial_distortions.py:66-69) ---------------------------------------------------

@@ -208,12 +208,32 @@ __device__ __forceinline__ void build_head_input(const float* __restrict__ direc
 }
 
 // encoded features: feature-major [32][M]; lane needs features 16t + 4g + r of its point
-__device__ __forceinline__ void load_enc_tile(const float* __restrict__ enc, int64_t M, int64_t p, int lane, v4f* out) {
+// Element (feature 16 t + 4 g + r, point p) of the feature-major [32, M] matrix = row base (16 t + r) M — uniform over the
+// wave: a scalar address — plus ONE per-lane 32-bit offset 4 g M + p. Written as (16 t + 4 g + r) M + p the compiler hoists
+// sixteen 64-bit per-lane products out of the tile loop: 32 loop-invariant VGPRs in kernels that run at the 256-register
+// limit (and spill). The host bounds M (kMaxFieldPoints) so that the offset fits 32 bits.
+constexpr int64_t kMaxFieldPoints = (int64_t)1 << 26;
+
+__device__ __forceinline__ uint32_t enc_lane_offset(int64_t M, int64_t p, int lane) {
+  return (uint32_t)(4 * (lane >> 4)) * (uint32_t)M + (uint32_t)p;
+}
+
+// (the forward kernels keep the plain form: at 112 VGPRs / 4 waves per SIMD they have room for the hoisted addresses, and
+//  with the scalar bases their allocation came out at 128 registers + spills)
+__device__ __forceinline__ void load_enc_tile_fwd(const float* __restrict__ enc, int64_t M, int64_t p, int lane, v4f* out) {
   const int g = lane >> 4;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[t][r] = enc[(int64_t)(16 * t + 4 * g + r) * M + p];
+}
+
+__device__ __forceinline__ void load_enc_tile(const float* __restrict__ enc, int64_t M, int64_t p, int lane, v4f* out) {
+  const uint32_t off = enc_lane_offset(M, p, lane);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[t][r] = (enc + (int64_t)(16 * t + r) * M)[off];
 }
 
 // view direction and appearance row of a lane's point, loaded ahead of the tile's arithmetic
@@ -338,7 +358,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 1 : 2) void field_mlp_fwd
     asm volatile("" ::: "memory");
     const TileInputs ti = tile_inputs(tile, lane, M, selector, cams, dir_group);
     FieldActs A;
-    load_enc_tile(enc, M, ti.p, lane, A.enc);
+    load_enc_tile_fwd(enc, M, ti.p, lane, A.enc);
     PROBE_STAMP(WAVES, 2 + 4 * probe_it);
     field_forward_tile(wf, bias, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A, 3 + 4 * probe_it);
     PROBE_STAMP(WAVES, 4 + 4 * probe_it);
@@ -492,7 +512,7 @@ __global__ __launch_bounds__(64 * kB3Waves, 1) void field_mlp_fwd_bf16x3_kernel(
     asm volatile("" ::: "memory");  // keep the fragments in LDS
     const TileInputs ti = tile_inputs(tile, lane, M, selector, cams, dir_group);
     v4f e[2];
-    load_enc_tile(enc, M, ti.p, lane, e);
+    load_enc_tile_fwd(enc, M, ti.p, lane, e);
     const HeadPre pre = load_head_pre(directions, app_table, app_const, app_dim, ti, g);
     Op3 x[2];
     v4f h1[4], o16[1], ha[4], hb[4], rgbp[1];
@@ -885,9 +905,16 @@ constexpr int kRouteCnt = kRouteLevels * (1 << kProducerMaxLog2Bins);
 // arguments the ~60 scalars stay live across the whole tile loop and spill (98 SGPRs / 27 VGPRs spilled in the first build).
 struct RouteLds {
   uint32_t cnt[kRouteCnt];          // [levels][bins] records of this workgroup per tile (rank counters)
-  uint32_t lmax[kRouteLevels];  // max |gradient| bits per level
-  float scal[kRouteLevels];
-  uint32_t loff[kRouteLevels];
+  // per level, ONE 16-byte record: a lane reads the scale, the queue offset and the running maximum of its four levels
+  // (8 t + 2 g + rr) through one address register and immediate offsets. As three arrays the compiler kept twelve
+  // loop-invariant addresses per lane, spilled five of them, and every reload inside the tile loop was an
+  // `s_waitcnt vmcnt(0)` — on this ISA stores count in vmcnt, so each one waited for the record stores in flight.
+  struct Level {
+    float scal;
+    uint32_t loff;
+    uint32_t lmax;  // max |gradient| bits
+    uint32_t pad;
+  } lv[kRouteLevels];
   nsamd_points P;
   nsamd_aabb box;
   int32_t transform, num_levels, log2_table_size, slice_log2, log2_bins;
@@ -904,10 +931,12 @@ constexpr int kRouteLdsWords = (sizeof(RouteLds) + 3) / 4;
 static_assert(sizeof(float) * (kRowTotal + 256 + kCoopWaves * 2 * kScratchTile) + sizeof(RouteLds) <= 160 * 1024, "160 KiB of LDS per CU");
 
 __device__ __forceinline__ void route_lds_init(RouteLds* L, const RouteArgs& R) {
-  for (int e = threadIdx.x; e < kRouteCnt + kRouteLevels; e += kCoopThreads) L->cnt[e] = 0u;  // cnt, then lmax
+  for (int e = threadIdx.x; e < kRouteCnt; e += kCoopThreads) L->cnt[e] = 0u;
   if (threadIdx.x < kRouteLevels) {
-    L->scal[threadIdx.x] = R.grid.scalings[threadIdx.x];
-    L->loff[threadIdx.x] = R.G.level_off[threadIdx.x];
+    L->lv[threadIdx.x].scal = R.grid.scalings[threadIdx.x];
+    L->lv[threadIdx.x].loff = R.G.level_off[threadIdx.x];
+    L->lv[threadIdx.x].lmax = 0u;
+    L->lv[threadIdx.x].pad = 0u;
   }
   if (threadIdx.x == 0) {
     L->P = R.P;
@@ -944,7 +973,6 @@ __device__ __forceinline__ void route_spill(RouteLds* L, uint32_t tile, uint4 re
   }
 }
 
-constexpr uint32_t kRankSkip = 0xffffffffu;
 
 // Slow path of one record (pair q of a level): the pair straddles two tiles, or its static segment is full — the tile's
 // dynamic area (one returning global atomic), then the spill list. Re-derives the record; reached by a handful of records
@@ -954,7 +982,7 @@ __device__ __noinline__ void route_record_slow(RouteLds* L, float x, float y, fl
   const uint32_t mask = (1u << L->log2_table_size) - 1u;
   const int sl = L->slice_log2, lb = L->log2_bins;
   const uint32_t local_mask = (1u << sl) - 1u;
-  const Cell c = locate_cell(x, y, z, L->scal[level]);
+  const Cell c = locate_cell(x, y, z, L->lv[level].scal);
   const PairHash h = pair_hash(c, q, mask);
   const uint32_t bin = h.ia >> sl, tile0 = (uint32_t)level << lb;
   const float bz = (q & 2) ? c.w[2] : 1.0f - c.w[2];
@@ -971,80 +999,116 @@ __device__ __noinline__ void route_record_slow(RouteLds* L, float x, float y, fl
                                (h.ia & local_mask) | ((h.ib & local_mask) << 14) | 0x80000000u);
   const uint32_t Q = L->level_cap, static_end = L->static_end;
   const uint32_t pos = atomicAdd(L->dyn_cursor + (tile0 + bin), 1u);
-  if (pos < Q - static_end) rec_store(L->queues + (L->loff[level] + bin * Q + static_end + pos), rec);
+  if (pos < Q - static_end) rec_store(L->queues + (L->lv[level].loff + bin * Q + static_end + pos), rec);
   else route_spill(L, tile0 + bin, rec);
 }
 
-// ONE record — pair Q of the lane's level K (K = 0..3 -> chain-layout slot (t, rr) = (K >> 1, K & 1), level 8 t + 2 g + rr) —
-// of the tile whose feature gradients and normalised positions sit in this wave's stash rows. The 16 records of a tile leave
-// one at a time, SPREAD over the next tile's iteration between its GEMMs: all waves storing their 16 records at once is a burst
-// of 8192 scattered 16-B write requests per CU that drains at the L2's request rate (~16 k clocks per tile with every matrix
-// core idle, profiles/r04_fused_route_probe.txt) — one store per wave every ~3 k clocks disappears beside the MFMA work.
-template <int K, int Q>
-__device__ __forceinline__ void route_step(RouteLds* L, const float (*stash)[64], int lane, int probe_skip) {
+// The FOUR records of the lane's level K at once — the stash reads, the cell and the level's constants are shared, the four
+// rank atomics are in flight together, the four stores leave back to back. (One record at a time was the schedule while the
+// record stores were FLAT instructions — each held up the wave's next LDS wait for a full L2 round trip, so they had to be
+// kept apart —; as global stores they are fire-and-forget, and what is left of a record is its chain of ~6 dependent LDS
+// round trips, which four records now share.)
+template <int K>
+__device__ __forceinline__ void route_level(RouteLds* L, const float (*stash)[64], int lane, int probe_skip) {
   constexpr int t = K >> 1, rr = K & 1;
   const int g = lane >> 4;
   const int level = 8 * t + 2 * g + rr;
   const float g0 = stash[4 * t + 2 * rr][lane], g1 = stash[4 * t + 2 * rr + 1][lane];
   if (level >= L->num_levels || (g0 == 0.0f && g1 == 0.0f)) return;  // adding zero is a no-op (NaN != 0: kept); dead lanes hold zeros
   const float x = stash[8][lane], y = stash[9][lane], z = stash[10][lane];
-  const Cell c = locate_cell(x, y, z, L->scal[level]);
-  if (Q == 0) {  // integer compare of |bits|: a NaN or Inf wins and marks the level non-finite
+  const Cell c = locate_cell(x, y, z, L->lv[level].scal);
+  {  // integer compare of |bits|: a NaN or Inf wins and marks the level non-finite
     const uint32_t b0 = __float_as_uint(g0) & 0x7fffffffu, b1 = __float_as_uint(g1) & 0x7fffffffu;
-    atomicMax(L->lmax + level, b0 > b1 ? b0 : b1);
+    atomicMax(&L->lv[level].lmax, b0 > b1 ? b0 : b1);
   }
   const uint32_t mask = (1u << L->log2_table_size) - 1u;
   const int sl = L->slice_log2;
   const uint32_t local_mask = (1u << sl) - 1u;
-  const PairHash h = pair_hash(c, Q, mask);
-  const uint32_t bin = h.ia >> sl;
-  const bool straddle = (h.ib >> sl) != bin;
   const uint32_t C = L->seg_cap;
-  const uint32_t rank = (probe_skip & 16) ? (uint32_t)(threadIdx.x & 127)
-                                          : atomicAdd(L->cnt + ((uint32_t)level << L->log2_bins) + bin, 1u);  // ds_add_rtn_u32
-  // autograd order ((g * wz) * wy) * wx; the x factor is applied by pass 2
-  const float bz = (Q & 2) ? c.w[2] : 1.0f - c.w[2];
-  const float by = (Q & 1) ? c.w[1] : 1.0f - c.w[1];
-  // (a straddling pair has taken a rank like any other: its slot gets a record that adds zero, the two halves leave
-  //  through the slow path)
-  const uint4 rec = make_uint4(straddle ? 0u : __float_as_uint((g0 * bz) * by), straddle ? 0u : __float_as_uint((g1 * bz) * by),
-                               __float_as_uint(c.w[0]),
-                               (h.ia & local_mask) | ((straddle ? h.ia : h.ib) & local_mask) << 14 | 0x80000000u);
-  const bool full = rank >= C;
-  // (record indices fit 32 bits: the plan checks queue_records < 2^31)
-  if (!full && !(probe_skip & 8)) rec_store(L->queues + (L->loff[level] + blockIdx.x * C + bin * L->level_cap + rank), rec);
-  if (straddle || full) route_record_slow(L, x, y, z, g0, g1, level, Q, full && !straddle);
+  uint32_t* const cnt = L->cnt + ((uint32_t)level << L->log2_bins);
+  PairHash h[4];
+  uint32_t rank[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) h[q] = pair_hash(c, q, mask);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    rank[q] = (probe_skip & 16) ? (uint32_t)(threadIdx.x & 127) : atomicAdd(cnt + (h[q].ia >> sl), 1u);  // ds_add_rtn_u32
+  uint4* const base = L->queues + (L->lv[level].loff + blockIdx.x * C);
+  const uint32_t level_cap = L->level_cap;
+  bool slow[4], full[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t bin = h[q].ia >> sl;
+    const bool straddle = (h[q].ib >> sl) != bin;
+    // autograd order ((g * wz) * wy) * wx; the x factor is applied by pass 2
+    const float bz = (q & 2) ? c.w[2] : 1.0f - c.w[2];
+    const float by = (q & 1) ? c.w[1] : 1.0f - c.w[1];
+    // (a straddling pair has taken a rank like any other: its slot gets a record that adds zero, the two halves leave
+    //  through the slow path)
+    const uint4 rec = make_uint4(straddle ? 0u : __float_as_uint((g0 * bz) * by), straddle ? 0u : __float_as_uint((g1 * bz) * by),
+                                 __float_as_uint(c.w[0]),
+                                 (h[q].ia & local_mask) | ((straddle ? h[q].ia : h[q].ib) & local_mask) << 14 | 0x80000000u);
+    full[q] = rank[q] >= C;
+    slow[q] = straddle || full[q];
+    // (record indices fit 32 bits: the plan checks queue_records < 2^31)
+    if (!full[q] && !(probe_skip & 8)) rec_store(base + (bin * level_cap + rank[q]), rec);
+    full[q] = full[q] && !straddle;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (slow[q]) route_record_slow(L, x, y, z, g0, g1, level, q, full[q]);
 }
 
 // every record of the stashed tile at once (after the last tile of a workgroup; emission of a tile normally rides on the next one)
 __device__ __forceinline__ void route_flush(RouteLds* L, const float (*stash)[64], int lane, int probe_skip) {
-  route_step<0, 0>(L, stash, lane, probe_skip); route_step<0, 1>(L, stash, lane, probe_skip);
-  route_step<0, 2>(L, stash, lane, probe_skip); route_step<0, 3>(L, stash, lane, probe_skip);
-  route_step<1, 0>(L, stash, lane, probe_skip); route_step<1, 1>(L, stash, lane, probe_skip);
-  route_step<1, 2>(L, stash, lane, probe_skip); route_step<1, 3>(L, stash, lane, probe_skip);
-  route_step<2, 0>(L, stash, lane, probe_skip); route_step<2, 1>(L, stash, lane, probe_skip);
-  route_step<2, 2>(L, stash, lane, probe_skip); route_step<2, 3>(L, stash, lane, probe_skip);
-  route_step<3, 0>(L, stash, lane, probe_skip); route_step<3, 1>(L, stash, lane, probe_skip);
-  route_step<3, 2>(L, stash, lane, probe_skip); route_step<3, 3>(L, stash, lane, probe_skip);
+  route_level<0>(L, stash, lane, probe_skip);
+  route_level<1>(L, stash, lane, probe_skip);
+  route_level<2>(L, stash, lane, probe_skip);
+  route_level<3>(L, stash, lane, probe_skip);
 }
 
-// Raw position of this lane's point of a tile (ray mode: one 32-bit division per lane for the ray index); false: no point.
-__device__ __forceinline__ bool route_load_position(const RouteLds* L, int64_t tile, int64_t tiles, int64_t M,
-                                                    int64_t dir_group, int lane, float& x, float& y, float& z) {
+// Raw position of this lane's point of a tile, in two halves: `route_issue_position` puts the loads out (one phase ahead of
+// their use: behind the base-layer-1 barrier, consumed after base layer 0's data-gradient GEMM), `route_finish_position` forms
+// the position. The loads are UNCONDITIONAL — the common layout (rays + bin edges, one ray per `dir_group` samples) reads its
+// three arrays, any other layout reads a dummy address here and takes `load_position` in the second half: loads inside a
+// branch would be waited for at the branch's end (see fetch_tile).
+struct RawPosition {
+  float o[3], d[3], t0, t1;
+};
+
+__device__ __forceinline__ bool route_ray_layout(const RouteLds* L, int64_t dir_group) {
+  return L->P.positions == nullptr && (int64_t)L->P.samples_per_ray == dir_group;
+}
+
+__device__ __forceinline__ void route_issue_position(const RouteLds* L, int64_t tile, int64_t tiles, int64_t M,
+                                                     int64_t dir_group, int lane, RawPosition& rp) {
+  const int64_t pt = tile * 16 + (lane & 15);
+  const bool rays = route_ray_layout(L, dir_group) && tile < tiles && pt < M;
+  const int64_t p = rays ? pt : 0;
+  const int64_t S = dir_group, ray = ray_of(p, S), s = p - ray * S;
+  // (pointers that live in LDS: global_ptr, or these are flat loads — common.h)
+  const NSAMD_GLOBAL_AS float* dummy = global_ptr(reinterpret_cast<const float*>(L->hdr));
+  const NSAMD_GLOBAL_AS float* tb = rays ? global_ptr(L->P.t_bins) + ray * (S + 1) + s : dummy;
+  const NSAMD_GLOBAL_AS float* o = rays ? global_ptr(L->P.origins) + 3 * ray : dummy;
+  const NSAMD_GLOBAL_AS float* d = rays ? global_ptr(L->P.directions) + 3 * ray : dummy;
+  rp.o[0] = o[0], rp.o[1] = o[1], rp.o[2] = o[2];
+  rp.d[0] = d[0], rp.d[1] = d[1], rp.d[2] = d[2];
+  rp.t0 = tb[0], rp.t1 = tb[1];
+}
+
+// false: no point
+__device__ __forceinline__ bool route_finish_position(const RouteLds* L, const RawPosition& rp, int64_t tile, int64_t tiles,
+                                                      int64_t M, int64_t dir_group, int lane, float& x, float& y, float& z) {
   const int64_t p = tile * 16 + (lane & 15);
   x = y = z = 0.0f;
   if (!(tile < tiles && p < M)) return false;
-  if (L->P.positions != nullptr || (int64_t)L->P.samples_per_ray != dir_group) {
+  if (!route_ray_layout(L, dir_group)) {
     load_position(L->P, p, x, y, z);
-  } else {
-    const int64_t S = dir_group, ray = ray_of(p, S), s = p - ray * S;
-    const float* tb = L->P.t_bins + ray * (S + 1) + s;
-    const float span = tb[0] + tb[1];
-    const float* o = L->P.origins + 3 * ray;
-    const float* d = L->P.directions + 3 * ray;
-    x = o[0] + d[0] * span / 2.0f;
-    y = o[1] + d[1] * span / 2.0f;
-    z = o[2] + d[2] * span / 2.0f;
+  } else {  // Frustums.get_positions (cameras/rays.py:50-59), the operations of common.h's load_position
+    const float span = rp.t0 + rp.t1;
+    x = rp.o[0] + rp.d[0] * span / 2.0f;
+    y = rp.o[1] + rp.d[1] * span / 2.0f;
+    z = rp.o[2] + rp.d[2] * span / 2.0f;
   }
   return true;
 }
@@ -1053,13 +1117,19 @@ __device__ __forceinline__ bool route_load_position(const RouteLds* L, int64_t t
 // base-layer-0 barrier and BEFORE that tile's records are stored — vector memory operations of a wave retire in order, so
 // loads issued behind the 16 scattered record stores would wait for the whole burst to drain through the L2).
 struct TileFetch {
-  TileInputs ti;
+  TileInputs ti;   // (sel, cam: RAW loads, see tile_fetched)
   v4f enc[2];
-  float up_rgb[3], up_density;
+  float up[4];     // RAW drgb[0..2], ddensity of the lane's point
   float dir[3];
-  v4f app[2];
+  v4f app[2];      // RAW appearance row slice
 };
 
+// Every load here is UNCONDITIONAL and nothing loaded is touched (no select, no copy) before `tile_fetched` runs at the top of
+// the next iteration: a load inside a branch — even a uniform one on a null pointer — makes the compiler close the branch with
+// `s_waitcnt vmcnt(0)`, which exposed the whole fetch (and, stores counting in vmcnt on this ISA, every record store in
+// flight) right here instead of behind the base-layer-0 weight-gradient GEMM that follows. Absent inputs read a valid dummy
+// address (`enc`) and are replaced by their constants in `tile_fetched`. The camera index is loaded first and waited for
+// with the other loads in flight behind it (its appearance row is the one dependent load).
 __device__ __forceinline__ void fetch_tile(TileFetch& f, int64_t tile, int64_t tiles, int lane, int64_t M,
                                            const float* __restrict__ enc, const float* __restrict__ selector,
                                            const float* __restrict__ directions, const int64_t* __restrict__ cams,
@@ -1067,28 +1137,41 @@ __device__ __forceinline__ void fetch_tile(TileFetch& f, int64_t tile, int64_t t
                                            int app_dim, int64_t dir_group, const float* __restrict__ ddensity,
                                            const float* __restrict__ drgb) {
   const int g = lane >> 4;
-  f.ti = tile_inputs(tile < tiles ? tile : tiles - 1, lane, M, selector, cams, dir_group);
-  if (tile >= tiles) f.ti.live = false;  // idle wave of the last round: computes, contributes zeros
+  const int64_t t = tile < tiles ? tile : tiles - 1;
+  const int64_t p = t * 16 + (lane & 15);
+  f.ti.live = p < M && tile < tiles;  // (tile >= tiles: idle wave of the last round — computes, contributes zeros)
+  f.ti.p = p < M ? p : M - 1;
+  f.ti.ray = ray_of(f.ti.p, dir_group);
+  const int64_t* cam_src = cams != nullptr ? cams + f.ti.ray : reinterpret_cast<const int64_t*>(enc);
+  f.ti.cam = *cam_src;
+  f.ti.sel = (selector != nullptr ? selector : enc)[f.ti.p];
   load_enc_tile(enc, M, f.ti.p, lane, f.enc);
-  f.up_rgb[0] = f.up_rgb[1] = f.up_rgb[2] = f.up_density = 0.f;
-  if (g == 0 && f.ti.live) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) f.up_rgb[c] = drgb[3 * f.ti.p + c];
-    f.up_density = ddensity[f.ti.p];
-  }
+  // (single-dword loads kept apart by compiler barriers: merged into dwordx3 the triples land in register tuples that are
+  //  re-shuffled with v_mov right behind the load — a wait for the whole fetch at the fetch site, the thing this avoids)
+#define NSAMD_KEEP_APART() asm volatile("" ::: "memory")
+  f.up[0] = drgb[3 * f.ti.p + 0];
+  NSAMD_KEEP_APART();
+  f.up[1] = drgb[3 * f.ti.p + 1];
+  NSAMD_KEEP_APART();
+  f.up[2] = drgb[3 * f.ti.p + 2];
+  NSAMD_KEEP_APART();
+  f.up[3] = ddensity[f.ti.p];
   const float* d = directions + 3 * f.ti.ray;
-  f.dir[0] = d[0]; f.dir[1] = d[1]; f.dir[2] = d[2];
-  if (app_dim > 0) {
-    const float* src = (app_table != nullptr) ? app_table + f.ti.cam * 32 : app_const;
-    f.app[0] = *reinterpret_cast<const v4f*>(src + 4 * g);
-    f.app[1] = *reinterpret_cast<const v4f*>(src + 16 + 4 * g);
-  } else {
-    f.app[0] = v4f{0.f, 0.f, 0.f, 0.f};
-    f.app[1] = v4f{0.f, 0.f, 0.f, 0.f};
-  }
+  f.dir[0] = d[0];
+  NSAMD_KEEP_APART();
+  f.dir[1] = d[1];
+  NSAMD_KEEP_APART();
+  f.dir[2] = d[2];
+  NSAMD_KEEP_APART();
+#undef NSAMD_KEEP_APART
+  const float* src = app_table != nullptr ? app_table + (cams != nullptr ? f.ti.cam : 0) * 32
+                                          : (app_const != nullptr ? app_const : enc);
+  f.app[0] = *reinterpret_cast<const v4f*>(src + 4 * g);
+  f.app[1] = *reinterpret_cast<const v4f*>(src + 16 + 4 * g);
 }
 
-// the record stores that ride on a tile's forward recomputation: records 0..5 of the previous tile (see route_step)
+// the record stores that ride on a tile's forward recomputation: the previous tile's levels K = 0 (behind base layer 0's
+// GEMM) and K = 1 (behind head layer 0's); K = 2, 3 leave between the backward phases
 struct RouteBetween {
   RouteLds* L;
   const float (*stash)[64];
@@ -1097,15 +1180,14 @@ struct RouteBetween {
   template <int I>
   __device__ __forceinline__ void at() const {
     if (!on) return;
-    if (I == 0) route_step<0, 0>(L, stash, lane, probe_skip);
-    if (I == 1) route_step<0, 1>(L, stash, lane, probe_skip);
-    if (I == 2) { route_step<0, 2>(L, stash, lane, probe_skip); route_step<0, 3>(L, stash, lane, probe_skip); }
-    if (I == 3) { route_step<1, 0>(L, stash, lane, probe_skip); route_step<1, 1>(L, stash, lane, probe_skip); }
-    if (I == 4) route_step<1, 2>(L, stash, lane, probe_skip);
+    if (I == 0) route_level<0>(L, stash, lane, probe_skip);
+    if (I == 2) route_level<1>(L, stash, lane, probe_skip);
   }
 };
 
-template <bool ROUTE>
+// ROUTE: the kernel also emits the table scatter's pass-1 records. SAVED: the forward's activations come from `acts`
+// (nsamd_field_mlp_bwd_saved) instead of being recomputed; every other variant fetches a tile's inputs one tile ahead.
+template <bool ROUTE, bool SAVED>
 __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
@@ -1170,8 +1252,14 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
   const int64_t per_iter = (int64_t)gridDim.x * kCoopWaves;
   const int64_t iters = (tiles + per_iter - 1) / per_iter;
   PROBE_STAMP(kCoopWaves, 1);
-  TileFetch nxt;  // (ROUTE) the next tile's inputs, fetched ahead of the current tile's record stores
-  if (ROUTE && iters > 0)
+  // the next tile's inputs are fetched behind the current tile's base-layer-0 barrier (NSAMD_NOROUTE_AHEAD=0 at build time:
+  // only in the record-emitting variant — same-box A/B of the plain backward)
+#ifndef NSAMD_NOROUTE_AHEAD
+#define NSAMD_NOROUTE_AHEAD 1
+#endif
+  constexpr bool AHEAD = !SAVED && (ROUTE || NSAMD_NOROUTE_AHEAD);
+  TileFetch nxt;
+  if (AHEAD && iters > 0)
     fetch_tile(nxt, (int64_t)blockIdx.x * kCoopWaves + wave, tiles, lane, M, enc, selector, directions, cams, app_table, app_const,
                app_dim, dir_group, ddensity, drgb);
   for (int64_t it = 0; it < iters; ++it) {
@@ -1180,18 +1268,27 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     TileInputs ti;
     FieldActs A;
     float up_rgb[3] = {0.f, 0.f, 0.f}, up_density = 0.f;
-    if (ROUTE) {
+    if (AHEAD) {
+      // (tile_fetched: what `fetch_tile` left raw gets its constants / masks here, where the values are first needed)
       ti = nxt.ti;
+      if (selector == nullptr) ti.sel = 1.0f;
+      if (cams == nullptr) ti.cam = 0;
       A.enc[0] = nxt.enc[0];
       A.enc[1] = nxt.enc[1];
+      const bool mine = g == 0 && ti.live;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) up_rgb[c] = nxt.up_rgb[c];
-      up_density = nxt.up_density;
+      for (int c = 0; c < 3; ++c) up_rgb[c] = mine ? nxt.up[c] : 0.0f;
+      up_density = mine ? nxt.up[3] : 0.0f;
       const float dir[3] = {nxt.dir[0], nxt.dir[1], nxt.dir[2]};
-      const v4f app[2] = {nxt.app[0], nxt.app[1]};
-      // records 0..6 of the PREVIOUS tile leave between this tile's forward GEMMs, the other nine between the phases below
-      const RouteBetween rb{RL, RL->stash[wave], lane, probe_skip, it > 0 && !(probe_skip & 32)};
-      coop_forward_tile(W, bias, dir, app_table, app_const, app_dim, ti, lane, A, app, rb);
+      const v4f zero4 = v4f{0.f, 0.f, 0.f, 0.f};
+      const v4f app[2] = {app_dim > 0 ? nxt.app[0] : zero4, app_dim > 0 ? nxt.app[1] : zero4};
+      if (ROUTE) {
+        // records 0..6 of the PREVIOUS tile leave between this tile's forward GEMMs, the other nine between the phases below
+        const RouteBetween rb{RL, RL->stash[wave], lane, probe_skip, it > 0 && !(probe_skip & 32)};
+        coop_forward_tile(W, bias, dir, app_table, app_const, app_dim, ti, lane, A, app, rb);
+      } else {
+        coop_forward_tile(W, bias, dir, app_table, app_const, app_dim, ti, lane, A, app, NoBetween{});
+      }
     } else {
       ti = tile_inputs(tile < tiles ? tile : tiles - 1, lane, M, selector, cams, dir_group);
       if (tile >= tiles) ti.live = false;  // idle wave of the last round: computes, contributes zeros
@@ -1214,10 +1311,10 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     }
     PROBE_STAMP(kCoopWaves, 3 + 10 * (int)it);
     const bool emit = ROUTE && it > 0 && !(probe_skip & 32);  // the previous tile's records are still going out
-#define NSAMD_ROUTE_STEP(K, Q)                                                    \
+#define NSAMD_ROUTE_LEVEL(K)                                                      \
   do {                                                                           \
     if (ROUTE) {                                                                 \
-      if (emit) route_step<K, Q>(RL, RL->stash[wave], lane, probe_skip);         \
+      if (emit) route_level<K>(RL, RL->stash[wave], lane, probe_skip);           \
     }                                                                            \
   } while (0)
 
@@ -1241,10 +1338,8 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     zero_tiles<4>(g_hb);
     if (!(probe_skip & 4)) rows_gemm_bwd<4, 1, kLd64>(W + kRowHead2, g_rgbp, g_hb, j, g);
     relu_mask<4>(g_hb, A.hb);
-    NSAMD_ROUTE_STEP(1, 3);
     if (!(probe_skip & 2)) __syncthreads();
     if (!(probe_skip & 1)) coop_dw<1>(dW_h2, &db_h2, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
-    NSAMD_ROUTE_STEP(2, 0);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 4 + 10 * (int)it);
 
@@ -1255,10 +1350,9 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     zero_tiles<4>(g_ha);
     if (!(probe_skip & 4)) rows_gemm_bwd<4, 4, kLd64>(W + kRowHead1, g_hb, g_ha, j, g);
     relu_mask<4>(g_ha, A.ha);
-    NSAMD_ROUTE_STEP(2, 1);
+    NSAMD_ROUTE_LEVEL(2);
     if (!(probe_skip & 2)) __syncthreads();
     if (!(probe_skip & 1)) coop_dw<2>(dW_h1, &db_h1, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
-    NSAMD_ROUTE_STEP(2, 2);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 5 + 10 * (int)it);
 
@@ -1269,10 +1363,8 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     zero_tiles<4>(g_hin);
     // input tile 0 is the SH block: it carries no gradient, so only columns 16..63 (tiles 1..3) are formed
     if (!(probe_skip & 4)) rows_gemm_bwd<3, 4, kLd64>(W + kRowHead0 + 16, g_ha, g_hin + 1, j, g);
-    NSAMD_ROUTE_STEP(2, 3);
     if (!(probe_skip & 2)) __syncthreads();
     if (!(probe_skip & 1)) coop_dw<2>(dW_h0, &db_h0, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
-    NSAMD_ROUTE_STEP(3, 0);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 6 + 10 * (int)it);
 
@@ -1300,7 +1392,11 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
             v[r] += __shfl_xor(v[r], 4);
             v[r] += __shfl_xor(v[r], 8);
           }
-          if (j == 0 && tile < tiles) *reinterpret_cast<v4f*>(app_partials + tile * 32 + 16 * (t - 2) + 4 * g) = v;
+          // (32-bit element offset from the kernel-argument base: as a hoisted 64-bit per-lane address this was a spilled
+          //  register pair, reloaded here with `s_waitcnt vmcnt(0)` — a drain of every record store in flight per tile;
+          //  tiles * 32 < 2^32 for any M whose 32 x M feature matrix exists)
+          if (j == 0 && tile < tiles)
+            *reinterpret_cast<v4f*>(app_partials + ((uint32_t)tile * 32u + (uint32_t)(16 * (t - 2) + 4 * g))) = v;
         }
       } else {
         const int cam32 = (int)ti.cam;
@@ -1344,14 +1440,15 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     zero_tiles<4>(g_h1);
     if (!(probe_skip & 4)) rows_gemm_bwd<4, 1, kLd64>(W + kRowBase1, g_o16, g_h1, j, g);
     relu_mask<4>(g_h1, A.h1);
-    NSAMD_ROUTE_STEP(3, 1);
+    NSAMD_ROUTE_LEVEL(3);
     if (!(probe_skip & 2)) __syncthreads();
     if (!(probe_skip & 1)) coop_dw<1>(dW_b1, &db_b1, bias_owner14, scratch, 4 * own_half, 4, 0, own_q, j, g);
-    NSAMD_ROUTE_STEP(3, 2);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 7 + 10 * (int)it);
 
     // ---- base layer 0 (32 -> 64) ----
+    RawPosition rawpos;
+    if (ROUTE) route_issue_position(RL, tile, tiles, M, dir_group, lane, rawpos);
     store_rows<4>(Sd, g_h1, j, g);
     store_rows<2>(Sx, A.enc, j, g);
     v4f g_enc[2];
@@ -1361,15 +1458,14 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) denc[(int64_t)(16 * t + 4 * g + r) * M + ti.p] = g_enc[t][r];
+        for (int r = 0; r < 4; ++r) (denc + (int64_t)(16 * t + r) * M)[enc_lane_offset(M, ti.p, lane)] = g_enc[t][r];
     }
     // The scatter's pass-1 records (see RouteArgs / route_step): the last record of the PREVIOUS tile leaves, then this
     // tile's feature gradients and normalised positions take its place in the wave's stash; they go out one record at a time
     // during the next tile's iteration (after the last one: route_flush below).
-    NSAMD_ROUTE_STEP(3, 3);
     if (ROUTE) {  // (a wave reads only its own rows of the stash back: no barrier is involved)
       float px, py, pz;
-      const bool plive = route_load_position(RL, tile, tiles, M, dir_group, lane, px, py, pz);
+      const bool plive = route_finish_position(RL, rawpos, tile, tiles, M, dir_group, lane, px, py, pz);
       (void)normalise_position(RL->transform, RL->box, px, py, pz);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -1380,14 +1476,14 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
       RL->stash[wave][10][lane] = pz;
     }
     if (!(probe_skip & 2)) __syncthreads();
-    if (ROUTE && it + 1 < iters)  // the next tile's inputs (see TileFetch)
+    if (AHEAD && it + 1 < iters)  // the next tile's inputs (see TileFetch)
       fetch_tile(nxt, tile + per_iter, tiles, lane, M, enc, selector, directions, cams, app_table, app_const, app_dim, dir_group,
                  ddensity, drgb);
     PROBE_STAMP(kCoopWaves, 9 + 10 * (int)it);
     if (!(probe_skip & 1)) coop_dw<1>(dW_b0, &db_b0, own_m1 == 0, scratch, 0, kCoopWaves, own_n, own_m1, j, g);
     // no barrier here: the next writer of the scratch is the next iteration's head layer 2, behind its own barrier
     PROBE_STAMP(kCoopWaves, 8 + 10 * (int)it);
-#undef NSAMD_ROUTE_STEP
+#undef NSAMD_ROUTE_LEVEL
   }
   if (ROUTE && iters > 0 && !(probe_skip & 32)) route_flush(RL, RL->stash[wave], lane, probe_skip);  // the last tile's records
   PROBE_STAMP(kCoopWaves, 62);
@@ -1401,8 +1497,8 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
       const uint32_t n = RL->cnt[e];
       RL->counts[(size_t)e * RL->segs + blockIdx.x] = n < RL->seg_cap ? n : RL->seg_cap;
     }
-    if (threadIdx.x < (unsigned)RL->num_levels && RL->lmax[threadIdx.x] != 0u)
-      atomicMax(RL->hdr + threadIdx.x, RL->lmax[threadIdx.x]);
+    if (threadIdx.x < (unsigned)RL->num_levels && RL->lv[threadIdx.x].lmax != 0u)
+      atomicMax(RL->hdr + threadIdx.x, RL->lv[threadIdx.x].lmax);
   }
   if (own_half == 1) {
     *reinterpret_cast<v4f*>(stash + ((0 * 4 + own_q) * 64 + lane) * 4) = dW_h2[0];
@@ -1492,7 +1588,9 @@ __device__ void app_reduce_block(const float* __restrict__ rows, const int64_t* 
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int64_t r = r0 + (int64_t)u * kReduceThreads;
-      mine[u] = r < num_rays && cams[r] == cam;
+      // (unconditional load, clamped row: predicated loads are waited for one by one — see the partial rows below)
+      const int64_t c = cams[r < num_rays ? r : num_rays - 1];
+      mine[u] = r < num_rays && c == cam;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1550,11 +1648,15 @@ __global__ __launch_bounds__(kReduceThreads) void field_dw_reduce_kernel(const f
       float v[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
+        // UNCONDITIONAL loads (a row past the end re-reads the last one and is dropped below): written as
+        // `b < n ? load : 0` every load sits in its own branch and the compiler waits for each with vmcnt(0) before it
+        // issues the next — sixteen memory latencies in a row instead of one (read off the ISA; the launch took 15 us
+        // for 12.8 MB)
         const int b = b0 + u * kReduceGroups;
-        v[u] = b < num_partials ? partials[(size_t)b * kPartialStride + e] : 0.0f;
+        v[u] = partials[(size_t)(b < num_partials ? b : num_partials - 1) * kPartialStride + e];
       }
 #pragma unroll
-      for (int u = 0; u < 16; ++u) s += v[u];
+      for (int u = 0; u < 16; ++u) s += (b0 + u * kReduceGroups < num_partials) ? v[u] : 0.0f;
     }
   }
   part[grp][el] = s;
@@ -1587,6 +1689,7 @@ using namespace nsamd;
 static int field_common_checks(const float* enc, const float* directions, int64_t dir_group, int64_t M,
                                const nsamd_field_mlp& mlp, const int64_t* cams, const float* app_const, int* app_dim) {
   NSAMD_REQUIRE(M >= 0 && dir_group >= 1);
+  if (M > kMaxFieldPoints) return NSAMD_ERR_UNSUPPORTED;  // 32-bit per-lane offsets into the [32, M] feature matrix
   NSAMD_REQUIRE(enc && directions);
   NSAMD_REQUIRE(mlp.base_W0 && mlp.base_b0 && mlp.base_W1 && mlp.base_b1 && mlp.head_W0 && mlp.head_b0 &&
                 mlp.head_W1 && mlp.head_b1 && mlp.head_W2 && mlp.head_b2);
@@ -1721,9 +1824,11 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return NSAMD_ERR_NO_DEVICE;
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {  // the dynamic-LDS opt-in is per device
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<false>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<true>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<true, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + sizeof(uint32_t) * kRouteLdsWords)) != hipSuccess)
       return NSAMD_ERR_LAUNCH;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
@@ -1757,15 +1862,20 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
     R.buf = scatter_bufs(scatter_ws, plan);
     R.buf.log2_table_size = R.grid.log2_table_size;
     if (phases & 1) {
-      field_mlp_bwd_kernel<true><<<blocks, kCoopThreads, lds + sizeof(uint32_t) * kRouteLdsWords, (hipStream_t)stream>>>(
+      field_mlp_bwd_kernel<true, false><<<blocks, kCoopThreads, lds + sizeof(uint32_t) * kRouteLdsWords, (hipStream_t)stream>>>(
           enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
           grads, partials, app_partials, app_rows_per_point, acts, probe_skip, R);
       NSAMD_CHECK_LAUNCH();
     }
   } else if (phases & 1) {
-    field_mlp_bwd_kernel<false><<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
-        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-        grads, partials, app_partials, app_rows_per_point, acts, probe_skip, RouteArgs{});
+    if (acts != nullptr)
+      field_mlp_bwd_kernel<false, true><<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
+          enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
+          grads, partials, app_partials, app_rows_per_point, acts, probe_skip, RouteArgs{});
+    else
+      field_mlp_bwd_kernel<false, false><<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
+          enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
+          grads, partials, app_partials, app_rows_per_point, nullptr, probe_skip, RouteArgs{});
     NSAMD_CHECK_LAUNCH();
   }
   if (partials != nullptr && (phases & 2)) {

@@ -119,9 +119,8 @@ __global__ __launch_bounds__(kHashBlock) void hash_encode_fwd_v2_kernel(nsamd_po
   const int64_t p = pb * kHashBlock + threadIdx.x;
   if (p >= M) return;
   float x, y, z;
-  load_position(P, p, x, y, z);
+  load_position_burst(P, p, x, y, z);
   const float sel = normalise_position(transform, box, x, y, z);
-  if (level == 0 && selector != nullptr) selector[p] = sel;
   const uint32_t mask = (1u << grid.log2_table_size) - 1u;
   const Cell c = locate_cell(x, y, z, grid.scalings[level]);
   const float2* __restrict__ tl = table + ((size_t)level << grid.log2_table_size);
@@ -165,6 +164,9 @@ __global__ __launch_bounds__(kHashBlock) void hash_encode_fwd_v2_kernel(nsamd_po
   float* o = enc + p * stride_p + (int64_t)(2 * level) * stride_k;
   o[0] = r[0];
   o[stride_k] = r[1];
+  // (behind the gathers: vector memory operations retire in order and stores count — in front of them the selector store
+  //  would have to complete before the first gathered value may be used)
+  if (level == 0 && selector != nullptr) selector[p] = sel;
 }
 
 // dL/dtable: one thread per (point, level); 16 fire-and-forget fp32 atomics (global_atomic_add_f32).

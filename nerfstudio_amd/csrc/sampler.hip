@@ -209,21 +209,35 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
   const int nb = S + 1;
   const float near_ray = nears[ray], far_ray = fars[ray];
   const float jit_ray = (jitter != nullptr && !jitter_per_edge) ? jitter[ray] : 0.0f;
+  // (... and UNCONDITIONALLY, at clamped indices, with nothing consumed before the last one is out: a load under a lane
+  //  predicate sits in a branch of its own, the compiler closes every such branch with s_waitcnt vmcnt(0), and the "burst" was
+  //  four round trips in a row — read off the ISA)
   float u_pre[2];
 #pragma unroll
-  for (int c = 0; c < 2; ++c) u_pre[c] = (lane + 64 * c) < nb ? u_base[lane + 64 * c] : 0.0f;
+  for (int c = 0; c < 2; ++c) u_pre[c] = u_base[min(lane + 64 * c, nb - 1)];
   const float* bp = s_bins_prev + ray * (S_prev + 1);
-  for (int i = lane; i <= S_prev; i += 64) bprev[i] = bp[i];
-  float dd_pre[4] = {0.f, 0.f, 0.f, 0.f};
+  float bp_pre[5];  // edges 0 .. 319 of the previous level (all of them for the nerfacto counts; the rest below)
+#pragma unroll
+  for (int c = 0; c < 5; ++c) bp_pre[c] = bp[min(lane + 64 * c, S_prev)];
+  float tb_lo[4] = {0.f, 0.f, 0.f, 0.f}, tb_hi[4] = {0.f, 0.f, 0.f, 0.f}, dn_pre[4] = {0.f, 0.f, 0.f, 0.f};
   if (kFused) {
     const float* tb0 = t_bins_prev + ray * (S_prev + 1);
     const float* dn0 = density + ray * S_prev;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int i = 64 * c + lane;
-      if (i < S_prev) dd_pre[c] = (tb0[i + 1] - tb0[i]) * dn0[i];
+      const int i = min(64 * c + lane, S_prev - 1);
+      tb_lo[c] = tb0[i];
+      tb_hi[c] = tb0[i + 1];
+      dn_pre[c] = dn0[i];
     }
   }
+#pragma unroll
+  for (int c = 0; c < 5; ++c)
+    if (lane + 64 * c <= S_prev) bprev[lane + 64 * c] = bp_pre[c];
+  for (int i = lane + 320; i <= S_prev; i += 64) bprev[i] = bp[i];
+  float dd_pre[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) dd_pre[c] = (64 * c + lane) < S_prev ? (tb_hi[c] - tb_lo[c]) * dn_pre[c] : 0.0f;
   PROBE_STAMP(0, 1);
 
   if (kFused) {

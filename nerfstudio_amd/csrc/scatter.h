@@ -98,15 +98,20 @@ constexpr uint32_t kSpillFold = 8192;  // spill records pass 2 folds into its ti
 #endif
 typedef uint32_t rec_vec __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void rec_store(uint4* dst, const uint4& r) {
-  *dst = r;  // (nontemporal STORES: 175 -> 399 us for the main table — the scattered 16-B records lose L2's write combining)
+  // (nontemporal STORES: 175 -> 399 us for the main table — the scattered 16-B records lose L2's write combining)
+  // a GLOBAL store whatever the pointer's provenance (common.h, global_ptr): a producer that keeps the queue pointer in LDS
+  // would otherwise issue flat stores
+  rec_vec v;
+  v.x = r.x, v.y = r.y, v.z = r.z, v.w = r.w;
+  *global_ptr(reinterpret_cast<rec_vec*>(dst)) = v;
 }
 __device__ __forceinline__ uint4 rec_load(const uint4* src) {
 #if NSAMD_SCATTER_NT
-  const rec_vec v = __builtin_nontemporal_load(reinterpret_cast<const rec_vec*>(src));
-  return make_uint4(v.x, v.y, v.z, v.w);
+  const rec_vec v = __builtin_nontemporal_load(global_ptr(reinterpret_cast<const rec_vec*>(src)));
 #else
-  return *src;
+  const rec_vec v = *global_ptr(reinterpret_cast<const rec_vec*>(src));
 #endif
+  return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 // Append a record that found no room in its tile (or an x-pair straddling two tiles). One returning atomic per

@@ -70,8 +70,8 @@ def executed_per_launch(key, main_points):
 
 # entry point -> the kernel name rocprofv3 --kernel-trace --stats lists for it (profiles/*_kernel_stats.csv)
 ROCPROF_KERNEL = {
-    "nsamd_field_mlp_bwd": "nsamd::field_mlp_bwd_kernel<false>",
-    "nsamd_field_mlp_bwd_scatter_phase[gradients+records]": "nsamd::field_mlp_bwd_kernel<true>",
+    "nsamd_field_mlp_bwd": "nsamd::field_mlp_bwd_kernel<false, false>",
+    "nsamd_field_mlp_bwd_scatter_phase[gradients+records]": "nsamd::field_mlp_bwd_kernel<true, false>",
     "nsamd_field_mlp_bwd_scatter_phase[apply]": "nsamd::scatter_apply_kernel + nsamd::scatter_finish_kernel",
     "nsamd_field_mlp_bwd_saved": "nsamd::field_mlp_bwd_kernel (saved activations)",
     "nsamd_field_mlp_fwd": "nsamd::field_mlp_fwd_kernel",
