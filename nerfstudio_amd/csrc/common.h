@@ -136,6 +136,51 @@ NSAMD_HD void load_position_burst(const nsamd_points& P, int64_t p, float& x, fl
   z = o2 + d2 * span / 2.0f;
 }
 
+// N positions of one lane with ONE branch on the layout around all of their loads (a branch per position is a wait per
+// position: the compiler closes each with s_waitcnt vmcnt(0)).
+template <int N>
+NSAMD_HD void load_positions_burst(const nsamd_points& P, const int64_t (&p)[N], float (&x)[N], float (&y)[N], float (&z)[N]) {
+  if (P.positions != nullptr) {
+    for (int k = 0; k < N; ++k) {
+      x[k] = P.positions[3 * p[k] + 0];
+      y[k] = P.positions[3 * p[k] + 1];
+      z[k] = P.positions[3 * p[k] + 2];
+    }
+    return;
+  }
+  const int64_t S = P.samples_per_ray;
+  float o0[N], o1[N], o2[N], d0[N], d1[N], d2[N], t0[N], t1[N];
+  for (int k = 0; k < N; ++k) {
+    const int64_t ray = p[k] / S;
+    const int64_t s = p[k] - ray * S;
+    const float* tb = P.t_bins + ray * (S + 1) + s;
+    const float* o = P.origins + 3 * ray;
+    const float* d = P.directions + 3 * ray;
+    o0[k] = o[0];
+    NSAMD_KEEP_LOADS_APART();
+    o1[k] = o[1];
+    NSAMD_KEEP_LOADS_APART();
+    o2[k] = o[2];
+    NSAMD_KEEP_LOADS_APART();
+    d0[k] = d[0];
+    NSAMD_KEEP_LOADS_APART();
+    d1[k] = d[1];
+    NSAMD_KEEP_LOADS_APART();
+    d2[k] = d[2];
+    NSAMD_KEEP_LOADS_APART();
+    t0[k] = tb[0];
+    NSAMD_KEEP_LOADS_APART();
+    t1[k] = tb[1];
+    NSAMD_KEEP_LOADS_APART();
+  }
+  for (int k = 0; k < N; ++k) {
+    const float span = t0[k] + t1[k];  // starts + ends
+    x[k] = o0[k] + d0[k] * span / 2.0f;
+    y[k] = o1[k] + d1[k] * span / 2.0f;
+    z[k] = o2[k] + d2[k] * span / 2.0f;
+  }
+}
+
 // ---- L-inf scene contraction (spatial_distortions.py:66-69) ---------------------------------------------------
 NSAMD_HD void contract_linf(float& x, float& y, float& z) {
   const float mag = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));

@@ -1193,10 +1193,18 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
     nsamd_field_mlp mlp, int app_dim, const float* __restrict__ ddensity, const float* __restrict__ drgb,
     float* __restrict__ denc, nsamd_field_mlp_grads grads, float* __restrict__ partials,
-    float* __restrict__ app_partials, int app_rows_per_point, const float* __restrict__ acts, int probe_skip,
+    float* __restrict__ app_partials, int app_rows_per_point, const float* __restrict__ acts, int probe_skip_arg,
     RouteArgs R) {
   // probe_skip (NSAMD_FIELD_BWD_SKIP, timing experiments only — results are wrong when set): 1 = no weight-gradient
-  // MFMAs, 2 = no workgroup barriers inside the tile loop, 4 = no data-gradient GEMMs
+  // MFMAs, 2 = no workgroup barriers inside the tile loop, 4 = no data-gradient GEMMs. A run-time value only in the
+  // instrumented build (`make probe`): the product kernel folds the switches away (a dozen scalar conditions and their
+  // registers in a kernel whose scalar registers spill).
+#ifdef NSAMD_PROBE_CLOCKS
+  const int probe_skip = probe_skip_arg;
+#else
+  constexpr int probe_skip = 0;
+  (void)probe_skip_arg;
+#endif
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* W = lds;                     // kRowTotal
   float* bias = lds + kRowTotal;      // 256

@@ -120,15 +120,36 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
     // values are finite, so dL/d density = dt * (0 * T * e - 0) = dt * 0 for every sample — no scans needed. Anything
     // else (a non-zero or NaN upstream gradient, a NaN / Inf / negative thickness) keeps the full path: 0 * NaN must
     // stay NaN as in autograd. The interlevel loss reaches few rays (profiles/r02_study_proposal_sparsity.txt).
+    // The first 256 samples' inputs in one burst of unconditional loads (clamped indices; all of a nerfacto level): in a loop
+    // that loads where it tests — behind the short-circuit of `carries ||` — this pre-pass was one memory round trip per 64
+    // samples, and it is all a ray without gradient does.
+    float lo_pre[4], hi_pre[4], dn_pre[4], dw_pre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = min(lane + 64 * q, S - 1);
+      lo_pre[q] = tb[i];
+      hi_pre[q] = tb[i + 1];
+      dn_pre[q] = dn[i];
+      dw_pre[q] = dw[i];
+    }
     bool carries = false;
-    for (int i = lane; i < S; i += 64) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float dd = (hi_pre[q] - lo_pre[q]) * dn_pre[q];
+      const bool c = dw_pre[q] != 0.0f || !(dd >= 0.0f && dd <= 3.4028234663852886e38f);
+      carries = carries || (lane + 64 * q < S && c);
+    }
+    for (int i = lane + 256; i < S; i += 64) {
       const float dd = (tb[i + 1] - tb[i]) * dn[i];
       carries = carries || dw[i] != 0.0f || !(dd >= 0.0f && dd <= 3.4028234663852886e38f);
     }
     const bool ray_carries = __ballot(carries) != 0ull;
     if (ray_mask != nullptr && lane == 0) ray_mask[ray] = ray_carries ? 1 : 0;  // per-ray form of the flag (see nsamd.h)
     if (!ray_carries) {
-      for (int i = lane; i < S; i += 64) ddensity[ray * S + i] = (tb[i + 1] - tb[i]) * 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (lane + 64 * q < S) ddensity[ray * S + lane + 64 * q] = (hi_pre[q] - lo_pre[q]) * 0.0f;
+      for (int i = lane + 256; i < S; i += 64) ddensity[ray * S + i] = (tb[i + 1] - tb[i]) * 0.0f;
       return;
     }
     // some ray of this launch carries gradient: the rest of the level's backward chain has work to do. A PLAIN store of

@@ -71,30 +71,44 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
   float g0[kPts][kLevels], g1[kPts][kLevels];
   float x[kPts], y[kPts], z[kPts];
   bool inside[kPts];
-#pragma unroll
-  for (int j = 0; j < kPts; ++j) {  // all gradient loads in flight before anything depends on them
-    const int64_t p = ((int64_t)blockIdx.x * kPts + j) * kThreads + threadIdx.x;
-    inside[j] = p < M;
-    // per-ray mask of a gated call: samples of rays without gradient are exact zeros that were never written — not loaded
-    if (inside[j] && ray_mask != nullptr) inside[j] = ray_mask[p / P.samples_per_ray] != 0;
-#pragma unroll
-    for (int i = 0; i < kLevels; ++i) {
-      g0[j][i] = 0.0f;
-      g1[j][i] = 0.0f;
-      if (inside[j] && lvl[i] >= 0) {
-        const float* gptr = denc + p * stride_p + (int64_t)(2 * lvl[i]) * stride_k;
-        g0[j][i] = gptr[0];
-        g1[j][i] = gptr[stride_k];
-      }
-    }
-  }
+  // Every load of the prologue — the ray's mask byte, the 2 * kLevels gradients, the position's inputs — is UNCONDITIONAL (at a
+  // clamped point, a level-0 address for an absent level, a dummy byte without a mask) and issued before the first is used;
+  // what must not count is zeroed by a select afterwards. Under their predicates (`inside && lvl >= 0`, the mask) each load
+  // sat in a branch of its own and was waited for before the next was issued: mask, gradients, bin edges, origin / direction
+  // were four memory round trips in a row per workgroup (read off the ISA), which is all a sparse gated call consists of.
+  uint8_t mask_raw[kPts];
+  int64_t pcl[kPts];
 #pragma unroll
   for (int j = 0; j < kPts; ++j) {
     const int64_t p = ((int64_t)blockIdx.x * kPts + j) * kThreads + threadIdx.x;
-    x[j] = y[j] = z[j] = 0.0f;
+    inside[j] = p < M;
+    const int64_t pc = inside[j] ? p : M - 1;
+    pcl[j] = pc;
+    // per-ray mask of a gated call: samples of rays without gradient are exact zeros that were never written — loaded (finite
+    // or not, whatever the buffer holds) and dropped
+    const uint8_t* mp = ray_mask != nullptr ? ray_mask + pc / P.samples_per_ray : reinterpret_cast<const uint8_t*>(denc);
+    mask_raw[j] = *mp;
+#pragma unroll
+    for (int i = 0; i < kLevels; ++i) {
+      const float* gptr = denc + pc * stride_p + (int64_t)(2 * (lvl[i] >= 0 ? lvl[i] : 0)) * stride_k;
+      g0[j][i] = gptr[0];
+      g1[j][i] = gptr[stride_k];
+    }
+  }
+  load_positions_burst<kPts>(P, pcl, x, y, z);
+#pragma unroll
+  for (int j = 0; j < kPts; ++j) {
+    if (ray_mask != nullptr) inside[j] = inside[j] && mask_raw[j] != 0;
+#pragma unroll
+    for (int i = 0; i < kLevels; ++i) {
+      const bool live = inside[j] && lvl[i] >= 0;
+      g0[j][i] = live ? g0[j][i] : 0.0f;
+      g1[j][i] = live ? g1[j][i] : 0.0f;
+    }
     if (inside[j]) {
-      load_position(P, p, x[j], y[j], z[j]);
       (void)normalise_position(transform, box, x[j], y[j], z[j]);
+    } else {
+      x[j] = y[j] = z[j] = 0.0f;
     }
   }
   // A workgroup whose points carry no gradient at all (proposal levels: the interlevel loss reaches few samples,
@@ -223,27 +237,38 @@ __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
   float g0[kRunLen][kLevels], g1[kRunLen][kLevels];
   float px[kRunLen], py[kRunLen], pz[kRunLen];
   bool act[kRunLen];
+  // (unconditional loads at clamped points, all issued before the first is used, selects afterwards: see the fine kernel —
+  //  here the predicated form was one round trip per sample for the mask and gradients and two more per sample for the position)
+  uint8_t mask_raw[kRunLen];
+  int64_t pcl[kRunLen];
 #pragma unroll
   for (int s = 0; s < kRunLen; ++s) {
-    // (per-ray mask of a gated call: rays without gradient are not loaded, see the fine kernel)
-    act[s] = p0 + s < M && (ray_mask == nullptr || ray_mask[(p0 + s) / P.samples_per_ray] != 0);
+    act[s] = p0 + s < M;
+    const int64_t pc = act[s] ? p0 + s : M - 1;
+    pcl[s] = pc;
+    const uint8_t* mp = ray_mask != nullptr ? ray_mask + pc / P.samples_per_ray : reinterpret_cast<const uint8_t*>(denc);
+    mask_raw[s] = *mp;
 #pragma unroll
     for (int i = 0; i < kLevels; ++i) {
-      g0[s][i] = 0.0f;
-      g1[s][i] = 0.0f;
-      if (act[s] && lvl[i] >= 0) {
-        const float* gptr = denc + (p0 + s) * stride_p + (int64_t)(2 * lvl[i]) * stride_k;
-        g0[s][i] = gptr[0];
-        g1[s][i] = gptr[stride_k];
-      }
+      const float* gptr = denc + pc * stride_p + (int64_t)(2 * (lvl[i] >= 0 ? lvl[i] : 0)) * stride_k;
+      g0[s][i] = gptr[0];
+      g1[s][i] = gptr[stride_k];
     }
   }
+  load_positions_burst<kRunLen>(P, pcl, px, py, pz);
 #pragma unroll
   for (int s = 0; s < kRunLen; ++s) {
-    px[s] = py[s] = pz[s] = 0.0f;
+    if (ray_mask != nullptr) act[s] = act[s] && mask_raw[s] != 0;
+#pragma unroll
+    for (int i = 0; i < kLevels; ++i) {
+      const bool live = act[s] && lvl[i] >= 0;
+      g0[s][i] = live ? g0[s][i] : 0.0f;
+      g1[s][i] = live ? g1[s][i] : 0.0f;
+    }
     if (act[s]) {
-      load_position(P, p0 + s, px[s], py[s], pz[s]);
       (void)normalise_position(transform, box, px[s], py[s], pz[s]);
+    } else {
+      px[s] = py[s] = pz[s] = 0.0f;
     }
   }
   // no gradient anywhere in this workgroup's samples: nothing to count, reserve or emit — and this kernel keeps no
@@ -463,8 +488,12 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
         // empty, and walking them cost ~2.2 k clocks of pure instruction issue per trip of four
         // (scripts/probe_gated_scatter_clocks.py: 27 k clocks per tile with next to nothing to add).
         unsigned long long rem = __ballot(cv != 0u);
-        // trips of 4 segments, software-pipelined: the records of the next trip are in flight while this one goes through the
-        // LDS atomics (all 16 waves of the workgroup otherwise alternate between waiting on memory and queueing on the LDS)
+        // trips of 4 segments, software-pipelined in the source: the records of the next trip are requested before this one goes
+        // through the LDS atomics. (The ISA does not keep them in flight — lane-predicated loads sit in branches, and the
+        // compiler settles each trip with s_waitcnt vmcnt(0) —, but the unconditional form that does (clamped lanes re-reading
+        // the segment's first record) measured 2-3 us SLOWER, as did the tile as two feature planes instead of (f0, f1) pairs:
+        // with 16 waves per CU the latency is covered by the other waves, and what bounds the pass is the LDS atomic pipe plus
+        // the VALU of the fixed-point conversions. profiles/r04_negative_results.txt.)
         uint32_t n[4], n_next[4], sg[4], sg_next[4];
         uint4 r[4][2], r_next[4][2];
         auto fetch = [&](uint32_t (&nn)[4], uint32_t (&ss)[4], uint4 (&rr)[4][2]) {
@@ -478,15 +507,11 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
               nn[u] = (uint32_t)__builtin_amdgcn_readlane((int)cv, j);
               ss[u] = wave + (c0 + (uint32_t)j) * nw;
             }
-            // UNCONDITIONAL loads (a lane past the count re-reads the segment's first record: same line, no extra traffic):
-            // a lane-predicated load compiles to a branch around it, and with loads inside branches the compiler settles
-            // every wait of this loop with s_waitcnt vmcnt(0) — the prefetch of the next trip was waited for together with
-            // the current one (read off the ISA; the "software pipeline" was four exposed memory latencies per tile and wave)
             const uint4* seg = q + (size_t)ss[u] * C;
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
               const uint32_t e = (uint32_t)lane + 64u * v;
-              rr[u][v] = rec_load(seg + (e < nn[u] ? e : 0u));
+              rr[u][v] = e < nn[u] ? rec_load(seg + e) : make_uint4(0u, 0u, 0u, 0u);
             }
           }
         };
@@ -519,7 +544,7 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const uint32_t e = e0 + (uint32_t)u * blockDim.x + threadIdx.x;
-        r[u] = rec_load(dq + (e < n_dyn ? e : 0u));  // (unconditional: see the static segments)
+        r[u] = e < n_dyn ? rec_load(dq + e) : make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
