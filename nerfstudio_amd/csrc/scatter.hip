@@ -78,16 +78,33 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
   // were four memory round trips in a row per workgroup (read off the ISA), which is all a sparse gated call consists of.
   uint8_t mask_raw[kPts];
   int64_t pcl[kPts];
+  // (the mask bytes FIRST, alone: a workgroup none of whose rays carries gradient — most of them while the interlevel loss
+  //  reaches few rays — leaves after this one small round trip, before it has asked for a single gradient or position)
 #pragma unroll
   for (int j = 0; j < kPts; ++j) {
     const int64_t p = ((int64_t)blockIdx.x * kPts + j) * kThreads + threadIdx.x;
     inside[j] = p < M;
-    const int64_t pc = inside[j] ? p : M - 1;
-    pcl[j] = pc;
-    // per-ray mask of a gated call: samples of rays without gradient are exact zeros that were never written — loaded (finite
-    // or not, whatever the buffer holds) and dropped
-    const uint8_t* mp = ray_mask != nullptr ? ray_mask + pc / P.samples_per_ray : reinterpret_cast<const uint8_t*>(denc);
-    mask_raw[j] = *mp;
+    pcl[j] = inside[j] ? p : M - 1;
+    // per-ray mask of a gated call: samples of rays without gradient are exact zeros that were never written
+    mask_raw[j] = ray_mask != nullptr ? ray_mask[pcl[j] / P.samples_per_ray] : (uint8_t)1;
+  }
+  if (ray_mask != nullptr) {
+    bool marked = false;
+#pragma unroll
+    for (int j = 0; j < kPts; ++j) marked = marked || (inside[j] && mask_raw[j] != 0);
+    if (!__syncthreads_or(marked)) {  // nothing to route: publish the zero segment counts of this workgroup's levels and leave
+      for (int t = threadIdx.x; t < kLevels * B; t += kThreads) {
+        const int i = t >> G.log2_bins;
+        if (lvl[i] < 0) continue;
+        const uint32_t tile = ((uint32_t)lvl[i] << G.log2_bins) + (uint32_t)(t & (B - 1));
+        buf.counts[(size_t)tile * G.segs + blockIdx.x] = 0u;
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kPts; ++j) {
+    const int64_t pc = pcl[j];
 #pragma unroll
     for (int i = 0; i < kLevels; ++i) {
       const float* gptr = denc + pc * stride_p + (int64_t)(2 * (lvl[i] >= 0 ? lvl[i] : 0)) * stride_k;
@@ -242,12 +259,20 @@ __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
   uint8_t mask_raw[kRunLen];
   int64_t pcl[kRunLen];
 #pragma unroll
-  for (int s = 0; s < kRunLen; ++s) {
+  for (int s = 0; s < kRunLen; ++s) {  // (the mask bytes first, alone: see the fine kernel)
     act[s] = p0 + s < M;
-    const int64_t pc = act[s] ? p0 + s : M - 1;
-    pcl[s] = pc;
-    const uint8_t* mp = ray_mask != nullptr ? ray_mask + pc / P.samples_per_ray : reinterpret_cast<const uint8_t*>(denc);
-    mask_raw[s] = *mp;
+    pcl[s] = act[s] ? p0 + s : M - 1;
+    mask_raw[s] = ray_mask != nullptr ? ray_mask[pcl[s] / P.samples_per_ray] : (uint8_t)1;
+  }
+  if (ray_mask != nullptr) {
+    bool marked = false;
+#pragma unroll
+    for (int s = 0; s < kRunLen; ++s) marked = marked || (act[s] && mask_raw[s] != 0);
+    if (!__syncthreads_or(marked)) return;  // (this kernel keeps no per-workgroup state in the workspace)
+  }
+#pragma unroll
+  for (int s = 0; s < kRunLen; ++s) {
+    const int64_t pc = pcl[s];
 #pragma unroll
     for (int i = 0; i < kLevels; ++i) {
       const float* gptr = denc + pc * stride_p + (int64_t)(2 * (lvl[i] >= 0 ? lvl[i] : 0)) * stride_k;

@@ -37,13 +37,14 @@ class EvalRenderer:
         self.chunk = int(chunk or model.config.eval_num_rays_per_chunk)
         dev = next(model.parameters()).device
         N.require_cuda(next(model.parameters()))
-        self.step = NerfactoTrainStep(model, self.chunk, dev, compute_depths=True)
+        self.step = NerfactoTrainStep(model, self.chunk, dev, compute_depths=True, forward_only=True)
         self.step.nears.zero_()  # NearFarCollider at inference (reset_near_plane)
         fld = model.field
         emb = fld.embedding_appearance.embedding.weight if fld.embedding_appearance is not None else None
         self.app_const = torch.zeros(emb.shape[1], device=dev) if emb is not None else None
         self.use_graph = use_graph
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self._captured_addresses = ()
         if self.step.bg_mode == 3:  # "random": eval composites without a background (renderers.py:112-115 adds none)
             self.bg_mode, self.bg_vals = N.BG_NONE, None
         else:
@@ -80,6 +81,7 @@ class EvalRenderer:
             fused = lib.nsamd_density_field_fwd(s._points(lvl), m, net._transform, net._box, N.ptr(net.encoding.hash_table),
                                                 net.encoding.spec.native(), dm, None, None, N.ptr(s.p_dens[lvl]), None, st)
             if fused == N.ERR_UNSUPPORTED:
+                s.ensure_proposal_features(lvl)
                 ck(lib.nsamd_hashgrid_encode_fwd(s._points(lvl), m, net._transform, net._box, N.ptr(net.encoding.hash_table),
                                                  net.encoding.spec.native(), N.ptr(s.p_enc[lvl]), 1, m, N.ptr(s.p_sel[lvl]), st),
                    "hashgrid_encode_fwd")
@@ -110,11 +112,20 @@ class EvalRenderer:
                                    N.ptr(s.rgb), N.ptr(s.acc), N.ptr(s.depth_exp), N.ptr(s.depth_med[L]), None,
                                    N.ptr(s.minmax_ws), st), "composite_fwd")
 
+    def _addresses(self):
+        """Everything the captured launches read through raw pointers that this object does not own: the model's parameters
+        and buffers (a ParamArena built later re-homes them, `.to()` moves them, an embedding may be swapped)."""
+        m = self.model
+        return tuple(t.data_ptr() for t in list(m.parameters()) + list(m.buffers()))
+
     def _run_chunk(self) -> None:
         if not self.use_graph:
             self._launch_chunk()
             return
+        if self.graph is not None and self._addresses() != self._captured_addresses:
+            self.graph = None  # the graph holds stale pointers: capture again (ADVICE r03)
         if self.graph is None:
+            # the warm-up launch below may allocate (a proposal network the fused density kernel does not take): outside the capture
             torch.cuda.synchronize()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -126,6 +137,7 @@ class EvalRenderer:
             with torch.cuda.graph(g):
                 self._launch_chunk()
             self.graph = g
+            self._captured_addresses = self._addresses()
         self.graph.replay()
 
     # ---- a frame ----------------------------------------------------------------------------------------------------------

@@ -60,6 +60,7 @@ class NgpTrainStep:
         self._grow_kept(int(cap_kept) if cap_kept > 0 else 32 * n)
         self.num_candidates = self.num_kept = 0
         self.accumulate_table = False
+        self.has_bounds = False
         bgc = model.renderer_rgb.background_color
         if isinstance(bgc, str) and bgc == "last_sample":
             raise NotImplementedError("Background color 'last_sample' not implemented for packed samples.")  # renderers.py:95-96
@@ -72,6 +73,7 @@ class NgpTrainStep:
     # a change within the capacity costs nothing (grown 1.5 x beyond it).
     _RAY_BUFFERS = (("origins", (3,), torch.float32), ("directions", (3,), torch.float32), ("target", (3,), torch.float32),
                     ("cams", (), torch.int64), ("jitter", (), torch.float32), ("counts", (), torch.int32),
+                    ("t_min", (), torch.float32), ("t_max", (), torch.float32),
                     ("kept", (), torch.int32), ("info", (2,), torch.int64), ("info2", (2,), torch.int64),
                     ("rgb", (3,), torch.float32), ("acc", (), torch.float32), ("depth", (), torch.float32),
                     ("bg", (3,), torch.float32), ("pred", (3,), torch.float32), ("g_rgb", (3,), torch.float32),
@@ -127,9 +129,16 @@ class NgpTrainStep:
         return int(self.totals_host[slot])
 
     # ---- batch ---------------------------------------------------------------------------------------------------------
-    def set_batch(self, origins: Tensor, directions: Tensor, camera_indices: Optional[Tensor], target: Optional[Tensor] = None) -> None:
-        """A batch of any number of rays (see `_set_num_rays`)."""
+    def set_batch(self, origins: Tensor, directions: Tensor, camera_indices: Optional[Tensor], target: Optional[Tensor] = None,
+                  nears: Optional[Tensor] = None, fars: Optional[Tensor] = None) -> None:
+        """A batch of any number of rays (see `_set_num_rays`). `nears` / `fars`: the per-ray interval a collider put on the
+        bundle — VolumetricSampler hands them to the marcher as t_min / t_max (ray_samplers.py:470-476), as the module path
+        does (this schedule used to march the global near / far planes whatever the bundle carried)."""
         self._set_num_rays(int(origins.reshape(-1, 3).shape[0]))
+        self.has_bounds = nears is not None and fars is not None
+        if self.has_bounds:
+            self.t_min.copy_(nears.reshape(-1))
+            self.t_max.copy_(fars.reshape(-1))
         self.origins.copy_(origins.reshape(-1, 3))
         self.directions.copy_(directions.reshape(-1, 3))
         if camera_indices is not None:
@@ -163,7 +172,8 @@ class NgpTrainStep:
         o, d = N.ptr(self.origins), N.ptr(self.directions)
         near, far, step, cone = float(cfg.near_plane), min(float(cfg.far_plane), 3.0e38), float(cfg.render_step_size), float(cfg.cone_angle)
         # -- candidates: count -> prefix -> (host read) -> write
-        ck(lib.nsamd_occgrid_march_count(o, d, None, None, n, near, far, og, step, cone, N.ptr(self.jitter), N.ptr(self.counts), st),
+        tmin, tmax = (N.ptr(self.t_min), N.ptr(self.t_max)) if self.has_bounds else (None, None)
+        ck(lib.nsamd_occgrid_march_count(o, d, tmin, tmax, n, near, far, og, step, cone, N.ptr(self.jitter), N.ptr(self.counts), st),
            "occgrid_march_count")
         ck(lib.nsamd_packed_info(N.ptr(self.counts), n, N.ptr(self.info), N.ptr(self.totals[0:1]), st), "packed_info")
         mc = self._read_total(0)
@@ -176,7 +186,7 @@ class NgpTrainStep:
         if mc:
             if mc > self.cap_c:
                 self._grow_candidates(int(1.5 * mc))
-            ck(lib.nsamd_occgrid_march_write(o, d, None, None, n, near, far, og, step, cone, N.ptr(self.jitter), N.ptr(self.info),
+            ck(lib.nsamd_occgrid_march_write(o, d, tmin, tmax, n, near, far, og, step, cone, N.ptr(self.jitter), N.ptr(self.info),
                                              N.ptr(self.c_ri), N.ptr(self.c_ts), N.ptr(self.c_te), st), "occgrid_march_write")
             # -- sigma_fn (ray_samplers.py:420-429): density of the candidates; no direction, a constant appearance row
             ck(lib.nsamd_packed_positions(o, d, N.ptr(self.c_ri), N.ptr(self.c_ts), N.ptr(self.c_te), mc, N.ptr(self.c_pos), st),
@@ -340,7 +350,8 @@ class NgpFusedStep:
             self.runner = NgpTrainStep(self.model, o.shape[0], o.device)
         r = self.runner
         cams = ray_bundle.camera_indices
-        r.set_batch(o, ray_bundle.directions.reshape(-1, 3), None if cams is None else cams.reshape(-1))
+        r.set_batch(o, ray_bundle.directions.reshape(-1, 3), None if cams is None else cams.reshape(-1),
+                    nears=getattr(ray_bundle, "nears", None), fars=getattr(ray_bundle, "fars", None))
         r.forward(jitter)
         out = r.outputs()
         out["ngp_step"] = self

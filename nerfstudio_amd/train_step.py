@@ -32,8 +32,12 @@ from .utils import profiler
 
 
 class NerfactoTrainStep:
-    def __init__(self, model: NerfactoModel, num_rays: int, device, compute_depths: bool = True) -> None:
+    def __init__(self, model: NerfactoModel, num_rays: int, device, compute_depths: bool = True,
+                 forward_only: bool = False) -> None:
+        """forward_only: no gradient / saved-activation buffers (eval_render.EvalRenderer: at 32 768 rays per chunk they
+        are ~1.5 GB an eval render never touches); `forward_backward` and the backward methods must not be called."""
         self.model = model
+        self.forward_only = bool(forward_only)
         cfg = model.config
         self.cfg = cfg
         self.n = n = int(num_rays)
@@ -48,6 +52,8 @@ class NerfactoTrainStep:
         self.gradient_scaling = bool(getattr(cfg, "use_gradient_scaling", False))
         f32 = dict(device=device, dtype=torch.float32)
         e = lambda *shape: torch.empty(shape, **f32)  # noqa: E731
+        # (training-only buffers: one element each in a forward-only runner)
+        t = (lambda *shape: torch.empty((1,) * len(shape), **f32)) if forward_only else e  # noqa: E731
         if cfg.background_color == "random":
             # the rendered colour carries no background; the loss blends `rand_like(pred) * (1 - accumulation)` into the
             # prediction (renderers.py:112-115, 194-196; models/nerfacto.py:377-381) — a per-ray colour the kernels read
@@ -76,9 +82,9 @@ class NerfactoTrainStep:
         self.p_enc, self.p_sel, self.p_pre, self.p_dens = [], [], [], []
         for lvl in range(self.n_prop):
             m = n * self.counts[lvl]
-            self.p_enc.append(e(self.props[lvl].encoding.get_out_dim(), m))
-            self.p_sel.append(e(m))
-            self.p_pre.append(e(m))
+            self.p_enc.append(t(self.props[lvl].encoding.get_out_dim(), m))  # (forward-only: see `ensure_proposal_features`)
+            self.p_sel.append(t(m))
+            self.p_pre.append(t(m))
             self.p_dens.append(e(m))
         self.m_main = mm = n * self.counts[-1]
         fld = model.field
@@ -92,9 +98,9 @@ class NerfactoTrainStep:
         self.dist_per_ray = e(n)
         self.inter_per_ray = [e(n) for _ in range(self.n_prop)]
         self.d_rgb_out = e(n, 3)
-        self.dw_dist = e(n, self.counts[-1])
-        self.dw_prop = [e(n, self.counts[lvl]) for lvl in range(self.n_prop)]
-        self.d_rgb_s, self.d_dens_main = e(mm, 3), e(mm)
+        self.dw_dist = t(n, self.counts[-1])
+        self.dw_prop = [t(n, self.counts[lvl]) for lvl in range(self.n_prop)]
+        self.d_rgb_s, self.d_dens_main = t(mm, 3), t(mm)
         # host arrays of device pointers for nsamd_proposal_losses (the buffers are static, so built once)
         def parr(ts):
             return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
@@ -104,12 +110,12 @@ class NerfactoTrainStep:
         self._pl_per_ray = parr(self.inter_per_ray)
         self._pl_dw = parr(self.dw_prop)
         self._pl_S = (C.c_int32 * self.n_prop)(*self.counts[: self.n_prop])
-        self.f_denc = torch.empty_like(self.f_enc)
-        self.p_ddens = [torch.empty_like(t) for t in self.p_dens]
-        self.p_denc = [torch.empty_like(t) for t in self.p_enc]
-        self.field_ws, _ = F.field_bwd_workspace(device)
+        self.f_denc = t(*self.f_enc.shape)
+        self.p_ddens = [t(*x.shape) for x in self.p_dens]
+        self.p_denc = [t(*x.shape) for x in self.p_enc]
+        self.field_ws = None if forward_only else F.field_bwd_workspace(device)[0]
         # one scratch per proposal level: their backward chains may run concurrently on different streams
-        self.density_ws = [F.density_bwd_workspace(device, slot=lvl) for lvl in range(self.n_prop)]
+        self.density_ws = [] if forward_only else [F.density_bwd_workspace(device, slot=lvl) for lvl in range(self.n_prop)]
         # Zero-gradient gating of the proposal chains (include/nsamd.h): one device flag per level, raised by the level's
         # weights backward when any ray carries interlevel-loss gradient; while it is clear the rest of the chain
         # (density MLP backward, table scatter, ray gradients) returns at once — the zero-filled gradients are the result.
@@ -217,6 +223,15 @@ class NerfactoTrainStep:
                 if prm.requires_grad and prm.grad is None:
                     prm.grad = torch.empty_like(prm) if prm is table else torch.zeros_like(prm)
 
+    def ensure_proposal_features(self, lvl: int) -> None:
+        """A forward-only runner whose proposal network the fused density kernel does not take (the two-kernel pair needs the
+        level's encoded features and selector): allocate them on first use."""
+        m = self.n * self.counts[lvl]
+        if self.p_sel[lvl].numel() != m:
+            dev = self.p_dens[lvl].device
+            self.p_enc[lvl] = torch.empty((self.props[lvl].encoding.get_out_dim(), m), device=dev)
+            self.p_sel[lvl] = torch.empty((m,), device=dev)
+
     def _grad(self, p: Tensor) -> Tensor:
         if self.grad_lookup is not None:  # an arena that keeps `param.grad` unset (arena.ParamArena(bind_grads=False))
             g = self.grad_lookup.get(id(p))
@@ -232,6 +247,8 @@ class NerfactoTrainStep:
     def forward_backward(self, updated: bool, draw_jitter: bool = True) -> None:
         """One iteration up to (not including) the optimiser. `updated`: proposal networks receive gradient this step
         (ProposalNetworkSampler.updated_this_step()). Gradients ACCUMULATE into param.grad (zero them first)."""
+        if self.forward_only:
+            raise RuntimeError("NerfactoTrainStep(forward_only=True) has no gradient buffers")
         self.forward_and_losses(updated, draw_jitter)
         self.backward_all(updated)
 
@@ -257,6 +274,12 @@ class NerfactoTrainStep:
         on the current stream. A data-parallel caller starts the main-field gradient exchange between this and
         backward_join — the proposal chains then run beside the main chain AND beside the collective."""
         branches = self.proposal_branches() if updated else []
+        if updated and os.environ.get("NSAMD_DIAG_SKIP_PROP_BWD") == "1":
+            # timing diagnostic only (wrong training): update iterations without the proposal networks' backward chains — what
+            # an update iteration would cost if those chains hid completely behind the main backward
+            self._open_branches = []
+            self.backward_main()
+            return
         self._open_branches = branches
         if branches:
             # The backward chains are independent (disjoint gradients, separate scratch): fork the proposal chains onto

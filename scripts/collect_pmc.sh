@@ -62,9 +62,14 @@ groups = {  # bench key -> (kernel substring, grid, streaming) parts; streaming 
     "nsamd_hashgrid_encode_bwd_set[L=16,M=196608]": [("scatter_route_fine_kernel<1024, 1, 4>", "786432", False),
                                                       ("scatter_apply_kernel", "1048576", True),
                                                       ("scatter_finish_kernel", "8192", False)],
-    "nsamd_field_mlp_bwd": [("field_mlp_bwd_kernel", "131072", False), ("field_dw_reduce_kernel", None, False)],
+    "nsamd_field_mlp_bwd": [("field_mlp_bwd_kernel<false", None, False), ("field_dw_reduce_kernel", None, False)],
+    # the fused launch group of the training step, one bench key per phase (nsamd_field_mlp_bwd_scatter_phase)
+    "nsamd_field_mlp_bwd_scatter_phase[gradients+records]": [("field_mlp_bwd_kernel<true", None, False)],
+    "nsamd_field_mlp_bwd_scatter_phase[dw_reduce]": [("field_dw_reduce_kernel", None, False)],
+    "nsamd_field_mlp_bwd_scatter_phase[apply]": [("scatter_apply_kernel", "1048576", True),
+                                                 ("scatter_finish_kernel", "8192", False)],
     "nsamd_field_mlp_fwd": [("field_mlp_fwd_kernel", None, False)],
-    "nsamd_adam_step": [("adam_kernel", "524288", True)],
+    "nsamd_adam_step[n=16826880]": [("adam_kernel", "524288", True)],
     "nsamd_hashgrid_encode_fwd[L=16,M=196608]": [("hash_encode_fwd", "3145728", False)],
 }
 traffic = {}

@@ -241,6 +241,48 @@ def test_ngp_model_outputs_vs_oracle_and_trains(F):
     assert ev["rgb"].shape == (8, 12, 3) and float(ev["rgb"].min()) >= 0 and float(ev["rgb"].max()) <= 1
 
 
+def test_ngp_explicit_schedule_honours_the_bundle_near_far(F):
+    """a collider puts per-ray nears / fars on the bundle and VolumetricSampler hands them to the marcher as
+    t_min / t_max (model_components/ray_samplers.py:470-476). The explicit schedule (ngp_step) must sample the same interval as
+    the module path — it used to march the global near / far planes whatever the bundle carried."""
+    from nerfstudio_amd.cameras.rays import RayBundle
+    from nerfstudio_amd.instant_ngp import InstantNGPModelConfig, NGPModel
+
+    cfg = orc.NerfactoCfg(main_grid=orc.HashGridCfg(16, 16, 2048, 12), prop_grids=(), num_images=4, average_init_density=1.0)
+    params = orc.init_params(cfg, seed=23, table_std=0.5)
+    mc = InstantNGPModelConfig(grid_resolution=16, grid_levels=2, log2_hashmap_size=12, background_color="white",
+                               cone_angle=0.004, render_step_size=0.02)
+    model = NGPModel(mc, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), cfg.num_images)
+    model.load_state_dict({k: v.detach().clone() for k, v in params.items() if k.startswith("field.")}, strict=False)
+    model = model.cuda().train()
+    n = 96
+    o, d, cam, tgt = orc.synthetic_rays(n, cfg.num_images, seed=6)
+    o, d, cam = o.cuda(), d.cuda(), cam.cuda()
+    model.update_occupancy_grid(step=0)
+    g = torch.Generator().manual_seed(2)
+    nears = (0.4 + 0.4 * torch.rand(n, 1, generator=g)).cuda()
+    fars = nears + (0.3 + 0.5 * torch.rand(n, 1, generator=g)).cuda()
+    jit = torch.rand(n, generator=g).cuda()
+
+    def bundle(with_bounds):
+        return RayBundle(origins=o, directions=d, pixel_area=torch.full((n, 1), 1e-6).cuda(), camera_indices=cam[:, None],
+                         nears=nears if with_bounds else None, fars=fars if with_bounds else None)
+
+    model.config.fused_train_step = False
+    ref = model(bundle(True), jitter=jit)
+    free = model(bundle(False), jitter=jit)
+    assert not torch.equal(ref["num_samples_per_ray"], free["num_samples_per_ray"])  # the interval matters on this batch
+    model.config.fused_train_step = True
+    out = model(bundle(True), jitter=jit)
+    assert "ngp_step" in out
+    assert torch.equal(out["num_samples_per_ray"], ref["num_samples_per_ray"])
+    np.testing.assert_allclose(out["rgb"].cpu().numpy(), ref["rgb"].detach().cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(out["depth"].cpu().numpy(), ref["depth"].detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # ... and a bundle without them afterwards marches the planes again (the flag is per batch)
+    out2 = model(bundle(False), jitter=jit)
+    assert torch.equal(out2["num_samples_per_ray"], free["num_samples_per_ray"])
+
+
 @pytest.mark.parametrize("background", ["random", "white"])
 def test_ngp_explicit_schedule_equals_the_module_path(F, background):
     """ngp_step.NgpTrainStep (static capacity-sized buffers, back-to-back launches) against NGPModel's nn.Module / autograd
