@@ -229,6 +229,8 @@ int nsamd_density_mlp_bwd_gated(const float* enc, const float* selector, const f
  * enc: feature-major [32, M]. directions: [num_dirs,3] with point p using row p / dir_group (dir_group = S for
  * per-ray directions, 1 for per-point). camera_indices likewise ([num_dirs] int64) — NULL selects
  * `appearance_const` ([32], the eval-time mean/zero embedding, nerfacto_field.py:253-261) for every point.
+ * nsamd_field_mlp_fwd with rgb == NULL: the density alone (Field.density_fn, fields/base_field.py:64-77 — what the instant-ngp
+ * sampler asks of its candidates, ray_samplers.py:420-429): the head MLP is not evaluated.
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct nsamd_field_mlp {
   const float* base_W0; const float* base_b0;   /* [64,32],[64] */
@@ -508,6 +510,18 @@ int nsamd_occgrid_march_write(const float* origins, const float* directions, con
                               int64_t num_rays, float near_plane, float far_plane, nsamd_occgrid grid, float step_size,
                               float cone_angle, const float* jitter, const int64_t* packed_info, int64_t* ray_indices,
                               float* t_starts, float* t_ends, nsamd_stream_t stream);
+/* The same two calls marching every ray ONCE: _count_stash also leaves a ray's first stash_cap kept steps as (t_start, t_end)
+ * pairs in stash [num_rays, stash_cap, 2]; _write_stashed copies them to their packed places and marches only the rays that
+ * kept more than stash_cap steps a second time. Same counts, same values as the plain pair (stash == NULL: the plain pair). */
+int nsamd_occgrid_march_count_stash(const float* origins, const float* directions, const float* t_min, const float* t_max,
+                                    int64_t num_rays, float near_plane, float far_plane, nsamd_occgrid grid, float step_size,
+                                    float cone_angle, const float* jitter, int32_t* counts, float* stash, int32_t stash_cap,
+                                    nsamd_stream_t stream);
+int nsamd_occgrid_march_write_stashed(const float* origins, const float* directions, const float* t_min, const float* t_max,
+                                      int64_t num_rays, float near_plane, float far_plane, nsamd_occgrid grid,
+                                      float step_size, float cone_angle, const float* jitter, const int64_t* packed_info,
+                                      const float* stash, int32_t stash_cap, int64_t* ray_indices, float* t_starts,
+                                      float* t_ends, nsamd_stream_t stream);
 
 /* Occupancy-grid maintenance — what nerfacc's OccGridEstimator.update_every_n_steps does around `occ_eval_fn` (call site
  * models/instant_ngp.py:151-156; nerfacc 0.5.2 restated, see above):

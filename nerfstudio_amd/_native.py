@@ -111,6 +111,8 @@ _SIGNATURES = {
     "nsamd_proposal_losses": [vp, vp, i32, i32, vp, vp, vp, i64, f32, f32, vp, vp, vp, vp, vp],
     "nsamd_occgrid_march_count": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp],
     "nsamd_occgrid_march_write": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp, vp, vp, vp],
+    "nsamd_occgrid_march_count_stash": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp, i32, vp],
+    "nsamd_occgrid_march_write_stashed": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp, i32, vp, vp, vp, vp],
     "nsamd_occgrid_coarse_words": [i32, i32],
     "nsamd_occgrid_cell_positions": [vp, i64, OccGrid, vp, vp, vp],
     "nsamd_occgrid_update": [vp, i64, vp, vp, i64, f32, vp, vp],

@@ -265,7 +265,8 @@ __device__ __forceinline__ void field_forward_tile(const float* wf, const float*
                                                    const float* __restrict__ app_table,
                                                    const float* __restrict__ app_const, int64_t dir_group, int64_t M,
                                                    int app_dim, const TileInputs& ti, int lane, FieldActs& A,
-                                                   int probe_slot = 63, const HeadPre* pre = nullptr) {
+                                                   int probe_slot = 63, const HeadPre* pre = nullptr,
+                                                   bool base_only = false) {
   const int g = lane >> 4;
   load_bias<4>(bias + kBiasBase0, A.h1, g);
   chain_gemm<4, 2>(wf + kOffBase0, A.enc, A.h1, lane);
@@ -273,6 +274,7 @@ __device__ __forceinline__ void field_forward_tile(const float* wf, const float*
   load_bias<1>(bias + kBiasBase1, A.o16, g);
   chain_gemm<1, 4>(wf + kOffBase1, A.h1, A.o16, lane);
   PROBE_STAMP(kWaves, probe_slot);
+  if (base_only) return;  // density only (Field.density_fn: the head's 8 320 of 11 392 MACs per point are not needed)
 
   // head input: SH of (dir + 1) / 2  (base_field.py:136-142), geo in place, appearance embedding
   if (pre == nullptr) {
@@ -360,14 +362,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 1 : 2) void field_mlp_fwd
     FieldActs A;
     load_enc_tile_fwd(enc, M, ti.p, lane, A.enc);
     PROBE_STAMP(WAVES, 2 + 4 * probe_it);
-    field_forward_tile(wf, bias, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A, 3 + 4 * probe_it);
+    field_forward_tile(wf, bias, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A, 3 + 4 * probe_it, nullptr,
+                       rgb == nullptr);
     PROBE_STAMP(WAVES, 4 + 4 * probe_it);
     if (acts != nullptr) store_acts(acts, tile, lane, A);
     if (lane < 16 && ti.live) {  // g == 0 holds neurons 0..3 of tile 0
       density[ti.p] = mlp.average_init_density * expf(A.o16[0][0]) * ti.sel;
-      float* o = rgb + 3 * ti.p;
+      if (rgb != nullptr) {
+        float* o = rgb + 3 * ti.p;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) o[c] = 1.0f / (1.0f + expf(-A.rgbp[0][c]));
+        for (int c = 0; c < 3; ++c) o[c] = 1.0f / (1.0f + expf(-A.rgbp[0][c]));
+      }
     }
     PROBE_STAMP(WAVES, 5 + 4 * probe_it);
     ++probe_it;
@@ -1730,14 +1735,14 @@ static int field_mlp_fwd_impl(const float* enc, const float* selector, const flo
   int app_dim = 0;
   int st = field_common_checks(enc, directions, dir_group, M, mlp, camera_indices, appearance_const, &app_dim);
   if (st) return st;
-  NSAMD_REQUIRE(density && rgb);
+  NSAMD_REQUIRE(density != nullptr && (rgb != nullptr || acts == nullptr));  // rgb NULL: density only (no saved activations)
   const size_t lds = sizeof(float) * (kFragTotal + 256);
   const int64_t tiles = (M + 15) / 16;
   // One 16-wave workgroup per CU by default (4 waves per SIMD, the weights staged once per CU): 57 us on the bench shape
   // against 59.5 (8 waves x 2 workgroups) and 65 (4 waves x 3) on the same box — NSAMD_FIELD_FWD_WAVES=8|4 selects those.
   static const int waves = getenv("NSAMD_FIELD_FWD_WAVES") ? atoi(getenv("NSAMD_FIELD_FWD_WAVES")) : 16;
   static const int bf16x3 = getenv("NSAMD_FIELD_FWD_BF16X3") ? atoi(getenv("NSAMD_FIELD_FWD_BF16X3")) : 0;
-  if (bf16x3 && acts == nullptr) {
+  if (bf16x3 && acts == nullptr && rgb != nullptr) {
     // bf16 matrix cores, three-way split operands (fp32 accuracy)
     const size_t lds3 = sizeof(float) * (4 * (size_t)kB3Total + 256);
     static bool attr3[64] = {};

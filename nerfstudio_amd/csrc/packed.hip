@@ -68,15 +68,41 @@ constexpr int kMarchThreads = 512;
 constexpr int kMarchWaves = kMarchThreads / 64;
 constexpr int kCoarseShift = 2;  // 4^3 cells per coarse block
 
+// `stash` [num_rays, stash_cap] (t_start, t_end) pairs (nullable): the COUNT pass leaves a ray's first stash_cap kept steps
+// there, and the WRITE pass copies them into the packed arrays instead of marching the ray a second time (a ray that kept more
+// is marched again, as before: same values either way). The march is the dominant packed kernel of the instant-ngp step
+// and its two passes were the same 65 us twice.
 template <bool kWrite>
 __global__ __launch_bounds__(kMarchThreads) void occgrid_march_kernel(
     const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ t_min,
     const float* __restrict__ t_max, int64_t num_rays, float near_plane, float far_plane, nsamd_occgrid grid, float step,
     float cone_angle, const float* __restrict__ jitter, int32_t* __restrict__ counts, const int64_t* __restrict__ starts,
-    int64_t* __restrict__ ray_indices, float* __restrict__ t_starts, float* __restrict__ t_ends, int coarse_words) {
+    int64_t* __restrict__ ray_indices, float* __restrict__ t_starts, float* __restrict__ t_ends, int coarse_words,
+    float2* __restrict__ stash, int stash_cap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t coarse_lds[];
   const int R = grid.resolution, L = grid.levels;
   const bool use_coarse = grid.coarse != nullptr && coarse_words > 0;
+  if (kWrite && stash != nullptr) {
+    // (before the coarse bits are staged: a workgroup all of whose rays fit their stash never reads the grid)
+    const int lane0 = threadIdx.x & 63;
+    const int64_t ray0 = (int64_t)blockIdx.x * kMarchWaves + (threadIdx.x >> 6);
+    bool remarch = false;
+    if (ray0 < num_rays) {
+      const int64_t cnt = starts[2 * ray0 + 1], at = starts[2 * ray0];
+      if (cnt <= stash_cap) {
+        const float2* src = stash + ray0 * stash_cap;
+        for (int64_t k = lane0; k < cnt; k += 64) {
+          const float2 v = src[k];
+          ray_indices[at + k] = ray0;
+          t_starts[at + k] = v.x;
+          t_ends[at + k] = v.y;
+        }
+      } else {
+        remarch = true;
+      }
+    }
+    if (!__syncthreads_or(remarch)) return;
+  }
   if (use_coarse) {
     for (int i = threadIdx.x; i < coarse_words; i += kMarchThreads) coarse_lds[i] = grid.coarse[i];
     __syncthreads();
@@ -84,6 +110,7 @@ __global__ __launch_bounds__(kMarchThreads) void occgrid_march_kernel(
   const int lane = threadIdx.x & 63;
   const int64_t ray = (int64_t)blockIdx.x * kMarchWaves + (threadIdx.x >> 6);
   if (ray >= num_rays) return;  // wave-uniform; no workgroup barrier below
+  if (kWrite && stash != nullptr && starts[2 * ray + 1] <= stash_cap) return;  // copied above
   const float o[3] = {origins[3 * ray], origins[3 * ray + 1], origins[3 * ray + 2]};
   const float d[3] = {directions[3 * ray], directions[3 * ray + 1], directions[3 * ray + 2]};
   float t_lo = near_plane, t_hi = far_plane;
@@ -162,6 +189,10 @@ __global__ __launch_bounds__(kMarchThreads) void occgrid_march_kernel(
         ray_indices[slot] = ray;
         t_starts[slot] = tj;
         t_ends[slot] = tj + dt;
+      }
+      if (!kWrite && stash != nullptr && keep) {
+        const int64_t slot = out + __builtin_popcountll(kept & ((1ull << lane) - 1ull));  // (out = kept so far in count mode)
+        if (slot < stash_cap) stash[ray * stash_cap + slot] = make_float2(tj, tj + dt);
       }
       const int c64 = __builtin_popcountll(kept);
       out += c64;
@@ -515,10 +546,11 @@ static int check_grid_desc(const nsamd_occgrid& g) {
 
 using namespace nsamd;
 
-extern "C" int nsamd_occgrid_march_count(const float* origins, const float* directions, const float* t_min,
-                                         const float* t_max, int64_t num_rays, float near_plane, float far_plane,
-                                         nsamd_occgrid grid, float step_size, float cone_angle, const float* jitter,
-                                         int32_t* counts, nsamd_stream_t stream) {
+extern "C" int nsamd_occgrid_march_count_stash(const float* origins, const float* directions, const float* t_min,
+                                               const float* t_max, int64_t num_rays, float near_plane, float far_plane,
+                                               nsamd_occgrid grid, float step_size, float cone_angle, const float* jitter,
+                                               int32_t* counts, float* stash, int32_t stash_cap, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(stash_cap >= 0 && (stash == nullptr || stash_cap > 0));
   NSAMD_REQUIRE(num_rays >= 0 && step_size > 0.0f && cone_angle >= 0.0f);
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(origins && directions && counts);
@@ -529,16 +561,25 @@ extern "C" int nsamd_occgrid_march_count(const float* origins, const float* dire
   const int cw = coarse_words(grid);
   occgrid_march_kernel<false><<<(unsigned)nb, kMarchThreads, sizeof(uint32_t) * (size_t)cw, (hipStream_t)stream>>>(
       origins, directions, t_min, t_max, num_rays, near_plane, far_plane, grid, step_size, cone_angle, jitter, counts,
-      nullptr, nullptr, nullptr, nullptr, cw);
+      nullptr, nullptr, nullptr, nullptr, cw, reinterpret_cast<float2*>(stash), stash_cap);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }
 
-extern "C" int nsamd_occgrid_march_write(const float* origins, const float* directions, const float* t_min,
+extern "C" int nsamd_occgrid_march_count(const float* origins, const float* directions, const float* t_min,
                                          const float* t_max, int64_t num_rays, float near_plane, float far_plane,
                                          nsamd_occgrid grid, float step_size, float cone_angle, const float* jitter,
-                                         const int64_t* packed_info, int64_t* ray_indices, float* t_starts, float* t_ends,
-                                         nsamd_stream_t stream) {
+                                         int32_t* counts, nsamd_stream_t stream) {
+  return nsamd_occgrid_march_count_stash(origins, directions, t_min, t_max, num_rays, near_plane, far_plane, grid, step_size,
+                                         cone_angle, jitter, counts, nullptr, 0, stream);
+}
+
+extern "C" int nsamd_occgrid_march_write_stashed(const float* origins, const float* directions, const float* t_min,
+                                                 const float* t_max, int64_t num_rays, float near_plane, float far_plane,
+                                                 nsamd_occgrid grid, float step_size, float cone_angle, const float* jitter,
+                                                 const int64_t* packed_info, const float* stash, int32_t stash_cap,
+                                                 int64_t* ray_indices, float* t_starts, float* t_ends, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(stash_cap >= 0 && (stash == nullptr || stash_cap > 0));
   NSAMD_REQUIRE(num_rays >= 0 && step_size > 0.0f && cone_angle >= 0.0f);
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(origins && directions && packed_info && ray_indices && t_starts && t_ends);
@@ -549,9 +590,18 @@ extern "C" int nsamd_occgrid_march_write(const float* origins, const float* dire
   const int cw = coarse_words(grid);
   occgrid_march_kernel<true><<<(unsigned)nb, kMarchThreads, sizeof(uint32_t) * (size_t)cw, (hipStream_t)stream>>>(
       origins, directions, t_min, t_max, num_rays, near_plane, far_plane, grid, step_size, cone_angle, jitter, nullptr,
-      packed_info, ray_indices, t_starts, t_ends, cw);
+      packed_info, ray_indices, t_starts, t_ends, cw, const_cast<float2*>(reinterpret_cast<const float2*>(stash)), stash_cap);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
+}
+
+extern "C" int nsamd_occgrid_march_write(const float* origins, const float* directions, const float* t_min,
+                                         const float* t_max, int64_t num_rays, float near_plane, float far_plane,
+                                         nsamd_occgrid grid, float step_size, float cone_angle, const float* jitter,
+                                         const int64_t* packed_info, int64_t* ray_indices, float* t_starts, float* t_ends,
+                                         nsamd_stream_t stream) {
+  return nsamd_occgrid_march_write_stashed(origins, directions, t_min, t_max, num_rays, near_plane, far_plane, grid, step_size,
+                                           cone_angle, jitter, packed_info, nullptr, 0, ray_indices, t_starts, t_ends, stream);
 }
 
 extern "C" int64_t nsamd_occgrid_coarse_words(int32_t levels, int32_t resolution) {

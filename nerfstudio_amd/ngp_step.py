@@ -21,6 +21,7 @@ written out by hand. tests/test_gpu_packed.py compares a step of the two routes 
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -29,6 +30,12 @@ from torch import Tensor
 from . import _native as N
 from . import functional as F
 from .utils import profiler
+
+
+# kept steps per ray the count pass of the marcher leaves behind for the write pass (nsamd_occgrid_march_count_stash): a ray
+# that keeps more is marched a second time (the benchmark's rays keep ~42 of ~840 lattice steps)
+STASH_CAP = 128
+_TWO_PASS = os.environ.get("NSAMD_NGP_TWO_PASS", "0") == "1"
 
 
 class NgpTrainStep:
@@ -73,7 +80,7 @@ class NgpTrainStep:
     # a change within the capacity costs nothing (grown 1.5 x beyond it).
     _RAY_BUFFERS = (("origins", (3,), torch.float32), ("directions", (3,), torch.float32), ("target", (3,), torch.float32),
                     ("cams", (), torch.int64), ("jitter", (), torch.float32), ("counts", (), torch.int32),
-                    ("t_min", (), torch.float32), ("t_max", (), torch.float32),
+                    ("t_min", (), torch.float32), ("t_max", (), torch.float32), ("stash", (STASH_CAP, 2), torch.float32),
                     ("kept", (), torch.int32), ("info", (2,), torch.int64), ("info2", (2,), torch.int64),
                     ("rgb", (3,), torch.float32), ("acc", (), torch.float32), ("depth", (), torch.float32),
                     ("bg", (3,), torch.float32), ("pred", (3,), torch.float32), ("g_rgb", (3,), torch.float32),
@@ -173,8 +180,9 @@ class NgpTrainStep:
         near, far, step, cone = float(cfg.near_plane), min(float(cfg.far_plane), 3.0e38), float(cfg.render_step_size), float(cfg.cone_angle)
         # -- candidates: count -> prefix -> (host read) -> write
         tmin, tmax = (N.ptr(self.t_min), N.ptr(self.t_max)) if self.has_bounds else (None, None)
-        ck(lib.nsamd_occgrid_march_count(o, d, tmin, tmax, n, near, far, og, step, cone, N.ptr(self.jitter), N.ptr(self.counts), st),
-           "occgrid_march_count")
+        stash = None if _TWO_PASS else N.ptr(self.stash)  # (NSAMD_NGP_TWO_PASS=1: march twice, full head on the candidates — A/B)
+        ck(lib.nsamd_occgrid_march_count_stash(o, d, tmin, tmax, n, near, far, og, step, cone, N.ptr(self.jitter), N.ptr(self.counts),
+                                               stash, 0 if _TWO_PASS else STASH_CAP, st), "occgrid_march_count_stash")
         ck(lib.nsamd_packed_info(N.ptr(self.counts), n, N.ptr(self.info), N.ptr(self.totals[0:1]), st), "packed_info")
         mc = self._read_total(0)
         self.num_candidates = mc
@@ -186,15 +194,16 @@ class NgpTrainStep:
         if mc:
             if mc > self.cap_c:
                 self._grow_candidates(int(1.5 * mc))
-            ck(lib.nsamd_occgrid_march_write(o, d, tmin, tmax, n, near, far, og, step, cone, N.ptr(self.jitter), N.ptr(self.info),
-                                             N.ptr(self.c_ri), N.ptr(self.c_ts), N.ptr(self.c_te), st), "occgrid_march_write")
+            ck(lib.nsamd_occgrid_march_write_stashed(o, d, tmin, tmax, n, near, far, og, step, cone, N.ptr(self.jitter), N.ptr(self.info),
+                                                     stash, 0 if _TWO_PASS else STASH_CAP, N.ptr(self.c_ri), N.ptr(self.c_ts), N.ptr(self.c_te), st),
+               "occgrid_march_write_stashed")
             # -- sigma_fn (ray_samplers.py:420-429): density of the candidates; no direction, a constant appearance row
             ck(lib.nsamd_packed_positions(o, d, N.ptr(self.c_ri), N.ptr(self.c_ts), N.ptr(self.c_te), mc, N.ptr(self.c_pos), st),
                "packed_positions")
             ck(lib.nsamd_hashgrid_encode_fwd(N.make_points(positions=self.c_pos), mc, fld._transform, fld._box, N.ptr(table),
                                              self.grid.native(), N.ptr(self.c_enc), 1, mc, N.ptr(self.c_sel), st), "hashgrid_encode_fwd")
             ck(lib.nsamd_field_mlp_fwd(N.ptr(self.c_enc), N.ptr(self.c_sel), N.ptr(self.view0), None, N.ptr(self.app0), mc, mc, fm,
-                                       N.ptr(self.c_sigma), N.ptr(self.c_rgb), st), "field_mlp_fwd")
+                                       N.ptr(self.c_sigma), N.ptr(self.c_rgb) if _TWO_PASS else None, st), "field_mlp_fwd")  # (rgb NULL: density only)
             # -- visibility-ordered early termination + alpha threshold, then compaction (OccGridEstimator.sampling)
             alpha = float(cfg.alpha_thre)
             if alpha > 0.0:

@@ -574,7 +574,7 @@ class NerfactoTrainStep:
         cams = N.ptr(self.camera_indices) if emb is not None else None
         grads = N.FieldMlpGrads(*(N.ptr(self._grad(p)) for p in params), N.ptr(self._grad(emb)) if emb is not None else None)
         split = self.split_reduce and self.side_stream is not None and not self.save_acts
-        if (self.fuse_route and self.main_table_write_only and not self.defer_table and not self.save_acts and not split
+        if (self.fuse_route and self.main_table_write_only and not self.defer_table and not self.save_acts
                 and enc.spec.num_levels == 16):
             sws, sws_n = F._producer_scatter_workspace(enc.spec, self.f_enc.device, mm)
             if sws is not None:
@@ -586,6 +586,18 @@ class NerfactoTrainStep:
                 if N.PROFILE is not None:  # the per-kernel table (utils/roofline.py): one launch group at a time, same bits
                     for phase in (1, 2, 4):
                         ck(lib.nsamd_field_mlp_bwd_scatter_phase(*args, phase, st), "field_mlp_bwd_scatter_phase")
+                elif split:
+                    # the weight-gradient reduce (12.8 MB of partial rows, latency-bound) needs nothing the apply pass produces
+                    # and vice versa: the reduce on its own stream BESIDE the apply pass (NSAMD_SPLIT_REDUCE=1; same bits)
+                    ck(lib.nsamd_field_mlp_bwd_scatter_phase(*args, 1, st), "field_mlp_bwd_scatter_phase")
+                    main = torch.cuda.current_stream()
+                    self._red_fork.record(main)
+                    self.reduce_stream.wait_event(self._red_fork)
+                    with torch.cuda.stream(self.reduce_stream):
+                        ck(lib.nsamd_field_mlp_bwd_scatter_phase(*args, 2, N.stream()), "field_mlp_bwd_scatter_phase")
+                        self._red_join.record(self.reduce_stream)
+                    ck(lib.nsamd_field_mlp_bwd_scatter_phase(*args, 4, st), "field_mlp_bwd_scatter_phase")
+                    main.wait_event(self._red_join)
                 else:
                     ck(lib.nsamd_field_mlp_bwd_scatter(*args, st), "field_mlp_bwd_scatter")
                 if self.cam_opt is not None:

@@ -119,9 +119,11 @@ def run_ngp(args, device, synthetic_rays, cpu_baseline_ngp):
     lattice = int(ngp_lattice_steps(o, d, cfg.render_step_size, cfg.cone_angle, cfg.near_plane, cfg.far_plane, cfg.grid_levels).sum())
     # roofline of the dominant PACKED kernel: the occupancy march. Algorithmic bytes per step: one occupancy byte per lattice
     # step and marching pass, 16 B per emitted sample (ray index, t_start, t_end), 24 B in + 20 B out per ray
+    # (the explicit schedule marches every ray ONCE — nsamd_occgrid_march_count_stash — and its second launch copies the
+    #  stashed steps; the module path marches twice)
     march = [(c, mean) for k, c, _, mean in table if k.startswith("nsamd_occgrid_march")]
     march_ms = sum(c * mean for c, mean in march)
-    passes = sum(c for c, _ in march)
+    passes = sum(c for k, c, _, _ in table if k.startswith("nsamd_occgrid_march") and "write_stashed" not in k)
     packed = [(k, ms) for k, _, ms, _ in table if "occgrid" in k or "packed" in k]
     march_bytes = passes * lattice + 16 * n_cand + 44 * n
     roof = {"bound": "hbm", "achieved": round(march_bytes / (march_ms * 1e-3) / 1e9, 2), "peak": RL.HBM_PEAK_GBS, "unit": "GB/s",

@@ -5,7 +5,7 @@
 # cpu_baseline and the per-kernel table), then the instant-ngp / 300-step / steady-state / unbounded lines, eval render, the
 # one-rank data-parallel rehearsal.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r03_final}
+TAG=${1:-r04_final}
 OUT=$R/gpurun_out/$TAG
 BUDGET_S=${BUDGET_S:-870}
 T0=$(date +%s)
@@ -30,6 +30,12 @@ timeout 200 python bench.py --steps 20 --warmup 5 --kernel-table > $OUT/bench_dr
 cat $OUT/bench_driver_window.json | tee -a $OUT/summary.txt
 grep -v amdgpu.ids $OUT/bench_driver_window_kernel_table.log | head -n 26 | tee -a $OUT/summary.txt
 say "elapsed $(( $(date +%s) - T0 )) s"
+if left; then
+say "== bench, camera optimiser ON (SO3xR3: the reference's nerfacto default, models/nerfacto.py:131)"
+timeout 150 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --camera-optimizer SO3xR3 --kernel-table > $OUT/bench_camera_SO3xR3.json 2> $OUT/bench_camera_SO3xR3_kernel_table.log
+cut -c1-400 $OUT/bench_camera_SO3xR3.json | tee -a $OUT/summary.txt
+grep -v amdgpu.ids $OUT/bench_camera_SO3xR3_kernel_table.log | head -n 8 | tee -a $OUT/summary.txt
+fi
 if left; then
 say "== bench ngp (explicit schedule)"
 timeout 150 python bench.py --workload ngp --steps 30 --warmup 10 --kernel-table > $OUT/bench_ngp.json 2> $OUT/bench_ngp_kernel_table.log
