@@ -32,10 +32,11 @@ def algorithmic_model(key, main_points):
     if key == "nsamd_field_fused_fwd":
         return "hbm", main_points * 16 * 8 * 8  # hash gathers (the bound of the fused launch)
     if key == "nsamd_field_mlp_bwd_scatter_phase[apply]":
-        # the table scatter whose route pass runs inside the field backward: the read-modify-write of 8 corners x 8 B per
-        # (sample, level) is still this op's algorithmic figure; the records (M x L x 4 x-pairs x 16 B, written by the
-        # gradient kernel, read here) are implementation traffic and not counted
-        return "hbm", main_points * 16 * 8 * 16
+        # the table scatter whose ROUTE pass runs inside the field backward: the op's algorithmic figure is the
+        # read-modify-write of 8 corners x 16 B per (sample, level); its two passes touch every corner update once each, so this
+        # launch is credited with HALF of it — the other half is the `fused_route_pass` share of the gradient kernel's line.
+        # (The 16-B records the passes hand over are implementation traffic and are counted nowhere.)
+        return "hbm", main_points * 16 * 8 * 8
     if key in ("nsamd_field_mlp_bwd", "nsamd_field_mlp_bwd_saved", "nsamd_field_mlp_bwd_scatter_phase[gradients+records]"):
         # training = 3x the forward FLOPs, the forward launch takes 1x, so the backward's ALGORITHMIC share is
         # 2x (data gradient + weight gradient); the recompute of the forward inside the kernel is executed, not algorithmic
@@ -63,7 +64,7 @@ def step_algorithmic_bytes(rays, counts=(256, 96, 48), main_levels=16, prop_leve
 
 # flops / bytes a launch actually executes where that differs from the algorithmic figure (reported next to it)
 def executed_per_launch(key, main_points):
-    if key in ("nsamd_field_mlp_bwd", "nsamd_field_mlp_bwd_scatter_phase"):
+    if key in ("nsamd_field_mlp_bwd", "nsamd_field_mlp_bwd_scatter_phase[gradients+records]"):
         return main_points * 2 * FIELD_MACS * 3  # + the forward recompute
     return None
 
@@ -138,11 +139,11 @@ def roofline_entry(kernel, mean_ms, bound, work, main_points):
     if kernel == "nsamd_field_mlp_bwd_scatter_phase[gradients+records]":
         # this launch also carries the table scatter's ROUTE pass: it derives and stores the x-pair records
         # — HBM work that `achieved` (flops only) does not credit; `roofline_min_ms` adds its streaming time at the HBM peak
-        rec = main_points * 16 * 4 * 16
-        roof["fused_route_pass"] = {"record_bytes": int(rec),
+        rec = main_points * 16 * 8 * 8  # its half of the scatter's algorithmic read-modify-write bytes (see the apply phase)
+        roof["fused_route_pass"] = {"algorithmic_bytes": int(rec),
                                     "roofline_min_ms": round((work / (F32_MFMA_PEAK_TFLOPS * 1e12) + rec / (HBM_PEAK_GBS * 1e9)) * 1e3, 4),
                                     "frac_of_roofline_min": round((work / (F32_MFMA_PEAK_TFLOPS * 1e12) + rec / (HBM_PEAK_GBS * 1e9)) / sec, 4)}
-    ex = executed_per_launch(base, main_points)
+    ex = executed_per_launch(kernel if "[" in kernel and kernel.startswith("nsamd_field_mlp_bwd_scatter_phase") else base, main_points)
     if ex is not None:  # the utilisation view (work the launch executes, incl. recomputation)
         roof["executed_per_launch"] = ex
         roof["executed_frac"] = round(ex / sec / (1e9 if bound == "hbm" else 1e12) / peak, 4)
