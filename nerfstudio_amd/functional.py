@@ -1061,10 +1061,11 @@ def packed_info_from_counts(counts: Tensor) -> Tuple[Tensor, int]:
 def occgrid_march(origins: Tensor, directions: Tensor, binaries: Tensor, roi_aabb: Sequence[float], step_size: float,
                   near_plane: float = 0.0, far_plane: float = 1e10, t_min: Optional[Tensor] = None,
                   t_max: Optional[Tensor] = None, cone_angle: float = 0.0, jitter: Optional[Tensor] = None,
-                  coarse: Optional[Tensor] = None):
+                  coarse: Optional[Tensor] = None, stash_cap: int = 128):
     """Ray marching through a multi-level occupancy grid (`binaries [levels,R,R,R]` uint8) -> (ray_indices int64 `[n]`,
     t_starts, t_ends fp32 `[n]`, packed_info `[N,2]`). Count pass, prefix, write pass. `coarse`: the grid's 4x4x4-block
-    bitfield (occgrid_binarise) — empty-space skipping, same samples."""
+    bitfield (occgrid_binarise) — empty-space skipping, same samples. `stash_cap` > 0: the count pass leaves every ray's first
+    `stash_cap` kept steps in a scratch and the write pass copies them (a ray is marched once; same values), 0: march twice."""
     N.require_cuda(origins, directions, binaries)
     o, d = _f32c(origins), _f32c(directions)
     assert binaries.dtype == torch.uint8 and binaries.is_contiguous() and binaries.dim() == 4
@@ -1077,18 +1078,19 @@ def occgrid_march(origins: Tensor, directions: Tensor, binaries: Tensor, roi_aab
     counts = torch.empty((n,), device=dev, dtype=torch.int32)
     lib = N.load()
     far = min(float(far_plane), 3.0e38)
-    N.check(lib.nsamd_occgrid_march_count(N.ptr(o), N.ptr(d), N.ptr(tmin), N.ptr(tmax), n, float(near_plane), far, grid,
-                                          float(step_size), float(cone_angle), N.ptr(jit), N.ptr(counts), N.stream()),
-            "occgrid_march_count")
+    stash = torch.empty((n, int(stash_cap), 2), device=dev, dtype=torch.float32) if stash_cap > 0 else None
+    N.check(lib.nsamd_occgrid_march_count_stash(N.ptr(o), N.ptr(d), N.ptr(tmin), N.ptr(tmax), n, float(near_plane), far, grid,
+                                                float(step_size), float(cone_angle), N.ptr(jit), N.ptr(counts), N.ptr(stash),
+                                                int(stash_cap), N.stream()), "occgrid_march_count_stash")
     info, total = packed_info_from_counts(counts)
     ray_indices = torch.empty((total,), device=dev, dtype=torch.int64)
     t_starts = torch.empty((total,), device=dev, dtype=torch.float32)
     t_ends = torch.empty((total,), device=dev, dtype=torch.float32)
     if total:
-        N.check(lib.nsamd_occgrid_march_write(N.ptr(o), N.ptr(d), N.ptr(tmin), N.ptr(tmax), n, float(near_plane), far, grid,
-                                              float(step_size), float(cone_angle), N.ptr(jit), N.ptr(info),
-                                              N.ptr(ray_indices), N.ptr(t_starts), N.ptr(t_ends), N.stream()),
-                "occgrid_march_write")
+        N.check(lib.nsamd_occgrid_march_write_stashed(N.ptr(o), N.ptr(d), N.ptr(tmin), N.ptr(tmax), n, float(near_plane), far,
+                                                      grid, float(step_size), float(cone_angle), N.ptr(jit), N.ptr(info),
+                                                      N.ptr(stash), int(stash_cap), N.ptr(ray_indices), N.ptr(t_starts),
+                                                      N.ptr(t_ends), N.stream()), "occgrid_march_write_stashed")
     return ray_indices, t_starts, t_ends, info
 
 

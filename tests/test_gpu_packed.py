@@ -436,6 +436,54 @@ def test_marcher_with_coarse_occupancy_bits_places_the_same_samples(F, levels, r
             np.testing.assert_array_equal(a.cpu().numpy(), c_)
 
 
+@pytest.mark.parametrize("stash_cap", [3, 40, 4096])
+def test_marcher_that_marches_every_ray_once_places_the_same_samples(F, stash_cap):
+    """nsamd_occgrid_march_count_stash / _write_stashed (the count pass leaves a ray's first `stash_cap` kept steps behind, the
+    write pass copies them and marches only the rays that kept more a second time) against the plain two-pass pair and the
+    oracle: identical ray indices, bin edges and packed_info — with a stash nearly every ray overflows (3), one that some rays
+    overflow (40) and one nobody does."""
+    rs = np.random.RandomState(11)
+    levels, res, n = 2, 32, 257
+    o, d = _rays(n, 5, scale=1.5)
+    jit = rs.uniform(0, 1, n).astype(np.float32)
+    B = rs.rand(levels, res, res, res) > 0.8
+    binaries = torch.from_numpy(B.astype(np.uint8)).cuda()
+    plain = F.occgrid_march(dev(o), dev(d), binaries, ROI, 0.02, 0.05, 50.0, None, None, 0.004, dev(jit), stash_cap=0)
+    once = F.occgrid_march(dev(o), dev(d), binaries, ROI, 0.02, 0.05, 50.0, None, None, 0.004, dev(jit), stash_cap=stash_cap)
+    ref = po.occgrid_march(o, d, B, ROI, 0.02, near_plane=0.05, far_plane=50.0, cone_angle=0.004, jitter=jit)
+    counts = plain[3][:, 1].cpu().numpy()
+    assert counts.max() > 40 > np.median(counts) > 3  # the three stash sizes do exercise the three cases
+    for a, b in zip(once, plain):
+        np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    for a, c_ in zip(once[:3], ref):
+        np.testing.assert_array_equal(a.cpu().numpy(), c_)
+
+
+def test_field_forward_without_the_head_gives_the_same_density(F):
+    """nsamd_field_mlp_fwd with rgb == NULL (Field.density_fn: what the instant-ngp sampler asks of its candidates) against the
+    full call: the density bit for bit, ragged M."""
+    from nerfstudio_amd import _native as N
+
+    g = torch.Generator().manual_seed(4)
+    M = 16 * 37 + 5
+    enc = (torch.randn(32, M, generator=g) * 0.5).cuda()
+    sel = (torch.rand(M, generator=g) > 0.1).float().cuda()
+    dirs = torch.nn.functional.normalize(torch.randn(1, 3, generator=g), dim=-1).cuda()
+    shapes = [(64, 32), (64,), (16, 64), (16,), (64, 63), (64,), (64, 64), (64,), (3, 64), (3,)]
+    prm = [(torch.randn(*sh, generator=g) * 0.3).cuda().contiguous() for sh in shapes]
+    app0 = torch.zeros(32, device="cuda")
+    fm = N.FieldMlp(*(N.ptr(p) for p in prm), None, 0, 1.0)
+    lib = N.load()
+    d_full, rgb = torch.empty(M, device="cuda"), torch.empty(M, 3, device="cuda")
+    d_only = torch.full((M,), -1.0, device="cuda")
+    N.check(lib.nsamd_field_mlp_fwd(N.ptr(enc), N.ptr(sel), N.ptr(dirs), None, N.ptr(app0), M, M, fm, N.ptr(d_full), N.ptr(rgb),
+                                    N.stream()), "field_mlp_fwd")
+    N.check(lib.nsamd_field_mlp_fwd(N.ptr(enc), N.ptr(sel), N.ptr(dirs), None, N.ptr(app0), M, M, fm, N.ptr(d_only), None,
+                                    N.stream()), "field_mlp_fwd (density only)")
+    torch.cuda.synchronize()
+    assert torch.equal(d_only, d_full) and float(d_full.abs().max()) > 0 and bool(torch.isfinite(rgb).all())
+
+
 def test_occupancy_grid_refresh_kernels_equal_the_torch_path(F):
     """OccGridEstimator.update_every_n_steps on the GPU (cell positions, decayed maximum with repeated cells, mean /
     threshold / binaries — csrc/packed.hip) against the same module on CPU tensors (plain torch), fed the same cells, offsets
