@@ -16,7 +16,7 @@ db = sqlite3.connect(dbs[0])
 rows = db.execute("select name, start, end, grid_x*grid_y*grid_z, workgroup_x, queue_id, stream_id from kernels order by start").fetchall()
 # a step starts at select_batch; take the last 3 complete steps
 starts = [i for i, r in enumerate(rows) if "select_batch" in r[0]]
-lo, hi = starts[-4], starts[-1]
+lo, hi = starts[-5], starts[-1]
 t0 = rows[lo][1]
 with open(os.path.join(out, "timeline.csv"), "w") as f:
     f.write("kernel,start_us,end_us,dur_us,grid,wg,queue,stream\n")
