@@ -441,16 +441,6 @@ int nsamd_render_train(const float* rgb, const float* density, const float* t_bi
                        int background, const float* bg_rgb_host, const float* target, float grad_scale, float* weights,
                        float* rgb_out, float* acc, float* depth_expected, float* depth_median, float* workspace,
                        float* sq_err, float* d_rgb_out, const float* bg_rays, nsamd_stream_t stream);
-/* nsamd_render_train in two halves, for a caller that takes the small dependent launch of the global depth clip
- * (renderers.py:310, torch.clip(depth, steps.min(), steps.max())) off its critical path: _unclipped leaves depth_expected
- * unclipped and the partial extrema in `workspace`; nsamd_depth_clip (any stream ordered after it) finishes it. Together they
- * are nsamd_render_train, bit for bit. */
-int nsamd_render_train_unclipped(const float* rgb, const float* density, const float* t_bins, int64_t num_rays, int32_t S,
-                                 int background, const float* bg_rgb_host, const float* target, float grad_scale,
-                                 float* weights, float* rgb_out, float* acc, float* depth_expected, float* depth_median,
-                                 float* workspace, float* sq_err, float* d_rgb_out, const float* bg_rays,
-                                 nsamd_stream_t stream);
-int nsamd_depth_clip(float* depth_expected, int64_t num_rays, float* workspace, nsamd_stream_t stream);
 int nsamd_render_train_bwd(const float* rgb, const float* weights, const float* density, const float* t_bins,
                            int64_t num_rays, int32_t S, int background, const float* bg_rgb_host,
                            const float* d_rgb_out, const float* d_weights_add, float* d_rgb, float* d_density,

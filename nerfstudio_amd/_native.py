@@ -102,8 +102,6 @@ _SIGNATURES = {
     "nsamd_proposal_resample": [vp, vp, vp, i32, vp, vp, vp, vp, f32, vp, f32, f32, f32, C.c_int, i64, i32, vp, vp, vp, vp, vp],
     "nsamd_composite_fwd": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), C.c_int, vp, vp, vp, vp, vp, vp, vp],
     "nsamd_render_train": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "nsamd_render_train_unclipped": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "nsamd_depth_clip": [vp, i64, vp, vp],
     "nsamd_render_train_bwd": [vp, vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, vp, vp, vp, vp, vp],
     "nsamd_composite_bwd": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, vp, vp, vp, vp, vp, vp, vp],
     "nsamd_distance_gradient_scale": [vp, i64, i32, vp, vp, vp],

@@ -431,11 +431,11 @@ extern "C" int nsamd_composite_bwd(const float* rgb, const float* weights, const
   return NSAMD_OK;
 }
 
-static int render_train_launch(const float* rgb, const float* density, const float* t_bins, int64_t num_rays, int32_t S,
-                               int background, const float* bg_rgb_host, const float* target, float grad_scale,
-                               float* weights, float* rgb_out, float* acc, float* depth_expected, float* depth_median,
-                               float* workspace, float* sq_err, float* d_rgb_out, const float* bg_rays,
-                               nsamd_stream_t stream, bool clip) {
+extern "C" int nsamd_render_train(const float* rgb, const float* density, const float* t_bins, int64_t num_rays,
+                                  int32_t S, int background, const float* bg_rgb_host, const float* target,
+                                  float grad_scale, float* weights, float* rgb_out, float* acc, float* depth_expected,
+                                  float* depth_median, float* workspace, float* sq_err, float* d_rgb_out,
+                                  const float* bg_rays, nsamd_stream_t stream) {
   NSAMD_REQUIRE(num_rays >= 0 && S > 0);
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(rgb && density && t_bins && weights && rgb_out);
@@ -452,44 +452,11 @@ static int render_train_launch(const float* rgb, const float* density, const flo
                                                           rgb_out, acc, depth_expected, depth_median, nullptr, workspace,
                                                           density, weights, target, grad_scale, sq_err, d_rgb_out, bg_rays);
   NSAMD_CHECK_LAUNCH();
-  if (depth_expected && clip) {
+  if (depth_expected) {
     depth_clip_kernel<<<(unsigned)((num_rays + 255) / 256), 256, 0, st>>>(depth_expected, num_rays, workspace,
                                                                           (int)blocks);
     NSAMD_CHECK_LAUNCH();
   }
-  return NSAMD_OK;
-}
-
-extern "C" int nsamd_render_train(const float* rgb, const float* density, const float* t_bins, int64_t num_rays,
-                                  int32_t S, int background, const float* bg_rgb_host, const float* target,
-                                  float grad_scale, float* weights, float* rgb_out, float* acc, float* depth_expected,
-                                  float* depth_median, float* workspace, float* sq_err, float* d_rgb_out,
-                                  const float* bg_rays, nsamd_stream_t stream) {
-  return render_train_launch(rgb, density, t_bins, num_rays, S, background, bg_rgb_host, target, grad_scale, weights, rgb_out,
-                             acc, depth_expected, depth_median, workspace, sq_err, d_rgb_out, bg_rays, stream, true);
-}
-
-// nsamd_render_train in two halves: everything but the global clip of the expected depth (nothing on the training path reads
-// the depth, so a caller can take the tiny dependent clip launch off its critical path) ...
-extern "C" int nsamd_render_train_unclipped(const float* rgb, const float* density, const float* t_bins, int64_t num_rays,
-                                            int32_t S, int background, const float* bg_rgb_host, const float* target,
-                                            float grad_scale, float* weights, float* rgb_out, float* acc,
-                                            float* depth_expected, float* depth_median, float* workspace, float* sq_err,
-                                            float* d_rgb_out, const float* bg_rays, nsamd_stream_t stream) {
-  return render_train_launch(rgb, density, t_bins, num_rays, S, background, bg_rgb_host, target, grad_scale, weights, rgb_out,
-                             acc, depth_expected, depth_median, workspace, sq_err, d_rgb_out, bg_rays, stream, false);
-}
-
-// ... and the clip: depth_expected [N] of the call above -> clip(depth, min t, max t) from the partial extrema it left in
-// `workspace` (renderers.py:310: torch.clip(depth, steps.min(), steps.max())). Any stream ordered after that call.
-extern "C" int nsamd_depth_clip(float* depth_expected, int64_t num_rays, float* workspace, nsamd_stream_t stream) {
-  NSAMD_REQUIRE(num_rays >= 0);
-  if (num_rays == 0) return NSAMD_OK;
-  NSAMD_REQUIRE(depth_expected && workspace);
-  const unsigned blocks = (unsigned)((num_rays + kRaysPerBlock - 1) / kRaysPerBlock);
-  depth_clip_kernel<<<(unsigned)((num_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(depth_expected, num_rays, workspace,
-                                                                                       (int)blocks);
-  NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }
 

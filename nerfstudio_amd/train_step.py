@@ -31,10 +31,6 @@ from .nerfacto import NerfactoModel
 from .utils import profiler
 
 
-# timing diagnostic only: no expected depth, hence no global-clip launch between the compositing and the proposal losses
-_DIAG_NO_DEPTH_CLIP = os.environ.get("NSAMD_DIAG_NO_DEPTH_CLIP") == "1"
-
-
 class NerfactoTrainStep:
     def __init__(self, model: NerfactoModel, num_rays: int, device, compute_depths: bool = True,
                  forward_only: bool = False) -> None:
@@ -156,19 +152,13 @@ class NerfactoTrainStep:
         self.reduce_stream = torch.cuda.Stream(device=device)
         self._red_fork, self._red_join = torch.cuda.Event(), torch.cuda.Event()
         self._level_join = [torch.cuda.Event() for _ in self.level_streams]
-        # The global clip of the expected depth (a 4 us launch nothing on the training path reads) beside the losses and the
-        # backward instead of between the compositing and the proposal losses; joined at the end of `backward_main`, so only
-        # a caller whose every iteration gets there (trainer.HipTrainer, N = 1) switches it on. Same bits.
-        self.clip_beside = False
-        self._clip_fork, self._clip_join = torch.cuda.Event(), torch.cuda.Event()
-        self._clip_open = False
         # Proposal levels may run their backward chains on separate streams only when they share nothing: a shared
         # network (use_same_proposal_network) means one gradient buffer, and equal (grid, sample count) means one
         # scatter workspace — concurrent launches would race on either.
         keys = [(id(self.props[lvl]), self.props[lvl].encoding.spec, n * self.counts[lvl]) for lvl in range(self.n_prop)]
         self.levels_independent = (len({k[0] for k in keys}) == self.n_prop and
                                    len({(k[1], k[2]) for k in keys}) == self.n_prop)
-        if os.environ.get("NSAMD_LEVEL_STREAMS", "1") == "0":  # A/B: every level's chain on the one side stream
+        if os.environ.get("NSAMD_LEVEL_STREAMS", "1") == "0":  # A/B (profiles/r04_exp14_*): every level's chain on the one side stream
             self.levels_independent = False
         # ---- camera optimiser (nerfstudio's nerfacto default is SO3xR3, the benchmark recipe is "off") ----
         # Host-side torch computes the corrected rays from `pose_adjustment` (a [num_cameras, 6] parameter); the kernels
@@ -422,17 +412,6 @@ class NerfactoTrainStep:
         self._corrected = None
 
     @profiler.time_function
-    def draw_jitters(self) -> None:
-        """This iteration's random numbers, drawn on the device (graph-safe Philox): depends on nothing, so a caller may
-        launch it on another stream ahead of `forward_proposals(draw_jitter=False)`."""
-        if not self.single_jitter:
-            for j in self.jitter_edges:
-                j.uniform_()
-        else:
-            self.jitter.uniform_()  # torch.rand per level and ray (ray_samplers.py:105, :322)
-        if self.bg_rays is not None:
-            self.bg_rays.uniform_()  # rand_like(pred) of the loss blend (renderers.py:195)
-
     def forward_proposals(self, draw_jitter: bool = True, need_enc: bool = True) -> None:
         """Initial bins and the proposal levels (density fields + resampling): reads only the proposal networks'
         parameters, so with data parallelism it can run while the main-field gradients of the previous step are still
@@ -443,7 +422,13 @@ class NerfactoTrainStep:
         ck = N.check
         per_edge = not self.single_jitter
         if draw_jitter:
-            self.draw_jitters()
+            if per_edge:
+                for j in self.jitter_edges:
+                    j.uniform_()
+            else:
+                self.jitter.uniform_()  # torch.rand per level and ray (ray_samplers.py:105, :322), drawn on the device
+            if self.bg_rays is not None:
+                self.bg_rays.uniform_()  # rand_like(pred) of the loss blend (renderers.py:195)
         S0 = self.counts[0]
         jit0 = self.jitter_edges[0] if per_edge else self.jitter[0]
         ck(lib.nsamd_piecewise_bins(N.ptr(self.nears), N.ptr(self.fars), N.ptr(self.edges), N.ptr(jit0), int(per_edge), n, S0,
@@ -545,21 +530,11 @@ class NerfactoTrainStep:
         L = self.n_prop
         S = self.counts[L]
         # weights + compositing + MSE value/gradient in one launch (+ the global depth clip)
-        beside = self.clip_beside and self.reduce_stream is not None and not _DIAG_NO_DEPTH_CLIP
-        entry = lib.nsamd_render_train_unclipped if beside else lib.nsamd_render_train
-        ck(entry(N.ptr(self.f_rgb), N.ptr(self.f_dens), N.ptr(self.t_bins[L]), n, S, self.bg_mode,
-                 self.bg_vals, N.ptr(self.target), 1.0 / (3 * n), N.ptr(self.weights[L]), N.ptr(self.rgb),
-                 N.ptr(self.acc), N.ptr(self.depth_exp) if not _DIAG_NO_DEPTH_CLIP else None,
-                 N.ptr(self.depth_med[L]) if self.compute_depths else None, N.ptr(self.minmax_ws),
-                 N.ptr(self.sq_err), N.ptr(self.d_rgb_out), N.ptr(self.bg_rays), st), "render_train")
-        if beside:
-            main = torch.cuda.current_stream()
-            self._clip_fork.record(main)
-            self.reduce_stream.wait_event(self._clip_fork)
-            with torch.cuda.stream(self.reduce_stream):
-                ck(lib.nsamd_depth_clip(N.ptr(self.depth_exp), n, N.ptr(self.minmax_ws), N.stream()), "depth_clip")
-                self._clip_join.record(self.reduce_stream)
-            self._clip_open = True
+        ck(lib.nsamd_render_train(N.ptr(self.f_rgb), N.ptr(self.f_dens), N.ptr(self.t_bins[L]), n, S, self.bg_mode,
+                                  self.bg_vals, N.ptr(self.target), 1.0 / (3 * n), N.ptr(self.weights[L]), N.ptr(self.rgb),
+                                  N.ptr(self.acc), N.ptr(self.depth_exp),
+                                  N.ptr(self.depth_med[L]) if self.compute_depths else None, N.ptr(self.minmax_ws),
+                                  N.ptr(self.sq_err), N.ptr(self.d_rgb_out), N.ptr(self.bg_rays), st), "render_train")
         # ---- proposal losses: value + gradient, all levels in one launch (models/nerfacto.py:363-375) ----
         ck(lib.nsamd_proposal_losses(N.ptr(self.s_bins[L]), N.ptr(self.weights[L]), S, self.n_prop, self._pl_s_bins,
                                      self._pl_weights, self._pl_S, n, float(cfg.interlevel_loss_mult) / (n * S),
@@ -584,13 +559,6 @@ class NerfactoTrainStep:
                "distance_gradient_scale")
         if field:
             self.backward_field_and_table()
-        self.join_depth_clip()
-
-    def join_depth_clip(self) -> None:
-        """`clip_beside`: the current stream waits for the depth clip `losses` put on another stream (no-op otherwise)."""
-        if self._clip_open:
-            torch.cuda.current_stream().wait_event(self._clip_join)
-            self._clip_open = False
 
     def backward_field_and_table(self) -> None:
         """Second half of backward_main: the main field's MLPs (from `d_dens_main`, `d_rgb_s`) and the table scatter. Separate

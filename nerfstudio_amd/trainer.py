@@ -87,8 +87,6 @@ class HipTrainer:
         self.hyper_ring = [torch.zeros(_HYPER_FLOATS).pin_memory() if self.on_gpu else torch.zeros(_HYPER_FLOATS) for _ in range(64)]
         self.hyper_events = [None] * 64
         self.hyper_slot = 0
-        self._diag_no_hyper = os.environ.get("NSAMD_DIAG_NO_HYPER") == "1"
-        self.hyper_parity = False
         if lr_source is None:
             from .schedulers import ExponentialDecayScheduler, ExponentialDecaySchedulerConfig, nerfacto_schedulers
 
@@ -144,20 +142,6 @@ class HipTrainer:
                 self.opt_stream = torch.cuda.Stream(device=dev)
                 self._opt_fork, self._opt_join = torch.cuda.Event(), torch.cuda.Event()
                 self._sh_fork, self._sh_join = torch.cuda.Event(), torch.cuda.Event()
-            # NSAMD_HYPER_PARITY=1: two copies of the device-resident scalars, iteration k reads copy k % 2, so that the host's
-            # upload for iteration k + 1 runs on its own stream WHILE iteration k executes instead of as a launch between two
-            # graph replays (measured upper bound: 8-16 us per iteration, profiles/r04_critical_path_launches.txt); the
-            # captured graphs exist once per copy.
-            self.hyper_parity = self.defer and os.environ.get("NSAMD_HYPER_PARITY", "0") == "1"
-            if self.hyper_parity:
-                self.hyper_bufs = [self.hyper, torch.zeros_like(self.hyper)]
-                self.copy_stream = torch.cuda.Stream(device=dev)
-                self._hyper_copied = [torch.cuda.Event(), torch.cuda.Event()]
-                self._hyper_read = [None, None]  # recorded after the last launch that reads copy i
-                self._parity = 1  # (the first push binds copy 0)
-            # the global depth clip beside the losses / backward (train_step.NerfactoTrainStep.clip_beside)
-            if hasattr(r, "clip_beside"):
-                r.clip_beside = not self.dp and self.on_gpu and os.environ.get("NSAMD_CLIP_BESIDE", "0") == "1"
             if self.dp:
                 from .dp_schedule import PipelinedExchange
 
@@ -195,23 +179,6 @@ class HipTrainer:
             self.model.set_step(self.step)  # BEFORE_TRAIN_ITERATION callback: proposal weight anneal
         self._push_hyper()
 
-    def _bind_hyper(self, i):
-        """Everything that passes an address inside the scalars' buffer to a kernel now points into copy i."""
-        self.hyper = self.hyper_bufs[i]
-        self.hyper_views = {g: self.hyper[o:o + 2] for g, o in _HYPER.items()}
-        anneal = self.hyper[_HYPER_ANNEAL:_HYPER_ANNEAL + 1]
-        self.model.proposal_sampler.anneal_dev = anneal
-        if self.runner is not None:
-            self.runner.anneal_dev = anneal
-
-    def _hyper_was_read(self):
-        """After the launches of an iteration (or of `finish`): the copy they read may be overwritten once they are done."""
-        if self.hyper_parity:
-            ev = self._hyper_read[self._parity]
-            if ev is None:
-                ev = self._hyper_read[self._parity] = torch.cuda.Event()
-            ev.record()
-
     def _push_hyper(self):
         """Adam step sizes of the NEXT update of each group + the anneal exponent -> device (async, race-free)."""
         from . import functional as F
@@ -231,22 +198,6 @@ class HipTrainer:
             h[off], h[off + 1] = F.adam_hyper(a.step_counts[group] + 1, lr, a.betas)
         h[_HYPER_ANNEAL] = m.proposal_sampler._anneal
         h[_HYPER_SLOT] = float(self.step % self.slots)
-        if self._diag_no_hyper and self.step > 12:  # timing diagnostic only (stale step sizes, one batch over and over)
-            return
-        if self.hyper_parity:
-            i = self._parity = self._parity ^ 1
-            self._bind_hyper(i)
-            main, cs = torch.cuda.current_stream(), self.copy_stream
-            if self._hyper_read[i] is not None:
-                cs.wait_event(self._hyper_read[i])  # the iteration before last: done long before the host gets here
-            with torch.cuda.stream(cs):
-                self.hyper.copy_(h, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(cs)
-                self.hyper_events[slot] = ev
-                self._hyper_copied[i].record(cs)
-            main.wait_event(self._hyper_copied[i])
-            return
         self.hyper.copy_(h, non_blocking=True)
         if self.on_gpu:
             ev = torch.cuda.Event()
@@ -464,7 +415,6 @@ class HipTrainer:
             if self.defer_scatter:
                 self.runner.backward_table(shadow=True)
             self.arena.step(grad_scale=1.0, groups=["fields"], hyper_dev=self.hyper_views)
-            self._hyper_was_read()
             self._pending_main = False
             self._true_steps = dict(self.arena.step_counts)
 
@@ -525,17 +475,12 @@ class HipTrainer:
                     self._seg(name)
                 graphs[name] = g
         elif self.defer:
-            for par in ((0, 1) if self.hyper_parity else (None,)):
-                if par is not None:
-                    self._bind_hyper(par)
-                for upd in (True, False):
-                    for pend in (True, False):
-                        g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g):  # the whole iteration is one graph
-                            self._deferred_iteration_body(upd, pend)
-                        graphs[("all", upd, pend, par)] = g
-            if self.hyper_parity:
-                self._bind_hyper(self._parity)
+            for upd in (True, False):
+                for pend in (True, False):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):  # the whole iteration is one graph
+                        self._deferred_iteration_body(upd, pend)
+                    graphs[("all", upd, pend)] = g
         else:
             for upd in (True, False):
                 g = torch.cuda.CUDAGraph()
@@ -574,7 +519,6 @@ class HipTrainer:
                 self._plain_body(updated)
             if self._cams_outside:
                 self._cameras_after(updated)
-            self._hyper_was_read()
         self._true_steps = dict(self.arena.step_counts)
 
     def try_capture(self, warm: bool = True):
@@ -603,7 +547,7 @@ class HipTrainer:
             if self._cams_outside:
                 self._cameras_before()
             if self.defer:
-                self.graphs[("all", updated, self._pending_main, self._parity if self.hyper_parity else None)].replay()
+                self.graphs[("all", updated, self._pending_main)].replay()
                 stepped = (("fields",) if self._pending_main else ()) + (("proposal_networks",) if updated else ())
                 self._pending_main = True
             else:
@@ -615,7 +559,6 @@ class HipTrainer:
                 self.arena.step_counts[name] += 1  # the replayed Adam launches did step these groups
             if self._cams_outside:
                 self._cameras_after(updated)
-            self._hyper_was_read()
             self._true_steps = dict(self.arena.step_counts)
         self.opt_step += 1
         if updated:

@@ -92,8 +92,7 @@ def test_bench_configuration_parity_through_replayed_graph(F, init):
     rs = np.random.RandomState(11)
     tr.runner.jitter.copy_(torch.from_numpy(rs.uniform(0, 1, (3, n)).astype(np.float32)))
     tr.capture()  # two eager warm-up iterations (parameters move), then the four variants
-    copies = (0, 1) if tr.hyper_parity else (None,)
-    assert tr.defer and set(tr.graphs) == {("all", u, p, c) for u in (True, False) for p in (True, False) for c in copies}
+    assert tr.defer and set(tr.graphs) == {("all", u, p) for u in (True, False) for p in (True, False)}
     # one replayed iteration first, so that the iterations under test run with the main-field Adam PENDING (the steady
     # state of the benched schedule: the update of iteration k-1 is the first node of iteration k's graph)
     tr.train_iteration()
@@ -230,13 +229,10 @@ def test_bench_configuration_parity_through_replayed_graph(F, init):
     print("\nbench-size parity [init %s] (updated, rgb L-inf, worst tensor: (gpu-f64, ref32-f64, gpu-ref32) rel-L2):" % init, checked)
 
 
-@pytest.mark.parametrize("schedule", ["default", "uploads and depth clip off the critical path"])
-def test_graph_replay_trains_through_the_same_bits_as_eager_launches(F, schedule, monkeypatch):
+def test_graph_replay_trains_through_the_same_bits_as_eager_launches(F):
     """(2) of the module docstring: K = 6 iterations at the benchmark configuration, replayed from the captured hipGraphs
     with the main-field Adam deferred, against eager launches with Adam in order on one stream. torch.equal on the
-    parameter arena and both moments — and on the expected depths of the last iteration. Second case: the graph arm with the
-    step-dependent scalars double-buffered (uploaded beside the previous iteration) and the global depth clip on a side branch."""
-    on = "0" if schedule == "default" else "1"
+    parameter arena and both moments."""
     cfg = orc.NerfactoCfg()
     K = 6
     rs = np.random.RandomState(3)
@@ -245,14 +241,11 @@ def test_graph_replay_trains_through_the_same_bits_as_eager_launches(F, schedule
     for use_graph in (True, False):
         F._SCATTER_WS.clear()
         params = orc.init_params(cfg, seed=0)
-        monkeypatch.setenv("NSAMD_HYPER_PARITY", on if use_graph else "0")
-        monkeypatch.setenv("NSAMD_CLIP_BESIDE", on if use_graph else "0")
         bench, model, arena, tr = _bench_trainer(F, params, cfg, use_graph=use_graph)
         tr.runner.jitter.copy_(torch.from_numpy(jit[K]))
         if use_graph:
             tr.capture()
-            assert tr.hyper_parity == (on == "1") and tr.runner.clip_beside == (on == "1")
-            assert tr.defer and len(tr.graphs) == (8 if tr.hyper_parity else 4)
+            assert tr.defer and len(tr.graphs) == 4
         else:
             assert not tr.defer
             tr.runner.side_stream = None  # one stream, kernels in program order
@@ -263,11 +256,11 @@ def test_graph_replay_trains_through_the_same_bits_as_eager_launches(F, schedule
         tr.finish()
         torch.cuda.synchronize()
         states.append((arena.flat.clone(), arena.exp_avg.clone(), arena.exp_avg_sq.clone(),
-                       float(sum(tr.runner.loss_dict().values())), tr.runner.depth_exp.clone()))
+                       float(sum(tr.runner.loss_dict().values()))))
         del tr, arena, model
     g, e = states
     assert np.isfinite(g[3]) and g[3] == e[3], (g[3], e[3])
-    for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq", "expected depth"), g[:3] + g[4:], e[:3] + e[4:]):
+    for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq"), g[:3], e[:3]):
         assert torch.equal(x, y), f"{name}: {int((x != y).sum())} of {x.numel()} elements differ between graph replay and eager"
 
 
