@@ -82,6 +82,34 @@ void hc_positions(const float* origins, const float* directions, const float* t_
   for (int64_t p = 0; p < rays * S; ++p) load_position(P, p, out[3 * p], out[3 * p + 1], out[3 * p + 2]);
 }
 
+// ... and through the two "burst" forms the hash forward and the scatter's route kernels use (same arithmetic, loads laid
+// out differently): variant 1 = load_position_burst, 2 = load_positions_burst<4> over 4 consecutive points
+void hc_positions_burst(const float* origins, const float* directions, const float* t_bins, const float* positions,
+                        int64_t rays, int64_t S, int variant, float* out /* [rays*S,3] */) {
+  nsamd_points P;
+  P.positions = positions;
+  P.origins = origins;
+  P.directions = directions;
+  P.t_bins = t_bins;
+  P.samples_per_ray = S;
+  const int64_t M = rays * S;
+  if (variant == 1) {
+    for (int64_t p = 0; p < M; ++p) load_position_burst(P, p, out[3 * p], out[3 * p + 1], out[3 * p + 2]);
+    return;
+  }
+  for (int64_t p0 = 0; p0 < M; p0 += 4) {
+    int64_t p[4];
+    float x[4], y[4], z[4];
+    for (int k = 0; k < 4; ++k) p[k] = p0 + k < M ? p0 + k : M - 1;  // (clamped, as the kernels do)
+    load_positions_burst<4>(P, p, x, y, z);
+    for (int k = 0; k < 4 && p0 + k < M; ++k) {
+      out[3 * (p0 + k)] = x[k];
+      out[3 * (p0 + k) + 1] = y[k];
+      out[3 * (p0 + k) + 2] = z[k];
+    }
+  }
+}
+
 void hc_nan_to_num(float* v, int64_t n, float nan_value) {
   for (int64_t i = 0; i < n; ++i) v[i] = nan_to_num(v[i], nan_value);
 }

@@ -40,6 +40,8 @@ def hc(tmp_path_factory):
     lib.hc_spacing_to_euclidean.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float]
     lib.hc_spacing_to_euclidean.restype = C.c_float
     lib.hc_positions.argtypes = [F32P, F32P, F32P, C.c_int64, C.c_int64, F32P]
+    opt = C.c_void_p  # (nullable float arrays: passed as raw addresses)
+    lib.hc_positions_burst.argtypes = [opt, opt, opt, opt, C.c_int64, C.c_int64, C.c_int, F32P]
     lib.hc_nan_to_num.argtypes = [F32P, C.c_int64, C.c_float]
     lib.hc_fixed_scale.argtypes = [C.c_uint32, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.hc_to_fixed.argtypes = [F32P, C.c_int64, C.c_int, I64P]
@@ -180,6 +182,28 @@ def test_frustum_positions(hc):
     hc.hc_positions(o, d, np.ascontiguousarray(t), rays, S, out)
     want = O.sample_positions(torch.from_numpy(o), torch.from_numpy(d), torch.from_numpy(t)).reshape(-1, 3).numpy()
     np.testing.assert_array_equal(out, want)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("explicit", [False, True])
+def test_burst_position_loaders_equal_the_plain_one(hc, variant, explicit):
+    """load_position_burst / load_positions_burst<N> (csrc/common.h: the loads of a lane's positions issued in one go — hash
+    forward, the scatter's route kernels) against load_position on ray-form and explicit points: same bits."""
+    rs = np.random.RandomState(16)
+    rays, S = 29, 7  # (rays * S not a multiple of 4: the last group of the <4> variant is clamped)
+    o = rs.standard_normal((rays, 3)).astype(np.float32)
+    d = rs.standard_normal((rays, 3)).astype(np.float32)
+    t = np.ascontiguousarray(np.sort(rs.uniform(0.05, 20.0, (rays, S + 1)).astype(np.float32), axis=-1))
+    want = np.zeros((rays * S, 3), np.float32)
+    hc.hc_positions(o, d, t, rays, S, want)
+    got = np.zeros_like(want)
+    pos = want.copy()
+    addr = lambda a: a.ctypes.data  # noqa: E731
+    if explicit:
+        hc.hc_positions_burst(None, None, None, addr(pos), rays, S, variant, got)
+    else:
+        hc.hc_positions_burst(addr(o), addr(d), addr(t), None, rays, S, variant, got)
+    np.testing.assert_array_equal(got, want)
 
 
 def test_nan_to_num(hc):
