@@ -284,14 +284,7 @@ int nsamd_field_mlp_bwd_scatter(nsamd_points pts, int transform, nsamd_aabb aabb
                                 int64_t scatter_workspace_floats, nsamd_stream_t stream);
 /* The same call one launch group at a time (per-kernel timing of the benchmark's roofline leg; the groups in order give the
  * single call's bits): phase 1 = the gradient kernel with the record emission, 2 = the weight-gradient reduce, 4 = the
- * scatter's apply + finish passes over the records phase 1 left in the queues.
- * Phase 2 depends on phase 1 only and nothing but the optimiser depends on it. Where
- * nsamd_field_mlp_bwd_reduce_is_self_contained(M, dir_group, mlp.num_images, grads.appearance != NULL, workspace_floats)
- * returns 1 it reads nothing but `workspace` (phase 1 keeps every tile's camera index beside its appearance row) and
- * accumulates into `grads`: a caller may then run it any time before the next phase 1 on this workspace — e.g. beside the
- * next iteration's sampling, after `camera_indices` has been refilled (the pointer is not read then). */
-int nsamd_field_mlp_bwd_reduce_is_self_contained(int64_t M, int64_t dir_group, int32_t num_images, int has_appearance_grad,
-                                                 int64_t workspace_floats);
+ * scatter's apply + finish passes over the records phase 1 left in the queues. */
 int nsamd_field_mlp_bwd_scatter_phase(nsamd_points pts, int transform, nsamd_aabb aabb, nsamd_grid grid, const float* enc,
                                       const float* selector, const float* directions, const int64_t* camera_indices,
                                       const float* appearance_const, int64_t dir_group, int64_t M, nsamd_field_mlp mlp,

@@ -84,7 +84,6 @@ _SIGNATURES = {
     "nsamd_field_mlp_bwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp, i64, vp],
     "nsamd_field_mlp_bwd_scatter": [Points, C.c_int, Aabb, Grid, vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp,
                                     i64, vp, vp, i64, vp],
-    "nsamd_field_mlp_bwd_reduce_is_self_contained": [i64, i64, i32, C.c_int, i64],
     "nsamd_field_mlp_bwd_scatter_phase": [Points, C.c_int, Aabb, Grid, vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads,
                                           vp, i64, vp, vp, i64, C.c_int, vp],
     "nsamd_field_mlp_bwd_scatter_workspace": [Grid, i64, C.POINTER(C.c_int64)],
@@ -207,7 +206,7 @@ def load():
         fn = getattr(cdll, name)  # AttributeError here = header / library mismatch
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
-        setattr(lib, name, _Entry(fn, name) if fn.restype is C.c_int and name not in ("nsamd_device_info", "nsamd_field_mlp_bwd_reduce_is_self_contained") else fn)
+        setattr(lib, name, _Entry(fn, name) if fn.restype is C.c_int and name not in ("nsamd_device_info",) else fn)
     _lib = lib
     return lib
 

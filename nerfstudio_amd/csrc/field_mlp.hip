@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
     nsamd_field_mlp mlp, int app_dim, const float* __restrict__ ddensity, const float* __restrict__ drgb,
     float* __restrict__ denc, nsamd_field_mlp_grads grads, float* __restrict__ partials,
-    float* __restrict__ app_partials, int32_t* __restrict__ tile_cams, int app_rows_per_point, const float* __restrict__ acts, int probe_skip_arg,
+    float* __restrict__ app_partials, int app_rows_per_point, const float* __restrict__ acts, int probe_skip_arg,
     RouteArgs R) {
   // probe_skip (NSAMD_FIELD_BWD_SKIP, timing experiments only — results are wrong when set): 1 = no weight-gradient
   // MFMAs, 2 = no workgroup barriers inside the tile loop, 4 = no data-gradient GEMMs. A run-time value only in the
@@ -1286,7 +1286,6 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
       ti = nxt.ti;
       if (selector == nullptr) ti.sel = 1.0f;
       if (cams == nullptr) ti.cam = 0;
-      if (tile_cams != nullptr && lane == 0 && tile < tiles) tile_cams[tile] = (int32_t)ti.cam;  // (for the reduce launch)
       A.enc[0] = nxt.enc[0];
       A.enc[1] = nxt.enc[1];
       const bool mine = g == 0 && ti.live;
@@ -1306,7 +1305,6 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     } else {
       ti = tile_inputs(tile < tiles ? tile : tiles - 1, lane, M, selector, cams, dir_group);
       if (tile >= tiles) ti.live = false;  // idle wave of the last round: computes, contributes zeros
-      if (tile_cams != nullptr && lane == 0 && tile < tiles) tile_cams[tile] = (int32_t)ti.cam;
       load_enc_tile(enc, M, ti.p, lane, A.enc);
       // the upstream gradients of this tile (lanes g == 0 use them two and five phases further down): fetched with the
       // inputs, so their latency hides behind the forward instead of opening the head-2 and base-1 phases
@@ -1593,26 +1591,18 @@ constexpr int kDwBlocks = (kPartialStride + 63) / 64;
 // per camera): thread t takes rays t, t + 1024, ... — their camera indices are fetched first, all in flight — and adds
 // the rows of the rays that belong to this camera in ray order; the partial sums are folded by a fixed butterfly per wave and the 16 wave sums are
 // added in wave order. Fixed assignment, fixed order: bit-reproducible (the float atomics this replaces were not).
-__device__ void app_reduce_block(const float* __restrict__ rows, const int64_t* __restrict__ cams,
-                                 const int32_t* __restrict__ tile_cams, int64_t num_rays, int tiles_per_ray,
-                                 float* __restrict__ grad, int64_t cam, float* lds_part) {
+__device__ void app_reduce_block(const float* __restrict__ rows, const int64_t* __restrict__ cams, int64_t num_rays,
+                                 int tiles_per_ray, float* __restrict__ grad, int64_t cam, float* lds_part) {
   float acc[32];
 #pragma unroll
   for (int k = 0; k < 32; ++k) acc[k] = 0.0f;
-  // one unconditional 32-bit load either way (a select between two differently typed loads would put each in a branch of
-  // its own): the low word of the caller's int64 index (little endian; indices are < num_images <= 8192) or the snapshot
-  const int32_t* cam_src = tile_cams != nullptr ? tile_cams : reinterpret_cast<const int32_t*>(cams);
-  const int64_t cam_stride = tile_cams != nullptr ? tiles_per_ray : 2;
   for (int64_t r0 = threadIdx.x; r0 < num_rays; r0 += (int64_t)kReduceThreads * 8) {
     bool mine[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int64_t r = r0 + (int64_t)u * kReduceThreads;
       // (unconditional load, clamped row: predicated loads are waited for one by one — see the partial rows below)
-      // (tile_cams: the camera index of every tile as the gradient kernel saw it, kept beside the rows — the reduce then
-      //  reads nothing but the workspace and may run after the caller has refilled its ray buffers)
-      const int64_t rc = r < num_rays ? r : num_rays - 1;
-      const int64_t c = cam_src[rc * cam_stride];
+      const int64_t c = cams[r < num_rays ? r : num_rays - 1];
       mine[u] = r < num_rays && c == cam;
     }
 #pragma unroll
@@ -1656,12 +1646,10 @@ __global__ __launch_bounds__(kReduceThreads) void field_dw_reduce_kernel(const f
                                                                           nsamd_field_mlp_grads grads, int app_dim,
                                                                           const float* __restrict__ app_rows,
                                                                           const int64_t* __restrict__ cams,
-                                                                          const int32_t* __restrict__ tile_cams,
                                                                           int64_t num_rays, int tiles_per_ray) {
   extern __shared__ __attribute__((aligned(16))) float red_lds[];
   if (blockIdx.x >= kDwBlocks) {
-    app_reduce_block(app_rows, cams, tile_cams, num_rays, tiles_per_ray, grads.appearance, (int64_t)blockIdx.x - kDwBlocks,
-                     red_lds);
+    app_reduce_block(app_rows, cams, num_rays, tiles_per_ray, grads.appearance, (int64_t)blockIdx.x - kDwBlocks, red_lds);
     return;
   }
   float(*part)[64] = reinterpret_cast<float(*)[64]>(red_lds);
@@ -1864,15 +1852,11 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
   // per-tile rows of the appearance-embedding gradient (fixed-order reduction per camera): needs every 16-point tile
   // inside one ray and room behind the weight-gradient partials; otherwise float atomics (sums in no fixed order)
   float* app_partials = nullptr;
-  int32_t* tile_cams = nullptr;
   int app_rows_per_point = 0;
   if (partials != nullptr && camera_indices != nullptr && grads.appearance != nullptr && dir_group % 16 == 0 &&
       M % dir_group == 0 && mlp.num_images <= 8192 &&
       workspace_floats >= (int64_t)blocks * kPartialStride + tiles * 32) {
     app_partials = workspace + (int64_t)blocks * kPartialStride;
-    // ... and, room permitting, the camera index of every tile behind the rows (app_reduce_block)
-    if (workspace_floats >= (int64_t)blocks * kPartialStride + tiles * 32 + tiles)
-      tile_cams = reinterpret_cast<int32_t*>(app_partials + tiles * 32);
   } else if (partials != nullptr && camera_indices != nullptr && grads.appearance != nullptr && dir_group == 1 &&
              mlp.num_images <= 8192 && workspace_floats >= (int64_t)blocks * kPartialStride + M * 32) {
     app_partials = workspace + (int64_t)blocks * kPartialStride;  // one row per POINT (a camera index per sample)
@@ -1893,18 +1877,18 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
     if (phases & 1) {
       field_mlp_bwd_kernel<true, false><<<blocks, kCoopThreads, lds + sizeof(uint32_t) * kRouteLdsWords, (hipStream_t)stream>>>(
           enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-          grads, partials, app_partials, tile_cams, app_rows_per_point, acts, probe_skip, R);
+          grads, partials, app_partials, app_rows_per_point, acts, probe_skip, R);
       NSAMD_CHECK_LAUNCH();
     }
   } else if (phases & 1) {
     if (acts != nullptr)
       field_mlp_bwd_kernel<false, true><<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
           enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-          grads, partials, app_partials, tile_cams, app_rows_per_point, acts, probe_skip, RouteArgs{});
+          grads, partials, app_partials, app_rows_per_point, acts, probe_skip, RouteArgs{});
     else
       field_mlp_bwd_kernel<false, false><<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
           enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-          grads, partials, app_partials, tile_cams, app_rows_per_point, nullptr, probe_skip, RouteArgs{});
+          grads, partials, app_partials, app_rows_per_point, nullptr, probe_skip, RouteArgs{});
     NSAMD_CHECK_LAUNCH();
   }
   if (partials != nullptr && (phases & 2)) {
@@ -1912,7 +1896,7 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
     const unsigned app_blocks = app_partials != nullptr ? (unsigned)mlp.num_images : 0u;
     const size_t red_lds = sizeof(float) * kReduceGroups * 64;
     field_dw_reduce_kernel<<<kDwBlocks + app_blocks, kReduceThreads, red_lds, (hipStream_t)stream>>>(
-        partials, (int)blocks, grads, app_dim, app_partials, camera_indices, tile_cams, app_rows_per_point ? M : M / dir_group,
+        partials, (int)blocks, grads, app_dim, app_partials, camera_indices, app_rows_per_point ? M : M / dir_group,
         app_rows_per_point ? 1 : (int)(dir_group / 16));
     NSAMD_CHECK_LAUNCH();
   }
@@ -1924,20 +1908,6 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
 static unsigned field_bwd_blocks(int64_t M) {
   const int64_t tiles = (M + 15) / 16;
   return (unsigned)min((int64_t)num_cus(), (tiles + kCoopWaves - 1) / kCoopWaves);
-}
-
-// 1: phase 2 (the weight-gradient reduce) of a backward over these sizes reads nothing but `workspace` and `grads` — no
-// appearance embedding, or the per-tile rows WITH the tiles' camera indices fit behind the partials (the conditions of
-// field_mlp_bwd_impl, restated) — so a caller may run it after its ray buffers have been refilled.
-extern "C" int nsamd_field_mlp_bwd_reduce_is_self_contained(int64_t M, int64_t dir_group, int32_t num_images,
-                                                            int has_appearance_grad, int64_t workspace_floats) {
-  if (M <= 0 || dir_group <= 0) return 0;
-  const int64_t tiles = (M + 15) / 16;
-  const int64_t blocks = (int64_t)field_bwd_blocks(M);
-  if (workspace_floats < blocks * kPartialStride) return 0;  // no partials at all: the kernel flushes with atomics
-  if (!has_appearance_grad) return 1;
-  return dir_group % 16 == 0 && M % dir_group == 0 && num_images <= 8192 &&
-         workspace_floats >= blocks * kPartialStride + tiles * 32 + tiles;
 }
 
 extern "C" int64_t nsamd_field_mlp_bwd_scatter_workspace(nsamd_grid grid, int64_t M, int64_t* state_words) {

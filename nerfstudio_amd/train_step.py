@@ -138,10 +138,6 @@ class NerfactoTrainStep:
         # round trip, no route launch); NSAMD_FUSE_ROUTE=0: the two entry points (A/B).
         self.fuse_route = os.environ.get("NSAMD_FUSE_ROUTE", "1") == "1"
         self.keep_denc = False  # True: the fused launch also stores the encoded-feature gradient in `f_denc` (tests read it)
-        # True (set by a caller that defers the main field's optimiser step, trainer.HipTrainer): the fused backward leaves
-        # its weight-gradient reduce — needed by nothing but that optimiser step — to `reduce_field_grads()`, which the caller
-        # runs in front of the deferred step, i.e. off the critical path. Only where `can_defer_reduce()`.
-        self.defer_reduce = False
         self.f_saved = e(int(N.load().nsamd_field_mlp_saved_floats(mm))) if self.save_acts else None
         # Second stream for the proposal-network backward: the two backward chains are independent, and since the
         # scatter kernels were reworked (latency-bound phases, small workgroups) they overlap: 3.87 -> 4.02 M rays/s on
@@ -582,12 +578,15 @@ class NerfactoTrainStep:
         split = self.split_reduce and self.side_stream is not None and not self.save_acts
         if (self.fuse_route and self.main_table_write_only and not self.defer_table and not self.save_acts
                 and enc.spec.num_levels == 16):
-            args = self._fused_backward_args()
-            if args is not None:
-                if N.PROFILE is not None or self.defer_reduce:
-                    # the per-kernel table (utils/roofline.py): one launch group at a time, same bits; `defer_reduce`:
-                    # group 2 is `reduce_field_grads`
-                    for phase in ((1, 4) if self.defer_reduce else (1, 2, 4)):
+            sws, sws_n = F._producer_scatter_workspace(enc.spec, self.f_enc.device, mm)
+            if sws is not None:
+                want_denc = self.cam_opt is not None or self.keep_denc  # the camera optimiser's share needs the feature gradient as well
+                args = (self._points(L), fld._transform, fld._box, enc.spec.native(), N.ptr(self.f_enc), N.ptr(self.f_sel),
+                        N.ptr(self.directions), cams, None, S, mm, fm, N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s),
+                        N.ptr(self.f_denc) if want_denc else None, grads, N.ptr(self.field_ws), self.field_ws.numel(),
+                        N.ptr(self._grad(enc.hash_table)), N.ptr(sws), sws_n)
+                if N.PROFILE is not None:  # the per-kernel table (utils/roofline.py): one launch group at a time, same bits
+                    for phase in (1, 2, 4):
                         ck(lib.nsamd_field_mlp_bwd_scatter_phase(*args, phase, st), "field_mlp_bwd_scatter_phase")
                 elif split:
                     # the weight-gradient reduce (12.8 MB of partial rows, latency-bound) needs nothing the apply pass produces
@@ -634,49 +633,6 @@ class NerfactoTrainStep:
             self.backward_table()
         if split:
             torch.cuda.current_stream().wait_event(self._red_join)
-
-    def can_defer_reduce(self) -> bool:
-        """The fused backward's reduce launch reads nothing but the kernel workspace (nsamd.h,
-        nsamd_field_mlp_bwd_reduce_is_self_contained) and the schedule takes the fused route."""
-        fld = self.model.field
-        enc = fld.mlp_base.encoding
-        if self.forward_only or not (self.fuse_route and self.main_table_write_only and not self.save_acts
-                                     and enc.spec.num_levels == 16 and not self.split_reduce):
-            return False
-        emb = fld.embedding_appearance.embedding.weight if fld.embedding_appearance is not None else None
-        return (self._fused_backward_args() is not None and bool(N.load().nsamd_field_mlp_bwd_reduce_is_self_contained(
-            self.m_main, self.counts[self.n_prop], emb.shape[0] if emb is not None else 0, int(emb is not None),
-            self.field_ws.numel())))
-
-    def _fused_backward_args(self):
-        """The arguments of nsamd_field_mlp_bwd_scatter[_phase] (all of them addresses of static buffers), or None without a
-        producer workspace for this table."""
-        fld = self.model.field
-        L = self.n_prop
-        S, mm = self.counts[L], self.m_main
-        enc = fld.mlp_base.encoding
-        sws, sws_n = F._producer_scatter_workspace(enc.spec, self.f_enc.device, mm)
-        if sws is None:
-            return None
-        params = [*fld.mlp_base.mlp.param_tensors(), *fld.mlp_head.param_tensors()]
-        emb = fld.embedding_appearance.embedding.weight if fld.embedding_appearance is not None else None
-        fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), emb.shape[0] if emb is not None else 0,
-                        float(fld.average_init_density))
-        cams = N.ptr(self.camera_indices) if emb is not None else None
-        grads = N.FieldMlpGrads(*(N.ptr(self._grad(p)) for p in params), N.ptr(self._grad(emb)) if emb is not None else None)
-        want_denc = self.cam_opt is not None or self.keep_denc  # the camera optimiser's share needs the feature gradient as well
-        return (self._points(L), fld._transform, fld._box, enc.spec.native(), N.ptr(self.f_enc), N.ptr(self.f_sel),
-                N.ptr(self.directions), cams, None, S, mm, fm, N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s),
-                N.ptr(self.f_denc) if want_denc else None, grads, N.ptr(self.field_ws), self.field_ws.numel(),
-                N.ptr(self._grad(enc.hash_table)), N.ptr(sws), sws_n)
-
-    def reduce_field_grads(self) -> None:
-        """The launch a `backward_field_and_table` under `defer_reduce` left out: the weight-gradient reduce of the main
-        field's backward (accumulates into the gradients; reads only the kernel workspace, `can_defer_reduce`)."""
-        args = self._fused_backward_args()
-        if args is None:
-            raise RuntimeError("reduce_field_grads: no fused backward on this configuration")
-        N.check(N.load().nsamd_field_mlp_bwd_scatter_phase(*args, 2, N.stream()), "field_mlp_bwd_scatter_phase")
 
     def backward_table(self, shadow: bool = False) -> None:
         """The main table's gradient scatter from `f_denc`. `shadow`: the sample points come from the copies `shadow_points`

@@ -105,7 +105,6 @@ class HipTrainer:
         self.runner = runner
         self.defer = False
         self.defer_scatter = False
-        self.defer_reduce = False
         self.opt_parallel = True  # False: the deferred Adam runs on the main stream (per-kernel timing)
         # False: the jitter buffer of the runner is filled by the caller before every iteration (parity tests inject the
         # draws the CPU oracle uses; the default draws them on the device inside the iteration, graph-safe Philox)
@@ -139,10 +138,6 @@ class HipTrainer:
             # NSAMD_DEFER_SCATTER=1 (opt-in, measured and NOT adopted: profiles/r03_negative_results.txt item 8) defers the
             # main TABLE SCATTER of iteration k as well, beside [select batch, proposal forward k+1]; same bits, 1-2 % slower.
             self.defer_scatter = self.defer and os.environ.get("NSAMD_DEFER_SCATTER", "0") == "1"
-            # ... and with it the weight-gradient reduce of the main field's backward (18 us + a dependent launch that only
-            # that Adam needs): iteration k's reduce leads the Adam branch of iteration k + 1. NSAMD_DEFER_REDUCE=0/1: A/B.
-            self.defer_reduce = (self.defer and not self.defer_scatter and os.environ.get("NSAMD_DEFER_REDUCE", "0") == "1"
-                                 and hasattr(r, "can_defer_reduce") and r.can_defer_reduce())
             if self.defer:
                 self.opt_stream = torch.cuda.Stream(device=dev)
                 self._opt_fork, self._opt_join = torch.cuda.Event(), torch.cuda.Event()
@@ -258,8 +253,6 @@ class HipTrainer:
         def pending_update():  # what iteration k-1 left behind: [its table scatter ->] its main-field Adam
             if self.defer_scatter:
                 r.backward_table(shadow=True)
-            if self.defer_reduce:
-                r.reduce_field_grads()
             a.step(grad_scale=1.0, groups=["fields"], hyper_dev=self.hyper_views)
             if beside:
                 # ... and, off the critical path, this iteration's zero-fills: the Adam above was the last reader of the
@@ -294,12 +287,10 @@ class HipTrainer:
             self._zero(updated)
         r.forward_main_and_losses(updated)
         r.defer_table = self.defer_scatter
-        r.defer_reduce = self.defer_reduce  # (its reduce launch: `pending_update` of the next iteration, or `finish`)
         try:
             r.backward_all(updated)
         finally:
             r.defer_table = False
-            r.defer_reduce = False
         if self.defer_scatter and self.opt_parallel:
             main.wait_event(self._sh_join)
         late = (["proposal_networks"] if updated else []) + ([self.cam_group] if self.cam_inside else [])
@@ -423,8 +414,6 @@ class HipTrainer:
             self._push_hyper()
             if self.defer_scatter:
                 self.runner.backward_table(shadow=True)
-            if self.defer_reduce:
-                self.runner.reduce_field_grads()
             self.arena.step(grad_scale=1.0, groups=["fields"], hyper_dev=self.hyper_views)
             self._pending_main = False
             self._true_steps = dict(self.arena.step_counts)

@@ -69,16 +69,6 @@ def test_argument_validation_without_gpu():
     state = lib.nsamd_hashgrid_encode_bwd_workspace_state(g19, 196608)
     assert 64 < state <= 64 + 16 * 64 + 4 and state % 4 == 0
     assert lib.nsamd_linear_fwd(None, None, None, 4, 0, 3, 0, None, None) == -1
-    # host-only query: is the field backward's reduce launch self-contained (reads nothing but the workspace)? The bench's
-    # sizes with the package's 1024 x 12544-float workspace: yes; without room for the tiles' camera indices, or with a
-    # camera index per SAMPLE (packed instant-ngp samples): no; without an appearance embedding nothing else is read anyway
-    q = lib.nsamd_field_mlp_bwd_reduce_is_self_contained
-    M, ws = 196608, 1024 * 12544
-    assert q(M, 48, 100, 1, ws) == 1
-    assert q(M, 48, 100, 1, 256 * 12544 + (M // 16) * 32) == 0  # rows fit, camera indices do not
-    assert q(M, 1, 100, 1, ws) == 0 and q(M, 1, 100, 0, ws) == 1
-    assert q(M, 48, 10000, 1, ws) == 0  # more cameras than the per-camera reduce handles
-    assert q(0, 48, 100, 1, ws) == 0 and q(M, 48, 100, 1, 100) == 0
 
 
 def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):

@@ -229,14 +229,10 @@ def test_bench_configuration_parity_through_replayed_graph(F, init):
     print("\nbench-size parity [init %s] (updated, rgb L-inf, worst tensor: (gpu-f64, ref32-f64, gpu-ref32) rel-L2):" % init, checked)
 
 
-@pytest.mark.parametrize("schedule", ["default", "weight-gradient reduce deferred with the Adam"])
-def test_graph_replay_trains_through_the_same_bits_as_eager_launches(F, schedule, monkeypatch):
+def test_graph_replay_trains_through_the_same_bits_as_eager_launches(F):
     """(2) of the module docstring: K = 6 iterations at the benchmark configuration, replayed from the captured hipGraphs
     with the main-field Adam deferred, against eager launches with Adam in order on one stream. torch.equal on the
-    parameter arena and both moments. Second case: the graph arm also leaves the main field's weight-gradient reduce of
-    iteration k to the head of iteration k + 1's Adam branch (NSAMD_DEFER_REDUCE=1: the reduce then runs after the ray
-    buffers have been refilled and must read the tiles' camera indices from the kernel workspace)."""
-    monkeypatch.setenv("NSAMD_DEFER_REDUCE", "0" if schedule == "default" else "1")
+    parameter arena and both moments."""
     cfg = orc.NerfactoCfg()
     K = 6
     rs = np.random.RandomState(3)
@@ -249,7 +245,7 @@ def test_graph_replay_trains_through_the_same_bits_as_eager_launches(F, schedule
         tr.runner.jitter.copy_(torch.from_numpy(jit[K]))
         if use_graph:
             tr.capture()
-            assert tr.defer and len(tr.graphs) == 4 and tr.defer_reduce == (schedule != "default")
+            assert tr.defer and len(tr.graphs) == 4
         else:
             assert not tr.defer
             tr.runner.side_stream = None  # one stream, kernels in program order
