@@ -69,7 +69,9 @@ __global__ __launch_bounds__(kCamThreads) void camera_backward_kernel(
 #pragma unroll
   for (int k = 0; k < 12; ++k) acc[k] = 0.0;
   for (int64_t i = tid; i < n; i += kCamThreads) {
-    if (cams[i] != c) continue;
+    int64_t ci = cams[i];
+    ci = ci < 0 ? 0 : (ci >= num_cameras ? num_cameras - 1 : ci);  // clamped as in the forward (camera_apply_kernel)
+    if (ci != c) continue;
     float go[3], gd[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {

@@ -28,6 +28,7 @@ nerfstudio itself is imported lazily (`pipeline_classes()`), as in plugin.py.
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Dict, Optional
 
 import torch
@@ -93,6 +94,14 @@ class TrainEngine:
         if ht is not None:
             if getattr(ht, "mixed_precision", False):
                 return "mixed precision"
+            # engine/trainer.py:513-516: with an enabled scaler the trainer calls grad_scaler.scale(loss).backward() and
+            # grad_scaler.update(), which asserts that an optimiser recorded inf checks — none does when the gradients live
+            # in the arena
+            scaler = getattr(ht, "grad_scaler", None)
+            if getattr(ht, "use_grad_scaler", False) or (scaler is not None and scaler.is_enabled()):
+                return "gradient scaler"
+            if getattr(getattr(ht, "config", None), "log_gradients", False):
+                return "log_gradients (param.grad stays None: the gradients live in the arena)"
             gas = getattr(ht, "gradient_accumulation_steps", None)
             if gas is not None and any(gas[k] != 1 for k in groups):
                 return "gradient accumulation"
@@ -196,7 +205,10 @@ class TrainEngine:
         # the first iterations run eagerly (they are the warm-up a capture needs, and every one of them is a real training
         # iteration on its own batch); then the schedule variants are captured once and replayed from there on
         self._eager_done = getattr(self, "_eager_done", 0)
-        if t.graphs is None and t.use_graph and self._eager_done >= self.EAGER_ITERATIONS and not getattr(t, "_capture_tried", False):
+        # More than one rank: eager segments unless NSAMD_DP_GRAPH=1 — captured segments with RCCL collectives between them
+        # have only been rehearsed on a one-rank communicator (trainer.py docstring)
+        may_capture = t.use_graph and (not t.dp or os.environ.get("NSAMD_DP_GRAPH", "0") == "1")
+        if t.graphs is None and may_capture and self._eager_done >= self.EAGER_ITERATIONS and not getattr(t, "_capture_tried", False):
             t._capture_tried = True
             t.try_capture(warm=False)
         self._eager_done += 1
@@ -244,6 +256,12 @@ class EngineSeam:
         """The trainer's `Optimizers` (engine/trainer.py:196-204 hands them to `get_training_callbacks`)."""
         if optimizers is not None and not self._engine_off:
             self._engine = TrainEngine(self, optimizers, trainer, **engine_kwargs)
+            # readers that go through the MODEL, not the pipeline (the viewer renders with `pipeline.model.eval()` /
+            # `get_outputs_for_camera`, viewer/render_state_machine.py) must see the pending main-field update too
+            try:
+                object.__setattr__(self.model, "_hip_flush", self.flush_engine)
+            except Exception:  # noqa: BLE001 - a model that refuses attributes keeps the pipeline-level flush only
+                pass
 
     def get_train_loss_dict(self, step: int):
         eng = self._engine
@@ -270,8 +288,33 @@ class EngineSeam:
             self._engine.flush()
 
 
+_PIPELINE_CLASS_NAMES = ("HipPipelineConfig", "HipPipeline")
+
+
+def _publish(*classes):
+    """Make classes that can only be built once nerfstudio is importable MODULE-LEVEL names: pickle (the reference's
+    multi-GPU launch hands the TrainerConfig to `mp.spawn`, scripts/train.py:205) and yaml (`config.yml`, written by
+    engine/trainer.py's `save_config` and read back by utils/eval_utils.py:90 for ns-eval / ns-render / ns-viewer /
+    ns-export) name a class as `module.qualname` and resolve it with `getattr(module, name)`."""
+    for cls in classes:
+        cls.__module__ = __name__
+        cls.__qualname__ = cls.__name__
+        globals()[cls.__name__] = cls
+    return classes
+
+
+def __getattr__(name: str):  # PEP 562: a freshly spawned process / a yaml loader resolves the classes by name
+    if name in _PIPELINE_CLASS_NAMES:
+        pipeline_classes()
+        return globals()[name]
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
 def pipeline_classes():
-    """(HipPipelineConfig, HipPipeline), built against the installed nerfstudio."""
+    """(HipPipelineConfig, HipPipeline), built ONCE against the installed nerfstudio and published as attributes of this
+    module (locally defined classes can neither be pickled nor found by yaml)."""
+    if "HipPipeline" in globals():
+        return globals()["HipPipelineConfig"], globals()["HipPipeline"]
     from dataclasses import dataclass, field
     from typing import Type
 
@@ -328,4 +371,5 @@ def pipeline_classes():
         """Training iterations as replayed hipGraphs with the arena's fused Adam (nerfstudio_amd/trainer.py); False: the
         module path under the trainer's own optimisers."""
 
+    _publish(HipPipelineConfig, HipPipeline)
     return HipPipelineConfig, HipPipeline

@@ -93,8 +93,20 @@ def hip_loss_terms(model: Any, outputs: dict, loss_dict: dict, metrics_dict: Opt
     return loss_dict
 
 
+def _publish(*classes):
+    """Classes that need nerfstudio to be built become module-level names (pickle of the TrainerConfig for `mp.spawn`,
+    scripts/train.py:205; yaml of `config.yml`, utils/eval_utils.py:90 — both resolve `module.qualname`)."""
+    for cls in classes:
+        cls.__module__ = __name__
+        cls.__qualname__ = cls.__name__
+        globals()[cls.__name__] = cls
+    return classes
+
+
 def _model_classes():
-    """(HipNerfactoModelConfig, HipNerfactoModel), built against the installed nerfstudio."""
+    """(HipNerfactoModelConfig, HipNerfactoModel), built ONCE against the installed nerfstudio."""
+    if "HipNerfactoModel" in globals():
+        return globals()["HipNerfactoModelConfig"], globals()["HipNerfactoModel"]
     from dataclasses import dataclass, field
     from typing import Literal, Type
 
@@ -126,6 +138,23 @@ def _model_classes():
             fused = self._fused_step()
             return fused.get_outputs(ray_bundle) if fused is not None else super().get_outputs(ray_bundle)
 
+        def _flush_pending(self):
+            """A pending (deferred / pipelined) main-field update of the pipeline's captured schedule is applied before the
+            parameters are read (pipeline.EngineSeam.attach_optimizers installs the hook)."""
+            flush = getattr(self, "_hip_flush", None)
+            if flush is not None:
+                flush()
+
+        def train(self, mode: bool = True):  # the viewer and the evaluation entry points switch the MODEL to eval
+            if not mode:
+                self._flush_pending()
+            return super().train(mode)
+
+        @torch.no_grad()
+        def get_outputs_for_camera(self, camera, obb_box=None):  # models/base_model.py:162-176 (viewer, ns-render)
+            self._flush_pending()
+            return super().get_outputs_for_camera(camera, obb_box=obb_box)
+
         @torch.no_grad()
         def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle):
             """models/base_model.py:178-205. In eval mode, with the rays already on the model's GPU, the chunk loop is the
@@ -137,6 +166,7 @@ def _model_classes():
 
             from . import eval_render
 
+            self._flush_pending()
             col = getattr(self, "collider", None)
             if (not self.training and camera_ray_bundle.origins.is_cuda and os.environ.get("NSAMD_EVAL_RUNNER", "1") == "1"
                     and camera_ray_bundle.origins.device == self.device and eval_render.supported(self) is None
@@ -189,6 +219,7 @@ def _model_classes():
         fused_train_step: bool = False
         """Run training iterations on the explicit kernel schedule behind the Model API (nerfstudio_amd/fused_step.py)."""
 
+    _publish(HipNerfactoModelConfig, HipNerfactoModel)
     return HipNerfactoModelConfig, HipNerfactoModel
 
 
@@ -230,7 +261,9 @@ def install_hip_ngp_modules(model: Any) -> None:
 
 
 def _ngp_model_classes():
-    """(HipInstantNGPModelConfig, HipNGPModel), built against the installed nerfstudio (which imports nerfacc)."""
+    """(HipInstantNGPModelConfig, HipNGPModel), built ONCE against the installed nerfstudio (which imports nerfacc)."""
+    if "HipNGPModel" in globals():
+        return globals()["HipInstantNGPModelConfig"], globals()["HipNGPModel"]
     from dataclasses import dataclass, field
     from typing import Type
 
@@ -278,6 +311,7 @@ def _ngp_model_classes():
         fused_train_step: bool = False
         """Run training iterations on the explicit kernel schedule behind the Model API (nerfstudio_amd/ngp_step.py)."""
 
+    _publish(HipInstantNGPModelConfig, HipNGPModel)
     return HipInstantNGPModelConfig, HipNGPModel
 
 
@@ -342,7 +376,14 @@ def nerfacto_hip():
 _LAZY_SPECS = {"nerfacto_hip_spec": nerfacto_hip, "instant_ngp_hip_spec": instant_ngp_hip}
 
 
+_LAZY_CLASSES = {"HipNerfactoModelConfig": _model_classes, "HipNerfactoModel": _model_classes,
+                 "HipInstantNGPModelConfig": _ngp_model_classes, "HipNGPModel": _ngp_model_classes}
+
+
 def __getattr__(name: str):
+    if name in _LAZY_CLASSES:  # a spawned rank unpickling the TrainerConfig, yaml loading config.yml
+        _LAZY_CLASSES[name]()
+        return globals()[name]
     builder = _LAZY_SPECS.get(name)
     if builder is None:
         raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

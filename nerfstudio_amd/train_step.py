@@ -176,6 +176,7 @@ class NerfactoTrainStep:
             self.cam_kernels = (os.environ.get("NSAMD_CAMERA_KERNELS", "1") == "1" and pose is not None and pose.is_cuda
                                 and pose.dtype == torch.float32 and pose.dim() == 2 and pose.shape[1] == 6
                                 and co.config.mode in ("SO3xR3", "SE3")
+                                and len(self.counts) <= 4  # nsamd_ray_grads has four level slots
                                 and getattr(co, "non_trainable_camera_indices", None) is None)
             self.cam_mode = {"SO3xR3": 1, "SE3": 2}.get(co.config.mode, 0)
             self.raw_origins, self.raw_directions = e(n, 3), e(n, 3)

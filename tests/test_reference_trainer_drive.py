@@ -654,3 +654,42 @@ def test_plugin_model_against_the_reference_model_itself(monkeypatch, predict_no
         ga, gb = grad_m[k].numpy(), grad_r[k].numpy()
         assert np.linalg.norm(ga - gb) <= (3e-2 if predict_normals else 1e-2) * max(np.linalg.norm(gb), 1e-30) + 1e-12, \
             (k, np.linalg.norm(ga - gb), np.linalg.norm(gb))
+
+
+@needs_reference
+def test_method_configs_survive_pickle_and_yaml(monkeypatch):
+    """the reference's multi-GPU launch pickles the TrainerConfig into `mp.spawn` (scripts/train.py:205) and
+    every run writes `config.yml` with yaml.dump, which ns-eval / ns-render / ns-viewer / ns-export read back with
+    yaml.load(Loader=yaml.Loader) (utils/eval_utils.py:90). Both name a class as module.qualname: the lazily built pipeline /
+    model classes must be module-level names of this package, built once, and resolvable in a process that has not built
+    them yet."""
+    refdrive.install()
+    import pickle
+    import subprocess
+
+    import yaml
+
+    from nerfstudio_amd import pipeline, plugin
+
+    for spec in (plugin.nerfacto_hip(), plugin.instant_ngp_hip()):
+        cfg = spec.config
+        again = pickle.loads(pickle.dumps(cfg))
+        assert type(again.pipeline) is type(cfg.pipeline) and type(again.pipeline.model) is type(cfg.pipeline.model)
+        assert again.pipeline.model._target is cfg.pipeline.model._target and again.method_name == cfg.method_name
+        text = yaml.dump(cfg)
+        loaded = yaml.load(text, Loader=yaml.Loader)
+        assert type(loaded.pipeline) is type(cfg.pipeline) and loaded.pipeline.model._target is cfg.pipeline.model._target
+        assert loaded.pipeline._target is cfg.pipeline._target
+    # built once: a second call hands back the same classes (a TrainerConfig built twice compares equal by type)
+    assert pipeline.pipeline_classes()[1] is pipeline.pipeline_classes()[1] is pipeline.HipPipeline
+    assert plugin._model_classes()[1] is plugin.HipNerfactoModel and plugin._ngp_model_classes()[1] is plugin.HipNGPModel
+    assert pipeline.HipPipelineConfig.__module__ == "nerfstudio_amd.pipeline" and pipeline.HipPipeline.__qualname__ == "HipPipeline"
+    # a fresh interpreter (what a spawned rank is) unpickles the nerfacto-hip config without having built anything
+    blob = pickle.dumps(plugin.nerfacto_hip().config)
+    code = ("import sys, pickle; sys.path[:0] = %r; import refdrive; refdrive.install(); "
+            "cfg = pickle.loads(sys.stdin.buffer.read()); "
+            "print(type(cfg.pipeline).__qualname__, cfg.pipeline._target.__qualname__, cfg.pipeline.model._target.__qualname__)"
+            % [HERE, os.path.dirname(HERE)])
+    out = subprocess.run([sys.executable, "-c", code], input=blob, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    assert out.stdout.decode().split() == ["HipPipelineConfig", "HipPipeline", "HipNerfactoModel"]
