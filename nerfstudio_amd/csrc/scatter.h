@@ -34,11 +34,21 @@ __device__ __forceinline__ FixedScale fixed_scale(uint32_t max_bits, int headroo
 // trunc(v * 2^k) as a 64-bit two's-complement integer, |v * 2^k| < 2^44 (headroom >= 18). 8 VALU operations: the scaled
 // value is split into a high part (multiple of 2^24) and the rest, both exactly representable, each converted with the
 // hardware float -> int32 conversion (round toward zero: symmetric, -0 -> 0) and rejoined by one 64-bit multiply-add.
+#ifndef NSAMD_FIXED_ROUND
+#define NSAMD_FIXED_ROUND 0
+#endif
 __device__ __forceinline__ unsigned long long to_fixed(float v, int k) {
   const float t = ldexpf(v, k);                          // exact (or flushed to zero when denormal)
   const float hi_f = truncf(t * 5.9604644775390625e-8f); // t * 2^-24
   const float lo_f = fmaf(hi_f, -16777216.0f, t);        // exact: t minus its high part
+#if NSAMD_FIXED_ROUND
+  // round-to-nearest-even of the low part (one v_rndne_f32 more): |error| <= 2^-(k+1) per summand and unbiased, where the
+  // truncation's error is one-sided (toward zero, <= 2^-k). Measured against each other on the PSNR stand-in
+  // (profiles/r05_psnr_ab.txt); a build-time switch because the sums' bits differ.
+  const long long r = (long long)(int)hi_f * 16777216ll + (long long)(int)rintf(lo_f);
+#else
   const long long r = (long long)(int)hi_f * 16777216ll + (long long)(int)lo_f;
+#endif
   return (unsigned long long)r;  // the atomics add modulo 2^64
 }
 
