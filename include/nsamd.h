@@ -478,6 +478,29 @@ int nsamd_proposal_losses(const float* s_bins_fine, const float* w_fine, int32_t
                           float* const* interlevel_per_ray, float* const* dw_prop, float* distortion_per_ray,
                           float* dw_distortion, nsamd_stream_t stream);
 
+/* The per-ray middle of a nerfacto training iteration in ONE launch — everything between the main field's forward and its
+ * backward (models/nerfacto.py:313-392 and what autograd runs back through it):
+ *   nsamd_render_train (weights, rgb / accumulation / depths, MSE value and gradient)
+ *   + nsamd_proposal_losses (interlevel loss per proposal level, distortion loss; values per ray, gradients)
+ *   + nsamd_render_train_bwd with d_weights_add = dw_distortion (d_rgb [N,S,3], d_density [N,S])
+ *   + optionally nsamd_weights_bwd_gate per proposal level (ray_samplers.py:590-609: the steps on which the proposal
+ *     networks receive gradient): entries of t_bins_prop / density_prop / ddensity_prop / gates / ray_masks (HOST arrays of
+ *     `levels` device pointers, or NULL arrays) — a level whose ddensity_prop entry is NULL, or whose dw_prop is NULL, is
+ *     left to the caller. The gates must have been cleared before the launch (as with gate_precleared = 1).
+ * One wavefront per (ray, job): job 0 = the fine level's chain, job 1 + l = proposal level l. Every output — including
+ * `weights`, `d_rgb_out` and `dw_distortion`, which the launch itself reads back — is bit-identical to the separate launches.
+ * Arguments as theirs; s_bins [N,S+1] are the fine level's spacing-domain edges (the losses), t_bins its euclidean ones. */
+int nsamd_render_losses_train(const float* rgb, const float* density, const float* t_bins, const float* s_bins,
+                              int64_t num_rays, int32_t S, int background, const float* bg_rgb_host, const float* target,
+                              float mse_grad_scale, const float* bg_rays, float* weights, float* rgb_out, float* acc,
+                              float* depth_expected, float* depth_median, float* workspace, float* sq_err, float* d_rgb_out,
+                              int32_t levels, const float* const* s_bins_prop, const float* const* w_prop,
+                              const int32_t* S_prop, float interlevel_grad_scale, float distortion_grad_scale,
+                              float* const* interlevel_per_ray, float* const* dw_prop, float* distortion_per_ray,
+                              float* dw_distortion, float* d_rgb, float* d_density, const float* const* t_bins_prop,
+                              const float* const* density_prop, float* const* ddensity_prop, uint32_t* const* gates,
+                              uint8_t* const* ray_masks, nsamd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Packed-sample path of instant-ngp (BASELINE configs[3]): what the reference gets from nerfacc 0.5.2
  * (OccGridEstimator.sampling, pack_info, render_weight_from_density, render_visibility_from_density,
@@ -606,6 +629,15 @@ int nsamd_rows_scatter(float* rows, const int64_t* index, int64_t n, int32_t fea
 int nsamd_select_batch(const float* slot_dev, int32_t slots, int64_t num_rays, const float* origins_pool,
                        const float* directions_pool, const int64_t* cameras_pool, const float* target_pool,
                        float* origins, float* directions, int64_t* cameras, float* target, nsamd_stream_t stream);
+
+/* nsamd_select_batch + nsamd_piecewise_bins in one launch (the head of a training iteration over a pool of batches: the
+ * hand-over of base_datamanager.py:506-515 and the initial sampler of ProposalNetworkSampler, ray_samplers.py:78-128, 586).
+ * Same numbers as the two launches; arguments as theirs. */
+int nsamd_select_bins(const float* slot_dev, int32_t slots, int64_t num_rays, const float* origins_pool,
+                      const float* directions_pool, const int64_t* cameras_pool, const float* target_pool, float* origins,
+                      float* directions, int64_t* cameras, float* target, const float* nears, const float* fars,
+                      const float* edges, const float* jitter, int32_t jitter_per_edge, int32_t S, int spacing,
+                      float* s_bins, float* t_bins, nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Camera-pose corrections (CameraOptimizer, cameras/camera_optimizers.py:85-185; exponential maps cameras/lie_groups.py:

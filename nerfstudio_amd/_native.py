@@ -109,6 +109,8 @@ _SIGNATURES = {
     "nsamd_interlevel_loss": [vp, vp, i32, vp, vp, i32, i64, f32, vp, vp, vp],
     "nsamd_distortion_loss": [vp, vp, i32, i64, f32, vp, vp, vp],
     "nsamd_proposal_losses": [vp, vp, i32, i32, vp, vp, vp, i64, f32, f32, vp, vp, vp, vp, vp],
+    "nsamd_render_losses_train": [vp, vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                  i32, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "nsamd_occgrid_march_count": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp],
     "nsamd_occgrid_march_write": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp, vp, vp, vp],
     "nsamd_occgrid_march_count_stash": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp, i32, vp],
@@ -129,6 +131,7 @@ _SIGNATURES = {
     "nsamd_rows_gather": [vp, vp, i64, i32, vp, vp],
     "nsamd_rows_scatter": [vp, vp, i64, i32, vp, vp],
     "nsamd_select_batch": [vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "nsamd_select_bins": [vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, C.c_int, vp, vp, vp],
     "nsamd_camera_apply": [vp, i32, i32, vp, vp, vp, i64, vp, vp, vp],
     "nsamd_camera_backward": [vp, i32, i32, vp, vp, i64, RayGrads, f32, f32, vp, vp, vp],
     "nsamd_adam_step": [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i32, f32, vp, vp],

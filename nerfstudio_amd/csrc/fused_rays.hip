@@ -1,0 +1,152 @@
+// The per-ray middle of the nerfacto training iteration in ONE launch (gfx950): everything between the main field's forward
+// and its backward is independent across rays — only the loss SUMS cross rays, and those are taken by the host on demand from
+// per-ray values. Reference: models/nerfacto.py:298-392 (get_outputs from the field outputs on, get_metrics_dict, get_loss_dict)
+// and what autograd runs back through them: cameras/rays.py:129-152 (get_weights), model_components/renderers.py:72-119, 293-317,
+// 354-383, model_components/losses.py:31, 53-146.
+//
+// The training step used to issue, back to back and each waiting for the one before:
+//   nsamd_render_train (weights + compositing + MSE)  ->  nsamd_proposal_losses (interlevel x levels, distortion)
+//   ->  nsamd_render_train_bwd (compositing backward + weights backward)  [-> nsamd_weights_bwd_gate per proposal level]
+// three to five launches of 5-16 us each with ~5 us of dependent-launch gap between them inside the replayed graph. Here the
+// grid's y index is a JOB and every job is one wave per ray running the stand-alone launches' device bodies (ray_bodies.h) one
+// after the other:
+//   job 0            compositing forward (weights, rgb, accumulation, depths, MSE value + gradient)
+//                    -> distortion loss (value + gradient on the fine weights) -> compositing backward -> d rgb / d density
+//   job 1 + l        interlevel loss of proposal level l against the fine samples (the fine weights are re-derived from the
+//                    densities in the wave: same operations, same bits) [-> that level's weights backward: d density of the
+//                    proposal samples, the level's gradient flag and per-ray mask]
+// What a later body reads of an earlier one's results (the fine weights, the MSE gradient, the distortion gradient, the
+// interlevel gradient) goes through global memory exactly as between the launches — written and read by the SAME wave, a fence
+// apart — so every output is bit-identical to the separate launches (tests/test_gpu_kernels.py).
+#include "ray_bodies.h"
+
+namespace nsamd {
+
+constexpr int kMaxFusedLevels = 4;
+
+struct FusedRayArgs {
+  // fine level
+  const float* rgb;       // [N,S,3]
+  const float* density;   // [N,S]
+  const float* t_bins;    // [N,S+1]
+  const float* s_bins;    // [N,S+1]
+  const float* target;    // [N,3]
+  const float* bg_rays;   // [N,3] or null
+  float* weights;         // [N,S] out
+  float* rgb_out;         // [N,3]
+  float* acc;             // [N]
+  float* depth_exp;       // [N] (raw; the finishing pass clips)
+  float* depth_med;       // [N] or null
+  float* ws;              // min / max partials
+  float* sq_err;          // [N]
+  float* d_rgb_out;       // [N,3]
+  float* dist_per_ray;    // [N]
+  float* dw_dist;         // [N,S]
+  float* d_rgb;           // [N,S,3]
+  float* d_density;       // [N,S]
+  // proposal levels
+  const float* p_s_bins[kMaxFusedLevels];
+  const float* p_weights[kMaxFusedLevels];
+  float* p_per_ray[kMaxFusedLevels];
+  float* p_dw[kMaxFusedLevels];              // null: no gradient for the proposal networks this step
+  const float* p_t_bins[kMaxFusedLevels];    // the level's weights backward (null entries: not fused)
+  const float* p_density[kMaxFusedLevels];
+  float* p_ddensity[kMaxFusedLevels];
+  uint32_t* p_gate[kMaxFusedLevels];
+  uint8_t* p_mask[kMaxFusedLevels];
+  int p_S[kMaxFusedLevels];
+  int levels;
+  int S;
+  int background;
+  float bg_r, bg_g, bg_b;
+  float mse_scale, inter_scale, dist_scale;
+  int row_floats;  // LDS floats per wave: the largest any body of this launch needs
+};
+
+__global__ __launch_bounds__(kRenderThreads) void render_losses_train_kernel(FusedRayArgs a, int64_t num_rays) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float blk_min[kRaysPerBlock], blk_max[kRaysPerBlock];
+  const int wave = threadIdx.x >> 6;
+  float* row = lds + (size_t)wave * a.row_floats;
+  const int job = blockIdx.y;
+  if (job == 0) {
+    composite_fwd_body(blk_min, blk_max, a.rgb, nullptr, a.t_bins, num_rays, a.S, a.background, a.bg_r, a.bg_g, a.bg_b, 0,
+                       a.rgb_out, a.acc, a.depth_exp, a.depth_med, nullptr, a.ws, a.density, a.weights, a.target, a.mse_scale,
+                       a.sq_err, a.d_rgb_out, a.bg_rays);
+    // this wave's weight row and MSE gradient are in memory; the next bodies of THIS wave read them back
+    __threadfence_block();
+    distortion_body(row, a.s_bins, a.weights, a.S, num_rays, a.dist_scale, a.dist_per_ray, a.dw_dist);
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();  // (the distortion body's LDS rows are dead; the backward reuses the wave's row)
+    composite_bwd_body(row, a.rgb, a.weights, a.t_bins, num_rays, a.S, a.background, a.bg_r, a.bg_g, a.bg_b, a.d_rgb_out, nullptr,
+                       nullptr, nullptr, a.dw_dist, a.d_rgb, nullptr, a.density, a.d_density, a.bg_rays);
+  } else {
+    const int l = job - 1;
+    interlevel_body(row, a.s_bins, nullptr, a.S, a.p_s_bins[l], a.p_weights[l], a.p_S[l], num_rays, a.inter_scale, a.p_per_ray[l],
+                    a.p_dw[l], a.density, a.t_bins);
+    if (a.p_dw[l] != nullptr && a.p_ddensity[l] != nullptr) {
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+      weights_bwd_body(row, a.p_t_bins[l], a.p_density[l], a.p_dw[l], num_rays, a.p_S[l], a.p_ddensity[l], a.p_gate[l],
+                       a.p_mask[l]);
+    }
+  }
+}
+
+}  // namespace nsamd
+
+using namespace nsamd;
+
+extern "C" int nsamd_render_losses_train(
+    const float* rgb, const float* density, const float* t_bins, const float* s_bins, int64_t num_rays, int32_t S, int background,
+    const float* bg_rgb_host, const float* target, float mse_grad_scale, const float* bg_rays, float* weights, float* rgb_out,
+    float* acc, float* depth_expected, float* depth_median, float* workspace, float* sq_err, float* d_rgb_out, int32_t levels,
+    const float* const* s_bins_prop, const float* const* w_prop, const int32_t* S_prop, float interlevel_grad_scale,
+    float distortion_grad_scale, float* const* interlevel_per_ray, float* const* dw_prop, float* distortion_per_ray,
+    float* dw_distortion, float* d_rgb, float* d_density, const float* const* t_bins_prop, const float* const* density_prop,
+    float* const* ddensity_prop, uint32_t* const* gates, uint8_t* const* ray_masks, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && S > 0 && levels >= 0 && levels <= kMaxFusedLevels);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(rgb && density && t_bins && s_bins && target && weights && rgb_out && sq_err && d_rgb_out);
+  NSAMD_REQUIRE(distortion_per_ray && dw_distortion && d_rgb && d_density);
+  NSAMD_REQUIRE(background >= 0 && background <= 3);
+  NSAMD_REQUIRE(background != 2 || bg_rgb_host != nullptr);
+  NSAMD_REQUIRE(background != 3 || bg_rays != nullptr);
+  NSAMD_REQUIRE(depth_expected == nullptr || workspace != nullptr);
+  NSAMD_REQUIRE(levels == 0 || (s_bins_prop && w_prop && S_prop && interlevel_per_ray));
+  if (S > 1024) return NSAMD_ERR_UNSUPPORTED;
+  FusedRayArgs a{};
+  a.rgb = rgb, a.density = density, a.t_bins = t_bins, a.s_bins = s_bins, a.target = target, a.bg_rays = bg_rays;
+  a.weights = weights, a.rgb_out = rgb_out, a.acc = acc, a.depth_exp = depth_expected, a.depth_med = depth_median;
+  a.ws = workspace, a.sq_err = sq_err, a.d_rgb_out = d_rgb_out, a.dist_per_ray = distortion_per_ray, a.dw_dist = dw_distortion;
+  a.d_rgb = d_rgb, a.d_density = d_density;
+  a.levels = levels, a.S = S, a.background = background;
+  a.bg_r = bg_rgb_host ? bg_rgb_host[0] : 0.f, a.bg_g = bg_rgb_host ? bg_rgb_host[1] : 0.f, a.bg_b = bg_rgb_host ? bg_rgb_host[2] : 0.f;
+  a.mse_scale = mse_grad_scale, a.inter_scale = interlevel_grad_scale, a.dist_scale = distortion_grad_scale;
+  int row = 3 * S;  // compositing backward: dw, ex, trans (the distortion body needs 2 S)
+  for (int i = 0; i < levels; ++i) {
+    NSAMD_REQUIRE(s_bins_prop[i] && w_prop[i] && interlevel_per_ray[i] && S_prop[i] > 0);
+    if (S_prop[i] > 1024) return NSAMD_ERR_UNSUPPORTED;
+    a.p_s_bins[i] = s_bins_prop[i], a.p_weights[i] = w_prop[i], a.p_per_ray[i] = interlevel_per_ray[i], a.p_S[i] = S_prop[i];
+    a.p_dw[i] = dw_prop ? dw_prop[i] : nullptr;
+    const bool wb = a.p_dw[i] != nullptr && ddensity_prop != nullptr && ddensity_prop[i] != nullptr;
+    if (wb) {
+      NSAMD_REQUIRE(t_bins_prop && density_prop && t_bins_prop[i] && density_prop[i]);
+      a.p_t_bins[i] = t_bins_prop[i], a.p_density[i] = density_prop[i], a.p_ddensity[i] = ddensity_prop[i];
+      a.p_gate[i] = gates ? gates[i] : nullptr, a.p_mask[i] = ray_masks ? ray_masks[i] : nullptr;
+      row = row > 3 * S_prop[i] ? row : 3 * S_prop[i];
+    }
+    const int ir = interlevel_row_floats(S, S_prop[i]);
+    row = row > ir ? row : ir;
+  }
+  a.row_floats = (row + 3) & ~3;  // rows stay 16-B aligned (the interlevel body keeps doubles at the start of its row)
+  const size_t lds = sizeof(float) * (size_t)a.row_floats * kRaysPerBlock;
+  if (lds > 64 * 1024) return NSAMD_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)((num_rays + kRaysPerBlock - 1) / kRaysPerBlock);
+  dim3 g(blocks, (unsigned)(levels + 1));
+  render_losses_train_kernel<<<g, kRenderThreads, lds, st>>>(a, num_rays);
+  NSAMD_CHECK_LAUNCH();
+  if (depth_expected) return depth_clip_launch(depth_expected, num_rays, workspace, (int)blocks, st);  // (render.hip)
+  return NSAMD_OK;
+}

@@ -10,8 +10,7 @@
 // Layout: 4 rays per 256-thread workgroup (N = 4096 -> 1024 workgroups); rows are read/written coalesced.
 #include <stdlib.h>
 
-#include "common.h"
-#include "wave.h"
+#include "ray_bodies.h"
 
 NSAMD_PROBE_DEFINE(sampler)
 
@@ -22,18 +21,10 @@ constexpr int kThreads = 256;  // 4 wavefronts
 // ---------------------------------------------------------------------------------------------------------------
 // UniformLinDispPiecewiseSampler (ray_samplers.py:78-128, 225-248): pure elementwise.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void piecewise_bins_kernel(const float* __restrict__ nears,
-                                                                  const float* __restrict__ fars,
-                                                                  const float* __restrict__ edges,
-                                                                  const float* __restrict__ jitter,
-                                                                  int jitter_per_edge, int64_t num_rays, int S,
-                                                                  int spacing, float* __restrict__ s_bins,
-                                                                  float* __restrict__ t_bins) {
-  // one wavefront per ray (4 rays per workgroup): per-ray scalars are computed once, the edge index is a 32-bit loop
-  // counter (the flat-index version spent its time in 64-bit divisions)
-  const int lane = threadIdx.x & 63;
-  const int64_t ray = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-  if (ray >= num_rays) return;
+__device__ __forceinline__ void piecewise_bins_body(int64_t ray, int lane, const float* __restrict__ nears,
+                                                    const float* __restrict__ fars, const float* __restrict__ edges,
+                                                    const float* __restrict__ jitter, int jitter_per_edge, int S, int spacing,
+                                                    float* __restrict__ s_bins, float* __restrict__ t_bins) {
   const float s_near = spacing_fn_mode(spacing, nears[ray]);
   const float s_far = spacing_fn_mode(spacing, fars[ray]);
   // single_jitter: one draw per ray; otherwise one per bin edge, [num_rays, S+1] (ray_samplers.py:104-107)
@@ -51,6 +42,47 @@ __global__ __launch_bounds__(kThreads) void piecewise_bins_kernel(const float* _
     sb[i] = b;
     tb[i] = spacing_to_euclidean_mode(spacing, b, s_near, s_far);
   }
+}
+
+__global__ __launch_bounds__(kThreads) void piecewise_bins_kernel(const float* __restrict__ nears,
+                                                                  const float* __restrict__ fars,
+                                                                  const float* __restrict__ edges,
+                                                                  const float* __restrict__ jitter,
+                                                                  int jitter_per_edge, int64_t num_rays, int S,
+                                                                  int spacing, float* __restrict__ s_bins,
+                                                                  float* __restrict__ t_bins) {
+  // one wavefront per ray (4 rays per workgroup): per-ray scalars are computed once, the edge index is a 32-bit loop
+  // counter (the flat-index version spent its time in 64-bit divisions)
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (ray >= num_rays) return;
+  piecewise_bins_body(ray, lane, nears, fars, edges, jitter, jitter_per_edge, S, spacing, s_bins, t_bins);
+}
+
+// nsamd_select_batch + nsamd_piecewise_bins in one launch (the first two launches of a training iteration over a pool of ray
+// batches; neither depends on the other — the bins need nears / fars / the jitter draw, not the rays): the ray's wave copies
+// its origin, direction, target colour and camera index out of the pool slot, then writes its initial bins.
+__global__ __launch_bounds__(kThreads) void select_bins_kernel(
+    const float* __restrict__ slot_dev, int32_t slots, int64_t num_rays, const float* __restrict__ origins_pool,
+    const float* __restrict__ directions_pool, const int64_t* __restrict__ cameras_pool, const float* __restrict__ target_pool,
+    float* __restrict__ origins, float* __restrict__ directions, int64_t* __restrict__ cameras, float* __restrict__ target,
+    const float* __restrict__ nears, const float* __restrict__ fars, const float* __restrict__ edges,
+    const float* __restrict__ jitter, int jitter_per_edge, int S, int spacing, float* __restrict__ s_bins,
+    float* __restrict__ t_bins) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (ray >= num_rays) return;
+  int32_t slot = (int32_t)slot_dev[0];
+  slot = slot < 0 ? 0 : (slot >= slots ? slots - 1 : slot);
+  if (lane < 3) {
+    const int64_t dst = 3 * ray + lane, src = (int64_t)slot * 3 * num_rays + dst;
+    origins[dst] = origins_pool[src];
+    directions[dst] = directions_pool[src];
+    target[dst] = target_pool[src];
+  } else if (lane == 3) {
+    cameras[ray] = cameras_pool[(int64_t)slot * num_rays + ray];
+  }
+  piecewise_bins_body(ray, lane, nears, fars, edges, jitter, jitter_per_edge, S, spacing, s_bins, t_bins);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -95,8 +127,6 @@ __global__ __launch_bounds__(kThreads) void weights_fwd_kernel(const float* __re
   }
 }
 
-// d(weights)/d(density): dd_j gets  gw_j * T_j * exp(-dd_j)  -  sum_{i>j} gw_i * w_i
-// LDS: per wave  ex[S], trans[S], gw[S]  (the reverse pass needs the forward values again)
 __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __restrict__ t_bins,
                                                                const float* __restrict__ density,
                                                                const float* __restrict__ dweights,
@@ -104,96 +134,8 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
                                                                float* __restrict__ ddensity,
                                                                uint32_t* __restrict__ gate_out,
                                                                uint8_t* __restrict__ ray_mask) {
-  extern __shared__ float lds[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int64_t ray = (int64_t)blockIdx.x * kWaves + wave;
-  if (ray >= num_rays) return;  // wave-uniform; no workgroup barrier below
-  float* ex_row = lds + (size_t)wave * 3 * S;
-  float* tr_row = ex_row + S;
-  float* g_row = tr_row + S;
-  const float* tb = t_bins + ray * (S + 1);
-  const float* dn = density + ray * S;
-  const float* dw = dweights + ray * S;
-  {
-    // A ray whose weights carry no gradient: with every optical thickness dt * density in [0, FLT_MAX] all forward
-    // values are finite, so dL/d density = dt * (0 * T * e - 0) = dt * 0 for every sample — no scans needed. Anything
-    // else (a non-zero or NaN upstream gradient, a NaN / Inf / negative thickness) keeps the full path: 0 * NaN must
-    // stay NaN as in autograd. The interlevel loss reaches few rays (profiles/r02_study_proposal_sparsity.txt).
-    // The first 256 samples' inputs in one burst of unconditional loads (clamped indices; all of a nerfacto level): in a loop
-    // that loads where it tests — behind the short-circuit of `carries ||` — this pre-pass was one memory round trip per 64
-    // samples, and it is all a ray without gradient does.
-    float lo_pre[4], hi_pre[4], dn_pre[4], dw_pre[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = min(lane + 64 * q, S - 1);
-      lo_pre[q] = tb[i];
-      hi_pre[q] = tb[i + 1];
-      dn_pre[q] = dn[i];
-      dw_pre[q] = dw[i];
-    }
-    bool carries = false;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float dd = (hi_pre[q] - lo_pre[q]) * dn_pre[q];
-      const bool c = dw_pre[q] != 0.0f || !(dd >= 0.0f && dd <= 3.4028234663852886e38f);
-      carries = carries || (lane + 64 * q < S && c);
-    }
-    for (int i = lane + 256; i < S; i += 64) {
-      const float dd = (tb[i + 1] - tb[i]) * dn[i];
-      carries = carries || dw[i] != 0.0f || !(dd >= 0.0f && dd <= 3.4028234663852886e38f);
-    }
-    const bool ray_carries = __ballot(carries) != 0ull;
-    if (ray_mask != nullptr && lane == 0) ray_mask[ray] = ray_carries ? 1 : 0;  // per-ray form of the flag (see nsamd.h)
-    if (!ray_carries) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (lane + 64 * q < S) ddensity[ray * S + lane + 64 * q] = (hi_pre[q] - lo_pre[q]) * 0.0f;
-      for (int i = lane + 256; i < S; i += 64) ddensity[ray * S + i] = (tb[i + 1] - tb[i]) * 0.0f;
-      return;
-    }
-    // some ray of this launch carries gradient: the rest of the level's backward chain has work to do. A PLAIN store of
-    // the same value from every carrying wave (merged in the L2s, written back at the end of the kernel, which is what the
-    // consumers — later kernels on the stream — need): write-through / atomic stores to ONE address are one fabric write
-    // each (~88 per us chip-wide, MI355X_MICROARCH.md) — 4096 carrying rays cost tens of us that way (measured).
-    if (gate_out != nullptr && lane == 0 && *reinterpret_cast<volatile uint32_t*>(gate_out) == 0u)
-      *reinterpret_cast<volatile uint32_t*>(gate_out) = 1u;
-  }
-  double carry = 0.0;
-  for (int i0 = 0; i0 < S; i0 += 64) {
-    const int i = i0 + lane;
-    const float dd = i < S ? (tb[i + 1] - tb[i]) * dn[i] : 0.0f;
-    const double incl = carry + wave_scan_inclusive((double)dd, lane);
-    double excl = wave_shift_up1_f64(incl);
-    if (lane == 0) excl = carry;
-    carry = wave_read_f64<63>(incl);
-    if (i < S) {
-      const float ex = expf(-dd);
-      const float trans = expf(-(float)excl);
-      const float w = (1.0f - ex) * trans;
-      const bool finite = (w == w) && (fabsf(w) <= 3.4028234663852886e38f);
-      const float g = finite ? dw[i] : 0.0f;  // nan_to_num backward masks non-finite products
-      ex_row[i] = ex;
-      tr_row[i] = trans;
-      g_row[i] = g;
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  // exclusive suffix sums  suf_j = sum_{i>j} g_i w_i  (reverse cumsum, as autograd): scan the reversed row
-  carry = 0.0;
-  for (int r0 = 0; r0 < S; r0 += 64) {
-    const int r = r0 + lane;      // reversed position
-    const int i = S - 1 - r;      // element
-    float ex = 0.0f, trans = 0.0f, g = 0.0f;
-    if (r < S) { ex = ex_row[i]; trans = tr_row[i]; g = g_row[i]; }
-    const float gw = g * ((1.0f - ex) * trans);
-    const double incl = carry + wave_scan_inclusive((double)(r < S ? gw : 0.0f), lane);
-    double excl = wave_shift_up1_f64(incl);
-    if (lane == 0) excl = carry;
-    carry = wave_read_f64<63>(incl);
-    if (r < S) ddensity[ray * S + i] = (tb[i + 1] - tb[i]) * (g * trans * ex - (float)excl);
-  }
+  extern __shared__ float lds[];  // (ray_bodies.h: weights_bwd_body — per wave ex[S], trans[S], gw[S])
+  weights_bwd_body(lds + (size_t)(threadIdx.x >> 6) * 3 * S, t_bins, density, dweights, num_rays, S, ddensity, gate_out, ray_mask);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -413,6 +355,24 @@ extern "C" int nsamd_piecewise_bins(const float* nears, const float* fars, const
   if (blocks64 > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
   piecewise_bins_kernel<<<(unsigned)blocks64, kThreads, 0, (hipStream_t)stream>>>(
       nears, fars, edges, jitter, jitter_per_edge != 0, num_rays, S, spacing, s_bins, t_bins);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_select_bins(const float* slot_dev, int32_t slots, int64_t num_rays, const float* origins_pool,
+                                 const float* directions_pool, const int64_t* cameras_pool, const float* target_pool,
+                                 float* origins, float* directions, int64_t* cameras, float* target, const float* nears,
+                                 const float* fars, const float* edges, const float* jitter, int32_t jitter_per_edge, int32_t S,
+                                 int spacing, float* s_bins, float* t_bins, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && slots >= 1 && S > 0 && (spacing == 0 || spacing == 1));
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(slot_dev && origins_pool && directions_pool && cameras_pool && target_pool && origins && directions &&
+                cameras && target && nears && fars && edges && s_bins && t_bins);
+  const int64_t blocks64 = (num_rays + (kThreads / 64) - 1) / (kThreads / 64);
+  if (blocks64 > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
+  select_bins_kernel<<<(unsigned)blocks64, kThreads, 0, (hipStream_t)stream>>>(
+      slot_dev, slots, num_rays, origins_pool, directions_pool, cameras_pool, target_pool, origins, directions, cameras, target,
+      nears, fars, edges, jitter, jitter_per_edge != 0, S, spacing, s_bins, t_bins);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

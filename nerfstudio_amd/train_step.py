@@ -110,8 +110,11 @@ class NerfactoTrainStep:
         self._pl_per_ray = parr(self.inter_per_ray)
         self._pl_dw = parr(self.dw_prop)
         self._pl_S = (C.c_int32 * self.n_prop)(*self.counts[: self.n_prop])
+        self._pl_t_bins = parr(self.t_bins[: self.n_prop])
+        self._pl_dens = parr(self.p_dens)
         self.f_denc = t(*self.f_enc.shape)
         self.p_ddens = [t(*x.shape) for x in self.p_dens]
+        self._pl_ddens = (C.c_void_p * self.n_prop)(*[x.data_ptr() for x in self.p_ddens])
         self.p_denc = [t(*x.shape) for x in self.p_enc]
         self.field_ws = None if forward_only else F.field_bwd_workspace(device)[0]
         # one scratch per proposal level: their backward chains may run concurrently on different streams
@@ -125,6 +128,8 @@ class NerfactoTrainStep:
         self.gates_precleared = False  # True: the caller zeroes `prop_gates` before every proposal backward (trainer.HipTrainer)
         # ... and its per-ray form (1 = the ray carries gradient): levels that are only partly without gradient
         self.prop_ray_masks = [torch.zeros(n, device=device, dtype=torch.uint8) for _ in range(self.n_prop)]
+        self._pl_masks = (C.c_void_p * max(self.n_prop, 1))(*[x.data_ptr() for x in self.prop_ray_masks])
+        self._pl_gates = (C.c_void_p * max(self.n_prop, 1))(*[self.prop_gates.data_ptr() + 16 * i for i in range(self.n_prop)])
         # Optional (NSAMD_FIELD_SAVE_ACTS=1): the forward saves the main field's activations (896 B per sample) and the
         # backward loads them instead of recomputing the forward. Measured on MI355X: backward 186 -> 176 us but forward
         # 60 -> 76 us — the backward is bound by its workgroup barriers, not by the recomputed MFMAs — so off by default.
@@ -138,6 +143,18 @@ class NerfactoTrainStep:
         # round trip, no route launch); NSAMD_FUSE_ROUTE=0: the two entry points (A/B).
         self.fuse_route = os.environ.get("NSAMD_FUSE_ROUTE", "1") == "1"
         self.keep_denc = False  # True: the fused launch also stores the encoded-feature gradient in `f_denc` (tests read it)
+        # Everything between the main field's forward and its backward in ONE launch (nsamd_render_losses_train: compositing +
+        # MSE, the proposal losses, the compositing backward — three dependent launches before — and, on the steps that update
+        # the proposal networks, each proposal level's weights backward); NSAMD_FUSE_RAYS=0: the separate launches (A/B), same
+        # bits. NSAMD_FOLD_WEIGHTS_BWD=0 keeps the levels' weights backward at the head of their own chains.
+        self.fuse_rays = os.environ.get("NSAMD_FUSE_RAYS", "1") == "1"
+        self.fold_weights_bwd = os.environ.get("NSAMD_FOLD_WEIGHTS_BWD", "1") == "1"
+        self._rays_bwd_fresh = False  # `losses` has already run the compositing backward for this forward
+        # (slot pointer, slots, pool) of a batch selection the caller leaves to `forward_proposals` (one launch with the initial
+        # bins, nsamd_select_bins); NSAMD_FUSE_SELECT=0: the caller launches nsamd_select_batch itself (A/B)
+        self.pending_select = None
+        self.fuse_select = os.environ.get("NSAMD_FUSE_SELECT", "1") == "1"
+        self._wb_folded = set()       # proposal levels whose weights backward `losses` has already run
         self.f_saved = e(int(N.load().nsamd_field_mlp_saved_floats(mm))) if self.save_acts else None
         # Second stream for the proposal-network backward: the two backward chains are independent, and since the
         # scatter kernels were reworked (latency-bound phases, small workgroups) they overlap: 3.87 -> 4.02 M rays/s on
@@ -432,8 +449,19 @@ class NerfactoTrainStep:
                 self.bg_rays.uniform_()  # rand_like(pred) of the loss blend (renderers.py:195)
         S0 = self.counts[0]
         jit0 = self.jitter_edges[0] if per_edge else self.jitter[0]
-        ck(lib.nsamd_piecewise_bins(N.ptr(self.nears), N.ptr(self.fars), N.ptr(self.edges), N.ptr(jit0), int(per_edge), n, S0,
-                                    self.spacing, N.ptr(self.s_bins[0]), N.ptr(self.t_bins[0]), st), "piecewise_bins")
+        sel, self.pending_select = self.pending_select, None
+        if sel is not None:
+            # the step's batch out of the caller's pool of batches AND the initial bins in one launch (trainer.HipTrainer hands
+            # the selection over instead of launching it: the bins need nears / fars / the draw, not the rays)
+            slot, slots, pool = sel
+            ck(lib.nsamd_select_bins(slot, slots, n, N.ptr(pool["origins"]), N.ptr(pool["directions"]), N.ptr(pool["cameras"]),
+                                     N.ptr(pool["target"]), N.ptr(self.origins), N.ptr(self.directions),
+                                     N.ptr(self.camera_indices), N.ptr(self.target), N.ptr(self.nears), N.ptr(self.fars),
+                                     N.ptr(self.edges), N.ptr(jit0), int(per_edge), S0, self.spacing, N.ptr(self.s_bins[0]),
+                                     N.ptr(self.t_bins[0]), st), "select_bins")
+        else:
+            ck(lib.nsamd_piecewise_bins(N.ptr(self.nears), N.ptr(self.fars), N.ptr(self.edges), N.ptr(jit0), int(per_edge), n,
+                                        S0, self.spacing, N.ptr(self.s_bins[0]), N.ptr(self.t_bins[0]), st), "piecewise_bins")
         # ---- proposal levels ----
         for lvl in range(self.n_prop):
             net = self.props[lvl]
@@ -530,6 +558,35 @@ class NerfactoTrainStep:
         ck = N.check
         L = self.n_prop
         S = self.counts[L]
+        self._rays_bwd_fresh = False
+        self._wb_folded = set()
+        if self.fuse_rays and not self.forward_only:
+            # one launch: weights + compositing + MSE, the proposal losses, the compositing backward (d rgb / d density of the
+            # fine samples) and, when the proposal networks get gradient this step, each level's weights backward
+            fold = updated and self.fold_weights_bwd and self.n_prop > 0
+            gated = False
+            if fold:
+                # the levels' chains are gated only when a binned-scatter workspace exists for them (backward_proposals)
+                gated = self.gate_proposals and all(
+                    F._scatter_workspace(self.props[lvl].encoding.spec, self.f_enc.device, n * self.counts[lvl])[0] is not None
+                    for lvl in range(self.n_prop))
+                if gated and not self.gates_precleared:
+                    self.prop_gates.zero_()
+            ck(lib.nsamd_render_losses_train(
+                N.ptr(self.f_rgb), N.ptr(self.f_dens), N.ptr(self.t_bins[L]), N.ptr(self.s_bins[L]), n, S, self.bg_mode,
+                self.bg_vals, N.ptr(self.target), 1.0 / (3 * n), N.ptr(self.bg_rays), N.ptr(self.weights[L]), N.ptr(self.rgb),
+                N.ptr(self.acc), N.ptr(self.depth_exp), N.ptr(self.depth_med[L]) if self.compute_depths else None,
+                N.ptr(self.minmax_ws), N.ptr(self.sq_err), N.ptr(self.d_rgb_out), self.n_prop, self._pl_s_bins,
+                self._pl_weights, self._pl_S, float(cfg.interlevel_loss_mult) / (n * S), float(cfg.distortion_loss_mult) / n,
+                self._pl_per_ray, self._pl_dw if updated else None, N.ptr(self.dist_per_ray), N.ptr(self.dw_dist),
+                N.ptr(self.d_rgb_s), N.ptr(self.d_dens_main), self._pl_t_bins if fold else None,
+                self._pl_dens if fold else None, self._pl_ddens if fold else None, self._pl_gates if (fold and gated) else None,
+                self._pl_masks if (fold and gated) else None, st), "render_losses_train")
+            self._rays_bwd_fresh = True
+            if fold:
+                self._wb_folded = set(range(self.n_prop))
+                self._wb_gated = gated
+            return
         # weights + compositing + MSE value/gradient in one launch (+ the global depth clip)
         ck(lib.nsamd_render_train(N.ptr(self.f_rgb), N.ptr(self.f_dens), N.ptr(self.t_bins[L]), n, S, self.bg_mode,
                                   self.bg_vals, N.ptr(self.target), 1.0 / (3 * n), N.ptr(self.weights[L]), N.ptr(self.rgb),
@@ -551,10 +608,13 @@ class NerfactoTrainStep:
         ck = N.check
         L = self.n_prop
         S = self.counts[L]
-        ck(lib.nsamd_render_train_bwd(N.ptr(self.f_rgb), N.ptr(self.weights[L]), N.ptr(self.f_dens), N.ptr(self.t_bins[L]),
-                                      n, S, self.bg_mode, self.bg_vals, N.ptr(self.d_rgb_out), N.ptr(self.dw_dist),
-                                      N.ptr(self.d_rgb_s), N.ptr(self.d_dens_main), N.ptr(self.bg_rays), st),
-           "render_train_bwd")
+        if self._rays_bwd_fresh:  # `losses` ran the compositing backward in its own launch (nsamd_render_losses_train)
+            self._rays_bwd_fresh = False
+        else:
+            ck(lib.nsamd_render_train_bwd(N.ptr(self.f_rgb), N.ptr(self.weights[L]), N.ptr(self.f_dens), N.ptr(self.t_bins[L]),
+                                          n, S, self.bg_mode, self.bg_vals, N.ptr(self.d_rgb_out), N.ptr(self.dw_dist),
+                                          N.ptr(self.d_rgb_s), N.ptr(self.d_dens_main), N.ptr(self.bg_rays), st),
+               "render_train_bwd")
         if self.gradient_scaling:  # scale_gradients_by_distance_squared on the field's outputs (models/nerfacto.py:321-322)
             ck(lib.nsamd_distance_gradient_scale(N.ptr(self.t_bins[L]), n, S, N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s), st),
                "distance_gradient_scale")
@@ -689,9 +749,14 @@ class NerfactoTrainStep:
                 spec = net.encoding.spec
                 ws, ws_n = F._scatter_workspace(spec, self.f_enc.device, m)
                 grads = (N.ptr(self._grad(W0)), N.ptr(self._grad(b0)), N.ptr(self._grad(W1)), N.ptr(self._grad(b1)))
+                folded = lvl in self._wb_folded  # `losses` already ran this level's weights backward (same launch as the losses)
+                self._wb_folded.discard(lvl)
+                if folded and getattr(self, "_wb_gated", False) != (gate is not None and ws is not None):
+                    folded = False  # (the gating mode changed between the two calls: run the level's own launch)
                 if gate is None or ws is None:  # ungated chain (A/B switch, or no binned-scatter workspace for this shape)
-                    ck(lib.nsamd_weights_bwd(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]), n,
-                                             S, N.ptr(self.p_ddens[lvl]), st), "weights_bwd")
+                    if not folded:
+                        ck(lib.nsamd_weights_bwd(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]),
+                                                 n, S, N.ptr(self.p_ddens[lvl]), st), "weights_bwd")
                     ck(lib.nsamd_density_mlp_bwd(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]),
                                                  N.ptr(self.p_ddens[lvl]), m, dm, N.ptr(self.p_denc[lvl]), *grads,
                                                  N.ptr(dws), dws.numel(), st), "density_mlp_bwd")
@@ -705,9 +770,10 @@ class NerfactoTrainStep:
                 # the weights backward raises the level's flag when any ray carries interlevel gradient; the rest of the
                 # chain returns at once while it is clear (the zero-filled gradients are then already the result)
                 mask = N.ptr(self.prop_ray_masks[lvl])
-                ck(lib.nsamd_weights_bwd_gate(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]), n,
-                                              S, N.ptr(self.p_ddens[lvl]), gate, mask, int(self.gates_precleared), st),
-                   "weights_bwd_gate")
+                if not folded:
+                    ck(lib.nsamd_weights_bwd_gate(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]),
+                                                  n, S, N.ptr(self.p_ddens[lvl]), gate, mask, int(self.gates_precleared), st),
+                       "weights_bwd_gate")
                 ck(lib.nsamd_density_mlp_bwd_gated(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]),
                                                    N.ptr(self.p_ddens[lvl]), m, dm, N.ptr(self.p_denc[lvl]), *grads,
                                                    N.ptr(dws), dws.numel(), gate, mask, S, st), "density_mlp_bwd_gated")

@@ -232,13 +232,22 @@ class HipTrainer:
         self.loss_buf.copy_(loss.detach())
 
     def _zero(self, updated, groups=None):
+        """Zero-fills ahead of an iteration's forward; `groups`: only these gradient slices (a later segment of the same
+        iteration: the proposal levels' gradient flags are raised by then and stay as they are)."""
+        whole = groups is None
         if groups is None:
             groups = ["fields", "proposal_networks"] if updated else ["fields"]
             if self.cam_inside:
                 groups = groups + [self.cam_group]
         self.arena.zero_grad(groups, skip=self.runner.written_params())
-        if updated and getattr(self.runner, "gates_precleared", False):
-            self.runner.prop_gates.zero_()  # (instead of one 4-byte memset node per level ahead of its weights backward)
+        if whole and updated:
+            self._clear_gates()
+
+    def _clear_gates(self):
+        # (instead of one 4-byte memset node per level ahead of its weights backward; BEFORE the losses launch, which raises
+        # the flags when it also runs the levels' weights backward)
+        if getattr(self.runner, "gates_precleared", False):
+            self.runner.prop_gates.zero_()
 
     def _deferred_iteration_body(self, updated, pending):
         """One iteration of the deferred schedule (N = 1, runner):
@@ -308,6 +317,10 @@ class HipTrainer:
         if self.runner is not None:
             r = self.runner
             co = getattr(r, "cam_opt", None) is not None  # the kernels read the pose-corrected copies
+            if not co and getattr(r, "fuse_select", False):
+                # the runner's next `forward_proposals` selects the batch in the launch that writes the initial bins
+                r.pending_select = (N.ptr(self.hyper[_HYPER_SLOT:_HYPER_SLOT + 1]), self.slots, p)
+                return
             o, d = (r.raw_origins, r.raw_directions) if co else (r.origins, r.directions)
             c, t = r.camera_indices, r.target
         else:
@@ -367,6 +380,8 @@ class HipTrainer:
                 r.backward_fork(True)
             else:
                 self._zero(False)
+                if name[1]:
+                    self._clear_gates()
                 r.forward_main_and_losses(name[1])
                 r.backward_main()
         elif name == "pbwd":

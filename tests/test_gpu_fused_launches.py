@@ -1,0 +1,222 @@
+"""The training iteration's merged launches against the launches they replace, BIT FOR BIT (round 5):
+
+* nsamd_render_losses_train = nsamd_render_train + nsamd_proposal_losses + nsamd_render_train_bwd [+ nsamd_weights_bwd(_gate) per
+  proposal level]: one launch, one wave per (ray, job), the stand-alone launches' device bodies run one after the other inside the
+  wave (csrc/ray_bodies.h, csrc/fused_rays.hip) — so every output must be the same bits, including the ones the launch reads
+  back itself (fine weights, MSE gradient, distortion gradient, interlevel gradient);
+* nsamd_select_bins = nsamd_select_batch + nsamd_piecewise_bins.
+
+The separate launches are pinned to the oracle / the reference's fixtures by tests/test_gpu_kernels.py; this file pins the merged
+forms to them and the whole runner (a few optimisation steps, both update kinds, gated and ungated proposal chains, every
+background mode) to the separate-launch runner."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerfacto_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F():
+    from nerfstudio_amd import _native, functional
+
+    _native.load()
+    return functional
+
+
+def _bits(t):
+    return t.detach().contiguous().view(torch.int32) if t.dtype == torch.float32 else t.detach()
+
+
+def _same(a, b, what):
+    assert a.shape == b.shape, what
+    assert torch.equal(_bits(a), _bits(b)), f"{what}: {int((_bits(a) != _bits(b)).sum())} of {a.numel()} words differ"
+
+
+def _runner(cfg, n, seed, background, fuse, gate=True, fold=True):
+    from test_gpu_kernels import _hip_model
+
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.train_step import NerfactoTrainStep
+
+    model = _hip_model(cfg, orc.init_params(cfg, seed=seed, table_std=0.4))
+    model.config.background_color = background
+    arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
+    r = NerfactoTrainStep(model, n, torch.device("cuda"))
+    r.fuse_rays, r.fold_weights_bwd, r.gate_proposals = fuse, fold, gate
+    r.side_stream = None
+    return model, arena, r
+
+
+@pytest.mark.parametrize("background", ["last_sample", "white", "random"])
+@pytest.mark.parametrize("gate", [True, False])
+def test_render_losses_train_equals_the_separate_launches(F, background, gate):
+    from test_gpu_kernels import small_cfg
+
+    cfg = small_cfg(12, 10, 6)
+    n = 333  # not a multiple of the four rays of a workgroup: tail waves
+    o, d, cam, tgt = orc.synthetic_rays(n, cfg.num_images, seed=3)
+    rs = np.random.RandomState(5)
+    jit = torch.from_numpy(rs.uniform(0, 1, (3, n)).astype(np.float32)).cuda()
+    bg = torch.from_numpy(rs.uniform(0, 1, (n, 3)).astype(np.float32)).cuda()
+    runs = {}
+    for fuse in (False, True):
+        F._SCATTER_WS.clear()
+        model, arena, r = _runner(cfg, n, 11, background, fuse, gate=gate)
+        r.set_batch(o.cuda(), d.cuda(), cam.cuda(), tgt.cuda())
+        r.jitter.copy_(jit)
+        if r.bg_rays is not None:
+            r.bg_rays.copy_(bg)
+        r.anneal_dev.fill_(0.7)
+        states = []
+        for step, updated in enumerate((True, False, True)):
+            arena.zero_grad(skip=r.written_params())
+            r.forward_backward(updated, draw_jitter=False)
+            torch.cuda.synchronize()
+            L = r.n_prop
+            snap = {"weights": r.weights[L], "rgb": r.rgb, "acc": r.acc, "depth_exp": r.depth_exp, "depth_med": r.depth_med[L],
+                    "sq_err": r.sq_err, "d_rgb_out": r.d_rgb_out, "dist_per_ray": r.dist_per_ray, "dw_dist": r.dw_dist,
+                    "d_rgb_s": r.d_rgb_s, "d_dens_main": r.d_dens_main, "grad": arena.grad, "minmax": r.minmax_ws[:2]}
+            for lvl in range(L):
+                snap[f"inter{lvl}"] = r.inter_per_ray[lvl]
+                if updated:
+                    snap[f"dw_prop{lvl}"], snap[f"p_ddens{lvl}"] = r.dw_prop[lvl], r.p_ddens[lvl]
+                    if gate:
+                        snap[f"mask{lvl}"] = r.prop_ray_masks[lvl]
+            if updated and gate:
+                snap["gates"] = r.prop_gates
+            states.append({k: v.detach().clone() for k, v in snap.items()})
+            arena.step(groups=["fields", "proposal_networks"] if updated else ["fields"])
+        states.append({"params": arena.flat.clone(), "m": arena.exp_avg.clone(), "v": arena.exp_avg_sq.clone()})
+        runs[fuse] = states
+        del model, arena, r
+    assert any(float(s["grad"].abs().max()) > 0 for s in runs[True][:3])
+    assert float(runs[True][0]["p_ddens0"].abs().max()) > 0, "the proposal level carried no gradient: the test shows nothing"
+    for i, (a, b) in enumerate(zip(runs[False], runs[True])):
+        assert a.keys() == b.keys()
+        for k in a:
+            _same(a[k], b[k], f"iteration {i}, {k} ({background}, gated={gate})")
+
+
+def test_folded_weights_backward_equals_its_own_launch_and_respects_the_switches(F):
+    """The level's weights backward inside the losses launch against the stand-alone nsamd_weights_bwd_gate at the head of the
+    level's chain (NSAMD_FOLD_WEIGHTS_BWD=0), and a chain that is asked for twice runs its own launch the second time."""
+    from test_gpu_kernels import small_cfg
+
+    cfg = small_cfg(12, 10, 6)
+    n = 256
+    o, d, cam, tgt = orc.synthetic_rays(n, cfg.num_images, seed=4)
+    jit = torch.from_numpy(np.random.RandomState(1).uniform(0, 1, (3, n)).astype(np.float32)).cuda()
+    out = {}
+    for fold in (False, True):
+        F._SCATTER_WS.clear()
+        model, arena, r = _runner(cfg, n, 12, "last_sample", True, fold=fold)
+        r.set_batch(o.cuda(), d.cuda(), cam.cuda(), tgt.cuda())
+        r.jitter.copy_(jit)
+        arena.zero_grad(skip=r.written_params())
+        r.forward_and_losses(True, draw_jitter=False)
+        assert (len(r._wb_folded) == r.n_prop) == fold
+        r.backward_all(True)
+        assert not r._wb_folded
+        torch.cuda.synchronize()
+        first = arena.grad.clone()
+        # the chains once more without a new `losses`: nothing is folded any more, each level launches its own weights backward
+        a, b = arena.groups["proposal_networks"]
+        arena.grad[a:b].zero_()
+        r.prop_gates.zero_()
+        r.backward_proposals()
+        torch.cuda.synchronize()
+        _same(arena.grad[a:b], first[a:b], f"second call of the proposal chains (fold={fold})")
+        out[fold] = (first, [x.clone() for x in r.p_ddens], [x.clone() for x in r.prop_ray_masks])
+    _same(out[False][0], out[True][0], "gradient arena")
+    for lvl in range(2):
+        _same(out[False][1][lvl], out[True][1][lvl], f"p_ddens[{lvl}]")
+        _same(out[False][2][lvl], out[True][2][lvl], f"ray mask [{lvl}]")
+
+
+@pytest.mark.parametrize("per_edge", [False, True])
+def test_select_bins_equals_select_batch_plus_piecewise_bins(F, per_edge):
+    from nerfstudio_amd import _native as N
+
+    lib = N.load()
+    n, slots, S = 1001, 3, 256
+    g = torch.Generator().manual_seed(0)
+    pool = {"origins": torch.randn(slots, n, 3, generator=g).cuda(), "directions": torch.randn(slots, n, 3, generator=g).cuda(),
+            "cameras": torch.randint(0, 50, (slots, n), generator=g).cuda(), "target": torch.rand(slots, n, 3, generator=g).cuda()}
+    nears, fars = torch.full((n,), 0.05).cuda(), torch.full((n,), 1000.0).cuda()
+    edges = F._linspace("edges", S, torch.device("cuda"))
+    jit = (torch.rand(n, S + 1, generator=g) if per_edge else torch.rand(n, generator=g)).cuda()
+    st = N.stream()
+    for slot_value in (0.0, 2.0, 7.0):  # (clamped to the last slot)
+        slot = torch.tensor([slot_value], device="cuda")
+        outs = []
+        for merged in (False, True):
+            o, d, t = (torch.full((n, 3), -1.0, device="cuda") for _ in range(3))
+            c = torch.full((n,), -1, dtype=torch.int64, device="cuda")
+            sb, tb = (torch.full((n, S + 1), -1.0, device="cuda") for _ in range(2))
+            if merged:
+                N.check(lib.nsamd_select_bins(N.ptr(slot), slots, n, N.ptr(pool["origins"]), N.ptr(pool["directions"]),
+                                              N.ptr(pool["cameras"]), N.ptr(pool["target"]), N.ptr(o), N.ptr(d), N.ptr(c), N.ptr(t),
+                                              N.ptr(nears), N.ptr(fars), N.ptr(edges), N.ptr(jit), int(per_edge), S, 0, N.ptr(sb),
+                                              N.ptr(tb), st), "select_bins")
+            else:
+                N.check(lib.nsamd_select_batch(N.ptr(slot), slots, n, N.ptr(pool["origins"]), N.ptr(pool["directions"]),
+                                               N.ptr(pool["cameras"]), N.ptr(pool["target"]), N.ptr(o), N.ptr(d), N.ptr(c), N.ptr(t),
+                                               st), "select_batch")
+                N.check(lib.nsamd_piecewise_bins(N.ptr(nears), N.ptr(fars), N.ptr(edges), N.ptr(jit), int(per_edge), n, S, 0,
+                                                 N.ptr(sb), N.ptr(tb), st), "piecewise_bins")
+            torch.cuda.synchronize()
+            outs.append((o, d, c, t, sb, tb))
+        k = min(int(slot_value), slots - 1)
+        assert torch.equal(outs[1][0], pool["origins"][k]) and torch.equal(outs[1][2], pool["cameras"][k])
+        for a, b, what in zip(outs[0], outs[1], ("origins", "directions", "cameras", "target", "s_bins", "t_bins")):
+            _same(a, b, f"{what} (slot {slot_value})")
+
+
+def test_trainer_with_merged_launches_trains_through_the_same_bits(F, monkeypatch):
+    """bench.py's trainer (captured graphs, deferred main-field Adam, pool of batches, bench-size batch) with the merged
+    launches against the same trainer on the separate launches: identical parameter and moment bits after 15 iterations of both
+    update kinds, replayed from the captured graphs."""
+    import hashlib
+
+    import bench
+
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.trainer import HipTrainer
+
+    digests = {}
+    dev = torch.device("cuda")
+    for arm, env in (("merged", {}), ("separate", {"NSAMD_FUSE_RAYS": "0", "NSAMD_FUSE_SELECT": "0"})):
+        for k in ("NSAMD_FUSE_RAYS", "NSAMD_FUSE_SELECT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        F._SCATTER_WS.clear()
+        torch.manual_seed(0)
+        torch.cuda.manual_seed(0)
+        model = bench.build_model(dev, seed=0)
+        arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
+        rb, batch, pool = bench.synthetic_batch(dev, seed=1000)
+        tr = HipTrainer(model, arena, rb, batch, world=1, use_graph=True, use_runner=True, pool=pool)
+        assert tr.runner.fuse_rays == (arm == "merged") and tr.runner.fuse_select == (arm == "merged")
+        torch.manual_seed(1)
+        torch.cuda.manual_seed(1)  # the jitter draws of the iterations below
+        tr.train_iteration()
+        tr.finish()
+        assert tr.try_capture()
+        torch.manual_seed(2)
+        torch.cuda.manual_seed(2)
+        kinds = set()
+        for _ in range(14):  # (every iteration before step 10 updates the proposal networks, then every other one)
+            kinds.add(bool(model.proposal_sampler.updated_this_step()))
+            tr.train_iteration()
+        tr.finish()
+        torch.cuda.synchronize()
+        assert kinds == {True, False}
+        digests[arm] = tuple(hashlib.sha256(x.detach().cpu().numpy().tobytes()).hexdigest()
+                             for x in (arena.flat, arena.exp_avg, arena.exp_avg_sq))
+        assert bool(torch.isfinite(tr.last_loss()))
+        del tr, arena, model
+    assert digests["merged"] == digests["separate"], digests
