@@ -489,7 +489,12 @@ int nsamd_proposal_losses(const float* s_bins_fine, const float* w_fine, int32_t
  *     left to the caller. The gates must have been cleared before the launch (as with gate_precleared = 1).
  * One wavefront per (ray, job): job 0 = the fine level's chain, job 1 + l = proposal level l. Every output — including
  * `weights`, `d_rgb_out` and `dw_distortion`, which the launch itself reads back — is bit-identical to the separate launches.
- * Arguments as theirs; s_bins [N,S+1] are the fine level's spacing-domain edges (the losses), t_bins its euclidean ones. */
+ * Arguments as theirs; s_bins [N,S+1] are the fine level's spacing-domain edges (the losses), t_bins its euclidean ones.
+ * loss_values (nullable, 8 floats): written by the launch's finishing pass (the one that clips the expected depth) — the
+ * iteration's loss values as models/nerfacto.py:363-375 scales them and the two training metrics of :352-361, from the per-ray
+ * terms summed in a fixed order in double: [0] rgb_loss = sum(sq_err) / (3 N), [1] interlevel_loss = interlevel_loss_mult *
+ * sum over levels and rays / (N S), [2] distortion_loss = distortion_loss_mult * sum(distortion_per_ray) / N,
+ * [3] psnr = -10 log10(rgb_loss), [4] distortion = sum(distortion_per_ray) / N, [5] = [0] + [1] + [2]. */
 int nsamd_render_losses_train(const float* rgb, const float* density, const float* t_bins, const float* s_bins,
                               int64_t num_rays, int32_t S, int background, const float* bg_rgb_host, const float* target,
                               float mse_grad_scale, const float* bg_rays, float* weights, float* rgb_out, float* acc,
@@ -499,7 +504,8 @@ int nsamd_render_losses_train(const float* rgb, const float* density, const floa
                               float* const* interlevel_per_ray, float* const* dw_prop, float* distortion_per_ray,
                               float* dw_distortion, float* d_rgb, float* d_density, const float* const* t_bins_prop,
                               const float* const* density_prop, float* const* ddensity_prop, uint32_t* const* gates,
-                              uint8_t* const* ray_masks, nsamd_stream_t stream);
+                              uint8_t* const* ray_masks, float interlevel_loss_mult, float distortion_loss_mult,
+                              float* loss_values, nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Packed-sample path of instant-ngp (BASELINE configs[3]): what the reference gets from nerfacc 0.5.2

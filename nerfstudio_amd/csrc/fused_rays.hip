@@ -93,6 +93,75 @@ __global__ __launch_bounds__(kRenderThreads) void render_losses_train_kernel(Fus
   }
 }
 
+// The launch's finishing pass: the expected depth's global clip (render.hip: depth_clip_kernel, same arithmetic) and — by its
+// last workgroup + 1, which has nothing else to do — the iteration's loss VALUES: the sums over rays of the per-ray terms in a
+// fixed order (thread t takes rays t, t + 256, ... in double, then a fixed tree), scaled as models/nerfacto.py:363-375 does,
+// plus the two training metrics derived from them (models/nerfacto.py:352-361: psnr of the rendered colour, distortion). A
+// trainer that logs the losses every step (engine/trainer.py:487-531) reads five floats instead of launching a dozen reductions.
+struct LossSumArgs {
+  const float* sq_err;
+  const float* dist_per_ray;
+  const float* inter_per_ray[kMaxFusedLevels];
+  int levels;
+  float rgb_scale, dist_scale, inter_scale, mean_scale;  // 1 / (3 n), mult / n, mult / (n S), 1 / n
+  float* out;  // [8]: rgb_loss, interlevel_loss, distortion_loss, psnr, distortion (metric), sum of the three losses
+};
+
+__global__ __launch_bounds__(256) void train_finish_kernel(float* __restrict__ depth, int64_t n, float* __restrict__ ws,
+                                                           int partials, int clip_blocks, LossSumArgs L) {
+  __shared__ float s_lo[256], s_hi[256];
+  __shared__ double s_sum[256];
+  if ((int)blockIdx.x < clip_blocks) {
+    float lo = __uint_as_float(0x7f800000u), hi = __uint_as_float(0xff800000u);
+    for (int i = threadIdx.x; i < partials; i += 256) {
+      lo = fminf(lo, ws[2 + 2 * i]);
+      hi = fmaxf(hi, ws[3 + 2 * i]);
+    }
+    s_lo[threadIdx.x] = lo;
+    s_hi[threadIdx.x] = hi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) {
+        s_lo[threadIdx.x] = fminf(s_lo[threadIdx.x], s_lo[threadIdx.x + o]);
+        s_hi[threadIdx.x] = fmaxf(s_hi[threadIdx.x], s_hi[threadIdx.x + o]);
+      }
+      __syncthreads();
+    }
+    lo = s_lo[0];
+    hi = s_hi[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ws[0] = lo; ws[1] = hi; }
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) depth[i] = fminf(fmaxf(depth[i], lo), hi);
+    return;
+  }
+  if (L.out == nullptr) return;
+  double tot[3] = {0.0, 0.0, 0.0};  // squared error, distortion, interlevel (levels in order)
+  for (int q = 0; q < 2 + L.levels; ++q) {
+    const float* src = q == 0 ? L.sq_err : q == 1 ? L.dist_per_ray : L.inter_per_ray[q - 2];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) acc += (double)src[i];
+    s_sum[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
+      __syncthreads();
+    }
+    tot[q < 2 ? q : 2] += s_sum[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float rgb_loss = (float)tot[0] * L.rgb_scale;
+    const float dist_loss = (float)tot[1] * L.dist_scale;
+    const float inter_loss = (float)tot[2] * L.inter_scale;
+    L.out[0] = rgb_loss;
+    L.out[1] = inter_loss;
+    L.out[2] = dist_loss;
+    L.out[3] = -10.0f * log10f(rgb_loss);
+    L.out[4] = (float)tot[1] * L.mean_scale;
+    L.out[5] = (rgb_loss + inter_loss) + dist_loss;
+  }
+}
+
 }  // namespace nsamd
 
 using namespace nsamd;
@@ -104,7 +173,8 @@ extern "C" int nsamd_render_losses_train(
     const float* const* s_bins_prop, const float* const* w_prop, const int32_t* S_prop, float interlevel_grad_scale,
     float distortion_grad_scale, float* const* interlevel_per_ray, float* const* dw_prop, float* distortion_per_ray,
     float* dw_distortion, float* d_rgb, float* d_density, const float* const* t_bins_prop, const float* const* density_prop,
-    float* const* ddensity_prop, uint32_t* const* gates, uint8_t* const* ray_masks, nsamd_stream_t stream) {
+    float* const* ddensity_prop, uint32_t* const* gates, uint8_t* const* ray_masks, float interlevel_loss_mult,
+    float distortion_loss_mult, float* loss_values, nsamd_stream_t stream) {
   NSAMD_REQUIRE(num_rays >= 0 && S > 0 && levels >= 0 && levels <= kMaxFusedLevels);
   if (num_rays == 0) return NSAMD_OK;
   NSAMD_REQUIRE(rgb && density && t_bins && s_bins && target && weights && rgb_out && sq_err && d_rgb_out);
@@ -147,6 +217,18 @@ extern "C" int nsamd_render_losses_train(
   dim3 g(blocks, (unsigned)(levels + 1));
   render_losses_train_kernel<<<g, kRenderThreads, lds, st>>>(a, num_rays);
   NSAMD_CHECK_LAUNCH();
-  if (depth_expected) return depth_clip_launch(depth_expected, num_rays, workspace, (int)blocks, st);  // (render.hip)
+  if (depth_expected != nullptr || loss_values != nullptr) {
+    LossSumArgs L{};
+    L.sq_err = sq_err, L.dist_per_ray = distortion_per_ray, L.levels = levels, L.out = loss_values;
+    for (int i = 0; i < levels; ++i) L.inter_per_ray[i] = interlevel_per_ray[i];
+    L.rgb_scale = 1.0f / (3.0f * (float)num_rays);
+    L.dist_scale = distortion_loss_mult / (float)num_rays;
+    L.inter_scale = interlevel_loss_mult / ((float)num_rays * (float)S);
+    L.mean_scale = 1.0f / (float)num_rays;
+    const int clip_blocks = depth_expected != nullptr ? (int)((num_rays + 255) / 256) : 0;
+    train_finish_kernel<<<(unsigned)(clip_blocks + (loss_values != nullptr ? 1 : 0)), 256, 0, st>>>(
+        depth_expected, num_rays, workspace, (int)blocks, clip_blocks, L);
+    NSAMD_CHECK_LAUNCH();
+  }
   return NSAMD_OK;
 }

@@ -42,6 +42,11 @@ class _AlreadyBackpropagated(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, *values):  # noqa: D102
+        if len(values) == 1 and values[0].dim() == 1:
+            # the runner's loss-value buffer (train_step.loss_vals): ONE clone, handed out as its first three elements —
+            # three outputs of this node, so the trainer's backward never meets a select node (whose backward launches)
+            out = values[0].clone()
+            return out[0], out[1], out[2], out[3], out[4]
         return tuple(v.clone() for v in values)
 
     @staticmethod
@@ -215,15 +220,24 @@ class TrainEngine:
         t.set_batch(ray_bundle, {"image": self._target(batch)})
         t.train_iteration()
         r = t.runner
-        ld = r.loss_dict()
-        values = _AlreadyBackpropagated.apply(self._anchor, *(ld[k] for k in _LOSS_KEYS))
-        loss_dict = dict(zip(_LOSS_KEYS, values))
         model = self.pipeline.model
-        if "camera_opt_regularizer" in ld:  # differentiated inside the iteration (train_step.backward_cameras)
-            loss_dict["camera_opt_regularizer"] = _AlreadyBackpropagated.apply(self._anchor, ld["camera_opt_regularizer"])[0]
         outputs = r.outputs()
-        mse = torch.mean((outputs["rgb"].detach() - r.target) ** 2)
-        metrics = {"psnr": -10.0 * torch.log10(mse), "distortion": r.dist_per_ray.sum() / r.n}
+        if getattr(r, "_loss_vals_fresh", False) and model.config.background_color != "random":
+            # the losses launch's finishing pass left the loss values and the training metrics in five floats
+            # (include/nsamd.h, nsamd_render_losses_train): one clone per iteration instead of a dozen reduction launches
+            rgb, inter, dist, psnr, dmetric = _AlreadyBackpropagated.apply(self._anchor, r.loss_vals)
+            loss_dict = {"rgb_loss": rgb, "interlevel_loss": inter, "distortion_loss": dist}
+            metrics = {"psnr": psnr.detach(), "distortion": dmetric.detach()}
+            if r.cam_opt is not None:
+                loss_dict["camera_opt_regularizer"] = _AlreadyBackpropagated.apply(self._anchor, r.camera_reg)[0]
+        else:
+            ld = r.loss_dict()
+            values = _AlreadyBackpropagated.apply(self._anchor, *(ld[k] for k in _LOSS_KEYS))
+            loss_dict = dict(zip(_LOSS_KEYS, values))
+            if "camera_opt_regularizer" in ld:  # differentiated inside the iteration (train_step.backward_cameras)
+                loss_dict["camera_opt_regularizer"] = _AlreadyBackpropagated.apply(self._anchor, ld["camera_opt_regularizer"])[0]
+            mse = torch.mean((outputs["rgb"].detach() - r.target) ** 2)
+            metrics = {"psnr": -10.0 * torch.log10(mse), "distortion": r.dist_per_ray.sum() / r.n}
         cam = getattr(model, "camera_optimizer", None)
         if cam is not None:
             cam.get_metrics_dict(metrics)

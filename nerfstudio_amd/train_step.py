@@ -150,9 +150,14 @@ class NerfactoTrainStep:
         self.fuse_rays = os.environ.get("NSAMD_FUSE_RAYS", "1") == "1"
         self.fold_weights_bwd = os.environ.get("NSAMD_FOLD_WEIGHTS_BWD", "1") == "1"
         self._rays_bwd_fresh = False  # `losses` has already run the compositing backward for this forward
+        # the iteration's loss values and training metrics, written by the losses launch's finishing pass (nsamd.h):
+        # rgb_loss, interlevel_loss, distortion_loss, psnr, distortion, sum of the three losses
+        self.loss_vals = torch.zeros(8, **f32)
+        self._loss_vals_fresh = False
         # (slot pointer, slots, pool) of a batch selection the caller leaves to `forward_proposals` (one launch with the initial
         # bins, nsamd_select_bins); NSAMD_FUSE_SELECT=0: the caller launches nsamd_select_batch itself (A/B)
         self.pending_select = None
+        self._slot0 = None  # a device zero: `set_batch` as a one-slot batch selection
         self.fuse_select = os.environ.get("NSAMD_FUSE_SELECT", "1") == "1"
         self._wb_folded = set()       # proposal levels whose weights backward `losses` has already run
         self.f_saved = e(int(N.load().nsamd_field_mlp_saved_floats(mm))) if self.save_acts else None
@@ -219,6 +224,19 @@ class NerfactoTrainStep:
     # -------------------------------------------------------------------------------------------------------------
     def set_batch(self, origins: Tensor, directions: Tensor, camera_indices: Tensor,
                   target_rgb: Optional[Tensor] = None) -> None:
+        cams = camera_indices.reshape(-1)
+        if (target_rgb is not None and origins.is_cuda and all(
+                x.dtype == torch.float32 and x.is_contiguous() and x.shape == (self.n, 3) and x.device == self.origins.device
+                for x in (origins, directions, target_rgb)) and cams.dtype == torch.int64 and cams.is_contiguous()
+                and cams.shape[0] == self.n and cams.device == self.origins.device):
+            # a datamanager's device-resident batch: ONE launch (a pool of one slot) instead of four copy kernels
+            if self._slot0 is None:
+                self._slot0 = torch.zeros(1, device=self.origins.device)
+            o, d = (self.raw_origins, self.raw_directions) if self.cam_opt is not None else (self.origins, self.directions)
+            N.check(N.load().nsamd_select_batch(N.ptr(self._slot0), 1, self.n, N.ptr(origins), N.ptr(directions), N.ptr(cams),
+                                                N.ptr(target_rgb), N.ptr(o), N.ptr(d), N.ptr(self.camera_indices),
+                                                N.ptr(self.target), N.stream()), "select_batch")
+            return
         if self.cam_opt is not None:  # the kernels see the pose-corrected rays (apply_camera_corrections)
             self.raw_origins.copy_(origins)
             self.raw_directions.copy_(directions)
@@ -559,6 +577,7 @@ class NerfactoTrainStep:
         L = self.n_prop
         S = self.counts[L]
         self._rays_bwd_fresh = False
+        self._loss_vals_fresh = False
         self._wb_folded = set()
         if self.fuse_rays and not self.forward_only:
             # one launch: weights + compositing + MSE, the proposal losses, the compositing backward (d rgb / d density of the
@@ -581,8 +600,10 @@ class NerfactoTrainStep:
                 self._pl_per_ray, self._pl_dw if updated else None, N.ptr(self.dist_per_ray), N.ptr(self.dw_dist),
                 N.ptr(self.d_rgb_s), N.ptr(self.d_dens_main), self._pl_t_bins if fold else None,
                 self._pl_dens if fold else None, self._pl_ddens if fold else None, self._pl_gates if (fold and gated) else None,
-                self._pl_masks if (fold and gated) else None, st), "render_losses_train")
+                self._pl_masks if (fold and gated) else None, float(cfg.interlevel_loss_mult),
+                float(cfg.distortion_loss_mult), N.ptr(self.loss_vals), st), "render_losses_train")
             self._rays_bwd_fresh = True
+            self._loss_vals_fresh = True
             if fold:
                 self._wb_folded = set(range(self.n_prop))
                 self._wb_gated = gated
@@ -789,6 +810,12 @@ class NerfactoTrainStep:
     def loss_dict(self) -> Dict[str, Tensor]:
         """Loss values of the last iteration (models/nerfacto.py:363-375); a few tiny torch reductions, call on demand."""
         n, S = self.n, self.counts[-1]
+        if self._loss_vals_fresh:  # views of what the losses launch left behind: no reduction launches
+            v = self.loss_vals
+            out = {"rgb_loss": v[0], "distortion_loss": v[2], "interlevel_loss": v[1]}
+            if self.cam_opt is not None:
+                out["camera_opt_regularizer"] = self.camera_reg
+            return out
         out = {"rgb_loss": self.sq_err.sum() / (3 * n),
                "distortion_loss": self.cfg.distortion_loss_mult * self.dist_per_ray.sum() / n}
         inter = sum(p.sum() for p in self.inter_per_ray) / (n * S)

@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""The training iteration a nerfstudio user gets — `Trainer.train_iteration` (engine/trainer.py:487-531) ->
+`pipeline.get_train_loss_dict(step)` (pipelines/base_pipeline.py:290-303) -> the captured kernel schedule behind the
+`nerfacto-hip` seam (nerfstudio_amd/pipeline.py) -> `loss.backward()` -> `Optimizers` -> schedulers — TIMED next to the
+direct `HipTrainer` line of bench.py on the same box, same batches, same window.
+
+The reference is absent on the GPU box: tests/trainer_restatement.py (pinned to the reference's trainer code by
+tests/test_reference_trainer_drive.py, CPU tier) is the trainer; the datamanager stand-in hands out bench.py's HBM-resident
+batches as fresh tensors every step (what a device-side datamanager does: base_datamanager.py:506-515).
+
+    python scripts/bench_seam.py [--steps 20] [--warmup 5] [--windows 7]
+prints one JSON line: ms_per_step of the three arms (direct over the pool, direct with set_batch, through the seam) and the ratios."""
+import argparse
+import collections
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench  # noqa: E402
+import trainer_restatement as R  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--warmup", type=int, default=5)
+ap.add_argument("--windows", type=int, default=7)
+args = ap.parse_args()
+
+from nerfstudio_amd import _native, functional as F  # noqa: E402
+from nerfstudio_amd.arena import ParamArena  # noqa: E402
+from nerfstudio_amd.cameras.rays import RayBundle  # noqa: E402
+from nerfstudio_amd.pipeline import EngineSeam  # noqa: E402
+from nerfstudio_amd.trainer import HipTrainer  # noqa: E402
+
+_native.load()
+F.DIRECT_GRAD = True
+dev = torch.device("cuda")
+n = bench.RAYS_PER_GPU
+_, _, pool = bench.synthetic_batch(dev, seed=1000)
+area = torch.full((n, 1), 1e-6, device=dev)
+
+
+def batch_of(step):
+    s = step % bench.BATCH_SLOTS
+    rb = RayBundle(origins=pool["origins"][s], directions=pool["directions"][s], pixel_area=area,
+                   camera_indices=pool["cameras"][s][:, None])
+    return rb, {"image": pool["target"][s]}
+
+
+def windows(run_step, finish, first_step):
+    """`--windows` timed windows of `--steps` iterations each (consecutive iterations: a trainer's step counter only moves
+    forward), device sync on both sides; -> list of ms per step."""
+    out, step = [], first_step
+    for _ in range(args.windows):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run_step(step)
+            step += 1
+        finish()
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) / args.steps * 1e3)
+    return out
+
+
+def opt_config(groups):
+    return {k: {"optimizer": {"lr": 1e-2, "eps": 1e-15}, "scheduler": {"lr_final": 1e-4, "max_steps": 200000}} for k in groups}
+
+
+results = {}
+# ---- arm 1 / 2: the trainer driven directly (bench.py's line); over its own pool, or with set_batch every step
+for arm in ("direct_pool", "direct_set_batch"):
+    F._SCATTER_WS.clear()
+    model = bench.build_model(dev, seed=0)
+    arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
+    rb, batch = batch_of(0)
+    tr = HipTrainer(model, arena, rb, batch, world=1, use_graph=True, use_runner=True, pool=pool if arm == "direct_pool" else None)
+
+    def step_direct(step, tr=tr, arm=arm):
+        if arm == "direct_set_batch":
+            tr.set_batch(*batch_of(step))
+        tr.train_iteration()
+
+    for s in range(2):
+        step_direct(s)
+    tr.finish()
+    assert tr.try_capture()
+    for s in range(2, args.warmup):
+        step_direct(s)
+    results[arm] = windows(step_direct, tr.finish, args.warmup)
+    del tr, arena, model
+
+# ---- arm 3: the restated reference trainer -> seam -> engine
+F._SCATTER_WS.clear()
+model = bench.build_model(dev, seed=0)
+groups = model.get_param_groups()
+opts = R.Optimizers(opt_config(groups), groups)
+
+
+class SeamPipeline(EngineSeam):
+    def __init__(self):
+        self.datamanager = SimpleNamespace(next_train=batch_of)
+        self.model = self._model = model
+        self.world_size = 1
+
+
+pipeline = SeamPipeline()
+trainer = SimpleNamespace(pipeline=pipeline, optimizers=opts, device="cuda:0", mixed_precision=False,
+                          gradient_accumulation_steps=collections.defaultdict(lambda: 1),
+                          grad_scaler=torch.amp.GradScaler("cuda", enabled=False), config=SimpleNamespace(log_gradients=False))
+pipeline.attach_optimizers(opts, trainer)
+
+
+def step_seam(step):
+    model.set_step(step)  # BEFORE_TRAIN_ITERATION callbacks
+    R.train_iteration(trainer, step)
+    model.after_step(step)  # AFTER_TRAIN_ITERATION callbacks
+
+
+for s in range(args.warmup):
+    step_seam(s)
+eng = pipeline._engine
+assert eng.reason is None, eng.reason
+results["seam"] = windows(step_seam, eng.flush, args.warmup)
+assert eng.trainer.graphs is not None, "the seam did not reach the captured schedule"
+med = {k: float(np.median(v)) for k, v in results.items()}
+print(json.dumps({
+    "metric": "ms per training iteration, 4096 rays (same box, same batches)", "steps": args.steps, "windows": args.windows,
+    "direct_pool_ms": round(med["direct_pool"], 4), "direct_set_batch_ms": round(med["direct_set_batch"], 4),
+    "seam_ms": round(med["seam"], 4), "seam_over_direct_pool": round(med["seam"] / med["direct_pool"], 4),
+    "seam_over_direct_set_batch": round(med["seam"] / med["direct_set_batch"], 4),
+    "rays_per_s": {k: round(n / (v * 1e-3), 1) for k, v in med.items()},
+    "windows_ms": {k: [round(x, 4) for x in v] for k, v in results.items()},
+    "note": "seam = tests/trainer_restatement.train_iteration (the reference's Trainer.train_iteration restated) over "
+            "pipeline.EngineSeam.get_train_loss_dict; windows are consecutive iterations (steps "
+            f"{args.warmup} .. {args.warmup + args.steps * args.windows - 1}), the direct arms run the same steps"}))
