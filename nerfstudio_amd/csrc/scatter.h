@@ -207,8 +207,12 @@ ScatterBufs scatter_bufs(float* workspace, const ScatterPlan& p);
 
 // Host: enqueue apply (pass 2) + finish for records that are already in the queues of `plan` (every level routed through
 // static segments + dynamic area; counts[tile][seg] and hdr[level] written by the producer).
+// `rider` (nullable): the main field's weight-gradient reduce carried along as extra workgroups of the apply pass
+// (field_reduce.h); only where `scatter_apply_takes_rider(plan)`.
+struct ReduceRider;
+bool scatter_apply_takes_rider(const ScatterPlan& plan);
 int scatter_apply_launch(const nsamd_grid& grid, const ScatterPlan& plan, float* workspace, float* dtable, bool overwrite,
-                         hipStream_t stream);
+                         hipStream_t stream, const ReduceRider* rider = nullptr);
 
 // Host: enqueue route (pass 1) + apply (pass 2) + finish on `stream`. Returns an nsamd_status. `gate` (nullable, device):
 // accumulating calls only — while *gate == 0 all kernels return at once (the gradient being scattered is all zeros);

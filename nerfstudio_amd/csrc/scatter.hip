@@ -28,6 +28,7 @@
 
 #include <type_traits>
 
+#include "field_reduce.h"
 #include "scatter.h"
 
 NSAMD_PROBE_DEFINE(scatter)
@@ -435,10 +436,23 @@ __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
 // ---- pass 2 ------------------------------------------------------------------------------------------------------
 // One workgroup per (level, tile): static segments, dynamic area and the folded part of the spill list are summed into
 // an LDS tile of 2 x int64 per entry; the finished tile is converted once and stored / added with coalesced accesses.
+// kRider: the launch carries the main field's weight-gradient reduce along (its own instantiation: the rider's registers —
+// 118 against 83 — must not cost the small-tile launches of the proposal levels their occupancy).
+template <bool kRider>
 __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs buf, float* __restrict__ dtable,
-                                     int overwrite, const uint32_t* __restrict__ gate) {
+                                     int overwrite, const uint32_t* __restrict__ gate, ReduceRider rider) {
   if (gate_is_clear(gate)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];  // [entries][2]
+  if (kRider && (int)blockIdx.y >= G.num_levels) {
+    // RIDER workgroups (rows of the grid behind the levels): the main field's weight-gradient reduce, which needs nothing of
+    // this pass and which this pass needs nothing of (field_reduce.h) — dispatched after the tiles, they fill the compute
+    // units the last round of tiles leaves idle instead of being a launch of their own
+    const int block = ((int)blockIdx.y - G.num_levels) * (int)gridDim.x + (int)blockIdx.x;
+    if (block < rider.blocks)
+      field_dw_reduce_body(reinterpret_cast<float*>(acc), block, rider.partials, rider.num_partials, rider.grads, rider.app_dim,
+                           rider.app_rows, rider.cams, rider.num_rays, rider.tiles_per_ray);
+    return;
+  }
   const int bin = blockIdx.x, level = blockIdx.y;
   const uint32_t tile = ((uint32_t)level << G.log2_bins) + (uint32_t)bin;
   const int entries = 1 << G.slice_log2;
@@ -810,7 +824,9 @@ static int apply_lds_attribute() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return NSAMD_ERR_NO_DEVICE;
   if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_apply_kernel),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_apply_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16u << kSliceLog2Max)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_apply_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16u << kSliceLog2Max)) != hipSuccess)
       return NSAMD_ERR_LAUNCH;
     if (dev >= 0 && dev < 64) attr_done[dev] = true;
@@ -819,7 +835,7 @@ static int apply_lds_attribute() {
 }
 
 int scatter_apply_launch(const nsamd_grid& grid, const ScatterPlan& plan, float* workspace, float* dtable, bool overwrite,
-                         hipStream_t st) {
+                         hipStream_t st, const ReduceRider* rider) {
   ScatterGeom G = plan.geom;
   ScatterBufs buf = scatter_bufs(workspace, plan);
   buf.log2_table_size = grid.log2_table_size;
@@ -827,13 +843,25 @@ int scatter_apply_launch(const nsamd_grid& grid, const ScatterPlan& plan, float*
   int rc = apply_lds_attribute();
   if (rc) return rc;
   const unsigned threads = G.slice_log2 > 11 ? 1024u : (G.slice_log2 > 9 ? 512u : 256u);
-  dim3 g2(1u << G.log2_bins, (unsigned)grid.num_levels);
-  scatter_apply_kernel<<<g2, threads, (size_t)16 << G.slice_log2, st>>>(grid, G, buf, dtable, overwrite ? 1 : 0, nullptr);
+  ReduceRider rd{};
+  unsigned extra_rows = 0u;
+  if (rider != nullptr && rider->blocks > 0) {
+    if (threads != (unsigned)kReduceThreads) return NSAMD_ERR_UNSUPPORTED;  // (callers check `scatter_apply_takes_rider` first)
+    rd = *rider;
+    extra_rows = ((unsigned)rd.blocks + (1u << G.log2_bins) - 1u) >> G.log2_bins;
+  }
+  dim3 g2(1u << G.log2_bins, (unsigned)grid.num_levels + extra_rows);
+  if (extra_rows != 0u)
+    scatter_apply_kernel<true><<<g2, threads, (size_t)16 << G.slice_log2, st>>>(grid, G, buf, dtable, overwrite ? 1 : 0, nullptr, rd);
+  else
+    scatter_apply_kernel<false><<<g2, threads, (size_t)16 << G.slice_log2, st>>>(grid, G, buf, dtable, overwrite ? 1 : 0, nullptr, rd);
   NSAMD_CHECK_LAUNCH();
   scatter_finish_kernel<<<32, 256, 0, st>>>(grid, G, buf, dtable, nullptr);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }
+
+bool scatter_apply_takes_rider(const ScatterPlan& plan) { return plan.geom.slice_log2 > 11; }  // 1024-thread workgroups
 
 ScatterBufs scatter_bufs(float* workspace, const ScatterPlan& p) {
   ScatterBufs b;
@@ -925,7 +953,8 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
   }
   const unsigned threads = G.slice_log2 > 11 ? 1024u : (G.slice_log2 > 9 ? 512u : 256u);
   dim3 g2(1u << G.log2_bins, (unsigned)grid.num_levels);
-  scatter_apply_kernel<<<g2, threads, (size_t)16 << G.slice_log2, st>>>(grid, G, buf, dtable, overwrite ? 1 : 0, gate);
+  scatter_apply_kernel<false><<<g2, threads, (size_t)16 << G.slice_log2, st>>>(grid, G, buf, dtable, overwrite ? 1 : 0, gate,
+                                                                               ReduceRider{});
   NSAMD_CHECK_LAUNCH();
   scatter_finish_kernel<<<32, 256, 0, st>>>(grid, G, buf, dtable, gate);
   NSAMD_CHECK_LAUNCH();

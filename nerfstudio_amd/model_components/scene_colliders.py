@@ -1,38 +1,35 @@
-"""Scene colliders (reference: nerfstudio/model_components/scene_colliders.py:28-46, 169-191)."""
+"""Scene colliders: near / far values for the rays of a bundle (reference: nerfstudio/model_components/scene_colliders.py:28-46,
+169-191). No kernel is involved — two [N,1] fills on any bundle with `origins`, `nears`, `fars` (this package's RayBundle or the
+reference's); the classes keep the reference's names, constructor arguments and eval-mode behaviour."""
 import torch
 from torch import nn
 
-from ..cameras.rays import RayBundle
-
 
 class SceneCollider(nn.Module):
-    """Module for setting near and far values for rays."""
+    """forward() leaves a bundle that already carries nears and fars alone, else asks the subclass for them."""
 
     def __init__(self, **kwargs) -> None:
         self.kwargs = kwargs
         super().__init__()
 
-    def set_nears_and_fars(self, ray_bundle: RayBundle) -> RayBundle:
+    def set_nears_and_fars(self, ray_bundle):
         raise NotImplementedError
 
-    def forward(self, ray_bundle: RayBundle) -> RayBundle:
-        if ray_bundle.nears is not None and ray_bundle.fars is not None:
-            return ray_bundle
-        return self.set_nears_and_fars(ray_bundle)
+    def forward(self, ray_bundle):
+        done = ray_bundle.nears is not None and ray_bundle.fars is not None
+        return ray_bundle if done else self.set_nears_and_fars(ray_bundle)
 
 
 class NearFarCollider(SceneCollider):
-    """Fixed near / far planes; the near plane resets to 0 at inference (scene_colliders.py:169-191)."""
+    """Constant planes for every ray; in eval mode the near plane drops to 0 unless reset_near_plane is off."""
 
     def __init__(self, near_plane: float, far_plane: float, reset_near_plane: bool = True, **kwargs) -> None:
-        self.near_plane = near_plane
-        self.far_plane = far_plane
-        self.reset_near_plane = reset_near_plane
+        self.near_plane, self.far_plane, self.reset_near_plane = near_plane, far_plane, reset_near_plane
         super().__init__(**kwargs)
 
-    def set_nears_and_fars(self, ray_bundle: RayBundle) -> RayBundle:
-        ones = torch.ones_like(ray_bundle.origins[..., 0:1])
-        near_plane = self.near_plane if (self.training or not self.reset_near_plane) else 0
-        ray_bundle.nears = ones * near_plane
-        ray_bundle.fars = ones * self.far_plane
+    def set_nears_and_fars(self, ray_bundle):
+        near = self.near_plane if (self.training or not self.reset_near_plane) else 0
+        template = ray_bundle.origins[..., 0:1]
+        ray_bundle.nears = torch.ones_like(template) * near
+        ray_bundle.fars = torch.ones_like(template) * self.far_plane
         return ray_bundle

@@ -220,3 +220,41 @@ def test_trainer_with_merged_launches_trains_through_the_same_bits(F, monkeypatc
         assert bool(torch.isfinite(tr.last_loss()))
         del tr, arena, model
     assert digests["merged"] == digests["separate"], digests
+
+
+def test_weight_gradient_reduce_riding_the_apply_pass_equals_its_own_launch(F):
+    """nsamd_field_mlp_bwd_scatter carries the weight-gradient reduce as extra workgroups of the scatter's apply pass
+    (csrc/field_reduce.h); the phase entry point runs the three launch groups one at a time (gradient kernel, reduce, apply):
+    the whole fields slice of the gradient arena — MLP weights, biases, appearance embedding, the table — must be the same bits,
+    at the benchmark's own size (1024-thread apply workgroups, 100 cameras)."""
+    import bench
+
+    from nerfstudio_amd import _native as N
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.train_step import NerfactoTrainStep
+
+    F._SCATTER_WS.clear()
+    dev = torch.device("cuda")
+    model = bench.build_model(dev, seed=0)
+    with torch.no_grad():  # (tables away from the all-but-zero initial state)
+        model.field.mlp_base.encoding.hash_table.normal_(0.0, 0.3)
+    arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
+    o, d, cam, tgt = (torch.from_numpy(a).to(dev) for a in bench.synthetic_rays(1003))
+    r = NerfactoTrainStep(model, bench.RAYS_PER_GPU, dev)
+    r.side_stream = None
+    r.set_batch(o, d, cam[:, 0], tgt)
+    r.jitter.copy_(torch.from_numpy(np.random.RandomState(4).uniform(0, 1, (3, bench.RAYS_PER_GPU)).astype(np.float32)))
+    r.forward_and_losses(False, draw_jitter=False)
+    a, b = arena.groups["fields"]
+    out = {}
+    for mode in ("rider", "phases"):
+        arena.zero_grad(["fields"], skip=r.written_params())
+        N.PROFILE = {} if mode == "phases" else None  # (the per-kernel table's route: one launch group per call)
+        try:
+            r.backward_main()
+        finally:
+            N.PROFILE = None
+        torch.cuda.synchronize()
+        out[mode] = arena.grad[a:b].clone()
+    assert float(out["rider"].abs().max()) > 0 and not torch.isnan(out["rider"]).any()
+    _same(out["rider"], out["phases"], "fields slice of the gradient arena")
