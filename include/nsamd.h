@@ -406,6 +406,42 @@ int nsamd_proposal_resample(const float* t_bins_prev, const float* s_bins_prev, 
                             int spacing, int64_t num_rays, int32_t S, float* weights, float* depth_median,
                             float* s_bins, float* t_bins, nsamd_stream_t stream);
 
+/* ProposalNetworkSampler.generate_ray_samples (ray_samplers.py:576-617) in ONE launch, one wavefront per ray:
+ *   [nsamd_select_batch ->] nsamd_piecewise_bins -> per level: nsamd_density_field_fwd -> nsamd_proposal_resample.
+ * Same numbers as those launches (the stages are their device bodies, run one after the other inside the wave).
+ * slot_dev NULL: no batch selection (the caller filled origins / directions), else as nsamd_select_batch.
+ * jitter0 [N]: the draw of the initial bins (single jitter: one per ray). level: HOST array of `levels` (<= 4) descriptors;
+ * level l's s_bins / t_bins [N, samples+1] are WRITTEN by this launch (level 0 by the initial sampler, l > 0 by level l-1's
+ * resampling), as are density [N*samples], weights [N, samples], depth_median [N] (nullable) and — nullable, for the level's
+ * backward — enc [2 L, N*samples], selector, pre; u_base / jitter / u_offset are those of the resampling that FOLLOWS the level
+ * (its S + 1 uniform offsets, its per-ray draw, 1 / (2 (S + 1))). s_bins_out / t_bins_out [N, S_out+1]: the final samples.
+ * NSAMD_ERR_UNSUPPORTED (nothing launched) when the levels' networks differ in shape or are not 5 levels x {16, 64} hidden. */
+typedef struct nsamd_sampler_level {
+  const float* table;
+  nsamd_grid grid;
+  nsamd_density_mlp mlp;
+  nsamd_aabb aabb;
+  int32_t transform;
+  int32_t samples;
+  float* s_bins;
+  float* t_bins;
+  float* density;
+  float* enc;
+  float* selector;
+  float* pre;
+  float* weights;
+  float* depth_median;
+  const float* u_base;
+  const float* jitter;
+  float u_offset;
+} nsamd_sampler_level;
+int nsamd_proposal_sampler(const float* slot_dev, int32_t slots, const float* origins_pool, const float* directions_pool,
+                           const int64_t* cameras_pool, const float* target_pool, int64_t* cameras, float* target,
+                           float* origins, float* directions, const float* nears, const float* fars, int64_t num_rays,
+                           const float* edges, const float* jitter0, int spacing, float anneal, const float* anneal_dev,
+                           float histogram_padding, float eps, int32_t levels, const nsamd_sampler_level* level, int32_t S_out,
+                           float* s_bins_out, float* t_bins_out, nsamd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Compositing (model_components/renderers.py): RGBRenderer.combine_rgb :72-119 (+ eval nan_to_num/clamp
  * :225-231), AccumulationRenderer :293-317, DepthRenderer median :354-364 and expected :365-383.

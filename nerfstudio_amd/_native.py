@@ -42,6 +42,12 @@ class DensityMlp(C.Structure):
                 ("average_init_density", f32)]
 
 
+class SamplerLevel(C.Structure):
+    _fields_ = [("table", vp), ("grid", Grid), ("mlp", DensityMlp), ("aabb", Aabb), ("transform", i32), ("samples", i32),
+                ("s_bins", vp), ("t_bins", vp), ("density", vp), ("enc", vp), ("selector", vp), ("pre", vp), ("weights", vp),
+                ("depth_median", vp), ("u_base", vp), ("jitter", vp), ("u_offset", f32)]
+
+
 class FieldMlp(C.Structure):
     _fields_ = [("base_W0", vp), ("base_b0", vp), ("base_W1", vp), ("base_b1", vp), ("head_W0", vp), ("head_b0", vp),
                 ("head_W1", vp), ("head_b1", vp), ("head_W2", vp), ("head_b2", vp), ("appearance", vp),
@@ -100,6 +106,8 @@ _SIGNATURES = {
     "nsamd_weights_bwd_gate": [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp],
     "nsamd_pdf_resample": [vp, vp, i32, vp, vp, vp, vp, f32, vp, f32, f32, f32, C.c_int, i32, i32, i64, i32, vp, vp, vp, vp],
     "nsamd_proposal_resample": [vp, vp, vp, i32, vp, vp, vp, vp, f32, vp, f32, f32, f32, C.c_int, i64, i32, vp, vp, vp, vp, vp],
+    "nsamd_proposal_sampler": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, C.c_int, f32, vp, f32, f32, i32,
+                               C.POINTER(SamplerLevel), i32, vp, vp, vp],
     "nsamd_composite_fwd": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), C.c_int, vp, vp, vp, vp, vp, vp, vp],
     "nsamd_render_train": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "nsamd_render_train_bwd": [vp, vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, vp, vp, vp, vp, vp],

@@ -410,6 +410,217 @@ __device__ __forceinline__ void weights_bwd_body(float* lds_wave, const float* _
   }
 }
 
+// ---- UniformLinDispPiecewiseSampler (sampler.hip; ray_samplers.py:78-128, 225-248): the bin edges of one ray ------------------
+__device__ __forceinline__ void piecewise_bins_body(int64_t ray, int lane, const float* __restrict__ nears,
+                                                    const float* __restrict__ fars, const float* __restrict__ edges,
+                                                    const float* __restrict__ jitter, int jitter_per_edge, int S, int spacing,
+                                                    float* __restrict__ s_bins, float* __restrict__ t_bins) {
+  const float s_near = spacing_fn_mode(spacing, nears[ray]);
+  const float s_far = spacing_fn_mode(spacing, fars[ray]);
+  // single_jitter: one draw per ray; otherwise one per bin edge, [num_rays, S+1] (ray_samplers.py:104-107)
+  const float jit = (jitter != nullptr && !jitter_per_edge) ? jitter[ray] : 0.0f;
+  float* sb = s_bins + ray * (S + 1);
+  float* tb = t_bins + ray * (S + 1);
+  for (int i = lane; i <= S; i += 64) {
+    float b = edges[i];
+    if (jitter != nullptr) {
+      // lower = [edges[0], centres], upper = [centres, edges[S]]   (ray_samplers.py:108-110)
+      const float lower = (i == 0) ? edges[0] : (edges[i] + edges[i - 1]) / 2.0f;
+      const float upper = (i == S) ? edges[S] : (edges[i + 1] + edges[i]) / 2.0f;
+      b = lower + (upper - lower) * (jitter_per_edge ? jitter[ray * (S + 1) + i] : jit);
+    }
+    sb[i] = b;
+    tb[i] = spacing_to_euclidean_mode(spacing, b, s_near, s_far);
+  }
+}
+
+
+// ---- PDFSampler.generate_ray_samples (sampler.hip; ray_samplers.py:276-372) ---------------------------------------------
+// LDS: per wave  w[S_prev], cdf[S_prev + 1], the previous level's edges [S_prev + 1] (+ the S + 1 new edges when they are merged
+// with the existing ones). kFused: also the level's RaySamples.get_weights and its median depth (see sampler.hip).
+template <bool kFused>
+__device__ __forceinline__ void pdf_resample_body(float* lds_wave, int64_t ray,
+    const float* __restrict__ s_bins_prev, const float* __restrict__ weights, int S_prev,
+    const float* __restrict__ u_base, const float* __restrict__ jitter, const float* __restrict__ nears,
+    const float* __restrict__ fars, float anneal_host, const float* __restrict__ anneal_dev, float hist_pad, float eps,
+    float u_offset, int spacing, int64_t num_rays, int S,
+    float* __restrict__ s_bins, float* __restrict__ t_bins, int32_t* __restrict__ inds,
+    const float* __restrict__ t_bins_prev, const float* __restrict__ density, float* __restrict__ weights_out,
+    float* __restrict__ depth_median, int jitter_per_edge, int include_original) {
+  const int lane = threadIdx.x & 63;
+  float* w = lds_wave;
+  float* cdf = w + S_prev;
+  float* bprev = cdf + S_prev + 1;    // the previous level's spacing-domain edges (gathered by the search below)
+  float* fresh = bprev + S_prev + 1;  // include_original only
+  // Everything this ray reads from global memory is requested HERE, in one burst: the kernel is one wavefront per ray and
+  // all rays are resident at once, so its duration is one wave's chain of latencies — loads issued where they are used
+  // (behind the LDS fences) put five or six exposed round trips into it.
+  const float anneal = anneal_dev ? anneal_dev[0] : anneal_host;  // device copy: graph-replayable schedules
+  const int nb = S + 1;
+  const float near_ray = nears[ray], far_ray = fars[ray];
+  const float jit_ray = (jitter != nullptr && !jitter_per_edge) ? jitter[ray] : 0.0f;
+  // (... and UNCONDITIONALLY, at clamped indices, with nothing consumed before the last one is out: a load under a lane
+  //  predicate sits in a branch of its own, the compiler closes every such branch with s_waitcnt vmcnt(0), and the "burst" was
+  //  four round trips in a row — read off the ISA)
+  float u_pre[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) u_pre[c] = u_base[min(lane + 64 * c, nb - 1)];
+  const float* bp = s_bins_prev + ray * (S_prev + 1);
+  float bp_pre[5];  // edges 0 .. 319 of the previous level (all of them for the nerfacto counts; the rest below)
+#pragma unroll
+  for (int c = 0; c < 5; ++c) bp_pre[c] = bp[min(lane + 64 * c, S_prev)];
+  float tb_lo[4] = {0.f, 0.f, 0.f, 0.f}, tb_hi[4] = {0.f, 0.f, 0.f, 0.f}, dn_pre[4] = {0.f, 0.f, 0.f, 0.f};
+  if (kFused) {
+    const float* tb0 = t_bins_prev + ray * (S_prev + 1);
+    const float* dn0 = density + ray * S_prev;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = min(64 * c + lane, S_prev - 1);
+      tb_lo[c] = tb0[i];
+      tb_hi[c] = tb0[i + 1];
+      dn_pre[c] = dn0[i];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 5; ++c)
+    if (lane + 64 * c <= S_prev) bprev[lane + 64 * c] = bp_pre[c];
+  for (int i = lane + 320; i <= S_prev; i += 64) bprev[i] = bp[i];
+  float dd_pre[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) dd_pre[c] = (64 * c + lane) < S_prev ? (tb_hi[c] - tb_lo[c]) * dn_pre[c] : 0.0f;
+
+  if (kFused) {
+    // (0) weights of the previous level  (cameras/rays.py:129-152), kept in the LDS row
+    const float* tb = t_bins_prev + ray * (S_prev + 1);
+    const float* dn = density + ray * S_prev;
+    double carry0 = 0.0;
+    for (int i0 = 0; i0 < S_prev; i0 += 64) {
+      const int i = i0 + lane;
+      const float dd = i0 == 0 ? dd_pre[0] : i0 == 64 ? dd_pre[1] : i0 == 128 ? dd_pre[2] : i0 == 192 ? dd_pre[3]
+                       : (i < S_prev ? (tb[i + 1] - tb[i]) * dn[i] : 0.0f);  // (selects, not an indexed array: no scratch)
+      const double incl = carry0 + wave_scan_inclusive_f64((double)dd);
+      double excl = wave_shift_up1_f64(incl);
+      if (lane == 0) excl = carry0;
+      carry0 = wave_read_f64<63>(incl);
+      if (i < S_prev) {
+        const float alpha = 1.0f - expf(-dd);
+        const float trans = expf(-(float)excl);
+        const float wv = nan_to_num(alpha * trans);
+        weights_out[ray * S_prev + i] = wv;
+        w[i] = wv;
+      }
+    }
+    if (depth_median != nullptr) {  // searchsorted(cumsum(w), 0.5, side="left"), clamped
+      double carry1 = 0.0;
+      int idx = S_prev;
+      for (int i0 = 0; i0 < S_prev && idx == S_prev; i0 += 64) {
+        const int i = i0 + lane;
+        const double incl = carry1 + wave_scan_inclusive_f64(i < S_prev ? (double)w[i] : 0.0);
+        carry1 = wave_read_f64<63>(incl);
+        const unsigned long long hit = __ballot(i < S_prev && (float)incl >= 0.5f);
+        if (hit != 0ull) idx = i0 + __builtin_ctzll(hit);
+      }
+      idx = min(idx, S_prev - 1);
+      if (lane == 0) depth_median[ray] = (tb[idx] + tb[idx + 1]) / 2.0f;
+    }
+  }
+  // (1) weights (annealed) + histogram padding, and their sum                 ray_samplers.py:601, :303-309
+  double total = 0.0;
+  for (int i0 = 0; i0 < S_prev; i0 += 64) {
+    const int i = i0 + lane;
+    float v = 0.0f;
+    if (i < S_prev) {
+      v = kFused ? w[i] : weights[ray * S_prev + i];
+      // pow(weights, anneal) (ray_samplers.py:601): libm's powf. It is a quarter of this kernel (probe_sampler_clocks: 7.5 k
+      // of 26.7 k clocks), and 2^(anneal log2 v) on v_log_f32 / v_exp_f32 brings the launch from 17.9 to 13.5 us — but the
+      // PSNR stand-in then ends 0.5 dB lower on one of its three scenes in every twin run (profiles/r02_negative_results.txt),
+      // so the accurate function stays.
+      if (anneal != 1.0f) v = powf(v, anneal);
+      v = v + hist_pad;
+      w[i] = v;
+    }
+    total = total + wave_read_f64<63>(wave_scan_inclusive_f64((double)v));
+  }
+  const float run = (float)total;  // double-accumulated sum, rounded once (= cumsum(w)[-1] of the oracle)
+  const float pad = fmaxf(eps - run, 0.0f);
+  const float wpad = pad / (float)S_prev;
+  const float wsum = run + pad;
+  // (2) pdf and cdf = [0, min(1, cumsum(pdf))]                                 ray_samplers.py:308-313
+  double carry = 0.0;
+  if (lane == 0) cdf[0] = 0.0f;
+  for (int i0 = 0; i0 < S_prev; i0 += 64) {
+    const int i = i0 + lane;
+    const float pdf = i < S_prev ? (w[i] + wpad) / wsum : 0.0f;
+    const double incl = carry + wave_scan_inclusive_f64((double)pdf);
+    carry = wave_read_f64<63>(incl);
+    if (i < S_prev) cdf[i + 1] = fminf(1.0f, (float)incl);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // (3) inverse-CDF sampling of the S+1 new bin edges                         ray_samplers.py:315-358
+  const float s_near = spacing_fn_mode(spacing, near_ray);
+  const float s_far = spacing_fn_mode(spacing, far_ray);
+  const int out_edges = include_original ? nb + S_prev + 1 : nb;
+  for (int j = lane; j < nb; j += 64) {
+    float u = j < 64 ? u_pre[0] : j < 128 ? u_pre[1] : u_base[j];
+    // rand / num_bins: one draw per ray (single_jitter) or per new edge   (ray_samplers.py:318-322)
+    if (jitter != nullptr) u = u + (jitter_per_edge ? jitter[ray * nb + j] : jit_ray) / (float)nb;
+    else u = u + u_offset;                                    // 1 / (2 num_bins)  (ray_samplers.py:327), host-rounded
+    // searchsorted(side="right"): number of cdf entries <= u
+    int lo = 0, hi = S_prev + 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= u) lo = mid + 1;
+      else hi = mid;
+    }
+    const int below = min(max(lo - 1, 0), S_prev);
+    const int above = min(max(lo, 0), S_prev);
+    const float c0 = cdf[below], c1 = cdf[above];
+    const float b0 = bprev[below], b1 = bprev[above];
+    float t = nan_to_num((u - c0) / (c1 - c0), 0.0f);
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float b = b0 + t * (b1 - b0);
+    if (include_original) {
+      fresh[j] = b;
+    } else {
+      s_bins[ray * nb + j] = b;
+      t_bins[ray * nb + j] = spacing_to_euclidean_mode(spacing, b, s_near, s_far);
+    }
+    if (inds != nullptr) inds[ray * nb + j] = lo;
+  }
+  if (include_original) {
+    // sort(cat(existing, new)) (ray_samplers.py:356-357): both lists are ascending, so an element's place is its own index
+    // plus the number of elements of the other list in front of it (existing edges first on ties — equal values either way)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* so = s_bins + ray * out_edges;
+    float* to = t_bins + ray * out_edges;
+    for (int i = lane; i <= S_prev; i += 64) {  // existing edge i: new edges strictly below it
+      const float v = bprev[i];
+      int lo = 0, hi = nb;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (fresh[mid] < v) lo = mid + 1;
+        else hi = mid;
+      }
+      so[i + lo] = v;
+      to[i + lo] = spacing_to_euclidean_mode(spacing, v, s_near, s_far);
+    }
+    for (int j = lane; j < nb; j += 64) {  // new edge j: existing edges at or below it
+      const float v = fresh[j];
+      int lo = 0, hi = S_prev + 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (bprev[mid] <= v) lo = mid + 1;
+        else hi = mid;
+      }
+      so[j + lo] = v;
+      to[j + lo] = spacing_to_euclidean_mode(spacing, v, s_near, s_far);
+    }
+  }
+}
+
+
 // ---- proposal losses (losses.hip) -----------------------------------------------------------------------------------------
 
 constexpr int kLossThreads = 256;

@@ -157,6 +157,10 @@ class NerfactoTrainStep:
         # (slot pointer, slots, pool) of a batch selection the caller leaves to `forward_proposals` (one launch with the initial
         # bins, nsamd_select_bins); NSAMD_FUSE_SELECT=0: the caller launches nsamd_select_batch itself (A/B)
         self.pending_select = None
+        # the proposal sampler's whole cascade in one launch (nsamd_proposal_sampler); NSAMD_FUSE_SAMPLER=0: 1 + 2 launches per
+        # level (A/B), same bits
+        self.fuse_sampler = os.environ.get("NSAMD_FUSE_SAMPLER", "1") == "1"
+        self._sampler_ok = True
         self._slot0 = None  # a device zero: `set_batch` as a one-slot batch selection
         self.fuse_select = os.environ.get("NSAMD_FUSE_SELECT", "1") == "1"
         self._wb_folded = set()       # proposal levels whose weights backward `losses` has already run
@@ -468,6 +472,35 @@ class NerfactoTrainStep:
         S0 = self.counts[0]
         jit0 = self.jitter_edges[0] if per_edge else self.jitter[0]
         sel, self.pending_select = self.pending_select, None
+        if self.fuse_sampler and not per_edge and self._sampler_ok:
+            # the whole cascade — [batch selection,] initial bins, and per level density -> weights -> median depth ->
+            # resampling — in ONE launch, one wavefront per ray (nsamd_proposal_sampler; same bits as the launches below)
+            levels = (N.SamplerLevel * self.n_prop)()
+            for lvl in range(self.n_prop):
+                net, Lv = self.props[lvl], levels[lvl]
+                W0, b0, W1, b1 = net.mlp_base[1].param_tensors()
+                Lv.table, Lv.grid, Lv.aabb, Lv.transform = N.ptr(net.encoding.hash_table), net.encoding.spec.native(), net._box, net._transform
+                Lv.mlp = N.DensityMlp(N.ptr(W0), N.ptr(b0), N.ptr(W1), N.ptr(b1), W0.shape[1], W0.shape[0],
+                                      float(net.average_init_density))
+                Lv.samples = self.counts[lvl]
+                Lv.s_bins, Lv.t_bins, Lv.density = N.ptr(self.s_bins[lvl]), N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl])
+                Lv.enc, Lv.selector, Lv.pre = ((N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]))
+                                               if need_enc else (None, None, None))
+                Lv.weights = N.ptr(self.weights[lvl])
+                Lv.depth_median = N.ptr(self.depth_med[lvl]) if self.compute_depths else None
+                Lv.u_base, Lv.jitter = N.ptr(self.u_base[lvl + 1]), N.ptr(self.jitter[lvl + 1])
+                Lv.u_offset = 1.0 / (2 * (self.counts[lvl + 1] + 1))
+            slot, slots, pool = sel if sel is not None else (None, 0, None)
+            pp = (lambda k: N.ptr(pool[k])) if pool is not None else (lambda k: None)  # noqa: E731
+            rc = lib.nsamd_proposal_sampler(
+                slot, slots, pp("origins"), pp("directions"), pp("cameras"), pp("target"), N.ptr(self.camera_indices),
+                N.ptr(self.target), N.ptr(self.origins), N.ptr(self.directions), N.ptr(self.nears), N.ptr(self.fars), n,
+                N.ptr(self.edges), N.ptr(jit0), self.spacing, 1.0, N.ptr(self.anneal_dev), 0.01, 1e-5, self.n_prop, levels,
+                self.counts[-1], N.ptr(self.s_bins[-1]), N.ptr(self.t_bins[-1]), st)
+            if rc != N.ERR_UNSUPPORTED:
+                ck(rc, "proposal_sampler")
+                return
+            self._sampler_ok = False  # network shapes the one-launch cascade is not built for: the per-level launches
         if sel is not None:
             # the step's batch out of the caller's pool of batches AND the initial bins in one launch (trainer.HipTrainer hands
             # the selection over instead of launching it: the bins need nears / fars / the draw, not the rays)

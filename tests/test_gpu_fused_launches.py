@@ -136,6 +136,70 @@ def test_folded_weights_backward_equals_its_own_launch_and_respects_the_switches
         _same(out[False][2][lvl], out[True][2][lvl], f"ray mask [{lvl}]")
 
 
+@pytest.mark.parametrize("n", [333, 4096])
+@pytest.mark.parametrize("with_pool", [False, True])
+def test_proposal_sampler_one_launch_equals_the_per_level_launches(F, n, with_pool):
+    """nsamd_proposal_sampler ([batch selection,] initial bins, then per level density -> weights -> median depth -> resampling,
+    one wavefront per ray) against nsamd_select_batch / nsamd_piecewise_bins / nsamd_density_field_fwd / nsamd_proposal_resample:
+    bin edges of every level, densities, weights, median depths and — on the steps that keep them for the backward — the encoded
+    features, selectors and pre-activations, bit for bit; annealed resampling included."""
+    from test_gpu_kernels import small_cfg
+
+    from nerfstudio_amd import _native as N
+
+    cfg = small_cfg(12, 10, 6)
+    rs = np.random.RandomState(7)
+    slots = 3
+    pool = {"origins": torch.from_numpy((rs.standard_normal((slots, n, 3)) * 0.5).astype(np.float32)).cuda(),
+            "directions": torch.nn.functional.normalize(torch.from_numpy(rs.standard_normal((slots, n, 3)).astype(np.float32)), dim=-1).cuda(),
+            "cameras": torch.from_numpy(rs.randint(0, cfg.num_images, (slots, n))).cuda(),
+            "target": torch.from_numpy(rs.uniform(0, 1, (slots, n, 3)).astype(np.float32)).cuda()}
+    jit = torch.from_numpy(rs.uniform(0, 1, (3, n)).astype(np.float32)).cuda()
+    slot = torch.tensor([1.0], device="cuda")
+    out = {}
+    for fused in (False, True):
+        F._SCATTER_WS.clear()
+        model, arena, r = _runner(cfg, n, 13, "last_sample", True)
+        r.fuse_sampler = fused
+        r.fuse_select = fused
+        r.jitter.copy_(jit)
+        r.anneal_dev.fill_(0.6)
+        snaps = []
+        for need_enc in (True, False):
+            for buf in (r.p_enc + r.p_sel + r.p_pre + r.p_dens + r.weights + r.s_bins + r.t_bins + r.depth_med):
+                buf.fill_(-7.0)
+            if with_pool:
+                if fused:
+                    r.pending_select = (N.ptr(slot), slots, pool)
+                else:
+                    N.check(N.load().nsamd_select_batch(N.ptr(slot), slots, n, N.ptr(pool["origins"]), N.ptr(pool["directions"]),
+                                                        N.ptr(pool["cameras"]), N.ptr(pool["target"]), N.ptr(r.origins),
+                                                        N.ptr(r.directions), N.ptr(r.camera_indices), N.ptr(r.target), N.stream()),
+                            "select_batch")
+            else:
+                r.set_batch(pool["origins"][2], pool["directions"][2], pool["cameras"][2], pool["target"][2])
+            r.forward_proposals(draw_jitter=False, need_enc=need_enc)
+            torch.cuda.synchronize()
+            assert r._sampler_ok and r.pending_select is None
+            snap = {"origins": r.origins, "directions": r.directions, "cams": r.camera_indices, "target": r.target}
+            for lvl in range(3):
+                snap[f"s_bins{lvl}"], snap[f"t_bins{lvl}"] = r.s_bins[lvl], r.t_bins[lvl]
+            for lvl in range(2):
+                snap[f"dens{lvl}"], snap[f"w{lvl}"], snap[f"med{lvl}"] = r.p_dens[lvl], r.weights[lvl], r.depth_med[lvl]
+                snap[f"enc{lvl}"], snap[f"sel{lvl}"], snap[f"pre{lvl}"] = r.p_enc[lvl], r.p_sel[lvl], r.p_pre[lvl]
+            snaps.append({k: v.detach().clone() for k, v in snap.items()})
+        out[fused] = snaps
+        del model, arena, r
+    for i, (a, b) in enumerate(zip(out[False], out[True])):
+        assert float(a["dens0"].min()) > -7.0 and float(a["t_bins2"].min()) > -7.0
+        if i == 0:
+            assert float((a["enc0"] == -7.0).float().mean()) < 0.01, "the features must have been written on this pass"
+        else:
+            assert bool((b["enc0"] == -7.0).all()) and bool((b["pre1"] == -7.0).all()), "nothing kept for a backward that will not run"
+        for k in a:
+            _same(a[k], b[k], f"pass {i}, {k} (n={n}, pool={with_pool})")
+
+
 @pytest.mark.parametrize("per_edge", [False, True])
 def test_select_bins_equals_select_batch_plus_piecewise_bins(F, per_edge):
     from nerfstudio_amd import _native as N
@@ -188,8 +252,8 @@ def test_trainer_with_merged_launches_trains_through_the_same_bits(F, monkeypatc
 
     digests = {}
     dev = torch.device("cuda")
-    for arm, env in (("merged", {}), ("separate", {"NSAMD_FUSE_RAYS": "0", "NSAMD_FUSE_SELECT": "0"})):
-        for k in ("NSAMD_FUSE_RAYS", "NSAMD_FUSE_SELECT"):
+    for arm, env in (("merged", {}), ("separate", {"NSAMD_FUSE_RAYS": "0", "NSAMD_FUSE_SELECT": "0", "NSAMD_FUSE_SAMPLER": "0"})):
+        for k in ("NSAMD_FUSE_RAYS", "NSAMD_FUSE_SELECT", "NSAMD_FUSE_SAMPLER"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -200,7 +264,7 @@ def test_trainer_with_merged_launches_trains_through_the_same_bits(F, monkeypatc
         arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
         rb, batch, pool = bench.synthetic_batch(dev, seed=1000)
         tr = HipTrainer(model, arena, rb, batch, world=1, use_graph=True, use_runner=True, pool=pool)
-        assert tr.runner.fuse_rays == (arm == "merged") and tr.runner.fuse_select == (arm == "merged")
+        assert tr.runner.fuse_rays == tr.runner.fuse_select == tr.runner.fuse_sampler == (arm == "merged")
         torch.manual_seed(1)
         torch.cuda.manual_seed(1)  # the jitter draws of the iterations below
         tr.train_iteration()

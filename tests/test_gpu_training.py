@@ -7,7 +7,7 @@
    cancelling sums).
 2. PSNR (north_star: within 0.1 dB of the reference; reference acceptance tests/test_nerfacto_integration.py:62-72:
    PSNR > 20 dB on evaluation views). Blender Lego is not in the container: the stand-in is the analytic scene of
-   tests/psnr_scene.py trained for 300 steps by the CPU oracle (fixtures tests/golden/psnr_scene_s*.npz, three seeds, each
+   tests/psnr_scene.py trained for 300 steps by the CPU oracle (fixtures tests/golden/psnr_scene_s*.npz, eight seeds, each
    with a perturbed twin run that measures the chaos of the optimisation) and by the GPU path on the same batches. The
    PSNR assertions come FIRST and are about means over 120 / 20 views; the loss curves are compared through windowed
    means — two correct implementations of a chaotic optimisation agree in statistics, not step by step."""
@@ -112,18 +112,23 @@ def test_training_is_bit_reproducible(F, size):
 
 
 def test_psnr_on_procedural_scene_matches_oracle_training(F, golden):
-    """PSNR stand-in (module docstring). Per seed: 300 steps of 512 fresh rays from 120 views on the GPU path, then
-    eval-mode renders of ALL 140 views (120 training, 20 held out). The optimisation is chaotic
-    (profiles/r02_psnr_chaos_controls.txt: CPU-oracle controls — a 1e-6 relative perturbation of the gradients moves the
-    120-view mean PSNR by up to 0.77 dB, a single view by > 3 dB, and the spread does not shrink by 600 steps), so the
-    statements are about means over views and about the measured envelope of two correct fp32 trainings, not about
-    north_star's 0.1 dB (which needs the converged Blender run). Asserted, in this order:
+    """PSNR stand-in (module docstring). Per seed (EIGHT seeds since round 5): 300 steps of 512 fresh rays from 120 views on the
+    GPU path, then eval-mode renders of ALL 140 views (120 training, 20 held out). The optimisation is chaotic
+    (profiles/r02_psnr_chaos_controls.txt: a 1e-6 relative perturbation of the gradients moves the 120-view mean PSNR of ONE run
+    by up to 0.77 dB, a single view by > 3 dB), so the statements are about means over views and seeds, measured against the
+    spread of two correct fp32 trainings: the CPU oracle's own twin run (initial tables perturbed by 1e-6) differs from its base
+    run by -0.06 +- 0.06 dB (training views, mean +- s.e. over the 8 seeds, s.d. 0.16 dB per seed) and -0.14 +- 0.09 dB (held out).
+    Round 4's three seeds read GPU - oracle = -0.23 dB with all three negative; with 8 seeds and a twin on either side
+    (profiles/r05_psnr_ab.txt, scripts/psnr_ab.py) the same library reads -0.06 +- 0.06 dB (training) / -0.12 +- 0.11 (held out),
+    the same with the fused record emission off (-0.06 +- 0.09) and with round-to-nearest fixed-point conversion (-0.05 +- 0.09):
+    neither the fixed-point scale nor its rounding moves the PSNR; the three-seed figure was a draw from this spread.
+    Asserted, in this order (the reference for a seed is the MEAN of the oracle's base and twin run):
       (a) reference acceptance level (tests/test_nerfacto_integration.py:71): mean PSNR > 20 dB, training and held-out;
-      (b) |mean PSNR_gpu - mean PSNR_oracle| <= 1.0 dB for every seed and <= 0.5 dB for the mean over the three seeds,
-          training and held-out views (measured on MI355X: max 0.38, means +0.15 / -0.03 dB, and after a change of Adam's
-              rounding -0.11 / +0.06 dB — inside the controls' spread);
-      (c) rgb-loss curves: first 10 steps equal to 1e-3 (same start), later 25-step window means within 10 % (the twin
-          oracle run stays within 6 % of the oracle)."""
+      (b) |mean over the 8 seeds of (PSNR_gpu - PSNR_oracle)| <= 0.2 dB on the training views (3 s.e. of the measured spread;
+          north_star's 0.1 dB is ~1.5 s.e. of what a 300-step stand-in on 8 seeds resolves) and <= 0.3 dB on the 20 held-out
+          views (their s.e. is 0.11 dB); every single seed within 0.75 dB (training) / 1.0 dB (held out);
+      (c) rgb-loss curves: first 10 steps equal to 1e-3 (same start), later 25-step window means within 25 % per window and
+          8 % on average (the twin oracle run stays within 6 % of the oracle)."""
     import psnr_scene as S
 
     from nerfstudio_amd.cameras.rays import RayBundle
@@ -153,17 +158,23 @@ def test_psnr_on_procedural_scene_matches_oracle_training(F, golden):
         rows.append((seed, psnr[tr].mean(), g["psnr_views"][tr].mean(), g["psnr_views_twin"][tr].mean(), psnr[ho].mean(),
                      g["psnr_views"][ho].mean(), g["psnr_views_twin"][ho].mean(), np.abs(psnr - g["psnr_views"]).max(),
                      np.abs(g["psnr_views_twin"] - g["psnr_views"]).max()))
+        del model, arena
     print("\nmean PSNR over views [dB]: seed | training: GPU path, CPU oracle, oracle twin | held-out: GPU, oracle, twin | "
           "largest single-view |difference| GPU-oracle, twin-oracle")
     for r in rows:
         print("   %d | %.3f %.3f %.3f | %.3f %.3f %.3f | %.2f %.2f" % r)
     rows = np.array(rows)
-    d_train, d_held = rows[:, 1] - rows[:, 2], rows[:, 4] - rows[:, 5]
-    print(f"   GPU - oracle, mean over seeds: training {d_train.mean():+.3f} dB, held-out {d_held.mean():+.3f} dB "
-          f"(twin - oracle: {np.mean(rows[:, 3] - rows[:, 2]):+.3f} / {np.mean(rows[:, 6] - rows[:, 5]):+.3f})")
+    n_seeds = len(rows)
+    # the reference of a seed: the mean of the oracle's two runs (base and perturbed twin)
+    d_train, d_held = rows[:, 1] - 0.5 * (rows[:, 2] + rows[:, 3]), rows[:, 4] - 0.5 * (rows[:, 5] + rows[:, 6])
+    se = lambda x: x.std(ddof=1) / np.sqrt(len(x))  # noqa: E731
+    print(f"   GPU - oracle (mean of its two runs), mean +- s.e. over {n_seeds} seeds: training {d_train.mean():+.3f} +- {se(d_train):.3f} dB "
+          f"({int((d_train < 0).sum())}/{n_seeds} negative), held-out {d_held.mean():+.3f} +- {se(d_held):.3f} dB; oracle twin - base: "
+          f"{np.mean(rows[:, 3] - rows[:, 2]):+.3f} +- {se(rows[:, 3] - rows[:, 2]):.3f} / {np.mean(rows[:, 6] - rows[:, 5]):+.3f} +- "
+          f"{se(rows[:, 6] - rows[:, 5]):.3f}")
     assert (rows[:, 1] > 20.0).all() and (rows[:, 4] > 20.0).all(), rows                                     # (a)
-    assert abs(d_train.mean()) <= 0.5 and abs(d_held.mean()) <= 0.5, (d_train, d_held)                       # (b)
-    assert np.abs(d_train).max() <= 1.0 and np.abs(d_held).max() <= 1.0, (d_train, d_held)
+    assert abs(d_train.mean()) <= 0.2 and abs(d_held.mean()) <= 0.3, (d_train, d_held)                       # (b)
+    assert np.abs(d_train).max() <= 0.75 and np.abs(d_held).max() <= 1.0, (d_train, d_held)
     for got, ref, twin in curves:                                                                            # (c)
         np.testing.assert_allclose(got[:10], ref[:10], rtol=1e-3)
         w = 25
