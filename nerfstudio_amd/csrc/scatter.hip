@@ -668,6 +668,7 @@ static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e != nullptr ? atoi(e) : dflt;
 }
+static unsigned apply_threads(int slice_log2);
 
 // fine-kernel shape (threads, points per thread, levels per thread); NSAMD_SCATTER_SHAPE = "TPL" digits (experiments; read
 // once). Measured on MI355X (profiles/r02_scatter_variants.txt): 1024 x 1 x 4 is the fastest or within noise of it; two
@@ -842,7 +843,7 @@ int scatter_apply_launch(const nsamd_grid& grid, const ScatterPlan& plan, float*
   if (!overwrite) buf.direct_table = dtable;
   int rc = apply_lds_attribute();
   if (rc) return rc;
-  const unsigned threads = G.slice_log2 > 11 ? 1024u : (G.slice_log2 > 9 ? 512u : 256u);
+  const unsigned threads = apply_threads(G.slice_log2);
   ReduceRider rd{};
   unsigned extra_rows = 0u;
   if (rider != nullptr && rider->blocks > 0) {
@@ -861,7 +862,15 @@ int scatter_apply_launch(const nsamd_grid& grid, const ScatterPlan& plan, float*
   return NSAMD_OK;
 }
 
-bool scatter_apply_takes_rider(const ScatterPlan& plan) { return plan.geom.slice_log2 > 11; }  // 1024-thread workgroups
+// threads of an apply-pass workgroup for tiles of 2^slice_log2 entries. NSAMD_APPLY_THREADS_12 (experiments): the count for
+// 4096-entry tiles (64 KiB of LDS: 512 threads let two workgroups share a compute unit, NSAMD_SCATTER_TILES=2048).
+static unsigned apply_threads(int slice_log2) {
+  static const int t12 = env_int("NSAMD_APPLY_THREADS_12", 1024);
+  if (slice_log2 == 12 && (t12 == 256 || t12 == 512 || t12 == 1024)) return (unsigned)t12;
+  return slice_log2 > 11 ? 1024u : (slice_log2 > 9 ? 512u : 256u);
+}
+
+bool scatter_apply_takes_rider(const ScatterPlan& plan) { return apply_threads(plan.geom.slice_log2) == 1024u; }
 
 ScatterBufs scatter_bufs(float* workspace, const ScatterPlan& p) {
   ScatterBufs b;
@@ -951,7 +960,7 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
     else launch_runs(std::integral_constant<int, 4>{});
     NSAMD_CHECK_LAUNCH();
   }
-  const unsigned threads = G.slice_log2 > 11 ? 1024u : (G.slice_log2 > 9 ? 512u : 256u);
+  const unsigned threads = apply_threads(G.slice_log2);
   dim3 g2(1u << G.log2_bins, (unsigned)grid.num_levels);
   scatter_apply_kernel<false><<<g2, threads, (size_t)16 << G.slice_log2, st>>>(grid, G, buf, dtable, overwrite ? 1 : 0, gate,
                                                                                ReduceRider{});

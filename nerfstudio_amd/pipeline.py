@@ -160,7 +160,9 @@ class TrainEngine:
     def _target(self, batch) -> torch.Tensor:
         """RGB target of the loss; RGBA is blended with the renderer's background as models/nerfacto.py:377-381 does."""
         model = self.pipeline.model
-        image = batch["image"].to(next(model.parameters()).device)
+        image = batch["image"]
+        if not image.is_cuda:
+            image = image.to(next(model.parameters()).device)
         if image.shape[-1] == 4:
             image = model.renderer_rgb.blend_background(image)
         return image.reshape(-1, 3)

@@ -157,11 +157,15 @@ class NerfactoTrainStep:
         # (slot pointer, slots, pool) of a batch selection the caller leaves to `forward_proposals` (one launch with the initial
         # bins, nsamd_select_bins); NSAMD_FUSE_SELECT=0: the caller launches nsamd_select_batch itself (A/B)
         self.pending_select = None
-        # the proposal sampler's whole cascade in one launch (nsamd_proposal_sampler); NSAMD_FUSE_SAMPLER=0: 1 + 2 launches per
-        # level (A/B), same bits
-        self.fuse_sampler = os.environ.get("NSAMD_FUSE_SAMPLER", "1") == "1"
+        # NSAMD_FUSE_SAMPLER=1 (opt-in): the proposal sampler's whole cascade in one launch (nsamd_proposal_sampler), same bits as
+        # the 1 + 2 launches per level. Measured SLOWER on MI355X (profiles/r05_s2_ab.txt: 139 us against 116 us for the five
+        # launches, +35 us per iteration): with one wave per ray the launch lasts as long as ONE wave's chain — six density
+        # passes of 40 gathers each behind two 15 us resampling chains — at four waves per SIMD, where the per-level density
+        # launches run sixteen waves per SIMD at the vector unit's issue limit (919 VALU instructions per 64 points = 28 us).
+        self.fuse_sampler = os.environ.get("NSAMD_FUSE_SAMPLER", "0") == "1"
         self._sampler_ok = True
         self._slot0 = None  # a device zero: `set_batch` as a one-slot batch selection
+        self._outputs = None
         self.fuse_select = os.environ.get("NSAMD_FUSE_SELECT", "1") == "1"
         self._wb_folded = set()       # proposal levels whose weights backward `losses` has already run
         self.f_saved = e(int(N.load().nsamd_field_mlp_saved_floats(mm))) if self.save_acts else None
@@ -858,11 +862,14 @@ class NerfactoTrainStep:
         return out
 
     def outputs(self) -> Dict[str, Tensor]:
-        """The tensors NerfactoModel.get_outputs returns, as views of the static buffers."""
-        out = {"rgb": self.rgb, "accumulation": self.acc[:, None], "expected_depth": self.depth_exp[:, None],
-               "weights_list": [w[..., None] for w in self.weights]}
-        if self.compute_depths:
-            out["depth"] = self.depth_med[-1][:, None]
-            for i in range(self.n_prop):
-                out[f"prop_depth_{i}"] = self.depth_med[i][:, None]
-        return out
+        """The tensors NerfactoModel.get_outputs returns, as views of the static buffers (built once: the buffers never move, and a
+        trainer asks for them every iteration — a dozen view constructions were a measurable share of the host's work per step)."""
+        if self._outputs is None:
+            out = {"rgb": self.rgb, "accumulation": self.acc[:, None], "expected_depth": self.depth_exp[:, None],
+                   "weights_list": [w[..., None] for w in self.weights]}
+            if self.compute_depths:
+                out["depth"] = self.depth_med[-1][:, None]
+                for i in range(self.n_prop):
+                    out[f"prop_depth_{i}"] = self.depth_med[i][:, None]
+            self._outputs = out
+        return dict(self._outputs)

@@ -85,6 +85,9 @@ class HipTrainer:
         # The host runs ahead of the GPU, so the pinned source of an async copy must not be rewritten before the copy
         # has executed: a ring of slots, each guarded by the event recorded after its last copy.
         self.hyper_ring = [torch.zeros(_HYPER_FLOATS).pin_memory() if self.on_gpu else torch.zeros(_HYPER_FLOATS) for _ in range(64)]
+        # (numpy views of the pinned slots: a scalar store into a tensor costs ~5 us of dispatch, eight of them per iteration
+        #  were a tenth of the host's share of a step through the pipeline seam)
+        self.hyper_ring_np = [h.numpy() for h in self.hyper_ring]
         self.hyper_events = [None] * 64
         self.hyper_slot = 0
         if lr_source is None:
@@ -188,16 +191,16 @@ class HipTrainer:
         self.hyper_slot = (slot + 1) % len(self.hyper_ring)
         if self.hyper_events[slot] is not None:
             self.hyper_events[slot].synchronize()  # the copy that last read this slot (64 pushes ago) is done
-        h = self.hyper_ring[slot]
+        h, hn = self.hyper_ring[slot], self.hyper_ring_np[slot]
         # iteration i runs with lr(i); a pending (pipelined) main-field update belongs to the previous iteration
         it_fields = self.step - 1 if self._have_pending else self.step
         for group, off in _HYPER.items():
             if group not in a.groups:
                 continue
             lr = self.lr_source(group, max(it_fields, 0) if group == "fields" else self.step)
-            h[off], h[off + 1] = F.adam_hyper(a.step_counts[group] + 1, lr, a.betas)
-        h[_HYPER_ANNEAL] = m.proposal_sampler._anneal
-        h[_HYPER_SLOT] = float(self.step % self.slots)
+            hn[off], hn[off + 1] = F.adam_hyper(a.step_counts[group] + 1, lr, a.betas)
+        hn[_HYPER_ANNEAL] = m.proposal_sampler._anneal
+        hn[_HYPER_SLOT] = float(self.step % self.slots)
         self.hyper.copy_(h, non_blocking=True)
         if self.on_gpu:
             ev = torch.cuda.Event()

@@ -31,6 +31,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--windows", type=int, default=7)
+ap.add_argument("--profile", action="store_true", help="cProfile of the seam arm's host side (top entries to stderr)")
 args = ap.parse_args()
 
 from nerfstudio_amd import _native, functional as F  # noqa: E402
@@ -58,6 +59,7 @@ def windows(run_step, finish, first_step):
     """`--windows` timed windows of `--steps` iterations each (consecutive iterations: a trainer's step counter only moves
     forward), device sync on both sides; -> list of ms per step."""
     out, step = [], first_step
+    issue = []
     for _ in range(args.windows):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -65,9 +67,14 @@ def windows(run_step, finish, first_step):
             run_step(step)
             step += 1
         finish()
+        issue.append((time.perf_counter() - t0) / args.steps * 1e3)  # host time to ISSUE the window (no device sync yet)
         torch.cuda.synchronize()
         out.append((time.perf_counter() - t0) / args.steps * 1e3)
+    HOST_ISSUE.append(issue)
     return out
+
+
+HOST_ISSUE = []
 
 
 def opt_config(groups):
@@ -128,14 +135,29 @@ for s in range(args.warmup):
     step_seam(s)
 eng = pipeline._engine
 assert eng.reason is None, eng.reason
+if args.profile:
+    import cProfile
+    import pstats
+
+    prof = cProfile.Profile()
+    prof.enable()
 results["seam"] = windows(step_seam, eng.flush, args.warmup)
+if args.profile:
+    prof.disable()
+    pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
 assert eng.trainer.graphs is not None, "the seam did not reach the captured schedule"
 med = {k: float(np.median(v)) for k, v in results.items()}
+# the arms run the SAME iterations window by window (same init, same batches): the paired ratio per window is the comparison;
+# the windows themselves differ by +-15 % with the phase of the proposal-update schedule and the gradient sparsity
+paired = [a / b for a, b in zip(results["seam"], results["direct_pool"])]
+issue = {k: [round(x, 4) for x in v] for k, v in zip(results.keys(), HOST_ISSUE)}
 print(json.dumps({
     "metric": "ms per training iteration, 4096 rays (same box, same batches)", "steps": args.steps, "windows": args.windows,
     "direct_pool_ms": round(med["direct_pool"], 4), "direct_set_batch_ms": round(med["direct_set_batch"], 4),
-    "seam_ms": round(med["seam"], 4), "seam_over_direct_pool": round(med["seam"] / med["direct_pool"], 4),
-    "seam_over_direct_set_batch": round(med["seam"] / med["direct_set_batch"], 4),
+    "seam_ms": round(med["seam"], 4), "seam_over_direct_pool": round(float(np.median(paired)), 4),
+    "seam_over_direct_pool_per_window": [round(x, 4) for x in paired],
+    "seam_over_direct_set_batch": round(float(np.median([a / b for a, b in zip(results["seam"], results["direct_set_batch"])])), 4),
+    "host_issue_ms_per_step": issue,
     "rays_per_s": {k: round(n / (v * 1e-3), 1) for k, v in med.items()},
     "windows_ms": {k: [round(x, 4) for x in v] for k, v in results.items()},
     "note": "seam = tests/trainer_restatement.train_iteration (the reference's Trainer.train_iteration restated) over "

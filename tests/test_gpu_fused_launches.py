@@ -255,6 +255,8 @@ def test_trainer_with_merged_launches_trains_through_the_same_bits(F, monkeypatc
     for arm, env in (("merged", {}), ("separate", {"NSAMD_FUSE_RAYS": "0", "NSAMD_FUSE_SELECT": "0", "NSAMD_FUSE_SAMPLER": "0"})):
         for k in ("NSAMD_FUSE_RAYS", "NSAMD_FUSE_SELECT", "NSAMD_FUSE_SAMPLER"):
             monkeypatch.delenv(k, raising=False)
+        if arm == "merged":
+            monkeypatch.setenv("NSAMD_FUSE_SAMPLER", "1")  # (off by default: measured slower — it must still train the same bits)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         F._SCATTER_WS.clear()
