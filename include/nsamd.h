@@ -543,6 +543,13 @@ int nsamd_render_losses_train(const float* rgb, const float* density, const floa
                               uint8_t* const* ray_masks, float interlevel_loss_mult, float distortion_loss_mult,
                               float* loss_values, nsamd_stream_t stream);
 
+/* loss_values of nsamd_render_losses_train alone, from the per-ray terms separate launches left behind (nsamd_render_train's
+ * sq_err, nsamd_proposal_losses' per-ray values): one small launch instead of a dozen host-issued reductions for a trainer that
+ * logs the loss dictionary every iteration (engine/trainer.py:487-531). Layout and scaling as there. */
+int nsamd_train_loss_values(const float* sq_err, const float* distortion_per_ray, int32_t levels,
+                            const float* const* interlevel_per_ray, int64_t num_rays, int32_t S, float interlevel_loss_mult,
+                            float distortion_loss_mult, float* loss_values, nsamd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Packed-sample path of instant-ngp (BASELINE configs[3]): what the reference gets from nerfacc 0.5.2
  * (OccGridEstimator.sampling, pack_info, render_weight_from_density, render_visibility_from_density,

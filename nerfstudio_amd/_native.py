@@ -119,6 +119,7 @@ _SIGNATURES = {
     "nsamd_proposal_losses": [vp, vp, i32, i32, vp, vp, vp, i64, f32, f32, vp, vp, vp, vp, vp],
     "nsamd_render_losses_train": [vp, vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                   i32, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp],
+    "nsamd_train_loss_values": [vp, vp, i32, vp, i64, i32, f32, f32, vp, vp],
     "nsamd_occgrid_march_count": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp],
     "nsamd_occgrid_march_write": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp, vp, vp, vp],
     "nsamd_occgrid_march_count_stash": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp, i32, vp],

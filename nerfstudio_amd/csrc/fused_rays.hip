@@ -232,3 +232,27 @@ extern "C" int nsamd_render_losses_train(
   }
   return NSAMD_OK;
 }
+
+// The iteration's loss values and training metrics alone (the finishing pass of nsamd_render_losses_train without a launch in
+// front of it): for a training step that runs the compositing, the losses and the compositing backward as separate launches and
+// whose caller logs the losses every iteration (pipeline.TrainEngine under the reference's Trainer.train_iteration).
+extern "C" int nsamd_train_loss_values(const float* sq_err, const float* distortion_per_ray, int32_t levels,
+                                       const float* const* interlevel_per_ray, int64_t num_rays, int32_t S,
+                                       float interlevel_loss_mult, float distortion_loss_mult, float* loss_values,
+                                       nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays > 0 && S > 0 && levels >= 0 && levels <= kMaxFusedLevels);
+  NSAMD_REQUIRE(sq_err && distortion_per_ray && loss_values && (levels == 0 || interlevel_per_ray));
+  LossSumArgs L{};
+  L.sq_err = sq_err, L.dist_per_ray = distortion_per_ray, L.levels = levels, L.out = loss_values;
+  for (int i = 0; i < levels; ++i) {
+    NSAMD_REQUIRE(interlevel_per_ray[i] != nullptr);
+    L.inter_per_ray[i] = interlevel_per_ray[i];
+  }
+  L.rgb_scale = 1.0f / (3.0f * (float)num_rays);
+  L.dist_scale = distortion_loss_mult / (float)num_rays;
+  L.inter_scale = interlevel_loss_mult / ((float)num_rays * (float)S);
+  L.mean_scale = 1.0f / (float)num_rays;
+  train_finish_kernel<<<1, 256, 0, (hipStream_t)stream>>>(nullptr, num_rays, nullptr, 0, 0, L);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}

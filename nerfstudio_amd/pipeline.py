@@ -257,6 +257,8 @@ class TrainEngine:
         self.trainer = HipTrainer(model, self.arena, rb, {"image": self._target(batch)}, world=int(self.pipeline.world_size),
                                   use_graph=True, use_runner=True, pool=None, lr_source=self._lr, drive_callbacks=False,
                                   runner=runner)
+        if hasattr(self.trainer.runner, "want_loss_vals"):
+            self.trainer.runner.want_loss_vals = True  # the reference's trainer reads the loss dictionary every iteration
         if self.on_build is not None:
             self.on_build(self.trainer)
 

@@ -147,13 +147,18 @@ class NerfactoTrainStep:
         # MSE, the proposal losses, the compositing backward — three dependent launches before — and, on the steps that update
         # the proposal networks, each proposal level's weights backward); NSAMD_FUSE_RAYS=0: the separate launches (A/B), same
         # bits. NSAMD_FOLD_WEIGHTS_BWD=0 keeps the levels' weights backward at the head of their own chains.
-        self.fuse_rays = os.environ.get("NSAMD_FUSE_RAYS", "1") == "1"
+        # Measured on MI355X (profiles/r05_s3_ab.txt, four alternating repeats on one box): the ONE launch is ~19 us per
+        # iteration SLOWER than the three to five it replaces (0.711 against 0.692 ms with everything else equal) — one wave per
+        # (ray, job) runs the stages one after the other, and a launch of latency chains lasts as long as its longest chain — so
+        # it is an opt-in (NSAMD_FUSE_RAYS=1), kept as the bit-identical reference of the launch-merging experiment.
+        self.fuse_rays = os.environ.get("NSAMD_FUSE_RAYS", "0") == "1"
         self.fold_weights_bwd = os.environ.get("NSAMD_FOLD_WEIGHTS_BWD", "1") == "1"
         self._rays_bwd_fresh = False  # `losses` has already run the compositing backward for this forward
         # the iteration's loss values and training metrics, written by the losses launch's finishing pass (nsamd.h):
         # rgb_loss, interlevel_loss, distortion_loss, psnr, distortion, sum of the three losses
         self.loss_vals = torch.zeros(8, **f32)
         self._loss_vals_fresh = False
+        self.want_loss_vals = False  # the separate-launch path: also launch nsamd_train_loss_values (set by pipeline.TrainEngine)
         # (slot pointer, slots, pool) of a batch selection the caller leaves to `forward_proposals` (one launch with the initial
         # bins, nsamd_select_bins); NSAMD_FUSE_SELECT=0: the caller launches nsamd_select_batch itself (A/B)
         self.pending_select = None
@@ -657,6 +662,13 @@ class NerfactoTrainStep:
                                      float(cfg.distortion_loss_mult) / n, self._pl_per_ray,
                                      self._pl_dw if updated else None, N.ptr(self.dist_per_ray), N.ptr(self.dw_dist), st),
            "proposal_losses")
+        if self.want_loss_vals:
+            # a caller that reads the loss dictionary every iteration (pipeline.TrainEngine): the values and the training metrics
+            # as five floats from one small launch instead of a dozen reductions issued by the host
+            ck(lib.nsamd_train_loss_values(N.ptr(self.sq_err), N.ptr(self.dist_per_ray), self.n_prop, self._pl_per_ray, n, S,
+                                           float(cfg.interlevel_loss_mult), float(cfg.distortion_loss_mult),
+                                           N.ptr(self.loss_vals), st), "train_loss_values")
+            self._loss_vals_fresh = True
 
     @profiler.time_function
     def backward_main(self, field: bool = True) -> None:

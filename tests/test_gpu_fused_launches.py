@@ -255,8 +255,9 @@ def test_trainer_with_merged_launches_trains_through_the_same_bits(F, monkeypatc
     for arm, env in (("merged", {}), ("separate", {"NSAMD_FUSE_RAYS": "0", "NSAMD_FUSE_SELECT": "0", "NSAMD_FUSE_SAMPLER": "0"})):
         for k in ("NSAMD_FUSE_RAYS", "NSAMD_FUSE_SELECT", "NSAMD_FUSE_SAMPLER"):
             monkeypatch.delenv(k, raising=False)
-        if arm == "merged":
-            monkeypatch.setenv("NSAMD_FUSE_SAMPLER", "1")  # (off by default: measured slower — it must still train the same bits)
+        if arm == "merged":  # (both off by default: measured slower — they must still train the same bits)
+            monkeypatch.setenv("NSAMD_FUSE_SAMPLER", "1")
+            monkeypatch.setenv("NSAMD_FUSE_RAYS", "1")
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         F._SCATTER_WS.clear()
@@ -324,3 +325,40 @@ def test_weight_gradient_reduce_riding_the_apply_pass_equals_its_own_launch(F):
         out[mode] = arena.grad[a:b].clone()
     assert float(out["rider"].abs().max()) > 0 and not torch.isnan(out["rider"]).any()
     _same(out["rider"], out["phases"], "fields slice of the gradient arena")
+
+
+def test_loss_values_of_the_finishing_pass_and_of_their_own_launch(F):
+    """The five floats a trainer reads every iteration (rgb / interlevel / distortion loss, psnr, distortion metric): written by
+    nsamd_render_losses_train's finishing pass and by nsamd_train_loss_values behind the separate launches — equal to each other
+    bit for bit (same per-ray terms, same fixed summation order) and to the float64 sums of the per-ray terms to 1e-6."""
+    from test_gpu_kernels import small_cfg
+
+    cfg = small_cfg(12, 10, 6)
+    n = 1000
+    o, d, cam, tgt = orc.synthetic_rays(n, cfg.num_images, seed=9)
+    jit = torch.from_numpy(np.random.RandomState(2).uniform(0, 1, (3, n)).astype(np.float32)).cuda()
+    vals = {}
+    for fuse in (False, True):
+        F._SCATTER_WS.clear()
+        model, arena, r = _runner(cfg, n, 14, "last_sample", fuse)
+        r.want_loss_vals = True
+        r.set_batch(o.cuda(), d.cuda(), cam.cuda(), tgt.cuda())
+        r.jitter.copy_(jit)
+        arena.zero_grad(skip=r.written_params())
+        r.forward_and_losses(True, draw_jitter=False)
+        torch.cuda.synchronize()
+        assert r._loss_vals_fresh
+        ld = r.loss_dict()
+        assert ld["rgb_loss"].data_ptr() == r.loss_vals.data_ptr()
+        mc, S = model.config, r.counts[-1]
+        ref = {"rgb_loss": float(r.sq_err.double().sum()) / (3 * n),
+               "interlevel_loss": mc.interlevel_loss_mult * float(sum(p.double().sum() for p in r.inter_per_ray)) / (n * S),
+               "distortion_loss": mc.distortion_loss_mult * float(r.dist_per_ray.double().sum()) / n}
+        for k, v in ref.items():
+            assert abs(float(ld[k]) - v) <= 1e-6 * max(abs(v), 1e-6) + 1e-9, (k, float(ld[k]), v)
+        assert abs(float(r.loss_vals[3]) + 10.0 * np.log10(ref["rgb_loss"])) <= 1e-4
+        assert abs(float(r.loss_vals[4]) - float(r.dist_per_ray.double().sum()) / n) <= 1e-6 * float(r.loss_vals[4]) + 1e-9
+        assert abs(float(r.loss_vals[5]) - sum(ref.values())) <= 2e-6 * sum(ref.values())
+        vals[fuse] = r.loss_vals.clone()
+        del model, arena, r
+    _same(vals[False], vals[True], "loss values: own launch vs the merged launch's finishing pass")
