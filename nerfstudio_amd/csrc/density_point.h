@@ -29,6 +29,24 @@ __device__ __forceinline__ void density_point(float x, float y, float z, int64_t
     for (int k = 0; k < 8; ++k) v[l][k] = tl[corner_index(c, k, mask)];
   }
   float feat[IN];
+#if !NSAMD_VALU_DIET
+#pragma unroll
+  for (int l = 0; l < LEVELS; ++l) {
+    const float wx = w[l][0], wy = w[l][1], wz = w[l][2];
+    const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      auto g = [&](int k) { return f == 0 ? v[l][k].x : v[l][k].y; };
+      const float yc_zc = g(7) * wx + g(6) * ux;
+      const float yf_zc = g(5) * wx + g(4) * ux;
+      const float yf_zf = g(1) * wx + g(0) * ux;
+      const float yc_zf = g(3) * wx + g(2) * ux;
+      const float zc = yc_zc * wy + yf_zc * uy;
+      const float zf = yc_zf * wy + yf_zf * uy;
+      feat[2 * l + f] = zc * wz + zf * uz;
+    }
+  }
+#else
   typedef float v2f __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int l = 0; l < LEVELS; ++l) {
@@ -48,6 +66,7 @@ __device__ __forceinline__ void density_point(float x, float y, float z, int64_t
     feat[2 * l] = r.x;
     feat[2 * l + 1] = r.y;
   }
+#endif
   if (enc_out != nullptr) {
 #pragma unroll
     for (int k = 0; k < IN; ++k) enc_out[(int64_t)k * M + p] = feat[k];

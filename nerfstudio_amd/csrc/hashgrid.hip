@@ -149,6 +149,24 @@ __global__ __launch_bounds__(kHashBlock) void hash_encode_fwd_v2_kernel(nsamd_po
   }
   const float wx = c.w[0], wy = c.w[1], wz = c.w[2];
   const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+#if !NSAMD_VALU_DIET
+  struct { float x, y; } r;
+  {
+    float rr[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      auto g = [&](const float2& a) { return f == 0 ? a.x : a.y; };
+      const float yc_zc = g(v7) * wx + g(v6) * ux;
+      const float yf_zc = g(v5) * wx + g(v4) * ux;
+      const float yf_zf = g(v1) * wx + g(v0) * ux;
+      const float yc_zf = g(v3) * wx + g(v2) * ux;
+      const float zc = yc_zc * wy + yf_zc * uy;
+      const float zf = yc_zf * wy + yf_zf * uy;
+      rr[f] = zc * wz + zf * uz;
+    }
+    r.x = rr[0], r.y = rr[1];
+  }
+#else
   // both features of a corner at once (v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations, half the issue slots)
   typedef float v2f __attribute__((ext_vector_type(2)));
   auto g = [](const float2& a) { return v2f{a.x, a.y}; };
@@ -159,6 +177,7 @@ __global__ __launch_bounds__(kHashBlock) void hash_encode_fwd_v2_kernel(nsamd_po
   const v2f zc = yc_zc * wy + yf_zc * uy;
   const v2f zf = yc_zf * wy + yf_zf * uy;
   const v2f r = zc * wz + zf * uz;
+#endif
   float* o = enc + p * stride_p + (int64_t)(2 * level) * stride_k;
   o[0] = r.x;
   o[stride_k] = r.y;

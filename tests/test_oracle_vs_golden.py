@@ -364,13 +364,14 @@ def test_c_oracle_hash_and_cdf(golden):
 
 
 def test_psnr_fixture_is_reproducible_from_the_scene_definition(golden):
-    """tests/golden/psnr_scene_s*.npz (oracle training runs on the procedural scene, three seeds): the stored PSNRs are
+    """tests/golden/psnr_scene_s*.npz (oracle training runs on the procedural scene, eight seeds): the stored PSNRs are
     those of the stored images against the ground truth recomputed from tests/psnr_scene.py, the batch streams are
     deterministic and differ between seeds, and the oracle itself reaches the reference's acceptance level (PSNR > 20 dB,
     tests/test_nerfacto_integration.py:71) on training AND held-out views."""
     import numpy as np
     import psnr_scene as S
 
+    twin_tr, twin_ho = [], []
     for seed in S.SEEDS:
         g = golden(f"psnr_scene_s{seed}")
         assert g["losses"].shape == (S.STEPS, 3) and g["losses"][-1].sum() < 0.02 * g["losses"][0].sum()
@@ -382,10 +383,14 @@ def test_psnr_fixture_is_reproducible_from_the_scene_definition(golden):
         tr, ho = slice(0, S.N_TRAIN), slice(S.N_TRAIN, None)
         assert g["psnr_views"].shape == (S.N_TRAIN + S.N_HELD_OUT,)
         assert g["psnr_views"][tr].mean() > 30 and g["psnr_views"][ho].mean() > 20  # the reference's acceptance level
-        # the twin run (1e-6 perturbation of the initial tables): means over views agree to 0.1 dB, single views do not
-        assert abs(g["psnr_views"][tr].mean() - g["psnr_views_twin"][tr].mean()) < 0.1
-        assert abs(g["psnr_views"][ho].mean() - g["psnr_views_twin"][ho].mean()) < 0.1
+        # the twin run (1e-6 perturbation of the initial tables) — the spread of two correct fp32 trainings of this problem, what
+        # an implementation difference is judged by: over the eight seeds the means over views differ by up to 0.30 dB (training;
+        # s.d. 0.16 dB) and 0.65 dB (held out; s.d. 0.25 dB) per seed, single views by dB
+        twin_tr.append(g["psnr_views_twin"][tr].mean() - g["psnr_views"][tr].mean())
+        twin_ho.append(g["psnr_views_twin"][ho].mean() - g["psnr_views"][ho].mean())
+        assert abs(twin_tr[-1]) < 0.4 and abs(twin_ho[-1]) < 0.8, (seed, twin_tr[-1], twin_ho[-1])
         assert np.abs(g["psnr_views"] - g["psnr_views_twin"]).max() > 0.5
+    assert abs(np.mean(twin_tr)) < 0.15 and abs(np.mean(twin_ho)) < 0.25, (twin_tr, twin_ho)  # measured -0.06 / -0.14 dB
     b1, b2, b3 = S.batches(seed=9, steps=2), S.batches(seed=9, steps=2), S.batches(seed=10, steps=2)
     for x, y, z in zip(b1, b2, b3):
         for u, v in zip(x, y):
