@@ -79,17 +79,12 @@ constexpr uint32_t kPrimeY = 2654435761u;  // encodings.py:410
 constexpr uint32_t kPrimeZ = 805459861u;   // encodings.py:410
 
 // ray of point p for S samples per ray: a 32-bit division whenever both fit (always, below 4 G points) — a 64-bit divide is
-// ~60 vector instructions, a fifth of what the hash forward issues per point and 7 % of the VALU-bound proposal field's 919
-// (NSAMD_VALU_DIET=0 at build time: the 64-bit division and the scalar feature blends of round 4, for same-box A/B)
-#ifndef NSAMD_VALU_DIET
-#define NSAMD_VALU_DIET 1
-#endif
+// ~60 vector instructions. (Round 5 measured what that buys: nothing — 919 -> 860 vector instructions per 64 points of the
+// proposal field, and 718 with the two features of a corner blended as one packed operation, leave its launch at 40.5 us and
+// the hash forward at 89 us on the same box: both are bound by their L1 line lookups, not by instruction issue. The division
+// stays, the packed blends — three more registers, 27 more for 8-level grids — went again; profiles/r05_s4_ab_valu_diet.txt.)
 NSAMD_HD int64_t point_ray(int64_t p, int64_t S) {
-#if NSAMD_VALU_DIET
   return (((uint64_t)p | (uint64_t)S) >> 32) ? p / S : (int64_t)((uint32_t)p / (uint32_t)S);
-#else
-  return p / S;
-#endif
 }
 
 // ---- position of sample p (Frustums.get_positions, cameras/rays.py:50-59) -------------------------------------

@@ -29,7 +29,6 @@ __device__ __forceinline__ void density_point(float x, float y, float z, int64_t
     for (int k = 0; k < 8; ++k) v[l][k] = tl[corner_index(c, k, mask)];
   }
   float feat[IN];
-#if !NSAMD_VALU_DIET
 #pragma unroll
   for (int l = 0; l < LEVELS; ++l) {
     const float wx = w[l][0], wy = w[l][1], wz = w[l][2];
@@ -46,27 +45,6 @@ __device__ __forceinline__ void density_point(float x, float y, float z, int64_t
       feat[2 * l + f] = zc * wz + zf * uz;
     }
   }
-#else
-  typedef float v2f __attribute__((ext_vector_type(2)));
-#pragma unroll
-  for (int l = 0; l < LEVELS; ++l) {
-    const float wx = w[l][0], wy = w[l][1], wz = w[l][2];
-    const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
-    // both features of a corner at once: v_pk_mul_f32 / v_pk_add_f32 are the same IEEE operations on the two halves of a
-    // register pair, at half the issue slots — this kernel is bound by its vector instructions (919 -> 718 per 64 points with
-    // the 32-bit ray division). Blend order x, y, z exactly as encodings.py:446-456.
-    auto g = [&](int k) { return v2f{v[l][k].x, v[l][k].y}; };
-    const v2f yc_zc = g(7) * wx + g(6) * ux;
-    const v2f yf_zc = g(5) * wx + g(4) * ux;
-    const v2f yf_zf = g(1) * wx + g(0) * ux;
-    const v2f yc_zf = g(3) * wx + g(2) * ux;
-    const v2f zc = yc_zc * wy + yf_zc * uy;
-    const v2f zf = yc_zf * wy + yf_zf * uy;
-    const v2f r = zc * wz + zf * uz;
-    feat[2 * l] = r.x;
-    feat[2 * l + 1] = r.y;
-  }
-#endif
   if (enc_out != nullptr) {
 #pragma unroll
     for (int k = 0; k < IN; ++k) enc_out[(int64_t)k * M + p] = feat[k];

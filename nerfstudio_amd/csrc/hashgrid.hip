@@ -149,38 +149,21 @@ __global__ __launch_bounds__(kHashBlock) void hash_encode_fwd_v2_kernel(nsamd_po
   }
   const float wx = c.w[0], wy = c.w[1], wz = c.w[2];
   const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
-#if !NSAMD_VALU_DIET
-  struct { float x, y; } r;
-  {
-    float rr[2];
+  float r[2];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      auto g = [&](const float2& a) { return f == 0 ? a.x : a.y; };
-      const float yc_zc = g(v7) * wx + g(v6) * ux;
-      const float yf_zc = g(v5) * wx + g(v4) * ux;
-      const float yf_zf = g(v1) * wx + g(v0) * ux;
-      const float yc_zf = g(v3) * wx + g(v2) * ux;
-      const float zc = yc_zc * wy + yf_zc * uy;
-      const float zf = yc_zf * wy + yf_zf * uy;
-      rr[f] = zc * wz + zf * uz;
-    }
-    r.x = rr[0], r.y = rr[1];
+  for (int f = 0; f < 2; ++f) {
+    auto g = [&](const float2& a) { return f == 0 ? a.x : a.y; };
+    const float yc_zc = g(v7) * wx + g(v6) * ux;  // blend order x, y, z exactly as encodings.py:446-456
+    const float yf_zc = g(v5) * wx + g(v4) * ux;
+    const float yf_zf = g(v1) * wx + g(v0) * ux;
+    const float yc_zf = g(v3) * wx + g(v2) * ux;
+    const float zc = yc_zc * wy + yf_zc * uy;
+    const float zf = yc_zf * wy + yf_zf * uy;
+    r[f] = zc * wz + zf * uz;
   }
-#else
-  // both features of a corner at once (v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations, half the issue slots)
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  auto g = [](const float2& a) { return v2f{a.x, a.y}; };
-  const v2f yc_zc = g(v7) * wx + g(v6) * ux;  // blend order x, y, z exactly as encodings.py:446-456
-  const v2f yf_zc = g(v5) * wx + g(v4) * ux;
-  const v2f yf_zf = g(v1) * wx + g(v0) * ux;
-  const v2f yc_zf = g(v3) * wx + g(v2) * ux;
-  const v2f zc = yc_zc * wy + yf_zc * uy;
-  const v2f zf = yc_zf * wy + yf_zf * uy;
-  const v2f r = zc * wz + zf * uz;
-#endif
   float* o = enc + p * stride_p + (int64_t)(2 * level) * stride_k;
-  o[0] = r.x;
-  o[stride_k] = r.y;
+  o[0] = r[0];
+  o[stride_k] = r[1];
   // (behind the gathers: vector memory operations retire in order and stores count — in front of them the selector store
   //  would have to complete before the first gathered value may be used)
   if (level == 0 && selector != nullptr) selector[p] = sel;
