@@ -18,6 +18,13 @@
 // What a later body reads of an earlier one's results (the fine weights, the MSE gradient, the distortion gradient, the
 // interlevel gradient) goes through global memory exactly as between the launches — written and read by the SAME wave, a fence
 // apart — so every output is bit-identical to the separate launches (tests/test_gpu_kernels.py).
+// The bodies below read back what the SAME wave stored a moment ago (the MSE gradient of its ray, its weight row): per-ray
+// scalars must then come through the vector cache like the stores did — the scalar cache is not coherent with a wave's own
+// vector stores inside one launch (a neighbouring ray's earlier read can have left the 64-byte line there). So this translation
+// unit keeps the wave index a vector value; the stand-alone launches, which only read what EARLIER launches wrote, use the
+// scalar form (wave.h).
+#undef NSAMD_SCALAR_RAY
+#define NSAMD_SCALAR_RAY 0
 #include "ray_bodies.h"
 
 namespace nsamd {
@@ -66,7 +73,7 @@ struct FusedRayArgs {
 __global__ __launch_bounds__(kRenderThreads) void render_losses_train_kernel(FusedRayArgs a, int64_t num_rays) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float blk_min[kRaysPerBlock], blk_max[kRaysPerBlock];
-  const int wave = threadIdx.x >> 6;
+  const int wave = wave_index();
   float* row = lds + (size_t)wave * a.row_floats;
   const int job = blockIdx.y;
   if (job == 0) {

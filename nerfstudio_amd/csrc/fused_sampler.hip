@@ -77,14 +77,16 @@ void proposal_sampler_kernel(SamplerArgs a, int64_t num_rays) {
   //  derived from the ray — its origin, direction, row pointers — lives in scalar registers)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave = wave_index();
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wave;
   if (ray >= num_rays) return;  // wave-uniform; no workgroup barrier below
   float* row = lds + (size_t)wave * a.row_floats;
   // ---- [batch selection] + initial bins (sampler.hip: select_bins_kernel) ----
+  int32_t sel_slot = 0;
   if (a.slot_dev != nullptr) {
     int32_t slot = (int32_t)a.slot_dev[0];
     slot = slot < 0 ? 0 : (slot >= a.slots ? a.slots - 1 : slot);
+    sel_slot = slot;
     if (lane < 3) {
       const int64_t dst = 3 * ray + lane, src = (int64_t)slot * 3 * num_rays + dst;
       a.origins[dst] = a.origins_pool[src];
@@ -102,8 +104,11 @@ void proposal_sampler_kernel(SamplerArgs a, int64_t num_rays) {
     const int S = Lv.S;
     const int64_t M = num_rays * S;
     // ---- density of the level's samples: one point per lane and pass; origin and direction are the wave's own ray ----
-    const float* o = a.origins + 3 * ray;
-    const float* d = a.directions + 3 * ray;
+    // (the ray as this launch's INPUT holds it — the pool slot when the launch selects the batch itself: the copy in
+    //  `origins` was stored by this wave's vector lanes a moment ago, and a scalar load of it could hit a line that a
+    //  neighbouring ray's wave left in the scalar cache before the store)
+    const float* o = (a.slot_dev != nullptr ? a.origins_pool + (int64_t)sel_slot * 3 * num_rays : a.origins) + 3 * ray;
+    const float* d = (a.slot_dev != nullptr ? a.directions_pool + (int64_t)sel_slot * 3 * num_rays : a.directions) + 3 * ray;
     const float o0 = o[0], o1 = o[1], o2 = o[2], d0 = d[0], d1 = d[1], d2 = d[2];
     const float* tb = Lv.t_bins + ray * (S + 1);
 #pragma unroll 1

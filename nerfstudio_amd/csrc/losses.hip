@@ -14,7 +14,7 @@ __global__ __launch_bounds__(kLossThreads) void interlevel_kernel(
     const float* __restrict__ wp_in, int Sp, int64_t num_rays, float grad_scale, float* __restrict__ per_ray,
     float* __restrict__ dwp) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  interlevel_body(lds + (size_t)(threadIdx.x >> 6) * interlevel_row_floats(Sf, Sp), c_in, w_in, Sf, cp_in, wp_in, Sp, num_rays,
+  interlevel_body(lds + (size_t)wave_index() * interlevel_row_floats(Sf, Sp), c_in, w_in, Sf, cp_in, wp_in, Sp, num_rays,
                   grad_scale, per_ray, dwp);
 }
 
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kLossThreads) void distortion_kernel(const float* _
                                                                   float* __restrict__ per_ray,
                                                                   float* __restrict__ dw) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  distortion_body(lds + (size_t)(threadIdx.x >> 6) * 2 * S, s_bins, weights, S, num_rays, grad_scale, per_ray, dw);
+  distortion_body(lds + (size_t)wave_index() * 2 * S, s_bins, weights, S, num_rays, grad_scale, per_ray, dw);
 }
 
 // All proposal losses of one training step in one launch: blockIdx.y < levels = interlevel loss of that proposal level,
@@ -45,10 +45,10 @@ __global__ __launch_bounds__(kLossThreads) void proposal_losses_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int job = blockIdx.y;
   if (job < a.levels) {
-    interlevel_body(lds + (size_t)(threadIdx.x >> 6) * interlevel_row_floats(Sf, a.S[job]), s_fine, w_fine, Sf, a.s_bins[job],
+    interlevel_body(lds + (size_t)wave_index() * interlevel_row_floats(Sf, a.S[job]), s_fine, w_fine, Sf, a.s_bins[job],
                     a.weights[job], a.S[job], num_rays, inter_scale, a.per_ray[job], a.dw[job]);
   } else {
-    distortion_body(lds + (size_t)(threadIdx.x >> 6) * 2 * Sf, s_fine, w_fine, Sf, num_rays, dist_scale, dist_per_ray, dw_dist);
+    distortion_body(lds + (size_t)wave_index() * 2 * Sf, s_fine, w_fine, Sf, num_rays, dist_scale, dist_per_ray, dw_dist);
   }
 }
 

@@ -61,7 +61,7 @@ __device__ __forceinline__ void composite_fwd_body(float* blk_min, float* blk_ma
   // density != nullptr (training step, nsamd_render_train): the weights are computed here from the densities
   // (RaySamples.get_weights, as sampler.hip) and written to weights_out; target != nullptr adds the per-ray squared
   // error and the MSE gradient of the composited colour.
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_index();
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wave;
   const bool want_minmax = t_bins != nullptr && depth_exp != nullptr;
   if (ray >= num_rays) {  // tail workgroup: idle waves still take part in the partial min/max
@@ -210,7 +210,7 @@ __device__ __forceinline__ void composite_bwd_body(float* lds_wave,
     const float* __restrict__ bg_rays) {
   // density != nullptr (nsamd_render_train_bwd): d_weights is not stored; the gradient goes on through
   // RaySamples.get_weights to d_density (same formulas as weights_bwd_kernel in sampler.hip).
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_index();
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wave;
   if (ray >= num_rays) return;
   const float* w_in = weights + ray * S;
@@ -320,7 +320,7 @@ __device__ __forceinline__ void weights_bwd_body(float* lds_wave, const float* _
                                                                uint32_t* __restrict__ gate_out,
                                                                uint8_t* __restrict__ ray_mask) {
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = wave_index();
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wave;
   if (ray >= num_rays) return;  // wave-uniform; no workgroup barrier below
   float* ex_row = lds_wave;
@@ -676,7 +676,7 @@ __device__ __forceinline__ void interlevel_body(
     const float* __restrict__ wp_in, int Sp, int64_t num_rays, float grad_scale, float* __restrict__ per_ray,
     float* __restrict__ dwp, const float* __restrict__ dens_fine = nullptr,
     const float* __restrict__ t_fine = nullptr) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_index();
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wave;
   if (ray >= num_rays) return;
   double* R = reinterpret_cast<double*>(lds_wave);
@@ -782,7 +782,7 @@ __device__ __forceinline__ void distortion_body(float* lds_wave, const float* __
                                                 const float* __restrict__ weights, int S, int64_t num_rays,
                                                 float grad_scale, float* __restrict__ per_ray,
                                                 float* __restrict__ dw) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_index();
   const int64_t ray = (int64_t)blockIdx.x * kRaysPerBlock + wave;
   if (ray >= num_rays) return;
   float* mid = lds_wave;

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kRenderThreads) void composite_bwd_kernel(
     float* __restrict__ d_weights, const float* __restrict__ density, float* __restrict__ d_density,
     const float* __restrict__ bg_rays) {
   extern __shared__ float lds[];
-  composite_bwd_body(lds + (size_t)(threadIdx.x >> 6) * 3 * S, rgb, weights, t_bins, num_rays, S, background, bg_r, bg_g, bg_b,
+  composite_bwd_body(lds + (size_t)wave_index() * 3 * S, rgb, weights, t_bins, num_rays, S, background, bg_r, bg_g, bg_b,
                      d_rgb_out, d_acc, d_depth, ws, d_weights_add, d_rgb, d_weights, density, d_density, bg_rays);
 }
 

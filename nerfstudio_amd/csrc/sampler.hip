@@ -31,7 +31,7 @@ __global__ __launch_bounds__(kThreads) void piecewise_bins_kernel(const float* _
   // one wavefront per ray (4 rays per workgroup): per-ray scalars are computed once, the edge index is a 32-bit loop
   // counter (the flat-index version spent its time in 64-bit divisions)
   const int lane = threadIdx.x & 63;
-  const int64_t ray = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  const int64_t ray = (int64_t)blockIdx.x * (kThreads / 64) + wave_index();
   if (ray >= num_rays) return;
   piecewise_bins_body(ray, lane, nears, fars, edges, jitter, jitter_per_edge, S, spacing, s_bins, t_bins);
 }
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kThreads) void select_bins_kernel(
     const float* __restrict__ jitter, int jitter_per_edge, int S, int spacing, float* __restrict__ s_bins,
     float* __restrict__ t_bins) {
   const int lane = threadIdx.x & 63;
-  const int64_t ray = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  const int64_t ray = (int64_t)blockIdx.x * (kThreads / 64) + wave_index();
   if (ray >= num_rays) return;
   int32_t slot = (int32_t)slot_dev[0];
   slot = slot < 0 ? 0 : (slot >= slots ? slots - 1 : slot);
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kThreads) void weights_fwd_kernel(const float* __re
                                                                int64_t num_rays, int S,
                                                                float* __restrict__ weights) {
   const int lane = threadIdx.x & 63;
-  const int64_t ray = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+  const int64_t ray = (int64_t)blockIdx.x * kWaves + wave_index();
   if (ray >= num_rays) return;  // wave-uniform
   const float* tb = t_bins + ray * (S + 1);
   const float* dn = density + ray * S;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
                                                                uint32_t* __restrict__ gate_out,
                                                                uint8_t* __restrict__ ray_mask) {
   extern __shared__ float lds[];  // (ray_bodies.h: weights_bwd_body — per wave ex[S], trans[S], gw[S])
-  weights_bwd_body(lds + (size_t)(threadIdx.x >> 6) * 3 * S, t_bins, density, dweights, num_rays, S, ddensity, gate_out, ray_mask);
+  weights_bwd_body(lds + (size_t)wave_index() * 3 * S, t_bins, density, dweights, num_rays, S, ddensity, gate_out, ray_mask);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -132,10 +132,10 @@ __global__ __launch_bounds__(kThreads) void pdf_resample_kernel(
     const float* __restrict__ t_bins_prev, const float* __restrict__ density, float* __restrict__ weights_out,
     float* __restrict__ depth_median, int jitter_per_edge, int include_original) {
   extern __shared__ float lds[];  // (ray_bodies.h: pdf_resample_body)
-  const int64_t ray = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+  const int64_t ray = (int64_t)blockIdx.x * kWaves + wave_index();
   if (ray >= num_rays) return;  // wave-uniform; no workgroup barrier in the body
   const int row_floats = 3 * S_prev + 2 + (include_original ? S + 1 : 0);
-  pdf_resample_body<kFused>(lds + (size_t)(threadIdx.x >> 6) * row_floats, ray, s_bins_prev, weights, S_prev, u_base, jitter, nears,
+  pdf_resample_body<kFused>(lds + (size_t)wave_index() * row_floats, ray, s_bins_prev, weights, S_prev, u_base, jitter, nears,
                             fars, anneal_host, anneal_dev, hist_pad, eps, u_offset, spacing, num_rays, S, s_bins, t_bins, inds,
                             t_bins_prev, density, weights_out, depth_median, jitter_per_edge, include_original);
 }

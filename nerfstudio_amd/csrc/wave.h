@@ -10,6 +10,20 @@
 
 namespace nsamd {
 
+// Index of this wavefront inside its workgroup as a SCALAR (wave-uniform by construction, which the compiler cannot prove of
+// threadIdx.x >> 6): everything derived from it — the wave's ray, its row pointers, the ray's near / far / jitter — then lives
+// in scalar registers and is fetched through the scalar cache. NSAMD_SCALAR_RAY=0 at build time: the plain expression (A/B).
+#ifndef NSAMD_SCALAR_RAY
+#define NSAMD_SCALAR_RAY 1
+#endif
+__device__ __forceinline__ int wave_index() {
+#if NSAMD_SCALAR_RAY
+  return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+  return (int)(threadIdx.x >> 6);
+#endif
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_move_f64(double v) {
   const unsigned long long b = (unsigned long long)__double_as_longlong(v);

@@ -73,7 +73,8 @@ def executed_per_launch(key, main_points):
 ROCPROF_KERNEL = {
     "nsamd_field_mlp_bwd": "nsamd::field_mlp_bwd_kernel<false, false>",
     "nsamd_field_mlp_bwd_scatter_phase[gradients+records]": "nsamd::field_mlp_bwd_kernel<true, false>",
-    "nsamd_field_mlp_bwd_scatter_phase[apply]": "nsamd::scatter_apply_kernel + nsamd::scatter_finish_kernel",
+    "nsamd_field_mlp_bwd_scatter_phase[apply]": "nsamd::scatter_apply_kernel<true> (replayed graphs: the weight-gradient reduce rides it) "
+                                                "+ nsamd::scatter_finish_kernel",
     "nsamd_field_mlp_bwd_saved": "nsamd::field_mlp_bwd_kernel (saved activations)",
     "nsamd_field_mlp_fwd": "nsamd::field_mlp_fwd_kernel",
     "nsamd_hashgrid_encode_fwd": "nsamd::hash_encode_fwd_kernel",

@@ -60,13 +60,16 @@ def kib(k, c):
     return (mean(agg[k][c]) or 0.0) * 1024.0
 groups = {  # bench key -> (kernel substring, grid, streaming) parts; streaming = 16 B/lane coalesced reads dominate
     "nsamd_hashgrid_encode_bwd_set[L=16,M=196608]": [("scatter_route_fine_kernel<1024, 1, 4>", "786432", False),
-                                                      ("scatter_apply_kernel", "1048576", True),
+                                                      ("scatter_apply_kernel<false>", "1048576", True),
                                                       ("scatter_finish_kernel", "8192", False)],
     "nsamd_field_mlp_bwd": [("field_mlp_bwd_kernel<false", None, False), ("field_dw_reduce_kernel", None, False)],
     # the fused launch group of the training step, one bench key per phase (nsamd_field_mlp_bwd_scatter_phase)
     "nsamd_field_mlp_bwd_scatter_phase[gradients+records]": [("field_mlp_bwd_kernel<true", None, False)],
     "nsamd_field_mlp_bwd_scatter_phase[dw_reduce]": [("field_dw_reduce_kernel", None, False)],
+    # (round 5: in the training step the weight-gradient reduce RIDES the apply pass — 5 more rows of 64 workgroups, grid
+    #  1376256 — so the eager PMC passes see that launch; its traffic then includes the reduce's 12.8 MB of partial rows)
     "nsamd_field_mlp_bwd_scatter_phase[apply]": [("scatter_apply_kernel", "1048576", True),
+                                                 ("scatter_apply_kernel", "1376256", True),
                                                  ("scatter_finish_kernel", "8192", False)],
     "nsamd_field_mlp_fwd": [("field_mlp_fwd_kernel", None, False)],
     "nsamd_adam_step[n=16826880]": [("adam_kernel", "524288", True)],
