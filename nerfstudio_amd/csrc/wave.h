@@ -10,11 +10,14 @@
 
 namespace nsamd {
 
-// Index of this wavefront inside its workgroup as a SCALAR (wave-uniform by construction, which the compiler cannot prove of
-// threadIdx.x >> 6): everything derived from it — the wave's ray, its row pointers, the ray's near / far / jitter — then lives
-// in scalar registers and is fetched through the scalar cache. NSAMD_SCALAR_RAY=0 at build time: the plain expression (A/B).
+// Index of this wavefront inside its workgroup. NSAMD_SCALAR_RAY=1 at build time makes it a SCALAR (wave-uniform by
+// construction, which the compiler cannot prove of threadIdx.x >> 6): everything derived from it — the wave's ray, its row
+// pointers, the ray's near / far / jitter — then lives in scalar registers and is fetched through the scalar cache. Measured on
+// MI355X (profiles/r05_s5_ab_scalar_ray.txt): nothing — every per-ray launch within 1 % either way, the step 0.698 against
+// 0.692 ms — so the plain expression is the default: the scalar cache is not coherent with a wave's own vector stores inside
+// one launch, which a kernel that reads back what it wrote (csrc/fused_rays.hip) would have to keep in mind for no gain.
 #ifndef NSAMD_SCALAR_RAY
-#define NSAMD_SCALAR_RAY 1
+#define NSAMD_SCALAR_RAY 0
 #endif
 __device__ __forceinline__ int wave_index() {
 #if NSAMD_SCALAR_RAY
