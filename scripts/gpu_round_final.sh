@@ -5,9 +5,9 @@
 # cpu_baseline and the per-kernel table), then the instant-ngp / 300-step / steady-state / unbounded lines, eval render, the
 # one-rank data-parallel rehearsal.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r04_final}
+TAG=${1:-r05_final}
 OUT=$R/gpurun_out/$TAG
-BUDGET_S=${BUDGET_S:-870}
+BUDGET_S=${BUDGET_S:-1150}
 T0=$(date +%s)
 mkdir -p $OUT
 cd $R
@@ -16,7 +16,7 @@ export TMPDIR=/tmp
 left() { [ $(( $(date +%s) - T0 )) -lt $BUDGET_S ]; }
 say() { echo "$@" | tee -a $OUT/summary.txt; }
 say "== pytest -m gpu"
-timeout 420 python -m pytest tests -m gpu -q -s > $OUT/pytest_gpu.log 2>&1
+timeout 780 python -m pytest tests -m gpu -q -s > $OUT/pytest_gpu.log 2>&1
 say "rc=$?"
 grep -E "mean PSNR|^   [0-9] \||GPU - oracle|passed|failed|^E  |bench-size parity|excluded" $OUT/pytest_gpu.log | cut -c1-400 | head -40 | tee -a $OUT/summary.txt
 say "== smoke"
@@ -30,6 +30,22 @@ timeout 200 python bench.py --steps 20 --warmup 5 --kernel-table > $OUT/bench_dr
 cat $OUT/bench_driver_window.json | tee -a $OUT/summary.txt
 grep -v amdgpu.ids $OUT/bench_driver_window_kernel_table.log | head -n 26 | tee -a $OUT/summary.txt
 say "elapsed $(( $(date +%s) - T0 )) s"
+if left; then
+say "== the iteration through the Trainer / Pipeline seam next to the direct line (scripts/bench_seam.py)"
+timeout 200 python scripts/bench_seam.py > $OUT/bench_seam.json 2> $OUT/bench_seam.err
+python -c "
+import json; j=json.load(open('$OUT/bench_seam.json'))
+print({k: j[k] for k in ('direct_pool_ms','direct_set_batch_ms','seam_ms','seam_over_direct_pool','seam_over_direct_pool_per_window')})" | tee -a $OUT/summary.txt
+fi
+if left; then
+say "== the merged launches that are opt-in (measured slower): one driver window each"
+for arm in NSAMD_FUSE_RAYS=1 NSAMD_FUSE_SAMPLER=1 NSAMD_REDUCE_RIDER=0; do
+  say "$arm: $(env $arm timeout 100 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --long-steps 0 --profile-steps 1 2>/dev/null | python -c 'import sys,json
+for l in sys.stdin:
+    if l.startswith("{"):
+        d=json.loads(l); print(d["ms_per_step"], d["value"])')"
+done
+fi
 if left; then
 say "== bench, camera optimiser ON (SO3xR3: the reference's nerfacto default, models/nerfacto.py:131)"
 timeout 150 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --camera-optimizer SO3xR3 --kernel-table > $OUT/bench_camera_SO3xR3.json 2> $OUT/bench_camera_SO3xR3_kernel_table.log
