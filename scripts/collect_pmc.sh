@@ -67,10 +67,12 @@ groups = {  # bench key -> (kernel substring, grid, streaming) parts; streaming 
     "nsamd_field_mlp_bwd_scatter_phase[gradients+records]": [("field_mlp_bwd_kernel<true", None, False)],
     "nsamd_field_mlp_bwd_scatter_phase[dw_reduce]": [("field_dw_reduce_kernel", None, False)],
     # (round 5: in the training step the weight-gradient reduce RIDES the apply pass — 5 more rows of 64 workgroups, grid
-    #  1376256 — so the eager PMC passes see that launch; its traffic then includes the reduce's 12.8 MB of partial rows)
-    "nsamd_field_mlp_bwd_scatter_phase[apply]": [("scatter_apply_kernel", "1048576", True),
-                                                 ("scatter_apply_kernel", "1376256", True),
+    #  1376256: the eager PMC passes see that launch, listed under its own key; the bench's "[apply]" key is the phase launch
+    #  of its per-kernel table, the apply pass alone)
+    "nsamd_field_mlp_bwd_scatter_phase[apply]": [("scatter_apply_kernel<false>", "1048576", True),
                                                  ("scatter_finish_kernel", "8192", False)],
+    "nsamd_field_mlp_bwd_scatter[apply + riding reduce]": [("scatter_apply_kernel<true>", "1376256", True),
+                                                           ("scatter_finish_kernel", "8192", False)],
     "nsamd_field_mlp_fwd": [("field_mlp_fwd_kernel", None, False)],
     "nsamd_adam_step[n=16826880]": [("adam_kernel", "524288", True)],
     "nsamd_hashgrid_encode_fwd[L=16,M=196608]": [("hash_encode_fwd", "3145728", False)],
