@@ -154,6 +154,7 @@ class NerfactoTrainStep:
         self.fuse_rays = os.environ.get("NSAMD_FUSE_RAYS", "0") == "1"
         self.fold_weights_bwd = os.environ.get("NSAMD_FOLD_WEIGHTS_BWD", "1") == "1"
         self._rays_bwd_fresh = False  # `losses` has already run the compositing backward for this forward
+        self.prop_mlp_inline = os.environ.get("NSAMD_PROP_MLP_INLINE", "0") == "1"
         # the iteration's loss values and training metrics, written by the losses launch's finishing pass (nsamd.h):
         # rgb_loss, interlevel_loss, distortion_loss, psnr, distortion, sum of the three losses
         self.loss_vals = torch.zeros(8, **f32)
@@ -336,11 +337,18 @@ class NerfactoTrainStep:
             # The backward chains are independent (disjoint gradients, separate scratch): fork the proposal chains onto
             # their own streams so that these latency-bound kernels overlap with the main chain.
             main = torch.cuda.current_stream()
+            side_stage = "all"
+            if self.prop_mlp_inline:
+                # NSAMD_PROP_MLP_INLINE=1 (experiment): the levels' weights + density-MLP backward run IN LINE ahead of the main
+                # backward — beside it their 44-KiB workgroups delay the persistent main-backward workgroups at its start, and
+                # what follows them starves until it ends — and only the table scatters are forked
+                self.backward_proposals(stage="mlp")
+                side_stage = "scatter"
             self._fork.record(main)
             for stream, join, levels in branches:
                 stream.wait_event(self._fork)
                 with torch.cuda.stream(stream):
-                    self.backward_proposals(levels=levels)
+                    self.backward_proposals(levels=levels, stage=side_stage)
                     join.record(stream)
             self.backward_main()
         else:
@@ -800,12 +808,14 @@ class NerfactoTrainStep:
         self.sh_t_bins.copy_(self.t_bins[L])
 
     @profiler.time_function
-    def backward_proposals(self, levels=None) -> None:
+    def backward_proposals(self, levels=None, stage: str = "all") -> None:
         """Backward of the proposal networks (interlevel loss only; main-level weights are detached, losses.py:119-120).
         Needs the dw_prop written by forward_backward_main(updated=True). `levels`: subset of proposal levels (their
-        chains share nothing, so they may run on different streams)."""
+        chains share nothing, so they may run on different streams). `stage`: "mlp" = weights backward + density-MLP backward
+        (its weight-gradient reduce included), "scatter" = ray gradients + table scatter, "all" = both in order."""
         lib, st, n = N.load(), N.stream(), self.n
         ck = N.check
+        do_mlp, do_scatter = stage in ("all", "mlp"), stage in ("all", "scatter")
         for _ in (0,):
             for lvl in (range(self.n_prop) if levels is None else levels):
                 net = self.props[lvl]
@@ -820,40 +830,45 @@ class NerfactoTrainStep:
                 ws, ws_n = F._scatter_workspace(spec, self.f_enc.device, m)
                 grads = (N.ptr(self._grad(W0)), N.ptr(self._grad(b0)), N.ptr(self._grad(W1)), N.ptr(self._grad(b1)))
                 folded = lvl in self._wb_folded  # `losses` already ran this level's weights backward (same launch as the losses)
-                self._wb_folded.discard(lvl)
+                if do_mlp:
+                    self._wb_folded.discard(lvl)
                 if folded and getattr(self, "_wb_gated", False) != (gate is not None and ws is not None):
                     folded = False  # (the gating mode changed between the two calls: run the level's own launch)
                 if gate is None or ws is None:  # ungated chain (A/B switch, or no binned-scatter workspace for this shape)
-                    if not folded:
-                        ck(lib.nsamd_weights_bwd(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]),
-                                                 n, S, N.ptr(self.p_ddens[lvl]), st), "weights_bwd")
-                    ck(lib.nsamd_density_mlp_bwd(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]),
-                                                 N.ptr(self.p_ddens[lvl]), m, dm, N.ptr(self.p_denc[lvl]), *grads,
-                                                 N.ptr(dws), dws.numel(), st), "density_mlp_bwd")
-                    if self.cam_opt is not None:
-                        self._rays_backward(lvl, net, self.p_denc[lvl])
-                    ck(lib.nsamd_hashgrid_encode_bwd(self._points(lvl), m, net._transform, net._box,
-                                                     N.ptr(net.encoding.hash_table), spec.native(), N.ptr(self.p_denc[lvl]),
-                                                     1, m, N.ptr(self._grad(net.encoding.hash_table)), None, N.ptr(ws), ws_n,
-                                                     st), "hashgrid_encode_bwd")
+                    if do_mlp:
+                        if not folded:
+                            ck(lib.nsamd_weights_bwd(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]),
+                                                     n, S, N.ptr(self.p_ddens[lvl]), st), "weights_bwd")
+                        ck(lib.nsamd_density_mlp_bwd(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]),
+                                                     N.ptr(self.p_ddens[lvl]), m, dm, N.ptr(self.p_denc[lvl]), *grads,
+                                                     N.ptr(dws), dws.numel(), st), "density_mlp_bwd")
+                    if do_scatter:
+                        if self.cam_opt is not None:
+                            self._rays_backward(lvl, net, self.p_denc[lvl])
+                        ck(lib.nsamd_hashgrid_encode_bwd(self._points(lvl), m, net._transform, net._box,
+                                                         N.ptr(net.encoding.hash_table), spec.native(), N.ptr(self.p_denc[lvl]),
+                                                         1, m, N.ptr(self._grad(net.encoding.hash_table)), None, N.ptr(ws), ws_n,
+                                                         st), "hashgrid_encode_bwd")
                     continue
                 # the weights backward raises the level's flag when any ray carries interlevel gradient; the rest of the
                 # chain returns at once while it is clear (the zero-filled gradients are then already the result)
                 mask = N.ptr(self.prop_ray_masks[lvl])
-                if not folded:
-                    ck(lib.nsamd_weights_bwd_gate(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]),
-                                                  n, S, N.ptr(self.p_ddens[lvl]), gate, mask, int(self.gates_precleared), st),
-                       "weights_bwd_gate")
-                ck(lib.nsamd_density_mlp_bwd_gated(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]),
-                                                   N.ptr(self.p_ddens[lvl]), m, dm, N.ptr(self.p_denc[lvl]), *grads,
-                                                   N.ptr(dws), dws.numel(), gate, mask, S, st), "density_mlp_bwd_gated")
-                if self.cam_opt is not None:
-                    self._rays_backward(lvl, net, self.p_denc[lvl], gate, mask)
-                ck(lib.nsamd_hashgrid_encode_bwd_gated(self._points(lvl), m, net._transform, net._box,
-                                                       N.ptr(net.encoding.hash_table), spec.native(),
-                                                       N.ptr(self.p_denc[lvl]), 1, m,
-                                                       N.ptr(self._grad(net.encoding.hash_table)), N.ptr(ws), ws_n, gate,
-                                                       mask, st), "hashgrid_encode_bwd_gated")
+                if do_mlp:
+                    if not folded:
+                        ck(lib.nsamd_weights_bwd_gate(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]),
+                                                      n, S, N.ptr(self.p_ddens[lvl]), gate, mask, int(self.gates_precleared), st),
+                           "weights_bwd_gate")
+                    ck(lib.nsamd_density_mlp_bwd_gated(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]),
+                                                       N.ptr(self.p_ddens[lvl]), m, dm, N.ptr(self.p_denc[lvl]), *grads,
+                                                       N.ptr(dws), dws.numel(), gate, mask, S, st), "density_mlp_bwd_gated")
+                if do_scatter:
+                    if self.cam_opt is not None:
+                        self._rays_backward(lvl, net, self.p_denc[lvl], gate, mask)
+                    ck(lib.nsamd_hashgrid_encode_bwd_gated(self._points(lvl), m, net._transform, net._box,
+                                                           N.ptr(net.encoding.hash_table), spec.native(),
+                                                           N.ptr(self.p_denc[lvl]), 1, m,
+                                                           N.ptr(self._grad(net.encoding.hash_table)), N.ptr(ws), ws_n, gate,
+                                                           mask, st), "hashgrid_encode_bwd_gated")
 
     # -------------------------------------------------------------------------------------------------------------
     def loss_dict(self) -> Dict[str, Tensor]:
