@@ -11,8 +11,10 @@ module API with autograd; this runner issues THE SAME kernels in a fixed order o
             -> composite_bwd -> weights_bwd -> field_mlp_bwd -> hash_bwd(main)
             -> (only on proposal-update steps, ray_samplers.py:590) weights_bwd -> density_mlp_bwd -> hash_bwd x 2
 
-~30 launches, every one a libnsamd kernel; parameter gradients accumulate directly into `param.grad` (the views of
-arena.ParamArena). Nothing here depends on host-side values that change from step to step (the jitter is drawn on the
+~25 launches, every one a libnsamd kernel (round 5: batch selection + initial bins are one launch, the main field's
+weight-gradient reduce rides the table scatter's apply pass; the fully merged forms of the per-ray stages — nsamd_proposal_sampler,
+nsamd_render_losses_train — exist, are bit-identical and measured slower, so they are opt-in: DESIGN.md 4.8); parameter gradients
+accumulate directly into `param.grad` (the views of arena.ParamArena). Nothing here depends on host-side values that change from step to step (the jitter is drawn on the
 device, the anneal exponent lives in device memory), so the whole iteration can be captured in a hipGraph once per
 schedule variant and replayed. Numerically identical to the autograd path (tests/test_gpu_kernels.py compares them).
 """
