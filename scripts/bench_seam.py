@@ -32,6 +32,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--windows", type=int, default=7)
 ap.add_argument("--profile", action="store_true", help="cProfile of the seam arm's host side (top entries to stderr)")
+ap.add_argument("--arms", default="direct_pool,direct_set_batch,seam", help="which arms to run (a kernel trace wants one)")
 args = ap.parse_args()
 
 from nerfstudio_amd import _native, functional as F  # noqa: E402
@@ -83,7 +84,8 @@ def opt_config(groups):
 
 results = {}
 # ---- arm 1 / 2: the trainer driven directly (bench.py's line); over its own pool, or with set_batch every step
-for arm in ("direct_pool", "direct_set_batch"):
+ARMS = args.arms.split(",")
+for arm in [a for a in ("direct_pool", "direct_set_batch") if a in ARMS]:
     F._SCATTER_WS.clear()
     model = bench.build_model(dev, seed=0)
     arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
@@ -104,6 +106,10 @@ for arm in ("direct_pool", "direct_set_batch"):
     results[arm] = windows(step_direct, tr.finish, args.warmup)
     del tr, arena, model
 
+if "seam" not in ARMS:
+    med = {k: float(np.median(v)) for k, v in results.items()}
+    print(json.dumps({"arms": ARMS, "ms_per_step": med, "windows_ms": results}))
+    sys.exit(0)
 # ---- arm 3: the restated reference trainer -> seam -> engine
 F._SCATTER_WS.clear()
 model = bench.build_model(dev, seed=0)
@@ -147,6 +153,9 @@ if args.profile:
     pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
 assert eng.trainer.graphs is not None, "the seam did not reach the captured schedule"
 med = {k: float(np.median(v)) for k, v in results.items()}
+if "direct_pool" not in ARMS or "direct_set_batch" not in ARMS:
+    print(json.dumps({"arms": ARMS, "ms_per_step": med, "windows_ms": results}))
+    sys.exit(0)
 # the arms run the SAME iterations window by window (same init, same batches): the paired ratio per window is the comparison;
 # the windows themselves differ by +-15 % with the phase of the proposal-update schedule and the gradient sparsity
 paired = [a / b for a, b in zip(results["seam"], results["direct_pool"])]
