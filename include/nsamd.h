@@ -526,7 +526,8 @@ int nsamd_proposal_losses(const float* s_bins_fine, const float* w_fine, int32_t
  * One wavefront per (ray, job): job 0 = the fine level's chain, job 1 + l = proposal level l. Every output — including
  * `weights`, `d_rgb_out` and `dw_distortion`, which the launch itself reads back — is bit-identical to the separate launches.
  * Arguments as theirs; s_bins [N,S+1] are the fine level's spacing-domain edges (the losses), t_bins its euclidean ones.
- * loss_values (nullable, 8 floats): written by the launch's finishing pass (the one that clips the expected depth) — the
+ * loss_values (nullable, 32 floats = 8 results + scratch of the pass: partial sums and a ticket word that must be ZERO before
+ * the first launch and resets itself): written by the launch's finishing pass (the one that clips the expected depth) — the
  * iteration's loss values as models/nerfacto.py:363-375 scales them and the two training metrics of :352-361, from the per-ray
  * terms summed in a fixed order in double: [0] rgb_loss = sum(sq_err) / (3 N), [1] interlevel_loss = interlevel_loss_mult *
  * sum over levels and rays / (N S), [2] distortion_loss = distortion_loss_mult * sum(distortion_per_ray) / N,
@@ -687,6 +688,17 @@ int nsamd_select_bins(const float* slot_dev, int32_t slots, int64_t num_rays, co
                       float* directions, int64_t* cameras, float* target, const float* nears, const float* fars,
                       const float* edges, const float* jitter, int32_t jitter_per_edge, int32_t S, int spacing,
                       float* s_bins, float* t_bins, nsamd_stream_t stream);
+
+/* Head of a captured training iteration: what changes from step to step, produced on the device (a replayed hipGraph then
+ * needs no host-issued upload in front of it). counter [2] int64 (device): [0] = row counter of `table`, [1] = draw counter;
+ * both are advanced by one. table [rows, 8] (nullable): the step scalars of the coming iterations as the HOST computed them
+ * (Adam step size and 1 / sqrt(bias_correction2) per optimiser group — torch/optim/adam.py —, the proposal weight anneal of
+ * models/nerfacto.py:270-280, the batch slot); row counter[0] % rows is copied to hyper [8]. uniform0 [n0], uniform1 [n1]
+ * (nullable with n = 0): U[0, 1) draws of this step — what the reference takes from torch.rand for the samplers' jitter
+ * (ray_samplers.py:105, 322) and the random background (renderers.py:195) — Philox-4x32-10 keyed by (seed, counter[1]): the same
+ * numbers whether the step is launched eagerly or replayed. */
+int nsamd_step_prologue(int64_t* counter, const float* table, int32_t rows, float* hyper, float* uniform0, int64_t n0,
+                        float* uniform1, int64_t n1, uint64_t seed, nsamd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Camera-pose corrections (CameraOptimizer, cameras/camera_optimizers.py:85-185; exponential maps cameras/lie_groups.py:

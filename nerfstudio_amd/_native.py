@@ -141,6 +141,7 @@ _SIGNATURES = {
     "nsamd_rows_scatter": [vp, vp, i64, i32, vp, vp],
     "nsamd_select_batch": [vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "nsamd_select_bins": [vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, C.c_int, vp, vp, vp],
+    "nsamd_step_prologue": [vp, vp, i32, vp, vp, i64, vp, i64, C.c_uint64, vp],
     "nsamd_camera_apply": [vp, i32, i32, vp, vp, vp, i64, vp, vp, vp],
     "nsamd_camera_backward": [vp, i32, i32, vp, vp, i64, RayGrads, f32, f32, vp, vp, vp],
     "nsamd_adam_step": [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i32, f32, vp, vp],

@@ -111,7 +111,8 @@ struct LossSumArgs {
   const float* inter_per_ray[kMaxFusedLevels];
   int levels;
   float rgb_scale, dist_scale, inter_scale, mean_scale;  // 1 / (3 n), mult / n, mult / (n S), 1 / n
-  float* out;  // [8]: rgb_loss, interlevel_loss, distortion_loss, psnr, distortion (metric), sum of the three losses
+  float* out;  // [32]: rgb_loss, interlevel_loss, distortion_loss, psnr, distortion (metric), sum of the three losses, 2 spare;
+               // then scratch of the finishing pass: 8 doubles of partial sums and its ticket word (zero before the first launch)
 };
 
 __global__ __launch_bounds__(256) void train_finish_kernel(float* __restrict__ depth, int64_t n, float* __restrict__ ws,
@@ -142,31 +143,50 @@ __global__ __launch_bounds__(256) void train_finish_kernel(float* __restrict__ d
     return;
   }
   if (L.out == nullptr) return;
-  double tot[3] = {0.0, 0.0, 0.0};  // squared error, distortion, interlevel (levels in order)
-  for (int q = 0; q < 2 + L.levels; ++q) {
-    const float* src = q == 0 ? L.sq_err : q == 1 ? L.dist_per_ray : L.inter_per_ray[q - 2];
-    double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) acc += (double)src[i];
-    s_sum[threadIdx.x] = acc;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
-      __syncthreads();
+  // One workgroup per per-ray array (squared error, distortion, interlevel per level), every load of a thread in flight at once,
+  // a wave butterfly in double and the four wave sums in wave order: ~3 us for the launch. (The first version summed the arrays
+  // one after the other in ONE workgroup with an LDS tree each: ~20 us on the critical path of every iteration that asks for
+  // the values — profiles/r05_s9_seam_trace_gaps.txt.) The last workgroup to arrive (a ticket in the scratch words behind the
+  // eight result floats) combines the sums in ARRAY order, so the values do not depend on the arrival order.
+  const int q = (int)blockIdx.x - clip_blocks;
+  const int arrays = 2 + L.levels;
+  if (q >= arrays) return;
+  const float* src = q == 0 ? L.sq_err : q == 1 ? L.dist_per_ray : L.inter_per_ray[q - 2];
+  double acc = 0.0;
+  for (int64_t i0 = threadIdx.x; i0 < n; i0 += 256 * 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int64_t i = i0 + (int64_t)u * 256;
+      v[u] = src[i < n ? i : n - 1];  // (unconditional loads at a clamped index; dropped below)
     }
-    tot[q < 2 ? q : 2] += s_sum[0];
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += (i0 + (int64_t)u * 256 < n) ? (double)v[u] : 0.0;
   }
-  if (threadIdx.x == 0) {
-    const float rgb_loss = (float)tot[0] * L.rgb_scale;
-    const float dist_loss = (float)tot[1] * L.dist_scale;
-    const float inter_loss = (float)tot[2] * L.inter_scale;
-    L.out[0] = rgb_loss;
-    L.out[1] = inter_loss;
-    L.out[2] = dist_loss;
-    L.out[3] = -10.0f * log10f(rgb_loss);
-    L.out[4] = (float)tot[1] * L.mean_scale;
-    L.out[5] = (rgb_loss + inter_loss) + dist_loss;
-  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double* scratch = reinterpret_cast<double*>(L.out + 8);      // [kMaxFusedLevels + 2] partial sums
+  unsigned* ticket = reinterpret_cast<unsigned*>(L.out + 24);  // self-resetting
+  scratch[q] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
+  __threadfence();
+  if (atomicAdd(ticket, 1u) != (unsigned)(arrays - 1)) return;
+  __threadfence();
+  const volatile double* sc = scratch;
+  double inter = 0.0;
+  for (int l = 0; l < L.levels; ++l) inter += sc[2 + l];
+  const float rgb_loss = (float)sc[0] * L.rgb_scale;
+  const float dist_loss = (float)sc[1] * L.dist_scale;
+  const float inter_loss = (float)inter * L.inter_scale;
+  L.out[0] = rgb_loss;
+  L.out[1] = inter_loss;
+  L.out[2] = dist_loss;
+  L.out[3] = -10.0f * log10f(rgb_loss);
+  L.out[4] = (float)sc[1] * L.mean_scale;
+  L.out[5] = (rgb_loss + inter_loss) + dist_loss;
+  *ticket = 0u;
 }
 
 }  // namespace nsamd
@@ -233,7 +253,7 @@ extern "C" int nsamd_render_losses_train(
     L.inter_scale = interlevel_loss_mult / ((float)num_rays * (float)S);
     L.mean_scale = 1.0f / (float)num_rays;
     const int clip_blocks = depth_expected != nullptr ? (int)((num_rays + 255) / 256) : 0;
-    train_finish_kernel<<<(unsigned)(clip_blocks + (loss_values != nullptr ? 1 : 0)), 256, 0, st>>>(
+    train_finish_kernel<<<(unsigned)(clip_blocks + (loss_values != nullptr ? 2 + levels : 0)), 256, 0, st>>>(
         depth_expected, num_rays, workspace, (int)blocks, clip_blocks, L);
     NSAMD_CHECK_LAUNCH();
   }
@@ -259,7 +279,7 @@ extern "C" int nsamd_train_loss_values(const float* sq_err, const float* distort
   L.dist_scale = distortion_loss_mult / (float)num_rays;
   L.inter_scale = interlevel_loss_mult / ((float)num_rays * (float)S);
   L.mean_scale = 1.0f / (float)num_rays;
-  train_finish_kernel<<<1, 256, 0, (hipStream_t)stream>>>(nullptr, num_rays, nullptr, 0, 0, L);
+  train_finish_kernel<<<(unsigned)(2 + levels), 256, 0, (hipStream_t)stream>>>(nullptr, num_rays, nullptr, 0, 0, L);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

@@ -96,6 +96,48 @@ __global__ void rows_scatter_kernel(float* __restrict__ rows, const int64_t* __r
   rows[index[r] * feat + (i - r * feat)] = packed[i];
 }
 
+// Head of a captured training iteration: everything that changes from step to step, produced ON THE DEVICE so that a replay
+// needs no host-issued operation in front of it (an eager 32-byte upload and torch's own generator-offset fill in front of every
+// hipGraphLaunch cost ~8 us of idle stream each — profiles/r05_s9_seam_trace_gaps.txt):
+//   * the step's scalars (Adam step sizes of every optimiser group, the anneal exponent, the batch slot): row counter[0] % rows
+//     of a table the host uploads ahead for the coming iterations (exact host arithmetic, nothing is re-derived here);
+//   * the step's uniform draws (the sampler's jitter per level and ray, the loss's random background): Philox-4x32-10 keyed by
+//     (seed, counter[1]) — a counter-based generator needs no state beyond the step number, so eager launches and replays of
+//     the same step draw the same numbers.
+// One workgroup: the counters are read by every thread before thread 0 advances them.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
+  c[0] = n0, c[1] = n1, c[2] = n2, c[3] = n3;
+  k[0] += 0x9E3779B9u, k[1] += 0xBB67AE85u;
+}
+
+__global__ __launch_bounds__(1024) void step_prologue_kernel(int64_t* __restrict__ counter, const float* __restrict__ table,
+                                                             int rows, float* __restrict__ hyper, float* __restrict__ out0,
+                                                             int64_t n0, float* __restrict__ out1, int64_t n1, uint64_t seed) {
+  const int64_t row = counter[0], draw = counter[1];
+  if (table != nullptr && rows > 0 && threadIdx.x < 8) hyper[threadIdx.x] = table[(row % rows) * 8 + threadIdx.x];
+  const int64_t total = n0 + n1;
+  for (int64_t q = threadIdx.x; 4 * q < total; q += 1024) {
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)draw, (uint32_t)(draw >> 32)};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = 4 * q + j;
+      const float u = (float)(c[j] >> 8) * 5.9604644775390625e-8f;  // 24 random bits: uniform on [0, 1)
+      if (i < n0) out0[i] = u;
+      else if (i < total) out1[i - n0] = u;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    counter[0] = row + 1;
+    counter[1] = draw + 1;
+  }
+}
+
 // torch.optim.Adam (no amsgrad / weight decay / maximize): one pass over the flat arena, 16 B per lane — with the operation
 // order of torch/optim/adam.py _single_tensor_adam on fp32 tensors, so that the update is the SAME BITS as torch's:
 //   exp_avg.lerp_(grad, 1 - beta1)                          fma(w1, g - m, m),   w1 = float(1 - beta1) (double subtraction)
@@ -230,6 +272,16 @@ extern "C" int nsamd_select_batch(const float* slot_dev, int32_t slots, int64_t 
   select_batch_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>(slot_dev, slots, num_rays, origins_pool,
                                                                      directions_pool, cameras_pool, target_pool,
                                                                      origins, directions, cameras, target);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_step_prologue(int64_t* counter, const float* table, int32_t rows, float* hyper, float* uniform0,
+                                   int64_t n0, float* uniform1, int64_t n1, uint64_t seed, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(counter != nullptr && n0 >= 0 && n1 >= 0 && rows >= 0);
+  NSAMD_REQUIRE(table == nullptr || (rows > 0 && hyper != nullptr));
+  NSAMD_REQUIRE((n0 == 0 || uniform0 != nullptr) && (n1 == 0 || uniform1 != nullptr));
+  step_prologue_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(counter, table, rows, hyper, uniform0, n0, uniform1, n1, seed);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

@@ -159,7 +159,7 @@ class NerfactoTrainStep:
         self.prop_mlp_inline = os.environ.get("NSAMD_PROP_MLP_INLINE", "0") == "1"
         # the iteration's loss values and training metrics, written by the losses launch's finishing pass (nsamd.h):
         # rgb_loss, interlevel_loss, distortion_loss, psnr, distortion, sum of the three losses
-        self.loss_vals = torch.zeros(8, **f32)
+        self.loss_vals = torch.zeros(32, **f32)  # (8 results + the finishing pass's scratch: partial sums, ticket)
         self._loss_vals_fresh = False
         self.want_loss_vals = False  # the separate-launch path: also launch nsamd_train_loss_values (set by pipeline.TrainEngine)
         # (slot pointer, slots, pool) of a batch selection the caller leaves to `forward_proposals` (one launch with the initial

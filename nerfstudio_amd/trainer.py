@@ -90,6 +90,7 @@ class HipTrainer:
         self.hyper_ring_np = [h.numpy() for h in self.hyper_ring]
         self.hyper_events = [None] * 64
         self.hyper_slot = 0
+        lr_source_is_default = lr_source is None
         if lr_source is None:
             from .schedulers import ExponentialDecayScheduler, ExponentialDecaySchedulerConfig, nerfacto_schedulers
 
@@ -100,6 +101,16 @@ class HipTrainer:
             lr_source = lambda group, it: sched[group].get_lr(max(it, 0), base[group])  # noqa: E731
         self.lr_source = lr_source
         self.exchange = None  # dp_schedule.PipelinedExchange (N > 1 with the runner)
+        # ---- device-side head of the iteration (nsamd_step_prologue), N = 1 with the runner on the GPU ----
+        # A replayed graph had two host-issued operations in front of it every iteration — the 32-byte upload of `hyper` and the
+        # offset fill of torch's graph-safe generator (for the jitter's uniform_) — and each eager -> graph hand-over leaves the
+        # stream idle for ~8 us (profiles/r05_s9_seam_trace_gaps.txt). With the prologue the first node of the graph copies the
+        # step's row of a TABLE of scalars the host uploaded ahead (exact host arithmetic; re-uploaded when the rows run out or a
+        # row differs from what the host computes for the iteration at hand) and draws the step's uniforms with a counter-based
+        # generator. NSAMD_STEP_PROLOGUE=0: the upload and torch's generator (A/B; other draws, same distribution).
+        self.prologue = False          # set below
+        self.prologue_table = False    # the scalars come from the table (else: the per-iteration upload, prologue for the draws only)
+        self.table_rows = 128
         self.hyper_views = {g: self.hyper[o:o + 2] for g, o in _HYPER.items()}
         self.loss_buf = torch.zeros((), device=dev)
         model.proposal_sampler.anneal_dev = self.hyper[_HYPER_ANNEAL:_HYPER_ANNEAL + 1]
@@ -145,6 +156,22 @@ class HipTrainer:
                 self.opt_stream = torch.cuda.Stream(device=dev)
                 self._opt_fork, self._opt_join = torch.cuda.Event(), torch.cuda.Event()
                 self._sh_fork, self._sh_join = torch.cuda.Event(), torch.cuda.Event()
+            want = os.environ.get("NSAMD_STEP_PROLOGUE", "1") == "1"
+            if (want and self.on_gpu and not self.dp and runner is None and getattr(r, "single_jitter", False)
+                    and hasattr(r, "jitter")):
+                self.prologue = True
+                # the table needs iterations whose scalars the host can compute AHEAD: this trainer drives the model's
+                # callbacks itself and the learning rates come from a function of the iteration (not from a trainer's optimisers)
+                self.prologue_table = bool(drive_callbacks) and lr_source_is_default
+                self.step_counter = torch.zeros(2, device=dev, dtype=torch.int64)  # [row of the table, draw]
+                self.hyper_table = torch.zeros(self.table_rows * _HYPER_FLOATS, device=dev)
+                self.table_host = torch.zeros(self.table_rows, _HYPER_FLOATS).pin_memory()
+                self.table_host_np = self.table_host.numpy()
+                self._table_pos, self._table_valid, self._table_event = 0, False, None
+                import numpy as np
+
+                self._row_scratch = np.zeros(_HYPER_FLOATS, dtype=np.float32)
+                self.rng_seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + 0x5851F42D4C957F2D) & 0xFFFFFFFFFFFFFFFF
             if self.dp:
                 from .dp_schedule import PipelinedExchange
 
@@ -182,42 +209,118 @@ class HipTrainer:
             self.model.set_step(self.step)  # BEFORE_TRAIN_ITERATION callback: proposal weight anneal
         self._push_hyper()
 
-    def _push_hyper(self):
-        """Adam step sizes of the NEXT update of each group + the anneal exponent -> device (async, race-free)."""
+    def _hyper_row(self, out, step, counts, have_pending):
+        """The step-dependent scalars of iteration `step` into `out` (8 floats, numpy): Adam step sizes of the NEXT update of
+        each group (`counts`: the groups' step counters before the iteration) + the anneal exponent + the batch slot."""
         from . import functional as F
 
-        m, a = self.model, self.arena
+        a = self.arena
+        # iteration i runs with lr(i); a pending (pipelined) main-field update belongs to the previous iteration
+        it_fields = step - 1 if have_pending else step
+        out[:] = 0.0
+        for group, off in _HYPER.items():
+            if group not in a.groups:
+                continue
+            lr = self.lr_source(group, max(it_fields, 0) if group == "fields" else step)
+            out[off], out[off + 1] = F.adam_hyper(counts[group] + 1, lr, a.betas)
+        out[_HYPER_ANNEAL] = self.model.proposal_sampler._anneal
+        out[_HYPER_SLOT] = float(step % self.slots)
+
+    def _predict_rows(self):
+        """Rows 1 .. of the table: the scalars of the iterations AFTER the one at hand, by running the host-side bookkeeping of
+        those iterations (the model's step callbacks, the sampler's update rule, the optimiser groups' step counters) ahead on
+        its own scalar state, which is put back afterwards. Row 0 (the iteration at hand) is already in place."""
+        m, ps = self.model, self.model.proposal_sampler
+        saved = (ps._step, ps._steps_since_update, ps._anneal, getattr(m, "step", None))
+        counts, pending, step = dict(self.arena.step_counts), self._have_pending, self.step
+        rows = self.table_host_np
+        try:
+            for r in range(self.table_rows):
+                if r > 0:
+                    m.set_step(step)  # BEFORE_TRAIN_ITERATION: the anneal exponent of that iteration
+                    self._hyper_row(rows[r], step, counts, pending)
+                updated = ps.updated_this_step()
+                # what the iteration does to the counters (train_iteration's `stepped`)
+                if self.defer:
+                    if pending:
+                        counts["fields"] += 1
+                    pending = True
+                else:
+                    counts["fields"] += 1
+                if updated:
+                    counts["proposal_networks"] += 1
+                    ps.mark_updated()
+                if self.cam_inside:
+                    counts[self.cam_group] += 1
+                m.after_step(step)  # AFTER_TRAIN_ITERATION: the sampler's step counter
+                step += 1
+        finally:
+            ps._step, ps._steps_since_update, ps._anneal = saved[:3]
+            if saved[3] is not None:
+                m.step = saved[3]
+
+    def _push_hyper(self, direct: bool = False):
+        """Adam step sizes of the NEXT update of each group + the anneal exponent -> device (async, race-free). `direct`: into
+        `hyper` itself whatever the mode (a caller that launches an update outside an iteration body: `finish`)."""
+        a = self.arena
+        if self.prologue_table and not direct:
+            # the graph's first node copies row `counter % rows` of the table into `hyper`: nothing to upload while the row the
+            # host computes for THIS iteration is the one the device is about to read
+            row = self._row_scratch
+            self._hyper_row(row, self.step, a.step_counts, self._have_pending)
+            pos = self._table_pos
+            if self._table_valid and pos < self.table_rows and (self.table_host_np[pos] == row).all():
+                self._table_pos = pos + 1
+                return
+            if self._table_event is not None:
+                self._table_event.synchronize()  # the previous upload has read the pinned table
+            self.table_host_np[0] = row
+            self._predict_rows()
+            self.hyper_table.copy_(self.table_host.reshape(-1), non_blocking=True)
+            self.step_counter[0:1].zero_()
+            self._table_event = torch.cuda.Event()
+            self._table_event.record()
+            self._table_pos, self._table_valid = 1, True
+            return
         slot = self.hyper_slot
         self.hyper_slot = (slot + 1) % len(self.hyper_ring)
         if self.hyper_events[slot] is not None:
             self.hyper_events[slot].synchronize()  # the copy that last read this slot (64 pushes ago) is done
         h, hn = self.hyper_ring[slot], self.hyper_ring_np[slot]
-        # iteration i runs with lr(i); a pending (pipelined) main-field update belongs to the previous iteration
-        it_fields = self.step - 1 if self._have_pending else self.step
-        for group, off in _HYPER.items():
-            if group not in a.groups:
-                continue
-            lr = self.lr_source(group, max(it_fields, 0) if group == "fields" else self.step)
-            hn[off], hn[off + 1] = F.adam_hyper(a.step_counts[group] + 1, lr, a.betas)
-        hn[_HYPER_ANNEAL] = m.proposal_sampler._anneal
-        hn[_HYPER_SLOT] = float(self.step % self.slots)
+        self._hyper_row(hn, self.step, a.step_counts, self._have_pending)
         self.hyper.copy_(h, non_blocking=True)
         if self.on_gpu:
             ev = torch.cuda.Event()
             ev.record()
             self.hyper_events[slot] = ev
 
+    def _step_prologue(self):
+        """First launch of an iteration body (captured with it): the step's scalars out of the table, the step's draws."""
+        if not self.prologue:
+            return
+        from . import _native as N
+
+        r = self.runner
+        draw = self.draw_jitter
+        j = r.jitter if draw else None
+        bg = r.bg_rays if (draw and r.bg_rays is not None) else None
+        N.check(N.load().nsamd_step_prologue(
+            N.ptr(self.step_counter), N.ptr(self.hyper_table) if self.prologue_table else None,
+            self.table_rows if self.prologue_table else 0, N.ptr(self.hyper), N.ptr(j), j.numel() if j is not None else 0,
+            N.ptr(bg), bg.numel() if bg is not None else 0, self.rng_seed, N.stream()), "step_prologue")
+
     def _fwd_bwd(self, updated):
         """Single-process path: forward, losses and the main backward (runner: also the proposal backward)."""
         from .cameras.rays import RayBundle
 
         if self.runner is not None:
+            self._step_prologue()
             self._select_batch()
             self.runner.apply_camera_corrections()
             # the main table's gradient is written, not accumulated; the proposal group's gradients are neither produced nor
             # consumed on a step that does not update it (ray_samplers.py:590-599), so its 10 MB need no zero-fill then
             self._zero(updated)
-            self.runner.forward_proposals(self.draw_jitter, need_enc=updated)
+            self.runner.forward_proposals(self.draw_jitter and not self.prologue, need_enc=updated)
             self.runner.forward_main_and_losses(updated)
             self.runner.backward_all(updated)  # the backward chains run as parallel branches
             return
@@ -261,6 +364,8 @@ class HipTrainer:
         r, a = self.runner, self.arena
         main = torch.cuda.current_stream()
         beside = pending and self.opt_parallel
+        self._step_prologue()  # the step's scalars and draws: first node, every branch below depends on it
+        draw = self.draw_jitter and not self.prologue
 
         def pending_update():  # what iteration k-1 left behind: [its table scatter ->] its main-field Adam
             if self.defer_scatter:
@@ -283,7 +388,7 @@ class HipTrainer:
         if not r.cameras_outside:
             self._select_batch()
             r.apply_camera_corrections()
-        r.forward_proposals(self.draw_jitter, need_enc=updated)
+        r.forward_proposals(draw, need_enc=updated)
         if beside:
             main.wait_event(self._opt_join)
         if self.defer_scatter:  # the final samples are known: copy what defines them, beside the main forward
@@ -429,7 +534,8 @@ class HipTrainer:
         if self.exchange is not None:
             self.exchange.finish()
         if self._pending_main:  # deferred schedule: the last iteration's [table scatter and] main-field update
-            self._push_hyper()
+            self._push_hyper(direct=True)
+            self._table_valid = False  # (the next iteration starts without a pending update: other scalars than the table's)
             if self.defer_scatter:
                 self.runner.backward_table(shadow=True)
             self.arena.step(grad_scale=1.0, groups=["fields"], hyper_dev=self.hyper_views)
@@ -513,8 +619,9 @@ class HipTrainer:
         """[select batch] -> forward -> losses -> backward -> Adam, in order (what a captured ("all", updated) graph holds)."""
         r = self.runner
         if r is not None and r.cameras_outside:
+            self._step_prologue()
             self._zero(updated)
-            r.forward_proposals(self.draw_jitter, need_enc=updated)
+            r.forward_proposals(self.draw_jitter and not self.prologue, need_enc=updated)
             r.forward_main_and_losses(updated)
             r.backward_all(updated)
         else:

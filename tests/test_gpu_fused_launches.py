@@ -362,3 +362,108 @@ def test_loss_values_of_the_finishing_pass_and_of_their_own_launch(F):
         vals[fuse] = r.loss_vals.clone()
         del model, arena, r
     _same(vals[False], vals[True], "loss values: own launch vs the merged launch's finishing pass")
+
+
+def _philox_reference(seed, draw, q):
+    """Philox-4x32-10 (Salmon et al. 2011) on counter (q, draw) with key `seed`, as csrc/misc.hip runs it -> 4 uint32."""
+    M0, M1, W0, W1, mask = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF
+    c = [q & mask, (q >> 32) & mask, draw & mask, (draw >> 32) & mask]
+    k = [seed & mask, (seed >> 32) & mask]
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k[0]) & mask, p1 & mask, ((p0 >> 32) ^ c[3] ^ k[1]) & mask, p0 & mask]
+        k = [(k[0] + W0) & mask, (k[1] + W1) & mask]
+    return c
+
+
+def test_step_prologue_rows_follow_the_table_and_draws_are_philox(F):
+    """nsamd_step_prologue: row `counter[0] % rows` of the host's table lands in `hyper`, both counters advance by one per launch,
+    and the step's uniforms are Philox-4x32-10 keyed by (seed, draw counter) — the numbers of a Python restatement, bit for bit —,
+    uniform on [0, 1) and different from step to step."""
+    from nerfstudio_amd import _native as N
+
+    lib = N.load()
+    rows, n0, n1, seed = 3, 1003, 501, 0x1234567890ABCDEF
+    table = torch.arange(rows * 8, dtype=torch.float32, device="cuda") * 0.5 + 1.0
+    counter = torch.tensor([1, 7], dtype=torch.int64, device="cuda")
+    hyper = torch.zeros(8, device="cuda")
+    u0, u1 = torch.full((n0,), -1.0, device="cuda"), torch.full((n1,), -1.0, device="cuda")
+    draws = []
+    for launch in range(4):
+        N.check(lib.nsamd_step_prologue(N.ptr(counter), N.ptr(table), rows, N.ptr(hyper), N.ptr(u0), n0, N.ptr(u1), n1, seed,
+                                        N.stream()), "step_prologue")
+        torch.cuda.synchronize()
+        row = (1 + launch) % rows
+        assert torch.equal(hyper, table[row * 8:(row + 1) * 8]) and counter.tolist() == [2 + launch, 8 + launch]
+        both = torch.cat([u0, u1]).cpu().numpy()
+        assert both.min() >= 0.0 and both.max() < 1.0
+        draws.append(both)
+        for i in (0, 1, 2, 3, 4, 1001, 1002, 1003, 1004, n0 + n1 - 1):  # (both sides of the seam between the two outputs)
+            want = np.float32(_philox_reference(seed, 7 + launch, i // 4)[i % 4] >> 8) * np.float32(2.0 ** -24)
+            assert both[i] == want, (launch, i, both[i], want)
+    allv = np.concatenate(draws)
+    assert abs(allv.mean() - 0.5) < 0.02 and abs(allv.var() - 1.0 / 12.0) < 0.01
+    assert not np.array_equal(draws[0], draws[1]) and len(np.unique(allv)) > 0.99 * len(allv)
+    # no table: the draws only; no draws: the row only
+    N.check(lib.nsamd_step_prologue(N.ptr(counter), None, 0, None, N.ptr(u0), n0, None, 0, seed, N.stream()), "step_prologue")
+    hyper.fill_(-3.0)
+    N.check(lib.nsamd_step_prologue(N.ptr(counter), N.ptr(table), rows, N.ptr(hyper), None, 0, None, 0, seed, N.stream()), "step_prologue")
+    torch.cuda.synchronize()
+    assert counter.tolist() == [7, 13] and torch.equal(hyper, table[0:8])  # (row 6 % 3 = 0)
+
+
+def test_trainer_prologue_hands_every_iteration_the_scalars_the_host_computes(F, monkeypatch):
+    """trainer.HipTrainer with the device-side prologue: over 150 replayed iterations — across two refills of the 128-row table,
+    a `finish()` in the middle and a rewind of the training state (bench.py's repeated windows) — `hyper` holds after every
+    iteration exactly the eight scalars the host computes for it (what the per-iteration upload used to carry); and graph replay
+    trains through the same bits as eager launches."""
+    import hashlib
+
+    import bench
+
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.trainer import HipTrainer
+
+    monkeypatch.delenv("NSAMD_STEP_PROLOGUE", raising=False)
+    dev = torch.device("cuda")
+    digests = {}
+    for arm in ("graph", "eager"):
+        F._SCATTER_WS.clear()
+        torch.manual_seed(0)
+        model = bench.build_model(dev, seed=0)
+        arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
+        rb, batch, pool = bench.synthetic_batch(dev, seed=1000)
+        tr = HipTrainer(model, arena, rb, batch, world=1, use_graph=arm == "graph", use_runner=True, pool=pool)
+        assert tr.prologue and tr.prologue_table
+        if arm == "graph":
+            tr.train_iteration()
+            tr.finish()
+            assert tr.try_capture()
+        else:
+            tr.train_iteration()
+            tr.finish()
+            tr.warm_variants()  # (the same real iterations the capture's warm-up runs)
+        state = bench.TrainingState(tr, arena, model)
+        want = np.zeros(8, dtype=np.float32)
+        checked = 0
+        for i in range(150 if arm == "graph" else 12):
+            if arm == "graph" and i == 40:
+                tr.finish()
+            if arm == "graph" and i == 90:
+                state.restore()
+            model.set_step(tr.step)  # (what `_prologue` is about to do: the anneal exponent of this iteration)
+            tr._hyper_row(want, tr.step, arena.step_counts, tr._have_pending)
+            tr.train_iteration()
+            if arm == "graph" and (i < 12 or i % 7 == 0 or 85 <= i <= 95 or 125 <= i <= 135):
+                torch.cuda.synchronize()
+                got = tr.hyper.cpu().numpy()
+                assert np.array_equal(got, want), (i, got, want)
+                checked += 1
+            if i == 11:
+                tr.finish()
+                torch.cuda.synchronize()
+                digests[arm] = tuple(hashlib.sha256(x.detach().cpu().numpy().tobytes()).hexdigest()
+                                     for x in (arena.flat, arena.exp_avg, arena.exp_avg_sq))
+        assert arm == "eager" or checked > 40
+        del tr, arena, model
+    assert digests["graph"] == digests["eager"], digests
