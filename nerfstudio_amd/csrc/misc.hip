@@ -100,7 +100,8 @@ __global__ void rows_scatter_kernel(float* __restrict__ rows, const int64_t* __r
 // needs no host-issued operation in front of it (an eager 32-byte upload and torch's own generator-offset fill in front of every
 // hipGraphLaunch cost ~8 us of idle stream each — profiles/r05_s9_seam_trace_gaps.txt):
 //   * the step's scalars (Adam step sizes of every optimiser group, the anneal exponent, the batch slot): row counter[0] % rows
-//     of a table the host uploads ahead for the coming iterations (exact host arithmetic, nothing is re-derived here);
+//     of a table of rows in exact host arithmetic (nothing is re-derived here) — either device memory the host uploaded ahead
+//     for the coming iterations, or a ring in pinned host memory the host fills one row per launch, read over the bus;
 //   * the step's uniform draws (the sampler's jitter per level and ray, the loss's random background): Philox-4x32-10 keyed by
 //     (seed, counter[1]) — a counter-based generator needs no state beyond the step number, so eager launches and replays of
 //     the same step draw the same numbers.
@@ -116,7 +117,10 @@ __global__ __launch_bounds__(1024) void step_prologue_kernel(int64_t* __restrict
                                                              int rows, float* __restrict__ hyper, float* __restrict__ out0,
                                                              int64_t n0, float* __restrict__ out1, int64_t n1, uint64_t seed) {
   const int64_t row = counter[0], draw = counter[1];
-  if (table != nullptr && rows > 0 && threadIdx.x < 8) hyper[threadIdx.x] = table[(row % rows) * 8 + threadIdx.x];
+  // (system-scope load: the rows may lie in pinned host memory the host wrote just before the launch — never a cached copy)
+  if (table != nullptr && rows > 0 && threadIdx.x < 8)
+    hyper[threadIdx.x] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(table) + (row % rows) * 8 + threadIdx.x,
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
   const int64_t total = n0 + n1;
   for (int64_t q = threadIdx.x; 4 * q < total; q += 1024) {
     uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)draw, (uint32_t)(draw >> 32)};

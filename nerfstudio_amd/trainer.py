@@ -104,13 +104,23 @@ class HipTrainer:
         # ---- device-side head of the iteration (nsamd_step_prologue), N = 1 with the runner on the GPU ----
         # A replayed graph had two host-issued operations in front of it every iteration — the 32-byte upload of `hyper` and the
         # offset fill of torch's graph-safe generator (for the jitter's uniform_) — and each eager -> graph hand-over leaves the
-        # stream idle for ~8 us (profiles/r05_s9_seam_trace_gaps.txt). With the prologue the first node of the graph copies the
-        # step's row of a TABLE of scalars the host uploaded ahead (exact host arithmetic; re-uploaded when the rows run out or a
-        # row differs from what the host computes for the iteration at hand) and draws the step's uniforms with a counter-based
-        # generator. NSAMD_STEP_PROLOGUE=0: the upload and torch's generator (A/B; other draws, same distribution).
+        # stream idle for ~8 us (profiles/r05_s9_seam_trace_gaps.txt). With the prologue the first node of the graph fetches the
+        # step's scalars itself and draws the step's uniforms with a counter-based generator. NSAMD_STEP_PROLOGUE selects where
+        # the scalars come from:
+        #   "ring" (default)  a ring of rows in pinned HOST memory the device reads directly: the host writes row i % rows for
+        #                     iteration i (exact host arithmetic, at the time it would have issued the upload) and launches; the
+        #                     device's own row counter picks it up. Nothing is predicted, so it serves a trainer whose learning
+        #                     rates come from outside (pipeline.TrainEngine) as well. An event every 64 rows keeps the host from
+        #                     lapping the device.
+        #   "table"           a table of rows in DEVICE memory the host computes AHEAD by running its own bookkeeping forward
+        #                     (re-uploaded when the rows run out or a row differs from what the host computes for the iteration at
+        #                     hand); needs iterations whose scalars are a function of the step (this trainer's own schedulers).
+        #   "0"               the per-iteration upload and torch's generator (A/B; other draws, same distribution).
         self.prologue = False          # set below
-        self.prologue_table = False    # the scalars come from the table (else: the per-iteration upload, prologue for the draws only)
+        self.prologue_table = False    # the scalars come from the predicted table
+        self.prologue_ring = False     # the scalars come from the ring in host memory
         self.table_rows = 128
+        self.ring_rows = 256
         self.hyper_views = {g: self.hyper[o:o + 2] for g, o in _HYPER.items()}
         self.loss_buf = torch.zeros((), device=dev)
         model.proposal_sampler.anneal_dev = self.hyper[_HYPER_ANNEAL:_HYPER_ANNEAL + 1]
@@ -156,22 +166,35 @@ class HipTrainer:
                 self.opt_stream = torch.cuda.Stream(device=dev)
                 self._opt_fork, self._opt_join = torch.cuda.Event(), torch.cuda.Event()
                 self._sh_fork, self._sh_join = torch.cuda.Event(), torch.cuda.Event()
-            want = os.environ.get("NSAMD_STEP_PROLOGUE", "1") == "1"
-            if (want and self.on_gpu and not self.dp and runner is None and getattr(r, "single_jitter", False)
-                    and hasattr(r, "jitter")):
+            mode = os.environ.get("NSAMD_STEP_PROLOGUE", "ring")
+            mode = "ring" if mode == "1" else mode
+            if (mode in ("ring", "table") and self.on_gpu and not self.dp and runner is None
+                    and getattr(r, "single_jitter", False) and hasattr(r, "jitter")):
                 self.prologue = True
-                # the table needs iterations whose scalars the host can compute AHEAD: this trainer drives the model's
-                # callbacks itself and the learning rates come from a function of the iteration (not from a trainer's optimisers)
-                self.prologue_table = bool(drive_callbacks) and lr_source_is_default
-                self.step_counter = torch.zeros(2, device=dev, dtype=torch.int64)  # [row of the table, draw]
-                self.hyper_table = torch.zeros(self.table_rows * _HYPER_FLOATS, device=dev)
-                self.table_host = torch.zeros(self.table_rows, _HYPER_FLOATS).pin_memory()
-                self.table_host_np = self.table_host.numpy()
-                self._table_pos, self._table_valid, self._table_event = 0, False, None
-                import numpy as np
-
-                self._row_scratch = np.zeros(_HYPER_FLOATS, dtype=np.float32)
+                self.step_counter = torch.zeros(2, device=dev, dtype=torch.int64)  # [row, draw]
                 self.rng_seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + 0x5851F42D4C957F2D) & 0xFFFFFFFFFFFFFFFF
+                # the batch slot must be read INSIDE the iteration body: with the camera parts outside the graph the batch is
+                # selected eagerly ahead of the replay, i.e. before the prologue would have written the slot (then: the upload
+                # for the scalars, the prologue for the draws only)
+                inside = not r.cameras_outside
+                if mode == "ring" and inside:
+                    self.prologue_ring = True
+                    self.ring_host = torch.zeros(self.ring_rows, _HYPER_FLOATS).pin_memory()  # (device-visible: hipHostMalloc)
+                    self.ring_np = self.ring_host.numpy()
+                    self._ring_pos = 0                 # rows written so far == the device's row counter at the next launch
+                    self._ring_events = [None] * 4     # recorded every 64 rows
+                elif mode == "table" and inside and bool(drive_callbacks) and lr_source_is_default:
+                    # (this trainer drives the model's callbacks itself and the learning rates are a function of the iteration)
+                    self.prologue_table = True
+                    self.hyper_table = torch.zeros(self.table_rows * _HYPER_FLOATS, device=dev)
+                    self.table_host = torch.zeros(self.table_rows, _HYPER_FLOATS).pin_memory()
+                    self.table_host_np = self.table_host.numpy()
+                    self._table_pos, self._table_valid, self._table_event, self._table_base = 0, False, None, 0
+                    import numpy as np
+
+                    self._row_scratch = np.zeros(_HYPER_FLOATS, dtype=np.float32)
+                    self._row_unread = np.zeros(_HYPER_FLOATS, dtype=bool)  # (entries an iteration without a pending update skips)
+                    self._row_unread[_HYPER["fields"]:_HYPER["fields"] + 2] = True
             if self.dp:
                 from .dp_schedule import PipelinedExchange
 
@@ -263,15 +286,46 @@ class HipTrainer:
         """Adam step sizes of the NEXT update of each group + the anneal exponent -> device (async, race-free). `direct`: into
         `hyper` itself whatever the mode (a caller that launches an update outside an iteration body: `finish`)."""
         a = self.arena
+        if self.prologue_ring and not direct:
+            # the graph's first node reads row `counter % rows` out of pinned host memory: write it, launch, done
+            i = self._ring_pos
+            if i % 64 == 0:
+                k = (i // 64) % 4
+                ago = self._ring_events[(k + 2) % 4]  # recorded 128 rows ago: the rows about to be rewritten were read long before
+                if ago is not None:
+                    ago.synchronize()
+                ev = torch.cuda.Event()
+                ev.record()
+                self._ring_events[k] = ev
+            self._hyper_row(self.ring_np[i % self.ring_rows], self.step, a.step_counts, self._have_pending)
+            self._ring_pos = i + 1
+            return
         if self.prologue_table and not direct:
             # the graph's first node copies row `counter % rows` of the table into `hyper`: nothing to upload while the row the
             # host computes for THIS iteration is the one the device is about to read
             row = self._row_scratch
             self._hyper_row(row, self.step, a.step_counts, self._have_pending)
             pos = self._table_pos
-            if self._table_valid and pos < self.table_rows and (self.table_host_np[pos] == row).all():
-                self._table_pos = pos + 1
-                return
+            unread = self.defer and not self._have_pending
+
+            def serves(r):
+                # an iteration of the deferred schedule WITHOUT a pending main-field update (the first one, and the one after
+                # every `finish`) launches no main-field Adam: its two scalars are not read, so the row predicted for an
+                # iteration with a pending update serves it as well — a `finish` does not cost a new table
+                want = self.table_host_np[r]
+                return bool(((want == row) | self._row_unread).all() if unread else (want == row).all())
+
+            if self._table_valid:
+                if pos < self.table_rows and serves(pos):
+                    self._table_pos = pos + 1
+                    return
+                # a caller that rewound the training state (bench.py repeats its window on the same iterations; a checkpoint
+                # restore): the rows of those iterations are still in the table — move the device's row counter, nothing else
+                back = self.step - self._table_base
+                if 0 <= back < self.table_rows and serves(back):
+                    self.step_counter[0:1].fill_(back)
+                    self._table_pos = back + 1
+                    return
             if self._table_event is not None:
                 self._table_event.synchronize()  # the previous upload has read the pinned table
             self.table_host_np[0] = row
@@ -280,7 +334,7 @@ class HipTrainer:
             self.step_counter[0:1].zero_()
             self._table_event = torch.cuda.Event()
             self._table_event.record()
-            self._table_pos, self._table_valid = 1, True
+            self._table_pos, self._table_valid, self._table_base = 1, True, self.step
             return
         slot = self.hyper_slot
         self.hyper_slot = (slot + 1) % len(self.hyper_ring)
@@ -304,9 +358,14 @@ class HipTrainer:
         draw = self.draw_jitter
         j = r.jitter if draw else None
         bg = r.bg_rays if (draw and r.bg_rays is not None) else None
+        if self.prologue_ring:
+            rows_ptr, rows = self.ring_host.data_ptr(), self.ring_rows
+        elif self.prologue_table:
+            rows_ptr, rows = N.ptr(self.hyper_table), self.table_rows
+        else:
+            rows_ptr, rows = None, 0
         N.check(N.load().nsamd_step_prologue(
-            N.ptr(self.step_counter), N.ptr(self.hyper_table) if self.prologue_table else None,
-            self.table_rows if self.prologue_table else 0, N.ptr(self.hyper), N.ptr(j), j.numel() if j is not None else 0,
+            N.ptr(self.step_counter), rows_ptr, rows, N.ptr(self.hyper), N.ptr(j), j.numel() if j is not None else 0,
             N.ptr(bg), bg.numel() if bg is not None else 0, self.rng_seed, N.stream()), "step_prologue")
 
     def _fwd_bwd(self, updated):
@@ -534,8 +593,7 @@ class HipTrainer:
         if self.exchange is not None:
             self.exchange.finish()
         if self._pending_main:  # deferred schedule: the last iteration's [table scatter and] main-field update
-            self._push_hyper(direct=True)
-            self._table_valid = False  # (the next iteration starts without a pending update: other scalars than the table's)
+            self._push_hyper(direct=True)  # (the table's rows stay valid: see `_push_hyper`)
             if self.defer_scatter:
                 self.runner.backward_table(shadow=True)
             self.arena.step(grad_scale=1.0, groups=["fields"], hyper_dev=self.hyper_views)
