@@ -21,12 +21,12 @@ import torch
 
 class NgpTrainer:
     def __init__(self, model, arena, num_rays: int, device, module_path: bool = False,
-                 after_refresh: Optional[Callable[[], None]] = None, refresh: bool = True) -> None:
+                 after_refresh: Optional[Callable[[], None]] = None, refresh: bool = True, runner=None) -> None:
         self.model, self.arena, self.refresh = model, arena, refresh
         self.after_refresh = after_refresh  # bench.py: keeps its synthetic grid stationary
         self.table = model.field.mlp_base.encoding.hash_table
-        self.runner = None
-        if not module_path:
+        self.runner = runner  # (tests: a CPU stand-in for ngp_step.NgpTrainStep)
+        if not module_path and runner is None:
             from .ngp_step import NgpTrainStep
 
             self.runner = NgpTrainStep(model, num_rays, device)
@@ -38,7 +38,9 @@ class NgpTrainer:
     def set_batch(self, ray_bundle, batch) -> None:
         self.rb, self.batch = ray_bundle, batch
         if self.runner is not None:
-            self.runner.set_batch(ray_bundle.origins, ray_bundle.directions, ray_bundle.camera_indices, batch["image"])
+            # (a collider's per-ray interval travels with the bundle: VolumetricSampler marches it, ray_samplers.py:470-476)
+            self.runner.set_batch(ray_bundle.origins, ray_bundle.directions, ray_bundle.camera_indices, batch["image"],
+                                  nears=getattr(ray_bundle, "nears", None), fars=getattr(ray_bundle, "fars", None))
 
     def update_occupancy_grid(self, step: int) -> None:
         """The model's BEFORE_TRAIN_ITERATION callback (models/instant_ngp.py:150-156)."""

@@ -24,7 +24,16 @@ gradient accumulation, mixed precision, RGBA targets over a random background, C
 `get_train_loss_dict` body over the module path — with one rank; with more the pipeline refuses loudly, because neither DDP
 nor the arena would then reduce the gradients.
 
-nerfstudio itself is imported lazily (`pipeline_classes()`), as in plugin.py.
+`HipDynamicBatchPipeline` is the same seam for `instant-ngp-hip`: the reference's `DynamicBatchPipeline`
+(pipelines/dynamic_batch.py:40-108 — it resizes the ray batch after every iteration from the number of samples the last one
+kept) with `get_train_loss_dict` on the explicit packed-sample schedule (ngp_trainer.NgpTrainer over ngp_step.NgpTrainStep:
+march -> candidates' density -> visibility scan + compaction -> field -> packed compositing -> MSE -> backward -> the arena's
+fused Adam) instead of the module path's ~40 torch glue operations per iteration. The batch size changes from step to step
+and the packed arrays are data-dependent in size (as in nerfacc), so this iteration is a sequence of eager launches over
+capacity-sized buffers with the two sample counts as its host reads — the second of which IS the number the pipeline's
+feedback needs, so `int(metrics["num_samples_per_batch"])` (dynamic_batch.py:91) costs no further synchronisation.
+
+nerfstudio itself is imported lazily (`pipeline_classes()`, `ngp_pipeline_classes()`), as in plugin.py.
 """
 from __future__ import annotations
 
@@ -263,17 +272,90 @@ class TrainEngine:
             self.on_build(self.trainer)
 
 
+class NgpEngine(TrainEngine):
+    """instant-ngp-hip: the arena (one optimiser group, models/instant_ngp.py:165-170) and ngp_trainer.NgpTrainer behind the
+    trainer's `Optimizers`. Per iteration: the learning rate the reference's scheduler has set -> the arena's Adam; the
+    parameters' `.grad` are views of the arena's gradient for the duration of the iteration (the packed kernels accumulate into
+    them) and None again afterwards, so that the trainer's own optimiser finds nothing to step (engine/optimizers.py:160-172).
+    The occupancy refresh stays the model's BEFORE_TRAIN_ITERATION callback, run by the trainer."""
+
+    def build(self, ray_bundle, batch) -> Optional[str]:
+        from .arena import ParamArena
+
+        model = self.pipeline.model
+        reason = self._optimizer_reason()
+        o = ray_bundle.origins
+        if reason is None and getattr(model.config, "use_gradient_scaling", False):
+            reason = "use_gradient_scaling"
+        if reason is None and not o.is_cuda and self.runner_factory is None:
+            reason = "rays on the CPU"
+        if reason is None and batch["image"].shape[-1] == 4:
+            reason = "RGBA targets"
+        params = self.optimizers.parameters
+        if reason is None and set(params) != {"fields"}:
+            reason = f"parameter groups {sorted(params)} (the schedule trains 'fields' only)"
+        if reason is not None:
+            self.reason = reason
+            return reason
+        g = self.optimizers.optimizers["fields"].param_groups[0]
+        self.arena = ParamArena({"fields": list(params["fields"])}, lr=float(g["lr"]), betas=tuple(g["betas"]), eps=float(g["eps"]),
+                                bind_grads=False)
+        self._grad_views = [(p, self.arena.grad[off:off + p.numel()].view(p.shape)) for p, off in zip(self.arena.params, self.arena.offsets)]
+        self._adopt_optimizer_state()
+        self._anchor = torch.zeros((), device=o.device, requires_grad=True)
+        self.build_trainer_only(ray_bundle, batch)
+        return None
+
+    def build_trainer_only(self, ray_bundle, batch) -> None:
+        from .ngp_trainer import NgpTrainer
+
+        o = ray_bundle.origins.reshape(-1, 3)
+        model = self.pipeline.model
+        runner = self.runner_factory(model, o.shape[0], o.device) if self.runner_factory is not None else None
+        self.trainer = NgpTrainer(model, self.arena, o.shape[0], o.device, refresh=False, runner=runner)
+        if self.on_build is not None:
+            self.on_build(self.trainer)
+
+    def flush(self) -> None:  # nothing is deferred on this schedule
+        return None
+
+    def train_iteration(self, step: int, ray_bundle, batch):
+        t, a = self.trainer, self.arena
+        a.lr = float(self.optimizers.optimizers["fields"].param_groups[0]["lr"])  # what the scheduler set for this iteration
+        image = batch["image"]
+        if not image.is_cuda and ray_bundle.origins.is_cuda:
+            image = image.to(ray_bundle.origins.device)
+        rb = ray_bundle.reshape(-1) if ray_bundle.origins.dim() > 2 else ray_bundle
+        for p, g in self._grad_views:
+            p.grad = g
+        try:
+            t.set_batch(rb, {"image": image.reshape(-1, 3)})  # any number of rays: capacity-sized buffers (ngp_step.py)
+            loss = t.train_iteration(step)
+        finally:
+            for p, _ in self._grad_views:
+                p.grad = None
+        r = t.runner
+        outputs = r.outputs()
+        loss_dict = {"rgb_loss": _AlreadyBackpropagated.apply(self._anchor, loss)[0]}
+        # models/instant_ngp.py:218-224: psnr of the rendered colours against the (RGB) target; the number of kept samples —
+        # already on the host (the schedule's second count read) — drives DynamicBatchPipeline's batch size
+        mse = torch.mean((outputs["rgb"].detach() - r.target) ** 2)
+        metrics = {"psnr": -10.0 * torch.log10(mse), "num_samples_per_batch": torch.tensor(int(r.num_kept))}
+        return outputs, loss_dict, metrics
+
+
 class EngineSeam:
     """What HipPipeline adds to VanillaPipeline, free of nerfstudio imports (the GPU tests compose it with a stand-in
     pipeline where the reference is absent). Expects `self.datamanager`, `self.model`, `self._model`, `self.world_size`."""
 
     _engine: Optional[TrainEngine] = None
     _engine_off: bool = False
+    _engine_class = TrainEngine
 
     def attach_optimizers(self, optimizers, trainer=None, **engine_kwargs) -> None:
         """The trainer's `Optimizers` (engine/trainer.py:196-204 hands them to `get_training_callbacks`)."""
         if optimizers is not None and not self._engine_off:
-            self._engine = TrainEngine(self, optimizers, trainer, **engine_kwargs)
+            self._engine = self._engine_class(self, optimizers, trainer, **engine_kwargs)
             # readers that go through the MODEL, not the pipeline (the viewer renders with `pipeline.model.eval()` /
             # `get_outputs_for_camera`, viewer/render_state_machine.py) must see the pending main-field update too
             try:
@@ -307,6 +389,7 @@ class EngineSeam:
 
 
 _PIPELINE_CLASS_NAMES = ("HipPipelineConfig", "HipPipeline")
+_NGP_PIPELINE_CLASS_NAMES = ("HipDynamicBatchPipelineConfig", "HipDynamicBatchPipeline")
 
 
 def _publish(*classes):
@@ -324,6 +407,9 @@ def _publish(*classes):
 def __getattr__(name: str):  # PEP 562: a freshly spawned process / a yaml loader resolves the classes by name
     if name in _PIPELINE_CLASS_NAMES:
         pipeline_classes()
+        return globals()[name]
+    if name in _NGP_PIPELINE_CLASS_NAMES:
+        ngp_pipeline_classes()
         return globals()[name]
     raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
@@ -391,3 +477,71 @@ def pipeline_classes():
 
     _publish(HipPipelineConfig, HipPipeline)
     return HipPipelineConfig, HipPipeline
+
+
+class DynamicBatchSeam(EngineSeam):
+    """What HipDynamicBatchPipeline adds to DynamicBatchPipeline, free of nerfstudio imports (tests compose it with a stand-in
+    where the reference is absent). Expects, besides EngineSeam's attributes, the reference class's
+    `_update_dynamic_num_rays_per_batch` / `_update_pixel_samplers` and `datamanager.train_pixel_sampler`."""
+
+    _engine_class = NgpEngine
+
+    def get_train_loss_dict(self, step: int):
+        eng = self._engine
+        ray_bundle, batch = self.datamanager.next_train(step)
+        if eng is None or eng.reason is not None or (eng.trainer is None and eng.build(ray_bundle, batch) is not None):
+            model_outputs, loss_dict, metrics_dict = self._module_path(step, ray_bundle, batch)
+        else:
+            model_outputs, loss_dict, metrics_dict = eng.train_iteration(step, ray_bundle, batch)
+        # pipelines/dynamic_batch.py:83-95: the next batch's number of rays from the samples this one kept
+        if "num_samples_per_batch" not in metrics_dict:
+            raise ValueError("'num_samples_per_batch' is not in metrics_dict."
+                             "Please return 'num_samples_per_batch' in the models get_metrics_dict function to use this method.")
+        self._update_dynamic_num_rays_per_batch(int(metrics_dict["num_samples_per_batch"]))
+        self._update_pixel_samplers()
+        assert "num_rays_per_batch" not in metrics_dict
+        assert self.datamanager.train_pixel_sampler is not None
+        metrics_dict["num_rays_per_batch"] = torch.tensor(self.datamanager.train_pixel_sampler.num_rays_per_batch)
+        return model_outputs, loss_dict, metrics_dict
+
+    def _module_path(self, step, ray_bundle, batch):
+        """The reference's own body (pipelines/base_pipeline.py:290-303) over the module path (DDP-wrapped for N > 1)."""
+        model_outputs = self._model(ray_bundle)
+        metrics_dict = self.model.get_metrics_dict(model_outputs, batch)
+        loss_dict = self.model.get_loss_dict(model_outputs, batch, metrics_dict)
+        return model_outputs, loss_dict, metrics_dict
+
+
+def ngp_pipeline_classes():
+    """(HipDynamicBatchPipelineConfig, HipDynamicBatchPipeline), built once against the installed nerfstudio and published as
+    attributes of this module (pickle / yaml resolve them by name, as `pipeline_classes`)."""
+    if "HipDynamicBatchPipeline" in globals():
+        return globals()["HipDynamicBatchPipelineConfig"], globals()["HipDynamicBatchPipeline"]
+    from dataclasses import dataclass, field
+    from typing import Type
+
+    from nerfstudio.pipelines.dynamic_batch import DynamicBatchPipeline, DynamicBatchPipelineConfig
+
+    class HipDynamicBatchPipeline(DynamicBatchSeam, DynamicBatchPipeline):
+        """DynamicBatchPipeline (pipelines/dynamic_batch.py:40-108) with the training iteration on ngp_trainer.NgpTrainer.
+        One rank: with more, VanillaPipeline wraps the model in DistributedDataParallel and training takes the module path."""
+
+        def __init__(self, config, device, test_mode="val", world_size=1, local_rank=0, grad_scaler=None):
+            DynamicBatchPipeline.__init__(self, config, device, test_mode, world_size, local_rank, grad_scaler)
+            self._engine = None
+            self._engine_off = not getattr(config, "kernel_schedule", True) or world_size > 1
+
+        def get_training_callbacks(self, training_callback_attributes):
+            self.attach_optimizers(getattr(training_callback_attributes, "optimizers", None),
+                                   getattr(training_callback_attributes, "trainer", None))
+            return super().get_training_callbacks(training_callback_attributes)
+
+    @dataclass
+    class HipDynamicBatchPipelineConfig(DynamicBatchPipelineConfig):
+        _target: Type = field(default_factory=lambda: HipDynamicBatchPipeline)
+        kernel_schedule: bool = True
+        """Training iterations on the explicit packed-sample kernel schedule with the arena's fused Adam
+        (nerfstudio_amd/ngp_step.py, ngp_trainer.py); False: the module path under the trainer's own optimiser."""
+
+    _publish(HipDynamicBatchPipelineConfig, HipDynamicBatchPipeline)
+    return HipDynamicBatchPipelineConfig, HipDynamicBatchPipeline

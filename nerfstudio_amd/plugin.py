@@ -334,6 +334,13 @@ def instant_ngp_hip():
     old = base.pipeline.model
     kwargs = {f.name: getattr(old, f.name) for f in dataclasses.fields(old) if f.name != "_target"}
     base.pipeline.model = cfg_cls(**kwargs)
+    # the pipeline whose `get_train_loss_dict` runs the explicit packed-sample schedule with the arena's fused Adam
+    # (pipeline.HipDynamicBatchPipeline): DynamicBatchPipelineConfig's fields, another `_target`
+    from .pipeline import ngp_pipeline_classes
+
+    pipe_cls, _ = ngp_pipeline_classes()
+    old_pipe = base.pipeline
+    base.pipeline = pipe_cls(**{f.name: getattr(old_pipe, f.name) for f in dataclasses.fields(old_pipe) if f.name != "_target"})
     base.method_name = "instant-ngp-hip"
     base.mixed_precision = False  # fp32 kernels: no autocast, no loss scaling
     return MethodSpecification(config=base, description=NGP_DESCRIPTION)

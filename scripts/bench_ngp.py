@@ -38,18 +38,12 @@ def ngp_lattice_steps(o, d, step, cone, near, far, levels):
     return n
 
 
-def build_ngp(device, synthetic_rays, module_path=False, refresh=True):
-    """NGPModel + the synthetic occupancy state + nerfstudio_amd.ngp_trainer.NgpTrainer on one batch of synthetic rays.
+def build_ngp_model(device):
+    """NGPModel + the synthetic occupancy state -> (model, keep_synthetic_grid).
     The grid is SYNTHETIC (random 5 %-occupied 128^3 x 4 levels) and the random field's density is lifted to
-    ~60 so that rays become opaque after ~45 kept samples. The refresh of the grid runs inside the iteration exactly as in
-    training (every 16th step: cells_per_lvl / 4 uniform + the occupied cells of each level, density of 2.5 M cell points,
-    decayed maximum, threshold, coarse bitfield); because the random field's own occupancy would replace the synthetic grid
-    (every cell occupied), the bench puts the synthetic `occs` back after each refresh — two more device copies INSIDE the
-    timed region, no work skipped — so that every step marches the same 5 % grid."""
-    from nerfstudio_amd.arena import ParamArena
-    from nerfstudio_amd.cameras.rays import RayBundle
+    ~60 so that rays become opaque after ~45 kept samples; `keep_synthetic_grid()` puts the synthetic `occs` back (after a
+    refresh replaced them by the random field's own occupancy: every cell occupied)."""
     from nerfstudio_amd.instant_ngp import InstantNGPModelConfig, NGPModel
-    from nerfstudio_amd.ngp_trainer import NgpTrainer
 
     torch.manual_seed(0)
     cfg = InstantNGPModelConfig()  # grid 128^3 x 4 levels, T = 2^19, cone_angle 0.004, alpha_thre 0.01, random background
@@ -68,6 +62,20 @@ def build_ngp(device, synthetic_rays, module_path=False, refresh=True):
         grid.occs.copy_(occs0)
         grid._refresh_derived(0.01)
 
+    return model, keep_synthetic_grid
+
+
+def build_ngp(device, synthetic_rays, module_path=False, refresh=True):
+    """`build_ngp_model` + nerfstudio_amd.ngp_trainer.NgpTrainer on one batch of synthetic rays.
+    The refresh of the grid runs inside the iteration exactly as in training (every 16th step: cells_per_lvl / 4 uniform + the
+    occupied cells of each level, density of 2.5 M cell points, decayed maximum, threshold, coarse bitfield); the bench puts
+    the synthetic `occs` back after each refresh — two more device copies INSIDE the timed region, no work skipped — so that
+    every step marches the same 5 % grid."""
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.cameras.rays import RayBundle
+    from nerfstudio_amd.ngp_trainer import NgpTrainer
+
+    model, keep_synthetic_grid = build_ngp_model(device)
     arena = ParamArena({"fields": list(model.field.parameters())}, lr=1e-2, eps=1e-15)
     o, d, cam, tgt = synthetic_rays(1000)
     n = RAYS_PER_GPU

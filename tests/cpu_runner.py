@@ -120,3 +120,47 @@ class CpuRunner:
 
     def outputs(self):
         return {"rgb": self._out["rgb"], "accumulation": self._out["accumulation"], "depth": self._out["depth"]}
+
+
+class CpuNgpRunner:
+    """The runner interface ngp_trainer.NgpTrainer drives (ngp_step.NgpTrainStep): set_batch with ANY number of rays, forward,
+    loss, backward into the parameters' `.grad` (the engine binds views of the arena's gradient; the table's gradient is
+    WRITTEN, the others accumulate), outputs, `num_kept`, `target`. The numbers come from the module path of the same model
+    (plugin.HipNGPModel under the reference's Model.forward / get_loss_dict) over tests/cpu_kernels.py."""
+
+    def __init__(self, model, num_rays, device, bundle_cls, seed_base=0):
+        self.model, self.n, self.bundle_cls = model, int(num_rays), bundle_cls
+        self.seed_base, self.iterations = seed_base, 0
+        self.sizes, self.num_kept = [], 0
+        self.target = None
+        self._out = self._loss = None
+
+    def set_batch(self, origins, directions, camera_indices, target=None, nears=None, fars=None):
+        self.origins, self.directions = origins.reshape(-1, 3).clone(), directions.reshape(-1, 3).clone()
+        self.cams = camera_indices.reshape(-1).clone()
+        self.n = self.origins.shape[0]
+        self.sizes.append(self.n)
+        if target is not None:
+            self.target = target.reshape(-1, 3).clone()
+
+    def forward(self, jitter=None):
+        torch.manual_seed(self.seed_base + self.iterations)  # the sampler's and the loss's torch.rand draws of this iteration
+        self.iterations += 1
+        rb = self.bundle_cls(origins=self.origins, directions=self.directions, pixel_area=torch.full((self.n, 1), 1e-6),
+                             camera_indices=self.cams[:, None])
+        self._out = self.model(rb)
+        self.num_kept = int(self._out["num_samples_per_ray"].sum())
+
+    def loss(self, background=None):
+        self._loss = self.model.get_loss_dict(self._out, {"image": self.target})["rgb_loss"]
+        return self._loss.detach()
+
+    def backward(self):
+        table = self.model.field.mlp_base.encoding.hash_table
+        table.grad.zero_()  # (the schedule's scatter writes the table's gradient, ngp_step.py)
+        self._loss.backward()
+
+    def outputs(self):
+        o = self._out
+        return {"rgb": o["rgb"].detach(), "accumulation": o["accumulation"].detach(), "depth": o["depth"].detach(),
+                "num_samples_per_ray": o["num_samples_per_ray"]}

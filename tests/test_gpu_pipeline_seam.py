@@ -198,3 +198,103 @@ def test_camera_optimizer_on_graph_replay_equals_eager(F):
     for other, what in ((e, "eager launches"), (o, "the camera parts outside the graph")):
         for name, x, y in zip(("parameters", "exp_avg", "exp_avg_sq"), g[:3], other[:3]):
             assert torch.equal(x, y), f"{name}: {int((x != y).sum())} elements differ between graph replay and {what}"
+
+
+def test_ngp_schedule_through_the_dynamic_batch_seam_same_bits_as_direct(F):
+    """`instant-ngp-hip` (BASELINE configs[3]) behind ITS seam: the restated reference trainer -> pipeline.DynamicBatchSeam
+    (what HipDynamicBatchPipeline adds to the reference's DynamicBatchPipeline, pipelines/dynamic_batch.py:40-108) ->
+    pipeline.NgpEngine -> ngp_trainer.NgpTrainer over the explicit packed-sample schedule, the ray batch RESIZED after every
+    iteration by the reference's rule from the samples the iteration kept — against ngp_trainer.NgpTrainer driven directly on
+    the same batches with the same learning rates: same parameter and moment bits. HipDynamicBatchPipeline itself runs under
+    the reference's own trainer and pipeline code in tests/test_ngp_pipeline_seam_cpu.py."""
+    import bench
+    from scripts.bench_ngp import build_ngp_model
+
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.cameras.rays import RayBundle
+    from nerfstudio_amd.ngp_trainer import NgpTrainer
+    from nerfstudio_amd.pipeline import DynamicBatchSeam
+
+    dev = torch.device("cuda")
+    K, STEP0 = 7, 513  # (past the grid's warm-up; no refresh step among them: the refresh is the model's callback, tested elsewhere)
+    TARGET, MAX_PER_RAY = 1 << 16, 1 << 5  # -> 2048 rays in the first batch
+    parts = [bench.synthetic_rays(1000 + i) for i in range(4)]
+    pool = [torch.from_numpy(np.concatenate([p[j] for p in parts])).to(dev) for j in range(4)]
+    total = pool[0].shape[0]
+
+    def batch_of_size(step, n):
+        n = min(int(n), total)
+        lo = (step * 997) % (total - n + 1)
+        o, d, cam, tgt = (x[lo:lo + n] for x in pool)
+        return RayBundle(origins=o, directions=d, pixel_area=torch.full((n, 1), 1e-6, device=dev), camera_indices=cam), {"image": tgt}
+
+    # ---- route 1: the restated reference trainer -> the dynamic-batch seam -> the engine
+    F._SCATTER_WS.clear()
+    model, _ = build_ngp_model(dev)
+    groups = {"fields": list(model.field.parameters())}
+    opts = R.Optimizers(_opt_config(groups), groups)
+    sizes = []
+
+    class SeamPipeline(DynamicBatchSeam):
+        def __init__(self):
+            self.config = SimpleNamespace(target_num_samples=TARGET, max_num_samples_per_ray=MAX_PER_RAY)
+            self.dynamic_num_rays_per_batch = TARGET // MAX_PER_RAY
+            self.sampler = SimpleNamespace(num_rays_per_batch=self.dynamic_num_rays_per_batch)
+            self.datamanager = SimpleNamespace(next_train=self.next_train, train_pixel_sampler=self.sampler)
+            self.model = self._model = model
+            self.world_size = 1
+
+        def next_train(self, step):
+            sizes.append(min(self.sampler.num_rays_per_batch, total))
+            return batch_of_size(step, sizes[-1])
+
+        def _update_dynamic_num_rays_per_batch(self, num_samples_per_batch):  # pipelines/dynamic_batch.py:71-76
+            self.dynamic_num_rays_per_batch = int(self.dynamic_num_rays_per_batch * (self.config.target_num_samples / num_samples_per_batch))
+
+        def _update_pixel_samplers(self):  # :64-69
+            self.sampler.num_rays_per_batch = self.dynamic_num_rays_per_batch
+
+    pipeline = SeamPipeline()
+    trainer = _fake_trainer(pipeline, opts)
+    pipeline.attach_optimizers(opts, trainer)
+    torch.manual_seed(77)  # (the lattice offsets and the loss's random background are torch draws on the device, in launch order)
+    losses, kept, lrs = [], [], []
+    for i in range(K):
+        lrs.append(float(opts.optimizers["fields"].param_groups[0]["lr"]))
+        loss, loss_dict, metrics = R.train_iteration(trainer, STEP0 + i)
+        losses.append(float(loss))
+        kept.append(int(metrics["num_samples_per_batch"]))
+        assert set(loss_dict) == {"rgb_loss"} and {"psnr", "num_samples_per_batch", "num_rays_per_batch"} <= set(metrics)
+        assert int(metrics["num_rays_per_batch"]) == pipeline.sampler.num_rays_per_batch
+    eng = pipeline._engine
+    assert eng.reason is None and isinstance(eng.trainer, NgpTrainer) and eng.trainer.runner is not None
+    assert all(p.grad is None for p in groups["fields"]), "the torch optimiser must find nothing to step"
+    assert kept == eng.trainer.samples and len(set(sizes)) > 1, (sizes, kept)
+    n = TARGET // MAX_PER_RAY
+    for i in range(K):  # the reference's rule, fed by the schedule's own count
+        assert sizes[i] == min(n, total), (i, sizes, kept)
+        n = int(n * (TARGET / kept[i]))
+    torch.cuda.synchronize()
+    a1 = eng.arena
+    got = (a1.flat.clone(), a1.exp_avg.clone(), a1.exp_avg_sq.clone(), dict(a1.step_counts))
+    assert got[3] == {"fields": K}
+    sd = opts.optimizers["fields"].state_dict()  # what the reference's checkpoint code would save
+    assert all(float(s["step"]) == K for s in sd["state"].values())
+    assert np.isfinite(losses).all()
+    del eng, pipeline, trainer, opts, model
+    # ---- route 2: the trainer driven directly on the same batches, the same learning rates
+    F._SCATTER_WS.clear()
+    model, _ = build_ngp_model(dev)
+    arena = ParamArena({"fields": list(model.field.parameters())}, lr=1e-2, eps=1e-15)
+    tr = NgpTrainer(model, arena, sizes[0], dev, refresh=False)
+    torch.manual_seed(77)
+    ref_losses = []
+    for i in range(K):
+        arena.lr = lrs[i]
+        tr.set_batch(*batch_of_size(STEP0 + i, sizes[i]))
+        ref_losses.append(float(tr.train_iteration(STEP0 + i)))
+    torch.cuda.synchronize()
+    assert tr.samples == kept
+    assert torch.equal(got[0], arena.flat), "parameters differ between the seam and the direct route"
+    assert torch.equal(got[1], arena.exp_avg) and torch.equal(got[2], arena.exp_avg_sq)
+    np.testing.assert_allclose(losses, ref_losses, rtol=1e-6)
