@@ -62,7 +62,12 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_fwd_kernel(const float*
 // proposal networks get no gradient (ray_samplers.py:590: most steps after warm-up), and only written on the others
 // (the backward's weight gradient needs them). Same operation order as hash_encode_fwd_kernel + density_mlp_fwd_kernel:
 // bit-identical outputs. The proposal tables (5 levels x 2^17 entries x 8 B = 5 MB) sit in every XCD's L2.
-template <int LEVELS, int H>
+// kLanePair (NSAMD_DENSITY_LANE_PAIR=1, opt-in): density_point_paired — the x-neighbours of a cell edge fetched by adjacent
+// lanes of one instruction, the arrangement that takes the main grid's forward from 76 to 63 us (csrc/hashgrid.hip). Here it
+// is SLOWER (37.2 -> 46.6 us on the 256-sample level, 24.6 -> 25.8 us on the 96-sample level, profiles/r05_s16_*): the proposal
+// grids are coarse against the sample spacing, adjacent lanes already share their lines, and the exchange's 154 registers cost
+// a wave per SIMD. Same bits; kept as the record of the measurement.
+template <int LEVELS, int H, bool kLanePair>
 __global__ __launch_bounds__(kMlpBlock) void density_field_fwd_kernel(nsamd_points P, int64_t M, int transform,
                                                                       nsamd_aabb box, const float2* __restrict__ table,
                                                                       nsamd_grid grid, nsamd_density_mlp mlp,
@@ -71,6 +76,13 @@ __global__ __launch_bounds__(kMlpBlock) void density_field_fwd_kernel(nsamd_poin
                                                                       float* __restrict__ density,
                                                                       float* __restrict__ pre_out) {
   const int64_t p = (int64_t)blockIdx.x * kMlpBlock + threadIdx.x;
+  if (kLanePair) {  // (every lane stays: its neighbour of the lane pair needs it for the exchange)
+    const bool live = p < M;
+    float x, y, z;
+    load_position(P, live ? p : M - 1, x, y, z);
+    density_point_paired<LEVELS, H>(x, y, z, p, M, live, transform, box, table, grid, mlp, enc_out, selector_out, density, pre_out);
+    return;
+  }
   if (p >= M) return;
   float x, y, z;
   load_position(P, p, x, y, z);
@@ -403,21 +415,26 @@ extern "C" int nsamd_density_field_fwd(nsamd_points pts, int64_t M, int transfor
   const int64_t nb = (M + kMlpBlock - 1) / kMlpBlock;
   if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
   const float2* t2 = reinterpret_cast<const float2*>(table);
+  static const bool lane_pair = [] { const char* e = getenv("NSAMD_DENSITY_LANE_PAIR"); return e != nullptr && atoi(e) != 0; }();
+#define NSAMD_DENSITY_FWD(L_, H_)                                                                                              \
+  if (lane_pair)                                                                                                               \
+    density_field_fwd_kernel<L_, H_, true><<<(unsigned)nb, kMlpBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, t2, grid, \
+                                                                                              mlp, enc, selector, density, pre); \
+  else                                                                                                                         \
+    density_field_fwd_kernel<L_, H_, false><<<(unsigned)nb, kMlpBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, t2, grid, \
+                                                                                               mlp, enc, selector, density, pre)
   if (grid.num_levels == 5 && mlp.hidden == 16) {
-    density_field_fwd_kernel<5, 16><<<(unsigned)nb, kMlpBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, t2, grid, mlp,
-                                                                                     enc, selector, density, pre);
+    NSAMD_DENSITY_FWD(5, 16);
   } else if (grid.num_levels == 8 && mlp.hidden == 16) {
-    density_field_fwd_kernel<8, 16><<<(unsigned)nb, kMlpBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, t2, grid, mlp,
-                                                                                     enc, selector, density, pre);
+    NSAMD_DENSITY_FWD(8, 16);
   } else if (grid.num_levels == 5 && mlp.hidden == 64) {
-    density_field_fwd_kernel<5, 64><<<(unsigned)nb, kMlpBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, t2, grid, mlp,
-                                                                                     enc, selector, density, pre);
+    NSAMD_DENSITY_FWD(5, 64);
   } else if (grid.num_levels == 8 && mlp.hidden == 64) {
-    density_field_fwd_kernel<8, 64><<<(unsigned)nb, kMlpBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, t2, grid, mlp,
-                                                                                     enc, selector, density, pre);
+    NSAMD_DENSITY_FWD(8, 64);
   } else {
     return NSAMD_ERR_UNSUPPORTED;  // callers fall back to nsamd_hashgrid_encode_fwd + nsamd_density_mlp_fwd
   }
+#undef NSAMD_DENSITY_FWD
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

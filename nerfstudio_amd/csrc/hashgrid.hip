@@ -32,6 +32,7 @@
 
 #include "common.h"
 #include "scatter.h"
+#include "wave.h"
 
 namespace nsamd {
 
@@ -166,6 +167,92 @@ __global__ __launch_bounds__(kHashBlock) void hash_encode_fwd_v2_kernel(nsamd_po
   o[stride_k] = r[1];
   // (behind the gathers: vector memory operations retire in order and stores count — in front of them the selector store
   //  would have to complete before the first gathered value may be used)
+  if (level == 0 && selector != nullptr) selector[p] = sel;
+}
+
+// kLanePair (NSAMD_HASH_FWD_MODE bit 4; round 5). What a divergent gather costs on this part is the number of distinct 128-B
+// LINES a wave instruction touches — ~0.47 lines per clock and CU whatever the access width, and lanes that share a line are
+// free (scripts/probe_gather.hip, profiles/r05_s14_probe_gather.txt: pairs of lanes on one line 2 x, quads 4 x the lane rate;
+// the forward at fine levels runs the address unit 91 % busy, profiles/r05_s13_hash_fwd_cache_counters.txt). The two
+// x-neighbours of a cell edge sit in ONE line 15 times out of 16 (their indices differ by lo ^ hi = 2^(k+1) - 1, k = trailing
+// ones of lo; a line holds 16 entries) but, fetched by the same lane in two instructions, the second fetch pays for the line
+// again (6 lines per point and level with the pair gathers above). Here lanes 2i and 2i + 1 work on ONE point at a time — the
+// even lane fetches the four lo-x corners, the odd lane the four hi-x corners, in the same four instructions — first on the even
+// lane's point, then on the odd lane's: 8 gather instructions of 32 points x ~1.06 lines instead of 4 x 64 + 4 x 32, i.e.
+// 4.25 lines per point and level. The neighbour's cell hashes and the fetched values cross the lane pair as DPP quad_perm
+// moves (VALU rate, no LDS); every lane then blends its own point exactly as before: same operations, same bits.
+template <bool kXcd>
+__global__ __launch_bounds__(kHashBlock) void hash_encode_fwd_v3_kernel(nsamd_points P, int64_t M, int transform,
+                                                                        nsamd_aabb box, const float2* __restrict__ table,
+                                                                        nsamd_grid grid, float* __restrict__ enc,
+                                                                        int64_t stride_p, int64_t stride_k,
+                                                                        float* __restrict__ selector, unsigned nb) {
+  int level;
+  int64_t pb;
+  if (kXcd) {
+    const unsigned xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
+    const unsigned li = q / nb;
+    pb = q - li * nb;
+    level = (li & 1u) ? (int)(8u * li + 7u - xcd) : (int)(8u * li + xcd);
+    if (level >= grid.num_levels) return;  // (block-uniform)
+  } else {
+    level = blockIdx.y;
+    pb = blockIdx.x;
+  }
+  const int64_t p = pb * kHashBlock + threadIdx.x;
+  const bool live = p < M;
+  float x, y, z;
+  load_position_burst(P, live ? p : M - 1, x, y, z);  // (every lane stays: its neighbour needs it for the exchange)
+  const float sel = normalise_position(transform, box, x, y, z);
+  const uint32_t mask = (1u << grid.log2_table_size) - 1u;
+  const Cell c = locate_cell(x, y, z, grid.scalings[level]);
+  const float2* __restrict__ tl = table + ((size_t)level << grid.log2_table_size);
+  const bool odd = (threadIdx.x & 1u) != 0u;
+  // this lane's x index in either round, the y / z hash terms of the point the round works on
+  const uint32_t hy0 = (uint32_t)c.lo[1] * kPrimeY, hy1 = (uint32_t)c.hi[1] * kPrimeY;
+  const uint32_t hz0 = (uint32_t)c.lo[2] * kPrimeZ, hz1 = (uint32_t)c.hi[2] * kPrimeZ;
+  // what the neighbour needs of this lane's cell: the x index of ITS side (even neighbour: lo, odd neighbour: hi) and the terms
+  const uint32_t x_for_nb = odd ? (uint32_t)c.lo[0] : (uint32_t)c.hi[0];  // (an odd lane's neighbour is even -> takes lo)
+  const uint32_t nx = pair_swap_u32(x_for_nb);
+  const uint32_t ny0 = pair_swap_u32(hy0), ny1 = pair_swap_u32(hy1), nz0 = pair_swap_u32(hz0), nz1 = pair_swap_u32(hz1);
+  const uint32_t own_x = odd ? (uint32_t)c.hi[0] : (uint32_t)c.lo[0];
+  // round E: the even lane's point (own for even lanes, the neighbour's for odd ones); round O: the odd lane's point
+  const uint32_t ex = odd ? nx : own_x, ey0 = odd ? ny0 : hy0, ey1 = odd ? ny1 : hy1, ez0 = odd ? nz0 : hz0, ez1 = odd ? nz1 : hz1;
+  const uint32_t ox = odd ? own_x : nx, oy0 = odd ? hy0 : ny0, oy1 = odd ? hy1 : ny1, oz0 = odd ? hz0 : nz0, oz1 = odd ? hz1 : nz1;
+  // corner pair q: (y, z) = (lo, lo), (hi, lo), (lo, hi), (hi, hi) — v0/v1, v2/v3, v4/v5, v6/v7 of the kernels above
+  const float2 e0 = tl[(ex ^ ey0 ^ ez0) & mask], e1 = tl[(ex ^ ey1 ^ ez0) & mask], e2 = tl[(ex ^ ey0 ^ ez1) & mask],
+               e3 = tl[(ex ^ ey1 ^ ez1) & mask];
+  const float2 o0 = tl[(ox ^ oy0 ^ oz0) & mask], o1 = tl[(ox ^ oy1 ^ oz0) & mask], o2 = tl[(ox ^ oy0 ^ oz1) & mask],
+               o3 = tl[(ox ^ oy1 ^ oz1) & mask];
+  // hand the neighbour what was fetched for ITS point (even lanes: round O, odd lanes: round E), keep the own round
+  auto swap2 = [&](const float2& a, const float2& b) {
+    const float2 send = odd ? a : b;  // (a: round E value, b: round O value)
+    return make_float2(pair_swap_f32(send.x), pair_swap_f32(send.y));
+  };
+  const float2 r0 = swap2(e0, o0), r1 = swap2(e1, o1), r2 = swap2(e2, o2), r3 = swap2(e3, o3);
+  // own point's corners: even lane = (lo-x: own round E, hi-x: received), odd lane = (lo-x: received, hi-x: own round O)
+  const float2 v0 = odd ? r0 : e0, v1 = odd ? o0 : r0;
+  const float2 v2 = odd ? r1 : e1, v3 = odd ? o1 : r1;
+  const float2 v4 = odd ? r2 : e2, v5 = odd ? o2 : r2;
+  const float2 v6 = odd ? r3 : e3, v7 = odd ? o3 : r3;
+  const float wx = c.w[0], wy = c.w[1], wz = c.w[2];
+  const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+  float r[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    auto g = [&](const float2& a) { return f == 0 ? a.x : a.y; };
+    const float yc_zc = g(v7) * wx + g(v6) * ux;  // blend order x, y, z exactly as encodings.py:446-456
+    const float yf_zc = g(v5) * wx + g(v4) * ux;
+    const float yf_zf = g(v1) * wx + g(v0) * ux;
+    const float yc_zf = g(v3) * wx + g(v2) * ux;
+    const float zc = yc_zc * wy + yf_zc * uy;
+    const float zf = yc_zf * wy + yf_zf * uy;
+    r[f] = zc * wz + zf * uz;
+  }
+  if (!live) return;
+  float* o = enc + p * stride_p + (int64_t)(2 * level) * stride_k;
+  o[0] = r[0];
+  o[stride_k] = r[1];
   if (level == 0 && selector != nullptr) selector[p] = sel;
 }
 
@@ -482,14 +569,22 @@ extern "C" int nsamd_hashgrid_encode_fwd(nsamd_points pts, int64_t M, int transf
     hash_encode_fwd_kernel<2><<<g, kHashBlock, 0, (hipStream_t)stream>>>(
         pts, M, transform, aabb, reinterpret_cast<const float2*>(table), grid, enc, stride_p, stride_k, selector);
   } else {
-    // pair gathers + XCD-aware level sweep: 83.8 -> 78.8 us on the main grid (81.5 with either alone), same arithmetic
-    static const int mode = env_int("NSAMD_HASH_FWD_MODE", 3);
+    // pair gathers + XCD-aware level sweep (mode 3): 83.8 -> 78.8 us on the main grid (81.5 with either alone); lane pairs on
+    // one line + the XCD-aware sweep (mode 7, round 5): 76.1 -> 63.3 us on one box, a fine level 5.5 -> 4.4 us
+    // (profiles/r05_s15_*). Same arithmetic in every mode.
+    static const int mode = env_int("NSAMD_HASH_FWD_MODE", 7);
     const float2* t2 = reinterpret_cast<const float2*>(table);
     const dim3 g2((unsigned)nb, (unsigned)grid.num_levels);
     const int64_t xcd_blocks = 8 * nb * ((grid.num_levels + 7) / 8);
     const bool xcd = (mode & 2) && grid.num_levels % 8 == 0 && xcd_blocks <= 0x7fffffffLL;
     const dim3 g1((unsigned)xcd_blocks);
-    if ((mode & 1) && xcd)
+    if ((mode & 4) && xcd)
+      hash_encode_fwd_v3_kernel<true><<<g1, kHashBlock, 0, (hipStream_t)stream>>>(
+          pts, M, transform, aabb, t2, grid, enc, stride_p, stride_k, selector, (unsigned)nb);
+    else if (mode & 4)
+      hash_encode_fwd_v3_kernel<false><<<g2, kHashBlock, 0, (hipStream_t)stream>>>(
+          pts, M, transform, aabb, t2, grid, enc, stride_p, stride_k, selector, (unsigned)nb);
+    else if ((mode & 1) && xcd)
       hash_encode_fwd_v2_kernel<true, true><<<g1, kHashBlock, 0, (hipStream_t)stream>>>(
           pts, M, transform, aabb, t2, grid, enc, stride_p, stride_k, selector, (unsigned)nb);
     else if (mode & 1)

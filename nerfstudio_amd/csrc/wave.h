@@ -60,4 +60,11 @@ __device__ __forceinline__ double wave_read_f64(double v) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
 }
 
+// Value of the neighbouring lane of the pair (2i, 2i + 1): DPP quad_perm [1, 0, 3, 2] — VALU rate, no LDS. All four lanes of
+// the quad must be active.
+__device__ __forceinline__ uint32_t pair_swap_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float pair_swap_f32(float v) { return __uint_as_float(pair_swap_u32(__float_as_uint(v))); }
+
 }  // namespace nsamd

@@ -135,6 +135,28 @@ def test_hashgrid_golden(F, golden):
     gclose(x.grad, g["dx"], 1e-4, "dx")
 
 
+def test_hashgrid_main_table_bit_exact_vs_oracle(F):
+    """The nerfacto MAIN grid (L = 16, 16 .. 2048, T = 2^19 — the table size that selects the one-level-per-thread forward with
+    its lane-pair gathers, csrc/hashgrid.hip) on an odd number of random points, points on lattice planes and on the box's
+    faces: features bit-identical to the oracle's torch expression (the kernel's blend is the reference's operation order,
+    encodings.py:417-458)."""
+    from nerfstudio_amd.field_components.encodings import HashEncoding
+
+    L, lo, hi, log2T = 16, 16, 2048, 19
+    enc = HashEncoding(num_levels=L, min_res=lo, max_res=hi, log2_hashmap_size=log2T).cuda()
+    rs = np.random.RandomState(11)
+    table = (rs.standard_normal((L * 2**log2T, 2)) * 0.1).astype(np.float32)
+    with torch.no_grad():
+        enc.hash_table.copy_(dev(table))
+    x = rs.uniform(0, 1, (30001, 3)).astype(np.float32)
+    x[:64] = np.round(x[:64] * 16) / 16          # on lattice planes of the coarsest level (lo == hi there)
+    x[64:96] = rs.randint(0, 2, (32, 3))          # the box's corners and faces
+    x[96:128, 0] = 1.0
+    out = enc(dev(x))
+    o = orc.hashgrid_encode(T(x), T(table), orc.hash_level_scalings(L, lo, hi), 2**log2T)
+    exact(out, o, "main-table hash features are not bit-identical to the oracle")
+
+
 def test_hashgrid_shapes_and_edges(F):
     """Reference test contract (tests/field_components/test_encodings.py:143-169): shape (10,16) for L=8,F=2; plus
     empty input and batch-shape preservation."""
