@@ -181,6 +181,8 @@ __global__ __launch_bounds__(kHashBlock) void hash_encode_fwd_v2_kernel(nsamd_po
 // lane's point, then on the odd lane's: 8 gather instructions of 32 points x ~1.06 lines instead of 4 x 64 + 4 x 32, i.e.
 // 4.25 lines per point and level. The neighbour's cell hashes and the fetched values cross the lane pair as DPP quad_perm
 // moves (VALU rate, no LDS); every lane then blends its own point exactly as before: same operations, same bits.
+// (Two points per lane on top of it — twice the gathers in flight, half the waves — changes nothing: 63.0 against 63.1 us,
+// profiles/r05_s17_*. What is left of a coarse level, 1.5 us, is the ~300 vector instructions of a (point, level) thread.)
 template <bool kXcd>
 __global__ __launch_bounds__(kHashBlock) void hash_encode_fwd_v3_kernel(nsamd_points P, int64_t M, int transform,
                                                                         nsamd_aabb box, const float2* __restrict__ table,
