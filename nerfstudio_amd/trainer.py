@@ -168,7 +168,7 @@ class HipTrainer:
                 self._sh_fork, self._sh_join = torch.cuda.Event(), torch.cuda.Event()
             mode = os.environ.get("NSAMD_STEP_PROLOGUE", "ring")
             mode = "ring" if mode == "1" else mode
-            if (mode in ("ring", "table") and self.on_gpu and not self.dp and runner is None
+            if (mode in ("ring", "table") and self.on_gpu and runner is None
                     and getattr(r, "single_jitter", False) and hasattr(r, "jitter")):
                 self.prologue = True
                 self.step_counter = torch.zeros(2, device=dev, dtype=torch.int64)  # [row, draw]
@@ -176,7 +176,10 @@ class HipTrainer:
                 # the batch slot must be read INSIDE the iteration body: with the camera parts outside the graph the batch is
                 # selected eagerly ahead of the replay, i.e. before the prologue would have written the slot (then: the upload
                 # for the scalars, the prologue for the draws only)
-                inside = not r.cameras_outside
+                # (the data-parallel segments keep the upload as well — their Adam launches are segments of their own, ordered by
+                #  the exchange — and take the DRAWS from the prologue: one generator for every schedule, so that a one-rank
+                #  data-parallel run trains through the bits of the single-GPU one)
+                inside = not r.cameras_outside and not self.dp
                 if mode == "ring" and inside:
                     self.prologue_ring = True
                     self.ring_host = torch.zeros(self.ring_rows, _HYPER_FLOATS).pin_memory()  # (device-visible: hipHostMalloc)
@@ -533,10 +536,11 @@ class HipTrainer:
         """The body of one captured segment (also what the eager path runs)."""
         r, a = self.runner, self.arena
         if name == "pfwd":
+            self._step_prologue()  # (the step's draws; the scalars were uploaded by `_prologue`)
             if not self._cams_outside:
                 self._select_batch()
                 r.apply_camera_corrections()
-            r.forward_proposals(self.draw_jitter)
+            r.forward_proposals(self.draw_jitter and not self.prologue)
         elif name in (("main", True), ("main", False)):
             if name[1] and self.dp_fork:
                 # update step, eager launches: the proposal chains start on their side streams here, beside the main chain
