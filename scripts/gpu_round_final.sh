@@ -5,7 +5,7 @@
 # cpu_baseline and the per-kernel table), then the instant-ngp / 300-step / steady-state / unbounded lines, eval render, the
 # one-rank data-parallel rehearsal.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r05_final}
+TAG=${1:-r05_final3}
 OUT=$R/gpurun_out/$TAG
 BUDGET_S=${BUDGET_S:-1150}
 T0=$(date +%s)
@@ -38,12 +38,12 @@ import json; j=json.load(open('$OUT/bench_seam.json'))
 print({k: j[k] for k in ('direct_pool_ms','direct_set_batch_ms','seam_ms','seam_over_direct_pool','seam_over_direct_pool_per_window')})" | tee -a $OUT/summary.txt
 fi
 if left; then
-say "== the merged launches that are opt-in (measured slower): one driver window each"
-for arm in NSAMD_FUSE_RAYS=1 NSAMD_FUSE_SAMPLER=1 NSAMD_REDUCE_RIDER=0; do
-  say "$arm: $(env $arm timeout 100 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --long-steps 0 --profile-steps 1 2>/dev/null | python -c 'import sys,json
+say "== what the round's later changes are worth on THIS box: one driver window each with the head of the iteration / the hash forward of the round's first evidence session"
+for arm in NSAMD_STEP_PROLOGUE=0 NSAMD_HASH_FWD_MODE=3 "NSAMD_STEP_PROLOGUE=0 NSAMD_HASH_FWD_MODE=3"; do
+  say "$arm: $(env $arm timeout 100 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --long-steps 100 --profile-steps 1 2>/dev/null | python -c 'import sys,json
 for l in sys.stdin:
     if l.startswith("{"):
-        d=json.loads(l); print(d["ms_per_step"], d["value"])')"
+        d=json.loads(l); print(d["ms_per_step"], d["value"], "long", (d.get("long_run") or {}).get("ms_per_step"))')"
 done
 fi
 if left; then
