@@ -29,53 +29,28 @@ class HashMLPDensityField(Field):
 
     aabb: Tensor
 
-    def __init__(
-        self,
-        aabb: Tensor,
-        num_layers: int = 2,
-        hidden_dim: int = 64,
-        spatial_distortion: Optional[SpatialDistortion] = None,
-        use_linear: bool = False,
-        num_levels: int = 8,
-        max_res: int = 1024,
-        base_res: int = 16,
-        log2_hashmap_size: int = 18,
-        features_per_level: int = 2,
-        average_init_density: float = 1.0,
-        implementation: Literal["hip"] = "hip",
-    ) -> None:
+    def __init__(self, aabb: Tensor, num_layers: int = 2, hidden_dim: int = 64,
+                 spatial_distortion: Optional[SpatialDistortion] = None, use_linear: bool = False, num_levels: int = 8,
+                 max_res: int = 1024, base_res: int = 16, log2_hashmap_size: int = 18, features_per_level: int = 2,
+                 average_init_density: float = 1.0, implementation: Literal["hip"] = "hip") -> None:
         super().__init__()
         check_implementation(implementation, "HashMLPDensityField")
         if not use_linear and num_layers != 2:
             raise ValueError("the hip density head is MLP(num_layers=2): in -> hidden -> 1")
-        self.register_buffer("aabb", aabb)
-        self.spatial_distortion = spatial_distortion
-        self.use_linear = use_linear
-        self.average_init_density = average_init_density
-        self.register_buffer("max_res", torch.tensor(max_res))
-        self.register_buffer("num_levels", torch.tensor(num_levels))
-        self.register_buffer("log2_hashmap_size", torch.tensor(log2_hashmap_size))
-        self.encoding = HashEncoding(
-            num_levels=num_levels,
-            min_res=base_res,
-            max_res=max_res,
-            log2_hashmap_size=log2_hashmap_size,
-            features_per_level=features_per_level,
-            implementation=implementation,
-        )
-        if not self.use_linear:
-            network = MLP(
-                in_dim=self.encoding.get_out_dim(),
-                num_layers=num_layers,
-                layer_width=hidden_dim,
-                out_dim=1,
-                activation=nn.ReLU(),
-                out_activation=None,
-                implementation=implementation,
-            )
-            self.mlp_base = torch.nn.Sequential(self.encoding, network)
-        else:  # density_fields.py:81-84: one dense layer on the hash features
-            self.linear = torch.nn.Linear(self.encoding.get_out_dim(), 1)
+        # state-dict contract of the reference (density_fields.py:63-71): the scene box and three grid hyper-parameters are buffers
+        for name, value in (("aabb", aabb), ("max_res", torch.tensor(max_res)), ("num_levels", torch.tensor(num_levels)),
+                            ("log2_hashmap_size", torch.tensor(log2_hashmap_size))):
+            self.register_buffer(name, value)
+        self.spatial_distortion, self.use_linear, self.average_init_density = spatial_distortion, use_linear, average_init_density
+        grid = HashEncoding(num_levels=num_levels, min_res=base_res, max_res=max_res, log2_hashmap_size=log2_hashmap_size,
+                            features_per_level=features_per_level, implementation=implementation)
+        self.encoding = grid
+        if use_linear:  # density_fields.py:81-84: one dense layer on the hash features
+            self.linear = torch.nn.Linear(grid.get_out_dim(), 1)
+        else:  # `mlp_base.0` is the grid, `mlp_base.1` the two-layer head: the reference's parameter names
+            head = MLP(in_dim=grid.get_out_dim(), num_layers=num_layers, layer_width=hidden_dim, out_dim=1, activation=nn.ReLU(),
+                       out_activation=None, implementation=implementation)
+            self.mlp_base = torch.nn.Sequential(grid, head)
         self._transform = transform_of(spatial_distortion)
         self._box = N.make_aabb(aabb)  # host copy of the scene box: no device sync on the hot path
 

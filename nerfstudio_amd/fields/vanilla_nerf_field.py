@@ -16,64 +16,51 @@ from .base_field import Field, point_spec
 
 
 class NeRFField(Field):
-    """Arguments as the reference (vanilla_nerf_field.py:45-58). Integrated encodings and temporal / spatial distortions
-    of the sample positions are not built (the vanilla-nerf method config uses neither)."""
+    """The reference's constructor contract (vanilla_nerf_field.py:45-58: argument names, defaults, sub-module names — what
+    the method config and a checkpoint's state dict address). Integrated encodings and temporal / spatial distortions of the
+    sample positions are not built (the vanilla-nerf method config uses neither)."""
 
-    def __init__(
-        self,
-        position_encoding: Encoding = Identity(in_dim=3),
-        direction_encoding: Encoding = Identity(in_dim=3),
-        base_mlp_num_layers: int = 8,
-        base_mlp_layer_width: int = 256,
-        head_mlp_num_layers: int = 2,
-        head_mlp_layer_width: int = 128,
-        skip_connections: Tuple[int] = (4,),
-        field_heads: Optional[Tuple[Type[FieldHead]]] = (RGBFieldHead,),
-        use_integrated_encoding: bool = False,
-        spatial_distortion: Optional[SpatialDistortion] = None,
-    ) -> None:
+    def __init__(self, position_encoding: Encoding = Identity(in_dim=3), direction_encoding: Encoding = Identity(in_dim=3),
+                 base_mlp_num_layers: int = 8, base_mlp_layer_width: int = 256, head_mlp_num_layers: int = 2,
+                 head_mlp_layer_width: int = 128, skip_connections: Tuple[int] = (4,),
+                 field_heads: Optional[Tuple[Type[FieldHead]]] = (RGBFieldHead,), use_integrated_encoding: bool = False,
+                 spatial_distortion: Optional[SpatialDistortion] = None) -> None:
         super().__init__()
-        if use_integrated_encoding:
-            raise NotImplementedError("integrated (mip-NeRF) encodings are not built for the hip backend")
-        if spatial_distortion is not None:
-            raise NotImplementedError("NeRFField(spatial_distortion=...) is not built for the hip backend")
-        self.position_encoding = position_encoding
-        self.direction_encoding = direction_encoding
-        self.use_integrated_encoding = use_integrated_encoding
-        self.spatial_distortion = spatial_distortion
-        self.mlp_base = MLP(
-            in_dim=self.position_encoding.get_out_dim(),
-            num_layers=base_mlp_num_layers,
-            layer_width=base_mlp_layer_width,
-            skip_connections=skip_connections,
-            out_activation=nn.ReLU(),
-        )
-        self.field_output_density = DensityFieldHead(in_dim=self.mlp_base.get_out_dim())
-        if field_heads:
-            self.mlp_head = MLP(
-                in_dim=self.mlp_base.get_out_dim() + self.direction_encoding.get_out_dim(),
-                num_layers=head_mlp_num_layers,
-                layer_width=head_mlp_layer_width,
-                out_activation=nn.ReLU(),
-            )
-        self.field_heads = nn.ModuleList([field_head() for field_head in field_heads] if field_heads else [])
-        for field_head in self.field_heads:
-            field_head.set_in_dim(self.mlp_head.get_out_dim())
+        for refused, what in ((use_integrated_encoding, "integrated (mip-NeRF) encodings are"),
+                              (spatial_distortion is not None, "NeRFField(spatial_distortion=...) is")):
+            if refused:
+                raise NotImplementedError(f"{what} not built for the hip backend")
+        self.position_encoding, self.direction_encoding = position_encoding, direction_encoding
+        self.use_integrated_encoding, self.spatial_distortion = False, None
+        width_in, width_dir = position_encoding.get_out_dim(), direction_encoding.get_out_dim()
+        # trunk: frequency-encoded position -> features (ReLU on the last layer too), density read off the features
+        self.mlp_base = MLP(in_dim=width_in, num_layers=base_mlp_num_layers, layer_width=base_mlp_layer_width,
+                            skip_connections=skip_connections, out_activation=nn.ReLU())
+        features = self.mlp_base.get_out_dim()
+        self.field_output_density = DensityFieldHead(in_dim=features)
+        # colour branch, only when a head asks for it: [encoded direction, features] -> head MLP -> the heads
+        heads = [make() for make in (field_heads or ())]
+        if heads:
+            self.mlp_head = MLP(in_dim=features + width_dir, num_layers=head_mlp_num_layers, layer_width=head_mlp_layer_width,
+                                out_activation=nn.ReLU())
+        self.field_heads = nn.ModuleList(heads)
+        for head in heads:
+            head.set_in_dim(self.mlp_head.get_out_dim())
 
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, Tensor]:
         spec, shape = point_spec(ray_samples)
-        if isinstance(self.position_encoding, NeRFEncoding):
-            encoded_xyz = self.position_encoding.spec_forward(spec)  # midpoints o + d (s + e) / 2 formed in the kernel
+        enc = self.position_encoding
+        if isinstance(enc, NeRFEncoding):
+            x = enc.spec_forward(spec)  # midpoints o + d (s + e) / 2 formed in the kernel
         else:
-            encoded_xyz = self.position_encoding(ray_samples.frustums.get_positions().reshape(-1, 3))
-        base_mlp_out = self.mlp_base(encoded_xyz)
-        density = self.field_output_density(base_mlp_out)
-        return density.view(*shape, 1), base_mlp_out.view(*shape, -1)
+            x = enc(ray_samples.frustums.get_positions().reshape(-1, 3))
+        features = self.mlp_base(x)
+        return self.field_output_density(features).view(*shape, 1), features.view(*shape, -1)
 
     def get_outputs(self, ray_samples: RaySamples, density_embedding: Optional[Tensor] = None) -> Dict[FieldHeadNames, Tensor]:
-        outputs = {}
-        for field_head in self.field_heads:
-            encoded_dir = self.direction_encoding(ray_samples.frustums.directions)
-            mlp_out = self.mlp_head(torch.cat([encoded_dir, density_embedding], dim=-1))
-            outputs[field_head.field_head_name] = field_head(mlp_out)
-        return outputs
+        if len(self.field_heads) == 0:
+            return {}
+        # (one head MLP evaluation serves every head: the reference recomputes the identical tensor per head, :119-124)
+        view = self.direction_encoding(ray_samples.frustums.directions)
+        hidden = self.mlp_head(torch.cat([view, density_embedding], dim=-1))
+        return {head.field_head_name: head(hidden) for head in self.field_heads}
