@@ -532,6 +532,9 @@ class NerfactoTrainStep:
         else:
             ck(lib.nsamd_piecewise_bins(N.ptr(self.nears), N.ptr(self.fars), N.ptr(self.edges), N.ptr(jit0), int(per_edge), n,
                                         S0, self.spacing, N.ptr(self.s_bins[0]), N.ptr(self.t_bins[0]), st), "piecewise_bins")
+        hook, self.after_bins = getattr(self, "after_bins", None), None
+        if hook is not None:  # (trainer.HipTrainer: the point where the pending main-field Adam is forked off, NSAMD_FORK_AFTER_BINS)
+            hook()
         # ---- proposal levels ----
         for lvl in range(self.n_prop):
             net = self.props[lvl]

@@ -162,6 +162,7 @@ class HipTrainer:
             # NSAMD_DEFER_SCATTER=1 (opt-in, measured and NOT adopted: profiles/r03_negative_results.txt item 8) defers the
             # main TABLE SCATTER of iteration k as well, beside [select batch, proposal forward k+1]; same bits, 1-2 % slower.
             self.defer_scatter = self.defer and os.environ.get("NSAMD_DEFER_SCATTER", "0") == "1"
+            self.fork_after_bins = os.environ.get("NSAMD_FORK_AFTER_BINS", "0") == "1"
             if self.defer:
                 self.opt_stream = torch.cuda.Stream(device=dev)
                 self._opt_fork, self._opt_join = torch.cuda.Event(), torch.cuda.Event()
@@ -439,17 +440,26 @@ class HipTrainer:
                 # nothing before the join below writes a gradient
                 self._zero(updated)
 
-        if beside:
+        def fork():
             self._opt_fork.record(main)
             self.opt_stream.wait_event(self._opt_fork)
             with torch.cuda.stream(self.opt_stream):
                 pending_update()
                 self._opt_join.record(self.opt_stream)
-        elif pending:
+
+        # NSAMD_FORK_AFTER_BINS=1: the branch starts BEHIND the launch that selects the batch and writes the initial bins (8 MB of
+        # stores that read 45 us beside the HBM-saturating Adam and 14 us alone) instead of in front of it
+        late_fork = beside and self.fork_after_bins and not r.cameras_outside and getattr(r, "fuse_select", False) \
+            and not getattr(r, "fuse_sampler", False) and getattr(r, "cam_opt", None) is None
+        if beside and not late_fork:
+            fork()
+        elif pending and not beside:
             pending_update()
         if not r.cameras_outside:
             self._select_batch()
             r.apply_camera_corrections()
+        if late_fork:
+            r.after_bins = fork
         r.forward_proposals(draw, need_enc=updated)
         if beside:
             main.wait_event(self._opt_join)
