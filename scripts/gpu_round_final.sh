@@ -5,7 +5,7 @@
 # cpu_baseline and the per-kernel table), then the instant-ngp / 300-step / steady-state / unbounded lines, eval render, the
 # one-rank data-parallel rehearsal.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r05_final3}
+TAG=${1:-r05_final4}
 OUT=$R/gpurun_out/$TAG
 BUDGET_S=${BUDGET_S:-1150}
 T0=$(date +%s)
@@ -39,7 +39,7 @@ print({k: j[k] for k in ('direct_pool_ms','direct_set_batch_ms','seam_ms','seam_
 fi
 if left; then
 say "== what the round's later changes are worth on THIS box: one driver window each with the head of the iteration / the hash forward of the round's first evidence session"
-for arm in NSAMD_STEP_PROLOGUE=0 NSAMD_HASH_FWD_MODE=3 "NSAMD_STEP_PROLOGUE=0 NSAMD_HASH_FWD_MODE=3"; do
+for arm in NSAMD_ADAM_BLOCKS_PER_CU=8 "NSAMD_ADAM_BLOCKS_PER_CU=8 NSAMD_STEP_PROLOGUE=0" "NSAMD_ADAM_BLOCKS_PER_CU=8 NSAMD_HASH_FWD_MODE=3" "NSAMD_ADAM_BLOCKS_PER_CU=8 NSAMD_STEP_PROLOGUE=0 NSAMD_HASH_FWD_MODE=3"; do
   say "$arm: $(env $arm timeout 100 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --long-steps 100 --profile-steps 1 2>/dev/null | python -c 'import sys,json
 for l in sys.stdin:
     if l.startswith("{"):
