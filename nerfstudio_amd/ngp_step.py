@@ -66,6 +66,9 @@ class NgpTrainStep:
         self._grow_candidates(int(cap_candidates) if cap_candidates > 0 else 64 * n)  # (grown on demand)
         self._grow_kept(int(cap_kept) if cap_kept > 0 else 32 * n)
         self.num_candidates = self.num_kept = 0
+        # {id(parameter): gradient buffer} of a caller that keeps the gradients outside `param.grad` (arena.ParamArena.grad_lookup:
+        # pipeline.NgpEngine under a trainer whose own optimiser must find `.grad` None); None: `param.grad`
+        self.grad_lookup = None
         self.accumulate_table = False
         self.has_bounds = False
         bgc = model.renderer_rgb.background_color
@@ -292,6 +295,8 @@ class NgpTrainStep:
         table's, which the scatter writes."""
         fld = self.model.field
         table = fld.mlp_base.encoding.hash_table
+        if self.grad_lookup is not None:
+            return
         for p in fld.parameters():
             if p.grad is None:
                 p.grad = torch.empty_like(p) if (p is table and not self.accumulate_table) else torch.zeros_like(p)
@@ -312,7 +317,9 @@ class NgpTrainStep:
                                         N.ptr(self.k_dsigma), st), "packed_weights_bwd")
         params = [*fld.mlp_base.mlp.param_tensors(), *fld.mlp_head.param_tensors()]
         emb = fld.embedding_appearance.embedding.weight if fld.embedding_appearance is not None else None
-        grads = N.FieldMlpGrads(*(N.ptr(p.grad) for p in params), N.ptr(emb.grad) if (emb is not None and self._train_app) else None)
+        gl = self.grad_lookup
+        grad_of = (lambda p: gl[id(p)]) if gl is not None else (lambda p: p.grad)  # noqa: E731
+        grads = N.FieldMlpGrads(*(N.ptr(grad_of(p)) for p in params), N.ptr(grad_of(emb)) if (emb is not None and self._train_app) else None)
         fws, fws_n = F.field_bwd_workspace(self.dev)
         ck(lib.nsamd_field_mlp_bwd(N.ptr(self.k_enc), N.ptr(self.k_sel), N.ptr(self.k_dirs), N.ptr(self.k_cams) if self._train_app else None,
                                    N.ptr(self._app_const), 1, mk, self._field_mlp(), N.ptr(self.k_dsigma), N.ptr(self.k_drgb),
@@ -321,7 +328,7 @@ class NgpTrainStep:
         ws, ws_n = F._scatter_workspace(self.grid, self.dev, mk, write_only=write_only)
         fn = lib.nsamd_hashgrid_encode_bwd_set if write_only else lib.nsamd_hashgrid_encode_bwd
         ck(fn(N.make_points(positions=self.k_pos), mk, fld._transform, fld._box, N.ptr(table), self.grid.native(), N.ptr(self.k_denc), 1, mk,
-              N.ptr(table.grad), None, N.ptr(ws), ws_n, st), "hashgrid_encode_bwd")
+              N.ptr(grad_of(table)), None, N.ptr(ws), ws_n, st), "hashgrid_encode_bwd")
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -275,8 +275,8 @@ class TrainEngine:
 class NgpEngine(TrainEngine):
     """instant-ngp-hip: the arena (one optimiser group, models/instant_ngp.py:165-170) and ngp_trainer.NgpTrainer behind the
     trainer's `Optimizers`. Per iteration: the learning rate the reference's scheduler has set -> the arena's Adam; the
-    parameters' `.grad` are views of the arena's gradient for the duration of the iteration (the packed kernels accumulate into
-    them) and None again afterwards, so that the trainer's own optimiser finds nothing to step (engine/optimizers.py:160-172).
+    parameters' `.grad` stay None — the packed kernels write into the arena's gradient views (`NgpTrainStep.grad_lookup`) — so that
+    the trainer's own optimiser finds nothing to step (engine/optimizers.py:160-172).
     The occupancy refresh stays the model's BEFORE_TRAIN_ITERATION callback, run by the trainer."""
 
     def build(self, ray_bundle, batch) -> Optional[str]:
@@ -313,6 +313,11 @@ class NgpEngine(TrainEngine):
         model = self.pipeline.model
         runner = self.runner_factory(model, o.shape[0], o.device) if self.runner_factory is not None else None
         self.trainer = NgpTrainer(model, self.arena, o.shape[0], o.device, refresh=False, runner=runner)
+        # the kernel schedule writes into the arena's gradient views directly; a stand-in runner (tests: autograd over the module
+        # path) needs them as `param.grad` for the duration of the iteration
+        self._bind_grads = not hasattr(self.trainer.runner, "grad_lookup")
+        if not self._bind_grads:
+            self.trainer.runner.grad_lookup = self.arena.grad_lookup()
         if self.on_build is not None:
             self.on_build(self.trainer)
 
@@ -326,14 +331,16 @@ class NgpEngine(TrainEngine):
         if not image.is_cuda and ray_bundle.origins.is_cuda:
             image = image.to(ray_bundle.origins.device)
         rb = ray_bundle.reshape(-1) if ray_bundle.origins.dim() > 2 else ray_bundle
-        for p, g in self._grad_views:
-            p.grad = g
+        if self._bind_grads:
+            for p, g in self._grad_views:
+                p.grad = g
         try:
             t.set_batch(rb, {"image": image.reshape(-1, 3)})  # any number of rays: capacity-sized buffers (ngp_step.py)
             loss = t.train_iteration(step)
         finally:
-            for p, _ in self._grad_views:
-                p.grad = None
+            if self._bind_grads:
+                for p, _ in self._grad_views:
+                    p.grad = None
         r = t.runner
         outputs = r.outputs()
         loss_dict = {"rgb_loss": _AlreadyBackpropagated.apply(self._anchor, loss)[0]}
