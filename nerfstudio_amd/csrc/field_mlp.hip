@@ -669,16 +669,55 @@ __global__ __launch_bounds__(kFusedThreads, 1) void field_fused_fwd_kernel(
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------
+// Attribution builds (scripts/build_variant.sh x "-DNSAMD_FIELD_BWD_SKIP_CONST=n", timing only, results are wrong): the bits of
+// NSAMD_FIELD_BWD_SKIP as a compile-time constant in the PRODUCT kernel (the instrumented build's run-time switches cost
+// registers and scalar spills of their own), plus 64 = no scratch stores (and splits), 128 = no forward GEMMs.
+#ifndef NSAMD_FIELD_BWD_SKIP_CONST
+#define NSAMD_FIELD_BWD_SKIP_CONST 0
+#endif
+constexpr int kSkipConst = NSAMD_FIELD_BWD_SKIP_CONST;
+
 // store a chain-layout vector (T tiles of 16 features) as S[feature][point]: lane (j, g) register (t, r) is feature
 // 16t + 4g + r of point j. Feature-major, so that a weight-gradient MFMA operand — 4 consecutive POINTS of one feature —
 // is one ds_read_b128 (the point-major layout of round 1 cost one ds_read_b32 per MFMA operand, 2-3 LDS round trips per
 // 1-2 MFMAs, r02b: dW 54 us against 31 us of MFMA time).
+//
+// Round 6: the scratch holds every value as TWO bf16 pieces in its dword — high half h = bf16(x) (RNE), low half
+// m = bf16(x - h) (the residual is exact in fp32), x = h + m up to 2^-17 |x| — because the weight-gradient GEMMs run on the
+// bf16 matrix cores (coop_dw). Same addresses, same one ds_write_b32 per value as the fp32 scratch; 3.5 vector
+// instructions per value for the split (one v_cvt_pk_bf16_f32 forms the h of two values).
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& o0, unsigned& o1) {
+  const unsigned hh = pack_bf16(x0, x1);                              // low = h0, high = h1
+  const float r0 = x0 - __uint_as_float(hh << 16);                    // exact
+  const float r1 = x1 - __uint_as_float(hh & 0xffff0000u);            // exact
+  o0 = pack_bf16(r0, x0);                                             // low = m0, high = h0 (the same RNE as above)
+  o1 = pack_bf16(r1, x1);
+}
+
+// (head layer 0 keeps fp32 scratch rows and the f32 weight-gradient GEMM: 48 of its 64 input slots — SH of the view direction,
+//  appearance row — are constant over a ray, so the 2^-18 representation error of a two-piece value is the SAME in every sample
+//  of the ray and does not average out over the points: 2.1 - 2.4e-6 relative L2 on that layer against 2 - 5e-7 on the other
+//  four, scripts/study_bf16_wgrad.py; the bench-size float64 test allows 2e-6.)
 template <int T>
-__device__ __forceinline__ void store_rows(float* S, const v4f* x, int j, int g) {
+__device__ __forceinline__ void store_rows_f32(float* S, const v4f* x, int j, int g) {
 #pragma unroll
   for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) S[(16 * t + 4 * g + r) * kScratchLd + j] = x[t][r];
+}
+
+template <int T>
+__device__ __forceinline__ void store_rows_pk(float* S, const v4f* x, int j, int g) {
+  unsigned* U = reinterpret_cast<unsigned*>(S);
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+      unsigned o0, o1;
+      split_pair(x[t][r], x[t][r + 1], o0, o1);
+      U[(16 * t + 4 * g + r) * kScratchLd + j] = o0;
+      U[(16 * t + 4 * g + r + 1) * kScratchLd + j] = o1;
+    }
 }
 
 template <int N>
@@ -740,6 +779,7 @@ template <int NT, int KT, int LD>
 __device__ __forceinline__ void rows_gemm_fwd(const float* Wrows, const v4f* in, v4f* out, int j, int g) {
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
+    if (kSkipConst & 128) continue;
     v4f a[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) a[n] = *reinterpret_cast<const v4f*>(Wrows + (16 * n + j) * LD + 16 * t + 4 * g);
@@ -816,12 +856,24 @@ __device__ __forceinline__ void coop_forward_tile(const float* W, const float* b
   between.template at<4>();
 }
 
-// dW tile (n, m) += sum over the points of scratch areas [first, first + count): Dout^T X. MFMA step q of an area
-// takes points 4g + q: A lane (j, g) = Dout[neuron 16n + j][point 4g + q], B lane (j, g) = X[feature 16m + j][4g + q] —
-// four steps per ds_read_b128 of each operand row.
+// dW tile (n, m) += sum over the points of scratch areas [first, first + count): Dout^T X on the bf16 matrix cores
+// (v_mfma_f32_16x16x32_bf16, fp32 accumulate). The contraction index of one instruction is the 16 points of an area x the two
+// pieces of a value: lane (j, g) holds k-slots 8g .. 8g + 7 = (m, h) of points 4g .. 4g + 3 — one ds_read_b128 of the operand's
+// scratch row, exactly the fp32 scratch's read. With A = (m, h) and B = (m', h') one instruction sums m m' + h h' over the 16
+// points; with A's halves swapped (one v_alignbit per dword, shared by the wave's column tiles) the other sums h m' + m h':
+// all four piece products, i.e. (h + m)(h' + m'), from 2 instructions of 16 clocks per (area, tile) where the f32 path
+// issued 4 of 32. Against float64 the two-piece operands cost <= 5e-6 max|dW| (profiles/r02_study_bf16_wgrad.txt: the sum
+// over 196 608 points averages the 2^-17 per-value error down); the per-point GEMMs (forward, data gradients) stay f32.
+// Bias gradient: sum over points of h + m, one v_dot2c_f32_bf16 against (1, 1) per dword.
+__device__ __forceinline__ float dot2_ones(unsigned a, float c) {
+  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(c) : "v"(a), "v"(0x3f803f80u));
+  return c;
+}
+
+// (fp32 scratch rows, v_mfma_f32_16x16x4_f32: MFMA step q of an area takes points 4g + q)
 template <int TILES>
-__device__ __forceinline__ void coop_dw(v4f* acc, float* dbacc, bool want_db, const float* scratch, int first,
-                                        int count, int n, int m0, int j, int g) {
+__device__ __forceinline__ void coop_dw_f32(v4f* acc, float* dbacc, bool want_db, const float* scratch, int first,
+                                            int count, int n, int m0, int j, int g) {
 #pragma unroll 2
   for (int area = first; area < first + count; ++area) {
     const float* Sd = scratch + area * 2 * kScratchTile;
@@ -836,6 +888,52 @@ __device__ __forceinline__ void coop_dw(v4f* acc, float* dbacc, bool want_db, co
 #pragma unroll
       for (int i = 0; i < TILES; ++i) acc[i] = mfma16(a[q], b[i][q], acc[i]);
   }
+}
+
+template <int TILES>
+__device__ __forceinline__ void coop_dw_pk(v4f* acc, float* dbacc, bool want_db, const float* scratch, int first,
+                                           int count, int n, int m0, int j, int g) {
+#pragma unroll 2
+  for (int area = first; area < first + count; ++area) {
+    const float* Sd = scratch + area * 2 * kScratchTile;
+    const float* Sx = Sd + kScratchTile;
+    const u4 a = *reinterpret_cast<const u4*>(Sd + (16 * n + j) * kScratchLd + 4 * g);
+    u4 b[TILES];
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) b[i] = *reinterpret_cast<const u4*>(Sx + (16 * (m0 + i) + j) * kScratchLd + 4 * g);
+    if (want_db) {
+      float s = *dbacc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s = dot2_ones(a[q], s);
+      *dbacc = s;
+    }
+    u4 ar;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ar[q] = __builtin_amdgcn_alignbit(a[q], a[q], 16);
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) acc[i] = mfma_bf16(a, b[i], acc[i]);
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) acc[i] = mfma_bf16(ar, b[i], acc[i]);
+  }
+}
+
+// Build-time choice of the weight-gradient arithmetic (same-box A/B, scripts/build_variant.sh): NSAMD_DW_BF16 = 0 every layer on
+// the f32 matrix-core path (rounds 2 - 5), 1 (default) two-piece bf16 for every layer but head layer 0, 2 for all five.
+#ifndef NSAMD_DW_BF16
+#define NSAMD_DW_BF16 1
+#endif
+template <int T, bool HEAD0 = false>
+__device__ __forceinline__ void store_rows(float* S, const v4f* x, int j, int g) {
+  if (kSkipConst & 64) return;
+  if (NSAMD_DW_BF16 == 0 || (NSAMD_DW_BF16 == 1 && HEAD0)) store_rows_f32<T>(S, x, j, g);
+  else store_rows_pk<T>(S, x, j, g);
+}
+
+template <int TILES, bool HEAD0 = false>
+__device__ __forceinline__ void coop_dw(v4f* acc, float* dbacc, bool want_db, const float* scratch, int first,
+                                        int count, int n, int m0, int j, int g) {
+  if (NSAMD_DW_BF16 == 0 || (NSAMD_DW_BF16 == 1 && HEAD0)) coop_dw_f32<TILES>(acc, dbacc, want_db, scratch, first, count, n, m0, j, g);
+  else coop_dw_pk<TILES>(acc, dbacc, want_db, scratch, first, count, n, m0, j, g);
 }
 
 // acc lane (j, g) reg r of tile (n, m) = dW[16n + 4g + r][slot 16m + j]: to the workgroup's partial row (plain stores,
@@ -1190,7 +1288,7 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
 #ifdef NSAMD_PROBE_CLOCKS
   const int probe_skip = probe_skip_arg;
 #else
-  constexpr int probe_skip = 0;
+  constexpr int probe_skip = kSkipConst;  // 0 in the product; -DNSAMD_FIELD_BWD_SKIP_CONST=n: attribution builds (wrong results)
   (void)probe_skip_arg;
 #endif
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1353,14 +1451,14 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     PROBE_STAMP(kCoopWaves, 5 + 10 * (int)it);
 
     // ---- head layer 0 (slots 64 -> 64) ----
-    store_rows<4>(Sd, g_ha, j, g);
-    store_rows<4>(Sx, A.hin, j, g);
+    store_rows<4, true>(Sd, g_ha, j, g);
+    store_rows<4, true>(Sx, A.hin, j, g);
     v4f g_hin[4];
     zero_tiles<4>(g_hin);
     // input tile 0 is the SH block: it carries no gradient, so only columns 16..63 (tiles 1..3) are formed
     if (!(probe_skip & 4)) rows_gemm_bwd<3, 4, kLd64>(W + kRowHead0 + 16, g_ha, g_hin + 1, j, g);
     if (!(probe_skip & 2)) __syncthreads();
-    if (!(probe_skip & 1)) coop_dw<2>(dW_h0, &db_h0, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
+    if (!(probe_skip & 1)) coop_dw<2, true>(dW_h0, &db_h0, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
     if (!(probe_skip & 2)) __syncthreads();
     PROBE_STAMP(kCoopWaves, 6 + 10 * (int)it);
 
