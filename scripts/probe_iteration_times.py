@@ -52,3 +52,5 @@ for kind in (False, True):
     if t:
         out.append(f"{'updated' if kind else 'not updated'} x{len(t)}: median {t[len(t) // 2]:7.1f} min {t[0]:7.1f}")
 print(" | ".join(out))
+if os.environ.get("PROBE_DUMP") == "1":  # the sequence itself (is a slow mode periodic?)
+    print("sequence (us, * = update):", " ".join(f"{a.elapsed_time(b) * 1e3:.0f}{'*' if k else ''}" for (a, b), k in zip(ev, kinds)))
