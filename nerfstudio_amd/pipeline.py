@@ -51,16 +51,28 @@ class _AlreadyBackpropagated(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, *values):  # noqa: D102
-        if len(values) == 1 and values[0].dim() == 1:
-            # the runner's loss-value buffer (train_step.loss_vals): ONE clone, handed out as its first three elements —
-            # three outputs of this node, so the trainer's backward never meets a select node (whose backward launches)
-            out = values[0].clone()
-            return out[0], out[1], out[2], out[3], out[4]
+        ctx.n_inputs = 1 + len(values)
         return tuple(v.clone() for v in values)
 
     @staticmethod
     def backward(ctx, *grads):  # noqa: D102
-        return (None,) * (1 + len(grads))
+        return (None,) * ctx.n_inputs
+
+
+class _LossValuesBackpropagated(torch.autograd.Function):
+    """The same for the runner's loss-value buffer (train_step.loss_vals, five floats: rgb, interlevel, distortion, psnr, the
+    distortion metric): ONE clone, handed out as five outputs of this node, so that the trainer's backward never meets a
+    select node (whose backward launches a kernel)."""
+
+    @staticmethod
+    def forward(ctx, anchor, loss_vals):  # noqa: D102
+        assert loss_vals.dim() == 1 and loss_vals.numel() >= 5
+        out = loss_vals.clone()
+        return out[0], out[1], out[2], out[3], out[4]
+
+    @staticmethod
+    def backward(ctx, *grads):  # noqa: D102
+        return None, None
 
 
 def unsupported_model_reason(model) -> Optional[str]:
@@ -236,7 +248,7 @@ class TrainEngine:
         if getattr(r, "_loss_vals_fresh", False) and model.config.background_color != "random":
             # the losses launch's finishing pass left the loss values and the training metrics in five floats
             # (include/nsamd.h, nsamd_render_losses_train): one clone per iteration instead of a dozen reduction launches
-            rgb, inter, dist, psnr, dmetric = _AlreadyBackpropagated.apply(self._anchor, r.loss_vals)
+            rgb, inter, dist, psnr, dmetric = _LossValuesBackpropagated.apply(self._anchor, r.loss_vals)
             loss_dict = {"rgb_loss": rgb, "interlevel_loss": inter, "distortion_loss": dist}
             metrics = {"psnr": psnr.detach(), "distortion": dmetric.detach()}
             if r.cam_opt is not None:
@@ -303,7 +315,14 @@ class NgpEngine(TrainEngine):
         self._grad_views = [(p, self.arena.grad[off:off + p.numel()].view(p.shape)) for p, off in zip(self.arena.params, self.arena.offsets)]
         self._adopt_optimizer_state()
         self._anchor = torch.zeros((), device=o.device, requires_grad=True)
-        self.build_trainer_only(ray_bundle, batch)
+        try:
+            self.build_trainer_only(ray_bundle, batch)
+        except (RuntimeError, NotImplementedError) as e:
+            # a model shape the explicit schedule does not cover (NgpTrainStep.__init__: hash-grid width, background mode ...):
+            # the module path trains it, as for every other `reason`
+            self.trainer = None
+            self.reason = f"kernel schedule unavailable for this model ({type(e).__name__}: {e})"
+            return self.reason
         return None
 
     def build_trainer_only(self, ray_bundle, batch) -> None:
@@ -331,6 +350,11 @@ class NgpEngine(TrainEngine):
         if not image.is_cuda and ray_bundle.origins.is_cuda:
             image = image.to(ray_bundle.origins.device)
         rb = ray_bundle.reshape(-1) if ray_bundle.origins.dim() > 2 else ray_bundle
+        # Model.forward runs the collider in front of get_outputs (models/base_model.py:140-141): with enable_collider the
+        # schedule must march the collider's near / far planes (NgpTrainer.set_batch reads the bundle's nears / fars)
+        collider = getattr(self.pipeline.model, "collider", None)
+        if collider is not None:
+            rb = collider(rb)
         if self._bind_grads:
             for p, g in self._grad_views:
                 p.grad = g

@@ -879,8 +879,10 @@ class NerfactoTrainStep:
     def loss_dict(self) -> Dict[str, Tensor]:
         """Loss values of the last iteration (models/nerfacto.py:363-375); a few tiny torch reductions, call on demand."""
         n, S = self.n, self.counts[-1]
-        if self._loss_vals_fresh:  # views of what the losses launch left behind: no reduction launches
-            v = self.loss_vals
+        if self._loss_vals_fresh:  # what the losses launch left behind: no reduction launches
+            # ONE clone: the buffer is overwritten by every iteration, and a caller that keeps the dictionaries of several
+            # iterations (a trainer's logging history) must not see them all change to the latest values
+            v = self.loss_vals[:3].clone()
             out = {"rgb_loss": v[0], "distortion_loss": v[2], "interlevel_loss": v[1]}
             if self.cam_opt is not None:
                 out["camera_opt_regularizer"] = self.camera_reg

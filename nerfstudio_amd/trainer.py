@@ -173,7 +173,18 @@ class HipTrainer:
                     and getattr(r, "single_jitter", False) and hasattr(r, "jitter")):
                 self.prologue = True
                 self.step_counter = torch.zeros(2, device=dev, dtype=torch.int64)  # [row, draw]
-                self.rng_seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + 0x5851F42D4C957F2D) & 0xFFFFFFFFFFFFFFFF
+                # The draws are keyed by (seed, draw counter). The counter starts at the model's training step, so that a trainer
+                # built in the middle of a run (a resumed checkpoint, an engine rebuilt for another batch size) does not replay
+                # the jitter and background draws of steps 0, 1, ...; the rank is mixed into the seed, so that data-parallel
+                # ranks that share torch's seed still draw different numbers (the reference: one generator per process).
+                self.step_counter[1] = int(getattr(model, "step", 0) or 0)
+                rank = 0
+                if world > 1 and os.environ.get("NSAMD_BENCH_SAME_RAYS") != "1":  # (the functional check: every rank the same rays AND draws)
+                    import torch.distributed as dist
+
+                    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+                self.rng_seed = ((int(torch.initial_seed()) + 0x632BE59BD9B4E019 * rank) * 0x9E3779B97F4A7C15
+                                 + 0x5851F42D4C957F2D) & 0xFFFFFFFFFFFFFFFF
                 # the batch slot must be read INSIDE the iteration body: with the camera parts outside the graph the batch is
                 # selected eagerly ahead of the replay, i.e. before the prologue would have written the slot (then: the upload
                 # for the scalars, the prologue for the draws only)

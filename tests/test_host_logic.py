@@ -319,3 +319,68 @@ def test_profiler_hooks_time_function_and_roctx_ranges(monkeypatch):
 
     for name in ("forward_proposals", "forward_main", "losses", "backward_main", "backward_proposals"):
         assert hasattr(getattr(NerfactoTrainStep, name), "__wrapped__"), name
+
+
+def test_ngp_engine_runs_the_collider_and_falls_back_when_the_schedule_refuses_the_model():
+    """pipeline.NgpEngine: (1) Model.forward applies the collider before get_outputs
+    (models/base_model.py:140-141) — the engine must hand the COLLIDED bundle to the schedule, or enable_collider configs march
+    the config's near / far planes instead of the collider's; (2) a model shape NgpTrainStep refuses must select the module
+    path (a `reason`), not crash the first training iteration."""
+    import types
+
+    import torch
+
+    from nerfstudio_amd.cameras.rays import RayBundle
+    from nerfstudio_amd.pipeline import NgpEngine
+
+    seen = {}
+
+    class _Runner:
+        num_kept = 7
+        target = torch.zeros(4, 3)
+
+        def outputs(self):
+            return {"rgb": torch.zeros(4, 3)}
+
+    class _Trainer:
+        runner = _Runner()
+
+        def set_batch(self, rb, batch):
+            seen["nears"], seen["fars"] = rb.nears, rb.fars
+
+        def train_iteration(self, step):
+            return torch.zeros(())
+
+    def collider(rb):
+        rb.nears = torch.full_like(rb.origins[..., :1], 0.25)
+        rb.fars = torch.full_like(rb.origins[..., :1], 3.5)
+        return rb
+
+    eng = object.__new__(NgpEngine)
+    eng.trainer, eng.arena = _Trainer(), types.SimpleNamespace(lr=0.0)
+    eng.optimizers = types.SimpleNamespace(optimizers={"fields": types.SimpleNamespace(param_groups=[{"lr": 1e-2}])})
+    eng.pipeline = types.SimpleNamespace(model=types.SimpleNamespace(collider=collider))
+    eng._bind_grads, eng._grad_views, eng._anchor = False, [], torch.zeros((), requires_grad=True)
+    rb = RayBundle(origins=torch.zeros(4, 3), directions=torch.ones(4, 3), pixel_area=torch.ones(4, 1),
+                   camera_indices=torch.zeros(4, 1, dtype=torch.long))
+    eng.train_iteration(0, rb, {"image": torch.zeros(4, 3)})
+    assert float(seen["nears"][0]) == 0.25 and float(seen["fars"][0]) == 3.5 and eng.arena.lr == 1e-2
+
+    # (2) the schedule's constructor refuses: build() answers with a reason and leaves no trainer behind
+    eng2 = object.__new__(NgpEngine)
+    eng2.reason, eng2.trainer, eng2.runner_factory, eng2.on_build = None, None, None, None
+    eng2._optimizer_reason = lambda: None
+    eng2._adopt_optimizer_state = lambda: None
+    p = torch.nn.Parameter(torch.zeros(8))
+    eng2.optimizers = types.SimpleNamespace(
+        parameters={"fields": [p]},
+        optimizers={"fields": types.SimpleNamespace(param_groups=[{"lr": 1e-2, "betas": (0.9, 0.999), "eps": 1e-15}])})
+    eng2.pipeline = types.SimpleNamespace(model=types.SimpleNamespace(config=types.SimpleNamespace(use_gradient_scaling=False)))
+
+    def refuse(ray_bundle, batch):
+        raise NotImplementedError("hash grid out_dim != 32")
+
+    eng2.build_trainer_only = refuse
+    eng2.runner_factory = object()  # (rays on the CPU are fine with a stand-in runner factory)
+    reason = eng2.build(rb, {"image": torch.zeros(4, 3)})
+    assert reason is not None and "out_dim" in reason and eng2.reason == reason and eng2.trainer is None
