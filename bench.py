@@ -207,6 +207,48 @@ def cpu_baseline_ngp(o, d, cam, tgt, binaries, cfg, n_rays=256, steps=2):
                       f"steps after 1 warm-up ({med:.2f} s/step)"}
 
 
+def secondary_lines(steps, warmup, headline_ms):
+    """The lines of the other workloads this repository covers, timed in the DEFAULT run so that the driver's one JSON line
+    carries them: one window of `steps` iterations each, measured by this same script (or scripts/bench_seam.py)
+    in a process of its own on the same GPU right after the headline — the reference's nerfacto default with the camera
+    optimiser on (models/nerfacto.py:131 SO3xR3), BASELINE configs[4] (unbounded / contraction), configs[3] (instant-ngp incl.
+    its occupancy refresh), and the iteration through the reference's Trainer / Pipeline seam against the direct line.
+    Never the headline; a failed sub-run is reported as such instead of failing the bench."""
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    common = ["--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-secondary", "--long-steps", "0",
+              "--windows", "3"]
+    runs = {"camera_optimizer_SO3xR3": [os.path.join(here, "bench.py"), "--camera-optimizer", "SO3xR3"] + common,
+            "unbounded_configs4": [os.path.join(here, "bench.py"), "--workload", "unbounded"] + common,
+            "instant_ngp_configs3": [os.path.join(here, "bench.py"), "--workload", "ngp"] + common,
+            "trainer_pipeline_seam": [os.path.join(here, "scripts", "bench_seam.py"), "--steps", str(steps), "--warmup", str(warmup),
+                                      "--windows", "3"]}
+    out = {}
+    for name, cmd in runs.items():
+        t0 = time.perf_counter()
+        try:
+            res = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=240, env=env)
+            line = next((ln for ln in reversed(res.stdout.splitlines()) if ln.startswith("{")), None)
+            if res.returncode != 0 or line is None:
+                out[name] = {"error": f"rc {res.returncode}: {(res.stderr or res.stdout)[-200:]}"}
+                continue
+            j = json.loads(line)
+        except Exception as e:  # noqa: BLE001 - a secondary line must never take the headline down
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+            continue
+        wall = round(time.perf_counter() - t0, 1)
+        if name == "trainer_pipeline_seam":
+            out[name] = {"seam_ms_per_step": j["seam_ms"], "direct_ms_per_step": j["direct_pool_ms"],
+                         "seam_over_direct": j["seam_over_direct_pool"], "windows": j["windows"], "process_s": wall}
+        else:
+            out[name] = {"ms_per_step": j["ms_per_step"], "value": j["value"], "unit": j["unit"], "steps": j["steps"],
+                         "over_headline": round(float(j["ms_per_step"]) / headline_ms, 4), "workload": j["config"].get("workload"),
+                         "process_s": wall}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,6 +282,8 @@ def main():
     ap.add_argument("--dp-mode", choices=["allreduce", "sharded"], default="allreduce")
     ap.add_argument("--param-checksum", action="store_true", help="add sha256 digests of the arenas after the FIRST window to config")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: rehearse the multi-GPU launch plumbing over gloo")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` object of the default N = 1 run (the other workloads' 20-step windows, see secondary_lines)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -417,6 +461,9 @@ def main():
             out["config"]["force_dp"] = "data-parallel schedule over a one-rank RCCL communicator (rehearsal of the N > 1 path)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(workload=args.workload)
+        if (world == 1 and not args.no_secondary and not args.force_dp and args.workload == "bounded" and args.camera_optimizer == "off"
+                and not (args.autograd or args.no_graph or args.start_step or args.kernel_table or args.param_checksum)):
+            out["secondary"] = secondary_lines(args.steps, args.warmup, float(out["ms_per_step"]))
         if args.kernel_table:
             for r in table:
                 print(f"{r['kernel']:64s} {r['calls_per_step']:5.1f}/step {r['ms_per_step']:9.4f} ms/step "

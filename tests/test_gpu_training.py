@@ -305,6 +305,69 @@ def test_data_parallel_path_over_one_rank_rccl_matches_single_gpu():
     # (graph replay against EAGER launches, bit for bit, with injected jitter: tests/test_gpu_bench_parity.py)
 
 
+def test_two_ranks_on_one_gpu_train_through_the_bits_of_the_single_gpu_run():
+    """N = 2 under the driver's eyes on the hardware it has: `bench.py --gpus 2 --share-gpu` launched the
+    way the driver launches N > 1 (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`), both ranks on
+    cuda:0, on IDENTICAL rays and draws (NSAMD_BENCH_SAME_RAYS=1): the all-reduced mean of two equal gradients is that gradient
+    bit for bit ((g + g) / 2), so the pipelined data-parallel schedule (dp_schedule.py: per-group exchanges on the
+    communication stream, the compact table-prefix exchange, Adam behind the exchange) must end at exactly the parameter and
+    Adam-moment bits of the N = 1 run — real inter-process collectives, not a one-rank identity. Over gloo (RCCL refuses two
+    ranks on one device; tried below and reported, not required). Reference: pipelines/base_pipeline.py:279-282 (DDP wrap),
+    scripts/train.py:98,139-145."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", NSAMD_BENCH_SAME_RAYS="1")
+    common = ["--steps", "8", "--warmup", "4", "--windows", "1", "--long-steps", "0", "--no-cpu-baseline", "--profile-steps", "1",
+              "--param-checksum"]
+
+    def last_json(r):
+        assert r.returncode == 0, (r.stderr or r.stdout)[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+    one = last_json(subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common], capture_output=True, text=True, env=env,
+                                   timeout=600, cwd=root))
+
+    def two_ranks(backend, port, *flags, timeout=900):
+        import signal
+        import types
+
+        p = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                              "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu",
+                              "--dist-backend", backend, *common, *flags], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                             env=env, cwd=root, start_new_session=True)
+        try:
+            out, err = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)  # the launcher AND its ranks (exactly the process group started here)
+            p.communicate()
+            raise
+        return types.SimpleNamespace(returncode=p.returncode, stdout=out, stderr=err)
+
+    for mode, flags in (("allreduce", ()), ("sharded", ("--dp-mode", "sharded"))):
+        two = last_json(two_ranks("gloo", 29561 if mode == "allreduce" else 29563, *flags))
+        assert two["n_gpus"] == 2 and two["config"]["rccl_ranks"] == 2 and two["config"]["dist_backend"] == "gloo", two["config"]
+        assert two["config"]["dp_mode"] == mode
+        assert two["config"]["final_loss"] == one["config"]["final_loss"], (mode, two["config"]["final_loss"], one["config"]["final_loss"])
+        assert two["config"]["param_checksum"] == one["config"]["param_checksum"], f"{mode}: two ranks on identical rays left other bits than N = 1"
+    # RCCL with two ranks on ONE device: reported, not required (NCCL-family libraries reject a duplicate device)
+    try:
+        r = two_ranks("nccl", 29565, timeout=180)
+    except subprocess.TimeoutExpired:
+        print("\ntwo RCCL ranks on one device: communicator did not come up within 180 s")
+        return
+    if r.returncode == 0:
+        rc = last_json(r)
+        assert rc["config"]["param_checksum"] == one["config"]["param_checksum"]
+        print("\ntwo RCCL ranks on one device: communicator came up, same bits as N = 1")
+    else:
+        tail = (r.stderr or r.stdout).strip().splitlines()[-1:] or ["?"]
+        print(f"\ntwo RCCL ranks on one device: not available here ({tail[0][:160]})")
+
+
 def test_checkpoint_round_trip_resumes_bit_exactly(F, tmp_path):
     """SURVEY.md §8 f5 / VERDICT r02 item 8: train a few steps -> checkpoint in the reference trainer's layout
     (checkpoint.make_checkpoint: `_model.`-prefixed tensors, torch.optim.Adam state per group, GradScaler state) ->
