@@ -304,32 +304,6 @@ int nsamd_field_mlp_bwd_phase(const float* enc, const float* selector, const flo
                               nsamd_field_mlp_grads grads, float* workspace, int64_t workspace_floats, int phase,
                               nsamd_stream_t stream);
 
-/* Training-step pair that trades HBM for MFMA time: the forward also writes the activations the backward needs
- * (`saved`: nsamd_field_mlp_saved_floats(M) floats = 896 B per point, chain-layout fragments), and the backward loads
- * them instead of recomputing the forward — a third of its matrix work. Same outputs as the plain pair. */
-int64_t nsamd_field_mlp_saved_floats(int64_t M);
-int nsamd_field_mlp_fwd_save(const float* enc, const float* selector, const float* directions,
-                             const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
-                             nsamd_field_mlp mlp, float* density, float* rgb, float* saved, nsamd_stream_t stream);
-int nsamd_field_mlp_bwd_saved(const float* enc, const float* selector, const float* directions,
-                              const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
-                              nsamd_field_mlp mlp, const float* saved, const float* ddensity, const float* drgb,
-                              float* denc, nsamd_field_mlp_grads grads, float* workspace, int64_t workspace_floats,
-                              nsamd_stream_t stream);
-
-/* nsamd_hashgrid_encode_fwd + nsamd_field_mlp_fwd in ONE launch for 16-level grids (the nerfacto main field,
- * fields/nerfacto_field.py:203-310 with MLPWithHashEncoding, field_components/mlp.py:187-295): the hash features go
- * from the gathers into the B operands of base layer 0 in registers; a wave's next tile of gathers is in flight while its
- * current tile runs on the matrix cores. selector [M] and enc [32, M] (feature-major) are optional outputs (the backward of
- * a training step reads them). Bit-identical to the two-launch path. NSAMD_ERR_UNSUPPORTED for other level counts.
- * Measured on MI355X at the nerfacto shape (196 608 points, 2^19-entry levels): 155-160 us against 78 + 56 us for the two
- * launches — gathering all 16 levels per wave gives up the L2 locality of the level-major sweep — so the training step
- * keeps the two launches; this entry point is the smaller-table / single-launch alternative. */
-int nsamd_field_fused_fwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
-                          nsamd_grid grid, const float* directions, const int64_t* camera_indices,
-                          const float* appearance_const, int64_t dir_group, nsamd_field_mlp mlp, float* selector,
-                          float* enc, float* density, float* rgb, nsamd_stream_t stream);
-
 /* ------------------------------------------------------------------------------------------------------------
  * Generic dense layer for the stand-alone MLP of the plugin API (MLP.pytorch_fwd, field_components/mlp.py:160-179):
  * y[M,N] = act(x[M,K] W[N,K]^T + b[N]); activation 0 = none, 1 = ReLU, 2 = Sigmoid, 3 = Softplus (the DensityFieldHead of
@@ -406,42 +380,6 @@ int nsamd_proposal_resample(const float* t_bins_prev, const float* s_bins_prev, 
                             int spacing, int64_t num_rays, int32_t S, float* weights, float* depth_median,
                             float* s_bins, float* t_bins, nsamd_stream_t stream);
 
-/* ProposalNetworkSampler.generate_ray_samples (ray_samplers.py:576-617) in ONE launch, one wavefront per ray:
- *   [nsamd_select_batch ->] nsamd_piecewise_bins -> per level: nsamd_density_field_fwd -> nsamd_proposal_resample.
- * Same numbers as those launches (the stages are their device bodies, run one after the other inside the wave).
- * slot_dev NULL: no batch selection (the caller filled origins / directions), else as nsamd_select_batch.
- * jitter0 [N]: the draw of the initial bins (single jitter: one per ray). level: HOST array of `levels` (<= 4) descriptors;
- * level l's s_bins / t_bins [N, samples+1] are WRITTEN by this launch (level 0 by the initial sampler, l > 0 by level l-1's
- * resampling), as are density [N*samples], weights [N, samples], depth_median [N] (nullable) and — nullable, for the level's
- * backward — enc [2 L, N*samples], selector, pre; u_base / jitter / u_offset are those of the resampling that FOLLOWS the level
- * (its S + 1 uniform offsets, its per-ray draw, 1 / (2 (S + 1))). s_bins_out / t_bins_out [N, S_out+1]: the final samples.
- * NSAMD_ERR_UNSUPPORTED (nothing launched) when the levels' networks differ in shape or are not 5 levels x {16, 64} hidden. */
-typedef struct nsamd_sampler_level {
-  const float* table;
-  nsamd_grid grid;
-  nsamd_density_mlp mlp;
-  nsamd_aabb aabb;
-  int32_t transform;
-  int32_t samples;
-  float* s_bins;
-  float* t_bins;
-  float* density;
-  float* enc;
-  float* selector;
-  float* pre;
-  float* weights;
-  float* depth_median;
-  const float* u_base;
-  const float* jitter;
-  float u_offset;
-} nsamd_sampler_level;
-int nsamd_proposal_sampler(const float* slot_dev, int32_t slots, const float* origins_pool, const float* directions_pool,
-                           const int64_t* cameras_pool, const float* target_pool, int64_t* cameras, float* target,
-                           float* origins, float* directions, const float* nears, const float* fars, int64_t num_rays,
-                           const float* edges, const float* jitter0, int spacing, float anneal, const float* anneal_dev,
-                           float histogram_padding, float eps, int32_t levels, const nsamd_sampler_level* level, int32_t S_out,
-                           float* s_bins_out, float* t_bins_out, nsamd_stream_t stream);
-
 /* ------------------------------------------------------------------------------------------------------------
  * Compositing (model_components/renderers.py): RGBRenderer.combine_rgb :72-119 (+ eval nan_to_num/clamp
  * :225-231), AccumulationRenderer :293-317, DepthRenderer median :354-364 and expected :365-383.
@@ -514,39 +452,14 @@ int nsamd_proposal_losses(const float* s_bins_fine, const float* w_fine, int32_t
                           float* const* interlevel_per_ray, float* const* dw_prop, float* distortion_per_ray,
                           float* dw_distortion, nsamd_stream_t stream);
 
-/* The per-ray middle of a nerfacto training iteration in ONE launch — everything between the main field's forward and its
- * backward (models/nerfacto.py:313-392 and what autograd runs back through it):
- *   nsamd_render_train (weights, rgb / accumulation / depths, MSE value and gradient)
- *   + nsamd_proposal_losses (interlevel loss per proposal level, distortion loss; values per ray, gradients)
- *   + nsamd_render_train_bwd with d_weights_add = dw_distortion (d_rgb [N,S,3], d_density [N,S])
- *   + optionally nsamd_weights_bwd_gate per proposal level (ray_samplers.py:590-609: the steps on which the proposal
- *     networks receive gradient): entries of t_bins_prop / density_prop / ddensity_prop / gates / ray_masks (HOST arrays of
- *     `levels` device pointers, or NULL arrays) — a level whose ddensity_prop entry is NULL, or whose dw_prop is NULL, is
- *     left to the caller. The gates must have been cleared before the launch (as with gate_precleared = 1).
- * One wavefront per (ray, job): job 0 = the fine level's chain, job 1 + l = proposal level l. Every output — including
- * `weights`, `d_rgb_out` and `dw_distortion`, which the launch itself reads back — is bit-identical to the separate launches.
- * Arguments as theirs; s_bins [N,S+1] are the fine level's spacing-domain edges (the losses), t_bins its euclidean ones.
- * loss_values (nullable, 32 floats = 8 results + scratch of the pass: partial sums and a ticket word that must be ZERO before
- * the first launch and resets itself): written by the launch's finishing pass (the one that clips the expected depth) — the
- * iteration's loss values as models/nerfacto.py:363-375 scales them and the two training metrics of :352-361, from the per-ray
- * terms summed in a fixed order in double: [0] rgb_loss = sum(sq_err) / (3 N), [1] interlevel_loss = interlevel_loss_mult *
- * sum over levels and rays / (N S), [2] distortion_loss = distortion_loss_mult * sum(distortion_per_ray) / N,
- * [3] psnr = -10 log10(rgb_loss), [4] distortion = sum(distortion_per_ray) / N, [5] = [0] + [1] + [2]. */
-int nsamd_render_losses_train(const float* rgb, const float* density, const float* t_bins, const float* s_bins,
-                              int64_t num_rays, int32_t S, int background, const float* bg_rgb_host, const float* target,
-                              float mse_grad_scale, const float* bg_rays, float* weights, float* rgb_out, float* acc,
-                              float* depth_expected, float* depth_median, float* workspace, float* sq_err, float* d_rgb_out,
-                              int32_t levels, const float* const* s_bins_prop, const float* const* w_prop,
-                              const int32_t* S_prop, float interlevel_grad_scale, float distortion_grad_scale,
-                              float* const* interlevel_per_ray, float* const* dw_prop, float* distortion_per_ray,
-                              float* dw_distortion, float* d_rgb, float* d_density, const float* const* t_bins_prop,
-                              const float* const* density_prop, float* const* ddensity_prop, uint32_t* const* gates,
-                              uint8_t* const* ray_masks, float interlevel_loss_mult, float distortion_loss_mult,
-                              float* loss_values, nsamd_stream_t stream);
-
-/* loss_values of nsamd_render_losses_train alone, from the per-ray terms separate launches left behind (nsamd_render_train's
+/* The iteration's loss values and training metrics from the per-ray terms the launches above left behind (nsamd_render_train's
  * sq_err, nsamd_proposal_losses' per-ray values): one small launch instead of a dozen host-issued reductions for a trainer that
- * logs the loss dictionary every iteration (engine/trainer.py:487-531). Layout and scaling as there. */
+ * logs the loss dictionary every iteration (engine/trainer.py:487-531). loss_values: 32 floats = 8 results + scratch of the
+ * pass (partial sums and a ticket word that must be ZERO before the first launch and resets itself); the values as
+ * models/nerfacto.py:363-375 scales them and the two training metrics of :352-361, summed in a fixed order in double:
+ * [0] rgb_loss = sum(sq_err) / (3 N), [1] interlevel_loss = interlevel_loss_mult * sum over levels and rays / (N S),
+ * [2] distortion_loss = distortion_loss_mult * sum(distortion_per_ray) / N, [3] psnr = -10 log10(rgb_loss),
+ * [4] distortion = sum(distortion_per_ray) / N, [5] = [0] + [1] + [2]. */
 int nsamd_train_loss_values(const float* sq_err, const float* distortion_per_ray, int32_t levels,
                             const float* const* interlevel_per_ray, int64_t num_rays, int32_t S, float interlevel_loss_mult,
                             float distortion_loss_mult, float* loss_values, nsamd_stream_t stream);
@@ -748,7 +661,7 @@ int nsamd_device_info(int32_t* num_cus, int32_t* wavefront_size, int32_t* lds_by
  * with the operand/result lane mapping the field kernels assume. */
 int nsamd_probe_mfma16(const float* A, const float* B, float* out, nsamd_stream_t stream);
 /* The same for v_mfma_f32_16x16x32_bf16 (A [16,32], B [32,16] fp32 holding bf16-representable values): the lane mapping of
- * the three-way-split forward (NSAMD_FIELD_FWD_BF16X3). */
+ * the field backward's weight-gradient GEMMs on two-piece bf16 operands. */
 int nsamd_probe_mfma_bf16(const float* A, const float* B, float* out, nsamd_stream_t stream);
 
 #ifdef __cplusplus

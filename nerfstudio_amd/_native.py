@@ -42,12 +42,6 @@ class DensityMlp(C.Structure):
                 ("average_init_density", f32)]
 
 
-class SamplerLevel(C.Structure):
-    _fields_ = [("table", vp), ("grid", Grid), ("mlp", DensityMlp), ("aabb", Aabb), ("transform", i32), ("samples", i32),
-                ("s_bins", vp), ("t_bins", vp), ("density", vp), ("enc", vp), ("selector", vp), ("pre", vp), ("weights", vp),
-                ("depth_median", vp), ("u_base", vp), ("jitter", vp), ("u_offset", f32)]
-
-
 class FieldMlp(C.Structure):
     _fields_ = [("base_W0", vp), ("base_b0", vp), ("base_W1", vp), ("base_b1", vp), ("head_W0", vp), ("head_b0", vp),
                 ("head_W1", vp), ("head_b1", vp), ("head_W2", vp), ("head_b2", vp), ("appearance", vp),
@@ -93,11 +87,7 @@ _SIGNATURES = {
     "nsamd_field_mlp_bwd_scatter_phase": [Points, C.c_int, Aabb, Grid, vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads,
                                           vp, i64, vp, vp, i64, C.c_int, vp],
     "nsamd_field_mlp_bwd_scatter_workspace": [Grid, i64, C.POINTER(C.c_int64)],
-    "nsamd_field_fused_fwd": [Points, i64, C.c_int, Aabb, vp, Grid, vp, vp, vp, i64, FieldMlp, vp, vp, vp, vp, vp],
-    "nsamd_field_mlp_saved_floats": [i64],
-    "nsamd_field_mlp_fwd_save": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, vp],
     "nsamd_field_mlp_bwd_phase": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp, i64, C.c_int, vp],
-    "nsamd_field_mlp_bwd_saved": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, vp, FieldMlpGrads, vp, i64, vp],
     "nsamd_linear_fwd": [vp, vp, vp, i64, i32, i32, C.c_int, vp, vp],
     "nsamd_linear_bwd": [vp, vp, vp, vp, i64, i32, i32, C.c_int, vp, vp, vp, vp],
     "nsamd_piecewise_bins": [vp, vp, vp, vp, i32, i64, i32, C.c_int, vp, vp, vp],
@@ -106,8 +96,6 @@ _SIGNATURES = {
     "nsamd_weights_bwd_gate": [vp, vp, vp, i64, i32, vp, vp, vp, i32, vp],
     "nsamd_pdf_resample": [vp, vp, i32, vp, vp, vp, vp, f32, vp, f32, f32, f32, C.c_int, i32, i32, i64, i32, vp, vp, vp, vp],
     "nsamd_proposal_resample": [vp, vp, vp, i32, vp, vp, vp, vp, f32, vp, f32, f32, f32, C.c_int, i64, i32, vp, vp, vp, vp, vp],
-    "nsamd_proposal_sampler": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, C.c_int, f32, vp, f32, f32, i32,
-                               C.POINTER(SamplerLevel), i32, vp, vp, vp],
     "nsamd_composite_fwd": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), C.c_int, vp, vp, vp, vp, vp, vp, vp],
     "nsamd_render_train": [vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "nsamd_render_train_bwd": [vp, vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, vp, vp, vp, vp, vp],
@@ -117,8 +105,6 @@ _SIGNATURES = {
     "nsamd_interlevel_loss": [vp, vp, i32, vp, vp, i32, i64, f32, vp, vp, vp],
     "nsamd_distortion_loss": [vp, vp, i32, i64, f32, vp, vp, vp],
     "nsamd_proposal_losses": [vp, vp, i32, i32, vp, vp, vp, i64, f32, f32, vp, vp, vp, vp, vp],
-    "nsamd_render_losses_train": [vp, vp, vp, vp, i64, i32, C.c_int, C.POINTER(f32), vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                  i32, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp],
     "nsamd_train_loss_values": [vp, vp, i32, vp, i64, i32, f32, f32, vp, vp],
     "nsamd_occgrid_march_count": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp],
     "nsamd_occgrid_march_write": [vp, vp, vp, vp, i64, f32, f32, OccGrid, f32, f32, vp, vp, vp, vp, vp, vp],
@@ -152,7 +138,7 @@ _SIGNATURES = {
     "nsamd_probe_mfma_bf16": [vp, vp, vp, vp],
 }
 _RESTYPES = {"nsamd_version": C.c_char_p, "nsamd_status_string": C.c_char_p,
-             "nsamd_hashgrid_encode_bwd_workspace": C.c_int64, "nsamd_hashgrid_encode_bwd_workspace_state": C.c_int64, "nsamd_field_mlp_saved_floats": C.c_int64,
+             "nsamd_hashgrid_encode_bwd_workspace": C.c_int64, "nsamd_hashgrid_encode_bwd_workspace_state": C.c_int64,
              "nsamd_field_mlp_bwd_scatter_workspace": C.c_int64,
              "nsamd_occgrid_coarse_words": C.c_int64}
 

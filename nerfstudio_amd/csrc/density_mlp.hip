@@ -62,12 +62,10 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_fwd_kernel(const float*
 // proposal networks get no gradient (ray_samplers.py:590: most steps after warm-up), and only written on the others
 // (the backward's weight gradient needs them). Same operation order as hash_encode_fwd_kernel + density_mlp_fwd_kernel:
 // bit-identical outputs. The proposal tables (5 levels x 2^17 entries x 8 B = 5 MB) sit in every XCD's L2.
-// kLanePair (NSAMD_DENSITY_LANE_PAIR=1, opt-in): density_point_paired — the x-neighbours of a cell edge fetched by adjacent
-// lanes of one instruction, the arrangement that takes the main grid's forward from 76 to 63 us (csrc/hashgrid.hip). Here it
-// is SLOWER (37.2 -> 46.6 us on the 256-sample level, 24.6 -> 25.8 us on the 96-sample level, profiles/r05_s16_*): the proposal
-// grids are coarse against the sample spacing, adjacent lanes already share their lines, and the exchange's 154 registers cost
-// a wave per SIMD. Same bits; kept as the record of the measurement.
-template <int LEVELS, int H, bool kLanePair>
+// (The lane-pair arrangement that takes the main grid's forward from 76 to 63 us is SLOWER here — 37.2 -> 46.6 us on the 256-sample
+// level, profiles/r05_s16_*: the proposal grids are coarse against the sample spacing and adjacent lanes already share their
+// lines; csrc/experiments/rounds2to5_opt_in_variants.patch.)
+template <int LEVELS, int H>
 __global__ __launch_bounds__(kMlpBlock) void density_field_fwd_kernel(nsamd_points P, int64_t M, int transform,
                                                                       nsamd_aabb box, const float2* __restrict__ table,
                                                                       nsamd_grid grid, nsamd_density_mlp mlp,
@@ -76,13 +74,6 @@ __global__ __launch_bounds__(kMlpBlock) void density_field_fwd_kernel(nsamd_poin
                                                                       float* __restrict__ density,
                                                                       float* __restrict__ pre_out) {
   const int64_t p = (int64_t)blockIdx.x * kMlpBlock + threadIdx.x;
-  if (kLanePair) {  // (every lane stays: its neighbour of the lane pair needs it for the exchange)
-    const bool live = p < M;
-    float x, y, z;
-    load_position(P, live ? p : M - 1, x, y, z);
-    density_point_paired<LEVELS, H>(x, y, z, p, M, live, transform, box, table, grid, mlp, enc_out, selector_out, density, pre_out);
-    return;
-  }
   if (p >= M) return;
   float x, y, z;
   load_position(P, p, x, y, z);
@@ -415,14 +406,9 @@ extern "C" int nsamd_density_field_fwd(nsamd_points pts, int64_t M, int transfor
   const int64_t nb = (M + kMlpBlock - 1) / kMlpBlock;
   if (nb > 0x7fffffffLL) return NSAMD_ERR_UNSUPPORTED;
   const float2* t2 = reinterpret_cast<const float2*>(table);
-  static const bool lane_pair = [] { const char* e = getenv("NSAMD_DENSITY_LANE_PAIR"); return e != nullptr && atoi(e) != 0; }();
-#define NSAMD_DENSITY_FWD(L_, H_)                                                                                              \
-  if (lane_pair)                                                                                                               \
-    density_field_fwd_kernel<L_, H_, true><<<(unsigned)nb, kMlpBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, t2, grid, \
-                                                                                              mlp, enc, selector, density, pre); \
-  else                                                                                                                         \
-    density_field_fwd_kernel<L_, H_, false><<<(unsigned)nb, kMlpBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, t2, grid, \
-                                                                                               mlp, enc, selector, density, pre)
+#define NSAMD_DENSITY_FWD(L_, H_)                                                                                       \
+  density_field_fwd_kernel<L_, H_><<<(unsigned)nb, kMlpBlock, 0, (hipStream_t)stream>>>(pts, M, transform, aabb, t2, grid, mlp, \
+                                                                                      enc, selector, density, pre)
   if (grid.num_levels == 5 && mlp.hidden == 16) {
     NSAMD_DENSITY_FWD(5, 16);
   } else if (grid.num_levels == 8 && mlp.hidden == 16) {

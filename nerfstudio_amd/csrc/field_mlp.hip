@@ -129,35 +129,6 @@ struct FieldActs {
   v4f rgbp[1];    // rgb pre-sigmoid (rows 0..2 of tile 0)
 };
 
-// Activations the backward needs, saved by the forward of a training step (nsamd_field_mlp_fwd_save) so that the backward
-// does not recompute the forward (a third of its MFMAs): per 16-point tile 14 fragments in the chain layout,
-// acts[tile][slot][lane] (v4f): h1[0..3], o16, ha[0..3], hb[0..3], rgbp. 896 B per point, fully coalesced.
-constexpr int kActSlots = 14;
-
-__device__ __forceinline__ void store_acts(float* __restrict__ acts, int64_t tile, int lane, const FieldActs& A) {
-  v4f* dst = reinterpret_cast<v4f*>(acts) + (tile * kActSlots) * 64 + lane;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) dst[t * 64] = A.h1[t];
-  dst[4 * 64] = A.o16[0];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) dst[(5 + t) * 64] = A.ha[t];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) dst[(9 + t) * 64] = A.hb[t];
-  dst[13 * 64] = A.rgbp[0];
-}
-
-__device__ __forceinline__ void load_acts(const float* __restrict__ acts, int64_t tile, int lane, FieldActs& A) {
-  const v4f* src = reinterpret_cast<const v4f*>(acts) + (tile * kActSlots) * 64 + lane;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) A.h1[t] = src[t * 64];
-  A.o16[0] = src[4 * 64];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) A.ha[t] = src[(5 + t) * 64];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) A.hb[t] = src[(9 + t) * 64];
-  A.rgbp[0] = src[13 * 64];
-}
-
 // head-input tile 0: the 4 SH components 4g + r of this lane's group, from the 16 of the view direction
 // (base_field.py:136-142: SH of (dir + 1) / 2). Selected by exact 0/1 blending (x * 1 + 0 + 0 + 0 = x): written as
 // selects, the compiler forms a dynamically indexed 16-float stack array — a scratch store + load per tile.
@@ -169,25 +140,6 @@ __device__ __forceinline__ v4f sh_quad(float dx, float dy, float dz, int g) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) out[r] = ((sh[r] * m0 + sh[4 + r] * m1) + sh[8 + r] * m2) + sh[12 + r] * m3;
   return out;
-}
-
-// head input slots of a tile from saved / recomputed pieces: SH of the view direction, base outputs, appearance row
-__device__ __forceinline__ void build_head_input(const float* __restrict__ directions,
-                                                 const float* __restrict__ app_table,
-                                                 const float* __restrict__ app_const, int64_t dir_group, int app_dim,
-                                                 const TileInputs& ti, int lane, FieldActs& A) {
-  const int g = lane >> 4;
-  const float* d = directions + 3 * ti.ray;
-  A.hin[0] = sh_quad(d[0], d[1], d[2], g);
-  A.hin[1] = A.o16[0];
-  if (app_dim > 0) {
-    const float* src = (app_table != nullptr) ? app_table + ti.cam * 32 : app_const;
-    A.hin[2] = *reinterpret_cast<const v4f*>(src + 4 * g);
-    A.hin[3] = *reinterpret_cast<const v4f*>(src + 16 + 4 * g);
-  } else {
-    A.hin[2] = v4f{0.f, 0.f, 0.f, 0.f};
-    A.hin[3] = v4f{0.f, 0.f, 0.f, 0.f};
-  }
 }
 
 // encoded features: feature-major [32][M]; lane needs features 16t + 4g + r of its point
@@ -219,37 +171,13 @@ __device__ __forceinline__ void load_enc_tile(const float* __restrict__ enc, int
     for (int r = 0; r < 4; ++r) out[t][r] = (enc + (int64_t)(16 * t + r) * M)[off];
 }
 
-// view direction and appearance row of a lane's point, loaded ahead of the tile's arithmetic
-struct HeadPre {
-  float d[3];
-  v4f app[2];
-};
-
-__device__ __forceinline__ HeadPre load_head_pre(const float* __restrict__ directions, const float* __restrict__ app_table,
-                                                 const float* __restrict__ app_const, int app_dim, const TileInputs& ti,
-                                                 int g) {
-  HeadPre h;
-  const float* d = directions + 3 * ti.ray;
-  h.d[0] = d[0]; h.d[1] = d[1]; h.d[2] = d[2];
-  if (app_dim > 0) {
-    const float* src = (app_table != nullptr) ? app_table + ti.cam * 32 : app_const;
-    h.app[0] = *reinterpret_cast<const v4f*>(src + 4 * g);
-    h.app[1] = *reinterpret_cast<const v4f*>(src + 16 + 4 * g);
-  } else {
-    h.app[0] = v4f{0.f, 0.f, 0.f, 0.f};
-    h.app[1] = v4f{0.f, 0.f, 0.f, 0.f};
-  }
-  return h;
-}
-
 // A.enc must hold the tile's encoded features (load_enc_tile) on entry.
 __device__ __forceinline__ void field_forward_tile(const float* wf, const float* bias,
                                                    const float* __restrict__ directions,
                                                    const float* __restrict__ app_table,
                                                    const float* __restrict__ app_const, int64_t dir_group, int64_t M,
                                                    int app_dim, const TileInputs& ti, int lane, FieldActs& A,
-                                                   int probe_slot = 63, const HeadPre* pre = nullptr,
-                                                   bool base_only = false) {
+                                                   int probe_slot = 63, bool base_only = false) {
   const int g = lane >> 4;
   load_bias<4>(bias + kBiasBase0, A.h1, g);
   chain_gemm<4, 2>(wf + kOffBase0, A.enc, A.h1, lane);
@@ -260,7 +188,7 @@ __device__ __forceinline__ void field_forward_tile(const float* wf, const float*
   if (base_only) return;  // density only (Field.density_fn: the head's 8 320 of 11 392 MACs per point are not needed)
 
   // head input: SH of (dir + 1) / 2  (base_field.py:136-142), geo in place, appearance embedding
-  if (pre == nullptr) {
+  {
     const float* d = directions + 3 * ti.ray;
     A.hin[0] = sh_quad(d[0], d[1], d[2], g);
     if (app_dim > 0) {
@@ -271,10 +199,6 @@ __device__ __forceinline__ void field_forward_tile(const float* wf, const float*
       A.hin[2] = v4f{0.f, 0.f, 0.f, 0.f};
       A.hin[3] = v4f{0.f, 0.f, 0.f, 0.f};
     }
-  } else {  // fetched by the caller ahead of other memory traffic (fused kernel)
-    A.hin[0] = sh_quad(pre->d[0], pre->d[1], pre->d[2], g);
-    A.hin[2] = pre->app[0];
-    A.hin[3] = pre->app[1];
   }
   A.hin[1] = A.o16[0];
   load_bias<4>(bias + kBiasHead0, A.ha, g);
@@ -324,8 +248,7 @@ template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 1 : 2) void field_mlp_fwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
-    nsamd_field_mlp mlp, int app_dim, float* __restrict__ density, float* __restrict__ rgb,
-    float* __restrict__ acts) {
+    nsamd_field_mlp mlp, int app_dim, float* __restrict__ density, float* __restrict__ rgb) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* wf = lds;
   float* bias = lds + kFragTotal;
@@ -345,10 +268,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 1 : 2) void field_mlp_fwd
     FieldActs A;
     load_enc_tile_fwd(enc, M, ti.p, lane, A.enc);
     PROBE_STAMP(WAVES, 2 + 4 * probe_it);
-    field_forward_tile(wf, bias, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A, 3 + 4 * probe_it, nullptr,
+    field_forward_tile(wf, bias, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A, 3 + 4 * probe_it,
                        rgb == nullptr);
     PROBE_STAMP(WAVES, 4 + 4 * probe_it);
-    if (acts != nullptr) store_acts(acts, tile, lane, A);
     if (lane < 16 && ti.live) {  // g == 0 holds neurons 0..3 of tile 0
       density[ti.p] = mlp.average_init_density * expf(A.o16[0][0]) * ti.sel;
       if (rgb != nullptr) {
@@ -363,16 +285,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 1 : 2) void field_mlp_fwd
   PROBE_STAMP(WAVES, 63);
 }
 
-// ---- forward on the bf16 matrix cores at fp32 accuracy (three-way operand split) -------------------------------------
-// v_mfma_f32_16x16x32_bf16 retires 8192 MACs in 4 passes, v_mfma_f32_16x16x4_f32 1024 in 8: 16x the rate. Every fp32 operand
-// is split into three bf16 pieces x = h + m + l (each the RNE bf16 of what the previous ones left; the residuals are exact
-// in fp32, so the three pieces carry 24 bits), and a product w x is formed from the six piece products down to 2^-16 of it:
-// wh xh + wh xm + wm xh + wm xm + wh xl + wl xh, accumulated in fp32 like the f32 MFMA's own chain (the three dropped terms
-// are <= 2^-23 |w x|, the size of an fp32 rounding). 6 bf16 MFMAs replace 8 f32 ones per 32 inputs: 2.7x less matrix-core
-// time, paid for with ~5.5 VALU operations per activation for the split.
-// Chain layout, K = 32: the B operand of input block kb (tiles 2kb, 2kb + 1 of the f32 chain layout) is, for lane (j, g),
-// slots s = 0..7 = features 16 (2kb) + 4g + s (s < 4), 16 (2kb + 1) + 4g + s - 4 — the lane's own accumulator registers,
-// packed in pairs; the weight fragments are staged with the same slot order, so no data moves between lanes.
+// ---- the bf16 matrix cores (v_mfma_f32_16x16x32_bf16: 8192 MACs in 4 passes, 16x the f32 MFMA's rate) ------------------------
+// Used by the backward's weight-gradient GEMMs on two-piece operands (coop_dw_pk). Operand layout: lane (j, g) holds the 8
+// contraction slots 8g .. 8g + 7 of row / column j, packed in pairs; result layout as the f32 MFMA's (probe_mfma_bf16_kernel,
+// tests/test_gpu_kernels.py). (Round 2's forward on three-piece operands — fp32-accurate, 12 % faster, not bit-identical to the
+// backward's recomputation — is csrc/experiments/rounds2to5_opt_in_variants.patch.)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));  // 8 packed bf16
@@ -386,153 +303,6 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // v_cvt_pk_b
   p[0] = (__bf16)a;
   p[1] = (__bf16)b;
   return __builtin_bit_cast(unsigned, p);
-}
-
-// (x0, x1) -> packed pieces: x = h + m + l up to 2^-25 |x|
-struct Pieces {
-  unsigned h, m, l;
-};
-
-__device__ __forceinline__ Pieces split3(float x0, float x1) {
-  Pieces p;
-  p.h = pack_bf16(x0, x1);
-  const float r0 = x0 - __uint_as_float(p.h << 16), r1 = x1 - __uint_as_float(p.h & 0xffff0000u);  // exact
-  p.m = pack_bf16(r0, r1);
-  const float s0 = r0 - __uint_as_float(p.m << 16), s1 = r1 - __uint_as_float(p.m & 0xffff0000u);  // exact
-  p.l = pack_bf16(s0, s1);
-  return p;
-}
-
-struct Op3 {
-  u4 h, m, l;
-};
-
-__device__ __forceinline__ Op3 pack_block(const v4f& t0, const v4f& t1) {
-  const Pieces a = split3(t0[0], t0[1]), b = split3(t0[2], t0[3]), c = split3(t1[0], t1[1]), d = split3(t1[2], t1[3]);
-  Op3 o;
-  o.h = u4{a.h, b.h, c.h, d.h};
-  o.m = u4{a.m, b.m, c.m, d.m};
-  o.l = u4{a.l, b.l, c.l, d.l};
-  return o;
-}
-
-// fragment sizes in u4 (16 B): [3 pieces][NT][KB][64 lanes]
-constexpr int kB3Base0 = 3 * 4 * 1 * 64, kB3Base1 = 3 * 1 * 2 * 64, kB3Head0 = 3 * 4 * 2 * 64, kB3Head1 = 3 * 4 * 2 * 64,
-              kB3Head2 = 3 * 1 * 2 * 64;
-constexpr int kB3OffBase0 = 0, kB3OffBase1 = kB3OffBase0 + kB3Base0, kB3OffHead0 = kB3OffBase1 + kB3Base1,
-              kB3OffHead1 = kB3OffHead0 + kB3Head0, kB3OffHead2 = kB3OffHead1 + kB3Head1,
-              kB3Total = kB3OffHead2 + kB3Head2;  // 4608 u4 = 72 KiB
-
-// out[n] += W[16n + .][block kb] . in[kb], smallest piece products first
-template <int NT, int KB>
-__device__ __forceinline__ void chain_gemm_bf16(const u4* frag, const Op3* in, v4f* out, int lane) {
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
-    u4 wh[NT], wm[NT], wl[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      wh[n] = frag[((0 * NT + n) * KB + kb) * 64 + lane];
-      wm[n] = frag[((1 * NT + n) * KB + kb) * 64 + lane];
-      wl[n] = frag[((2 * NT + n) * KB + kb) * 64 + lane];
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) out[n] = mfma_bf16(wl[n], in[kb].h, out[n]);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) out[n] = mfma_bf16(wh[n], in[kb].l, out[n]);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) out[n] = mfma_bf16(wm[n], in[kb].m, out[n]);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) out[n] = mfma_bf16(wm[n], in[kb].h, out[n]);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) out[n] = mfma_bf16(wh[n], in[kb].m, out[n]);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) out[n] = mfma_bf16(wh[n], in[kb].h, out[n]);
-  }
-}
-
-// one (n, kb) block of a layer: lane (i, g) slot s <-> W[16n + i][feature(kb, g, s)], split into the three piece arrays
-template <int NT, int KB>
-__device__ void stage_b3(u4* dst, const float* __restrict__ W, int n_real, int k_real, bool head0, int app_dim, int threads) {
-  for (int item = threadIdx.x; item < NT * KB * 64; item += threads) {
-    const int lane = item & 63, blk = item >> 6;
-    const int kb = blk % KB, n = blk / KB;
-    const int i = lane & 15, g = lane >> 4;
-    const int row = 16 * n + i;
-    float w[8];
-#pragma unroll
-    for (int s2 = 0; s2 < 8; ++s2) {
-      const int slot = 16 * (2 * kb + (s2 >> 2)) + 4 * g + (s2 & 3);
-      const int col = head0 ? head0_col(slot, app_dim) : slot;
-      w[s2] = (row < n_real && col >= 0 && col < k_real) ? W[row * k_real + col] : 0.0f;
-    }
-    const Pieces a = split3(w[0], w[1]), b = split3(w[2], w[3]), c = split3(w[4], w[5]), d = split3(w[6], w[7]);
-    dst[((0 * NT + n) * KB + kb) * 64 + lane] = u4{a.h, b.h, c.h, d.h};
-    dst[((1 * NT + n) * KB + kb) * 64 + lane] = u4{a.m, b.m, c.m, d.m};
-    dst[((2 * NT + n) * KB + kb) * 64 + lane] = u4{a.l, b.l, c.l, d.l};
-  }
-}
-
-constexpr int kB3Waves = 12;  // 3 waves per SIMD: 168 VGPRs each (16 waves would cap at 128 and spill)
-
-__global__ __launch_bounds__(64 * kB3Waves, 1) void field_mlp_fwd_bf16x3_kernel(
-    const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
-    const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
-    nsamd_field_mlp mlp, int app_dim, float* __restrict__ density, float* __restrict__ rgb) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  u4* wf = reinterpret_cast<u4*>(lds);
-  float* bias = lds + 4 * kB3Total;
-  constexpr int T = 64 * kB3Waves;
-  stage_b3<4, 1>(wf + kB3OffBase0, mlp.base_W0, 64, 32, false, 0, T);
-  stage_b3<1, 2>(wf + kB3OffBase1, mlp.base_W1, 16, 64, false, 0, T);
-  stage_b3<4, 2>(wf + kB3OffHead0, mlp.head_W0, 64, 31 + app_dim, true, app_dim, T);
-  stage_b3<4, 2>(wf + kB3OffHead1, mlp.head_W1, 64, 64, false, 0, T);
-  stage_b3<1, 2>(wf + kB3OffHead2, mlp.head_W2, 3, 64, false, 0, T);
-  stage_bias<T>(bias + kBiasBase0, mlp.base_b0, 64, 64);
-  stage_bias<T>(bias + kBiasBase1, mlp.base_b1, 16, 16);
-  stage_bias<T>(bias + kBiasHead0, mlp.head_b0, 64, 64);
-  stage_bias<T>(bias + kBiasHead1, mlp.head_b1, 64, 64);
-  stage_bias<T>(bias + kBiasHead2, mlp.head_b2, 3, 16);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int64_t tiles = (M + 15) / 16;
-  const float* app_table = cams ? mlp.appearance : nullptr;
-  for (int64_t tile = (int64_t)blockIdx.x * kB3Waves + wave; tile < tiles; tile += (int64_t)gridDim.x * kB3Waves) {
-    asm volatile("" ::: "memory");  // keep the fragments in LDS
-    const TileInputs ti = tile_inputs(tile, lane, M, selector, cams, dir_group);
-    v4f e[2];
-    load_enc_tile_fwd(enc, M, ti.p, lane, e);
-    const HeadPre pre = load_head_pre(directions, app_table, app_const, app_dim, ti, g);
-    Op3 x[2];
-    v4f h1[4], o16[1], ha[4], hb[4], rgbp[1];
-    x[0] = pack_block(e[0], e[1]);
-    load_bias<4>(bias + kBiasBase0, h1, g);
-    chain_gemm_bf16<4, 1>(wf + kB3OffBase0, x, h1, lane);
-    relu_tiles<4>(h1);
-    x[0] = pack_block(h1[0], h1[1]);
-    x[1] = pack_block(h1[2], h1[3]);
-    load_bias<1>(bias + kBiasBase1, o16, g);
-    chain_gemm_bf16<1, 2>(wf + kB3OffBase1, x, o16, lane);
-    x[0] = pack_block(sh_quad(pre.d[0], pre.d[1], pre.d[2], g), o16[0]);
-    x[1] = pack_block(pre.app[0], pre.app[1]);
-    load_bias<4>(bias + kBiasHead0, ha, g);
-    chain_gemm_bf16<4, 2>(wf + kB3OffHead0, x, ha, lane);
-    relu_tiles<4>(ha);
-    x[0] = pack_block(ha[0], ha[1]);
-    x[1] = pack_block(ha[2], ha[3]);
-    load_bias<4>(bias + kBiasHead1, hb, g);
-    chain_gemm_bf16<4, 2>(wf + kB3OffHead1, x, hb, lane);
-    relu_tiles<4>(hb);
-    x[0] = pack_block(hb[0], hb[1]);
-    x[1] = pack_block(hb[2], hb[3]);
-    load_bias<1>(bias + kBiasHead2, rgbp, g);
-    chain_gemm_bf16<1, 2>(wf + kB3OffHead2, x, rgbp, lane);
-    if (lane < 16 && ti.live) {
-      density[ti.p] = mlp.average_init_density * expf(o16[0][0]) * ti.sel;
-      float* o = rgb + 3 * ti.p;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) o[c] = 1.0f / (1.0f + expf(-rgbp[0][c]));
-    }
-  }
 }
 
 // one bf16 MFMA with the assumed lane mapping (layout probe for the tests): A[16][32], B[32][16] row-major fp32 holding
@@ -549,123 +319,6 @@ __global__ void probe_mfma_bf16_kernel(const float* __restrict__ A, const float*
   c = mfma_bf16(a, b, c);
 #pragma unroll
   for (int r = 0; r < 4; ++r) out[(4 * g + r) * 16 + j] = c[r];
-}
-
-// ---- fused forward: hash grid (16 levels) -> base MLP -> head MLP ----------------------------------------------------
-// One launch instead of nsamd_hashgrid_encode_fwd + nsamd_field_mlp_fwd. The two halves are bound by different units — the
-// gathers by the texture-address / L1 path (~0.55 lane-gathers per clock per CU, r02 probes), the MLPs by the matrix cores —
-// so a wave issues the 32 gathers of its NEXT tile, runs the MFMA chain of the current one while they fly, and only then
-// blends them: in the chain layout lane (j, g) holds features 16t + 4g + r of point j, i.e. the two features of levels
-// 8t + 2g and 8t + 2g + 1 — four levels of one point per lane, straight into the B operands of base layer 0.
-// Same arithmetic as hash_encode_fwd_kernel (blend order x, y, z, no contraction) and as field_forward_tile: outputs and
-// the saved features are bit-identical to the two-launch path (tests/test_gpu_kernels.py).
-constexpr int kFusedWaves = 8;
-constexpr int kFusedThreads = 64 * kFusedWaves;
-
-struct GatherSet {
-  float2 v[4][8];  // 4 levels x 8 corners of this lane's point
-  float x, y, z;   // normalised position (selector applied)
-  float sel;
-};
-
-// the 4 levels of lane group g: q = 0..3 -> 2g, 2g + 1, 8 + 2g, 9 + 2g
-__device__ __forceinline__ int fused_level(int q, int g) { return 8 * (q >> 1) + 2 * g + (q & 1); }
-
-__device__ __forceinline__ void fused_issue(const nsamd_points& P, int64_t p, int transform, const nsamd_aabb& box,
-                                            const float2* __restrict__ table, int log2_table_size,
-                                            const float* scalings_lds, int g, GatherSet& G) {
-  load_position(P, p, G.x, G.y, G.z);
-  G.sel = normalise_position(transform, box, G.x, G.y, G.z);
-  const uint32_t mask = (1u << log2_table_size) - 1u;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int level = fused_level(q, g);
-    const Cell c = locate_cell(G.x, G.y, G.z, scalings_lds[level]);
-    const float2* __restrict__ tl = table + ((size_t)level << log2_table_size);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) G.v[q][k] = tl[corner_index(c, k, mask)];
-  }
-}
-
-// blend order x, y, z exactly as encodings.py:446-456 (and hash_encode_fwd_kernel)
-__device__ __forceinline__ void fused_blend(const GatherSet& G, const float* scalings_lds, int g, v4f* enc) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const Cell c = locate_cell(G.x, G.y, G.z, scalings_lds[fused_level(q, g)]);
-    const float wx = c.w[0], wy = c.w[1], wz = c.w[2];
-    const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      auto h = [&](int k) { return f == 0 ? G.v[q][k].x : G.v[q][k].y; };
-      const float yc_zc = h(7) * wx + h(6) * ux;
-      const float yf_zc = h(5) * wx + h(4) * ux;
-      const float yf_zf = h(1) * wx + h(0) * ux;
-      const float yc_zf = h(3) * wx + h(2) * ux;
-      const float zc = yc_zc * wy + yf_zc * uy;
-      const float zf = yc_zf * wy + yf_zf * uy;
-      enc[q >> 1][2 * (q & 1) + f] = zc * wz + zf * uz;
-    }
-  }
-}
-
-__global__ __launch_bounds__(kFusedThreads, 1) void field_fused_fwd_kernel(
-    nsamd_points P, int64_t M, int transform, nsamd_aabb box, const float2* __restrict__ table, nsamd_grid grid,
-    const float* __restrict__ directions, const int64_t* __restrict__ cams, const float* __restrict__ app_const,
-    int64_t dir_group, nsamd_field_mlp mlp, int app_dim, float* __restrict__ selector_out, float* __restrict__ enc_out,
-    float* __restrict__ density, float* __restrict__ rgb) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* wf = lds;
-  float* bias = lds + kFragTotal;
-  float* scal = bias + 256;  // 16 level scalings (lane-dependent index: LDS, not the kernel-argument array)
-  stage_all_fwd<kFusedThreads>(wf, bias, mlp, app_dim);
-  if (threadIdx.x < 16) scal[threadIdx.x] = grid.scalings[threadIdx.x];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
-  const int64_t tiles = (M + 15) / 16;
-  const int64_t stride = (int64_t)gridDim.x * kFusedWaves;
-  const float* app_table = cams ? mlp.appearance : nullptr;
-  int64_t tile = (int64_t)blockIdx.x * kFusedWaves + wave;
-  GatherSet G;
-  TileInputs ti_next;
-  HeadPre pre_next;
-  if (tile < tiles) {
-    // order matters: vmcnt retires in order, so whatever the MFMA chain waits for must be OLDER than the gathers that are
-    // meant to stay in flight behind it
-    ti_next = tile_inputs(tile, lane, M, nullptr, cams, dir_group);
-    pre_next = load_head_pre(directions, app_table, app_const, app_dim, ti_next, g);
-    fused_issue(P, min(tile * 16 + j, M - 1), transform, box, table, grid.log2_table_size, scal, g, G);
-  }
-  for (; tile < tiles; tile += stride) {
-    asm volatile("" ::: "memory");  // keep the weight fragments in LDS (see field_mlp_fwd_kernel)
-    const TileInputs ti = ti_next;
-    const HeadPre pre = pre_next;
-    FieldActs A;
-    fused_blend(G, scal, g, A.enc);  // waits for this tile's gathers
-    const float sel = G.sel;
-    // the next tile's inputs, then its gathers: they fly while the matrix cores work on this one
-    if (tile + stride < tiles) {
-      ti_next = tile_inputs(tile + stride, lane, M, nullptr, cams, dir_group);
-      pre_next = load_head_pre(directions, app_table, app_const, app_dim, ti_next, g);
-      fused_issue(P, min((tile + stride) * 16 + j, M - 1), transform, box, table, grid.log2_table_size, scal, g, G);
-    }
-    if (ti.live) {  // (after the loads above: the appearance row depends on the camera index, and waiting for that load
-                    //  must not wait for these stores)
-      if (g == 0 && selector_out != nullptr) selector_out[ti.p] = sel;
-      if (enc_out != nullptr) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) enc_out[(int64_t)(16 * t + 4 * g + r) * M + ti.p] = A.enc[t][r];
-      }
-    }
-    field_forward_tile(wf, bias, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A, 63, &pre);
-    if (lane < 16 && ti.live) {
-      density[ti.p] = mlp.average_init_density * expf(A.o16[0][0]) * sel;
-      float* o = rgb + 3 * ti.p;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) o[c] = 1.0f / (1.0f + expf(-A.rgbp[0][c]));
-    }
-  }
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------
@@ -1271,16 +924,14 @@ struct RouteBetween {
   }
 };
 
-// ROUTE: the kernel also emits the table scatter's pass-1 records. SAVED: the forward's activations come from `acts`
-// (nsamd_field_mlp_bwd_saved) instead of being recomputed; every other variant fetches a tile's inputs one tile ahead.
-template <bool ROUTE, bool SAVED>
+// ROUTE: the kernel also emits the table scatter's pass-1 records. A tile's inputs are fetched one tile ahead.
+template <bool ROUTE>
 __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
     nsamd_field_mlp mlp, int app_dim, const float* __restrict__ ddensity, const float* __restrict__ drgb,
     float* __restrict__ denc, nsamd_field_mlp_grads grads, float* __restrict__ partials,
-    float* __restrict__ app_partials, int app_rows_per_point, const float* __restrict__ acts, int probe_skip_arg,
-    RouteArgs R) {
+    float* __restrict__ app_partials, int app_rows_per_point, int probe_skip_arg, RouteArgs R) {
   // probe_skip (NSAMD_FIELD_BWD_SKIP, timing experiments only — results are wrong when set): 1 = no weight-gradient
   // MFMAs, 2 = no workgroup barriers inside the tile loop, 4 = no data-gradient GEMMs. A run-time value only in the
   // instrumented build (`make probe`): the product kernel folds the switches away (a dozen scalar conditions and their
@@ -1351,7 +1002,7 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
 #ifndef NSAMD_NOROUTE_AHEAD
 #define NSAMD_NOROUTE_AHEAD 1
 #endif
-  constexpr bool AHEAD = !SAVED && (ROUTE || NSAMD_NOROUTE_AHEAD);
+  constexpr bool AHEAD = ROUTE || NSAMD_NOROUTE_AHEAD;
   TileFetch nxt;
   if (AHEAD && iters > 0)
     fetch_tile(nxt, (int64_t)blockIdx.x * kCoopWaves + wave, tiles, lane, M, enc, selector, directions, cams, app_table, app_const,
@@ -1394,14 +1045,9 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
         for (int c = 0; c < 3; ++c) up_rgb[c] = drgb[3 * ti.p + c];
         up_density = ddensity[ti.p];
       }
-      if (acts != nullptr) {  // saved by the forward of this step: no recomputation
-        load_acts(acts, tile < tiles ? tile : tiles - 1, lane, A);
-        build_head_input(directions, app_table, app_const, dir_group, app_dim, ti, lane, A);
-      } else {
-        const float* d = directions + 3 * ti.ray;  // consumed two layers further down
-        const float dir[3] = {d[0], d[1], d[2]};
-        coop_forward_tile(W, bias, dir, app_table, app_const, app_dim, ti, lane, A);
-      }
+      const float* d = directions + 3 * ti.ray;  // consumed two layers further down
+      const float dir[3] = {d[0], d[1], d[2]};
+      coop_forward_tile(W, bias, dir, app_table, app_const, app_dim, ti, lane, A);
     }
     PROBE_STAMP(kCoopWaves, 3 + 10 * (int)it);
     const bool emit = ROUTE && it > 0 && !(probe_skip & 32);  // the previous tile's records are still going out
@@ -1690,45 +1336,29 @@ static int num_cus() {
 
 static int field_mlp_fwd_impl(const float* enc, const float* selector, const float* directions,
                               const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
-                              nsamd_field_mlp mlp, float* density, float* rgb, float* acts, nsamd_stream_t stream) {
+                              nsamd_field_mlp mlp, float* density, float* rgb, nsamd_stream_t stream) {
   if (M == 0) return NSAMD_OK;
   int app_dim = 0;
   int st = field_common_checks(enc, directions, dir_group, M, mlp, camera_indices, appearance_const, &app_dim);
   if (st) return st;
-  NSAMD_REQUIRE(density != nullptr && (rgb != nullptr || acts == nullptr));  // rgb NULL: density only (no saved activations)
+  NSAMD_REQUIRE(density != nullptr);  // rgb NULL: density only
   const size_t lds = sizeof(float) * (kFragTotal + 256);
   const int64_t tiles = (M + 15) / 16;
   // One 16-wave workgroup per CU by default (4 waves per SIMD, the weights staged once per CU): 57 us on the bench shape
   // against 59.5 (8 waves x 2 workgroups) and 65 (4 waves x 3) on the same box — NSAMD_FIELD_FWD_WAVES=8|4 selects those.
   static const int waves = getenv("NSAMD_FIELD_FWD_WAVES") ? atoi(getenv("NSAMD_FIELD_FWD_WAVES")) : 16;
-  static const int bf16x3 = getenv("NSAMD_FIELD_FWD_BF16X3") ? atoi(getenv("NSAMD_FIELD_FWD_BF16X3")) : 0;
-  if (bf16x3 && acts == nullptr && rgb != nullptr) {
-    // bf16 matrix cores, three-way split operands (fp32 accuracy)
-    const size_t lds3 = sizeof(float) * (4 * (size_t)kB3Total + 256);
-    static bool attr3[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return NSAMD_ERR_NO_DEVICE;
-    if (dev < 0 || dev >= 64 || !attr3[dev]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_fwd_bf16x3_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess)
-        return NSAMD_ERR_LAUNCH;
-      if (dev >= 0 && dev < 64) attr3[dev] = true;
-    }
-    const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + kB3Waves - 1) / kB3Waves);
-    field_mlp_fwd_bf16x3_kernel<<<blocks, 64 * kB3Waves, lds3, (hipStream_t)stream>>>(
-        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb);
-  } else if (waves == 16) {
+  if (waves == 16) {
     const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + 15) / 16);
     field_mlp_fwd_kernel<16><<<blocks, 1024, lds, (hipStream_t)stream>>>(
-        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb, acts);
+        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb);
   } else if (waves == 8) {
     const unsigned blocks = (unsigned)min((int64_t)num_cus() * 2, (tiles + 7) / 8);
     field_mlp_fwd_kernel<8><<<blocks, 512, lds, (hipStream_t)stream>>>(
-        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb, acts);
+        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb);
   } else {
     const unsigned blocks = (unsigned)min((int64_t)num_cus() * 3, (tiles + kWaves - 1) / kWaves);
     field_mlp_fwd_kernel<kWaves><<<blocks, kFieldThreads, lds, (hipStream_t)stream>>>(
-        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb, acts);
+        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb);
   }
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
@@ -1739,51 +1369,14 @@ extern "C" int nsamd_field_mlp_fwd(const float* enc, const float* selector, cons
                                    int64_t M, nsamd_field_mlp mlp, float* density, float* rgb,
                                    nsamd_stream_t stream) {
   return field_mlp_fwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, density,
-                            rgb, nullptr, stream);
-}
-
-extern "C" int nsamd_field_fused_fwd(nsamd_points pts, int64_t M, int transform, nsamd_aabb aabb, const float* table,
-                                    nsamd_grid grid, const float* directions, const int64_t* camera_indices,
-                                    const float* appearance_const, int64_t dir_group, nsamd_field_mlp mlp,
-                                    float* selector, float* enc, float* density, float* rgb, nsamd_stream_t stream) {
-  if (M == 0) return NSAMD_OK;
-  if (grid.num_levels != 16) return NSAMD_ERR_UNSUPPORTED;  // 32 features = the K of base layer 0
-  NSAMD_REQUIRE(M > 0 && table != nullptr && transform >= 0 && transform <= 2);
-  NSAMD_REQUIRE(grid.log2_table_size >= 1 && grid.log2_table_size <= 28);
-  if (pts.positions == nullptr) {
-    NSAMD_REQUIRE(pts.origins && pts.directions && pts.t_bins && pts.samples_per_ray > 0 && M % pts.samples_per_ray == 0);
-  }
-  int app_dim = 0;
-  const float dummy = 0.0f;
-  int st = field_common_checks(&dummy, directions, dir_group, M, mlp, camera_indices, appearance_const, &app_dim);
-  if (st) return st;
-  NSAMD_REQUIRE(density && rgb);
-  const size_t lds = sizeof(float) * (kFragTotal + 256 + 16);
-  const int64_t tiles = (M + 15) / 16;
-  const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + kFusedWaves - 1) / kFusedWaves);
-  field_fused_fwd_kernel<<<blocks, kFusedThreads, lds, (hipStream_t)stream>>>(
-      pts, M, transform, aabb, reinterpret_cast<const float2*>(table), grid, directions, camera_indices, appearance_const,
-      dir_group, mlp, app_dim, selector, enc, density, rgb);
-  NSAMD_CHECK_LAUNCH();
-  return NSAMD_OK;
-}
-
-extern "C" int64_t nsamd_field_mlp_saved_floats(int64_t M) { return M <= 0 ? 0 : ((M + 15) / 16) * kActSlots * 256; }
-
-extern "C" int nsamd_field_mlp_fwd_save(const float* enc, const float* selector, const float* directions,
-                                        const int64_t* camera_indices, const float* appearance_const,
-                                        int64_t dir_group, int64_t M, nsamd_field_mlp mlp, float* density, float* rgb,
-                                        float* saved, nsamd_stream_t stream) {
-  NSAMD_REQUIRE(M == 0 || saved != nullptr);
-  return field_mlp_fwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, density,
-                            rgb, saved, stream);
+                            rgb, stream);
 }
 
 static int field_mlp_bwd_impl(const float* enc, const float* selector, const float* directions,
                               const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
                               nsamd_field_mlp mlp, const float* ddensity, const float* drgb, float* denc,
                               nsamd_field_mlp_grads grads, float* workspace, int64_t workspace_floats,
-                              const float* acts, nsamd_stream_t stream, int phases = 3, const RouteArgs* route_in = nullptr,
+                              nsamd_stream_t stream, int phases = 3, const RouteArgs* route_in = nullptr,
                               float* dtable = nullptr, float* scatter_ws = nullptr, int64_t scatter_ws_floats = 0) {
   // phases: 1 = the gradient kernel (denc + per-workgroup partials), 2 = the fixed-order sum of the partials, 3 = both
   if (M == 0) return NSAMD_OK;
@@ -1797,11 +1390,9 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return NSAMD_ERR_NO_DEVICE;
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {  // the dynamic-LDS opt-in is per device
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<false, false>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<false, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<true, false>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + sizeof(uint32_t) * kRouteLdsWords)) != hipSuccess)
       return NSAMD_ERR_LAUNCH;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
@@ -1826,7 +1417,7 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
   ScatterPlan plan{};
   if (route_in != nullptr) {
     // producer mode: the kernel emits the scatter's pass-1 records (one static segment per workgroup and tile)
-    NSAMD_REQUIRE(acts == nullptr && dtable != nullptr && scatter_ws != nullptr && partials != nullptr);
+    NSAMD_REQUIRE(dtable != nullptr && scatter_ws != nullptr && partials != nullptr);
     plan = scatter_plan_producers(route_in->grid, M, (int)blocks, kProducerSegCap);
     if (!plan.ok) return NSAMD_ERR_UNSUPPORTED;
     NSAMD_REQUIRE(scatter_ws_floats >= plan.total_words);
@@ -1835,20 +1426,15 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
     R.buf = scatter_bufs(scatter_ws, plan);
     R.buf.log2_table_size = R.grid.log2_table_size;
     if (phases & 1) {
-      field_mlp_bwd_kernel<true, false><<<blocks, kCoopThreads, lds + sizeof(uint32_t) * kRouteLdsWords, (hipStream_t)stream>>>(
+      field_mlp_bwd_kernel<true><<<blocks, kCoopThreads, lds + sizeof(uint32_t) * kRouteLdsWords, (hipStream_t)stream>>>(
           enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-          grads, partials, app_partials, app_rows_per_point, acts, probe_skip, R);
+          grads, partials, app_partials, app_rows_per_point, probe_skip, R);
       NSAMD_CHECK_LAUNCH();
     }
   } else if (phases & 1) {
-    if (acts != nullptr)
-      field_mlp_bwd_kernel<false, true><<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
-          enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-          grads, partials, app_partials, app_rows_per_point, acts, probe_skip, RouteArgs{});
-    else
-      field_mlp_bwd_kernel<false, false><<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
-          enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-          grads, partials, app_partials, app_rows_per_point, nullptr, probe_skip, RouteArgs{});
+    field_mlp_bwd_kernel<false><<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
+        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
+        grads, partials, app_partials, app_rows_per_point, probe_skip, RouteArgs{});
     NSAMD_CHECK_LAUNCH();
   }
   // weight-gradient partials -> gradients, and (extra blocks, one per camera) the appearance rows -> embedding gradient
@@ -1916,7 +1502,7 @@ extern "C" int nsamd_field_mlp_bwd_scatter_phase(nsamd_points pts, int transform
   R.box = aabb;
   R.grid = grid;
   return field_mlp_bwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, ddensity, drgb,
-                            denc, grads, workspace, workspace_floats, nullptr, stream, phase, &R, dtable, scatter_workspace,
+                            denc, grads, workspace, workspace_floats, stream, phase, &R, dtable, scatter_workspace,
                             scatter_workspace_floats);
 }
 
@@ -1938,7 +1524,7 @@ extern "C" int nsamd_field_mlp_bwd(const float* enc, const float* selector, cons
                                    float* denc, nsamd_field_mlp_grads grads, float* workspace,
                                    int64_t workspace_floats, nsamd_stream_t stream) {
   return field_mlp_bwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, ddensity,
-                            drgb, denc, grads, workspace, workspace_floats, nullptr, stream);
+                            drgb, denc, grads, workspace, workspace_floats, stream);
 }
 
 extern "C" int nsamd_field_mlp_bwd_phase(const float* enc, const float* selector, const float* directions,
@@ -1948,18 +1534,7 @@ extern "C" int nsamd_field_mlp_bwd_phase(const float* enc, const float* selector
                                          int64_t workspace_floats, int phase, nsamd_stream_t stream) {
   NSAMD_REQUIRE(phase == 1 || phase == 2);
   return field_mlp_bwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, ddensity,
-                            drgb, denc, grads, workspace, workspace_floats, nullptr, stream, phase);
-}
-
-extern "C" int nsamd_field_mlp_bwd_saved(const float* enc, const float* selector, const float* directions,
-                                         const int64_t* camera_indices, const float* appearance_const,
-                                         int64_t dir_group, int64_t M, nsamd_field_mlp mlp, const float* saved,
-                                         const float* ddensity, const float* drgb, float* denc,
-                                         nsamd_field_mlp_grads grads, float* workspace, int64_t workspace_floats,
-                                         nsamd_stream_t stream) {
-  NSAMD_REQUIRE(M == 0 || saved != nullptr);
-  return field_mlp_bwd_impl(enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, ddensity,
-                            drgb, denc, grads, workspace, workspace_floats, saved, stream);
+                            drgb, denc, grads, workspace, workspace_floats, stream, phase);
 }
 
 extern "C" int nsamd_probe_mfma_bf16(const float* A, const float* B, float* out, nsamd_stream_t stream) {

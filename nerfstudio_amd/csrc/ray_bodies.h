@@ -691,7 +691,7 @@ __device__ __forceinline__ void interlevel_body(
   for (int i = lane; i <= Sf; i += 64) c[i] = c_in[ray * (Sf + 1) + i];
   if (dens_fine != nullptr) {
     // the fine level's weights from its densities (RaySamples.get_weights, cameras/rays.py:129-152): the same operations as
-    // composite_fwd_body, so the same bits — a launch that composites and takes the losses at once (nsamd_render_losses_train)
+    // composite_fwd_body, so the same bits — a launch that composites and takes the losses at once (round 5's merged launch: csrc/experiments)
     // has no weight row in memory yet when this wave starts
     const float* tbf = t_fine + ray * (Sf + 1);
     double w_carry = 0.0;

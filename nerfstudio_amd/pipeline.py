@@ -246,8 +246,8 @@ class TrainEngine:
         model = self.pipeline.model
         outputs = r.outputs()
         if getattr(r, "_loss_vals_fresh", False) and model.config.background_color != "random":
-            # the losses launch's finishing pass left the loss values and the training metrics in five floats
-            # (include/nsamd.h, nsamd_render_losses_train): one clone per iteration instead of a dozen reduction launches
+            # nsamd_train_loss_values left the loss values and the training metrics in five floats (include/nsamd.h): one clone
+            # per iteration instead of a dozen reduction launches
             rgb, inter, dist, psnr, dmetric = _LossValuesBackpropagated.apply(self._anchor, r.loss_vals)
             loss_dict = {"rgb_loss": rgb, "interlevel_loss": inter, "distortion_loss": dist}
             metrics = {"psnr": psnr.detach(), "distortion": dmetric.detach()}

@@ -12,8 +12,8 @@ module API with autograd; this runner issues THE SAME kernels in a fixed order o
             -> (only on proposal-update steps, ray_samplers.py:590) weights_bwd -> density_mlp_bwd -> hash_bwd x 2
 
 ~25 launches, every one a libnsamd kernel (round 5: batch selection + initial bins are one launch, the main field's
-weight-gradient reduce rides the table scatter's apply pass; the fully merged forms of the per-ray stages — nsamd_proposal_sampler,
-nsamd_render_losses_train — exist, are bit-identical and measured slower, so they are opt-in: DESIGN.md 4.8); parameter gradients
+weight-gradient reduce rides the table scatter's apply pass; the fully merged forms of the per-ray stages were bit-identical and
+measured slower — csrc/experiments/rounds2to5_opt_in_variants.patch); parameter gradients
 accumulate directly into `param.grad` (the views of arena.ParamArena). Nothing here depends on host-side values that change from step to step (the jitter is drawn on the
 device, the anneal exponent lives in device memory), so the whole iteration can be captured in a hipGraph once per
 schedule variant and replayed. Numerically identical to the autograd path (tests/test_gpu_kernels.py compares them).
@@ -112,11 +112,8 @@ class NerfactoTrainStep:
         self._pl_per_ray = parr(self.inter_per_ray)
         self._pl_dw = parr(self.dw_prop)
         self._pl_S = (C.c_int32 * self.n_prop)(*self.counts[: self.n_prop])
-        self._pl_t_bins = parr(self.t_bins[: self.n_prop])
-        self._pl_dens = parr(self.p_dens)
         self.f_denc = t(*self.f_enc.shape)
         self.p_ddens = [t(*x.shape) for x in self.p_dens]
-        self._pl_ddens = (C.c_void_p * self.n_prop)(*[x.data_ptr() for x in self.p_ddens])
         self.p_denc = [t(*x.shape) for x in self.p_enc]
         self.field_ws = None if forward_only else F.field_bwd_workspace(device)[0]
         # one scratch per proposal level: their backward chains may run concurrently on different streams
@@ -130,32 +127,10 @@ class NerfactoTrainStep:
         self.gates_precleared = False  # True: the caller zeroes `prop_gates` before every proposal backward (trainer.HipTrainer)
         # ... and its per-ray form (1 = the ray carries gradient): levels that are only partly without gradient
         self.prop_ray_masks = [torch.zeros(n, device=device, dtype=torch.uint8) for _ in range(self.n_prop)]
-        self._pl_masks = (C.c_void_p * max(self.n_prop, 1))(*[x.data_ptr() for x in self.prop_ray_masks])
-        self._pl_gates = (C.c_void_p * max(self.n_prop, 1))(*[self.prop_gates.data_ptr() + 16 * i for i in range(self.n_prop)])
-        # Optional (NSAMD_FIELD_SAVE_ACTS=1): the forward saves the main field's activations (896 B per sample) and the
-        # backward loads them instead of recomputing the forward. Measured on MI355X: backward 186 -> 176 us but forward
-        # 60 -> 76 us — the backward is bound by its workgroup barriers, not by the recomputed MFMAs — so off by default.
-        self.save_acts = os.environ.get("NSAMD_FIELD_SAVE_ACTS", "0") == "1"
-        # One launch for hash grid + MLPs of the main field (nsamd_field_fused_fwd) — measured SLOWER than the two launches on
-        # MI355X (155-160 us against 78 + 56): a wave that gathers all 16 levels at once loses the level-major sweep's L2
-        # locality (each 4 MB level slice stays in one L2 while it is swept), which is worth more than hiding the gathers
-        # behind the MFMA chain. Kept as an opt-in, bit-identical alternative (profiles/r02_negative_results.txt).
-        self.fuse_main_forward = os.environ.get("NSAMD_FUSE_MAIN_FWD", "0") == "1"
         # The main field's backward emits the table scatter's pass-1 records itself (nsamd_field_mlp_bwd_scatter: no `denc`
         # round trip, no route launch); NSAMD_FUSE_ROUTE=0: the two entry points (A/B).
         self.fuse_route = os.environ.get("NSAMD_FUSE_ROUTE", "1") == "1"
         self.keep_denc = False  # True: the fused launch also stores the encoded-feature gradient in `f_denc` (tests read it)
-        # Everything between the main field's forward and its backward in ONE launch (nsamd_render_losses_train: compositing +
-        # MSE, the proposal losses, the compositing backward — three dependent launches before — and, on the steps that update
-        # the proposal networks, each proposal level's weights backward); NSAMD_FUSE_RAYS=0: the separate launches (A/B), same
-        # bits. NSAMD_FOLD_WEIGHTS_BWD=0 keeps the levels' weights backward at the head of their own chains.
-        # Measured on MI355X (profiles/r05_s3_ab.txt, four alternating repeats on one box): the ONE launch is ~19 us per
-        # iteration SLOWER than the three to five it replaces (0.711 against 0.692 ms with everything else equal) — one wave per
-        # (ray, job) runs the stages one after the other, and a launch of latency chains lasts as long as its longest chain — so
-        # it is an opt-in (NSAMD_FUSE_RAYS=1), kept as the bit-identical reference of the launch-merging experiment.
-        self.fuse_rays = os.environ.get("NSAMD_FUSE_RAYS", "0") == "1"
-        self.fold_weights_bwd = os.environ.get("NSAMD_FOLD_WEIGHTS_BWD", "1") == "1"
-        self._rays_bwd_fresh = False  # `losses` has already run the compositing backward for this forward
         self.prop_mlp_inline = os.environ.get("NSAMD_PROP_MLP_INLINE", "0") == "1"
         # the iteration's loss values and training metrics, written by the losses launch's finishing pass (nsamd.h):
         # rgb_loss, interlevel_loss, distortion_loss, psnr, distortion, sum of the three losses
@@ -165,18 +140,9 @@ class NerfactoTrainStep:
         # (slot pointer, slots, pool) of a batch selection the caller leaves to `forward_proposals` (one launch with the initial
         # bins, nsamd_select_bins); NSAMD_FUSE_SELECT=0: the caller launches nsamd_select_batch itself (A/B)
         self.pending_select = None
-        # NSAMD_FUSE_SAMPLER=1 (opt-in): the proposal sampler's whole cascade in one launch (nsamd_proposal_sampler), same bits as
-        # the 1 + 2 launches per level. Measured SLOWER on MI355X (profiles/r05_s2_ab.txt: 139 us against 116 us for the five
-        # launches, +35 us per iteration): with one wave per ray the launch lasts as long as ONE wave's chain — six density
-        # passes of 40 gathers each behind two 15 us resampling chains — at four waves per SIMD, where the per-level density
-        # launches run sixteen waves per SIMD at the vector unit's issue limit (919 VALU instructions per 64 points = 28 us).
-        self.fuse_sampler = os.environ.get("NSAMD_FUSE_SAMPLER", "0") == "1"
-        self._sampler_ok = True
         self._slot0 = None  # a device zero: `set_batch` as a one-slot batch selection
         self._outputs = None
         self.fuse_select = os.environ.get("NSAMD_FUSE_SELECT", "1") == "1"
-        self._wb_folded = set()       # proposal levels whose weights backward `losses` has already run
-        self.f_saved = e(int(N.load().nsamd_field_mlp_saved_floats(mm))) if self.save_acts else None
         # Second stream for the proposal-network backward: the two backward chains are independent, and since the
         # scatter kernels were reworked (latency-bound phases, small workgroups) they overlap: 3.87 -> 4.02 M rays/s on
         # MI355X (profiles/). `side_stream = None` runs them back to back (the data-parallel path does: its proposal
@@ -491,35 +457,6 @@ class NerfactoTrainStep:
         S0 = self.counts[0]
         jit0 = self.jitter_edges[0] if per_edge else self.jitter[0]
         sel, self.pending_select = self.pending_select, None
-        if self.fuse_sampler and not per_edge and self._sampler_ok:
-            # the whole cascade — [batch selection,] initial bins, and per level density -> weights -> median depth ->
-            # resampling — in ONE launch, one wavefront per ray (nsamd_proposal_sampler; same bits as the launches below)
-            levels = (N.SamplerLevel * self.n_prop)()
-            for lvl in range(self.n_prop):
-                net, Lv = self.props[lvl], levels[lvl]
-                W0, b0, W1, b1 = net.mlp_base[1].param_tensors()
-                Lv.table, Lv.grid, Lv.aabb, Lv.transform = N.ptr(net.encoding.hash_table), net.encoding.spec.native(), net._box, net._transform
-                Lv.mlp = N.DensityMlp(N.ptr(W0), N.ptr(b0), N.ptr(W1), N.ptr(b1), W0.shape[1], W0.shape[0],
-                                      float(net.average_init_density))
-                Lv.samples = self.counts[lvl]
-                Lv.s_bins, Lv.t_bins, Lv.density = N.ptr(self.s_bins[lvl]), N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl])
-                Lv.enc, Lv.selector, Lv.pre = ((N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]))
-                                               if need_enc else (None, None, None))
-                Lv.weights = N.ptr(self.weights[lvl])
-                Lv.depth_median = N.ptr(self.depth_med[lvl]) if self.compute_depths else None
-                Lv.u_base, Lv.jitter = N.ptr(self.u_base[lvl + 1]), N.ptr(self.jitter[lvl + 1])
-                Lv.u_offset = 1.0 / (2 * (self.counts[lvl + 1] + 1))
-            slot, slots, pool = sel if sel is not None else (None, 0, None)
-            pp = (lambda k: N.ptr(pool[k])) if pool is not None else (lambda k: None)  # noqa: E731
-            rc = lib.nsamd_proposal_sampler(
-                slot, slots, pp("origins"), pp("directions"), pp("cameras"), pp("target"), N.ptr(self.camera_indices),
-                N.ptr(self.target), N.ptr(self.origins), N.ptr(self.directions), N.ptr(self.nears), N.ptr(self.fars), n,
-                N.ptr(self.edges), N.ptr(jit0), self.spacing, 1.0, N.ptr(self.anneal_dev), 0.01, 1e-5, self.n_prop, levels,
-                self.counts[-1], N.ptr(self.s_bins[-1]), N.ptr(self.t_bins[-1]), st)
-            if rc != N.ERR_UNSUPPORTED:
-                ck(rc, "proposal_sampler")
-                return
-            self._sampler_ok = False  # network shapes the one-launch cascade is not built for: the per-level launches
         if sel is not None:
             # the step's batch out of the caller's pool of batches AND the initial bins in one launch (trainer.HipTrainer hands
             # the selection over instead of launching it: the bins need nears / fars / the draw, not the rays)
@@ -599,29 +536,11 @@ class NerfactoTrainStep:
         fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), emb.shape[0] if emb is not None else 0,
                         float(fld.average_init_density))
         cams = N.ptr(self.camera_indices) if emb is not None else None
-        fused = N.ERR_UNSUPPORTED
-        if not self.save_acts and self.fuse_main_forward:
-            # hash grid -> base -> head in one launch (features in registers, next tile's gathers behind the MFMA chain)
-            fused = lib.nsamd_field_fused_fwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
-                                              enc.spec.native(), N.ptr(self.directions), cams, None, S, fm,
-                                              N.ptr(self.f_sel), N.ptr(self.f_enc), N.ptr(self.f_dens), N.ptr(self.f_rgb), st)
-            if fused != N.ERR_UNSUPPORTED:
-                ck(fused, "field_fused_fwd")
-        if fused != N.ERR_UNSUPPORTED:
-            pass
-        elif self.save_acts:
-            ck(lib.nsamd_hashgrid_encode_fwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
-                                             enc.spec.native(), N.ptr(self.f_enc), 1, mm, N.ptr(self.f_sel), st),
-               "hashgrid_encode_fwd")
-            ck(lib.nsamd_field_mlp_fwd_save(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm,
-                                            fm, N.ptr(self.f_dens), N.ptr(self.f_rgb), N.ptr(self.f_saved), st),
-               "field_mlp_fwd_save")
-        else:
-            ck(lib.nsamd_hashgrid_encode_fwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
-                                             enc.spec.native(), N.ptr(self.f_enc), 1, mm, N.ptr(self.f_sel), st),
-               "hashgrid_encode_fwd")
-            ck(lib.nsamd_field_mlp_fwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
-                                       N.ptr(self.f_dens), N.ptr(self.f_rgb), st), "field_mlp_fwd")
+        ck(lib.nsamd_hashgrid_encode_fwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
+                                         enc.spec.native(), N.ptr(self.f_enc), 1, mm, N.ptr(self.f_sel), st),
+           "hashgrid_encode_fwd")
+        ck(lib.nsamd_field_mlp_fwd(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
+                                   N.ptr(self.f_dens), N.ptr(self.f_rgb), st), "field_mlp_fwd")
 
     @profiler.time_function
     def losses(self, updated: bool) -> None:
@@ -631,38 +550,7 @@ class NerfactoTrainStep:
         ck = N.check
         L = self.n_prop
         S = self.counts[L]
-        self._rays_bwd_fresh = False
         self._loss_vals_fresh = False
-        self._wb_folded = set()
-        if self.fuse_rays and not self.forward_only:
-            # one launch: weights + compositing + MSE, the proposal losses, the compositing backward (d rgb / d density of the
-            # fine samples) and, when the proposal networks get gradient this step, each level's weights backward
-            fold = updated and self.fold_weights_bwd and self.n_prop > 0
-            gated = False
-            if fold:
-                # the levels' chains are gated only when a binned-scatter workspace exists for them (backward_proposals)
-                gated = self.gate_proposals and all(
-                    F._scatter_workspace(self.props[lvl].encoding.spec, self.f_enc.device, n * self.counts[lvl])[0] is not None
-                    for lvl in range(self.n_prop))
-                if gated and not self.gates_precleared:
-                    self.prop_gates.zero_()
-            ck(lib.nsamd_render_losses_train(
-                N.ptr(self.f_rgb), N.ptr(self.f_dens), N.ptr(self.t_bins[L]), N.ptr(self.s_bins[L]), n, S, self.bg_mode,
-                self.bg_vals, N.ptr(self.target), 1.0 / (3 * n), N.ptr(self.bg_rays), N.ptr(self.weights[L]), N.ptr(self.rgb),
-                N.ptr(self.acc), N.ptr(self.depth_exp), N.ptr(self.depth_med[L]) if self.compute_depths else None,
-                N.ptr(self.minmax_ws), N.ptr(self.sq_err), N.ptr(self.d_rgb_out), self.n_prop, self._pl_s_bins,
-                self._pl_weights, self._pl_S, float(cfg.interlevel_loss_mult) / (n * S), float(cfg.distortion_loss_mult) / n,
-                self._pl_per_ray, self._pl_dw if updated else None, N.ptr(self.dist_per_ray), N.ptr(self.dw_dist),
-                N.ptr(self.d_rgb_s), N.ptr(self.d_dens_main), self._pl_t_bins if fold else None,
-                self._pl_dens if fold else None, self._pl_ddens if fold else None, self._pl_gates if (fold and gated) else None,
-                self._pl_masks if (fold and gated) else None, float(cfg.interlevel_loss_mult),
-                float(cfg.distortion_loss_mult), N.ptr(self.loss_vals), st), "render_losses_train")
-            self._rays_bwd_fresh = True
-            self._loss_vals_fresh = True
-            if fold:
-                self._wb_folded = set(range(self.n_prop))
-                self._wb_gated = gated
-            return
         # weights + compositing + MSE value/gradient in one launch (+ the global depth clip)
         ck(lib.nsamd_render_train(N.ptr(self.f_rgb), N.ptr(self.f_dens), N.ptr(self.t_bins[L]), n, S, self.bg_mode,
                                   self.bg_vals, N.ptr(self.target), 1.0 / (3 * n), N.ptr(self.weights[L]), N.ptr(self.rgb),
@@ -691,13 +579,10 @@ class NerfactoTrainStep:
         ck = N.check
         L = self.n_prop
         S = self.counts[L]
-        if self._rays_bwd_fresh:  # `losses` ran the compositing backward in its own launch (nsamd_render_losses_train)
-            self._rays_bwd_fresh = False
-        else:
-            ck(lib.nsamd_render_train_bwd(N.ptr(self.f_rgb), N.ptr(self.weights[L]), N.ptr(self.f_dens), N.ptr(self.t_bins[L]),
-                                          n, S, self.bg_mode, self.bg_vals, N.ptr(self.d_rgb_out), N.ptr(self.dw_dist),
-                                          N.ptr(self.d_rgb_s), N.ptr(self.d_dens_main), N.ptr(self.bg_rays), st),
-               "render_train_bwd")
+        ck(lib.nsamd_render_train_bwd(N.ptr(self.f_rgb), N.ptr(self.weights[L]), N.ptr(self.f_dens), N.ptr(self.t_bins[L]),
+                                      n, S, self.bg_mode, self.bg_vals, N.ptr(self.d_rgb_out), N.ptr(self.dw_dist),
+                                      N.ptr(self.d_rgb_s), N.ptr(self.d_dens_main), N.ptr(self.bg_rays), st),
+           "render_train_bwd")
         if self.gradient_scaling:  # scale_gradients_by_distance_squared on the field's outputs (models/nerfacto.py:321-322)
             ck(lib.nsamd_distance_gradient_scale(N.ptr(self.t_bins[L]), n, S, N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s), st),
                "distance_gradient_scale")
@@ -719,8 +604,8 @@ class NerfactoTrainStep:
                         float(fld.average_init_density))
         cams = N.ptr(self.camera_indices) if emb is not None else None
         grads = N.FieldMlpGrads(*(N.ptr(self._grad(p)) for p in params), N.ptr(self._grad(emb)) if emb is not None else None)
-        split = self.split_reduce and self.side_stream is not None and not self.save_acts
-        if (self.fuse_route and self.main_table_write_only and not self.defer_table and not self.save_acts
+        split = self.split_reduce and self.side_stream is not None
+        if (self.fuse_route and self.main_table_write_only and not self.defer_table
                 and enc.spec.num_levels == 16):
             sws, sws_n = F._producer_scatter_workspace(enc.spec, self.f_enc.device, mm)
             if sws is not None:
@@ -749,12 +634,7 @@ class NerfactoTrainStep:
                 if self.cam_opt is not None:
                     self._rays_backward(L, fld, self.f_denc)
                 return
-        if self.save_acts:
-            ck(lib.nsamd_field_mlp_bwd_saved(N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S,
-                                             mm, fm, N.ptr(self.f_saved), N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s),
-                                             N.ptr(self.f_denc), grads, N.ptr(self.field_ws), self.field_ws.numel(), st),
-               "field_mlp_bwd_saved")
-        elif split:
+        if split:
             # The sum of the per-workgroup weight-gradient partials needs nothing the table scatter produces and vice
             # versa: the gradient kernel here, the reduce on its own stream beside the scatter (joined at the end).
             args = (N.ptr(self.f_enc), N.ptr(self.f_sel), N.ptr(self.directions), cams, None, S, mm, fm,
@@ -834,16 +714,10 @@ class NerfactoTrainStep:
                 spec = net.encoding.spec
                 ws, ws_n = F._scatter_workspace(spec, self.f_enc.device, m)
                 grads = (N.ptr(self._grad(W0)), N.ptr(self._grad(b0)), N.ptr(self._grad(W1)), N.ptr(self._grad(b1)))
-                folded = lvl in self._wb_folded  # `losses` already ran this level's weights backward (same launch as the losses)
-                if do_mlp:
-                    self._wb_folded.discard(lvl)
-                if folded and getattr(self, "_wb_gated", False) != (gate is not None and ws is not None):
-                    folded = False  # (the gating mode changed between the two calls: run the level's own launch)
                 if gate is None or ws is None:  # ungated chain (A/B switch, or no binned-scatter workspace for this shape)
                     if do_mlp:
-                        if not folded:
-                            ck(lib.nsamd_weights_bwd(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]),
-                                                     n, S, N.ptr(self.p_ddens[lvl]), st), "weights_bwd")
+                        ck(lib.nsamd_weights_bwd(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]),
+                                                 n, S, N.ptr(self.p_ddens[lvl]), st), "weights_bwd")
                         ck(lib.nsamd_density_mlp_bwd(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]),
                                                      N.ptr(self.p_ddens[lvl]), m, dm, N.ptr(self.p_denc[lvl]), *grads,
                                                      N.ptr(dws), dws.numel(), st), "density_mlp_bwd")
@@ -859,10 +733,9 @@ class NerfactoTrainStep:
                 # chain returns at once while it is clear (the zero-filled gradients are then already the result)
                 mask = N.ptr(self.prop_ray_masks[lvl])
                 if do_mlp:
-                    if not folded:
-                        ck(lib.nsamd_weights_bwd_gate(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]),
-                                                      n, S, N.ptr(self.p_ddens[lvl]), gate, mask, int(self.gates_precleared), st),
-                           "weights_bwd_gate")
+                    ck(lib.nsamd_weights_bwd_gate(N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl]),
+                                                  n, S, N.ptr(self.p_ddens[lvl]), gate, mask, int(self.gates_precleared), st),
+                       "weights_bwd_gate")
                     ck(lib.nsamd_density_mlp_bwd_gated(N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl]),
                                                        N.ptr(self.p_ddens[lvl]), m, dm, N.ptr(self.p_denc[lvl]), *grads,
                                                        N.ptr(dws), dws.numel(), gate, mask, S, st), "density_mlp_bwd_gated")

@@ -461,7 +461,7 @@ class HipTrainer:
         # NSAMD_FORK_AFTER_BINS=1: the branch starts BEHIND the launch that selects the batch and writes the initial bins (8 MB of
         # stores that read 45 us beside the HBM-saturating Adam and 14 us alone) instead of in front of it
         late_fork = beside and self.fork_after_bins and not r.cameras_outside and getattr(r, "fuse_select", False) \
-            and not getattr(r, "fuse_sampler", False) and getattr(r, "cam_opt", None) is None
+            and getattr(r, "cam_opt", None) is None
         if beside and not late_fork:
             fork()
         elif pending and not beside:

@@ -27,17 +27,15 @@ def algorithmic_model(key, main_points):
         return "hbm", int(m.group(2)) * int(m.group(1)) * 8 * 8  # 8 corner gathers x 8 B (F=2 fp32) per level and sample
     if key.startswith("nsamd_hashgrid_encode_bwd") and m:
         return "hbm", int(m.group(2)) * int(m.group(1)) * 8 * 16  # read-modify-write of 8 corners x 8 B
-    if key in ("nsamd_field_mlp_fwd", "nsamd_field_mlp_fwd_save", "nsamd_field_density_fwd"):
+    if key in ("nsamd_field_mlp_fwd", "nsamd_field_density_fwd"):
         return "mfma", main_points * 2 * FIELD_MACS
-    if key == "nsamd_field_fused_fwd":
-        return "hbm", main_points * 16 * 8 * 8  # hash gathers (the bound of the fused launch)
     if key == "nsamd_field_mlp_bwd_scatter_phase[apply]":
         # the table scatter whose ROUTE pass runs inside the field backward: the op's algorithmic figure is the
         # read-modify-write of 8 corners x 16 B per (sample, level); its two passes touch every corner update once each, so this
         # launch is credited with HALF of it — the other half is the `fused_route_pass` share of the gradient kernel's line.
         # (The 16-B records the passes hand over are implementation traffic and are counted nowhere.)
         return "hbm", main_points * 16 * 8 * 8
-    if key in ("nsamd_field_mlp_bwd", "nsamd_field_mlp_bwd_saved", "nsamd_field_mlp_bwd_scatter_phase[gradients+records]"):
+    if key in ("nsamd_field_mlp_bwd", "nsamd_field_mlp_bwd_scatter_phase[gradients+records]"):
         # training = 3x the forward FLOPs, the forward launch takes 1x, so the backward's ALGORITHMIC share is
         # 2x (data gradient + weight gradient); the recompute of the forward inside the kernel is executed, not algorithmic
         return "mfma", main_points * 2 * FIELD_MACS * 2
@@ -71,11 +69,10 @@ def executed_per_launch(key, main_points):
 
 # entry point -> the kernel name rocprofv3 --kernel-trace --stats lists for it (profiles/*_kernel_stats.csv)
 ROCPROF_KERNEL = {
-    "nsamd_field_mlp_bwd": "nsamd::field_mlp_bwd_kernel<false, false>",
-    "nsamd_field_mlp_bwd_scatter_phase[gradients+records]": "nsamd::field_mlp_bwd_kernel<true, false>",
+    "nsamd_field_mlp_bwd": "nsamd::field_mlp_bwd_kernel<false>",
+    "nsamd_field_mlp_bwd_scatter_phase[gradients+records]": "nsamd::field_mlp_bwd_kernel<true>",
     "nsamd_field_mlp_bwd_scatter_phase[apply]": "nsamd::scatter_apply_kernel<true> (replayed graphs: the weight-gradient reduce rides it) "
                                                 "+ nsamd::scatter_finish_kernel",
-    "nsamd_field_mlp_bwd_saved": "nsamd::field_mlp_bwd_kernel (saved activations)",
     "nsamd_field_mlp_fwd": "nsamd::field_mlp_fwd_kernel",
     "nsamd_hashgrid_encode_fwd": "nsamd::hash_encode_fwd_kernel",
     "nsamd_hashgrid_encode_bwd_set": "nsamd::scatter_route_fine_kernel + nsamd::scatter_apply_kernel + nsamd::scatter_finish_kernel",

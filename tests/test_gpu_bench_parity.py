@@ -287,8 +287,7 @@ def test_gated_proposal_chain_equals_ungated(F, case):
         arena = ParamArena(model.get_param_groups_ordered())
         step = NerfactoTrainStep(model, n, torch.device("cuda"))
         step.gate_proposals = gated
-        step.fold_weights_bwd = False  # the interlevel gradient is replaced below, AFTER the losses launch: each level's
-        step.side_stream = None        # weights backward must run at the head of its own chain
+        step.side_stream = None  # (the interlevel gradient is replaced below, AFTER the losses launch)
         step.set_batch(o.cuda(), d.cuda(), cam.cuda(), tgt.cuda())
         step.jitter.copy_(jit)
         step.anneal_dev.fill_(1.0)

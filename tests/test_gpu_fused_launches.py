@@ -1,14 +1,12 @@
-"""The training iteration's merged launches against the launches they replace, BIT FOR BIT (round 5):
+"""The training iteration's merged launches against the launches they replace, BIT FOR BIT:
 
-* nsamd_render_losses_train = nsamd_render_train + nsamd_proposal_losses + nsamd_render_train_bwd [+ nsamd_weights_bwd(_gate) per
-  proposal level]: one launch, one wave per (ray, job), the stand-alone launches' device bodies run one after the other inside the
-  wave (csrc/ray_bodies.h, csrc/fused_rays.hip) — so every output must be the same bits, including the ones the launch reads
-  back itself (fine weights, MSE gradient, distortion gradient, interlevel gradient);
-* nsamd_select_bins = nsamd_select_batch + nsamd_piecewise_bins.
+* nsamd_select_bins = nsamd_select_batch + nsamd_piecewise_bins;
+* the main field's weight-gradient reduce riding the table scatter's apply pass = its own launch;
+* nsamd_train_loss_values (the five floats a trainer logs) against float64 sums of the per-ray terms;
+* nsamd_step_prologue (the step's scalars and Philox draws as the first node of the replayed graph).
 
-The separate launches are pinned to the oracle / the reference's fixtures by tests/test_gpu_kernels.py; this file pins the merged
-forms to them and the whole runner (a few optimisation steps, both update kinds, gated and ungated proposal chains, every
-background mode) to the separate-launch runner."""
+(Round 5's fully merged per-ray launches — nsamd_render_losses_train, nsamd_proposal_sampler — were bit-identical to the launches
+they replaced and measured slower; they and their tests live in nerfstudio_amd/csrc/experiments/rounds2to5_opt_in_variants.patch.)"""
 import numpy as np
 import pytest
 import torch
@@ -35,7 +33,7 @@ def _same(a, b, what):
     assert torch.equal(_bits(a), _bits(b)), f"{what}: {int((_bits(a) != _bits(b)).sum())} of {a.numel()} words differ"
 
 
-def _runner(cfg, n, seed, background, fuse, gate=True, fold=True):
+def _runner(cfg, n, seed, background, gate=True):
     from test_gpu_kernels import _hip_model
 
     from nerfstudio_amd.arena import ParamArena
@@ -45,159 +43,9 @@ def _runner(cfg, n, seed, background, fuse, gate=True, fold=True):
     model.config.background_color = background
     arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
     r = NerfactoTrainStep(model, n, torch.device("cuda"))
-    r.fuse_rays, r.fold_weights_bwd, r.gate_proposals = fuse, fold, gate
+    r.gate_proposals = gate
     r.side_stream = None
     return model, arena, r
-
-
-@pytest.mark.parametrize("background", ["last_sample", "white", "random"])
-@pytest.mark.parametrize("gate", [True, False])
-def test_render_losses_train_equals_the_separate_launches(F, background, gate):
-    from test_gpu_kernels import small_cfg
-
-    cfg = small_cfg(12, 10, 6)
-    n = 333  # not a multiple of the four rays of a workgroup: tail waves
-    o, d, cam, tgt = orc.synthetic_rays(n, cfg.num_images, seed=3)
-    rs = np.random.RandomState(5)
-    jit = torch.from_numpy(rs.uniform(0, 1, (3, n)).astype(np.float32)).cuda()
-    bg = torch.from_numpy(rs.uniform(0, 1, (n, 3)).astype(np.float32)).cuda()
-    runs = {}
-    for fuse in (False, True):
-        F._SCATTER_WS.clear()
-        model, arena, r = _runner(cfg, n, 11, background, fuse, gate=gate)
-        r.set_batch(o.cuda(), d.cuda(), cam.cuda(), tgt.cuda())
-        r.jitter.copy_(jit)
-        if r.bg_rays is not None:
-            r.bg_rays.copy_(bg)
-        r.anneal_dev.fill_(0.7)
-        states = []
-        for step, updated in enumerate((True, False, True)):
-            arena.zero_grad(skip=r.written_params())
-            r.forward_backward(updated, draw_jitter=False)
-            torch.cuda.synchronize()
-            L = r.n_prop
-            snap = {"weights": r.weights[L], "rgb": r.rgb, "acc": r.acc, "depth_exp": r.depth_exp, "depth_med": r.depth_med[L],
-                    "sq_err": r.sq_err, "d_rgb_out": r.d_rgb_out, "dist_per_ray": r.dist_per_ray, "dw_dist": r.dw_dist,
-                    "d_rgb_s": r.d_rgb_s, "d_dens_main": r.d_dens_main, "grad": arena.grad, "minmax": r.minmax_ws[:2]}
-            for lvl in range(L):
-                snap[f"inter{lvl}"] = r.inter_per_ray[lvl]
-                if updated:
-                    snap[f"dw_prop{lvl}"], snap[f"p_ddens{lvl}"] = r.dw_prop[lvl], r.p_ddens[lvl]
-                    if gate:
-                        snap[f"mask{lvl}"] = r.prop_ray_masks[lvl]
-            if updated and gate:
-                snap["gates"] = r.prop_gates
-            states.append({k: v.detach().clone() for k, v in snap.items()})
-            arena.step(groups=["fields", "proposal_networks"] if updated else ["fields"])
-        states.append({"params": arena.flat.clone(), "m": arena.exp_avg.clone(), "v": arena.exp_avg_sq.clone()})
-        runs[fuse] = states
-        del model, arena, r
-    assert any(float(s["grad"].abs().max()) > 0 for s in runs[True][:3])
-    assert float(runs[True][0]["p_ddens0"].abs().max()) > 0, "the proposal level carried no gradient: the test shows nothing"
-    for i, (a, b) in enumerate(zip(runs[False], runs[True])):
-        assert a.keys() == b.keys()
-        for k in a:
-            _same(a[k], b[k], f"iteration {i}, {k} ({background}, gated={gate})")
-
-
-def test_folded_weights_backward_equals_its_own_launch_and_respects_the_switches(F):
-    """The level's weights backward inside the losses launch against the stand-alone nsamd_weights_bwd_gate at the head of the
-    level's chain (NSAMD_FOLD_WEIGHTS_BWD=0), and a chain that is asked for twice runs its own launch the second time."""
-    from test_gpu_kernels import small_cfg
-
-    cfg = small_cfg(12, 10, 6)
-    n = 256
-    o, d, cam, tgt = orc.synthetic_rays(n, cfg.num_images, seed=4)
-    jit = torch.from_numpy(np.random.RandomState(1).uniform(0, 1, (3, n)).astype(np.float32)).cuda()
-    out = {}
-    for fold in (False, True):
-        F._SCATTER_WS.clear()
-        model, arena, r = _runner(cfg, n, 12, "last_sample", True, fold=fold)
-        r.set_batch(o.cuda(), d.cuda(), cam.cuda(), tgt.cuda())
-        r.jitter.copy_(jit)
-        arena.zero_grad(skip=r.written_params())
-        r.forward_and_losses(True, draw_jitter=False)
-        assert (len(r._wb_folded) == r.n_prop) == fold
-        r.backward_all(True)
-        assert not r._wb_folded
-        torch.cuda.synchronize()
-        first = arena.grad.clone()
-        # the chains once more without a new `losses`: nothing is folded any more, each level launches its own weights backward
-        a, b = arena.groups["proposal_networks"]
-        arena.grad[a:b].zero_()
-        r.prop_gates.zero_()
-        r.backward_proposals()
-        torch.cuda.synchronize()
-        _same(arena.grad[a:b], first[a:b], f"second call of the proposal chains (fold={fold})")
-        out[fold] = (first, [x.clone() for x in r.p_ddens], [x.clone() for x in r.prop_ray_masks])
-    _same(out[False][0], out[True][0], "gradient arena")
-    for lvl in range(2):
-        _same(out[False][1][lvl], out[True][1][lvl], f"p_ddens[{lvl}]")
-        _same(out[False][2][lvl], out[True][2][lvl], f"ray mask [{lvl}]")
-
-
-@pytest.mark.parametrize("n", [333, 4096])
-@pytest.mark.parametrize("with_pool", [False, True])
-def test_proposal_sampler_one_launch_equals_the_per_level_launches(F, n, with_pool):
-    """nsamd_proposal_sampler ([batch selection,] initial bins, then per level density -> weights -> median depth -> resampling,
-    one wavefront per ray) against nsamd_select_batch / nsamd_piecewise_bins / nsamd_density_field_fwd / nsamd_proposal_resample:
-    bin edges of every level, densities, weights, median depths and — on the steps that keep them for the backward — the encoded
-    features, selectors and pre-activations, bit for bit; annealed resampling included."""
-    from test_gpu_kernels import small_cfg
-
-    from nerfstudio_amd import _native as N
-
-    cfg = small_cfg(12, 10, 6)
-    rs = np.random.RandomState(7)
-    slots = 3
-    pool = {"origins": torch.from_numpy((rs.standard_normal((slots, n, 3)) * 0.5).astype(np.float32)).cuda(),
-            "directions": torch.nn.functional.normalize(torch.from_numpy(rs.standard_normal((slots, n, 3)).astype(np.float32)), dim=-1).cuda(),
-            "cameras": torch.from_numpy(rs.randint(0, cfg.num_images, (slots, n))).cuda(),
-            "target": torch.from_numpy(rs.uniform(0, 1, (slots, n, 3)).astype(np.float32)).cuda()}
-    jit = torch.from_numpy(rs.uniform(0, 1, (3, n)).astype(np.float32)).cuda()
-    slot = torch.tensor([1.0], device="cuda")
-    out = {}
-    for fused in (False, True):
-        F._SCATTER_WS.clear()
-        model, arena, r = _runner(cfg, n, 13, "last_sample", True)
-        r.fuse_sampler = fused
-        r.fuse_select = fused
-        r.jitter.copy_(jit)
-        r.anneal_dev.fill_(0.6)
-        snaps = []
-        for need_enc in (True, False):
-            for buf in (r.p_enc + r.p_sel + r.p_pre + r.p_dens + r.weights + r.s_bins + r.t_bins + r.depth_med):
-                buf.fill_(-7.0)
-            if with_pool:
-                if fused:
-                    r.pending_select = (N.ptr(slot), slots, pool)
-                else:
-                    N.check(N.load().nsamd_select_batch(N.ptr(slot), slots, n, N.ptr(pool["origins"]), N.ptr(pool["directions"]),
-                                                        N.ptr(pool["cameras"]), N.ptr(pool["target"]), N.ptr(r.origins),
-                                                        N.ptr(r.directions), N.ptr(r.camera_indices), N.ptr(r.target), N.stream()),
-                            "select_batch")
-            else:
-                r.set_batch(pool["origins"][2], pool["directions"][2], pool["cameras"][2], pool["target"][2])
-            r.forward_proposals(draw_jitter=False, need_enc=need_enc)
-            torch.cuda.synchronize()
-            assert r._sampler_ok and r.pending_select is None
-            snap = {"origins": r.origins, "directions": r.directions, "cams": r.camera_indices, "target": r.target}
-            for lvl in range(3):
-                snap[f"s_bins{lvl}"], snap[f"t_bins{lvl}"] = r.s_bins[lvl], r.t_bins[lvl]
-            for lvl in range(2):
-                snap[f"dens{lvl}"], snap[f"w{lvl}"], snap[f"med{lvl}"] = r.p_dens[lvl], r.weights[lvl], r.depth_med[lvl]
-                snap[f"enc{lvl}"], snap[f"sel{lvl}"], snap[f"pre{lvl}"] = r.p_enc[lvl], r.p_sel[lvl], r.p_pre[lvl]
-            snaps.append({k: v.detach().clone() for k, v in snap.items()})
-        out[fused] = snaps
-        del model, arena, r
-    for i, (a, b) in enumerate(zip(out[False], out[True])):
-        assert float(a["dens0"].min()) > -7.0 and float(a["t_bins2"].min()) > -7.0
-        if i == 0:
-            assert float((a["enc0"] == -7.0).float().mean()) < 0.01, "the features must have been written on this pass"
-        else:
-            assert bool((b["enc0"] == -7.0).all()) and bool((b["pre1"] == -7.0).all()), "nothing kept for a backward that will not run"
-        for k in a:
-            _same(a[k], b[k], f"pass {i}, {k} (n={n}, pool={with_pool})")
 
 
 @pytest.mark.parametrize("per_edge", [False, True])
@@ -240,9 +88,9 @@ def test_select_bins_equals_select_batch_plus_piecewise_bins(F, per_edge):
 
 
 def test_trainer_with_merged_launches_trains_through_the_same_bits(F, monkeypatch):
-    """bench.py's trainer (captured graphs, deferred main-field Adam, pool of batches, bench-size batch) with the merged
-    launches against the same trainer on the separate launches: identical parameter and moment bits after 15 iterations of both
-    update kinds, replayed from the captured graphs."""
+    """bench.py's trainer (captured graphs, deferred main-field Adam, pool of batches, bench-size batch) with batch selection +
+    initial bins as ONE launch (the default) against the same trainer on the two launches: identical parameter and moment bits
+    after 15 iterations of both update kinds, replayed from the captured graphs."""
     import hashlib
 
     import bench
@@ -252,12 +100,8 @@ def test_trainer_with_merged_launches_trains_through_the_same_bits(F, monkeypatc
 
     digests = {}
     dev = torch.device("cuda")
-    for arm, env in (("merged", {}), ("separate", {"NSAMD_FUSE_RAYS": "0", "NSAMD_FUSE_SELECT": "0", "NSAMD_FUSE_SAMPLER": "0"})):
-        for k in ("NSAMD_FUSE_RAYS", "NSAMD_FUSE_SELECT", "NSAMD_FUSE_SAMPLER"):
-            monkeypatch.delenv(k, raising=False)
-        if arm == "merged":  # (both off by default: measured slower — they must still train the same bits)
-            monkeypatch.setenv("NSAMD_FUSE_SAMPLER", "1")
-            monkeypatch.setenv("NSAMD_FUSE_RAYS", "1")
+    for arm, env in (("merged", {}), ("separate", {"NSAMD_FUSE_SELECT": "0"})):
+        monkeypatch.delenv("NSAMD_FUSE_SELECT", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         F._SCATTER_WS.clear()
@@ -267,7 +111,7 @@ def test_trainer_with_merged_launches_trains_through_the_same_bits(F, monkeypatc
         arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
         rb, batch, pool = bench.synthetic_batch(dev, seed=1000)
         tr = HipTrainer(model, arena, rb, batch, world=1, use_graph=True, use_runner=True, pool=pool)
-        assert tr.runner.fuse_rays == tr.runner.fuse_select == tr.runner.fuse_sampler == (arm == "merged")
+        assert tr.runner.fuse_select == (arm == "merged")
         torch.manual_seed(1)
         torch.cuda.manual_seed(1)  # the jitter draws of the iterations below
         tr.train_iteration()
@@ -327,29 +171,34 @@ def test_weight_gradient_reduce_riding_the_apply_pass_equals_its_own_launch(F):
     _same(out["rider"], out["phases"], "fields slice of the gradient arena")
 
 
-def test_loss_values_of_the_finishing_pass_and_of_their_own_launch(F):
-    """The five floats a trainer reads every iteration (rgb / interlevel / distortion loss, psnr, distortion metric): written by
-    nsamd_render_losses_train's finishing pass and by nsamd_train_loss_values behind the separate launches — equal to each other
-    bit for bit (same per-ray terms, same fixed summation order) and to the float64 sums of the per-ray terms to 1e-6."""
+def test_loss_values_launch_against_float64_sums(F):
+    """The five floats a trainer reads every iteration (rgb / interlevel / distortion loss, psnr, distortion metric), written by
+    nsamd_train_loss_values behind the compositing and loss launches: the float64 sums of the per-ray terms to 1e-6, and the same
+    bits on a second call (fixed summation order)."""
     from test_gpu_kernels import small_cfg
 
     cfg = small_cfg(12, 10, 6)
     n = 1000
     o, d, cam, tgt = orc.synthetic_rays(n, cfg.num_images, seed=9)
     jit = torch.from_numpy(np.random.RandomState(2).uniform(0, 1, (3, n)).astype(np.float32)).cuda()
-    vals = {}
-    for fuse in (False, True):
-        F._SCATTER_WS.clear()
-        model, arena, r = _runner(cfg, n, 14, "last_sample", fuse)
-        r.want_loss_vals = True
-        r.set_batch(o.cuda(), d.cuda(), cam.cuda(), tgt.cuda())
-        r.jitter.copy_(jit)
+    F._SCATTER_WS.clear()
+    model, arena, r = _runner(cfg, n, 14, "last_sample")
+    r.want_loss_vals = True
+    r.set_batch(o.cuda(), d.cuda(), cam.cuda(), tgt.cuda())
+    r.jitter.copy_(jit)
+    vals = []
+    for _ in range(2):
         arena.zero_grad(skip=r.written_params())
         r.forward_and_losses(True, draw_jitter=False)
         torch.cuda.synchronize()
         assert r._loss_vals_fresh
         ld = r.loss_dict()
-        assert ld["rgb_loss"].data_ptr() == r.loss_vals.data_ptr()
+        first = ld["rgb_loss"].clone()
+        r.loss_vals[:3].fill_(-1.0)  # the dictionary holds its own copy: a later iteration does not rewrite it
+        assert float(ld["rgb_loss"]) == float(first)
+        r.forward_and_losses(True, draw_jitter=False)
+        torch.cuda.synchronize()
+        ld = r.loss_dict()
         mc, S = model.config, r.counts[-1]
         ref = {"rgb_loss": float(r.sq_err.double().sum()) / (3 * n),
                "interlevel_loss": mc.interlevel_loss_mult * float(sum(p.double().sum() for p in r.inter_per_ray)) / (n * S),
@@ -359,9 +208,8 @@ def test_loss_values_of_the_finishing_pass_and_of_their_own_launch(F):
         assert abs(float(r.loss_vals[3]) + 10.0 * np.log10(ref["rgb_loss"])) <= 1e-4
         assert abs(float(r.loss_vals[4]) - float(r.dist_per_ray.double().sum()) / n) <= 1e-6 * float(r.loss_vals[4]) + 1e-9
         assert abs(float(r.loss_vals[5]) - sum(ref.values())) <= 2e-6 * sum(ref.values())
-        vals[fuse] = r.loss_vals.clone()
-        del model, arena, r
-    _same(vals[False], vals[True], "loss values: own launch vs the merged launch's finishing pass")
+        vals.append(r.loss_vals[:8].clone())
+    _same(vals[0], vals[1], "loss values of two calls on the same per-ray terms")
 
 
 def _philox_reference(seed, draw, q):

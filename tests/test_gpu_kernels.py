@@ -1158,119 +1158,6 @@ def test_fused_train_step_behind_the_model_api(F, camera_mode):
     assert first[table].shape == once.shape
 
 
-@pytest.mark.parametrize("contract,ray_mode,with_cams", [(True, True, True), (False, False, False), (True, False, True)])
-def test_fused_main_field_forward_is_bit_identical(F, contract, ray_mode, with_cams):
-    """nsamd_field_fused_fwd (hash L16 -> base -> head in one launch, features in registers) against
-    nsamd_hashgrid_encode_fwd + nsamd_field_mlp_fwd: selector, saved features, density and rgb equal bit for bit; ragged M
-    (not a multiple of the 16-point tile); other level counts are refused."""
-    from nerfstudio_amd import _native as N
-
-    lib, st = N.load(), N.stream()
-    torch.manual_seed(5)
-    n, S = 67, 48 if ray_mode else 1
-    M = n * S if ray_mode else 1000 + 7
-    log2 = 14
-    scal = [float(np.floor(16.0 * np.exp(np.log(2048 / 16) / 15) ** i)) for i in range(16)]
-    grid = N.make_grid(16, log2, scal)
-    table = ((torch.rand(16 << log2, 2) - 0.5) * 0.8).cuda()
-    if ray_mode:
-        o = ((torch.rand(n, 3) - 0.5) * 1.5).cuda()
-        d = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1).cuda()
-        t_bins = torch.sort(torch.rand(n, S + 1) * 4.0, dim=-1).values.cuda()
-        pts = N.make_points(None, o, d, t_bins, S)
-        dirs, group, rays = d, S, n
-    else:
-        pos = ((torch.rand(M, 3) - 0.5) * (6.0 if contract else 2.4)).cuda()
-        pts = N.make_points(positions=pos)
-        dirs, group, rays = torch.nn.functional.normalize(torch.randn(M, 3), dim=-1).cuda(), 1, M
-    shapes = [(64, 32), (64,), (16, 64), (16,), (64, 63 if with_cams else 31), (64,), (64, 64), (64,), (3, 64), (3,)]
-    params = [(torch.randn(*s) * 0.3).cuda() for s in shapes]
-    emb = (torch.randn(9, 32) * 0.2).cuda() if with_cams else None
-    cams = torch.randint(0, 9, (rays,)).cuda() if with_cams else None
-    fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), 9 if with_cams else 0, 0.8)
-    box = N.make_aabb(torch.tensor([[-1.2, -1.2, -1.2], [1.2, 1.2, 1.2]]))
-    xf = N.XFORM_CONTRACT if contract else N.XFORM_AABB
-    e = lambda *sh: torch.empty(sh, device="cuda")  # noqa: E731
-    enc_a, sel_a, dens_a, rgb_a = e(32, M), e(M), e(M), e(M, 3)
-    N.check(lib.nsamd_hashgrid_encode_fwd(pts, M, xf, box, N.ptr(table), grid, N.ptr(enc_a), 1, M, N.ptr(sel_a), st), "enc")
-    N.check(lib.nsamd_field_mlp_fwd(N.ptr(enc_a), N.ptr(sel_a), N.ptr(dirs), N.ptr(cams), None, group, M, fm, N.ptr(dens_a),
-                                    N.ptr(rgb_a), st), "mlp")
-    enc_b, sel_b, dens_b, rgb_b = e(32, M), e(M), e(M), e(M, 3)
-    N.check(lib.nsamd_field_fused_fwd(pts, M, xf, box, N.ptr(table), grid, N.ptr(dirs), N.ptr(cams), None, group, fm,
-                                      N.ptr(sel_b), N.ptr(enc_b), N.ptr(dens_b), N.ptr(rgb_b), st), "fused")
-    assert 0.05 < float(sel_a.mean()) <= 1.0
-    for a, b, name in ((sel_a, sel_b, "selector"), (enc_a, enc_b, "features"), (dens_a, dens_b, "density"), (rgb_a, rgb_b, "rgb")):
-        assert torch.equal(a, b), name
-    # the optional outputs are optional
-    dens_c, rgb_c = e(M), e(M, 3)
-    N.check(lib.nsamd_field_fused_fwd(pts, M, xf, box, N.ptr(table), grid, N.ptr(dirs), N.ptr(cams), None, group, fm, None, None,
-                                      N.ptr(dens_c), N.ptr(rgb_c), st), "fused, no saved outputs")
-    assert torch.equal(dens_c, dens_a) and torch.equal(rgb_c, rgb_a)
-    g8 = N.make_grid(8, log2, scal[:8])
-    assert lib.nsamd_field_fused_fwd.fn(pts, M, xf, box, N.ptr(table), g8, N.ptr(dirs), N.ptr(cams), None, group, fm, None, None,
-                                        N.ptr(dens_c), N.ptr(rgb_c), st) == N.ERR_UNSUPPORTED
-
-
-def test_field_forward_bf16x3_split_matches_f32(F):
-    """The main-field forward on the bf16 matrix cores with three-way split operands (NSAMD_FIELD_FWD_BF16X3=1, opt-in)
-    against the f32-MFMA forward and a float64 evaluation of the same network: the split keeps 24 bits per operand and drops
-    only products below 2^-23 of the leading one, so its error against float64 must be of the size of the f32 kernel's own.
-    Run in subprocesses: the switch is read once per process."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-
-    code = r"""
-import sys, numpy as np, torch
-sys.path.insert(0, %r)
-from nerfstudio_amd import _native as N
-lib, st = N.load(), N.stream()
-torch.manual_seed(11)
-n, S = 301, 48
-M = n * S
-enc = (torch.randn(32, M) * 0.3).cuda()
-sel = (torch.rand(M) > 0.1).float().cuda()
-dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1).cuda()
-cams = torch.randint(0, 7, (n,)).cuda()
-shapes = [(64, 32), (64,), (16, 64), (16,), (64, 63), (64,), (64, 64), (64,), (3, 64), (3,)]
-params = [(torch.randn(*s) * (0.25 if len(s) == 2 else 0.1)).cuda() for s in shapes]
-emb = (torch.randn(7, 32) * 0.3).cuda()
-fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), 7, 0.9)
-dens, rgb = torch.empty(M, device="cuda"), torch.empty(M, 3, device="cuda")
-N.check(lib.nsamd_field_mlp_fwd(N.ptr(enc), N.ptr(sel), N.ptr(dirs), N.ptr(cams), None, S, M, fm, N.ptr(dens), N.ptr(rgb), st), "fwd")
-torch.cuda.synchronize()
-np.savez(sys.argv[1], out=np.concatenate([dens.cpu().numpy()[:, None], rgb.cpu().numpy()], axis=1), enc=enc.cpu().numpy(),
-         sel=sel.cpu().numpy(), dirs=dirs.cpu().numpy(), cams=cams.cpu().numpy(), emb=emb.cpu().numpy(),
-         **{f"p{i}": p.cpu().numpy() for i, p in enumerate(params)})
-""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    with tempfile.TemporaryDirectory() as tmp:
-        for flag in ("0", "1"):
-            path = os.path.join(tmp, f"o{flag}.npz")
-            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, NSAMD_FIELD_FWD_BF16X3=flag),
-                               capture_output=True, text=True, timeout=300)
-            assert r.returncode == 0, r.stderr[-2000:]
-            outs.append(dict(np.load(path)))
-    f32, b3 = outs[0]["out"], outs[1]["out"]
-    assert np.isfinite(b3).all() and not np.array_equal(f32, b3), "the switch selected the same kernel twice"
-    # float64 evaluation of nerfacto_field.py:203-310 on the same inputs
-    d = {k: torch.from_numpy(v).double() for k, v in outs[0].items() if k != "out"}
-    x = d["enc"].t()
-    h = torch.relu(x @ d["p0"].t() + d["p1"]) @ d["p2"].t() + d["p3"]
-    dens64 = 0.9 * torch.exp(h[:, 0]) * d["sel"]
-    sh = orc.sh_levels4(((d["dirs"] + 1.0) / 2.0).float()).double().repeat_interleave(48, dim=0)
-    app = d["emb"][outs[0]["cams"]].repeat_interleave(48, dim=0)
-    hin = torch.cat([sh, h[:, 1:], app], dim=-1)
-    r64 = torch.sigmoid(torch.relu(torch.relu(hin @ d["p4"].t() + d["p5"]) @ d["p6"].t() + d["p7"]) @ d["p8"].t() + d["p9"])
-    ref = torch.cat([dens64[:, None], r64], dim=-1).numpy()
-    scale = np.maximum(np.abs(ref), 1e-3)
-    e32, e3 = np.abs(f32 - ref) / scale, np.abs(b3 - ref) / scale
-    assert e32.max() < 1e-4 and e3.max() < 1e-4, (e32.max(), e3.max())
-    assert e3.max() <= 3.0 * e32.max() + 1e-6 and e3.mean() <= 2.0 * e32.mean() + 1e-7, (e32.max(), e3.max(), e32.mean(), e3.mean())
-    np.testing.assert_allclose(b3[:, 1:], f32[:, 1:], rtol=0, atol=2e-6, err_msg="rgb")  # (north_star budget: 1e-4)
-
-
 def test_train_step_runner_random_background(F, monkeypatch):
     """background_color="random" on the fused runner (renderers.py:112-115, 194-196; models/nerfacto.py:377-381) against the
     module path with the same rand_like draw: rendered colour (no background), losses, every gradient."""
@@ -1683,48 +1570,3 @@ def test_table_scatter_binned_equals_scan_path(F, S, levels, log2_T, max_res):
     assert float((got - ref).abs().max()) <= 1e-4 * scale and float((got2 - ref).abs().max()) <= 1e-4 * scale
 
 
-def test_field_mlp_saved_activation_pair_equals_recompute(F):
-    """nsamd_field_mlp_fwd_save / _bwd_saved (activations through HBM) against the recomputing pair: same outputs, and
-    gradients equal up to the order of the weight-gradient sums (identical MFMA sequence, so bit-identical here)."""
-    from nerfstudio_amd import _native as N
-
-    lib = N.load()
-    torch.manual_seed(5)
-    M, S = 48 * 211 + 7 * 0, 48  # whole rays
-    M = 48 * 211
-    e = lambda *s: torch.empty(*s, device="cuda")
-    enc = torch.randn(32, M, device="cuda")
-    sel = (torch.rand(M, device="cuda") > 0.1).float()
-    dirs = torch.nn.functional.normalize(torch.randn(M // S, 3, device="cuda"), dim=-1)
-    cams = torch.randint(0, 7, (M // S,), device="cuda")
-    params = [torch.randn(64, 32), torch.randn(64), torch.randn(16, 64), torch.randn(16), torch.randn(64, 63), torch.randn(64),
-              torch.randn(64, 64), torch.randn(64), torch.randn(3, 64), torch.randn(3)]
-    params = [(p * 0.2).cuda().contiguous() for p in params]
-    emb = (torch.randn(7, 32) * 0.3).cuda()
-    fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), 7, 0.01)
-    st = N.stream()
-    dens_a, rgb_a, dens_b, rgb_b = e(M), e(M, 3), e(M), e(M, 3)
-    saved = e(int(lib.nsamd_field_mlp_saved_floats(M)))
-    N.check(lib.nsamd_field_mlp_fwd(N.ptr(enc), N.ptr(sel), N.ptr(dirs), N.ptr(cams), None, S, M, fm, N.ptr(dens_a),
-                                    N.ptr(rgb_a), st), "fwd")
-    N.check(lib.nsamd_field_mlp_fwd_save(N.ptr(enc), N.ptr(sel), N.ptr(dirs), N.ptr(cams), None, S, M, fm, N.ptr(dens_b),
-                                         N.ptr(rgb_b), N.ptr(saved), st), "fwd_save")
-    assert torch.equal(dens_a, dens_b) and torch.equal(rgb_a, rgb_b)
-    dd, dr = torch.randn(M, device="cuda"), torch.randn(M, 3, device="cuda")
-    ws, _ = F.field_bwd_workspace(torch.device("cuda"))
-    outs = []
-    for saved_mode in (False, True):
-        g = [torch.zeros_like(p) for p in params] + [torch.zeros_like(emb)]
-        grads = N.FieldMlpGrads(*(N.ptr(t) for t in g))
-        denc = e(32, M)
-        if saved_mode:
-            N.check(lib.nsamd_field_mlp_bwd_saved(N.ptr(enc), N.ptr(sel), N.ptr(dirs), N.ptr(cams), None, S, M, fm,
-                                                  N.ptr(saved), N.ptr(dd), N.ptr(dr), N.ptr(denc), grads, N.ptr(ws), ws.numel(),
-                                                  st), "bwd_saved")
-        else:
-            N.check(lib.nsamd_field_mlp_bwd(N.ptr(enc), N.ptr(sel), N.ptr(dirs), N.ptr(cams), None, S, M, fm, N.ptr(dd),
-                                            N.ptr(dr), N.ptr(denc), grads, N.ptr(ws), ws.numel(), st), "bwd")
-        outs.append([denc] + g)
-    for a, b in zip(*outs):
-        scale = float(a.abs().max()) + 1e-30
-        assert float((a - b).abs().max()) <= 1e-5 * scale
