@@ -574,6 +574,15 @@ int nsamd_raygen_pinhole(const int64_t* ray_indices, const float* c2w, const flo
                          const float* cx, const float* cy, int64_t num_rays, int32_t num_cameras, float* origins,
                          float* directions, float* pixel_area, float* directions_norm, nsamd_stream_t stream);
 
+/* The same rays for ONE camera's image in row-major pixel order, chunk by chunk: ray i = pixel first_pixel + i of the implicit
+ * (row, col) grid of width `width` — what Model.get_outputs_for_camera (models/base_model.py:166-175) gets from
+ * camera.generate_rays(camera_indices=0, keep_shape=True) and then slices into chunks (:178-205), generated straight into the
+ * render loop's input buffers: no [H,W,3] bundle and no index list in HBM. c2w [3,4] (device), intrinsics by value; rays
+ * num_rays .. padded_rays - 1 repeat the last pixel (the padding of a last, shorter chunk). Same bits as nsamd_raygen_pinhole. */
+int nsamd_raygen_pinhole_grid(const float* c2w, float fx, float fy, float cx, float cy, int32_t width, int64_t first_pixel,
+                              int64_t num_rays, int64_t padded_rays, float* origins, float* directions, float* pixel_area,
+                              nsamd_stream_t stream);
+
 /* Data-parallel exchange of a hash-table gradient whose coarse levels reach only a few of their rows (the torch path
  * hashes every level, encodings.py:398-415: level l touches at most (res_l + 1)^3 of its 2^log2_T rows): pack the
  * `n` reachable rows `index` (int64, sorted) of `rows` [*, feat] into `packed` [n, feat] before the all-reduce

@@ -123,6 +123,7 @@ _SIGNATURES = {
     "nsamd_packed_composite_bwd": [vp, vp, vp, i64, C.c_int, C.POINTER(f32), vp, vp, vp, vp, vp],
     "nsamd_packed_positions": [vp, vp, vp, vp, vp, i64, vp, vp],
     "nsamd_raygen_pinhole": [vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp],
+    "nsamd_raygen_pinhole_grid": [vp, f32, f32, f32, f32, i32, i64, i64, i64, vp, vp, vp, vp],
     "nsamd_rows_gather": [vp, vp, i64, i32, vp, vp],
     "nsamd_rows_scatter": [vp, vp, i64, i32, vp, vp],
     "nsamd_select_batch": [vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -9,18 +9,10 @@ namespace nsamd {
 // Cameras._generate_rays_from_coords, perspective branch (cameras/cameras.py:598-634 coords, :655-656 y flip,
 // :781-787 directions, :887-909 rotate, normalise, pixel area). One ray per lane; the per-camera pose and
 // intrinsics are gathered through L2 (a few hundred cameras at most).
-__global__ void raygen_pinhole_kernel(const int64_t* __restrict__ ray_indices, const float* __restrict__ c2w,
-                                      const float* __restrict__ fx, const float* __restrict__ fy,
-                                      const float* __restrict__ cx, const float* __restrict__ cy, int64_t num_rays,
-                                      float* __restrict__ origins, float* __restrict__ directions,
-                                      float* __restrict__ pixel_area, float* __restrict__ directions_norm) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= num_rays) return;
-  const int64_t cam = ray_indices[3 * i + 0];
-  const float y = (float)ray_indices[3 * i + 1] + 0.5f;  // image_coords = meshgrid + 0.5 (cameras.py:312-313)
-  const float x = (float)ray_indices[3 * i + 2] + 0.5f;
-  const float fxr = fx[cam], fyr = fy[cam], cxr = cx[cam], cyr = cy[cam];
-  const float* m = c2w + cam * 12;  // [3][4] row-major
+__device__ __forceinline__ void raygen_pinhole_one(float x, float y, float fxr, float fyr, float cxr, float cyr,
+                                                   const float* __restrict__ m, float* __restrict__ origin,
+                                                   float* __restrict__ direction, float* __restrict__ pixel_area,
+                                                   float* __restrict__ direction_norm) {
   const float eps = 8.881784197001252e-16f;  // camera_utils._EPS = 4 * float64 eps, cast to fp32
   // three coords: centre, +1 in x, +1 in y  (cameras.py:622-634)
   const float px[3] = {(x - cxr) / fxr, (x - cxr + 1.0f) / fxr, (x - cxr) / fxr};
@@ -49,11 +41,41 @@ __global__ void raygen_pinhole_kernel(const int64_t* __restrict__ ray_indices, c
   dy = sqrtf(dy);
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    origins[3 * i + r] = m[4 * r + 3];
-    directions[3 * i + r] = d[0][r];
+    origin[r] = m[4 * r + 3];
+    direction[r] = d[0][r];
   }
-  pixel_area[i] = dx * dy;
-  if (directions_norm) directions_norm[i] = n0;
+  if (pixel_area) *pixel_area = dx * dy;
+  if (direction_norm) *direction_norm = n0;
+}
+
+__global__ void raygen_pinhole_kernel(const int64_t* __restrict__ ray_indices, const float* __restrict__ c2w,
+                                      const float* __restrict__ fx, const float* __restrict__ fy,
+                                      const float* __restrict__ cx, const float* __restrict__ cy, int64_t num_rays,
+                                      float* __restrict__ origins, float* __restrict__ directions,
+                                      float* __restrict__ pixel_area, float* __restrict__ directions_norm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num_rays) return;
+  const int64_t cam = ray_indices[3 * i + 0];
+  const float y = (float)ray_indices[3 * i + 1] + 0.5f;  // image_coords = meshgrid + 0.5 (cameras.py:312-313)
+  const float x = (float)ray_indices[3 * i + 2] + 0.5f;
+  raygen_pinhole_one(x, y, fx[cam], fy[cam], cx[cam], cy[cam], c2w + cam * 12, origins + 3 * i, directions + 3 * i, pixel_area + i,
+                     directions_norm ? directions_norm + i : nullptr);
+}
+
+// The rays of ONE camera's image in row-major pixel order, generated where they are consumed: ray i of the launch is pixel
+// first_pixel + i of the implicit (row, col) grid — `Cameras.generate_rays(camera_indices=0, keep_shape=True)` of
+// Model.get_outputs_for_camera (models/base_model.py:166-175) restricted to the chunk the render loop is about to trace, so no
+// [H, W, 3] bundle (nor an index list) exists in HBM. Rays past `num_rays` (the padding of a last, shorter chunk) repeat the
+// last pixel. Same arithmetic as raygen_pinhole_kernel: the same bits as indexing the full bundle.
+__global__ void raygen_pinhole_grid_kernel(const float* __restrict__ c2w, float fx, float fy, float cx, float cy, int32_t width,
+                                           int64_t first_pixel, int64_t num_rays, int64_t padded, float* __restrict__ origins,
+                                           float* __restrict__ directions, float* __restrict__ pixel_area) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= padded) return;
+  const int64_t p = first_pixel + (i < num_rays ? i : num_rays - 1);
+  const int64_t row = p / width, col = p - row * width;
+  raygen_pinhole_one((float)col + 0.5f, (float)row + 0.5f, fx, fy, cx, cy, c2w, origins + 3 * i, directions + 3 * i,
+                     pixel_area ? pixel_area + i : nullptr, nullptr);
 }
 
 // The step's ray batch out of a pool of pre-generated batches resident in HBM: what VanillaDataManager.next_train
@@ -235,6 +257,18 @@ extern "C" int nsamd_raygen_pinhole(const int64_t* ray_indices, const float* c2w
   NSAMD_REQUIRE(ray_indices && c2w && fx && fy && cx && cy && origins && directions && pixel_area);
   raygen_pinhole_kernel<<<(unsigned)((num_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(
       ray_indices, c2w, fx, fy, cx, cy, num_rays, origins, directions, pixel_area, directions_norm);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+extern "C" int nsamd_raygen_pinhole_grid(const float* c2w, float fx, float fy, float cx, float cy, int32_t width,
+                                         int64_t first_pixel, int64_t num_rays, int64_t padded_rays, float* origins,
+                                         float* directions, float* pixel_area, nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0 && padded_rays >= num_rays && width > 0 && first_pixel >= 0);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(c2w && origins && directions && fx != 0.0f && fy != 0.0f);
+  raygen_pinhole_grid_kernel<<<(unsigned)((padded_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      c2w, fx, fy, cx, cy, width, first_pixel, num_rays, padded_rays, origins, directions, pixel_area);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

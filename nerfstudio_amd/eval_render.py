@@ -174,6 +174,63 @@ class EvalRenderer:
                 out[f"prop_depth_{i}"][a:b, 0].copy_(s.depth_med[i][:k])
         return {k_: v.view(*image_shape, -1) for k_, v in out.items()}
 
+    @profiler.time_function
+    @torch.no_grad()
+    def render_camera(self, c2w: Tensor, fx: float, fy: float, cx: float, cy: float, height: int, width: int) -> Dict[str, Tensor]:
+        """`render` for ONE pinhole camera WITHOUT a ray bundle: each chunk's rays are generated straight into the schedule's
+        static input buffers (nsamd_raygen_pinhole_grid: pixel first + i of the implicit row-major grid, the arithmetic of
+        Cameras.generate_rays(camera_indices=0, keep_shape=True), cameras/cameras.py:321-503 perspective branch) — what
+        Model.get_outputs_for_camera (models/base_model.py:166-175) builds as an [H, W] bundle with ~40 torch launches over
+        full-image tensors and then slices. Same bits as `render` on that bundle. c2w: [3, 4] on the model's device."""
+        s, n = self.step, self.chunk
+        total = int(height) * int(width)
+        dev = s.origins.device
+        c2w = c2w.reshape(3, 4).to(device=dev, dtype=torch.float32).contiguous()
+        out = {"rgb": torch.empty((total, 3), device=dev), "accumulation": torch.empty((total, 1), device=dev),
+               "depth": torch.empty((total, 1), device=dev), "expected_depth": torch.empty((total, 1), device=dev)}
+        for i in range(s.n_prop):
+            out[f"prop_depth_{i}"] = torch.empty((total, 1), device=dev)
+        self._refresh_constants()
+        lib = N.load()
+        for a in range(0, total, n):
+            k = min(a + n, total) - a
+            N.check(lib.nsamd_raygen_pinhole_grid(N.ptr(c2w), float(fx), float(fy), float(cx), float(cy), int(width), a, k, n,
+                                                  N.ptr(s.origins), N.ptr(s.directions), None, N.stream()), "raygen_pinhole_grid")
+            self._run_chunk()
+            b = a + k
+            out["rgb"][a:b].copy_(s.rgb[:k])
+            out["accumulation"][a:b, 0].copy_(s.acc[:k])
+            out["expected_depth"][a:b, 0].copy_(s.depth_exp[:k])
+            out["depth"][a:b, 0].copy_(s.depth_med[-1][:k])
+            for i in range(s.n_prop):
+                out[f"prop_depth_{i}"][a:b, 0].copy_(s.depth_med[i][:k])
+        return {k_: v.view(int(height), int(width), -1) for k_, v in out.items()}
+
+
+def pinhole_camera_args(camera):
+    """(c2w [3,4], fx, fy, cx, cy, H, W) of a single undistorted perspective `Cameras` object (cameras/cameras.py), or None when the
+    camera needs the general ray generator (fisheye / equirectangular / orthographic types, distortion parameters, several
+    cameras, per-camera metadata the field consumes)."""
+    try:
+        c2w = camera.camera_to_worlds
+        if c2w.dim() == 3:
+            if c2w.shape[0] != 1:
+                return None
+            c2w = c2w[0]
+        ctype = getattr(camera, "camera_type", None)
+        if ctype is not None and int(torch.as_tensor(ctype).reshape(-1)[0]) != 1:  # CameraType.PERSPECTIVE
+            return None
+        dist = getattr(camera, "distortion_params", None)
+        if dist is not None and bool(torch.any(torch.as_tensor(dist) != 0)):
+            return None
+        one = lambda t: float(torch.as_tensor(t).reshape(-1)[0])  # noqa: E731
+        h, w = int(one(camera.height)), int(one(camera.width))
+        if h <= 0 or w <= 0 or torch.as_tensor(camera.fx).numel() != 1:
+            return None
+        return c2w[:3, :4], one(camera.fx), one(camera.fy), one(camera.cx), one(camera.cy), h, w
+    except (AttributeError, TypeError, ValueError, IndexError):
+        return None
+
 
 def supported(model) -> Optional[str]:
     """None, or why this model's eval render has to stay on the module path."""

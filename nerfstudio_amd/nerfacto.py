@@ -293,6 +293,25 @@ class NerfactoModel(nn.Module):
         return loss_dict
 
     @torch.no_grad()
+    def get_outputs_for_camera(self, camera, obb_box=None) -> Dict[str, Tensor]:
+        """models/base_model.py:166-175. Eval mode, one undistorted pinhole camera, no crop box: the rays of each chunk are
+        generated inside the device-side chunk loop (eval_render.EvalRenderer.render_camera) — no [H, W] bundle in HBM; anything
+        else generates the bundle (`camera.generate_rays(camera_indices=0, keep_shape=True)`) and takes the loop below."""
+        import os
+
+        from . import eval_render
+
+        dev = next(self.parameters()).device
+        args = eval_render.pinhole_camera_args(camera) if obb_box is None else None
+        if (args is not None and not self.training and dev.type == "cuda" and os.environ.get("NSAMD_EVAL_RUNNER", "1") == "1"
+                and eval_render.supported(self) is None):
+            runner = getattr(self, "_eval_runner", None)
+            if runner is None or runner.chunk != self.config.eval_num_rays_per_chunk:
+                runner = self._eval_runner = eval_render.EvalRenderer(self)
+            return runner.render_camera(*args)
+        return self.get_outputs_for_camera_ray_bundle(camera.generate_rays(camera_indices=0, keep_shape=True, obb_box=obb_box))
+
+    @torch.no_grad()
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
         """Chunked full-image render (models/base_model.py:178-205). In eval mode on the GPU the chunk loop is device-side
         (eval_render.EvalRenderer: one captured kernel schedule per chunk over static buffers, outputs copied into

@@ -152,7 +152,24 @@ def _model_classes():
 
         @torch.no_grad()
         def get_outputs_for_camera(self, camera, obb_box=None):  # models/base_model.py:162-176 (viewer, ns-render)
+            """One undistorted pinhole camera without a crop box, in eval mode on the model's GPU: the rays of every chunk are
+            generated inside the device-side chunk loop (EvalRenderer.render_camera over nsamd_raygen_pinhole_grid: the arithmetic
+            of `camera.generate_rays(camera_indices=0, keep_shape=True)`, cameras/cameras.py:321-503) — no [H, W] ray bundle is
+            built. Anything else is the reference's own path."""
+            import os
+
+            from . import eval_render
+
             self._flush_pending()
+            col = getattr(self, "collider", None)
+            args = eval_render.pinhole_camera_args(camera) if obb_box is None else None
+            if (args is not None and not self.training and self.device.type == "cuda" and os.environ.get("NSAMD_EVAL_RUNNER", "1") == "1"
+                    and eval_render.supported(self) is None and getattr(col, "near_plane", None) == self.config.near_plane
+                    and getattr(col, "far_plane", None) == self.config.far_plane):
+                runner = getattr(self, "_eval_runner", None)
+                if runner is None or runner.chunk != self.config.eval_num_rays_per_chunk:
+                    runner = self._eval_runner = eval_render.EvalRenderer(self)
+                return runner.render_camera(*args)
             return super().get_outputs_for_camera(camera, obb_box=obb_box)
 
         @torch.no_grad()

@@ -23,6 +23,9 @@ ap.add_argument("--height", type=int, default=800)
 ap.add_argument("--width", type=int, default=800)
 ap.add_argument("--frames", type=int, default=5)
 ap.add_argument("--module-loop", action="store_true", help="the reference-shaped Python chunk loop + torch.cat (NSAMD_EVAL_RUNNER=0)")
+ap.add_argument("--bundle", action="store_true",
+                help="build the camera's [H, W] ray bundle first (nsamd_raygen_pinhole over an index list) and render it, as round 5 "
+                     "did; default: Model.get_outputs_for_camera with the rays generated inside the chunk loop")
 args = ap.parse_args()
 if args.module_loop:
     os.environ["NSAMD_EVAL_RUNNER"] = "0"
@@ -43,12 +46,18 @@ cams.fx = torch.tensor([[0.9 * W]])
 cams.fy = torch.tensor([[0.9 * W]])
 cams.cx = torch.tensor([[W / 2.0]])
 cams.cy = torch.tensor([[H / 2.0]])
+cams.height, cams.width = torch.tensor([[H]]), torch.tensor([[W]])
+cams.camera_type = torch.tensor([[1]])  # CameraType.PERSPECTIVE
+cams.distortion_params = None
 gen = RayGenerator(cams).to(dev)
+cams.camera_to_worlds = cams.camera_to_worlds.to(dev)
 yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
 idx = torch.stack([torch.zeros_like(yy), yy, xx], dim=-1).reshape(-1, 3).to(dev)
 
 
 def frame():
+    if not (args.bundle or args.module_loop):
+        return model.get_outputs_for_camera(cams)  # rays generated chunk by chunk inside the device-side loop
     rb = gen(idx)  # rays of the whole image on the device (nsamd_raygen_pinhole)
     out = model.get_outputs_for_camera_ray_bundle(rb.reshape((H, W)) if hasattr(rb, "reshape") else rb)
     return out
@@ -69,6 +78,7 @@ print(json.dumps({"metric": "eval render rays/sec (nerfacto, 256 -> 96 -> 48 sam
                   "unit": "rays/s", "ms_per_frame": round(dt * 1e3, 2), "image": [H, W],
                   "chunk": model.config.eval_num_rays_per_chunk,
                   "launch": "Python loop over forward + torch.cat (eager)" if args.module_loop else
-                            "device-side chunk loop: one captured kernel schedule per chunk (eval_render.py)",
+                            ("device-side chunk loop: one captured kernel schedule per chunk (eval_render.py)"
+                             + (", rays from a prebuilt [H,W] bundle" if args.bundle else ", rays generated per chunk (no bundle)")),
                   "forward_ceiling_rays_per_s": round(CEILING, 1), "frac_of_forward_ceiling": round(H * W / dt / CEILING, 4),
                   "data": "synthetic", "dtype": "f32"}))

@@ -1295,6 +1295,52 @@ def test_eval_renderer_equals_the_module_chunk_loop(F, monkeypatch):
     assert not torch.equal(ref2["rgb"], ref["rgb"]) and all(torch.equal(c[k], ref2[k]) for k in keys)
 
 
+def test_eval_render_of_a_camera_generates_its_rays_inside_the_chunk_loop(F):
+    """Model.get_outputs_for_camera (models/base_model.py:166-175) for one undistorted pinhole camera: the device-side chunk loop
+    generates each chunk's rays itself (nsamd_raygen_pinhole_grid — no [H, W] bundle, no index list) and must give, bit for bit,
+    what the bundle of `generate_rays(camera_indices=0, keep_shape=True)` gives through get_outputs_for_camera_ray_bundle — the
+    bundle here comes from nsamd_raygen_pinhole, which tests/golden pins to the reference's own generate_rays. A frame that is
+    not a multiple of the chunk; a camera the grid generator does not cover (fisheye) must take the bundle route."""
+    from nerfstudio_amd.model_components.ray_generators import RayGenerator
+
+    cfg = small_cfg(12, 10, 5)
+    model = _hip_model(cfg, orc.init_params(cfg, seed=3, table_std=0.4), training=False)
+    model.config.eval_num_rays_per_chunk = 512
+    H, W = 37, 41  # 1517 rays: 2 full chunks + 493
+    c2w = torch.tensor([[0.96, -0.10, 0.26, 0.3], [0.05, 0.98, 0.19, -0.2], [-0.27, -0.17, 0.95, 0.9]])
+
+    class Cam:
+        camera_to_worlds = c2w[None].cuda()
+        fx, fy = torch.tensor([[0.9 * W]]).cuda(), torch.tensor([[0.8 * W]]).cuda()
+        cx, cy = torch.tensor([[W / 2.0 + 0.25]]).cuda(), torch.tensor([[H / 2.0 - 0.5]]).cuda()
+        height, width = torch.tensor([[H]]), torch.tensor([[W]])
+        camera_type = torch.tensor([[1]])  # CameraType.PERSPECTIVE
+        distortion_params = None
+        calls = 0
+
+        def generate_rays(self, camera_indices=0, keep_shape=True, obb_box=None):
+            type(self).calls += 1
+            yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+            idx = torch.stack([torch.zeros_like(yy), yy, xx], dim=-1).reshape(-1, 3).cuda()
+            import types
+
+            pin = types.SimpleNamespace(camera_to_worlds=self.camera_to_worlds, fx=self.fx, fy=self.fy, cx=self.cx, cy=self.cy)
+            return RayGenerator(pin).cuda()(idx).reshape((H, W))
+
+    cam = Cam()
+    ref = model.get_outputs_for_camera_ray_bundle(cam.generate_rays())
+    Cam.calls = 0
+    for _ in range(2):  # (the second frame replays the captured chunk)
+        out = model.get_outputs_for_camera(cam)
+        assert Cam.calls == 0, "the pinhole camera must not build a ray bundle"
+        for k in ("rgb", "accumulation", "depth", "expected_depth", "prop_depth_0", "prop_depth_1"):
+            assert out[k].shape == ref[k].shape == (H, W, ref[k].shape[-1]), k
+            assert torch.equal(out[k], ref[k]), f"{k}: max |d| = {float((out[k] - ref[k]).abs().max()):.3e}"
+    cam.camera_type = torch.tensor([[2]])  # fisheye: the general generator's job
+    out = model.get_outputs_for_camera(cam)
+    assert Cam.calls == 1 and torch.equal(out["rgb"], ref["rgb"])
+
+
 def test_training_trajectory_matches_oracle(F):
     """30 full training steps (forward, 3 losses, backward, Adam) on the GPU runner and on the CPU oracle from the same
     initialisation, rays and jitter draws: the loss curves must track each other (tight at first, ulp-level

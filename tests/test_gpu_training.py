@@ -328,8 +328,9 @@ def test_two_ranks_on_one_gpu_train_through_the_bits_of_the_single_gpu_run():
         assert r.returncode == 0, (r.stderr or r.stdout)[-3000:]
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
-    one = last_json(subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common], capture_output=True, text=True, env=env,
-                                   timeout=600, cwd=root))
+    # (eager launches on both sides: a capture runs two more warm-up iterations — trainer.warm_variants — than the N > 1 default)
+    one = last_json(subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-graph", *common], capture_output=True,
+                                   text=True, env=env, timeout=600, cwd=root))
 
     def two_ranks(backend, port, *flags, timeout=900):
         import signal
