@@ -202,8 +202,19 @@ def load():
     cdll = C.CDLL(path)
     lib = _Lib()
     lib.cdll = cdll
+    older_ok = "NSAMD_LIB" in os.environ and os.environ.get("NSAMD_LIB_OLDER_ABI") == "1"
     for name, argtypes in _SIGNATURES.items():
-        fn = getattr(cdll, name)  # AttributeError here = header / library mismatch
+        try:
+            fn = getattr(cdll, name)  # AttributeError here = header / library mismatch
+        except AttributeError:
+            if not older_ok:
+                raise
+            # same-box A/B against an OLDER build (NSAMD_LIB=... NSAMD_LIB_OLDER_ABI=1): an entry point it lacks fails when called
+            def missing(*_a, _n=name):
+                raise RuntimeError(f"nsamd: {_n} is not exported by {path} (an older build loaded for A/B)")
+
+            setattr(lib, name, missing)
+            continue
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
         setattr(lib, name, _Entry(fn, name) if fn.restype is C.c_int and name not in ("nsamd_device_info",) else fn)

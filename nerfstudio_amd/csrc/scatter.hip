@@ -917,7 +917,13 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
   // threshold: levels with resolution below it are merged (1 = none).
   static const int combine_env = env_int("NSAMD_SCATTER_COMBINE_RES", 0);
   float coarse_below = 0.0f;
-  if (pts.positions == nullptr && pts.samples_per_ray >= 192) coarse_below = (float)pts.samples_per_ray;
+  // Round 6 (profiles/r06_s12_*, r06_s14_*): since the run kernel and the apply pass on non-empty segments (rounds 3 - 5) the
+  // 96-sample level is cheaper merged as well — its route + apply read 40 + 37 us plain against 35 + 9 us for the 2.7 x larger
+  // 256-sample level merged; all five of its levels through the run kernel: long run 0.6919 / 0.6883 against 0.6971 / 0.6959 ms
+  // from step 40, window 0.657 / 0.658 against 0.667 / 0.667 from step 0 (NSAMD_SCATTER_MERGE_96=0: the plain route, A/B).
+  static const int merge96 = env_int("NSAMD_SCATTER_MERGE_96", 1);
+  if (pts.positions == nullptr && pts.samples_per_ray >= (merge96 ? 96 : 192))
+    coarse_below = pts.samples_per_ray >= 192 ? (float)pts.samples_per_ray : 1e30f;
   if (combine_env > 0) coarse_below = (float)combine_env;
   LevelList coarse{}, fine{};
   for (int l = 0; l < grid.num_levels; ++l) {
