@@ -28,6 +28,7 @@
 #include "common.h"
 #include "field_reduce.h"
 #include "scatter.h"
+#include "wave.h"
 
 NSAMD_PROBE_DEFINE(field)
 
@@ -1126,12 +1127,7 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
         for (int t = 2; t < 4; ++t) {
           v4f v = g_hin[t];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] += __shfl_xor(v[r], 1);
-            v[r] += __shfl_xor(v[r], 2);
-            v[r] += __shfl_xor(v[r], 4);
-            v[r] += __shfl_xor(v[r], 8);
-          }
+          for (int r = 0; r < 4; ++r) v[r] = row16_sum_lane0(v[r]);  // (DPP: the butterfly's sums for lane j == 0, wave.h)
           // (32-bit element offset from the kernel-argument base: as a hoisted 64-bit per-lane address this was a spilled
           //  register pair, reloaded here with `s_waitcnt vmcnt(0)` — a drain of every record store in flight per tile;
           //  tiles * 32 < 2^32 for any M whose 32 x M feature matrix exists)
@@ -1147,11 +1143,7 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
           for (int t = 2; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float v = g_hin[t][r];
-              v += __shfl_xor(v, 1);
-              v += __shfl_xor(v, 2);
-              v += __shfl_xor(v, 4);
-              v += __shfl_xor(v, 8);
+              const float v = row16_sum_lane0(g_hin[t][r]);
               if (j == 0 && v != 0.0f) unsafeAtomicAdd(grads.appearance + (int64_t)cam0 * 32 + 16 * (t - 2) + 4 * g + r, v);
             }
         } else if (ti.live) {

@@ -67,4 +67,20 @@ __device__ __forceinline__ uint32_t pair_swap_u32(uint32_t v) {
 }
 __device__ __forceinline__ float pair_swap_f32(float v) { return __uint_as_float(pair_swap_u32(__float_as_uint(v))); }
 
+// Sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), valid in the row's lane 0 (and, up to the association, in every
+// lane): the xor-butterfly's additions for that lane — partners 1, 2, 4, 8 — as quad_perm [1,0,3,2], quad_perm [2,3,0,1],
+// row_ror:12, row_ror:8 at VALU rate. (`__shfl_xor` compiles to ds_bpermute_b32: an LDS-crossbar round trip per step; the field
+// backward's appearance-gradient rows took 32 of them per tile, four deep.) Same bits in lane 0 as the butterfly.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move_f32(float v) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum_lane0(float v) {
+  v += dpp_move_f32<0xB1>(v);
+  v += dpp_move_f32<0x4E>(v);
+  v += dpp_move_f32<0x12C>(v);  // row_ror:12: lane i reads lane (i + 4) % 16 — lane 0 its butterfly partner 4, lane 8 its partner 12
+  v += dpp_move_f32<0x128>(v);  // row_ror:8:  lane 0 reads lane 8
+  return v;
+}
+
 }  // namespace nsamd
