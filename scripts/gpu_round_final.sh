@@ -5,9 +5,9 @@
 # cpu_baseline and the per-kernel table), then the instant-ngp / 300-step / steady-state / unbounded lines, eval render, the
 # one-rank data-parallel rehearsal.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r05_final4}
+TAG=${1:-r06_final}
 OUT=$R/gpurun_out/$TAG
-BUDGET_S=${BUDGET_S:-1150}
+BUDGET_S=${BUDGET_S:-1700}
 T0=$(date +%s)
 mkdir -p $OUT
 cd $R
@@ -16,7 +16,7 @@ export TMPDIR=/tmp
 left() { [ $(( $(date +%s) - T0 )) -lt $BUDGET_S ]; }
 say() { echo "$@" | tee -a $OUT/summary.txt; }
 say "== pytest -m gpu"
-timeout 780 python -m pytest tests -m gpu -q -s > $OUT/pytest_gpu.log 2>&1
+timeout 1300 python -m pytest tests -m gpu -q -s > $OUT/pytest_gpu.log 2>&1
 say "rc=$?"
 grep -E "mean PSNR|^   [0-9] \||GPU - oracle|passed|failed|^E  |bench-size parity|excluded" $OUT/pytest_gpu.log | cut -c1-400 | head -40 | tee -a $OUT/summary.txt
 say "== smoke"
@@ -26,7 +26,9 @@ PMC_STATS_TIMEOUT=150 PMC_PASS_TIMEOUT=120 bash scripts/collect_pmc.sh $TAG > $O
 cp $OUT/pmc_traffic.json $R/profiles/pmc_traffic.json 2>/dev/null
 head -n 45 $OUT/kernel_stats.csv 2>/dev/null | cut -c1-200 | tee -a $OUT/summary.txt
 say "== bench, driver window (traffic now stamped for these sources)"
-timeout 200 python bench.py --steps 20 --warmup 5 --kernel-table > $OUT/bench_driver_window.json 2> $OUT/bench_driver_window_kernel_table.log
+timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_line.json 2> $OUT/bench_driver_line.err
+cat $OUT/bench_driver_line.json | tee -a $OUT/summary.txt
+timeout 200 python bench.py --steps 20 --warmup 5 --kernel-table --no-cpu-baseline > $OUT/bench_driver_window.json 2> $OUT/bench_driver_window_kernel_table.log
 cat $OUT/bench_driver_window.json | tee -a $OUT/summary.txt
 grep -v amdgpu.ids $OUT/bench_driver_window_kernel_table.log | head -n 26 | tee -a $OUT/summary.txt
 say "elapsed $(( $(date +%s) - T0 )) s"
@@ -36,15 +38,6 @@ timeout 200 python scripts/bench_seam.py > $OUT/bench_seam.json 2> $OUT/bench_se
 python -c "
 import json; j=json.load(open('$OUT/bench_seam.json'))
 print({k: j[k] for k in ('direct_pool_ms','direct_set_batch_ms','seam_ms','seam_over_direct_pool','seam_over_direct_pool_per_window')})" | tee -a $OUT/summary.txt
-fi
-if left; then
-say "== what the round's later changes are worth on THIS box: one driver window each with the head of the iteration / the hash forward of the round's first evidence session"
-for arm in NSAMD_ADAM_BLOCKS_PER_CU=8 "NSAMD_ADAM_BLOCKS_PER_CU=8 NSAMD_STEP_PROLOGUE=0" "NSAMD_ADAM_BLOCKS_PER_CU=8 NSAMD_HASH_FWD_MODE=3" "NSAMD_ADAM_BLOCKS_PER_CU=8 NSAMD_STEP_PROLOGUE=0 NSAMD_HASH_FWD_MODE=3"; do
-  say "$arm: $(env $arm timeout 100 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --long-steps 100 --profile-steps 1 2>/dev/null | python -c 'import sys,json
-for l in sys.stdin:
-    if l.startswith("{"):
-        d=json.loads(l); print(d["ms_per_step"], d["value"], "long", (d.get("long_run") or {}).get("ms_per_step"))')"
-done
 fi
 if left; then
 say "== bench, camera optimiser ON (SO3xR3: the reference's nerfacto default, models/nerfacto.py:131)"
