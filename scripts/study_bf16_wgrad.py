@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """CPU study (no GPU): how accurate would split-bf16 operands be for the WEIGHT-GRADIENT GEMMs of the main field's MLPs
-? The CPU oracle runs training iterations of the benchmark configuration (4096 rays x 48 samples,
+(profiles/NOTEBOOK.md §7.1 item 2)? The CPU oracle runs training iterations of the benchmark configuration (4096 rays x 48 samples,
 full tables); for every linear layer of the main field the layer input X [M, in] and the gradient of its pre-activation
 output dY [M, out] are captured, and dW = dY^T X is formed
   * in float64 (the yardstick),
