@@ -175,6 +175,7 @@ def test_psnr_on_procedural_scene_matches_oracle_training(F, golden):
     assert (rows[:, 1] > 20.0).all() and (rows[:, 4] > 20.0).all(), rows                                     # (a)
     assert abs(d_train.mean()) <= 0.2 and abs(d_held.mean()) <= 0.3, (d_train, d_held)                       # (b)
     assert np.abs(d_train).max() <= 0.75 and np.abs(d_held).max() <= 1.0, (d_train, d_held)
+    worst = []
     for got, ref, twin in curves:                                                                            # (c)
         np.testing.assert_allclose(got[:10], ref[:10], rtol=1e-3)
         w = 25
@@ -184,7 +185,14 @@ def test_psnr_on_procedural_scene_matches_oracle_training(F, golden):
         # in every summation order, i.e. by more than the twin's perturbation — single windows within 25 %, their average
         # deviation within 8 %
         dev_w = np.abs(wm(got)[1:] - wm(ref)[1:]) / wm(ref)[1:]
+        dev_t = np.abs(wm(twin)[1:] - wm(ref)[1:]) / wm(ref)[1:]
+        worst.append((dev_w.max(), dev_w.mean(), dev_t.max(), dev_t.mean()))
         assert dev_w.max() <= 0.25 and dev_w.mean() <= 0.08, np.round(dev_w, 3)
+    # (the measured envelope behind the 25 % / 8 % bounds, next to the oracle's own twin run on the same windows)
+    worst = np.array(worst)
+    print("   25-step window means of the rgb loss, relative deviation from the oracle: GPU path max %.3f (per-seed maxima %s), "
+          "mean %.3f; oracle twin max %.3f, mean %.3f" % (worst[:, 0].max(), np.round(worst[:, 0], 3).tolist(), worst[:, 1].mean(),
+                                                        worst[:, 2].max(), worst[:, 3].mean()))
     ev = _events(F)
     assert ev[1] == 0 and ev[2] == 0, ev
 
@@ -368,8 +376,9 @@ def test_two_ranks_on_one_gpu_train_through_the_bits_of_the_single_gpu_run():
         assert rc["config"]["param_checksum"] == one["config"]["param_checksum"]
         print("\ntwo RCCL ranks on one device: communicator came up, same bits as N = 1")
     else:
-        tail = (r.stderr or r.stdout).strip().splitlines()[-1:] or ["?"]
-        print(f"\ntwo RCCL ranks on one device: not available here ({tail[0][:160]})")
+        lines = (r.stderr or r.stdout).strip().splitlines()
+        why = next((ln.strip() for ln in reversed(lines) if "rror" in ln and "====" not in ln), lines[-1] if lines else "?")
+        print(f"\ntwo RCCL ranks on one device: not available here ({why[:200]})")
 
 
 def test_checkpoint_round_trip_resumes_bit_exactly(F, tmp_path):
