@@ -384,3 +384,31 @@ def test_ngp_engine_runs_the_collider_and_falls_back_when_the_schedule_refuses_t
     eng2.runner_factory = object()  # (rays on the CPU are fine with a stand-in runner factory)
     reason = eng2.build(rb, {"image": torch.zeros(4, 3)})
     assert reason is not None and "out_dim" in reason and eng2.reason == reason and eng2.trainer is None
+
+
+def test_pinhole_camera_args_picks_only_cameras_the_grid_generator_covers():
+    """eval_render.pinhole_camera_args (round 6): Model.get_outputs_for_camera generates rays inside the chunk loop only for ONE
+    undistorted perspective camera; everything else (other lens types, distortion, several cameras, missing fields) must take the
+    reference's generate_rays route (cameras/cameras.py:321-503)."""
+    import types
+
+    import torch
+
+    from nerfstudio_amd.eval_render import pinhole_camera_args
+
+    def cam(**kw):
+        base = dict(camera_to_worlds=torch.eye(4)[None, :3], fx=torch.tensor([[100.0]]), fy=torch.tensor([[90.0]]),
+                    cx=torch.tensor([[32.0]]), cy=torch.tensor([[24.0]]), height=torch.tensor([[48]]), width=torch.tensor([[64]]),
+                    camera_type=torch.tensor([[1]]), distortion_params=None)
+        base.update(kw)
+        return types.SimpleNamespace(**base)
+
+    c2w, fx, fy, cx, cy, h, w = pinhole_camera_args(cam())
+    assert c2w.shape == (3, 4) and (fx, fy, cx, cy, h, w) == (100.0, 90.0, 32.0, 24.0, 48, 64)
+    assert pinhole_camera_args(cam(camera_to_worlds=torch.eye(4)[:3])) is not None          # an unbatched [3, 4] pose
+    assert pinhole_camera_args(cam(distortion_params=torch.zeros(1, 6))) is not None          # all-zero distortion = none
+    assert pinhole_camera_args(cam(camera_type=torch.tensor([[2]]))) is None                  # fisheye
+    assert pinhole_camera_args(cam(distortion_params=torch.tensor([[0.1, 0, 0, 0, 0, 0]]))) is None
+    assert pinhole_camera_args(cam(camera_to_worlds=torch.eye(4)[None, :3].repeat(2, 1, 1))) is None  # two cameras
+    assert pinhole_camera_args(cam(fx=torch.tensor([[100.0], [101.0]]))) is None
+    assert pinhole_camera_args(types.SimpleNamespace(camera_to_worlds=torch.eye(4)[None, :3])) is None  # no intrinsics
