@@ -340,7 +340,9 @@ extern "C" int nsamd_adam_step(float* params, const float* grads, float* exp_avg
   // 67.3 us with 8 / 4 / 3 / 2 per CU — HBM is saturated from 3 on — but the deferred main-field pass runs BESIDE the next
   // proposal forward, and with 8 per CU it starves it (the launch that writes the initial bins reads 45 us there, 14 us alone):
   // driver window 0.7231 (8) / 0.7150 (4) / 0.7142 ms (2), three alternating repeats on one box, profiles/r05_s21_*, r05_s22_*.
-  static const int per_cu = [] { const char* e = getenv("NSAMD_ADAM_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 4; return v > 0 ? v : 4; }();
+  // Round 6 (profiles/r06_s18_*, three alternating repeats, window / 300-step long run): 4: 0.6532 / 0.7088, 3: 0.6486 / 0.7030,
+  // 2: 0.6533 / 0.7042, 1: 0.6586 / 0.7051 ms -> 3.
+  static const int per_cu = [] { const char* e = getenv("NSAMD_ADAM_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 3; return v > 0 ? v : 3; }();
   const unsigned blocks = (unsigned)min((int64_t)256 * per_cu, (n4 + 255) / 256);
   adam_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, (float)beta2,
                                                        (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, step_size,
