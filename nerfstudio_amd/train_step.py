@@ -162,7 +162,10 @@ class NerfactoTrainStep:
         keys = [(id(self.props[lvl]), self.props[lvl].encoding.spec, n * self.counts[lvl]) for lvl in range(self.n_prop)]
         self.levels_independent = (len({k[0] for k in keys}) == self.n_prop and
                                    len({(k[1], k[2]) for k in keys}) == self.n_prop)
-        if os.environ.get("NSAMD_LEVEL_STREAMS", "1") == "0":  # A/B (profiles/r04_exp14_*): every level's chain on the one side stream
+        # Every level's chain on the ONE side stream by default (round 6, profiles/r06_s19_*: three alternating repeats, window
+        # 0.6265 / 0.6304 / 0.6275 against 0.6494 / 0.6512 / 0.6278 ms with a stream per level, long run 0.689 against 0.695; the
+        # chains in line on the main stream 0.674 / 0.736 — same bits in all three). NSAMD_LEVEL_STREAMS=1: a stream per level.
+        if os.environ.get("NSAMD_LEVEL_STREAMS", "0") != "1":
             self.levels_independent = False
         # ---- camera optimiser (nerfstudio's nerfacto default is SO3xR3, the benchmark recipe is "off") ----
         # Host-side torch computes the corrected rays from `pose_adjustment` (a [num_cameras, 6] parameter); the kernels
