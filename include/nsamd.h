@@ -276,6 +276,14 @@ int nsamd_field_mlp_bwd(const float* enc, const float* selector, const float* di
  * scatter_workspace: nsamd_field_mlp_bwd_scatter_workspace(grid, M, &state) floats, the first `state` of them zero
  * before the first call (the kernels leave them zero). Returns NSAMD_ERR_UNSUPPORTED for other level counts. */
 int64_t nsamd_field_mlp_bwd_scatter_workspace(nsamd_grid grid, int64_t M, int64_t* state_words);
+/* Leave `cus` compute units out of the persistent workgroups of the NEXT launches of the field backward (all four entry
+ * points; 0 = none, the default; -1 = as many as ONE more sweep over the tiles frees — the workgroups take
+ * ceil(tile groups / workgroups) sweeps whatever their number, so that is the cheapest reservation: 6 sweeps on 256 CUs
+ * become 7 on 220 for 196 608 points) and return the previous setting. The backward's workgroups own a CU's LDS and registers
+ * for the whole launch; on the iterations whose proposal networks receive gradient (model_components/ray_samplers.py:
+ * 590-609) their latency-bound backward chains, queued on another stream, otherwise wait for its end. Process-wide,
+ * read when a launch is issued (or captured). Results are the same gradients summed in another fixed order. */
+int nsamd_field_mlp_bwd_reserve_cus(int cus);
 int nsamd_field_mlp_bwd_scatter(nsamd_points pts, int transform, nsamd_aabb aabb, nsamd_grid grid, const float* enc,
                                 const float* selector, const float* directions, const int64_t* camera_indices,
                                 const float* appearance_const, int64_t dir_group, int64_t M, nsamd_field_mlp mlp,
@@ -341,6 +349,54 @@ int nsamd_weights_bwd(const float* t_bins, const float* density, const float* dw
 int nsamd_weights_bwd_gate(const float* t_bins, const float* density, const float* dweights, int64_t num_rays,
                            int32_t S, float* ddensity, uint32_t* gate_out, uint8_t* ray_mask_out, int32_t gate_precleared,
                            nsamd_stream_t stream);
+
+/* ---- backward of ALL proposal levels of an update iteration, stage by stage across the levels -------------------------
+ * What ProposalNetworkSampler's levels receive through interlevel_loss on the steps that update them
+ * (model_components/ray_samplers.py:590-609): per level the gated chain
+ *   nsamd_weights_bwd_gate -> nsamd_density_mlp_bwd_gated -> nsamd_hashgrid_encode_bwd_gated      (ray mode, stride 1 / M)
+ * The levels share nothing (own network, table, gradients, scratch) and each of the chain's six launches is as long as
+ * its slowest workgroup's memory round trips, not as its work; here the SAME stage of two levels is ONE launch (level
+ * pairs (0,1), (2,3), ...; an odd level out, levels that share a workspace, network or table gradient, or shapes the
+ * merged kernels do not cover go through the per-level entry points inside the call). Results: bit for bit those of the
+ * per-level calls. One struct per level: */
+typedef struct {
+  int64_t num_rays;
+  int32_t samples_per_ray;
+  /* RaySamples.get_weights backward: bins [num_rays, S+1], density / dweights [num_rays, S] -> ddensity; *gate and
+   * ray_mask [num_rays] are WRITTEN (see "zero-gradient gating") */
+  const float* t_bins;
+  const float* density;
+  const float* dweights;
+  float* ddensity;
+  uint32_t* gate;
+  uint8_t* ray_mask;
+  /* density MLP backward (as nsamd_density_mlp_bwd_gated): enc [in_dim, M], selector (nullable), pre [M] -> denc [in_dim, M];
+   * dW0 .. db1 accumulate; mlp_workspace as there */
+  const float* enc;
+  const float* selector;
+  const float* pre;
+  nsamd_density_mlp mlp;
+  float* denc;
+  float* dW0;
+  float* db0;
+  float* dW1;
+  float* db1;
+  float* mlp_workspace;
+  int64_t mlp_workspace_floats;
+  /* table scatter (as nsamd_hashgrid_encode_bwd_gated on ray-mode points origins / directions / t_bins): dtable accumulates */
+  const float* origins;
+  const float* directions;
+  int transform;
+  nsamd_aabb aabb;
+  const float* table;
+  nsamd_grid grid;
+  float* dtable;
+  float* scatter_workspace;
+  int64_t scatter_workspace_floats;
+} nsamd_proposal_level_bwd;
+/* gates_precleared as in nsamd_weights_bwd_gate (0: every level's *gate is cleared on the stream first). */
+int nsamd_proposal_levels_bwd(const nsamd_proposal_level_bwd* levels, int32_t num_levels, int32_t gates_precleared,
+                              nsamd_stream_t stream);
 
 /* PDFSampler.generate_ray_samples (ray_samplers.py:276-372) preceded by the anneal pow(weights, anneal)
  * (ray_samplers.py:601; skipped when anneal == 1). include_original = 0: s_bins / t_bins are [num_rays, S+1] (the

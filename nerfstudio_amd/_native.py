@@ -61,6 +61,16 @@ class FieldMlpGrads(C.Structure):
                 ("head_W1", vp), ("head_b1", vp), ("head_W2", vp), ("head_b2", vp), ("appearance", vp)]
 
 
+class ProposalLevelBwd(C.Structure):
+    """nsamd_proposal_level_bwd: one proposal level's gated backward chain (nsamd_proposal_levels_bwd)."""
+    _fields_ = [("num_rays", i64), ("samples_per_ray", i32),
+                ("t_bins", vp), ("density", vp), ("dweights", vp), ("ddensity", vp), ("gate", vp), ("ray_mask", vp),
+                ("enc", vp), ("selector", vp), ("pre", vp), ("mlp", DensityMlp), ("denc", vp),
+                ("dW0", vp), ("db0", vp), ("dW1", vp), ("db1", vp), ("mlp_workspace", vp), ("mlp_workspace_floats", i64),
+                ("origins", vp), ("directions", vp), ("transform", C.c_int), ("aabb", Aabb), ("table", vp), ("grid", Grid),
+                ("dtable", vp), ("scatter_workspace", vp), ("scatter_workspace_floats", i64)]
+
+
 # name -> argtypes (restype is int unless listed in _RESTYPES). Mirrors include/nsamd.h one to one; the CPU test
 # tests/test_abi.py checks that every symbol declared in the header is exported by the library and listed here.
 _SIGNATURES = {
@@ -87,6 +97,8 @@ _SIGNATURES = {
     "nsamd_field_mlp_bwd_scatter_phase": [Points, C.c_int, Aabb, Grid, vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads,
                                           vp, i64, vp, vp, i64, C.c_int, vp],
     "nsamd_field_mlp_bwd_scatter_workspace": [Grid, i64, C.POINTER(C.c_int64)],
+    "nsamd_field_mlp_bwd_reserve_cus": [C.c_int],
+    "nsamd_proposal_levels_bwd": [C.POINTER(ProposalLevelBwd), i32, i32, vp],
     "nsamd_field_mlp_bwd_phase": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp, i64, C.c_int, vp],
     "nsamd_linear_fwd": [vp, vp, vp, i64, i32, i32, C.c_int, vp, vp],
     "nsamd_linear_bwd": [vp, vp, vp, vp, i64, i32, i32, C.c_int, vp, vp, vp, vp],

@@ -16,6 +16,7 @@
 // weight element).
 #include "common.h"
 #include "density_point.h"
+#include "proposal_chain.h"
 
 namespace nsamd {
 
@@ -80,12 +81,15 @@ __global__ __launch_bounds__(kMlpBlock) void density_field_fwd_kernel(nsamd_poin
   density_point<LEVELS, H>(x, y, z, p, M, transform, box, table, grid, mlp, enc_out, selector_out, density, pre_out);
 }
 
+// (a device body: launched by density_mlp_bwd_kernel and, two independent calls side by side, by density_mlp_bwd_pair_kernel;
+//  `nblocks` = the workgroups of THIS call, blockIdx.x < nblocks)
 template <int IN, int H>
-__global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
+__device__ __forceinline__ void density_mlp_bwd_body(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ pre,
-    const float* __restrict__ ddensity, int64_t M, nsamd_density_mlp mlp, float* __restrict__ denc,
+    const float* __restrict__ ddensity, int64_t M, const nsamd_density_mlp& mlp, float* __restrict__ denc,
     float* __restrict__ dW0, float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1,
-    float* __restrict__ partials, const uint32_t* __restrict__ gate, const uint8_t* __restrict__ ray_mask, int spr) {
+    float* __restrict__ partials, const uint32_t* __restrict__ gate, const uint8_t* __restrict__ ray_mask, int spr,
+    int nblocks) {
   // Gated call (nsamd_density_mlp_bwd_gated): the flag nsamd_weights_bwd_gate raises when any ray of the level carries
   // gradient is clear -> every upstream gradient is an exact zero, so are all results of this launch; the zero-filled
   // weight gradients stay as they are and nothing downstream (gated the same way) reads `denc`.
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
   // one memory round trip; it used to stage the weights (three round trips) and then look its chunks' rays up one load at a
   // time (22.4 -> 20.5 us per sparse launch of the 256-sample level).
   const int64_t chunks = (M + kMlpBlock - 1) / kMlpBlock;
-  const int64_t per_wg = (chunks + gridDim.x - 1) / gridDim.x;
+  const int64_t per_wg = (chunks + nblocks - 1) / nblocks;
   const int64_t c_lo = (int64_t)blockIdx.x * per_wg;
   const int64_t c_hi = c_lo + per_wg < chunks ? c_lo + per_wg : chunks;
   constexpr int kActMax = kDensityActMax;  // chunks per workgroup the activity table holds (beyond: every chunk counts as active)
@@ -294,16 +298,57 @@ __global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
   else if (threadIdx.x == 2 * H) unsafeAtomicAdd(db1, accV);
 }
 
+template <int IN, int H>
+__global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_kernel(
+    const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ pre,
+    const float* __restrict__ ddensity, int64_t M, nsamd_density_mlp mlp, float* __restrict__ denc,
+    float* __restrict__ dW0, float* __restrict__ db0, float* __restrict__ dW1, float* __restrict__ db1,
+    float* __restrict__ partials, const uint32_t* __restrict__ gate, const uint8_t* __restrict__ ray_mask, int spr) {
+  density_mlp_bwd_body<IN, H>(enc, selector, pre, ddensity, M, mlp, denc, dW0, db0, dW1, db1, partials, gate, ray_mask, spr,
+                              (int)gridDim.x);
+}
+
+// what one call of the kernel takes (proposal_chain.h: DensityBwdCall, plus the launch's choices)
+struct DensityBwdArgs {
+  const float* enc;
+  const float* selector;
+  const float* pre;
+  const float* ddensity;
+  int64_t M;
+  nsamd_density_mlp mlp;
+  float* denc;
+  float* dW0;
+  float* db0;
+  float* dW1;
+  float* db1;
+  float* partials;
+  const uint32_t* gate;
+  const uint8_t* ray_mask;
+  int spr;
+  int nblocks;
+};
+
+// two independent calls (the two proposal levels of an update iteration) in one launch: blockIdx.y selects the call
+template <int IN, int H>
+__global__ __launch_bounds__(kMlpBlock) void density_mlp_bwd_pair_kernel(DensityBwdArgs a, DensityBwdArgs b) {
+  if (blockIdx.y == 0) {
+    if ((int)blockIdx.x >= a.nblocks) return;
+    density_mlp_bwd_body<IN, H>(a.enc, a.selector, a.pre, a.ddensity, a.M, a.mlp, a.denc, a.dW0, a.db0, a.dW1, a.db1,
+                                a.partials, a.gate, a.ray_mask, a.spr, a.nblocks);
+  } else {
+    if ((int)blockIdx.x >= b.nblocks) return;
+    density_mlp_bwd_body<IN, H>(b.enc, b.selector, b.pre, b.ddensity, b.M, b.mlp, b.denc, b.dW0, b.db0, b.dW1, b.db1,
+                                b.partials, b.gate, b.ray_mask, b.spr, b.nblocks);
+  }
+}
+
 // grads += sum over the workgroups' partial rows, in a fixed order: 64 elements x 16 row-groups per workgroup, every
 // thread has 16 loads in flight (the partials are a pure latency problem), the 16 group sums meet in LDS.
 constexpr int kDwGroups = 16;
-__global__ __launch_bounds__(64 * kDwGroups) void density_dw_reduce_kernel(const float* __restrict__ partials, int rows,
-                                                                            int stride, int n_w0, int hidden,
-                                                                            float* __restrict__ dW0,
-                                                                            float* __restrict__ db0,
-                                                                            float* __restrict__ dW1,
-                                                                            float* __restrict__ db1,
-                                                                            const uint32_t* __restrict__ gate) {
+__device__ __forceinline__ void density_dw_reduce_body(const float* __restrict__ partials, int rows, int stride, int n_w0,
+                                                       int hidden, float* __restrict__ dW0, float* __restrict__ db0,
+                                                       float* __restrict__ dW1, float* __restrict__ db1,
+                                                       const uint32_t* __restrict__ gate) {
   if (gate != nullptr && __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
   __shared__ float part[kDwGroups][64];
   const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -332,6 +377,22 @@ __global__ __launch_bounds__(64 * kDwGroups) void density_dw_reduce_kernel(const
     float* dst = e < n_w0 ? dW0 + e : (e < n_w0 + hidden ? db0 + (e - n_w0) : (e < n_w0 + 2 * hidden ? dW1 + (e - n_w0 - hidden) : db1));
     *dst += t;
   }
+}
+
+__global__ __launch_bounds__(64 * kDwGroups) void density_dw_reduce_kernel(const float* __restrict__ partials, int rows,
+                                                                            int stride, int n_w0, int hidden,
+                                                                            float* __restrict__ dW0,
+                                                                            float* __restrict__ db0,
+                                                                            float* __restrict__ dW1,
+                                                                            float* __restrict__ db1,
+                                                                            const uint32_t* __restrict__ gate) {
+  density_dw_reduce_body(partials, rows, stride, n_w0, hidden, dW0, db0, dW1, db1, gate);
+}
+
+__global__ __launch_bounds__(64 * kDwGroups) void density_dw_reduce_pair_kernel(DensityBwdArgs a, DensityBwdArgs b, int stride,
+                                                                                 int n_w0, int hidden) {
+  if (blockIdx.y == 0) density_dw_reduce_body(a.partials, a.nblocks, stride, n_w0, hidden, a.dW0, a.db0, a.dW1, a.db1, a.gate);
+  else density_dw_reduce_body(b.partials, b.nblocks, stride, n_w0, hidden, b.dW0, b.db0, b.dW1, b.db1, b.gate);
 }
 
 template <int IN, int H>
@@ -368,6 +429,46 @@ static int launch_bwd(const float* enc, const float* selector, const float* pre,
     NSAMD_CHECK_LAUNCH();
   }
   return NSAMD_OK;
+}
+
+template <int IN, int H>
+static int launch_bwd_pair(const DensityBwdCall& a, const DensityBwdCall& b, hipStream_t stream) {
+  const DensityBwdCall* c[2] = {&a, &b};
+  const size_t lds = sizeof(float) * ((size_t)(2 * H + IN + 1) * (kMlpBlock + 1) + 8 + (size_t)H * (((IN + 3) & ~3) + 2)) +
+                     kDensityActMax;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&density_mlp_bwd_pair_kernel<IN, H>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return NSAMD_ERR_LAUNCH;
+  }
+  constexpr int stride = density_partial_stride(IN, H);
+  DensityBwdArgs k[2];
+  unsigned gx = 0;
+  for (int i = 0; i < 2; ++i) {
+    const unsigned blocks = (unsigned)min((int64_t)kMaxBlocks, (c[i]->M + kMlpBlock - 1) / kMlpBlock);
+    // (the merged launch is for the training step's calls, which bring the scratch of the fixed-order reduce)
+    if (c[i]->workspace == nullptr || c[i]->workspace_floats < (int64_t)blocks * stride) return NSAMD_ERR_UNSUPPORTED;
+    k[i] = DensityBwdArgs{c[i]->enc, c[i]->selector, c[i]->pre, c[i]->ddensity, c[i]->M, c[i]->mlp, c[i]->denc, c[i]->dW0,
+                          c[i]->db0, c[i]->dW1, c[i]->db1, c[i]->workspace, c[i]->gate, c[i]->ray_mask,
+                          c[i]->ray_mask ? c[i]->spr : 1, (int)blocks};
+    gx = blocks > gx ? blocks : gx;
+  }
+  if (a.workspace == b.workspace || a.dW0 == b.dW0) return NSAMD_ERR_UNSUPPORTED;  // one network for both levels: in turn
+  density_mlp_bwd_pair_kernel<IN, H><<<dim3(gx, 2u), kMlpBlock, lds, stream>>>(k[0], k[1]);
+  NSAMD_CHECK_LAUNCH();
+  const int total = H * IN + 2 * H + 1;
+  density_dw_reduce_pair_kernel<<<dim3((total + 63) / 64, 2u), 64 * kDwGroups, 0, stream>>>(k[0], k[1], stride, H * IN, H);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+int density_bwd_launch_pair(const DensityBwdCall& a, const DensityBwdCall& b, hipStream_t stream) {
+  if (a.mlp.in_dim != b.mlp.in_dim || a.mlp.hidden != b.mlp.hidden || a.M <= 0 || b.M <= 0) return NSAMD_ERR_UNSUPPORTED;
+  if (a.mlp.in_dim == 10 && a.mlp.hidden == 16) return launch_bwd_pair<10, 16>(a, b, stream);
+  if (a.mlp.in_dim == 16 && a.mlp.hidden == 16) return launch_bwd_pair<16, 16>(a, b, stream);
+  if (a.mlp.in_dim == 10 && a.mlp.hidden == 64) return launch_bwd_pair<10, 64>(a, b, stream);
+  if (a.mlp.in_dim == 16 && a.mlp.hidden == 64) return launch_bwd_pair<16, 64>(a, b, stream);
+  return NSAMD_ERR_UNSUPPORTED;
 }
 
 }  // namespace nsamd

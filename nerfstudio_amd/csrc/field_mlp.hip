@@ -1326,6 +1326,30 @@ static int num_cus() {
   return cached;
 }
 
+// Compute units the persistent backward leaves to other streams' launches (nsamd_field_mlp_bwd_reserve_cus): its workgroups
+// own a CU's LDS and registers for the whole launch, so whatever is queued beside it otherwise waits for its end.
+static int g_bwd_reserved_cus = 0;
+
+// workgroups of a backward launch over `groups` tile groups (kCoopWaves tiles each). Reservation -1 = "one more sweep": the
+// persistent workgroups take ceil(groups / workgroups) sweeps whatever the count, so a few CUs cannot be left out for free —
+// the cheapest reservation is the one that adds exactly one sweep and spreads it evenly (1536 groups on 256 CUs: 6 sweeps of
+// 256 -> 7 sweeps of 220, 36 CUs free); only where that costs <= 25 % (>= 4 sweeps).
+static int field_bwd_workgroups(int64_t groups) {
+  const int cus = num_cus();
+  if (g_bwd_reserved_cus > 0) return cus - g_bwd_reserved_cus > 1 ? cus - g_bwd_reserved_cus : 1;
+  if (g_bwd_reserved_cus < 0) {
+    const int64_t sweeps = (groups + cus - 1) / cus;
+    if (sweeps >= 4) return (int)((groups + sweeps) / (sweeps + 1));
+  }
+  return cus;
+}
+
+extern "C" int nsamd_field_mlp_bwd_reserve_cus(int cus) {
+  const int prev = g_bwd_reserved_cus;
+  g_bwd_reserved_cus = cus < 0 ? -1 : cus;
+  return prev;
+}
+
 static int field_mlp_fwd_impl(const float* enc, const float* selector, const float* directions,
                               const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
                               nsamd_field_mlp mlp, float* density, float* rgb, nsamd_stream_t stream) {
@@ -1390,7 +1414,8 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   static const int probe_skip = getenv("NSAMD_FIELD_BWD_SKIP") ? atoi(getenv("NSAMD_FIELD_BWD_SKIP")) : 0;
-  const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + kCoopWaves - 1) / kCoopWaves);
+  const int64_t groups = (tiles + kCoopWaves - 1) / kCoopWaves;
+  const unsigned blocks = (unsigned)min((int64_t)field_bwd_workgroups(groups), groups);
   float* partials = (workspace != nullptr && workspace_floats >= (int64_t)blocks * kPartialStride) ? workspace : nullptr;
   // per-tile rows of the appearance-embedding gradient (fixed-order reduction per camera): needs every 16-point tile
   // inside one ray and room behind the weight-gradient partials; otherwise float atomics (sums in no fixed order)

@@ -10,6 +10,7 @@
 // Layout: 4 rays per 256-thread workgroup (N = 4096 -> 1024 workgroups); rows are read/written coalesced.
 #include <stdlib.h>
 
+#include "proposal_chain.h"
 #include "ray_bodies.h"
 
 NSAMD_PROBE_DEFINE(sampler)
@@ -115,6 +116,17 @@ __global__ __launch_bounds__(kThreads) void weights_bwd_kernel(const float* __re
   weights_bwd_body(lds + (size_t)wave_index() * 3 * S, t_bins, density, dweights, num_rays, S, ddensity, gate_out, ray_mask);
 }
 
+// two levels' weights backward in one launch (proposal_chain.h): blockIdx.y selects the call, each with its own sample count
+__global__ __launch_bounds__(kThreads) void weights_bwd_pair_kernel(WeightsBwdCall a, WeightsBwdCall b) {
+  extern __shared__ float lds[];
+  if (blockIdx.y == 0)
+    weights_bwd_body(lds + (size_t)wave_index() * 3 * a.S, a.t_bins, a.density, a.dweights, a.num_rays, a.S, a.ddensity, a.gate,
+                     a.ray_mask);
+  else
+    weights_bwd_body(lds + (size_t)wave_index() * 3 * b.S, b.t_bins, b.density, b.dweights, b.num_rays, b.S, b.ddensity, b.gate,
+                     b.ray_mask);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // PDFSampler.generate_ray_samples (ray_samplers.py:276-372)
 // ---------------------------------------------------------------------------------------------------------------
@@ -205,6 +217,20 @@ static int weights_bwd_launch(const float* t_bins, const float* density, const f
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }
+
+namespace nsamd {
+int weights_bwd_launch_pair(const WeightsBwdCall& a, const WeightsBwdCall& b, hipStream_t stream) {
+  // (the gates are cleared by the caller)
+  if (a.num_rays <= 0 || b.num_rays <= 0 || a.S <= 0 || b.S <= 0 || a.S > 1024 || b.S > 1024) return NSAMD_ERR_UNSUPPORTED;
+  if (!(a.t_bins && a.density && a.dweights && a.ddensity && b.t_bins && b.density && b.dweights && b.ddensity))
+    return NSAMD_ERR_INVALID_ARG;
+  const int64_t rays = a.num_rays > b.num_rays ? a.num_rays : b.num_rays;
+  const size_t lds = sizeof(float) * 3 * kWaves * (size_t)(a.S > b.S ? a.S : b.S);
+  weights_bwd_pair_kernel<<<dim3(ray_blocks(rays), 2u), kThreads, lds, stream>>>(a, b);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+}  // namespace nsamd
 
 extern "C" int nsamd_weights_bwd(const float* t_bins, const float* density, const float* dweights,
                                  int64_t num_rays, int32_t S, float* ddensity, nsamd_stream_t stream) {

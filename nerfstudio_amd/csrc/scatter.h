@@ -222,4 +222,24 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
                    const ScatterPlan& plan, bool overwrite, const uint32_t* gate, const uint8_t* ray_mask,
                    hipStream_t stream);
 
+// Host: TWO independent calls (different tables, workspaces and gradients) with their route, apply and finish passes merged
+// pairwise into one launch each. NSAMD_ERR_UNSUPPORTED (nothing enqueued): the calls cannot be merged — the caller issues
+// scatter_launch for each.
+struct ScatterCall {
+  nsamd_points pts;
+  int64_t M;
+  int transform;
+  nsamd_aabb aabb;
+  nsamd_grid grid;
+  const float* denc;
+  int64_t stride_p, stride_k;
+  float* dtable;
+  float* workspace;
+  ScatterPlan plan;
+  bool overwrite;
+  const uint32_t* gate;
+  const uint8_t* ray_mask;
+};
+int scatter_launch_pair(const ScatterCall& a, const ScatterCall& b, hipStream_t stream);
+
 }  // namespace nsamd

@@ -233,10 +233,10 @@ __global__ __launch_bounds__(kThreads) void scatter_route_fine_kernel(
 // (value pair + local index). Sweep 0 counts per tile, the workgroup reserves its share of every tile's queue with one
 // returning atomic, sweep 1 recomputes the runs and stores — nothing is kept in registers or LDS between the sweeps.
 template <int kLevels>
-__global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
-    nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
-    int64_t stride_p, int64_t stride_k, ScatterGeom G, LevelList levels, ScatterBufs buf,
-    const uint32_t* __restrict__ gate, const uint8_t* __restrict__ ray_mask) {
+__device__ __forceinline__ void scatter_route_runs_body(
+    const nsamd_points& P, int64_t M, int transform, const nsamd_aabb& box, const nsamd_grid& grid,
+    const float* __restrict__ denc, int64_t stride_p, int64_t stride_k, const ScatterGeom& G, const LevelList& levels,
+    const ScatterBufs& buf, const uint32_t* __restrict__ gate, const uint8_t* __restrict__ ray_mask) {
   if (gate_is_clear(gate)) return;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   const int B = 1 << G.log2_bins;
@@ -433,14 +433,55 @@ __global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
   PROBE_STAMP(0, 24);
 }
 
+template <int kLevels>
+__global__ __launch_bounds__(kRunThreads) void scatter_route_runs_kernel(
+    nsamd_points P, int64_t M, int transform, nsamd_aabb box, nsamd_grid grid, const float* __restrict__ denc,
+    int64_t stride_p, int64_t stride_k, ScatterGeom G, LevelList levels, ScatterBufs buf,
+    const uint32_t* __restrict__ gate, const uint8_t* __restrict__ ray_mask) {
+  scatter_route_runs_body<kLevels>(P, M, transform, box, grid, denc, stride_p, stride_k, G, levels, buf, gate, ray_mask);
+}
+
+// TWO independent scatters in one launch (the two proposal levels' table gradients on an update iteration: each of these
+// kernels is as long as its slowest workgroup's chain of round trips, not as its work — side by side they cost one such chain).
+// blockIdx.z selects the call; a call's own grid is a corner of the launch's.
+struct RunsCall {
+  nsamd_points P;
+  int64_t M;
+  int transform;
+  nsamd_aabb box;
+  nsamd_grid grid;
+  const float* denc;
+  int64_t stride_p, stride_k;
+  ScatterGeom G;
+  LevelList levels;
+  ScatterBufs buf;
+  const uint32_t* gate;
+  const uint8_t* ray_mask;
+  uint32_t grid_x, grid_y;
+};
+
+template <int kLevels>
+__global__ __launch_bounds__(kRunThreads) void scatter_route_runs_pair_kernel(RunsCall a, RunsCall b) {
+  if (blockIdx.z == 0) {
+    if (blockIdx.x >= a.grid_x || blockIdx.y >= a.grid_y) return;
+    scatter_route_runs_body<kLevels>(a.P, a.M, a.transform, a.box, a.grid, a.denc, a.stride_p, a.stride_k, a.G, a.levels, a.buf,
+                                     a.gate, a.ray_mask);
+  } else {
+    if (blockIdx.x >= b.grid_x || blockIdx.y >= b.grid_y) return;
+    scatter_route_runs_body<kLevels>(b.P, b.M, b.transform, b.box, b.grid, b.denc, b.stride_p, b.stride_k, b.G, b.levels, b.buf,
+                                     b.gate, b.ray_mask);
+  }
+}
+
 // ---- pass 2 ------------------------------------------------------------------------------------------------------
 // One workgroup per (level, tile): static segments, dynamic area and the folded part of the spill list are summed into
 // an LDS tile of 2 x int64 per entry; the finished tile is converted once and stored / added with coalesced accesses.
 // kRider: the launch carries the main field's weight-gradient reduce along (its own instantiation: the rider's registers —
 // 118 against 83 — must not cost the small-tile launches of the proposal levels their occupancy).
 template <bool kRider>
-__global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs buf, float* __restrict__ dtable,
-                                     int overwrite, const uint32_t* __restrict__ gate, ReduceRider rider) {
+__device__ __forceinline__ void scatter_apply_body(const nsamd_grid& grid, const ScatterGeom& G, const ScatterBufs& buf,
+                                                   float* __restrict__ dtable, int overwrite,
+                                                   const uint32_t* __restrict__ gate, const ReduceRider& rider) {
   if (gate_is_clear(gate)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];  // [entries][2]
   if (kRider && (int)blockIdx.y >= G.num_levels) {
@@ -623,10 +664,36 @@ __global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs
   PROBE_STAMP(0, 16);
 }
 
+template <bool kRider>
+__global__ void scatter_apply_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs buf, float* __restrict__ dtable,
+                                     int overwrite, const uint32_t* __restrict__ gate, ReduceRider rider) {
+  scatter_apply_body<kRider>(grid, G, buf, dtable, overwrite, gate, rider);
+}
+
+struct ApplyCall {
+  nsamd_grid grid;
+  ScatterGeom G;
+  ScatterBufs buf;
+  float* dtable;
+  int overwrite;
+  const uint32_t* gate;
+};
+
+// two calls' pass 2 in one launch (see scatter_route_runs_pair_kernel); both with the same workgroup size and LDS tile
+__global__ void scatter_apply_pair_kernel(ApplyCall a, ApplyCall b) {
+  if (blockIdx.z == 0) {
+    if (blockIdx.x >= (1u << a.G.log2_bins) || (int)blockIdx.y >= a.G.num_levels) return;
+    scatter_apply_body<false>(a.grid, a.G, a.buf, a.dtable, a.overwrite, a.gate, ReduceRider{});
+  } else {
+    if (blockIdx.x >= (1u << b.G.log2_bins) || (int)blockIdx.y >= b.G.num_levels) return;
+    scatter_apply_body<false>(b.grid, b.G, b.buf, b.dtable, b.overwrite, b.gate, ReduceRider{});
+  }
+}
+
 // After pass 2: spill records beyond the folded prefix (a pathological batch) are applied with float atomics — exact
 // sums, but in no fixed order, so they are counted; then the per-call header state goes back to zero.
-__global__ void scatter_finish_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs buf, float* __restrict__ dtable,
-                                      const uint32_t* __restrict__ gate) {
+__device__ __forceinline__ void scatter_finish_body(const nsamd_grid& grid, const ScatterGeom& G, const ScatterBufs& buf,
+                                                    float* __restrict__ dtable, const uint32_t* __restrict__ gate) {
   if (gate_is_clear(gate)) return;  // nothing was routed: the per-call state is still zero
   const uint32_t total = buf.hdr[kHdrSpillCount];  // (may exceed the capacity: the excess went out directly)
   const uint32_t n = min(total, G.spill_cap);
@@ -661,6 +728,16 @@ __global__ void scatter_finish_kernel(nsamd_grid grid, ScatterGeom G, ScatterBuf
     buf.hdr[kHdrSpillCount] = 0u;
     buf.hdr[kHdrTicket] = 0u;
   }
+}
+
+__global__ void scatter_finish_kernel(nsamd_grid grid, ScatterGeom G, ScatterBufs buf, float* __restrict__ dtable,
+                                      const uint32_t* __restrict__ gate) {
+  scatter_finish_body(grid, G, buf, dtable, gate);
+}
+
+__global__ void scatter_finish_pair_kernel(ApplyCall a, ApplyCall b) {  // (same grid for both calls)
+  if (blockIdx.z == 0) scatter_finish_body(a.grid, a.G, a.buf, a.dtable, a.gate);
+  else scatter_finish_body(b.grid, b.G, b.buf, b.dtable, b.gate);
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------
@@ -828,6 +905,8 @@ static int apply_lds_attribute() {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_apply_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16u << kSliceLog2Max)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_apply_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16u << kSliceLog2Max)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&scatter_apply_pair_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16u << kSliceLog2Max)) != hipSuccess)
       return NSAMD_ERR_LAUNCH;
     if (dev >= 0 && dev < 64) attr_done[dev] = true;
@@ -901,6 +980,37 @@ static void launch_fine(const nsamd_points& pts, int64_t M, int transform, const
                                                                                  stride_p, stride_k, G, fine, buf, gate, ray_mask);
 }
 
+// Which levels of a call go through the run-merging kernel (coarse) and which through the plain route (fine); sets G.coarse_mask.
+static void classify_levels(const nsamd_points& pts, const nsamd_grid& grid, ScatterGeom& G, LevelList& coarse,
+                            LevelList& fine) {
+  static const int combine_env = env_int("NSAMD_SCATTER_COMBINE_RES", 0);
+  float coarse_below = 0.0f;
+  // Round 6 (profiles/r06_s12_*, r06_s14_*): since the run kernel and the apply pass on non-empty segments (rounds 3 - 5) the
+  // 96-sample level is cheaper merged as well — its route + apply read 40 + 37 us plain against 35 + 9 us for the 2.7 x larger
+  // 256-sample level merged; all five of its levels through the run kernel: long run 0.6919 / 0.6883 against 0.6971 / 0.6959 ms
+  // from step 40, window 0.657 / 0.658 against 0.667 / 0.667 from step 0 (NSAMD_SCATTER_MERGE_96=0: the plain route, A/B).
+  static const int merge96 = env_int("NSAMD_SCATTER_MERGE_96", 1);
+  if (pts.positions == nullptr && pts.samples_per_ray >= (merge96 ? 96 : 192))
+    coarse_below = pts.samples_per_ray >= 192 ? (float)pts.samples_per_ray : 1e30f;
+  if (combine_env > 0) coarse_below = (float)combine_env;
+  for (int l = 0; l < grid.num_levels; ++l) {
+    if (grid.scalings[l] < coarse_below) {
+      G.coarse_mask |= 1u << l;
+      coarse.level[coarse.count++] = (int8_t)l;
+    } else {
+      fine.level[fine.count++] = (int8_t)l;
+    }
+  }
+}
+
+// levels per thread of the run kernel (NSAMD_RUNS_LEVELS = 1 / 2 / 4, read once): fewer levels per thread = more, shorter
+// workgroups — its time is the latency of one workgroup's two sweeps (profiles/r03_sparse_regime_kernel_stats.csv)
+// (MI355X, driver window of the bench: 4 -> 75 us, 2 -> 54, 1 -> 54 per launch of the 256-sample level's scatter)
+static int runs_levels_setting() {
+  static const int runs_levels = env_int("NSAMD_RUNS_LEVELS", 2);
+  return runs_levels == 1 || runs_levels == 2 ? runs_levels : 4;
+}
+
 int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsamd_aabb& aabb, const nsamd_grid& grid,
                    const float* denc, int64_t stride_p, int64_t stride_k, float* dtable, float* workspace,
                    const ScatterPlan& plan, bool overwrite, const uint32_t* gate, const uint8_t* ray_mask, hipStream_t st) {
@@ -915,25 +1025,8 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
   // merging pays (75 vs 107 us at M = 1 M); with 96 or 48 samples per ray the plain route is faster on every level
   // (65 vs 88 us, 178 vs 197 us for the main table; profiles/r02a_*). NSAMD_SCATTER_COMBINE_RES > 0 overrides the
   // threshold: levels with resolution below it are merged (1 = none).
-  static const int combine_env = env_int("NSAMD_SCATTER_COMBINE_RES", 0);
-  float coarse_below = 0.0f;
-  // Round 6 (profiles/r06_s12_*, r06_s14_*): since the run kernel and the apply pass on non-empty segments (rounds 3 - 5) the
-  // 96-sample level is cheaper merged as well — its route + apply read 40 + 37 us plain against 35 + 9 us for the 2.7 x larger
-  // 256-sample level merged; all five of its levels through the run kernel: long run 0.6919 / 0.6883 against 0.6971 / 0.6959 ms
-  // from step 40, window 0.657 / 0.658 against 0.667 / 0.667 from step 0 (NSAMD_SCATTER_MERGE_96=0: the plain route, A/B).
-  static const int merge96 = env_int("NSAMD_SCATTER_MERGE_96", 1);
-  if (pts.positions == nullptr && pts.samples_per_ray >= (merge96 ? 96 : 192))
-    coarse_below = pts.samples_per_ray >= 192 ? (float)pts.samples_per_ray : 1e30f;
-  if (combine_env > 0) coarse_below = (float)combine_env;
   LevelList coarse{}, fine{};
-  for (int l = 0; l < grid.num_levels; ++l) {
-    if (grid.scalings[l] < coarse_below) {
-      G.coarse_mask |= 1u << l;
-      coarse.level[coarse.count++] = (int8_t)l;
-    } else {
-      fine.level[fine.count++] = (int8_t)l;
-    }
-  }
+  classify_levels(pts, grid, G, coarse, fine);
   {
     const int rc = apply_lds_attribute();
     if (rc) return rc;
@@ -949,10 +1042,7 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
     NSAMD_CHECK_LAUNCH();
   }
   if (coarse.count > 0) {
-    // levels per thread of the run kernel (NSAMD_RUNS_LEVELS = 1 / 2 / 4, read once): fewer levels per thread = more, shorter
-    // workgroups — its time is the latency of one workgroup's two sweeps (profiles/r03_sparse_regime_kernel_stats.csv)
-    // (MI355X, driver window of the bench: 4 -> 75 us, 2 -> 54, 1 -> 54 per launch of the 256-sample level's scatter)
-    static const int runs_levels = env_int("NSAMD_RUNS_LEVELS", 2);
+    const int runs_levels = runs_levels_setting();
     const int64_t per_block = (int64_t)kRunThreads * kRunLen;
     auto launch_runs = [&](auto tag) {
       constexpr int kL = decltype(tag)::value;
@@ -972,6 +1062,72 @@ int scatter_launch(const nsamd_points& pts, int64_t M, int transform, const nsam
                                                                                ReduceRider{});
   NSAMD_CHECK_LAUNCH();
   scatter_finish_kernel<<<32, 256, 0, st>>>(grid, G, buf, dtable, gate);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
+int scatter_launch_pair(const ScatterCall& a, const ScatterCall& b, hipStream_t st) {
+  const ScatterCall* c[2] = {&a, &b};
+  ScatterGeom G[2];
+  ScatterBufs buf[2];
+  LevelList coarse[2], fine[2];
+  for (int i = 0; i < 2; ++i) {
+    if (c[i]->gate != nullptr && c[i]->overwrite) return NSAMD_ERR_INVALID_ARG;
+    if (c[i]->ray_mask != nullptr && (c[i]->gate == nullptr || c[i]->pts.positions != nullptr)) return NSAMD_ERR_INVALID_ARG;
+    if (!c[i]->plan.ok || c[i]->M <= 0) return NSAMD_ERR_UNSUPPORTED;
+    G[i] = c[i]->plan.geom;
+    buf[i] = scatter_bufs(c[i]->workspace, c[i]->plan);
+    buf[i].log2_table_size = c[i]->grid.log2_table_size;
+    if (!c[i]->overwrite) buf[i].direct_table = c[i]->dtable;
+    coarse[i] = LevelList{};
+    fine[i] = LevelList{};
+    classify_levels(c[i]->pts, c[i]->grid, G[i], coarse[i], fine[i]);
+    // only calls that route every level through the run kernel are merged (the proposal levels of nerfacto: 256 and 96
+    // samples per ray on small grids); anything else goes through scatter_launch, call by call
+    if (fine[i].count != 0 || coarse[i].count == 0) return NSAMD_ERR_UNSUPPORTED;
+  }
+  if (a.workspace == b.workspace || a.dtable == b.dtable) return NSAMD_ERR_UNSUPPORTED;  // shared state: one after the other
+  const unsigned threads = apply_threads(G[0].slice_log2);
+  if (threads != apply_threads(G[1].slice_log2)) return NSAMD_ERR_UNSUPPORTED;
+  {
+    const int rc = apply_lds_attribute();
+    if (rc) return rc;
+  }
+  const int64_t per_block = (int64_t)kRunThreads * kRunLen;
+  auto launch_runs = [&](auto tag) {
+    constexpr int kL = decltype(tag)::value;
+    RunsCall rc[2];
+    size_t lds = 0;
+    unsigned gx = 0, gy = 0;
+    for (int i = 0; i < 2; ++i) {
+      rc[i] = RunsCall{c[i]->pts, c[i]->M, c[i]->transform, c[i]->aabb, c[i]->grid, c[i]->denc, c[i]->stride_p, c[i]->stride_k,
+                       G[i], coarse[i], buf[i], c[i]->gate, c[i]->ray_mask,
+                       (uint32_t)((c[i]->M + per_block - 1) / per_block), (uint32_t)((coarse[i].count + kL - 1) / kL)};
+      const size_t l = sizeof(uint32_t) * (3 * (size_t)kL * ((size_t)1 << G[i].log2_bins) + kL);
+      lds = l > lds ? l : lds;
+      gx = rc[i].grid_x > gx ? rc[i].grid_x : gx;
+      gy = rc[i].grid_y > gy ? rc[i].grid_y : gy;
+    }
+    scatter_route_runs_pair_kernel<kL><<<dim3(gx, gy, 2u), kRunThreads, lds, st>>>(rc[0], rc[1]);
+  };
+  const int runs_levels = runs_levels_setting();
+  if (runs_levels == 1) launch_runs(std::integral_constant<int, 1>{});
+  else if (runs_levels == 2) launch_runs(std::integral_constant<int, 2>{});
+  else launch_runs(std::integral_constant<int, 4>{});
+  NSAMD_CHECK_LAUNCH();
+  ApplyCall ac[2];
+  unsigned bins = 0, levels = 0;
+  size_t lds = 0;
+  for (int i = 0; i < 2; ++i) {
+    ac[i] = ApplyCall{c[i]->grid, G[i], buf[i], c[i]->dtable, c[i]->overwrite ? 1 : 0, c[i]->gate};
+    bins = (1u << G[i].log2_bins) > bins ? (1u << G[i].log2_bins) : bins;
+    levels = (unsigned)c[i]->grid.num_levels > levels ? (unsigned)c[i]->grid.num_levels : levels;
+    const size_t l = (size_t)16 << G[i].slice_log2;
+    lds = l > lds ? l : lds;
+  }
+  scatter_apply_pair_kernel<<<dim3(bins, levels, 2u), threads, lds, st>>>(ac[0], ac[1]);
+  NSAMD_CHECK_LAUNCH();
+  scatter_finish_pair_kernel<<<dim3(32u, 1u, 2u), 256, 0, st>>>(ac[0], ac[1]);
   NSAMD_CHECK_LAUNCH();
   return NSAMD_OK;
 }

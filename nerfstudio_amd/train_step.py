@@ -132,6 +132,13 @@ class NerfactoTrainStep:
         self.fuse_route = os.environ.get("NSAMD_FUSE_ROUTE", "1") == "1"
         self.keep_denc = False  # True: the fused launch also stores the encoded-feature gradient in `f_denc` (tests read it)
         self.prop_mlp_inline = os.environ.get("NSAMD_PROP_MLP_INLINE", "0") == "1"
+        # compute units the persistent main backward leaves to the proposal chains on the iterations that run them
+        # (0, the default: none; -1: one more sweep of the persistent workgroups, 36 of 256 CUs at 196 608 points; n: n CUs.
+        #  Measured round 6, profiles/r06_s22_*, r06_s27_*: -0.5 % window / -0.7 % long run for a field backward that is 16 %
+        #  longer on those iterations — opt-in)
+        self.bwd_reserve_cus = int(os.environ.get("NSAMD_BWD_RESERVE_CUS", "0"))
+        # the same stage of the proposal levels' backward chains as one launch across the levels (0: level by level, A/B)
+        self.merge_prop_levels = os.environ.get("NSAMD_MERGE_PROP_LEVELS", "1") == "1"
         # the iteration's loss values and training metrics, written by the losses launch's finishing pass (nsamd.h):
         # rgb_loss, interlevel_loss, distortion_loss, psnr, distortion, sum of the three losses
         self.loss_vals = torch.zeros(32, **f32)  # (8 results + the finishing pass's scratch: partial sums, ticket)
@@ -321,9 +328,10 @@ class NerfactoTrainStep:
                 with torch.cuda.stream(stream):
                     self.backward_proposals(levels=levels, stage=side_stage)
                     join.record(stream)
-            self.backward_main()
+            self.backward_main(reserve=True)
         else:
-            self.backward_main()
+            # (the reservation follows the KIND of iteration, not the streams: every schedule sums the same partials)
+            self.backward_main(reserve=updated)
             if updated:
                 self.backward_proposals()
 
@@ -340,7 +348,7 @@ class NerfactoTrainStep:
         parallelism the all-reduce of the main-field gradients can start right after this while `backward_proposals`
         (interlevel-loss gradients of the proposal networks) still runs."""
         self.forward_and_losses(updated, draw_jitter)
-        self.backward_main()
+        self.backward_main(reserve=updated)
 
     def written_params(self):
         """Parameters whose gradient this runner WRITES (hash tables, nsamd_hashgrid_encode_bwd_set): callers need not
@@ -575,9 +583,18 @@ class NerfactoTrainStep:
             self._loss_vals_fresh = True
 
     @profiler.time_function
-    def backward_main(self, field: bool = True) -> None:
+    def backward_main(self, field: bool = True, reserve: bool = False) -> None:
         """composite -> weights -> field MLPs -> main hash table (MSE + distortion gradients). `field=False`: stop before
-        the field's MLPs (the caller runs `backward_field_and_table`)."""
+        the field's MLPs (the caller runs `backward_field_and_table`). `reserve`: an iteration that also runs the proposal
+        levels' backward chains — the persistent field backward leaves `bwd_reserve_cus` compute units to them."""
+        if reserve and field and self.bwd_reserve_cus != 0:
+            lib = N.load()
+            prev = lib.nsamd_field_mlp_bwd_reserve_cus(self.bwd_reserve_cus)
+            try:
+                self.backward_main(field=True)
+            finally:
+                lib.nsamd_field_mlp_bwd_reserve_cus(prev)
+            return
         lib, st, n = N.load(), N.stream(), self.n
         ck = N.check
         L = self.n_prop
@@ -632,6 +649,11 @@ class NerfactoTrainStep:
                         self._red_join.record(self.reduce_stream)
                     ck(lib.nsamd_field_mlp_bwd_scatter_phase(*args, 4, st), "field_mlp_bwd_scatter_phase")
                     main.wait_event(self._red_join)
+                elif os.environ.get("NSAMD_DIAG_SKIP_DW_REDUCE") == "1":
+                    # timing diagnostic only (wrong training): no weight-gradient reduce at all — what the iteration would cost
+                    # if the reduce were free
+                    for phase in (1, 4):
+                        ck(lib.nsamd_field_mlp_bwd_scatter_phase(*args, phase, st), "field_mlp_bwd_scatter_phase")
                 else:
                     ck(lib.nsamd_field_mlp_bwd_scatter(*args, st), "field_mlp_bwd_scatter")
                 if self.cam_opt is not None:
@@ -704,8 +726,16 @@ class NerfactoTrainStep:
         lib, st, n = N.load(), N.stream(), self.n
         ck = N.check
         do_mlp, do_scatter = stage in ("all", "mlp"), stage in ("all", "scatter")
+        lvls = list(range(self.n_prop) if levels is None else levels)
+        if (self.merge_prop_levels and stage == "all" and len(lvls) >= 2 and self.gate_proposals and self.cam_opt is None
+                and N.PROFILE is None):
+            # every stage of the levels' chains as ONE launch across the levels (nsamd_proposal_levels_bwd; same bits)
+            arr = self._proposal_level_structs(lvls)
+            if arr is not None:
+                ck(lib.nsamd_proposal_levels_bwd(arr, len(lvls), int(self.gates_precleared), st), "proposal_levels_bwd")
+                return
         for _ in (0,):
-            for lvl in (range(self.n_prop) if levels is None else levels):
+            for lvl in lvls:
                 net = self.props[lvl]
                 S, m = self.counts[lvl], n * self.counts[lvl]
                 mlp = net.mlp_base[1]
@@ -750,6 +780,37 @@ class NerfactoTrainStep:
                                                            N.ptr(self.p_denc[lvl]), 1, m,
                                                            N.ptr(self._grad(net.encoding.hash_table)), N.ptr(ws), ws_n, gate,
                                                            mask, st), "hashgrid_encode_bwd_gated")
+
+    def _proposal_level_structs(self, lvls):
+        """ctypes array of nsamd_proposal_level_bwd for `lvls` (None: a level without a binned-scatter workspace). The structs
+        hold raw addresses of this runner's static buffers and of the parameters / gradients, which do not move."""
+        arr = (N.ProposalLevelBwd * len(lvls))()
+        n = self.n
+        for i, lvl in enumerate(lvls):
+            net = self.props[lvl]
+            S, m = self.counts[lvl], n * self.counts[lvl]
+            W0, b0, W1, b1 = net.mlp_base[1].param_tensors()
+            spec = net.encoding.spec
+            ws, ws_n = F._scatter_workspace(spec, self.f_enc.device, m)
+            if ws is None:
+                return None
+            dws = self.density_ws[lvl]
+            e = arr[i]
+            e.num_rays, e.samples_per_ray = n, S
+            e.t_bins, e.density, e.dweights = N.ptr(self.t_bins[lvl]), N.ptr(self.p_dens[lvl]), N.ptr(self.dw_prop[lvl])
+            e.ddensity, e.gate, e.ray_mask = N.ptr(self.p_ddens[lvl]), self._gate(lvl), N.ptr(self.prop_ray_masks[lvl])
+            e.enc, e.selector, e.pre = N.ptr(self.p_enc[lvl]), N.ptr(self.p_sel[lvl]), N.ptr(self.p_pre[lvl])
+            e.mlp = N.DensityMlp(N.ptr(W0), N.ptr(b0), N.ptr(W1), N.ptr(b1), W0.shape[1], W0.shape[0],
+                                 float(net.average_init_density))
+            e.denc = N.ptr(self.p_denc[lvl])
+            e.dW0, e.db0, e.dW1, e.db1 = (N.ptr(self._grad(t)) for t in (W0, b0, W1, b1))
+            e.mlp_workspace, e.mlp_workspace_floats = N.ptr(dws), dws.numel()
+            e.origins, e.directions = N.ptr(self.origins), N.ptr(self.directions)
+            e.transform, e.aabb = net._transform, net._box
+            e.table, e.grid = N.ptr(net.encoding.hash_table), spec.native()
+            e.dtable = N.ptr(self._grad(net.encoding.hash_table))
+            e.scatter_workspace, e.scatter_workspace_floats = N.ptr(ws), ws_n
+        return arr
 
     # -------------------------------------------------------------------------------------------------------------
     def loss_dict(self) -> Dict[str, Tensor]:

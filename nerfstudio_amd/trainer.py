@@ -575,7 +575,7 @@ class HipTrainer:
                 if name[1]:
                     self._clear_gates()
                 r.forward_main_and_losses(name[1])
-                r.backward_main()
+                r.backward_main(reserve=name[1])
         elif name == "pbwd":
             if self.dp_fork:
                 r.backward_join(True)

@@ -27,7 +27,7 @@ model = bench.build_model(device, seed=0)
 arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
 rb, batch, pool = bench.synthetic_batch(device, seed=1000, workload="bounded")
 trainer = bench.Trainer(model, arena, rb, batch, world=1, use_graph=False, use_runner=True, pool=pool)
-for _ in range(14):
+for _ in range(int(os.environ.get("PROBE_STEPS", "14"))):
     trainer.train_iteration()
 while not model.proposal_sampler.updated_this_step():
     trainer.train_iteration()

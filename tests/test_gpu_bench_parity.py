@@ -343,6 +343,62 @@ def test_gated_proposal_chain_equals_ungated(F, case):
             assert bool(torch.isnan(g_grad).any()), "a NaN density must reach the gradients as it does in autograd"
 
 
+@pytest.mark.parametrize("live", [0.03, 0.4, 1.0])
+def test_merged_proposal_levels_backward_equals_level_by_level(F, live):
+    """nsamd_proposal_levels_bwd (every stage of the two proposal levels' backward chains as one launch across the levels)
+    against the per-level gated entry points, bit for bit: weight gradients, table gradients, feature and density gradients,
+    flags and ray masks — with 3 %, 40 % and all of the rays carrying interlevel gradient (different rays per level)."""
+    from test_gpu_kernels import _hip_model, small_cfg
+
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.train_step import NerfactoTrainStep
+
+    cfg = small_cfg(12, 10, 6)
+    n = 1500
+    o, d, cam, tgt = orc.synthetic_rays(n, cfg.num_images, seed=11)
+    rs = np.random.RandomState(4)
+    jit = torch.from_numpy(rs.uniform(0, 1, (3, n)).astype(np.float32)).cuda()
+    results = []
+    for merged in (True, False):
+        F._SCATTER_WS.clear()
+        model = _hip_model(cfg, orc.init_params(cfg, seed=7, table_std=0.4))
+        arena = ParamArena(model.get_param_groups_ordered())
+        step = NerfactoTrainStep(model, n, torch.device("cuda"))
+        assert step.gate_proposals
+        step.merge_prop_levels = merged
+        step.side_stream = None
+        step.set_batch(o.cuda(), d.cuda(), cam.cuda(), tgt.cuda())
+        step.jitter.copy_(jit)
+        step.anneal_dev.fill_(1.0)
+        arena.zero_grad()
+        step.forward_and_losses(True, draw_jitter=False)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        for lvl in range(step.n_prop):
+            S_l = step.counts[lvl]
+            dw = torch.randn(n, S_l, device="cuda", generator=g) * 1e-3
+            keep = torch.rand(n, device="cuda", generator=g) < live
+            step.dw_prop[lvl].copy_((dw * keep[:, None]).view_as(step.dw_prop[lvl]))
+            step.p_denc[lvl].fill_(123.0)
+        for _ in range(2):  # twice: the workspaces' self-cleaning state must serve the next call
+            arena.zero_grad(["proposal_networks"])
+            if step.gates_precleared:
+                step.prop_gates.zero_()
+            step.backward_proposals()
+        torch.cuda.synchronize()
+        a, b = arena.groups["proposal_networks"]
+        results.append((arena.grad[a:b].clone(), [t.clone() for t in step.p_denc], [t.clone() for t in step.p_ddens],
+                        step.prop_gates.clone(), [t.clone() for t in step.prop_ray_masks]))
+    (m_grad, m_denc, m_ddens, m_flags, m_masks), (s_grad, s_denc, s_ddens, s_flags, s_masks) = results
+    assert float(m_grad.abs().max()) > 0.0
+    assert torch.equal(m_grad.view(torch.int32), s_grad.view(torch.int32)), \
+        f"{int((m_grad.view(torch.int32) != s_grad.view(torch.int32)).sum())} gradient words differ"
+    assert torch.equal(m_flags, s_flags)
+    for lvl in range(2):
+        assert torch.equal(m_masks[lvl], s_masks[lvl]) and int(m_masks[lvl].sum()) > 0
+        assert torch.equal(m_ddens[lvl].view(torch.int32), s_ddens[lvl].view(torch.int32))
+        assert torch.equal(m_denc[lvl].view(torch.int32), s_denc[lvl].view(torch.int32))
+
+
 def test_field_mlp_backward_at_bench_size_vs_float64(F):
     """The main-field MLP kernels alone at M = 196 608 (4096 rays x 48), fed the training step's own buffers (encoded
     features, selector, directions, camera ids, upstream dL/d density and dL/d rgb): every weight gradient, the
@@ -485,3 +541,58 @@ def test_backward_that_emits_the_scatter_records_equals_the_two_launches(F, init
         assert ev[1] == 0 and ev[2] == 0, f"scatter records on an unordered path / lost: {key[3]} {ev}"
     spilled = {k[3]: F.scatter_events(ws)[0] for k, ws in F._SCATTER_WS.items()}
     print(f"\nfused route [{init}]: worst table-gradient difference {worst:.2e} of a level's maximum; spilled records {spilled}")
+
+
+def test_field_backward_with_compute_units_left_free_gives_the_same_gradients(F):
+    """nsamd_field_mlp_bwd_reserve_cus: the persistent field backward on fewer workgroups (update iterations leave compute
+    units to the proposal levels' chains; -1 = one more sweep: 220 workgroups at 196 608 points, 36 = the same here, 100 = an
+    uneven last sweep). The table gradient's fixed-point sums do not depend on who emitted a record — bit-equal up to the
+    headroom the queue capacity sets (<= 1e-6 of the level's largest entry) —, the MLP weight gradients are the same partial
+    sums added in another fixed order (<= 1e-6 relative L2), and a repeated call gives the same bits."""
+    from test_gpu_kernels import _hip_model
+
+    from nerfstudio_amd.arena import ParamArena
+    from nerfstudio_amd.train_step import NerfactoTrainStep
+    import bench
+
+    cfg = orc.NerfactoCfg()
+    params = orc.init_params(cfg, seed=0, table_std=0.3)
+    F._SCATTER_WS.clear()
+    dev = torch.device("cuda")
+    model = _hip_model(cfg, params)
+    arena = ParamArena(model.get_param_groups_ordered(), lr=1e-2, eps=1e-15)
+    n = bench.RAYS_PER_GPU
+    o, d, cam, tgt = (torch.from_numpy(a).to(dev) for a in bench.synthetic_rays(1003))
+    r = NerfactoTrainStep(model, n, dev)
+    r.side_stream = None
+    r.set_batch(o, d, cam[:, 0], tgt)
+    r.jitter.copy_(torch.from_numpy(np.random.RandomState(4).uniform(0, 1, (3, n)).astype(np.float32)))
+    r.forward_and_losses(False, draw_jitter=False)
+    a, b = arena.groups["fields"]
+    table = model.field.mlp_base.encoding.hash_table
+    off = next(o_ for p_, o_ in zip(arena.params, arena.offsets) if p_ is table)
+    lo, hi = off - a, off - a + table.numel()
+    out = {}
+    for mode in (0, -1, 36, 100, "again"):
+        r.bwd_reserve_cus = -1 if mode == "again" else mode
+        arena.zero_grad(["fields"])
+        arena.grad[off:off + table.numel()].fill_(float("nan"))
+        r.backward_main(reserve=True)
+        torch.cuda.synchronize()
+        out[mode] = arena.grad[a:b].clone()
+    from nerfstudio_amd import _native as N
+
+    assert N.load().nsamd_field_mlp_bwd_reserve_cus(0) == 0, "the reservation must not outlive the call"
+    ref = out[0]
+    assert not torch.isnan(ref).any() and float(ref.abs().max()) > 0
+    assert torch.equal(out[-1], out["again"]) and torch.equal(out[-1], out[36])
+    T = 1 << 19
+    for mode in (-1, 100):
+        g = out[mode]
+        t0, t1 = ref[lo:hi].view(16, T, 2), g[lo:hi].view(16, T, 2)
+        for l in range(16):
+            m = float(t0[l].abs().max())
+            assert float((t0[l] - t1[l]).abs().max()) <= 1e-6 * m, f"reserve {mode}: table level {l}"
+        for sl in (slice(0, lo), slice(hi, None)):
+            x, y = ref[sl].double(), g[sl].double()
+            assert float((x - y).norm() / x.norm()) <= 1e-6, f"reserve {mode}: MLP / embedding gradients"
