@@ -241,7 +241,27 @@ typedef struct nsamd_field_mlp {
   const float* appearance;                      /* [num_images,32] embedding table (may be NULL if unused) */
   int32_t num_images;
   float average_init_density;
+  /* Ray terms (nullable, both NULL = the plain kernels). 48 of head layer 0's 63 inputs — SH16 of the view direction and
+   * the appearance row — are the same for every sample of a ray, so their share of the layer's pre-activation,
+   *   ray_terms[ray] = head_b0 + head_W0[:, SH | appearance] . [SH16(dir') | appearance row]          ([num_rays,64])
+   * is computed ONCE per ray (nsamd_field_ray_terms) and the per-sample GEMM of head layer 0 keeps K = 16 (the geo
+   * features) instead of 64: 8 320 of a sample's 11 392 MACs instead of all of them, the same sums in another order
+   * (nerfacto_field.py:283-310: `torch.cat([d, density_embedding, embedded_appearance])` into one Linear). Used by the
+   * forward and backward entry points below whenever every 16-sample tile lies inside one ray (dir_group % 16 == 0,
+   * M % dir_group == 0); the backward additionally needs `ray_inputs` ([num_rays,48] = SH16 | appearance32, written by the
+   * same call) for the weight gradient of those 48 columns and a workspace with room for 64 floats per tile, and falls
+   * back to the plain kernel otherwise. The caller recomputes the terms whenever head_W0 / head_b0 / the appearance
+   * table / the directions / the camera indices changed. */
+  const float* ray_terms;
+  const float* ray_inputs;
 } nsamd_field_mlp;
+
+/* ray_terms [num_rays,64] (and ray_inputs [num_rays,48], nullable) of the struct above for `num_rays` rays: directions
+ * [num_rays,3]; camera_indices [num_rays] int64 or NULL (then appearance_const [32], or neither: no appearance embedding).
+ * `mlp.ray_terms / ray_inputs` are ignored here. */
+int nsamd_field_ray_terms(const float* directions, const int64_t* camera_indices, const float* appearance_const,
+                          int64_t num_rays, nsamd_field_mlp mlp, float* ray_terms, float* ray_inputs,
+                          nsamd_stream_t stream);
 
 int nsamd_field_mlp_fwd(const float* enc, const float* selector, const float* directions,
                         const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,

@@ -45,7 +45,7 @@ class DensityMlp(C.Structure):
 class FieldMlp(C.Structure):
     _fields_ = [("base_W0", vp), ("base_b0", vp), ("base_W1", vp), ("base_b1", vp), ("head_W0", vp), ("head_b0", vp),
                 ("head_W1", vp), ("head_b1", vp), ("head_W2", vp), ("head_b2", vp), ("appearance", vp),
-                ("num_images", i32), ("average_init_density", f32)]
+                ("num_images", i32), ("average_init_density", f32), ("ray_terms", vp), ("ray_inputs", vp)]
 
 
 class OccGrid(C.Structure):
@@ -92,6 +92,7 @@ _SIGNATURES = {
     "nsamd_density_mlp_bwd_gated": [vp, vp, vp, vp, i64, DensityMlp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp],
     "nsamd_field_mlp_fwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp],
     "nsamd_field_mlp_bwd": [vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp, i64, vp],
+    "nsamd_field_ray_terms": [vp, vp, vp, i64, FieldMlp, vp, vp, vp],
     "nsamd_field_mlp_bwd_scatter": [Points, C.c_int, Aabb, Grid, vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads, vp,
                                     i64, vp, vp, i64, vp],
     "nsamd_field_mlp_bwd_scatter_phase": [Points, C.c_int, Aabb, Grid, vp, vp, vp, vp, vp, i64, i64, FieldMlp, vp, vp, vp, FieldMlpGrads,
@@ -239,6 +240,10 @@ def profile_summary(prof: dict) -> dict:
     out = {}
     for key, pairs in prof.items():
         ms = [a.elapsed_time(b) for a, b in pairs]
+        if os.environ.get("NSAMD_ROOFLINE_SAMPLES") == "1" and "field_mlp_bwd" in key:  # diagnostics: every launch's time
+            import sys
+
+            print(f"[samples] {key}: " + " ".join(f"{m:.4f}" for m in ms), file=sys.stderr)
         out[key] = (len(ms), float(sum(ms)), float(sum(ms) / max(1, len(ms))))
     return out
 

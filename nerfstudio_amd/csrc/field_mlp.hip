@@ -92,6 +92,19 @@ __device__ __forceinline__ void chain_gemm(const float* frag, const v4f* in, v4f
   }
 }
 
+// one input tile `t` of a [NT][KT] fragment block: out[n] += W[16n + j][16t ..] . in
+template <int NT, int KT>
+__device__ __forceinline__ void chain_gemm_tile(const float* frag, int t, const v4f& in, v4f* out, int lane) {
+  v4f a[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) a[n] = *reinterpret_cast<const v4f*>(frag + ((n * KT + t) * 64 + lane) * 4);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) out[n] = mfma16(a[n][r], in[r], out[n]);
+  }
+}
+
 template <int NT>
 __device__ __forceinline__ void load_bias(const float* bias, v4f* out, int g) {
 #pragma unroll
@@ -172,7 +185,14 @@ __device__ __forceinline__ void load_enc_tile(const float* __restrict__ enc, int
     for (int r = 0; r < 4; ++r) out[t][r] = (enc + (int64_t)(16 * t + r) * M)[off];
 }
 
-// A.enc must hold the tile's encoded features (load_enc_tile) on entry.
+// Ray terms (nsamd_field_mlp.ray_terms, include/nsamd.h): 48 of head layer 0's 64 input slots — the SH block and the appearance
+// row — are the same for every sample of a ray, and a 16-point tile lies inside one ray, so their share of the layer's
+// pre-activation (plus the bias) is a per-ray vector computed once by field_ray_terms_kernel. RAYC kernels start head layer
+// 0's accumulators from it and run the per-point GEMM over the geo tile alone: K = 16 instead of 64 — 16 of the layer's 64
+// MFMAs forward, 16 of 48 in the data gradient, and its weight gradient shrinks to the geo columns (the 48 per-ray columns
+// follow from the per-tile sums of dL/d(pre-activation), field_reduce.h). A.enc must hold the tile's encoded features
+// (load_enc_tile) on entry; RAYC: A.ha the ray's terms.
+template <bool RAYC = false>
 __device__ __forceinline__ void field_forward_tile(const float* wf, const float* bias,
                                                    const float* __restrict__ directions,
                                                    const float* __restrict__ app_table,
@@ -188,6 +208,16 @@ __device__ __forceinline__ void field_forward_tile(const float* wf, const float*
   PROBE_STAMP(kWaves, probe_slot);
   if (base_only) return;  // density only (Field.density_fn: the head's 8 320 of 11 392 MACs per point are not needed)
 
+  if (RAYC) {
+    chain_gemm_tile<4, 4>(wf + kOffHead0, 1, A.o16[0], A.ha, lane);
+    relu_tiles<4>(A.ha);
+    load_bias<4>(bias + kBiasHead1, A.hb, g);
+    chain_gemm<4, 4>(wf + kOffHead1, A.ha, A.hb, lane);
+    relu_tiles<4>(A.hb);
+    load_bias<1>(bias + kBiasHead2, A.rgbp, g);
+    chain_gemm<1, 4>(wf + kOffHead2, A.hb, A.rgbp, lane);
+    return;
+  }
   // head input: SH of (dir + 1) / 2  (base_field.py:136-142), geo in place, appearance embedding
   {
     const float* d = directions + 3 * ti.ray;
@@ -245,7 +275,7 @@ __device__ __forceinline__ void stage_all_fwd(float* wf, float* bias, const nsam
   stage_bias<THREADS>(bias + kBiasHead2, mlp.head_b2, 3, 16);
 }
 
-template <int WAVES>
+template <int WAVES, bool RAYC = false>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 1 : 2) void field_mlp_fwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
@@ -268,9 +298,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 1 : 2) void field_mlp_fwd
     const TileInputs ti = tile_inputs(tile, lane, M, selector, cams, dir_group);
     FieldActs A;
     load_enc_tile_fwd(enc, M, ti.p, lane, A.enc);
+    if (RAYC && rgb != nullptr) {  // the ray's terms: in flight with the features, consumed two layers further down
+      const float* c = mlp.ray_terms + ti.ray * 64 + 4 * (lane >> 4);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) A.ha[n] = *reinterpret_cast<const v4f*>(c + 16 * n);
+    }
     PROBE_STAMP(WAVES, 2 + 4 * probe_it);
-    field_forward_tile(wf, bias, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A, 3 + 4 * probe_it,
-                       rgb == nullptr);
+    field_forward_tile<RAYC>(wf, bias, directions, app_table, app_const, dir_group, M, app_dim, ti, lane, A, 3 + 4 * probe_it,
+                             rgb == nullptr);
     PROBE_STAMP(WAVES, 4 + 4 * probe_it);
     if (lane < 16 && ti.live) {  // g == 0 holds neurons 0..3 of tile 0
       density[ti.p] = mlp.average_init_density * expf(A.o16[0][0]) * ti.sel;
@@ -284,6 +319,59 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 1 : 2) void field_mlp_fwd
     ++probe_it;
   }
   PROBE_STAMP(WAVES, 63);
+}
+
+// ray_terms [num_rays, 64] (+ ray_inputs [num_rays, 16 + 32]): head layer 0 on the 48 per-ray inputs, 16 RAYS per wavefront in
+// the chain layout (a ray where the field kernels have a point): bias, then the SH tile, then the two appearance tiles.
+__global__ __launch_bounds__(kFieldThreads) void field_ray_terms_kernel(
+    const float* __restrict__ directions, const int64_t* __restrict__ cams, const float* __restrict__ app_const,
+    int64_t num_rays, nsamd_field_mlp mlp, int app_dim, float* __restrict__ terms, float* __restrict__ inputs) {
+  __shared__ __attribute__((aligned(16))) float wf[kFragHead0];
+  __shared__ __attribute__((aligned(16))) float bias[64];
+  {
+    float v[16];
+    stage_frag_load<4, 4, kFieldThreads>(v, mlp.head_W0, 64, 31 + app_dim, true, app_dim);
+    stage_frag_store<4, 4, kFieldThreads>(wf, v);
+    stage_bias<kFieldThreads>(bias, mlp.head_b0, 64, 64);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const float* app_table = cams ? mlp.appearance : nullptr;
+  const int64_t tiles = (num_rays + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += (int64_t)gridDim.x * kWaves) {
+    const int64_t ray = tile * 16 + j;
+    const bool live = ray < num_rays;
+    const int64_t rc = live ? ray : num_rays - 1;
+    const float* d = directions + 3 * rc;
+    v4f hin[4];
+    hin[0] = sh_quad(d[0], d[1], d[2], g);
+    if (app_dim > 0) {
+      const float* src = (app_table != nullptr) ? app_table + cams[rc] * 32 : app_const;
+      hin[2] = *reinterpret_cast<const v4f*>(src + 4 * g);
+      hin[3] = *reinterpret_cast<const v4f*>(src + 16 + 4 * g);
+    } else {
+      hin[2] = v4f{0.f, 0.f, 0.f, 0.f};
+      hin[3] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    v4f acc[4];
+    load_bias<4>(bias, acc, g);
+    chain_gemm_tile<4, 4>(wf, 0, hin[0], acc, lane);
+    chain_gemm_tile<4, 4>(wf, 2, hin[2], acc, lane);
+    chain_gemm_tile<4, 4>(wf, 3, hin[3], acc, lane);
+    if (live) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) *reinterpret_cast<v4f*>(terms + ray * 64 + 16 * n + 4 * g) = acc[n];
+      if (inputs != nullptr) {
+        float* x = inputs + ray * (16 + app_dim);
+        *reinterpret_cast<v4f*>(x + 4 * g) = hin[0];
+        if (app_dim > 0) {
+          *reinterpret_cast<v4f*>(x + 16 + 4 * g) = hin[2];
+          *reinterpret_cast<v4f*>(x + 32 + 4 * g) = hin[3];
+        }
+      }
+    }
+  }
 }
 
 // ---- the bf16 matrix cores (v_mfma_f32_16x16x32_bf16: 8192 MACs in 4 passes, 16x the f32 MFMA's rate) ------------------------
@@ -398,6 +486,7 @@ __device__ __forceinline__ void relu_mask(v4f* grad, const v4f* act) {
 //    stores the transposed (Dout, X) tiles of its 16 points in its scratch, the workgroup synchronises, and wave w
 //    accumulates its own 1-2 tiles of dW over all 128 points of the 8 scratch areas. 7 accumulator tiles per wave
 //    instead of 48, no cross-wave reduction at the end, and every wave writes its tiles of the partial straight out.
+constexpr int kRayS = 16 * kScratchLd, kRayX = kRayS + 64;  // RAYC: S_tile [64] and the ray's inputs [48] behind the geo tile's 16 rows
 constexpr int kCoopWaves = 8;
 constexpr int kCoopThreads = 64 * kCoopWaves;
 constexpr int kLd64 = 68, kLd32 = 36;  // row strides (floats) of the K = 64 / K = 32 weight matrices in LDS
@@ -470,12 +559,12 @@ struct NoBetween {
 };
 
 // `between.at<I>()` runs after GEMM I (0..4) of the chain: the producer mode of the backward slots its record stores there
-template <class Between = NoBetween>
+template <class Between = NoBetween, bool RAYC = false>
 __device__ __forceinline__ void coop_forward_tile(const float* W, const float* bias, const float (&dir)[3],
                                                   const float* __restrict__ app_table,
                                                   const float* __restrict__ app_const, int app_dim,
                                                   const TileInputs& ti, int lane, FieldActs& A, const v4f* app_pre = nullptr,
-                                                  const Between& between = Between()) {
+                                                  const Between& between = Between(), const v4f* ray_terms = nullptr) {
   const int j = lane & 15, g = lane >> 4;
   load_bias<4>(bias + kBiasBase0, A.h1, g);
   rows_gemm_fwd<4, 2, kLd32>(W + kRowBase0, A.enc, A.h1, j, g);
@@ -484,6 +573,11 @@ __device__ __forceinline__ void coop_forward_tile(const float* W, const float* b
   load_bias<1>(bias + kBiasBase1, A.o16, g);
   rows_gemm_fwd<1, 4, kLd64>(W + kRowBase1, A.h1, A.o16, j, g);
   between.template at<1>();
+  if (RAYC) {  // head layer 0 from the ray's terms + the geo tile (see field_forward_tile)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) A.ha[n] = ray_terms[n];
+    rows_gemm_fwd<4, 1, kLd64>(W + kRowHead0 + 16, A.o16, A.ha, j, g);
+  } else {
   A.hin[0] = sh_quad(dir[0], dir[1], dir[2], g);
   A.hin[1] = A.o16[0];
   if (app_pre != nullptr) {  // fetched by the caller ahead of other memory traffic
@@ -499,6 +593,7 @@ __device__ __forceinline__ void coop_forward_tile(const float* W, const float* b
   }
   load_bias<4>(bias + kBiasHead0, A.ha, g);
   rows_gemm_fwd<4, 4, kLd64>(W + kRowHead0, A.hin, A.ha, j, g);
+  }
   between.template at<2>();
   relu_tiles<4>(A.ha);
   load_bias<4>(bias + kBiasHead1, A.hb, g);
@@ -862,6 +957,8 @@ struct TileFetch {
   float up[4];     // RAW drgb[0..2], ddensity of the lane's point
   float dir[3];
   v4f app[2];      // RAW appearance row slice
+  v4f cterm[4];    // RAYC: the ray's terms (instead of dir / app / cam)
+  float xin;       // RAYC: lane l < 16 + app_dim: input l of the ray (ray_inputs)
 };
 
 // Every load here is UNCONDITIONAL and nothing loaded is touched (no select, no copy) before `tile_fetched` runs at the top of
@@ -870,20 +967,26 @@ struct TileFetch {
 // flight) right here instead of behind the base-layer-0 weight-gradient GEMM that follows. Absent inputs read a valid dummy
 // address (`enc`) and are replaced by their constants in `tile_fetched`. The camera index is loaded first and waited for
 // with the other loads in flight behind it (its appearance row is the one dependent load).
+template <bool RAYC = false>
 __device__ __forceinline__ void fetch_tile(TileFetch& f, int64_t tile, int64_t tiles, int lane, int64_t M,
                                            const float* __restrict__ enc, const float* __restrict__ selector,
                                            const float* __restrict__ directions, const int64_t* __restrict__ cams,
                                            const float* __restrict__ app_table, const float* __restrict__ app_const,
                                            int app_dim, int64_t dir_group, const float* __restrict__ ddensity,
-                                           const float* __restrict__ drgb) {
+                                           const float* __restrict__ drgb, const float* __restrict__ ray_terms = nullptr,
+                                           const float* __restrict__ ray_inputs = nullptr) {
   const int g = lane >> 4;
   const int64_t t = tile < tiles ? tile : tiles - 1;
   const int64_t p = t * 16 + (lane & 15);
   f.ti.live = p < M && tile < tiles;  // (tile >= tiles: idle wave of the last round — computes, contributes zeros)
   f.ti.p = p < M ? p : M - 1;
   f.ti.ray = ray_of(f.ti.p, dir_group);
-  const int64_t* cam_src = cams != nullptr ? cams + f.ti.ray : reinterpret_cast<const int64_t*>(enc);
-  f.ti.cam = *cam_src;
+  if (RAYC) {
+    f.ti.cam = 0;
+  } else {
+    const int64_t* cam_src = cams != nullptr ? cams + f.ti.ray : reinterpret_cast<const int64_t*>(enc);
+    f.ti.cam = *cam_src;
+  }
   f.ti.sel = (selector != nullptr ? selector : enc)[f.ti.p];
   load_enc_tile(enc, M, f.ti.p, lane, f.enc);
   // (single-dword loads kept apart by compiler barriers: merged into dwordx3 the triples land in register tuples that are
@@ -896,6 +999,14 @@ __device__ __forceinline__ void fetch_tile(TileFetch& f, int64_t tile, int64_t t
   f.up[2] = drgb[3 * f.ti.p + 2];
   NSAMD_KEEP_APART();
   f.up[3] = ddensity[f.ti.p];
+  if (RAYC) {
+    const float* c = ray_terms + f.ti.ray * 64 + 4 * g;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) f.cterm[n] = *reinterpret_cast<const v4f*>(c + 16 * n);
+    const int ncols = 16 + app_dim;
+    f.xin = ray_inputs[f.ti.ray * ncols + (lane < ncols ? lane : 0)];
+    return;
+  }
   const float* d = directions + 3 * f.ti.ray;
   f.dir[0] = d[0];
   NSAMD_KEEP_APART();
@@ -903,11 +1014,11 @@ __device__ __forceinline__ void fetch_tile(TileFetch& f, int64_t tile, int64_t t
   NSAMD_KEEP_APART();
   f.dir[2] = d[2];
   NSAMD_KEEP_APART();
-#undef NSAMD_KEEP_APART
   const float* src = app_table != nullptr ? app_table + (cams != nullptr ? f.ti.cam : 0) * 32
                                           : (app_const != nullptr ? app_const : enc);
   f.app[0] = *reinterpret_cast<const v4f*>(src + 4 * g);
   f.app[1] = *reinterpret_cast<const v4f*>(src + 16 + 4 * g);
+#undef NSAMD_KEEP_APART
 }
 
 // the record stores that ride on a tile's forward recomputation: the previous tile's levels K = 0 (behind base layer 0's
@@ -926,7 +1037,14 @@ struct RouteBetween {
 };
 
 // ROUTE: the kernel also emits the table scatter's pass-1 records. A tile's inputs are fetched one tile ahead.
-template <bool ROUTE>
+// RAYC: head layer 0 from the ray terms (mlp.ray_terms; the host has checked that every tile lies inside one ray). The layer's
+// per-point input is the geo tile alone, so its weight gradient's geo columns are formed like the other layers' (two-piece bf16:
+// both operands vary from point to point). Its 48 per-ray columns and the appearance rows' gradient need only
+// S_tile = the 64 sums of dL/d(pre-activation) over the tile's 16 points (DPP butterflies, fp32): with the 8 tiles of a
+// workgroup iteration on the k axis, dW0[:, per-ray columns] += S^T X (X = the tiles' ray_inputs rows) is 24 f32 MFMAs per
+// iteration for the whole workgroup where the per-point form took 384, and the tiles' appearance-gradient rows are
+// W0[:, appearance]^T S (32 MFMAs) — written to `app_partials` exactly as the plain kernel writes its per-tile sums.
+template <bool ROUTE, bool RAYC = false>
 __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     const float* __restrict__ enc, const float* __restrict__ selector, const float* __restrict__ directions,
     const int64_t* __restrict__ cams, const float* __restrict__ app_const, int64_t dir_group, int64_t M,
@@ -986,6 +1104,8 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
   const int own_q = wave & 3;            // 1 x 4 layers: column tile; the points are split in two halves
   const int own_half = wave >> 2;
   v4f dW_h1[2], dW_h0[2], dW_b0[1], dW_h2[1], dW_b1[1];
+  v4f dW_r[2];  // RAYC: the per-ray columns of head layer 0: tile (row tile wave & 3, slot tile 0 | 2), waves 0..3 also (wave, slot tile 3)
+  zero_tiles<2>(dW_r);
   float db_h1 = 0.f, db_h0 = 0.f, db_b0 = 0.f, db_h2 = 0.f, db_b1 = 0.f;
   zero_tiles<2>(dW_h1);
   zero_tiles<2>(dW_h0);
@@ -1005,15 +1125,17 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
 #endif
   constexpr bool AHEAD = ROUTE || NSAMD_NOROUTE_AHEAD;
   TileFetch nxt;
+  static_assert(AHEAD || !RAYC, "ray terms are fetched a tile ahead");
   if (AHEAD && iters > 0)
-    fetch_tile(nxt, (int64_t)blockIdx.x * kCoopWaves + wave, tiles, lane, M, enc, selector, directions, cams, app_table, app_const,
-               app_dim, dir_group, ddensity, drgb);
+    fetch_tile<RAYC>(nxt, (int64_t)blockIdx.x * kCoopWaves + wave, tiles, lane, M, enc, selector, directions, cams, app_table,
+                     app_const, app_dim, dir_group, ddensity, drgb, mlp.ray_terms, mlp.ray_inputs);
   for (int64_t it = 0; it < iters; ++it) {
     PROBE_STAMP(kCoopWaves, 2 + 10 * (int)it);
     const int64_t tile = (it * gridDim.x + blockIdx.x) * kCoopWaves + wave;
     TileInputs ti;
     FieldActs A;
     float up_rgb[3] = {0.f, 0.f, 0.f}, up_density = 0.f;
+    float nxt_xin = 0.0f;
     if (AHEAD) {
       // (tile_fetched: what `fetch_tile` left raw gets its constants / masks here, where the values are first needed)
       ti = nxt.ti;
@@ -1028,12 +1150,14 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
       const float dir[3] = {nxt.dir[0], nxt.dir[1], nxt.dir[2]};
       const v4f zero4 = v4f{0.f, 0.f, 0.f, 0.f};
       const v4f app[2] = {app_dim > 0 ? nxt.app[0] : zero4, app_dim > 0 ? nxt.app[1] : zero4};
+      const v4f cterm[4] = {nxt.cterm[0], nxt.cterm[1], nxt.cterm[2], nxt.cterm[3]};
+      nxt_xin = nxt.xin;
       if (ROUTE) {
         // records 0..6 of the PREVIOUS tile leave between this tile's forward GEMMs, the other nine between the phases below
         const RouteBetween rb{RL, RL->stash[wave], lane, probe_skip, it > 0 && !(probe_skip & 32)};
-        coop_forward_tile(W, bias, dir, app_table, app_const, app_dim, ti, lane, A, app, rb);
+        coop_forward_tile<RouteBetween, RAYC>(W, bias, dir, app_table, app_const, app_dim, ti, lane, A, app, rb, cterm);
       } else {
-        coop_forward_tile(W, bias, dir, app_table, app_const, app_dim, ti, lane, A, app, NoBetween{});
+        coop_forward_tile<NoBetween, RAYC>(W, bias, dir, app_table, app_const, app_dim, ti, lane, A, app, NoBetween{}, cterm);
       }
     } else {
       ti = tile_inputs(tile < tiles ? tile : tiles - 1, lane, M, selector, cams, dir_group);
@@ -1098,19 +1222,64 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     PROBE_STAMP(kCoopWaves, 5 + 10 * (int)it);
 
     // ---- head layer 0 (slots 64 -> 64) ----
-    store_rows<4, true>(Sd, g_ha, j, g);
-    store_rows<4, true>(Sx, A.hin, j, g);
     v4f g_hin[4];
     zero_tiles<4>(g_hin);
+    if (RAYC) {
+      // the geo tile is the only per-point input: X = base output tile (slot 16 = the density pre-activation: its column of the
+      // partial row is dropped by the reduce), data gradient for that tile alone
+      store_rows<4>(Sd, g_ha, j, g);
+      store_rows<1>(Sx, A.o16, j, g);
+      if (!(probe_skip & 4)) rows_gemm_bwd<1, 4, kLd64>(W + kRowHead0 + 16, g_ha, g_hin + 1, j, g);
+      // S_tile: the tile's 64 sums of dL/d(pre-activation) over its 16 points (DPP butterfly, lane j == 0 of every row), and the
+      // ray's inputs, into the free rows of the wave's X area (the geo tile takes 16 of its 64 rows)
+      float* Ss = Sx + kRayS;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        v4f v = g_ha[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = row16_sum_lane0(v[r]);
+        if (j == 0) *reinterpret_cast<v4f*>(Ss + 16 * n + 4 * g) = v;
+      }
+      if (lane < 48) Sx[kRayX + lane] = lane < 16 + app_dim ? nxt_xin : 0.0f;
+      if (!(probe_skip & 2)) __syncthreads();
+      if (!(probe_skip & 1)) {
+        coop_dw<1>(dW_h0, &db_h0, true, scratch, 4 * own_half, 4, own_q, 0, j, g);
+        // per-ray columns: k = the workgroup's 8 tiles (two instructions of 4), A = S (row 16 a + j), B = the tiles' inputs
+        const int a = wave & 3, b0 = wave >> 2;  // b: 0 = SH, 1 / 2 = appearance 0..15 / 16..31
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float* area = scratch + (4 * h + g) * 2 * kScratchTile + kScratchTile;
+          const float sa = area[kRayS + 16 * a + j];
+          if (b0 == 0 || app_dim > 0) dW_r[0] = mfma16(sa, area[kRayX + 16 * b0 + j], dW_r[0]);
+          if (wave < 4 && app_dim > 0) dW_r[1] = mfma16(sa, area[kRayX + 32 + j], dW_r[1]);
+        }
+        // the tiles' appearance-gradient rows: out[slot 16 w + j'][tile] = sum over n of W0[n][32 + slot] S_tile[n] (waves 0, 1)
+        if (wave < 2 && app_partials != nullptr) {
+          v4f o = {0.f, 0.f, 0.f, 0.f};
+          const float* st = scratch + (j & 7) * 2 * kScratchTile + kScratchTile + kRayS;
+#pragma unroll
+          for (int kk = 0; kk < 16; ++kk)
+            o = mfma16(W[kRowHead0 + (4 * kk + g) * kLd64 + 32 + 16 * wave + j], st[4 * kk + g], o);
+          // lane (j, g): rows 4 g .. 4 g + 3 of slot tile `wave`, tile j of the workgroup's eight
+          const int64_t tj = (it * gridDim.x + blockIdx.x) * kCoopWaves + j;
+          if (j < 8 && tj < tiles)
+            *reinterpret_cast<v4f*>(app_partials + ((uint32_t)tj * 32u + (uint32_t)(16 * wave + 4 * g))) = o;
+        }
+      }
+      if (!(probe_skip & 2)) __syncthreads();
+    } else {
+    store_rows<4, true>(Sd, g_ha, j, g);
+    store_rows<4, true>(Sx, A.hin, j, g);
     // input tile 0 is the SH block: it carries no gradient, so only columns 16..63 (tiles 1..3) are formed
     if (!(probe_skip & 4)) rows_gemm_bwd<3, 4, kLd64>(W + kRowHead0 + 16, g_ha, g_hin + 1, j, g);
     if (!(probe_skip & 2)) __syncthreads();
     if (!(probe_skip & 1)) coop_dw<2, true>(dW_h0, &db_h0, bias_owner44, scratch, 0, kCoopWaves, own_n, own_m2, j, g);
     if (!(probe_skip & 2)) __syncthreads();
+    }
     PROBE_STAMP(kCoopWaves, 6 + 10 * (int)it);
 
     // appearance-embedding gradient (slots 32..63): rows of one camera are pre-reduced over the tile's points
-    if (app_table != nullptr && grads.appearance != nullptr) {
+    if (!RAYC && app_table != nullptr && grads.appearance != nullptr) {
       if (app_partials != nullptr && app_rows_per_point) {
         // per-sample cameras (packed instant-ngp samples, explicit positions: a 16-point tile spans several rays): every
         // point writes its own 32 gradients; the reduce launch adds the rows of each camera in point order — no atomics
@@ -1209,8 +1378,8 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
     }
     if (!(probe_skip & 2)) __syncthreads();
     if (AHEAD && it + 1 < iters)  // the next tile's inputs (see TileFetch)
-      fetch_tile(nxt, tile + per_iter, tiles, lane, M, enc, selector, directions, cams, app_table, app_const, app_dim, dir_group,
-                 ddensity, drgb);
+      fetch_tile<RAYC>(nxt, tile + per_iter, tiles, lane, M, enc, selector, directions, cams, app_table, app_const, app_dim,
+                       dir_group, ddensity, drgb, mlp.ray_terms, mlp.ray_inputs);
     PROBE_STAMP(kCoopWaves, 9 + 10 * (int)it);
     if (!(probe_skip & 1)) coop_dw<1>(dW_b0, &db_b0, own_m1 == 0, scratch, 0, kCoopWaves, own_n, own_m1, j, g);
     // no barrier here: the next writer of the scratch is the next iteration's head layer 2, behind its own barrier
@@ -1239,6 +1408,10 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
       stash[2048 + lane] = db_h2;
       stash[2048 + 64 + lane] = db_b1;
     }
+    if (RAYC) {  // head layer 0's geo columns: row tile own_q, the points split in two halves like the 1 x 4 layers
+      *reinterpret_cast<v4f*>(stash + 2304 + (own_q * 64 + lane) * 4) = dW_h0[0];
+      stash[2304 + 1024 + own_q * 64 + lane] = db_h0;
+    }
   }
   __syncthreads();
   float* prow = partials != nullptr ? partials + (size_t)blockIdx.x * kPartialStride : nullptr;
@@ -1257,17 +1430,32 @@ __global__ __launch_bounds__(kCoopThreads) void field_mlp_bwd_kernel(
       coop_emit_bias(db_h2 + stash[2048 + lane], 0, j, g, pbias ? pbias + kBiasHead2 : nullptr, grads.head_b2, 3);
       coop_emit_bias(db_b1 + stash[2048 + 64 + lane], 0, j, g, pbias ? pbias + kBiasBase1 : nullptr, grads.base_b1, 16);
     }
+    if (RAYC) {
+      const v4f o_h0 = *reinterpret_cast<const v4f*>(stash + 2304 + (own_q * 64 + lane) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dW_h0[0][r] += o_h0[r];
+      coop_emit(dW_h0[0], own_q, 1, 64, prow ? prow + kOffHead0 : nullptr, grads.head_W0, 64, 31 + app_dim, true, app_dim, j, g);
+      coop_emit_bias(db_h0 + stash[2304 + 1024 + own_q * 64 + lane], own_q, j, g, pbias ? pbias + kBiasHead0 : nullptr,
+                     grads.head_b0, 64);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     coop_emit(dW_h1[i], own_n, own_m2 + i, 64, prow ? prow + kOffHead1 : nullptr, grads.head_W1, 64, 64, false, 0, j, g);
-    coop_emit(dW_h0[i], own_n, own_m2 + i, 64, prow ? prow + kOffHead0 : nullptr, grads.head_W0, 64, 31 + app_dim, true,
+    if (!RAYC)
+      coop_emit(dW_h0[i], own_n, own_m2 + i, 64, prow ? prow + kOffHead0 : nullptr, grads.head_W0, 64, 31 + app_dim, true,
+                app_dim, j, g);
+  }
+  if (RAYC) {  // the per-ray columns: slot tiles 0 (SH), 2, 3 (appearance); zeros where the field has no appearance embedding
+    coop_emit(dW_r[0], wave & 3, wave < 4 ? 0 : 2, 64, prow ? prow + kOffHead0 : nullptr, grads.head_W0, 64, 31 + app_dim, true,
               app_dim, j, g);
+    if (wave < 4)
+      coop_emit(dW_r[1], wave, 3, 64, prow ? prow + kOffHead0 : nullptr, grads.head_W0, 64, 31 + app_dim, true, app_dim, j, g);
   }
   coop_emit(dW_b0[0], own_n, own_m1, 32, prow ? prow + kOffBase0 : nullptr, grads.base_W0, 64, 32, false, 0, j, g);
   if (bias_owner44) {
     coop_emit_bias(db_h1, own_n, j, g, pbias ? pbias + kBiasHead1 : nullptr, grads.head_b1, 64);
-    coop_emit_bias(db_h0, own_n, j, g, pbias ? pbias + kBiasHead0 : nullptr, grads.head_b0, 64);
+    if (!RAYC) coop_emit_bias(db_h0, own_n, j, g, pbias ? pbias + kBiasHead0 : nullptr, grads.head_b0, 64);
   }
   if (own_m1 == 0) coop_emit_bias(db_b0, own_n, j, g, pbias ? pbias + kBiasBase0 : nullptr, grads.base_b0, 64);
   PROBE_STAMP(kCoopWaves, 63);
@@ -1350,6 +1538,33 @@ extern "C" int nsamd_field_mlp_bwd_reserve_cus(int cus) {
   return prev;
 }
 
+// the RAYC kernels apply: terms given and every 16-point tile inside one ray
+static bool field_ray_terms_apply(const nsamd_field_mlp& mlp, int64_t dir_group, int64_t M) {
+  static const bool on = getenv("NSAMD_RAY_TERMS") == nullptr || atoi(getenv("NSAMD_RAY_TERMS")) != 0;  // =0: A/B, the plain kernels
+  return on && mlp.ray_terms != nullptr && dir_group % 16 == 0 && M % dir_group == 0;
+}
+
+extern "C" int nsamd_field_ray_terms(const float* directions, const int64_t* camera_indices, const float* appearance_const,
+                                     int64_t num_rays, nsamd_field_mlp mlp, float* ray_terms, float* ray_inputs,
+                                     nsamd_stream_t stream) {
+  NSAMD_REQUIRE(num_rays >= 0);
+  if (num_rays == 0) return NSAMD_OK;
+  NSAMD_REQUIRE(directions && ray_terms && mlp.head_W0 && mlp.head_b0);
+  int app_dim = 0;
+  if (camera_indices != nullptr) {
+    NSAMD_REQUIRE(mlp.appearance != nullptr && mlp.num_images > 0);
+    app_dim = 32;
+  } else if (appearance_const != nullptr) {
+    app_dim = 32;
+  }
+  const int64_t tiles = (num_rays + 15) / 16;
+  const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + kWaves - 1) / kWaves);
+  field_ray_terms_kernel<<<blocks, kFieldThreads, 0, (hipStream_t)stream>>>(directions, camera_indices, appearance_const, num_rays,
+                                                                           mlp, app_dim, ray_terms, ray_inputs);
+  NSAMD_CHECK_LAUNCH();
+  return NSAMD_OK;
+}
+
 static int field_mlp_fwd_impl(const float* enc, const float* selector, const float* directions,
                               const int64_t* camera_indices, const float* appearance_const, int64_t dir_group, int64_t M,
                               nsamd_field_mlp mlp, float* density, float* rgb, nsamd_stream_t stream) {
@@ -1363,7 +1578,11 @@ static int field_mlp_fwd_impl(const float* enc, const float* selector, const flo
   // One 16-wave workgroup per CU by default (4 waves per SIMD, the weights staged once per CU): 57 us on the bench shape
   // against 59.5 (8 waves x 2 workgroups) and 65 (4 waves x 3) on the same box — NSAMD_FIELD_FWD_WAVES=8|4 selects those.
   static const int waves = getenv("NSAMD_FIELD_FWD_WAVES") ? atoi(getenv("NSAMD_FIELD_FWD_WAVES")) : 16;
-  if (waves == 16) {
+  if (field_ray_terms_apply(mlp, dir_group, M) && rgb != nullptr) {
+    const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + 15) / 16);
+    field_mlp_fwd_kernel<16, true><<<blocks, 1024, lds, (hipStream_t)stream>>>(
+        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb);
+  } else if (waves == 16) {
     const unsigned blocks = (unsigned)min((int64_t)num_cus(), (tiles + 15) / 16);
     field_mlp_fwd_kernel<16><<<blocks, 1024, lds, (hipStream_t)stream>>>(
         enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, density, rgb);
@@ -1406,9 +1625,13 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return NSAMD_ERR_NO_DEVICE;
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {  // the dynamic-LDS opt-in is per device
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<false>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<true>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + sizeof(uint32_t) * kRouteLdsWords)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&field_mlp_bwd_kernel<true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + sizeof(uint32_t) * kRouteLdsWords)) != hipSuccess)
       return NSAMD_ERR_LAUNCH;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
@@ -1421,6 +1644,8 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
   // inside one ray and room behind the weight-gradient partials; otherwise float atomics (sums in no fixed order)
   float* app_partials = nullptr;
   int app_rows_per_point = 0;
+  // ray terms (RAYC kernels): need the partial rows (their per-ray columns of head layer 0 are written, never added) and, for
+  // the appearance rows, the per-tile scratch below
   if (partials != nullptr && camera_indices != nullptr && grads.appearance != nullptr && dir_group % 16 == 0 &&
       M % dir_group == 0 && mlp.num_images <= 8192 &&
       workspace_floats >= (int64_t)blocks * kPartialStride + tiles * 32) {
@@ -1430,6 +1655,8 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
     app_partials = workspace + (int64_t)blocks * kPartialStride;  // one row per POINT (a camera index per sample)
     app_rows_per_point = 1;
   }
+  const bool rayc = partials != nullptr && field_ray_terms_apply(mlp, dir_group, M) && mlp.ray_inputs != nullptr &&
+                    (app_partials != nullptr || camera_indices == nullptr || grads.appearance == nullptr);
   if (phases != 3) NSAMD_REQUIRE(partials != nullptr);  // without scratch the kernel flushes with atomics: nothing to split
   ScatterPlan plan{};
   if (route_in != nullptr) {
@@ -1443,15 +1670,25 @@ static int field_mlp_bwd_impl(const float* enc, const float* selector, const flo
     R.buf = scatter_bufs(scatter_ws, plan);
     R.buf.log2_table_size = R.grid.log2_table_size;
     if (phases & 1) {
-      field_mlp_bwd_kernel<true><<<blocks, kCoopThreads, lds + sizeof(uint32_t) * kRouteLdsWords, (hipStream_t)stream>>>(
-          enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-          grads, partials, app_partials, app_rows_per_point, probe_skip, R);
+      if (rayc)
+        field_mlp_bwd_kernel<true, true><<<blocks, kCoopThreads, lds + sizeof(uint32_t) * kRouteLdsWords, (hipStream_t)stream>>>(
+            enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
+            grads, partials, app_partials, app_rows_per_point, probe_skip, R);
+      else
+        field_mlp_bwd_kernel<true, false><<<blocks, kCoopThreads, lds + sizeof(uint32_t) * kRouteLdsWords, (hipStream_t)stream>>>(
+            enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
+            grads, partials, app_partials, app_rows_per_point, probe_skip, R);
       NSAMD_CHECK_LAUNCH();
     }
   } else if (phases & 1) {
-    field_mlp_bwd_kernel<false><<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
-        enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
-        grads, partials, app_partials, app_rows_per_point, probe_skip, RouteArgs{});
+    if (rayc)
+      field_mlp_bwd_kernel<false, true><<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
+          enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
+          grads, partials, app_partials, app_rows_per_point, probe_skip, RouteArgs{});
+    else
+      field_mlp_bwd_kernel<false, false><<<blocks, kCoopThreads, lds, (hipStream_t)stream>>>(
+          enc, selector, directions, camera_indices, appearance_const, dir_group, M, mlp, app_dim, ddensity, drgb, denc,
+          grads, partials, app_partials, app_rows_per_point, probe_skip, RouteArgs{});
     NSAMD_CHECK_LAUNCH();
   }
   // weight-gradient partials -> gradients, and (extra blocks, one per camera) the appearance rows -> embedding gradient

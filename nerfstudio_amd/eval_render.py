@@ -103,6 +103,10 @@ class EvalRenderer:
         emb = fld.embedding_appearance.embedding.weight if fld.embedding_appearance is not None else None
         fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), emb.shape[0] if emb is not None else 0,
                         float(fld.average_init_density))
+        if s.ray_terms_on:  # head layer 0's per-ray share once per ray (include/nsamd.h, nsamd_field_mlp.ray_terms)
+            ck(lib.nsamd_field_ray_terms(N.ptr(s.directions), None, N.ptr(self.app_const), n, fm, N.ptr(s.ray_terms), None, st),
+               "field_ray_terms")
+            fm.ray_terms = N.ptr(s.ray_terms)
         ck(lib.nsamd_hashgrid_encode_fwd(s._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table), enc.spec.native(),
                                          N.ptr(s.f_enc), 1, mm, N.ptr(s.f_sel), st), "hashgrid_encode_fwd")
         ck(lib.nsamd_field_mlp_fwd(N.ptr(s.f_enc), N.ptr(s.f_sel), N.ptr(s.directions), None, N.ptr(self.app_const), S, mm, fm,

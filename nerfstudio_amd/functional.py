@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
 
@@ -549,6 +550,17 @@ class _NerfactoFieldFn(torch.autograd.Function):
                          appearance.shape[0] if appearance is not None else 0, avg_density)
         density = torch.empty((M,), device=dev, dtype=torch.float32)
         rgb = torch.empty((M, 3), device=dev, dtype=torch.float32)
+        # samples grouped by ray, a whole number of 16-sample tiles per ray: head layer 0's share of the 48 per-ray inputs once
+        # per ray (include/nsamd.h, nsamd_field_mlp.ray_terms)
+        ctx.ray_terms = ctx.ray_inputs = None
+        if dir_group % 16 == 0 and M % dir_group == 0 and M > 0 and os.environ.get("NSAMD_RAY_TERMS", "1") == "1":
+            rays = M // dir_group
+            has_app = cams is not None or appearance_const is not None
+            ctx.ray_terms = torch.empty((rays, 64), device=dev, dtype=torch.float32)
+            ctx.ray_inputs = torch.empty((rays, 48 if has_app else 16), device=dev, dtype=torch.float32)
+            N.check(lib.nsamd_field_ray_terms(N.ptr(view_dirs), N.ptr(cams), N.ptr(appearance_const), rays, mlp,
+                                              N.ptr(ctx.ray_terms), N.ptr(ctx.ray_inputs), N.stream()), "field_ray_terms")
+            mlp.ray_terms, mlp.ray_inputs = N.ptr(ctx.ray_terms), N.ptr(ctx.ray_inputs)
         N.check(lib.nsamd_field_mlp_fwd(N.ptr(enc), N.ptr(sel), N.ptr(view_dirs), N.ptr(cams),
                                         N.ptr(appearance_const), dir_group, M, mlp, N.ptr(density), N.ptr(rgb),
                                         N.stream()), "field_mlp_fwd")
@@ -577,6 +589,8 @@ class _NerfactoFieldFn(torch.autograd.Function):
         tapp, gapp = _grad_target(refs[11], True) if (appearance is not None and ctx.cams is not None) else (None, None)
         mlp = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(appearance),
                          appearance.shape[0] if appearance is not None else 0, ctx.avg)
+        if ctx.ray_terms is not None:
+            mlp.ray_terms, mlp.ray_inputs = N.ptr(ctx.ray_terms), N.ptr(ctx.ray_inputs)
         grads = N.FieldMlpGrads(*(N.ptr(g) for g in tparams), N.ptr(tapp))
         fws, fws_n = field_bwd_workspace(table.device)
         N.check(lib.nsamd_field_mlp_bwd(N.ptr(enc), N.ptr(sel), N.ptr(view_dirs), N.ptr(ctx.cams),

@@ -112,6 +112,13 @@ class NerfactoTrainStep:
         self._pl_per_ray = parr(self.inter_per_ray)
         self._pl_dw = parr(self.dw_prop)
         self._pl_S = (C.c_int32 * self.n_prop)(*self.counts[: self.n_prop])
+        # Ray terms (include/nsamd.h, nsamd_field_mlp.ray_terms): head layer 0's share of the 48 per-ray inputs (SH of the view
+        # direction, appearance row) once per ray instead of once per sample. NSAMD_RAY_TERMS=0: the plain kernels (A/B).
+        self.ray_terms_on = os.environ.get("NSAMD_RAY_TERMS", "1") == "1" and self.counts[-1] % 16 == 0
+        self.ray_terms = e(n, 64) if self.ray_terms_on else None
+        self._ray_terms_ready = False
+        self.ray_inputs = e(n, 16 + (32 if fld.embedding_appearance is not None else 0)) \
+            if (self.ray_terms_on and not forward_only) else None  # (the backward's: weight gradient of the 48 per-ray columns)
         self.f_denc = t(*self.f_enc.shape)
         self.p_ddens = [t(*x.shape) for x in self.p_dens]
         self.p_denc = [t(*x.shape) for x in self.p_enc]
@@ -533,6 +540,21 @@ class NerfactoTrainStep:
         self.forward_main()
         self.losses(updated)
 
+    def ray_terms_launch(self) -> None:
+        """nsamd_field_ray_terms for the batch in the static buffers: head layer 0's share of the 48 per-ray inputs. Needs the
+        batch's (pose-corrected) directions and camera indices and the CURRENT head_W0 / head_b0 / appearance table — i.e. it
+        runs after batch selection and after the main-field Adam of the previous iteration. On torch's current stream."""
+        lib, st, n = N.load(), N.stream(), self.n
+        fld = self.model.field
+        params = [*fld.mlp_base.mlp.param_tensors(), *fld.mlp_head.param_tensors()]
+        emb = fld.embedding_appearance.embedding.weight if fld.embedding_appearance is not None else None
+        fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), emb.shape[0] if emb is not None else 0,
+                        float(fld.average_init_density))
+        cams = N.ptr(self.camera_indices) if emb is not None else None
+        N.check(lib.nsamd_field_ray_terms(N.ptr(self.directions), cams, None, n, fm, N.ptr(self.ray_terms), N.ptr(self.ray_inputs),
+                                          st), "field_ray_terms")
+        self._ray_terms_ready = True
+
     @profiler.time_function
     def forward_main(self) -> None:
         """Hash grid + MLPs of the main field on the final samples -> per-sample density and rgb."""
@@ -547,6 +569,11 @@ class NerfactoTrainStep:
         fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), emb.shape[0] if emb is not None else 0,
                         float(fld.average_init_density))
         cams = N.ptr(self.camera_indices) if emb is not None else None
+        if self.ray_terms_on:
+            if not self._ray_terms_ready:  # (a caller may have launched them already, off the critical path: trainer.HipTrainer)
+                self.ray_terms_launch()
+            self._ray_terms_ready = False
+            fm.ray_terms, fm.ray_inputs = N.ptr(self.ray_terms), N.ptr(self.ray_inputs)
         ck(lib.nsamd_hashgrid_encode_fwd(self._points(L), mm, fld._transform, fld._box, N.ptr(enc.hash_table),
                                          enc.spec.native(), N.ptr(self.f_enc), 1, mm, N.ptr(self.f_sel), st),
            "hashgrid_encode_fwd")
@@ -623,6 +650,8 @@ class NerfactoTrainStep:
         fm = N.FieldMlp(*(N.ptr(p) for p in params), N.ptr(emb), emb.shape[0] if emb is not None else 0,
                         float(fld.average_init_density))
         cams = N.ptr(self.camera_indices) if emb is not None else None
+        if self.ray_terms_on:  # (what forward_main computed for this batch and these parameters)
+            fm.ray_terms, fm.ray_inputs = N.ptr(self.ray_terms), N.ptr(self.ray_inputs)
         grads = N.FieldMlpGrads(*(N.ptr(self._grad(p)) for p in params), N.ptr(self._grad(emb)) if emb is not None else None)
         split = self.split_reduce and self.side_stream is not None
         if (self.fuse_route and self.main_table_write_only and not self.defer_table

@@ -167,6 +167,8 @@ class HipTrainer:
                 self.opt_stream = torch.cuda.Stream(device=dev)
                 self._opt_fork, self._opt_join = torch.cuda.Event(), torch.cuda.Event()
                 self._sh_fork, self._sh_join = torch.cuda.Event(), torch.cuda.Event()
+                self._batch_ready = torch.cuda.Event()
+            self.terms_on_branch = os.environ.get("NSAMD_TERMS_ON_BRANCH", "1") == "1"  # (=0: in line, A/B)
             mode = os.environ.get("NSAMD_STEP_PROLOGUE", "ring")
             mode = "ring" if mode == "1" else mode
             if (mode in ("ring", "table") and self.on_gpu and runner is None
@@ -451,17 +453,31 @@ class HipTrainer:
                 # nothing before the join below writes a gradient
                 self._zero(updated)
 
+        # The ray terms of this iteration's main-field forward (train_step.ray_terms_launch) need the updated head weights and
+        # the selected batch, nothing else: they go on the Adam branch, behind an event the main branch records once the batch
+        # is in place — off the critical path instead of a launch (and a dependent-launch gap) in front of the hash forward.
+        terms_beside = beside and getattr(r, "ray_terms_on", False) and self.terms_on_branch
+
         def fork():
             self._opt_fork.record(main)
             self.opt_stream.wait_event(self._opt_fork)
             with torch.cuda.stream(self.opt_stream):
                 pending_update()
+                if not terms_beside:
+                    self._opt_join.record(self.opt_stream)
+
+        def terms_behind_batch():  # (runs inside forward_proposals, right behind the launch that selects the batch)
+            self._batch_ready.record(main)
+            self.opt_stream.wait_event(self._batch_ready)
+            with torch.cuda.stream(self.opt_stream):
+                r.ray_terms_launch()
                 self._opt_join.record(self.opt_stream)
 
         # NSAMD_FORK_AFTER_BINS=1: the branch starts BEHIND the launch that selects the batch and writes the initial bins (8 MB of
         # stores that read 45 us beside the HBM-saturating Adam and 14 us alone) instead of in front of it
         late_fork = beside and self.fork_after_bins and not r.cameras_outside and getattr(r, "fuse_select", False) \
             and getattr(r, "cam_opt", None) is None
+        terms_beside = terms_beside and not late_fork
         if beside and not late_fork:
             fork()
         elif pending and not beside:
@@ -471,6 +487,8 @@ class HipTrainer:
             r.apply_camera_corrections()
         if late_fork:
             r.after_bins = fork
+        elif terms_beside:
+            r.after_bins = terms_behind_batch
         r.forward_proposals(draw, need_enc=updated)
         if beside:
             main.wait_event(self._opt_join)

