@@ -265,9 +265,36 @@ def ptr(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
+# torch.cuda.current_stream() / `with torch.cuda.stream(s)` with no device argument resolve "the current device" through
+# torch._utils._get_available_device_type -> torch.cuda.is_available() -> a device-count query of the driver: ~20 us per call on
+# this ROCm build, 14 - 16 of them per eagerly launched iteration = a third of the host's share of an eager / data-parallel step
+# (profiles/r06_s30_eager_host_cprofile.txt: 3170 x _cuda_getDeviceCount in 225 iterations). The helpers below name the device.
 def stream() -> int:
     """The raw hipStream_t of torch's current stream (kernels must run on it, SURVEY.md §8b threading)."""
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+def current_stream() -> "torch.cuda.Stream":
+    """torch.cuda.current_stream() of the current device, without the device-count query."""
+    return torch.cuda.current_stream(torch._C._cuda_getDevice())
+
+
+class on_stream:
+    """`with on_stream(s):` — torch.cuda.stream(s) for a stream of the CURRENT device, without the two device-count queries."""
+
+    __slots__ = ("s", "prev")
+
+    def __init__(self, s) -> None:
+        self.s = s
+
+    def __enter__(self):
+        self.prev = current_stream()
+        torch.cuda.set_stream(self.s)
+        return self.s
+
+    def __exit__(self, *exc):
+        torch.cuda.set_stream(self.prev)
+        return False
 
 
 def require_cuda(*tensors: Optional[torch.Tensor]) -> None:

@@ -28,6 +28,8 @@ from __future__ import annotations
 
 from typing import Callable, Optional
 
+from . import _native as N
+
 SEGMENTS = ("pfwd", ("main", True), ("main", False), "pbwd", "mopt", "popt")
 
 
@@ -77,9 +79,9 @@ class PipelinedExchange:
         if self.update_stream is not None and self.pending:
             import torch
 
-            cur = torch.cuda.current_stream()
+            cur = N.current_stream()
             self.update_stream.wait_stream(cur)  # the step-dependent optimiser scalars were pushed on `cur`
-            with torch.cuda.stream(self.update_stream):
+            with N.on_stream(self.update_stream):
                 self._finish_main()  # wait() parks THIS stream until the exchange is done, then the update runs on it
             self.run("pfwd")      # meanwhile, on the caller's stream: reads only proposal-network parameters
             cur.wait_stream(self.update_stream)

@@ -321,7 +321,7 @@ class NerfactoTrainStep:
         if branches:
             # The backward chains are independent (disjoint gradients, separate scratch): fork the proposal chains onto
             # their own streams so that these latency-bound kernels overlap with the main chain.
-            main = torch.cuda.current_stream()
+            main = N.current_stream()
             side_stage = "all"
             if self.prop_mlp_inline:
                 # NSAMD_PROP_MLP_INLINE=1 (experiment): the levels' weights + density-MLP backward run IN LINE ahead of the main
@@ -332,7 +332,7 @@ class NerfactoTrainStep:
             self._fork.record(main)
             for stream, join, levels in branches:
                 stream.wait_event(self._fork)
-                with torch.cuda.stream(stream):
+                with N.on_stream(stream):
                     self.backward_proposals(levels=levels, stage=side_stage)
                     join.record(stream)
             self.backward_main(reserve=True)
@@ -344,7 +344,7 @@ class NerfactoTrainStep:
 
     def backward_join(self, updated: bool) -> None:
         """Second half of backward_all: wait for the proposal chains, then the camera optimiser's share."""
-        main = torch.cuda.current_stream()
+        main = N.current_stream()
         for _, join, _ in getattr(self, "_open_branches", []):
             main.wait_event(join)
         self._open_branches = []
@@ -670,10 +670,10 @@ class NerfactoTrainStep:
                     # the weight-gradient reduce (12.8 MB of partial rows, latency-bound) needs nothing the apply pass produces
                     # and vice versa: the reduce on its own stream BESIDE the apply pass (NSAMD_SPLIT_REDUCE=1; same bits)
                     ck(lib.nsamd_field_mlp_bwd_scatter_phase(*args, 1, st), "field_mlp_bwd_scatter_phase")
-                    main = torch.cuda.current_stream()
+                    main = N.current_stream()
                     self._red_fork.record(main)
                     self.reduce_stream.wait_event(self._red_fork)
-                    with torch.cuda.stream(self.reduce_stream):
+                    with N.on_stream(self.reduce_stream):
                         ck(lib.nsamd_field_mlp_bwd_scatter_phase(*args, 2, N.stream()), "field_mlp_bwd_scatter_phase")
                         self._red_join.record(self.reduce_stream)
                     ck(lib.nsamd_field_mlp_bwd_scatter_phase(*args, 4, st), "field_mlp_bwd_scatter_phase")
@@ -695,10 +695,10 @@ class NerfactoTrainStep:
                     N.ptr(self.d_dens_main), N.ptr(self.d_rgb_s), N.ptr(self.f_denc), grads, N.ptr(self.field_ws),
                     self.field_ws.numel())
             ck(lib.nsamd_field_mlp_bwd_phase(*args, 1, st), "field_mlp_bwd_phase")
-            main = torch.cuda.current_stream()
+            main = N.current_stream()
             self._red_fork.record(main)
             self.reduce_stream.wait_event(self._red_fork)
-            with torch.cuda.stream(self.reduce_stream):
+            with N.on_stream(self.reduce_stream):
                 ck(lib.nsamd_field_mlp_bwd_phase(*args, 2, N.stream()), "field_mlp_bwd_phase")
                 self._red_join.record(self.reduce_stream)
         else:
@@ -710,7 +710,7 @@ class NerfactoTrainStep:
         if not self.defer_table:
             self.backward_table()
         if split:
-            torch.cuda.current_stream().wait_event(self._red_join)
+            N.current_stream().wait_event(self._red_join)
 
     def backward_table(self, shadow: bool = False) -> None:
         """The main table's gradient scatter from `f_denc`. `shadow`: the sample points come from the copies `shadow_points`

@@ -45,6 +45,8 @@ from typing import Callable, Dict, Optional
 
 import torch
 
+from . import _native as N
+
 BATCH_SLOTS = 8  # default number of pre-generated ray batches of a pool (bench.py)
 
 _HYPER = {"fields": 0, "proposal_networks": 2, "camera_opt": 6}  # offsets of (step size, 1/sqrt(bc2)) per optimiser group
@@ -312,7 +314,7 @@ class HipTrainer:
                 if ago is not None:
                     ago.synchronize()
                 ev = torch.cuda.Event()
-                ev.record()
+                ev.record(N.current_stream())
                 self._ring_events[k] = ev
             self._hyper_row(self.ring_np[i % self.ring_rows], self.step, a.step_counts, self._have_pending)
             self._ring_pos = i + 1
@@ -350,7 +352,7 @@ class HipTrainer:
             self.hyper_table.copy_(self.table_host.reshape(-1), non_blocking=True)
             self.step_counter[0:1].zero_()
             self._table_event = torch.cuda.Event()
-            self._table_event.record()
+            self._table_event.record(N.current_stream())
             self._table_pos, self._table_valid, self._table_base = 1, True, self.step
             return
         slot = self.hyper_slot
@@ -362,7 +364,7 @@ class HipTrainer:
         self.hyper.copy_(h, non_blocking=True)
         if self.on_gpu:
             ev = torch.cuda.Event()
-            ev.record()
+            ev.record(N.current_stream())
             self.hyper_events[slot] = ev
 
     def _step_prologue(self):
@@ -438,7 +440,7 @@ class HipTrainer:
         Inside a captured hipGraph the two halves of the first line are parallel branches. With the camera optimiser on,
         batch selection and the pose corrections have already run (eagerly, `_cameras_before`)."""
         r, a = self.runner, self.arena
-        main = torch.cuda.current_stream()
+        main = N.current_stream()
         beside = pending and self.opt_parallel
         self._step_prologue()  # the step's scalars and draws: first node, every branch below depends on it
         draw = self.draw_jitter and not self.prologue
@@ -461,7 +463,7 @@ class HipTrainer:
         def fork():
             self._opt_fork.record(main)
             self.opt_stream.wait_event(self._opt_fork)
-            with torch.cuda.stream(self.opt_stream):
+            with N.on_stream(self.opt_stream):
                 pending_update()
                 if not terms_beside:
                     self._opt_join.record(self.opt_stream)
@@ -469,7 +471,7 @@ class HipTrainer:
         def terms_behind_batch():  # (runs inside forward_proposals, right behind the launch that selects the batch)
             self._batch_ready.record(main)
             self.opt_stream.wait_event(self._batch_ready)
-            with torch.cuda.stream(self.opt_stream):
+            with N.on_stream(self.opt_stream):
                 r.ray_terms_launch()
                 self._opt_join.record(self.opt_stream)
 
@@ -496,7 +498,7 @@ class HipTrainer:
             if self.opt_parallel:
                 self._sh_fork.record(main)
                 self.opt_stream.wait_event(self._sh_fork)
-                with torch.cuda.stream(self.opt_stream):
+                with N.on_stream(self.opt_stream):
                     r.shadow_points()
                     self._sh_join.record(self.opt_stream)
             else:
@@ -671,14 +673,14 @@ class HipTrainer:
         torch.cuda.synchronize()
         assert not self._have_pending
         side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        side.wait_stream(N.current_stream())
+        with N.on_stream(side):
             defer, self.defer = self.defer, False  # (in order, so that every schedule trains through the same states)
             for upd in (True, False):
                 self._eager_iteration(upd)
             self.finish()
             self.defer = defer
-        torch.cuda.current_stream().wait_stream(side)
+        N.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 
     def capture(self, warm: bool = True):

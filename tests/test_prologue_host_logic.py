@@ -11,7 +11,7 @@ from nerfstudio_amd import trainer as T
 
 
 class _Event:
-    def record(self):
+    def record(self, stream=None):
         pass
 
     def synchronize(self):
@@ -57,6 +57,7 @@ def _trainer(mode, defer, monkeypatch):
     from nerfstudio_amd.schedulers import nerfacto_schedulers
 
     monkeypatch.setattr(torch.cuda, "Event", _Event)
+    monkeypatch.setattr(T.N, "current_stream", lambda: None)  # (the events are recorded on torch's current stream)
     t = T.HipTrainer.__new__(T.HipTrainer)
     t.model, t.arena, t.step, t.slots, t.defer = _Model(), _Arena(), 0, 8, defer
     t._pending_main, t.exchange, t.cam_inside, t.cam_group, t.drive_callbacks = False, None, False, None, True
