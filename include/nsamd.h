@@ -312,7 +312,8 @@ int nsamd_field_mlp_bwd_scatter(nsamd_points pts, int transform, nsamd_aabb aabb
                                 int64_t scatter_workspace_floats, nsamd_stream_t stream);
 /* The same call one launch group at a time (per-kernel timing of the benchmark's roofline leg; the groups in order give the
  * single call's bits): phase 1 = the gradient kernel with the record emission, 2 = the weight-gradient reduce, 4 = the
- * scatter's apply + finish passes over the records phase 1 left in the queues. */
+ * scatter's apply + finish passes over the records phase 1 left in the queues; 6 = 2 and 4 as the single call issues them (the
+ * reduce riding the apply pass) — for a caller that puts work of its own between the gradient kernel and the rest. */
 int nsamd_field_mlp_bwd_scatter_phase(nsamd_points pts, int transform, nsamd_aabb aabb, nsamd_grid grid, const float* enc,
                                       const float* selector, const float* directions, const int64_t* camera_indices,
                                       const float* appearance_const, int64_t dir_group, int64_t M, nsamd_field_mlp mlp,

@@ -1742,7 +1742,7 @@ extern "C" int nsamd_field_mlp_bwd_scatter_phase(nsamd_points pts, int transform
                                                  float* workspace, int64_t workspace_floats, float* dtable,
                                                  float* scatter_workspace, int64_t scatter_workspace_floats, int phase,
                                                  nsamd_stream_t stream) {
-  NSAMD_REQUIRE(phase == 1 || phase == 2 || phase == 4 || phase == 7);
+  NSAMD_REQUIRE(phase == 1 || phase == 2 || phase == 4 || phase == 6 || phase == 7);
   if (M == 0) return NSAMD_OK;
   if (grid.num_levels != 16) return NSAMD_ERR_UNSUPPORTED;  // 32 features = the K of base layer 0
   NSAMD_REQUIRE(M > 0 && transform >= 0 && transform <= 2 && grid.log2_table_size >= 1 && grid.log2_table_size <= 28);

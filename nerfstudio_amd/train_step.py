@@ -168,6 +168,7 @@ class NerfactoTrainStep:
         # the field backward's weight-gradient reduce on its own stream, beside the table scatter (opt-in: NSAMD_SPLIT_REDUCE=1; measured neutral)
         self.split_reduce = os.environ.get("NSAMD_SPLIT_REDUCE", "0") == "1"
         self.reduce_stream = torch.cuda.Stream(device=device)
+        self.rays_beside_apply = os.environ.get("NSAMD_RAYS_BESIDE_APPLY", "1") == "1"  # (camera optimiser, see backward_field_and_table)
         self._red_fork, self._red_join = torch.cuda.Event(), torch.cuda.Event()
         self._level_join = [torch.cuda.Event() for _ in self.level_streams]
         # Proposal levels may run their backward chains on separate streams only when they share nothing: a shared
@@ -683,6 +684,20 @@ class NerfactoTrainStep:
                     # if the reduce were free
                     for phase in (1, 4):
                         ck(lib.nsamd_field_mlp_bwd_scatter_phase(*args, phase, st), "field_mlp_bwd_scatter_phase")
+                elif self.cam_opt is not None and self.rays_beside_apply:
+                    # camera optimiser: the rays' gradient through the main grid (a gather pass over the table, 96 us) needs the
+                    # encoded-feature gradient the kernel has just written and nothing of the table scatter's apply pass (LDS
+                    # atomics, latency-bound): beside it on the second stream instead of behind it (NSAMD_RAYS_BESIDE_APPLY=0: A/B)
+                    ck(lib.nsamd_field_mlp_bwd_scatter_phase(*args, 1, st), "field_mlp_bwd_scatter_phase")
+                    main = N.current_stream()
+                    self._red_fork.record(main)
+                    self.reduce_stream.wait_event(self._red_fork)
+                    with N.on_stream(self.reduce_stream):
+                        self._rays_backward(L, fld, self.f_denc)
+                        self._red_join.record(self.reduce_stream)
+                    ck(lib.nsamd_field_mlp_bwd_scatter_phase(*args, 6, st), "field_mlp_bwd_scatter_phase")  # (the reduce rides the apply pass)
+                    main.wait_event(self._red_join)
+                    return
                 else:
                     ck(lib.nsamd_field_mlp_bwd_scatter(*args, st), "field_mlp_bwd_scatter")
                 if self.cam_opt is not None:
