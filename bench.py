@@ -405,7 +405,7 @@ def main():
     elif world > 1:  # keep the collective pattern identical on every rank during the profiling steps
         if state is not None:
             state.restore()
-        for _ in range(max(1, args.profile_steps)):
+        for _ in range(max(1, args.profile_steps) + RL.ROOFLINE_WARMUP_ITERS):  # (+ measure_roofline's untimed warm-up on rank 0)
             trainer.train_iteration()
         trainer.finish()
 

@@ -17,6 +17,7 @@ PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ROOT = os.path.dirname(PKG)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-in MFMA = f32 vector peak
+ROOFLINE_WARMUP_ITERS = 10  # untimed eager iterations in front of the profiled ones (measure_roofline); every rank runs them
 FIELD_MACS = 11392  # MACs / sample of the main field: 32*64 + 64*16 + 63*64 + 64*64 + 64*3  
 
 
@@ -181,11 +182,13 @@ def measure_roofline(trainer, arena, steps, main_points):
             trainer.train_iteration()
         trainer.finish()
 
-    # one untimed eager iteration first: the first eager launch after a stretch of graph replays (and the state restore in front
-    # of this call) has been measured at 2.5 x the kernel's time (profiles/r06_s37_*: 0.41 ms, then 0.160 0.160 0.158 0.157) —
-    # a property of the hand-over, not of the kernel, that a five-launch average must not carry
-    trainer.train_iteration()
-    torch.cuda.synchronize()
+    # untimed eager iterations first: the first eager launches after a stretch of graph replays and the state restore in front
+    # of this call (a host-synchronous pause: the clocks drop) have been measured at 1.6 - 2.5 x the compute-bound kernel's time
+    # (profiles/r06_s37_*: 0.41 ms, then 0.160 0.160 0.158 0.157; with ONE warm-up iteration still 0.28 0.25 0.160 0.157 0.157,
+    # r06_s48_*; the memory- and latency-bound launches do not move) — a property of the hand-over, not of the kernel, that a
+    # five-launch average must not carry
+    for _ in range(ROOFLINE_WARMUP_ITERS):
+        trainer.train_iteration()
     prof = profile_table(run, steps)
     trainer.graphs = graphs
     trainer.opt_parallel = True
