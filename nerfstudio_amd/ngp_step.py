@@ -70,6 +70,7 @@ class NgpTrainStep:
         # pipeline.NgpEngine under a trainer whose own optimiser must find `.grad` None); None: `param.grad`
         self.grad_lookup = None
         self.accumulate_table = False
+        self.fuse_route = os.environ.get("NSAMD_NGP_FUSE_ROUTE", "1") == "1"  # the field backward emits the scatter's records (backward)
         self.has_bounds = False
         bgc = model.renderer_rgb.background_color
         if isinstance(bgc, str) and bgc == "last_sample":
@@ -321,10 +322,22 @@ class NgpTrainStep:
         grad_of = (lambda p: gl[id(p)]) if gl is not None else (lambda p: p.grad)  # noqa: E731
         grads = N.FieldMlpGrads(*(N.ptr(grad_of(p)) for p in params), N.ptr(grad_of(emb)) if (emb is not None and self._train_app) else None)
         fws, fws_n = F.field_bwd_workspace(self.dev)
+        write_only = not self.accumulate_table
+        if write_only and self.fuse_route and self.grid.num_levels == 16:
+            # as the nerfacto schedule does (train_step.backward_field_and_table): the field backward emits the table scatter's
+            # pass-1 records from its registers — no `denc` round trip, no route launch over the kept samples
+            # (NSAMD_NGP_FUSE_ROUTE=0: the two entry points, A/B)
+            sws, sws_n = F._producer_scatter_workspace(self.grid, self.dev, mk)
+            if sws is not None:
+                ck(lib.nsamd_field_mlp_bwd_scatter(
+                    N.make_points(positions=self.k_pos), fld._transform, fld._box, self.grid.native(), N.ptr(self.k_enc),
+                    N.ptr(self.k_sel), N.ptr(self.k_dirs), N.ptr(self.k_cams) if self._train_app else None, N.ptr(self._app_const), 1,
+                    mk, self._field_mlp(), N.ptr(self.k_dsigma), N.ptr(self.k_drgb), None, grads, N.ptr(fws), fws_n,
+                    N.ptr(grad_of(table)), N.ptr(sws), sws_n, st), "field_mlp_bwd_scatter")
+                return
         ck(lib.nsamd_field_mlp_bwd(N.ptr(self.k_enc), N.ptr(self.k_sel), N.ptr(self.k_dirs), N.ptr(self.k_cams) if self._train_app else None,
                                    N.ptr(self._app_const), 1, mk, self._field_mlp(), N.ptr(self.k_dsigma), N.ptr(self.k_drgb),
                                    N.ptr(self.k_denc), grads, N.ptr(fws), fws_n, st), "field_mlp_bwd")
-        write_only = not self.accumulate_table
         ws, ws_n = F._scatter_workspace(self.grid, self.dev, mk, write_only=write_only)
         fn = lib.nsamd_hashgrid_encode_bwd_set if write_only else lib.nsamd_hashgrid_encode_bwd
         ck(fn(N.make_points(positions=self.k_pos), mk, fld._transform, fld._box, N.ptr(table), self.grid.native(), N.ptr(self.k_denc), 1, mk,
