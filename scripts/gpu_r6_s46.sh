@@ -2,11 +2,11 @@
 # Round 6, GPU session 46: kernel timeline of REPLAYED iterations of the current tree (rocprofv3 --kernel-trace): one non-update and
 # one update iteration of the timed window, gaps and branch overlap read off
 R=${GRAFT_REPO_ROOT:-/root/repo}
-out=$R/gpurun_out/r6_s46
+out=$R/gpurun_out/${TAG:-r6_s46}
 mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp; rm -rf /tmp/ktl
-timeout 600 rocprofv3 --kernel-trace -d /tmp/ktl -o k -- python $R/bench.py --steps 12 --warmup 60 --windows 1 --long-steps 0 --no-cpu-baseline --no-secondary > $out/rocprof.log 2>&1
+NSAMD_ISSUE_MAIN_FIRST=${MAIN_FIRST:-0} timeout 600 rocprofv3 --kernel-trace -d /tmp/ktl -o k -- python $R/bench.py --steps 12 --warmup 60 --windows 1 --long-steps 0 --no-cpu-baseline --no-secondary > $out/rocprof.log 2>&1
 cd $R
 OUT=$out python - <<'PY'
 import glob, os, sqlite3
