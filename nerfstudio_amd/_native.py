@@ -269,14 +269,22 @@ def ptr(t: Optional[torch.Tensor]):
 # torch._utils._get_available_device_type -> torch.cuda.is_available() -> a device-count query of the driver: ~20 us per call on
 # this ROCm build, 14 - 16 of them per eagerly launched iteration = a third of the host's share of an eager / data-parallel step
 # (profiles/r06_s30_eager_host_cprofile.txt: 3170 x _cuda_getDeviceCount in 225 iterations). The helpers below name the device.
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # (private torch entry points: the public route is the fallback)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream() -> int:
     """The raw hipStream_t of torch's current stream (kernels must run on it, SURVEY.md §8b threading)."""
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    if _RAW_STREAM is None or _GET_DEVICE is None:
+        return torch.cuda.current_stream().cuda_stream
+    return _RAW_STREAM(_GET_DEVICE())
 
 
 def current_stream() -> "torch.cuda.Stream":
     """torch.cuda.current_stream() of the current device, without the device-count query."""
-    return torch.cuda.current_stream(torch._C._cuda_getDevice())
+    if _GET_DEVICE is None:
+        return torch.cuda.current_stream()
+    return torch.cuda.current_stream(_GET_DEVICE())
 
 
 class on_stream:
